@@ -1,0 +1,193 @@
+"""Pins the CPU oracle (oracle/bmt_oracle.py) against the golden vectors captured from the
+imported reference (tests/golden/make_golden.py).  CPU only; runs everywhere."""
+import numpy as np
+import pytest
+import torch
+
+from bmt_amd import synthetic as syn
+from oracle import bmt_oracle as orc
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def close(a, b, **kw):
+    t = dict(TOL); t.update(kw)
+    torch.testing.assert_close(a, b, **t)
+
+
+def test_masks_bit_exact(golden):
+    g = golden("masks_loss.npz")
+    fs = {"rgb": g["mk/rgb"], "audio": g["mk/audio"]}
+    caps = g["mk/caps"]
+    m = orc.make_masks(fs, caps[:, :-1], 1)
+    for k in ("V_mask", "A_mask", "C_mask"):
+        assert m[k].dtype == torch.bool
+        assert torch.equal(m[k], g["mk/" + k])
+    m2 = orc.make_masks(fs, None, 1)
+    assert torch.equal(m2["V_mask"], g["mk/V_mask_nocap"])
+    assert torch.equal(m2["A_mask"], g["mk/A_mask_nocap"])
+    assert torch.equal(orc.subsequent_mask(5), g["mk/subsequent5"])
+
+
+@pytest.mark.parametrize("tag,s", [("a", 0.7), ("a", 0.0), ("idx0", 0.7), ("nopad", 0.7), ("big", 0.7)])
+def test_label_smoothing(golden, tag, s):
+    g = golden("masks_loss.npz")
+    key = f"ls/{tag}/s{s}"
+    pred = g[key + "/pred"].clone().requires_grad_()
+    loss = orc.label_smoothing_kl(pred, g[key + "/target"], s, 1)
+    close(loss, g[key + "/loss"], rtol=1e-5, atol=1e-4)
+    loss.backward()
+    close(pred.grad, g[key + "/dpred"])
+
+
+def test_pos_enc(golden):
+    g = golden("modules_tiny.npz")
+    for d in (20, 128, 300, 1024):
+        tab = orc.pos_enc_table(3660, d)
+        np.testing.assert_array_equal(tab[:9], g.np(f"pe/{d}/head"))
+        np.testing.assert_array_equal(tab[3655:3660], g.np(f"pe/{d}/tail"))
+        close(orc.positional_encoder(g[f"pe/{d}/x"]), g[f"pe/{d}/y"])
+
+
+def test_vocab_embedder_and_generator(golden):
+    g = golden("modules_tiny.npz")
+    p = {"embedder.weight": g["vemb/weight"]}
+    close(orc.vocabulary_embedder(p, "", g["vemb/ids"], 20), g["vemb/out"])
+    close(orc.generator(g.sub("gen/sd/"), "", g["gen/X"]), g["gen/out"])
+
+
+def _run_and_check(g, tag, fn, inputs, grads):
+    xs = [g[f"{tag}/{n}"].clone().requires_grad_() for n in inputs]
+    p = {k: v.clone().requires_grad_() for k, v in g.sub(f"{tag}/sd/").items()}
+    out = fn(p, *xs)
+    close(out, g[f"{tag}/out"])
+    (out * g[f"{tag}/w"]).sum().backward()
+    for x, n in zip(xs, grads):
+        close(x.grad, g[f"{tag}/{n}"], atol=1e-4)
+    for k, v in g.sub(f"{tag}/grad/").items():
+        close(p[k].grad, v, atol=1e-4)
+
+
+def test_mha_cross_modal(golden):
+    g = golden("modules_tiny.npz")
+    _run_and_check(g, "mha", lambda p, Q, K: orc.multiheaded_attention(p, "", Q, K, K, g["mha/mask"], 4),
+                   ["Q", "K"], ["dQ", "dK"])
+
+
+def test_mha_causal(golden):
+    g = golden("modules_tiny.npz")
+    _run_and_check(g, "sa", lambda p, X: orc.multiheaded_attention(p, "", X, X, X, g["sa/mask"], 4),
+                   ["X"], ["dX"])
+
+
+def test_residual_ffn(golden):
+    g = golden("modules_tiny.npz")
+    _run_and_check(g, "resffn", lambda p, X: orc.residual(p, "res.", X, lambda y: orc.feed_forward(p, "ffn.", y)),
+                   ["X"], ["dX"])
+
+
+def test_bridge(golden):
+    g = golden("modules_tiny.npz")
+    _run_and_check(g, "bridge", lambda p, X: orc.bridge(p, "", X), ["X"], ["dX"])
+
+
+@pytest.mark.parametrize("name", ["tiny_cap.npz", "tiny_cap_trainemb.npz"])
+def test_tiny_captioning_full(golden, name):
+    g = golden(name)
+    cfg = syn.cfg_tiny()
+    sd = g.sub("sd/")
+    assert orc.state_dict_digest(sd) == str(g.np("sd_digest"))
+    frozen = name == "tiny_cap.npz"
+    p = {k: v.clone().requires_grad_(not (frozen and k == "emb_C.embedder.weight")) for k, v in sd.items()}
+    src = {"rgb": g["rgb"], "flow": g["flow"], "audio": g["audio"]}
+    loss, pred, n_tok = orc.train_cap_loss(p, cfg, src, g["captions"], 1, cfg.smoothing)
+    close(pred, g["pred"], atol=2e-5)
+    assert int(n_tok) == int(g["n_tokens"])
+    close(loss, g["loss"])
+    loss.backward()
+    for k, v in g.sub("grad/").items():
+        close(p[k].grad, v, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,cfgfn", [("cfg0_cap.npz", syn.cfg_config0), ("mid_cap.npz", syn.cfg_config1)])
+def test_seeded_captioning(golden, name, cfgfn):
+    """Weights re-created from the seed (digest pinned), inputs from the seeded generator."""
+    g = golden(name)
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = cfgfn()
+    glove = syn.make_glove(V, cfg.d_model_caps) if use_glove else None
+    sd = orc.init_captioning_params(cfg, V, seed=0, glove=glove)
+    assert orc.state_dict_digest(sd) == str(g.np("sd_digest"))
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    assert torch.equal(batch["captions"], g["captions"])
+    if "rgb" in g:
+        assert torch.equal(batch["feature_stacks"]["rgb"], g["rgb"])
+    p = {k: v.clone().requires_grad_(k != "emb_C.embedder.weight") for k, v in sd.items()}
+    loss, pred, _ = orc.train_cap_loss(p, cfg, batch["feature_stacks"], batch["captions"], 1, cfg.smoothing)
+    close(pred, g["pred"], atol=5e-5)
+    close(loss, g["loss"])
+    loss.backward()
+    names = [str(s) for s in g.np("grad_names")]
+    norms = g.np("grad_norms")
+    for n, ref_norm in zip(names, norms):
+        mine = float(p[n].grad.double().norm())
+        assert abs(mine - ref_norm) <= 1e-3 * ref_norm + 1e-7, (n, mine, ref_norm)
+    for k, v in g.sub("grad/").items():
+        close(p[k].grad, v, atol=5e-5, rtol=1e-4)
+
+
+def test_adam(golden):
+    g = golden("adam.npz")
+    p = g["p0"].clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        orc.adam_step(p, g[f"g{step}"], m, v, step, 5e-5)
+        close(p, g[f"p{step}"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["nocollide", "collide"])
+def test_make_targets_bit_exact(golden, tag):
+    g = golden("targets.npz")
+    obj, noobj, tx, tw, tobj = orc.make_targets(3, 5, 40, g[f"mt/{tag}/targets"], g[f"mt/{tag}/anchors"],
+                                                float(g[f"mt/{tag}/stride"]))
+    assert torch.equal(obj, g[f"mt/{tag}/obj"])
+    assert torch.equal(noobj, g[f"mt/{tag}/noobj"])
+    assert torch.equal(tx, g[f"mt/{tag}/tx"])
+    assert torch.equal(tw, g[f"mt/{tag}/tw"])
+    assert torch.equal(tobj, g[f"mt/{tag}/tobj"])
+
+
+def test_tiou(golden):
+    g = golden("targets.npz")
+    close(orc.tiou_vectorized(g["tiou/s1"], g["tiou/s2"]), g["tiou/full"])
+    close(orc.tiou_vectorized(g["tiou/s1"][:, 1:], g["tiou/s2"][:, 1:], True), g["tiou/nocenter"])
+
+
+def _prop_cfg():
+    cfg = syn.cfg_tiny(procedure="train_prop")
+    cfg.anchors_num_audio, cfg.anchors_num_video = 3, 5
+    cfg.conv_layers_audio, cfg.conv_layers_video = [16, 16], [16, 16]
+    cfg.kernel_sizes = {"audio": [1, 5], "video": [3, 7]}
+    return cfg
+
+
+def test_tiny_proposal_generator(golden):
+    g = golden("tiny_prop.npz")
+    cfg = _prop_cfg()
+    anchors = {"audio": [float(a) for a in g.np("anchors_audio")], "video": [float(a) for a in g.np("anchors_video")]}
+    p = {k: v.clone().requires_grad_() for k, v in g.sub("sd/").items()}
+    src = {"rgb": g["rgb"], "flow": g["flow"], "audio": g["audio"]}
+    masks = orc.make_masks(src, None, 1)
+    preds, loss, la, lv = orc.multimodal_proposal_generator(p, cfg, anchors, src, g["targets"], masks)
+    close(preds, g["preds"], atol=2e-5, rtol=1e-4)
+    close(loss, g["loss"], rtol=1e-5, atol=1e-4)
+    for k, v in g.sub("losses_A/").items():
+        close(la[k], v, atol=1e-5)
+    for k, v in g.sub("losses_V/").items():
+        close(lv[k], v, atol=1e-5)
+    loss.backward()
+    for k, v in g.sub("grad/").items():
+        close(p[k].grad, v, atol=5e-5, rtol=1e-4)
+    preds2, loss2, _, _ = orc.multimodal_proposal_generator(p, cfg, anchors, src, None, masks)
+    close(preds2, g["preds_notargets"], atol=2e-5, rtol=1e-4)
+    assert loss2 == 0
