@@ -1,0 +1,123 @@
+"""ctypes binding of libbmt_hip.so (the C ABI declared in include/bmt_hip.h).
+
+The library is built in-tree by ``bmt_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+There is NO fallback: if the shared object is missing or a symbol is absent, importing the
+ops raises -- the product path never silently degrades to eager PyTorch or to the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbmt_hip.so")
+
+PREC_BF16, PREC_BF16X3 = 1, 3
+EPI_BIAS, EPI_RELU, EPI_DROP_PRE, EPI_DROP_POST, EPI_RESIDUAL, EPI_GATE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("a_kcontig", i32),
+                ("B", vp), ("ldb", i64), ("b_kcontig", i32),
+                ("C", vp), ("ldc", i64),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("alpha", f32), ("flags", C.c_uint),
+                ("bias", vp), ("residual", vp), ("ldr", i64),
+                ("gate", vp), ("ldg", i64), ("gate_scale", f32),
+                ("drop_p", f32), ("rng", vp), ("site", u32),
+                ("precision", i32), ("splitk", i32)]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("lse", vp),
+                ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64),
+                ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64),
+                ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
+                ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
+                ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("dO", vp), ("lse", vp),
+                ("dQ", vp), ("dK", vp), ("dV", vp), ("delta_ws", vp),
+                ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64),
+                ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64),
+                ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
+                ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
+                ("scale", f32), ("drop_p", f32)]
+
+
+class Conv1dArgs(C.Structure):
+    _fields_ = [("x", vp), ("W", vp), ("bias", vp), ("y", vp),
+                ("B", i32), ("S", i32), ("Din", i32), ("Dout", i32), ("k", i32), ("mode", i32),
+                ("flags", C.c_uint), ("drop_p", f32), ("rng", vp), ("site", u32),
+                ("gate", vp), ("gate_scale", f32), ("precision", i32), ("splitk", i32)]
+
+
+# name -> (restype, argtypes); every symbol include/bmt_hip.h declares
+SIGNATURES = {
+    "bmt_version": (i32, []),
+    "bmt_last_error": (C.c_char_p, []),
+    "bmt_device_cus": (i32, []),
+    "bmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
+    "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
+    "bmt_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
+    "bmt_layernorm_bwd_blocks": (i32, [i32]),
+    "bmt_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, i32, vp]),
+    "bmt_prep_features": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, u32, vp]),
+    "bmt_prep_embed": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, u32, vp]),
+    "bmt_prep_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, u32, vp]),
+    "bmt_mask_from_features": (i32, [vp, i64, i64, f32, vp, i32, i32, vp]),
+    "bmt_mask_from_tokens": (i32, [vp, i64, vp, vp, i32, i32, vp]),
+    "bmt_dropout": (i32, [vp, vp, i64, f32, vp, u32, vp]),
+    "bmt_gate": (i32, [vp, vp, f32, vp, i64, vp]),
+    "bmt_dropout_add": (i32, [vp, vp, vp, i64, f32, vp, u32, vp]),
+    "bmt_add": (i32, [vp, vp, vp, i64, vp]),
+    "bmt_rng_advance": (i32, [vp, vp]),
+    "bmt_copy3d": (i32, [vp, i64, i64, i64, vp, i32, i32, i32, i32, vp]),
+    "bmt_log_softmax_fwd": (i32, [vp, i64, i32, i32, vp]),
+    "bmt_log_softmax_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "bmt_ls_kl_fwd": (i32, [vp, i64, vp, vp, vp, i32, i32, f32, i64, vp]),
+    "bmt_ls_kl_bwd": (i32, [vp, vp, i64, vp, vp, i32, i32, f32, i64, vp]),
+    "bmt_adam_step": (i32, [vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp, vp]),
+    "bmt_grad_sqnorm": (i32, [vp, vp, i32, i64, vp, f32, vp, vp]),
+    "bmt_scale_tensors": (i32, [vp, vp, i32, i64, vp, vp]),
+    "bmt_conv1d": (i32, [C.POINTER(Conv1dArgs), vp]),
+    "bmt_targets_init": (i32, [vp, vp, vp, vp, i64, vp]),
+    "bmt_make_targets": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "bmt_prop_decode_loss": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "bmt_prop_loss_finalize": (i32, [vp, f32, f32, vp, vp]),
+    "bmt_prop_loss_bwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with bmt_amd/csrc/build.sh (or __graft_entry__.build()). "
+            "bmt_amd has no CPU / eager fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bmt_version() != 1:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().bmt_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,233 @@
+// Input preparation and small HBM-bound kernels (K8 of SURVEY.md 2.3):
+//   rgb+flow add + positional table + dropout   (model/captioning_module.py:165,174-176; model/blocks.py:101-107)
+//   vocabulary gather * sqrt(d) + positional table + dropout (model/blocks.py:42-46)
+//   padding / causal masks, bit-exact            (model/masking.py:3-21; epoch_loops/captioning_epoch_loops.py:105-112)
+//   standalone dropout, add, RNG step advance, strided 3-D copy (Conv1d weight re-layout).
+// All are grid-stride, float4 where the widths allow (D % 4 == 0 on every hot-path tensor), coalesced over
+// the padded (B,T,d) feature tensors.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int grid_for(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void prep_features_kernel(const float* __restrict__ a, const float* __restrict__ b2,
+                                                             const float* __restrict__ pe, float* __restrict__ out, int B, int S,
+                                                             int D, float drop_p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = make_drop(drop_p, rng, site);
+    const int64_t SD = (int64_t)S * D;
+    const int64_t total = (int64_t)B * SD;
+    if constexpr (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+            float4 v = ld4(a + i);
+            if (b2) { const float4 w = ld4(b2 + i); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+            const float4 p = ld4(pe + (i % SD));
+            v.x = drop_apply(dc, v.x + p.x, (uint64_t)i + 0); v.y = drop_apply(dc, v.y + p.y, (uint64_t)i + 1);
+            v.z = drop_apply(dc, v.z + p.z, (uint64_t)i + 2); v.w = drop_apply(dc, v.w + p.w, (uint64_t)i + 3);
+            *reinterpret_cast<float4*>(out + i) = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            float v = a[i];
+            if (b2) v += b2[i];
+            out[i] = drop_apply(dc, v + pe[i % SD], (uint64_t)i);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ W,
+                                                          const float* __restrict__ pe, float* __restrict__ out, int B, int S, int D,
+                                                          int V, float emb_scale, float drop_p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = make_drop(drop_p, rng, site);
+    const int64_t total = (int64_t)B * S * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t tok = i / D;
+        const int d = (int)(i - tok * D);
+        const int s = (int)(tok % S);
+        int64_t id = ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        out[i] = drop_apply(dc, W[id * D + d] * emb_scale + pe[(int64_t)s * D + d], (uint64_t)i);
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                              float* __restrict__ dW, int B, int S, int D, int V, float emb_scale,
+                                                              float drop_p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = make_drop(drop_p, rng, site);
+    const int64_t total = (int64_t)B * S * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t tok = i / D;
+        const int d = (int)(i - tok * D);
+        int64_t id = ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        atomicAdd(dW + id * D + d, drop_apply(dc, dout[i], (uint64_t)i) * emb_scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_feat_kernel(const float* __restrict__ feat, int64_t bs, int64_t ld, float pad,
+                                                         uint8_t* __restrict__ out, int B, int S) {
+    const int64_t total = (int64_t)B * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / S), s = (int)(i % S);
+        out[i] = feat[(int64_t)b * bs + (int64_t)s * ld] != pad ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_tok_kernel(const int64_t* __restrict__ trg, int64_t pad_idx, uint8_t* __restrict__ src_mask,
+                                                        uint8_t* __restrict__ trg_mask, int B, int S) {
+    const int64_t total = (int64_t)B * S * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i % S);
+        const int64_t bi = i / S;
+        const int r = (int)(bi % S);
+        const int b = (int)(bi / S);
+        const bool nonpad = trg[(int64_t)b * S + j] != pad_idx;
+        if (trg_mask) trg_mask[i] = (nonpad && j <= r) ? 1 : 0;
+        if (src_mask && r == 0) src_mask[(int64_t)b * S + j] = nonpad ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float drop_p,
+                                                       const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = make_drop(drop_p, rng, site);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = drop_apply(dc, x[i], (uint64_t)i);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                   int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
+}
+
+// out[i0][i1][i2] (contiguous) (+)= in[i0*s0 + i1*s1 + i2*s2]
+__global__ __launch_bounds__(256) void copy3d_kernel(const float* __restrict__ in, int64_t s0, int64_t s1, int64_t s2,
+                                                      float* __restrict__ out, int n0, int n1, int n2, int accumulate) {
+    const int64_t total = (int64_t)n0 * n1 * n2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int i2 = (int)(i % n2);
+        const int64_t r = i / n2;
+        const int i1 = (int)(r % n1), i0 = (int)(r / n1);
+        const float v = in[i0 * s0 + i1 * s1 + i2 * s2];
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
+}  // namespace
+
+extern "C" int bmt_prep_features(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D, float drop_p,
+                                 const uint64_t* rng, uint32_t site, void* stream) {
+    BMT_CHECK_ARG(a && pe && out && B > 0 && S > 0 && D > 0, "bmt_prep_features: bad args");
+    const int64_t total = (int64_t)B * S * D;
+    const bool vec = (D % 4 == 0) && al16(a) && al16(pe) && al16(out) && (!b2 || al16(b2));
+    if (vec) hipLaunchKernelGGL(prep_features_kernel<true>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, a, b2, pe, out, B, S, D, drop_p, rng, site);
+    else hipLaunchKernelGGL(prep_features_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b2, pe, out, B, S, D, drop_p, rng, site);
+    BMT_CHECK_LAUNCH("bmt_prep_features");
+    return BMT_OK;
+}
+
+extern "C" int bmt_prep_embed(const int64_t* ids, const float* W, const float* pe, float* out, int B, int S, int D, int V,
+                              float emb_scale, float drop_p, const uint64_t* rng, uint32_t site, void* stream) {
+    BMT_CHECK_ARG(ids && W && pe && out && B > 0 && S > 0 && D > 0 && V > 0, "bmt_prep_embed: bad args");
+    hipLaunchKernelGGL(prep_embed_kernel, dim3(grid_for((int64_t)B * S * D)), dim3(256), 0, (hipStream_t)stream, ids, W, pe, out, B, S, D, V, emb_scale, drop_p, rng, site);
+    BMT_CHECK_LAUNCH("bmt_prep_embed");
+    return BMT_OK;
+}
+
+extern "C" int bmt_prep_embed_bwd(const int64_t* ids, const float* dout, float* dW, int B, int S, int D, int V, float emb_scale,
+                                  float drop_p, const uint64_t* rng, uint32_t site, void* stream) {
+    BMT_CHECK_ARG(ids && dout && dW && B > 0 && S > 0 && D > 0 && V > 0, "bmt_prep_embed_bwd: bad args");
+    hipLaunchKernelGGL(prep_embed_bwd_kernel, dim3(grid_for((int64_t)B * S * D)), dim3(256), 0, (hipStream_t)stream, ids, dout, dW, B, S, D, V, emb_scale, drop_p, rng, site);
+    BMT_CHECK_LAUNCH("bmt_prep_embed_bwd");
+    return BMT_OK;
+}
+
+extern "C" int bmt_mask_from_features(const float* feat, int64_t bs, int64_t ld, float pad, uint8_t* out, int B, int S, void* stream) {
+    BMT_CHECK_ARG(feat && out && B > 0 && S > 0, "bmt_mask_from_features: bad args");
+    hipLaunchKernelGGL(mask_feat_kernel, dim3(grid_for((int64_t)B * S)), dim3(256), 0, (hipStream_t)stream, feat, bs, ld, pad, out, B, S);
+    BMT_CHECK_LAUNCH("bmt_mask_from_features");
+    return BMT_OK;
+}
+
+extern "C" int bmt_mask_from_tokens(const int64_t* trg, int64_t pad_idx, uint8_t* src_mask, uint8_t* trg_mask, int B, int S, void* stream) {
+    BMT_CHECK_ARG(trg && (src_mask || trg_mask) && B > 0 && S > 0, "bmt_mask_from_tokens: bad args");
+    hipLaunchKernelGGL(mask_tok_kernel, dim3(grid_for((int64_t)B * S * S)), dim3(256), 0, (hipStream_t)stream, trg, pad_idx, src_mask, trg_mask, B, S);
+    BMT_CHECK_LAUNCH("bmt_mask_from_tokens");
+    return BMT_OK;
+}
+
+extern "C" int bmt_dropout(const float* x, float* y, int64_t n, float drop_p, const uint64_t* rng, uint32_t site, void* stream) {
+    BMT_CHECK_ARG(x && y && n >= 0, "bmt_dropout: bad args");
+    if (n == 0) return BMT_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, drop_p, rng, site);
+    BMT_CHECK_LAUNCH("bmt_dropout");
+    return BMT_OK;
+}
+
+extern "C" int bmt_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    BMT_CHECK_ARG(a && b && out && n >= 0, "bmt_add: bad args");
+    if (n == 0) return BMT_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    BMT_CHECK_LAUNCH("bmt_add");
+    return BMT_OK;
+}
+
+extern "C" int bmt_rng_advance(uint64_t* rng, void* stream) {
+    BMT_CHECK_ARG(rng, "bmt_rng_advance: null");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng);
+    BMT_CHECK_LAUNCH("bmt_rng_advance");
+    return BMT_OK;
+}
+
+extern "C" int bmt_copy3d(const float* in, int64_t s0, int64_t s1, int64_t s2, float* out, int n0, int n1, int n2, int accumulate,
+                          void* stream) {
+    BMT_CHECK_ARG(in && out && n0 > 0 && n1 > 0 && n2 > 0, "bmt_copy3d: bad args");
+    hipLaunchKernelGGL(copy3d_kernel, dim3(grid_for((int64_t)n0 * n1 * n2)), dim3(256), 0, (hipStream_t)stream, in, s0, s1, s2, out, n0, n1, n2, accumulate);
+    BMT_CHECK_LAUNCH("bmt_copy3d");
+    return BMT_OK;
+}
+
+// ---- backward helpers for fused activation/dropout epilogues
+namespace {
+// out = dy * (y != 0 ? scale : 0): derivative of relu(dropout(.)) / dropout(relu(.)) read off the saved OUTPUT y
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale,
+                                                    float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = (y[i] != 0.f) ? dy[i] * scale : 0.f;
+}
+// out = res + dropout(x)   (ResidualConnection: model/blocks.py:134-136)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                                           int64_t n, float drop_p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = make_drop(drop_p, rng, site);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = res[i] + drop_apply(dc, x[i], (uint64_t)i);
+}
+}  // namespace
+
+extern "C" int bmt_gate(const float* dy, const float* y, float scale, float* out, int64_t n, void* stream) {
+    BMT_CHECK_ARG(dy && y && out && n >= 0, "bmt_gate: bad args");
+    if (n == 0) return BMT_OK;
+    hipLaunchKernelGGL(gate_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, out, n);
+    BMT_CHECK_LAUNCH("bmt_gate");
+    return BMT_OK;
+}
+
+extern "C" int bmt_dropout_add(const float* x, const float* res, float* out, int64_t n, float drop_p, const uint64_t* rng,
+                               uint32_t site, void* stream) {
+    BMT_CHECK_ARG(x && res && out && n >= 0, "bmt_dropout_add: bad args");
+    if (n == 0) return BMT_OK;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, res, out, n, drop_p, rng, site);
+    BMT_CHECK_LAUNCH("bmt_dropout_add");
+    return BMT_OK;
+}

@@ -1,0 +1,224 @@
+// bmt_layernorm_fwd / bmt_layernorm_bwd -- nn.LayerNorm(size) of ResidualConnection / BridgeConnection
+// (model/blocks.py:127,131,143,150): biased variance, eps inside the sqrt, affine.
+//
+// HBM-bound.  One 64-lane wave per row, float4 accesses when D % 4 == 0 (every width on the hot path:
+// 128, 300, 600, 1024); the row is read from HBM once (second and third sweeps hit L1/L2).
+// Backward keeps per-column dgamma/dbeta partials in registers over a chunk of rows, reduces the four
+// waves of a workgroup through LDS and issues ONE atomic per column per workgroup.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
+                                                      float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float* yr = y + (int64_t)row * ldy;
+    float s = 0.f;
+    if constexpr (VEC) {
+        for (int c = lane * 4; c < D; c += 256) { const float4 v = ld4(xr + c); s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (int c = lane; c < D; c += 64) s += xr[c];
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+    if constexpr (VEC) {
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = ld4(xr + c);
+            const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) { const float a = xr[c] - mu; q += a * a; }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+    if constexpr (VEC) {
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = ld4(xr + c), g = ld4(gamma + c), b = ld4(beta + c);
+            float4 o;
+            o.x = (v.x - mu) * rs * g.x + b.x; o.y = (v.y - mu) * rs * g.y + b.y;
+            o.z = (v.z - mu) * rs * g.z + b.z; o.w = (v.w - mu) * rs * g.w + b.w;
+            *reinterpret_cast<float4*>(yr + c) = o;
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) yr[c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+    }
+}
+
+constexpr int LN_BWD_ROWS_PER_WAVE = 8;
+
+// NV = ceil(D / 256): float4 column groups per lane
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                      int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ dx, int64_t lddx,
+                                                      int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int rows, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][3 waves][NV*256]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 ag[NV], ab[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = ag[i];
+        const int c = lane * 4 + 256 * i;
+        gm[i] = (c < D) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int row0 = (blockIdx.x * 4 + wid) * LN_BWD_ROWS_PER_WAVE;
+    for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        const float* xr = x + (int64_t)row * ldx;
+        const float* dr = dy + (int64_t)row * lddy;
+        float4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) {
+                const float4 xv = ld4(xr + c), dv = ld4(dr + c);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            } else {
+                xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                g[i] = xh[i];
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        float* dxr = dx + (int64_t)row * lddx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) {
+                float4 o;
+                o.x = rs * (g[i].x - c1 - xh[i].x * c2); o.y = rs * (g[i].y - c1 - xh[i].y * c2);
+                o.z = rs * (g[i].z - c1 - xh[i].z * c2); o.w = rs * (g[i].w - c1 - xh[i].w * c2);
+                if (accumulate_dx) {
+                    const float4 p = ld4(dxr + c);
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                *reinterpret_cast<float4*>(dxr + c) = o;
+            }
+        }
+    }
+    // reduce the 4 waves' column partials through LDS; wave 0 issues the atomics
+    float* sg = sred;                     // [3][NV*256]
+    float* sb = sred + 3 * NV * 256;
+    if (wid > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            *reinterpret_cast<float4*>(sg + (wid - 1) * NV * 256 + lane * 4 + 256 * i) = ag[i];
+            *reinterpret_cast<float4*>(sb + (wid - 1) * NV * 256 + lane * 4 + 256 * i) = ab[i];
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) {
+                float4 tg = ag[i], tb = ab[i];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float4 a = *reinterpret_cast<float4*>(sg + w * NV * 256 + lane * 4 + 256 * i);
+                    const float4 b = *reinterpret_cast<float4*>(sb + w * NV * 256 + lane * 4 + 256 * i);
+                    tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w;
+                    tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
+                }
+                atomicAdd(dgamma + c + 0, tg.x); atomicAdd(dgamma + c + 1, tg.y);
+                atomicAdd(dgamma + c + 2, tg.z); atomicAdd(dgamma + c + 3, tg.w);
+                atomicAdd(dbeta + c + 0, tb.x); atomicAdd(dbeta + c + 1, tb.y);
+                atomicAdd(dbeta + c + 2, tb.z); atomicAdd(dbeta + c + 3, tb.w);
+            }
+        }
+    }
+}
+
+// generic fallback (any D, any alignment): one wave per row, per-element atomics for dgamma/dbeta
+__global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                             int64_t ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dx, int64_t lddx, int accumulate_dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (int64_t)row * ldx;
+    const float* dr = dy + (int64_t)row * lddy;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mu) * rs, g = dr[c] * gamma[c];
+        s1 += g; s2 += g * xh;
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+    float* dxr = dx + (int64_t)row * lddx;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mu) * rs, g = dr[c] * gamma[c];
+        const float o = rs * (g - c1 - xh * c2);
+        dxr[c] = accumulate_dx ? dxr[c] + o : o;
+        atomicAdd(dgamma + c, dr[c] * xh);
+        atomicAdd(dbeta + c, dr[c]);
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                                 float* mean, float* rstd, int rows, int D, float eps, void* stream) {
+    BMT_CHECK_ARG(x && gamma && beta && y && rows >= 0 && D > 0, "bmt_layernorm_fwd: bad args");
+    if (rows == 0) return BMT_OK;
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y) && al16(gamma) && al16(beta);
+    dim3 grid(bmt_cdiv(rows, 4)), block(256);
+    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps);
+    BMT_CHECK_LAUNCH("bmt_layernorm_fwd");
+    return BMT_OK;
+}
+
+extern "C" int bmt_layernorm_bwd_blocks(int rows) { return bmt_cdiv(rows, 4 * LN_BWD_ROWS_PER_WAVE); }
+
+extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
+                                 float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
+    (void)partial_ws;
+    BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
+    if (rows == 0) return BMT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && al16(x) && al16(dy) && al16(dx) &&
+                     al16(gamma) && D <= 2048;
+    if (!vec) {
+        hipLaunchKernelGGL(ln_bwd_scalar_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx,
+                           lddx, accumulate_dx, dgamma, dbeta, rows, D);
+        BMT_CHECK_LAUNCH("bmt_layernorm_bwd(scalar)");
+        return BMT_OK;
+    }
+    dim3 grid(bmt_layernorm_bwd_blocks(rows)), block(256);
+    const int nv = bmt_cdiv(D, 256);
+#define BMT_LN(NV)                                                                                                         \
+    hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 2 * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
+                       dx, lddx, accumulate_dx, dgamma, dbeta, rows, D)
+    if (nv <= 1) BMT_LN(1);
+    else if (nv <= 2) BMT_LN(2);
+    else if (nv <= 4) BMT_LN(4);
+    else BMT_LN(8);
+#undef BMT_LN
+    BMT_CHECK_LAUNCH("bmt_layernorm_bwd");
+    return BMT_OK;
+}

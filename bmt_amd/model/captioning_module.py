@@ -1,0 +1,175 @@
+"""Drop-in for the reference's model/captioning_module.py: Transformer :16-98, BiModalTransformer :101-187."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .blocks import (BridgeConnection, FeatureEmbedder, Identity, PositionalEncoder, VocabularyEmbedder, _embed)
+from .decoders import BiModelDecoder, Decoder
+from .encoders import BiModalEncoder, Encoder
+from .generators import Generator
+
+
+def _load_encoder_weights(path, strip):
+    cpt = torch.load(path, map_location='cpu', weights_only=False)
+    weights = {k: v for k, v in cpt['model_state_dict'].items() if 'encoder' in k}
+    return cpt['config'], {k.replace(strip, ''): v for k, v in weights.items()}
+
+
+class Transformer(nn.Module):
+    """Uni-modal captioning model (--modality audio|video), reference :16-98."""
+
+    def __init__(self, train_dataset, cfg):
+        super(Transformer, self).__init__()
+        self.modality = cfg.modality
+
+        if cfg.modality == 'video':
+            self.d_model = cfg.d_model_video
+            self.d_feat = cfg.d_vid
+            self.d_ff = cfg.d_ff_video
+        elif cfg.modality == 'audio':
+            self.d_feat = cfg.d_aud
+            self.d_model = cfg.d_model_audio
+            self.d_ff = cfg.d_ff_audio
+
+        if cfg.use_linear_embedder:
+            self.src_emb = FeatureEmbedder(self.d_feat, self.d_model)
+        else:
+            assert self.d_feat == self.d_model
+            self.src_emb = Identity()
+
+        self.trg_emb = VocabularyEmbedder(train_dataset.trg_voc_size, self.d_model)
+        self.pos_emb = PositionalEncoder(self.d_model, cfg.dout_p)
+        self.encoder = Encoder(self.d_model, cfg.dout_p, cfg.H, self.d_ff, cfg.N)
+        self.decoder = Decoder(self.d_model, cfg.dout_p, cfg.H, self.d_ff, cfg.N)
+        self.generator = Generator(self.d_model, train_dataset.trg_voc_size)
+
+        print('initialization: xavier')
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        # initialize embedding after, so it will replace the weights initialized previously
+        self.trg_emb.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
+
+        # load the pretrained encoder from the proposal (used in ablation studies)
+        if cfg.pretrained_prop_model_path is not None:
+            print(f'Pretrained prop path: \n {cfg.pretrained_prop_model_path}')
+            encoder_config, encoder_weights = _load_encoder_weights(cfg.pretrained_prop_model_path, 'encoder.')
+            if cfg.modality == 'video':
+                self.d_model = encoder_config.d_model_video
+                self.d_ff = encoder_config.d_ff_video
+            elif cfg.modality == 'audio':
+                self.d_model = encoder_config.d_model_audio
+                self.d_ff = encoder_config.d_ff_audio
+            self.encoder = Encoder(self.d_model, encoder_config.dout_p, encoder_config.H, self.d_ff, encoder_config.N)
+            self.encoder.load_state_dict(encoder_weights)
+            self.encoder = self.encoder.to(cfg.device)
+            for param in self.encoder.parameters():
+                param.requires_grad = cfg.finetune_prop_encoder
+
+    def forward(self, src: dict, trg, masks: dict):
+        ''' src (B, Ss, d_feat) trg (B, St) src_mask (B, 1, Ss) trg_mask (B, St, St) -> (B, St, voc_size) '''
+        if self.training:
+            ops.rng_advance()
+        if self.modality == 'audio':
+            src, add = src['audio'], None
+            src_mask = masks['A_mask']
+        elif self.modality == 'video':
+            src, add = src['rgb'], src['flow']
+            src_mask = masks['V_mask']
+        trg_mask = masks['C_mask']
+
+        if isinstance(self.src_emb, Identity):
+            src = self.pos_emb(src, fuse_add=add)
+        else:
+            src = self.pos_emb(self.src_emb(src if add is None else src + add))
+        trg = self.pos_emb(self.trg_emb(trg))
+
+        memory = self.encoder(src, src_mask)
+        out = self.decoder(trg, memory, src_mask, trg_mask)
+        return self.generator(out)
+
+
+class BiModalTransformer(nn.Module):
+    '''
+    Forward:
+        Inputs:
+            src {'rgb'&'flow' (B, Sv, Dv), 'audio': (B, Sa, Da)}
+            trg (C): ((B, Sc))
+            masks: {'V_mask': (B, 1, Sv), 'A_mask': (B, 1, Sa), 'C_mask' (B, Sc, Sc))}
+        Output:
+            C: (B, Sc, Vc) log-probabilities
+    '''
+
+    def __init__(self, cfg, train_dataset):
+        super(BiModalTransformer, self).__init__()
+
+        if cfg.use_linear_embedder:
+            self.emb_A = FeatureEmbedder(cfg.d_aud, cfg.d_model_audio)
+            self.emb_V = FeatureEmbedder(cfg.d_vid, cfg.d_model_video)
+        else:
+            self.emb_A = Identity()
+            self.emb_V = Identity()
+
+        self.emb_C = VocabularyEmbedder(train_dataset.trg_voc_size, cfg.d_model_caps)
+
+        self.pos_enc_A = PositionalEncoder(cfg.d_model_audio, cfg.dout_p)
+        self.pos_enc_V = PositionalEncoder(cfg.d_model_video, cfg.dout_p)
+        self.pos_enc_C = PositionalEncoder(cfg.d_model_caps, cfg.dout_p)
+
+        self.encoder = BiModalEncoder(
+            cfg.d_model_audio, cfg.d_model_video, cfg.d_model, cfg.dout_p, cfg.H,
+            cfg.d_ff_audio, cfg.d_ff_video, cfg.N
+        )
+
+        self.decoder = BiModelDecoder(
+            cfg.d_model_audio, cfg.d_model_video, cfg.d_model_caps, cfg.d_model, cfg.dout_p,
+            cfg.H, cfg.d_ff_caps, cfg.N
+        )
+
+        self.generator = Generator(cfg.d_model_caps, train_dataset.trg_voc_size)
+
+        print('initialization: xavier')
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        # initialize embedding after, so it will replace the weights of the prev. initialization
+        self.emb_C.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
+
+        # load the pretrained encoder from the proposal (used in ablation studies)
+        if cfg.pretrained_prop_model_path is not None:
+            print(f'Pretrained prop path: \n {cfg.pretrained_prop_model_path}')
+            encoder_config, encoder_weights = _load_encoder_weights(cfg.pretrained_prop_model_path, 'encoder.')
+            self.encoder = BiModalEncoder(
+                encoder_config.d_model_audio, encoder_config.d_model_video, encoder_config.d_model,
+                encoder_config.dout_p, encoder_config.H, encoder_config.d_ff_audio,
+                encoder_config.d_ff_video, encoder_config.N
+            )
+            self.encoder.load_state_dict(encoder_weights)
+            self.encoder = self.encoder.to(cfg.device)
+            for param in self.encoder.parameters():
+                param.requires_grad = cfg.finetune_prop_encoder
+
+    def forward(self, src: dict, trg, masks: dict):
+        if self.training:
+            ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
+        A = src['audio']
+        C = trg
+
+        # rgb + flow, (optional) linear embedders, positional tables, dropout  (reference :165-176)
+        if isinstance(self.emb_V, Identity):
+            V = self.pos_enc_V(src['rgb'], fuse_add=src['flow'])
+            A = self.pos_enc_A(A)
+        else:
+            V = self.pos_enc_V(self.emb_V(src['rgb'] + src['flow']))
+            A = self.pos_enc_A(self.emb_A(A))
+        if isinstance(self.emb_C.embedder, nn.Embedding):
+            pc = self.pos_enc_C
+            C = _embed(self.emb_C, C, pe=pc.table(self.emb_C.embedder.weight.device),
+                       p=pc.dout_p if self.training else 0.0, site=pc._site)
+        else:
+            C = self.pos_enc_C(self.emb_C(C))
+
+        Av, Va = self.encoder((A, V), masks)
+        C = self.decoder((C, (Av, Va)), masks)
+        # (B, Sc, Vc) <- (B, Sc, Dc)
+        return self.generator(C)

@@ -1,0 +1,88 @@
+"""Drop-in for the reference's model/decoders.py: DecoderLayer :9, BiModalDecoderLayer :37, Decoder :95,
+BiModelDecoder :114 (sic -- the reference's spelling is what callers import; BiModalDecoder is an alias)."""
+import torch
+import torch.nn as nn
+
+from .blocks import (BridgeConnection, LayerStack, PositionwiseFeedForward, ResidualConnection, clone)
+from .multihead_attention import MultiheadedAttention
+
+
+class DecoderLayer(nn.Module):
+
+    def __init__(self, d_model, dout_p, H, d_ff):
+        super(DecoderLayer, self).__init__()
+        self.res_layers = clone(ResidualConnection(d_model, dout_p), 3)
+        self.self_att = MultiheadedAttention(d_model, d_model, d_model, H)
+        self.enc_att = MultiheadedAttention(d_model, d_model, d_model, H)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dout_p=0.0)
+
+    def forward(self, x, memory, src_mask, trg_mask):
+        x = self.res_layers[0](x, lambda y: self.self_att(y, y, y, trg_mask))
+        x = self.res_layers[1](x, lambda y: self.enc_att(y, memory, memory, src_mask))
+        x = self.res_layers[2](x, self.feed_forward)
+        return x
+
+
+class BiModalDecoderLayer(nn.Module):
+
+    def __init__(self, d_model_A, d_model_V, d_model_C, d_model, dout_p, H, d_ff_C):
+        super(BiModalDecoderLayer, self).__init__()
+        # self attention
+        self.res_layer_self_att = ResidualConnection(d_model_C, dout_p)
+        self.self_att = MultiheadedAttention(d_model_C, d_model_C, d_model_C, H, dout_p, d_model)
+        # encoder attention
+        self.res_layer_enc_att_A = ResidualConnection(d_model_C, dout_p)
+        self.res_layer_enc_att_V = ResidualConnection(d_model_C, dout_p)
+        self.enc_att_A = MultiheadedAttention(d_model_C, d_model_A, d_model_A, H, dout_p, d_model)
+        self.enc_att_V = MultiheadedAttention(d_model_C, d_model_V, d_model_V, H, dout_p, d_model)
+        # bridge
+        self.bridge = BridgeConnection(2*d_model_C, d_model_C, dout_p)
+        # feed forward residual
+        self.res_layer_ff = ResidualConnection(d_model_C, dout_p)
+        self.feed_forward = PositionwiseFeedForward(d_model_C, d_ff_C, dout_p)
+
+    def forward(self, x, masks):
+        '''
+        x (C, memory): C: (B, Sc, Dc), memory: (Av: (B, Sa, Da), Va: (B, Sv, Dv))
+        masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa); C_mask (B, Sc, Sc)}
+        returns (C, memory) so the layer threads through LayerStack
+        '''
+        C, memory = x
+        Av, Va = memory
+
+        C = self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, masks['C_mask']))
+        Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']))
+        Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']))
+        # (B, Sc, 2*Dc) -> bridge -> (B, Sc, Dc); no residual across the bridge
+        C = self.bridge(torch.cat([Ca, Cv], dim=-1))
+        C = self.res_layer_ff(C, self.feed_forward)
+
+        return C, memory
+
+
+class Decoder(nn.Module):
+
+    def __init__(self, d_model, dout_p, H, d_ff, N):
+        super(Decoder, self).__init__()
+        self.dec_layers = clone(DecoderLayer(d_model, dout_p, H, d_ff), N)
+
+    def forward(self, x, memory, src_mask, trg_mask):
+        for layer in self.dec_layers:
+            x = layer(x, memory, src_mask, trg_mask)
+        return x
+
+
+class BiModelDecoder(nn.Module):
+
+    def __init__(self, d_model_A, d_model_V, d_model_C, d_model, dout_p, H, d_ff_C, N):
+        super(BiModelDecoder, self).__init__()
+        layer = BiModalDecoderLayer(d_model_A, d_model_V, d_model_C, d_model, dout_p, H, d_ff_C)
+        self.decoder = LayerStack(layer, N)
+
+    def forward(self, x, masks):
+        # x is (C, memory)
+        C, memory = self.decoder(x, masks)
+        return C
+
+
+BiModalDecoder = BiModelDecoder

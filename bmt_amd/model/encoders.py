@@ -1,0 +1,83 @@
+"""Drop-in for the reference's model/encoders.py: EncoderLayer :9, BiModalEncoderLayer :36, Encoder :90,
+BiModalEncoder :108.  Same submodule names (state_dict contract) and the same order of
+operations -- in particular the cross-modal K/V are the other stream's post-self-attention, un-normalised values
+(reference :63-79) and there is no final LayerNorm."""
+import torch
+import torch.nn as nn
+
+from .blocks import (BridgeConnection, LayerStack, PositionwiseFeedForward, ResidualConnection, clone)
+from .multihead_attention import MultiheadedAttention
+
+
+class EncoderLayer(nn.Module):
+
+    def __init__(self, d_model, dout_p, H, d_ff):
+        super(EncoderLayer, self).__init__()
+        self.res_layers = clone(ResidualConnection(d_model, dout_p), 2)
+        self.self_att = MultiheadedAttention(d_model, d_model, d_model, H)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dout_p=0.0)
+
+    def forward(self, x, src_mask):
+        ''' x: (B, S, d_model), src_mask: (B, 1, S) -> (B, S, d_model) '''
+        x = self.res_layers[0](x, lambda y: self.self_att(y, y, y, src_mask))
+        x = self.res_layers[1](x, self.feed_forward)
+        return x
+
+
+class BiModalEncoderLayer(nn.Module):
+
+    def __init__(self, d_model_M1, d_model_M2, d_model, dout_p, H, d_ff_M1, d_ff_M2):
+        super(BiModalEncoderLayer, self).__init__()
+        self.self_att_M1 = MultiheadedAttention(d_model_M1, d_model_M1, d_model_M1, H, dout_p, d_model)
+        self.self_att_M2 = MultiheadedAttention(d_model_M2, d_model_M2, d_model_M2, H, dout_p, d_model)
+        self.bi_modal_att_M1 = MultiheadedAttention(d_model_M1, d_model_M2, d_model_M2, H, dout_p, d_model)
+        self.bi_modal_att_M2 = MultiheadedAttention(d_model_M2, d_model_M1, d_model_M1, H, dout_p, d_model)
+        self.feed_forward_M1 = PositionwiseFeedForward(d_model_M1, d_ff_M1, dout_p)
+        self.feed_forward_M2 = PositionwiseFeedForward(d_model_M2, d_ff_M2, dout_p)
+        self.res_layers_M1 = clone(ResidualConnection(d_model_M1, dout_p), 3)
+        self.res_layers_M2 = clone(ResidualConnection(d_model_M2, dout_p), 3)
+
+    def forward(self, x, masks):
+        '''
+        x (M1, M2): (B, Sm, Dm); masks (M1, M2): (B, 1, Sm)  ->  M1m2 (B, Sm1, Dm1), M2m1 (B, Sm2, Dm2)
+        '''
+        M1, M2 = x
+        M1_mask, M2_mask = masks
+
+        # 1. self-attention on each stream
+        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask))
+        M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask))
+        # 2. cross-modal attention: queries are the normalised stream, keys/values the OTHER stream as it is now
+        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask))
+        M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask))
+        # 3. feed-forward
+        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1)
+        M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2)
+
+        return M1m2, M2m1
+
+
+class Encoder(nn.Module):
+
+    def __init__(self, d_model, dout_p, H, d_ff, N):
+        super(Encoder, self).__init__()
+        self.enc_layers = clone(EncoderLayer(d_model, dout_p, H, d_ff), N)
+
+    def forward(self, x, src_mask):
+        for layer in self.enc_layers:
+            x = layer(x, src_mask)
+        return x
+
+
+class BiModalEncoder(nn.Module):
+
+    def __init__(self, d_model_A, d_model_V, d_model, dout_p, H, d_ff_A, d_ff_V, N):
+        super(BiModalEncoder, self).__init__()
+        layer_AV = BiModalEncoderLayer(d_model_A, d_model_V, d_model, dout_p, H, d_ff_A, d_ff_V)
+        self.encoder_AV = LayerStack(layer_AV, N)
+
+    def forward(self, x, masks: dict):
+        ''' x (A, V): (B, Sm, D); masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa)}  ->  (Av, Va) '''
+        A, V = x
+        Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
+        return (Av, Va)

@@ -1,0 +1,74 @@
+"""Drop-in for the reference's model/multihead_attention.py (attention :8-26, MultiheadedAttention :29-86)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def attention(Q, K, V, mask, dropout=None):
+    """softmax(QK^T/sqrt(d_k) masked) V on (B,H,S,d_k) views, as model/multihead_attention.py:8-26.
+    Runs the flash kernel (the (B,H,Sq,Sk) score tensor is never materialised).  ``dropout`` is an
+    nn.Dropout-like module applied to the OUTPUT (reference :22-23)."""
+    B, H, Sq, dk = Q.shape
+    q = Q.transpose(1, 2).reshape(B, Sq, H * dk)
+    k = K.transpose(1, 2).reshape(B, K.shape[2], H * dk)
+    v = V.transpose(1, 2).reshape(B, V.shape[2], H * dk)
+    out = _CoreFn.apply(q, k, v, mask, H)
+    out = out.view(B, Sq, H, dk).transpose(1, 2)
+    if dropout is not None:
+        out = dropout(out)
+    return out
+
+
+class _CoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, H):
+        q, k, v = ops._f32c(q), ops._f32c(k), ops._f32c(v)
+        o, lse = ops.attn_fwd(q, k, v, mask, H)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.mask, ctx.H = mask, H
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = ops.attn_bwd(q, k, v, o, ops._f32c(do), lse, ctx.mask, ctx.H)
+        return dq, dk, dv, None, None
+
+
+class MultiheadedAttention(nn.Module):
+
+    def __init__(self, d_model_Q, d_model_K, d_model_V, H, dout_p=0.0, d_model=None):
+        super(MultiheadedAttention, self).__init__()
+        self.d_model_Q = d_model_Q
+        self.d_model_K = d_model_K
+        self.d_model_V = d_model_V
+        self.H = H
+        self.d_model = d_model
+        self.dout_p = dout_p
+
+        if self.d_model is None:
+            print(f'd_model: is None')
+            self.d_model = self.d_model_Q
+
+        self.d_k = self.d_model // H
+
+        self.linear_Q2d = nn.Linear(self.d_model_Q, self.d_model)
+        self.linear_K2d = nn.Linear(self.d_model_K, self.d_model)
+        self.linear_V2d = nn.Linear(self.d_model_V, self.d_model)
+        self.linear_d2Q = nn.Linear(self.d_model, self.d_model_Q)
+
+        self.dropout = nn.Dropout(self.dout_p)   # kept for the module surface; the mask is drawn in-kernel
+        self._site = ops.new_site()
+
+        assert self.d_model % H == 0
+
+    def forward(self, Q, K, V, mask):
+        ''' Q, K, V: (B, Sq, Dq), (B, Sk, Dk), (B, Sv, Dv); mask: (B, 1, Sk) or (B, Sq, Sk) '''
+        p = self.dout_p if self.training else 0.0
+        return ops.MHAFn.apply(Q, K, V, mask,
+                               self.linear_Q2d.weight, self.linear_Q2d.bias,
+                               self.linear_K2d.weight, self.linear_K2d.bias,
+                               self.linear_V2d.weight, self.linear_V2d.bias,
+                               self.linear_d2Q.weight, self.linear_d2Q.bias,
+                               self.H, p, self._site)

@@ -1,0 +1,417 @@
+"""Drop-in for the reference's model/proposal_generator.py: ProposalGenerationHead :11-47, ProposalGenerator :50-212,
+MultimodalProposalGenerator :215-387, make_targets :389-448.
+
+The Conv1d stacks run as implicit GEMMs on the MFMA kernel (bmt_conv1d: no im2col buffer, no (B,D,S) permutes),
+target assignment / decode / YOLO loss are the HIP kernels of csrc/proposal.hip.  state_dict keys are the
+reference's (``detection_layers_{A,V}.i.conv_layers.{0,3,6}.{weight,bias}`` with the default Sequential)."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .._lib import EPI_BIAS, EPI_DROP_PRE, EPI_RELU, Conv1dArgs
+from ..ops import _f32c, _p, _st, lib
+from .blocks import FeatureEmbedder, Identity, PositionalEncoder, Transpose, layer_norm
+from .encoders import BiModalEncoder, Encoder
+
+
+def _copy3d(src, s0, s1, s2, n0, n1, n2, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(n0, n1, n2, device=src.device, dtype=torch.float32)
+    _lib.check(lib.bmt_copy3d(_p(src), s0, s1, s2, _p(out), n0, n1, n2, int(accumulate), _st()), "bmt_copy3d")
+    return out
+
+
+def _conv(mode, x, W, bias, y, B, S, Din, Dout, k, flags=0, drop_p=0.0, site=0, precision=None, splitk=1):
+    use_drop = drop_p > 0 and (flags & EPI_DROP_PRE)
+    a = Conv1dArgs(_p(x), _p(W), _p(bias), _p(y), B, S, Din, Dout, k, mode, flags if use_drop else flags & ~EPI_DROP_PRE,
+                   drop_p if use_drop else 0.0, _p(ops.rng_tensor()) if use_drop else None, site, None, 1.0,
+                   precision or ops.FWD_PRECISION, splitk)
+    _lib.check(lib.bmt_conv1d(C.byref(a), _st()), "bmt_conv1d")
+
+
+class ConvKFn(torch.autograd.Function):
+    """relu?(dropout?(Conv1d(Din->Dout, k, padding=k//2)(x)))  on (B,S,Din) activations (reference :29-35,41-45)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu, p, site):
+        xc = _f32c(x)
+        B, S, Din = xc.shape
+        Dout, _, k = W.shape
+        Wc = W.contiguous()
+        # state_dict layout [Dout][Din][k] -> tap-major [Dout][k][Din] (reduction index contiguous for the MFMA B operand)
+        Wp = _copy3d(Wc, Din * k, 1, k, Dout, k, Din)
+        y = torch.empty(B, S, Dout, device=x.device, dtype=torch.float32)
+        flags = EPI_BIAS | (EPI_RELU if relu else 0) | (EPI_DROP_PRE if p > 0 else 0)
+        _conv(0, xc, Wp, b, y, B, S, Din, Dout, k, flags, p, site)
+        ctx.save_for_backward(xc, Wc, y if (relu or p > 0) else None)
+        ctx.relu, ctx.p, ctx.site = relu, p, site
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, Wc, y = ctx.saved_tensors
+        B, S, Din = xc.shape
+        Dout, _, k = Wc.shape
+        dyc = _f32c(dy)
+        if ctx.relu:
+            dz = torch.empty_like(dyc)
+            _lib.check(lib.bmt_gate(_p(dyc), _p(y), 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0, _p(dz), dyc.numel(), _st()), "bmt_gate")
+        elif ctx.p > 0:
+            dz = ops.dropout_raw(dyc, ctx.p, ctx.site)
+        else:
+            dz = dyc
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wt = _copy3d(Wc, k, 1, Din * k, Din, k, Dout)        # [Din][k][Dout]
+            dx = torch.empty(B, S, Din, device=dy.device, dtype=torch.float32)
+            _conv(1, dz, Wt, None, dx, B, S, Din, Dout, k, precision=ops.BWD_PRECISION)
+        # dWp[o][t][c] accumulated by split-K atomics, then folded back to the state_dict layout [o][c][t]
+        dWp = torch.zeros(Dout, k, Din, device=dy.device, dtype=torch.float32)
+        sk = ops._splitk_for(Dout, k * Din, B * S)
+        _conv(2, dz, xc, None, dWp, B, S, Din, Dout, k, precision=ops.BWD_PRECISION, splitk=sk)
+        dW = _copy3d(dWp, k * Din, 1, Din, Dout, Din, k)
+        db = ops.colsum(dz.view(-1, Dout))
+        return dx, dW, db, None, None, None
+
+
+class ProposalGenerationHead(nn.Module):
+
+    def __init__(self, d_model_list, kernel_size, dout_p, layer_norm=False):
+        super(ProposalGenerationHead, self).__init__()
+        assert kernel_size % 2 == 1, 'It is more convenient to use odd kernel_sizes for padding'
+        conv_layers = []
+        in_dims = d_model_list[:-1]
+        out_dims = d_model_list[1:]
+        N_layers = len(d_model_list) - 1
+        self._stages = []   # (index of LayerNorm or None, index of conv, has_dropout, has_relu)
+
+        for n, (in_d, out_d) in enumerate(zip(in_dims, out_dims)):
+            ln_idx = None
+            if layer_norm:
+                conv_layers.append(Transpose())
+                ln_idx = len(conv_layers)
+                conv_layers.append(nn.LayerNorm(in_d))
+                conv_layers.append(Transpose())
+
+            conv_idx = len(conv_layers)
+            if n == 0:
+                conv_layers.append(nn.Conv1d(in_d, out_d, kernel_size, padding=kernel_size//2))
+            else:
+                conv_layers.append(nn.Conv1d(in_d, out_d, kernel_size=1))
+
+            has_drop = has_relu = False
+            if n < (N_layers - 1):
+                if dout_p > 0:
+                    conv_layers.append(nn.Dropout(dout_p))
+                    has_drop = True
+                conv_layers.append(nn.ReLU())
+                has_relu = True
+            self._stages.append((ln_idx, conv_idx, has_drop, has_relu))
+
+        self.dout_p = dout_p
+        self.conv_layers = nn.Sequential(*conv_layers)
+        self._sites = [ops.new_site() for _ in self._stages]
+
+    def forward(self, x):
+        # (B, S, D) in, (B, S, d) out; the reference's two permutes (:41,:45) are folded into the GEMM addressing
+        p = self.dout_p if self.training else 0.0
+        for (ln_idx, conv_idx, has_drop, has_relu), site in zip(self._stages, self._sites):
+            if ln_idx is not None:
+                x = layer_norm(self.conv_layers[ln_idx], x)
+            conv = self.conv_layers[conv_idx]
+            pp = p if has_drop else 0.0
+            if conv.kernel_size[0] == 1:
+                x = ops.LinearActFn.apply(x, conv.weight[:, :, 0], conv.bias, has_relu, "pre" if has_drop else "none", pp, site)
+            else:
+                x = ConvKFn.apply(x, conv.weight, conv.bias, has_relu, pp, site)
+        return x
+
+
+def _targets_buffers(B, A, G, device):
+    n = B * A * G
+    obj = torch.empty(B, A, G, device=device, dtype=torch.uint8)
+    noobj = torch.empty(B, A, G, device=device, dtype=torch.uint8)
+    tx = torch.empty(B, A, G, device=device, dtype=torch.float32)
+    tw = torch.empty(B, A, G, device=device, dtype=torch.float32)
+    _lib.check(lib.bmt_targets_init(_p(obj), _p(noobj), _p(tx), _p(tw), n, _st()), "bmt_targets_init")
+    return obj, noobj, tx, tw
+
+
+def make_targets(predictions, targets, anchors, stride):
+    '''YOLO-style target assignment, reference :389-448.  predictions: (B, A, G, 3) (only its shape is used),
+    targets: (n, 4) [batch idx, center s, length s, meta], anchors: (A, 1) already divided by stride.
+    Returns obj_mask, noobj_mask (bool), target_x, target_w, target_obj (float), bit-exact masks.'''
+    B, num_anchs, G, _ = predictions.size()
+    dev = predictions.device
+    obj, noobj, tx, tw = _targets_buffers(B, num_anchs, G, dev)
+    t = _f32c(targets.to(dev))
+    a = _f32c(anchors.to(dev)).view(-1)
+    _lib.check(lib.bmt_make_targets(_p(t), t.shape[0], _p(a), num_anchs, B, G, float(stride), _p(obj), _p(noobj), _p(tx), _p(tw),
+                                    _st()), "bmt_make_targets")
+    obj_b = obj.view(torch.bool)
+    return obj_b, noobj.view(torch.bool), tx, tw, obj_b.float()
+
+
+class _PropLossFn(torch.autograd.Function):
+    """decode + masked MSE/BCE of one head (reference :281-335); returns (predictions, total loss, 4 loss terms)."""
+
+    @staticmethod
+    def forward(ctx, x, anchors_dev, stride, tgt, obj_coeff, noobj_coeff):
+        xc = _f32c(x)
+        B, S, D = xc.shape
+        A = anchors_dev.numel()
+        preds = torch.empty(B, A * S, 3, device=x.device, dtype=torch.float32)
+        if tgt is None:
+            _lib.check(lib.bmt_prop_decode_loss(_p(xc), _p(anchors_dev), B, S, A, float(stride), None, None, None, None, _p(preds),
+                                                None, _st()), "bmt_prop_decode_loss")
+            ctx.has_t = False
+            return preds, torch.zeros((), device=x.device), torch.zeros(4, device=x.device)
+        obj, noobj, tx, tw = tgt
+        ws = torch.empty(8, device=x.device, dtype=torch.float32)
+        losses = torch.empty(5, device=x.device, dtype=torch.float32)
+        _lib.check(lib.bmt_prop_decode_loss(_p(xc), _p(anchors_dev), B, S, A, float(stride), _p(obj), _p(noobj), _p(tx), _p(tw),
+                                            _p(preds), _p(ws), _st()), "bmt_prop_decode_loss")
+        _lib.check(lib.bmt_prop_loss_finalize(_p(ws), float(obj_coeff), float(noobj_coeff), _p(losses), _st()),
+                   "bmt_prop_loss_finalize")
+        ctx.has_t = True
+        ctx.save_for_backward(xc, obj, noobj, tx, tw, ws)
+        ctx.coeffs = (float(obj_coeff), float(noobj_coeff), A)
+        ctx.mark_non_differentiable(preds)
+        return preds, losses[4], losses[:4].detach()
+
+    @staticmethod
+    def backward(ctx, dpreds, dloss, dterms):
+        if not ctx.has_t:
+            return None, None, None, None, None, None
+        xc, obj, noobj, tx, tw, ws = ctx.saved_tensors
+        oc, nc, A = ctx.coeffs
+        B, S, _ = xc.shape
+        dx = torch.empty_like(xc)
+        g = _f32c(dloss).reshape(1)
+        _lib.check(lib.bmt_prop_loss_bwd(_p(xc), B, S, A, _p(obj), _p(noobj), _p(tx), _p(tw), _p(ws), oc, nc, _p(g), _p(dx), _st()),
+                   "bmt_prop_loss_bwd")
+        return dx, None, None, None, None, None
+
+
+_LOSS_KEYS = ('loss_x', 'loss_w', 'loss_conf_obj', 'loss_conf_noobj')
+
+
+def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache):
+    """shared body of forward_modality (:272-337) / kernel_size_forward (:123-184)."""
+    anchors_num = len(anchors_list)
+    x = detection(x)
+    B, S, D = x.shape
+    key = (anchors_num, S, float(stride))
+    if key not in tgt_cache:
+        # python-float division, then fp32 -- as torch.tensor([[anchor / stride] ...]) in the reference
+        anchors_dev = torch.tensor([a / stride for a in anchors_list], dtype=torch.float32, device=x.device)
+        tgt = None
+        if targets is not None:
+            obj, noobj, tx, tw = _targets_buffers(B, anchors_num, S, x.device)
+            t = _f32c(targets.to(x.device))
+            _lib.check(lib.bmt_make_targets(_p(t), t.shape[0], _p(anchors_dev), anchors_num, B, S, float(stride), _p(obj),
+                                            _p(noobj), _p(tx), _p(tw), _st()), "bmt_make_targets")
+            tgt = (obj, noobj, tx, tw)
+        tgt_cache[key] = (anchors_dev, tgt)
+    anchors_dev, tgt = tgt_cache[key]
+    preds, loss, terms = _PropLossFn.apply(x, anchors_dev, stride, tgt, cfg.obj_coeff, cfg.noobj_coeff)
+    if targets is None:
+        return preds, 0, {}
+    return preds, loss, {k: terms[i] for i, k in enumerate(_LOSS_KEYS)}
+
+
+def _add_dict(one, another):
+    return {k: another.get(k, 0) + v for k, v in one.items()}
+
+
+def _load_cap_encoder(path, strip='module.encoder.'):
+    cpt = torch.load(path, map_location='cpu', weights_only=False)
+    weights = {k: v for k, v in cpt['model_state_dict'].items() if 'encoder' in k}
+    return cpt['config'], {k.replace(strip, ''): v for k, v in weights.items()}
+
+
+class ProposalGenerator(nn.Module):
+    """uni-modal generator (--modality audio|video), reference :50-212."""
+
+    def __init__(self, cfg, anchors):
+        super(ProposalGenerator, self).__init__()
+        self.cfg = cfg
+        self.EPS = 1e-16
+        self.num_logits = 3  # 3: c, w, obj
+        self.anchors = anchors
+        self.anchors_list = anchors[cfg.modality]
+        self.anchors_num = len(self.anchors_list)
+
+        if cfg.modality == 'video':
+            self.d_feat = cfg.d_vid
+            self.d_model_modality = cfg.d_model_video
+            self.d_ff = cfg.d_ff_video
+            layer_dims = [self.d_model_modality, *cfg.conv_layers_video, self.num_logits*self.anchors_num]
+        elif cfg.modality == 'audio':
+            self.d_feat = cfg.d_aud
+            self.d_model_modality = cfg.d_model_audio
+            self.d_ff = cfg.d_ff_audio
+            layer_dims = [self.d_model_modality, *cfg.conv_layers_audio, self.num_logits*self.anchors_num]
+        else:
+            raise NotImplementedError
+
+        if cfg.use_linear_embedder:
+            self.emb = FeatureEmbedder(self.d_feat, self.d_model_modality)
+        else:
+            self.emb = Identity()
+        self.pos_enc = PositionalEncoder(self.d_model_modality, cfg.dout_p)
+
+        if cfg.pretrained_cap_model_path is not None:
+            print(f'Caption path: \n {cfg.pretrained_cap_model_path}')
+            encoder_config, encoder_weights = _load_cap_encoder(cfg.pretrained_cap_model_path)
+            if cfg.modality == 'video':
+                self.d_model_modality = encoder_config.d_model_video
+                self.d_ff = encoder_config.d_ff_video
+            elif cfg.modality == 'audio':
+                self.d_model_modality = encoder_config.d_model_audio
+                self.d_ff = encoder_config.d_ff_audio
+            self.encoder = Encoder(self.d_model_modality, encoder_config.dout_p, encoder_config.H, self.d_ff, encoder_config.N)
+            self.encoder.load_state_dict(encoder_weights)
+            self.encoder = self.encoder.to(cfg.device)
+            for param in self.encoder.parameters():
+                param.requires_grad = cfg.finetune_cap_encoder
+        else:
+            self.encoder = Encoder(self.d_model_modality, cfg.dout_p, cfg.H, self.d_ff, cfg.N)
+            for p in self.encoder.parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+
+        self.detection_layers = torch.nn.ModuleList([
+            ProposalGenerationHead(layer_dims, k, cfg.dout_p, cfg.layer_norm) for k in cfg.kernel_sizes[cfg.modality]
+        ])
+
+        print(self.detection_layers)
+        self.bce_loss = nn.BCELoss()
+        self.mse_loss = nn.MSELoss()
+
+    def kernel_size_forward(self, x, layer, stride, targets, _cache=None):
+        return _head_forward(x, targets, layer, stride, self.anchors_list, self.cfg, {} if _cache is None else _cache)
+
+    def forward(self, x, targets, masks):
+        if self.training:
+            ops.rng_advance()
+        if self.cfg.modality == 'video':
+            stride = self.cfg.strides['video']
+            x = self.pos_enc(x['rgb'], fuse_add=x['flow']) if isinstance(self.emb, Identity) else \
+                self.pos_enc(self.emb(x['rgb'] + x['flow']))
+            x = self.encoder(x, masks['V_mask'])
+        elif self.cfg.modality == 'audio':
+            stride = self.cfg.strides['audio']
+            x = self.pos_enc(self.emb(x['audio']))
+            x = self.encoder(x, masks['A_mask'])
+
+        all_predictions = []
+        sum_losses_dict = {}
+        total_loss = 0
+        cache = {}
+        for layer in self.detection_layers:
+            predictions, loss, loss_dict = self.kernel_size_forward(x, layer, stride, targets, cache)
+            total_loss += loss
+            all_predictions.append(predictions)
+            sum_losses_dict = _add_dict(loss_dict, sum_losses_dict)
+
+        all_predictions = torch.cat(all_predictions, dim=1)
+        return all_predictions, total_loss, sum_losses_dict
+
+
+class MultimodalProposalGenerator(nn.Module):
+
+    def __init__(self, cfg, anchors):
+        super(MultimodalProposalGenerator, self).__init__()
+        assert cfg.modality == 'audio_video'
+        self.cfg = cfg
+        self.anchors = anchors
+        self.EPS = 1e-16
+        self.num_logits = 3  # 3: c, w, obj
+
+        if cfg.use_linear_embedder:
+            self.emb_V = FeatureEmbedder(cfg.d_vid, cfg.d_model_video)
+            self.emb_A = FeatureEmbedder(cfg.d_aud, cfg.d_model_audio)
+        else:
+            self.emb_V = Identity()
+            self.emb_A = Identity()
+        self.pos_enc_V = PositionalEncoder(cfg.d_model_video, cfg.dout_p)
+        self.pos_enc_A = PositionalEncoder(cfg.d_model_audio, cfg.dout_p)
+
+        # load the pre-trained encoder from captioning module
+        if cfg.pretrained_cap_model_path is not None:
+            print(f'Pretrained caption path: \n {cfg.pretrained_cap_model_path}')
+            encoder_config, encoder_weights = _load_cap_encoder(cfg.pretrained_cap_model_path)
+            self.encoder = BiModalEncoder(
+                encoder_config.d_model_audio, encoder_config.d_model_video, encoder_config.d_model,
+                encoder_config.dout_p, encoder_config.H, encoder_config.d_ff_audio,
+                encoder_config.d_ff_video, encoder_config.N
+            )
+            self.encoder.load_state_dict(encoder_weights)
+            self.encoder = self.encoder.to(cfg.device)
+            for param in self.encoder.parameters():
+                param.requires_grad = cfg.finetune_cap_encoder
+        else:
+            self.encoder = BiModalEncoder(
+                cfg.d_model_audio, cfg.d_model_video, cfg.d_model, cfg.dout_p, cfg.H,
+                cfg.d_ff_audio, cfg.d_ff_video, cfg.N
+            )
+            # encoder initialization
+            for p in self.encoder.parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+
+        dims_A = [cfg.d_model_audio, *cfg.conv_layers_audio, self.num_logits*cfg.anchors_num_audio]
+        dims_V = [cfg.d_model_video, *cfg.conv_layers_video, self.num_logits*cfg.anchors_num_video]
+        self.detection_layers_A = torch.nn.ModuleList([
+            ProposalGenerationHead(dims_A, k, cfg.dout_p, cfg.layer_norm) for k in cfg.kernel_sizes['audio']
+        ])
+        self.detection_layers_V = torch.nn.ModuleList([
+            ProposalGenerationHead(dims_V, k, cfg.dout_p, cfg.layer_norm) for k in cfg.kernel_sizes['video']
+        ])
+
+        self.bce_loss = nn.BCELoss()
+        self.mse_loss = nn.MSELoss()
+
+    def forward_modality(self, x, targets, detection, stride, anchors_list, _cache=None):
+        return _head_forward(x, targets, detection, stride, anchors_list, self.cfg, {} if _cache is None else _cache)
+
+    def forward(self, x, targets, masks):
+        if self.training:
+            ops.rng_advance()
+        if isinstance(self.emb_V, Identity):
+            V = self.pos_enc_V(x['rgb'], fuse_add=x['flow'])
+            A = self.pos_enc_A(x['audio'])
+        else:
+            V = self.pos_enc_V(self.emb_V(x['rgb'] + x['flow']))
+            A = self.pos_enc_A(self.emb_A(x['audio']))
+        Av, Va = self.encoder((A, V), masks)
+
+        all_predictions_A, all_predictions_V = [], []
+        sum_losses_dict_A, sum_losses_dict_V = {}, {}
+        total_loss_A = 0
+        total_loss_V = 0
+        cache_A, cache_V = {}, {}   # the 10 heads of a modality share one target assignment (same anchors, stride, grid)
+
+        for layer in self.detection_layers_A:
+            props_A, loss_A, losses_A = self.forward_modality(
+                Av, targets, layer, self.cfg.strides['audio'], self.anchors['audio'], cache_A)
+            total_loss_A += loss_A
+            all_predictions_A.append(props_A)
+            sum_losses_dict_A = _add_dict(losses_A, sum_losses_dict_A)
+
+        for layer in self.detection_layers_V:
+            props_V, loss_V, losses_V = self.forward_modality(
+                Va, targets, layer, self.cfg.strides['video'], self.anchors['video'], cache_V)
+            total_loss_V += loss_V
+            all_predictions_V.append(props_V)
+            sum_losses_dict_V = _add_dict(losses_V, sum_losses_dict_V)
+
+        all_predictions_A = torch.cat(all_predictions_A, dim=1)
+        all_predictions_V = torch.cat(all_predictions_V, dim=1)
+        total_loss = total_loss_A + total_loss_V
+        all_predictions = torch.cat([all_predictions_A, all_predictions_V], dim=1)
+
+        return all_predictions, total_loss, sum_losses_dict_A, sum_losses_dict_V

@@ -1,0 +1,520 @@
+"""Host-side operators: thin wrappers over the C ABI plus the ``torch.autograd.Function``s the
+model classes are built from.  PyTorch is plumbing here (device memory, streams, autograd
+graph); every FLOP on the path is issued by libbmt_hip.so.
+
+Precision policy (DESIGN.md "precision"): forward products run split-bf16 (BMT_PREC_BF16X3) so the
+log-probabilities stay within 1e-3 of the fp32 reference; backward products run single-pass bf16.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROP_POST, EPI_DROP_PRE, EPI_GATE, EPI_RELU, EPI_RESIDUAL, PREC_BF16,
+                   PREC_BF16X3, AttnBwdArgs, AttnFwdArgs, Conv1dArgs, GemmArgs)
+
+lib = _lib.load()
+
+# ----------------------------------------------------------------------------- global knobs
+FWD_PRECISION = PREC_BF16X3
+BWD_PRECISION = PREC_BF16
+
+
+def set_precision(fwd: int = PREC_BF16X3, bwd: int = PREC_BF16):
+    global FWD_PRECISION, BWD_PRECISION
+    FWD_PRECISION, BWD_PRECISION = fwd, bwd
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32, CUDA, last dim contiguous 2-D-viewable tensor."""
+    if not t.is_cuda:
+        raise RuntimeError("bmt_amd ops need CUDA/HIP tensors: there is no CPU fallback (use the oracle for CPU checks)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_rng_state = {}
+_site_counter = [0]
+
+
+def rng_tensor(device=None) -> torch.Tensor:
+    """Per-device {seed, step} pair read by every dropout site (device memory => graph-replayable)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _rng_state:
+        _rng_state[key] = torch.tensor([0x5EED, 0], dtype=torch.int64, device=dev)
+    return _rng_state[key]
+
+
+def manual_seed(seed: int, device=None):
+    t = rng_tensor(device)
+    t.copy_(torch.tensor([seed, 0], dtype=torch.int64))
+
+
+def rng_advance():
+    _lib.check(lib.bmt_rng_advance(_p(rng_tensor()), _st()), "bmt_rng_advance")
+
+
+def new_site() -> int:
+    """A fresh dropout call-site id (one per module instance and dropout position)."""
+    _site_counter[0] += 1
+    return _site_counter[0]
+
+
+# ----------------------------------------------------------------------------- raw launches
+def gemm(A, B, C_out, M, N, K, *, lda, ldb, ldc, a_kc=True, b_kc=True, alpha=1.0, bias=None, relu=False,
+         drop_pre=False, drop_post=False, drop_p=0.0, site=0, residual=None, ldr=0, gate=None, ldg=0, gate_scale=1.0,
+         accum=False, splitk=1, precision=None):
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+    if relu:
+        flags |= EPI_RELU
+    use_drop = drop_p > 0.0 and (drop_pre or drop_post)
+    if use_drop and drop_pre:
+        flags |= EPI_DROP_PRE
+    if use_drop and drop_post:
+        flags |= EPI_DROP_POST
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+    if gate is not None:
+        flags |= EPI_GATE
+    if accum:
+        flags |= EPI_ACCUM
+    a = GemmArgs(_p(A), lda, int(a_kc), _p(B), ldb, int(b_kc), _p(C_out), ldc, M, N, K, alpha, flags, _p(bias),
+                 _p(residual), ldr, _p(gate), ldg, gate_scale, drop_p if use_drop else 0.0,
+                 _p(rng_tensor()) if use_drop else None, site, precision or FWD_PRECISION, splitk)
+    _lib.check(lib.bmt_gemm(C.byref(a), _st()), "bmt_gemm")
+
+
+def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
+    """Split the reduction of a weight-gradient GEMM so the launch fills the 256 CUs (2 workgroups each)."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    want = max(1, 512 // tiles)
+    return max(1, min(want, (red + 255) // 256))
+
+
+def linear_fwd(x2: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, **epi):
+    """y[M,N] = epilogue(x2[M,K] @ W[N,K]^T + b)."""
+    M, K = x2.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
+    gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=b, **epi)
+    return out
+
+
+def linear_dx(dy2: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
+    """dx[M,K] = dy2[M,N] @ W[N,K]   (reduction over N; W is read with the reduction index strided)."""
+    M, N = dy2.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty(M, K, device=dy2.device, dtype=torch.float32)
+    gemm(dy2, W, out, M, K, N, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), a_kc=True, b_kc=False,
+         precision=BWD_PRECISION, **epi)
+    return out
+
+
+def linear_dw(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW[N,K] = dy2[M,N]^T @ x2[M,K]   (reduction over M, split-K with atomic accumulation)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    sk = _splitk_for(N, K, M)
+    dW = torch.zeros(N, K, device=dy2.device, dtype=torch.float32) if sk > 1 else \
+        torch.empty(N, K, device=dy2.device, dtype=torch.float32)
+    gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=K, a_kc=False, b_kc=False,
+         accum=sk > 1, splitk=sk, precision=BWD_PRECISION)
+    return dW
+
+
+def colsum(x2: torch.Tensor) -> torch.Tensor:
+    M, N = x2.shape
+    out = torch.empty(N, device=x2.device, dtype=torch.float32)
+    _lib.check(lib.bmt_colsum(_p(x2), x2.stride(0), M, N, _p(out), 0, _st()), "bmt_colsum")
+    return out
+
+
+def _mask_args(mask: Optional[torch.Tensor], B: int, Sq: int, Sk: int):
+    """(tensor kept alive, ptr, batch stride, query stride) for a (B,1,Sk) or (B,Sq,Sk) bool/uint8 mask."""
+    if mask is None:
+        return None, None, 0, 0
+    if mask.dim() == 4:      # (B,1,1,Sk) / (B,1,Sq,Sk) as attention() receives it
+        mask = mask.squeeze(1)
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    elif mask.dtype != torch.uint8:
+        mask = (mask != 0).view(torch.uint8)
+    if mask.dim() != 3 or mask.shape[0] != B or mask.shape[2] != Sk or mask.shape[1] not in (1, Sq):
+        raise RuntimeError(f"attention mask shape {tuple(mask.shape)} does not match (B={B}, 1|Sq={Sq}, Sk={Sk})")
+    if mask.stride(2) != 1:
+        mask = mask.contiguous()
+    qs = 0 if mask.shape[1] == 1 else mask.stride(1)
+    return mask, _p(mask), mask.stride(0), qs
+
+
+def attn_fwd(q, k, v, mask, H, drop_p=0.0, site=0, precision=None):
+    """q:(B,Sq,D) k,v:(B,Sk,D) fp32 contiguous -> o:(B,Sq,D) (post-dropout), lse:(B,H,Sq)."""
+    B, Sq, D = q.shape
+    Sk = k.shape[1]
+    dk = D // H
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, Sq, device=q.device, dtype=torch.float32)
+    keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    use_drop = drop_p > 0.0
+    a = AttnFwdArgs(_p(q), _p(k), _p(v), _p(o), _p(lse), q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+                    q.stride(0), k.stride(0), v.stride(0), o.stride(0), mptr, mbs, mqs, B, H, Sq, Sk, dk,
+                    1.0 / math.sqrt(dk), drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site,
+                    precision or FWD_PRECISION)
+    _lib.check(lib.bmt_attn_fwd(C.byref(a), _st()), "bmt_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, mask, H, drop_p=0.0):
+    B, Sq, D = q.shape
+    Sk = k.shape[1]
+    dk = D // H
+    dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Sq, device=q.device, dtype=torch.float32)
+    keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    a = AttnBwdArgs(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk_), _p(dv), _p(delta),
+                    q.stride(1), k.stride(1), v.stride(1), o.stride(1), q.stride(0), k.stride(0), v.stride(0), o.stride(0),
+                    mptr, mbs, mqs, B, H, Sq, Sk, dk, 1.0 / math.sqrt(dk), drop_p)
+    _lib.check(lib.bmt_attn_bwd(C.byref(a), _st()), "bmt_attn_bwd")
+    return dq, dk_, dv
+
+
+def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
+    y = torch.empty_like(x)
+    _lib.check(lib.bmt_dropout(_p(x), _p(y), x.numel(), p, _p(rng_tensor()), site, _st()), "bmt_dropout")
+    return y
+
+
+# ----------------------------------------------------------------------------- autograd functions
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim (model/blocks.py:127,131)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = _f32c(x)
+        D = xc.shape[-1]
+        x2 = xc.view(-1, D)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(lib.bmt_layernorm_fwd(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), rows, D, eps, _st()),
+                   "bmt_layernorm_fwd")
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        return y.view(xc.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        rows, D = x2.shape
+        dy2 = _f32c(dy).view(rows, D)
+        dx = torch.empty_like(x2)
+        dg = torch.zeros(D, device=x2.device, dtype=torch.float32)
+        db = torch.zeros(D, device=x2.device, dtype=torch.float32)
+        _lib.check(lib.bmt_layernorm_bwd(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, 0, _p(dg), _p(db),
+                                         None, rows, D, _st()), "bmt_layernorm_bwd")
+        return dx.view(dy.shape), dg, db, None
+
+
+class DropoutAddFn(torch.autograd.Function):
+    """x + dropout(sub)   (ResidualConnection.forward model/blocks.py:134-136)."""
+
+    @staticmethod
+    def forward(ctx, x, sub, p, site):
+        xc, sc = _f32c(x), _f32c(sub)
+        out = torch.empty_like(xc)
+        _lib.check(lib.bmt_dropout_add(_p(sc), _p(xc), _p(out), xc.numel(), p, _p(rng_tensor()) if p > 0 else None, site, _st()),
+                   "bmt_dropout_add")
+        ctx.p, ctx.site = p, site
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyc = _f32c(dy)
+        dsub = dropout_raw(dyc, ctx.p, ctx.site) if ctx.p > 0 else dyc
+        return dyc, dsub, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """standalone dropout with the library RNG (nn.Dropout sites that are not fused anywhere)."""
+
+    @staticmethod
+    def forward(ctx, x, p, site):
+        ctx.p, ctx.site = p, site
+        return dropout_raw(_f32c(x), p, site) if p > 0 else x
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dropout_raw(_f32c(dy), ctx.p, ctx.site) if ctx.p > 0 else dy), None, None
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(dropout?(x W^T + b))   act in {none, relu}; dropout before (bridge, blocks.py:151-153) or
+    after (FFN hidden, blocks.py:168-171) the ReLU, fused in the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu, drop_mode, p, site):
+        xc = _f32c(x)
+        K = xc.shape[-1]
+        x2 = xc.view(-1, K)
+        y = linear_fwd(x2, W, b, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"), drop_p=p, site=site)
+        ctx.relu, ctx.drop_mode, ctx.p, ctx.site = relu, drop_mode, p, site
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x2, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
+        return y.view(*xc.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        N = W.shape[0]
+        dy2 = _f32c(dy).view(-1, N)
+        p = ctx.p if ctx.drop_mode != "none" else 0.0
+        if ctx.relu:
+            dz = torch.empty_like(dy2)
+            _lib.check(lib.bmt_gate(_p(dy2), _p(y), 1.0 / (1.0 - p) if p > 0 else 1.0, _p(dz), dy2.numel(), _st()), "bmt_gate")
+        elif p > 0:
+            dz = dropout_raw(dy2, p, ctx.site)
+        else:
+            dz = dy2
+        dx = linear_dx(dz, W).view(*dy.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
+        dW = linear_dw(dz, x2) if ctx.needs_input_grad[1] else None
+        db = colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, None, None, None, None
+
+
+class FFNFn(torch.autograd.Function):
+    """fc2(dropout(relu(fc1(x))))   PositionwiseFeedForward.forward model/blocks.py:167-174.
+    Backward applies the relu/dropout derivative inside the dH GEMM epilogue (gate on the saved hidden)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, p, site):
+        xc = _f32c(x)
+        x2 = xc.view(-1, xc.shape[-1])
+        h = linear_fwd(x2, W1, b1, relu=True, drop_post=True, drop_p=p, site=site)
+        y = linear_fwd(h, W2, b2)
+        ctx.p = p
+        ctx.save_for_backward(x2, W1, W2, h)
+        return y.view(*xc.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W1, W2, h = ctx.saved_tensors
+        dy2 = _f32c(dy).view(-1, W2.shape[0])
+        dW2 = linear_dw(dy2, h)
+        db2 = colsum(dy2)
+        dh = linear_dx(dy2, W2, gate=h, ldg=h.stride(0), gate_scale=1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0)
+        dW1 = linear_dw(dh, x2)
+        db1 = colsum(dh)
+        dx = linear_dx(dh, W1).view(*dy.shape[:-1], W1.shape[1]) if ctx.needs_input_grad[0] else None
+        return dx, dW1, db1, dW2, db2, None, None
+
+
+class MHAFn(torch.autograd.Function):
+    """MultiheadedAttention.forward model/multihead_attention.py:55-86: three input projections, the masked
+    softmax-attention core with dropout on its OUTPUT (:22-23), head merge and output projection."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site):
+        Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
+        B, Sq, Dq = Qc.shape
+        Sk = Kc.shape[1]
+        D = Wq.shape[0]
+        q = linear_fwd(Qc.view(-1, Dq), Wq, bq).view(B, Sq, D)
+        k = linear_fwd(Kc.view(-1, Kc.shape[-1]), Wk, bk).view(B, Sk, D)
+        v = linear_fwd(Vc.view(-1, Vc.shape[-1]), Wv, bv).view(B, Sk, D)
+        o, lse = attn_fwd(q, k, v, mask, H, drop_p=p, site=site)
+        out = linear_fwd(o.view(-1, D), Wo, bo).view(B, Sq, Dq)
+        ctx.H, ctx.p, ctx.site = H, p, site
+        ctx.same_qk = Q is K
+        ctx.same_kv = K is V
+        ctx.mask = mask
+        ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, q, k, v, o, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Qc, Kc, Vc, Wq, Wk, Wv, Wo, q, k, v, o, lse = ctx.saved_tensors
+        B, Sq, Dq = Qc.shape
+        Sk = Kc.shape[1]
+        D = Wq.shape[0]
+        dy2 = _f32c(dout).view(-1, Dq)
+        o2 = o.view(-1, D)
+        dWo = linear_dw(dy2, o2)
+        dbo = colsum(dy2)
+        # gradient w.r.t. the PRE-dropout attention output: the dropout mask is re-applied in the GEMM epilogue
+        do = linear_dx(dy2, Wo, drop_post=True, drop_p=ctx.p, site=ctx.site).view(B, Sq, D)
+        dq, dk, dv = attn_bwd(q, k, v, o, do, lse, ctx.mask, ctx.H, drop_p=ctx.p)
+        dq2, dk2, dv2 = dq.view(-1, D), dk.view(-1, D), dv.view(-1, D)
+        Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
+        dWq, dbq = linear_dw(dq2, Q2), colsum(dq2)
+        dWk, dbk = linear_dw(dk2, K2), colsum(dk2)
+        dWv, dbv = linear_dw(dv2, V2), colsum(dv2)
+        needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dQ = dK = dV = None
+        if ctx.same_qk and ctx.same_kv:          # self-attention: one input, three contributions summed in the epilogue
+            if needQ:
+                acc = linear_dx(dq2, Wq)
+                linear_dx(dk2, Wk, out=acc, residual=acc, ldr=acc.stride(0))
+                linear_dx(dv2, Wv, out=acc, residual=acc, ldr=acc.stride(0))
+                dQ = acc.view(Qc.shape)
+        else:
+            if needQ:
+                dQ = linear_dx(dq2, Wq).view(Qc.shape)
+            if ctx.same_kv:
+                if needK or needV:
+                    acc = linear_dx(dk2, Wk)
+                    linear_dx(dv2, Wv, out=acc, residual=acc, ldr=acc.stride(0))
+                    dK = acc.view(Kc.shape)     # autograd adds dK and dV for the shared tensor; dV stays None
+            else:
+                if needK:
+                    dK = linear_dx(dk2, Wk).view(Kc.shape)
+                if needV:
+                    dV = linear_dx(dv2, Wv).view(Vc.shape)
+        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
+
+
+class GeneratorFn(torch.autograd.Function):
+    """log_softmax(linear(x))   Generator.forward model/generators.py:18-19."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        xc = _f32c(x)
+        x2 = xc.view(-1, xc.shape[-1])
+        V = W.shape[0]
+        logp = linear_fwd(x2, W, b)
+        _lib.check(lib.bmt_log_softmax_fwd(_p(logp), logp.stride(0), logp.shape[0], V, _st()), "bmt_log_softmax_fwd")
+        ctx.save_for_backward(x2, W, logp)
+        return logp.view(*xc.shape[:-1], V)
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        x2, W, logp = ctx.saved_tensors
+        V = W.shape[0]
+        d2 = _f32c(dlogp).view(-1, V)
+        dlogits = torch.empty_like(d2)
+        _lib.check(lib.bmt_log_softmax_bwd(_p(logp), logp.stride(0), _p(d2), d2.stride(0), _p(dlogits), dlogits.stride(0),
+                                           d2.shape[0], V, _st()), "bmt_log_softmax_bwd")
+        dx = linear_dx(dlogits, W).view(*dlogp.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
+        return dx, linear_dw(dlogits, x2), colsum(dlogits)
+
+
+class LabelSmoothingFn(torch.autograd.Function):
+    """LabelSmoothing.forward loss/label_smoothing.py:12-32 (sum-KL incl. the flat-index-0 pad quirk)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, smoothing, pad_idx):
+        V = pred.shape[-1]
+        p2 = _f32c(pred).view(-1, V)
+        t = target.contiguous().view(-1).long()
+        rows = p2.shape[0]
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        ws = torch.empty(rows + 1, device=pred.device, dtype=torch.float32)
+        _lib.check(lib.bmt_ls_kl_fwd(_p(p2), p2.stride(0), _p(t), _p(loss), _p(ws), rows, V, smoothing, pad_idx, _st()),
+                   "bmt_ls_kl_fwd")
+        ctx.save_for_backward(t, ws)
+        ctx.shape, ctx.smoothing, ctx.pad_idx = pred.shape, smoothing, pad_idx
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        t, ws = ctx.saved_tensors
+        V = ctx.shape[-1]
+        rows = t.numel()
+        dpred = torch.empty(rows, V, device=t.device, dtype=torch.float32)
+        gs = _f32c(g).reshape(1)
+        _lib.check(lib.bmt_ls_kl_bwd(_p(t), _p(dpred), V, _p(gs), _p(ws), rows, V, ctx.smoothing, ctx.pad_idx, _st()),
+                   "bmt_ls_kl_bwd")
+        return dpred.view(ctx.shape), None, None, None
+
+
+class PrepFeaturesFn(torch.autograd.Function):
+    """dropout((a [+ b]) + PE)   model/captioning_module.py:165,174-175 + model/blocks.py:101-107."""
+
+    @staticmethod
+    def forward(ctx, a, b, pe, p, site):
+        ac = _f32c(a)
+        bc = None if b is None else _f32c(b)
+        B, S, D = ac.shape
+        out = torch.empty_like(ac)
+        _lib.check(lib.bmt_prep_features(_p(ac), _p(bc), _p(pe), _p(out), B, S, D, p, _p(rng_tensor()) if p > 0 else None, site,
+                                         _st()), "bmt_prep_features")
+        ctx.p, ctx.site, ctx.has_b = p, site, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = dropout_raw(_f32c(dy), ctx.p, ctx.site) if ctx.p > 0 else dy
+        return d, (d if ctx.has_b else None), None, None, None
+
+
+class EmbedFn(torch.autograd.Function):
+    """dropout(W[ids] * sqrt(d) + PE)   model/blocks.py:42-46 + positional encoder."""
+
+    @staticmethod
+    def forward(ctx, ids, W, pe, scale, p, site):
+        idc = ids.contiguous().long()
+        B, S = idc.shape
+        V, D = W.shape
+        out = torch.empty(B, S, D, device=W.device, dtype=torch.float32)
+        _lib.check(lib.bmt_prep_embed(_p(idc), _p(W), _p(pe), _p(out), B, S, D, V, scale, p, _p(rng_tensor()) if p > 0 else None,
+                                      site, _st()), "bmt_prep_embed")
+        ctx.save_for_backward(idc)
+        ctx.meta = (V, D, scale, p, site)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None
+        (idc,) = ctx.saved_tensors
+        V, D, scale, p, site = ctx.meta
+        B, S = idc.shape
+        dW = torch.zeros(V, D, device=dy.device, dtype=torch.float32)
+        dyc = _f32c(dy)
+        _lib.check(lib.bmt_prep_embed_bwd(_p(idc), _p(dyc), _p(dW), B, S, D, V, scale, p, _p(rng_tensor()) if p > 0 else None, site,
+                                          _st()), "bmt_prep_embed_bwd")
+        return None, dW, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- masks (bit-exact, no autograd)
+def mask_from_features(feat: torch.Tensor, pad) -> torch.Tensor:
+    """(feat[:, :, 0] != pad).unsqueeze(1) computed straight from the (B,S,D) stack (no slice copy)."""
+    if feat.dim() == 2:   # already a (B,S) channel-0 slice
+        B, S = feat.shape
+        bs, ld = feat.stride(0), feat.stride(1)
+    else:
+        B, S = feat.shape[0], feat.shape[1]
+        bs, ld = feat.stride(0), feat.stride(1)
+    if feat.dtype != torch.float32:
+        feat = feat.float()
+        bs, ld = feat.stride(0), feat.stride(1)
+    out = torch.empty(B, 1, S, device=feat.device, dtype=torch.uint8)
+    _lib.check(lib.bmt_mask_from_features(_p(feat), bs, ld, float(pad), _p(out), B, S, _st()), "bmt_mask_from_features")
+    return out.view(torch.bool)
+
+
+def mask_from_tokens(trg: torch.Tensor, pad_idx: int, want_src: bool = True, want_trg: bool = True):
+    t = trg.contiguous().long()
+    B, S = t.shape
+    src = torch.empty(B, 1, S, device=t.device, dtype=torch.uint8) if want_src else None
+    tm = torch.empty(B, S, S, device=t.device, dtype=torch.uint8) if want_trg else None
+    _lib.check(lib.bmt_mask_from_tokens(_p(t), int(pad_idx), _p(src), _p(tm), B, S, _st()), "bmt_mask_from_tokens")
+    return (None if src is None else src.view(torch.bool)), (None if tm is None else tm.view(torch.bool))

@@ -1,0 +1,240 @@
+/*
+ * bmt_hip.h -- C ABI of libbmt_hip.so: the MI355X (gfx950) kernels behind the bi-modal
+ * transformer hot path of v-iashin/BMT.
+ *
+ * The reference has no FFI of its own (it is pure PyTorch); the boundary it offers is the
+ * nn.Module surface of model/ and loss/ (SURVEY.md 8b).  Each entry point below replaces the ATen op
+ * sequence of the reference lines it cites; bmt_amd/ops.py binds them with ctypes and
+ * bmt_amd/model/ puts them back behind the reference's class names.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller; the library never allocates,
+ *     frees or retains device memory (workspaces are passed in);
+ *   - tensors are fp32 row-major unless stated; sizes/strides are in ELEMENTS;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), stateless
+ *     and re-entrant; one device per call (the stream's device);
+ *   - return value: 0 = ok, negative = BMT_E*; bmt_last_error() gives a thread-local
+ *     message.  Nothing throws or exits across the ABI.
+ *   - dropout: `rng` points at two device uint64 {seed, step}; a call site is identified by
+ *     `site` (any 32-bit constant); element i of the dropped tensor keeps iff
+ *     hash(seed, step, site, i) >= p.  p == 0 or rng == NULL disables it.  Reading the
+ *     seed/step from device memory keeps captured hipGraphs replayable.
+ */
+#ifndef BMT_HIP_H
+#define BMT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMT_OK 0
+#define BMT_EINVAL (-1)   /* bad argument / unsupported shape */
+#define BMT_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define BMT_EALIGN (-3)   /* pointer or stride alignment requirement violated */
+
+#define BMT_ABI_VERSION 1
+
+int bmt_version(void);
+const char* bmt_last_error(void);
+/* device properties the host side sizes grids/workspaces with: CU count of the stream's device */
+int bmt_device_cus(void);
+
+/* ---------------------------------------------------------------- precision modes */
+#define BMT_PREC_BF16 1    /* one bf16 MFMA pass, fp32 accumulate                      */
+#define BMT_PREC_BF16X3 3  /* split-bf16: hi*hi + hi*lo + lo*hi, ~2^-16 relative error */
+
+/* ---------------------------------------------------------------- GEMM epilogue flags */
+#define BMT_EPI_BIAS 1u        /* + bias[n]                                                    */
+#define BMT_EPI_RELU 2u        /* max(0, .)                                                    */
+#define BMT_EPI_DROP_PRE 4u    /* dropout BEFORE relu  (bridge, proposal heads: blocks.py:152) */
+#define BMT_EPI_DROP_POST 8u   /* dropout AFTER relu   (FFN hidden: blocks.py:170-171)         */
+#define BMT_EPI_RESIDUAL 16u   /* + residual[m, n]     (ResidualConnection: blocks.py:136)     */
+#define BMT_EPI_GATE 32u       /* *= (gate[m,n] != 0 ? gate_scale : 0)  (relu/dropout backward) */
+#define BMT_EPI_ACCUM 64u      /* C += result (atomic; required when splitk > 1)               */
+
+/*
+ * bmt_gemm: C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+ *   A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m]
+ *   B(n,k) = b_kcontig ? B[n*ldb + k] : B[k*ldb + n]
+ * Replaces nn.Linear forward (model/multihead_attention.py:66-68,84; model/blocks.py:151,168,172;
+ * model/generators.py:18) and its two backward products (dX = dY.W, dW = dY^T.X).
+ * Epilogue order: alpha -> +bias -> dropout_pre -> relu -> dropout_post -> gate -> +residual -> store/accumulate.
+ */
+typedef struct {
+    const float* A; int64_t lda; int a_kcontig;
+    const float* B; int64_t ldb; int b_kcontig;
+    float* C; int64_t ldc;
+    int M, N, K;
+    float alpha;
+    unsigned flags;
+    const float* bias;                     /* [N]  (BMT_EPI_BIAS)                    */
+    const float* residual; int64_t ldr;    /* [M,N] (BMT_EPI_RESIDUAL)               */
+    const float* gate; int64_t ldg; float gate_scale; /* (BMT_EPI_GATE)              */
+    float drop_p; const uint64_t* rng; uint32_t site; /* dropout, indexed by m*ldc+n */
+    int precision;                         /* BMT_PREC_*                             */
+    int splitk;                            /* >=1; >1 needs BMT_EPI_ACCUM only       */
+} bmt_gemm_args;
+int bmt_gemm(const bmt_gemm_args* args, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
+int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream);
+
+/*
+ * bmt_attn_fwd: O = dropout( softmax(Q K^T * scale, masked) V )   per (batch, head)
+ * Replaces attention() model/multihead_attention.py:8-26 together with the head split/merge
+ * views of :71-73,82 (heads are addressed in place: head h is columns [h*dk, (h+1)*dk)).
+ *   Q:[B,Sq,*] K,V:[B,Sk,*] O:[B,Sq,*]; row strides ldq/ldk/ldv/ldo, batch strides bsq/...
+ *   mask: uint8/bool, element (b,q,k) at mask[b*mask_bs + q*mask_qs + k]; mask_qs == 0 for a
+ *         key-padding mask (B,1,Sk); NULL = no mask.  mask==0 -> score = -inf (scale applied first).
+ *   lse: [B,H,Sq] log-sum-exp of the scaled, masked scores (saved for backward).
+ *   A fully masked row gives NaN, as the reference does.
+ *   dk in {32, 64, 128, 256}.
+ */
+typedef struct {
+    const float* Q; const float* K; const float* V; float* O; float* lse;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
+    const uint8_t* mask; int64_t mask_bs, mask_qs;
+    int B, H, Sq, Sk, dk;
+    float scale;
+    float drop_p; const uint64_t* rng; uint32_t site; /* dropout on O, indexed b*bso + q*ldo + col */
+    int precision;
+} bmt_attn_fwd_args;
+int bmt_attn_fwd(const bmt_attn_fwd_args* args, void* stream);
+
+/*
+ * bmt_attn_bwd: gradients of the softmax-attention core (bf16 MFMA, probabilities recomputed
+ * from lse).  dO is the gradient w.r.t. the PRE-dropout attention output (the out-projection's
+ * dX epilogue has already applied the dropout mask); O is the saved POST-dropout output and
+ * delta is rebuilt as (1-p) * rowsum(dO*O).   delta_ws: [B,H,Sq] fp32 workspace.
+ */
+typedef struct {
+    const float* Q; const float* K; const float* V; const float* O; const float* dO; const float* lse;
+    float* dQ; float* dK; float* dV; float* delta_ws;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;   /* dO shares O's strides; dQ/dK/dV share Q/K/V's */
+    const uint8_t* mask; int64_t mask_bs, mask_qs;
+    int B, H, Sq, Sk, dk;
+    float scale, drop_p;
+} bmt_attn_bwd_args;
+int bmt_attn_bwd(const bmt_attn_bwd_args* args, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm (model/blocks.py:127,131,143,150) */
+/* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */
+int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                      float* mean, float* rstd, int rows, int D, float eps, void* stream);
+/* dx (+)= LN backward; dgamma/dbeta += column reductions (atomic accumulate into pre-zeroed or live grads).
+ * dx[i] = (accumulate_dx ? dx[i] : 0) + ...   partial_ws: reserved (may be NULL) */
+int bmt_layernorm_bwd_blocks(int rows);
+int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
+                      float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream);
+
+/* ---------------------------------------------------------------- input prep / elementwise (K8) */
+/* out[b,s,:] = dropout( (a[b,s,:] (+ b2[b,s,:])) * in_scale + PE[s,:] )      model/captioning_module.py:165,174-176, blocks.py:101-107
+ * PE is the reference's table (sin on even j, cos on odd j, exponent j/D for both), passed in as fp32 [>=S, D]. */
+int bmt_prep_features(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D,
+                      float drop_p, const uint64_t* rng, uint32_t site, void* stream);
+/* out[b,s,:] = dropout( W[ids[b,s],:] * emb_scale + PE[s,:] )                model/blocks.py:42-46 + pos enc */
+int bmt_prep_embed(const int64_t* ids, const float* W, const float* pe, float* out, int B, int S, int D, int V,
+                   float emb_scale, float drop_p, const uint64_t* rng, uint32_t site, void* stream);
+/* dW[ids[b,s],:] += dout[b,s,:] * keep(b,s,:) * emb_scale   (trainable-embedding path) */
+int bmt_prep_embed_bwd(const int64_t* ids, const float* dout, float* dW, int B, int S, int D, int V,
+                       float emb_scale, float drop_p, const uint64_t* rng, uint32_t site, void* stream);
+/* masks, bit-exact: model/masking.py:14-21 + epoch_loops/captioning_epoch_loops.py:105-112
+ *   src_mask[b,0,s] = feat[b,s,0] != pad  (feat row stride ld, batch stride bs)
+ *   trg_mask[b,i,j] = (trg[b,j] != pad_idx) & (j <= i)                                   */
+int bmt_mask_from_features(const float* feat, int64_t bs, int64_t ld, float pad, uint8_t* out, int B, int S, void* stream);
+int bmt_mask_from_tokens(const int64_t* trg, int64_t pad_idx, uint8_t* src_mask, uint8_t* trg_mask, int B, int S, void* stream);
+/* y = dropout(x) and its mask re-application dy*keep/(1-p) (standalone nn.Dropout sites, residual backward) */
+int bmt_dropout(const float* x, float* y, int64_t n, float drop_p, const uint64_t* rng, uint32_t site, void* stream);
+/* out = dy * (y != 0 ? scale : 0): backward of relu/dropout fused epilogues, read off the saved output y */
+int bmt_gate(const float* dy, const float* y, float scale, float* out, int64_t n, void* stream);
+/* out = res + dropout(x)   (ResidualConnection.forward model/blocks.py:134-136) */
+int bmt_dropout_add(const float* x, const float* res, float* out, int64_t n, float drop_p, const uint64_t* rng,
+                    uint32_t site, void* stream);
+/* out = a + b (n elements) ; out may alias a */
+int bmt_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* rng[1] += 1 (advance the dropout step counter on device; graph-capturable) */
+int bmt_rng_advance(uint64_t* rng, void* stream);
+/* out[i0][i1][i2] (contiguous) (+)= in[i0*s0 + i1*s1 + i2*s2]  -- Conv1d weight re-layout
+ * ([Dout][Din][k] state_dict layout <-> the tap-major layouts bmt_conv1d consumes) */
+int bmt_copy3d(const float* in, int64_t s0, int64_t s1, int64_t s2, float* out, int n0, int n1, int n2, int accumulate,
+               void* stream);
+
+/* ---------------------------------------------------------------- generator + loss (K7) */
+/* in-place row log_softmax over V: model/generators.py:19 */
+int bmt_log_softmax_fwd(float* x, int64_t ldx, int rows, int V, void* stream);
+/* dlogits = dlogp - exp(logp) * rowsum(dlogp)   (dlogp may alias dlogits) */
+int bmt_log_softmax_bwd(const float* logp, int64_t ldp, const float* dlogp, int64_t ldd, float* dlogits, int64_t ldo,
+                        int rows, int V, void* stream);
+/* LabelSmoothing.forward loss/label_smoothing.py:12-32: sum-KL between the smoothed target
+ * distribution and pred (log-probs), incl. the quirk that pad rows are zeroed only when the
+ * SUM of their flat row indices is > 0.   loss: 1 float (overwritten).  row_ws: >= rows + 1 floats. */
+int bmt_ls_kl_fwd(const float* pred, int64_t ldp, const int64_t* target, float* loss, float* row_ws,
+                  int rows, int V, float smoothing, int64_t pad_idx, void* stream);
+/* dpred = -dist * (*gscale_dev)  (gscale_dev: device scalar = upstream grad; row_ws: the workspace the forward
+ * filled -- its trailing int carries the pad-row decision) */
+int bmt_ls_kl_bwd(const int64_t* target, float* dpred, int64_t ldp, const float* gscale_dev, const float* row_ws,
+                  int rows, int V, float smoothing, int64_t pad_idx, void* stream);
+
+/* ---------------------------------------------------------------- optimizer (K11) */
+/* torch.optim.Adam semantics (scripts/train_captioning_module.py:46-48) over n_tensors tensors.
+ * ptrs: device array of 4*n_tensors pointers laid out [p_0..][g_0..][m_0..][v_0..]; sizes: device int64[n].
+ * step_dev: device int64 step counter, incremented by the kernel launch itself (graph-replayable).
+ * grad_scale_dev: optional device float multiplied into every gradient (e.g. clip coefficient or 1/world); NULL = 1. */
+int bmt_adam_step(void* const* ptrs, const int64_t* sizes, int n_tensors, int64_t max_size, int64_t* step_dev,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  const float* grad_scale_dev, void* stream);
+/* sum of squares of n_tensors tensors -> out[0] (overwritten); clip coefficient helper:
+ * coef[0] = min(1, max_norm / (sqrt(out[0]) + 1e-6))   (torch.nn.utils.clip_grad_norm_) */
+int bmt_grad_sqnorm(void* const* ptrs, const int64_t* sizes, int n_tensors, int64_t max_size, float* out,
+                    float max_norm, float* coef, void* stream);
+
+/* every element of every tensor *= coef_dev[0] (the in-place scaling step of clip_grad_norm_) */
+int bmt_scale_tensors(void* const* ptrs, const int64_t* sizes, int n_tensors, int64_t max_size, const float* coef_dev,
+                      void* stream);
+
+/* ---------------------------------------------------------------- proposal generator (K9, K10) */
+/*
+ * Conv1d(D_in -> D_out, kernel k, padding k/2) over time as an implicit GEMM on (B,S,D_in) activations
+ * (model/proposal_generator.py:29,41-45; the permutes at :41,45 vanish because the GEMM reads (B,S,D) directly).
+ *   W: the Conv1d weight [D_out, D_in, k] as stored in the state_dict.
+ *   y[b,s,o] = epilogue( sum_{c,t} x[b, s+t-k/2, c] * W[o,c,t] + bias[o] ), zero outside [0,S).
+ *   mode 0: forward.  mode 1: dx[b,s,c] = sum_{o,t} dy[b, s-t+k/2, o] * W[o,c,t].
+ *   mode 2: dW[o,c,t] += sum_{b,s} dy[b,s,o] * x[b, s+t-k/2, c]   (atomic accumulate, split over (b,s)).
+ */
+typedef struct {
+    const float* x; const float* W; const float* bias; float* y;   /* roles per mode, see above */
+    int B, S, Din, Dout, k;
+    int mode;
+    unsigned flags; float drop_p; const uint64_t* rng; uint32_t site;
+    const float* gate; float gate_scale;
+    int precision; int splitk;
+} bmt_conv1d_args;
+int bmt_conv1d(const bmt_conv1d_args* args, void* stream);
+
+/* make_targets model/proposal_generator.py:389-448 (bit-exact masks / targets):
+ * targets [n,4] f32 (batch idx, center s, length s, meta); anchors [A] already divided by stride.
+ * obj/noobj: uint8 [B,A,G] (caller pre-fills obj=0, noobj=1, tx=tw=0 via bmt_targets_init);
+ * duplicates of one (b,a,cell) resolve in target order, last write wins (CPU index_put order). */
+int bmt_targets_init(uint8_t* obj, uint8_t* noobj, float* tx, float* tw, int64_t n, void* stream);
+int bmt_make_targets(const float* targets, int n, const float* anchors, int A, int B, int G, float stride,
+                     uint8_t* obj, uint8_t* noobj, float* tx, float* tw, void* stream);
+/* decode + YOLO loss for one head (model/proposal_generator.py:281-335).
+ * x: head output [B,S,A*3]; preds: [B, A*S, 3] written as (center_s, length_s, conf);
+ * loss_ws: 8 floats {sum_x, sum_w, sum_bce_obj, sum_bce_noobj, n_obj, n_noobj, -, -} (overwritten);
+ * with targets==NULL semantics (obj == NULL) only preds are produced. */
+int bmt_prop_decode_loss(const float* x, const float* anchors, int B, int S, int A, float stride,
+                         const uint8_t* obj, const uint8_t* noobj, const float* tx, const float* tw,
+                         float* preds, float* loss_ws, void* stream);
+/* losses[0..3] = {mse_x, mse_w, bce_obj, bce_noobj} (means), losses[4] = total with coefficients */
+int bmt_prop_loss_finalize(const float* loss_ws, float obj_coeff, float noobj_coeff, float* losses, void* stream);
+/* dx[B,S,A*3] = d total / d x * (*gscale_dev) */
+int bmt_prop_loss_bwd(const float* x, int B, int S, int A, const uint8_t* obj, const uint8_t* noobj,
+                      const float* tx, const float* tw, const float* loss_ws, float obj_coeff, float noobj_coeff,
+                      const float* gscale_dev, float* dx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMT_HIP_H */

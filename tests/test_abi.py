@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bmt_hip.h declares (no compute calls)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bmt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bmt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for need in ("bmt_gemm", "bmt_attn_fwd", "bmt_attn_bwd", "bmt_layernorm_fwd", "bmt_layernorm_bwd", "bmt_ls_kl_fwd",
+                 "bmt_adam_step", "bmt_conv1d", "bmt_make_targets", "bmt_last_error", "bmt_version"):
+        assert need in syms
+
+
+def test_library_loads_and_exports_everything():
+    from bmt_amd import _lib
+    lib = _lib.load()
+    assert lib.bmt_version() == 1
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/bmt_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in bmt_amd/_lib.py"
+    for s in _lib.SIGNATURES:
+        assert s in declared_symbols(), f"{s} bound in _lib.py but not declared in the header"
+
+
+def test_errors_are_reported_not_thrown():
+    """argument validation happens before any device work, so it is testable without a GPU."""
+    import ctypes as C
+    from bmt_amd import _lib
+    lib = _lib.load()
+    a = _lib.GemmArgs()
+    rc = lib.bmt_gemm(C.byref(a), None)
+    assert rc == -1 and b"null pointer" in lib.bmt_last_error()
+    rc = lib.bmt_log_softmax_fwd(None, 0, 1, 1, None)
+    assert rc == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from bmt_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libbmt_hip.so")
+    with pytest.raises(ImportError, match="no CPU / eager fallback"):
+        _lib.load()

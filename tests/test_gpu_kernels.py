@@ -1,0 +1,302 @@
+"""-m gpu: kernel-level parity of libbmt_hip.so (through the C ABI) against the CPU oracle.
+
+bf16 single-pass products are checked against the oracle evaluated on bf16-ROUNDED operands in
+fp64 (so only accumulation order differs: tight tolerance that still exposes any tile / lane
+mapping mistake); split-bf16 (x3) products are checked against plain fp64 at ~1e-5 relative."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, bf16_round, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bmt_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 128, 64), (130, 70, 100), (257, 300, 1024), (64, 10, 24), (1, 1, 1), (300, 1200, 300), (96, 40, 7)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("prec", [1, 3])
+def test_gemm_linear_forward(ops, M, N, K, prec):
+    x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), precision=prec)
+    if prec == 1:
+        want = bf16_round(x).double() @ bf16_round(W).double().t() + b.double()
+        assert_close(y, want, atol=2e-4 * math.sqrt(K), rtol=1e-4, name=f"linear x1 {M}x{N}x{K}")
+    else:
+        want = x.double() @ W.double().t() + b.double()
+        assert_close(y, want, atol=3e-5 * math.sqrt(K), rtol=2e-5, name=f"linear x3 {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 70, 100), (256, 128, 512), (33, 300, 1000)])
+def test_gemm_dx_dw_layouts(ops, M, N, K):
+    """dX = dY.W (B operand reduction-strided) and dW = dY^T.X (both operands reduction-strided, split-K atomics)."""
+    dy, W, x = rnd(M, N, seed=4), rnd(N, K, seed=5), rnd(M, K, seed=6)
+    dx = ops.linear_dx(dy.to(DEV), W.to(DEV))
+    want = bf16_round(dy).double() @ bf16_round(W).double()
+    assert_close(dx, want, atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx")
+    dW = ops.linear_dw(dy.to(DEV), x.to(DEV))
+    want = bf16_round(dy).double().t() @ bf16_round(x).double()
+    assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name="dw")
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 150, 90, 64
+    x, W, b, res = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9), rnd(M, N, seed=10)
+    xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV)
+    base = x.double() @ W.double().t() + b.double()
+    y = ops.linear_fwd(xd, Wd, bd, relu=True, precision=3)
+    assert_close(y, base.clamp(min=0), atol=3e-4, name="relu")
+    y = ops.linear_fwd(xd, Wd, bd, residual=rd, ldr=N, precision=3)
+    assert_close(y, base + res.double(), atol=3e-4, name="residual")
+    gate = (rnd(M, N, seed=11) > 0).float()
+    y = ops.linear_fwd(xd, Wd, None, gate=gate.to(DEV), ldg=N, gate_scale=1.25, precision=3)
+    assert_close(y, (x.double() @ W.double().t()) * gate.double() * 1.25, atol=3e-4, name="gate")
+    # in-place accumulate through the residual pointer (C aliases residual)
+    acc = rd.clone()
+    ops.linear_fwd(xd, Wd, None, out=acc, residual=acc, ldr=N, precision=3)
+    assert_close(acc, res.double() + x.double() @ W.double().t(), atol=3e-4, name="residual-alias")
+    cs = ops.colsum(rd)
+    assert_close(cs, res.double().sum(0), atol=1e-4, name="colsum")
+
+
+def test_gemm_dropout_epilogue_matches_standalone(ops):
+    """the fused dropout epilogue and bmt_dropout share one RNG: same site => same mask."""
+    M, N, K, p, site = 200, 96, 32, 0.3, 4242
+    ops.manual_seed(123)
+    x, W = rnd(M, K, seed=12).to(DEV), rnd(N, K, seed=13).to(DEV)
+    plain = ops.linear_fwd(x, W, None, precision=3)
+    fused = ops.linear_fwd(x, W, None, drop_post=True, drop_p=p, site=site, precision=3)
+    sep = ops.dropout_raw(plain, p, site)
+    assert torch.equal(fused, sep)
+    keep = (fused != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02, keep
+    kept = fused != 0
+    assert_close(fused[kept], plain[kept] / (1 - p), atol=1e-5, rtol=1e-5, name="scale")
+    # another site / another step -> another mask
+    other = ops.dropout_raw(plain, p, site + 1)
+    assert not torch.equal(other, sep)
+    ops.rng_advance()
+    assert not torch.equal(ops.dropout_raw(plain, p, site), sep)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _oracle_attention(q, k, v, mask, H, rounded):
+    from oracle import bmt_oracle as orc
+    B, Sq, D = q.shape
+    dk = D // H
+    f = (lambda t: bf16_round(t).double()) if rounded else (lambda t: t.double())
+    qh = f(q).view(B, Sq, H, dk).transpose(1, 2)
+    kh = f(k).view(B, -1, H, dk).transpose(1, 2)
+    vh = f(v).view(B, -1, H, dk).transpose(1, 2)
+    m = None if mask is None else mask.unsqueeze(1)
+    o = orc.attention(qh, kh, vh, m)
+    return o.transpose(1, 2).reshape(B, Sq, D)
+
+
+def _masks(kind, B, Sq, Sk):
+    if kind == "none":
+        return None
+    if kind == "pad":
+        m = torch.ones(B, 1, Sk, dtype=torch.bool)
+        for b in range(B):
+            m[b, 0, max(1, Sk - 3 - 7 * b):] = False
+        return m
+    if kind == "causal":
+        assert Sq == Sk
+        m = torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)).unsqueeze(0).repeat(B, 1, 1)
+        m[0, :, Sk - 2:] = False
+        return m
+    raise ValueError(kind)
+
+
+ATTN_CASES = [  # dk, H, B, Sq, Sk, mask
+    (32, 4, 2, 7, 11, "pad"), (32, 4, 2, 7, 7, "causal"), (32, 2, 1, 130, 200, "pad"), (64, 2, 2, 50, 77, "none"),
+    (128, 2, 2, 33, 130, "pad"), (256, 2, 1, 40, 70, "pad"), (256, 1, 2, 30, 30, "causal"), (256, 4, 1, 129, 64, "none"),
+]
+
+
+@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES)
+@pytest.mark.parametrize("prec", [1, 3])
+def test_attention_forward(ops, dk, H, B, Sq, Sk, kind, prec):
+    D = dk * H
+    q, k, v = rnd(B, Sq, D, seed=20), rnd(B, Sk, D, seed=21), rnd(B, Sk, D, seed=22)
+    mask = _masks(kind, B, Sq, Sk)
+    o, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), None if mask is None else mask.to(DEV), H, precision=prec)
+    want = _oracle_attention(q, k, v, mask, H, rounded=(prec == 1))
+    # x1: P is rounded to bf16 inside the kernel as well -> 2^-9 relative on O
+    assert_close(o, want, atol=(2e-2 if prec == 1 else 2e-4), rtol=0, name=f"attn o dk={dk} {kind} x{prec}")
+    # lse against a direct evaluation
+    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
+    s = torch.einsum("bqhd,bkhd->bhqk", f(q).view(B, Sq, H, dk), f(k).view(B, Sk, H, dk)) / math.sqrt(dk)
+    if mask is not None:
+        s = s.masked_fill(~mask.unsqueeze(1), -float("inf"))
+    assert_close(lse, torch.logsumexp(s, -1), atol=2e-3 if prec == 1 else 2e-4, name="lse")
+
+
+def test_attention_fully_masked_row_is_nan(ops):
+    q, k, v = rnd(1, 4, 64, seed=1), rnd(1, 6, 64, seed=2), rnd(1, 6, 64, seed=3)
+    mask = torch.ones(1, 4, 6, dtype=torch.bool)
+    mask[0, 2, :] = False
+    o, _ = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), 2)
+    assert torch.isnan(o[0, 2]).all() and not torch.isnan(o[0, [0, 1, 3]]).any()
+
+
+@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES)
+def test_attention_backward(ops, dk, H, B, Sq, Sk, kind):
+    D = dk * H
+    q, k, v = rnd(B, Sq, D, seed=30), rnd(B, Sk, D, seed=31), rnd(B, Sk, D, seed=32)
+    do = rnd(B, Sq, D, seed=33)
+    mask = _masks(kind, B, Sq, Sk)
+    md = None if mask is None else mask.to(DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = ops.attn_fwd(qd, kd, vd, md, H, precision=3)
+    dq, dk_, dv = ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, md, H)
+    qr, kr, vr = (t.clone().double().requires_grad_() for t in (q, k, v))
+    want = _oracle_attention(qr, kr, vr, mask, H, rounded=False)
+    (want * do.double()).sum().backward()
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk_, kr.grad), ("dv", dv, vr.grad)):
+        e = rel_err(got, ref)
+        assert e < 2e-2, f"{name} dk={dk} {kind}: relative error {e:.3e}\n" + __import__("tests.gpu_util", fromlist=["report"]).report(got, ref, name)
+
+
+def test_attention_dropout_roundtrip(ops):
+    """dropout on the attention OUTPUT: forward mask == the mask bmt_gemm re-applies in backward; delta uses (1-p)."""
+    B, H, Sq, Sk, dk, p, site = 2, 2, 40, 50, 64, 0.25, 77
+    D = H * dk
+    ops.manual_seed(5)
+    q, k, v = rnd(B, Sq, D, seed=40).to(DEV), rnd(B, Sk, D, seed=41).to(DEV), rnd(B, Sk, D, seed=42).to(DEV)
+    o0, _ = ops.attn_fwd(q, k, v, None, H, precision=3)
+    od, lse = ops.attn_fwd(q, k, v, None, H, drop_p=p, site=site, precision=3)
+    assert torch.equal(od, ops.dropout_raw(o0, p, site))
+    # backward with dropout == backward without dropout fed the masked upstream gradient
+    g = rnd(B, Sq, D, seed=43).to(DEV)
+    gm = ops.dropout_raw(g, p, site)
+    a = ops.attn_bwd(q, k, v, od, gm, lse, None, H, drop_p=p)
+    b = ops.attn_bwd(q, k, v, o0, gm, lse, None, H, drop_p=0.0)
+    for x, y, n in zip(a, b, ("dq", "dk", "dv")):
+        assert rel_err(x, y) < 1e-5, n
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,D", [(37, 128), (9, 300), (5, 600), (130, 1024), (3, 30), (50, 20)])
+def test_layernorm(ops, rows, D):
+    from oracle import bmt_oracle as orc
+    x = rnd(rows, D, seed=50) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd(D, seed=51), 0.1 * rnd(D, seed=52)
+    xd = x.to(DEV).requires_grad_()
+    gd, bd = g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.LayerNormFn.apply(xd, gd, bd, 1e-5)
+    xr, gr, br = (t.clone().double().requires_grad_() for t in (x, g, b))
+    want = orc.layer_norm(xr, gr, br)
+    assert_close(y, want, atol=2e-5, name="ln fwd")
+    w = rnd(rows, D, seed=53)
+    (y * w.to(DEV)).sum().backward()
+    (want * w.double()).sum().backward()
+    assert_close(xd.grad, xr.grad, atol=5e-5, rtol=1e-4, name="ln dx")
+    assert_close(gd.grad, gr.grad, atol=2e-4, rtol=1e-4, name="ln dgamma")
+    assert_close(bd.grad, br.grad, atol=2e-4, rtol=1e-4, name="ln dbeta")
+
+
+# ------------------------------------------------------------------------------------------ prep / masks / loss / adam
+def test_masks_bit_exact(ops, golden):
+    from bmt_amd.model.masking import mask, subsequent_mask
+    g = golden("masks_loss.npz")
+    rgb, audio, caps = g["mk/rgb"].to(DEV), g["mk/audio"].to(DEV), g["mk/caps"].to(DEV)
+    V_mask, C_mask = mask(rgb[:, :, 0], caps[:, :-1], 1)
+    A_mask = mask(audio[:, :, 0], None, 1)
+    for got, key in ((V_mask, "mk/V_mask"), (A_mask, "mk/A_mask"), (C_mask, "mk/C_mask")):
+        assert got.dtype == torch.bool and torch.equal(got.cpu(), g[key]), key
+    assert torch.equal(subsequent_mask(5), g["mk/subsequent5"])
+
+
+def test_prep_and_embed(ops, golden):
+    from bmt_amd.model.blocks import PositionalEncoder, VocabularyEmbedder
+    g = golden("modules_tiny.npz")
+    for d in (20, 128, 300, 1024):
+        pe = PositionalEncoder(d, 0.0).eval()
+        assert np.array_equal(pe.pos_enc_mat[0, :9].numpy(), g.np(f"pe/{d}/head"))
+        y = pe(g[f"pe/{d}/x"].to(DEV))
+        assert_close(y, g[f"pe/{d}/y"], atol=1e-6, name=f"pe {d}")
+    pe = PositionalEncoder(128, 0.0).eval()
+    a, b = rnd(2, 5, 128, seed=60), rnd(2, 5, 128, seed=61)
+    from oracle import bmt_oracle as orc
+    assert_close(pe(a.to(DEV), fuse_add=b.to(DEV)), orc.positional_encoder(a + b), atol=1e-6, name="fused add")
+    ve = VocabularyEmbedder(11, 20)
+    with torch.no_grad():
+        ve.embedder.weight.copy_(g["vemb/weight"])
+    ve = ve.to(DEV)
+    assert_close(ve(g["vemb/ids"].to(DEV)), g["vemb/out"], atol=1e-6, name="vocab embed")
+
+
+@pytest.mark.parametrize("tag,s", [("a", 0.7), ("a", 0.0), ("idx0", 0.7), ("nopad", 0.7), ("big", 0.7)])
+def test_label_smoothing_golden(ops, golden, tag, s):
+    from bmt_amd.loss.label_smoothing import LabelSmoothing
+    g = golden("masks_loss.npz")
+    key = f"ls/{tag}/s{s}"
+    pred = g[key + "/pred"].to(DEV).requires_grad_()
+    loss = LabelSmoothing(s, 1)(pred, g[key + "/target"].to(DEV))
+    assert_close(loss, g[key + "/loss"], atol=2e-4, rtol=2e-5, name="ls loss")
+    (loss * 0.5).backward()
+    assert_close(pred.grad, g[key + "/dpred"] * 0.5, atol=1e-7, rtol=1e-6, name="ls dpred")
+
+
+def test_generator_log_softmax(ops, golden):
+    from bmt_amd.model.generators import Generator
+    g = golden("modules_tiny.npz")
+    gen = Generator(20, 11)
+    gen.load_state_dict(g.sub("gen/sd/"))
+    gen = gen.to(DEV)
+    x = g["gen/X"].to(DEV).requires_grad_()
+    out = gen(x)
+    assert_close(out, g["gen/out"], atol=1e-5, name="generator")
+    # backward vs the oracle
+    from oracle import bmt_oracle as orc
+    p = {k: v.clone().double().requires_grad_() for k, v in g.sub("gen/sd/").items()}
+    xr = g["gen/X"].clone().double().requires_grad_()
+    w = rnd(*out.shape, seed=70)
+    (orc.generator(p, "", xr) * w.double()).sum().backward()
+    (out * w.to(DEV)).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 2e-2
+    assert rel_err(gen.linear.weight.grad, p["linear.weight"].grad) < 2e-2
+    assert rel_err(gen.linear.bias.grad, p["linear.bias"].grad) < 1e-4
+
+
+def test_adam_golden(golden):
+    from bmt_amd.optim import FusedAdam
+    g = golden("adam.npz")
+    p = torch.nn.Parameter(g["p0"].to(DEV))
+    opt = FusedAdam([p], lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    for step in range(1, 4):
+        p.grad = g[f"g{step}"].to(DEV)
+        opt.step()
+        assert_close(p.data, g[f"p{step}"], atol=1e-7, rtol=1e-6, name=f"adam step {step}")
+
+
+def test_clip_grad_norm(ops):
+    from bmt_amd.optim import clip_grad_norm_
+    ps = [torch.nn.Parameter(rnd(300, seed=80).to(DEV)), torch.nn.Parameter(rnd(40, 50, seed=81).to(DEV))]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    for p, r, s in zip(ps, ref, (82, 83)):
+        gsrc = rnd(*p.shape, seed=s)
+        p.grad, r.grad = gsrc.to(DEV), gsrc.clone()
+    n_ref = torch.nn.utils.clip_grad_norm_(ref, 0.5)
+    n = clip_grad_norm_(ps, 0.5)
+    assert abs(float(n) - float(n_ref)) < 1e-3 * float(n_ref)
+    for p, r in zip(ps, ref):
+        assert_close(p.grad, r.grad, atol=1e-6, rtol=1e-5, name="clipped grad")

@@ -1,0 +1,256 @@
+"""-m gpu: module- and model-level parity of bmt_amd.model / bmt_amd.loss (HIP kernels behind the reference's class
+surface) against the golden vectors captured from the imported reference, and against the CPU oracle.
+
+Tolerances: masks / indices bit-exact; log-probabilities <= 1e-3 abs (BASELINE.json north_star) -- with the
+split-bf16 forward they land around 1e-4; gradients (single-pass bf16 backward) <= 3e-2 relative per tensor."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from bmt_amd import synthetic as syn
+from tests.gpu_util import assert_close, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOGP_TOL = 1e-3
+GRAD_REL = 3e-2
+
+
+def _load(module, sd):
+    module.load_state_dict(sd)
+    return module.to(DEV)
+
+
+def _check_grads(named_params, ref_grads, tol=GRAD_REL, floor=1e-6):
+    bad = []
+    for k, p in named_params:
+        if k not in ref_grads:
+            continue
+        assert p.grad is not None, f"missing grad for {k}"
+        ref = ref_grads[k]
+        e = float((p.grad.detach().cpu().double() - ref.double()).norm())
+        n = float(ref.double().norm())
+        if e > tol * n + floor:
+            bad.append(f"{k}: |err|={e:.3e} |ref|={n:.3e}\n" + report(p.grad, ref, k))
+    assert not bad, "\n".join(bad)
+
+
+def test_mha_cross_modal(golden):
+    from bmt_amd.model.multihead_attention import MultiheadedAttention
+    g = golden("modules_tiny.npz")
+    mha = _load(MultiheadedAttention(20, 24, 24, 4, 0.0, 128), g.sub("mha/sd/")).eval()
+    Q, K = g["mha/Q"].to(DEV).requires_grad_(), g["mha/K"].to(DEV).requires_grad_()
+    out = mha(Q, K, K, g["mha/mask"].to(DEV))
+    assert_close(out, g["mha/out"], atol=2e-4, name="mha out")
+    (out * g["mha/w"].to(DEV)).sum().backward()
+    assert rel_err(Q.grad, g["mha/dQ"]) < GRAD_REL, report(Q.grad, g["mha/dQ"], "dQ")
+    assert rel_err(K.grad, g["mha/dK"]) < GRAD_REL, report(K.grad, g["mha/dK"], "dK")
+    _check_grads(mha.named_parameters(), g.sub("mha/grad/"))
+
+
+def test_mha_causal_self_attention(golden):
+    from bmt_amd.model.multihead_attention import MultiheadedAttention
+    g = golden("modules_tiny.npz")
+    sa = _load(MultiheadedAttention(20, 20, 20, 4, 0.0, 128), g.sub("sa/sd/")).eval()
+    X = g["sa/X"].to(DEV).requires_grad_()
+    out = sa(X, X, X, g["sa/mask"].to(DEV))
+    assert_close(out, g["sa/out"], atol=2e-4, name="sa out")
+    (out * g["sa/w"].to(DEV)).sum().backward()
+    assert rel_err(X.grad, g["sa/dX"]) < GRAD_REL, report(X.grad, g["sa/dX"], "dX")
+    _check_grads(sa.named_parameters(), g.sub("sa/grad/"))
+
+
+def test_attention_function_surface(golden):
+    """model.multihead_attention.attention(Q,K,V,mask,dropout) on (B,H,S,d_k) views."""
+    from bmt_amd.model.multihead_attention import attention
+    from oracle import bmt_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    Q, K, V = (torch.randn(2, 4, s, 32, generator=g) for s in (9, 13, 13))
+    mask = torch.ones(2, 1, 1, 13, dtype=torch.bool)
+    mask[1, 0, 0, 9:] = False
+    out = attention(Q.to(DEV), K.to(DEV), V.to(DEV), mask.to(DEV))
+    assert_close(out, orc.attention(Q.double(), K.double(), V.double(), mask), atol=2e-4, name="attention()")
+
+
+def test_residual_ffn(golden):
+    from bmt_amd.model.blocks import PositionwiseFeedForward, ResidualConnection
+    g = golden("modules_tiny.npz")
+    sd = g.sub("resffn/sd/")
+    res = _load(ResidualConnection(20, 0.0), {k[4:]: v for k, v in sd.items() if k.startswith("res.")}).eval()
+    ffn = _load(PositionwiseFeedForward(20, 80, 0.0), {k[4:]: v for k, v in sd.items() if k.startswith("ffn.")}).eval()
+    X = g["resffn/X"].to(DEV).requires_grad_()
+    out = res(X, ffn)
+    assert_close(out, g["resffn/out"], atol=2e-4, name="res+ffn out")
+    (out * g["resffn/w"].to(DEV)).sum().backward()
+    assert rel_err(X.grad, g["resffn/dX"]) < GRAD_REL
+    gr = g.sub("resffn/grad/")
+    _check_grads([("res." + k, p) for k, p in res.named_parameters()] + [("ffn." + k, p) for k, p in ffn.named_parameters()], gr)
+
+
+def test_bridge(golden):
+    from bmt_amd.model.blocks import BridgeConnection
+    g = golden("modules_tiny.npz")
+    br = _load(BridgeConnection(40, 20, 0.0), g.sub("bridge/sd/")).eval()
+    X = g["bridge/X"].to(DEV).requires_grad_()
+    out = br(X)
+    assert_close(out, g["bridge/out"], atol=2e-4, name="bridge out")
+    (out * g["bridge/w"].to(DEV)).sum().backward()
+    assert rel_err(X.grad, g["bridge/dX"]) < GRAD_REL
+    _check_grads(br.named_parameters(), g.sub("bridge/grad/"))
+
+
+def _build(cfg, V, use_glove, sd=None):
+    from bmt_amd.model.captioning_module import BiModalTransformer
+    cfg.device = DEV
+    torch.manual_seed(0)
+    glove = syn.make_glove(V, cfg.d_model_caps) if use_glove else None
+    model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, glove))
+    if sd is not None:
+        model.load_state_dict(sd)
+    return model.to(DEV)
+
+
+def _run_cap(model, cfg, fs, caps, train=False):
+    from bmt_amd.loss.label_smoothing import LabelSmoothing
+    from bmt_amd.model.masking import mask
+    fs = {k: v.to(DEV) for k, v in fs.items()}
+    caps = caps.to(DEV)
+    x, y = caps[:, :-1], caps[:, 1:]
+    masks = {}
+    masks["V_mask"], masks["C_mask"] = mask(fs["rgb"][:, :, 0], x, syn.PAD_IDX)
+    masks["A_mask"] = mask(fs["audio"][:, :, 0], None, syn.PAD_IDX)
+    model.train(train)
+    pred = model(fs, x, masks)
+    n_tokens = (y != syn.PAD_IDX).sum()
+    loss = LabelSmoothing(cfg.smoothing, syn.PAD_IDX)(pred, y) / n_tokens
+    return pred, loss, masks
+
+
+@pytest.mark.parametrize("name", ["tiny_cap.npz", "tiny_cap_trainemb.npz"])
+def test_tiny_captioning_model(golden, name):
+    g = golden(name)
+    cfg = syn.cfg_tiny()
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    model = _build(cfg, V, bool(use_glove), g.sub("sd/"))
+    pred, loss, masks = _run_cap(model, cfg, {"rgb": g["rgb"], "flow": g["flow"], "audio": g["audio"]}, g["captions"])
+    for k in ("V_mask", "A_mask", "C_mask"):
+        assert torch.equal(masks[k].cpu(), g[k]), k
+    assert_close(pred, g["pred"], atol=LOGP_TOL, name="log-probs")
+    assert_close(loss, g["loss"], atol=1e-3, rtol=1e-4, name="loss")
+    loss.backward()
+    _check_grads(model.named_parameters(), g.sub("grad/"))
+
+
+@pytest.mark.parametrize("name,cfgfn", [("cfg0_cap.npz", syn.cfg_config0), ("mid_cap.npz", syn.cfg_config1)])
+def test_seeded_captioning_model(golden, name, cfgfn):
+    """configs[0] and the mid-scale config[1]-width fixture: weights re-created from the seed (digest pinned by the
+    fixture), log-probs within 1e-3 of the reference CPU path."""
+    from oracle import bmt_oracle as orc
+    g = golden(name)
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = cfgfn()
+    model = _build(cfg, V, bool(use_glove))
+    assert orc.state_dict_digest({k: v.cpu() for k, v in model.state_dict().items()}) == str(g.np("sd_digest"))
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    pred, loss, masks = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"])
+    for k in ("V_mask", "A_mask", "C_mask"):
+        assert torch.equal(masks[k].cpu(), g[k]), k
+    err = float((pred.detach().cpu() - g["pred"]).abs().max())
+    print(f"\n{name}: max |dlogp| = {err:.3e} (bar {LOGP_TOL})")
+    assert_close(pred, g["pred"], atol=LOGP_TOL, name="log-probs")
+    assert_close(loss, g["loss"], atol=1e-3, rtol=1e-4, name="loss")
+    loss.backward()
+    names = [str(s) for s in g.np("grad_names")]
+    norms = g.np("grad_norms")
+    params = dict(model.named_parameters())
+    bad = []
+    for n, ref_norm in zip(names, norms):
+        mine = float(params[n].grad.double().norm())
+        if abs(mine - ref_norm) > GRAD_REL * ref_norm + 1e-7:
+            bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
+    assert not bad, "\n".join(bad)
+    _check_grads(model.named_parameters(), g.sub("grad/"))
+
+
+def test_bf16_forward_mode_is_measurably_worse(golden):
+    """documents why the forward runs split-bf16: single-pass bf16 operands miss the 1e-3 bar on the same fixture."""
+    from bmt_amd import ops
+    g = golden("mid_cap.npz")
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = syn.cfg_config1()
+    model = _build(cfg, V, bool(use_glove))
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    try:
+        ops.set_precision(fwd=1, bwd=1)
+        with torch.no_grad():
+            pred, _, _ = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"])
+    finally:
+        ops.set_precision()
+    err = float((pred.cpu() - g["pred"]).abs().max())
+    print(f"\nsingle-pass bf16 forward: max |dlogp| = {err:.3e}")
+    assert 1e-4 < err < 0.2
+
+
+def test_training_mode_dropout(golden):
+    from bmt_amd import ops
+    g = golden("tiny_cap.npz")
+    cfg = syn.cfg_tiny(dout_p=0.1)
+    V = int(g.np("meta")[0])
+    model = _build(cfg, V, True, g.sub("sd/"))
+    fs, caps = {"rgb": g["rgb"], "flow": g["flow"], "audio": g["audio"]}, g["captions"]
+    ops.manual_seed(7)
+    p1, l1, _ = _run_cap(model, cfg, fs, caps, train=True)
+    l1.backward()
+    assert torch.isfinite(l1) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert not torch.allclose(p1.detach().cpu(), g["pred"], atol=1e-3)   # dropout really is on
+    ops.manual_seed(7)                                                     # same seed & step -> same masks
+    model.zero_grad()
+    p2, l2, _ = _run_cap(model, cfg, fs, caps, train=True)
+    l2.backward()
+    assert torch.equal(p1, p2)
+    p3, _, _ = _run_cap(model, cfg, fs, caps, train=True)                  # next step -> new masks
+    assert not torch.equal(p1, p3)
+    # eval() switches every site off
+    p4, _, _ = _run_cap(model, cfg, fs, caps, train=False)
+    assert_close(p4, g["pred"], atol=LOGP_TOL, name="eval after train")
+
+
+def test_train_step_matches_oracle(golden):
+    """zero_grad -> masks -> forward -> KL/n_tokens -> backward -> clip -> Adam  (training_loop,
+    epoch_loops/captioning_epoch_loops.py:128-141) for two steps, against the CPU oracle."""
+    from bmt_amd.optim import FusedAdam, clip_grad_norm_
+    from oracle import bmt_oracle as orc
+    g = golden("tiny_cap_trainemb.npz")
+    cfg = syn.cfg_tiny(dout_p=0.0)
+    V = int(g.np("meta")[0])
+    model = _build(cfg, V, False, g.sub("sd/"))
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    fs, caps = {"rgb": g["rgb"], "flow": g["flow"], "audio": g["audio"]}, g["captions"]
+    p = {k: v.clone().requires_grad_() for k, v in g.sub("sd/").items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    for step in (1, 2):
+        opt.zero_grad()
+        _, loss, _ = _run_cap(model, cfg, fs, caps, train=True)
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        for t in p.values():
+            t.grad = None
+        oloss, _, _ = orc.train_cap_loss(p, cfg, fs, caps, 1, cfg.smoothing)
+        oloss.backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
+        with torch.no_grad():
+            for k in p:
+                orc.adam_step(p[k], p[k].grad, m[k], v2[k], step, 1e-3)
+        assert abs(float(loss) - float(oloss)) < 2e-3, (step, float(loss), float(oloss))
+    sd = model.state_dict()
+    agree, total = 0, 0
+    for k in p:
+        d = (sd[k].cpu() - p[k].detach()).abs()
+        agree += int((d < 2.5e-4).sum())
+        total += d.numel()
+    assert agree / total > 0.97, agree / total

@@ -1,0 +1,98 @@
+"""-m gpu: proposal-generator path (Conv1d heads as implicit GEMM, target assignment, decode + YOLO loss) against the
+golden vectors captured from the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from bmt_amd import synthetic as syn
+from tests.gpu_util import assert_close, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("tag", ["nocollide", "collide"])
+def test_make_targets_bit_exact(golden, tag):
+    from bmt_amd.model.proposal_generator import make_targets
+    g = golden("targets.npz")
+    preds = torch.zeros(3, 5, 40, 3, device=DEV)
+    obj, noobj, tx, tw, tobj = make_targets(preds, g[f"mt/{tag}/targets"].to(DEV), g[f"mt/{tag}/anchors"].to(DEV),
+                                            float(g[f"mt/{tag}/stride"]))
+    assert obj.dtype == torch.bool and torch.equal(obj.cpu(), g[f"mt/{tag}/obj"])
+    assert torch.equal(noobj.cpu(), g[f"mt/{tag}/noobj"])
+    assert torch.equal(tobj.cpu(), g[f"mt/{tag}/tobj"])
+    assert torch.equal(tx.cpu(), g[f"mt/{tag}/tx"])                       # gt_x - floor(gt_x): exact fp32 ops
+    assert_close(tw, g[f"mt/{tag}/tw"], atol=0, rtol=3e-7, name="target_w (device logf vs host logf)")
+
+
+@pytest.mark.parametrize("B,S,Din,Dout,k", [(2, 14, 24, 16, 5), (2, 9, 48, 16, 7), (1, 40, 128, 64, 13), (3, 50, 64, 136, 1 + 2 * 15)])
+def test_conv1d_heads_vs_torch_conv(B, S, Din, Dout, k):
+    from bmt_amd.model.proposal_generator import ConvKFn
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(B, S, Din, generator=g)
+    W = torch.randn(Dout, Din, k, generator=g) / (Din * k) ** 0.5
+    b = torch.randn(Dout, generator=g)
+    w = torch.randn(B, S, Dout, generator=g)
+    xd, Wd, bd = x.to(DEV).requires_grad_(), W.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ConvKFn.apply(xd, Wd, bd, True, 0.0, 0)
+    xr, Wr, br = x.double().requires_grad_(), W.double().requires_grad_(), b.double().requires_grad_()
+    want = torch.relu(torch.nn.functional.conv1d(xr.permute(0, 2, 1), Wr, br, padding=k // 2)).permute(0, 2, 1)
+    assert_close(y, want, atol=3e-4, name=f"conv k={k}")
+    (y * w.to(DEV)).sum().backward()
+    (want * w.double()).sum().backward()
+    for name, got, ref in (("dx", xd.grad, xr.grad), ("dW", Wd.grad, Wr.grad), ("db", bd.grad, br.grad)):
+        assert rel_err(got, ref) < 2e-2, report(got, ref, name)
+
+
+def _prop_cfg():
+    cfg = syn.cfg_tiny(procedure="train_prop")
+    cfg.anchors_num_audio, cfg.anchors_num_video = 3, 5
+    cfg.conv_layers_audio, cfg.conv_layers_video = [16, 16], [16, 16]
+    cfg.kernel_sizes = {"audio": [1, 5], "video": [3, 7]}
+    cfg.device = DEV
+    return cfg
+
+
+def test_tiny_proposal_generator(golden):
+    from bmt_amd.model.masking import mask
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    g = golden("tiny_prop.npz")
+    cfg = _prop_cfg()
+    anchors = {"audio": [float(a) for a in g.np("anchors_audio")], "video": [float(a) for a in g.np("anchors_video")]}
+    torch.manual_seed(0)
+    model = MultimodalProposalGenerator(cfg, anchors)
+    sd = g.sub("sd/")
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    fs = {k: g[k].to(DEV) for k in ("rgb", "flow", "audio")}
+    masks = {"A_mask": mask(fs["audio"][:, :, 0], None, 1), "V_mask": mask(fs["rgb"][:, :, 0], None, 1)}
+    preds, loss, la, lv = model(fs, g["targets"].to(DEV), masks)
+    assert_close(preds, g["preds"], atol=2e-3, rtol=1e-3, name="predictions")
+    assert_close(loss, g["loss"], atol=2e-3, rtol=1e-3, name="total loss")
+    for k, v in g.sub("losses_A/").items():
+        assert_close(la[k], v, atol=1e-3, rtol=1e-3, name="A " + k)
+    for k, v in g.sub("losses_V/").items():
+        assert_close(lv[k], v, atol=1e-3, rtol=1e-3, name="V " + k)
+    loss.backward()
+    bad = []
+    ref = g.sub("grad/")
+    for k, p in model.named_parameters():
+        if k in ref:
+            e = rel_err(p.grad, ref[k])
+            if e > 3e-2 and float((p.grad.cpu() - ref[k]).abs().max()) > 1e-5:
+                bad.append(f"{k}: rel {e:.3e}\n" + report(p.grad, ref[k], k))
+    assert not bad, "\n".join(bad)
+    # inference call: targets None -> loss is the python int 0 and predictions are unchanged
+    preds2, loss2, _, _ = model(fs, None, masks)
+    assert loss2 == 0
+    assert_close(preds2, g["preds_notargets"], atol=2e-3, rtol=1e-3, name="predictions (no targets)")
+
+
+def test_initial_state_dict_matches_reference_layout(golden):
+    """default Sequential indices conv_layers.{0,3,6} with dropout, {0,2,4} without (positional keys)."""
+    from bmt_amd.model.proposal_generator import ProposalGenerationHead
+    h = ProposalGenerationHead([24, 16, 16, 9], 5, 0.1)
+    assert sorted({k.split(".")[1] for k in h.state_dict()}) == ["0", "3", "6"]
+    h = ProposalGenerationHead([24, 16, 16, 9], 5, 0.0)
+    assert sorted({k.split(".")[1] for k in h.state_dict()}) == ["0", "2", "4"]
