@@ -1,0 +1,247 @@
+"""bench.py -- caption tokens/s of the train_cap step (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> masks -> forward -> LabelSmoothing/n_tokens -> backward -> gradient all-reduce -> Adam
+(epoch_loops/captioning_epoch_loops.py:128-141) on one synthetic batch already resident in HBM.
+Workload = BASELINE.json configs[1]: B=32 per GPU (weak scaling), N=2, d_model=1024, H=4, d_audio=128,
+d_video=1024, d_caps=300, T_v=256, T_a=800, T_c=30, V=10000, dropout 0.1, Adam lr 5e-5, GloVe frozen.
+Forward products run split-bf16 (3 MFMA passes, log-probs within 1e-3 of the fp32 reference, see
+tests/test_gpu_model.py), backward products single-pass bf16; accumulation, softmax, LayerNorm, loss, Adam in fp32.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel class, ALGORITHMIC flops / HIP-event time measured live in the timed region
+  cpu_baseline -- the CPU oracle (a port of the reference, oracle/bmt_oracle.py) on the host cores, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0
+
+
+class KernelTimer:
+    """HIP-event timing of kernel classes on the stream they are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}   # class -> list of (start, end, flops, bytes)
+        self.enabled = False
+
+    def wrap(self, ops):
+        timer = self
+        raw_gemm, raw_afwd, raw_abwd = ops.gemm, ops.attn_fwd, ops.attn_bwd
+
+        def gemm(A, B, C_out, M, N, K, **kw):
+            if not timer.enabled:
+                return raw_gemm(A, B, C_out, M, N, K, **kw)
+            prec = kw.get("precision") or ops.FWD_PRECISION
+            cls = f"gemm_{'kc' if kw.get('a_kc', True) else 'rc'}_{'kc' if kw.get('b_kc', True) else 'rc'}_x{prec}"
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_gemm(A, B, C_out, M, N, K, **kw)
+            e.record()
+            timer.records.setdefault(cls, []).append((s, e, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
+            return r
+
+        def attn_fwd(q, k, v, mask, H, **kw):
+            if not timer.enabled:
+                return raw_afwd(q, k, v, mask, H, **kw)
+            B_, Sq, D = q.shape
+            Sk = k.shape[1]
+            prec = kw.get("precision") or ops.FWD_PRECISION
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_afwd(q, k, v, mask, H, **kw)
+            e.record()
+            timer.records.setdefault(f"attn_fwd_dk{D // H}_x{prec}", []).append(
+                (s, e, 4.0 * B_ * Sq * Sk * D, 4.0 * B_ * D * (2 * Sq + 2 * Sk)))
+            return r
+
+        def attn_bwd(q, k, v, o, do, lse, mask, H, **kw):
+            if not timer.enabled:
+                return raw_abwd(q, k, v, o, do, lse, mask, H, **kw)
+            B_, Sq, D = q.shape
+            Sk = k.shape[1]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_abwd(q, k, v, o, do, lse, mask, H, **kw)
+            e.record()
+            # algorithmic backward = 5 products (dV, dP, dQ, dK + S recompute) = 2.5 x forward
+            timer.records.setdefault(f"attn_bwd_dk{D // H}", []).append(
+                (s, e, 10.0 * B_ * Sq * Sk * D, 4.0 * B_ * D * (4 * Sq + 4 * Sk)))
+            return r
+
+        ops.gemm, ops.attn_fwd, ops.attn_bwd = gemm, attn_fwd, attn_bwd
+
+    def summary(self):
+        out = {}
+        for cls, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            fl = sum(f for _, _, f, _ in recs)
+            by = sum(b for _, _, _, b in recs)
+            out[cls] = {"launches": len(recs), "ms": ms, "flops": fl, "bytes": by}
+        return out
+
+
+def cpu_baseline(cfg_fn, V, Tv, Ta, Tc, pad_idx):
+    """the reference's CPU path as restated by the oracle: fwd + bwd + Adam on a bounded sample of the same workload"""
+    from bmt_amd import synthetic as syn
+    from oracle import bmt_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = cfg_fn(dout_p=0.0)
+    Bs = 4
+    sd = orc.init_captioning_params(cfg, V, seed=0, glove=syn.make_glove(V, cfg.d_model_caps))
+    p = {k: v.clone().requires_grad_(k != "emb_C.embedder.weight") for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    batch = syn.make_cap_batch(cfg, Bs, Tv, Ta, Tc, V, seed=1234)
+
+    def step(i):
+        for t in p.values():
+            t.grad = None
+        loss, _, ntok = orc.train_cap_loss(p, cfg, batch["feature_stacks"], batch["captions"], pad_idx, cfg.smoothing)
+        loss.backward()
+        with torch.no_grad():
+            for k, t in p.items():
+                if t.grad is not None:
+                    orc.adam_step(t, t.grad, m[k], v2[k], i, cfg.lr)
+        return int(ntok)
+    step(1)
+    t0 = time.perf_counter()
+    toks, n = 0, 0
+    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 6):
+        toks += step(n + 2)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": toks / dt, "unit": "caption tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of config[1] at B={Bs} (fwd+bwd+Adam, fp32, dropout off), oracle/bmt_oracle.py on torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--fwd-precision", type=int, default=3, choices=[1, 3])
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bmt_amd import ops, synthetic as syn
+    from bmt_amd.model.captioning_module import BiModalTransformer
+    from bmt_amd.train import CaptioningTrainStep
+
+    ops.set_precision(fwd=args.fwd_precision, bwd=1)
+    V, Tv, Ta, Tc, B = 10000, 256, 800, 30, args.batch
+    cfg = syn.cfg_config1(dout_p=0.1)
+    cfg.device = str(dev)
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(dev)
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=1234 + rank)
+    fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}      # inputs resident in HBM before timing
+    caps = batch["captions"].to(dev)
+    tokens_local = int((caps[:, 1:] != syn.PAD_IDX).sum())
+    ops.manual_seed(1000 + rank)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1)
+
+    timer = KernelTimer()
+    if not args.no_kernel_timer:
+        timer.wrap(ops)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _ = step(fs, caps)
+    sync()
+    timer.enabled = not args.no_kernel_timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step(fs, caps)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    final_loss = float(loss)
+
+    t = torch.tensor([dt, float(tokens_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, tokens_all = float(tmax[0]), float(tsum[1])
+    else:
+        tokens_all = float(tokens_local)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = tokens_all * args.steps / dt
+        # algorithmic flops of the padded-dense step: 3.257 TFLOP per B=32 train step at V~10k
+        flops_step = 3.257e12 * (B / 32.0) * world
+        out = {
+            "metric": "caption tokens/sec/node (train_cap B=32/GPU, d=1024)", "value": value, "unit": "caption tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 fwd / bf16 bwd MFMA, fp32 accumulate" if args.fwd_precision == 3 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: train_cap, N=2 d_model=1024 H=4 d_aud=128 d_vid=1024 d_caps=300 "
+                                   "T_v=256 T_a=800 T_c=30 V=10000, dropout 0.1, Adam, GloVe frozen",
+                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "trainable_params": n_params, "tokens_per_step": tokens_all, "final_loss": final_loss},
+            "algorithmic_tflops": flops_step / (ms_per_step * 1e-3) / 1e12,
+            "mfma_peak_frac": flops_step / (ms_per_step * 1e-3) / 1e12 / (MFMA_BF16_DENSE_PEAK_TFLOPS * world),
+        }
+        if not args.no_kernel_timer:
+            summ = timer.summary()
+            tot = sum(v["ms"] for v in summ.values()) or 1.0
+            dom = max(summ, key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                               "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                               "share_of_timed_kernels": d["ms"] / tot,
+                               "mfma_passes": 3 if dom.endswith("x3") else 1}
+            out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                         "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches_per_step": v["launches"] / args.steps}
+                                     for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(syn.cfg_config1, V, Tv, Ta, Tc, syn.PAD_IDX)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Data parallelism for the train_cap / train_prop step: one process per GPU, RCCL (torch.distributed backend "nccl")
+sum-all-reduce of gradients over xGMI, bucketed in reverse-autograd order and overlapped with the backward pass.
+
+Replaces the reference's single-process ``nn.DataParallel`` (scripts/train_captioning_module.py:61), which per step
+broadcasts every parameter, scatters inputs, gathers the (B,Tc,V) log-probs to GPU 0, computes the loss there and
+reduces gradients to GPU 0.  Here every rank holds a replica and its own optimizer state; the only
+traffic is one gradient sum (~202 MB fp32 at config[1]) plus one scalar (the global token count the loss is
+normalised by, epoch_loops/captioning_epoch_loops.py:134-135).
+
+xGMI is a point-to-point mesh, so buckets are sized to keep all seven links busy rather than for an NVSwitch-style
+ring: a few large buckets (default 32 MB) launched as soon as their gradients are final -- generator and decoder first,
+the encoder layers (71 % of the bytes) while the earlier encoder layers are still in backward.
+
+Nothing here computes: it is torch.distributed plumbing, so it is exercised on CPU with the gloo backend in
+tests/test_parallel_gloo.py (world_size 2) and runs unchanged over RCCL on the GPU box."""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradientReducer:
+    """Owns flat gradient buckets; ``p.grad`` of every trainable parameter is a view into one of them, so autograd
+    accumulates straight into communication buffers and the optimizer reads the reduced values in place."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
+                 process_group: Optional[dist.ProcessGroup] = None, overlap: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        params = [p for p in params if p.requires_grad]
+        # reverse registration order ~ the order autograd finishes gradients (generator -> decoder -> encoder)
+        order = list(reversed(params))
+        self.buckets: List[dict] = []
+        cur, cur_bytes = [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._make_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._make_bucket(cur)
+        self._slot = {}   # Parameter (hashed by identity) -> (bucket index, slot in bucket)
+        for bi, b in enumerate(self.buckets):
+            for si, p in enumerate(b["params"]):
+                self._slot[p] = (bi, si)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self._handles = []
+        self.zero_grad()
+
+    def _make_bucket(self, ps):
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buckets.append({"params": ps, "flat": flat, "views": views, "pending": len(ps)})
+
+    def zero_grad(self):
+        """in-place zero of the flat buffers (one memset per bucket); keeps p.grad bound to its bucket view"""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = len(b["params"])
+            for p, v in zip(b["params"], b["views"]):
+                if p.grad is not v:
+                    p.grad = v
+        self._handles = []
+
+    def _on_grad(self, p):
+        bi, si = self._slot[p]
+        b = self.buckets[bi]
+        v = b["views"][si]
+        if p.grad.data_ptr() != v.data_ptr():
+            # autograd replaced the tensor (grad was None): copy into the bucket and re-bind
+            v.copy_(p.grad)
+            p.grad = v
+        b["pending"] -= 1
+        if b["pending"] == 0 and self.world > 1 and self.overlap:
+            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """wait for the in-flight buckets (and reduce any bucket whose hooks did not all fire, e.g. unused parameters)"""
+        if self.world > 1:
+            for b in self.buckets:
+                if b["pending"] != 0 or not self.overlap:
+                    self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+
+
+def global_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """sum of a small tensor over ranks (the loss normaliser: n_tokens, or the obj / noobj cell counts of train_prop)"""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

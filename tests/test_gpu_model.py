@@ -23,17 +23,30 @@ def _load(module, sd):
     return module.to(DEV)
 
 
-def _check_grads(named_params, ref_grads, tol=GRAD_REL, floor=1e-6):
-    bad = []
-    for k, p in named_params:
-        if k not in ref_grads:
-            continue
+def _check_grads(named_params, ref_grads, tol=0.08, global_tol=GRAD_REL):
+    """Backward runs single-pass bf16 (DESIGN.md "precision"): per-tensor relative error <= 8 %, error over ALL tensors
+    concatenated <= 3 %.  Gradients that are analytically zero (the key-projection bias: softmax is invariant to a
+    constant added to every key) come out as cancellation noise in any finite precision -- 1e-9 in the fp32 reference,
+    bf16-sized here -- and are only required to be small against the largest gradient element around them."""
+    items = [(k, p) for k, p in named_params if k in ref_grads]
+    gmax = max(float(ref_grads[k].abs().max()) for k, _ in items)
+    nmax = max(float(ref_grads[k].double().norm()) for k, _ in items)
+    bad, e2, r2 = [], 0.0, 0.0
+    for k, p in items:
         assert p.grad is not None, f"missing grad for {k}"
-        ref = ref_grads[k]
-        e = float((p.grad.detach().cpu().double() - ref.double()).norm())
-        n = float(ref.double().norm())
-        if e > tol * n + floor:
-            bad.append(f"{k}: |err|={e:.3e} |ref|={n:.3e}\n" + report(p.grad, ref, k))
+        ref = ref_grads[k].double()
+        got = p.grad.detach().cpu().double()
+        e, n = float((got - ref).norm()), float(ref.norm())
+        if n < 1e-4 * nmax:      # analytically-zero gradient
+            if float(got.abs().max()) > 0.05 * gmax:
+                bad.append(f"{k}: should be ~0, max|got|={float(got.abs().max()):.3e} vs largest gradient element {gmax:.3e}")
+            continue
+        e2 += e * e
+        r2 += n * n
+        if e > tol * n:
+            bad.append(f"{k}: |err|={e:.3e} |ref|={n:.3e}\n" + report(p.grad, ref_grads[k], k))
+    if r2 > 0 and (e2 / r2) ** 0.5 > global_tol:
+        bad.append(f"global relative gradient error {(e2 / r2) ** 0.5:.3e} > {global_tol}")
     assert not bad, "\n".join(bad)
 
 
@@ -166,9 +179,13 @@ def test_seeded_captioning_model(golden, name, cfgfn):
     norms = g.np("grad_norms")
     params = dict(model.named_parameters())
     bad = []
+    nmax = float(max(norms))
     for n, ref_norm in zip(names, norms):
         mine = float(params[n].grad.double().norm())
-        if abs(mine - ref_norm) > GRAD_REL * ref_norm + 1e-7:
+        if ref_norm < 1e-4 * nmax:          # analytically zero (key-projection biases): bf16 cancellation noise only
+            if mine > 2e-2 * nmax:
+                bad.append(f"{n}: should be ~0, |grad|={mine:.4e}")
+        elif abs(mine - ref_norm) > 0.08 * ref_norm:
             bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
     assert not bad, "\n".join(bad)
     _check_grads(model.named_parameters(), g.sub("grad/"))

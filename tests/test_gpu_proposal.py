@@ -75,14 +75,8 @@ def test_tiny_proposal_generator(golden):
     for k, v in g.sub("losses_V/").items():
         assert_close(lv[k], v, atol=1e-3, rtol=1e-3, name="V " + k)
     loss.backward()
-    bad = []
-    ref = g.sub("grad/")
-    for k, p in model.named_parameters():
-        if k in ref:
-            e = rel_err(p.grad, ref[k])
-            if e > 3e-2 and float((p.grad.cpu() - ref[k]).abs().max()) > 1e-5:
-                bad.append(f"{k}: rel {e:.3e}\n" + report(p.grad, ref[k], k))
-    assert not bad, "\n".join(bad)
+    from tests.test_gpu_model import _check_grads
+    _check_grads(model.named_parameters(), g.sub("grad/"))
     # inference call: targets None -> loss is the python int 0 and predictions are unchanged
     preds2, loss2, _, _ = model(fs, None, masks)
     assert loss2 == 0
