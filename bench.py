@@ -94,14 +94,19 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(cfg_fn, V, Tv, Ta, Tc, pad_idx):
-    """the reference's CPU path as restated by the oracle: fwd + bwd + Adam on a bounded sample of the same workload"""
+def cpu_baseline_worker():
+    """runs in a child process (see cpu_baseline): the reference's CPU path as restated by the oracle -- fwd + bwd + Adam
+    on a bounded sample of the same workload -- prints one JSON object."""
     from bmt_amd import synthetic as syn
     from oracle import bmt_oracle as orc
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))          # more threads than this only add contention at these sizes
     torch.set_num_threads(cores)
-    cfg = cfg_fn(dout_p=0.0)
-    Bs = 4
+    V, Tv, Ta, Tc, Bs = 10000, 256, 800, 30, 4
+    cfg = syn.cfg_config1(dout_p=0.0)
     sd = orc.init_captioning_params(cfg, V, seed=0, glove=syn.make_glove(V, cfg.d_model_caps))
     p = {k: v.clone().requires_grad_(k != "emb_C.embedder.weight") for k, v in sd.items()}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
@@ -111,7 +116,7 @@ def cpu_baseline(cfg_fn, V, Tv, Ta, Tc, pad_idx):
     def step(i):
         for t in p.values():
             t.grad = None
-        loss, _, ntok = orc.train_cap_loss(p, cfg, batch["feature_stacks"], batch["captions"], pad_idx, cfg.smoothing)
+        loss, _, ntok = orc.train_cap_loss(p, cfg, batch["feature_stacks"], batch["captions"], syn.PAD_IDX, cfg.smoothing)
         loss.backward()
         with torch.no_grad():
             for k, t in p.items():
@@ -125,8 +130,23 @@ def cpu_baseline(cfg_fn, V, Tv, Ta, Tc, pad_idx):
         toks += step(n + 2)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": toks / dt, "unit": "caption tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps of config[1] at B={Bs} (fwd+bwd+Adam, fp32, dropout off), oracle/bmt_oracle.py on torch CPU"}
+    print(json.dumps({"value": toks / dt, "unit": "caption tokens/s", "cores": cores, "kind": "port",
+                      "sample": f"{n} train steps of config[1] at B={Bs} (fwd+bwd+Adam, fp32, dropout off), "
+                                f"oracle/bmt_oracle.py on torch CPU, {cores} threads, {dt / n:.2f} s/step"}))
+
+
+def cpu_baseline(timeout_s=150):
+    """bounded: the oracle is timed in a child process that is killed after timeout_s (the bench must never hang on it)"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
+                           timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "error": (r.stderr or "no output")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"cpu baseline exceeded {timeout_s}s"}
 
 
 def main():
@@ -138,7 +158,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--fwd-precision", type=int, default=3, choices=[1, 3])
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker()
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,9 +204,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
     for _ in range(args.warmup):
         loss, _ = step(fs, caps)
     sync()
+    note(f"warmup done ({args.warmup} steps)")
     timer.enabled = not args.no_kernel_timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -192,6 +220,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     final_loss = float(loss)
+    note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
 
     t = torch.tensor([dt, float(tokens_local)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -236,7 +265,8 @@ def main():
                                          "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches_per_step": v["launches"] / args.steps}
                                      for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(syn.cfg_config1, V, Tv, Ta, Tc, syn.PAD_IDX)
+            note("timing the CPU oracle (bounded sample, child process)")
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -52,15 +52,21 @@ __device__ __forceinline__ uint32_t f2bf_bits(float x) {
 }
 __device__ __forceinline__ float bf_bits2f(uint32_t b) { return __uint_as_float(b << 16); }
 
-// pack two floats into one dword of 2 bf16 (lo = a, hi = b)
-__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return f2bf_bits(a) | (f2bf_bits(b) << 16); }
+// pack two floats into one dword of 2 bf16 (lo half = a, hi half = b): one v_cvt_pk_bf16_f32 (RNE) on gfx950
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
-// split x into hi (bf16) and lo = bf16(x - hi); returns packed pairs for two inputs
+// split (a, b) into hi = bf16(x) and lo = bf16(x - hi), both packed: 2 v_cvt_pk + 2 unpack + 1 packed subtract
 __device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    uint32_t ha = f2bf_bits(a), hb = f2bf_bits(b);
-    hi = ha | (hb << 16);
-    float ra = a - bf_bits2f(ha), rb = b - bf_bits2f(hb);
-    lo = f2bf_bits(ra) | (f2bf_bits(rb) << 16);
+    const f32x2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG

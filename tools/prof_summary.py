@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace run (rocpd sqlite .db or *_kernel_trace.csv) into a per-kernel stats CSV:
+name, calls, total_ms, avg_us, min_us, max_us, pct.   usage: prof_summary.py <in.db|in.csv> <out.csv> [note]"""
+import csv
+import re
+import sqlite3
+import sys
+
+
+def rows_from_db(path):
+    cur = sqlite3.connect(path).cursor()
+    return cur.execute("select name, end-start from kernels").fetchall()
+
+
+def rows_from_csv(path):
+    out = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out.append((r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return out
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    note = sys.argv[3] if len(sys.argv) > 3 else ""
+    rows = rows_from_db(src) if src.endswith(".db") else rows_from_csv(src)
+    agg = {}
+    for name, d in rows:
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        name = re.sub(r"^void ", "", name)
+        a = agg.setdefault(name, [0, 0, 10**18, 0])
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    with open(dst, "w", newline="") as f:
+        if note:
+            f.write(f"# {note}\n")
+        f.write(f"# total kernel time {tot / 1e6:.3f} ms over {sum(a[0] for a in agg.values())} dispatches\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"])
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([name[:160], a[0], f"{a[1] / 1e6:.3f}", f"{a[1] / a[0] / 1e3:.2f}", f"{a[2] / 1e3:.2f}", f"{a[3] / 1e3:.2f}",
+                        f"{100 * a[1] / tot:.2f}"])
+
+
+if __name__ == "__main__":
+    main()
