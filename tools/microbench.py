@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Kernel microbenchmarks on the config[1] shapes (HIP-event timed through the C ABI).
+usage: microbench.py [gemm] [attn] [attnbwd] [--iters N]"""
+import os
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bmt_amd import ops  # noqa: E402
+
+DEV = "cuda"
+ITERS = 5
+for i, a in enumerate(sys.argv):
+    if a == "--iters":
+        ITERS = int(sys.argv[i + 1])
+
+
+def timeit(fn, flops, name, iters=None):
+    iters = iters or ITERS
+    fn(); fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    print(f"{name:58s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+def gemm_bench():
+    shapes = [("ffn_v fc1   8192x4096x1024", 8192, 4096, 1024), ("v proj      8192x1024x1024", 8192, 1024, 1024),
+              ("a proj     25600x1024x128 ", 25600, 1024, 128), ("a d2Q      25600x128x1024 ", 25600, 128, 1024),
+              ("dec q       960x1024x300  ", 960, 1024, 300), ("generator   960x10000x300 ", 960, 10000, 300)]
+    for name, M, N, K in shapes:
+        x = torch.randn(M, K, device=DEV)
+        W = torch.randn(N, K, device=DEV)
+        b = torch.randn(N, device=DEV)
+        out = torch.empty(M, N, device=DEV)
+        for prec in (3, 1):
+            timeit(lambda: ops.linear_fwd(x, W, b, out=out, precision=prec), 2.0 * M * N * K, f"linear_fwd x{prec} {name}")
+        dy = torch.randn(M, N, device=DEV)
+        timeit(lambda: ops.linear_dx(dy, W), 2.0 * M * N * K, f"linear_dx  x1 {name}")
+        timeit(lambda: ops.linear_dw(dy, x), 2.0 * M * N * K, f"linear_dw  x1 {name}")
+
+
+def attn_bench(bwd=False):
+    B, H, dk = 32, 4, 256
+    D = H * dk
+    for name, Sq, Sk in (("A-self 800x800", 800, 800), ("V-self 256x256", 256, 256), ("A<-V 800x256", 800, 256),
+                         ("V<-A 256x800", 256, 800), ("C<-A 30x800", 30, 800)):
+        q = torch.randn(B, Sq, D, device=DEV)
+        k = torch.randn(B, Sk, D, device=DEV)
+        v = torch.randn(B, Sk, D, device=DEV)
+        mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=DEV)
+        mask[:, :, Sk - Sk // 5:] = False
+        fl = 4.0 * B * Sq * Sk * D
+        if not bwd:
+            for prec in (3, 1):
+                timeit(lambda: ops.attn_fwd(q, k, v, mask, H, precision=prec), fl, f"attn_fwd x{prec} {name}")
+            timeit(lambda: ops.attn_fwd(q, k, v, None, H, precision=3), fl, f"attn_fwd x3 nomask {name}")
+        else:
+            o, lse = ops.attn_fwd(q, k, v, mask, H, precision=3)
+            do = torch.randn_like(o)
+            timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, mask, H), 2.5 * fl, f"attn_bwd x1 {name}")
+
+
+if __name__ == "__main__":
+    if "gemm" in sys.argv:
+        gemm_bench()
+    if "attn" in sys.argv:
+        attn_bench()
+    if "attnbwd" in sys.argv:
+        attn_bench(bwd=True)
