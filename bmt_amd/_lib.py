@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64),
                 ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("rng", vp), ("site", u32),
-                ("precision", i32), ("splitk", i32)]
+                ("precision", i32), ("splitk", i32),
+                ("C_hi", vp), ("C_lo", vp), ("ldp", i64)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -49,6 +50,25 @@ class AttnBwdArgs(C.Structure):
                 ("scale", f32), ("drop_p", f32)]
 
 
+class AttnFwdBf16Args(C.Structure):
+    _fields_ = [("Qh", vp), ("Ql", vp), ("Kh", vp), ("Kl", vp), ("Vh", vp), ("Vl", vp), ("O", vp), ("lse", vp),
+                ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64),
+                ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64),
+                ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
+                ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
+                ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32)]
+
+
+class AttnBwdBf16Args(C.Structure):
+    _fields_ = [("Qh", vp), ("Kh", vp), ("Vh", vp), ("O", vp), ("dO", vp), ("lse", vp),
+                ("dQ", vp), ("dK", vp), ("dV", vp), ("delta_ws", vp), ("dOh_ws", vp),
+                ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64),
+                ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64), ("dkv_ld", i64), ("dkv_bs", i64),
+                ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
+                ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
+                ("scale", f32), ("drop_p", f32)]
+
+
 class Conv1dArgs(C.Structure):
     _fields_ = [("x", vp), ("W", vp), ("bias", vp), ("y", vp),
                 ("B", i32), ("S", i32), ("Din", i32), ("Dout", i32), ("k", i32), ("mode", i32),
@@ -65,6 +85,8 @@ SIGNATURES = {
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
+    "bmt_attn_fwd_bf16": (i32, [C.POINTER(AttnFwdBf16Args), vp]),
+    "bmt_attn_bwd_bf16": (i32, [C.POINTER(AttnBwdBf16Args), vp]),
     "bmt_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
     "bmt_layernorm_bwd_blocks": (i32, [i32]),
     "bmt_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, i32, vp]),

@@ -1,0 +1,696 @@
+// bmt_attn_fwd_bf16 / bmt_attn_bwd_bf16 -- flash-style masked attention over PRE-SPLIT bf16 operand planes.
+//
+// Same mathematics and the same transposed MFMA formulation as attention.hip (S^T = K.Q^T, O^T += V^T.P^T, softmax
+// axis lane-local), but Q/K/V arrive as bf16 planes (hi [+ lo residual]) written by the projection GEMM's epilogue:
+//   * the K/V staging loop moves 16-byte bf16 slots global -> registers -> LDS with NO conversion (the fp32 version
+//     spent 13 VALU instructions per MFMA, PMC: profiles/r01_b_attn_fwd_pmc.csv) and half the bytes;
+//   * key-padding masks are classified per staged tile (all valid / partly valid / all masked): fully valid tiles take
+//     an unmasked fast path, fully masked tiles are skipped (exact: they contribute exp(-inf) = 0);
+//   * the O^T accumulator is rescaled only when some lane's running maximum actually moved (exact, alpha == 1 otherwise);
+//   * the backward dK/dV kernel prefetches the next query tile into registers under the current tile's MFMAs.
+#include "common.h"
+
+namespace {
+
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+template <int DK>
+struct Geo {
+    static constexpr int BC = (DK == 256) ? 32 : 64;
+    static constexpr int NSUB = BC / 32;
+    static constexpr int DT = DK / 32;
+    static constexpr int K_BYTES = BC * DK * 2;
+    static constexpr int V_BYTES = DK * BC * 2;
+};
+
+template <int DK>
+__device__ __forceinline__ int kslot(int row, int slot) {
+    if constexpr (DK == 32) return row * 4 + (slot ^ ((row >> 2) & 3));
+    else if constexpr (DK == 64) return row * 8 + (slot ^ ((row >> 1) & 7));
+    else return row * (DK / 8) + (slot ^ (row & 15));
+}
+template <int ROWS>
+__device__ __forceinline__ int vunit(int d, int kg) {
+    if constexpr (ROWS == 64) return d * 16 + (kg ^ ((d >> 1) & 15));
+    else return d * 8 + (kg ^ ((d >> 2) & 7));
+}
+template <int DK, int ROWS> constexpr int rows_n() { return (ROWS * DK / 8 + 255) / 256; }
+template <int DK, int ROWS> constexpr int rowsT_n() { return (ROWS * DK / 16 + 255) / 256; }
+
+// ---- row-major bf16 tile [ROWS][DK]: global -> registers (16-B slots) -> swizzled LDS image
+template <int DK, int ROWS>
+__device__ __forceinline__ void tile_gload(const uint16_t* base, int64_t ld, int row0, int nrows, int tid,
+                                           uint4 (&v)[rows_n<DK, ROWS>()]) {
+    constexpr int SPR = DK / 8;
+#pragma unroll
+    for (int i = 0; i < rows_n<DK, ROWS>(); ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / SPR, slot = c % SPR;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (c < ROWS * SPR && row0 + row < nrows)
+            v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + row) * ld + slot * 8);
+    }
+}
+template <int DK, int ROWS>
+__device__ __forceinline__ void tile_lstore(uint4* img, int tid, const uint4 (&v)[rows_n<DK, ROWS>()]) {
+    constexpr int SPR = DK / 8;
+#pragma unroll
+    for (int i = 0; i < rows_n<DK, ROWS>(); ++i) {
+        const int c = tid + 256 * i;
+        if (c >= ROWS * SPR) break;
+        img[kslot<DK>(c / SPR, c % SPR)] = v[i];
+    }
+}
+// ---- transposed image [DK][ROWS] in 8-byte row-quads: each thread owns 4(row) x 4(d) blocks
+template <int DK, int ROWS>
+__device__ __forceinline__ void tileT_gload(const uint16_t* base, int64_t ld, int row0, int nrows, int tid,
+                                            uint2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
+    constexpr int DQ = DK / 4;
+#pragma unroll
+    for (int i = 0; i < rowsT_n<DK, ROWS>(); ++i) {
+        const int c = tid + 256 * i;
+        const int dq = c % DQ, kg = c / DQ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + kg * 4 + r;
+            v[i * 4 + r] = make_uint2(0, 0);
+            if (c < DQ * (ROWS / 4) && row < nrows)
+                v[i * 4 + r] = *reinterpret_cast<const uint2*>(base + (int64_t)row * ld + dq * 4);
+        }
+    }
+}
+template <int DK, int ROWS>
+__device__ __forceinline__ void tileT_lstore(uint2* img, int tid, const uint2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
+    constexpr int DQ = DK / 4;
+#pragma unroll
+    for (int i = 0; i < rowsT_n<DK, ROWS>(); ++i) {
+        const int c = tid + 256 * i;
+        if (c >= DQ * (ROWS / 4)) break;
+        const int dq = c % DQ, kg = c / DQ;
+        const uint2 a = v[i * 4 + 0], b = v[i * 4 + 1], cc = v[i * 4 + 2], d = v[i * 4 + 3];
+        // 4x4 bf16 transpose: output row = d index, 4 consecutive source rows packed low -> high
+        const uint2 o0 = make_uint2((a.x & 0xffffu) | (b.x << 16), (cc.x & 0xffffu) | (d.x << 16));
+        const uint2 o1 = make_uint2((a.x >> 16) | (b.x & 0xffff0000u), (cc.x >> 16) | (d.x & 0xffff0000u));
+        const uint2 o2 = make_uint2((a.y & 0xffffu) | (b.y << 16), (cc.y & 0xffffu) | (d.y << 16));
+        const uint2 o3 = make_uint2((a.y >> 16) | (b.y & 0xffff0000u), (cc.y >> 16) | (d.y & 0xffff0000u));
+        img[vunit<ROWS>(dq * 4 + 0, kg)] = o0;
+        img[vunit<ROWS>(dq * 4 + 1, kg)] = o1;
+        img[vunit<ROWS>(dq * 4 + 2, kg)] = o2;
+        img[vunit<ROWS>(dq * 4 + 3, kg)] = o3;
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ bf16x8 tfrag(const uint2* img, int d, int kg) {
+    const uint2 a = img[vunit<ROWS>(d, kg)], b = img[vunit<ROWS>(d, kg + 2)];
+    return as_bf16x8(make_uint4(a.x, a.y, b.x, b.y));
+}
+template <int NPASS>
+__device__ __forceinline__ void pack_p(const float (&p)[16], int s2, bf16x8& hi, bf16x8& lo) {
+    uint4 h, l = make_uint4(0, 0, 0, 0);
+    const int o = 8 * s2;
+    if constexpr (NPASS == 3) {
+        split_bf2(p[o + 0], p[o + 1], h.x, l.x); split_bf2(p[o + 2], p[o + 3], h.y, l.y);
+        split_bf2(p[o + 4], p[o + 5], h.z, l.z); split_bf2(p[o + 6], p[o + 7], h.w, l.w);
+    } else {
+        h.x = pack_bf2(p[o + 0], p[o + 1]); h.y = pack_bf2(p[o + 2], p[o + 3]);
+        h.z = pack_bf2(p[o + 4], p[o + 5]); h.w = pack_bf2(p[o + 6], p[o + 7]);
+    }
+    hi = as_bf16x8(h);
+    lo = as_bf16x8(l);
+}
+__device__ __forceinline__ bf16x8 ldfrag(const uint16_t* p, bool ok) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) v = *reinterpret_cast<const uint4*>(p);
+    return as_bf16x8(v);
+}
+
+struct AttnPB {
+    const uint16_t *Qh, *Ql, *Kh, *Kl, *Vh, *Vl, *dOh;
+    const float *O, *dO, *lse;
+    float *Ow, *lsew, *dQ, *dK, *dV, *delta;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;     // plane strides for Q/K/V (and dOh: ldo/bso); fp32 O/dO/dQ.. share them
+    const uint8_t* mask;
+    int64_t mask_bs, mask_qs;
+    int B, H, Sq, Sk;
+    float scale, drop_p;
+    const uint64_t* rng;
+    uint32_t site;
+};
+
+// stage the key-padding mask bytes of one tile and classify it: 0 = fully masked, 1 = partial, 2 = fully valid.
+// Called by every thread; result valid after the next __syncthreads().
+template <int BC>
+__device__ __forceinline__ void stage_mask(const AttnPB& p, int b, int key0, int tid, uint8_t* sMask, int* sFlag) {
+    if (tid < 64) {
+        uint8_t m = 0;
+        if (tid < BC && key0 + tid < p.Sk)
+            m = (p.mask != nullptr && p.mask_qs == 0) ? p.mask[(int64_t)b * p.mask_bs + key0 + tid] : (uint8_t)1;
+        if (tid < BC) sMask[tid] = m;
+        const unsigned long long valid = __ballot(m != 0);
+        const unsigned long long full = (BC == 64) ? ~0ull : ((1ull << BC) - 1ull);
+        if (tid == 0) {
+            int f = (valid == 0) ? 0 : ((valid == full) ? 2 : 1);
+            if (p.mask != nullptr && p.mask_qs != 0 && f == 2) f = 1;   // general (B,Sq,Sk) mask: checked per element
+            sFlag[0] = f;
+        }
+    }
+}
+
+// =================================================================================== forward
+template <int DK, int NPASS>
+__global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
+    using G = Geo<DK>;
+    constexpr int BC = G::BC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* sKh = reinterpret_cast<uint4*>(smem);
+    uint2* sVh = reinterpret_cast<uint2*>(smem + G::K_BYTES);
+    uint4* sKl = reinterpret_cast<uint4*>(smem + G::K_BYTES + G::V_BYTES);
+    uint2* sVl = reinterpret_cast<uint2*>(smem + 2 * G::K_BYTES + G::V_BYTES);
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + (NPASS == 3 ? 2 : 1) * (G::K_BYTES + G::V_BYTES));
+    int* sFlag = reinterpret_cast<int*>(sMask + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 32 + l31;
+    const bool qok = q < p.Sq;
+
+    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+
+    bf16x8 qh[DK / 16], ql[DK / 16];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * half;
+#pragma unroll
+        for (int s = 0; s < DK / 16; ++s) {
+            qh[s] = ldfrag(p.Qh + qo + 16 * s, qok);
+            if constexpr (NPASS == 3) ql[s] = ldfrag(p.Ql + qo + 16 * s, qok);
+        }
+    }
+
+    f32x16 o[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;
+
+    uint4 kh[rows_n<DK, BC>()], kl[rows_n<DK, BC>()];
+    uint2 vh[rowsT_n<DK, BC>() * 4], vl[rowsT_n<DK, BC>() * 4];
+    const int ntile = (p.Sk + BC - 1) / BC;
+    tile_gload<DK, BC>(p.Kh + koff, p.ldk, 0, p.Sk, tid, kh);
+    tileT_gload<DK, BC>(p.Vh + voff, p.ldv, 0, p.Sk, tid, vh);
+    if constexpr (NPASS == 3) {
+        tile_gload<DK, BC>(p.Kl + koff, p.ldk, 0, p.Sk, tid, kl);
+        tileT_gload<DK, BC>(p.Vl + voff, p.ldv, 0, p.Sk, tid, vl);
+    }
+
+    for (int t = 0; t < ntile; ++t) {
+        const int key0 = t * BC;
+        tile_lstore<DK, BC>(sKh, tid, kh);
+        tileT_lstore<DK, BC>(sVh, tid, vh);
+        if constexpr (NPASS == 3) {
+            tile_lstore<DK, BC>(sKl, tid, kl);
+            tileT_lstore<DK, BC>(sVl, tid, vl);
+        }
+        stage_mask<BC>(p, b, key0, tid, sMask, sFlag);
+        __syncthreads();
+        if (t + 1 < ntile) {
+            tile_gload<DK, BC>(p.Kh + koff, p.ldk, key0 + BC, p.Sk, tid, kh);
+            tileT_gload<DK, BC>(p.Vh + voff, p.ldv, key0 + BC, p.Sk, tid, vh);
+            if constexpr (NPASS == 3) {
+                tile_gload<DK, BC>(p.Kl + koff, p.ldk, key0 + BC, p.Sk, tid, kl);
+                tileT_gload<DK, BC>(p.Vl + voff, p.ldv, key0 + BC, p.Sk, tid, vl);
+            }
+        }
+        const int flag = sFlag[0];
+        if (flag != 0) {
+#pragma unroll
+            for (int sub = 0; sub < G::NSUB; ++sub) {
+                f32x16 st;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < DK / 16; ++s) {
+                    const int idx = kslot<DK>(sub * 32 + l31, 2 * s + half);
+                    const bf16x8 a = as_bf16x8(sKh[idx]);
+                    if constexpr (NPASS == 3) {
+                        st = mfma32(as_bf16x8(sKl[idx]), qh[s], st);
+                        st = mfma32(a, ql[s], st);
+                    }
+                    st = mfma32(a, qh[s], st);
+                }
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = st[r] * p.scale;
+                if (flag != 2) {
+                    if (p.mask != nullptr && p.mask_qs != 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = key0 + sub * 32 + acc_row(r, half);
+                            const bool ok = qok && key < p.Sk &&
+                                            p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
+                            pv[r] = ok ? pv[r] : NEG_INF;
+                        }
+                    } else {
+                        // this lane's 16 keys are four 4-byte groups of the staged mask bytes
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + sub * 32 + 8 * g + 4 * half);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) pv[4 * g + c] = ((mw >> (8 * c)) & 0xffu) ? pv[4 * g + c] : NEG_INF;
+                        }
+                    }
+                }
+                float tmax = pv[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, pv[r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __expf(pv[r] - m_use);
+                    psum += pv[r];
+                }
+                psum += __shfl_xor(psum, 32, 64);
+                if (!__all(m_new == m_run)) {      // some lane's running max moved: rescale (alpha == 1 for the others)
+                    const float alpha = __expf(m_run - m_use);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    m_run = m_new;
+                }
+                l_run += psum;
+                bf16x8 ph[2], pl[2];
+                pack_p<NPASS>(pv, 0, ph[0], pl[0]);
+                pack_p<NPASS>(pv, 1, ph[1], pl[1]);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int d = dt * 32 + l31, kg = sub * 8 + 4 * s2 + half;
+                        const bf16x8 a = tfrag<BC>(sVh, d, kg);
+                        if constexpr (NPASS == 3) {
+                            o[dt] = mfma32(tfrag<BC>(sVl, d, kg), ph[s2], o[dt]);
+                            o[dt] = mfma32(a, pl[s2], o[dt]);
+                        }
+                        o[dt] = mfma32(a, ph[s2], o[dt]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (qok) {
+        const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
+        const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = dt * 32 + 8 * r4 + 4 * half;
+                float4 v;
+                v.x = drop_apply(dc, o[dt][4 * r4 + 0] * inv, (uint64_t)(rowoff + d + 0));
+                v.y = drop_apply(dc, o[dt][4 * r4 + 1] * inv, (uint64_t)(rowoff + d + 1));
+                v.z = drop_apply(dc, o[dt][4 * r4 + 2] * inv, (uint64_t)(rowoff + d + 2));
+                v.w = drop_apply(dc, o[dt][4 * r4 + 3] * inv, (uint64_t)(rowoff + d + 3));
+                *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
+            }
+        if (half == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run + __logf(l_run);
+    }
+}
+
+// =================================================================================== backward
+// delta[b,h,q] = (1-p) * sum_d dO[b,q,h*DK+d] * O[b,q,h*DK+d]  (fp32 inputs), and the bf16 plane of dO for the MFMAs
+__global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, int DK, uint16_t* dOh) {
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t total = (int64_t)p.B * p.H * p.Sq;
+    if (row >= total) return;
+    const int q = (int)(row % p.Sq);
+    const int bh = (int)(row / p.Sq);
+    const int b = bh / p.H, h = bh % p.H;
+    const int64_t off = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+    float s = 0.f;
+    for (int d = lane * 4; d < DK; d += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(p.dO + off + d), c = *reinterpret_cast<const float4*>(p.O + off + d);
+        s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+        *reinterpret_cast<uint2*>(dOh + off + d) = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+    }
+    s = wave_sum(s);
+    if (lane == 0) p.delta[row] = s * (1.f - p.drop_p);
+}
+
+template <int DK>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p) {
+    constexpr int BC = 32, DT = DK / 32;
+    constexpr int TB = BC * DK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* sK = reinterpret_cast<uint4*>(smem);
+    uint4* sV = reinterpret_cast<uint4*>(smem + TB);
+    uint2* sKt = reinterpret_cast<uint2*>(smem + 2 * TB);
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 3 * TB);
+    int* sFlag = reinterpret_cast<int*>(sMask + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 32 + l31;
+    const bool qok = q < p.Sq;
+    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+
+    bf16x8 qf[DK / 16], dof[DK / 16];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * half;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * half;
+#pragma unroll
+        for (int s = 0; s < DK / 16; ++s) {
+            qf[s] = ldfrag(p.Qh + qo + 16 * s, qok);
+            dof[s] = ldfrag(p.dOh + oo + 16 * s, qok);
+        }
+    }
+    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
+    const float lse = qok ? p.lse[stat] : 0.f;
+    const float delta = qok ? p.delta[stat] : 0.f;
+
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    uint4 kv[rows_n<DK, BC>()], vv[rows_n<DK, BC>()];
+    uint2 ktv[rowsT_n<DK, BC>() * 4];
+    const int ntile = (p.Sk + BC - 1) / BC;
+    tile_gload<DK, BC>(p.Kh + koff, p.ldk, 0, p.Sk, tid, kv);
+    tile_gload<DK, BC>(p.Vh + voff, p.ldv, 0, p.Sk, tid, vv);
+    tileT_gload<DK, BC>(p.Kh + koff, p.ldk, 0, p.Sk, tid, ktv);
+    for (int t = 0; t < ntile; ++t) {
+        const int key0 = t * BC;
+        tile_lstore<DK, BC>(sK, tid, kv);
+        tile_lstore<DK, BC>(sV, tid, vv);
+        tileT_lstore<DK, BC>(sKt, tid, ktv);
+        stage_mask<BC>(p, b, key0, tid, sMask, sFlag);
+        __syncthreads();
+        if (t + 1 < ntile) {
+            tile_gload<DK, BC>(p.Kh + koff, p.ldk, key0 + BC, p.Sk, tid, kv);
+            tile_gload<DK, BC>(p.Vh + voff, p.ldv, key0 + BC, p.Sk, tid, vv);
+            tileT_gload<DK, BC>(p.Kh + koff, p.ldk, key0 + BC, p.Sk, tid, ktv);
+        }
+        const int flag = sFlag[0];
+        if (flag != 0) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < DK / 16; ++s) {
+                const int idx = kslot<DK>(l31, 2 * s + half);
+                st = mfma32(as_bf16x8(sK[idx]), qf[s], st);
+                dp = mfma32(as_bf16x8(sV[idx]), dof[s], dp);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = qok ? __expf(st[r] * p.scale - lse) : 0.f;
+                ds[r] = pr * (dp[r] - delta) * p.scale;
+            }
+            if (flag != 2) {
+                if (p.mask != nullptr && p.mask_qs != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + acc_row(r, half);
+                        const bool ok = qok && key < p.Sk && p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
+                        ds[r] = ok ? ds[r] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + 8 * g + 4 * half);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ds[4 * g + c] = ((mw >> (8 * c)) & 0xffu) ? ds[4 * g + c] : 0.f;
+                    }
+                }
+            }
+            bf16x8 dsf[2], unused;
+            pack_p<1>(ds, 0, dsf[0], unused);
+            pack_p<1>(ds, 1, dsf[1], unused);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    dq[dt] = mfma32(tfrag<BC>(sKt, dt * 32 + l31, 4 * s2 + half), dsf[s2], dq[dt]);
+        }
+        __syncthreads();
+    }
+    if (qok) {
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;   // dQ is laid out like O (fp32 [B,Sq,D])
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = dt * 32 + 8 * r4 + 4 * half;
+                *reinterpret_cast<float4*>(p.dQ + rowoff + d) =
+                    make_float4(dq[dt][4 * r4 + 0], dq[dt][4 * r4 + 1], dq[dt][4 * r4 + 2], dq[dt][4 * r4 + 3]);
+            }
+    }
+}
+
+// dK/dV: workgroup = 64 keys, 4 waves split by role (0,1: dV of keys [0,32)/[32,64); 2,3: dK), loop over 32-query tiles
+// with the next tile's four images prefetched into registers.   dkv_ld / dkv_bs: strides of the fp32 dK / dV outputs.
+template <int DK>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB p, int64_t dkv_ld, int64_t dkv_bs) {
+    constexpr int BQ = 32, DT = DK / 32, KB = 64;
+    constexpr int TB = BQ * DK * 2;
+    constexpr int KVB = KB * DK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* sK = reinterpret_cast<uint4*>(smem);
+    uint4* sV = reinterpret_cast<uint4*>(smem + KVB);
+    uint4* sQ = reinterpret_cast<uint4*>(smem + 2 * KVB);
+    uint4* sdO = reinterpret_cast<uint4*>(smem + 2 * KVB + TB);
+    uint2* sQt = reinterpret_cast<uint2*>(smem + 2 * KVB + 2 * TB);
+    uint2* sdOt = reinterpret_cast<uint2*>(smem + 2 * KVB + 3 * TB);
+    float* sLse = reinterpret_cast<float*>(smem + 2 * KVB + 4 * TB);
+    float* sDelta = sLse + BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int role = __builtin_amdgcn_readfirstlane(wid >> 1);
+    const int kgrp = __builtin_amdgcn_readfirstlane(wid & 1);
+    const int nkt = (p.Sk + KB - 1) / KB;
+    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    const int kt = w % nkt, bh = w / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int key = kt * KB + kgrp * 32 + l31;
+    const bool kok = key < p.Sk;
+
+    const uint16_t* Qb = p.Qh + (int64_t)b * p.bsq + h * DK;
+    const uint16_t* dOb = p.dOh + (int64_t)b * p.bso + h * DK;
+
+    bool kmask = kok;
+    if (kok && p.mask != nullptr && p.mask_qs == 0) kmask = p.mask[(int64_t)b * p.mask_bs + key] != 0;
+    float* dst = (role == 1 ? p.dK : p.dV) + (int64_t)b * dkv_bs + (int64_t)key * dkv_ld + h * DK;
+    if (__syncthreads_or(kmask ? 1 : 0) == 0) {   // every key of this workgroup is masked: gradients are exactly zero
+        if (kok) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    *reinterpret_cast<float4*>(dst + dt * 32 + 8 * r4 + 4 * half) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    {
+        uint4 tmp[rows_n<DK, KB>()];
+        tile_gload<DK, KB>(p.Kh + (int64_t)b * p.bsk + h * DK, p.ldk, kt * KB, p.Sk, tid, tmp);
+        tile_lstore<DK, KB>(sK, tid, tmp);
+        tile_gload<DK, KB>(p.Vh + (int64_t)b * p.bsv + h * DK, p.ldv, kt * KB, p.Sk, tid, tmp);
+        tile_lstore<DK, KB>(sV, tid, tmp);
+    }
+    const int myrow = kgrp * 32 + l31;
+
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+    uint4 rq[rows_n<DK, BQ>()], rdo[rows_n<DK, BQ>()];
+    uint2 rqt[rowsT_n<DK, BQ>() * 4], rdot[rowsT_n<DK, BQ>() * 4];
+    float rl = 0.f, rd = 0.f;
+    const int ntile = (p.Sq + BQ - 1) / BQ;
+#define BMT_FETCH(q0_)                                                             \
+    do {                                                                           \
+        tile_gload<DK, BQ>(Qb, p.ldq, (q0_), p.Sq, tid, rq);                       \
+        tile_gload<DK, BQ>(dOb, p.ldo, (q0_), p.Sq, tid, rdo);                     \
+        tileT_gload<DK, BQ>(Qb, p.ldq, (q0_), p.Sq, tid, rqt);                     \
+        tileT_gload<DK, BQ>(dOb, p.ldo, (q0_), p.Sq, tid, rdot);                   \
+        if (tid < BQ) {                                                            \
+            const int qq_ = (q0_) + tid;                                           \
+            const int64_t stat_ = ((int64_t)b * p.H + h) * p.Sq + qq_;             \
+            rl = (qq_ < p.Sq) ? p.lse[stat_] : 0.f;                                \
+            rd = (qq_ < p.Sq) ? p.delta[stat_] : 0.f;                              \
+        }                                                                          \
+    } while (0)
+    BMT_FETCH(0);
+    for (int t = 0; t < ntile; ++t) {
+        const int q0 = t * BQ;
+        __syncthreads();   // previous tile fully consumed (and the K/V images visible on t == 0)
+        tile_lstore<DK, BQ>(sQ, tid, rq);
+        tile_lstore<DK, BQ>(sdO, tid, rdo);
+        tileT_lstore<DK, BQ>(sQt, tid, rqt);
+        tileT_lstore<DK, BQ>(sdOt, tid, rdot);
+        if (tid < BQ) { sLse[tid] = rl; sDelta[tid] = rd; }
+        __syncthreads();
+        if (t + 1 < ntile) BMT_FETCH(q0 + BQ);
+        f32x16 sacc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < DK / 16; ++s) {
+            const int ia = kslot<DK>(l31, 2 * s + half), ib = kslot<DK>(myrow, 2 * s + half);
+            sacc = mfma32(as_bf16x8(sQ[ia]), as_bf16x8(sK[ib]), sacc);
+            if (role == 1) dp = mfma32(as_bf16x8(sdO[ia]), as_bf16x8(sV[ib]), dp);
+        }
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql_ = acc_row(r, half);
+            const int qq = q0 + ql_;
+            bool ok = kmask && qq < p.Sq;
+            if (ok && p.mask != nullptr && p.mask_qs != 0)
+                ok = p.mask[(int64_t)b * p.mask_bs + (int64_t)qq * p.mask_qs + key] != 0;
+            pr[r] = ok ? __expf(sacc[r] * p.scale - sLse[ql_]) : 0.f;
+            if (role == 1) pr[r] = pr[r] * (dp[r] - sDelta[ql_]) * p.scale;
+        }
+        bf16x8 bf[2], unused;
+        pack_p<1>(pr, 0, bf[0], unused);
+        pack_p<1>(pr, 1, bf[1], unused);
+        const uint2* timg = (role == 1) ? sQt : sdOt;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                acc[dt] = mfma32(tfrag<BQ>(timg, dt * 32 + l31, 4 * s2 + half), bf[s2], acc[dt]);
+    }
+#undef BMT_FETCH
+    if (kok) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = dt * 32 + 8 * r4 + 4 * half;
+                *reinterpret_cast<float4*>(dst + d) =
+                    make_float4(acc[dt][4 * r4 + 0], acc[dt][4 * r4 + 1], acc[dt][4 * r4 + 2], acc[dt][4 * r4 + 3]);
+            }
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int DK, int NPASS>
+int launch_fwd(const AttnPB& p, hipStream_t st) {
+    using G = Geo<DK>;
+    const int lds = (NPASS == 3 ? 2 : 1) * (G::K_BYTES + G::V_BYTES) + 128;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DK, NPASS>), dim3(nblk), dim3(256), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_attn_fwd_bf16");
+    return BMT_OK;
+}
+
+template <int DK>
+int launch_bwd(const AttnPB& p, uint16_t* dOh, int64_t dkv_ld, int64_t dkv_bs, hipStream_t st) {
+    const int64_t rows = (int64_t)p.B * p.H * p.Sq;
+    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
+    {
+        const int lds = 3 * 32 * DK * 2 + 128;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DK>), dim3(nblk), dim3(256), lds, st, p);
+    }
+    {
+        const int lds = 2 * 64 * DK * 2 + 4 * 32 * DK * 2 + 2 * 32 * 4;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        const int nblk = ((p.Sk + 63) / 64) * p.B * p.H;
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DK>), dim3(nblk), dim3(256), lds, st, p, dkv_ld, dkv_bs);
+    }
+    BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16");
+    return BMT_OK;
+}
+
+}  // namespace
+
+extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) {
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->O && a->lse, "bmt_attn_fwd_bf16: null pointer");
+    BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_fwd_bf16: bad sizes");
+    BMT_CHECK_ARG(a->dk == 32 || a->dk == 64 || a->dk == 128 || a->dk == 256, "bmt_attn_fwd_bf16: d_k=%d not in {32,64,128,256}", a->dk);
+    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || (a->precision == BMT_PREC_BF16X3 && a->Ql && a->Kl && a->Vl),
+                  "bmt_attn_fwd_bf16: BF16X3 needs the lo planes");
+    if (!(al16(a->Qh) && al16(a->Kh) && al16(a->Vh) && al16(a->O)) || ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv) & 7) ||
+        ((a->ldo | a->bso) & 3) || (a->Ql && !(al16(a->Ql) && al16(a->Kl) && al16(a->Vl)))) {
+        bmt_set_error("bmt_attn_fwd_bf16: planes must be 16-byte aligned with strides multiples of 8 elements");
+        return BMT_EALIGN;
+    }
+    AttnPB p;
+    memset(&p, 0, sizeof(p));
+    p.Qh = a->Qh; p.Ql = a->Ql; p.Kh = a->Kh; p.Kl = a->Kl; p.Vh = a->Vh; p.Vl = a->Vl;
+    p.Ow = a->O; p.lsew = a->lse;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+    p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.scale = a->scale; p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
+    hipStream_t st = (hipStream_t)stream;
+#define BMT_FWD(D) \
+    if (a->dk == D) return a->precision == BMT_PREC_BF16X3 ? launch_fwd<D, 3>(p, st) : launch_fwd<D, 1>(p, st);
+    BMT_FWD(32) BMT_FWD(64) BMT_FWD(128) BMT_FWD(256)
+#undef BMT_FWD
+    return BMT_EINVAL;
+}
+
+extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) {
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->O && a->dO && a->lse && a->dQ && a->dK && a->dV && a->delta_ws && a->dOh_ws,
+                  "bmt_attn_bwd_bf16: null pointer");
+    BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_bwd_bf16: bad sizes");
+    BMT_CHECK_ARG(a->dk == 32 || a->dk == 64 || a->dk == 128 || a->dk == 256, "bmt_attn_bwd_bf16: d_k=%d not in {32,64,128,256}", a->dk);
+    if (!(al16(a->Qh) && al16(a->Kh) && al16(a->Vh) && al16(a->O) && al16(a->dO) && al16(a->dQ) && al16(a->dK) && al16(a->dV) &&
+          al16(a->dOh_ws)) || ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv | a->ldo | a->bso | a->dkv_ld | a->dkv_bs) & 7)) {
+        bmt_set_error("bmt_attn_bwd_bf16: pointers must be 16-byte aligned with strides multiples of 8 elements");
+        return BMT_EALIGN;
+    }
+    AttnPB p;
+    memset(&p, 0, sizeof(p));
+    p.Qh = a->Qh; p.Kh = a->Kh; p.Vh = a->Vh; p.dOh = a->dOh_ws;
+    p.O = a->O; p.dO = a->dO; p.lse = a->lse; p.dQ = a->dQ; p.dK = a->dK; p.dV = a->dV; p.delta = a->delta_ws;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+    p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.scale = a->scale; p.drop_p = a->drop_p;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
+    if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
+    if (a->dk == 128) return launch_bwd<128>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
+    if (a->dk == 256) return launch_bwd<256>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
+    return BMT_EINVAL;
+}

@@ -6,7 +6,7 @@ OUT=../lib
 mkdir -p "$OUT" "$OUT/obj"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result"
 pids=()
-for f in gemm attention norm elementwise loss optim proposal; do
+for f in gemm attention attention_bf16 norm elementwise loss optim proposal; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$f.hip" -nt "$OUT/obj/$f.o" ] || [ common.h -nt "$OUT/obj/$f.o" ] || [ ../../include/bmt_hip.h -nt "$OUT/obj/$f.o" ]; then
     hipcc $FLAGS -c "$f.hip" -o "$OUT/obj/$f.o" &
     pids+=($!)

@@ -74,6 +74,9 @@ struct GemmP {
     float drop_p;
     const uint64_t* rng;
     uint32_t site;
+    uint16_t* Chi;
+    uint16_t* Clo;
+    int64_t ldp;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -286,7 +289,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
                 if (f & BMT_EPI_GATE) v = (p.gate[(int64_t)row * p.ldg + col] != 0.f) ? v * p.gate_scale : 0.f;
                 if (f & BMT_EPI_RESIDUAL) v += p.residual[(int64_t)row * p.ldr + col];
                 if (f & BMT_EPI_ACCUM) atomicAdd(p.C + idx, v);
-                else p.C[idx] = v;
+                else if (p.C) p.C[idx] = v;
+                if (p.Chi) {
+                    const __bf16 h = (__bf16)v;
+                    const int64_t pi = (int64_t)row * p.ldp + col;
+                    p.Chi[pi] = __builtin_bit_cast(uint16_t, h);
+                    if (p.Clo) p.Clo[pi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+                }
             }
         }
 }
@@ -359,7 +368,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }  // namespace
 
 extern "C" int bmt_gemm(const bmt_gemm_args* a, void* stream) {
-    BMT_CHECK_ARG(a && a->A && a->B && a->C, "bmt_gemm: null pointer");
+    BMT_CHECK_ARG(a && a->A && a->B && (a->C || a->C_hi), "bmt_gemm: null pointer");
+    BMT_CHECK_ARG(!(a->flags & BMT_EPI_ACCUM) || a->C, "bmt_gemm: ACCUM needs the fp32 output");
     GemmP p;
     memset(&p, 0, sizeof(p));
     p.a = Operand{a->A, a->lda, a->M, 0, 1, 1, 1, 0};
@@ -370,6 +380,7 @@ extern "C" int bmt_gemm(const bmt_gemm_args* a, void* stream) {
     p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias;
     p.residual = a->residual; p.ldr = a->ldr; p.gate = a->gate; p.ldg = a->ldg; p.gate_scale = a->gate_scale;
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
+    p.Chi = a->C_hi; p.Clo = a->C_lo; p.ldp = a->ldp;
     return launch_gemm(p, a->a_kcontig ? OP_KC : OP_RC, a->b_kcontig ? OP_KC : OP_RC, a->precision,
                        a->splitk < 1 ? 1 : a->splitk, (hipStream_t)stream);
 }

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROP_POST, EPI_DROP_PRE, EPI_GATE, EPI_RELU, EPI_RESIDUAL, PREC_BF16,
-                   PREC_BF16X3, AttnBwdArgs, AttnFwdArgs, Conv1dArgs, GemmArgs)
+                   PREC_BF16X3, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, Conv1dArgs, GemmArgs)
 
 lib = _lib.load()
 
@@ -78,7 +78,7 @@ def new_site() -> int:
 # ----------------------------------------------------------------------------- raw launches
 def gemm(A, B, C_out, M, N, K, *, lda, ldb, ldc, a_kc=True, b_kc=True, alpha=1.0, bias=None, relu=False,
          drop_pre=False, drop_post=False, drop_p=0.0, site=0, residual=None, ldr=0, gate=None, ldg=0, gate_scale=1.0,
-         accum=False, splitk=1, precision=None):
+         accum=False, splitk=1, precision=None, C_hi=None, C_lo=None, ldp=0):
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -97,7 +97,8 @@ def gemm(A, B, C_out, M, N, K, *, lda, ldb, ldc, a_kc=True, b_kc=True, alpha=1.0
         flags |= EPI_ACCUM
     a = GemmArgs(_p(A), lda, int(a_kc), _p(B), ldb, int(b_kc), _p(C_out), ldc, M, N, K, alpha, flags, _p(bias),
                  _p(residual), ldr, _p(gate), ldg, gate_scale, drop_p if use_drop else 0.0,
-                 _p(rng_tensor()) if use_drop else None, site, precision or FWD_PRECISION, splitk)
+                 _p(rng_tensor()) if use_drop else None, site, precision or FWD_PRECISION, splitk,
+                 _p(C_hi), _p(C_lo), ldp)
     _lib.check(lib.bmt_gemm(C.byref(a), _st()), "bmt_gemm")
 
 
@@ -116,6 +117,17 @@ def linear_fwd(x2: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out
         out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
     gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=b, **epi)
     return out
+
+
+def linear_fwd_planes(x2: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], want_lo: bool = True):
+    """(hi, lo) bf16 operand planes of x2 @ W^T + b, written straight from the GEMM epilogue (no fp32 copy in HBM):
+    hi = bf16(y), lo = bf16(y - hi).  Consumed by the attention kernels as MFMA operands."""
+    M, K = x2.shape
+    N = W.shape[0]
+    hi = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16)
+    lo = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16) if want_lo else None
+    gemm(x2, W, None, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=N, bias=b, C_hi=hi, C_lo=lo, ldp=N)
+    return hi, lo
 
 
 def linear_dx(dy2: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
@@ -194,6 +206,42 @@ def attn_bwd(q, k, v, o, do, lse, mask, H, drop_p=0.0):
                     q.stride(1), k.stride(1), v.stride(1), o.stride(1), q.stride(0), k.stride(0), v.stride(0), o.stride(0),
                     mptr, mbs, mqs, B, H, Sq, Sk, dk, 1.0 / math.sqrt(dk), drop_p)
     _lib.check(lib.bmt_attn_bwd(C.byref(a), _st()), "bmt_attn_bwd")
+    return dq, dk_, dv
+
+
+def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision=None):
+    """planes (B,S,D) bf16 -> o (B,Sq,D) fp32 post-dropout, lse (B,H,Sq)."""
+    B, Sq, D = qh.shape
+    Sk = kh.shape[1]
+    dk = D // H
+    prec = precision or FWD_PRECISION
+    o = torch.empty(B, Sq, D, device=qh.device, dtype=torch.float32)
+    lse = torch.empty(B, H, Sq, device=qh.device, dtype=torch.float32)
+    keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    use_drop = drop_p > 0.0
+    x3 = prec == PREC_BF16X3
+    a = AttnFwdBf16Args(_p(qh), _p(ql) if x3 else None, _p(kh), _p(kl) if x3 else None, _p(vh), _p(vl) if x3 else None,
+                        _p(o), _p(lse), qh.stride(1), kh.stride(1), vh.stride(1), o.stride(1),
+                        qh.stride(0), kh.stride(0), vh.stride(0), o.stride(0), mptr, mbs, mqs, B, H, Sq, Sk, dk,
+                        1.0 / math.sqrt(dk), drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec)
+    _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
+    return o, lse
+
+
+def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, drop_p=0.0):
+    B, Sq, D = qh.shape
+    Sk = kh.shape[1]
+    dk = D // H
+    dq = torch.empty(B, Sq, D, device=qh.device, dtype=torch.float32)
+    dk_ = torch.empty(B, Sk, D, device=qh.device, dtype=torch.float32)
+    dv = torch.empty(B, Sk, D, device=qh.device, dtype=torch.float32)
+    delta = torch.empty(B, H, Sq, device=qh.device, dtype=torch.float32)
+    doh = torch.empty(B, Sq, D, device=qh.device, dtype=torch.bfloat16)
+    keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    a = AttnBwdBf16Args(_p(qh), _p(kh), _p(vh), _p(o), _p(do), _p(lse), _p(dq), _p(dk_), _p(dv), _p(delta), _p(doh),
+                        qh.stride(1), kh.stride(1), vh.stride(1), o.stride(1), qh.stride(0), kh.stride(0), vh.stride(0),
+                        o.stride(0), dk_.stride(1), dk_.stride(0), mptr, mbs, mqs, B, H, Sq, Sk, dk, 1.0 / math.sqrt(dk), drop_p)
+    _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     return dq, dk_, dv
 
 
@@ -337,16 +385,21 @@ class MHAFn(torch.autograd.Function):
         B, Sq, Dq = Qc.shape
         Sk = Kc.shape[1]
         D = Wq.shape[0]
-        q = linear_fwd(Qc.view(-1, Dq), Wq, bq).view(B, Sq, D)
-        k = linear_fwd(Kc.view(-1, Kc.shape[-1]), Wk, bk).view(B, Sk, D)
-        v = linear_fwd(Vc.view(-1, Vc.shape[-1]), Wv, bv).view(B, Sk, D)
-        o, lse = attn_fwd(q, k, v, mask, H, drop_p=p, site=site)
+        # the projections write bf16 operand planes (hi, lo) straight from the GEMM epilogue; the attention kernels
+        # consume them as MFMA operands without any conversion.  Only the hi planes are kept for backward.
+        x3 = FWD_PRECISION == PREC_BF16X3
+        qh, ql = linear_fwd_planes(Qc.view(-1, Dq), Wq, bq, want_lo=x3)
+        kh, kl = linear_fwd_planes(Kc.view(-1, Kc.shape[-1]), Wk, bk, want_lo=x3)
+        vh, vl = linear_fwd_planes(Vc.view(-1, Vc.shape[-1]), Wv, bv, want_lo=x3)
+        v3 = lambda t, S: None if t is None else t.view(B, S, D)
+        o, lse = attn_fwd_bf16(v3(qh, Sq), v3(ql, Sq), v3(kh, Sk), v3(kl, Sk), v3(vh, Sk), v3(vl, Sk), mask, H,
+                               drop_p=p, site=site)
         out = linear_fwd(o.view(-1, D), Wo, bo).view(B, Sq, Dq)
         ctx.H, ctx.p, ctx.site = H, p, site
         ctx.same_qk = Q is K
         ctx.same_kv = K is V
         ctx.mask = mask
-        ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, q, k, v, o, lse)
+        ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, qh.view(B, Sq, D), kh.view(B, Sk, D), vh.view(B, Sk, D), o, lse)
         return out
 
     @staticmethod
@@ -361,7 +414,7 @@ class MHAFn(torch.autograd.Function):
         dbo = colsum(dy2)
         # gradient w.r.t. the PRE-dropout attention output: the dropout mask is re-applied in the GEMM epilogue
         do = linear_dx(dy2, Wo, drop_post=True, drop_p=ctx.p, site=ctx.site).view(B, Sq, D)
-        dq, dk, dv = attn_bwd(q, k, v, o, do, lse, ctx.mask, ctx.H, drop_p=ctx.p)
+        dq, dk, dv = attn_bwd_bf16(q, k, v, o, do, lse, ctx.mask, ctx.H, drop_p=ctx.p)
         dq2, dk2, dv2 = dq.view(-1, D), dk.view(-1, D), dv.view(-1, D)
         Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
         dWq, dbq = linear_dw(dq2, Q2), colsum(dq2)

@@ -74,6 +74,9 @@ typedef struct {
     float drop_p; const uint64_t* rng; uint32_t site; /* dropout, indexed by m*ldc+n */
     int precision;                         /* BMT_PREC_*                             */
     int splitk;                            /* >=1; >1 needs BMT_EPI_ACCUM only       */
+    /* optional bf16 "operand planes" of the result for the next MFMA consumer: hi = bf16(c), lo = bf16(c - hi);
+     * row stride ldp (elements); C may be NULL when planes are requested; C_lo may be NULL (hi only). */
+    uint16_t* C_hi; uint16_t* C_lo; int64_t ldp;
 } bmt_gemm_args;
 int bmt_gemm(const bmt_gemm_args* args, void* stream);
 
@@ -117,6 +120,37 @@ typedef struct {
     float scale, drop_p;
 } bmt_attn_bwd_args;
 int bmt_attn_bwd(const bmt_attn_bwd_args* args, void* stream);
+
+/*
+ * bmt_attn_fwd_bf16 / bmt_attn_bwd_bf16: the same attention core over PRE-SPLIT bf16 operand planes (hi = bf16(x),
+ * lo = bf16(x - hi)) as written by bmt_gemm's C_hi / C_lo epilogue outputs: no conversion in the K/V loop, half the
+ * staged bytes, per-tile mask classification (fully masked key tiles are skipped, fully valid ones run unmasked).
+ * Plane strides are in bf16 elements and must be multiples of 8; O / dO / dQ are fp32 [B,Sq,H*dk] (ldo, bso),
+ * dK / dV fp32 with (dkv_ld, dkv_bs).  Backward reads hi planes only (single-pass bf16); dOh_ws: bf16 workspace the size of O.
+ */
+typedef struct {
+    const uint16_t *Qh, *Ql, *Kh, *Kl, *Vh, *Vl;      /* lo planes may be NULL for BMT_PREC_BF16 */
+    float* O; float* lse;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
+    const uint8_t* mask; int64_t mask_bs, mask_qs;
+    int B, H, Sq, Sk, dk;
+    float scale;
+    float drop_p; const uint64_t* rng; uint32_t site;
+    int precision;
+} bmt_attn_fwd_bf16_args;
+int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* args, void* stream);
+
+typedef struct {
+    const uint16_t *Qh, *Kh, *Vh;
+    const float *O, *dO, *lse;
+    float *dQ, *dK, *dV, *delta_ws;
+    uint16_t* dOh_ws;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, dkv_ld, dkv_bs;
+    const uint8_t* mask; int64_t mask_bs, mask_qs;
+    int B, H, Sq, Sk, dk;
+    float scale, drop_p;
+} bmt_attn_bwd_bf16_args;
+int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (model/blocks.py:127,131,143,150) */
 /* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */

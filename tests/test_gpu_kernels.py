@@ -149,6 +149,62 @@ def test_attention_forward(ops, dk, H, B, Sq, Sk, kind, prec):
     assert_close(lse, torch.logsumexp(s, -1), atol=2e-3 if prec == 1 else 2e-4, name="lse")
 
 
+def _planes(t):
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return hi.to(DEV), lo.to(DEV)
+
+
+@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 333, "pad"), (128, 4, 1, 70, 257, "pad")])
+@pytest.mark.parametrize("prec", [1, 3])
+def test_attention_forward_bf16_planes(ops, dk, H, B, Sq, Sk, kind, prec):
+    D = dk * H
+    q, k, v = rnd(B, Sq, D, seed=20), rnd(B, Sk, D, seed=21), rnd(B, Sk, D, seed=22)
+    mask = _masks(kind, B, Sq, Sk)
+    if kind == "pad" and Sk > 100:
+        mask[0, 0, Sk // 3:] = False          # whole key tiles fully masked -> exercises the tile-skip path
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, None if mask is None else mask.to(DEV), H, precision=prec)
+    want = _oracle_attention(q, k, v, mask, H, rounded=(prec == 1))
+    assert_close(o, want, atol=(2e-2 if prec == 1 else 2e-4), rtol=0, name=f"attn(bf16 planes) o dk={dk} {kind} x{prec}")
+    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
+    s = torch.einsum("bqhd,bkhd->bhqk", f(q).view(B, Sq, H, dk), f(k).view(B, Sk, H, dk)) / math.sqrt(dk)
+    if mask is not None:
+        s = s.masked_fill(~mask.unsqueeze(1), -float("inf"))
+    assert_close(lse, torch.logsumexp(s, -1), atol=2e-3 if prec == 1 else 2e-4, name="lse")
+
+
+@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 333, "pad"), (128, 4, 1, 70, 257, "pad")])
+def test_attention_backward_bf16_planes(ops, dk, H, B, Sq, Sk, kind):
+    D = dk * H
+    q, k, v = rnd(B, Sq, D, seed=30), rnd(B, Sk, D, seed=31), rnd(B, Sk, D, seed=32)
+    do = rnd(B, Sq, D, seed=33)
+    mask = _masks(kind, B, Sq, Sk)
+    if kind == "pad" and Sk > 100:
+        mask[0, 0, Sk // 3:] = False
+    md = None if mask is None else mask.to(DEV)
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, md, H, precision=3)
+    dq, dk_, dv = ops.attn_bwd_bf16(qh, kh, vh, o, do.to(DEV), lse, md, H)
+    qr, kr, vr = (t.clone().double().requires_grad_() for t in (q, k, v))
+    want = _oracle_attention(qr, kr, vr, mask, H, rounded=False)
+    (want * do.double()).sum().backward()
+    from tests.gpu_util import report
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk_, kr.grad), ("dv", dv, vr.grad)):
+        e = rel_err(got, ref)
+        assert e < 2e-2, f"{name} dk={dk} {kind}: relative error {e:.3e}\n" + report(got, ref, name)
+
+
+def test_gemm_plane_outputs(ops):
+    M, N, K = 150, 96, 64
+    x, W, b = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9)
+    hi, lo = ops.linear_fwd_planes(x.to(DEV), W.to(DEV), b.to(DEV))
+    want = x.double() @ W.double().t() + b.double()
+    assert hi.dtype == torch.bfloat16
+    assert_close(hi.float(), want, atol=1e-6, rtol=2 ** -8, name="hi plane")
+    assert_close(hi.float().double() + lo.float().double(), want, atol=3e-4, rtol=2e-5, name="hi+lo planes")
+
+
 def test_attention_fully_masked_row_is_nan(ops):
     q, k, v = rnd(1, 4, 64, seed=1), rnd(1, 6, 64, seed=2), rnd(1, 6, 64, seed=3)
     mask = torch.ones(1, 4, 6, dtype=torch.bool)

@@ -11,7 +11,7 @@ run() { # name, timeout, pytest selection...
 }
 rm -f gpurun_out/summary.txt
 run gemm 300 tests/test_gpu_kernels.py -k "gemm"
-run attn_fwd 300 tests/test_gpu_kernels.py -k "attention_forward or fully_masked"
+run attn_fwd 300 tests/test_gpu_kernels.py -k "attention_forward or fully_masked or plane_outputs"
 run attn_bwd 300 tests/test_gpu_kernels.py -k "attention_backward or attention_dropout"
 run misc 300 tests/test_gpu_kernels.py -k "not gemm and not attention"
 run model 600 tests/test_gpu_model.py

@@ -57,14 +57,20 @@ def attn_bench(bwd=False):
         mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=DEV)
         mask[:, :, Sk - Sk // 5:] = False
         fl = 4.0 * B * Sq * Sk * D
+        pl = lambda t: (t.to(torch.bfloat16), (t - t.to(torch.bfloat16).float()).to(torch.bfloat16))
+        (qh, ql), (kh, kl), (vh, vl) = pl(q), pl(k), pl(v)
         if not bwd:
             for prec in (3, 1):
-                timeit(lambda: ops.attn_fwd(q, k, v, mask, H, precision=prec), fl, f"attn_fwd x{prec} {name}")
-            timeit(lambda: ops.attn_fwd(q, k, v, None, H, precision=3), fl, f"attn_fwd x3 nomask {name}")
+                if "v1" in sys.argv:
+                    timeit(lambda: ops.attn_fwd(q, k, v, mask, H, precision=prec), fl, f"attn_fwd  fp32-in x{prec} {name}")
+                timeit(lambda: ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, precision=prec), fl, f"attn_fwd  planes  x{prec} {name}")
+            timeit(lambda: ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, None, H, precision=3), fl, f"attn_fwd  planes  x3 nomask {name}")
         else:
-            o, lse = ops.attn_fwd(q, k, v, mask, H, precision=3)
+            o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, precision=3)
             do = torch.randn_like(o)
-            timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, mask, H), 2.5 * fl, f"attn_bwd x1 {name}")
+            if "v1" in sys.argv:
+                timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, mask, H), 2.5 * fl, f"attn_bwd  fp32-in x1 {name}")
+            timeit(lambda: ops.attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H), 2.5 * fl, f"attn_bwd  planes  x1 {name}")
 
 
 if __name__ == "__main__":
