@@ -82,7 +82,50 @@ class KernelTimer:
                 (s, e, 10.0 * B_ * Sq * Sk * D, 4.0 * B_ * D * (4 * Sq + 4 * Sk)))
             return r
 
+        raw_gb, raw_afb, raw_abb = ops.gemm_bf16, ops.attn_fwd_bf16, ops.attn_bwd_bf16
+
+        def gemm_bf16(A, B, C_out, **kw):
+            if not timer.enabled:
+                return raw_gb(A, B, C_out, **kw)
+            prec = kw.get("precision") or ops.FWD_PRECISION
+            M, N, K = A.rows, B.rows, A.cols
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_gb(A, B, C_out, **kw)
+            e.record()
+            nb = 2 * prec if prec == 3 else 2
+            timer.records.setdefault(f"gemm_planes_x{prec}", []).append((s, e, 2.0 * M * N * K, nb * (M * K + N * K) + 4.0 * M * N))
+            return r
+
+        def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, **kw):
+            if not timer.enabled:
+                return raw_afb(qh, ql, kh, kl, vh, vl, mask, H, **kw)
+            B_, Sq, D = qh.shape
+            Sk = kh.shape[1]
+            prec = kw.get("precision") or ops.FWD_PRECISION
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_afb(qh, ql, kh, kl, vh, vl, mask, H, **kw)
+            e.record()
+            timer.records.setdefault(f"attn_fwd_planes_dk{D // H}_x{prec}", []).append(
+                (s, e, 4.0 * B_ * Sq * Sk * D, (4.0 if prec == 3 else 2.0) * B_ * D * (Sq + 2 * Sk) + 4.0 * B_ * D * Sq))
+            return r
+
+        def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, **kw):
+            if not timer.enabled:
+                return raw_abb(qh, kh, vh, o, do, lse, mask, H, **kw)
+            B_, Sq, D = qh.shape
+            Sk = kh.shape[1]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_abb(qh, kh, vh, o, do, lse, mask, H, **kw)
+            e.record()
+            timer.records.setdefault(f"attn_bwd_planes_dk{D // H}", []).append(
+                (s, e, 10.0 * B_ * Sq * Sk * D, B_ * D * (2.0 * (Sq + 2 * Sk) + 8.0 * Sq + 4.0 * (Sq + 2 * Sk))))
+            return r
+
         ops.gemm, ops.attn_fwd, ops.attn_bwd = gemm, attn_fwd, attn_bwd
+        ops.gemm_bf16, ops.attn_fwd_bf16, ops.attn_bwd_bf16 = gemm_bf16, attn_fwd_bf16, attn_bwd_bf16
 
     def summary(self):
         out = {}
@@ -158,6 +201,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--fwd-precision", type=int, default=3, choices=[1, 3])
+    ap.add_argument("--fp32-staged-gemm", action="store_true", help="A/B: use the fp32-operand GEMM (csrc/gemm.hip)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -180,6 +224,7 @@ def main():
     from bmt_amd.train import CaptioningTrainStep
 
     ops.set_precision(fwd=args.fwd_precision, bwd=1)
+    ops.USE_PLANE_GEMM = not args.fp32_staged_gemm
     V, Tv, Ta, Tc, B = 10000, 256, 800, 30, args.batch
     cfg = syn.cfg_config1(dout_p=0.1)
     cfg.device = str(dev)
@@ -260,7 +305,7 @@ def main():
                                "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
                                "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                "share_of_timed_kernels": d["ms"] / tot,
-                               "mfma_passes": 3 if dom.endswith("x3") else 1}
+                               "mfma_passes": 3 if dom.endswith("x3") else 1, "gemm_path": "planes" if ops.USE_PLANE_GEMM else "fp32-staged"}
             out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                          "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches_per_step": v["launches"] / args.steps}
                                      for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}

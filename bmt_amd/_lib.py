@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbmt_hip.so")
+LIB_PATH = os.environ.get("BMT_LIB_PATH") or os.path.join(_HERE, "lib", "libbmt_hip.so")   # override: A/B builds only
 
 PREC_BF16, PREC_BF16X3 = 1, 3
 EPI_BIAS, EPI_RELU, EPI_DROP_PRE, EPI_DROP_POST, EPI_RESIDUAL, EPI_GATE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
@@ -29,6 +29,14 @@ class GemmArgs(C.Structure):
                 ("drop_p", f32), ("rng", vp), ("site", u32),
                 ("precision", i32), ("splitk", i32),
                 ("C_hi", vp), ("C_lo", vp), ("ldp", i64)]
+
+
+class GemmBf16Args(C.Structure):
+    _fields_ = [("A_hi", vp), ("A_lo", vp), ("lda", i64), ("B_hi", vp), ("B_lo", vp), ("ldb", i64),
+                ("C", vp), ("ldc", i64), ("C_hi", vp), ("C_lo", vp), ("ldp", i64),
+                ("M", i32), ("N", i32), ("Kpad", i32), ("alpha", f32), ("flags", C.c_uint),
+                ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
+                ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -82,6 +90,9 @@ SIGNATURES = {
     "bmt_last_error": (C.c_char_p, []),
     "bmt_device_cus": (i32, []),
     "bmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "bmt_gemm_bf16": (i32, [C.POINTER(GemmBf16Args), vp]),
+    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp]),
+    "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),

@@ -1,0 +1,344 @@
+// bmt_gemm_bf16 / bmt_planes -- MFMA GEMM over PRE-SPLIT bf16 operand planes, and the kernels that make the planes.
+//
+// Why a second GEMM: in gemm.hip the x1 and x3 variants of one shape take the same time
+// (profiles/r01_b_microbench.txt) -- it is bound by staging fp32 operands (64 KB per 128x128x64 stage through L2->LDS, plus
+// the conversion VALU), not by the matrix pipe.  Here every operand is converted ONCE per tensor into bf16 planes
+// (hi = bf16(x), lo = bf16(x - hi)), reduction index contiguous and zero-padded to a multiple of 64, so the main loop is
+// nothing but {16-byte global loads -> ds_write_b128 -> ds_read_b128 -> MFMA}: half the bytes, no conversion, no edge
+// branches (rows are clamped, the K tail is zero padding).
+//
+//   tile 128x128, 4 waves (2x2), 64x64 per wave = 2x2 v_mfma_f32_32x32x16_bf16; stage = 32 KB in both precisions
+//   (x1: BK = 64 of one plane per operand, x3: BK = 32 of hi+lo planes), LDS double-buffered (64 KB -> 2 workgroups/CU),
+//   ONE barrier per stage: global loads for stage t+1 are issued before the MFMAs of stage t and written to the other
+//   buffer after them.  16-B LDS slots XOR-swizzled so ds_read_b128 operand reads are conflict-free.
+//   Tile order: XCD-aware remap, then 8-row-panel groups, so the 64 workgroups resident on one XCD cover an ~8x8 block
+//   of tiles and both operand panels are re-read from that XCD's 4 MB L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int STAGE_BYTES = 32768;
+
+struct GemmB {
+    const uint16_t *Ah, *Al, *Bh, *Bl;   // planes [M][lda], [N][ldb]; reduction index contiguous, zero padded to Kpad
+    int64_t lda, ldb;
+    float* C;
+    int64_t ldc;
+    uint16_t *Chi, *Clo;
+    int64_t ldp;
+    int plane_cols;                      // planes are written for col < plane_cols (zeros for col >= N)
+    int M, N, Kpad;
+    int tiles_m, tiles_n, kchunk;
+    float alpha;
+    unsigned flags;
+    const float* bias;
+    const float* residual;
+    int64_t ldr;
+    const uint16_t* gate;                // bf16 plane of the saved forward output (relu / dropout backward)
+    int64_t ldg;
+    float gate_scale;
+    float drop_p;
+    const uint64_t* rng;
+    uint32_t site;
+};
+
+// LDS slot of (row, 16-byte slot) for rows of SPR slots
+template <int SPR>
+__device__ __forceinline__ int slot_of(int row, int s) {
+    if constexpr (SPR == 8) return row * 8 + (s ^ ((row >> 1) & 7));
+    else return row * 4 + (s ^ ((row >> 2) & 3));
+}
+
+// one operand plane, one stage: [128 rows][SPR slots]; thread t moves slots t, t+256, ...
+template <int SPR>
+__device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, int r0, int nrows, int k0, int tid, uint4 (&v)[128 * SPR / 256]) {
+#pragma unroll
+    for (int i = 0; i < 128 * SPR / 256; ++i) {
+        const int c = tid + 256 * i;
+        const int row = min(r0 + c / SPR, nrows - 1);
+        v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k0 + (c % SPR) * 8);
+    }
+}
+template <int SPR>
+__device__ __forceinline__ void plane_lstore(uint4* img, int tid, const uint4 (&v)[128 * SPR / 256]) {
+#pragma unroll
+    for (int i = 0; i < 128 * SPR / 256; ++i) {
+        const int c = tid + 256 * i;
+        img[slot_of<SPR>(c / SPR, c % SPR)] = v[i];
+    }
+}
+
+template <int NPASS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmB p) {
+    constexpr int BK = (NPASS == 3) ? 32 : 64;
+    constexpr int SPR = BK / 8;
+    constexpr int PB = 128 * BK * 2;        // bytes of one plane tile (x1: 16 KB, x3: 8 KB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // tile order: XCD remap, then groups of 8 row panels walked column by column
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int w = xcd_remap(blockIdx.x, ntiles);
+    const int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int g = w / per_group;
+    const int first_m = g * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int wi = w - g * per_group;
+    const int tm = first_m + wi % gsz, tn = wi / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.Kpad, kbeg + p.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[128 * SPR / 256], rb[128 * SPR / 256], ral[128 * SPR / 256], rbl[128 * SPR / 256];
+#define stage_ptr(buf_, which_) reinterpret_cast<uint4*>(smem + (buf_) * STAGE_BYTES + (which_) * PB)
+
+    if (kbeg < kend) {
+        plane_gload<SPR>(p.Ah, p.lda, m0, p.M, kbeg, tid, ra);
+        plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, kbeg, tid, rb);
+        if constexpr (NPASS == 3) {
+            plane_gload<SPR>(p.Al, p.lda, m0, p.M, kbeg, tid, ral);
+            plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, kbeg, tid, rbl);
+        }
+        plane_lstore<SPR>(stage_ptr(0, 0), tid, ra);
+        plane_lstore<SPR>(stage_ptr(0, 1), tid, rb);
+        if constexpr (NPASS == 3) {
+            plane_lstore<SPR>(stage_ptr(0, 2), tid, ral);
+            plane_lstore<SPR>(stage_ptr(0, 3), tid, rbl);
+        }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {   // stage t+1: global -> registers now, registers -> the other LDS buffer after the MFMAs
+            plane_gload<SPR>(p.Ah, p.lda, m0, p.M, k0 + BK, tid, ra);
+            plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, k0 + BK, tid, rb);
+            if constexpr (NPASS == 3) {
+                plane_gload<SPR>(p.Al, p.lda, m0, p.M, k0 + BK, tid, ral);
+                plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, k0 + BK, tid, rbl);
+            }
+        }
+        const uint4* sAh = stage_ptr(buf, 0);
+        const uint4* sBh = stage_ptr(buf, 1);
+        const uint4* sAl = stage_ptr(buf, 2);
+        const uint4* sBl = stage_ptr(buf, 3);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int sl = 2 * s + half;
+            bf16x8 ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ia = slot_of<SPR>(wr * 64 + i * 32 + l31, sl), ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl);
+                ah[i] = as_bf16x8(sAh[ia]);
+                bh[i] = as_bf16x8(sBh[ib]);
+                if constexpr (NPASS == 3) {
+                    al[i] = as_bf16x8(sAl[ia]);
+                    bl[i] = as_bf16x8(sBl[ib]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (NPASS == 3) {
+                        acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);
+                    }
+                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (more) {
+            plane_lstore<SPR>(stage_ptr(buf ^ 1, 0), tid, ra);
+            plane_lstore<SPR>(stage_ptr(buf ^ 1, 1), tid, rb);
+            if constexpr (NPASS == 3) {
+                plane_lstore<SPR>(stage_ptr(buf ^ 1, 2), tid, ral);
+                plane_lstore<SPR>(stage_ptr(buf ^ 1, 3), tid, rbl);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+#undef stage_ptr
+    // ---------------- epilogue (same order as bmt_gemm: alpha, bias, dropout_pre, relu, dropout_post, gate, residual)
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    const unsigned f = p.flags;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + l31;
+            const bool cin = col < p.N;
+            if (!cin && !(p.Chi && col < p.plane_cols)) continue;
+            const float bv = (cin && (f & BMT_EPI_BIAS)) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + acc_row(r, half);
+                if (row >= p.M) continue;
+                float v = 0.f;
+                if (cin) {
+                    v = acc[i][j][r] * p.alpha + bv;
+                    const int64_t idx = (int64_t)row * p.ldc + col;
+                    if (f & BMT_EPI_DROP_PRE) v = drop_apply(dc, v, (uint64_t)idx);
+                    if (f & BMT_EPI_RELU) v = fmaxf(v, 0.f);
+                    if (f & BMT_EPI_DROP_POST) v = drop_apply(dc, v, (uint64_t)idx);
+                    if (f & BMT_EPI_GATE) v = (p.gate[(int64_t)row * p.ldg + col] & 0x7fffu) ? v * p.gate_scale : 0.f;
+                    if (f & BMT_EPI_RESIDUAL) v += p.residual[(int64_t)row * p.ldr + col];
+                    if (f & BMT_EPI_ACCUM) atomicAdd(p.C + idx, v);
+                    else if (p.C) p.C[idx] = v;
+                }
+                if (p.Chi) {
+                    const __bf16 hv = (__bf16)v;
+                    const int64_t pi = (int64_t)row * p.ldp + col;
+                    p.Chi[pi] = __builtin_bit_cast(uint16_t, hv);
+                    if (p.Clo) p.Clo[pi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)hv));
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------- plane construction
+// 64x64 fp32 tile -> bf16 planes, straight (hi/lo [R][ldp]) and/or transposed (hiT/loT [C][ldpT]), zero padded.
+__global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ src, int64_t ld, int R, int C, uint16_t* __restrict__ hi,
+                                                      uint16_t* __restrict__ lo, int64_t ldp, int pcols, uint16_t* __restrict__ hiT,
+                                                      uint16_t* __restrict__ loT, int64_t ldpT, int pcolsT) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 row groups
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        const float v = (r < R && c < C) ? src[(int64_t)r * ld + c] : 0.f;
+        tile[ty * 16 + i][tx] = v;
+        if (hi && r < R && c < pcols) {
+            const __bf16 h = (__bf16)v;
+            hi[(int64_t)r * ldp + c] = __builtin_bit_cast(uint16_t, h);
+            if (lo) lo[(int64_t)r * ldp + c] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+        }
+    }
+    if (hiT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + ty * 16 + i, r = r0 + tx;     // output row = source column c, output column = source row r
+            if (c < C && r < pcolsT) {
+                const float v = tile[tx][ty * 16 + i];
+                const __bf16 h = (__bf16)v;
+                hiT[(int64_t)c * ldpT + r] = __builtin_bit_cast(uint16_t, h);
+                if (loT) loT[(int64_t)c * ldpT + r] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+            }
+        }
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int NPASS>
+int launch(const GemmB& p, int splitk, hipStream_t st) {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(256), 2 * STAGE_BYTES, st, p);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16");
+    return BMT_OK;
+}
+
+}  // namespace
+
+extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
+    BMT_CHECK_ARG(a && a->A_hi && a->B_hi && (a->C || a->C_hi), "bmt_gemm_bf16: null pointer");
+    BMT_CHECK_ARG(a->M > 0 && a->N > 0 && a->Kpad > 0 && a->Kpad % 64 == 0, "bmt_gemm_bf16: bad sizes M=%d N=%d Kpad=%d (Kpad %% 64 != 0?)",
+                  a->M, a->N, a->Kpad);
+    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || (a->precision == BMT_PREC_BF16X3 && a->A_lo && a->B_lo),
+                  "bmt_gemm_bf16: BF16X3 needs both lo planes");
+    BMT_CHECK_ARG(a->lda >= a->Kpad && a->ldb >= a->Kpad, "bmt_gemm_bf16: plane row stride smaller than Kpad");
+    if (!(al16(a->A_hi) && al16(a->B_hi)) || ((a->lda | a->ldb) & 7) || (a->A_lo && !al16(a->A_lo)) || (a->B_lo && !al16(a->B_lo))) {
+        bmt_set_error("bmt_gemm_bf16: planes must be 16-byte aligned with row strides multiples of 8 elements");
+        return BMT_EALIGN;
+    }
+    int splitk = a->splitk < 1 ? 1 : a->splitk;
+    const unsigned nonlin = BMT_EPI_RELU | BMT_EPI_DROP_PRE | BMT_EPI_DROP_POST | BMT_EPI_GATE | BMT_EPI_BIAS | BMT_EPI_RESIDUAL;
+    BMT_CHECK_ARG(splitk == 1 || ((a->flags & BMT_EPI_ACCUM) && !(a->flags & nonlin) && !a->C_hi),
+                  "bmt_gemm_bf16: splitk>1 needs BMT_EPI_ACCUM and no other epilogue op / plane output");
+    BMT_CHECK_ARG(!(a->flags & BMT_EPI_ACCUM) || a->C, "bmt_gemm_bf16: ACCUM needs the fp32 output");
+    BMT_CHECK_ARG(!(a->flags & BMT_EPI_BIAS) || a->bias, "bmt_gemm_bf16: BIAS flag without pointer");
+    BMT_CHECK_ARG(!(a->flags & BMT_EPI_RESIDUAL) || a->residual, "bmt_gemm_bf16: RESIDUAL flag without pointer");
+    BMT_CHECK_ARG(!(a->flags & BMT_EPI_GATE) || a->gate, "bmt_gemm_bf16: GATE flag without pointer");
+    GemmB p;
+    memset(&p, 0, sizeof(p));
+    p.Ah = a->A_hi; p.Al = a->A_lo; p.Bh = a->B_hi; p.Bl = a->B_lo; p.lda = a->lda; p.ldb = a->ldb;
+    p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_lo; p.ldp = a->ldp;
+    p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
+    p.M = a->M; p.N = a->N; p.Kpad = a->Kpad;
+    p.tiles_m = bmt_cdiv(a->M, BM);
+    p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
+    const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
+    const int ktiles = a->Kpad / bk;
+    if (splitk > ktiles) splitk = ktiles;
+    p.kchunk = bmt_cdiv(ktiles, splitk) * bk;
+    splitk = bmt_cdiv(a->Kpad, p.kchunk);
+    p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
+    p.gate = a->gate; p.ldg = a->ldg; p.gate_scale = a->gate_scale;
+    p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
+    return a->precision == BMT_PREC_BF16X3 ? launch<3>(p, splitk, (hipStream_t)stream) : launch<1>(p, splitk, (hipStream_t)stream);
+}
+
+extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
+                          uint16_t* loT, int64_t ldpT, void* stream) {
+    BMT_CHECK_ARG(src && (hi || hiT) && R > 0 && C > 0, "bmt_planes: bad args");
+    BMT_CHECK_ARG(!hi || ldp >= C, "bmt_planes: ldp < C");
+    BMT_CHECK_ARG(!hiT || ldpT >= R, "bmt_planes: ldpT < R");
+    // padding written with zeros: up to the next multiple of 64 (bounded by the row stride)
+    const int pcols = hi ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
+    const int pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
+    const int gx = bmt_cdiv(pcols > C ? pcols : C, 64), gy = bmt_cdiv(pcolsT > R ? pcolsT : R, 64);
+    hipLaunchKernelGGL(planes_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, ld, R, C, hi, lo, ldp, pcols, hiT, loT, ldpT, pcolsT);
+    BMT_CHECK_LAUNCH("bmt_planes");
+    return BMT_OK;
+}
+
+// bf16 [R][ld] -> transposed bf16 [C][ldT] (zero padded up to min(round_up(R,64), ldT)): operand planes of saved activations
+// (FFN hidden) for the weight-gradient GEMM, whose reduction runs over rows.
+namespace {
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ src, int64_t ld, int R, int C,
+                                                              uint16_t* __restrict__ dst, int64_t ldT, int pcolsT) {
+    __shared__ uint16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        tile[ty * 16 + i][tx] = (r < R && c < C) ? src[(int64_t)r * ld + c] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (c < C && r < pcolsT) dst[(int64_t)c * ldT + r] = tile[tx][ty * 16 + i];
+    }
+}
+}  // namespace
+
+extern "C" int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C, uint16_t* dst, int64_t ldT, void* stream) {
+    BMT_CHECK_ARG(src && dst && R > 0 && C > 0 && ldT >= R, "bmt_transpose_bf16: bad args");
+    const int pcolsT = (int)(((R + 63) / 64 * 64) < ldT ? ((R + 63) / 64 * 64) : ldT);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(bmt_cdiv(C, 64), bmt_cdiv(pcolsT, 64)), dim3(256), 0, (hipStream_t)stream, src, ld, R, C,
+                       dst, ldT, pcolsT);
+    BMT_CHECK_LAUNCH("bmt_transpose_bf16");
+    return BMT_OK;
+}

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROP_POST, EPI_DROP_PRE, EPI_GATE, EPI_RELU, EPI_RESIDUAL, PREC_BF16,
-                   PREC_BF16X3, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, Conv1dArgs, GemmArgs)
+                   PREC_BF16X3, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, Conv1dArgs, GemmArgs, GemmBf16Args)
 
 lib = _lib.load()
 
@@ -27,6 +27,12 @@ BWD_PRECISION = PREC_BF16
 def set_precision(fwd: int = PREC_BF16X3, bwd: int = PREC_BF16):
     global FWD_PRECISION, BWD_PRECISION
     FWD_PRECISION, BWD_PRECISION = fwd, bwd
+
+
+# GEMM path: True = operands pre-split into bf16 planes once per tensor (csrc/gemm_bf16.hip); False = the fp32-operand
+# kernel that converts while staging (csrc/gemm.hip).  Same arithmetic, same results to rounding; kept switchable for A/B.
+USE_PLANE_GEMM = True
+WEIGHT_EPOCH = [0]      # bumped by the optimizer: invalidates cached weight planes
 
 
 # ----------------------------------------------------------------------------- plumbing
@@ -109,48 +115,202 @@ def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     return max(1, min(want, (red + 255) // 256))
 
 
-def linear_fwd(x2: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, **epi):
-    """y[M,N] = epilogue(x2[M,K] @ W[N,K]^T + b)."""
-    M, K = x2.shape
-    N = W.shape[0]
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class Planes:
+    """bf16 operand planes of an fp32 [rows, cols] tensor: hi = bf16(x), lo = bf16(x - hi) (optional), row stride padded
+    to a multiple of 64 with zeros (the reduction extent of the consuming GEMM)."""
+    __slots__ = ("hi", "lo", "rows", "cols")
+
+    def __init__(self, hi, lo, rows, cols):
+        self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
+
+
+def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transposed: bool = False):
+    """one pass over fp32 x2 [R,C]: -> Planes [R][pad64(C)] (hi[,lo]) and/or transposed hi plane [C][pad64(R)]"""
+    R, Cc = x2.shape
+    hi = lo_ = hiT = None
+    if straight:
+        hi = torch.empty(R, _pad64(Cc), device=x2.device, dtype=torch.bfloat16)
+        lo_ = torch.empty(R, _pad64(Cc), device=x2.device, dtype=torch.bfloat16) if lo else None
+    if transposed:
+        hiT = torch.empty(Cc, _pad64(R), device=x2.device, dtype=torch.bfloat16)
+    _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _st()), "bmt_planes")
+    return (Planes(hi, lo_, R, Cc) if straight else None), (Planes(hiT, None, Cc, R) if transposed else None)
+
+
+def transpose_plane(pl: Planes) -> Planes:
+    """hi plane [R][.] -> transposed hi plane [C][pad64(R)]"""
+    dst = torch.empty(pl.cols, _pad64(pl.rows), device=pl.hi.device, dtype=torch.bfloat16)
+    _lib.check(lib.bmt_transpose_bf16(_p(pl.hi), pl.hi.stride(0), pl.rows, pl.cols, _p(dst), dst.stride(0), _st()), "bmt_transpose_bf16")
+    return Planes(dst, None, pl.cols, pl.rows)
+
+
+_wcache = {}
+
+
+def weight_planes(W: torch.Tensor, transposed: bool = False) -> Planes:
+    """planes of a weight [N,K] ([N][pad64(K)] hi+lo) or of its transpose ([K][pad64(N)] hi), cached until the weight
+    changes (optimizer step / in-place update)."""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
+    ver = (WEIGHT_EPOCH[0], W._version)
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    Wc = W.detach()
+    if transposed:
+        _, pl = make_planes(Wc, lo=False, straight=False, transposed=True)
+    else:
+        pl, _ = make_planes(Wc, lo=True)
+    _wcache[key] = (ver, pl)
+    return pl
+
+
+def as_planes(x, need_lo: bool) -> Planes:
+    if isinstance(x, Planes):
+        return x
+    return make_planes(x, lo=need_lo)[0]
+
+
+def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
+              drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=1, precision=None,
+              out_planes: Optional[Planes] = None):
+    """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded)."""
+    M, N = A.rows, B.rows
+    Kpad = A.hi.shape[1]
+    assert B.hi.shape[1] == Kpad, (A.hi.shape, B.hi.shape)
+    prec = precision or FWD_PRECISION
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+    if relu:
+        flags |= EPI_RELU
+    use_drop = drop_p > 0.0 and (drop_pre or drop_post)
+    if use_drop and drop_pre:
+        flags |= EPI_DROP_PRE
+    if use_drop and drop_post:
+        flags |= EPI_DROP_POST
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+    if gate is not None:
+        flags |= EPI_GATE
+    if accum:
+        flags |= EPI_ACCUM
+    x3 = prec == PREC_BF16X3
+    op = out_planes
+    a = GemmBf16Args(_p(A.hi), _p(A.lo) if x3 else None, A.hi.stride(0), _p(B.hi), _p(B.lo) if x3 else None, B.hi.stride(0),
+                     _p(C_out), ldc if C_out is not None else N, _p(op.hi) if op else None, _p(op.lo) if op else None,
+                     op.hi.stride(0) if op else 0, M, N, Kpad, alpha, flags, _p(bias), _p(residual), ldr,
+                     _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
+                     drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec, splitk)
+    _lib.check(lib.bmt_gemm_bf16(C.byref(a), _st()), "bmt_gemm_bf16")
+
+
+def linear_fwd(x, W: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, precision=None, **epi):
+    """y[M,N] = epilogue(x[M,K] @ W[N,K]^T + b);  x: fp32 tensor or Planes."""
+    prec = precision or FWD_PRECISION
+    if not USE_PLANE_GEMM:
+        x2 = x
+        M, K = x2.shape
+        N = W.shape[0]
+        if out is None:
+            out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
+        gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=b, precision=prec, **epi)
+        return out
+    A = as_planes(x, prec == PREC_BF16X3)
+    Bw = weight_planes(W)
     if out is None:
-        out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
-    gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=b, **epi)
+        out = torch.empty(A.rows, W.shape[0], device=W.device, dtype=torch.float32)
+    if "ldg" in epi:
+        epi.pop("ldg")
+    gemm_bf16(A, Bw, out, ldc=out.stride(0), bias=b, precision=prec, **epi)
     return out
 
 
-def linear_fwd_planes(x2: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], want_lo: bool = True):
-    """(hi, lo) bf16 operand planes of x2 @ W^T + b, written straight from the GEMM epilogue (no fp32 copy in HBM):
-    hi = bf16(y), lo = bf16(y - hi).  Consumed by the attention kernels as MFMA operands."""
-    M, K = x2.shape
+def linear_fwd_planes(x, W: torch.Tensor, b: Optional[torch.Tensor], want_lo: bool = True, pad: bool = False, **epi) -> Planes:
+    """bf16 operand planes (hi, lo) of epilogue(x @ W^T + b), written straight from the GEMM epilogue (no fp32 copy in
+    HBM).  pad=False: row stride N (attention operands); pad=True: row stride pad64(N), zero padded (GEMM operands)."""
     N = W.shape[0]
-    hi = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16)
-    lo = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16) if want_lo else None
-    gemm(x2, W, None, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=N, bias=b, C_hi=hi, C_lo=lo, ldp=N)
-    return hi, lo
+    if not USE_PLANE_GEMM:
+        x2 = x
+        M, K = x2.shape
+        ld = _pad64(N) if pad else N
+        mk = torch.zeros if (pad and ld != N) else torch.empty
+        hi = mk(M, ld, device=x2.device, dtype=torch.bfloat16)
+        lo = mk(M, ld, device=x2.device, dtype=torch.bfloat16) if want_lo else None
+        gemm(x2, W, None, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=N, bias=b, C_hi=hi, C_lo=lo, ldp=ld, **epi)
+        return Planes(hi, lo, M, N)
+    A = as_planes(x, FWD_PRECISION == PREC_BF16X3)
+    ld = _pad64(N) if pad else N
+    hi = torch.empty(A.rows, ld, device=W.device, dtype=torch.bfloat16)
+    lo = torch.empty(A.rows, ld, device=W.device, dtype=torch.bfloat16) if want_lo else None
+    op = Planes(hi, lo, A.rows, N)
+    gemm_bf16(A, weight_planes(W), None, bias=b, out_planes=op, **epi)
+    return op
 
 
-def linear_dx(dy2: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
-    """dx[M,K] = dy2[M,N] @ W[N,K]   (reduction over N; W is read with the reduction index strided)."""
-    M, N = dy2.shape
-    K = W.shape[1]
+def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
+    """dx[M,K] = dy[M,N] @ W[N,K]   (reduction over N);  dy: fp32 tensor or Planes (hi)."""
+    if not USE_PLANE_GEMM:
+        dy2 = dy
+        M, N = dy2.shape
+        K = W.shape[1]
+        if out is None:
+            out = torch.empty(M, K, device=dy2.device, dtype=torch.float32)
+        gate = epi.pop("gate", None)
+        if gate is not None:
+            raise RuntimeError("plane gate needs USE_PLANE_GEMM")
+        gemm(dy2, W, out, M, K, N, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), a_kc=True, b_kc=False,
+             precision=BWD_PRECISION, **epi)
+        return out
+    A = as_planes(dy, BWD_PRECISION == PREC_BF16X3)
+    Wt = weight_planes(W, transposed=True)          # [K][pad64(N)]
     if out is None:
-        out = torch.empty(M, K, device=dy2.device, dtype=torch.float32)
-    gemm(dy2, W, out, M, K, N, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), a_kc=True, b_kc=False,
-         precision=BWD_PRECISION, **epi)
+        out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
+    if "ldg" in epi:
+        epi.pop("ldg")
+    gemm_bf16(A, Wt, out, ldc=out.stride(0), precision=BWD_PRECISION, **epi)
     return out
 
 
-def linear_dw(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dW[N,K] = dy2[M,N]^T @ x2[M,K]   (reduction over M, split-K with atomic accumulation)."""
-    M, N = dy2.shape
-    K = x2.shape[1]
+def linear_dw(dyT, xT, N: int = 0, K: int = 0) -> torch.Tensor:
+    """dW[N,K] = dy[M,N]^T @ x[M,K]   (reduction over M, split-K with atomic accumulation).
+    plane path: dyT = transposed hi plane of dy [N][pad64(M)], xT = transposed hi plane of x [K][pad64(M)];
+    fp32 path: dyT = dy2 [M,N], xT = x2 [M,K]."""
+    if not USE_PLANE_GEMM:
+        dy2, x2 = dyT, xT
+        M, N = dy2.shape
+        K = x2.shape[1]
+        sk = _splitk_for(N, K, M)
+        dW = torch.zeros(N, K, device=dy2.device, dtype=torch.float32) if sk > 1 else \
+            torch.empty(N, K, device=dy2.device, dtype=torch.float32)
+        gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=K, a_kc=False, b_kc=False,
+             accum=sk > 1, splitk=sk, precision=BWD_PRECISION)
+        return dW
+    N, K, M = dyT.rows, xT.rows, dyT.cols
     sk = _splitk_for(N, K, M)
-    dW = torch.zeros(N, K, device=dy2.device, dtype=torch.float32) if sk > 1 else \
-        torch.empty(N, K, device=dy2.device, dtype=torch.float32)
-    gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=K, a_kc=False, b_kc=False,
-         accum=sk > 1, splitk=sk, precision=BWD_PRECISION)
+    dW = torch.zeros(N, K, device=dyT.hi.device, dtype=torch.float32) if sk > 1 else \
+        torch.empty(N, K, device=dyT.hi.device, dtype=torch.float32)
+    gemm_bf16(dyT, xT, dW, ldc=K, accum=sk > 1, splitk=sk, precision=PREC_BF16)
     return dW
+
+
+def grad_planes(dy2: torch.Tensor):
+    """(operand for dX, operand for dW) of an upstream gradient, one pass: hi plane and transposed hi plane."""
+    if not USE_PLANE_GEMM:
+        return dy2, dy2
+    return make_planes(dy2, lo=False, straight=True, transposed=True)
+
+
+def input_t(x2):
+    """operand of x for the dW product: transposed hi plane (x2: fp32 tensor or Planes)."""
+    if not USE_PLANE_GEMM:
+        return x2
+    if isinstance(x2, Planes):
+        return transpose_plane(x2)
+    return make_planes(x2, lo=False, straight=False, transposed=True)[1]
 
 
 def colsum(x2: torch.Tensor) -> torch.Tensor:
@@ -342,37 +502,61 @@ class LinearActFn(torch.autograd.Function):
             dz = dropout_raw(dy2, p, ctx.site)
         else:
             dz = dy2
-        dx = linear_dx(dz, W).view(*dy.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
-        dW = linear_dw(dz, x2) if ctx.needs_input_grad[1] else None
+        dzP, dzT = grad_planes(dz)
+        dx = linear_dx(dzP, W).view(*dy.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
+        dW = linear_dw(dzT, input_t(x2)) if ctx.needs_input_grad[1] else None
         db = colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, None, None, None, None
 
 
 class FFNFn(torch.autograd.Function):
     """fc2(dropout(relu(fc1(x))))   PositionwiseFeedForward.forward model/blocks.py:167-174.
-    Backward applies the relu/dropout derivative inside the dH GEMM epilogue (gate on the saved hidden)."""
+    The hidden activation only ever exists as bf16 operand planes (written by fc1's epilogue, read by fc2 and by the
+    backward); backward applies the relu/dropout derivative inside the dH GEMM epilogue (gate on the saved hidden)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, p, site):
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
-        h = linear_fwd(x2, W1, b1, relu=True, drop_post=True, drop_p=p, site=site)
-        y = linear_fwd(h, W2, b2)
+        x3 = FWD_PRECISION == PREC_BF16X3
+        h = linear_fwd_planes(x2, W1, b1, want_lo=x3, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
+        y = linear_fwd(h if USE_PLANE_GEMM else _planes_to_f32(h), W2, b2)
         ctx.p = p
-        ctx.save_for_backward(x2, W1, W2, h)
+        ctx.h = h
+        ctx.save_for_backward(x2, W1, W2)
         return y.view(*xc.shape[:-1], W2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W1, W2, h = ctx.saved_tensors
+        x2, W1, W2 = ctx.saved_tensors
+        h = ctx.h
         dy2 = _f32c(dy).view(-1, W2.shape[0])
-        dW2 = linear_dw(dy2, h)
+        gscale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
+        if USE_PLANE_GEMM:
+            dyP, dyT = grad_planes(dy2)
+            dW2 = linear_dw(dyT, transpose_plane(h))
+            dh = linear_dx(dyP, W2, gate=h, gate_scale=gscale)
+        else:
+            hf = _planes_to_f32(h)
+            dW2 = linear_dw(dy2, hf)
+            dh = linear_dx(dy2, W2)
+            tmp = torch.empty_like(dh)
+            _lib.check(lib.bmt_gate(_p(dh), _p(hf), gscale, _p(tmp), dh.numel(), _st()), "bmt_gate")
+            dh = tmp
         db2 = colsum(dy2)
-        dh = linear_dx(dy2, W2, gate=h, ldg=h.stride(0), gate_scale=1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0)
-        dW1 = linear_dw(dh, x2)
+        dhP, dhT = grad_planes(dh)
+        dW1 = linear_dw(dhT, input_t(x2))
         db1 = colsum(dh)
-        dx = linear_dx(dh, W1).view(*dy.shape[:-1], W1.shape[1]) if ctx.needs_input_grad[0] else None
+        dx = linear_dx(dhP, W1).view(*dy.shape[:-1], W1.shape[1]) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2, None, None
+
+
+def _planes_to_f32(pl: Planes) -> torch.Tensor:
+    """fp32 view of planes (A/B path without the plane GEMM only)"""
+    y = pl.hi[:, :pl.cols].float()
+    if pl.lo is not None:
+        y = y + pl.lo[:, :pl.cols].float()
+    return y.contiguous()
 
 
 class MHAFn(torch.autograd.Function):
@@ -385,21 +569,28 @@ class MHAFn(torch.autograd.Function):
         B, Sq, Dq = Qc.shape
         Sk = Kc.shape[1]
         D = Wq.shape[0]
+        same_qk, same_kv = Q is K, K is V
+        x3 = FWD_PRECISION == PREC_BF16X3
+        Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
+        if USE_PLANE_GEMM:      # each distinct input is split into operand planes once
+            Qp = as_planes(Q2, x3)
+            Kp = Qp if same_qk else as_planes(K2, x3)
+            Vp = Kp if same_kv else as_planes(V2, x3)
+        else:
+            Qp, Kp, Vp = Q2, K2, V2
         # the projections write bf16 operand planes (hi, lo) straight from the GEMM epilogue; the attention kernels
         # consume them as MFMA operands without any conversion.  Only the hi planes are kept for backward.
-        x3 = FWD_PRECISION == PREC_BF16X3
-        qh, ql = linear_fwd_planes(Qc.view(-1, Dq), Wq, bq, want_lo=x3)
-        kh, kl = linear_fwd_planes(Kc.view(-1, Kc.shape[-1]), Wk, bk, want_lo=x3)
-        vh, vl = linear_fwd_planes(Vc.view(-1, Vc.shape[-1]), Wv, bv, want_lo=x3)
+        q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
+        k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
+        v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
         v3 = lambda t, S: None if t is None else t.view(B, S, D)
-        o, lse = attn_fwd_bf16(v3(qh, Sq), v3(ql, Sq), v3(kh, Sk), v3(kl, Sk), v3(vh, Sk), v3(vl, Sk), mask, H,
+        o, lse = attn_fwd_bf16(v3(q.hi, Sq), v3(q.lo, Sq), v3(k.hi, Sk), v3(k.lo, Sk), v3(v.hi, Sk), v3(v.lo, Sk), mask, H,
                                drop_p=p, site=site)
         out = linear_fwd(o.view(-1, D), Wo, bo).view(B, Sq, Dq)
         ctx.H, ctx.p, ctx.site = H, p, site
-        ctx.same_qk = Q is K
-        ctx.same_kv = K is V
+        ctx.same_qk, ctx.same_kv = same_qk, same_kv
         ctx.mask = mask
-        ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, qh.view(B, Sq, D), kh.view(B, Sk, D), vh.view(B, Sk, D), o, lse)
+        ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, q.hi.view(B, Sq, D), k.hi.view(B, Sk, D), v.hi.view(B, Sk, D), o, lse)
         return out
 
     @staticmethod
@@ -410,37 +601,44 @@ class MHAFn(torch.autograd.Function):
         D = Wq.shape[0]
         dy2 = _f32c(dout).view(-1, Dq)
         o2 = o.view(-1, D)
-        dWo = linear_dw(dy2, o2)
+        dyP, dyT = grad_planes(dy2)
+        dWo = linear_dw(dyT, input_t(o2))
         dbo = colsum(dy2)
         # gradient w.r.t. the PRE-dropout attention output: the dropout mask is re-applied in the GEMM epilogue
-        do = linear_dx(dy2, Wo, drop_post=True, drop_p=ctx.p, site=ctx.site).view(B, Sq, D)
+        do = linear_dx(dyP, Wo, drop_post=True, drop_p=ctx.p, site=ctx.site).view(B, Sq, D)
         dq, dk, dv = attn_bwd_bf16(q, k, v, o, do, lse, ctx.mask, ctx.H, drop_p=ctx.p)
         dq2, dk2, dv2 = dq.view(-1, D), dk.view(-1, D), dv.view(-1, D)
         Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
-        dWq, dbq = linear_dw(dq2, Q2), colsum(dq2)
-        dWk, dbk = linear_dw(dk2, K2), colsum(dk2)
-        dWv, dbv = linear_dw(dv2, V2), colsum(dv2)
+        QT = input_t(Q2)
+        KT = QT if ctx.same_qk else input_t(K2)
+        VT = KT if ctx.same_kv else input_t(V2)
+        dqP, dqT = grad_planes(dq2)
+        dkP, dkT = grad_planes(dk2)
+        dvP, dvT = grad_planes(dv2)
+        dWq, dbq = linear_dw(dqT, QT), colsum(dq2)
+        dWk, dbk = linear_dw(dkT, KT), colsum(dk2)
+        dWv, dbv = linear_dw(dvT, VT), colsum(dv2)
         needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dQ = dK = dV = None
         if ctx.same_qk and ctx.same_kv:          # self-attention: one input, three contributions summed in the epilogue
             if needQ:
-                acc = linear_dx(dq2, Wq)
-                linear_dx(dk2, Wk, out=acc, residual=acc, ldr=acc.stride(0))
-                linear_dx(dv2, Wv, out=acc, residual=acc, ldr=acc.stride(0))
+                acc = linear_dx(dqP, Wq)
+                linear_dx(dkP, Wk, out=acc, residual=acc, ldr=acc.stride(0))
+                linear_dx(dvP, Wv, out=acc, residual=acc, ldr=acc.stride(0))
                 dQ = acc.view(Qc.shape)
         else:
             if needQ:
-                dQ = linear_dx(dq2, Wq).view(Qc.shape)
+                dQ = linear_dx(dqP, Wq).view(Qc.shape)
             if ctx.same_kv:
                 if needK or needV:
-                    acc = linear_dx(dk2, Wk)
-                    linear_dx(dv2, Wv, out=acc, residual=acc, ldr=acc.stride(0))
+                    acc = linear_dx(dkP, Wk)
+                    linear_dx(dvP, Wv, out=acc, residual=acc, ldr=acc.stride(0))
                     dK = acc.view(Kc.shape)     # autograd adds dK and dV for the shared tensor; dV stays None
             else:
                 if needK:
-                    dK = linear_dx(dk2, Wk).view(Kc.shape)
+                    dK = linear_dx(dkP, Wk).view(Kc.shape)
                 if needV:
-                    dV = linear_dx(dv2, Wv).view(Vc.shape)
+                    dV = linear_dx(dvP, Wv).view(Vc.shape)
         return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
 
 
@@ -465,8 +663,9 @@ class GeneratorFn(torch.autograd.Function):
         dlogits = torch.empty_like(d2)
         _lib.check(lib.bmt_log_softmax_bwd(_p(logp), logp.stride(0), _p(d2), d2.stride(0), _p(dlogits), dlogits.stride(0),
                                            d2.shape[0], V, _st()), "bmt_log_softmax_bwd")
-        dx = linear_dx(dlogits, W).view(*dlogp.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
-        return dx, linear_dw(dlogits, x2), colsum(dlogits)
+        dP, dT = grad_planes(dlogits)
+        dx = linear_dx(dP, W).view(*dlogp.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
+        return dx, linear_dw(dT, input_t(x2)), colsum(dlogits)
 
 
 class LabelSmoothingFn(torch.autograd.Function):

@@ -78,6 +78,8 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.check(lib.bmt_adam_step(_p(tab.ptrs), _p(tab.sizes), tab.n, tab.max_size, _p(self._steps[gi]),
                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                          float(group["weight_decay"]), _p(self.grad_scale), _st()), "bmt_adam_step")
+            from . import ops as _ops
+            _ops.WEIGHT_EPOCH[0] += 1      # cached bf16 weight planes are stale now
             for p in ps:   # host-side mirror of the step count (torch's state layout); the kernel uses the device counter
                 self.state[p]["step"] += 1
         return loss

@@ -80,6 +80,37 @@ typedef struct {
 } bmt_gemm_args;
 int bmt_gemm(const bmt_gemm_args* args, void* stream);
 
+/*
+ * bmt_gemm_bf16: the same product and epilogue over PRE-SPLIT bf16 operand planes (both operands reduction-contiguous):
+ *   C[M,N] = epilogue( alpha * sum_k (A_hi+A_lo)[m,k] * (B_hi+B_lo)[n,k] )     (x3: hi*hi + hi*lo + lo*hi; x1: hi*hi)
+ * Planes are [rows][ld] bf16 with the reduction extent zero-padded to Kpad (a multiple of 64); bmt_planes makes them from
+ * fp32 tensors (straight and/or transposed), bmt_gemm / bmt_gemm_bf16 can emit them for their own result (C_hi/C_lo,
+ * zero-padded up to min(round_up(N,64), ldp)).  gate is the bf16 hi plane of the saved forward output.
+ */
+typedef struct {
+    const uint16_t *A_hi, *A_lo; int64_t lda;
+    const uint16_t *B_hi, *B_lo; int64_t ldb;
+    float* C; int64_t ldc;
+    uint16_t *C_hi, *C_lo; int64_t ldp;
+    int M, N, Kpad;
+    float alpha;
+    unsigned flags;
+    const float* bias;
+    const float* residual; int64_t ldr;
+    const uint16_t* gate; int64_t ldg; float gate_scale;
+    float drop_p; const uint64_t* rng; uint32_t site;
+    int precision;
+    int splitk;
+} bmt_gemm_bf16_args;
+int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
+/* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL
+ * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
+int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
+               uint16_t* loT, int64_t ldpT, void* stream);
+
+/* bf16 [R][ld] -> transposed bf16 [C][ldT], zero padded up to min(round_up(R,64), ldT) */
+int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C, uint16_t* dst, int64_t ldT, void* stream);
+
 /* column sums: out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
 int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream);
 

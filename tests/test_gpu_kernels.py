@@ -32,7 +32,7 @@ GEMM_SHAPES = [(128, 128, 64), (130, 70, 100), (257, 300, 1024), (64, 10, 24), (
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("prec", [1, 3])
-def test_gemm_linear_forward(ops, M, N, K, prec):
+def test_gemm_linear_forward(ops, gemm_path, M, N, K, prec):
     x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
     y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), precision=prec)
     if prec == 1:
@@ -43,19 +43,42 @@ def test_gemm_linear_forward(ops, M, N, K, prec):
         assert_close(y, want, atol=3e-5 * math.sqrt(K), rtol=2e-5, name=f"linear x3 {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("M,N,K", [(130, 70, 100), (256, 128, 512), (33, 300, 1000)])
-def test_gemm_dx_dw_layouts(ops, M, N, K):
-    """dX = dY.W (B operand reduction-strided) and dW = dY^T.X (both operands reduction-strided, split-K atomics)."""
+@pytest.fixture(params=[True, False], ids=["planes", "fp32-staged"])
+def gemm_path(ops, request):
+    """both GEMM implementations: operand planes (gemm_bf16.hip) and fp32 operands converted while staging (gemm.hip)"""
+    old = ops.USE_PLANE_GEMM
+    ops.USE_PLANE_GEMM = request.param
+    yield request.param
+    ops.USE_PLANE_GEMM = old
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 70, 100), (256, 128, 512), (33, 300, 1000), (960, 300, 10000)])
+def test_gemm_dx_dw_layouts(ops, gemm_path, M, N, K):
+    """dX = dY.W and dW = dY^T.X (reduction over rows, split-K atomics) on both GEMM paths."""
     dy, W, x = rnd(M, N, seed=4), rnd(N, K, seed=5), rnd(M, K, seed=6)
-    dx = ops.linear_dx(dy.to(DEV), W.to(DEV))
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    dyP, dyT = ops.grad_planes(dyd)
+    dx = ops.linear_dx(dyP, W.to(DEV))
     want = bf16_round(dy).double() @ bf16_round(W).double()
     assert_close(dx, want, atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx")
-    dW = ops.linear_dw(dy.to(DEV), x.to(DEV))
+    dW = ops.linear_dw(dyT, ops.input_t(xd))
     want = bf16_round(dy).double().t() @ bf16_round(x).double()
     assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name="dw")
 
 
-def test_gemm_epilogues(ops):
+def test_planes_and_transpose(ops):
+    x = rnd(150, 70, seed=3) * 3
+    pl, plT = ops.make_planes(x.to(DEV), lo=True, straight=True, transposed=True)
+    assert pl.hi.shape == (150, 128) and plT.hi.shape == (70, 192)
+    assert torch.equal(pl.hi[:, :70].float().cpu(), x.to(torch.bfloat16).float())
+    assert float(pl.hi[:, 70:].float().abs().max()) == 0 and float(plT.hi[:, 150:].float().abs().max()) == 0
+    assert_close(pl.hi[:, :70].float() + pl.lo[:, :70].float(), x, atol=0, rtol=2 ** -15, name="hi+lo")
+    assert torch.equal(plT.hi[:, :150].float().cpu(), x.t().to(torch.bfloat16).float())
+    t2 = ops.transpose_plane(pl)
+    assert torch.equal(t2.hi[:, :150].cpu(), plT.hi[:, :150].cpu()) and float(t2.hi[:, 150:].float().abs().max()) == 0
+
+
+def test_gemm_epilogues(ops, gemm_path):
     M, N, K = 150, 90, 64
     x, W, b, res = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9), rnd(M, N, seed=10)
     xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV)
@@ -65,7 +88,12 @@ def test_gemm_epilogues(ops):
     y = ops.linear_fwd(xd, Wd, bd, residual=rd, ldr=N, precision=3)
     assert_close(y, base + res.double(), atol=3e-4, name="residual")
     gate = (rnd(M, N, seed=11) > 0).float()
-    y = ops.linear_fwd(xd, Wd, None, gate=gate.to(DEV), ldg=N, gate_scale=1.25, precision=3)
+    if gemm_path:
+        y = ops.linear_fwd(xd, Wd, None, gate=ops.make_planes(gate.to(DEV), lo=False)[0], gate_scale=1.25, precision=3)
+    else:
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm(xd, Wd, out, M, N, K, lda=K, ldb=K, ldc=N, gate=gate.to(DEV), ldg=N, gate_scale=1.25, precision=3)
+        y = out
     assert_close(y, (x.double() @ W.double().t()) * gate.double() * 1.25, atol=3e-4, name="gate")
     # in-place accumulate through the residual pointer (C aliases residual)
     acc = rd.clone()
@@ -75,7 +103,7 @@ def test_gemm_epilogues(ops):
     assert_close(cs, res.double().sum(0), atol=1e-4, name="colsum")
 
 
-def test_gemm_dropout_epilogue_matches_standalone(ops):
+def test_gemm_dropout_epilogue_matches_standalone(ops, gemm_path):
     """the fused dropout epilogue and bmt_dropout share one RNG: same site => same mask."""
     M, N, K, p, site = 200, 96, 32, 0.3, 4242
     ops.manual_seed(123)
@@ -195,14 +223,17 @@ def test_attention_backward_bf16_planes(ops, dk, H, B, Sq, Sk, kind):
         assert e < 2e-2, f"{name} dk={dk} {kind}: relative error {e:.3e}\n" + report(got, ref, name)
 
 
-def test_gemm_plane_outputs(ops):
+@pytest.mark.parametrize("pad", [False, True])
+def test_gemm_plane_outputs(ops, gemm_path, pad):
     M, N, K = 150, 96, 64
     x, W, b = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9)
-    hi, lo = ops.linear_fwd_planes(x.to(DEV), W.to(DEV), b.to(DEV))
+    pl = ops.linear_fwd_planes(x.to(DEV), W.to(DEV), b.to(DEV), pad=pad)
     want = x.double() @ W.double().t() + b.double()
-    assert hi.dtype == torch.bfloat16
-    assert_close(hi.float(), want, atol=1e-6, rtol=2 ** -8, name="hi plane")
-    assert_close(hi.float().double() + lo.float().double(), want, atol=3e-4, rtol=2e-5, name="hi+lo planes")
+    assert pl.hi.dtype == torch.bfloat16 and pl.hi.shape == (M, 128 if pad else N)
+    assert_close(pl.hi[:, :N].float(), want, atol=1e-3, rtol=2 ** -8, name="hi plane")
+    assert_close(pl.hi[:, :N].float().double() + pl.lo[:, :N].float().double(), want, atol=3e-4, rtol=2e-5, name="hi+lo planes")
+    if pad:
+        assert float(pl.hi[:, N:].float().abs().max()) == 0 and float(pl.lo[:, N:].float().abs().max()) == 0
 
 
 def test_attention_fully_masked_row_is_nan(ops):

@@ -39,11 +39,20 @@ def gemm_bench():
         W = torch.randn(N, K, device=DEV)
         b = torch.randn(N, device=DEV)
         out = torch.empty(M, N, device=DEV)
-        for prec in (3, 1):
-            timeit(lambda: ops.linear_fwd(x, W, b, out=out, precision=prec), 2.0 * M * N * K, f"linear_fwd x{prec} {name}")
         dy = torch.randn(M, N, device=DEV)
-        timeit(lambda: ops.linear_dx(dy, W), 2.0 * M * N * K, f"linear_dx  x1 {name}")
-        timeit(lambda: ops.linear_dw(dy, x), 2.0 * M * N * K, f"linear_dw  x1 {name}")
+        for path in (True, False):
+            ops.USE_PLANE_GEMM = path
+            tag = "planes" if path else "fp32st"
+            for prec in (3, 1):
+                xin = ops.make_planes(x, lo=True)[0] if path else x
+                timeit(lambda: ops.linear_fwd(xin, W, b, out=out, precision=prec), 2.0 * M * N * K, f"linear_fwd {tag} x{prec} {name}")
+            dyP, dyT = ops.grad_planes(dy)
+            xT = ops.input_t(x)
+            timeit(lambda: ops.linear_dx(dyP, W), 2.0 * M * N * K, f"linear_dx  {tag} x1 {name}")
+            timeit(lambda: ops.linear_dw(dyT, xT), 2.0 * M * N * K, f"linear_dw  {tag} x1 {name}")
+        ops.USE_PLANE_GEMM = True
+        timeit(lambda: ops.make_planes(x, lo=True), 0.0, f"make_planes(hi,lo)      {name}")
+        timeit(lambda: ops.grad_planes(dy), 0.0, f"grad_planes(hi,hiT)     {name}")
 
 
 def attn_bench(bwd=False):
