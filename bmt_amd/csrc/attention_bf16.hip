@@ -40,59 +40,63 @@ template <int DK, int ROWS> constexpr int rowsT_n() { return (ROWS * DK / 16 + 2
 // ---- row-major bf16 tile [ROWS][DK]: global -> registers (16-B slots) -> swizzled LDS image
 template <int DK, int ROWS>
 __device__ __forceinline__ void tile_gload(const uint16_t* base, int64_t ld, int row0, int nrows, int tid,
-                                           uint4 (&v)[rows_n<DK, ROWS>()]) {
+                                           u32x4 (&v)[rows_n<DK, ROWS>()]) {
+    // UNCONDITIONAL loads (row clamped to the last valid row): a guarded load into a register array makes hipcc either wait
+    // vmcnt(0) at the join or demote the array to scratch.  Clamped rows hold finite data and are neutralised downstream
+    // (masked scores / zero probabilities / rows that are never stored).
     constexpr int SPR = DK / 8;
 #pragma unroll
     for (int i = 0; i < rows_n<DK, ROWS>(); ++i) {
-        const int c = tid + 256 * i;
-        const int row = c / SPR, slot = c % SPR;
-        v[i] = make_uint4(0, 0, 0, 0);
-        if (c < ROWS * SPR && row0 + row < nrows)
-            v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + row) * ld + slot * 8);
+        const int c = (ROWS * SPR % 256 == 0) ? tid + 256 * i : min(tid + 256 * i, ROWS * SPR - 1);
+        const int row = min(row0 + c / SPR, nrows - 1), slot = c % SPR;
+        v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + slot * 8);
     }
 }
 template <int DK, int ROWS>
-__device__ __forceinline__ void tile_lstore(uint4* img, int tid, const uint4 (&v)[rows_n<DK, ROWS>()]) {
+__device__ __forceinline__ void tile_lstore(u32x4* img, int tid, const u32x4 (&v)[rows_n<DK, ROWS>()]) {
     constexpr int SPR = DK / 8;
 #pragma unroll
     for (int i = 0; i < rows_n<DK, ROWS>(); ++i) {
         const int c = tid + 256 * i;
-        if (c >= ROWS * SPR) break;
-        img[kslot<DK>(c / SPR, c % SPR)] = v[i];
+        if constexpr (ROWS * SPR % 256 != 0) {
+            if (c < ROWS * SPR) img[kslot<DK>(c / SPR, c % SPR)] = v[i];
+        } else {
+            img[kslot<DK>(c / SPR, c % SPR)] = v[i];
+        }
     }
 }
 // ---- transposed image [DK][ROWS] in 8-byte row-quads: each thread owns 4(row) x 4(d) blocks
 template <int DK, int ROWS>
 __device__ __forceinline__ void tileT_gload(const uint16_t* base, int64_t ld, int row0, int nrows, int tid,
-                                            uint2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
-    constexpr int DQ = DK / 4;
+                                            u32x2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
+    constexpr int DQ = DK / 4, NB = DQ * (ROWS / 4);
 #pragma unroll
     for (int i = 0; i < rowsT_n<DK, ROWS>(); ++i) {
-        const int c = tid + 256 * i;
+        const int c = (NB % 256 == 0) ? tid + 256 * i : min(tid + 256 * i, NB - 1);
         const int dq = c % DQ, kg = c / DQ;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row0 + kg * 4 + r;
-            v[i * 4 + r] = make_uint2(0, 0);
-            if (c < DQ * (ROWS / 4) && row < nrows)
-                v[i * 4 + r] = *reinterpret_cast<const uint2*>(base + (int64_t)row * ld + dq * 4);
+            const int row = min(row0 + kg * 4 + r, nrows - 1);
+            v[i * 4 + r] = *reinterpret_cast<const u32x2*>(base + (int64_t)row * ld + dq * 4);
         }
     }
 }
 template <int DK, int ROWS>
-__device__ __forceinline__ void tileT_lstore(uint2* img, int tid, const uint2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
+__device__ __forceinline__ void tileT_lstore(u32x2* img, int tid, const u32x2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
     constexpr int DQ = DK / 4;
 #pragma unroll
     for (int i = 0; i < rowsT_n<DK, ROWS>(); ++i) {
         const int c = tid + 256 * i;
-        if (c >= DQ * (ROWS / 4)) break;
+        if constexpr (DQ * (ROWS / 4) % 256 != 0) {
+            if (c >= DQ * (ROWS / 4)) continue;
+        }
         const int dq = c % DQ, kg = c / DQ;
-        const uint2 a = v[i * 4 + 0], b = v[i * 4 + 1], cc = v[i * 4 + 2], d = v[i * 4 + 3];
+        const u32x2 a = v[i * 4 + 0], b = v[i * 4 + 1], cc = v[i * 4 + 2], d = v[i * 4 + 3];
         // 4x4 bf16 transpose: output row = d index, 4 consecutive source rows packed low -> high
-        const uint2 o0 = make_uint2((a.x & 0xffffu) | (b.x << 16), (cc.x & 0xffffu) | (d.x << 16));
-        const uint2 o1 = make_uint2((a.x >> 16) | (b.x & 0xffff0000u), (cc.x >> 16) | (d.x & 0xffff0000u));
-        const uint2 o2 = make_uint2((a.y & 0xffffu) | (b.y << 16), (cc.y & 0xffffu) | (d.y << 16));
-        const uint2 o3 = make_uint2((a.y >> 16) | (b.y & 0xffff0000u), (cc.y >> 16) | (d.y & 0xffff0000u));
+        const u32x2 o0 = {(a.x & 0xffffu) | (b.x << 16), (cc.x & 0xffffu) | (d.x << 16)};
+        const u32x2 o1 = {(a.x >> 16) | (b.x & 0xffff0000u), (cc.x >> 16) | (d.x & 0xffff0000u)};
+        const u32x2 o2 = {(a.y & 0xffffu) | (b.y << 16), (cc.y & 0xffffu) | (d.y << 16)};
+        const u32x2 o3 = {(a.y >> 16) | (b.y & 0xffff0000u), (cc.y >> 16) | (d.y & 0xffff0000u)};
         img[vunit<ROWS>(dq * 4 + 0, kg)] = o0;
         img[vunit<ROWS>(dq * 4 + 1, kg)] = o1;
         img[vunit<ROWS>(dq * 4 + 2, kg)] = o2;
@@ -100,9 +104,10 @@ __device__ __forceinline__ void tileT_lstore(uint2* img, int tid, const uint2 (&
     }
 }
 template <int ROWS>
-__device__ __forceinline__ bf16x8 tfrag(const uint2* img, int d, int kg) {
-    const uint2 a = img[vunit<ROWS>(d, kg)], b = img[vunit<ROWS>(d, kg + 2)];
-    return as_bf16x8(make_uint4(a.x, a.y, b.x, b.y));
+__device__ __forceinline__ bf16x8 tfrag(const u32x2* img, int d, int kg) {
+    const u32x2 a = img[vunit<ROWS>(d, kg)], b = img[vunit<ROWS>(d, kg + 2)];
+    const u32x4 r = {a.x, a.y, b.x, b.y};
+    return as_bf16x8(r);
 }
 template <int NPASS>
 __device__ __forceinline__ void pack_p(const float (&p)[16], int s2, bf16x8& hi, bf16x8& lo) {
@@ -162,10 +167,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
     using G = Geo<DK>;
     constexpr int BC = G::BC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* sKh = reinterpret_cast<uint4*>(smem);
-    uint2* sVh = reinterpret_cast<uint2*>(smem + G::K_BYTES);
-    uint4* sKl = reinterpret_cast<uint4*>(smem + G::K_BYTES + G::V_BYTES);
-    uint2* sVl = reinterpret_cast<uint2*>(smem + 2 * G::K_BYTES + G::V_BYTES);
+    u32x4* sKh = reinterpret_cast<u32x4*>(smem);
+    u32x2* sVh = reinterpret_cast<u32x2*>(smem + G::K_BYTES);
+    u32x4* sKl = reinterpret_cast<u32x4*>(smem + G::K_BYTES + G::V_BYTES);
+    u32x2* sVl = reinterpret_cast<u32x2*>(smem + 2 * G::K_BYTES + G::V_BYTES);
     uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + (NPASS == 3 ? 2 : 1) * (G::K_BYTES + G::V_BYTES));
     int* sFlag = reinterpret_cast<int*>(sMask + 64);
 
@@ -197,34 +202,39 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = NEG_INF, l_run = 0.f;
 
-    uint4 kh[rows_n<DK, BC>()], kl[rows_n<DK, BC>()];
-    uint2 vh[rowsT_n<DK, BC>() * 4], vl[rowsT_n<DK, BC>() * 4];
+    u32x4 kh[rows_n<DK, BC>()], kl[rows_n<DK, BC>()];
+    u32x2 vh[rowsT_n<DK, BC>() * 4], vl[rowsT_n<DK, BC>() * 4];
     const int ntile = (p.Sk + BC - 1) / BC;
-    tile_gload<DK, BC>(p.Kh + koff, p.ldk, 0, p.Sk, tid, kh);
-    tileT_gload<DK, BC>(p.Vh + voff, p.ldv, 0, p.Sk, tid, vh);
-    if constexpr (NPASS == 3) {
-        tile_gload<DK, BC>(p.Kl + koff, p.ldk, 0, p.Sk, tid, kl);
-        tileT_gload<DK, BC>(p.Vl + voff, p.ldv, 0, p.Sk, tid, vl);
-    }
+    // Register arrays are filled and drained inside ONE loop iteration (fetch tile t+1 -> MFMAs of tile t -> barrier ->
+    // write tile t+1 to LDS -> barrier): a loop-carried or conditionally written array is demoted to scratch by hipcc,
+    // with a vmcnt(0) after every load (measured: profiles/r01_*).  The last iteration re-fetches its own tile.
+#define BMT_FWD_FETCH(key0_)                                                        \
+    do {                                                                            \
+        tile_gload<DK, BC>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kh);             \
+        tileT_gload<DK, BC>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vh);            \
+        if constexpr (NPASS == 3) {                                                 \
+            tile_gload<DK, BC>(p.Kl + koff, p.ldk, (key0_), p.Sk, tid, kl);         \
+            tileT_gload<DK, BC>(p.Vl + voff, p.ldv, (key0_), p.Sk, tid, vl);        \
+        }                                                                           \
+    } while (0)
+#define BMT_FWD_STORE(key0_)                                                        \
+    do {                                                                            \
+        tile_lstore<DK, BC>(sKh, tid, kh);                                          \
+        tileT_lstore<DK, BC>(sVh, tid, vh);                                         \
+        if constexpr (NPASS == 3) {                                                 \
+            tile_lstore<DK, BC>(sKl, tid, kl);                                      \
+            tileT_lstore<DK, BC>(sVl, tid, vl);                                     \
+        }                                                                           \
+        stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                           \
+    } while (0)
+    BMT_FWD_FETCH(0);
+    BMT_FWD_STORE(0);
+    __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
         const int key0 = t * BC;
-        tile_lstore<DK, BC>(sKh, tid, kh);
-        tileT_lstore<DK, BC>(sVh, tid, vh);
-        if constexpr (NPASS == 3) {
-            tile_lstore<DK, BC>(sKl, tid, kl);
-            tileT_lstore<DK, BC>(sVl, tid, vl);
-        }
-        stage_mask<BC>(p, b, key0, tid, sMask, sFlag);
-        __syncthreads();
-        if (t + 1 < ntile) {
-            tile_gload<DK, BC>(p.Kh + koff, p.ldk, key0 + BC, p.Sk, tid, kh);
-            tileT_gload<DK, BC>(p.Vh + voff, p.ldv, key0 + BC, p.Sk, tid, vh);
-            if constexpr (NPASS == 3) {
-                tile_gload<DK, BC>(p.Kl + koff, p.ldk, key0 + BC, p.Sk, tid, kl);
-                tileT_gload<DK, BC>(p.Vl + voff, p.ldv, key0 + BC, p.Sk, tid, vl);
-            }
-        }
+        const int kn = min(key0 + BC, (ntile - 1) * BC);
+        BMT_FWD_FETCH(kn);
         const int flag = sFlag[0];
         if (flag != 0) {
 #pragma unroll
@@ -305,7 +315,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
             }
         }
         __syncthreads();
+        BMT_FWD_STORE(kn);
+        __syncthreads();
     }
+#undef BMT_FWD_FETCH
+#undef BMT_FWD_STORE
 
     if (qok) {
         const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
@@ -353,9 +367,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     constexpr int BC = 32, DT = DK / 32;
     constexpr int TB = BC * DK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* sK = reinterpret_cast<uint4*>(smem);
-    uint4* sV = reinterpret_cast<uint4*>(smem + TB);
-    uint2* sKt = reinterpret_cast<uint2*>(smem + 2 * TB);
+    u32x4* sK = reinterpret_cast<u32x4*>(smem);
+    u32x4* sV = reinterpret_cast<u32x4*>(smem + TB);
+    u32x2* sKt = reinterpret_cast<u32x2*>(smem + 2 * TB);
     uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 3 * TB);
     int* sFlag = reinterpret_cast<int*>(sMask + 64);
 
@@ -389,24 +403,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    uint4 kv[rows_n<DK, BC>()], vv[rows_n<DK, BC>()];
-    uint2 ktv[rowsT_n<DK, BC>() * 4];
+    u32x4 kv[rows_n<DK, BC>()], vv[rows_n<DK, BC>()];
+    u32x2 ktv[rowsT_n<DK, BC>() * 4];
     const int ntile = (p.Sk + BC - 1) / BC;
-    tile_gload<DK, BC>(p.Kh + koff, p.ldk, 0, p.Sk, tid, kv);
-    tile_gload<DK, BC>(p.Vh + voff, p.ldv, 0, p.Sk, tid, vv);
-    tileT_gload<DK, BC>(p.Kh + koff, p.ldk, 0, p.Sk, tid, ktv);
+#define BMT_DQ_FETCH(key0_)                                                         \
+    do {                                                                            \
+        tile_gload<DK, BC>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kv);             \
+        tile_gload<DK, BC>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vv);             \
+        tileT_gload<DK, BC>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, ktv);           \
+    } while (0)
+#define BMT_DQ_STORE(key0_)                                                         \
+    do {                                                                            \
+        tile_lstore<DK, BC>(sK, tid, kv);                                           \
+        tile_lstore<DK, BC>(sV, tid, vv);                                           \
+        tileT_lstore<DK, BC>(sKt, tid, ktv);                                        \
+        stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                           \
+    } while (0)
+    BMT_DQ_FETCH(0);
+    BMT_DQ_STORE(0);
+    __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const int key0 = t * BC;
-        tile_lstore<DK, BC>(sK, tid, kv);
-        tile_lstore<DK, BC>(sV, tid, vv);
-        tileT_lstore<DK, BC>(sKt, tid, ktv);
-        stage_mask<BC>(p, b, key0, tid, sMask, sFlag);
-        __syncthreads();
-        if (t + 1 < ntile) {
-            tile_gload<DK, BC>(p.Kh + koff, p.ldk, key0 + BC, p.Sk, tid, kv);
-            tile_gload<DK, BC>(p.Vh + voff, p.ldv, key0 + BC, p.Sk, tid, vv);
-            tileT_gload<DK, BC>(p.Kh + koff, p.ldk, key0 + BC, p.Sk, tid, ktv);
-        }
+        const int kn = min(key0 + BC, (ntile - 1) * BC);
+        BMT_DQ_FETCH(kn);
         const int flag = sFlag[0];
         if (flag != 0) {
             f32x16 st, dp;
@@ -451,7 +470,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
                     dq[dt] = mfma32(tfrag<BC>(sKt, dt * 32 + l31, 4 * s2 + half), dsf[s2], dq[dt]);
         }
         __syncthreads();
+        BMT_DQ_STORE(kn);
+        __syncthreads();
     }
+#undef BMT_DQ_FETCH
+#undef BMT_DQ_STORE
     if (qok) {
         const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;   // dQ is laid out like O (fp32 [B,Sq,D])
 #pragma unroll
@@ -473,12 +496,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
     constexpr int TB = BQ * DK * 2;
     constexpr int KVB = KB * DK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* sK = reinterpret_cast<uint4*>(smem);
-    uint4* sV = reinterpret_cast<uint4*>(smem + KVB);
-    uint4* sQ = reinterpret_cast<uint4*>(smem + 2 * KVB);
-    uint4* sdO = reinterpret_cast<uint4*>(smem + 2 * KVB + TB);
-    uint2* sQt = reinterpret_cast<uint2*>(smem + 2 * KVB + 2 * TB);
-    uint2* sdOt = reinterpret_cast<uint2*>(smem + 2 * KVB + 3 * TB);
+    u32x4* sK = reinterpret_cast<u32x4*>(smem);
+    u32x4* sV = reinterpret_cast<u32x4*>(smem + KVB);
+    u32x4* sQ = reinterpret_cast<u32x4*>(smem + 2 * KVB);
+    u32x4* sdO = reinterpret_cast<u32x4*>(smem + 2 * KVB + TB);
+    u32x2* sQt = reinterpret_cast<u32x2*>(smem + 2 * KVB + 2 * TB);
+    u32x2* sdOt = reinterpret_cast<u32x2*>(smem + 2 * KVB + 3 * TB);
     float* sLse = reinterpret_cast<float*>(smem + 2 * KVB + 4 * TB);
     float* sDelta = sLse + BQ;
 
@@ -510,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
         return;
     }
     {
-        uint4 tmp[rows_n<DK, KB>()];
+        u32x4 tmp[rows_n<DK, KB>()];
         tile_gload<DK, KB>(p.Kh + (int64_t)b * p.bsk + h * DK, p.ldk, kt * KB, p.Sk, tid, tmp);
         tile_lstore<DK, KB>(sK, tid, tmp);
         tile_gload<DK, KB>(p.Vh + (int64_t)b * p.bsv + h * DK, p.ldv, kt * KB, p.Sk, tid, tmp);
@@ -524,8 +547,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
 
-    uint4 rq[rows_n<DK, BQ>()], rdo[rows_n<DK, BQ>()];
-    uint2 rqt[rowsT_n<DK, BQ>() * 4], rdot[rowsT_n<DK, BQ>() * 4];
+    u32x4 rq[rows_n<DK, BQ>()], rdo[rows_n<DK, BQ>()];
+    u32x2 rqt[rowsT_n<DK, BQ>() * 4], rdot[rowsT_n<DK, BQ>() * 4];
     float rl = 0.f, rd = 0.f;
     const int ntile = (p.Sq + BQ - 1) / BQ;
 #define BMT_FETCH(q0_)                                                             \
@@ -534,24 +557,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
         tile_gload<DK, BQ>(dOb, p.ldo, (q0_), p.Sq, tid, rdo);                     \
         tileT_gload<DK, BQ>(Qb, p.ldq, (q0_), p.Sq, tid, rqt);                     \
         tileT_gload<DK, BQ>(dOb, p.ldo, (q0_), p.Sq, tid, rdot);                   \
-        if (tid < BQ) {                                                            \
-            const int qq_ = (q0_) + tid;                                           \
+        {                                                                          \
+            const int qq_ = min((q0_) + (tid & (BQ - 1)), p.Sq - 1);               \
             const int64_t stat_ = ((int64_t)b * p.H + h) * p.Sq + qq_;             \
-            rl = (qq_ < p.Sq) ? p.lse[stat_] : 0.f;                                \
-            rd = (qq_ < p.Sq) ? p.delta[stat_] : 0.f;                              \
+            rl = p.lse[stat_];                                                     \
+            rd = p.delta[stat_];                                                   \
         }                                                                          \
     } while (0)
+#define BMT_DKV_STORE()                                                              \
+    do {                                                                            \
+        tile_lstore<DK, BQ>(sQ, tid, rq);                                           \
+        tile_lstore<DK, BQ>(sdO, tid, rdo);                                         \
+        tileT_lstore<DK, BQ>(sQt, tid, rqt);                                        \
+        tileT_lstore<DK, BQ>(sdOt, tid, rdot);                                      \
+        if (tid < BQ) { sLse[tid] = rl; sDelta[tid] = rd; }                         \
+    } while (0)
     BMT_FETCH(0);
+    BMT_DKV_STORE();
+    __syncthreads();   // also makes the K/V images visible
     for (int t = 0; t < ntile; ++t) {
         const int q0 = t * BQ;
-        __syncthreads();   // previous tile fully consumed (and the K/V images visible on t == 0)
-        tile_lstore<DK, BQ>(sQ, tid, rq);
-        tile_lstore<DK, BQ>(sdO, tid, rdo);
-        tileT_lstore<DK, BQ>(sQt, tid, rqt);
-        tileT_lstore<DK, BQ>(sdOt, tid, rdot);
-        if (tid < BQ) { sLse[tid] = rl; sDelta[tid] = rd; }
-        __syncthreads();
-        if (t + 1 < ntile) BMT_FETCH(q0 + BQ);
+        BMT_FETCH(min(q0 + BQ, (ntile - 1) * BQ));
+        // S[q][key] (both roles) and dP[q][key] (dK role): A rows = q (from LDS), B cols = key (this wave's K / V rows)
         f32x16 sacc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
@@ -575,14 +602,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
         bf16x8 bf[2], unused;
         pack_p<1>(pr, 0, bf[0], unused);
         pack_p<1>(pr, 1, bf[1], unused);
-        const uint2* timg = (role == 1) ? sQt : sdOt;
+        const u32x2* timg = (role == 1) ? sQt : sdOt;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
                 acc[dt] = mfma32(tfrag<BQ>(timg, dt * 32 + l31, 4 * s2 + half), bf[s2], acc[dt]);
+        __syncthreads();   // tile t fully consumed
+        BMT_DKV_STORE();
+        __syncthreads();
     }
 #undef BMT_FETCH
+#undef BMT_DKV_STORE
     if (kok) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)

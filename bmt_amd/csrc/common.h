@@ -34,7 +34,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;  // 8 bf16 = 4 VGPR (
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// native vector types for 16-B / 8-B register slots: first-class SSA values (HIP's uint4/uint2 are structs whose array
+// copies go through memcpy and can keep a whole register array in scratch)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     // D[32x32] += A[32x16] * B[16x32]; lane l holds A[row=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][col=l&31],
     // D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]  (cdna_hip_programming.md section 3)

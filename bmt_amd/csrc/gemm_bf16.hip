@@ -52,16 +52,16 @@ __device__ __forceinline__ int slot_of(int row, int s) {
 
 // one operand plane, one stage: [128 rows][SPR slots]; thread t moves slots t, t+256, ...
 template <int SPR>
-__device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, int r0, int nrows, int k0, int tid, uint4 (&v)[128 * SPR / 256]) {
+__device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, int r0, int nrows, int k0, int tid, u32x4 (&v)[128 * SPR / 256]) {
 #pragma unroll
     for (int i = 0; i < 128 * SPR / 256; ++i) {
         const int c = tid + 256 * i;
         const int row = min(r0 + c / SPR, nrows - 1);
-        v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k0 + (c % SPR) * 8);
+        v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + k0 + (c % SPR) * 8);
     }
 }
 template <int SPR>
-__device__ __forceinline__ void plane_lstore(uint4* img, int tid, const uint4 (&v)[128 * SPR / 256]) {
+__device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&v)[128 * SPR / 256]) {
 #pragma unroll
     for (int i = 0; i < 128 * SPR / 256; ++i) {
         const int c = tid + 256 * i;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void plane_lstore(uint4* img, int tid, const uint4 (&
 }
 
 template <int NPASS>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmB p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(const GemmB p) {
     constexpr int BK = (NPASS == 3) ? 32 : 64;
     constexpr int SPR = BK / 8;
     constexpr int PB = 128 * BK * 2;        // bytes of one plane tile (x1: 16 KB, x3: 8 KB)
@@ -102,39 +102,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmB p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[128 * SPR / 256], rb[128 * SPR / 256], ral[128 * SPR / 256], rbl[128 * SPR / 256];
-#define stage_ptr(buf_, which_) reinterpret_cast<uint4*>(smem + (buf_) * STAGE_BYTES + (which_) * PB)
+    u32x4 ra[128 * SPR / 256], rb[128 * SPR / 256], ral[128 * SPR / 256], rbl[128 * SPR / 256];
+#define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + (which_) * PB)
 
-    if (kbeg < kend) {
-        plane_gload<SPR>(p.Ah, p.lda, m0, p.M, kbeg, tid, ra);
-        plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, kbeg, tid, rb);
-        if constexpr (NPASS == 3) {
-            plane_gload<SPR>(p.Al, p.lda, m0, p.M, kbeg, tid, ral);
-            plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, kbeg, tid, rbl);
-        }
-        plane_lstore<SPR>(stage_ptr(0, 0), tid, ra);
-        plane_lstore<SPR>(stage_ptr(0, 1), tid, rb);
-        if constexpr (NPASS == 3) {
-            plane_lstore<SPR>(stage_ptr(0, 2), tid, ral);
-            plane_lstore<SPR>(stage_ptr(0, 3), tid, rbl);
-        }
+    // prologue: stage 0 (kbeg < kend always holds: the host never launches an empty split)
+    plane_gload<SPR>(p.Ah, p.lda, m0, p.M, kbeg, tid, ra);
+    plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, kbeg, tid, rb);
+    if constexpr (NPASS == 3) {
+        plane_gload<SPR>(p.Al, p.lda, m0, p.M, kbeg, tid, ral);
+        plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, kbeg, tid, rbl);
+    }
+    plane_lstore<SPR>(stage_ptr(0, 0), tid, ra);
+    plane_lstore<SPR>(stage_ptr(0, 1), tid, rb);
+    if constexpr (NPASS == 3) {
+        plane_lstore<SPR>(stage_ptr(0, 2), tid, ral);
+        plane_lstore<SPR>(stage_ptr(0, 3), tid, rbl);
     }
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) {   // stage t+1: global -> registers now, registers -> the other LDS buffer after the MFMAs
-            plane_gload<SPR>(p.Ah, p.lda, m0, p.M, k0 + BK, tid, ra);
-            plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, k0 + BK, tid, rb);
-            if constexpr (NPASS == 3) {
-                plane_gload<SPR>(p.Al, p.lda, m0, p.M, k0 + BK, tid, ral);
-                plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, k0 + BK, tid, rbl);
-            }
+        // stage t+1: global -> registers now, registers -> the other LDS buffer after the MFMAs.  Branch-free: the last
+        // iteration re-fetches its own stage (clamped k) and the redundant LDS image is never read.
+        const int kn = min(k0 + BK, kend - BK);
+        plane_gload<SPR>(p.Ah, p.lda, m0, p.M, kn, tid, ra);
+        plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, kn, tid, rb);
+        if constexpr (NPASS == 3) {
+            plane_gload<SPR>(p.Al, p.lda, m0, p.M, kn, tid, ral);
+            plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, kn, tid, rbl);
         }
-        const uint4* sAh = stage_ptr(buf, 0);
-        const uint4* sBh = stage_ptr(buf, 1);
-        const uint4* sAl = stage_ptr(buf, 2);
-        const uint4* sBl = stage_ptr(buf, 3);
+        const u32x4* sAh = stage_ptr(buf, 0);
+        const u32x4* sBh = stage_ptr(buf, 1);
+        const u32x4* sAl = stage_ptr(buf, 2);
+        const u32x4* sBl = stage_ptr(buf, 3);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int sl = 2 * s + half;
@@ -160,13 +159,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmB p) {
                     acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
                 }
         }
-        if (more) {
-            plane_lstore<SPR>(stage_ptr(buf ^ 1, 0), tid, ra);
-            plane_lstore<SPR>(stage_ptr(buf ^ 1, 1), tid, rb);
-            if constexpr (NPASS == 3) {
-                plane_lstore<SPR>(stage_ptr(buf ^ 1, 2), tid, ral);
-                plane_lstore<SPR>(stage_ptr(buf ^ 1, 3), tid, rbl);
-            }
+        plane_lstore<SPR>(stage_ptr(buf ^ 1, 0), tid, ra);
+        plane_lstore<SPR>(stage_ptr(buf ^ 1, 1), tid, rb);
+        if constexpr (NPASS == 3) {
+            plane_lstore<SPR>(stage_ptr(buf ^ 1, 2), tid, ral);
+            plane_lstore<SPR>(stage_ptr(buf ^ 1, 3), tid, rbl);
         }
         __syncthreads();
         buf ^= 1;

@@ -148,15 +148,20 @@ def transpose_plane(pl: Planes) -> Planes:
     return Planes(dst, None, pl.cols, pl.rows)
 
 
-_wcache = {}
-
-
 def weight_planes(W: torch.Tensor, transposed: bool = False) -> Planes:
-    """planes of a weight [N,K] ([N][pad64(K)] hi+lo) or of its transpose ([K][pad64(N)] hi), cached until the weight
-    changes (optimizer step / in-place update)."""
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
-    ver = (WEIGHT_EPOCH[0], W._version)
-    hit = _wcache.get(key)
+    """planes of a weight [N,K] ([N][pad64(K)] hi+lo) or of its transpose ([K][pad64(N)] hi), cached ON the owning
+    tensor object (so the cache dies with it) until the weight changes (optimizer step / in-place update)."""
+    owner = W._base if W._base is not None else W
+    key = (W.storage_offset(), tuple(W.shape), tuple(W.stride()), transposed)
+    ver = (WEIGHT_EPOCH[0], W._version, W.data_ptr())
+    cache = getattr(owner, "_bmt_planes", None)
+    if cache is None:
+        cache = {}
+        try:
+            owner._bmt_planes = cache
+        except AttributeError:
+            pass
+    hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     Wc = W.detach()
@@ -164,7 +169,7 @@ def weight_planes(W: torch.Tensor, transposed: bool = False) -> Planes:
         _, pl = make_planes(Wc, lo=False, straight=False, transposed=True)
     else:
         pl, _ = make_planes(Wc, lo=True)
-    _wcache[key] = (ver, pl)
+    cache[key] = (ver, pl)
     return pl
 
 
