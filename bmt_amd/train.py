@@ -3,15 +3,21 @@
     zero_grad -> shift captions -> masks -> forward -> LabelSmoothing(pred, y) / n_tokens -> backward
               -> [clip_grad_norm_] -> optimizer.step
 
-with the data-parallel differences of bmt_amd.parallel: n_tokens is the GLOBAL non-pad count and gradients are summed
-over ranks while the backward pass is still running.  No host synchronisation inside the step (the reference's
-``loss.item()`` becomes a device scalar the caller may read whenever it wants)."""
+Two things differ in form (not in result):
+  * the division by n_tokens is applied to the GRADIENTS inside the fused Adam kernel (``grad_scale``) instead of to the
+    loss before backward: d(KL/n)/dw == (dKL/dw)/n.  That makes the normaliser the GLOBAL non-pad count under data
+    parallelism (one scalar all-reduce, epoch_loops/captioning_epoch_loops.py:134-135 semantics) and keeps every collective
+    outside the captured graphs;
+  * the step can be captured into two hipGraphs (forward+backward, optimizer) so that ~800 kernel launches per step are
+    replayed by the runtime instead of being issued one at a time from Python; the gradient all-reduce sits between them.
+No host synchronisation inside the step (the reference's ``loss.item()`` becomes a device scalar)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
 
 import torch
 
+from . import _lib
 from .loss.label_smoothing import LabelSmoothing
 from .model.masking import mask as make_mask
 from .optim import FusedAdam, clip_grad_norm_
@@ -45,17 +51,34 @@ def make_masks(feature_stacks: Dict[str, torch.Tensor], captions: Optional[torch
 
 
 class CaptioningTrainStep:
-    def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20):
+    """One optimizer step of the captioning model.
+
+    ``static_grads`` (implied by ``data_parallel``) binds every ``p.grad`` to a persistent flat bucket
+    (bmt_amd.parallel.GradientReducer): that is what the all-reduce runs on and what lets the step be graph-captured.
+    ``overlap``: launch each bucket's all-reduce from the backward hooks (eager mode); captured steps reduce after the
+    backward graph instead (no collective is ever captured)."""
+
+    def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
+                 static_grads: bool = False, overlap: bool = True):
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
         self.optimizer = optimizer or FusedAdam(params, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
                                                 weight_decay=cfg.weight_decay)
         self.criterion = LabelSmoothing(cfg.smoothing, pad_idx)
-        self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes) if data_parallel else None
+        self.data_parallel = data_parallel
+        self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes, overlap=overlap) \
+            if (data_parallel or static_grads) else None
         self.modality = getattr(cfg, 'modality', 'audio_video')
+        self.grad_scale = torch.ones(1, device=params[0].device, dtype=torch.float32)
+        if hasattr(self.optimizer, "grad_scale"):
+            self.optimizer.grad_scale = self.grad_scale
+        self._fused_scale = hasattr(self.optimizer, "grad_scale")
+        self._graphs = None
 
-    def __call__(self, feature_stacks, caption_idx):
+    # ---- the three phases -------------------------------------------------------------------------------------
+    def _forward_backward(self, feature_stacks, caption_idx):
+        """zero_grad -> masks -> forward -> sum-KL -> backward.  Returns (sum-KL, local non-pad token count)."""
         model = self.model
         model.train()
         if self.reducer is not None:
@@ -66,12 +89,72 @@ class CaptioningTrainStep:
         masks = make_masks(feature_stacks, x, self.modality, self.pad_idx)
         pred = model(feature_stacks, x, masks)
         n_tokens = (y != self.pad_idx).sum()
-        n_global = global_sum(n_tokens) if self.reducer is not None else n_tokens
-        loss = self.criterion(pred, y) / n_global
-        loss.backward()
+        kl = self.criterion(pred, y)
+        kl.backward()
+        return kl.detach(), n_tokens
+
+    def _reduce(self, kl, n_tokens):
+        """gradient sum over ranks (if any) and the global normaliser -> grad_scale = 1 / n_tokens_global."""
         if self.reducer is not None:
             self.reducer.finish()
+        n_global = global_sum(n_tokens) if self.data_parallel else n_tokens
+        self.grad_scale.copy_((1.0 / n_global.to(torch.float32)).reshape(1))
+        return kl / n_global, n_global
+
+    def _optimize(self):
+        if not self._fused_scale or self.cfg.grad_clip is not None:
+            # generic optimizer, or clipping (which must see the normalised gradients): scale in place first
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.mul_(self.grad_scale)
+            if self._fused_scale:
+                self.optimizer.grad_scale = None
         if self.cfg.grad_clip is not None:
             clip_grad_norm_(self.params, self.cfg.grad_clip)
         self.optimizer.step()
-        return loss.detach(), n_tokens
+        if self._fused_scale:
+            self.optimizer.grad_scale = self.grad_scale
+
+    def __call__(self, feature_stacks, caption_idx):
+        kl, n_tokens = self._forward_backward(feature_stacks, caption_idx)
+        loss, _ = self._reduce(kl, n_tokens)
+        self._optimize()
+        return loss, n_tokens
+
+    # ---- hipGraph capture -------------------------------------------------------------------------------------
+    def capture(self, feature_stacks, caption_idx, warmup: int = 2):
+        """Capture {zero_grad .. backward} and {optimizer} into two graphs over STATIC input buffers (copies of the given
+        batch).  ``replay(fs, caps)`` copies a new batch of the same shape into those buffers and launches
+        graph 1 -> (eager) gradient all-reduce + normaliser -> graph 2.  Dropout masks still change on every replay
+        (seed/step live in device memory, the step counter is advanced by a captured kernel), as do Adam's bias corrections."""
+        if self.reducer is None:
+            raise RuntimeError("capture() needs static gradient buffers: construct with static_grads=True")
+        self.reducer.overlap = False            # collectives stay outside the captured region
+        self._static_fs = {k: v.clone() for k, v in feature_stacks.items()}
+        self._static_caps = caption_idx.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up: lazy inits, pointer tables, weight-plane caches, allocator pools
+            for _ in range(warmup):
+                self(self._static_fs, self._static_caps)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._static_kl, self._static_ntok = self._forward_backward(self._static_fs, self._static_caps)
+        self._reduce(self._static_kl, self._static_ntok)
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self._optimize()
+        self._graphs = (g1, g2)
+        return self._graphs
+
+    def replay(self, feature_stacks=None, caption_idx=None):
+        if feature_stacks is not None:
+            for k, v in feature_stacks.items():
+                self._static_fs[k].copy_(v, non_blocking=True)
+            self._static_caps.copy_(caption_idx, non_blocking=True)
+        g1, g2 = self._graphs
+        g1.replay()
+        loss, _ = self._reduce(self._static_kl, self._static_ntok)
+        g2.replay()
+        return loss, self._static_ntok
