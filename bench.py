@@ -275,7 +275,16 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     final_loss = float(loss)
-    note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
+    note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step ({mode})")
+    timer_steps = 0
+    if not args.no_kernel_timer:
+        # per-kernel HIP-event timing needs individual launches: the same step, eagerly issued, right after the timed region
+        timer_steps = 3
+        timer.enabled = True
+        for _ in range(timer_steps):
+            step(fs, caps)
+        torch.cuda.synchronize()
+        timer.enabled = False
 
     t = torch.tensor([dt, float(tokens_local)], dtype=torch.float64, device=dev)
     if world > 1:
