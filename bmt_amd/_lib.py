@@ -91,7 +91,10 @@ SIGNATURES = {
     "bmt_device_cus": (i32, []),
     "bmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "bmt_gemm_bf16": (i32, [C.POINTER(GemmBf16Args), vp]),
-    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp]),
+    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp]),
+    "bmt_planes_desc_bytes": (i32, []),
+    "bmt_planes_desc": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, i64]),
+    "bmt_planes_multi": (i32, [vp, i32, vp]),
     "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),

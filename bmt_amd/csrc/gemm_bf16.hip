@@ -208,36 +208,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------- plane construction
-// 64x64 fp32 tile -> bf16 planes, straight (hi/lo [R][ldp]) and/or transposed (hiT/loT [C][ldpT]), zero padded.
-__global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ src, int64_t ld, int R, int C, uint16_t* __restrict__ hi,
-                                                      uint16_t* __restrict__ lo, int64_t ldp, int pcols, uint16_t* __restrict__ hiT,
-                                                      uint16_t* __restrict__ loT, int64_t ldpT, int pcolsT) {
-    __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+// 64x64 fp32 tile -> bf16 planes, straight (hi/lo [R][ldp]) and/or transposed (hiT/loT [C][ldpT]), zero padded;
+// optional column sums of the source (bias gradients: the gradient tensor is being read here anyway).
+struct PlaneDesc {
+    const float* src; int64_t ld; int R, C;
+    uint16_t *hi, *lo; int64_t ldp; int pcols;
+    uint16_t *hiT, *loT; int64_t ldpT; int pcolsT;
+    float* colsum;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, float (*tile)[65]) {
+    const int r0 = by * 64, c0 = bx * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 row groups
+    float csum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
-        const float v = (r < R && c < C) ? src[(int64_t)r * ld + c] : 0.f;
+        const float v = (r < d.R && c < d.C) ? d.src[(int64_t)r * d.ld + c] : 0.f;
+        csum += v;
         tile[ty * 16 + i][tx] = v;
-        if (hi && r < R && c < pcols) {
+        if (d.hi && r < d.R && c < d.pcols) {
             const __bf16 h = (__bf16)v;
-            hi[(int64_t)r * ldp + c] = __builtin_bit_cast(uint16_t, h);
-            if (lo) lo[(int64_t)r * ldp + c] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+            d.hi[(int64_t)r * d.ldp + c] = __builtin_bit_cast(uint16_t, h);
+            if (d.lo) d.lo[(int64_t)r * d.ldp + c] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
         }
     }
-    if (hiT) {
+    if (d.hiT) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int c = c0 + ty * 16 + i, r = r0 + tx;     // output row = source column c, output column = source row r
-            if (c < C && r < pcolsT) {
+            if (c < d.C && r < d.pcolsT) {
                 const float v = tile[tx][ty * 16 + i];
                 const __bf16 h = (__bf16)v;
-                hiT[(int64_t)c * ldpT + r] = __builtin_bit_cast(uint16_t, h);
-                if (loT) loT[(int64_t)c * ldpT + r] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+                d.hiT[(int64_t)c * d.ldpT + r] = __builtin_bit_cast(uint16_t, h);
+                if (d.loT) d.loT[(int64_t)c * d.ldpT + r] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
             }
         }
+    }
+    if (d.colsum) {
+        __syncthreads();
+        tile[ty][tx] = csum;          // rows 0..3 of the tile reused as the 4 partial sums per column
+        __syncthreads();
+        if (ty == 0 && c0 + tx < d.C) atomicAdd(d.colsum + c0 + tx, (tile[0][tx] + tile[1][tx]) + (tile[2][tx] + tile[3][tx]));
+    }
+}
+
+__global__ __launch_bounds__(256) void planes_kernel(const PlaneDesc d) {
+    __shared__ float tile[64][65];
+    planes_tile(d, blockIdx.x, blockIdx.y, tile);
+}
+
+// every weight of the model in ONE launch: blockIdx.y = tensor, blockIdx.x strides over its 64x64 tiles
+__global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __restrict__ table) {
+    __shared__ float tile[64][65];
+    const PlaneDesc d = table[blockIdx.y];
+    const int nt = d.tiles_x * d.tiles_y;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        planes_tile(d, t % d.tiles_x, t / d.tiles_x, tile);
+        __syncthreads();
     }
 }
 
@@ -295,17 +325,49 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     return a->precision == BMT_PREC_BF16X3 ? launch<3>(p, splitk, (hipStream_t)stream) : launch<1>(p, splitk, (hipStream_t)stream);
 }
 
-extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-                          uint16_t* loT, int64_t ldpT, void* stream) {
-    BMT_CHECK_ARG(src && (hi || hiT) && R > 0 && C > 0, "bmt_planes: bad args");
+static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
+                     uint16_t* loT, int64_t ldpT, float* colsum) {
+    BMT_CHECK_ARG(src && (hi || hiT || colsum) && R > 0 && C > 0, "bmt_planes: bad args");
     BMT_CHECK_ARG(!hi || ldp >= C, "bmt_planes: ldp < C");
     BMT_CHECK_ARG(!hiT || ldpT >= R, "bmt_planes: ldpT < R");
     // padding written with zeros: up to the next multiple of 64 (bounded by the row stride)
-    const int pcols = hi ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
-    const int pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
-    const int gx = bmt_cdiv(pcols > C ? pcols : C, 64), gy = bmt_cdiv(pcolsT > R ? pcolsT : R, 64);
-    hipLaunchKernelGGL(planes_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, ld, R, C, hi, lo, ldp, pcols, hiT, loT, ldpT, pcolsT);
+    d.src = src; d.ld = ld; d.R = R; d.C = C; d.hi = hi; d.lo = lo; d.ldp = ldp; d.hiT = hiT; d.loT = loT; d.ldpT = ldpT;
+    d.colsum = colsum;
+    d.pcols = hi ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
+    d.pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
+    d.tiles_x = bmt_cdiv(d.pcols > C ? d.pcols : C, 64);
+    d.tiles_y = bmt_cdiv(d.pcolsT > R ? d.pcolsT : R, 64);
+    return BMT_OK;
+}
+
+extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
+                          uint16_t* loT, int64_t ldpT, float* colsum, void* stream) {
+    PlaneDesc d;
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, colsum);
+    if (rc) return rc;
+    hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
     BMT_CHECK_LAUNCH("bmt_planes");
+    return BMT_OK;
+}
+
+// host helper: fill one 96-byte descriptor of the multi-tensor table (the caller uploads the table to device memory)
+extern "C" int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,
+                               uint16_t* hiT, uint16_t* loT, int64_t ldpT) {
+    BMT_CHECK_ARG(desc_out, "bmt_planes_desc: null");
+    PlaneDesc d;
+    memset(&d, 0, sizeof(d));
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, nullptr);
+    if (rc) return rc;
+    memcpy(desc_out, &d, sizeof(d));
+    return BMT_OK;
+}
+extern "C" int bmt_planes_desc_bytes(void) { return (int)sizeof(PlaneDesc); }
+
+extern "C" int bmt_planes_multi(const void* table_dev, int n_tensors, void* stream) {
+    BMT_CHECK_ARG(table_dev && n_tensors > 0 && n_tensors <= 65535, "bmt_planes_multi: bad args");
+    hipLaunchKernelGGL(planes_multi_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PlaneDesc*>(table_dev));
+    BMT_CHECK_LAUNCH("bmt_planes_multi");
     return BMT_OK;
 }
 

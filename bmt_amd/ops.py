@@ -128,8 +128,9 @@ class Planes:
         self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
 
 
-def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transposed: bool = False):
-    """one pass over fp32 x2 [R,C]: -> Planes [R][pad64(C)] (hi[,lo]) and/or transposed hi plane [C][pad64(R)]"""
+def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transposed: bool = False, colsum=None):
+    """one pass over fp32 x2 [R,C]: -> Planes [R][pad64(C)] (hi[,lo]) and/or transposed hi plane [C][pad64(R)];
+    colsum (optional fp32 [C]) += column sums of x2 (atomic)."""
     R, Cc = x2.shape
     hi = lo_ = hiT = None
     if straight:
@@ -137,7 +138,8 @@ def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transp
         lo_ = torch.empty(R, _pad64(Cc), device=x2.device, dtype=torch.bfloat16) if lo else None
     if transposed:
         hiT = torch.empty(Cc, _pad64(R), device=x2.device, dtype=torch.bfloat16)
-    _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _st()), "bmt_planes")
+    _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _p(colsum), _st()),
+               "bmt_planes")
     return (Planes(hi, lo_, R, Cc) if straight else None), (Planes(hiT, None, Cc, R) if transposed else None)
 
 
@@ -148,29 +150,77 @@ def transpose_plane(pl: Planes) -> Planes:
     return Planes(dst, None, pl.cols, pl.rows)
 
 
+class _WeightPlanes:
+    """bf16 operand planes of every weight that takes part in a GEMM: [N][pad64(K)] hi+lo (forward operand) and the
+    transposed hi plane [K][pad64(N)] (dX operand), in persistent buffers, ALL refreshed by one multi-tensor launch the
+    first time a weight is needed after the optimizer moved them (WEIGHT_EPOCH) -- instead of ~200 small launches."""
+
+    def __init__(self):
+        self.entries = []          # [weakref(W), key, Planes straight, Planes transposed, version]
+        self.index = {}            # (id(owner), key) -> position
+        self.table = None          # device descriptor table
+        self.fresh_epoch = -1
+        self.dirty_table = True
+
+    @staticmethod
+    def _key(W):
+        return (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
+
+    def _register(self, W):
+        import weakref
+        N, K = W.shape
+        dev = W.device
+        st = Planes(torch.empty(N, _pad64(K), device=dev, dtype=torch.bfloat16),
+                    torch.empty(N, _pad64(K), device=dev, dtype=torch.bfloat16), N, K)
+        tr = Planes(torch.empty(K, _pad64(N), device=dev, dtype=torch.bfloat16), None, K, N)
+        owner = W._base if W._base is not None else W
+        self.entries.append([weakref.ref(owner), self._key(W), st, tr, None, W.detach()])
+        self.index[(id(owner), self._key(W))] = len(self.entries) - 1
+        self.dirty_table = True
+        return self.entries[-1]
+
+    def _prune(self):
+        alive = [e for e in self.entries if e[0]() is not None]
+        if len(alive) != len(self.entries):
+            self.entries = alive
+            self.index = {(id(e[0]()), e[1]): i for i, e in enumerate(alive)}
+            self.dirty_table = True
+
+    def _refresh_all(self):
+        self._prune()
+        if not self.entries:
+            return
+        if self.dirty_table:
+            nb = lib.bmt_planes_desc_bytes()
+            host = torch.zeros(len(self.entries), nb, dtype=torch.uint8)
+            for i, e in enumerate(self.entries):
+                Wd, st, tr = e[5], e[2], e[3]
+                _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
+                                               _p(st.hi), _p(st.lo), st.hi.stride(0), _p(tr.hi), None, tr.hi.stride(0)),
+                           "bmt_planes_desc")
+            self.table = host.to(self.entries[0][5].device)
+            self.dirty_table = False
+        _lib.check(lib.bmt_planes_multi(_p(self.table), len(self.entries), _st()), "bmt_planes_multi")
+        for e in self.entries:
+            e[4] = e[5]._version
+        self.fresh_epoch = WEIGHT_EPOCH[0]
+
+    def get(self, W, transposed):
+        owner = W._base if W._base is not None else W
+        pos = self.index.get((id(owner), self._key(W)))
+        e = self.entries[pos] if pos is not None and pos < len(self.entries) else None
+        if e is None or e[0]() is not owner:
+            e = self._register(W)
+        if self.fresh_epoch != WEIGHT_EPOCH[0] or e[4] != W._version or self.dirty_table:
+            self._refresh_all()
+        return e[3] if transposed else e[2]
+
+
+_weights = _WeightPlanes()
+
+
 def weight_planes(W: torch.Tensor, transposed: bool = False) -> Planes:
-    """planes of a weight [N,K] ([N][pad64(K)] hi+lo) or of its transpose ([K][pad64(N)] hi), cached ON the owning
-    tensor object (so the cache dies with it) until the weight changes (optimizer step / in-place update)."""
-    owner = W._base if W._base is not None else W
-    key = (W.storage_offset(), tuple(W.shape), tuple(W.stride()), transposed)
-    ver = (WEIGHT_EPOCH[0], W._version, W.data_ptr())
-    cache = getattr(owner, "_bmt_planes", None)
-    if cache is None:
-        cache = {}
-        try:
-            owner._bmt_planes = cache
-        except AttributeError:
-            pass
-    hit = cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
-    Wc = W.detach()
-    if transposed:
-        _, pl = make_planes(Wc, lo=False, straight=False, transposed=True)
-    else:
-        pl, _ = make_planes(Wc, lo=True)
-    cache[key] = (ver, pl)
-    return pl
+    return _weights.get(W, transposed)
 
 
 def as_planes(x, need_lo: bool) -> Planes:
@@ -280,33 +330,97 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     return out
 
 
-def linear_dw(dyT, xT, N: int = 0, K: int = 0) -> torch.Tensor:
+def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """dW[N,K] = dy[M,N]^T @ x[M,K]   (reduction over M, split-K with atomic accumulation).
     plane path: dyT = transposed hi plane of dy [N][pad64(M)], xT = transposed hi plane of x [K][pad64(M)];
-    fp32 path: dyT = dy2 [M,N], xT = x2 [M,K]."""
+    fp32 path: dyT = dy2 [M,N], xT = x2 [M,K].   into: accumulate straight into this (live) gradient buffer."""
     if not USE_PLANE_GEMM:
         dy2, x2 = dyT, xT
         M, N = dy2.shape
         K = x2.shape[1]
         sk = _splitk_for(N, K, M)
-        dW = torch.zeros(N, K, device=dy2.device, dtype=torch.float32) if sk > 1 else \
-            torch.empty(N, K, device=dy2.device, dtype=torch.float32)
-        gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=K, a_kc=False, b_kc=False,
-             accum=sk > 1, splitk=sk, precision=BWD_PRECISION)
-        return dW
+        acc = into is not None or sk > 1
+        dW = into if into is not None else (torch.zeros if sk > 1 else torch.empty)(N, K, device=dy2.device, dtype=torch.float32)
+        gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=dW.stride(0), a_kc=False, b_kc=False,
+             accum=acc, splitk=sk, precision=BWD_PRECISION)
+        return None if into is not None else dW
     N, K, M = dyT.rows, xT.rows, dyT.cols
     sk = _splitk_for(N, K, M)
-    dW = torch.zeros(N, K, device=dyT.hi.device, dtype=torch.float32) if sk > 1 else \
-        torch.empty(N, K, device=dyT.hi.device, dtype=torch.float32)
-    gemm_bf16(dyT, xT, dW, ldc=K, accum=sk > 1, splitk=sk, precision=PREC_BF16)
-    return dW
+    acc = into is not None or sk > 1
+    dW = into if into is not None else (torch.zeros if sk > 1 else torch.empty)(N, K, device=dyT.hi.device, dtype=torch.float32)
+    gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16)
+    return None if into is not None else dW
 
 
-def grad_planes(dy2: torch.Tensor):
-    """(operand for dX, operand for dW) of an upstream gradient, one pass: hi plane and transposed hi plane."""
+def static_grad(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """the persistent gradient buffer of a parameter, if bmt_amd.parallel.GradientReducer bound one (``p.grad`` is then a
+    view into a flat bucket that is zeroed once per step): weight / bias gradients are accumulated straight into it by
+    the GEMM epilogue / column-sum atomics -- no dW temporary, no zero-fill, no ``grad += dW`` pass."""
+    if p is None or not getattr(p, "_bmt_static_grad", False) or p.grad is None or not p.grad.is_contiguous():
+        return None
+    return p.grad
+
+
+def grad_done(p: Optional[torch.Tensor]):
+    """tell the reducer that p's gradient is final (replaces autograd's post-accumulate hook for fused accumulation)"""
+    cb = getattr(p, "_bmt_on_grad", None) if p is not None else None
+    if cb is not None:
+        cb(p)
+
+
+def wgrad(W, b, dyT, xT, dy2_for_bias=None, bias_sum=None):
+    """weight and bias gradient of a Linear: returns (dW, db) tensors for autograd, or (None, None) after accumulating into
+    the parameters' static buffers.  bias_sum: an already computed column sum (from grad_planes) or None."""
+    gW = static_grad(W)
+    dW = linear_dw(dyT, xT, into=gW)
+    if gW is not None:
+        grad_done(W)
+    db = None
+    if b is not None:
+        gb = static_grad(b)
+        if bias_sum is None:
+            bias_sum = colsum(dy2_for_bias)
+        if gb is not None:
+            gb.add_(bias_sum)
+            grad_done(b)
+        else:
+            db = bias_sum
+    return dW, db
+
+
+def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bool = True, **dx_epi):
+    """backward of y = x W^T + b given dy2 [M,N]: one pass builds the gradient's operand planes (+ bias column sums),
+    then dX = dY.W and dW += dY^T.X.  Returns (dx or None, dW or None, db or None); dW/db are None when they were
+    accumulated straight into the parameters' static gradient buffers."""
+    P, T, bias_done = grad_planes(dy2, b)
+    dx = linear_dx(P, W, **dx_epi) if need_dx else None
+    dW = db = None
+    if need_dw:
+        dW, db = wgrad(W, None if bias_done else b, T, input_t(x_for_dw) if not isinstance(x_for_dw, PlanesT) else x_for_dw.p,
+                       dy2_for_bias=dy2)
+    elif b is not None and not bias_done:
+        db = colsum(dy2)
+    return dx, dW, db
+
+
+class PlanesT:
+    """marker: an already transposed operand for the dW product"""
+    __slots__ = ("p",)
+
+    def __init__(self, p):
+        self.p = p
+
+
+def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """(operand for dX, operand for dW, bias-gradient handled?) of an upstream gradient in ONE pass over it: hi plane,
+    transposed hi plane and -- when ``bias`` has a static gradient buffer -- its column sums accumulated into that buffer."""
     if not USE_PLANE_GEMM:
-        return dy2, dy2
-    return make_planes(dy2, lo=False, straight=True, transposed=True)
+        return dy2, dy2, False
+    gb = static_grad(bias)
+    P, T = make_planes(dy2, lo=False, straight=True, transposed=True, colsum=gb)
+    if gb is not None:
+        grad_done(bias)
+    return P, T, gb is not None
 
 
 def input_t(x2):
@@ -491,6 +605,7 @@ class LinearActFn(torch.autograd.Function):
         y = linear_fwd(x2, W, b, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"), drop_p=p, site=site)
         ctx.relu, ctx.drop_mode, ctx.p, ctx.site = relu, drop_mode, p, site
         ctx.has_bias = b is not None
+        ctx.params = (W, b)
         ctx.save_for_backward(x2, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
         return y.view(*xc.shape[:-1], W.shape[0])
 
@@ -507,10 +622,11 @@ class LinearActFn(torch.autograd.Function):
             dz = dropout_raw(dy2, p, ctx.site)
         else:
             dz = dy2
-        dzP, dzT = grad_planes(dz)
-        dx = linear_dx(dzP, W).view(*dy.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
-        dW = linear_dw(dzT, input_t(x2)) if ctx.needs_input_grad[1] else None
-        db = colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        Wp, bp = ctx.params
+        dx, dW, db = lin_bwd(dz, Wp, bp if ctx.has_bias else None, x2, need_dx=ctx.needs_input_grad[0],
+                             need_dw=ctx.needs_input_grad[1])
+        if dx is not None:
+            dx = dx.view(*dy.shape[:-1], W.shape[1])
         return dx, dW, db, None, None, None, None
 
 
@@ -528,6 +644,7 @@ class FFNFn(torch.autograd.Function):
         y = linear_fwd(h if USE_PLANE_GEMM else _planes_to_f32(h), W2, b2)
         ctx.p = p
         ctx.h = h
+        ctx.params = (W1, b1, W2, b2)
         ctx.save_for_backward(x2, W1, W2)
         return y.view(*xc.shape[:-1], W2.shape[0])
 
@@ -537,22 +654,18 @@ class FFNFn(torch.autograd.Function):
         h = ctx.h
         dy2 = _f32c(dy).view(-1, W2.shape[0])
         gscale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
+        W1p, b1p, W2p, b2p = ctx.params
         if USE_PLANE_GEMM:
-            dyP, dyT = grad_planes(dy2)
-            dW2 = linear_dw(dyT, transpose_plane(h))
-            dh = linear_dx(dyP, W2, gate=h, gate_scale=gscale)
+            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(transpose_plane(h)), gate=h, gate_scale=gscale)
         else:
             hf = _planes_to_f32(h)
-            dW2 = linear_dw(dy2, hf)
-            dh = linear_dx(dy2, W2)
+            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, hf)
             tmp = torch.empty_like(dh)
             _lib.check(lib.bmt_gate(_p(dh), _p(hf), gscale, _p(tmp), dh.numel(), _st()), "bmt_gate")
             dh = tmp
-        db2 = colsum(dy2)
-        dhP, dhT = grad_planes(dh)
-        dW1 = linear_dw(dhT, input_t(x2))
-        db1 = colsum(dh)
-        dx = linear_dx(dhP, W1).view(*dy.shape[:-1], W1.shape[1]) if ctx.needs_input_grad[0] else None
+        dx, dW1, db1 = lin_bwd(dh, W1p, b1p, x2, need_dx=ctx.needs_input_grad[0])
+        if dx is not None:
+            dx = dx.view(*dy.shape[:-1], W1.shape[1])
         return dx, dW1, db1, dW2, db2, None, None
 
 
@@ -595,6 +708,7 @@ class MHAFn(torch.autograd.Function):
         ctx.H, ctx.p, ctx.site = H, p, site
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
         ctx.mask = mask
+        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, q.hi.view(B, Sq, D), k.hi.view(B, Sk, D), v.hi.view(B, Sk, D), o, lse)
         return out
 
@@ -606,44 +720,42 @@ class MHAFn(torch.autograd.Function):
         D = Wq.shape[0]
         dy2 = _f32c(dout).view(-1, Dq)
         o2 = o.view(-1, D)
-        dyP, dyT = grad_planes(dy2)
-        dWo = linear_dw(dyT, input_t(o2))
-        dbo = colsum(dy2)
-        # gradient w.r.t. the PRE-dropout attention output: the dropout mask is re-applied in the GEMM epilogue
-        do = linear_dx(dyP, Wo, drop_post=True, drop_p=ctx.p, site=ctx.site).view(B, Sq, D)
+        Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
+        # gradient w.r.t. the PRE-dropout attention output: the dropout mask is re-applied in the dX GEMM's epilogue
+        do, dWo, dbo = lin_bwd(dy2, Wop, bop, o2, drop_post=True, drop_p=ctx.p, site=ctx.site)
+        do = do.view(B, Sq, D)
         dq, dk, dv = attn_bwd_bf16(q, k, v, o, do, lse, ctx.mask, ctx.H, drop_p=ctx.p)
         dq2, dk2, dv2 = dq.view(-1, D), dk.view(-1, D), dv.view(-1, D)
         Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
-        QT = input_t(Q2)
-        KT = QT if ctx.same_qk else input_t(K2)
-        VT = KT if ctx.same_kv else input_t(V2)
-        dqP, dqT = grad_planes(dq2)
-        dkP, dkT = grad_planes(dk2)
-        dvP, dvT = grad_planes(dv2)
-        dWq, dbq = linear_dw(dqT, QT), colsum(dq2)
-        dWk, dbk = linear_dw(dkT, KT), colsum(dk2)
-        dWv, dbv = linear_dw(dvT, VT), colsum(dv2)
+        if USE_PLANE_GEMM:      # transposed operand of each distinct input, once
+            QT = PlanesT(input_t(Q2))
+            KT = QT if ctx.same_qk else PlanesT(input_t(K2))
+            VT = KT if ctx.same_kv else PlanesT(input_t(V2))
+        else:
+            QT, KT, VT = Q2, K2, V2
         needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dQ = dK = dV = None
-        if ctx.same_qk and ctx.same_kv:          # self-attention: one input, three contributions summed in the epilogue
+        self_attn = ctx.same_qk and ctx.same_kv
+        dxq, dWq, dbq = lin_bwd(dq2, Wqp, bqp, QT, need_dx=needQ)
+        if self_attn:            # one input, three contributions summed in the dX GEMM epilogue
+            _, dWk, dbk = lin_bwd(dk2, Wkp, bkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=dxq.stride(0) if needQ else 0)
+            _, dWv, dbv = lin_bwd(dv2, Wvp, bvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=dxq.stride(0) if needQ else 0)
             if needQ:
-                acc = linear_dx(dqP, Wq)
-                linear_dx(dkP, Wk, out=acc, residual=acc, ldr=acc.stride(0))
-                linear_dx(dvP, Wv, out=acc, residual=acc, ldr=acc.stride(0))
-                dQ = acc.view(Qc.shape)
+                dQ = dxq.view(Qc.shape)
         else:
             if needQ:
-                dQ = linear_dx(dqP, Wq).view(Qc.shape)
+                dQ = dxq.view(Qc.shape)
             if ctx.same_kv:
-                if needK or needV:
-                    acc = linear_dx(dkP, Wk)
-                    linear_dx(dvP, Wv, out=acc, residual=acc, ldr=acc.stride(0))
-                    dK = acc.view(Kc.shape)     # autograd adds dK and dV for the shared tensor; dV stays None
+                need = needK or needV
+                dxk, dWk, dbk = lin_bwd(dk2, Wkp, bkp, KT, need_dx=need)
+                _, dWv, dbv = lin_bwd(dv2, Wvp, bvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
+                if need:
+                    dK = dxk.view(Kc.shape)      # autograd adds dK and dV for the shared tensor; dV stays None
             else:
-                if needK:
-                    dK = linear_dx(dkP, Wk).view(Kc.shape)
-                if needV:
-                    dV = linear_dx(dvP, Wv).view(Vc.shape)
+                dxk, dWk, dbk = lin_bwd(dk2, Wkp, bkp, KT, need_dx=needK)
+                dxv, dWv, dbv = lin_bwd(dv2, Wvp, bvp, VT, need_dx=needV)
+                dK = dxk.view(Kc.shape) if needK else None
+                dV = dxv.view(Vc.shape) if needV else None
         return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
 
 
@@ -658,6 +770,7 @@ class GeneratorFn(torch.autograd.Function):
         logp = linear_fwd(x2, W, b)
         _lib.check(lib.bmt_log_softmax_fwd(_p(logp), logp.stride(0), logp.shape[0], V, _st()), "bmt_log_softmax_fwd")
         ctx.save_for_backward(x2, W, logp)
+        ctx.params = (W, b)
         return logp.view(*xc.shape[:-1], V)
 
     @staticmethod
@@ -668,9 +781,11 @@ class GeneratorFn(torch.autograd.Function):
         dlogits = torch.empty_like(d2)
         _lib.check(lib.bmt_log_softmax_bwd(_p(logp), logp.stride(0), _p(d2), d2.stride(0), _p(dlogits), dlogits.stride(0),
                                            d2.shape[0], V, _st()), "bmt_log_softmax_bwd")
-        dP, dT = grad_planes(dlogits)
-        dx = linear_dx(dP, W).view(*dlogp.shape[:-1], W.shape[1]) if ctx.needs_input_grad[0] else None
-        return dx, linear_dw(dT, input_t(x2)), colsum(dlogits)
+        Wp, bp = ctx.params
+        dx, dW, db = lin_bwd(dlogits, Wp, bp, x2, need_dx=ctx.needs_input_grad[0])
+        if dx is not None:
+            dx = dx.view(*dlogp.shape[:-1], W.shape[1])
+        return dx, dW, db
 
 
 class LabelSmoothingFn(torch.autograd.Function):

@@ -49,6 +49,9 @@ class GradientReducer:
             for si, p in enumerate(b["params"]):
                 self._slot[p] = (bi, si)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        for p in params:       # lets the fused weight-gradient path (ops.static_grad / ops.grad_done) find its buffer and report
+            p._bmt_static_grad = True
+            p._bmt_on_grad = self._on_grad
         self._handles = []
         self.zero_grad()
 
@@ -96,6 +99,10 @@ class GradientReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        for b in self.buckets:
+            for p in b["params"]:
+                p._bmt_static_grad = False
+                p._bmt_on_grad = None
 
 
 def global_sum(t: torch.Tensor, group=None) -> torch.Tensor:

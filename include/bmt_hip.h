@@ -106,7 +106,13 @@ int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL
  * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
 int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-               uint16_t* loT, int64_t ldpT, void* stream);
+               uint16_t* loT, int64_t ldpT, float* colsum /* optional: colsum[c] += sum_r src[r][c] (atomic) */, void* stream);
+/* the same for MANY tensors in one launch (all weights of a model after an optimizer step): the caller fills a host table of
+ * bmt_planes_desc_bytes()-sized descriptors with bmt_planes_desc, uploads it, and passes the device pointer. */
+int bmt_planes_desc_bytes(void);
+int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,
+                    uint16_t* hiT, uint16_t* loT, int64_t ldpT);
+int bmt_planes_multi(const void* table_dev, int n_tensors, void* stream);
 
 /* bf16 [R][ld] -> transposed bf16 [C][ldT], zero padded up to min(round_up(R,64), ldT) */
 int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C, uint16_t* dst, int64_t ldT, void* stream);

@@ -57,7 +57,7 @@ def test_gemm_dx_dw_layouts(ops, gemm_path, M, N, K):
     """dX = dY.W and dW = dY^T.X (reduction over rows, split-K atomics) on both GEMM paths."""
     dy, W, x = rnd(M, N, seed=4), rnd(N, K, seed=5), rnd(M, K, seed=6)
     dyd, xd = dy.to(DEV), x.to(DEV)
-    dyP, dyT = ops.grad_planes(dyd)
+    dyP, dyT, _ = ops.grad_planes(dyd)
     dx = ops.linear_dx(dyP, W.to(DEV))
     want = bf16_round(dy).double() @ bf16_round(W).double()
     assert_close(dx, want, atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx")

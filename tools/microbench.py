@@ -46,7 +46,7 @@ def gemm_bench():
             for prec in (3, 1):
                 xin = ops.make_planes(x, lo=True)[0] if path else x
                 timeit(lambda: ops.linear_fwd(xin, W, b, out=out, precision=prec), 2.0 * M * N * K, f"linear_fwd {tag} x{prec} {name}")
-            dyP, dyT = ops.grad_planes(dy)
+            dyP, dyT, _ = ops.grad_planes(dy)
             xT = ops.input_t(x)
             timeit(lambda: ops.linear_dx(dyP, W), 2.0 * M * N * K, f"linear_dx  {tag} x1 {name}")
             timeit(lambda: ops.linear_dw(dyT, xT), 2.0 * M * N * K, f"linear_dw  {tag} x1 {name}")
