@@ -64,7 +64,8 @@ class AttnFwdBf16Args(C.Structure):
                 ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64),
                 ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
-                ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32)]
+                ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32),
+                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64)]
 
 
 class AttnBwdBf16Args(C.Structure):
@@ -74,7 +75,11 @@ class AttnBwdBf16Args(C.Structure):
                 ("bsq", i64), ("bsk", i64), ("bsv", i64), ("bso", i64), ("dkv_ld", i64), ("dkv_bs", i64),
                 ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
-                ("scale", f32), ("drop_p", f32)]
+                ("scale", f32), ("drop_p", f32),
+                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64),
+                ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
+                ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
+                ("dbq", vp), ("dbk", vp), ("dbv", vp)]
 
 
 class Conv1dArgs(C.Structure):

@@ -129,11 +129,23 @@ __device__ __forceinline__ bf16x8 ldfrag(const uint16_t* p, bool ok) {
     return as_bf16x8(v);
 }
 
+// one gradient output (dQ, dK or dV) in up to four forms, all optional
+struct GradOut {
+    float* f32; int64_t f_ld, f_bs;        // fp32 [B,S,D]
+    uint16_t* hi; int64_t h_ld, h_bs;      // bf16 plane, row b*S+s at hi + b*h_bs + s*h_ld   (dX operand of the projection)
+    uint16_t* hiT; int64_t t_ld;           // transposed bf16 plane [D][t_ld], column b*S+s      (dW operand)
+    float* bsum;                           // fp32 [D] += sum over (b,s)                          (bias gradient)
+};
+
 struct AttnPB {
     const uint16_t *Qh, *Ql, *Kh, *Kl, *Vh, *Vl, *dOh;
     const float *O, *dO, *lse;
-    float *Ow, *lsew, *dQ, *dK, *dV, *delta;
-    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;     // plane strides for Q/K/V (and dOh: ldo/bso); fp32 O/dO/dQ.. share them
+    const uint16_t *Oph, *Opl;             // saved forward output as planes (backward, when O == nullptr)
+    float *Ow, *lsew, *delta;
+    uint16_t *Owh, *Owl;                   // forward output planes (optional), strides ldop / bsop
+    int64_t ldop, bsop;
+    GradOut gq, gk, gv;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;     // plane strides for Q/K/V (and dOh: ldo/bso); fp32 O/dO share ldo/bso
     const uint8_t* mask;
     int64_t mask_bs, mask_qs;
     int B, H, Sq, Sk;
@@ -157,6 +169,77 @@ __device__ __forceinline__ void stage_mask(const AttnPB& p, int b, int key0, int
             int f = (valid == 0) ? 0 : ((valid == full) ? 2 : 1);
             if (p.mask != nullptr && p.mask_qs != 0 && f == 2) f = 1;   // general (B,Sq,Sk) mask: checked per element
             sFlag[0] = f;
+        }
+    }
+}
+
+// ---- gradient tile epilogue.  acc[dt][r] = G^T[d = dt*32 + acc_row(r, half)][token = this lane's l31 column].
+template <int DK>
+__device__ __forceinline__ void grad_store_rows(const GradOut& g, const f32x16 (&acc)[DK / 32], int b, int h, int tok, bool ok, int half) {
+    if (!ok) return;
+    if (g.f32) {
+        float* dst = g.f32 + (int64_t)b * g.f_bs + (int64_t)tok * g.f_ld + h * DK;
+#pragma unroll
+        for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<float4*>(dst + dt * 32 + 8 * r4 + 4 * half) =
+                    make_float4(acc[dt][4 * r4 + 0], acc[dt][4 * r4 + 1], acc[dt][4 * r4 + 2], acc[dt][4 * r4 + 3]);
+    }
+    if (g.hi) {
+        uint16_t* dst = g.hi + (int64_t)b * g.h_bs + (int64_t)tok * g.h_ld + h * DK;
+#pragma unroll
+        for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                u32x2 v;
+                v[0] = pack_bf2(acc[dt][4 * r4 + 0], acc[dt][4 * r4 + 1]);
+                v[1] = pack_bf2(acc[dt][4 * r4 + 2], acc[dt][4 * r4 + 3]);
+                *reinterpret_cast<u32x2*>(dst + dt * 32 + 8 * r4 + 4 * half) = v;
+            }
+    }
+}
+// the transposed plane and the bias sums go through an LDS image [DK][NTOK + 8] of bf16 (tokens contiguous)
+template <int DK, int NTOK>
+__device__ __forceinline__ void grad_tile_write(uint16_t* tile, const f32x16 (&acc)[DK / 32], int tc, bool ok, int l31, int half) {
+    constexpr int TS = NTOK + 8;
+#pragma unroll
+    for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const __bf16 hv = (__bf16)acc[dt][r];
+            tile[(dt * 32 + acc_row(r, half)) * TS + tc + l31] = ok ? __builtin_bit_cast(uint16_t, hv) : (uint16_t)0;
+        }
+}
+template <int DK, int NTOK>
+__device__ __forceinline__ void grad_tile_flush(const uint16_t* tile, const GradOut& g, int b, int h, int tok0, int S, int tid) {
+    constexpr int TS = NTOK + 8, GR = NTOK / 8;
+    if (g.hiT) {
+        uint16_t* base = g.hiT + (int64_t)(h * DK) * g.t_ld + (int64_t)b * S + tok0;
+        const bool vec = (S % 8 == 0) && (g.t_ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.hiT) & 15) == 0);
+        if (vec) {
+            for (int idx = tid; idx < DK * GR; idx += 256) {
+                const int row = idx / GR, gq = idx % GR;
+                if (tok0 + gq * 8 < S)
+                    *reinterpret_cast<u32x4*>(base + (int64_t)row * g.t_ld + gq * 8) = *reinterpret_cast<const u32x4*>(tile + row * TS + gq * 8);
+            }
+        } else {
+            for (int idx = tid; idx < DK * NTOK; idx += 256) {
+                const int row = idx / NTOK, c = idx % NTOK;
+                if (tok0 + c < S) base[(int64_t)row * g.t_ld + c] = tile[row * TS + c];
+            }
+        }
+    }
+    if (g.bsum) {
+        for (int d = tid; d < DK; d += 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < GR; ++gq) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + d * TS + gq * 8);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sum += __uint_as_float(v[c] << 16) + __uint_as_float(v[c] & 0xffff0000u);
+            }
+            atomicAdd(g.bsum + h * DK + d, sum);
         }
     }
 }
@@ -335,7 +418,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                 v.y = drop_apply(dc, o[dt][4 * r4 + 1] * inv, (uint64_t)(rowoff + d + 1));
                 v.z = drop_apply(dc, o[dt][4 * r4 + 2] * inv, (uint64_t)(rowoff + d + 2));
                 v.w = drop_apply(dc, o[dt][4 * r4 + 3] * inv, (uint64_t)(rowoff + d + 3));
-                *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
+                if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
+                if (p.Owh) {      // operand planes of the out-projection, written here instead of by a conversion pass
+                    const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + d;
+                    uint32_t h0, l0, h1, l1;
+                    split_bf2(v.x, v.y, h0, l0);
+                    split_bf2(v.z, v.w, h1, l1);
+                    u32x2 hh, ll;
+                    hh[0] = h0; hh[1] = h1; ll[0] = l0; ll[1] = l1;
+                    *reinterpret_cast<u32x2*>(p.Owh + po) = hh;
+                    if (p.Owl) *reinterpret_cast<u32x2*>(p.Owl + po) = ll;
+                }
             }
         if (half == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run + __logf(l_run);
     }
@@ -352,9 +445,22 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, in
     const int bh = (int)(row / p.Sq);
     const int b = bh / p.H, h = bh % p.H;
     const int64_t off = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+    const int64_t poff = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK;
     float s = 0.f;
     for (int d = lane * 4; d < DK; d += 256) {
-        const float4 a = *reinterpret_cast<const float4*>(p.dO + off + d), c = *reinterpret_cast<const float4*>(p.O + off + d);
+        const float4 a = *reinterpret_cast<const float4*>(p.dO + off + d);
+        float4 c;
+        if (p.O) {
+            c = *reinterpret_cast<const float4*>(p.O + off + d);
+        } else {
+            const u32x2 hh = *reinterpret_cast<const u32x2*>(p.Oph + poff + d);
+            u32x2 ll; ll[0] = 0u; ll[1] = 0u;
+            if (p.Opl) ll = *reinterpret_cast<const u32x2*>(p.Opl + poff + d);
+            c.x = __uint_as_float(hh[0] << 16) + __uint_as_float(ll[0] << 16);
+            c.y = __uint_as_float(hh[0] & 0xffff0000u) + __uint_as_float(ll[0] & 0xffff0000u);
+            c.z = __uint_as_float(hh[1] << 16) + __uint_as_float(ll[1] << 16);
+            c.w = __uint_as_float(hh[1] & 0xffff0000u) + __uint_as_float(ll[1] & 0xffff0000u);
+        }
         s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
         *reinterpret_cast<uint2*>(dOh + off + d) = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
     }
@@ -475,23 +581,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     }
 #undef BMT_DQ_FETCH
 #undef BMT_DQ_STORE
-    if (qok) {
-        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;   // dQ is laid out like O (fp32 [B,Sq,D])
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = dt * 32 + 8 * r4 + 4 * half;
-                *reinterpret_cast<float4*>(p.dQ + rowoff + d) =
-                    make_float4(dq[dt][4 * r4 + 0], dq[dt][4 * r4 + 1], dq[dt][4 * r4 + 2], dq[dt][4 * r4 + 3]);
-            }
+    grad_store_rows<DK>(p.gq, dq, b, h, q, qok, half);
+    if (p.gq.hiT || p.gq.bsum) {       // uniform; the loop ended on a barrier, so the stage images are free
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+        grad_tile_write<DK, 128>(tile, dq, wid * 32, qok, l31, half);
+        __syncthreads();
+        grad_tile_flush<DK, 128>(tile, p.gq, b, h, qt * 128, p.Sq, tid);
     }
 }
 
 // dK/dV: workgroup = 64 keys, 4 waves split by role (0,1: dV of keys [0,32)/[32,64); 2,3: dK), loop over 32-query tiles
 // with the next tile's four images prefetched into registers.   dkv_ld / dkv_bs: strides of the fp32 dK / dV outputs.
 template <int DK>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB p, int64_t dkv_ld, int64_t dkv_bs) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB p) {
     constexpr int BQ = 32, DT = DK / 32, KB = 64;
     constexpr int TB = BQ * DK * 2;
     constexpr int KVB = KB * DK * 2;
@@ -521,17 +623,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
 
     bool kmask = kok;
     if (kok && p.mask != nullptr && p.mask_qs == 0) kmask = p.mask[(int64_t)b * p.mask_bs + key] != 0;
-    float* dst = (role == 1 ? p.dK : p.dV) + (int64_t)b * dkv_bs + (int64_t)key * dkv_ld + h * DK;
-    if (__syncthreads_or(kmask ? 1 : 0) == 0) {   // every key of this workgroup is masked: gradients are exactly zero
-        if (kok) {
+    // every key of this workgroup masked: the gradients are exactly zero (the loop is skipped, the epilogue writes zeros)
+    const bool dead = __syncthreads_or(kmask ? 1 : 0) == 0;
+    f32x16 acc[DT];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    *reinterpret_cast<float4*>(dst + dt * 32 + 8 * r4 + 4 * half) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    if (!dead) {
     {
         u32x4 tmp[rows_n<DK, KB>()];
         tile_gload<DK, KB>(p.Kh + (int64_t)b * p.bsk + h * DK, p.ldk, kt * KB, p.Sk, tid, tmp);
@@ -540,12 +639,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
         tile_lstore<DK, KB>(sV, tid, tmp);
     }
     const int myrow = kgrp * 32 + l31;
-
-    f32x16 acc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
 
     u32x4 rq[rows_n<DK, BQ>()], rdo[rows_n<DK, BQ>()];
     u32x2 rqt[rowsT_n<DK, BQ>() * 4], rdot[rowsT_n<DK, BQ>() * 4];
@@ -614,15 +707,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
     }
 #undef BMT_FETCH
 #undef BMT_DKV_STORE
-    if (kok) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = dt * 32 + 8 * r4 + 4 * half;
-                *reinterpret_cast<float4*>(dst + d) =
-                    make_float4(acc[dt][4 * r4 + 0], acc[dt][4 * r4 + 1], acc[dt][4 * r4 + 2], acc[dt][4 * r4 + 3]);
-            }
+    }   // !dead
+    const GradOut& g = (role == 1) ? p.gk : p.gv;
+    grad_store_rows<DK>(g, acc, b, h, key, kok, half);
+    if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [2 roles][DK][64 + 8]
+        grad_tile_write<DK, KB>(tile + role * DK * (KB + 8), acc, kgrp * 32, kok, l31, half);
+        __syncthreads();
+        grad_tile_flush<DK, KB>(tile, p.gv, b, h, kt * KB, p.Sk, tid);
+        grad_tile_flush<DK, KB>(tile + DK * (KB + 8), p.gk, b, h, kt * KB, p.Sk, tid);
     }
 }
 
@@ -644,11 +737,12 @@ int launch_fwd(const AttnPB& p, hipStream_t st) {
 }
 
 template <int DK>
-int launch_bwd(const AttnPB& p, uint16_t* dOh, int64_t dkv_ld, int64_t dkv_bs, hipStream_t st) {
+int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     {
-        const int lds = 3 * 32 * DK * 2 + 128;
+        const int lds_loop = 3 * 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
+        const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -665,7 +759,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, int64_t dkv_ld, int64_t dkv_bs, h
             done = true;
         }
         const int nblk = ((p.Sk + 63) / 64) * p.B * p.H;
-        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DK>), dim3(nblk), dim3(256), lds, st, p, dkv_ld, dkv_bs);
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DK>), dim3(nblk), dim3(256), lds, st, p);
     }
     BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16");
     return BMT_OK;
@@ -674,13 +768,14 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, int64_t dkv_ld, int64_t dkv_bs, h
 }  // namespace
 
 extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) {
-    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->O && a->lse, "bmt_attn_fwd_bf16: null pointer");
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh) && a->lse, "bmt_attn_fwd_bf16: null pointer");
     BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_fwd_bf16: bad sizes");
     BMT_CHECK_ARG(a->dk == 32 || a->dk == 64 || a->dk == 128 || a->dk == 256, "bmt_attn_fwd_bf16: d_k=%d not in {32,64,128,256}", a->dk);
     BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || (a->precision == BMT_PREC_BF16X3 && a->Ql && a->Kl && a->Vl),
                   "bmt_attn_fwd_bf16: BF16X3 needs the lo planes");
     if (!(al16(a->Qh) && al16(a->Kh) && al16(a->Vh) && al16(a->O)) || ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv) & 7) ||
-        ((a->ldo | a->bso) & 3) || (a->Ql && !(al16(a->Ql) && al16(a->Kl) && al16(a->Vl)))) {
+        ((a->ldo | a->bso) & 3) || (a->Ql && !(al16(a->Ql) && al16(a->Kl) && al16(a->Vl))) ||
+        (a->Oh && (!al16(a->Oh) || !al16(a->Ol) || ((a->ldop | a->bsop) & 7)))) {
         bmt_set_error("bmt_attn_fwd_bf16: planes must be 16-byte aligned with strides multiples of 8 elements");
         return BMT_EALIGN;
     }
@@ -688,6 +783,7 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
     memset(&p, 0, sizeof(p));
     p.Qh = a->Qh; p.Ql = a->Ql; p.Kh = a->Kh; p.Kl = a->Kl; p.Vh = a->Vh; p.Vl = a->Vl;
     p.Ow = a->O; p.lsew = a->lse;
+    p.Owh = a->Oh; p.Owl = a->Ol; p.ldop = a->ldop; p.bsop = a->bsop;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
@@ -701,27 +797,34 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
 }
 
 extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) {
-    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->O && a->dO && a->lse && a->dQ && a->dK && a->dV && a->delta_ws && a->dOh_ws,
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh) && a->dO && a->lse && a->delta_ws && a->dOh_ws,
                   "bmt_attn_bwd_bf16: null pointer");
+    BMT_CHECK_ARG((a->dQ || a->dQh) && (a->dK || a->dKh) && (a->dV || a->dVh), "bmt_attn_bwd_bf16: every gradient needs an fp32 or a plane output");
     BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_bwd_bf16: bad sizes");
     BMT_CHECK_ARG(a->dk == 32 || a->dk == 64 || a->dk == 128 || a->dk == 256, "bmt_attn_bwd_bf16: d_k=%d not in {32,64,128,256}", a->dk);
     if (!(al16(a->Qh) && al16(a->Kh) && al16(a->Vh) && al16(a->O) && al16(a->dO) && al16(a->dQ) && al16(a->dK) && al16(a->dV) &&
-          al16(a->dOh_ws)) || ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv | a->ldo | a->bso | a->dkv_ld | a->dkv_bs) & 7)) {
+          al16(a->dOh_ws) && al16(a->Oh) && al16(a->Ol) && al16(a->dQh) && al16(a->dKh) && al16(a->dVh)) ||
+        ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv | a->ldo | a->bso | a->dkv_ld | a->dkv_bs | a->ldop | a->bsop |
+          a->gq_ld | a->gq_bs | a->gkv_ld | a->gkv_bs) & 7)) {
         bmt_set_error("bmt_attn_bwd_bf16: pointers must be 16-byte aligned with strides multiples of 8 elements");
         return BMT_EALIGN;
     }
     AttnPB p;
     memset(&p, 0, sizeof(p));
     p.Qh = a->Qh; p.Kh = a->Kh; p.Vh = a->Vh; p.dOh = a->dOh_ws;
-    p.O = a->O; p.dO = a->dO; p.lse = a->lse; p.dQ = a->dQ; p.dK = a->dK; p.dV = a->dV; p.delta = a->delta_ws;
+    p.O = a->O; p.Oph = a->Oh; p.Opl = a->Ol; p.ldop = a->ldop; p.bsop = a->bsop;
+    p.dO = a->dO; p.lse = a->lse; p.delta = a->delta_ws;
+    p.gq = GradOut{a->dQ, a->ldo, a->bso, a->dQh, a->gq_ld, a->gq_bs, a->dQT, a->gqT_ld, a->dbq};
+    p.gk = GradOut{a->dK, a->dkv_ld, a->dkv_bs, a->dKh, a->gkv_ld, a->gkv_bs, a->dKT, a->gkvT_ld, a->dbk};
+    p.gv = GradOut{a->dV, a->dkv_ld, a->dkv_bs, a->dVh, a->gkv_ld, a->gkv_bs, a->dVT, a->gkvT_ld, a->dbv};
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.scale = a->scale; p.drop_p = a->drop_p;
     hipStream_t st = (hipStream_t)stream;
-    if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
-    if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
-    if (a->dk == 128) return launch_bwd<128>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
-    if (a->dk == 256) return launch_bwd<256>(p, a->dOh_ws, a->dkv_ld, a->dkv_bs, st);
+    if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, st);
+    if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, st);
+    if (a->dk == 128) return launch_bwd<128>(p, a->dOh_ws, st);
+    if (a->dk == 256) return launch_bwd<256>(p, a->dOh_ws, st);
     return BMT_EINVAL;
 }

@@ -28,6 +28,7 @@ struct GemmB {
     uint16_t *Chi, *Clo;
     int64_t ldp;
     int plane_cols;                      // planes are written for col < plane_cols (zeros for col >= N)
+    int plane_vec;                       // plane outputs 16-B aligned with ldp, plane_cols multiples of 8: staged through LDS
     int M, N, Kpad;
     int tiles_m, tiles_n, kchunk;
     float alpha;
@@ -171,8 +172,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #undef stage_ptr
     // ---------------- epilogue (same order as bmt_gemm: alpha, bias, dropout_pre, relu, dropout_post, gate, residual)
+    // fp32 C: each store instruction covers 128 contiguous bytes of two rows.  bf16 plane outputs would be 2-byte stores in
+    // that mapping, so they are staged through the (now idle) 64 KB of stage buffers as packed (hi | lo << 16) words and
+    // written out as full 16-byte row segments.
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
     const unsigned f = p.flags;
+    uint32_t* ct = reinterpret_cast<uint32_t*>(smem);   // [128][128] packed planes of this tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -183,7 +188,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float bv = (cin && (f & BMT_EPI_BIAS)) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + acc_row(r, half);
+                const int rl = wr * 64 + i * 32 + acc_row(r, half);
+                const int row = m0 + rl;
                 if (row >= p.M) continue;
                 float v = 0.f;
                 if (cin) {
@@ -199,12 +205,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 if (p.Chi) {
                     const __bf16 hv = (__bf16)v;
-                    const int64_t pi = (int64_t)row * p.ldp + col;
-                    p.Chi[pi] = __builtin_bit_cast(uint16_t, hv);
-                    if (p.Clo) p.Clo[pi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)hv));
+                    const uint32_t hb = __builtin_bit_cast(uint16_t, hv), lb = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)hv));
+                    if (p.plane_vec) {
+                        ct[rl * 128 + wc * 64 + j * 32 + l31] = hb | (lb << 16);
+                    } else {
+                        const int64_t pi = (int64_t)row * p.ldp + col;
+                        p.Chi[pi] = (uint16_t)hb;
+                        if (p.Clo) p.Clo[pi] = (uint16_t)lb;
+                    }
                 }
             }
         }
+    if (p.Chi && p.plane_vec) {      // uniform per launch
+        __syncthreads();
+        const int cg = (tid & 15) * 8;
+        const int col = n0 + cg;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rl = ps * 16 + (tid >> 4);
+            const int row = m0 + rl;
+            if (row < p.M && col < p.plane_cols) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(ct + rl * 128 + cg);
+                const u32x4 b = *reinterpret_cast<const u32x4*>(ct + rl * 128 + cg + 4);
+                u32x4 h;
+                h[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); h[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
+                h[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); h[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+                *reinterpret_cast<u32x4*>(p.Chi + (int64_t)row * p.ldp + col) = h;
+                if (p.Clo) {
+                    u32x4 l;
+                    l[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
+                    l[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u); l[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
+                    *reinterpret_cast<u32x4*>(p.Clo + (int64_t)row * p.ldp + col) = l;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- plane construction
@@ -311,6 +346,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.Ah = a->A_hi; p.Al = a->A_lo; p.Bh = a->B_hi; p.Bl = a->B_lo; p.lda = a->lda; p.ldb = a->ldb;
     p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_lo; p.ldp = a->ldp;
     p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
+    p.plane_vec = a->C_hi && al16(a->C_hi) && (!a->C_lo || al16(a->C_lo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad;
     p.tiles_m = bmt_cdiv(a->M, BM);
     p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);

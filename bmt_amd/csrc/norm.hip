@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-constexpr int LN_BWD_ROWS_PER_WAVE = 8;
+// rows each wave sweeps: sized so that a launch has ~512 workgroups (2 per CU); runtime parameter
+__host__ __device__ inline int ln_bwd_rows_per_wave(int rows) { const int r = (rows + 2047) / 2048; return r < 1 ? 1 : r; }
 
 // NV = ceil(D / 256): float4 column groups per lane
 template <int NV>
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                       int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, float* __restrict__ dx, int64_t lddx,
                                                       int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      int rows, int D) {
+                                                      float* __restrict__ partial, int rows_per_wave, int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][3 waves][NV*256]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float4 ag[NV], ab[NV], gm[NV];
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const int c = lane * 4 + 256 * i;
         gm[i] = (c < D) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int row0 = (blockIdx.x * 4 + wid) * LN_BWD_ROWS_PER_WAVE;
-    for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
+    const int row0 = (blockIdx.x * 4 + wid) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
         const int row = row0 + rr;
         if (row >= rows) break;
         const float mu = mean[row], rs = rstd[row];
@@ -139,12 +140,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w;
                     tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
                 }
+                if (partial) {   // two-stage: plain stores of this workgroup's column partials, summed by ln_bwd_reduce_kernel
+                    float* pr = partial + (int64_t)blockIdx.x * 2 * D;
+                    *reinterpret_cast<float4*>(pr + c) = tg;
+                    *reinterpret_cast<float4*>(pr + D + c) = tb;
+                    continue;
+                }
                 atomicAdd(dgamma + c + 0, tg.x); atomicAdd(dgamma + c + 1, tg.y);
                 atomicAdd(dgamma + c + 2, tg.z); atomicAdd(dgamma + c + 3, tg.w);
                 atomicAdd(dbeta + c + 0, tb.x); atomicAdd(dbeta + c + 1, tb.y);
                 atomicAdd(dbeta + c + 2, tb.z); atomicAdd(dbeta + c + 3, tb.w);
             }
         }
+    }
+}
+
+// second stage: dgamma[c] += sum_blk partial[blk][c], dbeta[c] += sum_blk partial[blk][D + c].  64 columns x 4 block-groups
+// per workgroup; one writer per column, no atomics.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int D) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;   // column in the concatenated [2*D] row
+    float s0 = 0.f, s1 = 0.f;
+    if (c < 2 * D) {
+        int b = grp;
+        for (; b + 4 < nblk; b += 8) { s0 += partial[(int64_t)b * 2 * D + c]; s1 += partial[(int64_t)(b + 4) * 2 * D + c]; }
+        if (b < nblk) s0 += partial[(int64_t)b * 2 * D + c];
+    }
+    red[grp][cl] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && c < 2 * D) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (c < D) dgamma[c] += t; else dbeta[c - D] += t;
     }
 }
 
@@ -192,12 +220,11 @@ extern "C" int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
     return BMT_OK;
 }
 
-extern "C" int bmt_layernorm_bwd_blocks(int rows) { return bmt_cdiv(rows, 4 * LN_BWD_ROWS_PER_WAVE); }
+extern "C" int bmt_layernorm_bwd_blocks(int rows) { return rows <= 0 ? 0 : bmt_cdiv(rows, 4 * ln_bwd_rows_per_wave(rows)); }
 
 extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                                  float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
-    (void)partial_ws;
     BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
     if (rows == 0) return BMT_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -213,12 +240,16 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     const int nv = bmt_cdiv(D, 256);
 #define BMT_LN(NV)                                                                                                         \
     hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 2 * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
-                       dx, lddx, accumulate_dx, dgamma, dbeta, rows, D)
+                       dx, lddx, accumulate_dx, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D)
     if (nv <= 1) BMT_LN(1);
     else if (nv <= 2) BMT_LN(2);
     else if (nv <= 4) BMT_LN(4);
     else BMT_LN(8);
 #undef BMT_LN
     BMT_CHECK_LAUNCH("bmt_layernorm_bwd");
+    if (partial_ws) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(bmt_cdiv(2 * D, 64)), dim3(256), 0, st, partial_ws, (int)grid.x, dgamma, dbeta, D);
+        BMT_CHECK_LAUNCH("bmt_layernorm_bwd(reduce)");
+    }
     return BMT_OK;
 }

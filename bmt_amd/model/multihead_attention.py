@@ -66,7 +66,8 @@ class MultiheadedAttention(nn.Module):
     def forward(self, Q, K, V, mask):
         ''' Q, K, V: (B, Sq, Dq), (B, Sk, Dk), (B, Sv, Dv); mask: (B, 1, Sk) or (B, Sq, Sk) '''
         p = self.dout_p if self.training else 0.0
-        return ops.MHAFn.apply(Q, K, V, mask,
+        fn = ops.MHAFn if ops.USE_PLANE_GEMM else ops.MHAFnStaged
+        return fn.apply(Q, K, V, mask,
                                self.linear_Q2d.weight, self.linear_Q2d.bias,
                                self.linear_K2d.weight, self.linear_K2d.bias,
                                self.linear_V2d.weight, self.linear_V2d.bias,

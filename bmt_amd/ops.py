@@ -229,6 +229,16 @@ def as_planes(x, need_lo: bool) -> Planes:
     return make_planes(x, lo=need_lo)[0]
 
 
+def attached_planes(t: torch.Tensor, rows: int, cols: int, need_lo: bool) -> Optional[Planes]:
+    """planes a producer kernel already wrote for exactly this tensor object (set as ``t._bmt_planes``): the consumer
+    GEMM then skips its own conversion pass.  The attribute lives on the Python tensor object the producer returned, so it
+    can never describe other data; anything that makes a new tensor (autograd accumulation, .contiguous() copies) drops it."""
+    pl = getattr(t, "_bmt_planes", None)
+    if pl is None or pl.rows != rows or pl.cols != cols or (need_lo and pl.lo is None):
+        return None
+    return pl
+
+
 def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
               drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=1, precision=None,
               out_planes: Optional[Planes] = None):
@@ -361,10 +371,24 @@ def static_grad(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return p.grad
 
 
+def note_use(*params):
+    """forward-side bookkeeping for fused gradient accumulation: count how many times a parameter with a static gradient
+    buffer takes part in this step's graph, so that ``grad_done`` reports it to the reducer only after the LAST of its
+    backward contributions (a parameter shared by two modules must not have its bucket all-reduced after the first)."""
+    for p in params:   # (counts are reset by GradientReducer.zero_grad, so forwards outside a training step are harmless)
+        if p is not None and getattr(p, "_bmt_static_grad", False):
+            p._bmt_uses = getattr(p, "_bmt_uses", 0) + 1
+
+
 def grad_done(p: Optional[torch.Tensor]):
-    """tell the reducer that p's gradient is final (replaces autograd's post-accumulate hook for fused accumulation)"""
+    """one backward contribution to p has been accumulated into its static buffer; when it was the last one, tell the
+    reducer that p's gradient is final (replaces autograd's post-accumulate hook for fused accumulation)"""
     cb = getattr(p, "_bmt_on_grad", None) if p is not None else None
-    if cb is not None:
+    if cb is None:
+        return
+    left = getattr(p, "_bmt_uses", 1) - 1
+    p._bmt_uses = left
+    if left <= 0:
         cb(p)
 
 
@@ -524,6 +548,85 @@ def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, drop_p=0.0):
     return dq, dk_, dv
 
 
+def _plane_buf(rows: int, cols: int, device) -> torch.Tensor:
+    """bf16 [rows][pad64(cols)] with the pad columns zero (they are reduction padding of the consuming GEMM)"""
+    ld = _pad64(cols)
+    return (torch.empty if ld == cols else torch.zeros)(rows, ld, device=device, dtype=torch.bfloat16)
+
+
+def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop_p=0.0, site=0, precision=None):
+    """attention core over projection planes; the post-dropout output is written as operand planes (hi[, lo]) of the
+    out-projection -- no fp32 copy.  Returns (Planes [B*Sq][pad64(D)], lse)."""
+    dk = D // H
+    prec = precision or FWD_PRECISION
+    x3 = prec == PREC_BF16X3
+    dev = q.hi.device
+    oh = _plane_buf(B * Sq, D, dev)
+    ol = _plane_buf(B * Sq, D, dev) if x3 else None
+    lse = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
+    keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    use_drop = drop_p > 0.0
+    ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), oh.stride(0)
+    a = AttnFwdBf16Args(Qh=_p(q.hi), Ql=_p(q.lo) if x3 else None, Kh=_p(k.hi), Kl=_p(k.lo) if x3 else None,
+                        Vh=_p(v.hi), Vl=_p(v.lo) if x3 else None, O=None, lse=_p(lse),
+                        ldq=ldq, ldk=ldk, ldv=ldv, ldo=D, bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D,
+                        mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk),
+                        drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=prec,
+                        Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop)
+    _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
+    return Planes(oh, ol, B * Sq, D), lse
+
+
+def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor, lse, B, Sq, Sk, D, mask, H, drop_p, biases):
+    """attention backward with the gradients written as GEMM operands: for each of dq, dk, dv the bf16 plane (dX operand of
+    the projection), its transpose (dW operand) and the bias gradient (column sums).  biases = (bq, bk, bv): a bias with a
+    static gradient buffer is accumulated in place (returned db is None), otherwise into a fresh fp32 [D].
+    Returns [(P, T, db)] * 3."""
+    dk = D // H
+    dev = q.hi.device
+    Mq, Mk = B * Sq, B * Sk
+    outs = []
+    for M, b in ((Mq, biases[0]), (Mk, biases[1]), (Mk, biases[2])):
+        hi = _plane_buf(M, D, dev)
+        hiT = _plane_buf(D, M, dev)
+        gb = static_grad(b)
+        db = None
+        if b is not None and gb is None:
+            db = torch.zeros(D, device=dev, dtype=torch.float32)
+        outs.append((hi, hiT, gb if gb is not None else db, db))
+    delta = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
+    doh = torch.empty(B, Sq, D, device=dev, dtype=torch.bfloat16)
+    keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), o.hi.stride(0)
+    (qh_, qT_, qb_, _), (kh_, kT_, kb_, _), (vh_, vT_, vb_, _) = outs
+    a = AttnBwdBf16Args(Qh=_p(q.hi), Kh=_p(k.hi), Vh=_p(v.hi), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
+                        delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
+                        bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
+                        mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk), drop_p=drop_p,
+                        Oh=_p(o.hi), Ol=_p(o.lo), ldop=ldop, bsop=Sq * ldop,
+                        dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
+                        gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
+                        dQT=_p(qT_), dKT=_p(kT_), dVT=_p(vT_), gqT_ld=qT_.stride(0), gkvT_ld=kT_.stride(0),
+                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_))
+    _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
+    res = []
+    for (hi, hiT, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
+        if b is not None and db is None:
+            grad_done(b)
+        res.append((Planes(hi, None, M, D), Planes(hiT, None, D, M), db))
+    return res
+
+
+def lin_bwd_planes(P: Planes, T: Planes, W, xT: Planes, need_dx: bool = True, **dx_epi):
+    """dX = dY.W and dW += dY^T.X from ready-made operand planes of dY (the bias gradient was produced with them)."""
+    dx = linear_dx(P, W, **dx_epi) if need_dx else None
+    gW = static_grad(W)
+    dW = linear_dw(T, xT, into=gW)
+    if gW is not None:
+        grad_done(W)
+    return dx, dW
+
+
 def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
     y = torch.empty_like(x)
     _lib.check(lib.bmt_dropout(_p(x), _p(y), x.numel(), p, _p(rng_tensor()), site, _st()), "bmt_dropout")
@@ -536,6 +639,7 @@ class LayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
+        note_use(gamma, beta)
         xc = _f32c(x)
         D = xc.shape[-1]
         x2 = xc.view(-1, D)
@@ -546,6 +650,7 @@ class LayerNormFn(torch.autograd.Function):
         _lib.check(lib.bmt_layernorm_fwd(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), rows, D, eps, _st()),
                    "bmt_layernorm_fwd")
         ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.beta = beta
         return y.view(xc.shape)
 
     @staticmethod
@@ -554,10 +659,18 @@ class LayerNormFn(torch.autograd.Function):
         rows, D = x2.shape
         dy2 = _f32c(dy).view(rows, D)
         dx = torch.empty_like(x2)
-        dg = torch.zeros(D, device=x2.device, dtype=torch.float32)
-        db = torch.zeros(D, device=x2.device, dtype=torch.float32)
+        beta = ctx.beta
+        sg, sb = static_grad(gamma), static_grad(beta)
+        fused = sg is not None and sb is not None          # accumulate straight into the static gradient buffers
+        dg = sg if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
+        db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
+        ws = torch.empty(max(1, lib.bmt_layernorm_bwd_blocks(rows)) * 2 * D, device=x2.device, dtype=torch.float32)
         _lib.check(lib.bmt_layernorm_bwd(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, 0, _p(dg), _p(db),
-                                         None, rows, D, _st()), "bmt_layernorm_bwd")
+                                         _p(ws), rows, D, _st()), "bmt_layernorm_bwd")
+        if fused:
+            grad_done(gamma)
+            grad_done(beta)
+            return dx.view(dy.shape), None, None, None
         return dx.view(dy.shape), dg, db, None
 
 
@@ -599,6 +712,7 @@ class LinearActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, relu, drop_mode, p, site):
+        note_use(W, b)
         xc = _f32c(x)
         K = xc.shape[-1]
         x2 = xc.view(-1, K)
@@ -637,6 +751,7 @@ class FFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, p, site):
+        note_use(W1, b1, W2, b2)
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
         x3 = FWD_PRECISION == PREC_BF16X3
@@ -679,10 +794,91 @@ def _planes_to_f32(pl: Planes) -> torch.Tensor:
 
 class MHAFn(torch.autograd.Function):
     """MultiheadedAttention.forward model/multihead_attention.py:55-86: three input projections, the masked
-    softmax-attention core with dropout on its OUTPUT (:22-23), head merge and output projection."""
+    softmax-attention core with dropout on its OUTPUT (:22-23), head merge and output projection.
+
+    Every tensor between the GEMMs and the attention kernels exists only as bf16 operand planes: the projections write
+    q/k/v planes from their epilogue, the attention forward writes the planes of its output, the attention backward writes
+    dq/dk/dv as (plane, transposed plane, bias sums).  The only fp32 intermediates are the module's input/output and dO."""
 
     @staticmethod
     def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site):
+        note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
+        B, Sq, Dq = Qc.shape
+        Sk = Kc.shape[1]
+        D = Wq.shape[0]
+        same_qk, same_kv = Q is K, K is V
+        x3 = FWD_PRECISION == PREC_BF16X3
+        train = any(ctx.needs_input_grad)
+        # each distinct input: operand planes (hi[, lo]) and, for the weight gradients, the transposed hi plane -- one pass
+        def split(x3d):
+            x2 = x3d.view(-1, x3d.shape[-1])
+            return make_planes(x2, lo=x3, straight=True, transposed=train)
+        Qp, QT = split(Qc)
+        Kp, KT = (Qp, QT) if same_qk else split(Kc)
+        Vp, VT = (Kp, KT) if same_kv else split(Vc)
+        q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
+        k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
+        v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
+        o, lse = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, drop_p=p, site=site)
+        out = linear_fwd(o, Wo, bo).view(B, Sq, Dq)
+        ctx.H, ctx.p, ctx.site = H, p, site
+        ctx.same_qk, ctx.same_kv = same_qk, same_kv
+        ctx.mask = mask
+        ctx.dims = (B, Sq, Sk, D, Dq, Kc.shape[-1], Vc.shape[-1])
+        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        none = torch.empty(0, device=Qc.device)
+        ctx.save_for_backward(Wq, Wk, Wv, Wo, q.hi, k.hi, v.hi, o.hi, o.lo if o.lo is not None else none, lse,
+                              QT.hi if train else none, KT.hi if train else none, VT.hi if train else none)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Wq, Wk, Wv, Wo, qh, kh, vh, oh, ol, lse, QTh, KTh, VTh = ctx.saved_tensors
+        B, Sq, Sk, D, Dq, Dk_in, Dv_in = ctx.dims
+        Mq, Mk = B * Sq, B * Sk
+        Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
+        q, k, v = Planes(qh, None, Mq, D), Planes(kh, None, Mk, D), Planes(vh, None, Mk, D)
+        o = Planes(oh, ol if ol.numel() else None, Mq, D)
+        QT, KT, VT = Planes(QTh, None, Dq, Mq), Planes(KTh, None, Dk_in, Mk), Planes(VTh, None, Dv_in, Mk)
+        dy2 = _f32c(dout).view(-1, Dq)
+        # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
+        do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(transpose_plane(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
+        (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p,
+                                                                      (bqp, bkp, bvp))
+        needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dQ = dK = dV = None
+        dxq, dWq = lin_bwd_planes(Pq, Tq, Wqp, QT, need_dx=needQ)
+        if ctx.same_qk and ctx.same_kv:     # one input, three contributions summed in the dX GEMM epilogue
+            ldr = dxq.stride(0) if needQ else 0
+            _, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+            _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+            if needQ:
+                dQ = dxq.view(B, Sq, Dq)
+        else:
+            if needQ:
+                dQ = dxq.view(B, Sq, Dq)
+            if ctx.same_kv:
+                need = needK or needV
+                dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=need)
+                _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
+                if need:
+                    dK = dxk.view(B, Sk, Dk_in)  # autograd adds dK and dV for the shared tensor; dV stays None
+            else:
+                dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needK)
+                dxv, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needV)
+                dK = dxk.view(B, Sk, Dk_in) if needK else None
+                dV = dxv.view(B, Sk, Dv_in) if needV else None
+        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
+
+
+class MHAFnStaged(torch.autograd.Function):
+    """MHAFn for the fp32-staged GEMM path (USE_PLANE_GEMM = False; A/B measurements and kernel tests only): attention
+    output and gradients travel as fp32 tensors."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site):
+        note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
         B, Sq, Dq = Qc.shape
         Sk = Kc.shape[1]
@@ -764,6 +960,7 @@ class GeneratorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b):
+        note_use(W, b)
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
         V = W.shape[0]

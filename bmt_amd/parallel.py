@@ -72,6 +72,7 @@ class GradientReducer:
             for p, v in zip(b["params"], b["views"]):
                 if p.grad is not v:
                     p.grad = v
+                p._bmt_uses = 0
         self._handles = []
 
     def _on_grad(self, p):

@@ -164,6 +164,14 @@ int bmt_attn_bwd(const bmt_attn_bwd_args* args, void* stream);
  * staged bytes, per-tile mask classification (fully masked key tiles are skipped, fully valid ones run unmasked).
  * Plane strides are in bf16 elements and must be multiples of 8; O / dO / dQ are fp32 [B,Sq,H*dk] (ldo, bso),
  * dK / dV fp32 with (dkv_ld, dkv_bs).  Backward reads hi planes only (single-pass bf16); dOh_ws: bf16 workspace the size of O.
+ *
+ * Outputs that feed GEMMs can be produced directly as operand planes, so that no conversion pass runs over them:
+ *   forward : Oh / Ol (hi, lo planes of the post-dropout output; row b*Sq+q at b*bsop + q*ldop).  O (fp32) may then be NULL;
+ *             ldo / bso must still describe the logical fp32 layout (they index the dropout mask).
+ *   backward: the saved output comes back as Oh / Ol when O is NULL.  Each gradient has up to four forms, all optional
+ *             but at least one of {fp32, hi plane}: fp32 (dQ|dK|dV), bf16 plane (dQh|dKh|dVh: row b*S+s at b*g?_bs + s*g?_ld),
+ *             transposed bf16 plane (dQT|dKT|dVT: [H*dk][g?T_ld], column b*S+s; the caller zero-fills columns past B*S) and
+ *             bias sums (dbq|dbk|dbv: fp32 [H*dk] += sum over (b,s), atomics; summed from the bf16-rounded values).
  */
 typedef struct {
     const uint16_t *Qh, *Ql, *Kh, *Kl, *Vh, *Vl;      /* lo planes may be NULL for BMT_PREC_BF16 */
@@ -174,6 +182,7 @@ typedef struct {
     float scale;
     float drop_p; const uint64_t* rng; uint32_t site;
     int precision;
+    uint16_t *Oh, *Ol; int64_t ldop, bsop;            /* optional plane outputs */
 } bmt_attn_fwd_bf16_args;
 int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* args, void* stream);
 
@@ -186,6 +195,10 @@ typedef struct {
     const uint8_t* mask; int64_t mask_bs, mask_qs;
     int B, H, Sq, Sk, dk;
     float scale, drop_p;
+    const uint16_t *Oh, *Ol; int64_t ldop, bsop;      /* saved forward output as planes (when O == NULL) */
+    uint16_t *dQh, *dKh, *dVh; int64_t gq_ld, gq_bs, gkv_ld, gkv_bs;
+    uint16_t *dQT, *dKT, *dVT; int64_t gqT_ld, gkvT_ld;
+    float *dbq, *dbk, *dbv;
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 
@@ -193,8 +206,10 @@ int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */
 int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                       float* mean, float* rstd, int rows, int D, float eps, void* stream);
-/* dx (+)= LN backward; dgamma/dbeta += column reductions (atomic accumulate into pre-zeroed or live grads).
- * dx[i] = (accumulate_dx ? dx[i] : 0) + ...   partial_ws: reserved (may be NULL) */
+/* dx (+)= LN backward; dgamma/dbeta += column reductions (accumulate into pre-zeroed or live grads).
+ * dx[i] = (accumulate_dx ? dx[i] : 0) + ...
+ * partial_ws: NULL -> one atomic per column per workgroup; else fp32 [bmt_layernorm_bwd_blocks(rows)][2][D] scratch for a
+ * two-stage (store partials, then one-writer-per-column sum) reduction -- no atomics, deterministic. */
 int bmt_layernorm_bwd_blocks(int rows);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,

@@ -223,6 +223,46 @@ def test_attention_backward_bf16_planes(ops, dk, H, B, Sq, Sk, kind):
         assert e < 2e-2, f"{name} dk={dk} {kind}: relative error {e:.3e}\n" + report(got, ref, name)
 
 
+@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 336, "pad"), (128, 4, 1, 70, 257, "pad"), (256, 4, 2, 128, 64, "pad")])
+def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind):
+    """forward O planes and backward (plane, transposed plane, bias sums) forms against the fp32 outputs of the same kernels:
+    hi == bf16(fp32) bit for bit, hi + lo == fp32 to 2^-16, transposed == transpose, bias sums == sums of the bf16 values"""
+    D = dk * H
+    q, k, v = rnd(B, Sq, D, seed=40), rnd(B, Sk, D, seed=41), rnd(B, Sk, D, seed=42)
+    do = rnd(B, Sq, D, seed=43).to(DEV)
+    mask = _masks(kind, B, Sq, Sk)
+    if kind == "pad" and Sk > 100:
+        mask[0, 0, Sk // 3:] = False
+    md = None if mask is None else mask.to(DEV)
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    P = lambda h, l, S: ops.Planes(h.view(B * S, D), None if l is None else l.view(B * S, D), B * S, D)
+    o32, lse32 = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, md, H, precision=3)
+    o, lse = ops.attn_fwd_planes(P(qh, ql, Sq), P(kh, kl, Sk), P(vh, vl, Sk), B, Sq, Sk, D, md, H)
+    assert torch.equal(lse, lse32)
+    o2 = o32.view(B * Sq, D)
+    finite = torch.isfinite(o2)
+    assert torch.equal(o.hi[:, :D][finite], o2.to(torch.bfloat16)[finite]), "O hi plane != bf16(O)"
+    rec = o.hi[:, :D].float() + o.lo[:, :D].float()
+    assert_close(rec[finite], o2[finite], atol=1e-6, rtol=2e-5, name="O hi+lo")
+    assert (o.hi[:, D:] == 0).all()
+
+    dq, dk_, dv = ops.attn_bwd_bf16(qh, kh, vh, o32, do, lse32, md, H)
+    bq = torch.nn.Parameter(torch.zeros(D, device=DEV))
+    res = ops.attn_bwd_planes(P(qh, None, Sq), P(kh, None, Sk), P(vh, None, Sk), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (bq, None, bq))
+    for name, (Pl, T, db), ref, S in (("dq", res[0], dq, Sq), ("dk", res[1], dk_, Sk), ("dv", res[2], dv, Sk)):
+        ref2 = ref.view(B * S, D)
+        # the plane path rebuilds O as hi+lo (2^-16 relative) inside delta: compare to bf16 resolution
+        got = Pl.hi[:, :D].float()
+        assert_close(got, ref2, atol=2e-3 * float(ref2.abs().max()), rtol=1e-2, name=f"{name} plane")
+        assert torch.equal(T.hi[:, :B * S], Pl.hi[:, :D].t()), f"{name}: transposed plane is not the transpose of the plane"
+        assert (T.hi[:, B * S:] == 0).all()
+        if name != "dk":
+            assert db is not None
+            assert_close(db, got.double().sum(0), atol=1e-4 * float(got.abs().sum(0).max()) + 1e-6, rtol=1e-4, name=f"{name} bias sums")
+        else:
+            assert db is None
+
+
 @pytest.mark.parametrize("pad", [False, True])
 def test_gemm_plane_outputs(ops, gemm_path, pad):
     M, N, K = 150, 96, 64

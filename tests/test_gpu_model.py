@@ -284,6 +284,7 @@ def test_graph_replay_matches_eager(golden):
     caps = g["captions"].to(DEV)
     results = []
     for use_graph in (False, True):
+        ops._site_counter[0] = 10_000       # both arms must draw the same dropout masks: same call-site ids
         cfg = syn.cfg_tiny(dout_p=0.1, lr=1e-3)
         model = _build(cfg, V, False, g.sub("sd/"))
         step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True)
