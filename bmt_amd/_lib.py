@@ -36,7 +36,8 @@ class GemmBf16Args(C.Structure):
                 ("C", vp), ("ldc", i64), ("C_hi", vp), ("C_lo", vp), ("ldp", i64),
                 ("M", i32), ("N", i32), ("Kpad", i32), ("alpha", f32), ("flags", C.c_uint),
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
-                ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32)]
+                ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64)]
 
 
 class AttnFwdArgs(C.Structure):

@@ -42,6 +42,8 @@ struct GemmB {
     float drop_p;
     const uint64_t* rng;
     uint32_t site;
+    float* ws;                           // split-K partials [split][tiles_m*128][tiles_n*128] (two-pass mode), or nullptr
+    int nsplit;
 };
 
 // LDS slot of (row, 16-byte slot) for rows of SPR slots
@@ -103,74 +105,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[128 * SPR / 256], rb[128 * SPR / 256], ral[128 * SPR / 256], rbl[128 * SPR / 256];
+    // Two register sets: the global loads of stage t+2 are issued before the MFMAs of stage t, so every load has two
+    // iterations (two barriers) to land -- with 2 workgroups per CU and ~0.2 us of MFMA work per stage a single stage of
+    // prefetch leaves the loop waiting on HBM/L2 latency (profiles/r01_c: 16 iterations of a 24-tile GEMM took 50 us).
+    constexpr int NR = 128 * SPR / 256;
+    u32x4 ra0[NR], rb0[NR], ral0[NR], rbl0[NR];
+    u32x4 ra1[NR], rb1[NR], ral1[NR], rbl1[NR];
 #define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + (which_) * PB)
+#define BMT_GLOAD(s_, RA, RB, RAL, RBL)                                                   \
+    do {                                                                                  \
+        const int k_ = min(kbeg + (s_) * BK, kend - BK);   /* branch-free tail: re-fetch the last stage */ \
+        plane_gload<SPR>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                              \
+        plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                              \
+        if constexpr (NPASS == 3) {                                                       \
+            plane_gload<SPR>(p.Al, p.lda, m0, p.M, k_, tid, RAL);                         \
+            plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);                         \
+        }                                                                                 \
+    } while (0)
+#define BMT_LSTORE(buf_, RA, RB, RAL, RBL)                                                \
+    do {                                                                                  \
+        plane_lstore<SPR>(stage_ptr(buf_, 0), tid, RA);                                   \
+        plane_lstore<SPR>(stage_ptr(buf_, 1), tid, RB);                                   \
+        if constexpr (NPASS == 3) {                                                       \
+            plane_lstore<SPR>(stage_ptr(buf_, 2), tid, RAL);                              \
+            plane_lstore<SPR>(stage_ptr(buf_, 3), tid, RBL);                              \
+        }                                                                                 \
+    } while (0)
+#define BMT_COMPUTE(buf_)                                                                 \
+    do {                                                                                  \
+        const u32x4* sAh = stage_ptr(buf_, 0);                                            \
+        const u32x4* sBh = stage_ptr(buf_, 1);                                            \
+        const u32x4* sAl = stage_ptr(buf_, 2);                                            \
+        const u32x4* sBl = stage_ptr(buf_, 3);                                            \
+        _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                             \
+            const int sl = 2 * s + half;                                                  \
+            bf16x8 ah[2], bh[2], al[2], bl[2];                                            \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                               \
+                const int ia = slot_of<SPR>(wr * 64 + i * 32 + l31, sl), ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl); \
+                ah[i] = as_bf16x8(sAh[ia]);                                               \
+                bh[i] = as_bf16x8(sBh[ib]);                                               \
+                if constexpr (NPASS == 3) {                                               \
+                    al[i] = as_bf16x8(sAl[ia]);                                           \
+                    bl[i] = as_bf16x8(sBl[ib]);                                           \
+                }                                                                         \
+            }                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                 \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                           \
+                    if constexpr (NPASS == 3) {                                           \
+                        acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);                      \
+                        acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);                      \
+                    }                                                                     \
+                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);                          \
+                }                                                                         \
+        }                                                                                 \
+    } while (0)
 
-    // prologue: stage 0 (kbeg < kend always holds: the host never launches an empty split)
-    plane_gload<SPR>(p.Ah, p.lda, m0, p.M, kbeg, tid, ra);
-    plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, kbeg, tid, rb);
-    if constexpr (NPASS == 3) {
-        plane_gload<SPR>(p.Al, p.lda, m0, p.M, kbeg, tid, ral);
-        plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, kbeg, tid, rbl);
-    }
-    plane_lstore<SPR>(stage_ptr(0, 0), tid, ra);
-    plane_lstore<SPR>(stage_ptr(0, 1), tid, rb);
-    if constexpr (NPASS == 3) {
-        plane_lstore<SPR>(stage_ptr(0, 2), tid, ral);
-        plane_lstore<SPR>(stage_ptr(0, 3), tid, rbl);
-    }
+    const int niter = (kend - kbeg) / BK;     // >= 1: the host never launches an empty split
+    BMT_GLOAD(0, ra0, rb0, ral0, rbl0);
+    BMT_GLOAD(1, ra1, rb1, ral1, rbl1);
+    BMT_LSTORE(0, ra0, rb0, ral0, rbl0);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        // stage t+1: global -> registers now, registers -> the other LDS buffer after the MFMAs.  Branch-free: the last
-        // iteration re-fetches its own stage (clamped k) and the redundant LDS image is never read.
-        const int kn = min(k0 + BK, kend - BK);
-        plane_gload<SPR>(p.Ah, p.lda, m0, p.M, kn, tid, ra);
-        plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, kn, tid, rb);
-        if constexpr (NPASS == 3) {
-            plane_gload<SPR>(p.Al, p.lda, m0, p.M, kn, tid, ral);
-            plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, kn, tid, rbl);
-        }
-        const u32x4* sAh = stage_ptr(buf, 0);
-        const u32x4* sBh = stage_ptr(buf, 1);
-        const u32x4* sAl = stage_ptr(buf, 2);
-        const u32x4* sBl = stage_ptr(buf, 3);
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            const int sl = 2 * s + half;
-            bf16x8 ah[2], bh[2], al[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ia = slot_of<SPR>(wr * 64 + i * 32 + l31, sl), ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl);
-                ah[i] = as_bf16x8(sAh[ia]);
-                bh[i] = as_bf16x8(sBh[ib]);
-                if constexpr (NPASS == 3) {
-                    al[i] = as_bf16x8(sAl[ia]);
-                    bl[i] = as_bf16x8(sBl[ib]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (NPASS == 3) {
-                        acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);
-                        acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);
-                    }
-                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
-                }
-        }
-        plane_lstore<SPR>(stage_ptr(buf ^ 1, 0), tid, ra);
-        plane_lstore<SPR>(stage_ptr(buf ^ 1, 1), tid, rb);
-        if constexpr (NPASS == 3) {
-            plane_lstore<SPR>(stage_ptr(buf ^ 1, 2), tid, ral);
-            plane_lstore<SPR>(stage_ptr(buf ^ 1, 3), tid, rbl);
-        }
+    int t = 0;
+    // invariant at the top of a pair: LDS buffer 0 = stage t, set 1 = stage t+1 (in flight), set 0 free
+    for (; t + 2 <= niter; t += 2) {
+        BMT_GLOAD(t + 2, ra0, rb0, ral0, rbl0);
+        __builtin_amdgcn_sched_barrier(0);    // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them below)
+        BMT_COMPUTE(0);
+        BMT_LSTORE(1, ra1, rb1, ral1, rbl1);
         __syncthreads();
-        buf ^= 1;
+        BMT_GLOAD(t + 3, ra1, rb1, ral1, rbl1);
+        __builtin_amdgcn_sched_barrier(0);
+        BMT_COMPUTE(1);
+        BMT_LSTORE(0, ra0, rb0, ral0, rbl0);
+        __syncthreads();
     }
+    if (t < niter) BMT_COMPUTE(0);
+    __syncthreads();      // the epilogue reuses the stage buffers
 
-#undef stage_ptr
+    // ---------------- split-K, two passes: each split stores its raw partial tile (plain coalesced fp32 stores) into
+    // ws[split][Mpad][Npad]; splitk_epilogue_kernel sums the splits and runs the epilogue.  Used for GEMMs with too few tiles to
+    // fill the chip and a long reduction (the k-loop is a chain of dependent ~2 us memory round trips: 24 tiles x 16 stages is
+    // ~50 us of latency on 24 CUs, 24 x 8 splits of 2 stages is ~10 us on 192) and for the weight gradients (reduction over
+    // B*S rows), where it replaces tiles*splits*16K fp32 atomics by streaming traffic.
+    if (p.ws != nullptr) {
+        const int64_t ldw = (int64_t)p.tiles_n * BN;
+        float* part = p.ws + (int64_t)blockIdx.y * p.tiles_m * BM * ldw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    part[(int64_t)(m0 + wr * 64 + i * 32 + acc_row(r, half)) * ldw + n0 + wc * 64 + j * 32 + l31] = acc[i][j][r];
+        return;
+    }
     // ---------------- epilogue (same order as bmt_gemm: alpha, bias, dropout_pre, relu, dropout_post, gate, residual)
     // fp32 C: each store instruction covers 128 contiguous bytes of two rows.  bf16 plane outputs would be 2-byte stores in
     // that mapping, so they are staged through the (now idle) 64 KB of stage buffers as packed (hi | lo << 16) words and
@@ -237,6 +265,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     l[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u); l[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
                     *reinterpret_cast<u32x4*>(p.Clo + (int64_t)row * p.ldp + col) = l;
                 }
+            }
+        }
+    }
+}
+
+// second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
+// and run the same epilogue as the GEMM kernel.  One writer per element: ACCUM is a plain read-modify-write.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
+    const int pc = p.Chi ? max(p.plane_cols, p.N) : p.N;
+    const int ncg = (pc + 3) / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * ncg) return;
+    const int row = (int)(idx / ncg), c0 = (int)(idx % ncg) * 4;
+    const int64_t ldw = (int64_t)p.tiles_n * BN;
+    const int64_t slab = (int64_t)p.tiles_m * BM * ldw;
+    const float* src = p.ws + (int64_t)row * ldw + c0;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sidx = 0; sidx < p.nsplit; ++sidx) {
+        const float4 v = *reinterpret_cast<const float4*>(src + sidx * slab);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const float acc4[4] = {a.x, a.y, a.z, a.w};
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    const unsigned f = p.flags;
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = c0 + c;
+        float v = 0.f;
+        if (col < p.N) {
+            v = acc4[c] * p.alpha + ((f & BMT_EPI_BIAS) ? p.bias[col] : 0.f);
+            const int64_t ci = (int64_t)row * p.ldc + col;
+            if (f & BMT_EPI_DROP_PRE) v = drop_apply(dc, v, (uint64_t)ci);
+            if (f & BMT_EPI_RELU) v = fmaxf(v, 0.f);
+            if (f & BMT_EPI_DROP_POST) v = drop_apply(dc, v, (uint64_t)ci);
+            if (f & BMT_EPI_GATE) v = (p.gate[(int64_t)row * p.ldg + col] & 0x7fffu) ? v * p.gate_scale : 0.f;
+            if (f & BMT_EPI_RESIDUAL) v += p.residual[(int64_t)row * p.ldr + col];
+            if (f & BMT_EPI_ACCUM) p.C[ci] += v;
+            else if (p.C) p.C[ci] = v;
+        }
+        out[c] = v;
+    }
+    if (p.Chi) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = c0 + c;
+            if (col < p.plane_cols) {
+                const __bf16 hv = (__bf16)out[c];
+                const int64_t pi = (int64_t)row * p.ldp + col;
+                p.Chi[pi] = __builtin_bit_cast(uint16_t, hv);
+                if (p.Clo) p.Clo[pi] = __builtin_bit_cast(uint16_t, (__bf16)(out[c] - (float)hv));
             }
         }
     }
@@ -334,9 +413,11 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         return BMT_EALIGN;
     }
     int splitk = a->splitk < 1 ? 1 : a->splitk;
+    const bool accum = (a->flags & BMT_EPI_ACCUM) != 0;
+    const bool two_pass = a->splitk_ws != nullptr;                            // split-K through a workspace: any epilogue
     const unsigned nonlin = BMT_EPI_RELU | BMT_EPI_DROP_PRE | BMT_EPI_DROP_POST | BMT_EPI_GATE | BMT_EPI_BIAS | BMT_EPI_RESIDUAL;
-    BMT_CHECK_ARG(splitk == 1 || ((a->flags & BMT_EPI_ACCUM) && !(a->flags & nonlin) && !a->C_hi),
-                  "bmt_gemm_bf16: splitk>1 needs BMT_EPI_ACCUM and no other epilogue op / plane output");
+    BMT_CHECK_ARG(splitk == 1 || two_pass || (accum && !(a->flags & nonlin) && !a->C_hi),
+                  "bmt_gemm_bf16: splitk>1 needs either a split-K workspace or BMT_EPI_ACCUM with no other epilogue op / plane output");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_ACCUM) || a->C, "bmt_gemm_bf16: ACCUM needs the fp32 output");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_BIAS) || a->bias, "bmt_gemm_bf16: BIAS flag without pointer");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_RESIDUAL) || a->residual, "bmt_gemm_bf16: RESIDUAL flag without pointer");
@@ -352,13 +433,34 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
     const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
+    const int tiles = p.tiles_m * p.tiles_n;
+    if (a->splitk == 0 && two_pass && tiles < 256 && ktiles >= 4) {
+        // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
+        int want = 512 / tiles, cap = ktiles / 2;
+        if (want > 32) want = 32;
+        splitk = want < cap ? want : cap;
+        if (splitk < 1) splitk = 1;
+    }
     if (splitk > ktiles) splitk = ktiles;
+    if (splitk > 1 && two_pass) {              // bounded by the workspace
+        const int64_t slab = (int64_t)tiles * BM * BN * (int64_t)sizeof(float);
+        const int64_t fit = a->splitk_ws_bytes / slab;
+        if (fit < splitk) splitk = (int)(fit < 1 ? 1 : fit);
+    }
     p.kchunk = bmt_cdiv(ktiles, splitk) * bk;
     splitk = bmt_cdiv(a->Kpad, p.kchunk);
+    BMT_CHECK_ARG(splitk == 1 || two_pass || accum, "bmt_gemm_bf16: split-K workspace too small");
+    if (splitk > 1 && two_pass) { p.ws = a->splitk_ws; p.nsplit = splitk; }
     p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
     p.gate = a->gate; p.ldg = a->ldg; p.gate_scale = a->gate_scale;
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
-    return a->precision == BMT_PREC_BF16X3 ? launch<3>(p, splitk, (hipStream_t)stream) : launch<1>(p, splitk, (hipStream_t)stream);
+    const int rc = a->precision == BMT_PREC_BF16X3 ? launch<3>(p, splitk, (hipStream_t)stream) : launch<1>(p, splitk, (hipStream_t)stream);
+    if (rc != BMT_OK || p.ws == nullptr) return rc;
+    const int pc = p.Chi ? (p.plane_cols > p.N ? p.plane_cols : p.N) : p.N;
+    const int64_t groups = (int64_t)p.M * ((pc + 3) / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)bmt_cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16(split-K epilogue)");
+    return BMT_OK;
 }
 
 static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,

@@ -155,24 +155,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// second stage: dgamma[c] += sum_blk partial[blk][c], dbeta[c] += sum_blk partial[blk][D + c].  64 columns x 4 block-groups
-// per workgroup; one writer per column, no atomics.
+// second stage: dgamma[c] += sum_blk partial[blk][c], dbeta[c] += sum_blk partial[blk][D + c].  64 columns x 4 row groups per
+// workgroup, blockIdx.y = slice of 64 partial rows (16 loads per thread); one atomic per column per slice.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int D) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;   // column in the concatenated [2*D] row
+    const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
     float s0 = 0.f, s1 = 0.f;
     if (c < 2 * D) {
-        int b = grp;
-        for (; b + 4 < nblk; b += 8) { s0 += partial[(int64_t)b * 2 * D + c]; s1 += partial[(int64_t)(b + 4) * 2 * D + c]; }
-        if (b < nblk) s0 += partial[(int64_t)b * 2 * D + c];
+        int b = b0 + grp;
+        for (; b + 4 < b1; b += 8) { s0 += partial[(int64_t)b * 2 * D + c]; s1 += partial[(int64_t)(b + 4) * 2 * D + c]; }
+        if (b < b1) s0 += partial[(int64_t)b * 2 * D + c];
     }
     red[grp][cl] = s0 + s1;
     __syncthreads();
     if (grp == 0 && c < 2 * D) {
         const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        if (c < D) dgamma[c] += t; else dbeta[c - D] += t;
+        atomicAdd(c < D ? dgamma + c : dbeta + (c - D), t);
     }
 }
 
@@ -248,7 +249,7 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
 #undef BMT_LN
     BMT_CHECK_LAUNCH("bmt_layernorm_bwd");
     if (partial_ws) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(bmt_cdiv(2 * D, 64)), dim3(256), 0, st, partial_ws, (int)grid.x, dgamma, dbeta, D);
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(bmt_cdiv(2 * D, 64), bmt_cdiv((int)grid.x, 64)), dim3(256), 0, st, partial_ws, (int)grid.x, dgamma, dbeta, D);
         BMT_CHECK_LAUNCH("bmt_layernorm_bwd(reduce)");
     }
     return BMT_OK;

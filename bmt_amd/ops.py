@@ -239,8 +239,26 @@ def attached_planes(t: torch.Tensor, rows: int, cols: int, need_lo: bool) -> Opt
     return pl
 
 
+_SPLITK_WS = {}          # device index -> fp32 scratch; one compute stream per device
+SPLITK_WS_BYTES = 128 << 20
+
+
+def splitk_workspace(device):
+    """scratch for the GEMM's two-pass split-K (bmt_gemm_bf16_args.splitk_ws)"""
+    idx = torch.device(device).index or 0
+    ws = _SPLITK_WS.get(idx)
+    if ws is None:
+        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        _SPLITK_WS[idx] = ws
+    return ws
+
+
+AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
+TWO_PASS_SPLITK = True   # split-K through the workspace + epilogue kernel (False: atomic accumulation, weight gradients only)
+
+
 def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
-              drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=1, precision=None,
+              drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None, precision=None,
               out_planes: Optional[Planes] = None):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded)."""
     M, N = A.rows, B.rows
@@ -265,11 +283,16 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=
         flags |= EPI_ACCUM
     x3 = prec == PREC_BF16X3
     op = out_planes
+    if splitk is None:
+        splitk = 0 if (AUTO_SPLITK and TWO_PASS_SPLITK) else 1
     a = GemmBf16Args(_p(A.hi), _p(A.lo) if x3 else None, A.hi.stride(0), _p(B.hi), _p(B.lo) if x3 else None, B.hi.stride(0),
                      _p(C_out), ldc if C_out is not None else N, _p(op.hi) if op else None, _p(op.lo) if op else None,
                      op.hi.stride(0) if op else 0, M, N, Kpad, alpha, flags, _p(bias), _p(residual), ldr,
                      _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
                      drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec, splitk)
+    if splitk != 1 and TWO_PASS_SPLITK:
+        ws = splitk_workspace(A.hi.device)
+        a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
     _lib.check(lib.bmt_gemm_bf16(C.byref(a), _st()), "bmt_gemm_bf16")
 
 
@@ -356,8 +379,9 @@ def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Te
         return None if into is not None else dW
     N, K, M = dyT.rows, xT.rows, dyT.cols
     sk = _splitk_for(N, K, M)
-    acc = into is not None or sk > 1
-    dW = into if into is not None else (torch.zeros if sk > 1 else torch.empty)(N, K, device=dyT.hi.device, dtype=torch.float32)
+    atomic = sk > 1 and not TWO_PASS_SPLITK      # two-pass split-K has one writer per element: no zero-fill, no atomics
+    acc = into is not None or atomic
+    dW = into if into is not None else (torch.zeros if atomic else torch.empty)(N, K, device=dyT.hi.device, dtype=torch.float32)
     gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16)
     return None if into is not None else dW
 

@@ -100,7 +100,12 @@ typedef struct {
     const uint16_t* gate; int64_t ldg; float gate_scale;
     float drop_p; const uint64_t* rng; uint32_t site;
     int precision;
-    int splitk;
+    int splitk;                 /* >1: split the reduction; 0: let the library choose (needs the workspace below); 1: never */
+    /* two-pass split-K: every split stores its partial output into this fp32 scratch (splitk * ceil128(M) * ceil128(N) floats,
+     * the split count is reduced to what fits) and a second kernel sums them in split order and runs the epilogue -- any
+     * epilogue, deterministic, ACCUM without atomics.  Without a workspace splitk>1 needs BMT_EPI_ACCUM and a plain epilogue
+     * (atomic accumulation).  One workspace serves every launch of one stream. */
+    float* splitk_ws; int64_t splitk_ws_bytes;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL
@@ -209,7 +214,7 @@ int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
 /* dx (+)= LN backward; dgamma/dbeta += column reductions (accumulate into pre-zeroed or live grads).
  * dx[i] = (accumulate_dx ? dx[i] : 0) + ...
  * partial_ws: NULL -> one atomic per column per workgroup; else fp32 [bmt_layernorm_bwd_blocks(rows)][2][D] scratch for a
- * two-stage (store partials, then one-writer-per-column sum) reduction -- no atomics, deterministic. */
+ * two-stage reduction (store per-workgroup partials, then sum them 64 at a time: one atomic per column per 64 workgroups). */
 int bmt_layernorm_bwd_blocks(int rows);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,

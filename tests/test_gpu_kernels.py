@@ -66,6 +66,31 @@ def test_gemm_dx_dw_layouts(ops, gemm_path, M, N, K):
     assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name="dw")
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(300, 200, 1024, 4), (960, 300, 1024, 8), (130, 70, 2048, 16), (257, 129, 640, 3), (960, 300, 1024, 0)])
+@pytest.mark.parametrize("prec", [1, 3])
+def test_gemm_splitk_two_pass(ops, M, N, K, splitk, prec):
+    """two-pass split-K (partials in the workspace + epilogue kernel): same result as one pass for any epilogue, bit-identical
+    between launches (partials are summed in split order)"""
+    x, W, b, res = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9), rnd(M, N, seed=10)
+    A = ops.make_planes(x.to(DEV), lo=True)[0]
+    Bw = ops.make_planes(W.to(DEV), lo=True)[0]
+    bd, resd = b.to(DEV), res.to(DEV)
+    outs = []
+    for sk in (1, splitk, splitk):
+        out = torch.empty(M, N, device=DEV)
+        pl = ops.Planes(torch.empty(M, 64 * ((N + 63) // 64), device=DEV, dtype=torch.bfloat16),
+                        torch.empty(M, 64 * ((N + 63) // 64), device=DEV, dtype=torch.bfloat16), M, N)
+        ops.gemm_bf16(A, Bw, out, ldc=N, bias=bd, relu=True, residual=resd, ldr=N, splitk=sk, precision=prec, out_planes=pl)
+        outs.append((out, pl))
+    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
+    want = torch.relu(f(x) @ f(W).t() + b.double()) + res.double()
+    for out, pl in outs:
+        assert_close(out, want, atol=(2e-4 if prec == 1 else 3e-4) * math.sqrt(K), rtol=1e-4, name=f"splitk out x{prec}")
+        assert torch.equal(pl.hi[:, :N], out.to(torch.bfloat16)), "plane output of the split-K path != bf16(fp32 output)"
+    assert torch.equal(outs[1][0], outs[2][0]), "split-K result differs between two launches (reduction order not fixed?)"
+    assert_close(outs[1][0], outs[0][0], atol=1e-4 * math.sqrt(K), rtol=1e-5, name="split vs single pass")
+
+
 def test_planes_and_transpose(ops):
     x = rnd(150, 70, seed=3) * 3
     pl, plT = ops.make_planes(x.to(DEV), lo=True, straight=True, transposed=True)
