@@ -34,7 +34,10 @@ def gemm_bench():
     shapes = [("ffn_v fc1   8192x4096x1024", 8192, 4096, 1024), ("v proj      8192x1024x1024", 8192, 1024, 1024),
               ("a proj     25600x1024x128 ", 25600, 1024, 128), ("a d2Q      25600x128x1024 ", 25600, 128, 1024),
               ("dec q       960x1024x300  ", 960, 1024, 300), ("generator   960x10000x300 ", 960, 10000, 300)]
+    flt = os.environ.get("MB_FILTER")
     for name, M, N, K in shapes:
+        if flt and flt not in name:
+            continue
         x = torch.randn(M, K, device=DEV)
         W = torch.randn(N, K, device=DEV)
         b = torch.randn(N, device=DEV)
