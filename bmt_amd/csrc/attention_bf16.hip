@@ -245,6 +245,8 @@ __device__ __forceinline__ void grad_tile_flush(const uint16_t* tile, const Grad
 }
 
 // =================================================================================== forward
+constexpr float RESCALE_TAU = 8.f;   // in units of the scaled scores (natural log): P <= e^8
+
 template <int DK, int NPASS>
 __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
     using G = Geo<DK>;
@@ -361,17 +363,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, pv[r]);
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float m_new = fmaxf(m_run, tmax);
-                const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pv[r] = __expf(pv[r] - m_use);
-                    psum += pv[r];
-                }
-                psum += __shfl_xor(psum, 32, 64);
-                if (!__all(m_new == m_run)) {      // some lane's running max moved: rescale (alpha == 1 for the others)
-                    const float alpha = __expf(m_run - m_use);
+                // Online softmax with a STALE reference: exponentials are taken relative to m_run, which is only moved (and the
+                // 32 x d_k accumulator only rescaled: 128 AGPR reads, multiplies and writes per lane) when some query of this
+                // wave sees a score more than RESCALE_TAU above it.  softmax is shift invariant, so this is exact; P stays
+                // below e^TAU (fp32 accumulation, bf16 operands keep their relative precision).  With the exact running max
+                // the rescale ran on ~90 % of the key tiles (32 queries x fresh keys), at VALU cost comparable to the MFMAs.
+                if (__any(tmax > m_run + RESCALE_TAU)) {
+                    const float m_new = fmaxf(m_run, tmax);
+                    const float alpha = __expf(m_run - ((m_new == NEG_INF) ? 0.f : m_new));
                     l_run *= alpha;
 #pragma unroll
                     for (int dt = 0; dt < G::DT; ++dt)
@@ -379,6 +378,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
                     m_run = m_new;
                 }
+                const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __expf(pv[r] - m_use);
+                    psum += pv[r];
+                }
+                psum += __shfl_xor(psum, 32, 64);
                 l_run += psum;
                 bf16x8 ph[2], pl[2];
                 pack_p<NPASS>(pv, 0, ph[0], pl[0]);
@@ -489,16 +496,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     const bool qok = q < p.Sq;
     const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
 
-    bf16x8 qf[DK / 16], dof[DK / 16];
+    // Q fragments stay in registers; the dO rows of this workgroup's 128 queries live in LDS (swizzled like K) and are read
+    // as B operands.  Holding both in registers needs dq (128) + Q (64) + dO (64) + S, dP (32) = 288 accumulator-file
+    // registers: more than the 256 AGPRs, and hipcc then moved all of dq out and back every key tile (288 v_accvgpr moves per
+    // 48 MFMAs).
+    u32x4* sdOq = reinterpret_cast<u32x4*>(smem + 3 * TB + 256);
+    bf16x8 qf[DK / 16];
     {
         const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * half;
-        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * half;
 #pragma unroll
-        for (int s = 0; s < DK / 16; ++s) {
-            qf[s] = ldfrag(p.Qh + qo + 16 * s, qok);
-            dof[s] = ldfrag(p.dOh + oo + 16 * s, qok);
-        }
+        for (int s = 0; s < DK / 16; ++s) qf[s] = ldfrag(p.Qh + qo + 16 * s, qok);
+        u32x4 tmp[rows_n<DK, 128>()];
+        tile_gload<DK, 128>(p.dOh + (int64_t)b * p.bso + h * DK, p.ldo, qt * 128, p.Sq, tid, tmp);
+        tile_lstore<DK, 128>(sdOq, tid, tmp);
     }
+    const int dorow = wid * 32 + l31;
     const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
     const float lse = qok ? p.lse[stat] : 0.f;
     const float delta = qok ? p.delta[stat] : 0.f;
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
             for (int s = 0; s < DK / 16; ++s) {
                 const int idx = kslot<DK>(l31, 2 * s + half);
                 st = mfma32(as_bf16x8(sK[idx]), qf[s], st);
-                dp = mfma32(as_bf16x8(sV[idx]), dof[s], dp);
+                dp = mfma32(as_bf16x8(sV[idx]), as_bf16x8(sdOq[kslot<DK>(dorow, 2 * s + half)]), dp);
             }
             float ds[16];
 #pragma unroll
@@ -741,7 +753,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     {
-        const int lds_loop = 3 * 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
+        const int lds_loop = 3 * 32 * DK * 2 + 256 + 128 * DK * 2, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
         const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
         static bool done = false;
         if (!done) {

@@ -45,6 +45,7 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     // D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]  (cdna_hip_programming.md section 3)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+
 // row of accumulator register r for this lane's half (l>>5)
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 

@@ -63,6 +63,8 @@ def attn_bench(bwd=False):
     D = H * dk
     for name, Sq, Sk in (("A-self 800x800", 800, 800), ("V-self 256x256", 256, 256), ("A<-V 800x256", 800, 256),
                          ("V<-A 256x800", 256, 800), ("C<-A 30x800", 30, 800)):
+        if os.environ.get("MB_FILTER") and os.environ["MB_FILTER"] not in name:
+            continue
         q = torch.randn(B, Sq, D, device=DEV)
         k = torch.randn(B, Sk, D, device=DEV)
         v = torch.randn(B, Sk, D, device=DEV)
