@@ -124,8 +124,39 @@ class KernelTimer:
                 (s, e, 10.0 * B_ * Sq * Sk * D, B_ * D * (2.0 * (Sq + 2 * Sk) + 8.0 * Sq + 4.0 * (Sq + 2 * Sk))))
             return r
 
+        raw_afp, raw_abp = ops.attn_fwd_planes, ops.attn_bwd_planes
+
+        def attn_fwd_planes(q, k, v, B_, Sq, Sk, D, mask, H, **kw):
+            if not timer.enabled:
+                return raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw)
+            prec = kw.get("precision") or ops.FWD_PRECISION
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw)
+            e.record()
+            side = "enc" if min(Sq, Sk) >= 128 else "dec"
+            nb = 4.0 if prec == 3 else 2.0          # hi (+lo) planes in and out
+            timer.records.setdefault(f"attn_fwd_{side}_dk{D // H}_x{prec}", []).append(
+                (s, e, 4.0 * B_ * Sq * Sk * D, nb * B_ * D * (2 * Sq + 2 * Sk)))
+            return r
+
+        def attn_bwd_planes(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases):
+            if not timer.enabled:
+                return raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases)
+            e.record()
+            side = "enc" if min(Sq, Sk) >= 128 else "dec"
+            # algorithmic backward = 5 products (S recompute, dP, dV, dK, dQ) = 2.5 x forward; bytes: q,k,v hi planes, O hi+lo,
+            # dO fp32 in; dq,dk,dv plane + transposed plane out
+            timer.records.setdefault(f"attn_bwd_{side}_dk{D // H}", []).append(
+                (s, e, 10.0 * B_ * Sq * Sk * D, B_ * D * (2.0 * (Sq + 2 * Sk) + 8.0 * Sq + 4.0 * (Sq + 2 * Sk))))
+            return r
+
         ops.gemm, ops.attn_fwd, ops.attn_bwd = gemm, attn_fwd, attn_bwd
         ops.gemm_bf16, ops.attn_fwd_bf16, ops.attn_bwd_bf16 = gemm_bf16, attn_fwd_bf16, attn_bwd_bf16
+        ops.attn_fwd_planes, ops.attn_bwd_planes = attn_fwd_planes, attn_bwd_planes
 
     def summary(self):
         out = {}
@@ -325,7 +356,23 @@ def main():
                                "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                "share_of_timed_kernels": d["ms"] / tot,
                                "mfma_passes": 3 if dom.endswith("x3") else 1, "gemm_path": "planes" if ops.USE_PLANE_GEMM else "fp32-staged",
-                               "timing": f"HIP events around every launch of the class, {timer_steps} eagerly issued steps right after the timed region"}
+                               "timing": f"HIP events around every launch of the class (a split-K GEMM launch = main kernel + its epilogue kernel), {timer_steps} eagerly issued steps right after the timed region"}
+            # the north-star quantity: bi-modal ENCODER attention against the MFMA roofline.  "issued" counts what the matrix
+            # pipe executes (forward: 3 split-bf16 passes; backward: 8 products as scheduled -- S is recomputed in both
+            # backward kernels and by both roles of the dK/dV kernel), "algorithmic" the 2 / 5 products of the math.
+            enc = {k: v for k, v in summ.items() if k.startswith(("attn_fwd_enc", "attn_bwd_enc"))}
+            if enc:
+                ms = sum(v["ms"] for v in enc.values())
+                alg = sum(v["flops"] for v in enc.values())
+                issued = sum(v["flops"] * (3.0 if k.startswith("attn_fwd") and k.endswith("x3") else (1.6 if k.startswith("attn_bwd") else 1.0))
+                             for k, v in enc.items())
+                out["attention_roofline"] = {
+                    "scope": "encoder self- and cross-attention cores, forward + backward, B=32 H=4 d_k=256 T_v=256 T_a=800",
+                    "bound": "mfma", "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "algorithmic": alg / (ms * 1e-3) / 1e12, "issued": issued / (ms * 1e-3) / 1e12,
+                    "frac_algorithmic": alg / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    "frac_issued": issued / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    "ms_per_step": ms / timer_steps, "share_of_timed_kernels": ms / tot}
             out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                          "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches_per_step": v["launches"] / timer_steps}
                                      for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}

@@ -158,3 +158,56 @@ class CaptioningTrainStep:
         loss, _ = self._reduce(self._static_kl, self._static_ntok)
         g2.replay()
         return loss, self._static_ntok
+
+
+class ProposalTrainStep:
+    """One optimizer step of the proposal generator, restated from ``train_av_loop``
+    (epoch_loops/proposal_epoch_loops.py:27-49):
+
+        zero_grad -> masks (no captions) -> model(feature_stacks, targets, masks) -> loss.backward()
+                  -> [clip_grad_norm_] -> optimizer.step
+
+    Only parameters with ``requires_grad`` take part: with ``cfg.pretrained_cap_model_path`` the bi-modal encoder is loaded
+    from the captioning checkpoint and frozen unless ``cfg.finetune_cap_encoder`` (model/proposal_generator.py:344-353), so
+    the step is {frozen encoder forward} + {20 Conv1d heads forward/backward} + Adam over the heads -- configs[3].
+    Data parallel: every rank computes the loss of its own videos (the reference's MSE / BCE means are per batch) and the
+    gradients are AVERAGED over ranks (sum all-reduce, 1/world folded into Adam's ``grad_scale``); the number of target
+    events differs per step, so this step is launched eagerly (no graph capture)."""
+
+    def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
+                 overlap: bool = True):
+        import torch.distributed as dist
+        self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.optimizer = optimizer or FusedAdam(self.params, lr=cfg.lr, betas=tuple(getattr(cfg, "betas", (0.9, 0.999))),
+                                                eps=getattr(cfg, "eps", 1e-8), weight_decay=getattr(cfg, "weight_decay", 0.0))
+        self.data_parallel = data_parallel
+        self.reducer = GradientReducer(self.params, bucket_bytes=bucket_bytes, overlap=overlap) if data_parallel else None
+        self.world = dist.get_world_size() if (data_parallel and dist.is_initialized()) else 1
+        self.modality = getattr(cfg, 'modality', 'audio_video')
+        self._fused_scale = hasattr(self.optimizer, "grad_scale")
+        self.grad_scale = torch.full((1,), 1.0 / self.world, device=self.params[0].device, dtype=torch.float32)
+
+    def __call__(self, feature_stacks, targets):
+        model = self.model
+        model.train()
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad()
+        masks = make_masks(feature_stacks, None, self.modality, self.pad_idx)
+        predictions, loss, losses_A, losses_V = model(feature_stacks, targets, masks)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        scale_in_adam = self._fused_scale and self.world > 1 and getattr(self.cfg, "grad_clip", None) is None
+        if self.world > 1 and not scale_in_adam:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.mul_(self.grad_scale)
+        if getattr(self.cfg, "grad_clip", None) is not None:
+            clip_grad_norm_(self.params, self.cfg.grad_clip)
+        if self._fused_scale:
+            self.optimizer.grad_scale = self.grad_scale if scale_in_adam else None
+        self.optimizer.step()
+        return predictions, loss.detach(), losses_A, losses_V

@@ -90,3 +90,50 @@ def test_initial_state_dict_matches_reference_layout(golden):
     assert sorted({k.split(".")[1] for k in h.state_dict()}) == ["0", "3", "6"]
     h = ProposalGenerationHead([24, 16, 16, 9], 5, 0.0)
     assert sorted({k.split(".")[1] for k in h.state_dict()}) == ["0", "2", "4"]
+
+
+def test_proposal_train_step_matches_oracle(golden):
+    """train_av_loop (epoch_loops/proposal_epoch_loops.py:35-49): zero_grad -> masks -> forward -> backward -> Adam, two steps
+    with dropout off, against the CPU oracle run from the same state_dict."""
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    from bmt_amd.train import ProposalTrainStep
+    from oracle import bmt_oracle as orc
+    g = golden("tiny_prop.npz")
+    cfg = _prop_cfg()        # built with dropout so that the Sequential keys match the fixture; switched off below
+    cfg.lr = 1e-3
+    cfg.grad_clip = None
+    anchors = {"audio": [float(a) for a in g.np("anchors_audio")], "video": [float(a) for a in g.np("anchors_video")]}
+    torch.manual_seed(0)
+    model = MultimodalProposalGenerator(cfg, anchors)
+    sd = g.sub("sd/")
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    for mod in model.modules():         # dropout off: every module reads its own dout_p at call time
+        if hasattr(mod, "dout_p"):
+            mod.dout_p = 0.0
+    step = ProposalTrainStep(model, cfg, pad_idx=1)
+    fs_cpu = {k: g[k] for k in ("rgb", "flow", "audio")}
+    fs = {k: v.to(DEV) for k, v in fs_cpu.items()}
+    targets = g["targets"]
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    omasks = {"A_mask": orc.mask(fs_cpu["audio"][:, :, 0], None, 1), "V_mask": orc.mask(fs_cpu["rgb"][:, :, 0], None, 1)}
+    for it in (1, 2):
+        _, loss, _, _ = step(fs, targets.to(DEV))
+        for t in p.values():
+            t.grad = None
+        _, oloss, _, _ = orc.multimodal_proposal_generator(p, cfg, anchors, fs_cpu, targets, omasks)
+        oloss.backward()
+        with torch.no_grad():
+            for k in p:
+                if p[k].grad is not None:
+                    orc.adam_step(p[k], p[k].grad, m[k], v2[k], it, cfg.lr)
+        assert abs(float(loss) - float(oloss.detach())) < 5e-3 * max(1.0, abs(float(oloss.detach()))), (it, float(loss), float(oloss))
+    msd = model.state_dict()
+    agree = total = 0
+    for k in p:
+        d = (msd[k].cpu() - p[k].detach()).abs()
+        agree += int((d < 2.5e-4).sum())
+        total += d.numel()
+    assert agree / total > 0.97, agree / total
