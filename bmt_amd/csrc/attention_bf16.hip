@@ -34,31 +34,31 @@ __device__ __forceinline__ int vunit(int d, int kg) {
     if constexpr (ROWS == 64) return d * 16 + (kg ^ ((d >> 1) & 15));
     else return d * 8 + (kg ^ ((d >> 2) & 7));
 }
-template <int DK, int ROWS> constexpr int rows_n() { return (ROWS * DK / 8 + 255) / 256; }
-template <int DK, int ROWS> constexpr int rowsT_n() { return (ROWS * DK / 16 + 255) / 256; }
+template <int DK, int ROWS, int NT = 256> constexpr int rows_n() { return (ROWS * DK / 8 + NT - 1) / NT; }
+template <int DK, int ROWS, int NT = 256> constexpr int rowsT_n() { return (ROWS * DK / 16 + NT - 1) / NT; }
 
 // ---- row-major bf16 tile [ROWS][DK]: global -> registers (16-B slots) -> swizzled LDS image
-template <int DK, int ROWS>
+template <int DK, int ROWS, int NT = 256>
 __device__ __forceinline__ void tile_gload(const uint16_t* base, int64_t ld, int row0, int nrows, int tid,
-                                           u32x4 (&v)[rows_n<DK, ROWS>()]) {
+                                           u32x4 (&v)[rows_n<DK, ROWS, NT>()]) {
     // UNCONDITIONAL loads (row clamped to the last valid row): a guarded load into a register array makes hipcc either wait
     // vmcnt(0) at the join or demote the array to scratch.  Clamped rows hold finite data and are neutralised downstream
     // (masked scores / zero probabilities / rows that are never stored).
     constexpr int SPR = DK / 8;
 #pragma unroll
-    for (int i = 0; i < rows_n<DK, ROWS>(); ++i) {
-        const int c = (ROWS * SPR % 256 == 0) ? tid + 256 * i : min(tid + 256 * i, ROWS * SPR - 1);
+    for (int i = 0; i < rows_n<DK, ROWS, NT>(); ++i) {
+        const int c = (ROWS * SPR % NT == 0) ? tid + NT * i : min(tid + NT * i, ROWS * SPR - 1);
         const int row = min(row0 + c / SPR, nrows - 1), slot = c % SPR;
         v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + slot * 8);
     }
 }
-template <int DK, int ROWS>
-__device__ __forceinline__ void tile_lstore(u32x4* img, int tid, const u32x4 (&v)[rows_n<DK, ROWS>()]) {
+template <int DK, int ROWS, int NT = 256>
+__device__ __forceinline__ void tile_lstore(u32x4* img, int tid, const u32x4 (&v)[rows_n<DK, ROWS, NT>()]) {
     constexpr int SPR = DK / 8;
 #pragma unroll
-    for (int i = 0; i < rows_n<DK, ROWS>(); ++i) {
-        const int c = tid + 256 * i;
-        if constexpr (ROWS * SPR % 256 != 0) {
+    for (int i = 0; i < rows_n<DK, ROWS, NT>(); ++i) {
+        const int c = tid + NT * i;
+        if constexpr (ROWS * SPR % NT != 0) {
             if (c < ROWS * SPR) img[kslot<DK>(c / SPR, c % SPR)] = v[i];
         } else {
             img[kslot<DK>(c / SPR, c % SPR)] = v[i];
@@ -66,13 +66,13 @@ __device__ __forceinline__ void tile_lstore(u32x4* img, int tid, const u32x4 (&v
     }
 }
 // ---- transposed image [DK][ROWS] in 8-byte row-quads: each thread owns 4(row) x 4(d) blocks
-template <int DK, int ROWS>
+template <int DK, int ROWS, int NT = 256>
 __device__ __forceinline__ void tileT_gload(const uint16_t* base, int64_t ld, int row0, int nrows, int tid,
-                                            u32x2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
+                                            u32x2 (&v)[rowsT_n<DK, ROWS, NT>() * 4]) {
     constexpr int DQ = DK / 4, NB = DQ * (ROWS / 4);
 #pragma unroll
-    for (int i = 0; i < rowsT_n<DK, ROWS>(); ++i) {
-        const int c = (NB % 256 == 0) ? tid + 256 * i : min(tid + 256 * i, NB - 1);
+    for (int i = 0; i < rowsT_n<DK, ROWS, NT>(); ++i) {
+        const int c = (NB % NT == 0) ? tid + NT * i : min(tid + NT * i, NB - 1);
         const int dq = c % DQ, kg = c / DQ;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -81,13 +81,13 @@ __device__ __forceinline__ void tileT_gload(const uint16_t* base, int64_t ld, in
         }
     }
 }
-template <int DK, int ROWS>
-__device__ __forceinline__ void tileT_lstore(u32x2* img, int tid, const u32x2 (&v)[rowsT_n<DK, ROWS>() * 4]) {
+template <int DK, int ROWS, int NT = 256>
+__device__ __forceinline__ void tileT_lstore(u32x2* img, int tid, const u32x2 (&v)[rowsT_n<DK, ROWS, NT>() * 4]) {
     constexpr int DQ = DK / 4;
 #pragma unroll
-    for (int i = 0; i < rowsT_n<DK, ROWS>(); ++i) {
-        const int c = tid + 256 * i;
-        if constexpr (DQ * (ROWS / 4) % 256 != 0) {
+    for (int i = 0; i < rowsT_n<DK, ROWS, NT>(); ++i) {
+        const int c = tid + NT * i;
+        if constexpr (DQ * (ROWS / 4) % NT != 0) {
             if (c >= DQ * (ROWS / 4)) continue;
         }
         const int dq = c % DQ, kg = c / DQ;
@@ -441,6 +441,216 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
     }
 }
 
+// =================================================================================== forward, 8 waves x 16 queries
+// Same algorithm, different decomposition, for d_k >= 128.  The 4-wave kernel above gives each wave 32 queries: its
+// 32 x d_k accumulator (128 registers at d_k = 256) plus the Q fragments push it past 256 registers, so it runs ONE wave per
+// SIMD, hipcc selects AGPR-form MFMAs and copies the accumulator between the register files every key tile, and MFMA, VALU
+// and LDS phases of the single wave serialise (PMC, profiles/r01_e_attn_pmc.csv: MFMA busy 20 %, VALU 25 %, waiting 41 %).
+// Here a wave owns 16 queries (v_mfma_f32_16x16x32_bf16): 16 x d_k accumulator = 64 registers, everything fits in 256
+// VGPRs, MFMAs are VGPR-form (the VALU rescales the accumulator in place) and TWO waves share each SIMD, so one wave's
+// softmax runs under the other's MFMAs.  Cost: K / V^T fragments are re-read from LDS by twice as many waves.
+//   S^T tile [16 keys x 16 q] = K[16 x 32] . Q^T[32 x 16]:   A = K rows (LDS), B = Q (registers);  lane (c = l&15, g = l>>4)
+//   holds S^T[key = 4g + r][q = c], r < 4.  Two key tiles per 32-key stage -> this lane's 8 probabilities are keys
+//   {4g..4g+3} and {16+4g..16+4g+3}: exactly the B operand of O^T[16 d x 16 q] += V^T[16 x 32] . P^T[32 x 16] if the MFMA's
+//   reduction index kk = 8g + j is read as key(kk) = (j < 4 ? 4g + j : 16 + 4g + j - 4); the A operand (V^T image, 4-key
+//   units) then takes units g and 4 + g.  No cross-lane movement between the two products.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
+    // D[16x16] += A[16x32] * B[32x16]; lane l: A[row = l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][col = l&15],
+    // D[row = 4*(l>>4) + r][col = l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int DK, int NPASS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd16_kernel(const AttnPB p) {
+    constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
+    constexpr int KB = BC * DK * 2, VB = DK * BC * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* sKh = reinterpret_cast<u32x4*>(smem);
+    u32x2* sVh = reinterpret_cast<u32x2*>(smem + KB);
+    u32x4* sKl = reinterpret_cast<u32x4*>(smem + KB + VB);
+    u32x2* sVl = reinterpret_cast<u32x2*>(smem + 2 * KB + VB);
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + (NPASS == 3 ? 2 : 1) * (KB + VB));
+    int* sFlag = reinterpret_cast<int*>(sMask + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 16 + c;
+    const bool qok = q < p.Sq;
+    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+
+    bf16x8 qh[KS], ql[KS];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qh[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
+            if constexpr (NPASS == 3) ql[ks] = ldfrag(p.Ql + qo + 32 * ks, qok);
+        }
+    }
+    f32x4v o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_INF, l_run = 0.f;
+
+    u32x4 kh[rows_n<DK, BC, NT>()], kl[rows_n<DK, BC, NT>()];
+    u32x2 vh[rowsT_n<DK, BC, NT>() * 4], vl[rowsT_n<DK, BC, NT>() * 4];
+    const int ntile = (p.Sk + BC - 1) / BC;
+#define BMT_F16_FETCH(key0_)                                                            \
+    do {                                                                                \
+        tile_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kh);             \
+        tileT_gload<DK, BC, NT>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vh);            \
+        if constexpr (NPASS == 3) {                                                     \
+            tile_gload<DK, BC, NT>(p.Kl + koff, p.ldk, (key0_), p.Sk, tid, kl);         \
+            tileT_gload<DK, BC, NT>(p.Vl + voff, p.ldv, (key0_), p.Sk, tid, vl);        \
+        }                                                                               \
+    } while (0)
+#define BMT_F16_STORE(key0_)                                                            \
+    do {                                                                                \
+        tile_lstore<DK, BC, NT>(sKh, tid, kh);                                          \
+        tileT_lstore<DK, BC, NT>(sVh, tid, vh);                                         \
+        if constexpr (NPASS == 3) {                                                     \
+            tile_lstore<DK, BC, NT>(sKl, tid, kl);                                      \
+            tileT_lstore<DK, BC, NT>(sVl, tid, vl);                                     \
+        }                                                                               \
+        stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
+    } while (0)
+    BMT_F16_FETCH(0);
+    BMT_F16_STORE(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int key0 = t * BC;
+        const int kn = min(key0 + BC, (ntile - 1) * BC);
+        BMT_F16_FETCH(kn);
+        const int flag = sFlag[0];
+        if (flag != 0) {
+            f32x4v st[2];
+            st[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            st[1] = st[0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int idx = kslot<DK>(kt * 16 + c, 4 * ks + g);
+                    const bf16x8 a = as_bf16x8(sKh[idx]);
+                    if constexpr (NPASS == 3) {
+                        st[kt] = mfma16(as_bf16x8(sKl[idx]), qh[ks], st[kt]);
+                        st[kt] = mfma16(a, ql[ks], st[kt]);
+                    }
+                    st[kt] = mfma16(a, qh[ks], st[kt]);
+                }
+            float pv[8];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[4 * kt + r] = st[kt][r] * p.scale;
+            if (flag != 2) {
+                if (p.mask != nullptr && p.mask_qs != 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int key = key0 + 16 * (i >> 2) + 4 * g + (i & 3);
+                        const bool ok = qok && key < p.Sk && p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
+                        pv[i] = ok ? pv[i] : NEG_INF;
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + 16 * kt + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[4 * kt + r] = ((mw >> (8 * r)) & 0xffu) ? pv[4 * kt + r] : NEG_INF;
+                    }
+                }
+            }
+            float tmax = pv[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) tmax = fmaxf(tmax, pv[i]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m_run + RESCALE_TAU)) {     // stale-reference online softmax, see the 4-wave kernel
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __expf(m_run - ((m_new == NEG_INF) ? 0.f : m_new));
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+                m_run = m_new;
+            }
+            const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pv[i] = __expf(pv[i] - m_use);
+                psum += pv[i];
+            }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run += psum;
+            u32x4 phw, plw = {0u, 0u, 0u, 0u};
+            if constexpr (NPASS == 3) {
+                uint32_t hh, ll;
+                split_bf2(pv[0], pv[1], hh, ll); phw[0] = hh; plw[0] = ll;
+                split_bf2(pv[2], pv[3], hh, ll); phw[1] = hh; plw[1] = ll;
+                split_bf2(pv[4], pv[5], hh, ll); phw[2] = hh; plw[2] = ll;
+                split_bf2(pv[6], pv[7], hh, ll); phw[3] = hh; plw[3] = ll;
+            } else {
+                phw[0] = pack_bf2(pv[0], pv[1]); phw[1] = pack_bf2(pv[2], pv[3]);
+                phw[2] = pack_bf2(pv[4], pv[5]); phw[3] = pack_bf2(pv[6], pv[7]);
+            }
+            const bf16x8 ph = as_bf16x8(phw), pl = as_bf16x8(plw);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + c;
+                const u32x2 a0 = sVh[vunit<BC>(d, g)], a1 = sVh[vunit<BC>(d, 4 + g)];
+                const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
+                const bf16x8 a = as_bf16x8(aw);
+                if constexpr (NPASS == 3) {
+                    const u32x2 b0 = sVl[vunit<BC>(d, g)], b1 = sVl[vunit<BC>(d, 4 + g)];
+                    const u32x4 bw = {b0.x, b0.y, b1.x, b1.y};
+                    o[dt] = mfma16(as_bf16x8(bw), ph, o[dt]);
+                    o[dt] = mfma16(a, pl, o[dt]);
+                }
+                o[dt] = mfma16(a, ph, o[dt]);
+            }
+        }
+        __syncthreads();
+        BMT_F16_STORE(kn);
+        __syncthreads();
+    }
+#undef BMT_F16_FETCH
+#undef BMT_F16_STORE
+
+    if (qok) {
+        const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
+        const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + 4 * g;
+            float4 v;
+            v.x = drop_apply(dc, o[dt][0] * inv, (uint64_t)(rowoff + d + 0));
+            v.y = drop_apply(dc, o[dt][1] * inv, (uint64_t)(rowoff + d + 1));
+            v.z = drop_apply(dc, o[dt][2] * inv, (uint64_t)(rowoff + d + 2));
+            v.w = drop_apply(dc, o[dt][3] * inv, (uint64_t)(rowoff + d + 3));
+            if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
+            if (p.Owh) {
+                const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + d;
+                uint32_t h0, l0, h1, l1;
+                split_bf2(v.x, v.y, h0, l0);
+                split_bf2(v.z, v.w, h1, l1);
+                u32x2 hh, ll;
+                hh[0] = h0; hh[1] = h1; ll[0] = l0; ll[1] = l1;
+                *reinterpret_cast<u32x2*>(p.Owh + po) = hh;
+                if (p.Owl) *reinterpret_cast<u32x2*>(p.Owl + po) = ll;
+            }
+        }
+        if (g == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run + __logf(l_run);
+    }
+}
+
 // =================================================================================== backward
 // delta[b,h,q] = (1-p) * sum_d dO[b,q,h*DK+d] * O[b,q,h*DK+d]  (fp32 inputs), and the bf16 plane of dO for the MFMAs
 __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, int DK, uint16_t* dOh) {
@@ -735,15 +945,25 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int DK, int NPASS>
 int launch_fwd(const AttnPB& p, hipStream_t st) {
-    using G = Geo<DK>;
-    const int lds = (NPASS == 3 ? 2 : 1) * (G::K_BYTES + G::V_BYTES) + 128;
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        done = true;
-    }
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DK, NPASS>), dim3(nblk), dim3(256), lds, st, p);
+    if constexpr (DK >= 128) {        // 8 waves x 16 queries, two waves per SIMD
+        const int lds = (NPASS == 3 ? 2 : 1) * (2 * 32 * DK * 2) + 128;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        hipLaunchKernelGGL((attn_fwd16_kernel<DK, NPASS>), dim3(nblk), dim3(512), lds, st, p);
+    } else {
+        using G = Geo<DK>;
+        const int lds = (NPASS == 3 ? 2 : 1) * (G::K_BYTES + G::V_BYTES) + 128;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<DK, NPASS>), dim3(nblk), dim3(256), lds, st, p);
+    }
     BMT_CHECK_LAUNCH("bmt_attn_fwd_bf16");
     return BMT_OK;
 }
