@@ -211,27 +211,27 @@ __device__ __forceinline__ void grad_tile_write(uint16_t* tile, const f32x16 (&a
             tile[(dt * 32 + acc_row(r, half)) * TS + tc + l31] = ok ? __builtin_bit_cast(uint16_t, hv) : (uint16_t)0;
         }
 }
-template <int DK, int NTOK>
+template <int DK, int NTOK, int NT = 256>
 __device__ __forceinline__ void grad_tile_flush(const uint16_t* tile, const GradOut& g, int b, int h, int tok0, int S, int tid) {
     constexpr int TS = NTOK + 8, GR = NTOK / 8;
     if (g.hiT) {
         uint16_t* base = g.hiT + (int64_t)(h * DK) * g.t_ld + (int64_t)b * S + tok0;
         const bool vec = (S % 8 == 0) && (g.t_ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.hiT) & 15) == 0);
         if (vec) {
-            for (int idx = tid; idx < DK * GR; idx += 256) {
+            for (int idx = tid; idx < DK * GR; idx += NT) {
                 const int row = idx / GR, gq = idx % GR;
                 if (tok0 + gq * 8 < S)
                     *reinterpret_cast<u32x4*>(base + (int64_t)row * g.t_ld + gq * 8) = *reinterpret_cast<const u32x4*>(tile + row * TS + gq * 8);
             }
         } else {
-            for (int idx = tid; idx < DK * NTOK; idx += 256) {
+            for (int idx = tid; idx < DK * NTOK; idx += NT) {
                 const int row = idx / NTOK, c = idx % NTOK;
                 if (tok0 + c < S) base[(int64_t)row * g.t_ld + c] = tile[row * TS + c];
             }
         }
     }
     if (g.bsum) {
-        for (int d = tid; d < DK; d += 256) {
+        for (int d = tid; d < DK; d += NT) {
             float sum = 0.f;
 #pragma unroll
             for (int gq = 0; gq < GR; ++gq) {
@@ -941,6 +941,296 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
     }
 }
 
+// ---- gradient epilogue for the 16x16 accumulator layout: acc[dt][r] = G^T[d = 16 dt + 4 g + r][token = this lane's c column]
+template <int DK>
+__device__ __forceinline__ void grad_store_rows16(const GradOut& gr, const f32x4v (&acc)[DK / 16], int b, int h, int tok, bool ok, int g) {
+    if (!ok) return;
+    if (gr.f32) {
+        float* dst = gr.f32 + (int64_t)b * gr.f_bs + (int64_t)tok * gr.f_ld + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DK / 16; ++dt)
+            *reinterpret_cast<float4*>(dst + dt * 16) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
+    }
+    if (gr.hi) {
+        uint16_t* dst = gr.hi + (int64_t)b * gr.h_bs + (int64_t)tok * gr.h_ld + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DK / 16; ++dt) {
+            u32x2 v;
+            v[0] = pack_bf2(acc[dt][0], acc[dt][1]);
+            v[1] = pack_bf2(acc[dt][2], acc[dt][3]);
+            *reinterpret_cast<u32x2*>(dst + dt * 16) = v;
+        }
+    }
+}
+template <int DK, int NTOK>
+__device__ __forceinline__ void grad_tile_write16(uint16_t* tile, const f32x4v (&acc)[DK / 16], int tc, bool ok, int c, int g) {
+    constexpr int TS = NTOK + 8;
+#pragma unroll
+    for (int dt = 0; dt < DK / 16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const __bf16 hv = (__bf16)acc[dt][r];
+            tile[(dt * 16 + 4 * g + r) * TS + tc + c] = ok ? __builtin_bit_cast(uint16_t, hv) : (uint16_t)0;
+        }
+}
+
+// dQ, 8 waves x 16 queries (see attn_fwd16_kernel for the decomposition and the key permutation of the second product)
+template <int DK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16_kernel(const AttnPB p) {
+    constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
+    constexpr int TB = BC * DK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* sK = reinterpret_cast<u32x4*>(smem);
+    u32x4* sV = reinterpret_cast<u32x4*>(smem + TB);
+    u32x2* sKt = reinterpret_cast<u32x2*>(smem + 2 * TB);
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 3 * TB);
+    int* sFlag = reinterpret_cast<int*>(sMask + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 16 + c;
+    const bool qok = q < p.Sq;
+    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+
+    bf16x8 qf[KS], dof[KS];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
+            dof[ks] = ldfrag(p.dOh + oo + 32 * ks, qok);
+        }
+    }
+    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
+    const float lse = qok ? p.lse[stat] : 0.f;
+    const float delta = qok ? p.delta[stat] : 0.f;
+
+    f32x4v dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 kv[rows_n<DK, BC, NT>()], vv[rows_n<DK, BC, NT>()];
+    u32x2 ktv[rowsT_n<DK, BC, NT>() * 4];
+    const int ntile = (p.Sk + BC - 1) / BC;
+#define BMT_DQ16_FETCH(key0_)                                                           \
+    do {                                                                                \
+        tile_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kv);             \
+        tile_gload<DK, BC, NT>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vv);             \
+        tileT_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, ktv);           \
+    } while (0)
+#define BMT_DQ16_STORE(key0_)                                                           \
+    do {                                                                                \
+        tile_lstore<DK, BC, NT>(sK, tid, kv);                                           \
+        tile_lstore<DK, BC, NT>(sV, tid, vv);                                           \
+        tileT_lstore<DK, BC, NT>(sKt, tid, ktv);                                        \
+        stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
+    } while (0)
+    BMT_DQ16_FETCH(0);
+    BMT_DQ16_STORE(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int key0 = t * BC;
+        const int kn = min(key0 + BC, (ntile - 1) * BC);
+        BMT_DQ16_FETCH(kn);
+        const int flag = sFlag[0];
+        if (flag != 0) {
+            f32x4v st[2], dp[2];
+            st[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            st[1] = st[0]; dp[0] = st[0]; dp[1] = st[0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int idx = kslot<DK>(kt * 16 + c, 4 * ks + g);
+                    st[kt] = mfma16(as_bf16x8(sK[idx]), qf[ks], st[kt]);
+                    dp[kt] = mfma16(as_bf16x8(sV[idx]), dof[ks], dp[kt]);
+                }
+            float ds[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float pr = qok ? __expf(st[i >> 2][i & 3] * p.scale - lse) : 0.f;
+                ds[i] = pr * (dp[i >> 2][i & 3] - delta) * p.scale;
+            }
+            if (flag != 2) {
+                if (p.mask != nullptr && p.mask_qs != 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int key = key0 + 16 * (i >> 2) + 4 * g + (i & 3);
+                        const bool ok = qok && key < p.Sk && p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
+                        ds[i] = ok ? ds[i] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + 16 * kt + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ds[4 * kt + r] = ((mw >> (8 * r)) & 0xffu) ? ds[4 * kt + r] : 0.f;
+                    }
+                }
+            }
+            u32x4 dsw;
+            dsw[0] = pack_bf2(ds[0], ds[1]); dsw[1] = pack_bf2(ds[2], ds[3]);
+            dsw[2] = pack_bf2(ds[4], ds[5]); dsw[3] = pack_bf2(ds[6], ds[7]);
+            const bf16x8 dsf = as_bf16x8(dsw);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + c;
+                const u32x2 a0 = sKt[vunit<BC>(d, g)], a1 = sKt[vunit<BC>(d, 4 + g)];
+                const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
+                dq[dt] = mfma16(as_bf16x8(aw), dsf, dq[dt]);
+            }
+        }
+        __syncthreads();
+        BMT_DQ16_STORE(kn);
+        __syncthreads();
+    }
+#undef BMT_DQ16_FETCH
+#undef BMT_DQ16_STORE
+    grad_store_rows16<DK>(p.gq, dq, b, h, q, qok, g);
+    if (p.gq.hiT || p.gq.bsum) {
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+        grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
+        __syncthreads();
+        grad_tile_flush<DK, 128, NT>(tile, p.gq, b, h, qt * 128, p.Sq, tid);
+    }
+}
+
+// dK / dV, 8 waves: waves 0..3 accumulate dV, waves 4..7 dK, each for 16 of the workgroup's 64 keys; loop over 32-query
+// stages.  S[q][key] = Q . K^T and dP[q][key] = dO . V^T (A = staged Q / dO rows, B = this wave's K / V rows held in
+// registers); the lane's 8 values are queries {4g..4g+3} and {16+4g..} of the stage -> B operand of
+// dV^T[16 d x 16 keys] += dO^T[16 x 32 q] . P[32 q x 16 keys] with the same permutation of the reduction index.
+template <int DK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv16_kernel(const AttnPB p) {
+    constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 64;
+    constexpr int TB = BQ * DK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* sQ = reinterpret_cast<u32x4*>(smem);
+    u32x4* sdO = reinterpret_cast<u32x4*>(smem + TB);
+    u32x2* sQt = reinterpret_cast<u32x2*>(smem + 2 * TB);
+    u32x2* sdOt = reinterpret_cast<u32x2*>(smem + 3 * TB);
+    float* sLse = reinterpret_cast<float*>(smem + 4 * TB);
+    float* sDelta = sLse + BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int role = __builtin_amdgcn_readfirstlane(wid >> 2);      // 0: dV, 1: dK
+    const int kgrp = __builtin_amdgcn_readfirstlane(wid & 3);
+    const int nkt = (p.Sk + KBLK - 1) / KBLK;
+    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    const int kt = w % nkt, bh = w / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int key = kt * KBLK + kgrp * 16 + c;
+    const bool kok = key < p.Sk;
+    const uint16_t* Qb = p.Qh + (int64_t)b * p.bsq + h * DK;
+    const uint16_t* dOb = p.dOh + (int64_t)b * p.bso + h * DK;
+
+    bool kmask = kok;
+    if (kok && p.mask != nullptr && p.mask_qs == 0) kmask = p.mask[(int64_t)b * p.mask_bs + key] != 0;
+    const bool dead = __syncthreads_or(kmask ? 1 : 0) == 0;   // every key of the workgroup masked: gradients exactly zero
+    f32x4v acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    if (!dead) {
+        // this lane's K (and, for dK, V) row fragments: B operands, loop invariant
+        bf16x8 kf[KS], vf[KS];
+        {
+            const int krow = min(key, p.Sk - 1);
+            const int64_t ko = (int64_t)b * p.bsk + (int64_t)krow * p.ldk + h * DK + 8 * g;
+            const int64_t vo = (int64_t)b * p.bsv + (int64_t)krow * p.ldv + h * DK + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kf[ks] = ldfrag(p.Kh + ko + 32 * ks, true);
+                vf[ks] = ldfrag(p.Vh + vo + 32 * ks, role == 1);
+            }
+        }
+        u32x4 rq[rows_n<DK, BQ, NT>()], rdo[rows_n<DK, BQ, NT>()];
+        u32x2 rqt[rowsT_n<DK, BQ, NT>() * 4], rdot[rowsT_n<DK, BQ, NT>() * 4];
+        float rl = 0.f, rd = 0.f;
+        const int ntile = (p.Sq + BQ - 1) / BQ;
+#define BMT_DKV16_FETCH(q0_)                                                            \
+    do {                                                                                \
+        tile_gload<DK, BQ, NT>(Qb, p.ldq, (q0_), p.Sq, tid, rq);                        \
+        tile_gload<DK, BQ, NT>(dOb, p.ldo, (q0_), p.Sq, tid, rdo);                      \
+        tileT_gload<DK, BQ, NT>(Qb, p.ldq, (q0_), p.Sq, tid, rqt);                      \
+        tileT_gload<DK, BQ, NT>(dOb, p.ldo, (q0_), p.Sq, tid, rdot);                    \
+        {                                                                               \
+            const int qq_ = min((q0_) + (tid & (BQ - 1)), p.Sq - 1);                    \
+            const int64_t stat_ = ((int64_t)b * p.H + h) * p.Sq + qq_;                  \
+            rl = p.lse[stat_];                                                          \
+            rd = p.delta[stat_];                                                        \
+        }                                                                               \
+    } while (0)
+#define BMT_DKV16_STORE()                                                               \
+    do {                                                                                \
+        tile_lstore<DK, BQ, NT>(sQ, tid, rq);                                           \
+        tile_lstore<DK, BQ, NT>(sdO, tid, rdo);                                         \
+        tileT_lstore<DK, BQ, NT>(sQt, tid, rqt);                                        \
+        tileT_lstore<DK, BQ, NT>(sdOt, tid, rdot);                                      \
+        if (tid < BQ) { sLse[tid] = rl; sDelta[tid] = rd; }                             \
+    } while (0)
+        BMT_DKV16_FETCH(0);
+        BMT_DKV16_STORE();
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            const int q0 = t * BQ;
+            BMT_DKV16_FETCH(min(q0 + BQ, (ntile - 1) * BQ));
+            f32x4v sacc[2], dp[2];
+            sacc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            sacc[1] = sacc[0]; dp[0] = sacc[0]; dp[1] = sacc[0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    const int ia = kslot<DK>(qi * 16 + c, 4 * ks + g);
+                    sacc[qi] = mfma16(as_bf16x8(sQ[ia]), kf[ks], sacc[qi]);
+                    if (role == 1) dp[qi] = mfma16(as_bf16x8(sdO[ia]), vf[ks], dp[qi]);
+                }
+            float pr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ql_ = 16 * (i >> 2) + 4 * g + (i & 3);
+                const int qq = q0 + ql_;
+                bool ok = kmask && qq < p.Sq;
+                if (ok && p.mask != nullptr && p.mask_qs != 0)
+                    ok = p.mask[(int64_t)b * p.mask_bs + (int64_t)qq * p.mask_qs + key] != 0;
+                pr[i] = ok ? __expf(sacc[i >> 2][i & 3] * p.scale - sLse[ql_]) : 0.f;
+                if (role == 1) pr[i] = pr[i] * (dp[i >> 2][i & 3] - sDelta[ql_]) * p.scale;
+            }
+            u32x4 bw;
+            bw[0] = pack_bf2(pr[0], pr[1]); bw[1] = pack_bf2(pr[2], pr[3]);
+            bw[2] = pack_bf2(pr[4], pr[5]); bw[3] = pack_bf2(pr[6], pr[7]);
+            const bf16x8 bf = as_bf16x8(bw);
+            const u32x2* timg = (role == 1) ? sQt : sdOt;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + c;
+                const u32x2 a0 = timg[vunit<BQ>(d, g)], a1 = timg[vunit<BQ>(d, 4 + g)];
+                const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
+                acc[dt] = mfma16(as_bf16x8(aw), bf, acc[dt]);
+            }
+            __syncthreads();
+            BMT_DKV16_STORE();
+            __syncthreads();
+        }
+#undef BMT_DKV16_FETCH
+#undef BMT_DKV16_STORE
+    }
+    const GradOut& gr = (role == 1) ? p.gk : p.gv;
+    grad_store_rows16<DK>(gr, acc, b, h, key, kok, g);
+    if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [2 roles][DK][64 + 8]
+        grad_tile_write16<DK, KBLK>(tile + role * DK * (KBLK + 8), acc, kgrp * 16, kok, c, g);
+        __syncthreads();
+        grad_tile_flush<DK, KBLK, NT>(tile, p.gv, b, h, kt * KBLK, p.Sk, tid);
+        grad_tile_flush<DK, KBLK, NT>(tile + DK * (KBLK + 8), p.gk, b, h, kt * KBLK, p.Sk, tid);
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int DK, int NPASS>
@@ -972,26 +1262,48 @@ template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
-    {
-        const int lds_loop = 3 * 32 * DK * 2 + 256 + 128 * DK * 2, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
-        const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
+    const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
+    if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
+        {
+            const int lds_loop = 3 * 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;
+            const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, p);
         }
-        const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
-        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DK>), dim3(nblk), dim3(256), lds, st, p);
-    }
-    {
-        const int lds = 2 * 64 * DK * 2 + 4 * 32 * DK * 2 + 2 * 32 * 4;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
+        {
+            const int lds_loop = 4 * 32 * DK * 2 + 2 * 32 * 4, lds_epi = 2 * DK * (64 + 8) * 2;
+            const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k), dim3(512), lds, st, p);
         }
-        const int nblk = ((p.Sk + 63) / 64) * p.B * p.H;
-        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DK>), dim3(nblk), dim3(256), lds, st, p);
+    } else {
+        {
+            const int lds_loop = 3 * 32 * DK * 2 + 256 + 128 * DK * 2, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
+            const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DK>), dim3(nblk_q), dim3(256), lds, st, p);
+        }
+        {
+            const int lds = 2 * 64 * DK * 2 + 4 * 32 * DK * 2 + 2 * 32 * 4;
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DK>), dim3(nblk_k), dim3(256), lds, st, p);
+        }
     }
     BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16");
     return BMT_OK;
