@@ -441,6 +441,47 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
     }
 }
 
+// ---- padded row-major image + hardware transpose read (gfx950 ds_read_b64_tr_b16), used by the 16-wide kernels.
+// Image: [ROWS][DK] bf16, row stride DK*2 + 32 bytes.  It serves two access patterns without bank conflicts:
+//   * row fragments (A/B operand with the reduction along d): lane (row c, 16-B slot s) -> ds_read_b128;
+//   * column fragments (operand [16 d x 32 rows], reduction along the ROWS): ds_read_b64_tr_b16.  Measured semantics
+//     (tools/probes/tr_probe.hip): within a 16-lane group lane m supplies the address of a 4-element chunk and lane i receives
+//     element j = chunk[4 j + (i >> 2)][i & 3].  With lane m pointing at image[r0 + (m >> 2)][d0 + 4 (m & 3) ..] lane i gets
+//     image[r0 + j][d0 + i], j < 4: a 4-row x 16-column block transposed in flight.  Two reads (rows r0 = 4 g and 16 + 4 g)
+//     give lane (c, g) the MFMA fragment for reduction indices 8 g + j in exactly the order the preceding product leaves its
+//     probabilities in (see attn_fwd16_kernel).  The d-tile enters as a compile-time byte offset: one address VGPR per kernel.
+// This replaces the separately loaded and transposed images (a second global read of every tile, 4x4 register transposes and
+// 8-byte LDS stores).
+template <int DK> constexpr int pad_rs() { return DK * 2 + 32; }
+template <int DK, int ROWS, int NT>
+__device__ __forceinline__ void tile_lstore_pad(char* img, int tid, const u32x4 (&v)[rows_n<DK, ROWS, NT>()]) {
+    constexpr int SPR = DK / 8;
+#pragma unroll
+    for (int i = 0; i < rows_n<DK, ROWS, NT>(); ++i) {
+        const int c = tid + NT * i;
+        if constexpr (ROWS * SPR % NT != 0) {
+            if (c >= ROWS * SPR) continue;
+        }
+        *reinterpret_cast<u32x4*>(img + (c / SPR) * pad_rs<DK>() + (c % SPR) * 16) = v[i];
+    }
+}
+template <int DK>
+__device__ __forceinline__ bf16x8 rowfrag_pad(const char* img, int row, int slot) {
+    return as_bf16x8(*reinterpret_cast<const u32x4*>(img + row * pad_rs<DK>() + slot * 16));
+}
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+// lane_base = img + (4 g + (c >> 2)) * RS + 8 * (c & 3)   (bytes); fragment of d-tile dt = columns [16 dt, 16 dt + 16)
+template <int DK>
+__device__ __forceinline__ bf16x8 trfrag(const char* lane_base, int dt) {
+    typedef v4s16 __attribute__((address_space(3))) * lds_v4s;
+    const v4s16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(lane_base + dt * 32));
+    const v4s16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(lane_base + dt * 32 + 16 * pad_rs<DK>()));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ int tr_lane_off(int rs, int c, int g) { return (4 * g + (c >> 2)) * rs + 8 * (c & 3); }
+
 // =================================================================================== forward, 8 waves x 16 queries
 // Same algorithm, different decomposition, for d_k >= 128.  The 4-wave kernel above gives each wave 32 queries: its
 // 32 x d_k accumulator (128 registers at d_k = 256) plus the Q fragments push it past 256 registers, so it runs ONE wave per
@@ -464,12 +505,12 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 template <int DK, int NPASS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd16_kernel(const AttnPB p) {
     constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
-    constexpr int KB = BC * DK * 2, VB = DK * BC * 2;
+    constexpr int KB = BC * DK * 2, VB = BC * pad_rs<DK>();       // K: swizzled rows; V: padded rows read through the transpose unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* sKh = reinterpret_cast<u32x4*>(smem);
-    u32x2* sVh = reinterpret_cast<u32x2*>(smem + KB);
+    char* sVh = smem + KB;
     u32x4* sKl = reinterpret_cast<u32x4*>(smem + KB + VB);
-    u32x2* sVl = reinterpret_cast<u32x2*>(smem + 2 * KB + VB);
+    char* sVl = smem + 2 * KB + VB;
     uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + (NPASS == 3 ? 2 : 1) * (KB + VB));
     int* sFlag = reinterpret_cast<int*>(sMask + 64);
 
@@ -496,26 +537,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
     float m_run = NEG_INF, l_run = 0.f;
+    const int troff = tr_lane_off(pad_rs<DK>(), c, g);
 
     u32x4 kh[rows_n<DK, BC, NT>()], kl[rows_n<DK, BC, NT>()];
-    u32x2 vh[rowsT_n<DK, BC, NT>() * 4], vl[rowsT_n<DK, BC, NT>() * 4];
+    u32x4 vh[rows_n<DK, BC, NT>()], vl[rows_n<DK, BC, NT>()];
     const int ntile = (p.Sk + BC - 1) / BC;
 #define BMT_F16_FETCH(key0_)                                                            \
     do {                                                                                \
         tile_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kh);             \
-        tileT_gload<DK, BC, NT>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vh);            \
+        tile_gload<DK, BC, NT>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vh);            \
         if constexpr (NPASS == 3) {                                                     \
             tile_gload<DK, BC, NT>(p.Kl + koff, p.ldk, (key0_), p.Sk, tid, kl);         \
-            tileT_gload<DK, BC, NT>(p.Vl + voff, p.ldv, (key0_), p.Sk, tid, vl);        \
+            tile_gload<DK, BC, NT>(p.Vl + voff, p.ldv, (key0_), p.Sk, tid, vl);        \
         }                                                                               \
     } while (0)
 #define BMT_F16_STORE(key0_)                                                            \
     do {                                                                                \
         tile_lstore<DK, BC, NT>(sKh, tid, kh);                                          \
-        tileT_lstore<DK, BC, NT>(sVh, tid, vh);                                         \
+        tile_lstore_pad<DK, BC, NT>(sVh, tid, vh);                                         \
         if constexpr (NPASS == 3) {                                                     \
             tile_lstore<DK, BC, NT>(sKl, tid, kl);                                      \
-            tileT_lstore<DK, BC, NT>(sVl, tid, vl);                                     \
+            tile_lstore_pad<DK, BC, NT>(sVl, tid, vl);                                     \
         }                                                                               \
         stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
     } while (0)
@@ -603,14 +645,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bf16x8 ph = as_bf16x8(phw), pl = as_bf16x8(plw);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const int d = dt * 16 + c;
-                const u32x2 a0 = sVh[vunit<BC>(d, g)], a1 = sVh[vunit<BC>(d, 4 + g)];
-                const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
-                const bf16x8 a = as_bf16x8(aw);
+                const bf16x8 a = trfrag<DK>(sVh + troff, dt);
                 if constexpr (NPASS == 3) {
-                    const u32x2 b0 = sVl[vunit<BC>(d, g)], b1 = sVl[vunit<BC>(d, 4 + g)];
-                    const u32x4 bw = {b0.x, b0.y, b1.x, b1.y};
-                    o[dt] = mfma16(as_bf16x8(bw), ph, o[dt]);
+                    o[dt] = mfma16(trfrag<DK>(sVl + troff, dt), ph, o[dt]);
                     o[dt] = mfma16(a, pl, o[dt]);
                 }
                 o[dt] = mfma16(a, ph, o[dt]);
@@ -1237,7 +1274,7 @@ template <int DK, int NPASS>
 int launch_fwd(const AttnPB& p, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries, two waves per SIMD
-        const int lds = (NPASS == 3 ? 2 : 1) * (2 * 32 * DK * 2) + 128;
+        const int lds = (NPASS == 3 ? 2 : 1) * (32 * DK * 2 + 32 * (DK * 2 + 32)) + 128;
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
