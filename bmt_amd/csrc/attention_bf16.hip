@@ -1015,12 +1015,11 @@ __device__ __forceinline__ void grad_tile_write16(uint16_t* tile, const f32x4v (
 template <int DK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16_kernel(const AttnPB p) {
     constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
-    constexpr int TB = BC * DK * 2;
+    constexpr int TB = BC * DK * 2, KP = BC * pad_rs<DK>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* sK = reinterpret_cast<u32x4*>(smem);
-    u32x4* sV = reinterpret_cast<u32x4*>(smem + TB);
-    u32x2* sKt = reinterpret_cast<u32x2*>(smem + 2 * TB);
-    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 3 * TB);
+    char* sK = smem;                                          // padded rows: S^T row fragments AND the K^T fragments of dQ
+    u32x4* sV = reinterpret_cast<u32x4*>(smem + KP);
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + KP + TB);
     int* sFlag = reinterpret_cast<int*>(sMask + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1046,25 +1045,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
     const float lse = qok ? p.lse[stat] : 0.f;
     const float delta = qok ? p.delta[stat] : 0.f;
+    const int troff = tr_lane_off(pad_rs<DK>(), c, g);
 
     f32x4v dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     u32x4 kv[rows_n<DK, BC, NT>()], vv[rows_n<DK, BC, NT>()];
-    u32x2 ktv[rowsT_n<DK, BC, NT>() * 4];
     const int ntile = (p.Sk + BC - 1) / BC;
 #define BMT_DQ16_FETCH(key0_)                                                           \
     do {                                                                                \
         tile_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kv);             \
         tile_gload<DK, BC, NT>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vv);             \
-        tileT_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, ktv);           \
     } while (0)
 #define BMT_DQ16_STORE(key0_)                                                           \
     do {                                                                                \
-        tile_lstore<DK, BC, NT>(sK, tid, kv);                                           \
+        tile_lstore_pad<DK, BC, NT>(sK, tid, kv);                                       \
         tile_lstore<DK, BC, NT>(sV, tid, vv);                                           \
-        tileT_lstore<DK, BC, NT>(sKt, tid, ktv);                                        \
         stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
     } while (0)
     BMT_DQ16_FETCH(0);
@@ -1083,9 +1080,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
-                    const int idx = kslot<DK>(kt * 16 + c, 4 * ks + g);
-                    st[kt] = mfma16(as_bf16x8(sK[idx]), qf[ks], st[kt]);
-                    dp[kt] = mfma16(as_bf16x8(sV[idx]), dof[ks], dp[kt]);
+                    st[kt] = mfma16(rowfrag_pad<DK>(sK, kt * 16 + c, 4 * ks + g), qf[ks], st[kt]);
+                    dp[kt] = mfma16(as_bf16x8(sV[kslot<DK>(kt * 16 + c, 4 * ks + g)]), dof[ks], dp[kt]);
                 }
             float ds[8];
 #pragma unroll
@@ -1115,12 +1111,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dsw[2] = pack_bf2(ds[4], ds[5]); dsw[3] = pack_bf2(ds[6], ds[7]);
             const bf16x8 dsf = as_bf16x8(dsw);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = dt * 16 + c;
-                const u32x2 a0 = sKt[vunit<BC>(d, g)], a1 = sKt[vunit<BC>(d, 4 + g)];
-                const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
-                dq[dt] = mfma16(as_bf16x8(aw), dsf, dq[dt]);
-            }
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma16(trfrag<DK>(sK + troff, dt), dsf, dq[dt]);
         }
         __syncthreads();
         BMT_DQ16_STORE(kn);
@@ -1144,13 +1135,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int DK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv16_kernel(const AttnPB p) {
     constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 64;
-    constexpr int TB = BQ * DK * 2;
+    constexpr int TP = BQ * pad_rs<DK>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* sQ = reinterpret_cast<u32x4*>(smem);
-    u32x4* sdO = reinterpret_cast<u32x4*>(smem + TB);
-    u32x2* sQt = reinterpret_cast<u32x2*>(smem + 2 * TB);
-    u32x2* sdOt = reinterpret_cast<u32x2*>(smem + 3 * TB);
-    float* sLse = reinterpret_cast<float*>(smem + 4 * TB);
+    char* sQ = smem;                          // padded rows: A operands of S / dP by row, of dK / dV through the transpose unit
+    char* sdO = smem + TP;
+    float* sLse = reinterpret_cast<float*>(smem + 2 * TP);
     float* sDelta = sLse + BQ;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1163,6 +1152,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int b = bh / p.H, h = bh % p.H;
     const int key = kt * KBLK + kgrp * 16 + c;
     const bool kok = key < p.Sk;
+    const int troff = tr_lane_off(pad_rs<DK>(), c, g);
     const uint16_t* Qb = p.Qh + (int64_t)b * p.bsq + h * DK;
     const uint16_t* dOb = p.dOh + (int64_t)b * p.bso + h * DK;
 
@@ -1186,15 +1176,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         u32x4 rq[rows_n<DK, BQ, NT>()], rdo[rows_n<DK, BQ, NT>()];
-        u32x2 rqt[rowsT_n<DK, BQ, NT>() * 4], rdot[rowsT_n<DK, BQ, NT>() * 4];
         float rl = 0.f, rd = 0.f;
         const int ntile = (p.Sq + BQ - 1) / BQ;
 #define BMT_DKV16_FETCH(q0_)                                                            \
     do {                                                                                \
         tile_gload<DK, BQ, NT>(Qb, p.ldq, (q0_), p.Sq, tid, rq);                        \
         tile_gload<DK, BQ, NT>(dOb, p.ldo, (q0_), p.Sq, tid, rdo);                      \
-        tileT_gload<DK, BQ, NT>(Qb, p.ldq, (q0_), p.Sq, tid, rqt);                      \
-        tileT_gload<DK, BQ, NT>(dOb, p.ldo, (q0_), p.Sq, tid, rdot);                    \
         {                                                                               \
             const int qq_ = min((q0_) + (tid & (BQ - 1)), p.Sq - 1);                    \
             const int64_t stat_ = ((int64_t)b * p.H + h) * p.Sq + qq_;                  \
@@ -1204,10 +1191,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
 #define BMT_DKV16_STORE()                                                               \
     do {                                                                                \
-        tile_lstore<DK, BQ, NT>(sQ, tid, rq);                                           \
-        tile_lstore<DK, BQ, NT>(sdO, tid, rdo);                                         \
-        tileT_lstore<DK, BQ, NT>(sQt, tid, rqt);                                        \
-        tileT_lstore<DK, BQ, NT>(sdOt, tid, rdot);                                      \
+        tile_lstore_pad<DK, BQ, NT>(sQ, tid, rq);                                       \
+        tile_lstore_pad<DK, BQ, NT>(sdO, tid, rdo);                                     \
         if (tid < BQ) { sLse[tid] = rl; sDelta[tid] = rd; }                             \
     } while (0)
         BMT_DKV16_FETCH(0);
@@ -1223,9 +1208,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
-                    const int ia = kslot<DK>(qi * 16 + c, 4 * ks + g);
-                    sacc[qi] = mfma16(as_bf16x8(sQ[ia]), kf[ks], sacc[qi]);
-                    if (role == 1) dp[qi] = mfma16(as_bf16x8(sdO[ia]), vf[ks], dp[qi]);
+                    sacc[qi] = mfma16(rowfrag_pad<DK>(sQ, qi * 16 + c, 4 * ks + g), kf[ks], sacc[qi]);
+                    if (role == 1) dp[qi] = mfma16(rowfrag_pad<DK>(sdO, qi * 16 + c, 4 * ks + g), vf[ks], dp[qi]);
                 }
             float pr[8];
 #pragma unroll
@@ -1242,14 +1226,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bw[0] = pack_bf2(pr[0], pr[1]); bw[1] = pack_bf2(pr[2], pr[3]);
             bw[2] = pack_bf2(pr[4], pr[5]); bw[3] = pack_bf2(pr[6], pr[7]);
             const bf16x8 bf = as_bf16x8(bw);
-            const u32x2* timg = (role == 1) ? sQt : sdOt;
+            const char* timg = ((role == 1) ? sQ : sdO) + troff;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = dt * 16 + c;
-                const u32x2 a0 = timg[vunit<BQ>(d, g)], a1 = timg[vunit<BQ>(d, 4 + g)];
-                const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
-                acc[dt] = mfma16(as_bf16x8(aw), bf, acc[dt]);
-            }
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma16(trfrag<DK>(timg, dt), bf, acc[dt]);
             __syncthreads();
             BMT_DKV16_STORE();
             __syncthreads();
@@ -1302,7 +1281,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
         {
-            const int lds_loop = 3 * 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;
+            const int lds_loop = 32 * (DK * 2 + 32) + 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
             static bool done = false;
             if (!done) {
@@ -1312,7 +1291,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, p);
         }
         {
-            const int lds_loop = 4 * 32 * DK * 2 + 2 * 32 * 4, lds_epi = 2 * DK * (64 + 8) * 2;
+            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 2 * 32 * 4, lds_epi = 2 * DK * (64 + 8) * 2;
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
             static bool done = false;
             if (!done) {
