@@ -1128,13 +1128,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// dK / dV, 8 waves: waves 0..3 accumulate dV, waves 4..7 dK, each for 16 of the workgroup's 64 keys; loop over 32-query
-// stages.  S[q][key] = Q . K^T and dP[q][key] = dO . V^T (A = staged Q / dO rows, B = this wave's K / V rows held in
-// registers); the lane's 8 values are queries {4g..4g+3} and {16+4g..} of the stage -> B operand of
-// dV^T[16 d x 16 keys] += dO^T[16 x 32 q] . P[32 q x 16 keys] with the same permutation of the reduction index.
+// dK / dV, 8 waves x 16 keys (128 keys per workgroup), loop over 32-query stages.  Every wave computes S[q][key] = Q . K^T and
+// dP[q][key] = dO . V^T once (A = staged Q / dO rows, B = this wave's K / V rows held in registers) and accumulates BOTH
+// dV^T += dO^T . P and dK^T += Q^T . dS for its keys (an earlier version split the waves into a dV and a dK role: S was
+// computed twice and the Q / dO fragments were read by twice as many waves).  The lane's 8 probabilities are queries
+// {4g..4g+3} and {16+4g..} of the stage -> B operand of the second products with the same permutation of the reduction index
+// as in the forward kernel; the A operands come through the transpose unit from the same padded Q / dO images.
 template <int DK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv16_kernel(const AttnPB p) {
-    constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 64;
+    constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 128;
     constexpr int TP = BQ * pad_rs<DK>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;                          // padded rows: A operands of S / dP by row, of dK / dV through the transpose unit
@@ -1144,13 +1146,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int role = __builtin_amdgcn_readfirstlane(wid >> 2);      // 0: dV, 1: dK
-    const int kgrp = __builtin_amdgcn_readfirstlane(wid & 3);
     const int nkt = (p.Sk + KBLK - 1) / KBLK;
     const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
     const int kt = w % nkt, bh = w / nkt;
     const int b = bh / p.H, h = bh % p.H;
-    const int key = kt * KBLK + kgrp * 16 + c;
+    const int key = kt * KBLK + wid * 16 + c;
     const bool kok = key < p.Sk;
     const int troff = tr_lane_off(pad_rs<DK>(), c, g);
     const uint16_t* Qb = p.Qh + (int64_t)b * p.bsq + h * DK;
@@ -1159,12 +1159,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     bool kmask = kok;
     if (kok && p.mask != nullptr && p.mask_qs == 0) kmask = p.mask[(int64_t)b * p.mask_bs + key] != 0;
     const bool dead = __syncthreads_or(kmask ? 1 : 0) == 0;   // every key of the workgroup masked: gradients exactly zero
-    f32x4v acc[DT];
+    f32x4v accv[DT], acck[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) { accv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f}; acck[dt] = accv[dt]; }
     if (!dead) {
-        // this lane's K (and, for dK, V) row fragments: B operands, loop invariant
-        bf16x8 kf[KS], vf[KS];
+        bf16x8 kf[KS], vf[KS];       // this lane's K and V row fragments: B operands, loop invariant
         {
             const int krow = min(key, p.Sk - 1);
             const int64_t ko = (int64_t)b * p.bsk + (int64_t)krow * p.ldk + h * DK + 8 * g;
@@ -1172,7 +1171,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 kf[ks] = ldfrag(p.Kh + ko + 32 * ks, true);
-                vf[ks] = ldfrag(p.Vh + vo + 32 * ks, role == 1);
+                vf[ks] = ldfrag(p.Vh + vo + 32 * ks, true);
             }
         }
         u32x4 rq[rows_n<DK, BQ, NT>()], rdo[rows_n<DK, BQ, NT>()];
@@ -1209,9 +1208,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
                     sacc[qi] = mfma16(rowfrag_pad<DK>(sQ, qi * 16 + c, 4 * ks + g), kf[ks], sacc[qi]);
-                    if (role == 1) dp[qi] = mfma16(rowfrag_pad<DK>(sdO, qi * 16 + c, 4 * ks + g), vf[ks], dp[qi]);
+                    dp[qi] = mfma16(rowfrag_pad<DK>(sdO, qi * 16 + c, 4 * ks + g), vf[ks], dp[qi]);
                 }
-            float pr[8];
+            float pr[8], ds[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int ql_ = 16 * (i >> 2) + 4 * g + (i & 3);
@@ -1220,15 +1219,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (ok && p.mask != nullptr && p.mask_qs != 0)
                     ok = p.mask[(int64_t)b * p.mask_bs + (int64_t)qq * p.mask_qs + key] != 0;
                 pr[i] = ok ? __expf(sacc[i >> 2][i & 3] * p.scale - sLse[ql_]) : 0.f;
-                if (role == 1) pr[i] = pr[i] * (dp[i >> 2][i & 3] - sDelta[ql_]) * p.scale;
+                ds[i] = pr[i] * (dp[i >> 2][i & 3] - sDelta[ql_]) * p.scale;
             }
-            u32x4 bw;
-            bw[0] = pack_bf2(pr[0], pr[1]); bw[1] = pack_bf2(pr[2], pr[3]);
-            bw[2] = pack_bf2(pr[4], pr[5]); bw[3] = pack_bf2(pr[6], pr[7]);
-            const bf16x8 bf = as_bf16x8(bw);
-            const char* timg = ((role == 1) ? sQ : sdO) + troff;
+            u32x4 pw, dw;
+            pw[0] = pack_bf2(pr[0], pr[1]); pw[1] = pack_bf2(pr[2], pr[3]);
+            pw[2] = pack_bf2(pr[4], pr[5]); pw[3] = pack_bf2(pr[6], pr[7]);
+            dw[0] = pack_bf2(ds[0], ds[1]); dw[1] = pack_bf2(ds[2], ds[3]);
+            dw[2] = pack_bf2(ds[4], ds[5]); dw[3] = pack_bf2(ds[6], ds[7]);
+            const bf16x8 pf = as_bf16x8(pw), dsf = as_bf16x8(dw);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma16(trfrag<DK>(timg, dt), bf, acc[dt]);
+            for (int dt = 0; dt < DT; ++dt) {
+                accv[dt] = mfma16(trfrag<DK>(sdO + troff, dt), pf, accv[dt]);
+                acck[dt] = mfma16(trfrag<DK>(sQ + troff, dt), dsf, acck[dt]);
+            }
             __syncthreads();
             BMT_DKV16_STORE();
             __syncthreads();
@@ -1236,11 +1239,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef BMT_DKV16_FETCH
 #undef BMT_DKV16_STORE
     }
-    const GradOut& gr = (role == 1) ? p.gk : p.gv;
-    grad_store_rows16<DK>(gr, acc, b, h, key, kok, g);
+    grad_store_rows16<DK>(p.gv, accv, b, h, key, kok, g);
+    grad_store_rows16<DK>(p.gk, acck, b, h, key, kok, g);
     if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
-        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [2 roles][DK][64 + 8]
-        grad_tile_write16<DK, KBLK>(tile + role * DK * (KBLK + 8), acc, kgrp * 16, kok, c, g);
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [dV, dK][DK][128 + 8]
+        grad_tile_write16<DK, KBLK>(tile, accv, wid * 16, kok, c, g);
+        grad_tile_write16<DK, KBLK>(tile + DK * (KBLK + 8), acck, wid * 16, kok, c, g);
         __syncthreads();
         grad_tile_flush<DK, KBLK, NT>(tile, p.gv, b, h, kt * KBLK, p.Sk, tid);
         grad_tile_flush<DK, KBLK, NT>(tile + DK * (KBLK + 8), p.gk, b, h, kt * KBLK, p.Sk, tid);
@@ -1279,6 +1283,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
+    const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
         {
             const int lds_loop = 32 * (DK * 2 + 32) + 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;
@@ -1291,14 +1296,14 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, p);
         }
         {
-            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 2 * 32 * 4, lds_epi = 2 * DK * (64 + 8) * 2;
+            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 2 * 32 * 4, lds_epi = 2 * DK * (128 + 8) * 2;
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
             static bool done = false;
             if (!done) {
                 (void)hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 done = true;
             }
-            hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k), dim3(512), lds, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k16), dim3(512), lds, st, p);
         }
     } else {
         {
