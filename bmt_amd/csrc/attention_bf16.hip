@@ -505,11 +505,11 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 template <int DK, int NPASS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd16_kernel(const AttnPB p) {
     constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
-    constexpr int KB = BC * DK * 2, VB = BC * pad_rs<DK>();       // K: swizzled rows; V: padded rows read through the transpose unit
+    constexpr int KB = BC * pad_rs<DK>(), VB = BC * pad_rs<DK>();   // padded rows: K read by row, V through the transpose unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* sKh = reinterpret_cast<u32x4*>(smem);
+    char* sKh = smem;
     char* sVh = smem + KB;
-    u32x4* sKl = reinterpret_cast<u32x4*>(smem + KB + VB);
+    char* sKl = smem + KB + VB;
     char* sVl = smem + 2 * KB + VB;
     uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + (NPASS == 3 ? 2 : 1) * (KB + VB));
     int* sFlag = reinterpret_cast<int*>(sMask + 64);
@@ -553,10 +553,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
 #define BMT_F16_STORE(key0_)                                                            \
     do {                                                                                \
-        tile_lstore<DK, BC, NT>(sKh, tid, kh);                                          \
+        tile_lstore_pad<DK, BC, NT>(sKh, tid, kh);                                          \
         tile_lstore_pad<DK, BC, NT>(sVh, tid, vh);                                         \
         if constexpr (NPASS == 3) {                                                     \
-            tile_lstore<DK, BC, NT>(sKl, tid, kl);                                      \
+            tile_lstore_pad<DK, BC, NT>(sKl, tid, kl);                                      \
             tile_lstore_pad<DK, BC, NT>(sVl, tid, vl);                                     \
         }                                                                               \
         stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
@@ -578,10 +578,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
-                    const int idx = kslot<DK>(kt * 16 + c, 4 * ks + g);
-                    const bf16x8 a = as_bf16x8(sKh[idx]);
+                    const bf16x8 a = rowfrag_pad<DK>(sKh, kt * 16 + c, 4 * ks + g);
                     if constexpr (NPASS == 3) {
-                        st[kt] = mfma16(as_bf16x8(sKl[idx]), qh[ks], st[kt]);
+                        st[kt] = mfma16(rowfrag_pad<DK>(sKl, kt * 16 + c, 4 * ks + g), qh[ks], st[kt]);
                         st[kt] = mfma16(a, ql[ks], st[kt]);
                     }
                     st[kt] = mfma16(a, qh[ks], st[kt]);
@@ -1018,8 +1017,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int TB = BC * DK * 2, KP = BC * pad_rs<DK>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                                          // padded rows: S^T row fragments AND the K^T fragments of dQ
-    u32x4* sV = reinterpret_cast<u32x4*>(smem + KP);
-    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + KP + TB);
+    char* sV = smem + KP;
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 2 * KP);
     int* sFlag = reinterpret_cast<int*>(sMask + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1061,7 +1060,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define BMT_DQ16_STORE(key0_)                                                           \
     do {                                                                                \
         tile_lstore_pad<DK, BC, NT>(sK, tid, kv);                                       \
-        tile_lstore<DK, BC, NT>(sV, tid, vv);                                           \
+        tile_lstore_pad<DK, BC, NT>(sV, tid, vv);                                       \
         stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
     } while (0)
     BMT_DQ16_FETCH(0);
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     st[kt] = mfma16(rowfrag_pad<DK>(sK, kt * 16 + c, 4 * ks + g), qf[ks], st[kt]);
-                    dp[kt] = mfma16(as_bf16x8(sV[kslot<DK>(kt * 16 + c, 4 * ks + g)]), dof[ks], dp[kt]);
+                    dp[kt] = mfma16(rowfrag_pad<DK>(sV, kt * 16 + c, 4 * ks + g), dof[ks], dp[kt]);
                 }
             float ds[8];
 #pragma unroll
@@ -1257,7 +1256,7 @@ template <int DK, int NPASS>
 int launch_fwd(const AttnPB& p, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries, two waves per SIMD
-        const int lds = (NPASS == 3 ? 2 : 1) * (32 * DK * 2 + 32 * (DK * 2 + 32)) + 128;
+        const int lds = (NPASS == 3 ? 2 : 1) * (2 * 32 * (DK * 2 + 32)) + 128;
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1286,7 +1285,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
         {
-            const int lds_loop = 32 * (DK * 2 + 32) + 32 * DK * 2 + 128, lds_epi = DK * (128 + 8) * 2;
+            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 128, lds_epi = DK * (128 + 8) * 2;
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
             static bool done = false;
             if (!done) {
