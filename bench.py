@@ -358,13 +358,13 @@ def main():
                                "mfma_passes": 3 if dom.endswith("x3") else 1, "gemm_path": "planes" if ops.USE_PLANE_GEMM else "fp32-staged",
                                "timing": f"HIP events around every launch of the class (a split-K GEMM launch = main kernel + its epilogue kernel), {timer_steps} eagerly issued steps right after the timed region"}
             # the north-star quantity: bi-modal ENCODER attention against the MFMA roofline.  "issued" counts what the matrix
-            # pipe executes (forward: 3 split-bf16 passes; backward: 8 products as scheduled -- S is recomputed in both
-            # backward kernels and by both roles of the dK/dV kernel), "algorithmic" the 2 / 5 products of the math.
+            # pipe executes (forward: 3 split-bf16 passes; backward: 7 products as scheduled -- S and dP are computed by both
+            # backward kernels), "algorithmic" the 2 / 5 products of the math.
             enc = {k: v for k, v in summ.items() if k.startswith(("attn_fwd_enc", "attn_bwd_enc"))}
             if enc:
                 ms = sum(v["ms"] for v in enc.values())
                 alg = sum(v["flops"] for v in enc.values())
-                issued = sum(v["flops"] * (3.0 if k.startswith("attn_fwd") and k.endswith("x3") else (1.6 if k.startswith("attn_bwd") else 1.0))
+                issued = sum(v["flops"] * (3.0 if k.startswith("attn_fwd") and k.endswith("x3") else (1.4 if k.startswith("attn_bwd") else 1.0))
                              for k, v in enc.items())
                 out["attention_roofline"] = {
                     "scope": "encoder self- and cross-attention cores, forward + backward, B=32 H=4 d_k=256 T_v=256 T_a=800",
