@@ -14,11 +14,11 @@
 //   Tile order: XCD-aware remap, then 8-row-panel groups, so the 64 workgroups resident on one XCD cover an ~8x8 block
 //   of tiles and both operand panels are re-read from that XCD's 4 MB L2.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int STAGE_BYTES = 32768;
+constexpr int BN = 128;          // tile columns; tile rows are 64 * WM (WM = waves along M: 2 -> 128 rows, 4 -> 256 rows)
 
 struct GemmB {
     const uint16_t *Ah, *Al, *Bh, *Bl;   // planes [M][lda], [N][ldb]; reduction index contiguous, zero padded to Kpad
@@ -31,6 +31,7 @@ struct GemmB {
     int plane_vec;                       // plane outputs 16-B aligned with ldp, plane_cols multiples of 8: staged through LDS
     int M, N, Kpad;
     int tiles_m, tiles_n, kchunk;
+    int bm;                              // tile rows (128 or 256)
     float alpha;
     unsigned flags;
     const float* bias;
@@ -53,30 +54,37 @@ __device__ __forceinline__ int slot_of(int row, int s) {
     else return row * 4 + (s ^ ((row >> 2) & 3));
 }
 
-// one operand plane, one stage: [128 rows][SPR slots]; thread t moves slots t, t+256, ...
-template <int SPR>
-__device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, int r0, int nrows, int k0, int tid, u32x4 (&v)[128 * SPR / 256]) {
+// one operand plane, one stage: [ROWS rows][SPR slots]; thread t moves slots t, t+NT, ...
+template <int SPR, int ROWS, int NT>
+__device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, int r0, int nrows, int k0, int tid, u32x4 (&v)[ROWS * SPR / NT]) {
 #pragma unroll
-    for (int i = 0; i < 128 * SPR / 256; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < ROWS * SPR / NT; ++i) {
+        const int c = tid + NT * i;
         const int row = min(r0 + c / SPR, nrows - 1);
         v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + k0 + (c % SPR) * 8);
     }
 }
-template <int SPR>
-__device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&v)[128 * SPR / 256]) {
+template <int SPR, int ROWS, int NT>
+__device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&v)[ROWS * SPR / NT]) {
 #pragma unroll
-    for (int i = 0; i < 128 * SPR / 256; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < ROWS * SPR / NT; ++i) {
+        const int c = tid + NT * i;
         img[slot_of<SPR>(c / SPR, c % SPR)] = v[i];
     }
 }
 
-template <int NPASS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(const GemmB p) {
+// WM = 2: 128x128 tile, 4 waves, two workgroups per CU.  WM = 4: 256x128 tile, 8 waves, one workgroup per CU -- the same two
+// waves per SIMD, but 3/4 of the operand bytes per FLOP: the 128x128 kernel moves ~7.5 TB/s of operand tiles L2 -> LDS at
+// 29 % MFMA utilisation (profiles/r01_d_gemm_l2_pmc.txt), i.e. it is bound by the L2 -> CU fabric, not by L1, LDS or MFMA.
+// TI = 32-row MFMA tiles per wave along M (wave tile 32 TI x 64): TI = 2 is the layout above; TI = 1 doubles the waves of a
+// tile (more waves per SIMD to hide the LDS / barrier latency of the stage loop, 1.5x the fragment reads).
+template <int NPASS, int WM, int TI>
+__global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
     constexpr int BK = (NPASS == 3) ? 32 : 64;
     constexpr int SPR = BK / 8;
-    constexpr int PB = 128 * BK * 2;        // bytes of one plane tile (x1: 16 KB, x3: 8 KB)
+    constexpr int BM = 32 * TI * WM, NT = 128 * WM;       // WM waves along M x 2 along N
+    constexpr int PA = BM * BK * 2, PBB = BN * BK * 2;      // bytes of one A / B plane tile
+    constexpr int STAGE_BYTES = (NPASS == 3 ? 2 : 1) * (PA + PBB);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -97,9 +105,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kbeg = blockIdx.y * p.kchunk;
     const int kend = min(p.Kpad, kbeg + p.kchunk);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -108,27 +116,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // Two register sets: the global loads of stage t+2 are issued before the MFMAs of stage t, so every load has two
     // iterations (two barriers) to land -- with 2 workgroups per CU and ~0.2 us of MFMA work per stage a single stage of
     // prefetch leaves the loop waiting on HBM/L2 latency (profiles/r01_c: 16 iterations of a 24-tile GEMM took 50 us).
-    constexpr int NR = 128 * SPR / 256;
-    u32x4 ra0[NR], rb0[NR], ral0[NR], rbl0[NR];
-    u32x4 ra1[NR], rb1[NR], ral1[NR], rbl1[NR];
-#define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + (which_) * PB)
+    constexpr int NRA = BM * SPR / NT, NRB = BN * SPR / NT;
+    u32x4 ra0[NRA], rb0[NRB], ral0[NRA], rbl0[NRB];
+    u32x4 ra1[NRA], rb1[NRB], ral1[NRA], rbl1[NRB];
+    // stage image: A hi | B hi | A lo | B lo
+#define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + ((which_) == 0 ? 0 : (which_) == 1 ? PA : (which_) == 2 ? PA + PBB : 2 * PA + PBB))
 #define BMT_GLOAD(s_, RA, RB, RAL, RBL)                                                   \
     do {                                                                                  \
         const int k_ = min(kbeg + (s_) * BK, kend - BK);   /* branch-free tail: re-fetch the last stage */ \
-        plane_gload<SPR>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                              \
-        plane_gload<SPR>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                              \
+        plane_gload<SPR, BM, NT>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                      \
+        plane_gload<SPR, BN, NT>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                      \
         if constexpr (NPASS == 3) {                                                       \
-            plane_gload<SPR>(p.Al, p.lda, m0, p.M, k_, tid, RAL);                         \
-            plane_gload<SPR>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);                         \
+            plane_gload<SPR, BM, NT>(p.Al, p.lda, m0, p.M, k_, tid, RAL);                 \
+            plane_gload<SPR, BN, NT>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);                 \
         }                                                                                 \
     } while (0)
 #define BMT_LSTORE(buf_, RA, RB, RAL, RBL)                                                \
     do {                                                                                  \
-        plane_lstore<SPR>(stage_ptr(buf_, 0), tid, RA);                                   \
-        plane_lstore<SPR>(stage_ptr(buf_, 1), tid, RB);                                   \
+        plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 0), tid, RA);                           \
+        plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 1), tid, RB);                           \
         if constexpr (NPASS == 3) {                                                       \
-            plane_lstore<SPR>(stage_ptr(buf_, 2), tid, RAL);                              \
-            plane_lstore<SPR>(stage_ptr(buf_, 3), tid, RBL);                              \
+            plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 2), tid, RAL);                      \
+            plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 3), tid, RBL);                      \
         }                                                                                 \
     } while (0)
 #define BMT_COMPUTE(buf_)                                                                 \
@@ -139,17 +148,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const u32x4* sBl = stage_ptr(buf_, 3);                                            \
         _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                             \
             const int sl = 2 * s + half;                                                  \
-            bf16x8 ah[2], bh[2], al[2], bl[2];                                            \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                               \
-                const int ia = slot_of<SPR>(wr * 64 + i * 32 + l31, sl), ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl); \
+            bf16x8 ah[TI], bh[2], al[TI], bl[2];                                          \
+            _Pragma("unroll") for (int i = 0; i < TI; ++i) {                              \
+                const int ia = slot_of<SPR>(wr * 32 * TI + i * 32 + l31, sl);             \
                 ah[i] = as_bf16x8(sAh[ia]);                                               \
-                bh[i] = as_bf16x8(sBh[ib]);                                               \
-                if constexpr (NPASS == 3) {                                               \
-                    al[i] = as_bf16x8(sAl[ia]);                                           \
-                    bl[i] = as_bf16x8(sBl[ib]);                                           \
-                }                                                                         \
+                if constexpr (NPASS == 3) al[i] = as_bf16x8(sAl[ia]);                     \
             }                                                                             \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                               \
+                const int ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl);                  \
+                bh[i] = as_bf16x8(sBh[ib]);                                               \
+                if constexpr (NPASS == 3) bl[i] = as_bf16x8(sBl[ib]);                     \
+            }                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TI; ++i)                                \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) {                           \
                     if constexpr (NPASS == 3) {                                           \
                         acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);                      \
@@ -191,12 +201,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int64_t ldw = (int64_t)p.tiles_n * BN;
         float* part = p.ws + (int64_t)blockIdx.y * p.tiles_m * BM * ldw;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    part[(int64_t)(m0 + wr * 64 + i * 32 + acc_row(r, half)) * ldw + n0 + wc * 64 + j * 32 + l31] = acc[i][j][r];
+                    part[(int64_t)(m0 + wr * 32 * TI + i * 32 + acc_row(r, half)) * ldw + n0 + wc * 64 + j * 32 + l31] = acc[i][j][r];
         return;
     }
     // ---------------- epilogue (same order as bmt_gemm: alpha, bias, dropout_pre, relu, dropout_post, gate, residual)
@@ -205,9 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // written out as full 16-byte row segments.
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
     const unsigned f = p.flags;
-    uint32_t* ct = reinterpret_cast<uint32_t*>(smem);   // [128][128] packed planes of this tile
+    uint32_t* ct = reinterpret_cast<uint32_t*>(smem);   // [BM][128] packed planes of this tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wc * 64 + j * 32 + l31;
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float bv = (cin && (f & BMT_EPI_BIAS)) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = wr * 64 + i * 32 + acc_row(r, half);
+                const int rl = wr * 32 * TI + i * 32 + acc_row(r, half);
                 const int row = m0 + rl;
                 if (row >= p.M) continue;
                 float v = 0.f;
@@ -249,8 +259,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cg = (tid & 15) * 8;
         const int col = n0 + cg;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int rl = ps * 16 + (tid >> 4);
+        for (int ps = 0; ps < BM * 16 / NT; ++ps) {
+            const int rl = ps * (NT / 16) + (tid >> 4);
             const int row = m0 + rl;
             if (row < p.M && col < p.plane_cols) {
                 const u32x4 a = *reinterpret_cast<const u32x4*>(ct + rl * 128 + cg);
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
     if (idx >= (int64_t)p.M * ncg) return;
     const int row = (int)(idx / ncg), c0 = (int)(idx % ncg) * 4;
     const int64_t ldw = (int64_t)p.tiles_n * BN;
-    const int64_t slab = (int64_t)p.tiles_m * BM * ldw;
+    const int64_t slab = (int64_t)p.tiles_m * p.bm * ldw;
     const float* src = p.ws + (int64_t)row * ldw + c0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int sidx = 0; sidx < p.nsplit; ++sidx) {
@@ -387,14 +397,18 @@ __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __re
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int NPASS>
+template <int NPASS, int WM, int TI>
 int launch(const GemmB& p, int splitk, hipStream_t st) {
+    constexpr int BK = (NPASS == 3) ? 32 : 64;
+    constexpr int BMr = 32 * TI * WM;
+    constexpr int stage = (NPASS == 3 ? 2 : 1) * (BMr + BN) * BK * 2;
+    constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;   // two stage buffers / the packed plane tile of the epilogue
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(256), 2 * STAGE_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16");
     return BMT_OK;
 }
@@ -429,8 +443,14 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
     p.plane_vec = a->C_hi && al16(a->C_hi) && (!a->C_lo || al16(a->C_lo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad;
-    p.tiles_m = bmt_cdiv(a->M, BM);
     p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
+    // tile height: 256 rows (8 waves, one workgroup per CU) when that still fills the chip, else 128 rows (4 waves, two per CU)
+    static const int force_bm = getenv("BMT_GEMM_BM") ? atoi(getenv("BMT_GEMM_BM")) : 0;      // A/B experiments only
+    // measured (tools/microbench.py gemm with BMT_GEMM_BM / BMT_GEMM_8W): the 256-row tile gains 5 % for the 3-pass kernel on
+    // K >= 512 shapes and loses 2-8 % elsewhere; the 8-wave 128-row tile (below) beats both, so 256 rows is opt-in only
+    p.bm = 128;
+    if (force_bm == 128 || force_bm == 256) p.bm = force_bm;
+    p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
@@ -443,7 +463,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     }
     if (splitk > ktiles) splitk = ktiles;
     if (splitk > 1 && two_pass) {              // bounded by the workspace
-        const int64_t slab = (int64_t)tiles * BM * BN * (int64_t)sizeof(float);
+        const int64_t slab = (int64_t)tiles * p.bm * BN * (int64_t)sizeof(float);
         const int64_t fit = a->splitk_ws_bytes / slab;
         if (fit < splitk) splitk = (int)(fit < 1 ? 1 : fit);
     }
@@ -454,7 +474,15 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
     p.gate = a->gate; p.ldg = a->ldg; p.gate_scale = a->gate_scale;
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
-    const int rc = a->precision == BMT_PREC_BF16X3 ? launch<3>(p, splitk, (hipStream_t)stream) : launch<1>(p, splitk, (hipStream_t)stream);
+    int rc;
+    // 128-row tile: 8 waves of 32x64 (4 waves per SIMD across two workgroups) hide the stage loop's LDS / barrier latency
+    // better than 4 waves of 64x64 -- 25600x1024x128 forward 81 -> 57 us, 8192x1024x1024 x1 38 -> 33 us, whole step -6 % --
+    // except for the single-pass kernel on very large grids (FFN dX / dW, 2048 tiles: 93 -> 96..100 us)
+    static const int force8 = getenv("BMT_GEMM_8W") ? atoi(getenv("BMT_GEMM_8W")) : -1;          // A/B experiments only
+    const int waves8 = force8 >= 0 ? force8 : !(a->precision == BMT_PREC_BF16 && p.tiles_m * p.tiles_n >= 1024);
+    if (p.bm == 256) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 2>(p, splitk, (hipStream_t)stream) : launch<1, 4, 2>(p, splitk, (hipStream_t)stream);
+    else if (waves8) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1>(p, splitk, (hipStream_t)stream) : launch<1, 4, 1>(p, splitk, (hipStream_t)stream);
+    else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 2, 2>(p, splitk, (hipStream_t)stream) : launch<1, 2, 2>(p, splitk, (hipStream_t)stream);
     if (rc != BMT_OK || p.ws == nullptr) return rc;
     const int pc = p.Chi ? (p.plane_cols > p.N ? p.plane_cols : p.N) : p.N;
     const int64_t groups = (int64_t)p.M * ((pc + 3) / 4);
