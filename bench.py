@@ -140,12 +140,12 @@ class KernelTimer:
                 (s, e, 4.0 * B_ * Sq * Sk * D, nb * B_ * D * (2 * Sq + 2 * Sk)))
             return r
 
-        def attn_bwd_planes(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases):
+        def attn_bwd_planes(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw):
             if not timer.enabled:
-                return raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases)
+                return raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases)
+            r = raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw)
             e.record()
             side = "enc" if min(Sq, Sk) >= 128 else "dec"
             # algorithmic backward = 5 products (S recompute, dP, dV, dK, dQ) = 2.5 x forward; bytes: q,k,v hi planes, O hi+lo,

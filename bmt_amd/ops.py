@@ -161,6 +161,7 @@ class _WeightPlanes:
         self.table = None          # device descriptor table
         self.fresh_epoch = -1
         self.dirty_table = True
+        self.groups = {}           # (id(owner), ...) -> [weakrefs, Planes straight [sum N][Kpad], Planes transposed [K][sum N], bias, bias refs, epoch]
 
     @staticmethod
     def _key(W):
@@ -178,6 +179,59 @@ class _WeightPlanes:
         self.index[(id(owner), self._key(W))] = len(self.entries) - 1
         self.dirty_table = True
         return self.entries[-1]
+
+    def _put(self, W, st, tr):
+        import weakref
+        owner = W._base if W._base is not None else W
+        entry = [weakref.ref(owner), self._key(W), st, tr, None, W.detach()]
+        pos = self.index.get((id(owner), self._key(W)))
+        if pos is not None and pos < len(self.entries) and self.entries[pos][0]() is owner:
+            self.entries[pos] = entry          # re-registered (now as a member of a group): same slot, new buffers
+        else:
+            self.entries.append(entry)
+            self.index[(id(owner), self._key(W))] = len(self.entries) - 1
+        self.dirty_table = True
+        return entry
+
+    def get_group(self, Ws, bs):
+        """weights that multiply the SAME input (Q/K/V of a self-attention, K/V of a cross-attention) as ONE operand: their
+        planes live in adjacent row blocks of one buffer ([sum N][Kpad] straight, [K][sum N] transposed), refreshed by the same
+        multi-tensor launch, so the three projections are one GEMM forward, one dX GEMM and (with adjacent gradients) one dW
+        GEMM.  Returns (straight Planes, transposed Planes, concatenated bias) or None if the shapes do not allow it."""
+        import weakref
+        K = Ws[0].shape[1]
+        if any(W.shape[1] != K or W.shape[0] % 64 != 0 or W.dim() != 2 or not W.is_contiguous() for W in Ws):
+            return None
+        key = tuple(id(W) for W in Ws)
+        g = self.groups.get(key)
+        if g is None or any(r() is not W for r, W in zip(g[0], Ws)):
+            Nt = sum(W.shape[0] for W in Ws)
+            dev = Ws[0].device
+            big_hi = torch.empty(Nt, _pad64(K), device=dev, dtype=torch.bfloat16)
+            big_lo = torch.empty(Nt, _pad64(K), device=dev, dtype=torch.bfloat16)
+            bigT = torch.empty(K, Nt, device=dev, dtype=torch.bfloat16)
+            off = 0
+            for W in Ws:
+                N = W.shape[0]
+                self._put(W, Planes(big_hi[off:off + N], big_lo[off:off + N], N, K), Planes(bigT[:, off:off + N], None, K, N))
+                off += N
+            bias = torch.empty(Nt, device=dev, dtype=torch.float32) if all(b is not None for b in bs) else None
+            g = [[weakref.ref(W) for W in Ws], Planes(big_hi, big_lo, Nt, K), Planes(bigT, None, K, Nt), bias, -1]
+            self.groups[key] = g
+            if len(self.groups) > 4096:     # models come and go in tests
+                self.groups = {k: v for k, v in self.groups.items() if all(r() is not None for r in v[0])}
+        stale = self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table
+        if not stale:
+            for W in Ws:
+                owner = W._base if W._base is not None else W
+                e = self.entries[self.index[(id(owner), self._key(W))]]
+                stale = stale or e[4] != W._version
+        if stale:
+            self._refresh_all()
+        if g[3] is not None and g[4] != WEIGHT_EPOCH[0] and all(b is not None for b in bs):
+            torch.cat([b.detach() for b in bs], out=g[3])
+            g[4] = WEIGHT_EPOCH[0]
+        return g[1], g[2], g[3]
 
     def _prune(self):
         alive = [e for e in self.entries if e[0]() is not None]
@@ -221,6 +275,34 @@ _weights = _WeightPlanes()
 
 def weight_planes(W: torch.Tensor, transposed: bool = False) -> Planes:
     return _weights.get(W, transposed)
+
+
+import os as _os
+FUSE_PROJECTIONS = _os.environ.get("BMT_NO_FUSE") != "1"      # Q/K/V (self-attention) and K/V (cross-attention) projections as one GEMM each way
+
+
+def weight_group(Ws, bs):
+    return _weights.get_group(tuple(Ws), tuple(bs)) if (FUSE_PROJECTIONS and USE_PLANE_GEMM) else None
+
+
+def group_static_grad(Ws):
+    """one [sum N, K] view over the static gradient buffers of Ws if GradientReducer laid them out back to back, else None"""
+    gs = [static_grad(W) for W in Ws]
+    if any(g is None for g in gs):
+        return None
+    for a, b in zip(gs[:-1], gs[1:]):
+        if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr() or b.storage_offset() != a.storage_offset() + a.numel():
+            return None
+    return gs[0].as_strided((sum(W.shape[0] for W in Ws), Ws[0].shape[1]), (Ws[0].shape[1], 1), gs[0].storage_offset())
+
+
+def fused_weight_groups(model):
+    """parameter groups whose gradients should sit back to back (bmt_amd.parallel.GradientReducer(groups=...))"""
+    out = []
+    for m in model.modules():
+        if all(hasattr(m, n) for n in ("linear_Q2d", "linear_K2d", "linear_V2d")):
+            out.append([m.linear_Q2d.weight, m.linear_K2d.weight, m.linear_V2d.weight])
+    return out
 
 
 def as_planes(x, need_lo: bool) -> Planes:
@@ -601,18 +683,32 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D), lse
 
 
-def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor, lse, B, Sq, Sk, D, mask, H, drop_p, biases):
+def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
+                    fuse: Optional[str] = None):
     """attention backward with the gradients written as GEMM operands: for each of dq, dk, dv the bf16 plane (dX operand of
     the projection), its transpose (dW operand) and the bias gradient (column sums).  biases = (bq, bk, bv): a bias with a
     static gradient buffer is accumulated in place (returned db is None), otherwise into a fresh fp32 [D].
-    Returns [(P, T, db)] * 3."""
+    fuse = "qkv" (Sq == Sk) / "kv": the gradients share one plane [M][3D | 2D] and one transposed plane [3D | 2D][M] (column /
+    row blocks), the operands of the fused projection backward; the combined planes are returned as a 4th element.
+    Returns [(P, T, db)] * 3 (+ [(P_all, T_all)])."""
     dk = D // H
     dev = q.hi.device
     Mq, Mk = B * Sq, B * Sk
     outs = []
-    for M, b in ((Mq, biases[0]), (Mk, biases[1]), (Mk, biases[2])):
-        hi = _plane_buf(M, D, dev)
-        hiT = _plane_buf(D, M, dev)
+    comb = None
+    if fuse in ("qkv", "kv") and D % 64 == 0 and (fuse == "kv" or Mq == Mk):
+        n = 3 if fuse == "qkv" else 2
+        big = _plane_buf(Mk, n * D, dev)
+        bigT = _plane_buf(n * D, Mk, dev)
+        comb = (Planes(big, None, Mk, n * D), Planes(bigT, None, n * D, Mk))
+    for idx, (M, b) in enumerate(((Mq, biases[0]), (Mk, biases[1]), (Mk, biases[2]))):
+        slot = None if comb is None else (idx if fuse == "qkv" else idx - 1)
+        if slot is not None and slot >= 0:
+            hi = comb[0].hi[:, slot * D:(slot + 1) * D]
+            hiT = comb[1].hi[slot * D:(slot + 1) * D]
+        else:
+            hi = _plane_buf(M, D, dev)
+            hiT = _plane_buf(D, M, dev)
         gb = static_grad(b)
         db = None
         if b is not None and gb is None:
@@ -638,6 +734,8 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor
         if b is not None and db is None:
             grad_done(b)
         res.append((Planes(hi, None, M, D), Planes(hiT, None, D, M), db))
+    if comb is not None:
+        res.append(comb)
     return res
 
 
@@ -841,13 +939,43 @@ class MHAFn(torch.autograd.Function):
         Qp, QT = split(Qc)
         Kp, KT = (Qp, QT) if same_qk else split(Kc)
         Vp, VT = (Kp, KT) if same_kv else split(Vc)
-        q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
-        k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
-        v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
+        # projections that read the same input run as ONE GEMM over adjacent weight planes (q|k|v or k|v column blocks of one
+        # plane buffer, which the attention kernels address with the buffer's row stride)
+        def fused_proj(Xp, Ws, bs):
+            grp = weight_group(Ws, bs)
+            if grp is None:
+                return None
+            gst, _, gb = grp
+            Nt = gst.rows
+            hi = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16)
+            lo = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16) if x3 else None
+            gemm_bf16(Xp, gst, None, bias=gb, out_planes=Planes(hi, lo, Xp.rows, Nt))
+            outs, off = [], 0
+            for W in Ws:
+                N = W.shape[0]
+                outs.append(Planes(hi[:, off:off + N], None if lo is None else lo[:, off:off + N], Xp.rows, N))
+                off += N
+            return outs
+        fuse = None
+        q = k = v = None
+        if same_qk and same_kv:
+            r = fused_proj(Qp, (Wq, Wk, Wv), (bq, bk, bv))
+            if r is not None:
+                (q, k, v), fuse = r, "qkv"
+        elif same_kv:
+            r = fused_proj(Kp, (Wk, Wv), (bk, bv))
+            if r is not None:
+                (k, v), fuse = r, "kv"
+        if q is None:
+            q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
+        if k is None:
+            k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
+            v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
         o, lse = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, drop_p=p, site=site)
         out = linear_fwd(o, Wo, bo).view(B, Sq, Dq)
         ctx.H, ctx.p, ctx.site = H, p, site
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
+        ctx.fuse = fuse
         ctx.mask = mask
         ctx.dims = (B, Sq, Sk, D, Dq, Kc.shape[-1], Vc.shape[-1])
         ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
@@ -868,31 +996,70 @@ class MHAFn(torch.autograd.Function):
         dy2 = _f32c(dout).view(-1, Dq)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
         do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(transpose_plane(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
-        (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p,
-                                                                      (bqp, bkp, bvp))
+        res = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p, (bqp, bkp, bvp), fuse=ctx.fuse)
+        (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = res[:3]
+        comb = res[3] if len(res) > 3 else None
         needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dQ = dK = dV = None
-        dxq, dWq = lin_bwd_planes(Pq, Tq, Wqp, QT, need_dx=needQ)
-        if ctx.same_qk and ctx.same_kv:     # one input, three contributions summed in the dX GEMM epilogue
-            ldr = dxq.stride(0) if needQ else 0
-            _, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
-            _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+        dQ = dK = dV = dWq = dWk = dWv = None
+
+        def fused_bwd(Ws, xT, need_dx):
+            """dX = [dq|dk|dv] . [Wq;Wk;Wv] as one GEMM; dW as one GEMM when the gradients are adjacent, else one per weight"""
+            P_all, T_all = comb
+            _, gtr, _ = weight_group(Ws, tuple(None for _ in Ws))
+            dx = None
+            if need_dx:
+                dx = torch.empty(P_all.rows, gtr.rows, device=dy2.device, dtype=torch.float32)
+                gemm_bf16(P_all, gtr, dx, ldc=dx.stride(0), precision=BWD_PRECISION)
+            gW = group_static_grad(Ws)
+            if gW is not None:
+                linear_dw(T_all, xT, into=gW)
+                for W in Ws:
+                    grad_done(W)
+                return dx, [None] * len(Ws)
+            dWs, off = [], 0
+            for W in Ws:
+                N = W.shape[0]
+                g1 = static_grad(W)
+                dWs.append(linear_dw(Planes(T_all.hi[off:off + N], None, N, T_all.cols), xT, into=g1))
+                if g1 is not None:
+                    grad_done(W)
+                off += N
+            return dx, dWs
+
+        if comb is not None and ctx.fuse == "qkv":
+            dxq, (dWq, dWk, dWv) = fused_bwd((Wqp, Wkp, Wvp), QT, needQ)
             if needQ:
                 dQ = dxq.view(B, Sq, Dq)
+        elif comb is not None and ctx.fuse == "kv":
+            dxq, dWq = lin_bwd_planes(Pq, Tq, Wqp, QT, need_dx=needQ)
+            if needQ:
+                dQ = dxq.view(B, Sq, Dq)
+            need = needK or needV
+            dxk, (dWk, dWv) = fused_bwd((Wkp, Wvp), KT, need)
+            if need:
+                dK = dxk.view(B, Sk, Dk_in)      # autograd adds dK and dV for the shared tensor; dV stays None
         else:
-            if needQ:
-                dQ = dxq.view(B, Sq, Dq)
-            if ctx.same_kv:
-                need = needK or needV
-                dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=need)
-                _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
-                if need:
-                    dK = dxk.view(B, Sk, Dk_in)  # autograd adds dK and dV for the shared tensor; dV stays None
+            dxq, dWq = lin_bwd_planes(Pq, Tq, Wqp, QT, need_dx=needQ)
+            if ctx.same_qk and ctx.same_kv:     # one input, three contributions summed in the dX GEMM epilogue
+                ldr = dxq.stride(0) if needQ else 0
+                _, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+                _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+                if needQ:
+                    dQ = dxq.view(B, Sq, Dq)
             else:
-                dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needK)
-                dxv, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needV)
-                dK = dxk.view(B, Sk, Dk_in) if needK else None
-                dV = dxv.view(B, Sk, Dv_in) if needV else None
+                if needQ:
+                    dQ = dxq.view(B, Sq, Dq)
+                if ctx.same_kv:
+                    need = needK or needV
+                    dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=need)
+                    _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
+                    if need:
+                        dK = dxk.view(B, Sk, Dk_in)  # autograd adds dK and dV for the shared tensor; dV stays None
+                else:
+                    dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needK)
+                    dxv, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needV)
+                    dK = dxk.view(B, Sk, Dk_in) if needK else None
+                    dV = dxv.view(B, Sk, Dv_in) if needV else None
         return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
 
 
@@ -918,9 +1085,38 @@ class MHAFnStaged(torch.autograd.Function):
             Qp, Kp, Vp = Q2, K2, V2
         # the projections write bf16 operand planes (hi, lo) straight from the GEMM epilogue; the attention kernels
         # consume them as MFMA operands without any conversion.  Only the hi planes are kept for backward.
-        q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
-        k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
-        v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
+        # projections that read the same input run as ONE GEMM over adjacent weight planes (q|k|v or k|v column blocks of one
+        # plane buffer, which the attention kernels address with the buffer's row stride)
+        def fused_proj(Xp, Ws, bs):
+            grp = weight_group(Ws, bs)
+            if grp is None:
+                return None
+            gst, _, gb = grp
+            Nt = gst.rows
+            hi = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16)
+            lo = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16) if x3 else None
+            gemm_bf16(Xp, gst, None, bias=gb, out_planes=Planes(hi, lo, Xp.rows, Nt))
+            outs, off = [], 0
+            for W in Ws:
+                N = W.shape[0]
+                outs.append(Planes(hi[:, off:off + N], None if lo is None else lo[:, off:off + N], Xp.rows, N))
+                off += N
+            return outs
+        fuse = None
+        q = k = v = None
+        if same_qk and same_kv:
+            r = fused_proj(Qp, (Wq, Wk, Wv), (bq, bk, bv))
+            if r is not None:
+                (q, k, v), fuse = r, "qkv"
+        elif same_kv:
+            r = fused_proj(Kp, (Wk, Wv), (bk, bv))
+            if r is not None:
+                (k, v), fuse = r, "kv"
+        if q is None:
+            q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
+        if k is None:
+            k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
+            v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
         v3 = lambda t, S: None if t is None else t.view(B, S, D)
         o, lse = attn_fwd_bf16(v3(q.hi, Sq), v3(q.lo, Sq), v3(k.hi, Sk), v3(k.lo, Sk), v3(v.hi, Sk), v3(v.lo, Sk), mask, H,
                                drop_p=p, site=site)

@@ -26,21 +26,36 @@ class GradientReducer:
     accumulates straight into communication buffers and the optimizer reads the reduced values in place."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 process_group: Optional[dist.ProcessGroup] = None, overlap: bool = True):
+                 process_group: Optional[dist.ProcessGroup] = None, overlap: bool = True, groups=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
         params = [p for p in params if p.requires_grad]
         # reverse registration order ~ the order autograd finishes gradients (generator -> decoder -> encoder)
         order = list(reversed(params))
+        # ``groups``: lists of parameters whose gradients must sit back to back, in the given order, inside one bucket (the
+        # fused Q/K/V weight gradient is ONE GEMM writing one [3D, d_in] block: ops.group_static_grad)
+        member = {}
+        for g in (groups or []):
+            g = [p for p in g if p.requires_grad]
+            if len(g) > 1:
+                for p in g:
+                    member[id(p)] = g
+        units, placed = [], set()
+        for p in order:
+            if id(p) in placed:
+                continue
+            u = member.get(id(p), [p])
+            units.append(u)
+            placed.update(id(x) for x in u)
         self.buckets: List[dict] = []
         cur, cur_bytes = [], 0
-        for p in order:
-            nbytes = p.numel() * 4
+        for u in units:
+            nbytes = sum(p.numel() for p in u) * 4
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self._make_bucket(cur)
                 cur, cur_bytes = [], 0
-            cur.append(p)
+            cur.extend(u)
             cur_bytes += nbytes
         if cur:
             self._make_bucket(cur)

@@ -67,7 +67,8 @@ class CaptioningTrainStep:
                                                 weight_decay=cfg.weight_decay)
         self.criterion = LabelSmoothing(cfg.smoothing, pad_idx)
         self.data_parallel = data_parallel
-        self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes, overlap=overlap) \
+        from . import ops as _ops
+        self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, groups=_ops.fused_weight_groups(model)) \
             if (data_parallel or static_grads) else None
         self.modality = getattr(cfg, 'modality', 'audio_video')
         self.grad_scale = torch.ones(1, device=params[0].device, dtype=torch.float32)
