@@ -37,7 +37,7 @@ class GemmBf16Args(C.Structure):
                 ("M", i32), ("N", i32), ("Kpad", i32), ("alpha", f32), ("flags", C.c_uint),
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
-                ("splitk_ws", vp), ("splitk_ws_bytes", i64)]
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32)]
 
 
 class AttnFwdArgs(C.Structure):

@@ -32,6 +32,7 @@ struct GemmB {
     int M, N, Kpad;
     int tiles_m, tiles_n, kchunk;
     int bm;                              // tile rows (128 or 256)
+    int krows;                           // k-major operands: valid rows (the true reduction length); rows [krows, Kpad) read as 0
     float alpha;
     unsigned flags;
     const float* bias;
@@ -73,17 +74,62 @@ __device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&
     }
 }
 
+// ---- k-major operands (single-pass kernel only).  The operand is stored with the REDUCTION index as its row: for the weight
+// gradient dW = dY^T . X both dY [rows, N] and X [rows, K] are used as they are, for dX = dY . W the weight plane [N, K] is.  A
+// stage tile is [BK reduction rows][COLS columns], staged row-major with a padded row stride (COLS*2 + 64 bytes), and the MFMA
+// fragment (8 reduction indices of one column per lane) is read with ds_read_b64_tr_b16 (semantics: attention_bf16.hip /
+// tools/probes/tr_probe.hip).  This removes every transposed plane from the model: weights, activations and gradients are
+// converted once, in one orientation.
+template <int COLS> constexpr int km_rs() { return COLS * 2 + 64; }
+template <int COLS, int BK, int NT>
+__device__ __forceinline__ void plane_gload_km(const uint16_t* base, int64_t ld, int c0, int k0, int krows, int tid,
+                                               u32x4 (&v)[COLS * BK / 8 / NT]) {
+    constexpr int SPC = COLS / 8;
+#pragma unroll
+    for (int i = 0; i < COLS * BK / 8 / NT; ++i) {
+        const int c = tid + NT * i;
+        const int kr = k0 + c / SPC;
+        const int col = min(c0 + (c % SPC) * 8, (int)ld - 8);          // columns past the operand's extent: duplicates, discarded
+        const u32x4 x = *reinterpret_cast<const u32x4*>(base + (int64_t)min(kr, krows - 1) * ld + col);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        v[i] = (kr < krows) ? x : z;                                   // select, not a guarded load
+    }
+}
+template <int COLS, int BK, int NT>
+__device__ __forceinline__ void plane_lstore_km(char* img, int tid, const u32x4 (&v)[COLS * BK / 8 / NT]) {
+    constexpr int SPC = COLS / 8;
+#pragma unroll
+    for (int i = 0; i < COLS * BK / 8 / NT; ++i) {
+        const int c = tid + NT * i;
+        *reinterpret_cast<u32x4*>(img + (c / SPC) * km_rs<COLS>() + (c % SPC) * 16) = v[i];
+    }
+}
+// fragment for MFMA rows/cols [colbase, colbase + 32) and reduction indices [k16, k16 + 16): lane l -> column colbase + (l & 31),
+// k = k16 + 8 (l >> 5) + j
+template <int COLS>
+__device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase, int lane) {
+    typedef short v4s16 __attribute__((ext_vector_type(4)));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    typedef v4s16 __attribute__((address_space(3))) * lds_v4s;
+    const int m = lane & 15;
+    const char* a = img + (k16 + 8 * (lane >> 5) + (m >> 2)) * km_rs<COLS>() + (colbase + 16 * ((lane >> 4) & 1) + 4 * (m & 3)) * 2;
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)a);
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a + 4 * km_rs<COLS>()));
+    return __builtin_bit_cast(bf16x8, (v8s16)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // WM = 2: 128x128 tile, 4 waves, two workgroups per CU.  WM = 4: 256x128 tile, 8 waves, one workgroup per CU -- the same two
 // waves per SIMD, but 3/4 of the operand bytes per FLOP: the 128x128 kernel moves ~7.5 TB/s of operand tiles L2 -> LDS at
 // 29 % MFMA utilisation (profiles/r01_d_gemm_l2_pmc.txt), i.e. it is bound by the L2 -> CU fabric, not by L1, LDS or MFMA.
 // TI = 32-row MFMA tiles per wave along M (wave tile 32 TI x 64): TI = 2 is the layout above; TI = 1 doubles the waves of a
 // tile (more waves per SIMD to hide the LDS / barrier latency of the stage loop, 1.5x the fragment reads).
-template <int NPASS, int WM, int TI>
+template <int NPASS, int WM, int TI, bool AKM, bool BKM>
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
+    static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
     constexpr int BK = (NPASS == 3) ? 32 : 64;
     constexpr int SPR = BK / 8;
     constexpr int BM = 32 * TI * WM, NT = 128 * WM;       // WM waves along M x 2 along N
-    constexpr int PA = BM * BK * 2, PBB = BN * BK * 2;      // bytes of one A / B plane tile
+    constexpr int PA = AKM ? BK * km_rs<BM>() : BM * BK * 2, PBB = BKM ? BK * km_rs<BN>() : BN * BK * 2;   // bytes of one A / B plane tile
     constexpr int STAGE_BYTES = (NPASS == 3 ? 2 : 1) * (PA + PBB);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -124,8 +170,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
 #define BMT_GLOAD(s_, RA, RB, RAL, RBL)                                                   \
     do {                                                                                  \
         const int k_ = min(kbeg + (s_) * BK, kend - BK);   /* branch-free tail: re-fetch the last stage */ \
-        plane_gload<SPR, BM, NT>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                      \
-        plane_gload<SPR, BN, NT>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                      \
+        if constexpr (AKM) plane_gload_km<BM, BK, NT>(p.Ah, p.lda, m0, k_, p.krows, tid, RA);   \
+        else plane_gload<SPR, BM, NT>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                 \
+        if constexpr (BKM) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0, k_, p.krows, tid, RB);   \
+        else plane_gload<SPR, BN, NT>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                 \
         if constexpr (NPASS == 3) {                                                       \
             plane_gload<SPR, BM, NT>(p.Al, p.lda, m0, p.M, k_, tid, RAL);                 \
             plane_gload<SPR, BN, NT>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);                 \
@@ -133,8 +181,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     } while (0)
 #define BMT_LSTORE(buf_, RA, RB, RAL, RBL)                                                \
     do {                                                                                  \
-        plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 0), tid, RA);                           \
-        plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 1), tid, RB);                           \
+        if constexpr (AKM) plane_lstore_km<BM, BK, NT>(reinterpret_cast<char*>(stage_ptr(buf_, 0)), tid, RA);  \
+        else plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 0), tid, RA);                      \
+        if constexpr (BKM) plane_lstore_km<BN, BK, NT>(reinterpret_cast<char*>(stage_ptr(buf_, 1)), tid, RB);  \
+        else plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 1), tid, RB);                      \
         if constexpr (NPASS == 3) {                                                       \
             plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 2), tid, RAL);                      \
             plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 3), tid, RBL);                      \
@@ -151,12 +201,14 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
             bf16x8 ah[TI], bh[2], al[TI], bl[2];                                          \
             _Pragma("unroll") for (int i = 0; i < TI; ++i) {                              \
                 const int ia = slot_of<SPR>(wr * 32 * TI + i * 32 + l31, sl);             \
-                ah[i] = as_bf16x8(sAh[ia]);                                               \
+                if constexpr (AKM) ah[i] = km_frag<BM>(reinterpret_cast<const char*>(sAh), 16 * s, wr * 32 * TI + i * 32, lane); \
+                else ah[i] = as_bf16x8(sAh[ia]);                                          \
                 if constexpr (NPASS == 3) al[i] = as_bf16x8(sAl[ia]);                     \
             }                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                               \
                 const int ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl);                  \
-                bh[i] = as_bf16x8(sBh[ib]);                                               \
+                if constexpr (BKM) bh[i] = km_frag<BN>(reinterpret_cast<const char*>(sBh), 16 * s, wc * 64 + i * 32, lane); \
+                else bh[i] = as_bf16x8(sBh[ib]);                                          \
                 if constexpr (NPASS == 3) bl[i] = as_bf16x8(sBl[ib]);                     \
             }                                                                             \
             _Pragma("unroll") for (int i = 0; i < TI; ++i)                                \
@@ -397,18 +449,18 @@ __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __re
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int NPASS, int WM, int TI>
+template <int NPASS, int WM, int TI, bool AKM = false, bool BKM = false>
 int launch(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int BK = (NPASS == 3) ? 32 : 64;
     constexpr int BMr = 32 * TI * WM;
-    constexpr int stage = (NPASS == 3 ? 2 : 1) * (BMr + BN) * BK * 2;
+    constexpr int stage = (NPASS == 3 ? 2 : 1) * ((AKM ? BK * km_rs<BMr>() : BMr * BK * 2) + (BKM ? BK * km_rs<BN>() : BN * BK * 2));
     constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;   // two stage buffers / the packed plane tile of the epilogue
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16");
     return BMT_OK;
 }
@@ -421,7 +473,10 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
                   a->M, a->N, a->Kpad);
     BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || (a->precision == BMT_PREC_BF16X3 && a->A_lo && a->B_lo),
                   "bmt_gemm_bf16: BF16X3 needs both lo planes");
-    BMT_CHECK_ARG(a->lda >= a->Kpad && a->ldb >= a->Kpad, "bmt_gemm_bf16: plane row stride smaller than Kpad");
+    BMT_CHECK_ARG(!(a->a_kmajor || a->b_kmajor) || (a->precision == BMT_PREC_BF16 && a->K > 0 && a->K <= a->Kpad && a->Kpad - a->K < 64),
+                  "bmt_gemm_bf16: k-major operands need BMT_PREC_BF16 and the true reduction length K (Kpad = K rounded up to 64)");
+    BMT_CHECK_ARG((a->a_kmajor ? a->lda >= 8 : a->lda >= a->Kpad) && (a->b_kmajor ? a->ldb >= 8 : a->ldb >= a->Kpad),
+                  "bmt_gemm_bf16: plane row stride smaller than Kpad");
     if (!(al16(a->A_hi) && al16(a->B_hi)) || ((a->lda | a->ldb) & 7) || (a->A_lo && !al16(a->A_lo)) || (a->B_lo && !al16(a->B_lo))) {
         bmt_set_error("bmt_gemm_bf16: planes must be 16-byte aligned with row strides multiples of 8 elements");
         return BMT_EALIGN;
@@ -442,7 +497,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_lo; p.ldp = a->ldp;
     p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
     p.plane_vec = a->C_hi && al16(a->C_hi) && (!a->C_lo || al16(a->C_lo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
-    p.M = a->M; p.N = a->N; p.Kpad = a->Kpad;
+    p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
     p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
     // tile height: 256 rows (8 waves, one workgroup per CU) when that still fills the chip, else 128 rows (4 waves, two per CU)
     static const int force_bm = getenv("BMT_GEMM_BM") ? atoi(getenv("BMT_GEMM_BM")) : 0;      // A/B experiments only
@@ -450,6 +505,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     // K >= 512 shapes and loses 2-8 % elsewhere; the 8-wave 128-row tile (below) beats both, so 256 rows is opt-in only
     p.bm = 128;
     if (force_bm == 128 || force_bm == 256) p.bm = force_bm;
+    if (a->a_kmajor || a->b_kmajor) p.bm = 128;
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
@@ -480,9 +536,15 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     // except for the single-pass kernel on very large grids (FFN dX / dW, 2048 tiles: 93 -> 96..100 us)
     static const int force8 = getenv("BMT_GEMM_8W") ? atoi(getenv("BMT_GEMM_8W")) : -1;          // A/B experiments only
     const int waves8 = force8 >= 0 ? force8 : !(a->precision == BMT_PREC_BF16 && p.tiles_m * p.tiles_n >= 1024);
-    if (p.bm == 256) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 2>(p, splitk, (hipStream_t)stream) : launch<1, 4, 2>(p, splitk, (hipStream_t)stream);
-    else if (waves8) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1>(p, splitk, (hipStream_t)stream) : launch<1, 4, 1>(p, splitk, (hipStream_t)stream);
-    else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 2, 2>(p, splitk, (hipStream_t)stream) : launch<1, 2, 2>(p, splitk, (hipStream_t)stream);
+    hipStream_t st_ = (hipStream_t)stream;
+    const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
+    if (akm || bkm) {                 // single-pass kernel, 128-row tiles
+        if (akm && bkm) rc = waves8 ? launch<1, 4, 1, true, true>(p, splitk, st_) : launch<1, 2, 2, true, true>(p, splitk, st_);
+        else if (bkm) rc = waves8 ? launch<1, 4, 1, false, true>(p, splitk, st_) : launch<1, 2, 2, false, true>(p, splitk, st_);
+        else rc = waves8 ? launch<1, 4, 1, true, false>(p, splitk, st_) : launch<1, 2, 2, true, false>(p, splitk, st_);
+    } else if (p.bm == 256) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 2>(p, splitk, st_) : launch<1, 4, 2>(p, splitk, st_);
+    else if (waves8) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1>(p, splitk, st_) : launch<1, 4, 1>(p, splitk, st_);
+    else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 2, 2>(p, splitk, st_) : launch<1, 2, 2>(p, splitk, st_);
     if (rc != BMT_OK || p.ws == nullptr) return rc;
     const int pc = p.Chi ? (p.plane_cols > p.N ? p.plane_cols : p.N) : p.N;
     const int64_t groups = (int64_t)p.M * ((pc + 3) / 4);

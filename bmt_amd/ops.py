@@ -341,11 +341,21 @@ TWO_PASS_SPLITK = True   # split-K through the workspace + epilogue kernel (Fals
 
 def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
               drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None, precision=None,
-              out_planes: Optional[Planes] = None):
-    """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded)."""
-    M, N = A.rows, B.rows
-    Kpad = A.hi.shape[1]
-    assert B.hi.shape[1] == Kpad, (A.hi.shape, B.hi.shape)
+              out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False):
+    """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded).
+    a_km / b_km: that operand is given K-MAJOR -- its plane has the reduction index as the row ([K rows][M or N columns]), i.e.
+    it is the transpose of what the product needs, read through the hardware transpose unit (single-pass precision only)."""
+    M = A.cols if a_km else A.rows
+    N = B.cols if b_km else B.rows
+    Ktrue = 0
+    if a_km or b_km:
+        Ktrue = A.rows if a_km else B.rows
+        Kpad = _pad64(Ktrue)
+        assert (A.rows == Ktrue if a_km else A.hi.shape[1] == Kpad) and (B.rows == Ktrue if b_km else B.hi.shape[1] == Kpad), \
+            (A.hi.shape, A.rows, B.hi.shape, B.rows)
+    else:
+        Kpad = A.hi.shape[1]
+        assert B.hi.shape[1] == Kpad, (A.hi.shape, B.hi.shape)
     prec = precision or FWD_PRECISION
     flags = 0
     if bias is not None:
@@ -372,6 +382,7 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=
                      op.hi.stride(0) if op else 0, M, N, Kpad, alpha, flags, _p(bias), _p(residual), ldr,
                      _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
                      drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec, splitk)
+    a.a_kmajor, a.b_kmajor, a.K = int(a_km), int(b_km), Ktrue
     if splitk != 1 and TWO_PASS_SPLITK:
         ws = splitk_workspace(A.hi.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4

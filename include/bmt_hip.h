@@ -106,6 +106,12 @@ typedef struct {
      * epilogue, deterministic, ACCUM without atomics.  Without a workspace splitk>1 needs BMT_EPI_ACCUM and a plain epilogue
      * (atomic accumulation).  One workspace serves every launch of one stream. */
     float* splitk_ws; int64_t splitk_ws_bytes;
+    /* k-major operands (BMT_PREC_BF16 only): the operand's plane has the REDUCTION index as its row -- A_hi is [K][lda] with M
+     * valid columns, B_hi is [K][ldb] with N valid columns (lda/ldb multiples of 8; rows [K, Kpad) are treated as zero, so the
+     * plane needs no row padding).  dW = dY^T . X takes both gradient and activation planes as they are (a_kmajor = b_kmajor = 1),
+     * dX = dY . W takes the weight plane [N][K] as it is (b_kmajor = 1): no transposed copies of anything.  K: true reduction
+     * length, Kpad = K rounded up to a multiple of 64. */
+    int a_kmajor, b_kmajor, K;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL

@@ -91,6 +91,25 @@ def test_gemm_splitk_two_pass(ops, M, N, K, splitk, prec):
     assert_close(outs[1][0], outs[0][0], atol=1e-4 * math.sqrt(K), rtol=1e-5, name="split vs single pass")
 
 
+@pytest.mark.parametrize("M,N,K", [(130, 70, 100), (256, 128, 512), (33, 300, 1000), (960, 300, 1030), (928, 1024, 300)])
+def test_gemm_kmajor_operands(ops, M, N, K):
+    """operands given with the reduction index as their row (read through ds_read_b64_tr_b16): dX = dY . W with the weight plane
+    as stored, dW = dY^T . X with gradient and activation planes as stored -- no transposed planes anywhere"""
+    dy, W, x = rnd(M, N, seed=14), rnd(N, K, seed=15), rnd(M, K, seed=16)
+    dyP = ops.make_planes(dy.to(DEV), lo=False)[0]
+    WP = ops.make_planes(W.to(DEV), lo=False)[0]
+    xP = ops.make_planes(x.to(DEV), lo=False)[0]
+    dx = torch.empty(M, K, device=DEV)
+    ops.gemm_bf16(dyP, WP, dx, ldc=K, precision=1, b_km=True)                      # reduction over N: W [N rows][K cols] is k-major
+    want = bf16_round(dy).double() @ bf16_round(W).double()
+    assert_close(dx, want, atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx (k-major W)")
+    for sk in (1, 3):
+        dW = torch.empty(N, K, device=DEV)
+        ops.gemm_bf16(dyP, xP, dW, ldc=K, precision=1, a_km=True, b_km=True, splitk=sk)   # reduction over M (rows of both planes)
+        want = bf16_round(dy).double().t() @ bf16_round(x).double()
+        assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name=f"dW (k-major dY and X, splitk={sk})")
+
+
 def test_planes_and_transpose(ops):
     x = rnd(150, 70, seed=3) * 3
     pl, plT = ops.make_planes(x.to(DEV), lo=True, straight=True, transposed=True)
