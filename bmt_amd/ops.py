@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os as _os
 from typing import Optional
 
 import torch
@@ -173,7 +174,7 @@ class _WeightPlanes:
         dev = W.device
         st = Planes(torch.empty(N, _pad64(K), device=dev, dtype=torch.bfloat16),
                     torch.empty(N, _pad64(K), device=dev, dtype=torch.bfloat16), N, K)
-        tr = Planes(torch.empty(K, _pad64(N), device=dev, dtype=torch.bfloat16), None, K, N)
+        tr = None if _kmajor() else Planes(torch.empty(K, _pad64(N), device=dev, dtype=torch.bfloat16), None, K, N)
         owner = W._base if W._base is not None else W
         self.entries.append([weakref.ref(owner), self._key(W), st, tr, None, W.detach()])
         self.index[(id(owner), self._key(W))] = len(self.entries) - 1
@@ -209,14 +210,15 @@ class _WeightPlanes:
             dev = Ws[0].device
             big_hi = torch.empty(Nt, _pad64(K), device=dev, dtype=torch.bfloat16)
             big_lo = torch.empty(Nt, _pad64(K), device=dev, dtype=torch.bfloat16)
-            bigT = torch.empty(K, Nt, device=dev, dtype=torch.bfloat16)
+            bigT = None if _kmajor() else torch.empty(K, Nt, device=dev, dtype=torch.bfloat16)
             off = 0
             for W in Ws:
                 N = W.shape[0]
-                self._put(W, Planes(big_hi[off:off + N], big_lo[off:off + N], N, K), Planes(bigT[:, off:off + N], None, K, N))
+                self._put(W, Planes(big_hi[off:off + N], big_lo[off:off + N], N, K),
+                          None if bigT is None else Planes(bigT[:, off:off + N], None, K, N))
                 off += N
             bias = torch.empty(Nt, device=dev, dtype=torch.float32) if all(b is not None for b in bs) else None
-            g = [[weakref.ref(W) for W in Ws], Planes(big_hi, big_lo, Nt, K), Planes(bigT, None, K, Nt), bias, -1]
+            g = [[weakref.ref(W) for W in Ws], Planes(big_hi, big_lo, Nt, K), None if bigT is None else Planes(bigT, None, K, Nt), bias, -1]
             self.groups[key] = g
             if len(self.groups) > 4096:     # models come and go in tests
                 self.groups = {k: v for k, v in self.groups.items() if all(r() is not None for r in v[0])}
@@ -250,7 +252,8 @@ class _WeightPlanes:
             for i, e in enumerate(self.entries):
                 Wd, st, tr = e[5], e[2], e[3]
                 _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
-                                               _p(st.hi), _p(st.lo), st.hi.stride(0), _p(tr.hi), None, tr.hi.stride(0)),
+                                               _p(st.hi), _p(st.lo), st.hi.stride(0), _p(tr.hi) if tr is not None else None, None,
+                                               tr.hi.stride(0) if tr is not None else 0),
                            "bmt_planes_desc")
             self.table = host.to(self.entries[0][5].device)
             self.dirty_table = False
@@ -335,6 +338,7 @@ def splitk_workspace(device):
     return ws
 
 
+KMAJOR = _os.environ.get("BMT_NO_KMAJOR") != "1"   # backward GEMMs read operands k-major (no transposed planes)
 AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
 TWO_PASS_SPLITK = True   # split-K through the workspace + epilogue kernel (False: atomic accumulation, weight gradients only)
 
@@ -432,6 +436,10 @@ def linear_fwd_planes(x, W: torch.Tensor, b: Optional[torch.Tensor], want_lo: bo
     return op
 
 
+def _kmajor() -> bool:
+    return KMAJOR and USE_PLANE_GEMM and BWD_PRECISION == PREC_BF16
+
+
 def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     """dx[M,K] = dy[M,N] @ W[N,K]   (reduction over N);  dy: fp32 tensor or Planes (hi)."""
     if not USE_PLANE_GEMM:
@@ -447,12 +455,15 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
              precision=BWD_PRECISION, **epi)
         return out
     A = as_planes(dy, BWD_PRECISION == PREC_BF16X3)
-    Wt = weight_planes(W, transposed=True)          # [K][pad64(N)]
     if out is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
     if "ldg" in epi:
         epi.pop("ldg")
-    gemm_bf16(A, Wt, out, ldc=out.stride(0), precision=BWD_PRECISION, **epi)
+    if _kmajor():       # the weight plane [N][K] as stored: its row IS the reduction index
+        gemm_bf16(A, weight_planes(W), out, ldc=out.stride(0), precision=PREC_BF16, b_km=True, **epi)
+    else:
+        Wt = weight_planes(W, transposed=True)          # [K][pad64(N)]
+        gemm_bf16(A, Wt, out, ldc=out.stride(0), precision=BWD_PRECISION, **epi)
     return out
 
 
@@ -470,12 +481,13 @@ def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Te
         gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=dW.stride(0), a_kc=False, b_kc=False,
              accum=acc, splitk=sk, precision=BWD_PRECISION)
         return None if into is not None else dW
-    N, K, M = dyT.rows, xT.rows, dyT.cols
+    km = _kmajor()          # k-major: dyT / xT are the STRAIGHT planes dY [M][N], X [M][K] (rows = the reduction index)
+    N, K, M = (dyT.cols, xT.cols, dyT.rows) if km else (dyT.rows, xT.rows, dyT.cols)
     sk = _splitk_for(N, K, M)
     atomic = sk > 1 and not TWO_PASS_SPLITK      # two-pass split-K has one writer per element: no zero-fill, no atomics
     acc = into is not None or atomic
     dW = into if into is not None else (torch.zeros if atomic else torch.empty)(N, K, device=dyT.hi.device, dtype=torch.float32)
-    gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16)
+    gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16, a_km=km, b_km=km)
     return None if into is not None else dW
 
 
@@ -558,7 +570,11 @@ def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None):
     if not USE_PLANE_GEMM:
         return dy2, dy2, False
     gb = static_grad(bias)
-    P, T = make_planes(dy2, lo=False, straight=True, transposed=True, colsum=gb)
+    if _kmajor():       # one plane serves dX (as A) and dW (k-major)
+        P = make_planes(dy2, lo=False, straight=True, transposed=False, colsum=gb)[0]
+        T = P
+    else:
+        P, T = make_planes(dy2, lo=False, straight=True, transposed=True, colsum=gb)
     if gb is not None:
         grad_done(bias)
     return P, T, gb is not None
@@ -568,6 +584,8 @@ def input_t(x2):
     """operand of x for the dW product: transposed hi plane (x2: fp32 tensor or Planes)."""
     if not USE_PLANE_GEMM:
         return x2
+    if _kmajor():
+        return x2 if isinstance(x2, Planes) else make_planes(x2, lo=False)[0]
     if isinstance(x2, Planes):
         return transpose_plane(x2)
     return make_planes(x2, lo=False, straight=False, transposed=True)[1]
@@ -707,19 +725,20 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor
     Mq, Mk = B * Sq, B * Sk
     outs = []
     comb = None
+    km = _kmajor()        # k-major GEMMs take the gradient plane as it is: no transposed plane is produced
     if fuse in ("qkv", "kv") and D % 64 == 0 and (fuse == "kv" or Mq == Mk):
         n = 3 if fuse == "qkv" else 2
         big = _plane_buf(Mk, n * D, dev)
-        bigT = _plane_buf(n * D, Mk, dev)
-        comb = (Planes(big, None, Mk, n * D), Planes(bigT, None, n * D, Mk))
+        bigT = None if km else _plane_buf(n * D, Mk, dev)
+        comb = (Planes(big, None, Mk, n * D), Planes(big, None, Mk, n * D) if km else Planes(bigT, None, n * D, Mk))
     for idx, (M, b) in enumerate(((Mq, biases[0]), (Mk, biases[1]), (Mk, biases[2]))):
         slot = None if comb is None else (idx if fuse == "qkv" else idx - 1)
         if slot is not None and slot >= 0:
             hi = comb[0].hi[:, slot * D:(slot + 1) * D]
-            hiT = comb[1].hi[slot * D:(slot + 1) * D]
+            hiT = None if km else comb[1].hi[slot * D:(slot + 1) * D]
         else:
             hi = _plane_buf(M, D, dev)
-            hiT = _plane_buf(D, M, dev)
+            hiT = None if km else _plane_buf(D, M, dev)
         gb = static_grad(b)
         db = None
         if b is not None and gb is None:
@@ -737,14 +756,15 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor
                         Oh=_p(o.hi), Ol=_p(o.lo), ldop=ldop, bsop=Sq * ldop,
                         dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
-                        dQT=_p(qT_), dKT=_p(kT_), dVT=_p(vT_), gqT_ld=qT_.stride(0), gkvT_ld=kT_.stride(0),
+                        dQT=_p(qT_), dKT=_p(kT_), dVT=_p(vT_), gqT_ld=0 if qT_ is None else qT_.stride(0), gkvT_ld=0 if kT_ is None else kT_.stride(0),
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_))
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
     for (hi, hiT, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
         if b is not None and db is None:
             grad_done(b)
-        res.append((Planes(hi, None, M, D), Planes(hiT, None, D, M), db))
+        P_ = Planes(hi, None, M, D)
+        res.append((P_, P_ if hiT is None else Planes(hiT, None, D, M), db))
     if comb is not None:
         res.append(comb)
     return res
@@ -904,7 +924,7 @@ class FFNFn(torch.autograd.Function):
         gscale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
         W1p, b1p, W2p, b2p = ctx.params
         if USE_PLANE_GEMM:
-            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(transpose_plane(h)), gate=h, gate_scale=gscale)
+            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(input_t(h)), gate=h, gate_scale=gscale)
         else:
             hf = _planes_to_f32(h)
             dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, hf)
@@ -946,7 +966,8 @@ class MHAFn(torch.autograd.Function):
         # each distinct input: operand planes (hi[, lo]) and, for the weight gradients, the transposed hi plane -- one pass
         def split(x3d):
             x2 = x3d.view(-1, x3d.shape[-1])
-            return make_planes(x2, lo=x3, straight=True, transposed=train)
+            P_, T_ = make_planes(x2, lo=x3, straight=True, transposed=train and not _kmajor())
+            return P_, (P_ if _kmajor() else T_)
         Qp, QT = split(Qc)
         Kp, KT = (Qp, QT) if same_qk else split(Kc)
         Vp, VT = (Kp, KT) if same_kv else split(Vc)
@@ -1003,10 +1024,13 @@ class MHAFn(torch.autograd.Function):
         Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
         q, k, v = Planes(qh, None, Mq, D), Planes(kh, None, Mk, D), Planes(vh, None, Mk, D)
         o = Planes(oh, ol if ol.numel() else None, Mq, D)
-        QT, KT, VT = Planes(QTh, None, Dq, Mq), Planes(KTh, None, Dk_in, Mk), Planes(VTh, None, Dv_in, Mk)
+        if _kmajor():     # the inputs' own hi planes are the dW operands
+            QT, KT, VT = Planes(QTh, None, Mq, Dq), Planes(KTh, None, Mk, Dk_in), Planes(VTh, None, Mk, Dv_in)
+        else:
+            QT, KT, VT = Planes(QTh, None, Dq, Mq), Planes(KTh, None, Dk_in, Mk), Planes(VTh, None, Dv_in, Mk)
         dy2 = _f32c(dout).view(-1, Dq)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
-        do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(transpose_plane(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
+        do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(input_t(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
         res = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p, (bqp, bkp, bvp), fuse=ctx.fuse)
         (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = res[:3]
         comb = res[3] if len(res) > 3 else None
@@ -1016,11 +1040,14 @@ class MHAFn(torch.autograd.Function):
         def fused_bwd(Ws, xT, need_dx):
             """dX = [dq|dk|dv] . [Wq;Wk;Wv] as one GEMM; dW as one GEMM when the gradients are adjacent, else one per weight"""
             P_all, T_all = comb
-            _, gtr, _ = weight_group(Ws, tuple(None for _ in Ws))
+            gst, gtr, _ = weight_group(Ws, tuple(None for _ in Ws))
             dx = None
             if need_dx:
-                dx = torch.empty(P_all.rows, gtr.rows, device=dy2.device, dtype=torch.float32)
-                gemm_bf16(P_all, gtr, dx, ldc=dx.stride(0), precision=BWD_PRECISION)
+                dx = torch.empty(P_all.rows, gst.cols, device=dy2.device, dtype=torch.float32)
+                if _kmajor():      # [Wq;Wk;Wv] as stored ([3D][d_in]): its row is the reduction index
+                    gemm_bf16(P_all, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
+                else:
+                    gemm_bf16(P_all, gtr, dx, ldc=dx.stride(0), precision=BWD_PRECISION)
             gW = group_static_grad(Ws)
             if gW is not None:
                 linear_dw(T_all, xT, into=gW)
@@ -1031,7 +1058,8 @@ class MHAFn(torch.autograd.Function):
             for W in Ws:
                 N = W.shape[0]
                 g1 = static_grad(W)
-                dWs.append(linear_dw(Planes(T_all.hi[off:off + N], None, N, T_all.cols), xT, into=g1))
+                Tw = Planes(T_all.hi[:, off:off + N], None, T_all.rows, N) if _kmajor() else Planes(T_all.hi[off:off + N], None, N, T_all.cols)
+                dWs.append(linear_dw(Tw, xT, into=g1))
                 if g1 is not None:
                     grad_done(W)
                 off += N

@@ -292,7 +292,16 @@ def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind)
 
     dq, dk_, dv = ops.attn_bwd_bf16(qh, kh, vh, o32, do, lse32, md, H)
     bq = torch.nn.Parameter(torch.zeros(D, device=DEV))
-    res = ops.attn_bwd_planes(P(qh, None, Sq), P(kh, None, Sk), P(vh, None, Sk), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (bq, None, bq))
+    km_was = ops.KMAJOR          # the model path runs k-major GEMMs and asks for no transposed planes; the kernels' transposed
+    ops.KMAJOR = False           # output form is part of the C ABI and is checked here
+    try:
+        res = ops.attn_bwd_planes(P(qh, None, Sq), P(kh, None, Sk), P(vh, None, Sk), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (bq, None, bq))
+    finally:
+        ops.KMAJOR = km_was
+    if km_was:
+        res_km = ops.attn_bwd_planes(P(qh, None, Sq), P(kh, None, Sk), P(vh, None, Sk), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (None, None, None))
+        for (Pa, Ta, _), (Pb, _, _) in zip(res_km, res):
+            assert Ta is Pa and torch.equal(Pa.hi, Pb.hi)
     for name, (Pl, T, db), ref, S in (("dq", res[0], dq, Sq), ("dk", res[1], dk_, Sk), ("dv", res[2], dv, Sk)):
         ref2 = ref.view(B * S, D)
         # the plane path rebuilds O as hi+lo (2^-16 relative) inside delta: compare to bf16 resolution
