@@ -88,7 +88,10 @@ class KernelTimer:
             if not timer.enabled:
                 return raw_gb(A, B, C_out, **kw)
             prec = kw.get("precision") or ops.FWD_PRECISION
-            M, N, K = A.rows, B.rows, A.cols
+            akm, bkm = kw.get("a_km", False), kw.get("b_km", False)        # k-major operand: its ROWS are the reduction index
+            M = A.cols if akm else A.rows
+            N = B.cols if bkm else B.rows
+            K = A.rows if akm else (B.rows if bkm else A.cols)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = raw_gb(A, B, C_out, **kw)
