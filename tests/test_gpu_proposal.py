@@ -1,5 +1,7 @@
 """-m gpu: proposal-generator path (Conv1d heads as implicit GEMM, target assignment, decode + YOLO loss) against the
 golden vectors captured from the reference and against the CPU oracle."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -137,3 +139,50 @@ def test_proposal_train_step_matches_oracle(golden):
         agree += int((d < 2.5e-4).sum())
         total += d.numel()
     assert agree / total > 0.97, agree / total
+
+
+def test_full_size_properties_config3():
+    """BASELINE configs[3] at full size: train_prop B=16 over full-video streams (T_v=1024, T_a=3200), bi-modal encoder of the
+    configs[1] width FROZEN (as with cfg.pretrained_cap_model_path / finetune_cap_encoder=False), 10 + 10 Conv1d heads with the
+    reference's kernel sizes and 128 / 48 anchors.  The CPU oracle is far too slow here; checked instead:
+    finite predictions of the documented shape, bit-identical eval forward, a sample's predictions independent of the rest of the
+    batch, gradients only on the heads, and a decreasing loss over three optimizer steps on one batch."""
+    import contextlib, io
+    from bmt_amd import ops
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    from bmt_amd.train import ProposalTrainStep, make_masks
+    B, Tv, Ta = 16, 1024, 3200
+    cfg = syn.cfg_config1(procedure="train_prop", dout_p=0.1, lr=1e-4)
+    cfg.device = DEV
+    cfg.grad_clip = None
+    anchors = {"audio": syn.make_anchors(cfg.anchors_num_audio), "video": syn.make_anchors(cfg.anchors_num_video)}
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = MultimodalProposalGenerator(cfg, anchors).to(DEV)
+    for p in model.encoder.parameters():        # what loading a pre-trained captioning encoder does (model/proposal_generator.py:344-353)
+        p.requires_grad = False
+    batch = syn.make_prop_batch(cfg, B, Tv, Ta, seed=11)
+    fs = {k: v.to(DEV) for k, v in batch["feature_stacks"].items()}
+    targets = batch["targets"].to(DEV)
+    masks = make_masks(fs, None, "audio_video", syn.PAD_IDX)
+    model.eval()
+    with torch.no_grad():
+        p1, l1, _, _ = model(fs, targets, masks)
+        p2, l2, _, _ = model(fs, targets, masks)
+    n_pred = len(cfg.kernel_sizes["audio"]) * Ta * cfg.anchors_num_audio + len(cfg.kernel_sizes["video"]) * Tv * cfg.anchors_num_video
+    assert p1.shape == (B, n_pred, 3) and torch.isfinite(p1).all() and math.isfinite(float(l1))
+    assert torch.equal(p1, p2), "eval forward is not deterministic"
+    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1))      # the loss terms are summed with atomics: order may differ
+    other = syn.make_prop_batch(cfg, B, Tv, Ta, seed=12)
+    fs2 = {k: v.to(DEV).clone() for k, v in other["feature_stacks"].items()}
+    for k in fs2:
+        fs2[k][3] = fs[k][3]
+    with torch.no_grad():
+        p3, _, _, _ = model(fs2, None, make_masks(fs2, None, "audio_video", syn.PAD_IDX))
+    assert_close(p3[3], p1[3], atol=1e-3, rtol=1e-4, name="predictions of a sample under a different batch")
+    ops.manual_seed(5)
+    step = ProposalTrainStep(model, cfg, syn.PAD_IDX)
+    losses = [float(step(fs, targets)[1]) for _ in range(3)]
+    assert all(math.isfinite(v) for v in losses) and losses[2] < losses[0], losses
+    assert all(p.grad is None for p in model.encoder.parameters())
+    assert all(p.grad is not None for n, p in model.named_parameters() if n.startswith("detection_layers"))
