@@ -37,7 +37,8 @@ class GemmBf16Args(C.Structure):
                 ("M", i32), ("N", i32), ("Kpad", i32), ("alpha", f32), ("flags", C.c_uint),
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
-                ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32)]
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32),
+                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -97,6 +98,7 @@ SIGNATURES = {
     "bmt_device_cus": (i32, []),
     "bmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "bmt_gemm_bf16": (i32, [C.POINTER(GemmBf16Args), vp]),
+    "bmt_pad_planes": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i64, vp]),
     "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp]),
     "bmt_planes_desc_bytes": (i32, []),
     "bmt_planes_desc": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, i64]),

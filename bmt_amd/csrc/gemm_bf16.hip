@@ -32,6 +32,9 @@ struct GemmB {
     int M, N, Kpad;
     int tiles_m, tiles_n, kchunk;
     int bm;                              // tile rows (128 or 256)
+    int conv_cin;                        // > 0: implicit Conv1d, channels per tap (padded width of the activation plane); see bmt_gemm_bf16_args
+    int conv_rows;                       // rows of the halo-padded activation plane reachable from its base pointer
+    int conv_S, conv_halo;               // sequence length and halo rows on each side of a sequence
     int krows;                           // k-major operands: valid rows (the true reduction length); rows [krows, Kpad) read as 0
     float alpha;
     unsigned flags;
@@ -65,6 +68,19 @@ __device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, in
         v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + k0 + (c % SPR) * 8);
     }
 }
+// implicit Conv1d (forward / dX): the reduction index is (tap, channel); a stage lies inside one tap (cin % BK == 0) and reads the
+// activation rows shifted by that tap.  The activation plane is HALO-PADDED per sequence (zero rows between the batches), so no
+// per-row validity test is needed: output row m = b * S + s (compact) reads plane rows m + 2 b * halo + tap from a base pointer advanced by (halo - pad) rows;
+// the per-thread row bases are computed once (one integer division per row).
+template <int SPR, int ROWS, int NT>
+__device__ __forceinline__ void plane_gload_conv(const uint16_t* base, int64_t ld, const int (&abase)[ROWS * SPR / NT], int maxrow, int tap, int c0,
+                                                 int tid, u32x4 (&v)[ROWS * SPR / NT]) {
+#pragma unroll
+    for (int i = 0; i < ROWS * SPR / NT; ++i) {
+        const int c = tid + NT * i;
+        v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(abase[i] + tap, maxrow) * ld + c0 + (c % SPR) * 8);
+    }
+}
 template <int SPR, int ROWS, int NT>
 __device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&v)[ROWS * SPR / NT]) {
 #pragma unroll
@@ -83,14 +99,14 @@ __device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&
 template <int COLS> constexpr int km_rs() { return COLS * 2 + 64; }
 template <int COLS, int BK, int NT>
 __device__ __forceinline__ void plane_gload_km(const uint16_t* base, int64_t ld, int c0, int k0, int krows, int tid,
-                                               u32x4 (&v)[COLS * BK / 8 / NT]) {
+                                               u32x4 (&v)[COLS * BK / 8 / NT], int shift = 0, int maxrow = 0x7fffffff) {
     constexpr int SPC = COLS / 8;
 #pragma unroll
     for (int i = 0; i < COLS * BK / 8 / NT; ++i) {
         const int c = tid + NT * i;
         const int kr = k0 + c / SPC;
         const int col = min(c0 + (c % SPC) * 8, (int)ld - 8);          // columns past the operand's extent: duplicates, discarded
-        const u32x4 x = *reinterpret_cast<const u32x4*>(base + (int64_t)min(kr, krows - 1) * ld + col);
+        const u32x4 x = *reinterpret_cast<const u32x4*>(base + (int64_t)min(min(kr, krows - 1) + shift, maxrow) * ld + col);
         const u32x4 z = {0u, 0u, 0u, 0u};
         v[i] = (kr < krows) ? x : z;                                   // select, not a guarded load
     }
@@ -123,9 +139,12 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
 // 29 % MFMA utilisation (profiles/r01_d_gemm_l2_pmc.txt), i.e. it is bound by the L2 -> CU fabric, not by L1, LDS or MFMA.
 // TI = 32-row MFMA tiles per wave along M (wave tile 32 TI x 64): TI = 2 is the layout above; TI = 1 doubles the waves of a
 // tile (more waves per SIMD to hide the LDS / barrier latency of the stage loop, 1.5x the fragment reads).
-template <int NPASS, int WM, int TI, bool AKM, bool BKM>
+// CONV = 1: operand A is a halo-padded activation plane read with a per-stage row shift (Conv1d forward and dX);
+// CONV = 2: operand B (k-major) is that plane read with a per-TILE row shift (Conv1d dW: output column block = tap).
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0>
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
+    static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = (NPASS == 3) ? 32 : 64;
     constexpr int SPR = BK / 8;
     constexpr int BM = 32 * TI * WM, NT = 128 * WM;       // WM waves along M x 2 along N
@@ -165,17 +184,28 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     constexpr int NRA = BM * SPR / NT, NRB = BN * SPR / NT;
     u32x4 ra0[NRA], rb0[NRB], ral0[NRA], rbl0[NRB];
     u32x4 ra1[NRA], rb1[NRB], ral1[NRA], rbl1[NRB];
+    int abase[NRA];                      // CONV == 1: halo-padded plane row of each staged output row
+    if constexpr (CONV == 1) {
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int row = min(m0 + (tid + NT * i) / SPR, p.M - 1);
+            abase[i] = row + 2 * (row / p.conv_S) * p.conv_halo;       // + tap, from a base pointer advanced by halo - pad rows
+        }
+    }
     // stage image: A hi | B hi | A lo | B lo
 #define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + ((which_) == 0 ? 0 : (which_) == 1 ? PA : (which_) == 2 ? PA + PBB : 2 * PA + PBB))
 #define BMT_GLOAD(s_, RA, RB, RAL, RBL)                                                   \
     do {                                                                                  \
         const int k_ = min(kbeg + (s_) * BK, kend - BK);   /* branch-free tail: re-fetch the last stage */ \
-        if constexpr (AKM) plane_gload_km<BM, BK, NT>(p.Ah, p.lda, m0, k_, p.krows, tid, RA);   \
+        if constexpr (CONV == 1) plane_gload_conv<SPR, BM, NT>(p.Ah, p.lda, abase, p.conv_rows - 1, k_ / p.conv_cin, k_ % p.conv_cin, tid, RA); \
+        else if constexpr (AKM) plane_gload_km<BM, BK, NT>(p.Ah, p.lda, m0, k_, p.krows, tid, RA);   \
         else plane_gload<SPR, BM, NT>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                 \
-        if constexpr (BKM) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0, k_, p.krows, tid, RB);   \
+        if constexpr (CONV == 2) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0 % p.conv_cin, k_, p.krows, tid, RB, n0 / p.conv_cin, p.conv_rows - 1); \
+        else if constexpr (BKM) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0, k_, p.krows, tid, RB);   \
         else plane_gload<SPR, BN, NT>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                 \
         if constexpr (NPASS == 3) {                                                       \
-            plane_gload<SPR, BM, NT>(p.Al, p.lda, m0, p.M, k_, tid, RAL);                 \
+            if constexpr (CONV == 1) plane_gload_conv<SPR, BM, NT>(p.Al, p.lda, abase, p.conv_rows - 1, k_ / p.conv_cin, k_ % p.conv_cin, tid, RAL); \
+            else plane_gload<SPR, BM, NT>(p.Al, p.lda, m0, p.M, k_, tid, RAL);            \
             plane_gload<SPR, BN, NT>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);                 \
         }                                                                                 \
     } while (0)
@@ -449,7 +479,7 @@ __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __re
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int NPASS, int WM, int TI, bool AKM = false, bool BKM = false>
+template <int NPASS, int WM, int TI, bool AKM = false, bool BKM = false, int CONV = 0>
 int launch(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int BK = (NPASS == 3) ? 32 : 64;
     constexpr int BMr = 32 * TI * WM;
@@ -457,10 +487,10 @@ int launch(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;   // two stage buffers / the packed plane tile of the epilogue
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM, CONV>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16");
     return BMT_OK;
 }
@@ -475,7 +505,11 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
                   "bmt_gemm_bf16: BF16X3 needs both lo planes");
     BMT_CHECK_ARG(!(a->a_kmajor || a->b_kmajor) || (a->precision == BMT_PREC_BF16 && a->K > 0 && a->K <= a->Kpad && a->Kpad - a->K < 64),
                   "bmt_gemm_bf16: k-major operands need BMT_PREC_BF16 and the true reduction length K (Kpad = K rounded up to 64)");
-    BMT_CHECK_ARG((a->a_kmajor ? a->lda >= 8 : a->lda >= a->Kpad) && (a->b_kmajor ? a->ldb >= 8 : a->ldb >= a->Kpad),
+    BMT_CHECK_ARG(a->conv_mode == 0 || (a->conv_cin > 0 && a->conv_cin % 64 == 0 && a->conv_rows > 0 &&
+                                        (a->conv_mode == 1 ? (!a->a_kmajor && !a->b_kmajor && a->Kpad % a->conv_cin == 0 && a->lda >= a->conv_cin)
+                                                           : (a->conv_mode == 2 && a->a_kmajor && a->b_kmajor && a->conv_cin % 128 == 0 && a->N % a->conv_cin == 0))),
+                  "bmt_gemm_bf16: bad implicit-convolution arguments");
+    BMT_CHECK_ARG(((a->a_kmajor || a->conv_mode == 1) ? a->lda >= 8 : a->lda >= a->Kpad) && (a->b_kmajor ? a->ldb >= 8 : a->ldb >= a->Kpad),
                   "bmt_gemm_bf16: plane row stride smaller than Kpad");
     if (!(al16(a->A_hi) && al16(a->B_hi)) || ((a->lda | a->ldb) & 7) || (a->A_lo && !al16(a->A_lo)) || (a->B_lo && !al16(a->B_lo))) {
         bmt_set_error("bmt_gemm_bf16: planes must be 16-byte aligned with row strides multiples of 8 elements");
@@ -498,6 +532,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
     p.plane_vec = a->C_hi && al16(a->C_hi) && (!a->C_lo || al16(a->C_lo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
+    p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
     p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
     // tile height: 256 rows (8 waves, one workgroup per CU) when that still fills the chip, else 128 rows (4 waves, two per CU)
     static const int force_bm = getenv("BMT_GEMM_BM") ? atoi(getenv("BMT_GEMM_BM")) : 0;      // A/B experiments only
@@ -505,7 +540,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     // K >= 512 shapes and loses 2-8 % elsewhere; the 8-wave 128-row tile (below) beats both, so 256 rows is opt-in only
     p.bm = 128;
     if (force_bm == 128 || force_bm == 256) p.bm = force_bm;
-    if (a->a_kmajor || a->b_kmajor) p.bm = 128;
+    if (a->a_kmajor || a->b_kmajor || a->conv_mode) p.bm = 128;
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
@@ -538,7 +573,11 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     const int waves8 = force8 >= 0 ? force8 : !(a->precision == BMT_PREC_BF16 && p.tiles_m * p.tiles_n >= 1024);
     hipStream_t st_ = (hipStream_t)stream;
     const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
-    if (akm || bkm) {                 // single-pass kernel, 128-row tiles
+    if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
+        rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1, false, false, 1>(p, splitk, st_) : launch<1, 4, 1, false, false, 1>(p, splitk, st_);
+    } else if (a->conv_mode == 2) {   // implicit Conv1d dW
+        rc = launch<1, 4, 1, true, true, 2>(p, splitk, st_);
+    } else if (akm || bkm) {                 // single-pass kernel, 128-row tiles
         if (akm && bkm) rc = waves8 ? launch<1, 4, 1, true, true>(p, splitk, st_) : launch<1, 2, 2, true, true>(p, splitk, st_);
         else if (bkm) rc = waves8 ? launch<1, 4, 1, false, true>(p, splitk, st_) : launch<1, 2, 2, false, true>(p, splitk, st_);
         else rc = waves8 ? launch<1, 4, 1, true, false>(p, splitk, st_) : launch<1, 2, 2, true, false>(p, splitk, st_);
@@ -627,5 +666,46 @@ extern "C" int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C,
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3(bmt_cdiv(C, 64), bmt_cdiv(pcolsT, 64)), dim3(256), 0, (hipStream_t)stream, src, ld, R, C,
                        dst, ldT, pcolsT);
     BMT_CHECK_LAUNCH("bmt_transpose_bf16");
+    return BMT_OK;
+}
+
+// ---------------------------------------------------------------- halo-padded planes for the implicit Conv1d
+// x fp32 (B, S, C) -> bf16 planes [B * (S + 2 halo) + tail][ldp]: row b * (S + 2 halo) + halo + s holds x[b, s, :] (hi = bf16(x),
+// lo = bf16(x - hi), optional), every other row and the columns [C, ldp) are zero.
+namespace {
+__global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict__ x, int B, int S, int C, int halo, int tail,
+                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int64_t ldp) {
+    const int groups = (int)(ldp / 8);
+    const int64_t total = ((int64_t)B * (S + 2 * halo) + tail) * groups;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t r = idx / groups;
+    const int c0 = (int)(idx % groups) * 8;
+    const int SP = S + 2 * halo;
+    const int b = (int)(r / SP), s = (int)(r % SP) - halo;
+    u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+    if (b < B && s >= 0 && s < S) {
+        const float* src = x + ((int64_t)b * S + s) * C;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? src[c0 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t hh, ll;
+            split_bf2(v[2 * j], v[2 * j + 1], hh, ll);
+            h[j] = hh; l[j] = ll;
+        }
+    }
+    *reinterpret_cast<u32x4*>(hi + r * ldp + c0) = h;
+    if (lo) *reinterpret_cast<u32x4*>(lo + r * ldp + c0) = l;
+}
+}  // namespace
+
+extern "C" int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream) {
+    BMT_CHECK_ARG(x && hi && B > 0 && S > 0 && C > 0 && halo >= 0 && tail >= 0 && ldp >= C && ldp % 8 == 0, "bmt_pad_planes: bad args");
+    if (!al16(hi) || (lo && !al16(lo))) { bmt_set_error("bmt_pad_planes: planes must be 16-byte aligned"); return BMT_EALIGN; }
+    const int64_t total = ((int64_t)B * (S + 2 * halo) + tail) * (ldp / 8);
+    hipLaunchKernelGGL(pad_planes_kernel, dim3((unsigned)bmt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, B, S, C, halo, tail, hi, lo, ldp);
+    BMT_CHECK_LAUNCH("bmt_pad_planes");
     return BMT_OK;
 }

@@ -31,8 +31,8 @@ def _conv(mode, x, W, bias, y, B, S, Din, Dout, k, flags=0, drop_p=0.0, site=0, 
     _lib.check(lib.bmt_conv1d(C.byref(a), _st()), "bmt_conv1d")
 
 
-class ConvKFn(torch.autograd.Function):
-    """relu?(dropout?(Conv1d(Din->Dout, k, padding=k//2)(x)))  on (B,S,Din) activations (reference :29-35,41-45)."""
+class ConvKFnStaged(torch.autograd.Function):
+    """ConvKFn on the fp32-staged implicit-GEMM kernel (bmt_conv1d, csrc/gemm.hip): the A/B reference for ConvKFn below."""
 
     @staticmethod
     def forward(ctx, x, W, b, relu, p, site):
@@ -72,6 +72,103 @@ class ConvKFn(torch.autograd.Function):
         sk = ops._splitk_for(Dout, k * Din, B * S)
         _conv(2, dz, xc, None, dWp, B, S, Din, Dout, k, precision=ops.BWD_PRECISION, splitk=sk)
         dW = _copy3d(dWp, k * Din, 1, Din, Dout, Din, k)
+        db = ops.colsum(dz.view(-1, Dout))
+        return dx, dW, db, None, None, None
+
+
+def _conv_weight_planes(Wsrc, cin_pad, lo):
+    """[N][C][k]-indexed source (any strides) -> planes [N][k * cin_pad] in tap-major order (reduction index = tap * cin_pad + c)"""
+    N, Cc, k = Wsrc.shape
+    Wp = torch.zeros(N, k, cin_pad, device=Wsrc.device, dtype=torch.float32)
+    Wp[:, :, :Cc] = Wsrc.permute(0, 2, 1)
+    return ops.make_planes(Wp.view(N, k * cin_pad), lo=lo)[0]
+
+
+def _pad128(n):
+    return (n + 127) // 128 * 128
+
+
+class ConvKFn(torch.autograd.Function):
+    """relu?(dropout?(Conv1d(Din->Dout, k, padding=k//2)(x)))  on (B,S,Din) activations (reference :29-35,41-45), as an IMPLICIT
+    GEMM on the plane kernel: no im2col buffer, no (B,D,S) permutes.  The activation is written once as halo-padded bf16 planes
+    (zero rows between the sequences, ``x._bmt_halo`` lets the ten heads of a modality share them); forward and dX read it with
+    a per-stage row shift (reduction index = (tap, channel)), dW reads gradient and activation k-major with a per-tile shift."""
+
+    @staticmethod
+    def _padded(x3, halo, k, lo):
+        cache = getattr(x3, "_bmt_padplanes", None)
+        if cache is not None and cache[0] == halo and cache[1] >= k and (cache[2].lo is not None or not lo):
+            return cache[2]
+        tail = 64 + k
+        pl = ops.pad_planes(x3, halo, tail, lo)
+        x3._bmt_padplanes = (halo, k, pl)
+        return pl
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu, p, site):
+        xc = _f32c(x)
+        if xc is not x and hasattr(x, "_bmt_halo"):
+            xc._bmt_halo = x._bmt_halo
+        B, S, Din = xc.shape
+        Dout, _, k = W.shape
+        pad = k // 2
+        halo = max(pad, getattr(xc, "_bmt_halo", pad))
+        x3 = ops.FWD_PRECISION == ops.PREC_BF16X3
+        kmax = 2 * halo + 1
+        X = ConvKFn._padded(xc, halo, kmax, x3)
+        cin = X.hi.shape[1]
+        Wp = _conv_weight_planes(W, cin, x3)                                    # [Dout][k * cin]
+        off = halo - pad
+        A = ops.Planes(X.hi[off:], None if X.lo is None or not x3 else X.lo[off:], B * S, Din)
+        y = torch.empty(B * S, Dout, device=x.device, dtype=torch.float32)
+        ops.gemm_bf16(A, Wp, y, ldc=Dout, bias=b, relu=relu, drop_pre=p > 0, drop_p=p, site=site,
+                      conv={"mode": 1, "M": B * S, "cin": cin, "rows": X.rows - off, "S": S, "halo": halo})
+        ctx.save_for_backward(xc, W, y if (relu or p > 0) else None)
+        ctx.relu, ctx.p, ctx.site, ctx.halo = relu, p, site, halo
+        return y.view(B, S, Dout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, W, y = ctx.saved_tensors
+        B, S, Din = xc.shape
+        Dout, _, k = W.shape
+        pad, halo = k // 2, ctx.halo
+        dyc = _f32c(dy)
+        if ctx.relu:
+            dz = torch.empty_like(dyc)
+            _lib.check(lib.bmt_gate(_p(dyc), _p(y), 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0, _p(dz), dyc.numel(), _st()), "bmt_gate")
+        elif ctx.p > 0:
+            dz = ops.dropout_raw(dyc, ctx.p, ctx.site)
+        else:
+            dz = dyc
+        dz3 = dz.view(B, S, Dout)
+        # gradient planes, halo-padded like the activations (zero halo rows: they add nothing to dW and give dX its padding)
+        G = ops.pad_planes(dz3, halo, 64 + 2 * halo + 1, False)
+        off = halo - pad
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx[s] = sum_tap dz[s - tap + pad] . W[:, :, tap]  ==  forward-style convolution of dz with the taps reversed
+            cout = G.hi.shape[1]
+            W2 = _conv_weight_planes(W.permute(1, 0, 2).flip(2), cout, False)   # [Din][k * cout]
+            dx = torch.empty(B * S, Din, device=dy.device, dtype=torch.float32)
+            ops.gemm_bf16(ops.Planes(G.hi[off:], None, B * S, Dout), W2, dx, ldc=Din, precision=ops.PREC_BF16,
+                          conv={"mode": 1, "M": B * S, "cin": cout, "rows": G.rows - off, "S": S, "halo": halo})
+            dx = dx.view(B, S, Din)
+        # dW[o][tap][c] = sum_r dz[r][o] * x[r + tap - pad][c]: reduction over the padded rows, both operands k-major
+        X = ConvKFn._padded(xc, halo, 2 * halo + 1, False)
+        if X.hi.shape[1] % 128 != 0:       # the dW tile (128 output columns) must stay inside one tap
+            Xw = ops.Planes(torch.nn.functional.pad(X.hi, (0, _pad128(X.hi.shape[1]) - X.hi.shape[1])), None, X.rows, X.cols)
+        else:
+            Xw = X
+        cin = Xw.hi.shape[1]
+        rows_red = B * (S + 2 * halo)
+        dWp = torch.empty(Dout, k * cin, device=dy.device, dtype=torch.float32)
+        sk = ops._splitk_for(Dout, k * cin, rows_red)
+        # the kernel pairs (A[r], B[r + tap]): A = gradient plane advanced by pad rows (zero halo rows skipped), B = activations
+        ops.gemm_bf16(ops.Planes(G.hi[pad:], None, rows_red, Dout), ops.Planes(Xw.hi, None, rows_red, cin), dWp,
+                      ldc=k * cin, precision=ops.PREC_BF16, a_km=True, b_km=True, splitk=sk,
+                      conv={"mode": 2, "N": k * cin, "cin": cin, "rows": Xw.rows})
+        dW = dWp.view(Dout, k, cin)[:, :, :Din].permute(0, 2, 1)
         db = ops.colsum(dz.view(-1, Dout))
         return dx, dW, db, None, None, None
 
@@ -311,6 +408,7 @@ class ProposalGenerator(nn.Module):
         sum_losses_dict = {}
         total_loss = 0
         cache = {}
+        x._bmt_halo = max(self.cfg.kernel_sizes[self.cfg.modality]) // 2     # the heads share one halo-padded copy (ConvKFn)
         for layer in self.detection_layers:
             predictions, loss, loss_dict = self.kernel_size_forward(x, layer, stride, targets, cache)
             total_loss += loss
@@ -388,6 +486,9 @@ class MultimodalProposalGenerator(nn.Module):
             V = self.pos_enc_V(self.emb_V(x['rgb'] + x['flow']))
             A = self.pos_enc_A(self.emb_A(x['audio']))
         Av, Va = self.encoder((A, V), masks)
+        # the ten heads of a modality share one halo-padded plane copy of the encoder output (ConvKFn)
+        Av._bmt_halo = max(self.cfg.kernel_sizes['audio']) // 2
+        Va._bmt_halo = max(self.cfg.kernel_sizes['video']) // 2
 
         all_predictions_A, all_predictions_V = [], []
         sum_losses_dict_A, sum_losses_dict_V = {}, {}

@@ -144,6 +144,17 @@ def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transp
     return (Planes(hi, lo_, R, Cc) if straight else None), (Planes(hiT, None, Cc, R) if transposed else None)
 
 
+def pad_planes(x3: torch.Tensor, halo: int, tail: int, lo: bool) -> Planes:
+    """x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][pad64(C)] (bmt_pad_planes): the activation operand of the
+    implicit Conv1d GEMMs.  rows / cols of the returned Planes describe the whole padded buffer."""
+    B, S, Cc = x3.shape
+    rows = B * (S + 2 * halo) + tail
+    hi = torch.empty(rows, _pad64(Cc), device=x3.device, dtype=torch.bfloat16)
+    lo_ = torch.empty(rows, _pad64(Cc), device=x3.device, dtype=torch.bfloat16) if lo else None
+    _lib.check(lib.bmt_pad_planes(_p(x3), B, S, Cc, halo, tail, _p(hi), _p(lo_), hi.stride(0), _st()), "bmt_pad_planes")
+    return Planes(hi, lo_, rows, Cc)
+
+
 def transpose_plane(pl: Planes) -> Planes:
     """hi plane [R][.] -> transposed hi plane [C][pad64(R)]"""
     dst = torch.empty(pl.cols, _pad64(pl.rows), device=pl.hi.device, dtype=torch.bfloat16)
@@ -345,14 +356,19 @@ TWO_PASS_SPLITK = True   # split-K through the workspace + epilogue kernel (Fals
 
 def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
               drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None, precision=None,
-              out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False):
+              out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False, conv=None):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded).
     a_km / b_km: that operand is given K-MAJOR -- its plane has the reduction index as the row ([K rows][M or N columns]), i.e.
     it is the transpose of what the product needs, read through the hardware transpose unit (single-pass precision only)."""
     M = A.cols if a_km else A.rows
     N = B.cols if b_km else B.rows
     Ktrue = 0
-    if a_km or b_km:
+    if conv is not None and conv["mode"] == 1:       # implicit Conv1d forward / dX: A = halo-padded activation plane (advanced view)
+        M, Kpad = conv["M"], B.hi.shape[1]
+    elif conv is not None and conv["mode"] == 2:     # implicit Conv1d dW: dY and the halo-padded activations, both k-major
+        Ktrue, N = A.rows, conv["N"]
+        Kpad = _pad64(Ktrue)
+    elif a_km or b_km:
         Ktrue = A.rows if a_km else B.rows
         Kpad = _pad64(Ktrue)
         assert (A.rows == Ktrue if a_km else A.hi.shape[1] == Kpad) and (B.rows == Ktrue if b_km else B.hi.shape[1] == Kpad), \
@@ -387,6 +403,10 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=
                      _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
                      drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec, splitk)
     a.a_kmajor, a.b_kmajor, a.K = int(a_km), int(b_km), Ktrue
+    if conv is not None:
+        a.N = N
+        a.conv_mode, a.conv_cin, a.conv_rows = conv["mode"], conv["cin"], conv["rows"]
+        a.conv_S, a.conv_halo = conv.get("S", 1), conv.get("halo", 0)
     if splitk != 1 and TWO_PASS_SPLITK:
         ws = splitk_workspace(A.hi.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4

@@ -112,8 +112,18 @@ typedef struct {
      * dX = dY . W takes the weight plane [N][K] as it is (b_kmajor = 1): no transposed copies of anything.  K: true reduction
      * length, Kpad = K rounded up to a multiple of 64. */
     int a_kmajor, b_kmajor, K;
+    /* implicit Conv1d over a HALO-PADDED activation plane X [rows][conv_cin] (bf16 planes; every sequence is followed by zero
+     * rows, so that row r + tap never leaves its sequence's halo; conv_rows = rows reachable from the given base pointer):
+     *   conv_mode 1 (forward, dX): A = X, reduction index = tap * conv_cin + c, Kpad = taps * conv_cin, B = weights [N][Kpad]
+     *                C[r][n] = epilogue( sum_{tap,c} X[r + tap][c] * B[n][tap * conv_cin + c] )      (move A_hi by halo - pad rows)
+     *   conv_mode 2 (dW): A = dY [K rows][M cols] k-major, B = X k-major; output column block j = tap * conv_cin + c
+     *                C[m][tap * conv_cin + c] = sum_r dY[r][m] * X[r + tap][c]                       (N = taps * conv_cin) */
+    int conv_mode, conv_cin, conv_rows;
+    int conv_S, conv_halo;      /* conv_mode 1: output rows are compact (m = b * S + s); they read rows m + 2 b * halo + tap of the advanced plane */
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
+/* x fp32 (B,S,C) -> halo-padded bf16 planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C); lo may be NULL */
+int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL
  * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
 int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
