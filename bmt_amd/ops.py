@@ -325,16 +325,6 @@ def as_planes(x, need_lo: bool) -> Planes:
     return make_planes(x, lo=need_lo)[0]
 
 
-def attached_planes(t: torch.Tensor, rows: int, cols: int, need_lo: bool) -> Optional[Planes]:
-    """planes a producer kernel already wrote for exactly this tensor object (set as ``t._bmt_planes``): the consumer
-    GEMM then skips its own conversion pass.  The attribute lives on the Python tensor object the producer returned, so it
-    can never describe other data; anything that makes a new tensor (autograd accumulation, .contiguous() copies) drops it."""
-    pl = getattr(t, "_bmt_planes", None)
-    if pl is None or pl.rows != rows or pl.cols != cols or (need_lo and pl.lo is None):
-        return None
-    return pl
-
-
 _SPLITK_WS = {}          # device index -> fp32 scratch; one compute stream per device
 SPLITK_WS_BYTES = 128 << 20
 
