@@ -91,3 +91,28 @@ def test_reducer_single_process_is_a_noop_binding():
     torch.testing.assert_close(lin.weight.grad, torch.full((3, 4), 2.0))
     red.zero_grad()
     assert float(lin.weight.grad.abs().sum()) == 0.0
+
+
+def test_reducer_lays_grouped_gradients_back_to_back():
+    """GradientReducer(groups=...): the gradients of a group are adjacent, in group order, inside one bucket (what lets the
+    fused Q/K/V weight gradient be written by one GEMM), whatever the registration order and the bucket size"""
+    import torch
+    from bmt_amd.parallel import GradientReducer
+    ps = [torch.nn.Parameter(torch.randn(n, 3)) for n in (4, 5, 6, 7, 8, 9)]
+    groups = [[ps[4], ps[1], ps[2]]]
+    red = GradientReducer(ps, bucket_bytes=40 * 4, groups=groups)
+    try:
+        a, b, c = ps[4].grad, ps[1].grad, ps[2].grad
+        assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+        assert b.storage_offset() == a.storage_offset() + a.numel() and c.storage_offset() == b.storage_offset() + b.numel()
+        # every parameter still owns a distinct slot and accumulates into it
+        seen = set()
+        for p in ps:
+            key = (p.grad.untyped_storage().data_ptr(), p.grad.storage_offset())
+            assert key not in seen
+            seen.add(key)
+        (sum((p * (i + 1)).sum() for i, p in enumerate(ps))).backward()
+        for i, p in enumerate(ps):
+            assert torch.equal(p.grad, torch.full_like(p, float(i + 1)))
+    finally:
+        red.remove()
