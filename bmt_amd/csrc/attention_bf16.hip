@@ -701,7 +701,14 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, in
     const int64_t poff = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK;
     float s = 0.f;
     for (int d = lane * 4; d < DK; d += 256) {
-        const float4 a = *reinterpret_cast<const float4*>(p.dO + off + d);
+        float4 a;
+        if (p.dO) {
+            a = *reinterpret_cast<const float4*>(p.dO + off + d);
+        } else {          // dO arrives as the bf16 plane the MFMAs read (written by the out-projection's dX epilogue)
+            const u32x2 gh = *reinterpret_cast<const u32x2*>(dOh + off + d);
+            a.x = __uint_as_float(gh[0] << 16); a.y = __uint_as_float(gh[0] & 0xffff0000u);
+            a.z = __uint_as_float(gh[1] << 16); a.w = __uint_as_float(gh[1] & 0xffff0000u);
+        }
         float4 c;
         if (p.O) {
             c = *reinterpret_cast<const float4*>(p.O + off + d);
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, in
             c.w = __uint_as_float(hh[1] & 0xffff0000u) + __uint_as_float(ll[1] & 0xffff0000u);
         }
         s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
-        *reinterpret_cast<uint2*>(dOh + off + d) = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+        if (p.dO) *reinterpret_cast<uint2*>(dOh + off + d) = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
     }
     s = wave_sum(s);
     if (lane == 0) p.delta[row] = s * (1.f - p.drop_p);
@@ -1361,7 +1368,7 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
 }
 
 extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) {
-    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh) && a->dO && a->lse && a->delta_ws && a->dOh_ws,
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh) && a->lse && a->delta_ws && a->dOh_ws,
                   "bmt_attn_bwd_bf16: null pointer");
     BMT_CHECK_ARG((a->dQ || a->dQh) && (a->dK || a->dKh) && (a->dV || a->dVh), "bmt_attn_bwd_bf16: every gradient needs an fp32 or a plane output");
     BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_bwd_bf16: bad sizes");

@@ -465,12 +465,13 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
              precision=BWD_PRECISION, **epi)
         return out
     A = as_planes(dy, BWD_PRECISION == PREC_BF16X3)
-    if out is None:
+    if out is None and epi.get("out_planes") is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
     if "ldg" in epi:
         epi.pop("ldg")
     if _kmajor():       # the weight plane [N][K] as stored: its row IS the reduction index
-        gemm_bf16(A, weight_planes(W), out, ldc=out.stride(0), precision=PREC_BF16, b_km=True, **epi)
+        gemm_bf16(A, weight_planes(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
+        return out if out is not None else epi["out_planes"]
     else:
         Wt = weight_planes(W, transposed=True)          # [K][pad64(N)]
         gemm_bf16(A, Wt, out, ldc=out.stride(0), precision=BWD_PRECISION, **epi)
@@ -755,7 +756,11 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor
             db = torch.zeros(D, device=dev, dtype=torch.float32)
         outs.append((hi, hiT, gb if gb is not None else db, db))
     delta = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
-    doh = torch.empty(B, Sq, D, device=dev, dtype=torch.bfloat16)
+    if isinstance(do, Planes):       # dO already as the bf16 plane the kernels read
+        assert do.hi.stride(0) == D and do.rows == Mq, (do.hi.shape, D, Mq)
+        doh, do = do.hi, None
+    else:
+        doh = torch.empty(B, Sq, D, device=dev, dtype=torch.bfloat16)
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
     ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), o.hi.stride(0)
     (qh_, qT_, qb_, _), (kh_, kT_, kb_, _), (vh_, vT_, vb_, _) = outs
@@ -1040,7 +1045,13 @@ class MHAFn(torch.autograd.Function):
             QT, KT, VT = Planes(QTh, None, Dq, Mq), Planes(KTh, None, Dk_in, Mk), Planes(VTh, None, Dv_in, Mk)
         dy2 = _f32c(dout).view(-1, Dq)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
-        do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(input_t(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
+        if _kmajor() and D % 64 == 0 and _os.environ.get("BMT_DO_FP32") != "1":      # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
+            P_, T_, bias_done = grad_planes(dy2, bop)
+            do = linear_dx(P_, Wop, out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
+                           drop_post=True, drop_p=ctx.p, site=ctx.site)
+            dWo, dbo = wgrad(Wop, None if bias_done else bop, T_, input_t(o), dy2_for_bias=dy2)
+        else:
+            do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(input_t(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
         res = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p, (bqp, bkp, bvp), fuse=ctx.fuse)
         (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = res[:3]
         comb = res[3] if len(res) > 3 else None

@@ -189,7 +189,8 @@ int bmt_attn_bwd(const bmt_attn_bwd_args* args, void* stream);
  * Outputs that feed GEMMs can be produced directly as operand planes, so that no conversion pass runs over them:
  *   forward : Oh / Ol (hi, lo planes of the post-dropout output; row b*Sq+q at b*bsop + q*ldop).  O (fp32) may then be NULL;
  *             ldo / bso must still describe the logical fp32 layout (they index the dropout mask).
- *   backward: the saved output comes back as Oh / Ol when O is NULL.  Each gradient has up to four forms, all optional
+ *   backward: the saved output comes back as Oh / Ol when O is NULL; with dO == NULL, dOh_ws is an INPUT: the gradient of the
+ *             output already as a bf16 plane (ldo / bso strides), e.g. written by the out-projection's dX GEMM epilogue.  Each gradient has up to four forms, all optional
  *             but at least one of {fp32, hi plane}: fp32 (dQ|dK|dV), bf16 plane (dQh|dKh|dVh: row b*S+s at b*g?_bs + s*g?_ld),
  *             transposed bf16 plane (dQT|dKT|dVT: [H*dk][g?T_ld], column b*S+s; the caller zero-fills columns past B*S) and
  *             bias sums (dbq|dbk|dbv: fp32 [H*dk] += sum over (b,s), atomics; summed from the bf16-rounded values).
