@@ -226,6 +226,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
         const u32x4* sBh = stage_ptr(buf_, 1);                                            \
         const u32x4* sAl = stage_ptr(buf_, 2);                                            \
         const u32x4* sBl = stage_ptr(buf_, 3);                                            \
+        __builtin_amdgcn_s_setprio(1);                                                    \
         _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                             \
             const int sl = 2 * s + half;                                                  \
             bf16x8 ah[TI], bh[2], al[TI], bl[2];                                          \
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
                     acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);                          \
                 }                                                                         \
         }                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                    \
     } while (0)
 
     const int niter = (kend - kbeg) / BK;     // >= 1: the host never launches an empty split
