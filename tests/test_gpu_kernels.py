@@ -221,6 +221,35 @@ def test_attention_forward(ops, dk, H, B, Sq, Sk, kind, prec):
     assert_close(lse, torch.logsumexp(s, -1), atol=2e-3 if prec == 1 else 2e-4, name="lse")
 
 
+@pytest.mark.parametrize("dk,H", [(256, 2), (128, 2), (64, 2)])
+@pytest.mark.parametrize("prec", [1, 3])
+def test_attention_forward_rescale_branch(ops, dk, H, prec):
+    """the online softmax keeps a STALE reference and rescales only when a score exceeds it by e^8: a rare, data-dependent branch
+    that bounded random data never takes after the first tiles.  Force it late and repeatedly: a few (query, key) pairs far apart
+    along the key axis get scores 10, 25, 45 above everything before them; also rows whose maximum sits in the FIRST tile (the
+    branch is never taken again) and a row of large negative scores."""
+    B, Sq, Sk = 2, 70, 300
+    D = dk * H
+    q, k, v = rnd(B, Sq, D, seed=50) * 0.3, rnd(B, Sk, D, seed=51) * 0.3, rnd(B, Sk, D, seed=52)
+    scale = math.sqrt(dk)
+    for (b, qi, ki, boost) in ((0, 3, 40, 10.0), (0, 3, 150, 25.0), (0, 3, 290, 45.0), (1, 17, 5, 60.0), (1, 33, 299, 30.0), (0, 64, 200, 12.0)):
+        for h in range(H):
+            sl = slice(h * dk, (h + 1) * dk)
+            qv = q[b, qi, sl]
+            k[b, ki, sl] = qv / qv.norm() ** 2 * boost * scale      # q . k / sqrt(dk) == boost
+    q[1, 50] *= -40.0                                                 # a row of large-magnitude scores of both signs
+    mask = torch.ones(B, 1, Sk, dtype=torch.bool)
+    mask[1, 0, 280:295] = False
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask.to(DEV), H, precision=prec)
+    want = _oracle_attention(q, k, v, mask, H, rounded=(prec == 1))
+    assert_close(o, want, atol=(3e-2 if prec == 1 else 3e-4), rtol=0, name=f"attn o with forced rescales dk={dk} x{prec}")
+    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
+    s_ = torch.einsum("bqhd,bkhd->bhqk", f(q).view(B, Sq, H, dk), f(k).view(B, Sk, H, dk)) / math.sqrt(dk)
+    s_ = s_.masked_fill(~mask.unsqueeze(1), -float("inf"))
+    assert_close(lse, torch.logsumexp(s_, -1), atol=(5e-2 if prec == 1 else 1e-3), rtol=1e-5, name="lse with forced rescales")
+
+
 def _planes(t):
     hi = t.to(torch.bfloat16)
     lo = (t - hi.float()).to(torch.bfloat16)
