@@ -264,7 +264,7 @@ def test_train_step_matches_oracle(golden):
         with torch.no_grad():
             for k in p:
                 orc.adam_step(p[k], p[k].grad, m[k], v2[k], step, 1e-3)
-        assert abs(float(loss) - float(oloss)) < 2e-3, (step, float(loss), float(oloss))
+        assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-3, (step, float(loss.detach()), float(oloss.detach()))
     sd = model.state_dict()
     agree, total = 0, 0
     for k in p:
