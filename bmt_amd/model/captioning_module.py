@@ -149,27 +149,33 @@ class BiModalTransformer(nn.Module):
             for param in self.encoder.parameters():
                 param.requires_grad = cfg.finetune_prop_encoder
 
-    def forward(self, src: dict, trg, masks: dict):
-        if self.training:
-            ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
+    def encode(self, src: dict, masks: dict):
+        """features -> encoder memory (Av, Va): rgb + flow, (optional) linear embedders, positional tables, dropout, bi-modal
+        encoder (reference :165-181).  Independent of the caption prefix: greedy decoding calls it once (bmt_amd.decode)."""
         A = src['audio']
-        C = trg
-
-        # rgb + flow, (optional) linear embedders, positional tables, dropout  (reference :165-176)
         if isinstance(self.emb_V, Identity):
             V = self.pos_enc_V(src['rgb'], fuse_add=src['flow'])
             A = self.pos_enc_A(A)
         else:
             V = self.pos_enc_V(self.emb_V(src['rgb'] + src['flow']))
             A = self.pos_enc_A(self.emb_A(A))
+        return self.encoder((A, V), masks)
+
+    def decode(self, trg, memory, masks: dict):
+        """caption prefix + encoder memory -> decoder states (B, Sc, Dc)  (reference :172-173,182-184)"""
+        C = trg
         if isinstance(self.emb_C.embedder, nn.Embedding):
             pc = self.pos_enc_C
             C = _embed(self.emb_C, C, pe=pc.table(self.emb_C.embedder.weight.device),
                        p=pc.dout_p if self.training else 0.0, site=pc._site)
         else:
             C = self.pos_enc_C(self.emb_C(C))
+        return self.decoder((C, memory), masks)
 
-        Av, Va = self.encoder((A, V), masks)
-        C = self.decoder((C, (Av, Va)), masks)
+    def forward(self, src: dict, trg, masks: dict):
+        if self.training:
+            ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
+        memory = self.encode(src, masks)
+        C = self.decode(trg, memory, masks)
         # (B, Sc, Vc) <- (B, Sc, Dc)
         return self.generator(C)

@@ -66,6 +66,11 @@ class MultiheadedAttention(nn.Module):
     def forward(self, Q, K, V, mask):
         ''' Q, K, V: (B, Sq, Dq), (B, Sk, Dk), (B, Sv, Dv); mask: (B, 1, Sk) or (B, Sq, Sk) '''
         p = self.dout_p if self.training else 0.0
+        if ops.KV_CACHE is not None and not torch.is_grad_enabled() and K is V and K is not Q and ops.USE_PLANE_GEMM:
+            # greedy decoding: the key / value projections of the encoder memory are computed once per decode (bmt_amd.decode)
+            return ops.mha_infer(Q, K, mask, self.linear_Q2d.weight, self.linear_Q2d.bias, self.linear_K2d.weight, self.linear_K2d.bias,
+                                 self.linear_V2d.weight, self.linear_V2d.bias, self.linear_d2Q.weight, self.linear_d2Q.bias,
+                                 self.H, ops.KV_CACHE, id(self))
         fn = ops.MHAFn if ops.USE_PLANE_GEMM else ops.MHAFnStaged
         return fn.apply(Q, K, V, mask,
                                self.linear_Q2d.weight, self.linear_Q2d.bias,

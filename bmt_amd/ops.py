@@ -960,6 +960,54 @@ def _planes_to_f32(pl: Planes) -> torch.Tensor:
     return y.contiguous()
 
 
+def project_group(Xp: Planes, Ws, bs, x3: bool):
+    """projections that read the same input as ONE GEMM over adjacent weight planes (q|k|v or k|v column blocks of one plane
+    buffer, which the attention kernels address with the buffer's row stride); None if the weights cannot be grouped"""
+    grp = weight_group(Ws, bs)
+    if grp is None:
+        return None
+    gst, _, gb = grp
+    Nt = gst.rows
+    hi = torch.empty(Xp.rows, Nt, device=Xp.hi.device, dtype=torch.bfloat16)
+    lo = torch.empty(Xp.rows, Nt, device=Xp.hi.device, dtype=torch.bfloat16) if x3 else None
+    gemm_bf16(Xp, gst, None, bias=gb, out_planes=Planes(hi, lo, Xp.rows, Nt))
+    outs, off = [], 0
+    for W in Ws:
+        N = W.shape[0]
+        outs.append(Planes(hi[:, off:off + N], None if lo is None else lo[:, off:off + N], Xp.rows, N))
+        off += N
+    return outs
+
+
+KV_CACHE = None      # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory tensor, k planes, v planes)
+
+
+def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key):
+    """MultiheadedAttention.forward for inference with K is V (cross-attention over the encoder memory): the key / value
+    projections are taken from ``cache`` when they were computed for the same memory tensor before (greedy decoding re-uses
+    them for every generated token; the reference re-encodes the video and re-projects the memory per token,
+    epoch_loops/captioning_epoch_loops.py:58-61)."""
+    x3 = FWD_PRECISION == PREC_BF16X3
+    Qc = _f32c(Q)
+    B, Sq, Dq = Qc.shape
+    D = Wq.shape[0]
+    Sk = K.shape[1]
+    ent = cache.get(key)
+    if ent is None or ent[0] is not K:
+        Kc = _f32c(K)
+        Kp = make_planes(Kc.view(-1, Kc.shape[-1]), lo=x3)[0]
+        r = project_group(Kp, (Wk, Wv), (bk, bv), x3)
+        if r is None:
+            r = (linear_fwd_planes(Kp, Wk, bk, want_lo=x3), linear_fwd_planes(Kp, Wv, bv, want_lo=x3))
+        ent = (K, r[0], r[1])
+        cache[key] = ent
+    k, v = ent[1], ent[2]
+    Qp = make_planes(Qc.view(-1, Dq), lo=x3)[0]
+    q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
+    o, _ = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H)
+    return linear_fwd(o, Wo, bo).view(B, Sq, Dq)
+
+
 class MHAFn(torch.autograd.Function):
     """MultiheadedAttention.forward model/multihead_attention.py:55-86: three input projections, the masked
     softmax-attention core with dropout on its OUTPUT (:22-23), head merge and output projection.
@@ -986,23 +1034,7 @@ class MHAFn(torch.autograd.Function):
         Qp, QT = split(Qc)
         Kp, KT = (Qp, QT) if same_qk else split(Kc)
         Vp, VT = (Kp, KT) if same_kv else split(Vc)
-        # projections that read the same input run as ONE GEMM over adjacent weight planes (q|k|v or k|v column blocks of one
-        # plane buffer, which the attention kernels address with the buffer's row stride)
-        def fused_proj(Xp, Ws, bs):
-            grp = weight_group(Ws, bs)
-            if grp is None:
-                return None
-            gst, _, gb = grp
-            Nt = gst.rows
-            hi = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16)
-            lo = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16) if x3 else None
-            gemm_bf16(Xp, gst, None, bias=gb, out_planes=Planes(hi, lo, Xp.rows, Nt))
-            outs, off = [], 0
-            for W in Ws:
-                N = W.shape[0]
-                outs.append(Planes(hi[:, off:off + N], None if lo is None else lo[:, off:off + N], Xp.rows, N))
-                off += N
-            return outs
+        fused_proj = lambda Xp, Ws, bs: project_group(Xp, Ws, bs, x3)
         fuse = None
         q = k = v = None
         if same_qk and same_kv:
@@ -1145,8 +1177,6 @@ class MHAFnStaged(torch.autograd.Function):
             Qp, Kp, Vp = Q2, K2, V2
         # the projections write bf16 operand planes (hi, lo) straight from the GEMM epilogue; the attention kernels
         # consume them as MFMA operands without any conversion.  Only the hi planes are kept for backward.
-        # projections that read the same input run as ONE GEMM over adjacent weight planes (q|k|v or k|v column blocks of one
-        # plane buffer, which the attention kernels address with the buffer's row stride)
         def fused_proj(Xp, Ws, bs):
             grp = weight_group(Ws, bs)
             if grp is None:

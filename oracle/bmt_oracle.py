@@ -538,3 +538,27 @@ def state_dict_digest(sd: Params) -> str:
         t = sd[k].detach().cpu().contiguous()
         h.update(k.encode()); h.update(str(tuple(t.shape)).encode()); h.update(t.numpy().tobytes())
     return h.hexdigest()
+
+
+# --------------------------------------------------------------------------------------
+# greedy decoding  (epoch_loops/captioning_epoch_loops.py:39-65)
+# --------------------------------------------------------------------------------------
+def greedy_decode(p: Params, cfg, src: Dict[str, Tensor], max_len: int, start_idx: int, end_idx: int, pad_idx: int,
+                  return_margins: bool = False):
+    """greedy_decoder, restated: start from <s>, run the WHOLE model on the growing prefix, append the arg-max of the last
+    position, stop when every sequence has produced </s> or the prefix is longer than max_len (:58-63).  Sequences keep
+    growing after their </s> (the reference does not pad them).  ``return_margins``: also the top-1 minus top-2 log-prob of
+    every decision (test infrastructure: a decision with a tiny margin is not a fair bit-exactness target)."""
+    B = src["audio"].shape[0]
+    done = torch.zeros(B, 1, dtype=torch.bool)
+    trg = torch.full((B, 1), start_idx, dtype=torch.long)
+    margins = []
+    while trg.size(-1) <= max_len and not bool(done.all()):
+        masks = make_masks(src, trg, pad_idx)
+        preds = bimodal_transformer(p, cfg, src, trg, masks)
+        top2 = preds[:, -1].topk(2, dim=-1)
+        nxt = top2.indices[:, :1]
+        margins.append(top2.values[:, 0] - top2.values[:, 1])
+        trg = torch.cat([trg, nxt], dim=-1)
+        done = done | (nxt == end_idx)
+    return (trg, torch.stack(margins, 1)) if return_margins else trg

@@ -191,3 +191,19 @@ def test_tiny_proposal_generator(golden):
     preds2, loss2, _, _ = orc.multimodal_proposal_generator(p, cfg, anchors, src, None, masks)
     close(preds2, g["preds_notargets"], atol=2e-5, rtol=1e-4)
     assert loss2 == 0
+
+
+@pytest.mark.parametrize("tag,cfgfn", [("tiny", syn.cfg_tiny), ("cfg0", syn.cfg_config0)])
+def test_greedy_decode(golden, tag, cfgfn):
+    """the oracle's greedy decoder against the token matrices the REFERENCE's greedy_decoder produced
+    (tests/golden/make_golden_decode.py); weights re-created from the seed, generator weight scaled as in the generator."""
+    g = golden("greedy_decode.npz")
+    V, B, Tv, Ta, max_len, seed = [int(x) for x in g.np(f"{tag}/meta")]
+    cfg = cfgfn()
+    sd = orc.init_captioning_params(cfg, V, seed=0, glove=syn.make_glove(V, cfg.d_model_caps))
+    sd["generator.linear.weight"] = sd["generator.linear.weight"] * float(g.np(f"{tag}/wscale"))
+    fs = syn.make_cap_batch(cfg, B, Tv, Ta, 4, V, seed=seed)["feature_stacks"]
+    trg, margins = orc.greedy_decode(sd, cfg, fs, max_len, syn.START_IDX, syn.END_IDX, syn.PAD_IDX, return_margins=True)
+    assert torch.equal(trg, g[f"{tag}/tokens"])
+    close(margins, g[f"{tag}/margins"], atol=1e-4)
+    assert trg.shape[1] <= max_len + 1 and bool((trg[:, 0] == syn.START_IDX).all())
