@@ -20,6 +20,7 @@ class Transformer(nn.Module):
 
     def __init__(self, train_dataset, cfg):
         super(Transformer, self).__init__()
+        self.register_load_state_dict_post_hook(ops.weights_changed)   # cached bf16 weight planes go stale
         self.modality = cfg.modality
 
         if cfg.modality == 'video':
@@ -102,6 +103,7 @@ class BiModalTransformer(nn.Module):
 
     def __init__(self, cfg, train_dataset):
         super(BiModalTransformer, self).__init__()
+        self.register_load_state_dict_post_hook(ops.weights_changed)   # cached bf16 weight planes go stale
 
         if cfg.use_linear_embedder:
             self.emb_A = FeatureEmbedder(cfg.d_aud, cfg.d_model_audio)

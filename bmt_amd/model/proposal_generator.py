@@ -334,6 +334,7 @@ class ProposalGenerator(nn.Module):
 
     def __init__(self, cfg, anchors):
         super(ProposalGenerator, self).__init__()
+        self.register_load_state_dict_post_hook(ops.weights_changed)   # cached bf16 weight planes go stale
         self.cfg = cfg
         self.EPS = 1e-16
         self.num_logits = 3  # 3: c, w, obj
@@ -423,6 +424,7 @@ class MultimodalProposalGenerator(nn.Module):
 
     def __init__(self, cfg, anchors):
         super(MultimodalProposalGenerator, self).__init__()
+        self.register_load_state_dict_post_hook(ops.weights_changed)   # cached bf16 weight planes go stale
         assert cfg.modality == 'audio_video'
         self.cfg = cfg
         self.anchors = anchors

@@ -36,6 +36,11 @@ USE_PLANE_GEMM = True
 WEIGHT_EPOCH = [0]      # bumped by the optimizer: invalidates cached weight planes
 
 
+def weights_changed(*_):
+    """call after writing parameters behind the optimizer's back (load_state_dict does, through a module hook)"""
+    WEIGHT_EPOCH[0] += 1
+
+
 # ----------------------------------------------------------------------------- plumbing
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -49,6 +49,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._steps = {}
         self.grad_scale = None   # optional device float multiplied into every gradient inside the kernel
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam / FusedAdam state (``optimizer_state_dict`` of a reference checkpoint): the pointer tables and the
+        device step counters are rebuilt at the next step from the loaded state"""
+        super().load_state_dict(state_dict)
+        self._tables, self._steps = {}, {}
+        for st in self.state.values():      # torch.optim.Adam keeps ``step`` as a tensor (possibly on the device) or a float
+            if "step" in st:
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -70,7 +79,8 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam needs contiguous fp32 parameters and gradients")
             if gi not in self._tables:
                 self._tables[gi] = _PtrTable(dev)
-                self._steps[gi] = torch.zeros(1, dtype=torch.int64, device=dev)
+                # device-side step counter; resumes from a loaded state_dict (torch layout: one ``step`` per parameter)
+                self._steps[gi] = torch.full((1,), int(self.state[ps[0]]["step"]), dtype=torch.int64, device=dev)
             tab = self._tables[gi]
             tab.update([ps, [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
                         [self.state[p]["exp_avg_sq"] for p in ps]])
