@@ -91,9 +91,20 @@ class Conv1dArgs(C.Structure):
                 ("gate", vp), ("gate_scale", f32), ("precision", i32), ("splitk", i32)]
 
 
+class SelectProposalsArgs(C.Structure):
+    _fields_ = [("preds", vp), ("B", i32), ("S", i64), ("k", i32), ("flags", C.c_uint), ("durations", vp),
+                ("min_len", f32), ("nms_thresh", f32), ("out", vp), ("out_idx", vp), ("count", vp), ("ws", vp),
+                ("ws_bytes", C.c_size_t)]
+
+
+PP_CORNERS, PP_TRIM, PP_FILTER = 1, 2, 4
+
 # name -> (restype, argtypes); every symbol include/bmt_hip.h declares
 SIGNATURES = {
     "bmt_version": (i32, []),
+    "bmt_select_proposals_ws_bytes": (C.c_size_t, [i32, i64, i32]),
+    "bmt_select_proposals": (i32, [C.POINTER(SelectProposalsArgs), vp]),
+    "bmt_transform_proposals": (i32, [vp, i32, i64, C.c_uint, vp, vp]),
     "bmt_last_error": (C.c_char_p, []),
     "bmt_device_cus": (i32, []),
     "bmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),

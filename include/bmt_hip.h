@@ -342,6 +342,39 @@ int bmt_prop_loss_bwd(const float* x, int B, int S, int A, const uint8_t* obj, c
                       const float* tx, const float* tw, const float* loss_ws, float obj_coeff, float noobj_coeff,
                       const float* gscale_dev, float* dx, void* stream);
 
+/* ---------------------------------------------------------------- proposal post-processing
+ * Replaces utilities/proposal_utils.py:115-121 (get_corner_coords), :136-149 (select_topk_predictions: argsort over all S
+ * candidates), :152-161 (trim_proposals), :163-172 (remove_very_short_segments), :175-194 (non_max_suppresion) and their
+ * compositions :196-212 (postprocess_preds) and sample/single_video_prediction.py:176-186 (generate_proposals).
+ * preds: [B, S, 3] fp32 rows (center_s, length_s, confidence) -- or (start, end, confidence) without BMT_PP_CORNERS.
+ * Selection: the k rows of largest confidence per video, descending; equal confidences in candidate-index order (a stable
+ * descending sort).  With BMT_PP_FILTER only rows whose transformed segment has end - start > min_len are candidates.
+ * out: [B, k, 3] transformed rows (start, end, confidence), rows >= count[b] are zero; out_idx (optional): [B, k] int64
+ * candidate indices (-1 beyond count[b]); nms_thresh >= 0 applies greedy NMS to the selected rows (kept while tIoU <
+ * nms_thresh against every kept row before it), count[b] is the number that survive. k <= 2048, S < 2^32. */
+#define BMT_PP_CORNERS 1u   /* (center, length) -> (start, end) */
+#define BMT_PP_TRIM 2u      /* start = min(max(start, 0), duration), end = min(end, duration) */
+#define BMT_PP_FILTER 4u    /* candidates must satisfy end - start > min_len (after CORNERS / TRIM) */
+typedef struct {
+    const float* preds;
+    int B;
+    int64_t S;
+    int k;
+    unsigned flags;
+    const float* durations; /* [B] seconds (device); required with BMT_PP_TRIM */
+    float min_len;
+    float nms_thresh;       /* < 0: no NMS */
+    float* out;
+    int64_t* out_idx;       /* may be NULL */
+    int* count;             /* [B] */
+    void* ws;               /* bmt_select_proposals_ws_bytes(B, S, k) bytes */
+    size_t ws_bytes;
+} bmt_select_proposals_args;
+size_t bmt_select_proposals_ws_bytes(int B, int64_t S, int k);
+int bmt_select_proposals(const bmt_select_proposals_args* a, void* stream);
+/* in place over every candidate: the CORNERS / TRIM transforms above (get_corner_coords, trim_proposals) */
+int bmt_transform_proposals(float* preds, int B, int64_t S, unsigned flags, const float* durations, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -562,3 +562,75 @@ def greedy_decode(p: Params, cfg, src: Dict[str, Tensor], max_len: int, start_id
         trg = torch.cat([trg, nxt], dim=-1)
         done = done | (nxt == end_idx)
     return (trg, torch.stack(margins, 1)) if return_margins else trg
+
+
+# --------------------------------------------------------------------------------------
+# proposal post-processing  (utilities/proposal_utils.py:115-212, sample/single_video_prediction.py:176-186)
+# --------------------------------------------------------------------------------------
+def select_topk_predictions(model_output: Tensor, k: int, return_indices: bool = False):
+    """utilities/proposal_utils.py:136-149: sort every video's rows by confidence (column 2), descending, keep k.
+    The reference's ``argsort(descending=True)`` is not a stable sort: among EQUAL confidences its order is whatever the
+    sort implementation leaves (probed: neither ascending nor descending index).  This restatement -- and the device kernel
+    -- fix that freedom to candidate-index order (``stable=True``); on inputs without equal confidences it is the
+    reference's result bit for bit, with ties it is one of the orders the reference's contract allows."""
+    B, S, F = model_output.shape
+    idx = model_output[:, :, 2].argsort(dim=-1, descending=True, stable=True)[:, :k]
+    out = model_output.gather(1, idx.view(B, -1, 1).repeat(1, 1, F))
+    return (out, idx) if return_indices else out
+
+
+def get_corner_coords(predictions: Tensor) -> Tensor:
+    """:115-121 (center, length) -> (start, end); returns a new tensor (the reference writes in place)"""
+    out = predictions.clone()
+    out[:, :, 0] = predictions[:, :, 0] - predictions[:, :, 1] / 2
+    out[:, :, 1] = predictions[:, :, 0] + predictions[:, :, 1] / 2
+    return out
+
+
+def trim_proposals(model_output: Tensor, duration_in_secs) -> Tensor:
+    """:152-161 start clipped to [0, duration], end clipped to <= duration (an end below 0 stays)"""
+    dur = torch.as_tensor(duration_in_secs, dtype=torch.float32).view(-1, 1)
+    out = model_output.clone()
+    out[:, :, 0] = model_output[:, :, 0].max(torch.tensor([0.0])).min(dur)
+    out[:, :, 1] = model_output[:, :, 1].min(dur)
+    return out
+
+
+def remove_very_short_segments(model_output: Tensor, shortest_segment_prior: float) -> Tensor:
+    """:163-172, batch of one video"""
+    assert model_output.shape[0] == 1
+    lengths = model_output[0, :, 1] - model_output[0, :, 0]
+    return model_output[:, lengths > shortest_segment_prior, :]
+
+
+def tiou_start_end(one: Tensor, many: Tensor) -> Tensor:
+    """tiou_vectorized(center_length=False) of one (start, end) segment against N, :11-57"""
+    s1, e1, s2, e2 = one[0], one[1], many[:, 0], many[:, 1]
+    inter = torch.clamp(torch.min(e1, e2) - torch.max(s1, s2), min=0.0)
+    union = (e1 - s1) + (e2 - s2) - inter
+    union = torch.min(torch.max(e1, e2) - torch.min(s1, s2), union)
+    return inter / (union + 1e-8)
+
+
+def non_max_suppression(video_preds: Tensor, tiou_threshold: float) -> Tensor:
+    """:175-194 greedy NMS over rows sorted by confidence: keep the head, drop every remaining row whose tIoU with it is not
+    below the threshold, repeat"""
+    kept = []
+    while len(video_preds) > 0:
+        kept.append(video_preds[:1])
+        if len(video_preds) == 1:
+            break
+        t = tiou_start_end(video_preds[0], video_preds[1:])
+        video_preds = video_preds[1:][t < tiou_threshold]
+    return torch.cat(kept) if kept else video_preds
+
+
+def postprocess_preds(model_output: Tensor, k: int, duration_in_secs) -> Tensor:
+    """:196-212 (validation loop): top-k -> corners -> trim"""
+    return trim_proposals(get_corner_coords(select_topk_predictions(model_output, k)), duration_in_secs)
+
+
+def generate_proposals_post(predictions: Tensor, duration_in_secs: float, k: int, shortest_segment_prior: float = 0.2) -> Tensor:
+    """sample/single_video_prediction.py:176-186 (one video): corners -> trim -> drop short -> top-k"""
+    p = trim_proposals(get_corner_coords(predictions), [duration_in_secs])
+    return select_topk_predictions(remove_very_short_segments(p, shortest_segment_prior), k)

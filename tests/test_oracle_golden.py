@@ -207,3 +207,33 @@ def test_greedy_decode(golden, tag, cfgfn):
     assert torch.equal(trg, g[f"{tag}/tokens"])
     close(margins, g[f"{tag}/margins"], atol=1e-4)
     assert trg.shape[1] <= max_len + 1 and bool((trg[:, 0] == syn.START_IDX).all())
+
+
+# ---------------------------------------------------------------- proposal post-processing
+def test_postprocess_oracle_matches_reference_outputs(golden):
+    """oracle restatement of utilities/proposal_utils.py:115-212 against the outputs the reference produced on the seeded
+    inputs (tests/golden/make_golden_postprocess.py).  Distinct confidences: bit-exact.  Quantised confidences: the
+    reference's unstable argsort leaves the order inside a tie group open, so the confidence columns must agree and every
+    row must be an input row."""
+    from tests.postprocess_util import CASES, make_preds
+    g = golden("postprocess.npz")
+    for tag, (B, S, k, seed, ties) in CASES.items():
+        preds, dur = make_preds(B, S, seed, ties)
+        post = orc.postprocess_preds(preds, k, dur)
+        topk = orc.select_topk_predictions(preds, k)
+        if not ties:
+            assert torch.equal(post, g[f"{tag}/post"]) and torch.equal(topk, g[f"{tag}/topk"]), tag
+        else:
+            assert torch.equal(post[:, :, 2], g[f"{tag}/post"][:, :, 2]), tag
+            rows = {tuple(r) for r in preds[0].tolist()}
+            assert all(tuple(r) in rows for r in topk[0].tolist())
+        for thr in (0.3, 0.7):
+            for b in range(B):
+                ref_in = g[f"{tag}/post"][b]         # NMS on the reference's own sorted rows: always unique
+                assert torch.equal(orc.non_max_suppression(ref_in, thr), g[f"{tag}/nms{thr}/{b}"]), (tag, thr, b)
+        for b in range(B):
+            gen = orc.generate_proposals_post(preds[b:b + 1], dur[b], k)
+            want = g[f"{tag}/gen/{b}"]
+            assert torch.equal(gen, want) if not ties else torch.equal(gen[:, :, 2], want[:, :, 2]), (tag, b)
+        assert torch.equal(orc.get_corner_coords(preds)[:, :64], g[f"{tag}/corners_head"])
+        assert torch.equal(orc.trim_proposals(orc.get_corner_coords(preds), dur)[:, :64], g[f"{tag}/trim_head"])
