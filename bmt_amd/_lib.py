@@ -102,6 +102,9 @@ PP_CORNERS, PP_TRIM, PP_FILTER = 1, 2, 4
 # name -> (restype, argtypes); every symbol include/bmt_hip.h declares
 SIGNATURES = {
     "bmt_version": (i32, []),
+    "bmt_npy_shape": (i32, [C.c_char_p, vp, vp, vp]),
+    "bmt_npy_read_rows": (i32, [C.c_char_p, i64, i64, vp, i64, vp, vp]),
+    "bmt_pad_batch": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
     "bmt_select_proposals_ws_bytes": (C.c_size_t, [i32, i64, i32]),
     "bmt_select_proposals": (i32, [C.POINTER(SelectProposalsArgs), vp]),
     "bmt_transform_proposals": (i32, [vp, i32, i64, C.c_uint, vp, vp]),
@@ -170,6 +173,9 @@ def load():
         raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 1")
     _lib = lib
     return lib
+
+
+ENOENT = -3     # BMT_ENOENT: a feature file cannot be opened
 
 
 def check(rc: int, what: str):

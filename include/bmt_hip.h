@@ -31,6 +31,7 @@ extern "C" {
 #define BMT_OK 0
 #define BMT_EINVAL (-1)   /* bad argument / unsupported shape */
 #define BMT_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-3)   /* pointer or stride alignment requirement violated */
 
 #define BMT_ABI_VERSION 1
@@ -374,6 +375,19 @@ size_t bmt_select_proposals_ws_bytes(int B, int64_t S, int k);
 int bmt_select_proposals(const bmt_select_proposals_args* a, void* stream);
 /* in place over every candidate: the CORNERS / TRIM transforms above (get_corner_coords, trim_proposals) */
 int bmt_transform_proposals(float* preds, int B, int64_t S, unsigned flags, const float* durations, void* stream);
+
+/* ---------------------------------------------------------------- feature ingest
+ * Host: read rows [row0, row1) (row1 < 0: to the end; the range is clipped to the array) of a 1-D / 2-D little-endian
+ * float32 or float64 C-ordered .npy file into dst as float32 -- np.load + torch.from_numpy(x).float() + x[row0:row1] of
+ * datasets/load_features.py:50-53,67-71,19-33 without intermediates.  dst == NULL: only *rows / *cols of the range.
+ * Returns BMT_ENOENT when the file cannot be opened.  Thread-safe; no HIP call. */
+int bmt_npy_shape(const char* path, int64_t* rows, int64_t* cols, int* elem_bytes);
+int bmt_npy_read_rows(const char* path, int64_t row0, int64_t row1, float* dst, int64_t dst_floats, int64_t* rows,
+                      int64_t* cols);
+/* Device: packed [offsets[B], D] ragged rows (sample b = rows offsets[b] .. offsets[b+1]) -> out [B, T, D], rows beyond a
+ * sample's length filled with pad: pad_sequence(batch_first=True, padding_value=pad) of
+ * datasets/captioning_dataset.py:259-261 / pad_segment of datasets/load_features.py:38-44.  offsets: int64 [B+1], device. */
+int bmt_pad_batch(const float* packed, const int64_t* offsets, int B, int T, int D, float pad, float* out, void* stream);
 
 #ifdef __cplusplus
 }

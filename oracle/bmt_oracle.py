@@ -634,3 +634,53 @@ def generate_proposals_post(predictions: Tensor, duration_in_secs: float, k: int
     """sample/single_video_prediction.py:176-186 (one video): corners -> trim -> drop short -> top-k"""
     p = trim_proposals(get_corner_coords(predictions), [duration_in_secs])
     return select_topk_predictions(remove_very_short_segments(p, shortest_segment_prior), k)
+
+
+# --------------------------------------------------------------------------------------
+# feature ingest  (datasets/load_features.py:14-95, datasets/captioning_dataset.py:214-275,
+#                  datasets/proposal_dataset.py:69-103)
+# --------------------------------------------------------------------------------------
+def crop_a_segment(feature: Tensor, start: float, end: float, duration: float):
+    """load_features.py:14-36: rows int(S*start/duration) .. int(S*end/duration) (python float arithmetic, truncation); an
+    empty range becomes one row ([S:S] -> [S-1:S] at the end of the video); None if the slice is still empty"""
+    S = feature.shape[0]
+    a, b = int(S * (start / duration)), int(S * (end / duration))
+    if a == b:
+        if a == S:
+            a -= 1
+        else:
+            b += 1
+    out = feature[a:b, :]
+    return None if len(out) == 0 else out
+
+
+def pad_segment(feature: Tensor, max_feature_len: int, pad_idx: float) -> Tensor:
+    """load_features.py:38-44"""
+    assert feature.shape[0] <= max_feature_len
+    return torch.nn.functional.pad(feature, [0, 0, 0, max_feature_len - feature.shape[0]], value=pad_idx)
+
+
+def collate_caption_features(arrays, items, pad_idx: float, d_vid: int, d_aud: int):
+    """captioning_dataset.py:214-261 for in-memory arrays: ``arrays[i]`` = {'rgb','flow','audio'} -> (S, D) fp32 tensor or None
+    (missing file); crop every sample to its segment, replace missing / empty stacks by one zero row, pad the batch to its
+    longest sample -- rgb and audio with pad_idx, flow with 0."""
+    rgb, flow, aud = [], [], []
+    for arr, (start, end, duration) in zip(arrays, items):
+        r = None if arr.get("rgb") is None else crop_a_segment(arr["rgb"], start, end, duration)
+        f = None if arr.get("flow") is None else crop_a_segment(arr["flow"], start, end, duration)
+        a = None if arr.get("audio") is None else crop_a_segment(arr["audio"], start, end, duration)
+        if r is None or f is None:
+            r, f = torch.zeros(1, d_vid), torch.zeros(1, d_vid)
+        if a is None:
+            a = torch.zeros(1, d_aud)
+        rgb.append(r); flow.append(f); aud.append(a)
+    ps = torch.nn.utils.rnn.pad_sequence
+    return {"rgb": ps(rgb, batch_first=True, padding_value=pad_idx), "flow": ps(flow, batch_first=True, padding_value=0),
+            "audio": ps(aud, batch_first=True, padding_value=pad_idx)}
+
+
+def collate_proposal_features(arrays, pad_idx: float, pad_video: int, pad_audio: int):
+    """proposal_dataset.py:69-86 + load_features.py get_full_feat branch: whole videos padded to fixed lengths"""
+    return {"rgb": torch.stack([pad_segment(a["rgb"], pad_video, pad_idx) for a in arrays]),
+            "flow": torch.stack([pad_segment(a["flow"], pad_video, 0) for a in arrays]),
+            "audio": torch.stack([pad_segment(a["audio"], pad_audio, pad_idx) for a in arrays])}
