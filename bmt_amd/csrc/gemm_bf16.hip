@@ -424,16 +424,19 @@ struct PlaneDesc {
     uint16_t *hiT, *loT; int64_t ldpT; int pcolsT;
     float* colsum;
     int tiles_x, tiles_y;
+    float drop_p; uint32_t drop_site; const uint64_t* drop_rng;     // optional: the source is masked (inverted dropout) first
 };
 
 __device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, float (*tile)[65]) {
     const int r0 = by * 64, c0 = bx * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 row groups
     float csum = 0.f;
+    const DropCtx dc = make_drop(d.drop_p, d.drop_rng, d.drop_site);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
-        const float v = (r < d.R && c < d.C) ? d.src[(int64_t)r * d.ld + c] : 0.f;
+        float v = (r < d.R && c < d.C) ? d.src[(int64_t)r * d.ld + c] : 0.f;
+        if (dc.on) v = drop_apply(dc, v, (uint64_t)((int64_t)r * d.C + c));      // element index of the [R][C] tensor
         csum += v;
         tile[ty * 16 + i][tx] = v;
         if (d.hi && r < d.R && c < d.pcols) {
@@ -602,6 +605,7 @@ static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, u
     // padding written with zeros: up to the next multiple of 64 (bounded by the row stride)
     d.src = src; d.ld = ld; d.R = R; d.C = C; d.hi = hi; d.lo = lo; d.ldp = ldp; d.hiT = hiT; d.loT = loT; d.ldpT = ldpT;
     d.colsum = colsum;
+    d.drop_p = 0.f; d.drop_site = 0; d.drop_rng = nullptr;
     d.pcols = hi ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
     d.pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
     d.tiles_x = bmt_cdiv(d.pcols > C ? d.pcols : C, 64);
@@ -619,7 +623,20 @@ extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* 
     return BMT_OK;
 }
 
-// host helper: fill one 96-byte descriptor of the multi-tensor table (the caller uploads the table to device memory)
+extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
+                                  uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site,
+                                  void* stream) {
+    PlaneDesc d;
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, colsum);
+    if (rc) return rc;
+    BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_planes_dropout: bad dropout arguments");
+    d.drop_p = drop_p; d.drop_site = site; d.drop_rng = rng;
+    hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
+    BMT_CHECK_LAUNCH("bmt_planes_dropout");
+    return BMT_OK;
+}
+
+// host helper: fill one descriptor of the multi-tensor table (the caller uploads the table to device memory)
 extern "C" int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,
                                uint16_t* hiT, uint16_t* loT, int64_t ldpT) {
     BMT_CHECK_ARG(desc_out, "bmt_planes_desc: null");

@@ -15,12 +15,15 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
-                                                      float eps) {
+                                                      float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                      int64_t ldp, int pcols) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * ldx;
-    float* yr = y + (int64_t)row * ldy;
+    float* yr = y ? y + (int64_t)row * ldy : nullptr;
+    uint16_t* hr = hi ? hi + (int64_t)row * ldp : nullptr;      // bf16 operand planes of the output (GEMM / attention input)
+    uint16_t* lr = lo ? lo + (int64_t)row * ldp : nullptr;
     float s = 0.f;
     if constexpr (VEC) {
         for (int c = lane * 4; c < D; c += 256) { const float4 v = ld4(xr + c); s += (v.x + v.y) + (v.z + v.w); }
@@ -47,11 +50,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             float4 o;
             o.x = (v.x - mu) * rs * g.x + b.x; o.y = (v.y - mu) * rs * g.y + b.y;
             o.z = (v.z - mu) * rs * g.z + b.z; o.w = (v.w - mu) * rs * g.w + b.w;
-            *reinterpret_cast<float4*>(yr + c) = o;
+            if (yr) *reinterpret_cast<float4*>(yr + c) = o;
+            if (hr) {
+                uint32_t h0, l0, h1, l1;
+                split_bf2(o.x, o.y, h0, l0);
+                split_bf2(o.z, o.w, h1, l1);
+                *reinterpret_cast<uint2*>(hr + c) = make_uint2(h0, h1);
+                if (lr) *reinterpret_cast<uint2*>(lr + c) = make_uint2(l0, l1);
+            }
         }
     } else {
-        for (int c = lane; c < D; c += 64) yr[c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+        for (int c = lane; c < D; c += 64) {
+            const float o = (xr[c] - mu) * rs * gamma[c] + beta[c];
+            if (yr) yr[c] = o;
+            if (hr) {
+                const __bf16 h = (__bf16)o;
+                hr[c] = __builtin_bit_cast(uint16_t, h);
+                if (lr) lr[c] = __builtin_bit_cast(uint16_t, (__bf16)(o - (float)h));
+            }
+        }
     }
+    if (hr)      // zero padding of the reduction extent (planes are read in 64-column steps)
+        for (int c = D + lane; c < pcols; c += 64) {
+            hr[c] = 0;
+            if (lr) lr[c] = 0;
+        }
 }
 
 // rows each wave sweeps: sized so that a launch has ~512 workgroups (2 per CU); runtime parameter
@@ -61,8 +84,8 @@ __host__ __device__ inline int ln_bwd_rows_per_wave(int rows) { const int r = (r
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                       int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, float* __restrict__ dx, int64_t lddx,
-                                                      int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      const float* __restrict__ rstd, float* dx, int64_t lddx,
+                                                      const float* dx_add, int64_t ldadd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ partial, int rows_per_wave, int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][3 waves][NV*256]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -108,8 +131,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 float4 o;
                 o.x = rs * (g[i].x - c1 - xh[i].x * c2); o.y = rs * (g[i].y - c1 - xh[i].y * c2);
                 o.z = rs * (g[i].z - c1 - xh[i].z * c2); o.w = rs * (g[i].w - c1 - xh[i].w * c2);
-                if (accumulate_dx) {
-                    const float4 p = ld4(dxr + c);
+                if (dx_add) {
+                    const float4 p = ld4(dx_add + (int64_t)row * ldadd + c);
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 *reinterpret_cast<float4*>(dxr + c) = o;
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                              int64_t ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             float* __restrict__ dx, int64_t lddx, int accumulate_dx,
+                                                             float* dx, int64_t lddx, const float* dx_add, int64_t ldadd,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const float* __restr
     for (int c = lane; c < D; c += 64) {
         const float xh = (xr[c] - mu) * rs, g = dr[c] * gamma[c];
         const float o = rs * (g - c1 - xh * c2);
-        dxr[c] = accumulate_dx ? dxr[c] + o : o;
+        dxr[c] = dx_add ? dx_add[(int64_t)row * ldadd + c] + o : o;
         atomicAdd(dgamma + c, dr[c] * xh);
         atomicAdd(dbeta + c, dr[c]);
     }
@@ -209,16 +232,28 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-extern "C" int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
-                                 float* mean, float* rstd, int rows, int D, float eps, void* stream) {
-    BMT_CHECK_ARG(x && gamma && beta && y && rows >= 0 && D > 0, "bmt_layernorm_fwd: bad args");
+extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                                        float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int64_t ldp, int rows, int D,
+                                        float eps, void* stream) {
+    BMT_CHECK_ARG(x && gamma && beta && (y || hi) && rows >= 0 && D > 0, "bmt_layernorm_fwd: bad args");
+    BMT_CHECK_ARG(!lo || hi, "bmt_layernorm_fwd_planes: lo plane without hi plane");
+    BMT_CHECK_ARG(!hi || ldp >= D, "bmt_layernorm_fwd_planes: plane row stride %lld < D=%d", (long long)ldp, D);
     if (rows == 0) return BMT_OK;
-    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y) && al16(gamma) && al16(beta);
+    const int pad = (D + 63) / 64 * 64;
+    const int pcols = hi ? (int)(pad < ldp ? pad : ldp) : 0;
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (!y || (ldy % 4 == 0 && al16(y))) && al16(x) && al16(gamma) && al16(beta) &&
+                     (!hi || ((ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0));
     dim3 grid(bmt_cdiv(rows, 4)), block(256);
-    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps);
-    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps);
+    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols);
     BMT_CHECK_LAUNCH("bmt_layernorm_fwd");
     return BMT_OK;
+}
+
+extern "C" int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                                 float* mean, float* rstd, int rows, int D, float eps, void* stream) {
+    BMT_CHECK_ARG(y, "bmt_layernorm_fwd: bad args");
+    return bmt_layernorm_fwd_planes(x, ldx, gamma, beta, y, ldy, mean, rstd, nullptr, nullptr, 0, rows, D, eps, stream);
 }
 
 extern "C" int bmt_layernorm_bwd_blocks(int rows) { return rows <= 0 ? 0 : bmt_cdiv(rows, 4 * ln_bwd_rows_per_wave(rows)); }
@@ -226,14 +261,21 @@ extern "C" int bmt_layernorm_bwd_blocks(int rows) { return rows <= 0 ? 0 : bmt_c
 extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                                  float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
+    return bmt_layernorm_bwd_add(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, accumulate_dx ? dx : nullptr, lddx, dgamma, dbeta,
+                                 partial_ws, rows, D, stream);
+}
+
+extern "C" int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                     const float* mean, const float* rstd, float* dx, int64_t lddx, const float* dx_add,
+                                     int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
     BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
     if (rows == 0) return BMT_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && al16(x) && al16(dy) && al16(dx) &&
-                     al16(gamma) && D <= 2048;
+                     al16(gamma) && D <= 2048 && (!dx_add || (al16(dx_add) && ldadd % 4 == 0));
     if (!vec) {
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx,
-                           lddx, accumulate_dx, dgamma, dbeta, rows, D);
+                           lddx, dx_add, ldadd, dgamma, dbeta, rows, D);
         BMT_CHECK_LAUNCH("bmt_layernorm_bwd(scalar)");
         return BMT_OK;
     }
@@ -241,7 +283,7 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     const int nv = bmt_cdiv(D, 256);
 #define BMT_LN(NV)                                                                                                         \
     hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 2 * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
-                       dx, lddx, accumulate_dx, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D)
+                       dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D)
     if (nv <= 1) BMT_LN(1);
     else if (nv <= 2) BMT_LN(2);
     else if (nv <= 4) BMT_LN(4);

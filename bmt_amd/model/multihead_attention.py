@@ -71,10 +71,16 @@ class MultiheadedAttention(nn.Module):
             return ops.mha_infer(Q, K, mask, self.linear_Q2d.weight, self.linear_Q2d.bias, self.linear_K2d.weight, self.linear_K2d.bias,
                                  self.linear_V2d.weight, self.linear_V2d.bias, self.linear_d2Q.weight, self.linear_d2Q.bias,
                                  self.H, ops.KV_CACHE, id(self))
-        fn = ops.MHAFn if ops.USE_PLANE_GEMM else ops.MHAFnStaged
-        return fn.apply(Q, K, V, mask,
-                               self.linear_Q2d.weight, self.linear_Q2d.bias,
-                               self.linear_K2d.weight, self.linear_K2d.bias,
-                               self.linear_V2d.weight, self.linear_V2d.bias,
-                               self.linear_d2Q.weight, self.linear_d2Q.bias,
-                               self.H, p, self._site)
+        args = (Q, K, V, mask,
+                self.linear_Q2d.weight, self.linear_Q2d.bias,
+                self.linear_K2d.weight, self.linear_K2d.bias,
+                self.linear_V2d.weight, self.linear_V2d.bias,
+                self.linear_d2Q.weight, self.linear_d2Q.bias,
+                self.H, p, self._site)
+        if not ops.USE_PLANE_GEMM:
+            return ops.MHAFnStaged.apply(*args)
+        off = ops.take_residual()        # an enclosing ResidualConnection offers x, p, site: fused into the out-projection
+        if off is None:
+            return ops.MHAFn.apply(*args, None, 0.0, 0)
+        off.out = ops.MHAFn.apply(*args, off.x, off.p, off.site)
+        return off.out

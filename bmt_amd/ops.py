@@ -134,9 +134,10 @@ class Planes:
         self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
 
 
-def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transposed: bool = False, colsum=None):
+def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transposed: bool = False, colsum=None, drop=None):
     """one pass over fp32 x2 [R,C]: -> Planes [R][pad64(C)] (hi[,lo]) and/or transposed hi plane [C][pad64(R)];
-    colsum (optional fp32 [C]) += column sums of x2 (atomic)."""
+    colsum (optional fp32 [C]) += column sums of x2 (atomic).  drop = (p, site): the planes (and column sums) are those of
+    dropout(x2) with the mask of that site over a contiguous [R][C] tensor."""
     R, Cc = x2.shape
     hi = lo_ = hiT = None
     if straight:
@@ -144,8 +145,12 @@ def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transp
         lo_ = torch.empty(R, _pad64(Cc), device=x2.device, dtype=torch.bfloat16) if lo else None
     if transposed:
         hiT = torch.empty(Cc, _pad64(R), device=x2.device, dtype=torch.bfloat16)
-    _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _p(colsum), _st()),
-               "bmt_planes")
+    if drop is not None and drop[0] > 0.0:
+        _lib.check(lib.bmt_planes_dropout(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _p(colsum),
+                                          drop[0], _p(rng_tensor()), drop[1], _st()), "bmt_planes_dropout")
+    else:
+        _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _p(colsum), _st()),
+                   "bmt_planes")
     return (Planes(hi, lo_, R, Cc) if straight else None), (Planes(hiT, None, Cc, R) if transposed else None)
 
 
@@ -557,11 +562,22 @@ def wgrad(W, b, dyT, xT, dy2_for_bias=None, bias_sum=None):
     return dW, db
 
 
-def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bool = True, **dx_epi):
+def drop_grad(dy2: torch.Tensor, b, p: float, site: int):
+    """gradient through a dropout site on its way into a Linear's backward: (dy2, (p, site)) when the mask can be applied inside
+    the operand conversion (grad_planes), else (dropout(dy2), None)"""
+    if p <= 0.0:
+        return dy2, None
+    if USE_PLANE_GEMM and (b is None or static_grad(b) is not None):
+        return dy2, (p, site)
+    return dropout_raw(dy2, p, site), None
+
+
+def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bool = True, drop=None, **dx_epi):
     """backward of y = x W^T + b given dy2 [M,N]: one pass builds the gradient's operand planes (+ bias column sums),
     then dX = dY.W and dW += dY^T.X.  Returns (dx or None, dW or None, db or None); dW/db are None when they were
     accumulated straight into the parameters' static gradient buffers."""
-    P, T, bias_done = grad_planes(dy2, b)
+    P, T, bias_done = grad_planes(dy2, b, drop=drop)
+    assert drop is None or bias_done or b is None       # (drop_grad guarantees it: the bias sum must see the masked gradient)
     dx = linear_dx(P, W, **dx_epi) if need_dx else None
     dW = db = None
     if need_dw:
@@ -580,17 +596,19 @@ class PlanesT:
         self.p = p
 
 
-def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None):
+def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=None):
     """(operand for dX, operand for dW, bias-gradient handled?) of an upstream gradient in ONE pass over it: hi plane,
-    transposed hi plane and -- when ``bias`` has a static gradient buffer -- its column sums accumulated into that buffer."""
+    transposed hi plane and -- when ``bias`` has a static gradient buffer -- its column sums accumulated into that buffer.
+    drop = (p, site): the gradient first goes through that dropout site's mask (backward of ``x + dropout(y)`` w.r.t. y)."""
     if not USE_PLANE_GEMM:
+        assert drop is None
         return dy2, dy2, False
     gb = static_grad(bias)
     if _kmajor():       # one plane serves dX (as A) and dW (k-major)
-        P = make_planes(dy2, lo=False, straight=True, transposed=False, colsum=gb)[0]
+        P = make_planes(dy2, lo=False, straight=True, transposed=False, colsum=gb, drop=drop)[0]
         T = P
     else:
-        P, T = make_planes(dy2, lo=False, straight=True, transposed=True, colsum=gb)
+        P, T = make_planes(dy2, lo=False, straight=True, transposed=True, colsum=gb, drop=drop)
     if gb is not None:
         grad_done(bias)
     return P, T, gb is not None
@@ -806,6 +824,106 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
     return y
 
 
+# ----------------------------------------------------------------------------- fused residual block
+# ResidualConnection computes x + dropout(sublayer(LN(x))).  Fused form (FUSE_RESIDUAL): LN writes the operand planes of its
+# output itself (no conversion pass), the sublayer's LAST GEMM adds dropout + residual in its epilogue (no dropout_add pass),
+# backward applies the dropout mask while converting the incoming gradient to planes (no dropout pass) and the LayerNorm
+# backward adds the residual stream's gradient to its own (no autograd add pass).  The residual is OFFERED to the sublayer
+# through a module-level slot; MultiheadedAttention / PositionwiseFeedForward take it, anything else leaves it and the
+# ResidualConnection falls back to the separate dropout_add kernel.
+FUSE_RESIDUAL = _os.environ.get("BMT_NO_FUSE_RES") != "1"
+_RES_OFFER = None
+_LAST_LN_PLANES = None
+
+
+class ResidualOffer:
+    __slots__ = ("x", "p", "site", "out")
+
+    def __init__(self, x, p, site):
+        self.x, self.p, self.site, self.out = x, p, site, None
+
+
+def offer_residual(x, p, site) -> ResidualOffer:
+    global _RES_OFFER
+    _RES_OFFER = ResidualOffer(x, p, site)
+    return _RES_OFFER
+
+
+def take_residual() -> Optional[ResidualOffer]:
+    """the pending offer, if any (one taker: the slot is cleared)"""
+    global _RES_OFFER
+    off, _RES_OFFER = _RES_OFFER, None
+    return off
+
+
+def planes_of(t, need_lo: bool):
+    """operand planes attached to an activation by its producer (ResidualNormFn), usable as a k-major dW operand too"""
+    pl = getattr(t, "_bmt_planes", None)
+    if pl is None or (need_lo and pl.lo is None) or not _kmajor():
+        return None
+    return pl
+
+
+class ResidualNormFn(torch.autograd.Function):
+    """x -> (x, LayerNorm(x)): the two branches of a ResidualConnection leave one node, so that their gradients meet again
+    in ONE kernel (dx = g_residual + LN backward(g_norm)).  The forward kernel also writes the bf16 operand planes of the
+    normalised output (``last_ln_planes()``), which is all the sublayer's first GEMM reads."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        global _LAST_LN_PLANES
+        note_use(gamma, beta)
+        xc = _f32c(x)
+        D = xc.shape[-1]
+        x2 = xc.view(-1, D)
+        rows = x2.shape[0]
+        x3 = FWD_PRECISION == PREC_BF16X3
+        y = torch.empty_like(x2)
+        ld = _pad64(D)
+        hi = torch.empty(rows, ld, device=x.device, dtype=torch.bfloat16)
+        lo = torch.empty(rows, ld, device=x.device, dtype=torch.bfloat16) if x3 else None
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), _p(hi), _p(lo), ld,
+                                                rows, D, eps, _st()), "bmt_layernorm_fwd_planes")
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.beta = beta
+        _LAST_LN_PLANES = Planes(hi, lo, rows, D)
+        return xc.view_as(xc), y.view(xc.shape)
+
+    @staticmethod
+    def backward(ctx, g_id, g_n):
+        if g_n is None:
+            return g_id, None, None, None
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        rows, D = x2.shape
+        dy2 = _f32c(g_n).view(rows, D)
+        add = _f32c(g_id).view(rows, D) if g_id is not None else None
+        dx = torch.empty_like(x2)
+        beta = ctx.beta
+        sg, sb = static_grad(gamma), static_grad(beta)
+        fused = sg is not None and sb is not None
+        dg = sg if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
+        db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
+        ws = torch.empty(max(1, lib.bmt_layernorm_bwd_blocks(rows)) * 2 * D, device=x2.device, dtype=torch.float32)
+        _lib.check(lib.bmt_layernorm_bwd_add(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(dg), _p(db),
+                                             _p(ws), rows, D, _st()), "bmt_layernorm_bwd_add")
+        dx = dx.view(g_n.shape)
+        if fused:
+            grad_done(gamma)
+            grad_done(beta)
+            return dx, None, None, None
+        return dx, dg, db, None
+
+
+def residual_norm(x, gamma, beta, eps):
+    """(x passed through, LayerNorm(x) carrying its operand planes as ``_bmt_planes``)"""
+    global _LAST_LN_PLANES
+    xid, xn = ResidualNormFn.apply(x, gamma, beta, eps)
+    xn._bmt_planes, _LAST_LN_PLANES = _LAST_LN_PLANES, None
+    return xid, xn
+
+
 # ----------------------------------------------------------------------------- autograd functions
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim (model/blocks.py:127,131)."""
@@ -923,15 +1041,22 @@ class FFNFn(torch.autograd.Function):
     backward); backward applies the relu/dropout derivative inside the dH GEMM epilogue (gate on the saved hidden)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p, site):
+    def forward(ctx, x, W1, b1, W2, b2, p, site, res=None, res_p=0.0, res_site=0):
         note_use(W1, b1, W2, b2)
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
         x3 = FWD_PRECISION == PREC_BF16X3
-        h = linear_fwd_planes(x2, W1, b1, want_lo=x3, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
-        y = linear_fwd(h if USE_PLANE_GEMM else _planes_to_f32(h), W2, b2)
+        xp = planes_of(x, x3)            # LayerNorm wrote the operand planes of its output already
+        h = linear_fwd_planes(x2 if xp is None else xp, W1, b1, want_lo=x3, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
+        epi = {}
+        if res is not None:              # x_res + dropout(fc2(h)) in fc2's epilogue (ResidualConnection)
+            r2 = _f32c(res).view(-1, W2.shape[0])
+            epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        y = linear_fwd(h if USE_PLANE_GEMM else _planes_to_f32(h), W2, b2, **epi)
         ctx.p = p
         ctx.h = h
+        ctx.xp = None if xp is None else Planes(xp.hi, None, xp.rows, xp.cols)
+        ctx.res = (res is not None, res_p, res_site)
         ctx.params = (W1, b1, W2, b2)
         ctx.save_for_backward(x2, W1, W2)
         return y.view(*xc.shape[:-1], W2.shape[0])
@@ -943,18 +1068,22 @@ class FFNFn(torch.autograd.Function):
         dy2 = _f32c(dy).view(-1, W2.shape[0])
         gscale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
         W1p, b1p, W2p, b2p = ctx.params
+        has_res, res_p, res_site = ctx.res
+        drop = None
+        if has_res:
+            dy2, drop = drop_grad(dy2, b2p, res_p, res_site)
         if USE_PLANE_GEMM:
-            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(input_t(h)), gate=h, gate_scale=gscale)
+            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(input_t(h)), gate=h, gate_scale=gscale, drop=drop)
         else:
             hf = _planes_to_f32(h)
             dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, hf)
             tmp = torch.empty_like(dh)
             _lib.check(lib.bmt_gate(_p(dh), _p(hf), gscale, _p(tmp), dh.numel(), _st()), "bmt_gate")
             dh = tmp
-        dx, dW1, db1 = lin_bwd(dh, W1p, b1p, x2, need_dx=ctx.needs_input_grad[0])
+        dx, dW1, db1 = lin_bwd(dh, W1p, b1p, x2 if ctx.xp is None else PlanesT(ctx.xp), need_dx=ctx.needs_input_grad[0])
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], W1.shape[1])
-        return dx, dW1, db1, dW2, db2, None, None
+        return dx, dW1, db1, dW2, db2, None, None, (dy if has_res else None), None, None
 
 
 def _planes_to_f32(pl: Planes) -> torch.Tensor:
@@ -1007,7 +1136,7 @@ def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key):
         ent = (K, r[0], r[1])
         cache[key] = ent
     k, v = ent[1], ent[2]
-    Qp = make_planes(Qc.view(-1, Dq), lo=x3)[0]
+    Qp = planes_of(Q, x3) or make_planes(Qc.view(-1, Dq), lo=x3)[0]
     q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
     o, _ = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H)
     return linear_fwd(o, Wo, bo).view(B, Sq, Dq)
@@ -1022,7 +1151,7 @@ class MHAFn(torch.autograd.Function):
     dq/dk/dv as (plane, transposed plane, bias sums).  The only fp32 intermediates are the module's input/output and dO."""
 
     @staticmethod
-    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site):
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, res=None, res_p=0.0, res_site=0):
         note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
         B, Sq, Dq = Qc.shape
@@ -1032,13 +1161,17 @@ class MHAFn(torch.autograd.Function):
         x3 = FWD_PRECISION == PREC_BF16X3
         train = any(ctx.needs_input_grad)
         # each distinct input: operand planes (hi[, lo]) and, for the weight gradients, the transposed hi plane -- one pass
-        def split(x3d):
+        # (none at all when the producer -- LayerNorm -- attached the planes of its output)
+        def split(orig, x3d):
+            pl = planes_of(orig, x3)
+            if pl is not None:
+                return pl, pl
             x2 = x3d.view(-1, x3d.shape[-1])
             P_, T_ = make_planes(x2, lo=x3, straight=True, transposed=train and not _kmajor())
             return P_, (P_ if _kmajor() else T_)
-        Qp, QT = split(Qc)
-        Kp, KT = (Qp, QT) if same_qk else split(Kc)
-        Vp, VT = (Kp, KT) if same_kv else split(Vc)
+        Qp, QT = split(Q, Qc)
+        Kp, KT = (Qp, QT) if same_qk else split(K, Kc)
+        Vp, VT = (Kp, KT) if same_kv else split(V, Vc)
         fused_proj = lambda Xp, Ws, bs: project_group(Xp, Ws, bs, x3)
         fuse = None
         q = k = v = None
@@ -1056,8 +1189,13 @@ class MHAFn(torch.autograd.Function):
             k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
             v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
         o, lse = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, drop_p=p, site=site)
-        out = linear_fwd(o, Wo, bo).view(B, Sq, Dq)
+        epi = {}
+        if res is not None:              # x_res + dropout(out-projection) in the projection's epilogue (ResidualConnection)
+            r2 = _f32c(res).view(-1, Dq)
+            epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        out = linear_fwd(o, Wo, bo, **epi).view(B, Sq, Dq)
         ctx.H, ctx.p, ctx.site = H, p, site
+        ctx.res = (res is not None, res_p, res_site)
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
         ctx.fuse = fuse
         ctx.mask = mask
@@ -1081,14 +1219,18 @@ class MHAFn(torch.autograd.Function):
         else:
             QT, KT, VT = Planes(QTh, None, Dq, Mq), Planes(KTh, None, Dk_in, Mk), Planes(VTh, None, Dv_in, Mk)
         dy2 = _f32c(dout).view(-1, Dq)
+        has_res, res_p, res_site = ctx.res
+        drop = None
+        if has_res:                      # the residual branch takes dout as it is; this branch sees it through the dropout mask
+            dy2, drop = drop_grad(dy2, bop, res_p, res_site)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
         if _kmajor() and D % 64 == 0 and _os.environ.get("BMT_DO_FP32") != "1":      # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
-            P_, T_, bias_done = grad_planes(dy2, bop)
+            P_, T_, bias_done = grad_planes(dy2, bop, drop=drop)
             do = linear_dx(P_, Wop, out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
                            drop_post=True, drop_p=ctx.p, site=ctx.site)
             dWo, dbo = wgrad(Wop, None if bias_done else bop, T_, input_t(o), dy2_for_bias=dy2)
         else:
-            do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(input_t(o)), drop_post=True, drop_p=ctx.p, site=ctx.site)
+            do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(input_t(o)), drop=drop, drop_post=True, drop_p=ctx.p, site=ctx.site)
         res = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p, (bqp, bkp, bvp), fuse=ctx.fuse)
         (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = res[:3]
         comb = res[3] if len(res) > 3 else None
@@ -1157,7 +1299,7 @@ class MHAFn(torch.autograd.Function):
                     dxv, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needV)
                     dK = dxk.view(B, Sk, Dk_in) if needK else None
                     dV = dxv.view(B, Sk, Dv_in) if needV else None
-        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
+        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, (dout if has_res else None), None, None
 
 
 class MHAFnStaged(torch.autograd.Function):

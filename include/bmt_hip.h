@@ -129,6 +129,11 @@ int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint
  * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
 int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
                uint16_t* loT, int64_t ldpT, float* colsum /* optional: colsum[c] += sum_r src[r][c] (atomic) */, void* stream);
+/* bmt_planes of dropout(src): the fp32 source is masked with the library's counter-based dropout (site, element index
+ * r * C + c -- the mask bmt_dropout / the GEMM epilogues draw for a contiguous [R][C] tensor) before it is split; colsum sums
+ * the masked values.  Backward of `x + dropout(sub)` fused into the gradient's operand conversion. */
+int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
+                       uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site, void* stream);
 /* the same for MANY tensors in one launch (all weights of a model after an optimizer step): the caller fills a host table of
  * bmt_planes_desc_bytes()-sized descriptors with bmt_planes_desc, uploads it, and passes the device pointer. */
 int bmt_planes_desc_bytes(void);
@@ -229,6 +234,12 @@ int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */
 int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                       float* mean, float* rstd, int rows, int D, float eps, void* stream);
+/* bmt_layernorm_fwd that also (or only: y == NULL) writes the bf16 operand planes of y: hi = bf16(y), lo = bf16(y - hi)
+ * (lo may be NULL), row stride ldp >= D, columns D .. min(pad64(D), ldp) zero filled -- the next GEMM / attention kernel reads
+ * them directly, no separate conversion pass. */
+int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                             float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int64_t ldp, int rows, int D, float eps,
+                             void* stream);
 /* dx (+)= LN backward; dgamma/dbeta += column reductions (accumulate into pre-zeroed or live grads).
  * dx[i] = (accumulate_dx ? dx[i] : 0) + ...
  * partial_ws: NULL -> one atomic per column per workgroup; else fp32 [bmt_layernorm_bwd_blocks(rows)][2][D] scratch for a
@@ -237,6 +248,11 @@ int bmt_layernorm_bwd_blocks(int rows);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                       float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream);
+/* dx = dx_add + LN backward (dx_add may be NULL or alias dx): the residual stream's gradient joins here, so that the sum
+ * autograd would form with a separate add kernel is produced by the LayerNorm backward itself. */
+int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                          const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma,
+                          float* dbeta, float* partial_ws, int rows, int D, void* stream);
 
 /* ---------------------------------------------------------------- input prep / elementwise (K8) */
 /* out[b,s,:] = dropout( (a[b,s,:] (+ b2[b,s,:])) * in_scale + PE[s,:] )      model/captioning_module.py:165,174-176, blocks.py:101-107

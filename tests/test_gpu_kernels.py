@@ -509,3 +509,73 @@ def test_clip_grad_norm(ops):
     assert abs(float(n) - float(n_ref)) < 1e-3 * float(n_ref)
     for p, r in zip(ps, ref):
         assert_close(p.grad, r.grad, atol=1e-6, rtol=1e-5, name="clipped grad")
+
+
+# ---------------------------------------------------------------- fused residual block pieces
+@pytest.mark.parametrize("rows,D", [(37, 128), (50, 300), (9, 1024), (5, 77)])
+def test_layernorm_forward_writes_its_operand_planes(ops, rows, D):
+    """bmt_layernorm_fwd_planes: fp32 output == bmt_layernorm_fwd, planes == bmt_planes of that output (zero padded)"""
+    from bmt_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.3).to(DEV)
+    gamma, beta = torch.randn(D, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)
+    y0 = torch.empty_like(x)
+    m0, r0 = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    _lib.check(lib.bmt_layernorm_fwd(ops._p(x), D, ops._p(gamma), ops._p(beta), ops._p(y0), D, ops._p(m0), ops._p(r0), rows, D, 1e-5,
+                                     ops._st()), "ln")
+    ld = ops._pad64(D)
+    for with_y in (True, False):
+        y = torch.full_like(x, float("nan"))
+        hi = torch.full((rows, ld), 7.0, device=DEV, dtype=torch.bfloat16)
+        lo = torch.full((rows, ld), 7.0, device=DEV, dtype=torch.bfloat16)
+        m, r = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        _lib.check(lib.bmt_layernorm_fwd_planes(ops._p(x), D, ops._p(gamma), ops._p(beta), ops._p(y) if with_y else None, D, ops._p(m),
+                                                ops._p(r), ops._p(hi), ops._p(lo), ld, rows, D, 1e-5, ops._st()), "ln planes")
+        if with_y:
+            assert torch.equal(y, y0)
+        assert torch.equal(m, m0) and torch.equal(r, r0)
+        want = ops.make_planes(y0, lo=True)[0]
+        assert torch.equal(hi, want.hi) and torch.equal(lo, want.lo)
+
+
+@pytest.mark.parametrize("rows,D", [(37, 128), (50, 300), (4100, 1024), (5, 77)])
+def test_layernorm_backward_adds_the_residual_gradient(ops, rows, D):
+    from bmt_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows)
+    x, dy, add = [torch.randn(rows, D, generator=g).to(DEV) for _ in range(3)]
+    gamma = torch.randn(D, generator=g).to(DEV)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    outs = []
+    for a in (None, add):
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        ws = torch.empty(max(1, lib.bmt_layernorm_bwd_blocks(rows)) * 2 * D, device=DEV)
+        _lib.check(lib.bmt_layernorm_bwd_add(ops._p(dy), D, ops._p(x), D, ops._p(gamma), ops._p(mean), ops._p(rstd), ops._p(dx), D,
+                                             ops._p(a), D, ops._p(dg), ops._p(db), ops._p(ws), rows, D, ops._st()), "ln bwd add")
+        outs.append((dx, dg, db))
+    assert torch.equal(outs[1][0], outs[0][0] + add)              # one fp32 add, same rounding as the separate kernel
+    assert_close(outs[1][1], outs[0][1], atol=1e-4, rtol=1e-5, name="dgamma")
+    xr = x.double().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (D,), gamma.double(), torch.zeros(D, device=DEV, dtype=torch.double), 1e-5).backward(dy.double())
+    assert_close(outs[0][0], xr.grad, atol=2e-4, rtol=1e-4, name="dx")
+
+
+@pytest.mark.parametrize("R,C", [(100, 128), (33, 300), (257, 1024)])
+def test_planes_of_a_dropped_gradient(ops, R, C):
+    """bmt_planes_dropout == bmt_planes(bmt_dropout(x)) bit for bit, column sums included"""
+    ops.manual_seed(3)
+    x = torch.randn(R, C, device=DEV)
+    p, site = 0.3, 41
+    dropped = ops.dropout_raw(x, p, site)
+    assert 0.2 < float((dropped == 0).float().mean()) < 0.4
+    cs0, cs1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    want = ops.make_planes(dropped, lo=True, colsum=cs0)[0]
+    got = ops.make_planes(x, lo=True, colsum=cs1, drop=(p, site))[0]
+    assert torch.equal(got.hi, want.hi) and torch.equal(got.lo, want.lo)
+    assert_close(cs1, cs0, atol=1e-4, rtol=1e-5, name="colsum")
+    wantT = ops.make_planes(dropped, lo=False, straight=False, transposed=True)[1]
+    gotT = ops.make_planes(x, lo=False, straight=False, transposed=True, drop=(p, site))[1]
+    assert torch.equal(gotT.hi, wantT.hi)

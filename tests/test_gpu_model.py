@@ -422,3 +422,41 @@ def test_greedy_decoder_reuse_is_identical_to_full_forward_config1_shapes():
         last = model.generator(C[:, -1:])[:, 0]
     assert torch.equal(C, C2)
     assert_close(last, full, atol=1e-5, name="cached last-position log-probs")
+
+
+# ---------------------------------------------------------------- fused residual block (ops.FUSE_RESIDUAL)
+def test_fused_residual_block_equals_the_separate_kernels(golden):
+    """ResidualConnection fused (LN writes planes, dropout + residual in the last GEMM's epilogue, dropout mask applied while the
+    gradient is converted, residual gradient added by the LN backward) against the separate LN / planes / dropout_add / add
+    kernels: same dropout masks, same roundings -> log-probs and gradients agree to fp32 round-off, in training mode."""
+    from bmt_amd import ops
+    g = golden("mid_cap.npz")
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = syn.cfg_config1()
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    res = {}
+    first_site = ops._site_counter[0]
+    for fused in (True, False):
+        ops.FUSE_RESIDUAL = fused
+        try:
+            ops._site_counter[0] = first_site        # both models draw the same dropout masks (site ids are per module instance)
+            model = _build(cfg, V, bool(use_glove))
+            ops.manual_seed(11)
+            pred, loss, _ = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"], train=True)
+            loss.backward()
+            res[fused] = (pred.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            ops.FUSE_RESIDUAL = True
+    assert_close(res[True][0], res[False][0], atol=2e-5, name="log-probs fused vs separate")
+    # gradients: the backward products take bf16 operands, so an fp32 1-ulp difference upstream (fma contraction in the fused
+    # epilogue) flips bf16 roundings: tensors agree to bf16 noise, not bit for bit.  A wrong mask or a lost residual gradient
+    # would show as O(1) errors on every tensor upstream of it.
+    # (key-projection biases have an analytically zero gradient -- softmax ignores a constant added to every key -- so what is
+    # compared there is cancellation noise: left out)
+    errs = sorted(((rel_err(res[True][1][k], gsep), k) for k, gsep in res[False][1].items() if not k.endswith("linear_K2d.bias")),
+                  reverse=True)
+    print("\nworst fused-vs-separate gradient differences:", [(f"{e:.2e}", k) for e, k in errs[:5]])
+    a = torch.cat([res[True][1][k].flatten() for _, k in errs])
+    b = torch.cat([res[False][1][k].flatten() for _, k in errs])
+    assert rel_err(a, b) < 1e-2, rel_err(a, b)
+    assert errs[0][0] < 2e-2, errs[:5]
