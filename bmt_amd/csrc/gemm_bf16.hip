@@ -43,6 +43,7 @@ struct GemmB {
     int64_t ldr;
     const uint16_t* gate;                // bf16 plane of the saved forward output (relu / dropout backward)
     int64_t ldg;
+    float* colsum;                       // optional: colsum[col] += sum over rows of the epilogue value (bias gradient of the next layer back)
     float gate_scale;
     float drop_p;
     const uint64_t* rng;
@@ -300,6 +301,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
     const unsigned f = p.flags;
     uint32_t* ct = reinterpret_cast<uint32_t*>(smem);   // [BM][128] packed planes of this tile
+    // plane-only output with a gate: the mask is applied to whole 16-byte row segments in the write-out pass below (one vector
+    // load of the gate plane per segment instead of a 2-byte load per accumulator element); only the scale is applied here
+    const bool defer_gate = (f & BMT_EPI_GATE) && p.Chi && p.plane_vec && !p.C && !(f & BMT_EPI_RESIDUAL) &&
+                            (p.ldg % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.gate) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -320,7 +325,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
                     if (f & BMT_EPI_DROP_PRE) v = drop_apply(dc, v, (uint64_t)idx);
                     if (f & BMT_EPI_RELU) v = fmaxf(v, 0.f);
                     if (f & BMT_EPI_DROP_POST) v = drop_apply(dc, v, (uint64_t)idx);
-                    if (f & BMT_EPI_GATE) v = (p.gate[(int64_t)row * p.ldg + col] & 0x7fffu) ? v * p.gate_scale : 0.f;
+                    if (f & BMT_EPI_GATE) {
+                        if (defer_gate) v *= p.gate_scale;
+                        else v = (p.gate[(int64_t)row * p.ldg + col] & 0x7fffu) ? v * p.gate_scale : 0.f;
+                    }
                     if (f & BMT_EPI_RESIDUAL) v += p.residual[(int64_t)row * p.ldr + col];
                     if (f & BMT_EPI_ACCUM) atomicAdd(p.C + idx, v);
                     else if (p.C) p.C[idx] = v;
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
         __syncthreads();
         const int cg = (tid & 15) * 8;
         const int col = n0 + cg;
+        float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of this thread's 8 columns over its rows
 #pragma unroll
         for (int ps = 0; ps < BM * 16 / NT; ++ps) {
             const int rl = ps * (NT / 16) + (tid >> 4);
@@ -352,13 +361,58 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
                 u32x4 h;
                 h[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); h[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
                 h[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); h[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+                u32x4 gm = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (defer_gate) {     // keep an element iff the saved forward output is non-zero (sign bit ignored)
+                    const u32x4 gv = (col + 8 <= p.N) ? *reinterpret_cast<const u32x4*>(p.gate + (int64_t)row * p.ldg + col) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        gm[q] = ((gv[q] & 0x00007FFFu) ? 0x0000FFFFu : 0u) | ((gv[q] & 0x7FFF0000u) ? 0xFFFF0000u : 0u);
+                    if (col + 8 > p.N) {   // ragged last segment: element-wise
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c0_ = col + 2 * q;
+                            const uint32_t g0 = (c0_ < p.N && (p.gate[(int64_t)row * p.ldg + c0_] & 0x7fffu)) ? 0x0000FFFFu : 0u;
+                            const uint32_t g1 = (c0_ + 1 < p.N && (p.gate[(int64_t)row * p.ldg + c0_ + 1] & 0x7fffu)) ? 0xFFFF0000u : 0u;
+                            gm[q] = g0 | g1;
+                        }
+                    }
+                    h[0] &= gm[0]; h[1] &= gm[1]; h[2] &= gm[2]; h[3] &= gm[3];
+                }
+                if (p.colsum) {       // hi + lo of the staged value (16 significant bits), masked like the output
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t w0 = (q < 2 ? a[2 * q] : b[2 * q - 4]) & ((gm[q] & 0xFFFFu) ? 0xFFFFFFFFu : 0u);
+                        const uint32_t w1 = (q < 2 ? a[2 * q + 1] : b[2 * q - 3]) & ((gm[q] >> 16) ? 0xFFFFFFFFu : 0u);
+                        cs8[2 * q] += bf_bits2f(w0 & 0xFFFFu) + bf_bits2f(w0 >> 16);
+                        cs8[2 * q + 1] += bf_bits2f(w1 & 0xFFFFu) + bf_bits2f(w1 >> 16);
+                    }
+                }
                 *reinterpret_cast<u32x4*>(p.Chi + (int64_t)row * p.ldp + col) = h;
                 if (p.Clo) {
                     u32x4 l;
                     l[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
                     l[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u); l[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
+                    l[0] &= gm[0]; l[1] &= gm[1]; l[2] &= gm[2]; l[3] &= gm[3];
                     *reinterpret_cast<u32x4*>(p.Clo + (int64_t)row * p.ldp + col) = l;
                 }
+            }
+        }
+        if (p.colsum) {              // lanes 16 apart share a column group: fold them, then the waves through LDS
+            __syncthreads();         // every staged row has been read
+            float* cs = reinterpret_cast<float*>(smem);      // [NT / 64][128]
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = cs8[q];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 16) cs[wid * 128 + cg + q] = v;
+            }
+            __syncthreads();
+            if (tid < 128 && n0 + tid < p.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < NT / 64; ++w_) t += cs[w_ * 128 + tid];
+                atomicAdd(p.colsum + n0 + tid, t);
             }
         }
     }
@@ -550,7 +604,9 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
-    if (a->splitk == 0 && two_pass && tiles < 256 && ktiles >= 4) {
+    static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 256;          // A/B experiments only
+    static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 4;
+    if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt) {
         // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
         int want = 512 / tiles, cap = ktiles / 2;
         if (want > 32) want = 32;
@@ -566,16 +622,19 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.kchunk = bmt_cdiv(ktiles, splitk) * bk;
     splitk = bmt_cdiv(a->Kpad, p.kchunk);
     BMT_CHECK_ARG(splitk == 1 || two_pass || accum, "bmt_gemm_bf16: split-K workspace too small");
+    if (a->colsum && splitk > 1) splitk = 1, p.kchunk = a->Kpad;      // column sums come from the main kernel's epilogue only
     if (splitk > 1 && two_pass) { p.ws = a->splitk_ws; p.nsplit = splitk; }
     p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
     p.gate = a->gate; p.ldg = a->ldg; p.gate_scale = a->gate_scale;
+    p.colsum = a->colsum;
+    BMT_CHECK_ARG(!a->colsum || (a->C_hi && p.plane_vec && !a->C), "bmt_gemm_bf16: colsum needs 16-byte aligned plane-only output");
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
     int rc;
     // 128-row tile: 8 waves of 32x64 (4 waves per SIMD across two workgroups) hide the stage loop's LDS / barrier latency
-    // better than 4 waves of 64x64 -- 25600x1024x128 forward 81 -> 57 us, 8192x1024x1024 x1 38 -> 33 us, whole step -6 % --
-    // except for the single-pass kernel on very large grids (FFN dX / dW, 2048 tiles: 93 -> 96..100 us)
+    // better than 4 waves of 64x64 -- 25600x1024x128 forward 81 -> 57 us, 8192x1024x1024 x1 38 -> 33 us, whole step -6 %; also on
+    // the very large grids (FFN fc2 dX, 2048 tiles of 16 stages: 156 -> 127 us; whole step 15.25 -> 14.97 ms same box)
     static const int force8 = getenv("BMT_GEMM_8W") ? atoi(getenv("BMT_GEMM_8W")) : -1;          // A/B experiments only
-    const int waves8 = force8 >= 0 ? force8 : !(a->precision == BMT_PREC_BF16 && p.tiles_m * p.tiles_n >= 1024);
+    const int waves8 = force8 >= 0 ? force8 : 1;
     hipStream_t st_ = (hipStream_t)stream;
     const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
     if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles

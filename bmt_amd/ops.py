@@ -351,12 +351,14 @@ def splitk_workspace(device):
 
 KMAJOR = _os.environ.get("BMT_NO_KMAJOR") != "1"   # backward GEMMs read operands k-major (no transposed planes)
 AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
+DW_ATOMIC = _os.environ.get("BMT_DW_ATOMIC") == "1"     # A/B: weight gradients accumulate with fp32 atomics instead of workspace + epilogue
 TWO_PASS_SPLITK = True   # split-K through the workspace + epilogue kernel (False: atomic accumulation, weight gradients only)
 
 
 def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
               drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None, precision=None,
-              out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False, conv=None):
+              out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False, conv=None, two_pass: bool = True,
+              colsum: Optional[torch.Tensor] = None):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded).
     a_km / b_km: that operand is given K-MAJOR -- its plane has the reduction index as the row ([K rows][M or N columns]), i.e.
     it is the transpose of what the product needs, read through the hardware transpose unit (single-pass precision only)."""
@@ -403,11 +405,12 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=
                      _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
                      drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec, splitk)
     a.a_kmajor, a.b_kmajor, a.K = int(a_km), int(b_km), Ktrue
+    a.colsum = _p(colsum)        # += column sums of the (plane-only) output: the bias gradient of the Linear below a dX GEMM
     if conv is not None:
         a.N = N
         a.conv_mode, a.conv_cin, a.conv_rows = conv["mode"], conv["cin"], conv["rows"]
         a.conv_S, a.conv_halo = conv.get("S", 1), conv.get("halo", 0)
-    if splitk != 1 and TWO_PASS_SPLITK:
+    if splitk != 1 and TWO_PASS_SPLITK and two_pass:
         ws = splitk_workspace(A.hi.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
     _lib.check(lib.bmt_gemm_bf16(C.byref(a), _st()), "bmt_gemm_bf16")
@@ -505,10 +508,10 @@ def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Te
     km = _kmajor()          # k-major: dyT / xT are the STRAIGHT planes dY [M][N], X [M][K] (rows = the reduction index)
     N, K, M = (dyT.cols, xT.cols, dyT.rows) if km else (dyT.rows, xT.rows, dyT.cols)
     sk = _splitk_for(N, K, M)
-    atomic = sk > 1 and not TWO_PASS_SPLITK      # two-pass split-K has one writer per element: no zero-fill, no atomics
+    atomic = sk > 1 and (not TWO_PASS_SPLITK or (DW_ATOMIC and into is not None))      # two-pass split-K has one writer per element: no zero-fill, no atomics
     acc = into is not None or atomic
     dW = into if into is not None else (torch.zeros if atomic else torch.empty)(N, K, device=dyT.hi.device, dtype=torch.float32)
-    gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16, a_km=km, b_km=km)
+    gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16, a_km=km, b_km=km, two_pass=not atomic)
     return None if into is not None else dW
 
 
@@ -1072,6 +1075,26 @@ class FFNFn(torch.autograd.Function):
         drop = None
         if has_res:
             dy2, drop = drop_grad(dy2, b2p, res_p, res_site)
+        if USE_PLANE_GEMM and _kmajor() and _os.environ.get("BMT_FFN_DH_FP32") != "1":
+            # dH never exists in fp32: the fc2 dX GEMM writes its bf16 plane (relu / dropout derivative applied to whole row
+            # segments from the saved hidden plane) and its column sums -- fc1's bias gradient -- from the same epilogue
+            P2, T2, b2_done = grad_planes(dy2, b2p, drop=drop)
+            M_, Dff = h.rows, h.cols
+            gb1 = static_grad(b1p)
+            cs = gb1 if gb1 is not None else torch.zeros(Dff, device=dy2.device, dtype=torch.float32)
+            dhP = Planes(torch.empty(M_, _pad64(Dff), device=dy2.device, dtype=torch.bfloat16), None, M_, Dff)
+            linear_dx(P2, W2p, out_planes=dhP, gate=h, gate_scale=gscale, colsum=cs if b1p is not None else None)
+            dW2, db2 = wgrad(W2p, None if b2_done else b2p, T2, input_t(h), dy2_for_bias=dy2)
+            db1 = None
+            if b1p is not None:
+                if gb1 is not None:
+                    grad_done(b1p)
+                else:
+                    db1 = cs
+            dx, dW1 = lin_bwd_planes(dhP, dhP, W1p, ctx.xp if ctx.xp is not None else input_t(x2), need_dx=ctx.needs_input_grad[0])
+            if dx is not None:
+                dx = dx.view(*dy.shape[:-1], W1.shape[1])
+            return dx, dW1, db1, dW2, db2, None, None, (dy if has_res else None), None, None
         if USE_PLANE_GEMM:
             dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(input_t(h)), gate=h, gate_scale=gscale, drop=drop)
         else:

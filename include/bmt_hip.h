@@ -121,6 +121,9 @@ typedef struct {
      *                C[m][tap * conv_cin + c] = sum_r dY[r][m] * X[r + tap][c]                       (N = taps * conv_cin) */
     int conv_mode, conv_cin, conv_rows;
     int conv_S, conv_halo;      /* conv_mode 1: output rows are compact (m = b * S + s); they read rows m + 2 b * halo + tap of the advanced plane */
+    /* optional fp32 [N]: colsum[n] += sum over rows of the epilogue value (before bf16 rounding).  The column sums of a dX GEMM's
+     * output are the bias gradient of the Linear below it; asking for them disables split-K for the launch. */
+    float* colsum;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* x fp32 (B,S,C) -> halo-padded bf16 planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C); lo may be NULL */

@@ -579,3 +579,32 @@ def test_planes_of_a_dropped_gradient(ops, R, C):
     wantT = ops.make_planes(dropped, lo=False, straight=False, transposed=True)[1]
     gotT = ops.make_planes(x, lo=False, straight=False, transposed=True, drop=(p, site))[1]
     assert torch.equal(gotT.hi, wantT.hi)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 4096, 1024), (130, 200, 96), (128, 1024, 64)])
+def test_gemm_plane_output_with_vector_gate_and_column_sums(ops, M, N, K):
+    """dX GEMM of the FFN backward: plane-only output, relu/dropout gate applied per 16-byte segment from the saved hidden plane,
+    column sums (the next bias gradient) from the same epilogue -- against the fp32-output GEMM with the per-element gate."""
+    if not ops._kmajor():
+        pytest.skip("k-major operands disabled")
+    dy, W = rnd(M, K, seed=1).to(DEV), (rnd(K, N, seed=2) * 0.1).to(DEV)
+    hid = torch.relu(rnd(M, N, seed=3)).to(DEV)
+    hid[:, ::5] = 0
+    h = ops.make_planes(hid, lo=False)[0]
+    dyP = ops.make_planes(dy, lo=False)[0]
+    want = ops.linear_dx(dyP, W, gate=h, gate_scale=1.25)                      # fp32 out, per-element gate
+    assert bool((want[:, ::5] == 0).all()) and float(want.abs().max()) > 0
+    op = ops.Planes(torch.full((M, ops._pad64(N)), 3.0, device=DEV, dtype=torch.bfloat16), None, M, N)
+    cs = torch.zeros(N, device=DEV)
+    ops.linear_dx(dyP, W, out_planes=op, gate=h, gate_scale=1.25, colsum=cs)
+    got = op.hi[:, :N].float()
+    assert torch.equal(got == 0, want == 0)                                    # the mask itself: exact
+    # values: the fp32-output launch may be split-K (other summation order), so a bf16 rounding can flip: one bf16 ulp
+    assert_close(got, want, atol=1e-6, rtol=2 ** -7, name="gated plane output")
+    assert bool((op.hi[:, N:] == 0).all())
+    ref = want.double().sum(0)
+    assert_close(cs, ref, atol=2e-3 * float(ref.abs().max()) + 1e-3, name="column sums (hi + lo of the staged values)")
+    cs2 = torch.zeros(N, device=DEV)                                           # no gate: sums of the plain product
+    ops.linear_dx(dyP, W, out_planes=op, colsum=cs2)
+    full = ops.linear_dx(dyP, W)
+    assert_close(cs2, full.double().sum(0), atol=2e-3 * float(full.abs().sum(0).max()) + 1e-3, name="column sums, no gate")

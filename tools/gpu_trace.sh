@@ -11,7 +11,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last step: everything after the last rng_advance_kernel
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("rng_advance")]
+idx = [i for i, r in enumerate(rows) if "rng_advance" in r["Kernel_Name"]]
 last = rows[idx[-1]:] if idx else rows
 t0 = int(last[0]["Start_Timestamp"])
 with open("gpurun_out/trace_step.csv", "w") as f:
