@@ -226,6 +226,25 @@ def cpu_baseline(timeout_s=150):
         return {"value": None, "error": f"cpu baseline exceeded {timeout_s}s"}
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the newest committed PMC pass (profiles/*pmc_traffic.json, produced by
+    tools/gpu_pmc_bench.sh: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over this same step, gfx950 correction applied).
+    The counters cannot be read from inside the process that runs the step, so this is a recorded measurement, not a live one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, "no PMC pass committed"
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(kernel_class)
+    except (OSError, ValueError, KeyError):
+        return None, "unreadable PMC summary"
+    if not k:
+        return None, f"{os.path.basename(files[-1])} has no entry for {kernel_class}"
+    return k["traffic_bytes"], (f"profiles/{os.path.basename(files[-1])}: FETCH_SIZE x2 + WRITE_SIZE, mean over {k['launches_seen']} launches of the "
+                                "eagerly issued step (separate rocprofv3 --pmc passes); includes the split-K workspace traffic")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,8 +373,11 @@ def main():
             dom = max(summ, key=lambda k: summ[k]["ms"])
             d = summ[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic, traffic_note = pmc_traffic(dom)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
+                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"] if "bytes" in d else None,
                                "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                "share_of_timed_kernels": d["ms"] / tot,
                                "mfma_passes": 3 if dom.endswith("x3") else 1, "gemm_path": "planes" if ops.USE_PLANE_GEMM else "fp32-staged",
