@@ -608,7 +608,8 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 4;
     if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt) {
         // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
-        int want = 512 / tiles, cap = ktiles / 2;
+        static const int sk_target = getenv("BMT_SPLITK_TARGET") ? atoi(getenv("BMT_SPLITK_TARGET")) : 512;           // A/B experiments only
+        int want = sk_target / tiles, cap = ktiles / 2;
         if (want > 32) want = 32;
         splitk = want < cap ? want : cap;
         if (splitk < 1) splitk = 1;

@@ -114,10 +114,13 @@ def gemm(A, B, C_out, M, N, K, *, lda, ldb, ldc, a_kc=True, b_kc=True, alpha=1.0
     _lib.check(lib.bmt_gemm(C.byref(a), _st()), "bmt_gemm")
 
 
+_SPLITK_TARGET = int(_os.environ.get("BMT_SPLITK_TARGET", "512"))     # workgroups a split launch aims for (A/B experiments)
+
+
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     """Split the reduction of a weight-gradient GEMM so the launch fills the 256 CUs (2 workgroups each)."""
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    want = max(1, 512 // tiles)
+    want = max(1, _SPLITK_TARGET // tiles)
     return max(1, min(want, (red + 255) // 256))
 
 
