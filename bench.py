@@ -127,6 +127,21 @@ class KernelTimer:
                 (s, e, 10.0 * B_ * Sq * Sk * D, B_ * D * (2.0 * (Sq + 2 * Sk) + 8.0 * Sq + 4.0 * (Sq + 2 * Sk))))
             return r
 
+        raw_gg = ops.gemm_bf16_grouped
+
+        def gemm_bf16_grouped(items):
+            if not timer.enabled:
+                return raw_gg(items)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = raw_gg(items)
+            e.record()
+            fl = sum(2.0 * A.cols * B.cols * A.rows for A, B, _ in items)
+            by = sum(2.0 * A.rows * (A.cols + B.cols) + 4.0 * A.cols * B.cols for A, B, _ in items)
+            timer.records.setdefault("gemm_planes_x1", []).append((s, e, fl, by))      # the step's weight gradients, one launch
+            return r
+
+        ops.gemm_bf16_grouped = gemm_bf16_grouped
         raw_afp, raw_abp = ops.attn_fwd_planes, ops.attn_bwd_planes
 
         def attn_fwd_planes(q, k, v, B_, Sq, Sk, D, mask, H, **kw):

@@ -102,6 +102,8 @@ PP_CORNERS, PP_TRIM, PP_FILTER = 1, 2, 4
 # name -> (restype, argtypes); every symbol include/bmt_hip.h declares
 SIGNATURES = {
     "bmt_version": (i32, []),
+    "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
+    "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
     "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp]),
     "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "bmt_layernorm_bwd_add": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp]),

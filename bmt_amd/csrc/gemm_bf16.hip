@@ -143,7 +143,7 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
 // CONV = 1: operand A is a halo-padded activation plane read with a per-stage row shift (Conv1d forward and dX);
 // CONV = 2: operand B (k-major) is that plane read with a per-TILE row shift (Conv1d dW: output column block = tap).
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0>
-__global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
+__device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = (NPASS == 3) ? 32 : 64;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
 
     // tile order: XCD remap, then groups of 8 row panels walked column by column
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int w = xcd_remap(blockIdx.x, ntiles);
+    const int w = xcd_remap(tile_id, ntiles);
     const int GM = 8;
     const int per_group = GM * p.tiles_n;
     const int g = w / per_group;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     const int wi = w - g * per_group;
     const int tm = first_m + wi % gsz, tn = wi / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * p.kchunk;
+    const int kbeg = split_id * p.kchunk;
     const int kend = min(p.Kpad, kbeg + p.kchunk);
 
     f32x16 acc[TI][2];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     // B*S rows), where it replaces tiles*splits*16K fp32 atomics by streaming traffic.
     if (p.ws != nullptr) {
         const int64_t ldw = (int64_t)p.tiles_n * BN;
-        float* part = p.ws + (int64_t)blockIdx.y * p.tiles_m * BM * ldw;
+        float* part = p.ws + (int64_t)split_id * p.tiles_m * BM * ldw;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -416,6 +416,28 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
             }
         }
     }
+}
+
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0>
+__global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
+    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, CONV>(p, blockIdx.x, blockIdx.y);
+}
+
+// MANY independent GEMMs in one launch (the weight gradients of a whole step: each dW = dY^T . X is too small to fill the chip
+// on its own -- 64 tiles for a 1024 x 1024 weight -- which is why the single launches split their reduction and pay an
+// epilogue kernel plus the workspace traffic; together they are ~3000 tiles, enough to run every reduction unsplit).
+// table[i] describes problem i, first_tile[i] its first workgroup; problems are ordered by reduction length, longest first.
+template <int NPASS, int WM, int TI, bool AKM, bool BKM>
+__global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_grouped_kernel(
+    const GemmB* __restrict__ table, const int* __restrict__ first_tile, int nprob) {
+    int lo = 0, hi = nprob - 1;                       // last problem whose first tile is <= blockIdx.x (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_tile[mid] <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const GemmB p = table[lo];
+    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, (int)blockIdx.x - first_tile[lo], 0);
 }
 
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
@@ -556,7 +578,8 @@ int launch(const GemmB& p, int splitk, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
+// validate the arguments and fill the kernel descriptor; splitk: in = 0 (decide here) / forced value, out = splits to launch
+static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool allow_split) {
     BMT_CHECK_ARG(a && a->A_hi && a->B_hi && (a->C || a->C_hi), "bmt_gemm_bf16: null pointer");
     BMT_CHECK_ARG(a->M > 0 && a->N > 0 && a->Kpad > 0 && a->Kpad % 64 == 0, "bmt_gemm_bf16: bad sizes M=%d N=%d Kpad=%d (Kpad %% 64 != 0?)",
                   a->M, a->N, a->Kpad);
@@ -574,9 +597,10 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         bmt_set_error("bmt_gemm_bf16: planes must be 16-byte aligned with row strides multiples of 8 elements");
         return BMT_EALIGN;
     }
-    int splitk = a->splitk < 1 ? 1 : a->splitk;
+    splitk = a->splitk < 1 ? 1 : a->splitk;
+    if (!allow_split) splitk = 1;
     const bool accum = (a->flags & BMT_EPI_ACCUM) != 0;
-    const bool two_pass = a->splitk_ws != nullptr;                            // split-K through a workspace: any epilogue
+    const bool two_pass = allow_split && a->splitk_ws != nullptr;             // split-K through a workspace: any epilogue
     const unsigned nonlin = BMT_EPI_RELU | BMT_EPI_DROP_PRE | BMT_EPI_DROP_POST | BMT_EPI_GATE | BMT_EPI_BIAS | BMT_EPI_RESIDUAL;
     BMT_CHECK_ARG(splitk == 1 || two_pass || (accum && !(a->flags & nonlin) && !a->C_hi),
                   "bmt_gemm_bf16: splitk>1 needs either a split-K workspace or BMT_EPI_ACCUM with no other epilogue op / plane output");
@@ -584,7 +608,6 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_BIAS) || a->bias, "bmt_gemm_bf16: BIAS flag without pointer");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_RESIDUAL) || a->residual, "bmt_gemm_bf16: RESIDUAL flag without pointer");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_GATE) || a->gate, "bmt_gemm_bf16: GATE flag without pointer");
-    GemmB p;
     memset(&p, 0, sizeof(p));
     p.Ah = a->A_hi; p.Al = a->A_lo; p.Bh = a->B_hi; p.Bl = a->B_lo; p.lda = a->lda; p.ldb = a->ldb;
     p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_lo; p.ldp = a->ldp;
@@ -630,7 +653,14 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     p.colsum = a->colsum;
     BMT_CHECK_ARG(!a->colsum || (a->C_hi && p.plane_vec && !a->C), "bmt_gemm_bf16: colsum needs 16-byte aligned plane-only output");
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
-    int rc;
+    return BMT_OK;
+}
+
+extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
+    GemmB p;
+    int splitk = 0;
+    int rc = gemm_prepare(a, p, splitk, true);
+    if (rc != BMT_OK) return rc;
     // 128-row tile: 8 waves of 32x64 (4 waves per SIMD across two workgroups) hide the stage loop's LDS / barrier latency
     // better than 4 waves of 64x64 -- 25600x1024x128 forward 81 -> 57 us, 8192x1024x1024 x1 38 -> 33 us, whole step -6 %; also on
     // the very large grids (FFN fc2 dX, 2048 tiles of 16 stages: 156 -> 127 us; whole step 15.25 -> 14.97 ms same box)
@@ -654,6 +684,93 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     const int64_t groups = (int64_t)p.M * ((pc + 3) / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)bmt_cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(split-K epilogue)");
+    return BMT_OK;
+}
+
+// ---- grouped launch (see gemm_bf16_grouped_kernel).  The descriptor table lives in device memory and is written by small
+// kernels whose ARGUMENTS carry the descriptors: nothing is read from host memory when the launch executes, so the sequence can
+// be captured in a hipGraph and replayed (a memcpy node would re-read a host buffer that may have changed since the capture).
+struct GemmPack {
+    GemmB d[14];
+    int first[14];
+    int n, base;
+};
+static_assert(sizeof(GemmPack) <= 4000, "descriptor pack must fit the kernel argument buffer");
+
+__global__ void gemm_table_write_kernel(const GemmPack pk, GemmB* __restrict__ table, int* __restrict__ first_tile) {
+    const int i = blockIdx.x;
+    if (i >= pk.n) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&pk.d[i]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(table + pk.base + i);
+    for (int w = threadIdx.x; w < (int)(sizeof(GemmB) / 4); w += blockDim.x) dst[w] = src[w];
+    if (threadIdx.x == 0) first_tile[pk.base + i] = pk.first[i];
+}
+
+extern "C" size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob) {
+    return nprob <= 0 ? 0 : (size_t)nprob * (sizeof(GemmB) + sizeof(int)) + 256;
+}
+
+extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream) {
+    BMT_CHECK_ARG(args && ws && nprob > 0 && nprob <= 4096, "bmt_gemm_bf16_grouped: bad arguments");
+    BMT_CHECK_ARG(ws_bytes >= bmt_gemm_bf16_grouped_ws_bytes(nprob) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                  "bmt_gemm_bf16_grouped: workspace too small or not 16-byte aligned");
+    static_assert(sizeof(GemmB) % 4 == 0, "descriptor is copied word-wise");
+    struct Prob { GemmB p; int tiles, stages; };
+    Prob* pr = (Prob*)malloc(sizeof(Prob) * (size_t)nprob);
+    int* order = (int*)malloc(sizeof(int) * (size_t)nprob);
+    if (!pr || !order) { free(pr); free(order); bmt_set_error("bmt_gemm_bf16_grouped: out of host memory"); return BMT_EINVAL; }
+    int rc = BMT_OK;
+    for (int i = 0; i < nprob && rc == BMT_OK; ++i) {
+        const bmt_gemm_bf16_args* a = args + i;
+        if (!(a->precision == BMT_PREC_BF16 && a->a_kmajor && a->b_kmajor && a->conv_mode == 0 && a->C && !a->C_hi && !a->colsum)) {
+            bmt_set_error("bmt_gemm_bf16_grouped: problem %d: the grouped launch takes single-pass GEMMs with both operands k-major and "
+                          "fp32 output", i);
+            rc = BMT_EINVAL;
+            break;
+        }
+        int splitk = 1;
+        rc = gemm_prepare(a, pr[i].p, splitk, false);
+        pr[i].tiles = pr[i].p.tiles_m * pr[i].p.tiles_n;
+        pr[i].stages = a->Kpad / 64;
+        order[i] = i;
+    }
+    if (rc != BMT_OK) { free(pr); free(order); return rc; }
+    // longest reductions first (stable insertion sort: nprob is small), so that the tail of the launch is made of short tiles
+    for (int i = 1; i < nprob; ++i) {
+        const int o = order[i];
+        int j = i - 1;
+        while (j >= 0 && pr[order[j]].stages < pr[o].stages) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = o;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    GemmB* table = reinterpret_cast<GemmB*>(ws);
+    int* first_tile = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15));
+    int total = 0;
+    GemmPack pk;
+    for (int base = 0; base < nprob; base += 14) {
+        pk.n = nprob - base < 14 ? nprob - base : 14;
+        pk.base = base;
+        for (int i = 0; i < pk.n; ++i) {
+            const Prob& q = pr[order[base + i]];
+            pk.d[i] = q.p;
+            pk.first[i] = total;
+            total += q.tiles;
+        }
+        hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table, first_tile);
+    }
+    free(pr);
+    free(order);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(table)");
+    constexpr int BK = 64, BMr = 128;
+    constexpr int stage = BK * km_rs<BMr>() + BK * km_rs<BN>();
+    constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 4, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(total), dim3(512), lds, st, table, first_tile, nprob);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped");
     return BMT_OK;
 }
 

@@ -494,6 +494,55 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     return out
 
 
+# ---- deferred weight gradients: one grouped launch for every dW of a backward pass
+# Each dW = dY^T . X (reduction over the batch * sequence rows) accumulates into a static gradient buffer and nothing downstream of
+# the backward pass reads it before the optimizer, so the products need not run where autograd reaches them: a training step
+# queues them (DEFER_DW) and ``flush_dw`` issues ONE launch over all of them.  Alone a 1024 x 1024 weight is 64 tiles -- the single
+# launches split their reductions 8 ways and pay an epilogue kernel and the workspace traffic for it; together the step's ~50
+# weight gradients are ~3000 tiles and every reduction runs unsplit.
+DEFER_DW = False
+GROUPED_DW = _os.environ.get("BMT_NO_GROUPED_DW") != "1"
+_pending_dw = []
+
+
+_dw_ws = {}
+
+
+def gemm_bf16_grouped(items):
+    """items: [(dY planes [rows][N_out], X planes [rows][K_in], dW fp32 [N_out][K_in] accumulated in place)] -> one launch"""
+    n = len(items)
+    arr = (GemmBf16Args * n)()
+    for a, (A, B, Cm) in zip(arr, items):
+        rows = A.rows
+        assert B.rows == rows, (A.rows, B.rows)
+        a.A_hi, a.lda, a.B_hi, a.ldb = A.hi.data_ptr(), A.hi.stride(0), B.hi.data_ptr(), B.hi.stride(0)
+        a.C, a.ldc = Cm.data_ptr(), Cm.stride(0)
+        a.M, a.N, a.Kpad, a.K = A.cols, B.cols, _pad64(rows), rows
+        a.alpha, a.gate_scale, a.flags, a.precision, a.splitk = 1.0, 1.0, EPI_ACCUM, PREC_BF16, 1
+        a.a_kmajor, a.b_kmajor = 1, 1
+    dev = items[0][2].device
+    need = int(lib.bmt_gemm_bf16_grouped_ws_bytes(n))
+    ws = _dw_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)     # (allocated in the eager warm-up steps, before a capture)
+        _dw_ws[dev] = ws
+    _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
+
+
+def flush_dw():
+    """issue the queued weight-gradient products (call after the backward pass, before anything reads the gradients)"""
+    global _pending_dw
+    items, _pending_dw = _pending_dw, []
+    if not items:
+        return
+    if len(items) == 1 or not GROUPED_DW:
+        for dyT, xT, into in items:
+            gemm_bf16(dyT, xT, into, ldc=into.stride(0), accum=True, splitk=_splitk_for(dyT.cols, xT.cols, dyT.rows), precision=PREC_BF16,
+                      a_km=True, b_km=True)
+        return
+    gemm_bf16_grouped(items)
+
+
 def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """dW[N,K] = dy[M,N]^T @ x[M,K]   (reduction over M, split-K with atomic accumulation).
     plane path: dyT = transposed hi plane of dy [N][pad64(M)], xT = transposed hi plane of x [K][pad64(M)];
@@ -509,6 +558,9 @@ def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Te
              accum=acc, splitk=sk, precision=BWD_PRECISION)
         return None if into is not None else dW
     km = _kmajor()          # k-major: dyT / xT are the STRAIGHT planes dY [M][N], X [M][K] (rows = the reduction index)
+    if DEFER_DW and km and into is not None:
+        _pending_dw.append((dyT, xT, into))
+        return None
     N, K, M = (dyT.cols, xT.cols, dyT.rows) if km else (dyT.rows, xT.rows, dyT.cols)
     sk = _splitk_for(N, K, M)
     atomic = sk > 1 and (not TWO_PASS_SPLITK or (DW_ATOMIC and into is not None))      # two-pass split-K has one writer per element: no zero-fill, no atomics

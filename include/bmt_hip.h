@@ -126,6 +126,14 @@ typedef struct {
     float* colsum;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
+/* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight
+ * gradients dW = dY^T . X of a whole training step (each `weight.grad` product of autograd's backward is too small to fill the
+ * chip alone and would have to split its reduction).  args: host array of nprob argument structs (the same struct as
+ * bmt_gemm_bf16; precision BMT_PREC_BF16, a_kmajor = b_kmajor = 1, fp32 C, no plane output, no split).  ws: device scratch of
+ * bmt_gemm_bf16_grouped_ws_bytes(nprob) bytes, 16-byte aligned, that must stay untouched until the launch has executed; it is
+ * filled by kernels that carry the descriptors in their arguments, so the call can be captured in a hipGraph. */
+size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob);
+int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream);
 /* x fp32 (B,S,C) -> halo-padded bf16 planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C); lo may be NULL */
 int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL

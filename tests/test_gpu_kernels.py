@@ -608,3 +608,36 @@ def test_gemm_plane_output_with_vector_gate_and_column_sums(ops, M, N, K):
     ops.linear_dx(dyP, W, out_planes=op, colsum=cs2)
     full = ops.linear_dx(dyP, W)
     assert_close(cs2, full.double().sum(0), atol=2e-3 * float(full.abs().sum(0).max()) + 1e-3, name="column sums, no gate")
+
+
+def test_grouped_weight_gradient_launch(ops):
+    """bmt_gemm_bf16_grouped: the weight gradients of several layers (different shapes, ragged reduction lengths and widths) in one
+    launch, accumulated into live buffers -- against one split-K launch per problem."""
+    if not ops._kmajor():
+        pytest.skip("k-major operands disabled")
+    shapes = [(8192, 1024, 1024), (960, 300, 1024), (1000, 128, 512), (257, 130, 70), (64, 10000, 300), (25600, 1024, 128), (5000, 3072, 128)]
+    items, want = [], []
+    for i, (rows, n_out, k_in) in enumerate(shapes):
+        dy = ops.make_planes((rnd(rows, n_out, seed=10 + i) * 0.1).to(DEV), lo=False)[0]
+        x = ops.make_planes(rnd(rows, k_in, seed=40 + i).to(DEV), lo=False)[0]
+        acc = rnd(n_out, k_in, seed=70 + i).to(DEV)
+        ref = acc.clone()
+        ops.linear_dw(dy, x, into=ref)                     # one launch (split-K workspace + epilogue) per problem
+        items.append((dy, x, acc))
+        want.append(ref)
+    ops.gemm_bf16_grouped(items)
+    for (rows, n_out, k_in), (_, _, acc), ref in zip(shapes, items, want):
+        assert_close(acc, ref, atol=2e-4 * math.sqrt(rows), rtol=1e-5, name=f"grouped dW {n_out}x{k_in} over {rows} rows")
+    # queueing through linear_dw: nothing runs until flush_dw
+    ops.DEFER_DW = True
+    try:
+        accs = [torch.zeros_like(a) for _, _, a in items]
+        for (dy, x, _), a in zip(items, accs):
+            assert ops.linear_dw(dy, x, into=a) is None
+        assert all(float(a.abs().max()) == 0.0 for a in accs)
+        ops.flush_dw()
+    finally:
+        ops.DEFER_DW = False
+    for a, (_, _, acc0), ref, (rows, n_out, k_in) in zip(accs, items, want, shapes):
+        base = rnd(n_out, k_in, seed=70 + shapes.index((rows, n_out, k_in))).to(DEV)
+        assert_close(a, ref - base, atol=3e-4 * math.sqrt(rows), rtol=1e-5, name="deferred dW")

@@ -23,63 +23,69 @@ from bmt_amd import ops, synthetic as syn  # noqa: E402
 from bmt_amd.model.captioning_module import BiModalTransformer  # noqa: E402
 from bmt_amd.train import CaptioningTrainStep  # noqa: E402
 
-dev = torch.device("cuda", 0)
-torch.cuda.set_device(dev)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-V, Tv, Ta, Tc, B = 1000, 64, 200, 12, 8
-cfg = syn.cfg_config0(dout_p=0.1)
-cfg.device = str(dev)
-batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=5)
-fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
-caps = batch["captions"].to(dev)
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    V, Tv, Ta, Tc, B = 1000, 64, 200, 12, 8
+    cfg = syn.cfg_config0(dout_p=0.1)
+    cfg.device = str(dev)
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=5)
+    fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
+    caps = batch["captions"].to(dev)
 
 
-def run(mode):
-    first_site = ops._site_counter[0] if not hasattr(run, "site") else run.site
-    run.site = first_site
-    ops._site_counter[0] = first_site
-    torch.manual_seed(0)
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(dev)
-    ops.manual_seed(77)
-    dp = mode != "single"
-    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=dp, static_grads=True, overlap=(mode == "dp_eager_overlap"))
-    calls = [0]
-    if dp:
-        step.reducer.world = 2            # one rank, but issue every collective
-        raw = dist.all_reduce
-
-        def counted(*a, **k):
-            calls[0] += 1
-            return raw(*a, **k)
-        dist.all_reduce = counted
-    losses = []
-    try:
-        if mode in ("single", "dp_graph"):
-            step.capture(fs, caps, warmup=1)
-            for _ in range(4):
-                loss, _ = step.replay()
-                losses.append(float(loss))
-        else:
-            for _ in range(5):
-                loss, _ = step(fs, caps)
-                losses.append(float(loss))
-            losses = losses[1:]
-    finally:
+    def run(mode):
+        first_site = ops._site_counter[0] if not hasattr(run, "site") else run.site
+        run.site = first_site
+        ops._site_counter[0] = first_site
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(dev)
+        ops.manual_seed(77)
+        dp = mode != "single"
+        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=dp, static_grads=True, overlap=(mode == "dp_eager_overlap"))
+        calls = [0]
         if dp:
-            dist.all_reduce = raw
+            step.reducer.world = 2            # one rank, but issue every collective
+            raw = dist.all_reduce
+
+            def counted(*a, **k):
+                calls[0] += 1
+                return raw(*a, **k)
+            dist.all_reduce = counted
+        losses = []
+        try:
+            if mode in ("single", "dp_graph"):
+                step.capture(fs, caps, warmup=1)
+                for _ in range(4):
+                    loss, _ = step.replay()
+                    losses.append(float(loss))
+            else:
+                for _ in range(5):
+                    loss, _ = step(fs, caps)
+                    losses.append(float(loss))
+                losses = losses[1:]
+        finally:
+            if dp:
+                dist.all_reduce = raw
+        torch.cuda.synchronize()
+        return losses, calls[0]
+
+
+    ref, _ = run("single")
+    ok = True
+    for mode in ("dp_graph", "dp_eager_overlap", "dp_eager_after"):
+        got, n = run(mode)
+        same = all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(got, ref))
+        ok &= same and n > 0
+        print(f"{mode:18s} all_reduce calls {n:3d}  losses {'match' if same else 'DIFFER from'} the single-process step {got if not same else ''}")
+    print("single            ", ref)
     torch.cuda.synchronize()
-    return losses, calls[0]
+    dist.destroy_process_group()
+    print("DP-SMOKE", "OK" if ok else "FAILED")
+    return ok
 
 
-ref, _ = run("single")
-ok = True
-for mode in ("dp_graph", "dp_eager_overlap", "dp_eager_after"):
-    got, n = run(mode)
-    same = all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(got, ref))
-    ok &= same and n > 0
-    print(f"{mode:18s} all_reduce calls {n:3d}  losses {'match' if same else 'DIFFER from'} the single-process step {got if not same else ''}")
-print("single            ", ref)
-dist.destroy_process_group()
-print("DP-SMOKE", "OK" if ok else "FAILED")
-sys.exit(0 if ok else 1)
+if __name__ == "__main__":
+    sys.exit(0 if main() else 1)
