@@ -390,7 +390,8 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic, traffic_note = pmc_traffic(dom)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                               "frac_issued": ach * (3 if dom.endswith("x3") else 1) / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"] if "bytes" in d else None,
                                "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],

@@ -437,7 +437,9 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
         else hi = mid - 1;
     }
     const GemmB p = table[lo];
-    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, (int)blockIdx.x - first_tile[lo], 0);
+    const int tile = (int)blockIdx.x - first_tile[lo];
+    if (tile >= p.tiles_m * p.tiles_n) return;        // padding up to the next multiple of 8 workgroups
+    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, tile, 0);
 }
 
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
@@ -754,7 +756,7 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
             const Prob& q = pr[order[base + i]];
             pk.d[i] = q.p;
             pk.first[i] = total;
-            total += q.tiles;
+            total += (q.tiles + 7) / 8 * 8;          // every problem starts on XCD 0: its tile order keeps neighbours on one XCD
         }
         hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table, first_tile);
     }
@@ -769,7 +771,17 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 4, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(total), dim3(512), lds, st, table, first_tile, nprob);
+    static const int four = getenv("BMT_GROUPED_4W") ? atoi(getenv("BMT_GROUPED_4W")) : 0;      // A/B experiments only
+    if (four) {
+        static bool done4 = false;
+        if (!done4) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 2, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done4 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 2, 2, true, true>), dim3(total), dim3(256), lds, st, table, first_tile, nprob);
+    } else {
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(total), dim3(512), lds, st, table, first_tile, nprob);
+    }
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped");
     return BMT_OK;
 }
