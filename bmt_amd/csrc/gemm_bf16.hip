@@ -549,6 +549,67 @@ __global__ __launch_bounds__(256) void planes_kernel(const PlaneDesc d) {
     planes_tile(d, blockIdx.x, blockIdx.y, tile);
 }
 
+// Straight planes only (no transposed output -- the common case since the backward GEMMs read k-major operands): each thread
+// converts 8 consecutive columns of a row, two 16-byte loads in, one 16-byte store per plane out (planes_tile moves 4 / 2 bytes
+// per access because its thread mapping serves the LDS transpose).  Block = 64 rows x 128 columns; column sums: 8 partials per
+// thread, folded over the 16 row-threads of a column group through LDS, one atomic per column per block.
+__global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
+    __shared__ float cs[16][129];
+    const int tid = threadIdx.x;
+    const int cg = (tid & 15) * 8, rt = tid >> 4;
+    const int c0 = blockIdx.x * 128 + cg, r0 = blockIdx.y * 64;
+    const DropCtx dc = make_drop(d.drop_p, d.drop_rng, d.drop_site);
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < d.pcols) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = r0 + ps * 16 + rt;
+            if (r >= d.R) continue;
+            float v[8];
+            if (c0 + 8 <= d.C) {
+                const float4 a = *reinterpret_cast<const float4*>(d.src + (int64_t)r * d.ld + c0);
+                const float4 b = *reinterpret_cast<const float4*>(d.src + (int64_t)r * d.ld + c0 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (c0 + q < d.C) ? d.src[(int64_t)r * d.ld + c0 + q] : 0.f;     // ragged edge / zero padding
+            }
+            if (dc.on) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)((int64_t)r * d.C + c0 + q));
+            }
+            u32x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t hh, ll;
+                split_bf2(v[2 * q], v[2 * q + 1], hh, ll);
+                h[q] = hh; l[q] = ll;
+                part[2 * q] += v[2 * q]; part[2 * q + 1] += v[2 * q + 1];
+            }
+            *reinterpret_cast<u32x4*>(d.hi + (int64_t)r * d.ldp + c0) = h;
+            if (d.lo) *reinterpret_cast<u32x4*>(d.lo + (int64_t)r * d.ldp + c0) = l;
+        }
+    }
+    if (d.colsum) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cs[rt][cg + q] = part[q];
+        __syncthreads();
+        if (tid < 128 && blockIdx.x * 128 + tid < d.C) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += cs[i][tid];
+            atomicAdd(d.colsum + blockIdx.x * 128 + tid, t);
+        }
+    }
+}
+
+// the vector kernel applies when there is a straight hi plane and nothing transposed, everything 16-byte aligned
+static bool planes_rows_ok(const PlaneDesc& d) {
+    static const int old = getenv("BMT_PLANES_OLD") ? atoi(getenv("BMT_PLANES_OLD")) : 0;        // A/B experiments only
+    return !old && d.hi && !d.hiT && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
+           ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.hi) | reinterpret_cast<uintptr_t>(d.lo)) & 15) == 0;
+}
+
 // every weight of the model in ONE launch: blockIdx.y = tensor, blockIdx.x strides over its 64x64 tiles
 __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __restrict__ table) {
     __shared__ float tile[64][65];
@@ -807,7 +868,8 @@ extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* 
     PlaneDesc d;
     int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, colsum);
     if (rc) return rc;
-    hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
+    if (planes_rows_ok(d)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
     BMT_CHECK_LAUNCH("bmt_planes");
     return BMT_OK;
 }
@@ -820,7 +882,8 @@ extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, ui
     if (rc) return rc;
     BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_planes_dropout: bad dropout arguments");
     d.drop_p = drop_p; d.drop_site = site; d.drop_rng = rng;
-    hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
+    if (planes_rows_ok(d)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
     BMT_CHECK_LAUNCH("bmt_planes_dropout");
     return BMT_OK;
 }
