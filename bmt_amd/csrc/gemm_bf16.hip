@@ -503,6 +503,7 @@ struct PlaneDesc {
     float* colsum;
     int tiles_x, tiles_y;
     float drop_p; uint32_t drop_site; const uint64_t* drop_rng;     // optional: the source is masked (inverted dropout) first
+    int rows_ok;                                                    // bmt_planes_desc: eligible for the 16-byte row kernel
 };
 
 __device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, float (*tile)[65]) {
@@ -553,11 +554,10 @@ __global__ __launch_bounds__(256) void planes_kernel(const PlaneDesc d) {
 // converts 8 consecutive columns of a row, two 16-byte loads in, one 16-byte store per plane out (planes_tile moves 4 / 2 bytes
 // per access because its thread mapping serves the LDS transpose).  Block = 64 rows x 128 columns; column sums: 8 partials per
 // thread, folded over the 16 row-threads of a column group through LDS, one atomic per column per block.
-__global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
-    __shared__ float cs[16][129];
+__device__ __forceinline__ void planes_rows_tile(const PlaneDesc& d, int bx, int by, float (*cs)[129]) {
     const int tid = threadIdx.x;
     const int cg = (tid & 15) * 8, rt = tid >> 4;
-    const int c0 = blockIdx.x * 128 + cg, r0 = blockIdx.y * 64;
+    const int c0 = bx * 128 + cg, r0 = by * 64;
     const DropCtx dc = make_drop(d.drop_p, d.drop_rng, d.drop_site);
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c0 < d.pcols) {
@@ -594,13 +594,18 @@ __global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) cs[rt][cg + q] = part[q];
         __syncthreads();
-        if (tid < 128 && blockIdx.x * 128 + tid < d.C) {
+        if (tid < 128 && bx * 128 + tid < d.C) {
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) t += cs[i][tid];
-            atomicAdd(d.colsum + blockIdx.x * 128 + tid, t);
+            atomicAdd(d.colsum + bx * 128 + tid, t);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
+    __shared__ float cs[16][129];
+    planes_rows_tile(d, blockIdx.x, blockIdx.y, cs);
 }
 
 // the vector kernel applies when there is a straight hi plane and nothing transposed, everything 16-byte aligned
@@ -614,6 +619,11 @@ static bool planes_rows_ok(const PlaneDesc& d) {
 __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __restrict__ table) {
     __shared__ float tile[64][65];
     const PlaneDesc d = table[blockIdx.y];
+    if (d.rows_ok) {                 // straight planes only, aligned: the 16-byte path (64 x 128 tiles)
+        const int ntx = (d.pcols + 127) / 128, nt = ntx * ((d.R + 63) / 64);
+        for (int t = blockIdx.x; t < nt; t += gridDim.x) planes_rows_tile(d, t % ntx, t / ntx, nullptr);
+        return;
+    }
     const int nt = d.tiles_x * d.tiles_y;
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         planes_tile(d, t % d.tiles_x, t / d.tiles_x, tile);
@@ -896,6 +906,7 @@ extern "C" int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int
     memset(&d, 0, sizeof(d));
     int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, nullptr);
     if (rc) return rc;
+    d.rows_ok = planes_rows_ok(d) ? 1 : 0;
     memcpy(desc_out, &d, sizeof(d));
     return BMT_OK;
 }
