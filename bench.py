@@ -322,7 +322,8 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    # ---- the step is captured into ONE hipGraph (zero_grad .. Adam, incl. the RCCL all-reduce); eager issue is the fallback
+    # ---- the step is captured into two hipGraphs ({zero_grad .. backward}, {Adam}) with the eager RCCL all-reduce of the flat
+    # gradient buckets between them (nothing collective is captured); eager issue of every kernel is the fallback
     mode = "eager"
     run = lambda: step(fs, caps)
     if not args.no_graph:
