@@ -143,7 +143,7 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
 // CONV = 1: operand A is a halo-padded activation plane read with a per-stage row shift (Conv1d forward and dX);
 // CONV = 2: operand B (k-major) is that plane read with a per-TILE row shift (Conv1d dW: output column block = tap).
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0>
-__device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id) {
+__device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = (NPASS == 3) ? 32 : 64;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 
     // tile order: XCD remap, then groups of 8 row panels walked column by column
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int w = xcd_remap(tile_id, ntiles);
+    const int w = raw_order ? tile_id : xcd_remap(tile_id, ntiles);      // raw: the caller already placed this tile on its XCD
     const int GM = 8;
     const int per_group = GM * p.tiles_n;
     const int g = w / per_group;
@@ -426,20 +426,32 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
 // MANY independent GEMMs in one launch (the weight gradients of a whole step: each dW = dY^T . X is too small to fill the chip
 // on its own -- 64 tiles for a 1024 x 1024 weight -- which is why the single launches split their reduction and pay an
 // epilogue kernel plus the workspace traffic; together they are ~3000 tiles, enough to run every reduction unsplit).
-// table[i] describes problem i, first_tile[i] its first workgroup; problems are ordered by reduction length, longest first.
+// Every XCD has its own L2, so a problem spread over all 8 of them streams its operand panels from HBM 8 times; here the host
+// packs the problems onto XCDs (whole problems, large ones in 2-8 contiguous parts): XCD x = workgroup index mod 8 works through
+// its own list of segments {first slot, problem, first tile, tile count}, a tile's neighbours in the L2-friendly order run
+// on the same XCD, and an operand panel is fetched by as few XCDs as the load balance allows.
+struct XcdSeg {
+    int first_slot, prob, tile_off, count;
+};
+constexpr int XCD_MAXSEG = 64;
+
 template <int NPASS, int WM, int TI, bool AKM, bool BKM>
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_grouped_kernel(
-    const GemmB* __restrict__ table, const int* __restrict__ first_tile, int nprob) {
-    int lo = 0, hi = nprob - 1;                       // last problem whose first tile is <= blockIdx.x (uniform: scalar loads)
+    const GemmB* __restrict__ table, const XcdSeg* __restrict__ segs, const int* __restrict__ nseg) {
+    const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const XcdSeg* sx = segs + x * XCD_MAXSEG;
+    int lo = 0, hi = nseg[x] - 1;                     // last segment of this XCD whose first slot is <= slot (uniform: scalar loads)
+    if (hi < 0) return;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (first_tile[mid] <= (int)blockIdx.x) lo = mid;
+        if (sx[mid].first_slot <= slot) lo = mid;
         else hi = mid - 1;
     }
-    const GemmB p = table[lo];
-    const int tile = (int)blockIdx.x - first_tile[lo];
-    if (tile >= p.tiles_m * p.tiles_n) return;        // padding up to the next multiple of 8 workgroups
-    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, tile, 0);
+    const XcdSeg sg = sx[lo];
+    const int local = slot - sg.first_slot;
+    if (local >= sg.count) return;                    // past the end of this XCD's list
+    const GemmB p = table[sg.prob];
+    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, sg.tile_off + local, 0, true);
 }
 
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
@@ -760,27 +772,35 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     return BMT_OK;
 }
 
-// ---- grouped launch (see gemm_bf16_grouped_kernel).  The descriptor table lives in device memory and is written by small
-// kernels whose ARGUMENTS carry the descriptors: nothing is read from host memory when the launch executes, so the sequence can
-// be captured in a hipGraph and replayed (a memcpy node would re-read a host buffer that may have changed since the capture).
+// ---- grouped launch (see gemm_bf16_grouped_kernel).  The descriptor table and the per-XCD segment lists live in device memory
+// and are written by small kernels whose ARGUMENTS carry them: nothing is read from host memory when the launch executes, so the
+// sequence can be captured in a hipGraph and replayed (a memcpy node would re-read a host buffer that may have changed).
 struct GemmPack {
     GemmB d[14];
-    int first[14];
     int n, base;
 };
 static_assert(sizeof(GemmPack) <= 4000, "descriptor pack must fit the kernel argument buffer");
+struct SegPack {
+    XcdSeg s[2][XCD_MAXSEG];
+    int n[2], xcd0;
+};
+static_assert(sizeof(SegPack) <= 4000, "segment pack must fit the kernel argument buffer");
 
-__global__ void gemm_table_write_kernel(const GemmPack pk, GemmB* __restrict__ table, int* __restrict__ first_tile) {
+__global__ void gemm_table_write_kernel(const GemmPack pk, GemmB* __restrict__ table) {
     const int i = blockIdx.x;
     if (i >= pk.n) return;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&pk.d[i]);
     uint32_t* dst = reinterpret_cast<uint32_t*>(table + pk.base + i);
     for (int w = threadIdx.x; w < (int)(sizeof(GemmB) / 4); w += blockDim.x) dst[w] = src[w];
-    if (threadIdx.x == 0) first_tile[pk.base + i] = pk.first[i];
+}
+__global__ void gemm_segs_write_kernel(const SegPack pk, XcdSeg* __restrict__ segs, int* __restrict__ nseg) {
+    const int x = blockIdx.x;                  // 0, 1: XCD pk.xcd0 + x
+    for (int i = threadIdx.x; i < pk.n[x]; i += blockDim.x) segs[(pk.xcd0 + x) * XCD_MAXSEG + i] = pk.s[x][i];
+    if (threadIdx.x == 0) nseg[pk.xcd0 + x] = pk.n[x];
 }
 
 extern "C" size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob) {
-    return nprob <= 0 ? 0 : (size_t)nprob * (sizeof(GemmB) + sizeof(int)) + 256;
+    return nprob <= 0 ? 0 : (size_t)nprob * sizeof(GemmB) + 8 * XCD_MAXSEG * sizeof(XcdSeg) + 8 * sizeof(int) + 512;
 }
 
 extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream) {
@@ -791,8 +811,10 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     struct Prob { GemmB p; int tiles, stages; };
     Prob* pr = (Prob*)malloc(sizeof(Prob) * (size_t)nprob);
     int* order = (int*)malloc(sizeof(int) * (size_t)nprob);
-    if (!pr || !order) { free(pr); free(order); bmt_set_error("bmt_gemm_bf16_grouped: out of host memory"); return BMT_EINVAL; }
+    SegPack* sp = (SegPack*)malloc(sizeof(SegPack) * 4);
+    if (!pr || !order || !sp) { free(pr); free(order); free(sp); bmt_set_error("bmt_gemm_bf16_grouped: out of host memory"); return BMT_EINVAL; }
     int rc = BMT_OK;
+    double total_work = 0.0;
     for (int i = 0; i < nprob && rc == BMT_OK; ++i) {
         const bmt_gemm_bf16_args* a = args + i;
         if (!(a->precision == BMT_PREC_BF16 && a->a_kmajor && a->b_kmajor && a->conv_mode == 0 && a->C && !a->C_hi && !a->colsum)) {
@@ -805,34 +827,67 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         rc = gemm_prepare(a, pr[i].p, splitk, false);
         pr[i].tiles = pr[i].p.tiles_m * pr[i].p.tiles_n;
         pr[i].stages = a->Kpad / 64;
+        total_work += (double)pr[i].tiles * (pr[i].stages + 2);      // + prologue / epilogue of a tile
         order[i] = i;
     }
-    if (rc != BMT_OK) { free(pr); free(order); return rc; }
-    // longest reductions first (stable insertion sort: nprob is small), so that the tail of the launch is made of short tiles
+    if (rc != BMT_OK) { free(pr); free(order); free(sp); return rc; }
+    // largest problems first (stable insertion sort: nprob is small)
+    auto work = [&](int i) { return (double)pr[i].tiles * (pr[i].stages + 2); };
     for (int i = 1; i < nprob; ++i) {
         const int o = order[i];
         int j = i - 1;
-        while (j >= 0 && pr[order[j]].stages < pr[o].stages) { order[j + 1] = order[j]; --j; }
+        while (j >= 0 && work(order[j]) < work(o)) { order[j + 1] = order[j]; --j; }
         order[j + 1] = o;
     }
+    // pack onto the 8 XCDs: a problem goes to the least loaded XCD; one that is more than ~60 % of an XCD's fair share is cut
+    // into 2, 4 or 8 contiguous tile ranges first (placed independently)
+    static const int spread = getenv("BMT_GROUPED_SPREAD") ? atoi(getenv("BMT_GROUPED_SPREAD")) : 0;       // A/B: every problem over all 8 XCDs
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double share = total_work / 8.0;
+    bool overflow = false;
+    for (int oi = 0; oi < nprob && !overflow; ++oi) {
+        const int i = order[oi];
+        int parts = 1;
+        while (parts < 8 && work(i) / parts > 0.6 * share) parts *= 2;
+        if (spread) parts = 8;
+        if (parts > pr[i].tiles) parts = 1;
+        const int per = (pr[i].tiles + parts - 1) / parts;
+        for (int part = 0; part < parts; ++part) {
+            const int t0 = part * per, cnt = (t0 + per <= pr[i].tiles) ? per : pr[i].tiles - t0;
+            if (cnt <= 0) break;
+            int x = 0;
+            if (spread) x = part;
+            else for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+            if (ns[x] >= XCD_MAXSEG) { overflow = true; break; }
+            XcdSeg& sg = sp[x / 2].s[x & 1][ns[x]++];
+            sg.first_slot = slots[x]; sg.prob = i; sg.tile_off = t0; sg.count = cnt;
+            slots[x] += cnt;
+            load[x] += (double)cnt * (pr[i].stages + 2);
+        }
+    }
+    if (overflow) { free(pr); free(order); free(sp); bmt_set_error("bmt_gemm_bf16_grouped: too many segments for one XCD"); return BMT_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     GemmB* table = reinterpret_cast<GemmB*>(ws);
-    int* first_tile = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15));
-    int total = 0;
+    char* tail = reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15);
+    XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
+    int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
     GemmPack pk;
     for (int base = 0; base < nprob; base += 14) {
         pk.n = nprob - base < 14 ? nprob - base : 14;
         pk.base = base;
-        for (int i = 0; i < pk.n; ++i) {
-            const Prob& q = pr[order[base + i]];
-            pk.d[i] = q.p;
-            pk.first[i] = total;
-            total += (q.tiles + 7) / 8 * 8;          // every problem starts on XCD 0: its tile order keeps neighbours on one XCD
-        }
-        hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table, first_tile);
+        for (int i = 0; i < pk.n; ++i) pk.d[i] = pr[base + i].p;
+        hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table);
+    }
+    int max_slots = 0;
+    for (int x = 0; x < 8; ++x) max_slots = slots[x] > max_slots ? slots[x] : max_slots;
+    for (int q = 0; q < 4; ++q) {
+        sp[q].n[0] = ns[2 * q]; sp[q].n[1] = ns[2 * q + 1]; sp[q].xcd0 = 2 * q;
+        hipLaunchKernelGGL(gemm_segs_write_kernel, dim3(2), dim3(64), 0, st, sp[q], segs, nseg);
     }
     free(pr);
     free(order);
+    free(sp);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(table)");
     constexpr int BK = 64, BMr = 128;
     constexpr int stage = BK * km_rs<BMr>() + BK * km_rs<BN>();
@@ -842,17 +897,7 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 4, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    static const int four = getenv("BMT_GROUPED_4W") ? atoi(getenv("BMT_GROUPED_4W")) : 0;      // A/B experiments only
-    if (four) {
-        static bool done4 = false;
-        if (!done4) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 2, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done4 = true;
-        }
-        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 2, 2, true, true>), dim3(total), dim3(256), lds, st, table, first_tile, nprob);
-    } else {
-        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(total), dim3(512), lds, st, table, first_tile, nprob);
-    }
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(8 * max_slots), dim3(512), lds, st, table, segs, nseg);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped");
     return BMT_OK;
 }
