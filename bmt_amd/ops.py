@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROP_POST, EPI_DROP_PRE, EPI_GATE, EPI_RELU, EPI_RESIDUAL, PREC_BF16,
-                   PREC_BF16X3, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, Conv1dArgs, GemmArgs, GemmBf16Args)
+                   PREC_BF16X3, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, GemmArgs, GemmBf16Args)
 
 lib = _lib.load()
 

@@ -17,7 +17,6 @@ from typing import Dict, Optional
 
 import torch
 
-from . import _lib
 from .loss.label_smoothing import LabelSmoothing
 from .model.masking import mask as make_mask
 from .optim import FusedAdam, clip_grad_norm_
