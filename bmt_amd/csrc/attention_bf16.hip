@@ -142,6 +142,7 @@ struct AttnPB {
     const float *O, *dO, *lse;
     const uint16_t *Oph, *Opl;             // saved forward output as planes (backward, when O == nullptr)
     float *Ow, *lsew, *delta;
+    int fuse_delta;                        // backward, 16-wide kernels: the dQ kernel computes delta = rowsum(dO * O) itself (and stores it for dK/dV)
     uint16_t *Owh, *Owl;                   // forward output planes (optional), strides ldop / bsop
     int64_t ldop, bsop;
     GradOut gq, gk, gv;
@@ -1050,7 +1051,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
     const float lse = qok ? p.lse[stat] : 0.f;
-    const float delta = qok ? p.delta[stat] : 0.f;
+    float delta;
+    if (p.fuse_delta) {
+        // delta_i = (1 - p_drop) * sum_d dO_id * O_id from the dO fragments this lane already holds and the matching slices of
+        // the saved output planes (8 g + 32 ks .. + 8 of the row: the four lanes of a query cover it); replaces a separate pass
+        // over dO and O.  Stored for the dK / dV kernel, which runs after this one.
+        const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + 8 * g;
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 oh = ldfrag(p.Oph + po + 32 * ks, qok);
+            bf16x8 ol = oh;
+            if (p.Opl) ol = ldfrag(p.Opl + po + 32 * ks, qok);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float ov = (float)oh[j];
+                if (p.Opl) ov += (float)ol[j];
+                acc += (float)dof[ks][j] * ov;
+            }
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        delta = acc * (1.f - p.drop_p);
+        if (qok && g == 0) p.delta[stat] = delta;
+    } else {
+        delta = qok ? p.delta[stat] : 0.f;
+    }
     const int troff = tr_lane_off(pad_rs<DK>(), c, g);
 
     f32x4v dq[DT];
@@ -1295,7 +1321,11 @@ int launch_fwd(const AttnPB& p, hipStream_t st) {
 template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
-    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
+    static const int sep = getenv("BMT_ATTN_DELTA_SEPARATE") ? atoi(getenv("BMT_ATTN_DELTA_SEPARATE")) : 0;      // A/B experiments only
+    const bool fuse = DK >= 128 && !sep && p.dO == nullptr && p.O == nullptr && p.Oph != nullptr;
+    if (!fuse) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
+    AttnPB pf = p;
+    pf.fuse_delta = fuse ? 1 : 0;
     const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
     const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
@@ -1307,7 +1337,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
                 (void)hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 done = true;
             }
-            hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, p);
+            hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, pf);
         }
         {
             const int lds_loop = 2 * 32 * (DK * 2 + 32) + 2 * 32 * 4, lds_epi = 2 * DK * (128 + 8) * 2;
