@@ -1,15 +1,17 @@
 """bench.py -- caption tokens/s of the train_cap step (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE from the environment)
+    python bench.py --procedure train_prop                 (configs[3]: the proposal generator step, its own roofline line)
 
 A step = zero_grad -> masks -> forward -> LabelSmoothing/n_tokens -> backward -> gradient all-reduce -> Adam
 (epoch_loops/captioning_epoch_loops.py:128-141) on one synthetic batch already resident in HBM.
 Workload = BASELINE.json configs[1]: B=32 per GPU (weak scaling), N=2, d_model=1024, H=4, d_audio=128,
 d_video=1024, d_caps=300, T_v=256, T_a=800, T_c=30, V=10000, dropout 0.1, Adam lr 5e-5, GloVe frozen.
-Forward products run split-bf16 (3 MFMA passes, log-probs within 1e-3 of the fp32 reference, see
-tests/test_gpu_model.py), backward products single-pass bf16; accumulation, softmax, LayerNorm, loss, Adam in fp32.
+Forward products follow the per-site operand policy of bmt_amd/ops.py (DESIGN.md "precision": fp16 / split-fp16 / split-bf16
+MFMA operands chosen so that the log-probs stay within 1e-3 of the fp32 reference, see tests/test_gpu_model.py), backward
+products run single-pass bf16; accumulation, softmax, LayerNorm, loss, Adam in fp32.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel class, ALGORITHMIC flops / HIP-event time measured live in the timed region
@@ -36,144 +38,69 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}   # class -> list of (start, end, flops, bytes)
+        self.passes = {}    # class -> MFMA passes per algorithmic product
         self.enabled = False
+
+    def _timed(self, cls, passes, flops, nbytes, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self.records.setdefault(cls, []).append((s, e, flops, nbytes))
+        self.passes[cls] = passes
+        return r
 
     def wrap(self, ops):
         timer = self
-        raw_gemm, raw_afwd, raw_abwd = ops.gemm, ops.attn_fwd, ops.attn_bwd
-
-        def gemm(A, B, C_out, M, N, K, **kw):
-            if not timer.enabled:
-                return raw_gemm(A, B, C_out, M, N, K, **kw)
-            prec = kw.get("precision") or ops.FWD_PRECISION
-            cls = f"gemm_{'kc' if kw.get('a_kc', True) else 'rc'}_{'kc' if kw.get('b_kc', True) else 'rc'}_x{prec}"
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_gemm(A, B, C_out, M, N, K, **kw)
-            e.record()
-            timer.records.setdefault(cls, []).append((s, e, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
-            return r
-
-        def attn_fwd(q, k, v, mask, H, **kw):
-            if not timer.enabled:
-                return raw_afwd(q, k, v, mask, H, **kw)
-            B_, Sq, D = q.shape
-            Sk = k.shape[1]
-            prec = kw.get("precision") or ops.FWD_PRECISION
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_afwd(q, k, v, mask, H, **kw)
-            e.record()
-            timer.records.setdefault(f"attn_fwd_dk{D // H}_x{prec}", []).append(
-                (s, e, 4.0 * B_ * Sq * Sk * D, 4.0 * B_ * D * (2 * Sq + 2 * Sk)))
-            return r
-
-        def attn_bwd(q, k, v, o, do, lse, mask, H, **kw):
-            if not timer.enabled:
-                return raw_abwd(q, k, v, o, do, lse, mask, H, **kw)
-            B_, Sq, D = q.shape
-            Sk = k.shape[1]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_abwd(q, k, v, o, do, lse, mask, H, **kw)
-            e.record()
-            # algorithmic backward = 5 products (dV, dP, dQ, dK + S recompute) = 2.5 x forward
-            timer.records.setdefault(f"attn_bwd_dk{D // H}", []).append(
-                (s, e, 10.0 * B_ * Sq * Sk * D, 4.0 * B_ * D * (4 * Sq + 4 * Sk)))
-            return r
-
-        raw_gb, raw_afb, raw_abb = ops.gemm_bf16, ops.attn_fwd_bf16, ops.attn_bwd_bf16
+        raw_gb, raw_gg = ops.gemm_bf16, ops.gemm_bf16_grouped
+        raw_afp, raw_abp = ops.attn_fwd_planes, ops.attn_bwd_planes
 
         def gemm_bf16(A, B, C_out, **kw):
             if not timer.enabled:
                 return raw_gb(A, B, C_out, **kw)
             prec = kw.get("precision") or ops.FWD_PRECISION
-            akm, bkm = kw.get("a_km", False), kw.get("b_km", False)        # k-major operand: its ROWS are the reduction index
-            M = A.cols if akm else A.rows
-            N = B.cols if bkm else B.rows
-            K = A.rows if akm else (B.rows if bkm else A.cols)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_gb(A, B, C_out, **kw)
-            e.record()
-            nb = 2 * prec if prec == 3 else 2
-            timer.records.setdefault(f"gemm_planes_x{prec}", []).append((s, e, 2.0 * M * N * K, nb * (M * K + N * K) + 4.0 * M * N))
-            return r
-
-        def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, **kw):
-            if not timer.enabled:
-                return raw_afb(qh, ql, kh, kl, vh, vl, mask, H, **kw)
-            B_, Sq, D = qh.shape
-            Sk = kh.shape[1]
-            prec = kw.get("precision") or ops.FWD_PRECISION
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_afb(qh, ql, kh, kl, vh, vl, mask, H, **kw)
-            e.record()
-            timer.records.setdefault(f"attn_fwd_planes_dk{D // H}_x{prec}", []).append(
-                (s, e, 4.0 * B_ * Sq * Sk * D, (4.0 if prec == 3 else 2.0) * B_ * D * (Sq + 2 * Sk) + 4.0 * B_ * D * Sq))
-            return r
-
-        def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, **kw):
-            if not timer.enabled:
-                return raw_abb(qh, kh, vh, o, do, lse, mask, H, **kw)
-            B_, Sq, D = qh.shape
-            Sk = kh.shape[1]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_abb(qh, kh, vh, o, do, lse, mask, H, **kw)
-            e.record()
-            timer.records.setdefault(f"attn_bwd_planes_dk{D // H}", []).append(
-                (s, e, 10.0 * B_ * Sq * Sk * D, B_ * D * (2.0 * (Sq + 2 * Sk) + 8.0 * Sq + 4.0 * (Sq + 2 * Sk))))
-            return r
-
-        raw_gg = ops.gemm_bf16_grouped
+            akm, bkm, conv = kw.get("a_km", False), kw.get("b_km", False), kw.get("conv")
+            if conv is not None and conv["mode"] == 1:       # implicit Conv1d forward / dX: reduction over (tap, channel)
+                M, N, K = conv["M"], B.rows, B.hi.shape[1]
+            elif conv is not None:                            # implicit Conv1d dW
+                M, N, K = A.cols, conv["N"], A.rows
+            else:                                             # k-major operand: its ROWS are the reduction index
+                M = A.cols if akm else A.rows
+                N = B.cols if bkm else B.rows
+                K = A.rows if akm else (B.rows if bkm else A.cols)
+            nb = ops.prec_operand_bytes(prec)
+            cls = ("conv_planes_" if conv is not None else "gemm_planes_") + ops.prec_name(prec)
+            return timer._timed(cls, ops.prec_passes(prec), 2.0 * M * N * K, nb[0] * M * K + nb[1] * N * K + 4.0 * M * N,
+                                lambda: raw_gb(A, B, C_out, **kw))
 
         def gemm_bf16_grouped(items):
             if not timer.enabled:
                 return raw_gg(items)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_gg(items)
-            e.record()
             fl = sum(2.0 * A.cols * B.cols * A.rows for A, B, _ in items)
             by = sum(2.0 * A.rows * (A.cols + B.cols) + 4.0 * A.cols * B.cols for A, B, _ in items)
-            timer.records.setdefault("gemm_planes_x1", []).append((s, e, fl, by))      # the step's weight gradients, one launch
-            return r
-
-        ops.gemm_bf16_grouped = gemm_bf16_grouped
-        raw_afp, raw_abp = ops.attn_fwd_planes, ops.attn_bwd_planes
+            return timer._timed("gemm_planes_dw_grouped_bf16", 1, fl, by, lambda: raw_gg(items))     # the step's weight gradients, one launch
 
         def attn_fwd_planes(q, k, v, B_, Sq, Sk, D, mask, H, **kw):
             if not timer.enabled:
                 return raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw)
-            prec = kw.get("precision") or ops.FWD_PRECISION
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw)
-            e.record()
+            prec = kw.get("precision") or ops.ATTN_PRECISION
             side = "enc" if min(Sq, Sk) >= 128 else "dec"
-            nb = 4.0 if prec == 3 else 2.0          # hi (+lo) planes in and out
-            timer.records.setdefault(f"attn_fwd_{side}_dk{D // H}_x{prec}", []).append(
-                (s, e, 4.0 * B_ * Sq * Sk * D, nb * B_ * D * (2 * Sq + 2 * Sk)))
-            return r
+            nb = sum(ops.prec_operand_bytes(prec)) / 2.0          # operand plane bytes per element in, the same again out
+            return timer._timed(f"attn_fwd_{side}_dk{D // H}_{ops.prec_name(prec)}", ops.prec_passes(prec),
+                                4.0 * B_ * Sq * Sk * D, nb * B_ * D * (Sq + 2 * Sk) + 4.0 * B_ * D * Sq,
+                                lambda: raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw))
 
         def attn_bwd_planes(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw):
             if not timer.enabled:
                 return raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw)
-            e.record()
             side = "enc" if min(Sq, Sk) >= 128 else "dec"
-            # algorithmic backward = 5 products (S recompute, dP, dV, dK, dQ) = 2.5 x forward; bytes: q,k,v hi planes, O hi+lo,
-            # dO fp32 in; dq,dk,dv plane + transposed plane out
-            timer.records.setdefault(f"attn_bwd_{side}_dk{D // H}", []).append(
-                (s, e, 10.0 * B_ * Sq * Sk * D, B_ * D * (2.0 * (Sq + 2 * Sk) + 8.0 * Sq + 4.0 * (Sq + 2 * Sk))))
-            return r
+            # algorithmic backward = 5 products (S recompute, dP, dV, dK, dQ) = 2.5 x forward; bytes: q,k,v bf16 planes, O planes,
+            # dO plane in; dq,dk,dv planes out
+            return timer._timed(f"attn_bwd_{side}_dk{D // H}_bf16", 1, 10.0 * B_ * Sq * Sk * D,
+                                B_ * D * (2.0 * (Sq + 2 * Sk) + 6.0 * Sq + 2.0 * (Sq + 2 * Sk)),
+                                lambda: raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw))
 
-        ops.gemm, ops.attn_fwd, ops.attn_bwd = gemm, attn_fwd, attn_bwd
-        ops.gemm_bf16, ops.attn_fwd_bf16, ops.attn_bwd_bf16 = gemm_bf16, attn_fwd_bf16, attn_bwd_bf16
+        ops.gemm_bf16, ops.gemm_bf16_grouped = gemm_bf16, gemm_bf16_grouped
         ops.attn_fwd_planes, ops.attn_bwd_planes = attn_fwd_planes, attn_bwd_planes
 
     def summary(self):
@@ -187,18 +114,21 @@ class KernelTimer:
 
 
 def cpu_baseline_worker():
-    """runs in a child process (see cpu_baseline): the reference's CPU path as restated by the oracle -- fwd + bwd + Adam
-    on a bounded sample of the same workload -- prints one JSON object."""
+    """runs in a child process (see cpu_baseline): the reference's CPU path as restated by the oracle -- the identical config[1]
+    step (B=32, fwd + bwd + Adam, fp32, dropout 0.1) -- 3 warm-up steps, then timed steps; prints one JSON object after EVERY
+    timed step (median so far), so a parent that has to kill the child on its time bound still has a number."""
     from bmt_amd import synthetic as syn
     from oracle import bmt_oracle as orc
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))          # more threads than this only add contention at these sizes
+    cores = max(1, min(avail, 64))
     torch.set_num_threads(cores)
-    V, Tv, Ta, Tc, Bs = 10000, 256, 800, 30, 4
-    cfg = syn.cfg_config1(dout_p=0.0)
+    V, Tv, Ta, Tc, Bs = 10000, 256, 800, 30, 32
+    cfg = syn.cfg_config1(dout_p=0.1)
+    orc.set_dropout(cfg.dout_p)
+    torch.manual_seed(0)
     sd = orc.init_captioning_params(cfg, V, seed=0, glove=syn.make_glove(V, cfg.d_model_caps))
     p = {k: v.clone().requires_grad_(k != "emb_C.embedder.weight") for k, v in sd.items()}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
@@ -215,86 +145,136 @@ def cpu_baseline_worker():
                 if t.grad is not None:
                     orc.adam_step(t, t.grad, m[k], v2[k], i, cfg.lr)
         return int(ntok)
-    step(1)
-    t0 = time.perf_counter()
-    toks, n = 0, 0
-    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 6):
-        toks += step(n + 2)
-        n += 1
-    dt = time.perf_counter() - t0
-    print(json.dumps({"value": toks / dt, "unit": "caption tokens/s", "cores": cores, "kind": "port",
-                      "sample": f"{n} train steps of config[1] at B={Bs} (fwd+bwd+Adam, fp32, dropout off), "
-                                f"oracle/bmt_oracle.py on torch CPU, {cores} threads, {dt / n:.2f} s/step"}))
+    warm, timed = 3, 5
+    t_w = time.perf_counter()
+    for i in range(warm):
+        step(i + 1)
+        if time.perf_counter() - t_w > 60.0 and i >= 0:      # a slow host: spend the bound on timed steps
+            warm = i + 1
+            break
+    times, toks = [], 0
+    for n in range(timed):
+        t0 = time.perf_counter()
+        toks = step(warm + n + 1)
+        times.append(time.perf_counter() - t0)
+        med = sorted(times)[len(times) // 2]
+        print(json.dumps({"value": toks / med, "unit": "caption tokens/s", "cores": cores, "kind": "port",
+                          "sample": f"config[1] step at B={Bs} (fwd+bwd+Adam, fp32, dropout {cfg.dout_p}), oracle/bmt_oracle.py on torch "
+                                    f"{torch.__version__} CPU, {cores} threads: {warm} warm-up + {len(times)} timed steps, median {med:.2f} s/step, "
+                                    f"{toks} tokens/step"}), flush=True)
 
 
-def cpu_baseline(timeout_s=150):
-    """bounded: the oracle is timed in a child process that is killed after timeout_s (the bench must never hang on it)"""
+def cpu_baseline(timeout_s=240):
+    """bounded: the oracle is timed in a child process that is killed after timeout_s (the bench must never hang on it); the
+    child reports after every timed step, the last report wins"""
     import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out, err, note = "", "", None
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
-                           timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"value": None, "error": (r.stderr or "no output")[-300:]}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "error": f"cpu baseline exceeded {timeout_s}s"}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        out, err = r.stdout, r.stderr
+    except subprocess.TimeoutExpired as exc:
+        out = exc.stdout.decode() if isinstance(exc.stdout, bytes) else (exc.stdout or "")
+        note = f"stopped at the {timeout_s} s bound"
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            res = json.loads(line)
+            if note:
+                res["sample"] += f" ({note})"
+            return res
+    return {"value": None, "error": (note or err or "no output")[-300:]}
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the newest committed PMC pass (profiles/*pmc_traffic.json, produced by
-    tools/gpu_pmc_bench.sh: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over this same step, gfx950 correction applied).
-    The counters cannot be read from inside the process that runs the step, so this is a recorded measurement, not a live one."""
+def csrc_digest():
+    """sha256 over the HIP sources + the C ABI header: ties a recorded PMC pass to the kernels it measured"""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bmt_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "bmt_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record():
+    """the newest committed PMC pass (profiles/*pmc_traffic.json, written by tools/gpu_pmc_bench.sh: FETCH_SIZE / WRITE_SIZE / SQ
+    counters in separate rocprofv3 --pmc passes over this same step, gfx950 FETCH correction applied).  The counters cannot be
+    read from inside the process that runs the step, so this is a recorded measurement; it is REFUSED when the kernel sources
+    have changed since (the record carries the digest of bmt_amd/csrc it was taken with)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None, "no PMC pass committed"
+    name = os.path.basename(files[-1])
     try:
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(kernel_class)
-    except (OSError, ValueError, KeyError):
-        return None, "unreadable PMC summary"
-    if not k:
-        return None, f"{os.path.basename(files[-1])} has no entry for {kernel_class}"
-    return k["traffic_bytes"], (f"profiles/{os.path.basename(files[-1])}: FETCH_SIZE x2 + WRITE_SIZE, mean over {k['launches_seen']} launches of the "
-                                "eagerly issued step (separate rocprofv3 --pmc passes); includes the split-K workspace traffic")
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, f"profiles/{name}: unreadable"
+    want, have = rec.get("csrc_digest"), csrc_digest()
+    if want != have:
+        return None, f"profiles/{name} was taken with kernel sources {want}, the tree is {have}: stale, refused"
+    return rec, f"profiles/{name} (csrc {have}): FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 --pmc passes over the eagerly issued step"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--fwd-precision", type=int, default=3, choices=[1, 3])
-    ap.add_argument("--fp32-staged-gemm", action="store_true", help="A/B: use the fp32-operand GEMM (csrc/gemm.hip)")
-    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying one hipGraph")
-    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    if args.cpu_baseline_worker:
-        return cpu_baseline_worker()
+def self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: become the launcher (one rank per GPU, rendezvous on
+    127.0.0.1) -- the ranks run this same file with the same arguments; rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
 
+
+def dry_run(args, world, rank):
+    """launcher / rendezvous / timing protocol without a GPU (gloo): what CI can check of `--gpus N` on a CPU-only box"""
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, 100.0 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, units = float(tmax[0]), float(tsum[1])
+    else:
+        units = float(t[1])
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "dry_run": True, "value": units * args.steps / dt, "unit": "units/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def build_cap(args, dev, rank, world):
     from bmt_amd import ops, synthetic as syn
     from bmt_amd.model.captioning_module import BiModalTransformer
     from bmt_amd.train import CaptioningTrainStep
-
-    ops.set_precision(fwd=args.fwd_precision, bwd=1)
-    ops.USE_PLANE_GEMM = not args.fp32_staged_gemm
-    V, Tv, Ta, Tc, B = 10000, 256, 800, 30, args.batch
+    V, Tv, Ta, Tc, B = 10000, 256, 800, 30, args.batch or 32
     cfg = syn.cfg_config1(dout_p=0.1)
     cfg.device = str(dev)
     torch.manual_seed(0)                                   # identical replicas on every rank
@@ -305,9 +285,85 @@ def main():
     batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=1234 + rank)
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}      # inputs resident in HBM before timing
     caps = batch["captions"].to(dev)
-    tokens_local = int((caps[:, 1:] != syn.PAD_IDX).sum())
-    ops.manual_seed(1000 + rank)
-    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True)
+    units_local = int((caps[:, 1:] != syn.PAD_IDX).sum())
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000)
+    desc = {"metric": "caption tokens/sec/node (train_cap B=32/GPU, d=1024)", "unit": "caption tokens/s",
+            "workload": "configs[1]: train_cap, N=2 d_model=1024 H=4 d_aud=128 d_vid=1024 d_caps=300 T_v=256 T_a=800 T_c=30 V=10000, "
+                        "dropout 0.1, Adam, GloVe frozen",
+            "B": B, "n_params": n_params, "units_name": "tokens_per_step",
+            # algorithmic flops of the padded-dense step: 3.257 TFLOP per B=32 train step at V~10k
+            "flops_step": 3.257e12 * (B / 32.0)}
+    return step, (fs, caps), units_local, desc
+
+
+def build_prop(args, dev, rank, world):
+    from bmt_amd import ops, synthetic as syn
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    from bmt_amd.train import ProposalTrainStep
+    B, Tv, Ta = args.batch or 16, 1024, 3200
+    cfg = syn.cfg_config1(procedure="train_prop", dout_p=0.1, lr=1e-4)
+    cfg.device, cfg.grad_clip = str(dev), None
+    anchors = {"audio": syn.make_anchors(cfg.anchors_num_audio), "video": syn.make_anchors(cfg.anchors_num_video)}
+    torch.manual_seed(0)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = MultimodalProposalGenerator(cfg, anchors).to(dev)
+    for p in model.encoder.parameters():        # configs[3]: the bi-modal encoder comes from the captioning model and stays frozen
+        p.requires_grad = False
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    batch = syn.make_prop_batch(cfg, B, Tv, Ta, seed=11 + rank)
+    fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
+    tg = batch["targets"].to(dev)
+    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000)
+    # heads 348.7 + 322.9 GF and encoder 230.0 GF forward per sample at (T_a, T_v) = (3200, 1024); the frozen
+    # encoder has no backward, the heads have 2x their forward
+    heads, enc = (348.7 + 322.9) * 1e9, 230.0e9
+    desc = {"metric": "videos/sec/node (train_prop B=16/GPU, frozen bi-modal encoder, T_v=1024 T_a=3200)", "unit": "videos/s",
+            "workload": "configs[3]: train_prop, bi-modal proposal generator (10+10 Conv1d heads, 48/128 anchors) over full-video streams "
+                        "T_v=1024 T_a=3200, encoder of the configs[1] width frozen, dropout 0.1, Adam",
+            "B": B, "n_params": n_params, "units_name": "videos_per_step", "flops_step": B * (enc + 3.0 * heads)}
+    return step, (fs, tg), B, desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--procedure", default="train_cap", choices=["train_cap", "train_prop"],
+                    help="train_cap = BASELINE.json's metric (configs[1]); train_prop = configs[3]")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); default 32 (train_cap) / 16 (train_prop)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing protocol only (gloo, no GPU)")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a "
+                         "torch.distributed environment: bench.py starts its own ranks)")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bmt_amd import ops
+    cap = args.procedure == "train_cap"
+    step, inputs, units_local, desc = (build_cap if cap else build_prop)(args, dev, rank, world)
+    B = desc["B"]
 
     timer = KernelTimer()
     if not args.no_kernel_timer:
@@ -322,28 +378,32 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    # ---- the step is captured into two hipGraphs ({zero_grad .. backward}, {Adam}) with the eager RCCL all-reduce of the flat
-    # gradient buckets between them (nothing collective is captured); eager issue of every kernel is the fallback
+    # ---- train_cap: the step is captured into hipGraphs with the RCCL all-reduce of the flat gradient buckets issued between /
+    # beside them (nothing collective is captured); eager issue of every kernel is the fallback.  train_prop: eager (the number
+    # of target events changes per batch).
     mode = "eager"
-    run = lambda: step(fs, caps)
-    if not args.no_graph:
+    run = lambda: step(*inputs)
+    if cap and not args.no_graph:
         try:
-            step.capture(fs, caps, warmup=2)
+            step.capture(*inputs, warmup=2)
             run = lambda: step.replay()
             mode = "hipgraph"
         except Exception as exc:      # noqa: BLE001 -- e.g. a collective that refuses capture: keep measuring, say so
             note(f"graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
             torch.cuda.synchronize()
     for _ in range(args.warmup):
-        loss, _ = run()
+        res = run()
     sync()
     note(f"warmup done ({args.warmup} steps, {mode})")
+    if hasattr(step, "reduce_timing"):
+        step.reduce_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = run()
+        res = run()
     sync()
     dt = time.perf_counter() - t0
-    final_loss = float(loss)
+    exposed_ms = step.reduce_timing(False) if hasattr(step, "reduce_timing") else None
+    final_loss = float(res[0] if cap else res[1])
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step ({mode})")
     timer_steps = 0
     if not args.no_kernel_timer:
@@ -351,63 +411,65 @@ def main():
         timer_steps = 3
         timer.enabled = True
         for _ in range(timer_steps):
-            step(fs, caps)
+            step(*inputs)
         torch.cuda.synchronize()
         timer.enabled = False
 
-    t = torch.tensor([dt, float(tokens_local)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(units_local)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, tokens_all = float(tmax[0]), float(tsum[1])
+        dt, units_all = float(tmax[0]), float(tsum[1])
     else:
-        tokens_all = float(tokens_local)
+        units_all = float(units_local)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = tokens_all * args.steps / dt
-        # algorithmic flops of the padded-dense step: 3.257 TFLOP per B=32 train step at V~10k
-        flops_step = 3.257e12 * (B / 32.0) * world
+        value = units_all * args.steps / dt
+        flops_step = desc["flops_step"] * world
         out = {
-            "metric": "caption tokens/sec/node (train_cap B=32/GPU, d=1024)", "value": value, "unit": "caption tokens/s",
+            "metric": desc["metric"], "value": value, "unit": desc["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "launch_mode": mode,
-            "dtype": "bf16x3 fwd / bf16 bwd MFMA, fp32 accumulate" if args.fwd_precision == 3 else "bf16",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: train_cap, N=2 d_model=1024 H=4 d_aud=128 d_vid=1024 d_caps=300 "
-                                   "T_v=256 T_a=800 T_c=30 V=10000, dropout 0.1, Adam, GloVe frozen",
-                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "trainable_params": n_params, "tokens_per_step": tokens_all, "final_loss": final_loss},
+            "dtype": ops.precision_description(), "data": "synthetic",
+            "config": {"workload": desc["workload"], "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "trainable_params": desc["n_params"], desc["units_name"]: units_all, "final_loss": final_loss},
             "algorithmic_tflops": flops_step / (ms_per_step * 1e-3) / 1e12,
             "mfma_peak_frac": flops_step / (ms_per_step * 1e-3) / 1e12 / (MFMA_BF16_DENSE_PEAK_TFLOPS * world),
         }
+        if world > 1:
+            out["allreduce_exposed_ms"] = exposed_ms
+            out["allreduce"] = getattr(step, "reduce_description", lambda: None)()
         if not args.no_kernel_timer:
             summ = timer.summary()
             tot = sum(v["ms"] for v in summ.values()) or 1.0
             dom = max(summ, key=lambda k: summ[k]["ms"])
             d = summ[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic, traffic_note = pmc_traffic(dom)
+            rec, rec_note = pmc_record()
+            kern = (rec or {}).get("kernels", {}).get(dom)
+            passes = timer.passes.get(dom, 1)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                               "frac_issued": ach * (3 if dom.endswith("x3") else 1) / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
+                               "frac_issued": ach * passes / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                               "traffic": kern["traffic_bytes"] if kern else None,
+                               "traffic_unit": "HBM bytes per launch", "traffic_source": rec_note if kern or rec is None else rec_note + f" -- no entry for {dom}",
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"] if "bytes" in d else None,
                                "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                               "share_of_timed_kernels": d["ms"] / tot,
-                               "mfma_passes": 3 if dom.endswith("x3") else 1, "gemm_path": "planes" if ops.USE_PLANE_GEMM else "fp32-staged",
+                               "share_of_timed_kernels": d["ms"] / tot, "mfma_passes": passes,
                                "timing": f"HIP events around every launch of the class (a split-K GEMM launch = main kernel + its epilogue kernel), {timer_steps} eagerly issued steps right after the timed region"}
+            if kern and kern.get("mfma_busy") is not None:
+                out["roofline"]["mfma_busy"] = kern["mfma_busy"]
             # the north-star quantity: bi-modal ENCODER attention against the MFMA roofline.  "issued" counts what the matrix
-            # pipe executes (forward: 3 split-bf16 passes; backward: 7 products as scheduled -- S and dP are computed by both
-            # backward kernels), "algorithmic" the 2 / 5 products of the math.
+            # pipe executes (backward: 7 products as scheduled -- S and dP are computed by both backward kernels),
+            # "algorithmic" the 2 / 5 products of the math.
             enc = {k: v for k, v in summ.items() if k.startswith(("attn_fwd_enc", "attn_bwd_enc"))}
             if enc:
                 ms = sum(v["ms"] for v in enc.values())
                 alg = sum(v["flops"] for v in enc.values())
-                issued = sum(v["flops"] * (3.0 if k.startswith("attn_fwd") and k.endswith("x3") else (1.4 if k.startswith("attn_bwd") else 1.0))
-                             for k, v in enc.items())
+                issued = sum(v["flops"] * (timer.passes.get(k, 1) if k.startswith("attn_fwd") else 1.4) for k, v in enc.items())
                 out["attention_roofline"] = {
                     "scope": "encoder self- and cross-attention cores, forward + backward, B=32 H=4 d_k=256 T_v=256 T_a=800",
                     "bound": "mfma", "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -415,12 +477,22 @@ def main():
                     "frac_algorithmic": alg / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
                     "frac_issued": issued / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
                     "ms_per_step": ms / timer_steps, "share_of_timed_kernels": ms / tot}
+                if rec:          # rocprofv3 --pmc passes over the same step (tools/gpu_pmc_bench.sh), per encoder attention kernel
+                    pm = {k: {x: v.get(x) for x in ("mfma_busy", "hbm_gbs", "launches_seen", "avg_us")} for k, v in rec["kernels"].items()
+                          if k.startswith("attn_") and v.get("mfma_busy") is not None}
+                    if pm:
+                        out["attention_roofline"]["pmc"] = pm
+                        out["attention_roofline"]["pmc_source"] = rec_note
             out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                          "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches_per_step": v["launches"] / timer_steps}
                                      for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cap and not args.no_cpu_baseline:
             note("timing the CPU oracle (bounded sample, child process)")
             out["cpu_baseline"] = cpu_baseline()
+        elif world == 1 and not cap:
+            out["cpu_baseline"] = {"value": None, "unit": desc["unit"], "cores": None, "kind": "port",
+                                   "sample": "not timed: the reference at this size needs >10 min per step on the host (BASELINE.md 2: 6.3 s "
+                                             "for B=2 at T_v=300/T_a=800); the train_cap line carries the CPU baseline"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -221,6 +221,15 @@ class FeatureIngest:
     def _run(self, items):
         keys = [k for k in self.KEYS if k[1] in self.names]
         plans = {k[0]: list(self.io.map(lambda it, kk=k[0]: self._plan(it, kk), items)) for k in keys}
+        if 'rgb' in plans and 'flow' in plans:
+            # the reference loads the two i3d stacks TOGETHER (datasets/load_features.py:70-93): if either file is missing or
+            # its crop is empty BOTH become the single zero row, and the stacks must have equal shapes
+            for i, (pr, pf) in enumerate(zip(plans['rgb'], plans['flow'])):
+                if pr[0] is None or pf[0] is None:
+                    D = pr[3] if pr[3] is not None else pf[3]
+                    plans['rgb'][i] = plans['flow'][i] = (None, 0, 1, D)
+                else:
+                    assert pr[2] - pr[1] == pf[2] - pf[1], f"rgb / flow stacks of {items[i][0]} differ in length"
         B = len(items)
         layout, total = {}, 0
         for key, _, mod in keys:

@@ -255,7 +255,7 @@ class _PropLossFn(torch.autograd.Function):
     """decode + masked MSE/BCE of one head (reference :281-335); returns (predictions, total loss, 4 loss terms)."""
 
     @staticmethod
-    def forward(ctx, x, anchors_dev, stride, tgt, obj_coeff, noobj_coeff):
+    def forward(ctx, x, anchors_dev, stride, tgt, obj_coeff, noobj_coeff, counts=None):
         xc = _f32c(x)
         B, S, D = xc.shape
         A = anchors_dev.numel()
@@ -265,11 +265,13 @@ class _PropLossFn(torch.autograd.Function):
                                                 None, _st()), "bmt_prop_decode_loss")
             ctx.has_t = False
             return preds, torch.zeros((), device=x.device), torch.zeros(4, device=x.device)
-        obj, noobj, tx, tw = tgt
+        obj, noobj, tx, tw = tgt[:4]
         ws = torch.empty(8, device=x.device, dtype=torch.float32)
         losses = torch.empty(5, device=x.device, dtype=torch.float32)
         _lib.check(lib.bmt_prop_decode_loss(_p(xc), _p(anchors_dev), B, S, A, float(stride), _p(obj), _p(noobj), _p(tx), _p(tw),
                                             _p(preds), _p(ws), _st()), "bmt_prop_decode_loss")
+        if counts is not None:       # data parallel: LOCAL sums over GLOBAL obj / noobj cell counts (the per-rank losses add up
+            ws[4:6].copy_(counts)    # to the full-batch means of reference :316-321)
         _lib.check(lib.bmt_prop_loss_finalize(_p(ws), float(obj_coeff), float(noobj_coeff), _p(losses), _st()),
                    "bmt_prop_loss_finalize")
         ctx.has_t = True
@@ -281,7 +283,7 @@ class _PropLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpreds, dloss, dterms):
         if not ctx.has_t:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         xc, obj, noobj, tx, tw, ws = ctx.saved_tensors
         oc, nc, A = ctx.coeffs
         B, S, _ = xc.shape
@@ -289,14 +291,15 @@ class _PropLossFn(torch.autograd.Function):
         g = _f32c(dloss).reshape(1)
         _lib.check(lib.bmt_prop_loss_bwd(_p(xc), B, S, A, _p(obj), _p(noobj), _p(tx), _p(tw), _p(ws), oc, nc, _p(g), _p(dx), _st()),
                    "bmt_prop_loss_bwd")
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 _LOSS_KEYS = ('loss_x', 'loss_w', 'loss_conf_obj', 'loss_conf_noobj')
 
 
-def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache):
-    """shared body of forward_modality (:272-337) / kernel_size_forward (:123-184)."""
+def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache, count_reduce=None):
+    """shared body of forward_modality (:272-337) / kernel_size_forward (:123-184).  count_reduce (data parallel): sums the
+    {obj, noobj} cell counts of this modality's target assignment over the ranks, once per step (the heads share it)."""
     anchors_num = len(anchors_list)
     x = detection(x)
     B, S, D = x.shape
@@ -310,10 +313,14 @@ def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache):
             t = _f32c(targets.to(x.device))
             _lib.check(lib.bmt_make_targets(_p(t), t.shape[0], _p(anchors_dev), anchors_num, B, S, float(stride), _p(obj),
                                             _p(noobj), _p(tx), _p(tw), _st()), "bmt_make_targets")
-            tgt = (obj, noobj, tx, tw)
+            counts = None
+            if count_reduce is not None:
+                counts = count_reduce(torch.stack([obj.sum(dtype=torch.float32), noobj.sum(dtype=torch.float32)]))
+            tgt = (obj, noobj, tx, tw, counts)
         tgt_cache[key] = (anchors_dev, tgt)
     anchors_dev, tgt = tgt_cache[key]
-    preds, loss, terms = _PropLossFn.apply(x, anchors_dev, stride, tgt, cfg.obj_coeff, cfg.noobj_coeff)
+    preds, loss, terms = _PropLossFn.apply(x, anchors_dev, stride, tgt, cfg.obj_coeff, cfg.noobj_coeff,
+                                           None if tgt is None else tgt[4])
     if targets is None:
         return preds, 0, {}
     return preds, loss, {k: terms[i] for i, k in enumerate(_LOSS_KEYS)}
@@ -390,7 +397,8 @@ class ProposalGenerator(nn.Module):
         self.mse_loss = nn.MSELoss()
 
     def kernel_size_forward(self, x, layer, stride, targets, _cache=None):
-        return _head_forward(x, targets, layer, stride, self.anchors_list, self.cfg, {} if _cache is None else _cache)
+        return _head_forward(x, targets, layer, stride, self.anchors_list, self.cfg, {} if _cache is None else _cache,
+                             getattr(self, "count_reduce", None))
 
     def forward(self, x, targets, masks):
         if self.training:
@@ -476,7 +484,8 @@ class MultimodalProposalGenerator(nn.Module):
         self.mse_loss = nn.MSELoss()
 
     def forward_modality(self, x, targets, detection, stride, anchors_list, _cache=None):
-        return _head_forward(x, targets, detection, stride, anchors_list, self.cfg, {} if _cache is None else _cache)
+        return _head_forward(x, targets, detection, stride, anchors_list, self.cfg, {} if _cache is None else _cache,
+                             getattr(self, "count_reduce", None))
 
     def forward(self, x, targets, masks):
         if self.training:

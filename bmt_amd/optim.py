@@ -26,6 +26,7 @@ class _PtrTable:
         self.sizes = None
         self.max_size = 0
         self.n = 0
+        self._retired = []   # tables a captured hipGraph may still read: never freed (a few KB each)
 
     def update(self, columns: List[List[torch.Tensor]]):
         key = tuple(t.data_ptr() for col in columns for t in col)
@@ -33,6 +34,8 @@ class _PtrTable:
             return
         n = len(columns[0])
         host = torch.tensor(key, dtype=torch.int64)
+        if self.ptrs is not None:
+            self._retired.append((self.ptrs, self.sizes))
         self.ptrs = host.to(self.device)
         sizes = [t.numel() for t in columns[0]]
         self.sizes = torch.tensor(sizes, dtype=torch.int64).to(self.device)
@@ -57,6 +60,20 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self.state.values():      # torch.optim.Adam keeps ``step`` as a tensor (possibly on the device) or a float
             if "step" in st:
                 st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32)
+
+    def state_dict(self):
+        """torch.optim.Adam's layout.  The step count that matters lives on the device (``_steps``: a captured optimizer graph
+        advances it without running this Python), so the per-parameter ``step`` entries are refreshed from it first --
+        otherwise a checkpoint written after N graph replays would resume Adam's bias correction near step 0 against fully
+        warmed moments."""
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._steps:
+                n = float(self._steps[gi].item())
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st is not None and "step" in st:
+                        st["step"] = torch.as_tensor(n, dtype=torch.float32)
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -95,7 +112,8 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
-_clip_tables = {}
+_clip_tables = {}      # (device, gradient pointers) -> (table, sq, coef): one per parameter set, kept for the life of the process
+                       # (a captured optimizer graph has the table's address baked in; see _PtrTable._retired)
 
 
 @torch.no_grad()
@@ -106,7 +124,7 @@ def clip_grad_norm_(parameters: Iterable[torch.nn.Parameter], max_norm: float) -
     if not ps:
         return torch.zeros(())
     dev = ps[0].device
-    key = str(dev)
+    key = (str(dev), tuple(p.grad.data_ptr() for p in ps))
     if key not in _clip_tables:
         _clip_tables[key] = (_PtrTable(dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev))
     tab, sq, coef = _clip_tables[key]

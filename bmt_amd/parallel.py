@@ -127,3 +127,16 @@ def global_sum(t: torch.Tensor, group=None) -> torch.Tensor:
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def shard_proposal_batch(feature_stacks, targets: torch.Tensor, rank: int, world: int):
+    """contiguous split of a train_prop batch over ranks: videos [lo, hi) of every feature stack and the rows of
+    ``targets`` ((n_events, 4): [batch idx, center s, length s, meta idx], datasets/proposal_dataset.py:133-166) that belong to
+    them, with the batch index re-based to the shard."""
+    B = next(iter(feature_stacks.values())).shape[0]
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    fs = {k: v[lo:hi] for k, v in feature_stacks.items()}
+    keep = (targets[:, 0] >= lo) & (targets[:, 0] < hi)
+    t = targets[keep].clone()
+    t[:, 0] -= lo
+    return fs, t

@@ -23,6 +23,25 @@ from .optim import FusedAdam, clip_grad_norm_
 from .parallel import GradientReducer, global_sum
 
 
+def _ops_weights_changed():
+    from . import ops as _ops
+    _ops.weights_changed()
+
+
+def _seed_dropout(seed: Optional[int], data_parallel: bool, device):
+    """dropout masks come from the library RNG in device memory (ops.rng_tensor), not from torch's: under data parallelism every
+    rank must draw DIFFERENT masks (as nn.DataParallel's replicas do), so the per-rank seed is base + rank.  seed=None keeps
+    the current state on a single process and derives base 0x5EED under data parallelism."""
+    import torch.distributed as dist
+    from . import ops as _ops
+    rank = dist.get_rank() if (data_parallel and dist.is_initialized()) else 0
+    if seed is None and not data_parallel:
+        return
+    if not torch.device(device).type == "cuda":
+        return
+    _ops.manual_seed((0x5EED if seed is None else seed) + rank, device)
+
+
 def make_masks(feature_stacks: Dict[str, torch.Tensor], captions: Optional[torch.Tensor], modality: str, pad_idx: int):
     """make_masks (epoch_loops/captioning_epoch_loops.py:91-119), 'audio_video' / 'video' / 'audio' branches: masks come
     from channel 0 of rgb / audio compared with pad_idx, before rgb+flow."""
@@ -58,8 +77,9 @@ class CaptioningTrainStep:
     backward graph instead (no collective is ever captured)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 static_grads: bool = False, overlap: bool = True):
+                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None):
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
+        _seed_dropout(seed, data_parallel, next(model.parameters()).device)
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
         self.optimizer = optimizer or FusedAdam(params, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
@@ -75,6 +95,7 @@ class CaptioningTrainStep:
             self.optimizer.grad_scale = self.grad_scale
         self._fused_scale = hasattr(self.optimizer, "grad_scale")
         self._graphs = None
+        self._reduce_events = None      # bench: [(start, end)] HIP events around the exposed part of the gradient reduction
 
     # ---- the three phases -------------------------------------------------------------------------------------
     def _forward_backward(self, feature_stacks, caption_idx):
@@ -164,9 +185,40 @@ class CaptioningTrainStep:
             self._static_caps.copy_(caption_idx, non_blocking=True)
         g1, g2 = self._graphs
         g1.replay()
+        ev = self._reduce_events
+        if ev is not None:
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
         loss, _ = self._reduce(self._static_kl, self._static_ntok)
+        if ev is not None:
+            e_.record()
+            ev.append((s_, e_))
         g2.replay()
+        # the captured Adam kernel wrote the parameters behind torch's back (no _version bump, and the host-side epoch
+        # increment of FusedAdam.step ran once, at capture time): an eager forward after this replay must refresh the
+        # cached weight planes
+        _ops_weights_changed()
         return loss, self._static_ntok
+
+    def reduce_timing(self, on: bool):
+        """bench: on -> start collecting HIP events around the part of the gradient reduction that is NOT hidden behind the
+        backward pass (everything between the end of the backward graph and the optimizer graph); off -> mean ms per step"""
+        if on:
+            self._reduce_events = []
+            return None
+        ev, self._reduce_events = self._reduce_events, None
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return sum(s_.elapsed_time(e_) for s_, e_ in ev) / len(ev)
+
+    def reduce_description(self):
+        r = self.reducer
+        if r is None:
+            return None
+        return {"payload_mb": sum(b["flat"].numel() for b in r.buckets) * 4 / 1e6, "buckets": len(r.buckets),
+                "mode": "sum all-reduce (RCCL) of the flat fp32 gradient buckets between the backward graph and the optimizer graph, "
+                        "plus one scalar all-reduce (global n_tokens)"}
 
 
 class ProposalTrainStep:
@@ -179,14 +231,17 @@ class ProposalTrainStep:
     Only parameters with ``requires_grad`` take part: with ``cfg.pretrained_cap_model_path`` the bi-modal encoder is loaded
     from the captioning checkpoint and frozen unless ``cfg.finetune_cap_encoder`` (model/proposal_generator.py:344-353), so
     the step is {frozen encoder forward} + {20 Conv1d heads forward/backward} + Adam over the heads -- configs[3].
-    Data parallel: every rank computes the loss of its own videos (the reference's MSE / BCE means are per batch) and the
-    gradients are AVERAGED over ranks (sum all-reduce, 1/world folded into Adam's ``grad_scale``); the number of target
-    events differs per step, so this step is launched eagerly (no graph capture)."""
+    Data parallel: the reference's MSE / BCE are means over the selected cells of the WHOLE batch
+    (model/proposal_generator.py:316-321), so every rank divides its LOCAL sums by the GLOBAL obj / noobj cell counts (one
+    all-reduce of two scalars per modality, before backward: ``model.count_reduce``) and the gradients are SUMMED over
+    ranks -- the result is the full-batch step (tests/test_parallel_gloo.py).  The number of target events
+    differs per step, so this step is launched eagerly (no graph capture)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 overlap: bool = True):
+                 overlap: bool = True, seed: Optional[int] = None):
         import torch.distributed as dist
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
+        _seed_dropout(seed, data_parallel, next(model.parameters()).device)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.optimizer = optimizer or FusedAdam(self.params, lr=cfg.lr, betas=tuple(getattr(cfg, "betas", (0.9, 0.999))),
                                                 eps=getattr(cfg, "eps", 1e-8), weight_decay=getattr(cfg, "weight_decay", 0.0))
@@ -194,8 +249,10 @@ class ProposalTrainStep:
         self.reducer = GradientReducer(self.params, bucket_bytes=bucket_bytes, overlap=overlap) if data_parallel else None
         self.world = dist.get_world_size() if (data_parallel and dist.is_initialized()) else 1
         self.modality = getattr(cfg, 'modality', 'audio_video')
-        self._fused_scale = hasattr(self.optimizer, "grad_scale")
-        self.grad_scale = torch.full((1,), 1.0 / self.world, device=self.params[0].device, dtype=torch.float32)
+        # data parallel: the loss means use the global cell counts (sum of the per-rank losses == full-batch loss)
+        model.count_reduce = global_sum if self.world > 1 else None
+        if hasattr(self.optimizer, "grad_scale"):
+            self.optimizer.grad_scale = None
 
     def __call__(self, feature_stacks, targets):
         model = self.model
@@ -209,14 +266,10 @@ class ProposalTrainStep:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        scale_in_adam = self._fused_scale and self.world > 1 and getattr(self.cfg, "grad_clip", None) is None
-        if self.world > 1 and not scale_in_adam:
-            for p in self.params:
-                if p.grad is not None:
-                    p.grad.mul_(self.grad_scale)
         if getattr(self.cfg, "grad_clip", None) is not None:
             clip_grad_norm_(self.params, self.cfg.grad_clip)
-        if self._fused_scale:
-            self.optimizer.grad_scale = self.grad_scale if scale_in_adam else None
         self.optimizer.step()
-        return predictions, loss.detach(), losses_A, losses_V
+        loss = loss.detach()
+        if self.world > 1:
+            loss = global_sum(loss)          # the full-batch loss, for logging
+        return predictions, loss, losses_A, losses_V

@@ -45,6 +45,23 @@ def _q(x: Tensor, site: str) -> Tensor:
     return x if fn is None else fn(x, site)
 
 
+# --------------------------------------------------------------------------------------
+# optional training-mode dropout (the reference's nn.Dropout sites; off by default = eval())
+# --------------------------------------------------------------------------------------
+_DROP = {"p": 0.0}
+
+
+def set_dropout(p: float):
+    """p > 0: every nn.Dropout site of the captioning path draws a mask from the torch CPU RNG (train() mode of the
+    reference: model/blocks.py:105,135,152,171, model/multihead_attention.py:22-23); 0 = eval()."""
+    _DROP["p"] = float(p)
+
+
+def _drop(x: Tensor) -> Tensor:
+    p = _DROP["p"]
+    return x if p <= 0.0 else torch.nn.functional.dropout(x, p, training=True)
+
+
 def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], site: str = "linear") -> Tensor:
     y = _q(x, site) @ _q(w, site).transpose(-1, -2)
     return y if b is None else y + b
@@ -94,10 +111,10 @@ def pos_enc_table(seq_len: int, d_model: int) -> np.ndarray:
 
 
 def positional_encoder(x: Tensor) -> Tensor:
-    """model/blocks.py:101-107 (eval mode: dropout is identity)."""
+    """model/blocks.py:101-107 (dropout after the sum; identity unless set_dropout)."""
     B, S, D = x.shape
     tab = torch.from_numpy(pos_enc_table(S, D)).unsqueeze(0)
-    return x + tab.type_as(x)
+    return _drop(x + tab.type_as(x))
 
 
 def vocabulary_embedder(p: Params, prefix: str, idx: Tensor, emb_dim: int) -> Tensor:
@@ -120,19 +137,19 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
 
 def residual(p: Params, prefix: str, x: Tensor, sublayer) -> Tensor:
     """model/blocks.py:130-136 -- x + dropout(sublayer(LN(x))); eval: dropout = id."""
-    return x + sublayer(layer_norm(x, p[prefix + "norm.weight"], p[prefix + "norm.bias"]))
+    return x + _drop(sublayer(layer_norm(x, p[prefix + "norm.weight"], p[prefix + "norm.bias"])))
 
 
 def feed_forward(p: Params, prefix: str, x: Tensor) -> Tensor:
     """model/blocks.py:167-174 -- fc2(dropout(relu(fc1(x))))."""
-    h = torch.relu(_linear(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"], "ffn1"))
+    h = _drop(torch.relu(_linear(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"], "ffn1")))
     return _linear(h, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"], "ffn2")
 
 
 def bridge(p: Params, prefix: str, x: Tensor) -> Tensor:
     """model/blocks.py:149-153 -- relu(dropout(linear(LN(x)))), no residual."""
     y = layer_norm(x, p[prefix + "norm.weight"], p[prefix + "norm.bias"])
-    return torch.relu(_linear(y, p[prefix + "linear.weight"], p[prefix + "linear.bias"], "bridge"))
+    return torch.relu(_drop(_linear(y, p[prefix + "linear.weight"], p[prefix + "linear.bias"], "bridge")))
 
 
 # --------------------------------------------------------------------------------------
@@ -145,7 +162,7 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, msk: Optional[Tensor]) -> Tensor:
     s = (_q(Q, "qk") @ _q(K, "qk").transpose(-1, -2)) / np.sqrt(d_k)
     if msk is not None:
         s = s.masked_fill(msk == 0, -float("inf"))
-    return _q(torch.softmax(s, dim=-1), "pv") @ _q(V, "pv")
+    return _drop(_q(torch.softmax(s, dim=-1), "pv") @ _q(V, "pv"))
 
 
 def multiheaded_attention(p: Params, prefix: str, Q: Tensor, K: Tensor, V: Tensor,
@@ -350,8 +367,10 @@ def _bce(x: Tensor, t: Tensor) -> Tensor:
 
 
 def forward_modality(p: Params, pre: str, x: Tensor, targets: Optional[Tensor], kernel_size: int,
-                     stride: float, anchors_list, obj_coeff: float = 1.0, noobj_coeff: float = 100.0):
-    """model/proposal_generator.py:272-337."""
+                     stride: float, anchors_list, obj_coeff: float = 1.0, noobj_coeff: float = 100.0, count_reduce=None):
+    """model/proposal_generator.py:272-337.  ``count_reduce`` (data-parallel checks only): a callable that sums a tensor
+    over ranks; the MSE / BCE means then divide the LOCAL sums by the GLOBAL obj / noobj cell counts, so that the sum of
+    the per-rank losses is the full-batch loss of :316-321."""
     A = len(anchors_list)
     y = proposal_head(p, pre, x, kernel_size)
     B, S, _ = y.shape
@@ -367,10 +386,17 @@ def forward_modality(p: Params, pre: str, x: Tensor, targets: Optional[Tensor], 
     loss, losses = 0, {}
     if targets is not None:
         obj, noobj, gx, gw, gobj = make_targets(B, A, S, targets, anchors, stride)
-        lx = ((sc[obj] - gx[obj]) ** 2).mean()
-        lw = ((l[obj] - gw[obj]) ** 2).mean()
-        lo = _bce(so[obj], gobj[obj])
-        ln = _bce(so[noobj], gobj[noobj])
+        if count_reduce is None:
+            lx = ((sc[obj] - gx[obj]) ** 2).mean()
+            lw = ((l[obj] - gw[obj]) ** 2).mean()
+            lo = _bce(so[obj], gobj[obj])
+            ln = _bce(so[noobj], gobj[noobj])
+        else:
+            n = count_reduce(torch.stack([obj.sum(), noobj.sum()]).float())
+            lx = ((sc[obj] - gx[obj]) ** 2).sum() / n[0]
+            lw = ((l[obj] - gw[obj]) ** 2).sum() / n[0]
+            lo = _bce(so[obj], gobj[obj]) * obj.sum() / n[0] if obj.any() else so.sum() * 0
+            ln = _bce(so[noobj], gobj[noobj]) * noobj.sum() / n[1] if noobj.any() else so.sum() * 0
         loss = lx + lw + obj_coeff * lo + noobj_coeff * ln
         losses = {"loss_x": lx, "loss_w": lw, "loss_conf_obj": lo, "loss_conf_noobj": ln}
     preds = preds.view(B, S * A, 3)
@@ -378,7 +404,7 @@ def forward_modality(p: Params, pre: str, x: Tensor, targets: Optional[Tensor], 
     return preds, loss, losses
 
 
-def multimodal_proposal_generator(p: Params, cfg, anchors: Dict[str, list], src, targets, masks):
+def multimodal_proposal_generator(p: Params, cfg, anchors: Dict[str, list], src, targets, masks, count_reduce=None):
     """model/proposal_generator.py:339-387."""
     V = src["rgb"] + src["flow"]
     A = src["audio"]
@@ -390,12 +416,12 @@ def multimodal_proposal_generator(p: Params, cfg, anchors: Dict[str, list], src,
     preds_A, preds_V, loss_A, loss_V, sum_A, sum_V = [], [], 0, 0, {}, {}
     for i, k in enumerate(cfg.kernel_sizes["audio"]):
         pr, lo, ls = forward_modality(p, f"detection_layers_A.{i}.", Av, targets, k, cfg.strides["audio"],
-                                      anchors["audio"], cfg.obj_coeff, cfg.noobj_coeff)
+                                      anchors["audio"], cfg.obj_coeff, cfg.noobj_coeff, count_reduce)
         preds_A.append(pr); loss_A = loss_A + lo
         sum_A = {kk: sum_A.get(kk, 0) + vv for kk, vv in ls.items()}
     for i, k in enumerate(cfg.kernel_sizes["video"]):
         pr, lo, ls = forward_modality(p, f"detection_layers_V.{i}.", Va, targets, k, cfg.strides["video"],
-                                      anchors["video"], cfg.obj_coeff, cfg.noobj_coeff)
+                                      anchors["video"], cfg.obj_coeff, cfg.noobj_coeff, count_reduce)
         preds_V.append(pr); loss_V = loss_V + lo
         sum_V = {kk: sum_V.get(kk, 0) + vv for kk, vv in ls.items()}
     all_preds = torch.cat([torch.cat(preds_A, dim=1), torch.cat(preds_V, dim=1)], dim=1)

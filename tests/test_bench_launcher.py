@@ -1,0 +1,52 @@
+"""CPU: `python bench.py --gpus N` starts its own ranks (the driver's form) and the ranks rendezvous, time and reduce the way
+the GPU run does -- exercised with --dry-run (gloo, no HIP work), plus the stale-PMC refusal of the roofline's traffic field."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=e)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_self_launch_two_ranks_dry_run():
+    r, out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out and out["dry_run"] and out["n_gpus"] == 2 and out["steps"] == 3
+    # max over ranks of the wall time (rank 1 sleeps 2 ms per step), sum over ranks of the units (100 + 200)
+    assert out["ms_per_step"] >= 1.9 and abs(out["value"] * out["ms_per_step"] * 1e-3 - 300.0) < 1e-6
+
+
+def test_single_process_dry_run_and_world_mismatch():
+    r, out = _run(["--dry-run", "--steps", "2", "--warmup", "0"])
+    assert r.returncode == 0 and out["n_gpus"] == 1
+    r, out = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_stale_pmc_record_is_refused(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "bmt_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (tmp_path / "bmt_amd" / "csrc" / "k.hip").write_text("// v1\n")
+    good = bench.csrc_digest()
+    (prof / "r99_pmc_traffic.json").write_text(json.dumps({"csrc_digest": good, "kernels": {"gemm": {"traffic_bytes": 1.0}}}))
+    rec, note = bench.pmc_record()
+    assert rec is not None and good in note
+    (tmp_path / "bmt_amd" / "csrc" / "k.hip").write_text("// v2\n")
+    rec, note = bench.pmc_record()
+    assert rec is None and "stale" in note

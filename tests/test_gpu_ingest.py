@@ -57,6 +57,22 @@ def test_full_feature_batches_match_reference(golden, feats):
     ing.close()
 
 
+def test_one_missing_i3d_stack_zeroes_both(tmp_path):
+    """datasets/load_features.py:70-93 loads rgb and flow together: if EITHER file is missing both stacks become one zero row
+    (planning them independently gave a real rgb crop beside a 1-row zero flow, with different T)"""
+    import os
+    from bmt_amd.ingest import FeatureIngest
+    feats = write_features(str(tmp_path))
+    os.remove(os.path.join(feats.video_features_path, "v_f_flow.npy"))
+    ing = FeatureIngest(feats, NAMES, PAD, DEV)
+    out = ing([("v_f", 0.0, 19.0, VIDEOS["v_f"][2]), ("v_a", 3.0, 17.5, VIDEOS["v_a"][2])])
+    assert out["rgb"].shape == out["flow"].shape
+    assert bool((out["rgb"][0, 0] == 0).all()) and bool((out["flow"][0, 0] == 0).all())          # the single zero row
+    assert bool((out["rgb"][0, 1:] == float(PAD)).all()) and bool((out["flow"][0, 1:] == 0).all())   # then padding
+    assert bool((out["rgb"][1, 0] != 0).any()) and bool((out["flow"][1, 0] != 0).any())            # the intact sample is untouched
+    ing.close()
+
+
 @pytest.mark.parametrize("D", [1, 7, 24, 1024])
 def test_pad_batch_kernel(D):
     from bmt_amd import _lib

@@ -116,3 +116,78 @@ def test_reducer_lays_grouped_gradients_back_to_back():
             assert torch.equal(p.grad, torch.full_like(p, float(i + 1)))
     finally:
         red.remove()
+
+
+# ---------------------------------------------------------------- train_prop under data parallelism
+def _prop_cfg():
+    cfg = syn.cfg_tiny(procedure="train_prop", dout_p=0.0)
+    cfg.anchors_num_audio, cfg.anchors_num_video = 3, 5
+    cfg.conv_layers_audio, cfg.conv_layers_video = [16, 16], [16, 16]
+    cfg.kernel_sizes = {"audio": [1, 5], "video": [3, 7]}
+    return cfg
+
+
+def _prop_params(golden_name="tiny_prop.npz"):
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", golden_name))
+    sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("sd/")}
+    anchors = {"audio": [float(a) for a in z["anchors_audio"]], "video": [float(a) for a in z["anchors_video"]]}
+    return sd, anchors
+
+
+def _prop_loss(p, cfg, anchors, fs, targets, count_reduce=None):
+    masks = orc.make_masks(fs, None, syn.PAD_IDX)
+    _, loss, _, _ = orc.multimodal_proposal_generator(p, cfg, anchors, fs, targets, masks, count_reduce=count_reduce)
+    return loss
+
+
+def _prop_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmt_amd.parallel import GradientReducer, global_sum, shard_proposal_batch
+    cfg = _prop_cfg()
+    sd, anchors = _prop_params()
+    names = list(sd.keys())
+    plist = [torch.nn.Parameter(sd[k].clone()) for k in names]
+    batch = syn.make_prop_batch(cfg, 4, 9, 14, seed=9, events_per_video=2)
+    fs, tg = shard_proposal_batch(batch["feature_stacks"], batch["targets"], rank, world)
+    red = GradientReducer(plist, bucket_bytes=64 << 10)
+    red.zero_grad()
+    loss = _prop_loss(dict(zip(names, plist)), cfg, anchors, fs, tg, count_reduce=global_sum)
+    loss.backward()
+    red.finish()
+    total = global_sum(loss.detach())
+    if rank == 0:
+        torch.save({"grads": {k: p.grad.clone() for k, p in zip(names, plist)}, "loss": total}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_proposal_step_equals_full_batch(tmp_path):
+    """per-rank LOCAL sums over GLOBAL obj / noobj counts + a gradient SUM == the full-batch MSE / BCE means of
+    model/proposal_generator.py:316-321 (ranks hold different numbers of events: 2+3 vs 2+3 videos' events re-based)"""
+    out = str(tmp_path / "prop.pt")
+    mp.spawn(_prop_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    cfg = _prop_cfg()
+    sd, anchors = _prop_params()
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    batch = syn.make_prop_batch(cfg, 4, 9, 14, seed=9, events_per_video=2)
+    loss = _prop_loss(p, cfg, anchors, batch["feature_stacks"], batch["targets"])
+    loss.backward()
+    torch.testing.assert_close(got["loss"], loss.detach(), rtol=1e-5, atol=1e-5)
+    for k in p:
+        torch.testing.assert_close(got["grads"][k], p[k].grad, rtol=2e-4, atol=2e-6, msg=k)
+
+
+def test_shard_proposal_batch_rebases_targets():
+    from bmt_amd.parallel import shard_proposal_batch
+    cfg = _prop_cfg()
+    batch = syn.make_prop_batch(cfg, 4, 9, 14, seed=9, events_per_video=2)
+    seen = 0
+    for r in range(2):
+        fs, tg = shard_proposal_batch(batch["feature_stacks"], batch["targets"], r, 2)
+        assert fs["rgb"].shape[0] == 2 and set(tg[:, 0].tolist()) <= {0.0, 1.0}
+        seen += tg.shape[0]
+    assert seen == batch["targets"].shape[0]
