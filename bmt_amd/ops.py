@@ -25,9 +25,31 @@ FWD_PRECISION = PREC_BF16X3
 BWD_PRECISION = PREC_BF16
 
 
+ATTN_PRECISION = PREC_BF16X3
+
+
 def set_precision(fwd: int = PREC_BF16X3, bwd: int = PREC_BF16):
-    global FWD_PRECISION, BWD_PRECISION
-    FWD_PRECISION, BWD_PRECISION = fwd, bwd
+    global FWD_PRECISION, BWD_PRECISION, ATTN_PRECISION
+    FWD_PRECISION, BWD_PRECISION, ATTN_PRECISION = fwd, bwd, fwd
+
+
+def prec_name(prec: int) -> str:
+    return {PREC_BF16: "bf16", PREC_BF16X3: "bf16x3"}[prec]
+
+
+def prec_passes(prec: int) -> int:
+    """MFMA passes issued per algorithmic product"""
+    return {PREC_BF16: 1, PREC_BF16X3: 3}[prec]
+
+
+def prec_operand_bytes(prec: int):
+    """(A, B) operand plane bytes per element read by a product of this precision"""
+    return {PREC_BF16: (2.0, 2.0), PREC_BF16X3: (4.0, 4.0)}[prec]
+
+
+def precision_description() -> str:
+    return (f"forward GEMMs {prec_name(FWD_PRECISION)}, attention forward {prec_name(ATTN_PRECISION)}, backward "
+            f"{prec_name(BWD_PRECISION)} MFMA operands; fp32 accumulate, softmax, LayerNorm, loss, Adam")
 
 
 # GEMM path: True = operands pre-split into bf16 planes once per tensor (csrc/gemm_bf16.hip); False = the fp32-operand

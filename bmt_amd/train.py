@@ -273,3 +273,47 @@ class ProposalTrainStep:
         if self.world > 1:
             loss = global_sum(loss)          # the full-batch loss, for logging
         return predictions, loss, losses_A, losses_V
+
+
+class MixedTrainStep:
+    """BASELINE configs[4]: alternating train_cap / train_prop steps of ONE job.  The proposal generator works on top of the
+    captioning model's bi-modal encoder -- the reference hands that encoder over through a checkpoint
+    (model/proposal_generator.py:344-353, ``pretrained_cap_model_path`` with ``finetune_cap_encoder=False``); here the two models
+    share the encoder MODULE, so every train_prop step sees the encoder as the latest train_cap step left it, frozen on the
+    proposal side (its parameters belong to the captioning optimizer only).  One call = one train_cap step (captured graphs if
+    ``capture`` was called) followed by one train_prop step (eager: the number of target events changes per batch)."""
+
+    def __init__(self, cap_model, prop_model, cfg_cap, cfg_prop, pad_idx: int, data_parallel: bool = False,
+                 bucket_bytes: int = 32 << 20, seed: Optional[int] = None):
+        prop_model.encoder = cap_model.encoder
+        self.cap = CaptioningTrainStep(cap_model, cfg_cap, pad_idx, data_parallel=data_parallel, static_grads=True,
+                                       bucket_bytes=bucket_bytes, seed=seed)
+        enc = {id(p) for p in cap_model.encoder.parameters()}
+        self._enc_flags = [(p, p.requires_grad) for p in cap_model.encoder.parameters()]
+        for p in cap_model.encoder.parameters():      # frozen while the proposal step's parameter list is built
+            p.requires_grad = False
+        try:
+            self.prop = ProposalTrainStep(prop_model, cfg_prop, pad_idx, data_parallel=data_parallel, bucket_bytes=bucket_bytes)
+        finally:
+            for p, f in self._enc_flags:
+                p.requires_grad = f
+        assert not any(id(p) in enc for p in self.prop.params)
+
+    def capture(self, feature_stacks, caption_idx, warmup: int = 2):
+        return self.cap.capture(feature_stacks, caption_idx, warmup=warmup)
+
+    def __call__(self, cap_batch, prop_batch):
+        """cap_batch = (feature_stacks, caption_idx) or None to replay the captured batch; prop_batch = (feature_stacks, targets).
+        Returns (captioning loss, proposal loss)."""
+        if self.cap._graphs is not None:
+            cap_loss, _ = self.cap.replay(*(cap_batch or (None, None)))
+        else:
+            cap_loss, _ = self.cap(*cap_batch)
+        for p, _ in self._enc_flags:                  # no autograd graph through the shared encoder on the proposal side
+            p.requires_grad = False
+        try:
+            _, prop_loss, _, _ = self.prop(*prop_batch)
+        finally:
+            for p, f in self._enc_flags:
+                p.requires_grad = f
+        return cap_loss, prop_loss

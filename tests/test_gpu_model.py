@@ -460,3 +460,145 @@ def test_fused_residual_block_equals_the_separate_kernels(golden):
     b = torch.cat([res[False][1][k].flatten() for _, k in errs])
     assert rel_err(a, b) < 1e-2, rel_err(a, b)
     assert errs[0][0] < 2e-2, errs[:5]
+
+
+# ---------------------------------------------------------------- round-2 parity cases (tests/golden/make_golden_r2.py)
+def test_full_length_captioning_model(golden):
+    """configs[1] at its TRUE lengths (T_v=256, T_a=800, T_c=30, V=10000; 13 key tiles / 7 query tiles in the attention
+    kernels), B=2: log-probs within 1e-3 of the reference CPU path, gradient norms within 10 %"""
+    from oracle import bmt_oracle as orc
+    from tests.test_oracle_golden import check_full_cap_pred
+    g = golden("full_cap.npz")
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = syn.cfg_config1()
+    model = _build(cfg, V, True)
+    assert orc.state_dict_digest({k: v.cpu() for k, v in model.state_dict().items()}) == str(g.np("sd_digest"))
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    pred, loss, masks = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"])
+    for k in ("V_mask", "A_mask", "C_mask"):
+        assert torch.equal(masks[k].cpu(), g[k]), k
+    err = float((pred.detach().cpu()[:, :, ::8] - g["pred_sub"]).abs().max())
+    print(f"\nfull_cap: max |dlogp| (every 8th column) = {err:.3e} (bar {LOGP_TOL})")
+    check_full_cap_pred(pred.detach().cpu(), g, atol=LOGP_TOL)
+    assert_close(loss, g["loss"], atol=1e-3, rtol=1e-4, name="loss")
+    loss.backward()
+    params = dict(model.named_parameters())
+    norms = g.np("grad_norms")
+    nmax, bad = float(max(norms)), []
+    for n, ref_norm in zip([str(s) for s in g.np("grad_names")], norms):
+        mine = float(params[n].grad.double().norm())
+        if ref_norm < 1e-4 * nmax:
+            if mine > 2e-2 * nmax:
+                bad.append(f"{n}: should be ~0, |grad|={mine:.4e}")
+        elif abs(mine - ref_norm) > 0.10 * ref_norm:
+            bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
+    assert not bad, "\n".join(bad)
+    _check_grads(model.named_parameters(), g.sub("grad/"))
+
+
+def test_deep_config_captioning_model(golden):
+    """configs[4]-shaped model (N=6, H=8 -> d_k=128, d_model=1024) at reduced B / T / V against the reference"""
+    from oracle import bmt_oracle as orc
+    from tests.test_oracle_golden import deep_cfg
+    g = golden("deep_cap.npz")
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = deep_cfg()
+    model = _build(cfg, V, True)
+    assert orc.state_dict_digest({k: v.cpu() for k, v in model.state_dict().items()}) == str(g.np("sd_digest"))
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    pred, loss, masks = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"])
+    err = float((pred.detach().cpu() - g["pred"]).abs().max())
+    print(f"\ndeep_cap: max |dlogp| = {err:.3e} (bar {LOGP_TOL})")
+    assert_close(pred, g["pred"], atol=LOGP_TOL, name="log-probs")
+    assert_close(loss, g["loss"], atol=1e-3, rtol=1e-4, name="loss")
+    loss.backward()
+    _check_grads(model.named_parameters(), g.sub("grad/"))
+
+
+def test_linear_embedder_captioning_model(golden):
+    """use_linear_embedder=True (FeatureEmbedder, model/blocks.py:66-81; model/captioning_module.py:113-120)"""
+    g = golden("tiny_cap_linemb.npz")
+    cfg = syn.cfg_tiny(use_linear_embedder=True)
+    V = int(g.np("meta")[0])
+    model = _build(cfg, V, True, g.sub("sd/"))
+    pred, loss, masks = _run_cap(model, cfg, {"rgb": g["rgb"], "flow": g["flow"], "audio": g["audio"]}, g["captions"])
+    assert_close(pred, g["pred"], atol=LOGP_TOL, name="log-probs")
+    assert_close(loss, g["loss"], atol=1e-3, rtol=1e-4, name="loss")
+    loss.backward()
+    _check_grads(model.named_parameters(), g.sub("grad/"))
+
+
+def test_ten_adam_steps_stay_within_the_logprob_bar(golden):
+    """what a user of train_cap would notice: after 10 real optimizer steps (bf16 backward, fused Adam) on the mid-scale
+    fixture the log-probs of the trained model are still within 1e-3 of the fp32 CPU path trained the same way"""
+    from bmt_amd.train import CaptioningTrainStep
+    from oracle import bmt_oracle as orc
+    g = golden("mid_cap.npz")
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = syn.cfg_config1(dout_p=0.0)
+    model = _build(cfg, V, True)
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    fs = {k: v.to(DEV) for k, v in batch["feature_stacks"].items()}
+    caps = batch["captions"].to(DEV)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True)
+    sd = orc.init_captioning_params(cfg, V, seed=0, glove=syn.make_glove(V, cfg.d_model_caps))
+    p = {k: v.clone().requires_grad_(k != "emb_C.embedder.weight") for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    for it in range(1, 11):
+        loss, _ = step(fs, caps)
+        for t in p.values():
+            t.grad = None
+        oloss, _, _ = orc.train_cap_loss(p, cfg, batch["feature_stacks"], batch["captions"], syn.PAD_IDX, cfg.smoothing)
+        oloss.backward()
+        with torch.no_grad():
+            for k, t in p.items():
+                if t.grad is not None:
+                    orc.adam_step(t, t.grad, m[k], v2[k], it, cfg.lr)
+        assert abs(float(loss) - float(oloss.detach())) < 1e-3, (it, float(loss), float(oloss))
+    pred, _, _ = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"])
+    with torch.no_grad():
+        _, opred, _ = orc.train_cap_loss(p, cfg, batch["feature_stacks"], batch["captions"], syn.PAD_IDX, cfg.smoothing)
+    err = float((pred.detach().cpu() - opred).abs().max())
+    print(f"\nafter 10 Adam steps: max |dlogp| = {err:.3e} (bar {LOGP_TOL})")
+    assert err < LOGP_TOL
+
+
+def test_optimizer_state_and_weight_planes_after_graph_replays(golden):
+    """(a) the optimizer's state_dict carries the DEVICE step count after graph replays (resuming from it continues
+    the eager trajectory); (b) an eager forward after replays sees the replayed optimizer's weights (plane cache refreshed)"""
+    from bmt_amd import ops
+    from bmt_amd.optim import FusedAdam
+    from bmt_amd.train import CaptioningTrainStep
+    g = golden("tiny_cap_trainemb.npz")
+    V = int(g.np("meta")[0])
+    fs = {k: g[k].to(DEV) for k in ("rgb", "flow", "audio")}
+    caps = g["captions"].to(DEV)
+    cfg = syn.cfg_tiny(dout_p=0.0, lr=1e-3)
+    model = _build(cfg, V, False, g.sub("sd/"))
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True)
+    step.capture(fs, caps, warmup=1)                      # 1 eager warm-up step
+    for _ in range(4):
+        step.replay()
+    osd = step.optimizer.state_dict()
+    steps = {float(st["step"]) for st in osd["state"].values()}
+    assert steps == {5.0}, steps                           # 1 warm-up + 4 replays
+    # (b): eval now, one more replay, eval again: the second eval must see the new weights
+    with torch.no_grad():
+        p1, _, _ = _run_cap(model, cfg, {k: g[k] for k in ("rgb", "flow", "audio")}, g["captions"])
+    step.replay()
+    with torch.no_grad():
+        p2, _, _ = _run_cap(model, cfg, {k: g[k] for k in ("rgb", "flow", "audio")}, g["captions"])
+    ops.weights_changed()                                  # force a refresh: must not change anything if the cache was fresh
+    with torch.no_grad():
+        p3, _, _ = _run_cap(model, cfg, {k: g[k] for k in ("rgb", "flow", "audio")}, g["captions"])
+    assert not torch.equal(p1, p2) and torch.equal(p2, p3)
+    # (a): resume an eager optimizer from the state_dict: its next step must use bias corrections of step 7
+    opt2 = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    opt2.load_state_dict(step.optimizer.state_dict())
+    opt2.zero_grad()
+    _, loss, _ = _run_cap(model, cfg, {k: g[k] for k in ("rgb", "flow", "audio")}, g["captions"], train=True)
+    loss.backward()
+    opt2.step()
+    assert int(opt2._steps[0].item()) == 7

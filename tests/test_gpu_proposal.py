@@ -186,3 +186,90 @@ def test_full_size_properties_config3():
     assert all(math.isfinite(v) for v in losses) and losses[2] < losses[0], losses
     assert all(p.grad is None for p in model.encoder.parameters())
     assert all(p.grad is not None for n, p in model.named_parameters() if n.startswith("detection_layers"))
+
+
+def _deep_models(cfg_cap, cfg_prop, V, anchors):
+    import contextlib, io
+    from bmt_amd.model.captioning_module import BiModalTransformer
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    cfg_cap.device = cfg_prop.device = DEV
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(0)
+        prop = MultimodalProposalGenerator(cfg_prop, anchors)
+        psd = {k: v.detach().clone() for k, v in prop.state_dict().items()}
+        torch.manual_seed(0)
+        cap = BiModalTransformer(cfg_cap, syn.FakeTrainDataset(V, syn.make_glove(V, cfg_cap.d_model_caps)))
+    return cap.to(DEV), prop.to(DEV), psd
+
+
+def test_deep_config_proposal_generator(golden):
+    """configs[4]-shaped proposal generator (N=6, H=8 -> d_k=128 encoder, reduced heads) against the reference's outputs"""
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    from bmt_amd.train import make_masks
+    from oracle import bmt_oracle as orc
+    from tests.test_oracle_golden import deep_prop_cfg
+    import contextlib, io
+    g = golden("deep_prop.npz")
+    B, Tv, Ta, seed, ev = [int(x) for x in g.np("meta")]
+    cfg = deep_prop_cfg()
+    cfg.device = DEV
+    anchors = {"audio": syn.make_anchors(6), "video": syn.make_anchors(10)}
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = MultimodalProposalGenerator(cfg, anchors)
+    assert orc.state_dict_digest({k: v.cpu() for k, v in model.state_dict().items()}) == str(g.np("sd_digest"))
+    model = model.to(DEV).eval()
+    batch = syn.make_prop_batch(cfg, B, Tv, Ta, seed=seed, events_per_video=ev)
+    fs = {k: v.to(DEV) for k, v in batch["feature_stacks"].items()}
+    preds, loss, la, lv = model(fs, batch["targets"].to(DEV), make_masks(fs, None, "audio_video", 1))
+    assert_close(preds, g["preds"], atol=2e-3, rtol=1e-3, name="predictions")
+    assert_close(loss, g["loss"], atol=2e-3, rtol=1e-3, name="total loss")
+    loss.backward()
+    from tests.test_gpu_model import _check_grads
+    _check_grads(model.named_parameters(), g.sub("grad/"))
+
+
+def test_mixed_cap_prop_step_matches_oracle():
+    """configs[4]: alternating train_cap / train_prop steps of one job on the N=6, H=8 (d_k=128) model at reduced B / T -- the
+    proposal heads train on top of the captioning model's live encoder (frozen on the proposal side).  Two rounds against the
+    CPU oracle running the same protocol in fp32."""
+    from bmt_amd.train import MixedTrainStep
+    from oracle import bmt_oracle as orc
+    from tests.test_oracle_golden import deep_cfg, deep_prop_cfg
+    V, B, Tv, Ta, Tc = 200, 2, 24, 72, 9
+    cfg_cap, cfg_prop = deep_cfg(dout_p=0.0, lr=2e-4), deep_prop_cfg()
+    cfg_prop.dout_p, cfg_prop.lr, cfg_prop.grad_clip = 0.0, 1e-3, None
+    anchors = {"audio": syn.make_anchors(6), "video": syn.make_anchors(10)}
+    cap, prop, psd = _deep_models(cfg_cap, cfg_prop, V, anchors)
+    mixed = MixedTrainStep(cap, prop, cfg_cap, cfg_prop, syn.PAD_IDX)
+    cb = syn.make_cap_batch(cfg_cap, B, Tv, Ta, Tc, V, seed=3)
+    pb = syn.make_prop_batch(cfg_prop, B, 40, 120, seed=4, events_per_video=2)
+    cfs, ccaps = {k: v.to(DEV) for k, v in cb["feature_stacks"].items()}, cb["captions"].to(DEV)
+    pfs, ptg = {k: v.to(DEV) for k, v in pb["feature_stacks"].items()}, pb["targets"].to(DEV)
+    # oracle side: captioning parameters + the heads of the proposal generator; the proposal model reads the captioning encoder
+    pc = orc.init_captioning_params(cfg_cap, V, seed=0, glove=syn.make_glove(V, cfg_cap.d_model_caps))
+    pc = {k: v.clone().requires_grad_(k != "emb_C.embedder.weight") for k, v in pc.items()}
+    ph = {k: v.clone().requires_grad_() for k, v in psd.items() if not k.startswith("encoder.")}
+    st = {id(t): (torch.zeros_like(t), torch.zeros_like(t)) for t in list(pc.values()) + list(ph.values())}
+    pmasks = orc.make_masks(pb["feature_stacks"], None, 1)
+    for it in (1, 2):
+        closs, ploss = mixed((cfs, ccaps), (pfs, ptg))
+        for t in list(pc.values()) + list(ph.values()):
+            t.grad = None
+        ol, _, _ = orc.train_cap_loss(pc, cfg_cap, cb["feature_stacks"], cb["captions"], syn.PAD_IDX, cfg_cap.smoothing)
+        ol.backward()
+        with torch.no_grad():
+            for t in pc.values():
+                if t.grad is not None:
+                    orc.adam_step(t, t.grad, st[id(t)][0], st[id(t)][1], it, cfg_cap.lr)
+        pp = dict(ph)
+        pp.update({k: v.detach() for k, v in pc.items() if k.startswith("encoder.")})
+        _, opl, _, _ = orc.multimodal_proposal_generator(pp, cfg_prop, anchors, pb["feature_stacks"], pb["targets"], pmasks)
+        opl.backward()
+        with torch.no_grad():
+            for t in ph.values():
+                orc.adam_step(t, t.grad, st[id(t)][0], st[id(t)][1], it, cfg_prop.lr)
+        assert abs(float(closs) - float(ol.detach())) < 2e-3, (it, float(closs), float(ol))
+        assert abs(float(ploss) - float(opl.detach())) < 5e-3 * max(1.0, abs(float(opl.detach()))), (it, float(ploss), float(opl))
+    assert all(p.grad is None or True for p in prop.encoder.parameters())
+    assert prop.encoder is cap.encoder
