@@ -58,7 +58,7 @@ class KernelTimer:
         def gemm_bf16(A, B, C_out, **kw):
             if not timer.enabled:
                 return raw_gb(A, B, C_out, **kw)
-            prec = kw.get("precision") or ops.FWD_PRECISION
+            prec = kw["precision"]
             akm, bkm, conv = kw.get("a_km", False), kw.get("b_km", False), kw.get("conv")
             if conv is not None and conv["mode"] == 1:       # implicit Conv1d forward / dX: reduction over (tap, channel)
                 M, N, K = conv["M"], B.rows, B.hi.shape[1]
@@ -83,7 +83,7 @@ class KernelTimer:
         def attn_fwd_planes(q, k, v, B_, Sq, Sk, D, mask, H, **kw):
             if not timer.enabled:
                 return raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw)
-            prec = kw.get("precision") or ops.ATTN_PRECISION
+            prec = kw.get("precision", ops.PREC_BF16X3)
             side = "enc" if min(Sq, Sk) >= 128 else "dec"
             nb = sum(ops.prec_operand_bytes(prec)) / 2.0          # operand plane bytes per element in, the same again out
             return timer._timed(f"attn_fwd_{side}_dk{D // H}_{ops.prec_name(prec)}", ops.prec_passes(prec),
@@ -410,10 +410,17 @@ def main():
         # per-kernel HIP-event timing needs individual launches: the same step, eagerly issued, right after the timed region
         timer_steps = 3
         timer.enabled = True
+        # the events must see back-to-back kernels: park the GPU behind a spin kernel first, so that the host (which needs less
+        # time to issue an eager step than the GPU to run it) is a full step ahead and no launch gap lands between two events
+        torch.cuda._sleep(int(0.05 * torch.cuda.get_device_properties(dev).clock_rate * 1e3))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         for _ in range(timer_steps):
             step(*inputs)
+        ev1.record()
         torch.cuda.synchronize()
         timer.enabled = False
+        eager_ms = ev0.elapsed_time(ev1) / timer_steps
 
     t = torch.tensor([dt, float(units_local)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -483,6 +490,9 @@ def main():
                     if pm:
                         out["attention_roofline"]["pmc"] = pm
                         out["attention_roofline"]["pmc_source"] = rec_note
+            out["kernel_timer"] = {"eager_ms_per_step": eager_ms, "timed_classes_ms_per_step": tot / timer_steps,
+                                   "note": "HIP events on torch's current stream around every launch of a class; the GPU is parked behind a "
+                                           "spin kernel first so that launches are queued back to back"}
             out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                          "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches_per_step": v["launches"] / timer_steps}
                                      for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}

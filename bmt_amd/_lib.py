@@ -12,23 +12,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BMT_LIB_PATH") or os.path.join(_HERE, "lib", "libbmt_hip.so")   # override: A/B builds only
 
-PREC_BF16, PREC_BF16X3 = 1, 3
+PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16W2 = 1, 3, 4, 5
 EPI_BIAS, EPI_RELU, EPI_DROP_PRE, EPI_DROP_POST, EPI_RESIDUAL, EPI_GATE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
-
-
-class GemmArgs(C.Structure):
-    _fields_ = [("A", vp), ("lda", i64), ("a_kcontig", i32),
-                ("B", vp), ("ldb", i64), ("b_kcontig", i32),
-                ("C", vp), ("ldc", i64),
-                ("M", i32), ("N", i32), ("K", i32),
-                ("alpha", f32), ("flags", C.c_uint),
-                ("bias", vp), ("residual", vp), ("ldr", i64),
-                ("gate", vp), ("ldg", i64), ("gate_scale", f32),
-                ("drop_p", f32), ("rng", vp), ("site", u32),
-                ("precision", i32), ("splitk", i32),
-                ("C_hi", vp), ("C_lo", vp), ("ldp", i64)]
 
 
 class GemmBf16Args(C.Structure):
@@ -38,7 +25,7 @@ class GemmBf16Args(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32),
-                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp)]
+                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -67,7 +54,7 @@ class AttnFwdBf16Args(C.Structure):
                 ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
                 ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32),
-                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64)]
+                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64), ("Of", vp)]
 
 
 class AttnBwdBf16Args(C.Structure):
@@ -81,14 +68,7 @@ class AttnBwdBf16Args(C.Structure):
                 ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64),
                 ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
-                ("dbq", vp), ("dbk", vp), ("dbv", vp)]
-
-
-class Conv1dArgs(C.Structure):
-    _fields_ = [("x", vp), ("W", vp), ("bias", vp), ("y", vp),
-                ("B", i32), ("S", i32), ("Din", i32), ("Dout", i32), ("k", i32), ("mode", i32),
-                ("flags", C.c_uint), ("drop_p", f32), ("rng", vp), ("site", u32),
-                ("gate", vp), ("gate_scale", f32), ("precision", i32), ("splitk", i32)]
+                ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp)]
 
 
 class SelectProposalsArgs(C.Structure):
@@ -104,8 +84,8 @@ SIGNATURES = {
     "bmt_version": (i32, []),
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
-    "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp]),
-    "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp]),
+    "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp]),
     "bmt_layernorm_bwd_add": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp]),
     "bmt_npy_shape": (i32, [C.c_char_p, vp, vp, vp]),
     "bmt_npy_read_rows": (i32, [C.c_char_p, i64, i64, vp, i64, vp, vp]),
@@ -115,12 +95,11 @@ SIGNATURES = {
     "bmt_transform_proposals": (i32, [vp, i32, i64, C.c_uint, vp, vp]),
     "bmt_last_error": (C.c_char_p, []),
     "bmt_device_cus": (i32, []),
-    "bmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "bmt_gemm_bf16": (i32, [C.POINTER(GemmBf16Args), vp]),
-    "bmt_pad_planes": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i64, vp]),
-    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp]),
+    "bmt_pad_planes": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, vp]),
+    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp]),
     "bmt_planes_desc_bytes": (i32, []),
-    "bmt_planes_desc": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, i64]),
+    "bmt_planes_desc": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64]),
     "bmt_planes_multi": (i32, [vp, i32, vp]),
     "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
@@ -149,7 +128,6 @@ SIGNATURES = {
     "bmt_adam_step": (i32, [vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp, vp]),
     "bmt_grad_sqnorm": (i32, [vp, vp, i32, i64, vp, f32, vp, vp]),
     "bmt_scale_tensors": (i32, [vp, vp, i32, i64, vp, vp]),
-    "bmt_conv1d": (i32, [C.POINTER(Conv1dArgs), vp]),
     "bmt_targets_init": (i32, [vp, vp, vp, vp, i64, vp]),
     "bmt_make_targets": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "bmt_prop_decode_loss": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
@@ -174,8 +152,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 1:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 1")
+    if lib.bmt_version() != 2:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 2")
     _lib = lib
     return lib
 

@@ -109,11 +109,14 @@ __device__ __forceinline__ bf16x8 tfrag(const u32x2* img, int d, int kg) {
     const u32x4 r = {a.x, a.y, b.x, b.y};
     return as_bf16x8(r);
 }
-template <int NPASS>
+template <int NPASS, bool F16 = false>
 __device__ __forceinline__ void pack_p(const float (&p)[16], int s2, bf16x8& hi, bf16x8& lo) {
     uint4 h, l = make_uint4(0, 0, 0, 0);
     const int o = 8 * s2;
-    if constexpr (NPASS == 3) {
+    if constexpr (F16) {
+        h.x = pack_h2(p[o + 0], p[o + 1]); h.y = pack_h2(p[o + 2], p[o + 3]);
+        h.z = pack_h2(p[o + 4], p[o + 5]); h.w = pack_h2(p[o + 6], p[o + 7]);
+    } else if constexpr (NPASS == 3) {
         split_bf2(p[o + 0], p[o + 1], h.x, l.x); split_bf2(p[o + 2], p[o + 3], h.y, l.y);
         split_bf2(p[o + 4], p[o + 5], h.z, l.z); split_bf2(p[o + 6], p[o + 7], h.w, l.w);
     } else {
@@ -143,7 +146,9 @@ struct AttnPB {
     const uint16_t *Oph, *Opl;             // saved forward output as planes (backward, when O == nullptr)
     float *Ow, *lsew, *delta;
     int fuse_delta;                        // backward, 16-wide kernels: the dQ kernel computes delta = rowsum(dO * O) itself (and stores it for dK/dV)
-    uint16_t *Owh, *Owl;                   // forward output planes (optional), strides ldop / bsop
+    uint16_t *Owh, *Owl;                   // forward output planes (optional), strides ldop / bsop: bf16(o) and bf16(o - hi), or fp16(o) when ow_f16
+    int ow_f16;
+    const uint16_t* Opf;                   // backward: the saved output's fp16 plane (delta = rowsum(dO * O) reads it instead of Oph + Opl)
     int64_t ldop, bsop;
     GradOut gq, gk, gv;
     int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;     // plane strides for Q/K/V (and dOh: ldo/bso); fp32 O/dO share ldo/bso
@@ -248,8 +253,10 @@ __device__ __forceinline__ void grad_tile_flush(const uint16_t* tile, const Grad
 // =================================================================================== forward
 constexpr float RESCALE_TAU = 8.f;   // in units of the scaled scores (natural log): P <= e^8
 
-template <int DK, int NPASS>
+// F16: Q / K / V planes hold fp16 values and P is rounded to fp16 (one pass, v_mfma_*_f16) -- the forward's operand policy
+template <int DK, int NPASS, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
+    static_assert(!F16 || NPASS == 1, "fp16 operands: single pass");
     using G = Geo<DK>;
     constexpr int BC = G::BC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                         st = mfma32(as_bf16x8(sKl[idx]), qh[s], st);
                         st = mfma32(a, ql[s], st);
                     }
-                    st = mfma32(a, qh[s], st);
+                    st = mfma32t<F16>(a, qh[s], st);
                 }
                 float pv[16];
 #pragma unroll
@@ -389,8 +396,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                 psum += __shfl_xor(psum, 32, 64);
                 l_run += psum;
                 bf16x8 ph[2], pl[2];
-                pack_p<NPASS>(pv, 0, ph[0], pl[0]);
-                pack_p<NPASS>(pv, 1, ph[1], pl[1]);
+                pack_p<NPASS, F16>(pv, 0, ph[0], pl[0]);
+                pack_p<NPASS, F16>(pv, 1, ph[1], pl[1]);
 #pragma unroll
                 for (int dt = 0; dt < G::DT; ++dt)
 #pragma unroll
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                             o[dt] = mfma32(tfrag<BC>(sVl, d, kg), ph[s2], o[dt]);
                             o[dt] = mfma32(a, pl[s2], o[dt]);
                         }
-                        o[dt] = mfma32(a, ph[s2], o[dt]);
+                        o[dt] = mfma32t<F16>(a, ph[s2], o[dt]);
                     }
             }
         }
@@ -432,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                     uint32_t h0, l0, h1, l1;
                     split_bf2(v.x, v.y, h0, l0);
                     split_bf2(v.z, v.w, h1, l1);
+                    if (p.ow_f16) { l0 = pack_h2(v.x, v.y); l1 = pack_h2(v.z, v.w); }
                     u32x2 hh, ll;
                     hh[0] = h0; hh[1] = h1; ll[0] = l0; ll[1] = l1;
                     *reinterpret_cast<u32x2*>(p.Owh + po) = hh;
@@ -502,9 +510,15 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
     // D[row = 4*(l>>4) + r][col = l&15]
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+template <bool F16>
+__device__ __forceinline__ f32x4v mfma16t(bf16x8 a, bf16x8 b, f32x4v c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
-template <int DK, int NPASS>
+template <int DK, int NPASS, bool F16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd16_kernel(const AttnPB p) {
+    static_assert(!F16 || NPASS == 1, "fp16 operands: single pass");
     constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
     constexpr int KB = BC * pad_rs<DK>(), VB = BC * pad_rs<DK>();   // padded rows: K read by row, V through the transpose unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         st[kt] = mfma16(rowfrag_pad<DK>(sKl, kt * 16 + c, 4 * ks + g), qh[ks], st[kt]);
                         st[kt] = mfma16(a, ql[ks], st[kt]);
                     }
-                    st[kt] = mfma16(a, qh[ks], st[kt]);
+                    st[kt] = mfma16t<F16>(a, qh[ks], st[kt]);
                 }
             float pv[8];
 #pragma unroll
@@ -639,8 +653,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 split_bf2(pv[4], pv[5], hh, ll); phw[2] = hh; plw[2] = ll;
                 split_bf2(pv[6], pv[7], hh, ll); phw[3] = hh; plw[3] = ll;
             } else {
-                phw[0] = pack_bf2(pv[0], pv[1]); phw[1] = pack_bf2(pv[2], pv[3]);
-                phw[2] = pack_bf2(pv[4], pv[5]); phw[3] = pack_bf2(pv[6], pv[7]);
+                phw[0] = pack_2<F16>(pv[0], pv[1]); phw[1] = pack_2<F16>(pv[2], pv[3]);
+                phw[2] = pack_2<F16>(pv[4], pv[5]); phw[3] = pack_2<F16>(pv[6], pv[7]);
             }
             const bf16x8 ph = as_bf16x8(phw), pl = as_bf16x8(plw);
 #pragma unroll
@@ -650,7 +664,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     o[dt] = mfma16(trfrag<DK>(sVl + troff, dt), ph, o[dt]);
                     o[dt] = mfma16(a, pl, o[dt]);
                 }
-                o[dt] = mfma16(a, ph, o[dt]);
+                o[dt] = mfma16t<F16>(a, ph, o[dt]);
             }
         }
         __syncthreads();
@@ -678,6 +692,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 uint32_t h0, l0, h1, l1;
                 split_bf2(v.x, v.y, h0, l0);
                 split_bf2(v.z, v.w, h1, l1);
+                if (p.ow_f16) { l0 = pack_h2(v.x, v.y); l1 = pack_h2(v.z, v.w); }
                 u32x2 hh, ll;
                 hh[0] = h0; hh[1] = h1; ll[0] = l0; ll[1] = l1;
                 *reinterpret_cast<u32x2*>(p.Owh + po) = hh;
@@ -713,6 +728,10 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, in
         float4 c;
         if (p.O) {
             c = *reinterpret_cast<const float4*>(p.O + off + d);
+        } else if (p.Opf) {
+            const u32x2 hh = *reinterpret_cast<const u32x2*>(p.Opf + poff + d);
+            c.x = h_bits2f(hh[0] & 0xffffu); c.y = h_bits2f(hh[0] >> 16);
+            c.z = h_bits2f(hh[1] & 0xffffu); c.w = h_bits2f(hh[1] >> 16);
         } else {
             const u32x2 hh = *reinterpret_cast<const u32x2*>(p.Oph + poff + d);
             u32x2 ll; ll[0] = 0u; ll[1] = 0u;
@@ -1060,14 +1079,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float acc = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 oh = ldfrag(p.Oph + po + 32 * ks, qok);
-            bf16x8 ol = oh;
-            if (p.Opl) ol = ldfrag(p.Opl + po + 32 * ks, qok);
+            if (p.Opf) {
+                const f16x8 of = __builtin_bit_cast(f16x8, ldfrag(p.Opf + po + 32 * ks, qok));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float ov = (float)oh[j];
-                if (p.Opl) ov += (float)ol[j];
-                acc += (float)dof[ks][j] * ov;
+                for (int j = 0; j < 8; ++j) acc += (float)dof[ks][j] * (float)of[j];
+            } else {
+                const bf16x8 oh = ldfrag(p.Oph + po + 32 * ks, qok);
+                bf16x8 ol = oh;
+                if (p.Opl) ol = ldfrag(p.Opl + po + 32 * ks, qok);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float ov = (float)oh[j];
+                    if (p.Opl) ov += (float)ol[j];
+                    acc += (float)dof[ks][j] * ov;
+                }
             }
         }
         acc += __shfl_xor(acc, 16, 64);
@@ -1293,26 +1318,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int DK, int NPASS>
+template <int DK, int NPASS, bool F16 = false>
 int launch_fwd(const AttnPB& p, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries, two waves per SIMD
         const int lds = (NPASS == 3 ? 2 : 1) * (2 * 32 * (DK * 2 + 32)) + 128;
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<DK, NPASS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             done = true;
         }
-        hipLaunchKernelGGL((attn_fwd16_kernel<DK, NPASS>), dim3(nblk), dim3(512), lds, st, p);
+        hipLaunchKernelGGL((attn_fwd16_kernel<DK, NPASS, F16>), dim3(nblk), dim3(512), lds, st, p);
     } else {
         using G = Geo<DK>;
         const int lds = (NPASS == 3 ? 2 : 1) * (G::K_BYTES + G::V_BYTES) + 128;
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<DK, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<DK, NPASS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             done = true;
         }
-        hipLaunchKernelGGL((attn_fwd_bf16_kernel<DK, NPASS>), dim3(nblk), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<DK, NPASS, F16>), dim3(nblk), dim3(256), lds, st, p);
     }
     BMT_CHECK_LAUNCH("bmt_attn_fwd_bf16");
     return BMT_OK;
@@ -1322,7 +1347,7 @@ template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     static const int sep = getenv("BMT_ATTN_DELTA_SEPARATE") ? atoi(getenv("BMT_ATTN_DELTA_SEPARATE")) : 0;      // A/B experiments only
-    const bool fuse = DK >= 128 && !sep && p.dO == nullptr && p.O == nullptr && p.Oph != nullptr;
+    const bool fuse = DK >= 128 && !sep && p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr);
     if (!fuse) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     AttnPB pf = p;
     pf.fuse_delta = fuse ? 1 : 0;
@@ -1380,11 +1405,12 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
     BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh) && a->lse, "bmt_attn_fwd_bf16: null pointer");
     BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_fwd_bf16: bad sizes");
     BMT_CHECK_ARG(a->dk == 32 || a->dk == 64 || a->dk == 128 || a->dk == 256, "bmt_attn_fwd_bf16: d_k=%d not in {32,64,128,256}", a->dk);
-    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || (a->precision == BMT_PREC_BF16X3 && a->Ql && a->Kl && a->Vl),
-                  "bmt_attn_fwd_bf16: BF16X3 needs the lo planes");
+    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || (a->precision == BMT_PREC_BF16X3 && a->Ql && a->Kl && a->Vl),
+                  "bmt_attn_fwd_bf16: precision must be BF16, F16 or BF16X3 (which needs the lo planes)");
+    BMT_CHECK_ARG(!(a->Ol && a->Of), "bmt_attn_fwd_bf16: Ol and Of are alternatives (one second output plane)");
     if (!(al16(a->Qh) && al16(a->Kh) && al16(a->Vh) && al16(a->O)) || ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv) & 7) ||
         ((a->ldo | a->bso) & 3) || (a->Ql && !(al16(a->Ql) && al16(a->Kl) && al16(a->Vl))) ||
-        (a->Oh && (!al16(a->Oh) || !al16(a->Ol) || ((a->ldop | a->bsop) & 7)))) {
+        (a->Oh && (!al16(a->Oh) || !al16(a->Ol) || !al16(a->Of) || ((a->ldop | a->bsop) & 7)))) {
         bmt_set_error("bmt_attn_fwd_bf16: planes must be 16-byte aligned with strides multiples of 8 elements");
         return BMT_EALIGN;
     }
@@ -1392,27 +1418,27 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
     memset(&p, 0, sizeof(p));
     p.Qh = a->Qh; p.Ql = a->Ql; p.Kh = a->Kh; p.Kl = a->Kl; p.Vh = a->Vh; p.Vl = a->Vl;
     p.Ow = a->O; p.lsew = a->lse;
-    p.Owh = a->Oh; p.Owl = a->Ol; p.ldop = a->ldop; p.bsop = a->bsop;
+    p.Owh = a->Oh; p.Owl = a->Of ? a->Of : a->Ol; p.ow_f16 = a->Of != nullptr; p.ldop = a->ldop; p.bsop = a->bsop;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.scale = a->scale; p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
     hipStream_t st = (hipStream_t)stream;
 #define BMT_FWD(D) \
-    if (a->dk == D) return a->precision == BMT_PREC_BF16X3 ? launch_fwd<D, 3>(p, st) : launch_fwd<D, 1>(p, st);
+    if (a->dk == D) return a->precision == BMT_PREC_BF16X3 ? launch_fwd<D, 3>(p, st) : (a->precision == BMT_PREC_F16 ? launch_fwd<D, 1, true>(p, st) : launch_fwd<D, 1>(p, st));
     BMT_FWD(32) BMT_FWD(64) BMT_FWD(128) BMT_FWD(256)
 #undef BMT_FWD
     return BMT_EINVAL;
 }
 
 extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) {
-    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh) && a->lse && a->delta_ws && a->dOh_ws,
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh || a->Of) && a->lse && a->delta_ws && a->dOh_ws,
                   "bmt_attn_bwd_bf16: null pointer");
     BMT_CHECK_ARG((a->dQ || a->dQh) && (a->dK || a->dKh) && (a->dV || a->dVh), "bmt_attn_bwd_bf16: every gradient needs an fp32 or a plane output");
     BMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Sk > 0, "bmt_attn_bwd_bf16: bad sizes");
     BMT_CHECK_ARG(a->dk == 32 || a->dk == 64 || a->dk == 128 || a->dk == 256, "bmt_attn_bwd_bf16: d_k=%d not in {32,64,128,256}", a->dk);
     if (!(al16(a->Qh) && al16(a->Kh) && al16(a->Vh) && al16(a->O) && al16(a->dO) && al16(a->dQ) && al16(a->dK) && al16(a->dV) &&
-          al16(a->dOh_ws) && al16(a->Oh) && al16(a->Ol) && al16(a->dQh) && al16(a->dKh) && al16(a->dVh)) ||
+          al16(a->dOh_ws) && al16(a->Oh) && al16(a->Ol) && al16(a->Of) && al16(a->dQh) && al16(a->dKh) && al16(a->dVh)) ||
         ((a->ldq | a->ldk | a->ldv | a->bsq | a->bsk | a->bsv | a->ldo | a->bso | a->dkv_ld | a->dkv_bs | a->ldop | a->bsop |
           a->gq_ld | a->gq_bs | a->gkv_ld | a->gkv_bs) & 7)) {
         bmt_set_error("bmt_attn_bwd_bf16: pointers must be 16-byte aligned with strides multiples of 8 elements");
@@ -1421,7 +1447,7 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     AttnPB p;
     memset(&p, 0, sizeof(p));
     p.Qh = a->Qh; p.Kh = a->Kh; p.Vh = a->Vh; p.dOh = a->dOh_ws;
-    p.O = a->O; p.Oph = a->Oh; p.Opl = a->Ol; p.ldop = a->ldop; p.bsop = a->bsop;
+    p.O = a->O; p.Oph = a->Oh; p.Opl = a->Ol; p.Opf = a->Of; p.ldop = a->ldop; p.bsop = a->bsop;
     p.dO = a->dO; p.lse = a->lse; p.delta = a->delta_ws;
     p.gq = GradOut{a->dQ, a->ldo, a->bso, a->dQh, a->gq_ld, a->gq_bs, a->dQT, a->gqT_ld, a->dbq};
     p.gk = GradOut{a->dK, a->dkv_ld, a->dkv_bs, a->dKh, a->gkv_ld, a->gkv_bs, a->dKT, a->gkvT_ld, a->dbk};

@@ -46,6 +46,15 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// fp16 operands: the same MFMA shapes and rate, 11 significand bits instead of 8 (the forward's operand policy, DESIGN.md
+// "precision").  Fragments travel as bf16x8 = four untyped 32-bit registers; F16 selects the instruction.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32t(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // row of accumulator register r for this lane's half (l>>5)
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -73,6 +82,26 @@ __device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32
     const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+}
+
+// fp16 (RNE): pack two floats; split (a, b) into hi = fp16(x) and lo = fp16(x - hi)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ void split_h2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2_t v = {a, b};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ float h_bits2f(uint32_t b) { return (float)__builtin_bit_cast(_Float16, (uint16_t)b); }
+template <bool F16>
+__device__ __forceinline__ uint32_t pack_2(float a, float b) {
+    if constexpr (F16) return pack_h2(a, b);
+    else return pack_bf2(a, b);
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG

@@ -25,7 +25,8 @@ struct GemmB {
     int64_t lda, ldb;
     float* C;
     int64_t ldc;
-    uint16_t *Chi, *Clo;
+    uint16_t *Chi, *Clo;                 // output planes: Chi = bf16(c); Clo = bf16(c - hi), or fp16(c) when second_f16
+    int second_f16;
     int64_t ldp;
     int plane_cols;                      // planes are written for col < plane_cols (zeros for col >= N)
     int plane_vec;                       // plane outputs 16-B aligned with ldp, plane_cols multiples of 8: staged through LDS
@@ -142,15 +143,18 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
 // tile (more waves per SIMD to hide the LDS / barrier latency of the stage loop, 1.5x the fragment reads).
 // CONV = 1: operand A is a halo-padded activation plane read with a per-stage row shift (Conv1d forward and dX);
 // CONV = 2: operand B (k-major) is that plane read with a per-TILE row shift (Conv1d dW: output column block = tap).
-template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0>
+// NPASS: 1 = A.B (one plane each); 2 = A.(Bh + Bl) (the activation as ONE plane, the weight split: the fp16 forward policy, two
+// MFMA passes); 3 = split-bf16 (Ah.Bh + Ah.Bl + Al.Bh).  F16: the planes hold fp16 values (v_mfma_f32_32x32x16_f16).
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
-    constexpr int BK = (NPASS == 3) ? 32 : 64;
+    constexpr int BK = (NPASS == 1) ? 64 : 32;
+    constexpr bool ALO = NPASS == 3, BLO = NPASS >= 2;
     constexpr int SPR = BK / 8;
     constexpr int BM = 32 * TI * WM, NT = 128 * WM;       // WM waves along M x 2 along N
     constexpr int PA = AKM ? BK * km_rs<BM>() : BM * BK * 2, PBB = BKM ? BK * km_rs<BN>() : BN * BK * 2;   // bytes of one A / B plane tile
-    constexpr int STAGE_BYTES = (NPASS == 3 ? 2 : 1) * (PA + PBB);
+    constexpr int STAGE_BYTES = (ALO ? 2 : 1) * PA + (BLO ? 2 : 1) * PBB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -193,8 +197,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             abase[i] = row + 2 * (row / p.conv_S) * p.conv_halo;       // + tap, from a base pointer advanced by halo - pad rows
         }
     }
-    // stage image: A hi | B hi | A lo | B lo
-#define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + ((which_) == 0 ? 0 : (which_) == 1 ? PA : (which_) == 2 ? PA + PBB : 2 * PA + PBB))
+    // stage image: A hi | B hi | [A lo] | [B lo]
+#define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + ((which_) == 0 ? 0 : (which_) == 1 ? PA : (which_) == 2 ? PA + PBB : (ALO ? 2 : 1) * PA + PBB))
 #define BMT_GLOAD(s_, RA, RB, RAL, RBL)                                                   \
     do {                                                                                  \
         const int k_ = min(kbeg + (s_) * BK, kend - BK);   /* branch-free tail: re-fetch the last stage */ \
@@ -204,11 +208,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         if constexpr (CONV == 2) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0 % p.conv_cin, k_, p.krows, tid, RB, n0 / p.conv_cin, p.conv_rows - 1); \
         else if constexpr (BKM) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0, k_, p.krows, tid, RB);   \
         else plane_gload<SPR, BN, NT>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                 \
-        if constexpr (NPASS == 3) {                                                       \
+        if constexpr (ALO) {                                                              \
             if constexpr (CONV == 1) plane_gload_conv<SPR, BM, NT>(p.Al, p.lda, abase, p.conv_rows - 1, k_ / p.conv_cin, k_ % p.conv_cin, tid, RAL); \
             else plane_gload<SPR, BM, NT>(p.Al, p.lda, m0, p.M, k_, tid, RAL);            \
-            plane_gload<SPR, BN, NT>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);                 \
         }                                                                                 \
+        if constexpr (BLO) plane_gload<SPR, BN, NT>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);  \
     } while (0)
 #define BMT_LSTORE(buf_, RA, RB, RAL, RBL)                                                \
     do {                                                                                  \
@@ -216,10 +220,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         else plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 0), tid, RA);                      \
         if constexpr (BKM) plane_lstore_km<BN, BK, NT>(reinterpret_cast<char*>(stage_ptr(buf_, 1)), tid, RB);  \
         else plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 1), tid, RB);                      \
-        if constexpr (NPASS == 3) {                                                       \
-            plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 2), tid, RAL);                      \
-            plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 3), tid, RBL);                      \
-        }                                                                                 \
+        if constexpr (ALO) plane_lstore<SPR, BM, NT>(stage_ptr(buf_, 2), tid, RAL);       \
+        if constexpr (BLO) plane_lstore<SPR, BN, NT>(stage_ptr(buf_, 3), tid, RBL);       \
     } while (0)
 #define BMT_COMPUTE(buf_)                                                                 \
     do {                                                                                  \
@@ -235,21 +237,19 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
                 const int ia = slot_of<SPR>(wr * 32 * TI + i * 32 + l31, sl);             \
                 if constexpr (AKM) ah[i] = km_frag<BM>(reinterpret_cast<const char*>(sAh), 16 * s, wr * 32 * TI + i * 32, lane); \
                 else ah[i] = as_bf16x8(sAh[ia]);                                          \
-                if constexpr (NPASS == 3) al[i] = as_bf16x8(sAl[ia]);                     \
+                if constexpr (ALO) al[i] = as_bf16x8(sAl[ia]);                            \
             }                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                               \
                 const int ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl);                  \
                 if constexpr (BKM) bh[i] = km_frag<BN>(reinterpret_cast<const char*>(sBh), 16 * s, wc * 64 + i * 32, lane); \
                 else bh[i] = as_bf16x8(sBh[ib]);                                          \
-                if constexpr (NPASS == 3) bl[i] = as_bf16x8(sBl[ib]);                     \
+                if constexpr (BLO) bl[i] = as_bf16x8(sBl[ib]);                            \
             }                                                                             \
             _Pragma("unroll") for (int i = 0; i < TI; ++i)                                \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) {                           \
-                    if constexpr (NPASS == 3) {                                           \
-                        acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);                      \
-                        acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);                      \
-                    }                                                                     \
-                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);                          \
+                    if constexpr (ALO) acc[i][j] = mfma32t<F16>(al[i], bh[j], acc[i][j]); \
+                    if constexpr (BLO) acc[i][j] = mfma32t<F16>(ah[i], bl[j], acc[i][j]); \
+                    acc[i][j] = mfma32t<F16>(ah[i], bh[j], acc[i][j]);                    \
                 }                                                                         \
         }                                                                                 \
         __builtin_amdgcn_s_setprio(0);                                                    \
@@ -335,7 +335,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
                 }
                 if (p.Chi) {
                     const __bf16 hv = (__bf16)v;
-                    const uint32_t hb = __builtin_bit_cast(uint16_t, hv), lb = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)hv));
+                    const uint32_t hb = __builtin_bit_cast(uint16_t, hv);
+                    const uint32_t lb = p.second_f16 ? (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v)
+                                                     : (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(v - (float)hv));
                     if (p.plane_vec) {
                         ct[rl * 128 + wc * 64 + j * 32 + l31] = hb | (lb << 16);
                     } else {
@@ -418,9 +420,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     }
 }
 
-template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0>
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false>
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
-    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, CONV>(p, blockIdx.x, blockIdx.y);
+    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, CONV, F16>(p, blockIdx.x, blockIdx.y);
 }
 
 // MANY independent GEMMs in one launch (the weight gradients of a whole step: each dW = dY^T . X is too small to fill the chip
@@ -499,7 +501,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
                 const __bf16 hv = (__bf16)out[c];
                 const int64_t pi = (int64_t)row * p.ldp + col;
                 p.Chi[pi] = __builtin_bit_cast(uint16_t, hv);
-                if (p.Clo) p.Clo[pi] = __builtin_bit_cast(uint16_t, (__bf16)(out[c] - (float)hv));
+                if (p.Clo) p.Clo[pi] = p.second_f16 ? __builtin_bit_cast(uint16_t, (_Float16)out[c])
+                                                    : __builtin_bit_cast(uint16_t, (__bf16)(out[c] - (float)hv));
             }
         }
     }
@@ -511,6 +514,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
 struct PlaneDesc {
     const float* src; int64_t ld; int R, C;
     uint16_t *hi, *lo; int64_t ldp; int pcols;
+    uint16_t *fh, *fl;                                              // optional fp16 planes, same [R][ldp] layout: fh = fp16(x), fl = fp16(x - fh)
     uint16_t *hiT, *loT; int64_t ldpT; int pcolsT;
     float* colsum;
     int tiles_x, tiles_y;
@@ -534,6 +538,11 @@ __device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, 
             const __bf16 h = (__bf16)v;
             d.hi[(int64_t)r * d.ldp + c] = __builtin_bit_cast(uint16_t, h);
             if (d.lo) d.lo[(int64_t)r * d.ldp + c] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+        }
+        if (d.fh && r < d.R && c < d.pcols) {
+            const _Float16 h = (_Float16)v;
+            d.fh[(int64_t)r * d.ldp + c] = __builtin_bit_cast(uint16_t, h);
+            if (d.fl) d.fl[(int64_t)r * d.ldp + c] = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)h));
         }
     }
     if (d.hiT) {
@@ -598,8 +607,18 @@ __device__ __forceinline__ void planes_rows_tile(const PlaneDesc& d, int bx, int
                 h[q] = hh; l[q] = ll;
                 part[2 * q] += v[2 * q]; part[2 * q + 1] += v[2 * q + 1];
             }
-            *reinterpret_cast<u32x4*>(d.hi + (int64_t)r * d.ldp + c0) = h;
+            if (d.hi) *reinterpret_cast<u32x4*>(d.hi + (int64_t)r * d.ldp + c0) = h;
             if (d.lo) *reinterpret_cast<u32x4*>(d.lo + (int64_t)r * d.ldp + c0) = l;
+            if (d.fh) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t hh, ll;
+                    split_h2(v[2 * q], v[2 * q + 1], hh, ll);
+                    h[q] = hh; l[q] = ll;
+                }
+                *reinterpret_cast<u32x4*>(d.fh + (int64_t)r * d.ldp + c0) = h;
+                if (d.fl) *reinterpret_cast<u32x4*>(d.fl + (int64_t)r * d.ldp + c0) = l;
+            }
         }
     }
     if (d.colsum) {
@@ -623,8 +642,9 @@ __global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
 // the vector kernel applies when there is a straight hi plane and nothing transposed, everything 16-byte aligned
 static bool planes_rows_ok(const PlaneDesc& d) {
     static const int old = getenv("BMT_PLANES_OLD") ? atoi(getenv("BMT_PLANES_OLD")) : 0;        // A/B experiments only
-    return !old && d.hi && !d.hiT && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
-           ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.hi) | reinterpret_cast<uintptr_t>(d.lo)) & 15) == 0;
+    return !old && (d.hi || d.fh) && !d.hiT && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
+           ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.hi) | reinterpret_cast<uintptr_t>(d.lo) |
+             reinterpret_cast<uintptr_t>(d.fh) | reinterpret_cast<uintptr_t>(d.fl)) & 15) == 0;
 }
 
 // every weight of the model in ONE launch: blockIdx.y = tensor, blockIdx.x strides over its 64x64 tiles
@@ -645,18 +665,18 @@ __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __re
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int NPASS, int WM, int TI, bool AKM = false, bool BKM = false, int CONV = 0>
+template <int NPASS, int WM, int TI, bool AKM = false, bool BKM = false, int CONV = 0, bool F16 = false>
 int launch(const GemmB& p, int splitk, hipStream_t st) {
-    constexpr int BK = (NPASS == 3) ? 32 : 64;
+    constexpr int BK = (NPASS == 1) ? 64 : 32;
     constexpr int BMr = 32 * TI * WM;
-    constexpr int stage = (NPASS == 3 ? 2 : 1) * ((AKM ? BK * km_rs<BMr>() : BMr * BK * 2) + (BKM ? BK * km_rs<BN>() : BN * BK * 2));
+    constexpr int stage = (NPASS == 3 ? 2 : 1) * (AKM ? BK * km_rs<BMr>() : BMr * BK * 2) + (NPASS >= 2 ? 2 : 1) * (BKM ? BK * km_rs<BN>() : BN * BK * 2);
     constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;   // two stage buffers / the packed plane tile of the epilogue
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM, CONV, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM, CONV>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<NPASS, WM, TI, AKM, BKM, CONV, F16>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(128 * WM), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16");
     return BMT_OK;
 }
@@ -668,8 +688,11 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     BMT_CHECK_ARG(a && a->A_hi && a->B_hi && (a->C || a->C_hi), "bmt_gemm_bf16: null pointer");
     BMT_CHECK_ARG(a->M > 0 && a->N > 0 && a->Kpad > 0 && a->Kpad % 64 == 0, "bmt_gemm_bf16: bad sizes M=%d N=%d Kpad=%d (Kpad %% 64 != 0?)",
                   a->M, a->N, a->Kpad);
-    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || (a->precision == BMT_PREC_BF16X3 && a->A_lo && a->B_lo),
-                  "bmt_gemm_bf16: BF16X3 needs both lo planes");
+    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || (a->precision == BMT_PREC_BF16X3 && a->A_lo && a->B_lo) ||
+                      (a->precision == BMT_PREC_F16W2 && a->B_lo),
+                  "bmt_gemm_bf16: BF16X3 needs both lo planes, F16W2 the lo plane of B");
+    BMT_CHECK_ARG(!(a->C_lo && a->C_f16), "bmt_gemm_bf16: C_lo and C_f16 are alternatives (one second output plane)");
+    BMT_CHECK_ARG(!(a->C_f16 && a->colsum), "bmt_gemm_bf16: colsum is taken from bf16 hi + lo of the staged value, not with C_f16");
     BMT_CHECK_ARG(!(a->a_kmajor || a->b_kmajor) || (a->precision == BMT_PREC_BF16 && a->K > 0 && a->K <= a->Kpad && a->Kpad - a->K < 64),
                   "bmt_gemm_bf16: k-major operands need BMT_PREC_BF16 and the true reduction length K (Kpad = K rounded up to 64)");
     BMT_CHECK_ARG(a->conv_mode == 0 || (a->conv_cin > 0 && a->conv_cin % 64 == 0 && a->conv_rows > 0 &&
@@ -695,9 +718,9 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_GATE) || a->gate, "bmt_gemm_bf16: GATE flag without pointer");
     memset(&p, 0, sizeof(p));
     p.Ah = a->A_hi; p.Al = a->A_lo; p.Bh = a->B_hi; p.Bl = a->B_lo; p.lda = a->lda; p.ldb = a->ldb;
-    p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_lo; p.ldp = a->ldp;
+    p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_f16 ? a->C_f16 : a->C_lo; p.second_f16 = a->C_f16 != nullptr; p.ldp = a->ldp;
     p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
-    p.plane_vec = a->C_hi && al16(a->C_hi) && (!a->C_lo || al16(a->C_lo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
+    p.plane_vec = a->C_hi && al16(a->C_hi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
     p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
@@ -707,9 +730,9 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     // K >= 512 shapes and loses 2-8 % elsewhere; the 8-wave 128-row tile (below) beats both, so 256 rows is opt-in only
     p.bm = 128;
     if (force_bm == 128 || force_bm == 256) p.bm = force_bm;
-    if (a->a_kmajor || a->b_kmajor || a->conv_mode) p.bm = 128;
+    if (a->a_kmajor || a->b_kmajor || a->conv_mode || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2) p.bm = 128;
     p.tiles_m = bmt_cdiv(a->M, p.bm);
-    const int bk = (a->precision == BMT_PREC_BF16X3) ? 32 : 64;
+    const int bk = (a->precision == BMT_PREC_BF16X3 || a->precision == BMT_PREC_F16W2) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
     static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 256;          // A/B experiments only
@@ -753,8 +776,17 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     const int waves8 = force8 >= 0 ? force8 : 1;
     hipStream_t st_ = (hipStream_t)stream;
     const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
+    const bool f16 = a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2;
+    if (f16 && (akm || bkm || a->conv_mode == 2)) {
+        bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
+        return BMT_EINVAL;
+    }
     if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
-        rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1, false, false, 1>(p, splitk, st_) : launch<1, 4, 1, false, false, 1>(p, splitk, st_);
+        if (a->precision == BMT_PREC_F16W2) rc = launch<2, 4, 1, false, false, 1, true>(p, splitk, st_);
+        else if (a->precision == BMT_PREC_F16) rc = launch<1, 4, 1, false, false, 1, true>(p, splitk, st_);
+        else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1, false, false, 1>(p, splitk, st_) : launch<1, 4, 1, false, false, 1>(p, splitk, st_);
+    } else if (f16) {                 // fp16 forward policy: 8-wave 128-row tiles
+        rc = a->precision == BMT_PREC_F16W2 ? launch<2, 4, 1, false, false, 0, true>(p, splitk, st_) : launch<1, 4, 1, false, false, 0, true>(p, splitk, st_);
     } else if (a->conv_mode == 2) {   // implicit Conv1d dW
         rc = launch<1, 4, 1, true, true, 2>(p, splitk, st_);
     } else if (akm || bkm) {                 // single-pass kernel, 128-row tiles
@@ -902,26 +934,27 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     return BMT_OK;
 }
 
-static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-                     uint16_t* loT, int64_t ldpT, float* colsum) {
-    BMT_CHECK_ARG(src && (hi || hiT || colsum) && R > 0 && C > 0, "bmt_planes: bad args");
-    BMT_CHECK_ARG(!hi || ldp >= C, "bmt_planes: ldp < C");
+static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
+                     uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum) {
+    BMT_CHECK_ARG(src && (hi || fh || hiT || colsum) && R > 0 && C > 0, "bmt_planes: bad args");
+    BMT_CHECK_ARG(!(hi || fh) || ldp >= C, "bmt_planes: ldp < C");
+    BMT_CHECK_ARG((!lo || hi) && (!fl || fh), "bmt_planes: a lo plane without its hi plane");
     BMT_CHECK_ARG(!hiT || ldpT >= R, "bmt_planes: ldpT < R");
     // padding written with zeros: up to the next multiple of 64 (bounded by the row stride)
-    d.src = src; d.ld = ld; d.R = R; d.C = C; d.hi = hi; d.lo = lo; d.ldp = ldp; d.hiT = hiT; d.loT = loT; d.ldpT = ldpT;
+    d.src = src; d.ld = ld; d.R = R; d.C = C; d.hi = hi; d.lo = lo; d.fh = fh; d.fl = fl; d.ldp = ldp; d.hiT = hiT; d.loT = loT; d.ldpT = ldpT;
     d.colsum = colsum;
     d.drop_p = 0.f; d.drop_site = 0; d.drop_rng = nullptr;
-    d.pcols = hi ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
+    d.pcols = (hi || fh) ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
     d.pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
     d.tiles_x = bmt_cdiv(d.pcols > C ? d.pcols : C, 64);
     d.tiles_y = bmt_cdiv(d.pcolsT > R ? d.pcolsT : R, 64);
     return BMT_OK;
 }
 
-extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-                          uint16_t* loT, int64_t ldpT, float* colsum, void* stream) {
+extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
+                          uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, void* stream) {
     PlaneDesc d;
-    int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, colsum);
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, hiT, loT, ldpT, colsum);
     if (rc) return rc;
     if (planes_rows_ok(d)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
@@ -929,11 +962,11 @@ extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* 
     return BMT_OK;
 }
 
-extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-                                  uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site,
+extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
+                                  uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site,
                                   void* stream) {
     PlaneDesc d;
-    int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, colsum);
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, hiT, loT, ldpT, colsum);
     if (rc) return rc;
     BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_planes_dropout: bad dropout arguments");
     d.drop_p = drop_p; d.drop_site = site; d.drop_rng = rng;
@@ -944,12 +977,12 @@ extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, ui
 }
 
 // host helper: fill one descriptor of the multi-tensor table (the caller uploads the table to device memory)
-extern "C" int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,
-                               uint16_t* hiT, uint16_t* loT, int64_t ldpT) {
+extern "C" int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl,
+                               int64_t ldp, uint16_t* hiT, uint16_t* loT, int64_t ldpT) {
     BMT_CHECK_ARG(desc_out, "bmt_planes_desc: null");
     PlaneDesc d;
     memset(&d, 0, sizeof(d));
-    int rc = fill_desc(d, src, ld, R, C, hi, lo, ldp, hiT, loT, ldpT, nullptr);
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, hiT, loT, ldpT, nullptr);
     if (rc) return rc;
     d.rows_ok = planes_rows_ok(d) ? 1 : 0;
     memcpy(desc_out, &d, sizeof(d));
@@ -1001,7 +1034,7 @@ extern "C" int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C,
 // lo = bf16(x - hi), optional), every other row and the columns [C, ldp) are zero.
 namespace {
 __global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict__ x, int B, int S, int C, int halo, int tail,
-                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int64_t ldp) {
+                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int lo_f16, int64_t ldp) {
     const int groups = (int)(ldp / 8);
     const int64_t total = ((int64_t)B * (S + 2 * halo) + tail) * groups;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1020,6 +1053,7 @@ __global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) {
             uint32_t hh, ll;
             split_bf2(v[2 * j], v[2 * j + 1], hh, ll);
+            if (lo_f16) ll = pack_h2(v[2 * j], v[2 * j + 1]);        // second plane = fp16(x) (fp16 forward operand)
             h[j] = hh; l[j] = ll;
         }
     }
@@ -1028,11 +1062,12 @@ __global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict
 }
 }  // namespace
 
-extern "C" int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream) {
+extern "C" int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp,
+                              void* stream) {
     BMT_CHECK_ARG(x && hi && B > 0 && S > 0 && C > 0 && halo >= 0 && tail >= 0 && ldp >= C && ldp % 8 == 0, "bmt_pad_planes: bad args");
     if (!al16(hi) || (lo && !al16(lo))) { bmt_set_error("bmt_pad_planes: planes must be 16-byte aligned"); return BMT_EALIGN; }
     const int64_t total = ((int64_t)B * (S + 2 * halo) + tail) * (ldp / 8);
-    hipLaunchKernelGGL(pad_planes_kernel, dim3((unsigned)bmt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, B, S, C, halo, tail, hi, lo, ldp);
+    hipLaunchKernelGGL(pad_planes_kernel, dim3((unsigned)bmt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, B, S, C, halo, tail, hi, lo, lo_f16, ldp);
     BMT_CHECK_LAUNCH("bmt_pad_planes");
     return BMT_OK;
 }

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                       const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
                                                       float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                      int64_t ldp, int pcols) {
+                                                      int64_t ldp, int pcols, int lo_f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 uint32_t h0, l0, h1, l1;
                 split_bf2(o.x, o.y, h0, l0);
                 split_bf2(o.z, o.w, h1, l1);
+                if (lo_f16) { l0 = pack_h2(o.x, o.y); l1 = pack_h2(o.z, o.w); }     // second plane = fp16(o) (fp16 forward operand)
                 *reinterpret_cast<uint2*>(hr + c) = make_uint2(h0, h1);
                 if (lr) *reinterpret_cast<uint2*>(lr + c) = make_uint2(l0, l1);
             }
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             if (hr) {
                 const __bf16 h = (__bf16)o;
                 hr[c] = __builtin_bit_cast(uint16_t, h);
-                if (lr) lr[c] = __builtin_bit_cast(uint16_t, (__bf16)(o - (float)h));
+                if (lr) lr[c] = lo_f16 ? __builtin_bit_cast(uint16_t, (_Float16)o) : __builtin_bit_cast(uint16_t, (__bf16)(o - (float)h));
             }
         }
     }
@@ -233,7 +234,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace
 
 extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
-                                        float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int64_t ldp, int rows, int D,
+                                        float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp, int rows, int D,
                                         float eps, void* stream) {
     BMT_CHECK_ARG(x && gamma && beta && (y || hi) && rows >= 0 && D > 0, "bmt_layernorm_fwd: bad args");
     BMT_CHECK_ARG(!lo || hi, "bmt_layernorm_fwd_planes: lo plane without hi plane");
@@ -244,8 +245,8 @@ extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (!y || (ldy % 4 == 0 && al16(y))) && al16(x) && al16(gamma) && al16(beta) &&
                      (!hi || ((ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0));
     dim3 grid(bmt_cdiv(rows, 4)), block(256);
-    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols);
-    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols);
+    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
     BMT_CHECK_LAUNCH("bmt_layernorm_fwd");
     return BMT_OK;
 }
@@ -253,7 +254,7 @@ extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float
 extern "C" int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                                  float* mean, float* rstd, int rows, int D, float eps, void* stream) {
     BMT_CHECK_ARG(y, "bmt_layernorm_fwd: bad args");
-    return bmt_layernorm_fwd_planes(x, ldx, gamma, beta, y, ldy, mean, rstd, nullptr, nullptr, 0, rows, D, eps, stream);
+    return bmt_layernorm_fwd_planes(x, ldx, gamma, beta, y, ldy, mean, rstd, nullptr, nullptr, 0, 0, rows, D, eps, stream);
 }
 
 extern "C" int bmt_layernorm_bwd_blocks(int rows) { return rows <= 0 ? 0 : bmt_cdiv(rows, 4 * ln_bwd_rows_per_wave(rows)); }

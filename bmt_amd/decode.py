@@ -10,7 +10,7 @@ that expose ``encode`` / ``decode`` (bmt_amd.model.captioning_module.BiModalTran
 
 * the encoder runs ONCE per call;
 * the key / value operand planes of the two cross-attentions of every decoder layer are computed once and kept for the
-  whole call (``ops.KV_CACHE``; bmt_amd.ops.mha_infer);
+  whole call (``ops.context().kv_cache``; bmt_amd.ops.mha_infer);
 * the generator (d_model -> vocabulary GEMM + log-softmax) runs on the last position only.
 
 The decoder self-attention / bridge / FFN still run over the whole prefix (<= 30 tokens: a launch-bound tail next to the
@@ -39,17 +39,18 @@ def greedy_decoder(model, feature_stacks, max_len, start_idx, end_idx, pad_idx, 
         else:
             raise Exception(f'Unknown modality: {modality}')
 
-        reuse = reuse and hasattr(model, 'encode') and hasattr(model, 'decode') and ops.USE_PLANE_GEMM
+        reuse = reuse and hasattr(model, 'encode') and hasattr(model, 'decode')
         # 1 where the ending token occurred; stop when it occurred in every sequence
         done = torch.zeros(B, 1, dtype=torch.bool, device=device)
         trg = torch.full((B, 1), start_idx, dtype=torch.long, device=device)
 
         memory = None
-        prev_cache = ops.KV_CACHE
+        ctx = ops.context()          # per (device, stream): concurrent decodes on other streams keep their own cache
+        prev_cache = ctx.kv_cache
         try:
             if reuse:
                 memory = model.encode(feature_stacks, make_masks(feature_stacks, trg, modality, pad_idx))
-                ops.KV_CACHE = {}
+                ctx.kv_cache = {}
             while trg.size(-1) <= max_len and not bool(done.all()):
                 masks = make_masks(feature_stacks, trg, modality, pad_idx)
                 if reuse:
@@ -61,5 +62,5 @@ def greedy_decoder(model, feature_stacks, max_len, start_idx, end_idx, pad_idx, 
                 trg = torch.cat([trg, next_word], dim=-1)
                 done = done | torch.eq(next_word, end_idx)
         finally:
-            ops.KV_CACHE = prev_cache
+            ctx.kv_cache = prev_cache
         return trg

@@ -188,12 +188,12 @@ class ResidualConnection(nn.Module):
     def forward(self, x, sublayer):
         # x (B, S, D):  x + dropout(sublayer(LN(x)))
         p = self.dout_p if self.training else 0.0
-        if not (ops.FUSE_RESIDUAL and ops.USE_PLANE_GEMM):
+        if not ops.FUSE_RESIDUAL:
             res = sublayer(layer_norm(self.norm, x))
             return ops.DropoutAddFn.apply(x, res, p, self._site)
         # fused form (ops.ResidualNormFn): LN emits its operand planes, the sublayer's last GEMM takes the offered residual and
         # adds dropout + x in its epilogue; a sublayer that does not take the offer gets the separate kernel
-        xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm)
         off = ops.offer_residual(xid, p, self._site)
         res = sublayer(xn)
         ops.take_residual()
@@ -238,8 +238,9 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, x):
         '''In, Out: (B, S, D)'''
         p = self.dout_p if self.training else 0.0
-        off = ops.take_residual() if ops.USE_PLANE_GEMM else None
+        pol = ops.policy_of(self)
+        off = ops.take_residual()
         if off is None:
-            return ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, None, 0.0, 0)
-        off.out = ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, off.x, off.p, off.site)
+            return ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, pol, None, 0.0, 0)
+        off.out = ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, pol, off.x, off.p, off.site)
         return off.out

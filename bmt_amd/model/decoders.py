@@ -3,6 +3,8 @@ BiModelDecoder :114 (sic -- the reference's spelling is what callers import; BiM
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 from .blocks import (BridgeConnection, LayerStack, PositionwiseFeedForward, ResidualConnection, clone)
 from .multihead_attention import MultiheadedAttention
 
@@ -40,6 +42,7 @@ class BiModalDecoderLayer(nn.Module):
         # feed forward residual
         self.res_layer_ff = ResidualConnection(d_model_C, dout_p)
         self.feed_forward = PositionwiseFeedForward(d_model_C, d_ff_C, dout_p)
+        ops.tag_policy(self, "dec")     # MFMA operand formats of this layer's products (bmt_amd.ops.POLICIES)
 
     def forward(self, x, masks):
         '''

@@ -5,6 +5,8 @@ operations -- in particular the cross-modal K/V are the other stream's post-self
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 from .blocks import (BridgeConnection, LayerStack, PositionwiseFeedForward, ResidualConnection, clone)
 from .multihead_attention import MultiheadedAttention
 
@@ -36,6 +38,7 @@ class BiModalEncoderLayer(nn.Module):
         self.feed_forward_M2 = PositionwiseFeedForward(d_model_M2, d_ff_M2, dout_p)
         self.res_layers_M1 = clone(ResidualConnection(d_model_M1, dout_p), 3)
         self.res_layers_M2 = clone(ResidualConnection(d_model_M2, dout_p), 3)
+        ops.tag_policy(self, "enc")     # MFMA operand formats of this layer's products (bmt_amd.ops.POLICIES)
 
     def forward(self, x, masks):
         '''

@@ -66,19 +66,19 @@ class MultiheadedAttention(nn.Module):
     def forward(self, Q, K, V, mask):
         ''' Q, K, V: (B, Sq, Dq), (B, Sk, Dk), (B, Sv, Dv); mask: (B, 1, Sk) or (B, Sq, Sk) '''
         p = self.dout_p if self.training else 0.0
-        if ops.KV_CACHE is not None and not torch.is_grad_enabled() and K is V and K is not Q and ops.USE_PLANE_GEMM:
+        pol = ops.policy_of(self)         # operand formats of this module's sites (set by the enclosing encoder / decoder layer)
+        kv_cache = ops.context().kv_cache
+        if kv_cache is not None and not torch.is_grad_enabled() and K is V and K is not Q:
             # greedy decoding: the key / value projections of the encoder memory are computed once per decode (bmt_amd.decode)
             return ops.mha_infer(Q, K, mask, self.linear_Q2d.weight, self.linear_Q2d.bias, self.linear_K2d.weight, self.linear_K2d.bias,
                                  self.linear_V2d.weight, self.linear_V2d.bias, self.linear_d2Q.weight, self.linear_d2Q.bias,
-                                 self.H, ops.KV_CACHE, id(self))
+                                 self.H, kv_cache, id(self), pol)
         args = (Q, K, V, mask,
                 self.linear_Q2d.weight, self.linear_Q2d.bias,
                 self.linear_K2d.weight, self.linear_K2d.bias,
                 self.linear_V2d.weight, self.linear_V2d.bias,
                 self.linear_d2Q.weight, self.linear_d2Q.bias,
-                self.H, p, self._site)
-        if not ops.USE_PLANE_GEMM:
-            return ops.MHAFnStaged.apply(*args)
+                self.H, p, self._site, pol)
         off = ops.take_residual()        # an enclosing ResidualConnection offers x, p, site: fused into the out-projection
         if off is None:
             return ops.MHAFn.apply(*args, None, 0.0, 0)

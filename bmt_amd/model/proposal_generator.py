@@ -1,7 +1,7 @@
 """Drop-in for the reference's model/proposal_generator.py: ProposalGenerationHead :11-47, ProposalGenerator :50-212,
 MultimodalProposalGenerator :215-387, make_targets :389-448.
 
-The Conv1d stacks run as implicit GEMMs on the MFMA kernel (bmt_conv1d: no im2col buffer, no (B,D,S) permutes),
+The Conv1d stacks run as implicit GEMMs on the MFMA plane kernel (bmt_gemm_bf16 conv modes: no im2col buffer, no (B,D,S) permutes),
 target assignment / decode / YOLO loss are the HIP kernels of csrc/proposal.hip.  state_dict keys are the
 reference's (``detection_layers_{A,V}.i.conv_layers.{0,3,6}.{weight,bias}`` with the default Sequential)."""
 import ctypes as C
@@ -10,7 +10,6 @@ import torch
 import torch.nn as nn
 
 from .. import _lib, ops
-from .._lib import EPI_BIAS, EPI_DROP_PRE, EPI_RELU, Conv1dArgs
 from ..ops import _f32c, _p, _st, lib
 from .blocks import FeatureEmbedder, Identity, PositionalEncoder, Transpose, layer_norm
 from .encoders import BiModalEncoder, Encoder
@@ -23,65 +22,12 @@ def _copy3d(src, s0, s1, s2, n0, n1, n2, out=None, accumulate=False):
     return out
 
 
-def _conv(mode, x, W, bias, y, B, S, Din, Dout, k, flags=0, drop_p=0.0, site=0, precision=None, splitk=1):
-    use_drop = drop_p > 0 and (flags & EPI_DROP_PRE)
-    a = Conv1dArgs(_p(x), _p(W), _p(bias), _p(y), B, S, Din, Dout, k, mode, flags if use_drop else flags & ~EPI_DROP_PRE,
-                   drop_p if use_drop else 0.0, _p(ops.rng_tensor()) if use_drop else None, site, None, 1.0,
-                   precision or ops.FWD_PRECISION, splitk)
-    _lib.check(lib.bmt_conv1d(C.byref(a), _st()), "bmt_conv1d")
-
-
-class ConvKFnStaged(torch.autograd.Function):
-    """ConvKFn on the fp32-staged implicit-GEMM kernel (bmt_conv1d, csrc/gemm.hip): the A/B reference for ConvKFn below."""
-
-    @staticmethod
-    def forward(ctx, x, W, b, relu, p, site):
-        xc = _f32c(x)
-        B, S, Din = xc.shape
-        Dout, _, k = W.shape
-        Wc = W.contiguous()
-        # state_dict layout [Dout][Din][k] -> tap-major [Dout][k][Din] (reduction index contiguous for the MFMA B operand)
-        Wp = _copy3d(Wc, Din * k, 1, k, Dout, k, Din)
-        y = torch.empty(B, S, Dout, device=x.device, dtype=torch.float32)
-        flags = EPI_BIAS | (EPI_RELU if relu else 0) | (EPI_DROP_PRE if p > 0 else 0)
-        _conv(0, xc, Wp, b, y, B, S, Din, Dout, k, flags, p, site)
-        ctx.save_for_backward(xc, Wc, y if (relu or p > 0) else None)
-        ctx.relu, ctx.p, ctx.site = relu, p, site
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        xc, Wc, y = ctx.saved_tensors
-        B, S, Din = xc.shape
-        Dout, _, k = Wc.shape
-        dyc = _f32c(dy)
-        if ctx.relu:
-            dz = torch.empty_like(dyc)
-            _lib.check(lib.bmt_gate(_p(dyc), _p(y), 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0, _p(dz), dyc.numel(), _st()), "bmt_gate")
-        elif ctx.p > 0:
-            dz = ops.dropout_raw(dyc, ctx.p, ctx.site)
-        else:
-            dz = dyc
-        dx = None
-        if ctx.needs_input_grad[0]:
-            Wt = _copy3d(Wc, k, 1, Din * k, Din, k, Dout)        # [Din][k][Dout]
-            dx = torch.empty(B, S, Din, device=dy.device, dtype=torch.float32)
-            _conv(1, dz, Wt, None, dx, B, S, Din, Dout, k, precision=ops.BWD_PRECISION)
-        # dWp[o][t][c] accumulated by split-K atomics, then folded back to the state_dict layout [o][c][t]
-        dWp = torch.zeros(Dout, k, Din, device=dy.device, dtype=torch.float32)
-        sk = ops._splitk_for(Dout, k * Din, B * S)
-        _conv(2, dz, xc, None, dWp, B, S, Din, Dout, k, precision=ops.BWD_PRECISION, splitk=sk)
-        dW = _copy3d(dWp, k * Din, 1, Din, Dout, Din, k)
-        db = ops.colsum(dz.view(-1, Dout))
-        return dx, dW, db, None, None, None
-
-
-def _conv_weight_planes(Wsrc, cin_pad, lo):
+def _conv_weight_planes(Wsrc, cin_pad, fmt):
     """[N][C][k]-indexed source (any strides) -> planes [N][k * cin_pad] in tap-major order (reduction index = tap * cin_pad + c)"""
     N, Cc, k = Wsrc.shape
     Wp = torch.zeros(N, k, cin_pad, device=Wsrc.device, dtype=torch.float32)
     Wp[:, :, :Cc] = Wsrc.permute(0, 2, 1)
-    return ops.make_planes(Wp.view(N, k * cin_pad), lo=lo)[0]
+    return ops.make_planes(Wp.view(N, k * cin_pad), fmt)
 
 
 def _pad128(n):
@@ -95,12 +41,12 @@ class ConvKFn(torch.autograd.Function):
     a per-stage row shift (reduction index = (tap, channel)), dW reads gradient and activation k-major with a per-tile shift."""
 
     @staticmethod
-    def _padded(x3, halo, k, lo):
+    def _padded(x3, halo, k, fmt):
         cache = getattr(x3, "_bmt_padplanes", None)
-        if cache is not None and cache[0] == halo and cache[1] >= k and (cache[2].lo is not None or not lo):
+        if cache is not None and cache[0] == halo and cache[1] >= k and cache[2].has(fmt):
             return cache[2]
         tail = 64 + k
-        pl = ops.pad_planes(x3, halo, tail, lo)
+        pl = ops.pad_planes(x3, halo, tail, fmt)
         x3._bmt_padplanes = (halo, k, pl)
         return pl
 
@@ -113,15 +59,16 @@ class ConvKFn(torch.autograd.Function):
         Dout, _, k = W.shape
         pad = k // 2
         halo = max(pad, getattr(xc, "_bmt_halo", pad))
-        x3 = ops.FWD_PRECISION == ops.PREC_BF16X3
+        prec = ops.policy_of("head").gemm
         kmax = 2 * halo + 1
-        X = ConvKFn._padded(xc, halo, kmax, x3)
+        X = ConvKFn._padded(xc, halo, kmax, ops.act_fmt(prec))
         cin = X.hi.shape[1]
-        Wp = _conv_weight_planes(W, cin, x3)                                    # [Dout][k * cin]
+        Wp = _conv_weight_planes(W, cin, ops.weight_fmt(prec))                 # [Dout][k * cin]
         off = halo - pad
-        A = ops.Planes(X.hi[off:], None if X.lo is None or not x3 else X.lo[off:], B * S, Din)
+        adv = lambda t: None if t is None else t[off:]
+        A = ops.Planes(adv(X.hi), adv(X.lo), B * S, Din, adv(X.fh))
         y = torch.empty(B * S, Dout, device=x.device, dtype=torch.float32)
-        ops.gemm_bf16(A, Wp, y, ldc=Dout, bias=b, relu=relu, drop_pre=p > 0, drop_p=p, site=site,
+        ops.gemm_bf16(A, Wp, y, ldc=Dout, bias=b, relu=relu, drop_pre=p > 0, drop_p=p, site=site, precision=prec,
                       conv={"mode": 1, "M": B * S, "cin": cin, "rows": X.rows - off, "S": S, "halo": halo})
         ctx.save_for_backward(xc, W, y if (relu or p > 0) else None)
         ctx.relu, ctx.p, ctx.site, ctx.halo = relu, p, site, halo
@@ -143,19 +90,19 @@ class ConvKFn(torch.autograd.Function):
             dz = dyc
         dz3 = dz.view(B, S, Dout)
         # gradient planes, halo-padded like the activations (zero halo rows: they add nothing to dW and give dX its padding)
-        G = ops.pad_planes(dz3, halo, 64 + 2 * halo + 1, False)
+        G = ops.pad_planes(dz3, halo, 64 + 2 * halo + 1, "bwd")
         off = halo - pad
         dx = None
         if ctx.needs_input_grad[0]:
             # dx[s] = sum_tap dz[s - tap + pad] . W[:, :, tap]  ==  forward-style convolution of dz with the taps reversed
             cout = G.hi.shape[1]
-            W2 = _conv_weight_planes(W.permute(1, 0, 2).flip(2), cout, False)   # [Din][k * cout]
+            W2 = _conv_weight_planes(W.permute(1, 0, 2).flip(2), cout, "bwd")   # [Din][k * cout]
             dx = torch.empty(B * S, Din, device=dy.device, dtype=torch.float32)
             ops.gemm_bf16(ops.Planes(G.hi[off:], None, B * S, Dout), W2, dx, ldc=Din, precision=ops.PREC_BF16,
                           conv={"mode": 1, "M": B * S, "cin": cout, "rows": G.rows - off, "S": S, "halo": halo})
             dx = dx.view(B, S, Din)
         # dW[o][tap][c] = sum_r dz[r][o] * x[r + tap - pad][c]: reduction over the padded rows, both operands k-major
-        X = ConvKFn._padded(xc, halo, 2 * halo + 1, False)
+        X = ConvKFn._padded(xc, halo, 2 * halo + 1, "bwd")
         if X.hi.shape[1] % 128 != 0:       # the dW tile (128 output columns) must stay inside one tap
             Xw = ops.Planes(torch.nn.functional.pad(X.hi, (0, _pad128(X.hi.shape[1]) - X.hi.shape[1])), None, X.rows, X.cols)
         else:

@@ -2,8 +2,11 @@
 model classes are built from.  PyTorch is plumbing here (device memory, streams, autograd
 graph); every FLOP on the path is issued by libbmt_hip.so.
 
-Precision policy (DESIGN.md "precision"): forward products run split-bf16 (BMT_PREC_BF16X3) so the
-log-probabilities stay within 1e-3 of the fp32 reference; backward products run single-pass bf16.
+Precision policy (DESIGN.md "precision", tests/study_precision_policy.py): every forward product names the MFMA operand
+format of its site -- the encoder's GEMMs and the decoder's memory K/V projections run A(fp16) x W(fp16 hi + lo), two passes;
+every attention core runs single-pass fp16; the decoder's own small GEMMs, the bridge and the generator run split-bf16 (three
+passes) -- chosen so that the log-probabilities stay within 1e-3 of the fp32 reference with >= 2x margin.  Backward products
+run single-pass bf16.
 """
 from __future__ import annotations
 
@@ -16,45 +19,85 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROP_POST, EPI_DROP_PRE, EPI_GATE, EPI_RELU, EPI_RESIDUAL, PREC_BF16,
-                   PREC_BF16X3, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, GemmArgs, GemmBf16Args)
+                   PREC_BF16X3, PREC_F16, PREC_F16W2, AttnBwdArgs, AttnBwdBf16Args, AttnFwdArgs, AttnFwdBf16Args, GemmBf16Args)
 
 lib = _lib.load()
 
-# ----------------------------------------------------------------------------- global knobs
-FWD_PRECISION = PREC_BF16X3
+# ----------------------------------------------------------------------------- precision policy
 BWD_PRECISION = PREC_BF16
-
-
-ATTN_PRECISION = PREC_BF16X3
-
-
-def set_precision(fwd: int = PREC_BF16X3, bwd: int = PREC_BF16):
-    global FWD_PRECISION, BWD_PRECISION, ATTN_PRECISION
-    FWD_PRECISION, BWD_PRECISION, ATTN_PRECISION = fwd, bwd, fwd
+_PREC = {PREC_BF16: ("bf16", 1, (2.0, 2.0)), PREC_BF16X3: ("bf16x3", 3, (4.0, 4.0)),
+         PREC_F16: ("fp16", 1, (2.0, 2.0)), PREC_F16W2: ("fp16 x (fp16 hi+lo)", 2, (2.0, 4.0))}
 
 
 def prec_name(prec: int) -> str:
-    return {PREC_BF16: "bf16", PREC_BF16X3: "bf16x3"}[prec]
+    return _PREC[prec][0]
 
 
 def prec_passes(prec: int) -> int:
     """MFMA passes issued per algorithmic product"""
-    return {PREC_BF16: 1, PREC_BF16X3: 3}[prec]
+    return _PREC[prec][1]
 
 
 def prec_operand_bytes(prec: int):
     """(A, B) operand plane bytes per element read by a product of this precision"""
-    return {PREC_BF16: (2.0, 2.0), PREC_BF16X3: (4.0, 4.0)}[prec]
+    return _PREC[prec][2]
+
+
+class Policy:
+    """forward operand formats of one module family: ``gemm`` for its projections / FFN, ``kv_gemm`` for the key / value projections
+    of a CROSS-attention (their input is the long encoder memory), ``attn`` for the attention core"""
+    __slots__ = ("gemm", "kv_gemm", "attn", "name")
+
+    def __init__(self, gemm, kv_gemm, attn, name):
+        self.gemm, self.kv_gemm, self.attn, self.name = gemm, kv_gemm, attn, name
+
+
+# max |d log-prob| vs the fp32 reference on the mid fixture with this table: 3.4e-4 (CPU emulation, tests/study_precision_policy.py)
+POLICIES = {
+    "enc": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc"),       # bi-modal encoder layers (89 % of the FLOPs)
+    "dec": Policy(PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),      # bi-modal decoder layers
+    "head": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "head"),     # Conv1d stacks of the proposal heads
+    None: Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
+}
+_OVERRIDE = [None]      # a Policy applied to EVERY site (A/B measurements, tests), or None
+
+
+def set_precision(fwd: Optional[int] = None, bwd: int = PREC_BF16):
+    """fwd = None: the per-site policy table (default).  fwd = PREC_*: that format at every forward site (PREC_F16W2 for GEMMs
+    implies PREC_F16 attention cores)."""
+    global BWD_PRECISION
+    BWD_PRECISION = bwd
+    if fwd is None:
+        _OVERRIDE[0] = None
+    else:
+        attn = PREC_F16 if fwd == PREC_F16W2 else fwd
+        _OVERRIDE[0] = Policy(fwd, fwd, attn, prec_name(fwd))
+
+
+def policy_of(module_or_tag) -> Policy:
+    if _OVERRIDE[0] is not None:
+        return _OVERRIDE[0]
+    tag = module_or_tag if (module_or_tag is None or isinstance(module_or_tag, str)) else getattr(module_or_tag, "bmt_policy", None)
+    return POLICIES[tag]
+
+
+def tag_policy(module: torch.nn.Module, tag: Optional[str]):
+    """mark a module tree (an encoder / decoder layer) with the policy its sites run under"""
+    for m in module.modules():
+        m.bmt_policy = tag
+    return module
 
 
 def precision_description() -> str:
-    return (f"forward GEMMs {prec_name(FWD_PRECISION)}, attention forward {prec_name(ATTN_PRECISION)}, backward "
-            f"{prec_name(BWD_PRECISION)} MFMA operands; fp32 accumulate, softmax, LayerNorm, loss, Adam")
+    if _OVERRIDE[0] is not None:
+        o = _OVERRIDE[0]
+        return f"every forward GEMM {prec_name(o.gemm)}, attention forward {prec_name(o.attn)}, backward {prec_name(BWD_PRECISION)} MFMA operands; fp32 accumulate"
+    e, d, x = POLICIES["enc"], POLICIES["dec"], POLICIES[None]
+    return (f"MFMA operands per site: encoder GEMMs + decoder memory K/V projections {prec_name(e.gemm)} (2 passes), attention forward "
+            f"{prec_name(e.attn)} (1 pass), decoder GEMMs / bridge / generator {prec_name(x.gemm)} (3 passes), backward {prec_name(BWD_PRECISION)} "
+            "(1 pass); fp32 accumulate, softmax, LayerNorm, loss, Adam")
 
 
-# GEMM path: True = operands pre-split into bf16 planes once per tensor (csrc/gemm_bf16.hip); False = the fp32-operand
-# kernel that converts while staging (csrc/gemm.hip).  Same arithmetic, same results to rounding; kept switchable for A/B.
-USE_PLANE_GEMM = True
 WEIGHT_EPOCH = [0]      # bumped by the optimizer: invalidates cached weight planes
 
 
@@ -79,6 +122,33 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+class StepContext:
+    """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
+    threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
+    autograd's backward threads, which run a node on the stream its forward ran on."""
+    __slots__ = ("defer_dw", "pending_dw", "res_offer", "last_ln", "kv_cache")
+
+    def __init__(self):
+        self.defer_dw = False        # queue the weight-gradient products of this backward pass for one grouped launch (flush_dw)
+        self.pending_dw = []
+        self.res_offer = None        # residual offered by a ResidualConnection to its sublayer's last GEMM
+        self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
+        self.kv_cache = None         # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory, k planes, v planes)
+
+
+_contexts = {}
+_contexts_lock = __import__("threading").Lock()
+
+
+def context() -> StepContext:
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    c = _contexts.get(key)
+    if c is None:
+        with _contexts_lock:
+            c = _contexts.setdefault(key, StepContext())
+    return c
 
 
 _rng_state = {}
@@ -110,32 +180,6 @@ def new_site() -> int:
 
 
 # ----------------------------------------------------------------------------- raw launches
-def gemm(A, B, C_out, M, N, K, *, lda, ldb, ldc, a_kc=True, b_kc=True, alpha=1.0, bias=None, relu=False,
-         drop_pre=False, drop_post=False, drop_p=0.0, site=0, residual=None, ldr=0, gate=None, ldg=0, gate_scale=1.0,
-         accum=False, splitk=1, precision=None, C_hi=None, C_lo=None, ldp=0):
-    flags = 0
-    if bias is not None:
-        flags |= EPI_BIAS
-    if relu:
-        flags |= EPI_RELU
-    use_drop = drop_p > 0.0 and (drop_pre or drop_post)
-    if use_drop and drop_pre:
-        flags |= EPI_DROP_PRE
-    if use_drop and drop_post:
-        flags |= EPI_DROP_POST
-    if residual is not None:
-        flags |= EPI_RESIDUAL
-    if gate is not None:
-        flags |= EPI_GATE
-    if accum:
-        flags |= EPI_ACCUM
-    a = GemmArgs(_p(A), lda, int(a_kc), _p(B), ldb, int(b_kc), _p(C_out), ldc, M, N, K, alpha, flags, _p(bias),
-                 _p(residual), ldr, _p(gate), ldg, gate_scale, drop_p if use_drop else 0.0,
-                 _p(rng_tensor()) if use_drop else None, site, precision or FWD_PRECISION, splitk,
-                 _p(C_hi), _p(C_lo), ldp)
-    _lib.check(lib.bmt_gemm(C.byref(a), _st()), "bmt_gemm")
-
-
 _SPLITK_TARGET = int(_os.environ.get("BMT_SPLITK_TARGET", "512"))     # workgroups a split launch aims for (A/B experiments)
 
 
@@ -151,135 +195,153 @@ def _pad64(n: int) -> int:
 
 
 class Planes:
-    """bf16 operand planes of an fp32 [rows, cols] tensor: hi = bf16(x), lo = bf16(x - hi) (optional), row stride padded
-    to a multiple of 64 with zeros (the reduction extent of the consuming GEMM)."""
-    __slots__ = ("hi", "lo", "rows", "cols")
+    """16-bit operand planes of an fp32 [rows, cols] tensor, row stride padded to a multiple of 64 with zeros (the reduction
+    extent of the consuming GEMM); any subset of
+        hi = bf16(x)          every backward product, and the first plane of a split-bf16 forward operand
+        lo = bf16(x - hi)     split-bf16 forward operand (PREC_BF16X3)
+        fh = fp16(x)          fp16 forward operand (PREC_F16 / PREC_F16W2)
+        fl = fp16(x - fh)     weights of a PREC_F16W2 product"""
+    __slots__ = ("hi", "lo", "fh", "fl", "rows", "cols")
 
-    def __init__(self, hi, lo, rows, cols):
-        self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
+    def __init__(self, hi, lo, rows, cols, fh=None, fl=None):
+        self.hi, self.lo, self.fh, self.fl, self.rows, self.cols = hi, lo, fh, fl, rows, cols
+
+    @property
+    def any(self):
+        return self.hi if self.hi is not None else self.fh
+
+    def has(self, fmt: str) -> bool:
+        return all(getattr(self, n) is not None for n in _FMT[fmt])
+
+    def only(self, *names):
+        """a view holding just the named planes (what a backward pass keeps alive)"""
+        return Planes(*(getattr(self, n) if n in names else None for n in ("hi", "lo")), self.rows, self.cols,
+                      *(getattr(self, n) if n in names else None for n in ("fh", "fl")))
 
 
-def make_planes(x2: torch.Tensor, lo: bool = True, straight: bool = True, transposed: bool = False, colsum=None, drop=None):
-    """one pass over fp32 x2 [R,C]: -> Planes [R][pad64(C)] (hi[,lo]) and/or transposed hi plane [C][pad64(R)];
-    colsum (optional fp32 [C]) += column sums of x2 (atomic).  drop = (p, site): the planes (and column sums) are those of
-    dropout(x2) with the mask of that site over a contiguous [R][C] tensor."""
+# plane sets by consumer: "bwd" single-pass bf16; "x3" split-bf16 activation / weight; "f16" fp16 activation (+ bf16 for the
+# backward); "w2" weight of a PREC_F16W2 product (+ bf16 for the k-major dX GEMM)
+_FMT = {"bwd": ("hi",), "x3": ("hi", "lo"), "f16": ("hi", "fh"), "w2": ("hi", "fh", "fl"), "f16only": ("fh",)}
+
+
+def act_fmt(prec: int) -> str:
+    """plane set an ACTIVATION needs to be the A operand of a forward product of this precision (and of the backward's dW)"""
+    return {PREC_BF16: "bwd", PREC_BF16X3: "x3", PREC_F16: "f16", PREC_F16W2: "f16"}[prec]
+
+
+def weight_fmt(prec: int) -> str:
+    return {PREC_BF16: "bwd", PREC_BF16X3: "x3", PREC_F16: "f16", PREC_F16W2: "w2"}[prec]
+
+
+def _alloc_planes(rows: int, cols: int, fmt: str, device, ld: Optional[int] = None, zero_pad: bool = False) -> Planes:
+    ld = _pad64(cols) if ld is None else ld
+    mk = torch.zeros if (zero_pad and ld != cols) else torch.empty
+    bufs = {n: mk(rows, ld, device=device, dtype=torch.bfloat16 if n in ("hi", "lo") else torch.float16) for n in _FMT[fmt]}
+    return Planes(bufs.get("hi"), bufs.get("lo"), rows, cols, bufs.get("fh"), bufs.get("fl"))
+
+
+def make_planes(x2: torch.Tensor, fmt: str = "x3", colsum=None, drop=None) -> Planes:
+    """one pass over fp32 x2 [R,C] -> Planes [R][pad64(C)] of the given set; colsum (optional fp32 [C]) += column sums of x2
+    (atomic).  drop = (p, site): the planes (and column sums) are those of dropout(x2) with the mask of that site over a
+    contiguous [R][C] tensor."""
     R, Cc = x2.shape
-    hi = lo_ = hiT = None
-    if straight:
-        hi = torch.empty(R, _pad64(Cc), device=x2.device, dtype=torch.bfloat16)
-        lo_ = torch.empty(R, _pad64(Cc), device=x2.device, dtype=torch.bfloat16) if lo else None
-    if transposed:
-        hiT = torch.empty(Cc, _pad64(R), device=x2.device, dtype=torch.bfloat16)
+    pl = _alloc_planes(R, Cc, fmt, x2.device)
+    ld = pl.any.stride(0)
     if drop is not None and drop[0] > 0.0:
-        _lib.check(lib.bmt_planes_dropout(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _p(colsum),
+        _lib.check(lib.bmt_planes_dropout(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, None, None, 0, _p(colsum),
                                           drop[0], _p(rng_tensor()), drop[1], _st()), "bmt_planes_dropout")
     else:
-        _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(hi), _p(lo_), _pad64(Cc), _p(hiT), None, _pad64(R), _p(colsum), _st()),
+        _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, None, None, 0, _p(colsum), _st()),
                    "bmt_planes")
-    return (Planes(hi, lo_, R, Cc) if straight else None), (Planes(hiT, None, Cc, R) if transposed else None)
+    return pl
 
 
-def pad_planes(x3: torch.Tensor, halo: int, tail: int, lo: bool) -> Planes:
-    """x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][pad64(C)] (bmt_pad_planes): the activation operand of the
-    implicit Conv1d GEMMs.  rows / cols of the returned Planes describe the whole padded buffer."""
+def pad_planes(x3: torch.Tensor, halo: int, tail: int, fmt: str) -> Planes:
+    """x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][pad64(C)] (bmt_pad_planes) of the set "bwd" / "x3" / "f16": the
+    activation operand of the implicit Conv1d GEMMs.  rows / cols of the returned Planes describe the whole padded buffer."""
     B, S, Cc = x3.shape
     rows = B * (S + 2 * halo) + tail
-    hi = torch.empty(rows, _pad64(Cc), device=x3.device, dtype=torch.bfloat16)
-    lo_ = torch.empty(rows, _pad64(Cc), device=x3.device, dtype=torch.bfloat16) if lo else None
-    _lib.check(lib.bmt_pad_planes(_p(x3), B, S, Cc, halo, tail, _p(hi), _p(lo_), hi.stride(0), _st()), "bmt_pad_planes")
-    return Planes(hi, lo_, rows, Cc)
-
-
-def transpose_plane(pl: Planes) -> Planes:
-    """hi plane [R][.] -> transposed hi plane [C][pad64(R)]"""
-    dst = torch.empty(pl.cols, _pad64(pl.rows), device=pl.hi.device, dtype=torch.bfloat16)
-    _lib.check(lib.bmt_transpose_bf16(_p(pl.hi), pl.hi.stride(0), pl.rows, pl.cols, _p(dst), dst.stride(0), _st()), "bmt_transpose_bf16")
-    return Planes(dst, None, pl.cols, pl.rows)
+    pl = _alloc_planes(rows, Cc, fmt, x3.device)
+    second = pl.lo if pl.lo is not None else pl.fh
+    _lib.check(lib.bmt_pad_planes(_p(x3), B, S, Cc, halo, tail, _p(pl.hi), _p(second), int(pl.fh is not None), pl.hi.stride(0), _st()),
+               "bmt_pad_planes")
+    return pl
 
 
 class _WeightPlanes:
-    """bf16 operand planes of every weight that takes part in a GEMM: [N][pad64(K)] hi+lo (forward operand) and the
-    transposed hi plane [K][pad64(N)] (dX operand), in persistent buffers, ALL refreshed by one multi-tensor launch the
-    first time a weight is needed after the optimizer moved them (WEIGHT_EPOCH) -- instead of ~200 small launches."""
+    """operand planes of every weight that takes part in a GEMM ([N][pad64(K)], the plane set its site's precision needs), in
+    persistent buffers, ALL refreshed by one multi-tensor launch the first time a weight is needed after the optimizer moved
+    them (WEIGHT_EPOCH) -- instead of ~200 small launches.  The backward GEMMs read the bf16 hi plane k-major, so no transposed
+    copy of a weight exists."""
 
     def __init__(self):
-        self.entries = []          # [weakref(W), key, Planes straight, Planes transposed, version]
+        self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W]
         self.index = {}            # (id(owner), key) -> position
         self.table = None          # device descriptor table
         self.fresh_epoch = -1
         self.dirty_table = True
-        self.groups = {}           # (id(owner), ...) -> [weakrefs, Planes straight [sum N][Kpad], Planes transposed [K][sum N], bias, bias refs, epoch]
+        self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt]
 
     @staticmethod
     def _key(W):
         return (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
 
-    def _register(self, W):
-        import weakref
-        N, K = W.shape
-        dev = W.device
-        st = Planes(torch.empty(N, _pad64(K), device=dev, dtype=torch.bfloat16),
-                    torch.empty(N, _pad64(K), device=dev, dtype=torch.bfloat16), N, K)
-        tr = None if _kmajor() else Planes(torch.empty(K, _pad64(N), device=dev, dtype=torch.bfloat16), None, K, N)
-        owner = W._base if W._base is not None else W
-        self.entries.append([weakref.ref(owner), self._key(W), st, tr, None, W.detach()])
-        self.index[(id(owner), self._key(W))] = len(self.entries) - 1
-        self.dirty_table = True
-        return self.entries[-1]
-
-    def _put(self, W, st, tr):
+    def _put(self, W, pl, fmt):
         import weakref
         owner = W._base if W._base is not None else W
-        entry = [weakref.ref(owner), self._key(W), st, tr, None, W.detach()]
+        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach()]
         pos = self.index.get((id(owner), self._key(W)))
         if pos is not None and pos < len(self.entries) and self.entries[pos][0]() is owner:
-            self.entries[pos] = entry          # re-registered (now as a member of a group): same slot, new buffers
+            self.entries[pos] = entry          # re-registered (a new plane set, or now as a member of a group): same slot
         else:
             self.entries.append(entry)
             self.index[(id(owner), self._key(W))] = len(self.entries) - 1
         self.dirty_table = True
         return entry
 
-    def get_group(self, Ws, bs):
+    def _entry(self, W):
+        owner = W._base if W._base is not None else W
+        pos = self.index.get((id(owner), self._key(W)))
+        e = self.entries[pos] if pos is not None and pos < len(self.entries) else None
+        return e if (e is not None and e[0]() is owner) else None
+
+    def get_group(self, Ws, bs, fmt):
         """weights that multiply the SAME input (Q/K/V of a self-attention, K/V of a cross-attention) as ONE operand: their
-        planes live in adjacent row blocks of one buffer ([sum N][Kpad] straight, [K][sum N] transposed), refreshed by the same
-        multi-tensor launch, so the three projections are one GEMM forward, one dX GEMM and (with adjacent gradients) one dW
-        GEMM.  Returns (straight Planes, transposed Planes, concatenated bias) or None if the shapes do not allow it."""
+        planes live in adjacent row blocks of one buffer ([sum N][Kpad]), refreshed by the same multi-tensor launch, so the
+        three projections are one GEMM forward, one dX GEMM and (with adjacent gradients) one dW GEMM.  Returns (Planes,
+        concatenated bias) or None if the shapes do not allow it."""
         import weakref
         K = Ws[0].shape[1]
         if any(W.shape[1] != K or W.shape[0] % 64 != 0 or W.dim() != 2 or not W.is_contiguous() for W in Ws):
             return None
         key = tuple(id(W) for W in Ws)
         g = self.groups.get(key)
-        if g is None or any(r() is not W for r, W in zip(g[0], Ws)):
+        if g is None or any(r() is not W for r, W in zip(g[0], Ws)) or not g[1].has(fmt):
             Nt = sum(W.shape[0] for W in Ws)
-            dev = Ws[0].device
-            big_hi = torch.empty(Nt, _pad64(K), device=dev, dtype=torch.bfloat16)
-            big_lo = torch.empty(Nt, _pad64(K), device=dev, dtype=torch.bfloat16)
-            bigT = None if _kmajor() else torch.empty(K, Nt, device=dev, dtype=torch.bfloat16)
+            if g is not None and g[1].any.shape[0] == Nt and all(r() is W for r, W in zip(g[0], Ws)):
+                fmt = _merge_fmt(fmt, g[4])
+            big = _alloc_planes(Nt, K, fmt, Ws[0].device)
             off = 0
             for W in Ws:
                 N = W.shape[0]
-                self._put(W, Planes(big_hi[off:off + N], big_lo[off:off + N], N, K),
-                          None if bigT is None else Planes(bigT[:, off:off + N], None, K, N))
+                sl = lambda t: None if t is None else t[off:off + N]
+                self._put(W, Planes(sl(big.hi), sl(big.lo), N, K, sl(big.fh), sl(big.fl)), fmt)
                 off += N
-            bias = torch.empty(Nt, device=dev, dtype=torch.float32) if all(b is not None for b in bs) else None
-            g = [[weakref.ref(W) for W in Ws], Planes(big_hi, big_lo, Nt, K), None if bigT is None else Planes(bigT, None, K, Nt), bias, -1]
+            bias = torch.empty(Nt, device=Ws[0].device, dtype=torch.float32) if all(b is not None for b in bs) else None
+            g = [[weakref.ref(W) for W in Ws], big, bias, -1, fmt]
             self.groups[key] = g
             if len(self.groups) > 4096:     # models come and go in tests
                 self.groups = {k: v for k, v in self.groups.items() if all(r() is not None for r in v[0])}
         stale = self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table
         if not stale:
             for W in Ws:
-                owner = W._base if W._base is not None else W
-                e = self.entries[self.index[(id(owner), self._key(W))]]
-                stale = stale or e[4] != W._version
+                stale = stale or self._entry(W)[4] != W._version
         if stale:
             self._refresh_all()
-        if g[3] is not None and g[4] != WEIGHT_EPOCH[0] and all(b is not None for b in bs):
-            torch.cat([b.detach() for b in bs], out=g[3])
-            g[4] = WEIGHT_EPOCH[0]
-        return g[1], g[2], g[3]
+        if g[2] is not None and g[3] != WEIGHT_EPOCH[0] and all(b is not None for b in bs):
+            torch.cat([b.detach() for b in bs], out=g[2])
+            g[3] = WEIGHT_EPOCH[0]
+        return g[1], g[2]
 
     def _prune(self):
         alive = [e for e in self.entries if e[0]() is not None]
@@ -296,10 +358,9 @@ class _WeightPlanes:
             nb = lib.bmt_planes_desc_bytes()
             host = torch.zeros(len(self.entries), nb, dtype=torch.uint8)
             for i, e in enumerate(self.entries):
-                Wd, st, tr = e[5], e[2], e[3]
+                Wd, pl = e[5], e[2]
                 _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
-                                               _p(st.hi), _p(st.lo), st.hi.stride(0), _p(tr.hi) if tr is not None else None, None,
-                                               tr.hi.stride(0) if tr is not None else 0),
+                                               _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0), None, None, 0),
                            "bmt_planes_desc")
             self.table = host.to(self.entries[0][5].device)
             self.dirty_table = False
@@ -308,30 +369,42 @@ class _WeightPlanes:
             e[4] = e[5]._version
         self.fresh_epoch = WEIGHT_EPOCH[0]
 
-    def get(self, W, transposed):
-        owner = W._base if W._base is not None else W
-        pos = self.index.get((id(owner), self._key(W)))
-        e = self.entries[pos] if pos is not None and pos < len(self.entries) else None
-        if e is None or e[0]() is not owner:
-            e = self._register(W)
+    def get(self, W, fmt):
+        e = self._entry(W)
+        if e is None or not e[2].has(fmt):
+            if e is not None and e[2].any._base is not None:
+                raise RuntimeError(f"weight planes: a member of a fused projection group (planes {e[3]}) was asked for '{fmt}' on its own; "
+                                   "request the group with that format instead")
+            want = fmt if e is None else _merge_fmt(fmt, e[3])
+            N, K = W.shape
+            e = self._put(W, _alloc_planes(N, K, want, W.device), want)
         if self.fresh_epoch != WEIGHT_EPOCH[0] or e[4] != W._version or self.dirty_table:
             self._refresh_all()
-        return e[3] if transposed else e[2]
+        return e[2]
 
 
+def _merge_fmt(a: str, b: str) -> str:
+    """the smallest plane set that serves both (a weight used under two policies keeps every plane either needs)"""
+    names = set(_FMT[a]) | set(_FMT[b])
+    for f in ("bwd", "x3", "f16", "w2"):
+        if names <= set(_FMT[f]):
+            return f
+    return "all"
+
+
+_FMT["all"] = ("hi", "lo", "fh", "fl")
 _weights = _WeightPlanes()
 
 
-def weight_planes(W: torch.Tensor, transposed: bool = False) -> Planes:
-    return _weights.get(W, transposed)
+def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:
+    return _weights.get(W, fmt)
 
 
-import os as _os
 FUSE_PROJECTIONS = _os.environ.get("BMT_NO_FUSE") != "1"      # Q/K/V (self-attention) and K/V (cross-attention) projections as one GEMM each way
 
 
-def weight_group(Ws, bs):
-    return _weights.get_group(tuple(Ws), tuple(bs)) if (FUSE_PROJECTIONS and USE_PLANE_GEMM) else None
+def weight_group(Ws, bs, fmt: str = "x3"):
+    return _weights.get_group(tuple(Ws), tuple(bs), fmt) if FUSE_PROJECTIONS else None
 
 
 def group_static_grad(Ws):
@@ -354,10 +427,13 @@ def fused_weight_groups(model):
     return out
 
 
-def as_planes(x, need_lo: bool) -> Planes:
+def as_planes(x, fmt: str) -> Planes:
+    """x: an fp32 [R,C] tensor or Planes; converts (one pass) unless the planes the consumer needs are already there"""
     if isinstance(x, Planes):
+        if not x.has(fmt):
+            raise RuntimeError(f"operand planes {[n for n in ('hi', 'lo', 'fh', 'fl') if getattr(x, n) is not None]} do not serve a '{fmt}' consumer")
         return x
-    return make_planes(x, lo=need_lo)[0]
+    return make_planes(x, fmt)
 
 
 _SPLITK_WS = {}          # device index -> fp32 scratch; one compute stream per device
@@ -374,36 +450,50 @@ def splitk_workspace(device):
     return ws
 
 
-KMAJOR = _os.environ.get("BMT_NO_KMAJOR") != "1"   # backward GEMMs read operands k-major (no transposed planes)
 AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
 DW_ATOMIC = _os.environ.get("BMT_DW_ATOMIC") == "1"     # A/B: weight gradients accumulate with fp32 atomics instead of workspace + epilogue
-TWO_PASS_SPLITK = True   # split-K through the workspace + epilogue kernel (False: atomic accumulation, weight gradients only)
 
 
-def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
-              drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None, precision=None,
+def _operands(A: Planes, B: Planes, prec: int):
+    """(A_hi, A_lo, B_hi, B_lo) pointers tensors of a product of this precision"""
+    if prec == PREC_BF16:
+        return A.hi, None, B.hi, None
+    if prec == PREC_BF16X3:
+        return A.hi, A.lo, B.hi, B.lo
+    if prec == PREC_F16:
+        return A.fh, None, B.fh, None
+    if prec == PREC_F16W2:
+        return A.fh, None, B.fh, B.fl
+    raise ValueError(prec)
+
+
+def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
+              drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None,
               out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False, conv=None, two_pass: bool = True,
               colsum: Optional[torch.Tensor] = None):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded).
     a_km / b_km: that operand is given K-MAJOR -- its plane has the reduction index as the row ([K rows][M or N columns]), i.e.
-    it is the transpose of what the product needs, read through the hardware transpose unit (single-pass precision only)."""
+    it is the transpose of what the product needs, read through the hardware transpose unit (single-pass bf16 only).
+    out_planes: the result as operand planes -- hi = bf16(c) and ONE of lo = bf16(c - hi) / fh = fp16(c)."""
+    ah, al, bh, bl = _operands(A, B, precision)
+    if ah is None or bh is None or (precision == PREC_BF16X3 and (al is None or bl is None)) or (precision == PREC_F16W2 and bl is None):
+        raise RuntimeError(f"gemm_bf16: operand planes missing for {prec_name(precision)}")
     M = A.cols if a_km else A.rows
     N = B.cols if b_km else B.rows
     Ktrue = 0
     if conv is not None and conv["mode"] == 1:       # implicit Conv1d forward / dX: A = halo-padded activation plane (advanced view)
-        M, Kpad = conv["M"], B.hi.shape[1]
+        M, Kpad = conv["M"], bh.shape[1]
     elif conv is not None and conv["mode"] == 2:     # implicit Conv1d dW: dY and the halo-padded activations, both k-major
         Ktrue, N = A.rows, conv["N"]
         Kpad = _pad64(Ktrue)
     elif a_km or b_km:
         Ktrue = A.rows if a_km else B.rows
         Kpad = _pad64(Ktrue)
-        assert (A.rows == Ktrue if a_km else A.hi.shape[1] == Kpad) and (B.rows == Ktrue if b_km else B.hi.shape[1] == Kpad), \
-            (A.hi.shape, A.rows, B.hi.shape, B.rows)
+        assert (A.rows == Ktrue if a_km else ah.shape[1] == Kpad) and (B.rows == Ktrue if b_km else bh.shape[1] == Kpad), \
+            (ah.shape, A.rows, bh.shape, B.rows)
     else:
-        Kpad = A.hi.shape[1]
-        assert B.hi.shape[1] == Kpad, (A.hi.shape, B.hi.shape)
-    prec = precision or FWD_PRECISION
+        Kpad = ah.shape[1]
+        assert bh.shape[1] == Kpad, (ah.shape, bh.shape)
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -420,100 +510,58 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, ldc=0, alpha=1.0, bias=None, relu=
         flags |= EPI_GATE
     if accum:
         flags |= EPI_ACCUM
-    x3 = prec == PREC_BF16X3
     op = out_planes
+    if op is not None and (op.hi is None or (op.lo is not None and op.fh is not None) or op.fl is not None):
+        raise RuntimeError("gemm_bf16: output planes are hi + (lo | fh)")
     if splitk is None:
-        splitk = 0 if (AUTO_SPLITK and TWO_PASS_SPLITK) else 1
-    a = GemmBf16Args(_p(A.hi), _p(A.lo) if x3 else None, A.hi.stride(0), _p(B.hi), _p(B.lo) if x3 else None, B.hi.stride(0),
+        splitk = 0 if AUTO_SPLITK else 1
+    a = GemmBf16Args(_p(ah), _p(al), ah.stride(0), _p(bh), _p(bl), bh.stride(0),
                      _p(C_out), ldc if C_out is not None else N, _p(op.hi) if op else None, _p(op.lo) if op else None,
                      op.hi.stride(0) if op else 0, M, N, Kpad, alpha, flags, _p(bias), _p(residual), ldr,
                      _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
-                     drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec, splitk)
+                     drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, precision, splitk)
+    a.C_f16 = _p(op.fh) if op else None
     a.a_kmajor, a.b_kmajor, a.K = int(a_km), int(b_km), Ktrue
     a.colsum = _p(colsum)        # += column sums of the (plane-only) output: the bias gradient of the Linear below a dX GEMM
     if conv is not None:
         a.N = N
         a.conv_mode, a.conv_cin, a.conv_rows = conv["mode"], conv["cin"], conv["rows"]
         a.conv_S, a.conv_halo = conv.get("S", 1), conv.get("halo", 0)
-    if splitk != 1 and TWO_PASS_SPLITK and two_pass:
-        ws = splitk_workspace(A.hi.device)
+    if splitk != 1 and two_pass:
+        ws = splitk_workspace(ah.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
     _lib.check(lib.bmt_gemm_bf16(C.byref(a), _st()), "bmt_gemm_bf16")
 
 
-def linear_fwd(x, W: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, precision=None, **epi):
+def linear_fwd(x, W: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, precision=PREC_BF16X3, **epi):
     """y[M,N] = epilogue(x[M,K] @ W[N,K]^T + b);  x: fp32 tensor or Planes."""
-    prec = precision or FWD_PRECISION
-    if not USE_PLANE_GEMM:
-        x2 = x
-        M, K = x2.shape
-        N = W.shape[0]
-        if out is None:
-            out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
-        gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=b, precision=prec, **epi)
-        return out
-    A = as_planes(x, prec == PREC_BF16X3)
-    Bw = weight_planes(W)
+    A = as_planes(x, act_fmt(precision))
+    Bw = weight_planes(W, weight_fmt(precision))
     if out is None:
         out = torch.empty(A.rows, W.shape[0], device=W.device, dtype=torch.float32)
-    if "ldg" in epi:
-        epi.pop("ldg")
-    gemm_bf16(A, Bw, out, ldc=out.stride(0), bias=b, precision=prec, **epi)
+    gemm_bf16(A, Bw, out, ldc=out.stride(0), bias=b, precision=precision, **epi)
     return out
 
 
-def linear_fwd_planes(x, W: torch.Tensor, b: Optional[torch.Tensor], want_lo: bool = True, pad: bool = False, **epi) -> Planes:
-    """bf16 operand planes (hi, lo) of epilogue(x @ W^T + b), written straight from the GEMM epilogue (no fp32 copy in
-    HBM).  pad=False: row stride N (attention operands); pad=True: row stride pad64(N), zero padded (GEMM operands)."""
+def linear_fwd_planes(x, W: torch.Tensor, b: Optional[torch.Tensor], precision=PREC_BF16X3, out_fmt: str = "x3", pad: bool = False, **epi) -> Planes:
+    """operand planes (hi + lo | fh, whatever the consumer's ``out_fmt`` names) of epilogue(x @ W^T + b), written straight from
+    the GEMM epilogue (no fp32 copy in HBM).  pad=False: row stride N (attention operands); pad=True: row stride pad64(N), zero
+    padded (GEMM operands)."""
     N = W.shape[0]
-    if not USE_PLANE_GEMM:
-        x2 = x
-        M, K = x2.shape
-        ld = _pad64(N) if pad else N
-        mk = torch.zeros if (pad and ld != N) else torch.empty
-        hi = mk(M, ld, device=x2.device, dtype=torch.bfloat16)
-        lo = mk(M, ld, device=x2.device, dtype=torch.bfloat16) if want_lo else None
-        gemm(x2, W, None, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=N, bias=b, C_hi=hi, C_lo=lo, ldp=ld, **epi)
-        return Planes(hi, lo, M, N)
-    A = as_planes(x, FWD_PRECISION == PREC_BF16X3)
-    ld = _pad64(N) if pad else N
-    hi = torch.empty(A.rows, ld, device=W.device, dtype=torch.bfloat16)
-    lo = torch.empty(A.rows, ld, device=W.device, dtype=torch.bfloat16) if want_lo else None
-    op = Planes(hi, lo, A.rows, N)
-    gemm_bf16(A, weight_planes(W), None, bias=b, out_planes=op, **epi)
+    A = as_planes(x, act_fmt(precision))
+    op = _alloc_planes(A.rows, N, out_fmt, W.device, ld=_pad64(N) if pad else N)
+    gemm_bf16(A, weight_planes(W, weight_fmt(precision)), None, bias=b, out_planes=op, precision=precision, **epi)
     return op
 
 
-def _kmajor() -> bool:
-    return KMAJOR and USE_PLANE_GEMM and BWD_PRECISION == PREC_BF16
-
-
 def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
-    """dx[M,K] = dy[M,N] @ W[N,K]   (reduction over N);  dy: fp32 tensor or Planes (hi)."""
-    if not USE_PLANE_GEMM:
-        dy2 = dy
-        M, N = dy2.shape
-        K = W.shape[1]
-        if out is None:
-            out = torch.empty(M, K, device=dy2.device, dtype=torch.float32)
-        gate = epi.pop("gate", None)
-        if gate is not None:
-            raise RuntimeError("plane gate needs USE_PLANE_GEMM")
-        gemm(dy2, W, out, M, K, N, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), a_kc=True, b_kc=False,
-             precision=BWD_PRECISION, **epi)
-        return out
-    A = as_planes(dy, BWD_PRECISION == PREC_BF16X3)
+    """dx[M,K] = dy[M,N] @ W[N,K]   (reduction over N);  dy: fp32 tensor or Planes (hi).  The weight's bf16 plane [N][K] is read
+    as stored, k-major: its row IS the reduction index."""
+    A = as_planes(dy, "bwd")
     if out is None and epi.get("out_planes") is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
-    if "ldg" in epi:
-        epi.pop("ldg")
-    if _kmajor():       # the weight plane [N][K] as stored: its row IS the reduction index
-        gemm_bf16(A, weight_planes(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
-        return out if out is not None else epi["out_planes"]
-    else:
-        Wt = weight_planes(W, transposed=True)          # [K][pad64(N)]
-        gemm_bf16(A, Wt, out, ldc=out.stride(0), precision=BWD_PRECISION, **epi)
-    return out
+    gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
+    return out if out is not None else epi["out_planes"]
 
 
 # ---- deferred weight gradients: one grouped launch for every dW of a backward pass
@@ -522,11 +570,7 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
 # queues them (DEFER_DW) and ``flush_dw`` issues ONE launch over all of them.  Alone a 1024 x 1024 weight is 64 tiles -- the single
 # launches split their reductions 8 ways and pay an epilogue kernel and the workspace traffic for it; together the step's ~50
 # weight gradients are ~3000 tiles and every reduction runs unsplit.
-DEFER_DW = False
 GROUPED_DW = _os.environ.get("BMT_NO_GROUPED_DW") != "1"
-_pending_dw = []
-
-
 _dw_ws = {}
 
 
@@ -544,17 +588,17 @@ def gemm_bf16_grouped(items):
         a.a_kmajor, a.b_kmajor = 1, 1
     dev = items[0][2].device
     need = int(lib.bmt_gemm_bf16_grouped_ws_bytes(n))
-    ws = _dw_ws.get(dev)
+    ws = _dw_ws.get((dev, n))
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)     # (allocated in the eager warm-up steps, before a capture)
-        _dw_ws[dev] = ws
+        _dw_ws[(dev, n)] = ws
     _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
 
 
 def flush_dw():
     """issue the queued weight-gradient products (call after the backward pass, before anything reads the gradients)"""
-    global _pending_dw
-    items, _pending_dw = _pending_dw, []
+    ctx = context()
+    items, ctx.pending_dw = ctx.pending_dw, []
     if not items:
         return
     if len(items) == 1 or not GROUPED_DW:
@@ -565,30 +609,19 @@ def flush_dw():
     gemm_bf16_grouped(items)
 
 
-def linear_dw(dyT, xT, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """dW[N,K] = dy[M,N]^T @ x[M,K]   (reduction over M, split-K with atomic accumulation).
-    plane path: dyT = transposed hi plane of dy [N][pad64(M)], xT = transposed hi plane of x [K][pad64(M)];
-    fp32 path: dyT = dy2 [M,N], xT = x2 [M,K].   into: accumulate straight into this (live) gradient buffer."""
-    if not USE_PLANE_GEMM:
-        dy2, x2 = dyT, xT
-        M, N = dy2.shape
-        K = x2.shape[1]
-        sk = _splitk_for(N, K, M)
-        acc = into is not None or sk > 1
-        dW = into if into is not None else (torch.zeros if sk > 1 else torch.empty)(N, K, device=dy2.device, dtype=torch.float32)
-        gemm(dy2, x2, dW, N, K, M, lda=dy2.stride(0), ldb=x2.stride(0), ldc=dW.stride(0), a_kc=False, b_kc=False,
-             accum=acc, splitk=sk, precision=BWD_PRECISION)
-        return None if into is not None else dW
-    km = _kmajor()          # k-major: dyT / xT are the STRAIGHT planes dY [M][N], X [M][K] (rows = the reduction index)
-    if DEFER_DW and km and into is not None:
-        _pending_dw.append((dyT, xT, into))
+def linear_dw(dy: Planes, x: Planes, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """dW[N,K] = dy[M,N]^T @ x[M,K]: both bf16 planes as stored, k-major (their rows are the reduction index).
+    into: accumulate straight into this (live) gradient buffer."""
+    ctx = context()
+    if ctx.defer_dw and into is not None:
+        ctx.pending_dw.append((dy, x, into))
         return None
-    N, K, M = (dyT.cols, xT.cols, dyT.rows) if km else (dyT.rows, xT.rows, dyT.cols)
+    N, K, M = dy.cols, x.cols, dy.rows
     sk = _splitk_for(N, K, M)
-    atomic = sk > 1 and (not TWO_PASS_SPLITK or (DW_ATOMIC and into is not None))      # two-pass split-K has one writer per element: no zero-fill, no atomics
+    atomic = sk > 1 and DW_ATOMIC and into is not None      # two-pass split-K has one writer per element: no zero-fill, no atomics
     acc = into is not None or atomic
-    dW = into if into is not None else (torch.zeros if atomic else torch.empty)(N, K, device=dyT.hi.device, dtype=torch.float32)
-    gemm_bf16(dyT, xT, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16, a_km=km, b_km=km, two_pass=not atomic)
+    dW = into if into is not None else (torch.zeros if atomic else torch.empty)(N, K, device=dy.hi.device, dtype=torch.float32)
+    gemm_bf16(dy, x, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16, a_km=True, b_km=True, two_pass=not atomic)
     return None if into is not None else dW
 
 
@@ -622,11 +655,11 @@ def grad_done(p: Optional[torch.Tensor]):
         cb(p)
 
 
-def wgrad(W, b, dyT, xT, dy2_for_bias=None, bias_sum=None):
+def wgrad(W, b, dyP: Planes, xP: Planes, dy2_for_bias=None, bias_sum=None):
     """weight and bias gradient of a Linear: returns (dW, db) tensors for autograd, or (None, None) after accumulating into
     the parameters' static buffers.  bias_sum: an already computed column sum (from grad_planes) or None."""
     gW = static_grad(W)
-    dW = linear_dw(dyT, xT, into=gW)
+    dW = linear_dw(dyP, xP, into=gW)
     if gW is not None:
         grad_done(W)
     db = None
@@ -647,62 +680,45 @@ def drop_grad(dy2: torch.Tensor, b, p: float, site: int):
     the operand conversion (grad_planes), else (dropout(dy2), None)"""
     if p <= 0.0:
         return dy2, None
-    if USE_PLANE_GEMM and (b is None or static_grad(b) is not None):
+    if b is None or static_grad(b) is not None:
         return dy2, (p, site)
     return dropout_raw(dy2, p, site), None
 
 
 def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bool = True, drop=None, **dx_epi):
-    """backward of y = x W^T + b given dy2 [M,N]: one pass builds the gradient's operand planes (+ bias column sums),
-    then dX = dY.W and dW += dY^T.X.  Returns (dx or None, dW or None, db or None); dW/db are None when they were
-    accumulated straight into the parameters' static gradient buffers."""
-    P, T, bias_done = grad_planes(dy2, b, drop=drop)
+    """backward of y = x W^T + b given dy2 [M,N]: one pass builds the gradient's operand plane (+ bias column sums),
+    then dX = dY.W and dW += dY^T.X.  x_for_dw: the layer input, fp32 or Planes with a bf16 hi plane.  Returns
+    (dx or None, dW or None, db or None); dW/db are None when they were accumulated straight into the parameters' static
+    gradient buffers."""
+    P, bias_done = grad_planes(dy2, b, drop=drop)
     assert drop is None or bias_done or b is None       # (drop_grad guarantees it: the bias sum must see the masked gradient)
     dx = linear_dx(P, W, **dx_epi) if need_dx else None
     dW = db = None
     if need_dw:
-        dW, db = wgrad(W, None if bias_done else b, T, input_t(x_for_dw) if not isinstance(x_for_dw, PlanesT) else x_for_dw.p,
-                       dy2_for_bias=dy2)
+        dW, db = wgrad(W, None if bias_done else b, P, bwd_planes(x_for_dw), dy2_for_bias=dy2)
     elif b is not None and not bias_done:
         db = colsum(dy2)
     return dx, dW, db
 
 
-class PlanesT:
-    """marker: an already transposed operand for the dW product"""
-    __slots__ = ("p",)
-
-    def __init__(self, p):
-        self.p = p
-
-
 def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=None):
-    """(operand for dX, operand for dW, bias-gradient handled?) of an upstream gradient in ONE pass over it: hi plane,
-    transposed hi plane and -- when ``bias`` has a static gradient buffer -- its column sums accumulated into that buffer.
+    """(bf16 plane of an upstream gradient -- the A operand of dX and, k-major, of dW --, bias-gradient handled?) in ONE pass
+    over it; when ``bias`` has a static gradient buffer its column sums are accumulated into that buffer by the same pass.
     drop = (p, site): the gradient first goes through that dropout site's mask (backward of ``x + dropout(y)`` w.r.t. y)."""
-    if not USE_PLANE_GEMM:
-        assert drop is None
-        return dy2, dy2, False
     gb = static_grad(bias)
-    if _kmajor():       # one plane serves dX (as A) and dW (k-major)
-        P = make_planes(dy2, lo=False, straight=True, transposed=False, colsum=gb, drop=drop)[0]
-        T = P
-    else:
-        P, T = make_planes(dy2, lo=False, straight=True, transposed=True, colsum=gb, drop=drop)
+    P = make_planes(dy2, "bwd", colsum=gb, drop=drop)
     if gb is not None:
         grad_done(bias)
-    return P, T, gb is not None
+    return P, gb is not None
 
 
-def input_t(x2):
-    """operand of x for the dW product: transposed hi plane (x2: fp32 tensor or Planes)."""
-    if not USE_PLANE_GEMM:
-        return x2
-    if _kmajor():
-        return x2 if isinstance(x2, Planes) else make_planes(x2, lo=False)[0]
-    if isinstance(x2, Planes):
-        return transpose_plane(x2)
-    return make_planes(x2, lo=False, straight=False, transposed=True)[1]
+def bwd_planes(x) -> Planes:
+    """operand of x for the dW product (its bf16 hi plane, k-major): x fp32 tensor or Planes"""
+    if isinstance(x, Planes):
+        if x.hi is None:
+            raise RuntimeError("the backward needs the bf16 plane of a saved activation")
+        return x
+    return make_planes(x, "bwd")
 
 
 def colsum(x2: torch.Tensor) -> torch.Tensor:
@@ -730,8 +746,9 @@ def _mask_args(mask: Optional[torch.Tensor], B: int, Sq: int, Sk: int):
     return mask, _p(mask), mask.stride(0), qs
 
 
-def attn_fwd(q, k, v, mask, H, drop_p=0.0, site=0, precision=None):
-    """q:(B,Sq,D) k,v:(B,Sk,D) fp32 contiguous -> o:(B,Sq,D) (post-dropout), lse:(B,H,Sq)."""
+def attn_fwd(q, k, v, mask, H, drop_p=0.0, site=0, precision=PREC_BF16X3):
+    """fp32 operands (the module-level ``attention()`` surface): q:(B,Sq,D) k,v:(B,Sk,D) contiguous -> o:(B,Sq,D) (post-dropout),
+    lse:(B,H,Sq); the kernel converts while staging."""
     B, Sq, D = q.shape
     Sk = k.shape[1]
     dk = D // H
@@ -741,8 +758,7 @@ def attn_fwd(q, k, v, mask, H, drop_p=0.0, site=0, precision=None):
     use_drop = drop_p > 0.0
     a = AttnFwdArgs(_p(q), _p(k), _p(v), _p(o), _p(lse), q.stride(1), k.stride(1), v.stride(1), o.stride(1),
                     q.stride(0), k.stride(0), v.stride(0), o.stride(0), mptr, mbs, mqs, B, H, Sq, Sk, dk,
-                    1.0 / math.sqrt(dk), drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site,
-                    precision or FWD_PRECISION)
+                    1.0 / math.sqrt(dk), drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, precision)
     _lib.check(lib.bmt_attn_fwd(C.byref(a), _st()), "bmt_attn_fwd")
     return o, lse
 
@@ -761,21 +777,21 @@ def attn_bwd(q, k, v, o, do, lse, mask, H, drop_p=0.0):
     return dq, dk_, dv
 
 
-def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision=None):
-    """planes (B,S,D) bf16 -> o (B,Sq,D) fp32 post-dropout, lse (B,H,Sq)."""
+def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision=PREC_BF16X3):
+    """raw kernel call (kernel tests): planes (B,S,D) -- bf16 hi [+ lo], or fp16 for PREC_F16 -- -> o (B,Sq,D) fp32 post-dropout,
+    lse (B,H,Sq)."""
     B, Sq, D = qh.shape
     Sk = kh.shape[1]
     dk = D // H
-    prec = precision or FWD_PRECISION
     o = torch.empty(B, Sq, D, device=qh.device, dtype=torch.float32)
     lse = torch.empty(B, H, Sq, device=qh.device, dtype=torch.float32)
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
     use_drop = drop_p > 0.0
-    x3 = prec == PREC_BF16X3
+    x3 = precision == PREC_BF16X3
     a = AttnFwdBf16Args(_p(qh), _p(ql) if x3 else None, _p(kh), _p(kl) if x3 else None, _p(vh), _p(vl) if x3 else None,
                         _p(o), _p(lse), qh.stride(1), kh.stride(1), vh.stride(1), o.stride(1),
                         qh.stride(0), kh.stride(0), vh.stride(0), o.stride(0), mptr, mbs, mqs, B, H, Sq, Sk, dk,
-                        1.0 / math.sqrt(dk), drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, prec)
+                        1.0 / math.sqrt(dk), drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, precision)
     _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
     return o, lse
 
@@ -797,67 +813,65 @@ def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, drop_p=0.0):
     return dq, dk_, dv
 
 
-def _plane_buf(rows: int, cols: int, device) -> torch.Tensor:
-    """bf16 [rows][pad64(cols)] with the pad columns zero (they are reduction padding of the consuming GEMM)"""
+def _plane_buf(rows: int, cols: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """16-bit [rows][pad64(cols)] with the pad columns zero (they are reduction padding of the consuming GEMM)"""
     ld = _pad64(cols)
-    return (torch.empty if ld == cols else torch.zeros)(rows, ld, device=device, dtype=torch.bfloat16)
+    return (torch.empty if ld == cols else torch.zeros)(rows, ld, device=device, dtype=dtype)
 
 
-def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop_p=0.0, site=0, precision=None):
-    """attention core over projection planes; the post-dropout output is written as operand planes (hi[, lo]) of the
-    out-projection -- no fp32 copy.  Returns (Planes [B*Sq][pad64(D)], lse)."""
+def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop_p=0.0, site=0, precision=PREC_BF16X3, out_fmt: str = "x3"):
+    """attention core over projection planes; the post-dropout output is written as operand planes of the out-projection
+    (``out_fmt``: "x3" = bf16 hi + lo, "f16" = bf16 hi + fp16, "bwd" = bf16 hi) -- no fp32 copy.
+    precision: PREC_BF16X3 (hi + lo planes of q / k / v), PREC_F16 (their fp16 planes) or PREC_BF16.
+    Returns (Planes [B*Sq][pad64(D)], lse)."""
     dk = D // H
-    prec = precision or FWD_PRECISION
-    x3 = prec == PREC_BF16X3
-    dev = q.hi.device
+    x3, f16 = precision == PREC_BF16X3, precision == PREC_F16
+    qa, ka, va = (q.fh, k.fh, v.fh) if f16 else (q.hi, k.hi, v.hi)
+    if qa is None or ka is None or va is None or (x3 and (q.lo is None or k.lo is None or v.lo is None)):
+        raise RuntimeError(f"attn_fwd_planes: projection planes missing for {prec_name(precision)}")
+    dev = qa.device
     oh = _plane_buf(B * Sq, D, dev)
-    ol = _plane_buf(B * Sq, D, dev) if x3 else None
+    ol = _plane_buf(B * Sq, D, dev) if out_fmt == "x3" else None
+    of = _plane_buf(B * Sq, D, dev, torch.float16) if out_fmt == "f16" else None
     lse = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
     use_drop = drop_p > 0.0
-    ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), oh.stride(0)
-    a = AttnFwdBf16Args(Qh=_p(q.hi), Ql=_p(q.lo) if x3 else None, Kh=_p(k.hi), Kl=_p(k.lo) if x3 else None,
-                        Vh=_p(v.hi), Vl=_p(v.lo) if x3 else None, O=None, lse=_p(lse),
+    ldq, ldk, ldv, ldop = qa.stride(0), ka.stride(0), va.stride(0), oh.stride(0)
+    a = AttnFwdBf16Args(Qh=_p(qa), Ql=_p(q.lo) if x3 else None, Kh=_p(ka), Kl=_p(k.lo) if x3 else None,
+                        Vh=_p(va), Vl=_p(v.lo) if x3 else None, O=None, lse=_p(lse),
                         ldq=ldq, ldk=ldk, ldv=ldv, ldo=D, bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D,
                         mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk),
-                        drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=prec,
-                        Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop)
+                        drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=precision,
+                        Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop, Of=_p(of))
     _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
-    return Planes(oh, ol, B * Sq, D), lse
+    return Planes(oh, ol, B * Sq, D, fh=of), lse
 
 
-def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
+def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
                     fuse: Optional[str] = None):
-    """attention backward with the gradients written as GEMM operands: for each of dq, dk, dv the bf16 plane (dX operand of
-    the projection), its transpose (dW operand) and the bias gradient (column sums).  biases = (bq, bk, bv): a bias with a
-    static gradient buffer is accumulated in place (returned db is None), otherwise into a fresh fp32 [D].
-    fuse = "qkv" (Sq == Sk) / "kv": the gradients share one plane [M][3D | 2D] and one transposed plane [3D | 2D][M] (column /
-    row blocks), the operands of the fused projection backward; the combined planes are returned as a 4th element.
-    Returns [(P, T, db)] * 3 (+ [(P_all, T_all)])."""
+    """attention backward (single-pass bf16 on the hi planes) with the gradients written as GEMM operands: for each of dq, dk,
+    dv the bf16 plane (the A operand of the projection's dX and, k-major, of its dW) and the bias gradient (column sums).
+    o: the saved output planes (hi + lo, or hi + fh: delta = rowsum(dO * O) reads the most precise form present).
+    biases = (bq, bk, bv): a bias with a static gradient buffer is accumulated in place (returned db is None), otherwise into a
+    fresh fp32 [D].  fuse = "qkv" (Sq == Sk) / "kv": the gradients share one plane [M][3D | 2D] (column blocks), the operand of
+    the fused projection backward; the combined plane is returned as a 4th element.
+    Returns [(P, db)] * 3 (+ [P_all])."""
     dk = D // H
     dev = q.hi.device
     Mq, Mk = B * Sq, B * Sk
     outs = []
     comb = None
-    km = _kmajor()        # k-major GEMMs take the gradient plane as it is: no transposed plane is produced
     if fuse in ("qkv", "kv") and D % 64 == 0 and (fuse == "kv" or Mq == Mk):
         n = 3 if fuse == "qkv" else 2
-        big = _plane_buf(Mk, n * D, dev)
-        bigT = None if km else _plane_buf(n * D, Mk, dev)
-        comb = (Planes(big, None, Mk, n * D), Planes(big, None, Mk, n * D) if km else Planes(bigT, None, n * D, Mk))
+        comb = Planes(_plane_buf(Mk, n * D, dev), None, Mk, n * D)
     for idx, (M, b) in enumerate(((Mq, biases[0]), (Mk, biases[1]), (Mk, biases[2]))):
         slot = None if comb is None else (idx if fuse == "qkv" else idx - 1)
-        if slot is not None and slot >= 0:
-            hi = comb[0].hi[:, slot * D:(slot + 1) * D]
-            hiT = None if km else comb[1].hi[slot * D:(slot + 1) * D]
-        else:
-            hi = _plane_buf(M, D, dev)
-            hiT = None if km else _plane_buf(D, M, dev)
+        hi = comb.hi[:, slot * D:(slot + 1) * D] if (slot is not None and slot >= 0) else _plane_buf(M, D, dev)
         gb = static_grad(b)
         db = None
         if b is not None and gb is None:
             db = torch.zeros(D, device=dev, dtype=torch.float32)
-        outs.append((hi, hiT, gb if gb is not None else db, db))
+        outs.append((hi, gb if gb is not None else db, db))
     delta = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
     if isinstance(do, Planes):       # dO already as the bf16 plane the kernels read
         assert do.hi.stride(0) == D and do.rows == Mq, (do.hi.shape, D, Mq)
@@ -866,7 +880,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor
         doh = torch.empty(B, Sq, D, device=dev, dtype=torch.bfloat16)
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
     ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), o.hi.stride(0)
-    (qh_, qT_, qb_, _), (kh_, kT_, kb_, _), (vh_, vT_, vb_, _) = outs
+    (qh_, qb_, _), (kh_, kb_, _), (vh_, vb_, _) = outs
     a = AttnBwdBf16Args(Qh=_p(q.hi), Kh=_p(k.hi), Vh=_p(v.hi), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
@@ -874,25 +888,24 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do: torch.Tensor
                         Oh=_p(o.hi), Ol=_p(o.lo), ldop=ldop, bsop=Sq * ldop,
                         dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
-                        dQT=_p(qT_), dKT=_p(kT_), dVT=_p(vT_), gqT_ld=0 if qT_ is None else qT_.stride(0), gkvT_ld=0 if kT_ is None else kT_.stride(0),
-                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_))
+                        dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
+                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh))
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
-    for (hi, hiT, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
+    for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
         if b is not None and db is None:
             grad_done(b)
-        P_ = Planes(hi, None, M, D)
-        res.append((P_, P_ if hiT is None else Planes(hiT, None, D, M), db))
+        res.append((Planes(hi, None, M, D), db))
     if comb is not None:
         res.append(comb)
     return res
 
 
-def lin_bwd_planes(P: Planes, T: Planes, W, xT: Planes, need_dx: bool = True, **dx_epi):
-    """dX = dY.W and dW += dY^T.X from ready-made operand planes of dY (the bias gradient was produced with them)."""
+def lin_bwd_planes(P: Planes, W, xP: Planes, need_dx: bool = True, **dx_epi):
+    """dX = dY.W and dW += dY^T.X from the ready-made bf16 plane of dY (the bias gradient was produced with it)."""
     dx = linear_dx(P, W, **dx_epi) if need_dx else None
     gW = static_grad(W)
-    dW = linear_dw(T, xT, into=gW)
+    dW = linear_dw(P, xP, into=gW)
     if gW is not None:
         grad_done(W)
     return dx, dW
@@ -912,8 +925,6 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
 # through a module-level slot; MultiheadedAttention / PositionwiseFeedForward take it, anything else leaves it and the
 # ResidualConnection falls back to the separate dropout_add kernel.
 FUSE_RESIDUAL = _os.environ.get("BMT_NO_FUSE_RES") != "1"
-_RES_OFFER = None
-_LAST_LN_PLANES = None
 
 
 class ResidualOffer:
@@ -924,57 +935,61 @@ class ResidualOffer:
 
 
 def offer_residual(x, p, site) -> ResidualOffer:
-    global _RES_OFFER
-    _RES_OFFER = ResidualOffer(x, p, site)
-    return _RES_OFFER
+    off = ResidualOffer(x, p, site)
+    context().res_offer = off
+    return off
 
 
 def take_residual() -> Optional[ResidualOffer]:
     """the pending offer, if any (one taker: the slot is cleared)"""
-    global _RES_OFFER
-    off, _RES_OFFER = _RES_OFFER, None
+    c = context()
+    off, c.res_offer = c.res_offer, None
     return off
 
 
-def planes_of(t, need_lo: bool):
-    """operand planes attached to an activation by its producer (ResidualNormFn), usable as a k-major dW operand too"""
+def planes_of(t, fmt: str):
+    """operand planes attached to an activation by its producer (ResidualNormFn) or by an earlier consumer, if they serve a
+    consumer of this format and the tensor has not been written since"""
     pl = getattr(t, "_bmt_planes", None)
-    if pl is None or (need_lo and pl.lo is None) or not _kmajor():
+    if pl is None or not pl.has(fmt) or getattr(t, "_bmt_planes_version", t._version) != t._version:
         return None
     return pl
 
 
+def attach_planes(t, pl: Planes):
+    if isinstance(t, torch.Tensor):
+        t._bmt_planes, t._bmt_planes_version = pl, t._version
+
+
 class ResidualNormFn(torch.autograd.Function):
     """x -> (x, LayerNorm(x)): the two branches of a ResidualConnection leave one node, so that their gradients meet again
-    in ONE kernel (dx = g_residual + LN backward(g_norm)).  The forward kernel also writes the bf16 operand planes of the
-    normalised output (``last_ln_planes()``), which is all the sublayer's first GEMM reads."""
+    in ONE kernel (dx = g_residual + LN backward(g_norm)).  The forward kernel also writes the operand planes of the
+    normalised output (bf16 hi + the second plane the sublayer's first GEMM reads: bf16 lo or fp16), which is all that GEMM
+    reads."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
-        global _LAST_LN_PLANES
+    def forward(ctx, x, gamma, beta, eps, fmt):
         note_use(gamma, beta)
         xc = _f32c(x)
         D = xc.shape[-1]
         x2 = xc.view(-1, D)
         rows = x2.shape[0]
-        x3 = FWD_PRECISION == PREC_BF16X3
         y = torch.empty_like(x2)
-        ld = _pad64(D)
-        hi = torch.empty(rows, ld, device=x.device, dtype=torch.bfloat16)
-        lo = torch.empty(rows, ld, device=x.device, dtype=torch.bfloat16) if x3 else None
+        pl = _alloc_planes(rows, D, fmt, x.device)
+        second = pl.lo if pl.lo is not None else pl.fh
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), _p(hi), _p(lo), ld,
-                                                rows, D, eps, _st()), "bmt_layernorm_fwd_planes")
+        _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), _p(pl.hi), _p(second),
+                                                int(pl.fh is not None), pl.hi.stride(0), rows, D, eps, _st()), "bmt_layernorm_fwd_planes")
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
-        _LAST_LN_PLANES = Planes(hi, lo, rows, D)
+        context().last_ln = pl
         return xc.view_as(xc), y.view(xc.shape)
 
     @staticmethod
     def backward(ctx, g_id, g_n):
         if g_n is None:
-            return g_id, None, None, None
+            return g_id, None, None, None, None
         x2, gamma, mean, rstd = ctx.saved_tensors
         rows, D = x2.shape
         dy2 = _f32c(g_n).view(rows, D)
@@ -992,15 +1007,17 @@ class ResidualNormFn(torch.autograd.Function):
         if fused:
             grad_done(gamma)
             grad_done(beta)
-            return dx, None, None, None
-        return dx, dg, db, None
+            return dx, None, None, None, None
+        return dx, dg, db, None, None
 
 
-def residual_norm(x, gamma, beta, eps):
-    """(x passed through, LayerNorm(x) carrying its operand planes as ``_bmt_planes``)"""
-    global _LAST_LN_PLANES
-    xid, xn = ResidualNormFn.apply(x, gamma, beta, eps)
-    xn._bmt_planes, _LAST_LN_PLANES = _LAST_LN_PLANES, None
+def residual_norm(x, gamma, beta, eps, prec: int = PREC_BF16X3):
+    """(x passed through, LayerNorm(x) carrying its operand planes as ``_bmt_planes``); prec: the forward precision of the
+    sublayer's first GEMM"""
+    xid, xn = ResidualNormFn.apply(x, gamma, beta, eps, act_fmt(prec))
+    c = context()
+    attach_planes(xn, c.last_ln)
+    c.last_ln = None
     return xid, xn
 
 
@@ -1087,7 +1104,8 @@ class LinearActFn(torch.autograd.Function):
         xc = _f32c(x)
         K = xc.shape[-1]
         x2 = xc.view(-1, K)
-        y = linear_fwd(x2, W, b, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"), drop_p=p, site=site)
+        y = linear_fwd(x2, W, b, precision=policy_of(None).gemm, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"),
+                       drop_p=p, site=site)
         ctx.relu, ctx.drop_mode, ctx.p, ctx.site = relu, drop_mode, p, site
         ctx.has_bias = b is not None
         ctx.params = (W, b)
@@ -1117,33 +1135,37 @@ class LinearActFn(torch.autograd.Function):
 
 class FFNFn(torch.autograd.Function):
     """fc2(dropout(relu(fc1(x))))   PositionwiseFeedForward.forward model/blocks.py:167-174.
-    The hidden activation only ever exists as bf16 operand planes (written by fc1's epilogue, read by fc2 and by the
-    backward); backward applies the relu/dropout derivative inside the dH GEMM epilogue (gate on the saved hidden)."""
+    The hidden activation only ever exists as 16-bit operand planes (written by fc1's epilogue, read by fc2 and by the
+    backward); backward applies the relu/dropout derivative inside the dH GEMM epilogue (gate on the saved hidden) and dH itself
+    only ever exists as a bf16 plane.  pol: the Policy of the enclosing layer."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p, site, res=None, res_p=0.0, res_site=0):
+    def forward(ctx, x, W1, b1, W2, b2, p, site, pol, res=None, res_p=0.0, res_site=0):
         note_use(W1, b1, W2, b2)
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
-        x3 = FWD_PRECISION == PREC_BF16X3
-        xp = planes_of(x, x3)            # LayerNorm wrote the operand planes of its output already
-        h = linear_fwd_planes(x2 if xp is None else xp, W1, b1, want_lo=x3, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
+        prec = pol.gemm
+        fmt = act_fmt(prec)
+        xp = planes_of(x, fmt)            # LayerNorm wrote the operand planes of its output already
+        if xp is None:
+            xp = make_planes(x2, fmt)
+        h = linear_fwd_planes(xp, W1, b1, precision=prec, out_fmt=fmt, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
         epi = {}
         if res is not None:              # x_res + dropout(fc2(h)) in fc2's epilogue (ResidualConnection)
             r2 = _f32c(res).view(-1, W2.shape[0])
             epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
-        y = linear_fwd(h if USE_PLANE_GEMM else _planes_to_f32(h), W2, b2, **epi)
+        y = linear_fwd(h, W2, b2, precision=prec, **epi)
         ctx.p = p
-        ctx.h = h
-        ctx.xp = None if xp is None else Planes(xp.hi, None, xp.rows, xp.cols)
+        ctx.h = h.only("hi")             # the backward reads bf16 planes only
+        ctx.xp = xp.only("hi")
         ctx.res = (res is not None, res_p, res_site)
         ctx.params = (W1, b1, W2, b2)
-        ctx.save_for_backward(x2, W1, W2)
+        ctx.save_for_backward(W1, W2)
         return y.view(*xc.shape[:-1], W2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W1, W2 = ctx.saved_tensors
+        W1, W2 = ctx.saved_tensors
         h = ctx.h
         dy2 = _f32c(dy).view(-1, W2.shape[0])
         gscale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
@@ -1152,148 +1174,131 @@ class FFNFn(torch.autograd.Function):
         drop = None
         if has_res:
             dy2, drop = drop_grad(dy2, b2p, res_p, res_site)
-        if USE_PLANE_GEMM and _kmajor() and _os.environ.get("BMT_FFN_DH_FP32") != "1":
-            # dH never exists in fp32: the fc2 dX GEMM writes its bf16 plane (relu / dropout derivative applied to whole row
-            # segments from the saved hidden plane) and its column sums -- fc1's bias gradient -- from the same epilogue
-            P2, T2, b2_done = grad_planes(dy2, b2p, drop=drop)
-            M_, Dff = h.rows, h.cols
-            gb1 = static_grad(b1p)
-            cs = gb1 if gb1 is not None else torch.zeros(Dff, device=dy2.device, dtype=torch.float32)
-            dhP = Planes(torch.empty(M_, _pad64(Dff), device=dy2.device, dtype=torch.bfloat16), None, M_, Dff)
-            linear_dx(P2, W2p, out_planes=dhP, gate=h, gate_scale=gscale, colsum=cs if b1p is not None else None)
-            dW2, db2 = wgrad(W2p, None if b2_done else b2p, T2, input_t(h), dy2_for_bias=dy2)
-            db1 = None
-            if b1p is not None:
-                if gb1 is not None:
-                    grad_done(b1p)
-                else:
-                    db1 = cs
-            dx, dW1 = lin_bwd_planes(dhP, dhP, W1p, ctx.xp if ctx.xp is not None else input_t(x2), need_dx=ctx.needs_input_grad[0])
-            if dx is not None:
-                dx = dx.view(*dy.shape[:-1], W1.shape[1])
-            return dx, dW1, db1, dW2, db2, None, None, (dy if has_res else None), None, None
-        if USE_PLANE_GEMM:
-            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, PlanesT(input_t(h)), gate=h, gate_scale=gscale, drop=drop)
-        else:
-            hf = _planes_to_f32(h)
-            dh, dW2, db2 = lin_bwd(dy2, W2p, b2p, hf)
-            tmp = torch.empty_like(dh)
-            _lib.check(lib.bmt_gate(_p(dh), _p(hf), gscale, _p(tmp), dh.numel(), _st()), "bmt_gate")
-            dh = tmp
-        dx, dW1, db1 = lin_bwd(dh, W1p, b1p, x2 if ctx.xp is None else PlanesT(ctx.xp), need_dx=ctx.needs_input_grad[0])
+        # dH never exists in fp32: the fc2 dX GEMM writes its bf16 plane (relu / dropout derivative applied to whole row
+        # segments from the saved hidden plane) and its column sums -- fc1's bias gradient -- from the same epilogue
+        P2, b2_done = grad_planes(dy2, b2p, drop=drop)
+        M_, Dff = h.rows, h.cols
+        gb1 = static_grad(b1p)
+        cs = gb1 if gb1 is not None else torch.zeros(Dff, device=dy2.device, dtype=torch.float32)
+        dhP = Planes(torch.empty(M_, _pad64(Dff), device=dy2.device, dtype=torch.bfloat16), None, M_, Dff)
+        linear_dx(P2, W2p, out_planes=dhP, gate=h, gate_scale=gscale, colsum=cs if b1p is not None else None)
+        dW2, db2 = wgrad(W2p, None if b2_done else b2p, P2, h, dy2_for_bias=dy2)
+        db1 = None
+        if b1p is not None:
+            if gb1 is not None:
+                grad_done(b1p)
+            else:
+                db1 = cs
+        dx, dW1 = lin_bwd_planes(dhP, W1p, ctx.xp, need_dx=ctx.needs_input_grad[0])
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], W1.shape[1])
-        return dx, dW1, db1, dW2, db2, None, None, (dy if has_res else None), None, None
+        return dx, dW1, db1, dW2, db2, None, None, None, (dy if has_res else None), None, None
 
 
-def _planes_to_f32(pl: Planes) -> torch.Tensor:
-    """fp32 view of planes (A/B path without the plane GEMM only)"""
-    y = pl.hi[:, :pl.cols].float()
-    if pl.lo is not None:
-        y = y + pl.lo[:, :pl.cols].float()
-    return y.contiguous()
-
-
-def project_group(Xp: Planes, Ws, bs, x3: bool):
+def project_group(Xp: Planes, Ws, bs, prec: int, out_fmt: str):
     """projections that read the same input as ONE GEMM over adjacent weight planes (q|k|v or k|v column blocks of one plane
     buffer, which the attention kernels address with the buffer's row stride); None if the weights cannot be grouped"""
-    grp = weight_group(Ws, bs)
+    grp = weight_group(Ws, bs, weight_fmt(prec))
     if grp is None:
         return None
-    gst, _, gb = grp
+    gst, gb = grp
     Nt = gst.rows
-    hi = torch.empty(Xp.rows, Nt, device=Xp.hi.device, dtype=torch.bfloat16)
-    lo = torch.empty(Xp.rows, Nt, device=Xp.hi.device, dtype=torch.bfloat16) if x3 else None
-    gemm_bf16(Xp, gst, None, bias=gb, out_planes=Planes(hi, lo, Xp.rows, Nt))
+    big = _alloc_planes(Xp.rows, Nt, out_fmt, Xp.any.device, ld=Nt)
+    gemm_bf16(Xp, gst, None, bias=gb, out_planes=big, precision=prec)
     outs, off = [], 0
     for W in Ws:
         N = W.shape[0]
-        outs.append(Planes(hi[:, off:off + N], None if lo is None else lo[:, off:off + N], Xp.rows, N))
+        sl = lambda t: None if t is None else t[:, off:off + N]
+        outs.append(Planes(sl(big.hi), sl(big.lo), Xp.rows, N, sl(big.fh), sl(big.fl)))
         off += N
     return outs
 
 
-KV_CACHE = None      # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory tensor, k planes, v planes)
+def attn_operand_fmt(attn_prec: int) -> str:
+    """plane set the projections write for q / k / v: the attention forward's operands + the bf16 planes of its backward"""
+    return {PREC_BF16X3: "x3", PREC_F16: "f16", PREC_BF16: "bwd"}[attn_prec]
 
 
-def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key):
+def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key, pol):
     """MultiheadedAttention.forward for inference with K is V (cross-attention over the encoder memory): the key / value
     projections are taken from ``cache`` when they were computed for the same memory tensor before (greedy decoding re-uses
     them for every generated token; the reference re-encodes the video and re-projects the memory per token,
     epoch_loops/captioning_epoch_loops.py:58-61)."""
-    x3 = FWD_PRECISION == PREC_BF16X3
     Qc = _f32c(Q)
     B, Sq, Dq = Qc.shape
     D = Wq.shape[0]
     Sk = K.shape[1]
+    qkv_fmt = attn_operand_fmt(pol.attn)
     ent = cache.get(key)
     if ent is None or ent[0] is not K:
         Kc = _f32c(K)
-        Kp = make_planes(Kc.view(-1, Kc.shape[-1]), lo=x3)[0]
-        r = project_group(Kp, (Wk, Wv), (bk, bv), x3)
+        Kp = make_planes(Kc.view(-1, Kc.shape[-1]), act_fmt(pol.kv_gemm))
+        r = project_group(Kp, (Wk, Wv), (bk, bv), pol.kv_gemm, qkv_fmt)
         if r is None:
-            r = (linear_fwd_planes(Kp, Wk, bk, want_lo=x3), linear_fwd_planes(Kp, Wv, bv, want_lo=x3))
+            r = (linear_fwd_planes(Kp, Wk, bk, precision=pol.kv_gemm, out_fmt=qkv_fmt),
+                 linear_fwd_planes(Kp, Wv, bv, precision=pol.kv_gemm, out_fmt=qkv_fmt))
         ent = (K, r[0], r[1])
         cache[key] = ent
     k, v = ent[1], ent[2]
-    Qp = planes_of(Q, x3) or make_planes(Qc.view(-1, Dq), lo=x3)[0]
-    q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
-    o, _ = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H)
-    return linear_fwd(o, Wo, bo).view(B, Sq, Dq)
+    Qp = planes_of(Q, act_fmt(pol.gemm)) or make_planes(Qc.view(-1, Dq), act_fmt(pol.gemm))
+    q = linear_fwd_planes(Qp, Wq, bq, precision=pol.gemm, out_fmt=qkv_fmt)
+    o, _ = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, precision=pol.attn, out_fmt=act_fmt(pol.gemm))
+    return linear_fwd(o, Wo, bo, precision=pol.gemm).view(B, Sq, Dq)
 
 
 class MHAFn(torch.autograd.Function):
     """MultiheadedAttention.forward model/multihead_attention.py:55-86: three input projections, the masked
     softmax-attention core with dropout on its OUTPUT (:22-23), head merge and output projection.
 
-    Every tensor between the GEMMs and the attention kernels exists only as bf16 operand planes: the projections write
-    q/k/v planes from their epilogue, the attention forward writes the planes of its output, the attention backward writes
-    dq/dk/dv as (plane, transposed plane, bias sums).  The only fp32 intermediates are the module's input/output and dO."""
+    Every tensor between the GEMMs and the attention kernels exists only as 16-bit operand planes: the projections write
+    q/k/v planes from their epilogue (the attention forward's operand format + the bf16 plane its backward reads), the attention
+    forward writes the planes of its output, the attention backward writes dq/dk/dv as (bf16 plane, bias sums).  The only fp32
+    intermediates are the module's input/output.  pol: the Policy of the enclosing layer (ops.POLICIES)."""
 
     @staticmethod
-    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, res=None, res_p=0.0, res_site=0):
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, pol, res=None, res_p=0.0, res_site=0):
         note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
         B, Sq, Dq = Qc.shape
         Sk = Kc.shape[1]
         D = Wq.shape[0]
         same_qk, same_kv = Q is K, K is V
-        x3 = FWD_PRECISION == PREC_BF16X3
-        train = any(ctx.needs_input_grad)
-        # each distinct input: operand planes (hi[, lo]) and, for the weight gradients, the transposed hi plane -- one pass
-        # (none at all when the producer -- LayerNorm -- attached the planes of its output)
-        def split(orig, x3d):
-            pl = planes_of(orig, x3)
-            if pl is not None:
-                return pl, pl
-            x2 = x3d.view(-1, x3d.shape[-1])
-            P_, T_ = make_planes(x2, lo=x3, straight=True, transposed=train and not _kmajor())
-            return P_, (P_ if _kmajor() else T_)
-        Qp, QT = split(Q, Qc)
-        Kp, KT = (Qp, QT) if same_qk else split(K, Kc)
-        Vp, VT = (Kp, KT) if same_kv else split(V, Vc)
-        fused_proj = lambda Xp, Ws, bs: project_group(Xp, Ws, bs, x3)
+        prec_q = pol.gemm
+        prec_kv = pol.gemm if same_qk else pol.kv_gemm       # cross-attention: K / V project the (long) other stream
+        qkv_fmt = attn_operand_fmt(pol.attn)
+
+        # each distinct input: operand planes of the format its projection reads, holding the bf16 plane the dW product needs
+        # -- one pass (none at all when the producer -- LayerNorm -- attached the planes of its output)
+        def split(orig, x3d, prec):
+            pl = planes_of(orig, act_fmt(prec))
+            if pl is None:       # kept on the tensor: the encoder memory is the K / V input of every decoder layer
+                pl = make_planes(x3d.view(-1, x3d.shape[-1]), act_fmt(prec))
+                attach_planes(orig, pl)
+            return pl
+        Qp = split(Q, Qc, prec_q)
+        Kp = Qp if same_qk else split(K, Kc, prec_kv)
+        Vp = Kp if same_kv else split(V, Vc, prec_kv)
         fuse = None
         q = k = v = None
         if same_qk and same_kv:
-            r = fused_proj(Qp, (Wq, Wk, Wv), (bq, bk, bv))
+            r = project_group(Qp, (Wq, Wk, Wv), (bq, bk, bv), prec_q, qkv_fmt)
             if r is not None:
                 (q, k, v), fuse = r, "qkv"
         elif same_kv:
-            r = fused_proj(Kp, (Wk, Wv), (bk, bv))
+            r = project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
             if r is not None:
                 (k, v), fuse = r, "kv"
         if q is None:
-            q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
+            q = linear_fwd_planes(Qp, Wq, bq, precision=prec_q, out_fmt=qkv_fmt)
         if k is None:
-            k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
-            v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
-        o, lse = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, drop_p=p, site=site)
+            k = linear_fwd_planes(Kp, Wk, bk, precision=prec_kv, out_fmt=qkv_fmt)
+            v = linear_fwd_planes(Vp, Wv, bv, precision=prec_kv, out_fmt=qkv_fmt)
+        o, lse = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, drop_p=p, site=site, precision=pol.attn, out_fmt=act_fmt(pol.gemm))
         epi = {}
         if res is not None:              # x_res + dropout(out-projection) in the projection's epilogue (ResidualConnection)
             r2 = _f32c(res).view(-1, Dq)
             epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
-        out = linear_fwd(o, Wo, bo, **epi).view(B, Sq, Dq)
+        out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, Sq, Dq)
         ctx.H, ctx.p, ctx.site = H, p, site
         ctx.res = (res is not None, res_p, res_site)
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
@@ -1302,55 +1307,53 @@ class MHAFn(torch.autograd.Function):
         ctx.dims = (B, Sq, Sk, D, Dq, Kc.shape[-1], Vc.shape[-1])
         ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         none = torch.empty(0, device=Qc.device)
-        ctx.save_for_backward(Wq, Wk, Wv, Wo, q.hi, k.hi, v.hi, o.hi, o.lo if o.lo is not None else none, lse,
-                              QT.hi if train else none, KT.hi if train else none, VT.hi if train else none)
+        train = any(ctx.needs_input_grad)
+        osec = o.lo if o.lo is not None else (o.fh if o.fh is not None else none)      # delta = rowsum(dO * O) reads hi + lo, or fp16
+        ctx.o_f16 = o.fh is not None
+        ctx.save_for_backward(Wq, Wk, Wv, Wo, q.hi, k.hi, v.hi, o.hi, osec, lse,
+                              Qp.hi if train else none, Kp.hi if train else none, Vp.hi if train else none)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        Wq, Wk, Wv, Wo, qh, kh, vh, oh, ol, lse, QTh, KTh, VTh = ctx.saved_tensors
+        Wq, Wk, Wv, Wo, qh, kh, vh, oh, osec, lse, QTh, KTh, VTh = ctx.saved_tensors
         B, Sq, Sk, D, Dq, Dk_in, Dv_in = ctx.dims
         Mq, Mk = B * Sq, B * Sk
         Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
         q, k, v = Planes(qh, None, Mq, D), Planes(kh, None, Mk, D), Planes(vh, None, Mk, D)
-        o = Planes(oh, ol if ol.numel() else None, Mq, D)
-        if _kmajor():     # the inputs' own hi planes are the dW operands
-            QT, KT, VT = Planes(QTh, None, Mq, Dq), Planes(KTh, None, Mk, Dk_in), Planes(VTh, None, Mk, Dv_in)
-        else:
-            QT, KT, VT = Planes(QTh, None, Dq, Mq), Planes(KTh, None, Dk_in, Mk), Planes(VTh, None, Dv_in, Mk)
+        osec = osec if osec.numel() else None
+        o = Planes(oh, None if ctx.o_f16 else osec, Mq, D, fh=osec if ctx.o_f16 else None)
+        # the inputs' own bf16 planes are the (k-major) dW operands
+        QT, KT, VT = Planes(QTh, None, Mq, Dq), Planes(KTh, None, Mk, Dk_in), Planes(VTh, None, Mk, Dv_in)
         dy2 = _f32c(dout).view(-1, Dq)
         has_res, res_p, res_site = ctx.res
         drop = None
         if has_res:                      # the residual branch takes dout as it is; this branch sees it through the dropout mask
             dy2, drop = drop_grad(dy2, bop, res_p, res_site)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
-        if _kmajor() and D % 64 == 0 and _os.environ.get("BMT_DO_FP32") != "1":      # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
-            P_, T_, bias_done = grad_planes(dy2, bop, drop=drop)
+        if D % 64 == 0:                  # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
+            P_, bias_done = grad_planes(dy2, bop, drop=drop)
             do = linear_dx(P_, Wop, out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
                            drop_post=True, drop_p=ctx.p, site=ctx.site)
-            dWo, dbo = wgrad(Wop, None if bias_done else bop, T_, input_t(o), dy2_for_bias=dy2)
+            dWo, dbo = wgrad(Wop, None if bias_done else bop, P_, o, dy2_for_bias=dy2)
         else:
-            do, dWo, dbo = lin_bwd(dy2, Wop, bop, PlanesT(input_t(o)), drop=drop, drop_post=True, drop_p=ctx.p, site=ctx.site)
+            do, dWo, dbo = lin_bwd(dy2, Wop, bop, o, drop=drop, drop_post=True, drop_p=ctx.p, site=ctx.site)
         res = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p, (bqp, bkp, bvp), fuse=ctx.fuse)
-        (Pq, Tq, dbq), (Pk, Tk, dbk), (Pv, Tv, dbv) = res[:3]
+        (Pq, dbq), (Pk, dbk), (Pv, dbv) = res[:3]
         comb = res[3] if len(res) > 3 else None
         needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dQ = dK = dV = dWq = dWk = dWv = None
 
         def fused_bwd(Ws, xT, need_dx):
             """dX = [dq|dk|dv] . [Wq;Wk;Wv] as one GEMM; dW as one GEMM when the gradients are adjacent, else one per weight"""
-            P_all, T_all = comb
-            gst, gtr, _ = weight_group(Ws, tuple(None for _ in Ws))
+            gst, _ = weight_group(Ws, tuple(None for _ in Ws), "bwd")
             dx = None
-            if need_dx:
-                dx = torch.empty(P_all.rows, gst.cols, device=dy2.device, dtype=torch.float32)
-                if _kmajor():      # [Wq;Wk;Wv] as stored ([3D][d_in]): its row is the reduction index
-                    gemm_bf16(P_all, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
-                else:
-                    gemm_bf16(P_all, gtr, dx, ldc=dx.stride(0), precision=BWD_PRECISION)
+            if need_dx:          # [Wq;Wk;Wv] as stored ([3D][d_in]): its row is the reduction index
+                dx = torch.empty(comb.rows, gst.cols, device=dy2.device, dtype=torch.float32)
+                gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
             gW = group_static_grad(Ws)
             if gW is not None:
-                linear_dw(T_all, xT, into=gW)
+                linear_dw(comb, xT, into=gW)
                 for W in Ws:
                     grad_done(W)
                 return dx, [None] * len(Ws)
@@ -1358,8 +1361,7 @@ class MHAFn(torch.autograd.Function):
             for W in Ws:
                 N = W.shape[0]
                 g1 = static_grad(W)
-                Tw = Planes(T_all.hi[:, off:off + N], None, T_all.rows, N) if _kmajor() else Planes(T_all.hi[off:off + N], None, N, T_all.cols)
-                dWs.append(linear_dw(Tw, xT, into=g1))
+                dWs.append(linear_dw(Planes(comb.hi[:, off:off + N], None, comb.rows, N), xT, into=g1))
                 if g1 is not None:
                     grad_done(W)
                 off += N
@@ -1370,7 +1372,7 @@ class MHAFn(torch.autograd.Function):
             if needQ:
                 dQ = dxq.view(B, Sq, Dq)
         elif comb is not None and ctx.fuse == "kv":
-            dxq, dWq = lin_bwd_planes(Pq, Tq, Wqp, QT, need_dx=needQ)
+            dxq, dWq = lin_bwd_planes(Pq, Wqp, QT, need_dx=needQ)
             if needQ:
                 dQ = dxq.view(B, Sq, Dq)
             need = needK or needV
@@ -1378,11 +1380,11 @@ class MHAFn(torch.autograd.Function):
             if need:
                 dK = dxk.view(B, Sk, Dk_in)      # autograd adds dK and dV for the shared tensor; dV stays None
         else:
-            dxq, dWq = lin_bwd_planes(Pq, Tq, Wqp, QT, need_dx=needQ)
+            dxq, dWq = lin_bwd_planes(Pq, Wqp, QT, need_dx=needQ)
             if ctx.same_qk and ctx.same_kv:     # one input, three contributions summed in the dX GEMM epilogue
                 ldr = dxq.stride(0) if needQ else 0
-                _, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
-                _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+                _, dWk = lin_bwd_planes(Pk, Wkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
+                _, dWv = lin_bwd_planes(Pv, Wvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=ldr)
                 if needQ:
                     dQ = dxq.view(B, Sq, Dq)
             else:
@@ -1390,126 +1392,16 @@ class MHAFn(torch.autograd.Function):
                     dQ = dxq.view(B, Sq, Dq)
                 if ctx.same_kv:
                     need = needK or needV
-                    dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=need)
-                    _, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
+                    dxk, dWk = lin_bwd_planes(Pk, Wkp, KT, need_dx=need)
+                    _, dWv = lin_bwd_planes(Pv, Wvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
                     if need:
                         dK = dxk.view(B, Sk, Dk_in)  # autograd adds dK and dV for the shared tensor; dV stays None
                 else:
-                    dxk, dWk = lin_bwd_planes(Pk, Tk, Wkp, KT, need_dx=needK)
-                    dxv, dWv = lin_bwd_planes(Pv, Tv, Wvp, VT, need_dx=needV)
+                    dxk, dWk = lin_bwd_planes(Pk, Wkp, KT, need_dx=needK)
+                    dxv, dWv = lin_bwd_planes(Pv, Wvp, VT, need_dx=needV)
                     dK = dxk.view(B, Sk, Dk_in) if needK else None
                     dV = dxv.view(B, Sk, Dv_in) if needV else None
-        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, (dout if has_res else None), None, None
-
-
-class MHAFnStaged(torch.autograd.Function):
-    """MHAFn for the fp32-staged GEMM path (USE_PLANE_GEMM = False; A/B measurements and kernel tests only): attention
-    output and gradients travel as fp32 tensors."""
-
-    @staticmethod
-    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site):
-        note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
-        Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
-        B, Sq, Dq = Qc.shape
-        Sk = Kc.shape[1]
-        D = Wq.shape[0]
-        same_qk, same_kv = Q is K, K is V
-        x3 = FWD_PRECISION == PREC_BF16X3
-        Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
-        if USE_PLANE_GEMM:      # each distinct input is split into operand planes once
-            Qp = as_planes(Q2, x3)
-            Kp = Qp if same_qk else as_planes(K2, x3)
-            Vp = Kp if same_kv else as_planes(V2, x3)
-        else:
-            Qp, Kp, Vp = Q2, K2, V2
-        # the projections write bf16 operand planes (hi, lo) straight from the GEMM epilogue; the attention kernels
-        # consume them as MFMA operands without any conversion.  Only the hi planes are kept for backward.
-        def fused_proj(Xp, Ws, bs):
-            grp = weight_group(Ws, bs)
-            if grp is None:
-                return None
-            gst, _, gb = grp
-            Nt = gst.rows
-            hi = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16)
-            lo = torch.empty(Xp.rows, Nt, device=Qc.device, dtype=torch.bfloat16) if x3 else None
-            gemm_bf16(Xp, gst, None, bias=gb, out_planes=Planes(hi, lo, Xp.rows, Nt))
-            outs, off = [], 0
-            for W in Ws:
-                N = W.shape[0]
-                outs.append(Planes(hi[:, off:off + N], None if lo is None else lo[:, off:off + N], Xp.rows, N))
-                off += N
-            return outs
-        fuse = None
-        q = k = v = None
-        if same_qk and same_kv:
-            r = fused_proj(Qp, (Wq, Wk, Wv), (bq, bk, bv))
-            if r is not None:
-                (q, k, v), fuse = r, "qkv"
-        elif same_kv:
-            r = fused_proj(Kp, (Wk, Wv), (bk, bv))
-            if r is not None:
-                (k, v), fuse = r, "kv"
-        if q is None:
-            q = linear_fwd_planes(Qp, Wq, bq, want_lo=x3)
-        if k is None:
-            k = linear_fwd_planes(Kp, Wk, bk, want_lo=x3)
-            v = linear_fwd_planes(Vp, Wv, bv, want_lo=x3)
-        v3 = lambda t, S: None if t is None else t.view(B, S, D)
-        o, lse = attn_fwd_bf16(v3(q.hi, Sq), v3(q.lo, Sq), v3(k.hi, Sk), v3(k.lo, Sk), v3(v.hi, Sk), v3(v.lo, Sk), mask, H,
-                               drop_p=p, site=site)
-        out = linear_fwd(o.view(-1, D), Wo, bo).view(B, Sq, Dq)
-        ctx.H, ctx.p, ctx.site = H, p, site
-        ctx.same_qk, ctx.same_kv = same_qk, same_kv
-        ctx.mask = mask
-        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
-        ctx.save_for_backward(Qc, Kc, Vc, Wq, Wk, Wv, Wo, q.hi.view(B, Sq, D), k.hi.view(B, Sk, D), v.hi.view(B, Sk, D), o, lse)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        Qc, Kc, Vc, Wq, Wk, Wv, Wo, q, k, v, o, lse = ctx.saved_tensors
-        B, Sq, Dq = Qc.shape
-        Sk = Kc.shape[1]
-        D = Wq.shape[0]
-        dy2 = _f32c(dout).view(-1, Dq)
-        o2 = o.view(-1, D)
-        Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
-        # gradient w.r.t. the PRE-dropout attention output: the dropout mask is re-applied in the dX GEMM's epilogue
-        do, dWo, dbo = lin_bwd(dy2, Wop, bop, o2, drop_post=True, drop_p=ctx.p, site=ctx.site)
-        do = do.view(B, Sq, D)
-        dq, dk, dv = attn_bwd_bf16(q, k, v, o, do, lse, ctx.mask, ctx.H, drop_p=ctx.p)
-        dq2, dk2, dv2 = dq.view(-1, D), dk.view(-1, D), dv.view(-1, D)
-        Q2, K2, V2 = Qc.view(-1, Dq), Kc.view(-1, Kc.shape[-1]), Vc.view(-1, Vc.shape[-1])
-        if USE_PLANE_GEMM:      # transposed operand of each distinct input, once
-            QT = PlanesT(input_t(Q2))
-            KT = QT if ctx.same_qk else PlanesT(input_t(K2))
-            VT = KT if ctx.same_kv else PlanesT(input_t(V2))
-        else:
-            QT, KT, VT = Q2, K2, V2
-        needQ, needK, needV = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dQ = dK = dV = None
-        self_attn = ctx.same_qk and ctx.same_kv
-        dxq, dWq, dbq = lin_bwd(dq2, Wqp, bqp, QT, need_dx=needQ)
-        if self_attn:            # one input, three contributions summed in the dX GEMM epilogue
-            _, dWk, dbk = lin_bwd(dk2, Wkp, bkp, KT, need_dx=needQ, out=dxq, residual=dxq, ldr=dxq.stride(0) if needQ else 0)
-            _, dWv, dbv = lin_bwd(dv2, Wvp, bvp, VT, need_dx=needQ, out=dxq, residual=dxq, ldr=dxq.stride(0) if needQ else 0)
-            if needQ:
-                dQ = dxq.view(Qc.shape)
-        else:
-            if needQ:
-                dQ = dxq.view(Qc.shape)
-            if ctx.same_kv:
-                need = needK or needV
-                dxk, dWk, dbk = lin_bwd(dk2, Wkp, bkp, KT, need_dx=need)
-                _, dWv, dbv = lin_bwd(dv2, Wvp, bvp, VT, need_dx=need, out=dxk, residual=dxk, ldr=dxk.stride(0) if need else 0)
-                if need:
-                    dK = dxk.view(Kc.shape)      # autograd adds dK and dV for the shared tensor; dV stays None
-            else:
-                dxk, dWk, dbk = lin_bwd(dk2, Wkp, bkp, KT, need_dx=needK)
-                dxv, dWv, dbv = lin_bwd(dv2, Wvp, bvp, VT, need_dx=needV)
-                dK = dxk.view(Kc.shape) if needK else None
-                dV = dxv.view(Vc.shape) if needV else None
-        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None
+        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None
 
 
 class GeneratorFn(torch.autograd.Function):
@@ -1521,7 +1413,7 @@ class GeneratorFn(torch.autograd.Function):
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
         V = W.shape[0]
-        logp = linear_fwd(x2, W, b)
+        logp = linear_fwd(x2, W, b, precision=policy_of(None).gemm)
         _lib.check(lib.bmt_log_softmax_fwd(_p(logp), logp.stride(0), logp.shape[0], V, _st()), "bmt_log_softmax_fwd")
         ctx.save_for_backward(x2, W, logp)
         ctx.params = (W, b)

@@ -114,13 +114,14 @@ class CaptioningTrainStep:
         # the weight-gradient GEMMs of the whole backward pass go out as one grouped launch -- unless gradients are all-reduced
         # bucket by bucket from the backward hooks, which needs them finished in autograd order
         from . import ops as _ops
-        _ops.DEFER_DW = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap)
+        sctx = _ops.context()
+        sctx.defer_dw = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap)
         try:
             kl.backward()
             _ops.flush_dw()
         finally:
-            _ops.DEFER_DW = False
-            _ops._pending_dw.clear()
+            sctx.defer_dw = False
+            sctx.pending_dw.clear()
         return kl.detach(), n_tokens
 
     def _reduce(self, kl, n_tokens):

@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-3)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 1
+#define BMT_ABI_VERSION 2
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -44,6 +44,9 @@ int bmt_device_cus(void);
 /* ---------------------------------------------------------------- precision modes */
 #define BMT_PREC_BF16 1    /* one bf16 MFMA pass, fp32 accumulate                      */
 #define BMT_PREC_BF16X3 3  /* split-bf16: hi*hi + hi*lo + lo*hi, ~2^-16 relative error */
+#define BMT_PREC_F16 4     /* one fp16 MFMA pass (planes hold fp16 values, 11 significand bits), fp32 accumulate: forward attention cores */
+#define BMT_PREC_F16W2 5   /* two fp16 passes: A as ONE fp16 plane, B (the weight) as fp16 hi + lo: the weight is exact to ~2^-21, the
+                            * activation rounds to 2^-11 -- what the per-site study (tests/study_precision_policy.py) showed to matter */
 
 /* ---------------------------------------------------------------- GEMM epilogue flags */
 #define BMT_EPI_BIAS 1u        /* + bias[n]                                                    */
@@ -55,37 +58,16 @@ int bmt_device_cus(void);
 #define BMT_EPI_ACCUM 64u      /* C += result (atomic; required when splitk > 1)               */
 
 /*
- * bmt_gemm: C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
- *   A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m]
- *   B(n,k) = b_kcontig ? B[n*ldb + k] : B[k*ldb + n]
- * Replaces nn.Linear forward (model/multihead_attention.py:66-68,84; model/blocks.py:151,168,172;
+ * bmt_gemm_bf16: C[M,N] = epilogue( alpha * sum_k A[m,k] * B[n,k] ) over PRE-CONVERTED 16-bit operand planes (both operands
+ * reduction-contiguous).  Replaces nn.Linear forward (model/multihead_attention.py:66-68,84; model/blocks.py:151,168,172;
  * model/generators.py:18) and its two backward products (dX = dY.W, dW = dY^T.X).
  * Epilogue order: alpha -> +bias -> dropout_pre -> relu -> dropout_post -> gate -> +residual -> store/accumulate.
- */
-typedef struct {
-    const float* A; int64_t lda; int a_kcontig;
-    const float* B; int64_t ldb; int b_kcontig;
-    float* C; int64_t ldc;
-    int M, N, K;
-    float alpha;
-    unsigned flags;
-    const float* bias;                     /* [N]  (BMT_EPI_BIAS)                    */
-    const float* residual; int64_t ldr;    /* [M,N] (BMT_EPI_RESIDUAL)               */
-    const float* gate; int64_t ldg; float gate_scale; /* (BMT_EPI_GATE)              */
-    float drop_p; const uint64_t* rng; uint32_t site; /* dropout, indexed by m*ldc+n */
-    int precision;                         /* BMT_PREC_*                             */
-    int splitk;                            /* >=1; >1 needs BMT_EPI_ACCUM only       */
-    /* optional bf16 "operand planes" of the result for the next MFMA consumer: hi = bf16(c), lo = bf16(c - hi);
-     * row stride ldp (elements); C may be NULL when planes are requested; C_lo may be NULL (hi only). */
-    uint16_t* C_hi; uint16_t* C_lo; int64_t ldp;
-} bmt_gemm_args;
-int bmt_gemm(const bmt_gemm_args* args, void* stream);
-
-/*
- * bmt_gemm_bf16: the same product and epilogue over PRE-SPLIT bf16 operand planes (both operands reduction-contiguous):
- *   C[M,N] = epilogue( alpha * sum_k (A_hi+A_lo)[m,k] * (B_hi+B_lo)[n,k] )     (x3: hi*hi + hi*lo + lo*hi; x1: hi*hi)
+ *   BMT_PREC_BF16   A_hi.B_hi                           (bf16 planes, one pass: the backward products)
+ *   BMT_PREC_BF16X3 A_hi.B_hi + A_hi.B_lo + A_lo.B_hi   (bf16 hi/lo planes)
+ *   BMT_PREC_F16    A_hi.B_hi                           (fp16 planes)
+ *   BMT_PREC_F16W2  A_hi.(B_hi + B_lo)                  (fp16 planes; A_lo unused)
  * Planes are [rows][ld] bf16 with the reduction extent zero-padded to Kpad (a multiple of 64); bmt_planes makes them from
- * fp32 tensors (straight and/or transposed), bmt_gemm / bmt_gemm_bf16 can emit them for their own result (C_hi/C_lo,
+ * fp32 tensors (straight and/or transposed), bmt_gemm_bf16 can emit them for its own result (C_hi/C_lo,
  * zero-padded up to min(round_up(N,64), ldp)).  gate is the bf16 hi plane of the saved forward output.
  */
 typedef struct {
@@ -124,6 +106,9 @@ typedef struct {
     /* optional fp32 [N]: colsum[n] += sum over rows of the epilogue value (before bf16 rounding).  The column sums of a dX GEMM's
      * output are the bias gradient of the Linear below it; asking for them disables split-K for the launch. */
     float* colsum;
+    /* alternative to C_lo: the second output plane holds fp16(c) (same layout as C_hi).  A forward activation is then stored as
+     * {bf16(c) for the single-pass bf16 backward, fp16(c) for the fp16 forward consumer} -- the same bytes as hi + lo. */
+    uint16_t* C_f16;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight
@@ -134,22 +119,26 @@ int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
  * filled by kernels that carry the descriptors in their arguments, so the call can be captured in a hipGraph. */
 size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob);
 int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream);
-/* x fp32 (B,S,C) -> halo-padded bf16 planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C); lo may be NULL */
-int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream);
+/* x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C): hi = bf16(x) and, optionally,
+ * lo = bf16(x - hi) or (lo_f16) fp16(x) */
+int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp,
+                   void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL
  * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
-int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-               uint16_t* loT, int64_t ldpT, float* colsum /* optional: colsum[c] += sum_r src[r][c] (atomic) */, void* stream);
+int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh /* fp16(x), optional */,
+               uint16_t* fl /* fp16(x - fh), optional */, int64_t ldp, uint16_t* hiT, uint16_t* loT, int64_t ldpT,
+               float* colsum /* optional: colsum[c] += sum_r src[r][c] (atomic) */, void* stream);
 /* bmt_planes of dropout(src): the fp32 source is masked with the library's counter-based dropout (site, element index
  * r * C + c -- the mask bmt_dropout / the GEMM epilogues draw for a contiguous [R][C] tensor) before it is split; colsum sums
  * the masked values.  Backward of `x + dropout(sub)` fused into the gradient's operand conversion. */
-int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, uint16_t* hiT,
-                       uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site, void* stream);
+int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
+                       uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site,
+                       void* stream);
 /* the same for MANY tensors in one launch (all weights of a model after an optimizer step): the caller fills a host table of
  * bmt_planes_desc_bytes()-sized descriptors with bmt_planes_desc, uploads it, and passes the device pointer. */
 int bmt_planes_desc_bytes(void);
-int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,
-                    uint16_t* hiT, uint16_t* loT, int64_t ldpT);
+int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl,
+                    int64_t ldp, uint16_t* hiT, uint16_t* loT, int64_t ldpT);
 int bmt_planes_multi(const void* table_dev, int n_tensors, void* stream);
 
 /* bf16 [R][ld] -> transposed bf16 [C][ldT], zero padded up to min(round_up(R,64), ldT) */
@@ -198,7 +187,7 @@ int bmt_attn_bwd(const bmt_attn_bwd_args* args, void* stream);
 
 /*
  * bmt_attn_fwd_bf16 / bmt_attn_bwd_bf16: the same attention core over PRE-SPLIT bf16 operand planes (hi = bf16(x),
- * lo = bf16(x - hi)) as written by bmt_gemm's C_hi / C_lo epilogue outputs: no conversion in the K/V loop, half the
+ * lo = bf16(x - hi)) as written by bmt_gemm_bf16's C_hi / C_lo epilogue outputs: no conversion in the K/V loop, half the
  * staged bytes, per-tile mask classification (fully masked key tiles are skipped, fully valid ones run unmasked).
  * Plane strides are in bf16 elements and must be multiples of 8; O / dO / dQ are fp32 [B,Sq,H*dk] (ldo, bso),
  * dK / dV fp32 with (dkv_ld, dkv_bs).  Backward reads hi planes only (single-pass bf16); dOh_ws: bf16 workspace the size of O.
@@ -222,6 +211,7 @@ typedef struct {
     float drop_p; const uint64_t* rng; uint32_t site;
     int precision;
     uint16_t *Oh, *Ol; int64_t ldop, bsop;            /* optional plane outputs */
+    uint16_t* Of;                                     /* alternative to Ol: fp16(o) plane (consumer: an fp16-policy out-projection) */
 } bmt_attn_fwd_bf16_args;
 int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* args, void* stream);
 
@@ -238,6 +228,7 @@ typedef struct {
     uint16_t *dQh, *dKh, *dVh; int64_t gq_ld, gq_bs, gkv_ld, gkv_bs;
     uint16_t *dQT, *dKT, *dVT; int64_t gqT_ld, gkvT_ld;
     float *dbq, *dbk, *dbv;
+    const uint16_t* Of;                               /* saved forward output as an fp16 plane (delta = rowsum(dO * O) reads it when set) */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 
@@ -249,8 +240,8 @@ int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
  * (lo may be NULL), row stride ldp >= D, columns D .. min(pad64(D), ldp) zero filled -- the next GEMM / attention kernel reads
  * them directly, no separate conversion pass. */
 int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
-                             float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int64_t ldp, int rows, int D, float eps,
-                             void* stream);
+                             float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int lo_f16 /* lo receives fp16(y) instead */,
+                             int64_t ldp, int rows, int D, float eps, void* stream);
 /* dx (+)= LN backward; dgamma/dbeta += column reductions (accumulate into pre-zeroed or live grads).
  * dx[i] = (accumulate_dx ? dx[i] : 0) + ...
  * partial_ws: NULL -> one atomic per column per workgroup; else fp32 [bmt_layernorm_bwd_blocks(rows)][2][D] scratch for a
@@ -293,7 +284,7 @@ int bmt_add(const float* a, const float* b, float* out, int64_t n, void* stream)
 /* rng[1] += 1 (advance the dropout step counter on device; graph-capturable) */
 int bmt_rng_advance(uint64_t* rng, void* stream);
 /* out[i0][i1][i2] (contiguous) (+)= in[i0*s0 + i1*s1 + i2*s2]  -- Conv1d weight re-layout
- * ([Dout][Din][k] state_dict layout <-> the tap-major layouts bmt_conv1d consumes) */
+ * ([Dout][Din][k] state_dict layout <-> the tap-major layouts the implicit-convolution GEMM consumes) */
 int bmt_copy3d(const float* in, int64_t s0, int64_t s1, int64_t s2, float* out, int n0, int n1, int n2, int accumulate,
                void* stream);
 
@@ -331,24 +322,8 @@ int bmt_scale_tensors(void* const* ptrs, const int64_t* sizes, int n_tensors, in
                       void* stream);
 
 /* ---------------------------------------------------------------- proposal generator (K9, K10) */
-/*
- * Conv1d(D_in -> D_out, kernel k, padding k/2) over time as an implicit GEMM on (B,S,D_in) activations
- * (model/proposal_generator.py:29,41-45; the permutes at :41,45 vanish because the GEMM reads (B,S,D) directly).
- *   W: the Conv1d weight [D_out, D_in, k] as stored in the state_dict.
- *   y[b,s,o] = epilogue( sum_{c,t} x[b, s+t-k/2, c] * W[o,c,t] + bias[o] ), zero outside [0,S).
- *   mode 0: forward.  mode 1: dx[b,s,c] = sum_{o,t} dy[b, s-t+k/2, o] * W[o,c,t].
- *   mode 2: dW[o,c,t] += sum_{b,s} dy[b,s,o] * x[b, s+t-k/2, c]   (atomic accumulate, split over (b,s)).
- */
-typedef struct {
-    const float* x; const float* W; const float* bias; float* y;   /* roles per mode, see above */
-    int B, S, Din, Dout, k;
-    int mode;
-    unsigned flags; float drop_p; const uint64_t* rng; uint32_t site;
-    const float* gate; float gate_scale;
-    int precision; int splitk;
-} bmt_conv1d_args;
-int bmt_conv1d(const bmt_conv1d_args* args, void* stream);
-
+/* The Conv1d heads (model/proposal_generator.py:29,41-45) run on bmt_gemm_bf16's implicit-convolution modes (conv_mode 1 / 2
+ * over halo-padded activation planes, bmt_pad_planes); the (B,S,D) <-> (B,D,S) permutes at :41,45 vanish in the addressing. */
 /* make_targets model/proposal_generator.py:389-448 (bit-exact masks / targets):
  * targets [n,4] f32 (batch idx, center s, length s, meta); anchors [A] already divided by stride.
  * obj/noobj: uint8 [B,A,G] (caller pre-fills obj=0, noobj=1, tx=tw=0 via bmt_targets_init);

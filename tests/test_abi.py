@@ -15,15 +15,16 @@ def declared_symbols():
 
 def test_header_declares_the_hot_path():
     syms = declared_symbols()
-    for need in ("bmt_gemm", "bmt_attn_fwd", "bmt_attn_bwd", "bmt_layernorm_fwd", "bmt_layernorm_bwd", "bmt_ls_kl_fwd",
-                 "bmt_adam_step", "bmt_conv1d", "bmt_make_targets", "bmt_last_error", "bmt_version"):
+    for need in ("bmt_gemm_bf16", "bmt_gemm_bf16_grouped", "bmt_planes", "bmt_attn_fwd", "bmt_attn_bwd", "bmt_attn_fwd_bf16", "bmt_attn_bwd_bf16",
+                 "bmt_layernorm_fwd", "bmt_layernorm_bwd", "bmt_ls_kl_fwd", "bmt_adam_step", "bmt_pad_planes", "bmt_make_targets",
+                 "bmt_prop_decode_loss", "bmt_last_error", "bmt_version"):
         assert need in syms
 
 
 def test_library_loads_and_exports_everything():
     from bmt_amd import _lib
     lib = _lib.load()
-    assert lib.bmt_version() == 1
+    assert lib.bmt_version() == 2
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/bmt_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in bmt_amd/_lib.py"
@@ -36,8 +37,11 @@ def test_errors_are_reported_not_thrown():
     import ctypes as C
     from bmt_amd import _lib
     lib = _lib.load()
-    a = _lib.GemmArgs()
-    rc = lib.bmt_gemm(C.byref(a), None)
+    a = _lib.GemmBf16Args()
+    rc = lib.bmt_gemm_bf16(C.byref(a), None)
+    assert rc == -1 and b"null pointer" in lib.bmt_last_error()
+    f = _lib.AttnFwdBf16Args()
+    rc = lib.bmt_attn_fwd_bf16(C.byref(f), None)
     assert rc == -1 and b"null pointer" in lib.bmt_last_error()
     rc = lib.bmt_log_softmax_fwd(None, 0, 1, 1, None)
     assert rc == -1

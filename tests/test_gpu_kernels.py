@@ -1,8 +1,8 @@
 """-m gpu: kernel-level parity of libbmt_hip.so (through the C ABI) against the CPU oracle.
 
-bf16 single-pass products are checked against the oracle evaluated on bf16-ROUNDED operands in
-fp64 (so only accumulation order differs: tight tolerance that still exposes any tile / lane
-mapping mistake); split-bf16 (x3) products are checked against plain fp64 at ~1e-5 relative."""
+Single-pass products (bf16, fp16) are checked against the oracle evaluated on operands ROUNDED to that format in fp64 (so only
+the accumulation order differs: tight tolerance that still exposes any tile / lane mapping mistake); the split formats (bf16
+hi+lo x3, fp16 activation x fp16 hi+lo weight) against fp64 with only the single-plane operand rounded."""
 import math
 
 import numpy as np
@@ -28,65 +28,84 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ------------------------------------------------------------------------------------------ GEMM
 GEMM_SHAPES = [(128, 128, 64), (130, 70, 100), (257, 300, 1024), (64, 10, 24), (1, 1, 1), (300, 1200, 300), (96, 40, 7)]
+BF16, X3, F16, F16W2 = 1, 3, 4, 5
+
+
+def f16_round(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+def operand_rounding(prec):
+    """(rounding of A, rounding of B) the oracle applies to model a product of this precision: the kernel then differs by its fp32
+    accumulation order only (and, for the split formats, by the dropped lo.lo term, ~2^-16 / 2^-21 relative)"""
+    idt = lambda t: t
+    return {BF16: (bf16_round, bf16_round), X3: (idt, idt), F16: (f16_round, f16_round), F16W2: (f16_round, idt)}[prec]
+
+
+def tol(prec, K):
+    return dict(atol=(3e-5 if prec == X3 else 2e-4) * math.sqrt(K), rtol=(2e-5 if prec == X3 else 1e-4))
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("prec", [1, 3])
-def test_gemm_linear_forward(ops, gemm_path, M, N, K, prec):
+@pytest.mark.parametrize("prec", [BF16, X3, F16, F16W2])
+def test_gemm_linear_forward(ops, M, N, K, prec):
     x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
     y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), precision=prec)
-    if prec == 1:
-        want = bf16_round(x).double() @ bf16_round(W).double().t() + b.double()
-        assert_close(y, want, atol=2e-4 * math.sqrt(K), rtol=1e-4, name=f"linear x1 {M}x{N}x{K}")
-    else:
-        want = x.double() @ W.double().t() + b.double()
-        assert_close(y, want, atol=3e-5 * math.sqrt(K), rtol=2e-5, name=f"linear x3 {M}x{N}x{K}")
+    fa, fb = operand_rounding(prec)
+    want = fa(x).double() @ fb(W).double().t() + b.double()
+    assert_close(y, want, name=f"linear {ops.prec_name(prec)} {M}x{N}x{K}", **tol(prec, K))
 
 
-@pytest.fixture(params=[True, False], ids=["planes", "fp32-staged"])
-def gemm_path(ops, request):
-    """both GEMM implementations: operand planes (gemm_bf16.hip) and fp32 operands converted while staging (gemm.hip)"""
-    old = ops.USE_PLANE_GEMM
-    ops.USE_PLANE_GEMM = request.param
-    yield request.param
-    ops.USE_PLANE_GEMM = old
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 1024), (25600, 384, 128)])
+def test_gemm_f16w2_beats_single_pass_on_weight_rounding(ops, M, N, K):
+    """the point of PREC_F16W2: the weight enters exactly (hi + lo), so against the UNROUNDED-weight product it is ~2^-11/sqrt-K-accurate
+    in the activation only, while one fp16 pass carries the weight's rounding too"""
+    x, W = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.03
+    xd, Wd = x.to(DEV), W.to(DEV)
+    want = f16_round(x).double() @ W.double().t()
+    y2 = ops.linear_fwd(xd, Wd, None, precision=F16W2)
+    y1 = ops.linear_fwd(xd, Wd, None, precision=F16)
+    e2, e1 = rel_err(y2, want), rel_err(y1, want)
+    assert e2 < 5e-6 and e1 > 10 * e2, (e1, e2)
 
 
 @pytest.mark.parametrize("M,N,K", [(130, 70, 100), (256, 128, 512), (33, 300, 1000), (960, 300, 10000)])
-def test_gemm_dx_dw_layouts(ops, gemm_path, M, N, K):
-    """dX = dY.W and dW = dY^T.X (reduction over rows, split-K atomics) on both GEMM paths."""
+def test_gemm_dx_dw_layouts(ops, M, N, K):
+    """dX = dY.W and dW = dY^T.X (reduction over rows): every backward operand is a bf16 plane as stored, read k-major."""
     dy, W, x = rnd(M, N, seed=4), rnd(N, K, seed=5), rnd(M, K, seed=6)
     dyd, xd = dy.to(DEV), x.to(DEV)
-    dyP, dyT, _ = ops.grad_planes(dyd)
+    dyP, _ = ops.grad_planes(dyd)
     dx = ops.linear_dx(dyP, W.to(DEV))
     want = bf16_round(dy).double() @ bf16_round(W).double()
     assert_close(dx, want, atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx")
-    dW = ops.linear_dw(dyT, ops.input_t(xd))
+    dW = ops.linear_dw(dyP, ops.bwd_planes(xd))
     want = bf16_round(dy).double().t() @ bf16_round(x).double()
     assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name="dw")
 
 
 @pytest.mark.parametrize("M,N,K,splitk", [(300, 200, 1024, 4), (960, 300, 1024, 8), (130, 70, 2048, 16), (257, 129, 640, 3), (960, 300, 1024, 0)])
-@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("prec", [BF16, X3, F16W2])
 def test_gemm_splitk_two_pass(ops, M, N, K, splitk, prec):
     """two-pass split-K (partials in the workspace + epilogue kernel): same result as one pass for any epilogue, bit-identical
-    between launches (partials are summed in split order)"""
+    between launches (partials are summed in split order); plane outputs (bf16 hi + bf16 lo | fp16) from the epilogue kernel"""
     x, W, b, res = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9), rnd(M, N, seed=10)
-    A = ops.make_planes(x.to(DEV), lo=True)[0]
-    Bw = ops.make_planes(W.to(DEV), lo=True)[0]
+    A = ops.make_planes(x.to(DEV), "all")
+    Bw = ops.make_planes(W.to(DEV), "all")
     bd, resd = b.to(DEV), res.to(DEV)
+    out_fmt = "f16" if prec == F16W2 else "x3"
     outs = []
     for sk in (1, splitk, splitk):
         out = torch.empty(M, N, device=DEV)
-        pl = ops.Planes(torch.empty(M, 64 * ((N + 63) // 64), device=DEV, dtype=torch.bfloat16),
-                        torch.empty(M, 64 * ((N + 63) // 64), device=DEV, dtype=torch.bfloat16), M, N)
+        pl = ops._alloc_planes(M, N, out_fmt, DEV)
         ops.gemm_bf16(A, Bw, out, ldc=N, bias=bd, relu=True, residual=resd, ldr=N, splitk=sk, precision=prec, out_planes=pl)
         outs.append((out, pl))
-    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
-    want = torch.relu(f(x) @ f(W).t() + b.double()) + res.double()
+    fa, fb = operand_rounding(prec)
+    want = torch.relu(fa(x).double() @ fb(W).double().t() + b.double()) + res.double()
     for out, pl in outs:
-        assert_close(out, want, atol=(2e-4 if prec == 1 else 3e-4) * math.sqrt(K), rtol=1e-4, name=f"splitk out x{prec}")
+        assert_close(out, want, atol=(3e-4 if prec == X3 else 2e-4) * math.sqrt(K), rtol=1e-4, name=f"splitk out {ops.prec_name(prec)}")
         assert torch.equal(pl.hi[:, :N], out.to(torch.bfloat16)), "plane output of the split-K path != bf16(fp32 output)"
+        if out_fmt == "f16":
+            assert torch.equal(pl.fh[:, :N], out.to(torch.float16)), "fp16 plane output != fp16(fp32 output)"
     assert torch.equal(outs[1][0], outs[2][0]), "split-K result differs between two launches (reduction order not fixed?)"
     assert_close(outs[1][0], outs[0][0], atol=1e-4 * math.sqrt(K), rtol=1e-5, name="split vs single pass")
 
@@ -96,64 +115,68 @@ def test_gemm_kmajor_operands(ops, M, N, K):
     """operands given with the reduction index as their row (read through ds_read_b64_tr_b16): dX = dY . W with the weight plane
     as stored, dW = dY^T . X with gradient and activation planes as stored -- no transposed planes anywhere"""
     dy, W, x = rnd(M, N, seed=14), rnd(N, K, seed=15), rnd(M, K, seed=16)
-    dyP = ops.make_planes(dy.to(DEV), lo=False)[0]
-    WP = ops.make_planes(W.to(DEV), lo=False)[0]
-    xP = ops.make_planes(x.to(DEV), lo=False)[0]
+    dyP = ops.make_planes(dy.to(DEV), "bwd")
+    WP = ops.make_planes(W.to(DEV), "bwd")
+    xP = ops.make_planes(x.to(DEV), "bwd")
     dx = torch.empty(M, K, device=DEV)
-    ops.gemm_bf16(dyP, WP, dx, ldc=K, precision=1, b_km=True)                      # reduction over N: W [N rows][K cols] is k-major
+    ops.gemm_bf16(dyP, WP, dx, ldc=K, precision=BF16, b_km=True)                      # reduction over N: W [N rows][K cols] is k-major
     want = bf16_round(dy).double() @ bf16_round(W).double()
     assert_close(dx, want, atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx (k-major W)")
     for sk in (1, 3):
         dW = torch.empty(N, K, device=DEV)
-        ops.gemm_bf16(dyP, xP, dW, ldc=K, precision=1, a_km=True, b_km=True, splitk=sk)   # reduction over M (rows of both planes)
+        ops.gemm_bf16(dyP, xP, dW, ldc=K, precision=BF16, a_km=True, b_km=True, splitk=sk)   # reduction over M (rows of both planes)
         want = bf16_round(dy).double().t() @ bf16_round(x).double()
         assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name=f"dW (k-major dY and X, splitk={sk})")
 
 
-def test_planes_and_transpose(ops):
-    x = rnd(150, 70, seed=3) * 3
-    pl, plT = ops.make_planes(x.to(DEV), lo=True, straight=True, transposed=True)
-    assert pl.hi.shape == (150, 128) and plT.hi.shape == (70, 192)
-    assert torch.equal(pl.hi[:, :70].float().cpu(), x.to(torch.bfloat16).float())
-    assert float(pl.hi[:, 70:].float().abs().max()) == 0 and float(plT.hi[:, 150:].float().abs().max()) == 0
-    assert_close(pl.hi[:, :70].float() + pl.lo[:, :70].float(), x, atol=0, rtol=2 ** -15, name="hi+lo")
-    assert torch.equal(plT.hi[:, :150].float().cpu(), x.t().to(torch.bfloat16).float())
-    t2 = ops.transpose_plane(pl)
-    assert torch.equal(t2.hi[:, :150].cpu(), plT.hi[:, :150].cpu()) and float(t2.hi[:, 150:].float().abs().max()) == 0
+@pytest.mark.parametrize("R,C", [(150, 70), (64, 1024), (33, 300)])
+def test_planes_formats(ops, R, C):
+    """bmt_planes: bf16 hi / lo and fp16 hi / lo of one tensor in one pass, zero padded to the next multiple of 64"""
+    x = rnd(R, C, seed=3) * 3
+    pl = ops.make_planes(x.to(DEV), "all")
+    ld = ops._pad64(C)
+    for t in (pl.hi, pl.lo, pl.fh, pl.fl):
+        assert t.shape == (R, ld) and float(t[:, C:].float().abs().max() if ld > C else 0.0) == 0
+    assert torch.equal(pl.hi[:, :C].float().cpu(), x.to(torch.bfloat16).float())
+    assert torch.equal(pl.fh[:, :C].float().cpu(), x.to(torch.float16).float())
+    assert_close(pl.hi[:, :C].float() + pl.lo[:, :C].float(), x, atol=0, rtol=2 ** -15, name="bf16 hi+lo")
+    assert_close(pl.fh[:, :C].float() + pl.fl[:, :C].float(), x, atol=1e-7, rtol=2 ** -20, name="fp16 hi+lo")
+    for fmt, names in (("bwd", ("hi",)), ("x3", ("hi", "lo")), ("f16", ("hi", "fh")), ("w2", ("hi", "fh", "fl"))):
+        one = ops.make_planes(x.to(DEV), fmt)
+        for n in ("hi", "lo", "fh", "fl"):
+            assert (getattr(one, n) is not None) == (n in names)
+            if n in names:
+                assert torch.equal(getattr(one, n), getattr(pl, n)), (fmt, n)
 
 
-def test_gemm_epilogues(ops, gemm_path):
+def test_gemm_epilogues(ops):
     M, N, K = 150, 90, 64
     x, W, b, res = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9), rnd(M, N, seed=10)
     xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV)
     base = x.double() @ W.double().t() + b.double()
-    y = ops.linear_fwd(xd, Wd, bd, relu=True, precision=3)
+    y = ops.linear_fwd(xd, Wd, bd, relu=True, precision=X3)
     assert_close(y, base.clamp(min=0), atol=3e-4, name="relu")
-    y = ops.linear_fwd(xd, Wd, bd, residual=rd, ldr=N, precision=3)
+    y = ops.linear_fwd(xd, Wd, bd, residual=rd, ldr=N, precision=X3)
     assert_close(y, base + res.double(), atol=3e-4, name="residual")
     gate = (rnd(M, N, seed=11) > 0).float()
-    if gemm_path:
-        y = ops.linear_fwd(xd, Wd, None, gate=ops.make_planes(gate.to(DEV), lo=False)[0], gate_scale=1.25, precision=3)
-    else:
-        out = torch.empty(M, N, device=DEV)
-        ops.gemm(xd, Wd, out, M, N, K, lda=K, ldb=K, ldc=N, gate=gate.to(DEV), ldg=N, gate_scale=1.25, precision=3)
-        y = out
+    y = ops.linear_fwd(xd, Wd, None, gate=ops.make_planes(gate.to(DEV), "bwd"), gate_scale=1.25, precision=X3)
     assert_close(y, (x.double() @ W.double().t()) * gate.double() * 1.25, atol=3e-4, name="gate")
     # in-place accumulate through the residual pointer (C aliases residual)
     acc = rd.clone()
-    ops.linear_fwd(xd, Wd, None, out=acc, residual=acc, ldr=N, precision=3)
+    ops.linear_fwd(xd, Wd, None, out=acc, residual=acc, ldr=N, precision=X3)
     assert_close(acc, res.double() + x.double() @ W.double().t(), atol=3e-4, name="residual-alias")
     cs = ops.colsum(rd)
     assert_close(cs, res.double().sum(0), atol=1e-4, name="colsum")
 
 
-def test_gemm_dropout_epilogue_matches_standalone(ops, gemm_path):
+@pytest.mark.parametrize("prec", [X3, F16W2])
+def test_gemm_dropout_epilogue_matches_standalone(ops, prec):
     """the fused dropout epilogue and bmt_dropout share one RNG: same site => same mask."""
     M, N, K, p, site = 200, 96, 32, 0.3, 4242
     ops.manual_seed(123)
     x, W = rnd(M, K, seed=12).to(DEV), rnd(N, K, seed=13).to(DEV)
-    plain = ops.linear_fwd(x, W, None, precision=3)
-    fused = ops.linear_fwd(x, W, None, drop_post=True, drop_p=p, site=site, precision=3)
+    plain = ops.linear_fwd(x, W, None, precision=prec)
+    fused = ops.linear_fwd(x, W, None, drop_post=True, drop_p=p, site=site, precision=prec)
     sep = ops.dropout_raw(plain, p, site)
     assert torch.equal(fused, sep)
     keep = (fused != 0).float().mean().item()
@@ -169,10 +192,11 @@ def test_gemm_dropout_epilogue_matches_standalone(ops, gemm_path):
 
 # ------------------------------------------------------------------------------------------ attention
 def _oracle_attention(q, k, v, mask, H, rounded):
+    """rounded: False / 3 = exact operands, True / 1 = bf16-rounded, 4 = fp16-rounded"""
     from oracle import bmt_oracle as orc
     B, Sq, D = q.shape
     dk = D // H
-    f = (lambda t: bf16_round(t).double()) if rounded else (lambda t: t.double())
+    f = _round_fn({False: 3, True: 1}.get(rounded, rounded))
     qh = f(q).view(B, Sq, H, dk).transpose(1, 2)
     kh = f(k).view(B, -1, H, dk).transpose(1, 2)
     vh = f(v).view(B, -1, H, dk).transpose(1, 2)
@@ -222,7 +246,7 @@ def test_attention_forward(ops, dk, H, B, Sq, Sk, kind, prec):
 
 
 @pytest.mark.parametrize("dk,H", [(256, 2), (128, 2), (64, 2)])
-@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("prec", [1, 3, 4])
 def test_attention_forward_rescale_branch(ops, dk, H, prec):
     """the online softmax keeps a STALE reference and rescales only when a score exceeds it by e^8: a rare, data-dependent branch
     that bounded random data never takes after the first tiles.  Force it late and repeatedly: a few (query, key) pairs far apart
@@ -240,39 +264,50 @@ def test_attention_forward_rescale_branch(ops, dk, H, prec):
     q[1, 50] *= -40.0                                                 # a row of large-magnitude scores of both signs
     mask = torch.ones(B, 1, Sk, dtype=torch.bool)
     mask[1, 0, 280:295] = False
-    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q, prec), _planes(k, prec), _planes(v, prec)
     o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask.to(DEV), H, precision=prec)
-    want = _oracle_attention(q, k, v, mask, H, rounded=(prec == 1))
-    assert_close(o, want, atol=(3e-2 if prec == 1 else 3e-4), rtol=0, name=f"attn o with forced rescales dk={dk} x{prec}")
-    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
+    want = _oracle_attention(q, k, v, mask, H, rounded=prec)
+    assert_close(o, want, atol=_ATOL_O[prec] * 1.5, rtol=0, name=f"attn o with forced rescales dk={dk} x{prec}")
+    f = _round_fn(prec)
     s_ = torch.einsum("bqhd,bkhd->bhqk", f(q).view(B, Sq, H, dk), f(k).view(B, Sk, H, dk)) / math.sqrt(dk)
     s_ = s_.masked_fill(~mask.unsqueeze(1), -float("inf"))
-    assert_close(lse, torch.logsumexp(s_, -1), atol=(5e-2 if prec == 1 else 1e-3), rtol=1e-5, name="lse with forced rescales")
+    assert_close(lse, torch.logsumexp(s_, -1), atol={1: 5e-2, 3: 1e-3, 4: 8e-3}[prec], rtol=1e-5, name="lse with forced rescales")
 
 
-def _planes(t):
+def _planes(t, prec=3):
+    """(first plane, second plane) a raw attention-kernel call of this precision takes: bf16 hi + lo, or the fp16 plane"""
+    if prec == 4:
+        return t.to(torch.float16).to(DEV), None
     hi = t.to(torch.bfloat16)
     lo = (t - hi.float()).to(torch.bfloat16)
     return hi.to(DEV), lo.to(DEV)
 
 
-@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 333, "pad"), (128, 4, 1, 70, 257, "pad")])
-@pytest.mark.parametrize("prec", [1, 3])
+def _round_fn(prec):
+    return {1: lambda t: bf16_round(t).double(), 3: lambda t: t.double(), 4: lambda t: f16_round(t).double()}[prec]
+
+
+# max |O - oracle on rounded operands|: single-pass kernels also round P (2^-9 bf16, 2^-12 fp16)
+_ATOL_O = {1: 2e-2, 3: 2e-4, 4: 3e-3}
+
+
+@pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 333, "pad"), (128, 4, 1, 70, 257, "pad"), (256, 1, 1, 256, 800, "pad")])
+@pytest.mark.parametrize("prec", [1, 3, 4])
 def test_attention_forward_bf16_planes(ops, dk, H, B, Sq, Sk, kind, prec):
     D = dk * H
     q, k, v = rnd(B, Sq, D, seed=20), rnd(B, Sk, D, seed=21), rnd(B, Sk, D, seed=22)
     mask = _masks(kind, B, Sq, Sk)
     if kind == "pad" and Sk > 100:
         mask[0, 0, Sk // 3:] = False          # whole key tiles fully masked -> exercises the tile-skip path
-    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q, prec), _planes(k, prec), _planes(v, prec)
     o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, None if mask is None else mask.to(DEV), H, precision=prec)
-    want = _oracle_attention(q, k, v, mask, H, rounded=(prec == 1))
-    assert_close(o, want, atol=(2e-2 if prec == 1 else 2e-4), rtol=0, name=f"attn(bf16 planes) o dk={dk} {kind} x{prec}")
-    f = (lambda t: bf16_round(t).double()) if prec == 1 else (lambda t: t.double())
+    want = _oracle_attention(q, k, v, mask, H, rounded=prec)
+    assert_close(o, want, atol=_ATOL_O[prec], rtol=0, name=f"attn(planes) o dk={dk} {kind} prec {prec}")
+    f = _round_fn(prec)
     s = torch.einsum("bqhd,bkhd->bhqk", f(q).view(B, Sq, H, dk), f(k).view(B, Sk, H, dk)) / math.sqrt(dk)
     if mask is not None:
         s = s.masked_fill(~mask.unsqueeze(1), -float("inf"))
-    assert_close(lse, torch.logsumexp(s, -1), atol=2e-3 if prec == 1 else 2e-4, name="lse")
+    assert_close(lse, torch.logsumexp(s, -1), atol={1: 2e-3, 3: 2e-4, 4: 5e-4}[prec], name="lse")
 
 
 @pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 333, "pad"), (128, 4, 1, 70, 257, "pad")])
@@ -297,9 +332,11 @@ def test_attention_backward_bf16_planes(ops, dk, H, B, Sq, Sk, kind):
 
 
 @pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 336, "pad"), (128, 4, 1, 70, 257, "pad"), (256, 4, 2, 128, 64, "pad")])
-def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind):
-    """forward O planes and backward (plane, transposed plane, bias sums) forms against the fp32 outputs of the same kernels:
-    hi == bf16(fp32) bit for bit, hi + lo == fp32 to 2^-16, transposed == transpose, bias sums == sums of the bf16 values"""
+@pytest.mark.parametrize("prec,out_fmt", [(3, "x3"), (4, "f16"), (4, "x3")])
+def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind, prec, out_fmt):
+    """forward O planes and backward (plane, bias sums) forms against the fp32 outputs of the same kernels:
+    hi == bf16(fp32) bit for bit, hi + lo == fp32 to 2^-16 / fp16 plane == fp16(fp32), bias sums == sums of the bf16 values;
+    the backward's delta = rowsum(dO * O) from either form of the saved output"""
     D = dk * H
     q, k, v = rnd(B, Sq, D, seed=40), rnd(B, Sk, D, seed=41), rnd(B, Sk, D, seed=42)
     do = rnd(B, Sq, D, seed=43).to(DEV)
@@ -307,37 +344,38 @@ def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind)
     if kind == "pad" and Sk > 100:
         mask[0, 0, Sk // 3:] = False
     md = None if mask is None else mask.to(DEV)
-    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
-    P = lambda h, l, S: ops.Planes(h.view(B * S, D), None if l is None else l.view(B * S, D), B * S, D)
-    o32, lse32 = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, md, H, precision=3)
-    o, lse = ops.attn_fwd_planes(P(qh, ql, Sq), P(kh, kl, Sk), P(vh, vl, Sk), B, Sq, Sk, D, md, H)
+
+    def P(t, S):       # every plane of the projection output, as the projection GEMM's epilogue would leave them
+        hi = t.to(torch.bfloat16)
+        return ops.Planes(hi.to(DEV).view(B * S, D), (t - hi.float()).to(torch.bfloat16).to(DEV).view(B * S, D), B * S, D,
+                          fh=t.to(torch.float16).to(DEV).view(B * S, D))
+    qp, kp, vp = P(q, Sq), P(k, Sk), P(v, Sk)
+    v3 = lambda t, S: None if t is None else t.view(B, S, D)
+    raw = (lambda pl, S: (v3(pl.fh, S), None)) if prec == 4 else (lambda pl, S: (v3(pl.hi, S), v3(pl.lo, S)))
+    (qa, qb), (ka, kb), (va, vb) = raw(qp, Sq), raw(kp, Sk), raw(vp, Sk)
+    o32, lse32 = ops.attn_fwd_bf16(qa, qb, ka, kb, va, vb, md, H, precision=prec)
+    o, lse = ops.attn_fwd_planes(qp, kp, vp, B, Sq, Sk, D, md, H, precision=prec, out_fmt=out_fmt)
     assert torch.equal(lse, lse32)
     o2 = o32.view(B * Sq, D)
     finite = torch.isfinite(o2)
     assert torch.equal(o.hi[:, :D][finite], o2.to(torch.bfloat16)[finite]), "O hi plane != bf16(O)"
-    rec = o.hi[:, :D].float() + o.lo[:, :D].float()
-    assert_close(rec[finite], o2[finite], atol=1e-6, rtol=2e-5, name="O hi+lo")
+    if out_fmt == "x3":
+        rec = o.hi[:, :D].float() + o.lo[:, :D].float()
+        assert_close(rec[finite], o2[finite], atol=1e-6, rtol=2e-5, name="O hi+lo")
+        assert o.fh is None
+    else:
+        assert torch.equal(o.fh[:, :D][finite], o2.to(torch.float16)[finite]), "O fp16 plane != fp16(O)"
+        assert o.lo is None
     assert (o.hi[:, D:] == 0).all()
 
-    dq, dk_, dv = ops.attn_bwd_bf16(qh, kh, vh, o32, do, lse32, md, H)
+    dq, dk_, dv = ops.attn_bwd_bf16(qp.hi.view(B, Sq, D), kp.hi.view(B, Sk, D), vp.hi.view(B, Sk, D), o32, do, lse32, md, H)
     bq = torch.nn.Parameter(torch.zeros(D, device=DEV))
-    km_was = ops.KMAJOR          # the model path runs k-major GEMMs and asks for no transposed planes; the kernels' transposed
-    ops.KMAJOR = False           # output form is part of the C ABI and is checked here
-    try:
-        res = ops.attn_bwd_planes(P(qh, None, Sq), P(kh, None, Sk), P(vh, None, Sk), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (bq, None, bq))
-    finally:
-        ops.KMAJOR = km_was
-    if km_was:
-        res_km = ops.attn_bwd_planes(P(qh, None, Sq), P(kh, None, Sk), P(vh, None, Sk), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (None, None, None))
-        for (Pa, Ta, _), (Pb, _, _) in zip(res_km, res):
-            assert Ta is Pa and torch.equal(Pa.hi, Pb.hi)
-    for name, (Pl, T, db), ref, S in (("dq", res[0], dq, Sq), ("dk", res[1], dk_, Sk), ("dv", res[2], dv, Sk)):
+    res = ops.attn_bwd_planes(qp, kp, vp, o, do, lse, B, Sq, Sk, D, md, H, 0.0, (bq, None, bq))
+    for name, (Pl, db), ref, S in (("dq", res[0], dq, Sq), ("dk", res[1], dk_, Sk), ("dv", res[2], dv, Sk)):
         ref2 = ref.view(B * S, D)
-        # the plane path rebuilds O as hi+lo (2^-16 relative) inside delta: compare to bf16 resolution
+        # the plane path rebuilds O from its planes (2^-16 / 2^-12 relative) inside delta: compare to bf16 resolution
         got = Pl.hi[:, :D].float()
         assert_close(got, ref2, atol=2e-3 * float(ref2.abs().max()), rtol=1e-2, name=f"{name} plane")
-        assert torch.equal(T.hi[:, :B * S], Pl.hi[:, :D].t()), f"{name}: transposed plane is not the transpose of the plane"
-        assert (T.hi[:, B * S:] == 0).all()
         if name != "dk":
             assert db is not None
             assert_close(db, got.double().sum(0), atol=1e-4 * float(got.abs().sum(0).max()) + 1e-6, rtol=1e-4, name=f"{name} bias sums")
@@ -346,16 +384,23 @@ def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind)
 
 
 @pytest.mark.parametrize("pad", [False, True])
-def test_gemm_plane_outputs(ops, gemm_path, pad):
+@pytest.mark.parametrize("prec,out_fmt", [(X3, "x3"), (X3, "f16"), (F16W2, "f16"), (F16W2, "x3")])
+def test_gemm_plane_outputs(ops, pad, prec, out_fmt):
+    """the epilogue's plane outputs: bf16 hi + (bf16 lo | fp16) of the fp32 result, whatever the product's own precision"""
     M, N, K = 150, 96, 64
     x, W, b = rnd(M, K, seed=7), rnd(N, K, seed=8), rnd(N, seed=9)
-    pl = ops.linear_fwd_planes(x.to(DEV), W.to(DEV), b.to(DEV), pad=pad)
-    want = x.double() @ W.double().t() + b.double()
+    pl = ops.linear_fwd_planes(x.to(DEV), W.to(DEV), b.to(DEV), precision=prec, out_fmt=out_fmt, pad=pad)
+    y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), precision=prec)
     assert pl.hi.dtype == torch.bfloat16 and pl.hi.shape == (M, 128 if pad else N)
-    assert_close(pl.hi[:, :N].float(), want, atol=1e-3, rtol=2 ** -8, name="hi plane")
-    assert_close(pl.hi[:, :N].float().double() + pl.lo[:, :N].float().double(), want, atol=3e-4, rtol=2e-5, name="hi+lo planes")
+    assert torch.equal(pl.hi[:, :N], y.to(torch.bfloat16))
+    if out_fmt == "x3":
+        assert_close(pl.hi[:, :N].float().double() + pl.lo[:, :N].float().double(), y, atol=1e-6, rtol=2e-5, name="hi+lo planes")
+        second = pl.lo
+    else:
+        assert pl.fh.dtype == torch.float16 and torch.equal(pl.fh[:, :N], y.to(torch.float16))
+        second = pl.fh
     if pad:
-        assert float(pl.hi[:, N:].float().abs().max()) == 0 and float(pl.lo[:, N:].float().abs().max()) == 0
+        assert float(pl.hi[:, N:].float().abs().max()) == 0 and float(second[:, N:].float().abs().max()) == 0
 
 
 def test_attention_fully_masked_row_is_nan(ops):
@@ -525,18 +570,18 @@ def test_layernorm_forward_writes_its_operand_planes(ops, rows, D):
     _lib.check(lib.bmt_layernorm_fwd(ops._p(x), D, ops._p(gamma), ops._p(beta), ops._p(y0), D, ops._p(m0), ops._p(r0), rows, D, 1e-5,
                                      ops._st()), "ln")
     ld = ops._pad64(D)
-    for with_y in (True, False):
+    want = ops.make_planes(y0, "all")
+    for with_y, f16 in ((True, False), (False, False), (True, True)):
         y = torch.full_like(x, float("nan"))
         hi = torch.full((rows, ld), 7.0, device=DEV, dtype=torch.bfloat16)
-        lo = torch.full((rows, ld), 7.0, device=DEV, dtype=torch.bfloat16)
+        lo = torch.full((rows, ld), 7.0, device=DEV, dtype=torch.float16 if f16 else torch.bfloat16)
         m, r = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
         _lib.check(lib.bmt_layernorm_fwd_planes(ops._p(x), D, ops._p(gamma), ops._p(beta), ops._p(y) if with_y else None, D, ops._p(m),
-                                                ops._p(r), ops._p(hi), ops._p(lo), ld, rows, D, 1e-5, ops._st()), "ln planes")
+                                                ops._p(r), ops._p(hi), ops._p(lo), int(f16), ld, rows, D, 1e-5, ops._st()), "ln planes")
         if with_y:
             assert torch.equal(y, y0)
         assert torch.equal(m, m0) and torch.equal(r, r0)
-        want = ops.make_planes(y0, lo=True)[0]
-        assert torch.equal(hi, want.hi) and torch.equal(lo, want.lo)
+        assert torch.equal(hi, want.hi) and torch.equal(lo, want.fh if f16 else want.lo)
 
 
 @pytest.mark.parametrize("rows,D", [(37, 128), (50, 300), (4100, 1024), (5, 77)])
@@ -572,26 +617,22 @@ def test_planes_of_a_dropped_gradient(ops, R, C):
     dropped = ops.dropout_raw(x, p, site)
     assert 0.2 < float((dropped == 0).float().mean()) < 0.4
     cs0, cs1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    want = ops.make_planes(dropped, lo=True, colsum=cs0)[0]
-    got = ops.make_planes(x, lo=True, colsum=cs1, drop=(p, site))[0]
-    assert torch.equal(got.hi, want.hi) and torch.equal(got.lo, want.lo)
+    want = ops.make_planes(dropped, "all", colsum=cs0)
+    got = ops.make_planes(x, "all", colsum=cs1, drop=(p, site))
+    for n in ("hi", "lo", "fh", "fl"):
+        assert torch.equal(getattr(got, n), getattr(want, n)), n
     assert_close(cs1, cs0, atol=1e-4, rtol=1e-5, name="colsum")
-    wantT = ops.make_planes(dropped, lo=False, straight=False, transposed=True)[1]
-    gotT = ops.make_planes(x, lo=False, straight=False, transposed=True, drop=(p, site))[1]
-    assert torch.equal(gotT.hi, wantT.hi)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 4096, 1024), (130, 200, 96), (128, 1024, 64)])
 def test_gemm_plane_output_with_vector_gate_and_column_sums(ops, M, N, K):
     """dX GEMM of the FFN backward: plane-only output, relu/dropout gate applied per 16-byte segment from the saved hidden plane,
     column sums (the next bias gradient) from the same epilogue -- against the fp32-output GEMM with the per-element gate."""
-    if not ops._kmajor():
-        pytest.skip("k-major operands disabled")
     dy, W = rnd(M, K, seed=1).to(DEV), (rnd(K, N, seed=2) * 0.1).to(DEV)
     hid = torch.relu(rnd(M, N, seed=3)).to(DEV)
     hid[:, ::5] = 0
-    h = ops.make_planes(hid, lo=False)[0]
-    dyP = ops.make_planes(dy, lo=False)[0]
+    h = ops.make_planes(hid, "bwd")
+    dyP = ops.make_planes(dy, "bwd")
     want = ops.linear_dx(dyP, W, gate=h, gate_scale=1.25)                      # fp32 out, per-element gate
     assert bool((want[:, ::5] == 0).all()) and float(want.abs().max()) > 0
     op = ops.Planes(torch.full((M, ops._pad64(N)), 3.0, device=DEV, dtype=torch.bfloat16), None, M, N)
@@ -613,13 +654,11 @@ def test_gemm_plane_output_with_vector_gate_and_column_sums(ops, M, N, K):
 def test_grouped_weight_gradient_launch(ops):
     """bmt_gemm_bf16_grouped: the weight gradients of several layers (different shapes, ragged reduction lengths and widths) in one
     launch, accumulated into live buffers -- against one split-K launch per problem."""
-    if not ops._kmajor():
-        pytest.skip("k-major operands disabled")
     shapes = [(8192, 1024, 1024), (960, 300, 1024), (1000, 128, 512), (257, 130, 70), (64, 10000, 300), (25600, 1024, 128), (5000, 3072, 128)]
     items, want = [], []
     for i, (rows, n_out, k_in) in enumerate(shapes):
-        dy = ops.make_planes((rnd(rows, n_out, seed=10 + i) * 0.1).to(DEV), lo=False)[0]
-        x = ops.make_planes(rnd(rows, k_in, seed=40 + i).to(DEV), lo=False)[0]
+        dy = ops.make_planes((rnd(rows, n_out, seed=10 + i) * 0.1).to(DEV), "bwd")
+        x = ops.make_planes(rnd(rows, k_in, seed=40 + i).to(DEV), "bwd")
         acc = rnd(n_out, k_in, seed=70 + i).to(DEV)
         ref = acc.clone()
         ops.linear_dw(dy, x, into=ref)                     # one launch (split-K workspace + epilogue) per problem
@@ -629,7 +668,7 @@ def test_grouped_weight_gradient_launch(ops):
     for (rows, n_out, k_in), (_, _, acc), ref in zip(shapes, items, want):
         assert_close(acc, ref, atol=2e-4 * math.sqrt(rows), rtol=1e-5, name=f"grouped dW {n_out}x{k_in} over {rows} rows")
     # queueing through linear_dw: nothing runs until flush_dw
-    ops.DEFER_DW = True
+    ops.context().defer_dw = True
     try:
         accs = [torch.zeros_like(a) for _, _, a in items]
         for (dy, x, _), a in zip(items, accs):
@@ -637,7 +676,7 @@ def test_grouped_weight_gradient_launch(ops):
         assert all(float(a.abs().max()) == 0.0 for a in accs)
         ops.flush_dw()
     finally:
-        ops.DEFER_DW = False
+        ops.context().defer_dw = False
     for a, (_, _, acc0), ref, (rows, n_out, k_in) in zip(accs, items, want, shapes):
         base = rnd(n_out, k_in, seed=70 + shapes.index((rows, n_out, k_in))).to(DEV)
         assert_close(a, ref - base, atol=3e-4 * math.sqrt(rows), rtol=1e-5, name="deferred dW")

@@ -42,9 +42,9 @@ def main():
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(dev)
-        ops.manual_seed(77)
         dp = mode != "single"
-        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=dp, static_grads=True, overlap=(mode == "dp_eager_overlap"))
+        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=dp, static_grads=True, overlap=(mode == "dp_eager_overlap"),
+                                   seed=77)          # dropout seed = 77 + rank on every arm (rank 0 here)
         calls = [0]
         if dp:
             step.reducer.world = 2            # one rank, but issue every collective
