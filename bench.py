@@ -412,7 +412,7 @@ def main():
         timer.enabled = True
         # the events must see back-to-back kernels: park the GPU behind a spin kernel first, so that the host (which needs less
         # time to issue an eager step than the GPU to run it) is a full step ahead and no launch gap lands between two events
-        torch.cuda._sleep(int(0.05 * torch.cuda.get_device_properties(dev).clock_rate * 1e3))
+        torch.cuda._sleep(120_000_000)          # ~50 ms of shader cycles
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(timer_steps):

@@ -56,7 +56,10 @@ class Policy:
 POLICIES = {
     "enc": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc"),       # bi-modal encoder layers (89 % of the FLOPs)
     "dec": Policy(PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),      # bi-modal decoder layers
-    "head": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "head"),     # Conv1d stacks of the proposal heads
+    # Conv1d stacks of the proposal heads: split-bf16.  (fp16 activation x split weight leaves 6-8e-4 abs on the head outputs,
+    # tests/test_gpu_proposal.py at round 2: inside the 1e-3 bar but with < 2x margin, and exp() turns it into 1e-3 relative on
+    # the predicted lengths.)
+    "head": Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "head"),
     None: Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
 }
 _OVERRIDE = [None]      # a Policy applied to EVERY site (A/B measurements, tests), or None

@@ -238,7 +238,7 @@ def test_mixed_cap_prop_step_matches_oracle():
     from tests.test_oracle_golden import deep_cfg, deep_prop_cfg
     V, B, Tv, Ta, Tc = 200, 2, 24, 72, 9
     cfg_cap, cfg_prop = deep_cfg(dout_p=0.0, lr=2e-4), deep_prop_cfg()
-    cfg_prop.dout_p, cfg_prop.lr, cfg_prop.grad_clip = 0.0, 1e-3, None
+    cfg_prop.dout_p, cfg_prop.lr, cfg_prop.grad_clip = 0.0, 2e-5, None     # small: Adam trajectories are chaotic in the gradient's low bits
     anchors = {"audio": syn.make_anchors(6), "video": syn.make_anchors(10)}
     cap, prop, psd = _deep_models(cfg_cap, cfg_prop, V, anchors)
     mixed = MixedTrainStep(cap, prop, cfg_cap, cfg_prop, syn.PAD_IDX)
@@ -252,6 +252,7 @@ def test_mixed_cap_prop_step_matches_oracle():
     ph = {k: v.clone().requires_grad_() for k, v in psd.items() if not k.startswith("encoder.")}
     st = {id(t): (torch.zeros_like(t), torch.zeros_like(t)) for t in list(pc.values()) + list(ph.values())}
     pmasks = orc.make_masks(pb["feature_stacks"], None, 1)
+    seen = []
     for it in (1, 2):
         closs, ploss = mixed((cfs, ccaps), (pfs, ptg))
         for t in list(pc.values()) + list(ph.values()):
@@ -271,5 +272,8 @@ def test_mixed_cap_prop_step_matches_oracle():
                 orc.adam_step(t, t.grad, st[id(t)][0], st[id(t)][1], it, cfg_prop.lr)
         assert abs(float(closs) - float(ol.detach())) < 2e-3, (it, float(closs), float(ol))
         assert abs(float(ploss) - float(opl.detach())) < 5e-3 * max(1.0, abs(float(opl.detach()))), (it, float(ploss), float(opl))
-    assert all(p.grad is None or True for p in prop.encoder.parameters())
+        seen.append((float(closs), float(ploss), float(ol.detach()), float(opl.detach())))
+    # both optimizers really stepped: the second round's losses moved, and in the oracle's direction
+    assert seen[1][0] != seen[0][0] and (seen[1][0] - seen[0][0]) * (seen[1][2] - seen[0][2]) > 0
+    assert seen[1][1] != seen[0][1] and (seen[1][1] - seen[0][1]) * (seen[1][3] - seen[0][3]) > 0
     assert prop.encoder is cap.encoder
