@@ -336,6 +336,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "graph", "overlap"],
+                    help="N > 1: hipGraphs with the all-reduce exposed between them, eager launches with the all-reduce overlapped with "
+                         "the backward pass, or (auto) whichever a short trial finds faster")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing protocol only (gloo, no GPU)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -383,14 +386,45 @@ def main():
     # of target events changes per batch).
     mode = "eager"
     run = lambda: step(*inputs)
+
+    def trial(fn, n=4):
+        """ms per step of n steps, max over ranks (mode selection; outside the timed region)"""
+        fn()
+        sync()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        v = torch.tensor([(time.perf_counter() - t_) / n * 1e3], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v[0])
+
     if cap and not args.no_graph:
-        try:
-            step.capture(*inputs, warmup=2)
-            run = lambda: step.replay()
-            mode = "hipgraph"
-        except Exception as exc:      # noqa: BLE001 -- e.g. a collective that refuses capture: keep measuring, say so
-            note(f"graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
-            torch.cuda.synchronize()
+        eager_ms = None
+        if world > 1 and args.dp_mode in ("auto", "overlap"):
+            # N > 1 has two ways to run the step: eager launches with the bucket all-reduces overlapped with the backward pass, or
+            # hipGraphs with the all-reduce exposed between them.  Both are timed briefly; the faster one is measured.
+            for _ in range(2):
+                step(*inputs)
+            eager_ms = trial(lambda: step(*inputs))
+            note(f"eager + overlapped all-reduce: {eager_ms:.2f} ms/step")
+        if not (world > 1 and args.dp_mode == "overlap"):
+            try:
+                step.capture(*inputs, warmup=2)
+                graph_ms = trial(lambda: step.replay()) if eager_ms is not None else None
+                if graph_ms is not None:
+                    note(f"hipGraphs + exposed all-reduce: {graph_ms:.2f} ms/step")
+                if eager_ms is not None and eager_ms < graph_ms:
+                    step.uncapture()
+                else:
+                    run = lambda: step.replay()
+                    mode = "hipgraph"
+            except Exception as exc:      # noqa: BLE001 -- e.g. a collective that refuses capture: keep measuring, say so
+                note(f"graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
+                torch.cuda.synchronize()
+        if mode == "eager" and world > 1:
+            mode = "eager+overlap"
     for _ in range(args.warmup):
         res = run()
     sync()

@@ -131,11 +131,13 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "res_offer", "last_ln", "kv_cache")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "res_offer", "last_ln", "kv_cache")
 
     def __init__(self):
-        self.defer_dw = False        # queue the weight-gradient products of this backward pass for one grouped launch (flush_dw)
+        self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
         self.pending_dw = []
+        self.pending_ids = set()     # parameters whose gradient product is queued: their "gradient final" report waits for the flush
+        self.pending_done = []
         self.res_offer = None        # residual offered by a ResidualConnection to its sublayer's last GEMM
         self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
         self.kv_cache = None         # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory, k planes, v planes)
@@ -591,10 +593,14 @@ def gemm_bf16_grouped(items):
         a.a_kmajor, a.b_kmajor = 1, 1
     dev = items[0][2].device
     need = int(lib.bmt_gemm_bf16_grouped_ws_bytes(n))
-    ws = _dw_ws.get((dev, n))
+    # the descriptor tables live in device memory until the launch has executed; several grouped launches of one backward pass
+    # (flush points) are in flight together, so the scratch buffers rotate (allocated in the eager warm-up steps, before a capture)
+    slot = _dw_ws.setdefault((dev, "turn"), [0])
+    slot[0] = (slot[0] + 1) % 8
+    ws = _dw_ws.get((dev, slot[0]))
     if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)     # (allocated in the eager warm-up steps, before a capture)
-        _dw_ws[(dev, n)] = ws
+        ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)
+        _dw_ws[(dev, slot[0])] = ws
     _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
 
 
@@ -602,22 +608,27 @@ def flush_dw():
     """issue the queued weight-gradient products (call after the backward pass, before anything reads the gradients)"""
     ctx = context()
     items, ctx.pending_dw = ctx.pending_dw, []
-    if not items:
-        return
-    if len(items) == 1 or not GROUPED_DW:
-        for dyT, xT, into in items:
-            gemm_bf16(dyT, xT, into, ldc=into.stride(0), accum=True, splitk=_splitk_for(dyT.cols, xT.cols, dyT.rows), precision=PREC_BF16,
-                      a_km=True, b_km=True)
-        return
-    gemm_bf16_grouped(items)
+    done, ctx.pending_done = ctx.pending_done, []
+    ctx.pending_ids.clear()
+    if items:
+        if len(items) == 1 or not GROUPED_DW:
+            for dyT, xT, into in items:
+                gemm_bf16(dyT, xT, into, ldc=into.stride(0), accum=True, splitk=_splitk_for(dyT.cols, xT.cols, dyT.rows), precision=PREC_BF16,
+                          a_km=True, b_km=True)
+        else:
+            gemm_bf16_grouped(items)
+    for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
+        grad_done(p)
 
 
-def linear_dw(dy: Planes, x: Planes, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+def linear_dw(dy: Planes, x: Planes, into: Optional[torch.Tensor] = None, params=()) -> Optional[torch.Tensor]:
     """dW[N,K] = dy[M,N]^T @ x[M,K]: both bf16 planes as stored, k-major (their rows are the reduction index).
-    into: accumulate straight into this (live) gradient buffer."""
+    into: accumulate straight into this (live) gradient buffer.  params: the parameter(s) ``into`` belongs to -- when the product
+    is queued for a grouped launch, their grad_done reports are held back until flush_dw has issued it."""
     ctx = context()
     if ctx.defer_dw and into is not None:
         ctx.pending_dw.append((dy, x, into))
+        ctx.pending_ids.update(id(p) for p in params)
         return None
     N, K, M = dy.cols, x.cols, dy.rows
     sk = _splitk_for(N, K, M)
@@ -652,6 +663,10 @@ def grad_done(p: Optional[torch.Tensor]):
     cb = getattr(p, "_bmt_on_grad", None) if p is not None else None
     if cb is None:
         return
+    ctx = context()
+    if id(p) in ctx.pending_ids:         # its weight-gradient product is still queued (ops.flush_dw reports it)
+        ctx.pending_done.append(p)
+        return
     left = getattr(p, "_bmt_uses", 1) - 1
     p._bmt_uses = left
     if left <= 0:
@@ -662,7 +677,7 @@ def wgrad(W, b, dyP: Planes, xP: Planes, dy2_for_bias=None, bias_sum=None):
     """weight and bias gradient of a Linear: returns (dW, db) tensors for autograd, or (None, None) after accumulating into
     the parameters' static buffers.  bias_sum: an already computed column sum (from grad_planes) or None."""
     gW = static_grad(W)
-    dW = linear_dw(dyP, xP, into=gW)
+    dW = linear_dw(dyP, xP, into=gW, params=(W,))
     if gW is not None:
         grad_done(W)
     db = None
@@ -908,7 +923,7 @@ def lin_bwd_planes(P: Planes, W, xP: Planes, need_dx: bool = True, **dx_epi):
     """dX = dY.W and dW += dY^T.X from the ready-made bf16 plane of dY (the bias gradient was produced with it)."""
     dx = linear_dx(P, W, **dx_epi) if need_dx else None
     gW = static_grad(W)
-    dW = linear_dw(P, xP, into=gW)
+    dW = linear_dw(P, xP, into=gW, params=(W,))
     if gW is not None:
         grad_done(W)
     return dx, dW
@@ -1356,7 +1371,7 @@ class MHAFn(torch.autograd.Function):
                 gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
             gW = group_static_grad(Ws)
             if gW is not None:
-                linear_dw(comb, xT, into=gW)
+                linear_dw(comb, xT, into=gW, params=Ws)
                 for W in Ws:
                     grad_done(W)
                 return dx, [None] * len(Ws)
@@ -1364,7 +1379,7 @@ class MHAFn(torch.autograd.Function):
             for W in Ws:
                 N = W.shape[0]
                 g1 = static_grad(W)
-                dWs.append(linear_dw(Planes(comb.hi[:, off:off + N], None, comb.rows, N), xT, into=g1))
+                dWs.append(linear_dw(Planes(comb.hi[:, off:off + N], None, comb.rows, N), xT, into=g1, params=(W,)))
                 if g1 is not None:
                     grad_done(W)
                 off += N

@@ -96,6 +96,32 @@ class CaptioningTrainStep:
         self._fused_scale = hasattr(self.optimizer, "grad_scale")
         self._graphs = None
         self._reduce_events = None      # bench: [(start, end)] HIP events around the exposed part of the gradient reduction
+        self._flush_points = 0
+        if data_parallel:
+            self._install_flush_points()
+
+    def _install_flush_points(self):
+        """Overlap of the gradient all-reduce with the backward pass (eager launches, ``reducer.overlap``): the weight-gradient
+        products are queued for grouped launches (ops.flush_dw), so a bucket's gradients are final only once its group has been
+        issued.  Flush points = the moments the backward pass crosses into an earlier encoder layer (the gradient w.r.t. a layer's
+        output arrives: everything after that layer -- later layers, decoder, generator -- has been differentiated): the queue is
+        flushed there, the finished buckets' RCCL all-reduces start behind it on the communication stream and run under the
+        remaining layers' backward.  ~1000 tiles per flush still fill the chip."""
+        from . import ops as _ops
+        stack = getattr(getattr(getattr(self.model, "encoder", None), "encoder_AV", None), "layers", None)
+        if stack is None:
+            return
+        step = self
+
+        def attach(mod, inp, out):
+            if not (step.reducer is not None and step.reducer.overlap and step.reducer.world > 1 and torch.is_grad_enabled()):
+                return
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(t, torch.Tensor) and t.requires_grad:
+                    t.register_hook(lambda g: (_ops.flush_dw(), g)[1])
+        for layer in stack:
+            layer.register_forward_hook(attach)
+            self._flush_points += 1
 
     # ---- the three phases -------------------------------------------------------------------------------------
     def _forward_backward(self, feature_stacks, caption_idx):
@@ -115,7 +141,9 @@ class CaptioningTrainStep:
         # bucket by bucket from the backward hooks, which needs them finished in autograd order
         from . import ops as _ops
         sctx = _ops.context()
-        sctx.defer_dw = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap)
+        # with bucket-by-bucket overlap the queue is flushed at the layer boundaries (_install_flush_points); without flush points
+        # the products run where autograd reaches them, so that a bucket is final when its last hook fires
+        sctx.defer_dw = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap or self._flush_points > 0)
         try:
             kl.backward()
             _ops.flush_dw()
@@ -148,7 +176,14 @@ class CaptioningTrainStep:
 
     def __call__(self, feature_stacks, caption_idx):
         kl, n_tokens = self._forward_backward(feature_stacks, caption_idx)
+        ev = self._reduce_events
+        if ev is not None:
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
         loss, _ = self._reduce(kl, n_tokens)
+        if ev is not None:
+            e_.record()
+            ev.append((s_, e_))
         self._optimize()
         return loss, n_tokens
 
@@ -178,6 +213,12 @@ class CaptioningTrainStep:
             self._optimize()
         self._graphs = (g1, g2)
         return self._graphs
+
+    def uncapture(self):
+        """back to eager launches (bucket all-reduces overlapped with the backward pass again)"""
+        self._graphs = None
+        if self.reducer is not None:
+            self.reducer.overlap = True
 
     def replay(self, feature_stacks=None, caption_idx=None):
         if feature_stacks is not None:
@@ -217,9 +258,14 @@ class CaptioningTrainStep:
         r = self.reducer
         if r is None:
             return None
-        return {"payload_mb": sum(b["flat"].numel() for b in r.buckets) * 4 / 1e6, "buckets": len(r.buckets),
-                "mode": "sum all-reduce (RCCL) of the flat fp32 gradient buckets between the backward graph and the optimizer graph, "
-                        "plus one scalar all-reduce (global n_tokens)"}
+        if self._graphs is not None:
+            mode = ("sum all-reduce (RCCL) of the flat fp32 gradient buckets between the backward graph and the optimizer graph (exposed), "
+                    "plus one scalar all-reduce (global n_tokens)")
+        else:
+            mode = (f"bucket all-reduces (RCCL) launched from the backward pass on the communication stream: the queued weight-gradient "
+                    f"products are flushed at {self._flush_points} encoder-layer boundaries and each finished bucket reduces under the "
+                    "remaining layers' backward; plus one scalar all-reduce (global n_tokens)")
+        return {"payload_mb": sum(b["flat"].numel() for b in r.buckets) * 4 / 1e6, "buckets": len(r.buckets), "mode": mode}
 
 
 class ProposalTrainStep:
