@@ -33,6 +33,7 @@ struct GemmB {
     int M, N, Kpad;
     int tiles_m, tiles_n, kchunk;
     int bm;                              // tile rows (128 or 256)
+    int pipe;                            // host: launch the LDS-DMA pipelined kernel (256 x 128 tiles)
     int conv_cin;                        // > 0: implicit Conv1d, channels per tap (padded width of the activation plane); see bmt_gemm_bf16_args
     int conv_rows;                       // rows of the halo-padded activation plane reachable from its base pointer
     int conv_S, conv_halo;               // sequence length and halo rows on each side of a sequence
@@ -60,27 +61,38 @@ __device__ __forceinline__ int slot_of(int row, int s) {
     else return row * 4 + (s ^ ((row >> 2) & 3));
 }
 
-// one operand plane, one stage: [ROWS rows][SPR slots]; thread t moves slots t, t+NT, ...
+// ---- operand tiles: global -> registers.  Every load is a buffer_load_dwordx4 through a wave-uniform descriptor: the per-lane byte
+// offset (row, 16-byte slot) is computed ONCE per tile, the reduction offset of a stage travels in an SGPR, and rows past the
+// operand's extent (k-major planes: reduction rows >= the true K) read as zero by the descriptor's bounds check -- no address
+// arithmetic, clamp or select in the stage loop (it was 25 vector instructions per stage and wave, PMC: profiles/r02_e_*).
+// Operand planes are therefore limited to 2 GiB each (checked by the host).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const uint16_t* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+template <int N>
+__device__ __forceinline__ void plane_bload(const __amdgpu_buffer_rsrc_t rs, const int (&voff)[N], int soff, u32x4 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0);
+}
+// per-lane byte offsets of the 16-byte slots thread tid moves (slot c = tid + NT i).  Row-major tile [ROWS rows][SPR slots]:
 template <int SPR, int ROWS, int NT>
-__device__ __forceinline__ void plane_gload(const uint16_t* base, int64_t ld, int r0, int nrows, int k0, int tid, u32x4 (&v)[ROWS * SPR / NT]) {
+__device__ __forceinline__ void plane_voff(int64_t ld, int r0, int nrows, int tid, int (&vo)[ROWS * SPR / NT]) {
 #pragma unroll
     for (int i = 0; i < ROWS * SPR / NT; ++i) {
         const int c = tid + NT * i;
-        const int row = min(r0 + c / SPR, nrows - 1);
-        v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + k0 + (c % SPR) * 8);
+        vo[i] = (int)((int64_t)min(r0 + c / SPR, nrows - 1) * ld * 2) + (c % SPR) * 16;
     }
 }
-// implicit Conv1d (forward / dX): the reduction index is (tap, channel); a stage lies inside one tap (cin % BK == 0) and reads the
-// activation rows shifted by that tap.  The activation plane is HALO-PADDED per sequence (zero rows between the batches), so no
-// per-row validity test is needed: output row m = b * S + s (compact) reads plane rows m + 2 b * halo + tap from a base pointer advanced by (halo - pad) rows;
-// the per-thread row bases are computed once (one integer division per row).
-template <int SPR, int ROWS, int NT>
-__device__ __forceinline__ void plane_gload_conv(const uint16_t* base, int64_t ld, const int (&abase)[ROWS * SPR / NT], int maxrow, int tap, int c0,
-                                                 int tid, u32x4 (&v)[ROWS * SPR / NT]) {
+// k-major tile [BK reduction rows][COLS columns] (reduction row of the stage added through the scalar offset); `shift`: extra rows
+// (implicit Conv1d dW: the activation rows of this tile's tap)
+template <int COLS, int BK, int NT>
+__device__ __forceinline__ void plane_voff_km(int64_t ld, int c0, int shift, int tid, int (&vo)[COLS * BK / 8 / NT]) {
+    constexpr int SPC = COLS / 8;
 #pragma unroll
-    for (int i = 0; i < ROWS * SPR / NT; ++i) {
+    for (int i = 0; i < COLS * BK / 8 / NT; ++i) {
         const int c = tid + NT * i;
-        v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(abase[i] + tap, maxrow) * ld + c0 + (c % SPR) * 8);
+        const int col = min(c0 + (c % SPC) * 8, (int)ld - 8);          // columns past the operand's extent: duplicates, discarded
+        vo[i] = (int)((int64_t)(c / SPC + shift) * ld * 2) + col * 2;
     }
 }
 template <int SPR, int ROWS, int NT>
@@ -99,19 +111,10 @@ __device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&
 // tools/probes/tr_probe.hip).  This removes every transposed plane from the model: weights, activations and gradients are
 // converted once, in one orientation.
 template <int COLS> constexpr int km_rs() { return COLS * 2 + 64; }
-template <int COLS, int BK, int NT>
-__device__ __forceinline__ void plane_gload_km(const uint16_t* base, int64_t ld, int c0, int k0, int krows, int tid,
-                                               u32x4 (&v)[COLS * BK / 8 / NT], int shift = 0, int maxrow = 0x7fffffff) {
-    constexpr int SPC = COLS / 8;
-#pragma unroll
-    for (int i = 0; i < COLS * BK / 8 / NT; ++i) {
-        const int c = tid + NT * i;
-        const int kr = k0 + c / SPC;
-        const int col = min(c0 + (c % SPC) * 8, (int)ld - 8);          // columns past the operand's extent: duplicates, discarded
-        const u32x4 x = *reinterpret_cast<const u32x4*>(base + (int64_t)min(min(kr, krows - 1) + shift, maxrow) * ld + col);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        v[i] = (kr < krows) ? x : z;                                   // select, not a guarded load
-    }
+constexpr int pipe_ring(int stage_bytes, int ti) {
+    const int budget = (ti == 2 ? 163840 : 81920) - 1024;
+    const int r = budget / stage_bytes;
+    return r > 4 ? 4 : (r < 2 ? 2 : r);
 }
 template <int COLS, int BK, int NT>
 __device__ __forceinline__ void plane_lstore_km(char* img, int tid, const u32x4 (&v)[COLS * BK / 8 / NT]) {
@@ -145,9 +148,14 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
 // CONV = 2: operand B (k-major) is that plane read with a per-TILE row shift (Conv1d dW: output column block = tap).
 // NPASS: 1 = A.B (one plane each); 2 = A.(Bh + Bl) (the activation as ONE plane, the weight split: the fp16 forward policy, two
 // MFMA passes); 3 = split-bf16 (Ah.Bh + Ah.Bl + Al.Bh).  F16: the planes hold fp16 values (v_mfma_f32_32x32x16_f16).
-template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false>
+// PIPE: the deep-pipelined main loop (row-major operands, 256 x 128 tile = WM 4, TI 2, one workgroup per CU): operand tiles go
+// global -> LDS by LDS-DMA (global_load_lds, no staging registers, no ds_write), a ring of R stage buffers with R - 1 tiles in
+// flight ACROSS the (single, raw) barrier of a stage, counted vmcnt -- cdna_hip_programming.md section 5 "pipelining across
+// barriers".  Everything around the loop (tile order, split-K, epilogue) is shared with the register-staged loop.
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
+    static_assert(!PIPE || (WM == 4 && !AKM && !BKM && CONV == 0 && NPASS <= 2), "pipelined loop: 8 waves, row-major operands");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = (NPASS == 1) ? 64 : 32;
     constexpr bool ALO = NPASS == 3, BLO = NPASS >= 2;
@@ -189,30 +197,40 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     constexpr int NRA = BM * SPR / NT, NRB = BN * SPR / NT;
     u32x4 ra0[NRA], rb0[NRB], ral0[NRA], rbl0[NRB];
     u32x4 ra1[NRA], rb1[NRB], ral1[NRA], rbl1[NRB];
-    int abase[NRA];                      // CONV == 1: halo-padded plane row of each staged output row
-    if constexpr (CONV == 1) {
+    // per-lane byte offsets of this thread's slots (loop invariant) and the descriptors of the operand planes
+    int avo[NRA], bvo[NRB];
+    if constexpr (!PIPE) {
+        if constexpr (CONV == 1) {           // halo-padded activation plane: output row m = b * S + s reads plane rows m + 2 b * halo (+ tap, per stage)
 #pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const int row = min(m0 + (tid + NT * i) / SPR, p.M - 1);
-            abase[i] = row + 2 * (row / p.conv_S) * p.conv_halo;       // + tap, from a base pointer advanced by halo - pad rows
-        }
+            for (int i = 0; i < NRA; ++i) {
+                const int c = tid + NT * i;
+                const int row = min(m0 + c / SPR, p.M - 1);
+                avo[i] = (int)((int64_t)(row + 2 * (row / p.conv_S) * p.conv_halo) * p.lda * 2) + (c % SPR) * 16;
+            }
+        } else if constexpr (AKM) plane_voff_km<BM, BK, NT>(p.lda, m0, 0, tid, avo);
+        else plane_voff<SPR, BM, NT>(p.lda, m0, p.M, tid, avo);
+        if constexpr (CONV == 2) plane_voff_km<BN, BK, NT>(p.ldb, n0 % p.conv_cin, n0 / p.conv_cin, tid, bvo);
+        else if constexpr (BKM) plane_voff_km<BN, BK, NT>(p.ldb, n0, 0, tid, bvo);
+        else plane_voff<SPR, BN, NT>(p.ldb, n0, p.N, tid, bvo);
     }
+    // extents: row-major planes end after their last row; k-major planes after reduction row K (later rows read as zero); the
+    // Conv1d activation plane after the rows reachable from its (advanced) base pointer
+    const int64_t a_bytes = (CONV == 1 ? (int64_t)p.conv_rows : (AKM ? (int64_t)p.krows : (int64_t)p.M)) * p.lda * 2;
+    const int64_t b_bytes = (CONV == 2 ? (int64_t)p.conv_rows : (BKM ? (int64_t)p.krows : (int64_t)p.N)) * p.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rsAh = plane_rsrc(p.Ah, a_bytes), rsAl = plane_rsrc(ALO ? p.Al : p.Ah, a_bytes);
+    const __amdgpu_buffer_rsrc_t rsBh = plane_rsrc(p.Bh, b_bytes), rsBl = plane_rsrc(BLO ? p.Bl : p.Bh, b_bytes);
     // stage image: A hi | B hi | [A lo] | [B lo]
 #define stage_ptr(buf_, which_) reinterpret_cast<u32x4*>(smem + (buf_) * STAGE_BYTES + ((which_) == 0 ? 0 : (which_) == 1 ? PA : (which_) == 2 ? PA + PBB : (ALO ? 2 : 1) * PA + PBB))
 #define BMT_GLOAD(s_, RA, RB, RAL, RBL)                                                   \
     do {                                                                                  \
         const int k_ = min(kbeg + (s_) * BK, kend - BK);   /* branch-free tail: re-fetch the last stage */ \
-        if constexpr (CONV == 1) plane_gload_conv<SPR, BM, NT>(p.Ah, p.lda, abase, p.conv_rows - 1, k_ / p.conv_cin, k_ % p.conv_cin, tid, RA); \
-        else if constexpr (AKM) plane_gload_km<BM, BK, NT>(p.Ah, p.lda, m0, k_, p.krows, tid, RA);   \
-        else plane_gload<SPR, BM, NT>(p.Ah, p.lda, m0, p.M, k_, tid, RA);                 \
-        if constexpr (CONV == 2) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0 % p.conv_cin, k_, p.krows, tid, RB, n0 / p.conv_cin, p.conv_rows - 1); \
-        else if constexpr (BKM) plane_gload_km<BN, BK, NT>(p.Bh, p.ldb, n0, k_, p.krows, tid, RB);   \
-        else plane_gload<SPR, BN, NT>(p.Bh, p.ldb, n0, p.N, k_, tid, RB);                 \
-        if constexpr (ALO) {                                                              \
-            if constexpr (CONV == 1) plane_gload_conv<SPR, BM, NT>(p.Al, p.lda, abase, p.conv_rows - 1, k_ / p.conv_cin, k_ % p.conv_cin, tid, RAL); \
-            else plane_gload<SPR, BM, NT>(p.Al, p.lda, m0, p.M, k_, tid, RAL);            \
-        }                                                                                 \
-        if constexpr (BLO) plane_gload<SPR, BN, NT>(p.Bl, p.ldb, n0, p.N, k_, tid, RBL);  \
+        /* scalar byte offset of the stage: k columns (row-major), k rows (k-major), (tap rows, channel) (Conv1d) */ \
+        const int sa_ = (CONV == 1) ? ((k_ / p.conv_cin) * (int)p.lda + k_ % p.conv_cin) * 2 : (AKM ? k_ * (int)p.lda * 2 : k_ * 2); \
+        const int sb_ = BKM ? k_ * (int)p.ldb * 2 : k_ * 2;                               \
+        plane_bload<NRA>(rsAh, avo, sa_, RA);                                             \
+        plane_bload<NRB>(rsBh, bvo, sb_, RB);                                             \
+        if constexpr (ALO) plane_bload<NRA>(rsAl, avo, sa_, RAL);                         \
+        if constexpr (BLO) plane_bload<NRB>(rsBl, bvo, sb_, RBL);                         \
     } while (0)
 #define BMT_LSTORE(buf_, RA, RB, RAL, RBL)                                                \
     do {                                                                                  \
@@ -255,6 +273,82 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         __builtin_amdgcn_s_setprio(0);                                                    \
     } while (0)
 
+    if constexpr (PIPE) {
+        // ---- ring geometry: one step = BK reduction indices of A [BM rows] | B hi [128 rows] | (B lo); 1 KB pieces, one per
+        // wave-instruction (64 lanes x 16 B, LDS destination = piece base + 16 lane); the XOR swizzle of the 16-byte slots is applied
+        // on the SOURCE side (lane -> which k-slot of its row it fetches), so the image is exactly what slot_of<SPR> reads.
+        // Loads are buffer_load ... lds: the per-lane byte offset is loop invariant, the reduction offset advances in an SGPR and
+        // the LDS address goes through M0 from scalar arithmetic -- no vector instruction per load.  The step loop is unrolled by
+        // the ring depth so that every LDS address of a step is a loop-invariant register plus an immediate.
+        constexpr int RPP = 1024 / (BK * 2);                   // rows per piece: 16 (BK 32) / 8 (BK 64)
+        constexpr int PA_PIECES = BM / RPP, PB_PIECES = BN / RPP;
+        constexpr int APW = PA_PIECES / 8, BPW = PB_PIECES / 8; // pieces per wave
+        constexpr int LPT = APW + (BLO ? 2 : 1) * BPW;          // LDS-DMA instructions per thread per step
+        constexpr int R = pipe_ring(STAGE_BYTES, TI);
+        const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+        const int rl = lane / SPR, sp = lane % SPR;             // row within the piece, slot POSITION within the row
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsBl = __builtin_amdgcn_make_buffer_rsrc((void*)(BLO ? p.Bl : p.Bh), 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+        int avo[APW], bvo[BPW];
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int row = (wid_s * APW + i) * RPP + rl;
+            const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
+            avo[i] = (int)((int64_t)min(m0 + row, p.M - 1) * p.lda * 2) + ks * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int row = (wid_s * BPW + i) * RPP + rl;
+            const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
+            bvo[i] = (int)((int64_t)min(n0 + row, p.N - 1) * p.ldb * 2) + ks * 16;
+        }
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#define BMT_DMA(step_, slot_)                                                                                    \
+        do {                                                                                                     \
+            char* base_ = smem + (slot_) * STAGE_BYTES;                                                          \
+            const int so_ = (kbeg + (step_) * BK) * 2;                                                           \
+            _Pragma("unroll") for (int i = 0; i < APW; ++i)                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base_ + (wid_s * APW + i) * 1024), 16, avo[i], so_, 0, 0);          \
+            _Pragma("unroll") for (int i = 0; i < BPW; ++i)                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(base_ + PA + (wid_s * BPW + i) * 1024), 16, bvo[i], so_, 0, 0);     \
+            if constexpr (BLO) {                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < BPW; ++i)                                                  \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBl, (lptr_t)(base_ + PA + PBB + (wid_s * BPW + i) * 1024), 16, bvo[i], so_, 0, 0); \
+            }                                                                                                    \
+        } while (0)
+#define BMT_VMWAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+        // one step: tile `step_` (in ring slot `slot_`, a compile-time constant) has landed once at most min(R - 2, later tiles)
+        // younger tiles are still in flight; after the barrier every wave's pieces of it are in LDS and every wave is done reading
+        // tile step_ - 1, whose slot the next DMA overwrites
+#define BMT_STEP(step_, slot_)                                                                                   \
+        do {                                                                                                     \
+            const int younger_ = min(R - 2, niter - 1 - (step_));                                                \
+            if (younger_ >= 2) BMT_VMWAIT(2 * LPT);                                                              \
+            else if (younger_ == 1) BMT_VMWAIT(LPT);                                                             \
+            else BMT_VMWAIT(0);                                                                                  \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            if ((step_) + R - 1 < niter) BMT_DMA((step_) + R - 1, ((slot_) + R - 1) % R);                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            BMT_COMPUTE(slot_);                                                                                  \
+        } while (0)
+        const int niter = (kend - kbeg) / BK;
+#pragma unroll
+        for (int s0 = 0; s0 < R - 1; ++s0)
+            if (s0 < niter) BMT_DMA(s0, s0);
+        int t = 0;
+        for (; t + R <= niter; t += R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) BMT_STEP(t + r, r);
+        }
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r)
+            if (t + r < niter) BMT_STEP(t + r, r);
+#undef BMT_STEP
+#undef BMT_DMA
+#undef BMT_VMWAIT
+        __syncthreads();      // the epilogue reuses the stage buffers
+    } else {
     const int niter = (kend - kbeg) / BK;     // >= 1: the host never launches an empty split
     BMT_GLOAD(0, ra0, rb0, ral0, rbl0);
     BMT_GLOAD(1, ra1, rb1, ral1, rbl1);
@@ -277,6 +371,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     if (t < niter) BMT_COMPUTE(0);
     __syncthreads();      // the epilogue reuses the stage buffers
 
+    }
     // ---------------- split-K, two passes: each split stores its raw partial tile (plain coalesced fp32 stores) into
     // ws[split][Mpad][Npad]; splitk_epilogue_kernel sums the splits and runs the epilogue.  Used for GEMMs with too few tiles to
     // fill the chip and a long reduction (the k-loop is a chain of dependent ~2 us memory round trips: 24 tiles x 16 stages is
@@ -423,6 +518,10 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false>
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
     gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, CONV, F16>(p, blockIdx.x, blockIdx.y);
+}
+template <int NPASS, bool F16, int TI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_pipe_kernel(const GemmB p) {
+    gemm_bf16_tile<NPASS, 4, TI, false, false, 0, F16, true>(p, blockIdx.x, blockIdx.y);
 }
 
 // MANY independent GEMMs in one launch (the weight gradients of a whole step: each dW = dY^T . X is too small to fill the chip
@@ -681,6 +780,23 @@ int launch(const GemmB& p, int splitk, hipStream_t st) {
     return BMT_OK;
 }
 
+template <int NPASS, bool F16, int TI>
+int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
+    constexpr int BK = (NPASS == 1) ? 64 : 32;
+    constexpr int BMr = 128 * TI;
+    constexpr int stage = BMr * BK * 2 + (NPASS >= 2 ? 2 : 1) * BN * BK * 2;
+    constexpr int R = pipe_ring(stage, TI);
+    constexpr int lds = (R * stage > BMr * BN * 4) ? R * stage : BMr * BN * 4;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(512), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16(pipelined)");
+    return BMT_OK;
+}
+
 }  // namespace
 
 // validate the arguments and fill the kernel descriptor; splitk: in = 0 (decide here) / forced value, out = splits to launch
@@ -704,6 +820,14 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     if (!(al16(a->A_hi) && al16(a->B_hi)) || ((a->lda | a->ldb) & 7) || (a->A_lo && !al16(a->A_lo)) || (a->B_lo && !al16(a->B_lo))) {
         bmt_set_error("bmt_gemm_bf16: planes must be 16-byte aligned with row strides multiples of 8 elements");
         return BMT_EALIGN;
+    }
+    {   // operand tiles are fetched with 32-bit byte offsets (buffer loads): a plane must stay below 2 GiB
+        const int64_t a_rows = a->conv_mode == 1 ? a->conv_rows : (a->a_kmajor ? a->K : a->M);
+        const int64_t b_rows = a->conv_mode == 2 ? a->conv_rows : (a->b_kmajor ? a->K : a->N);
+        BMT_CHECK_ARG(a_rows * a->lda * 2 < (1ll << 31) && b_rows * a->ldb * 2 < (1ll << 31) &&
+                          (!a->a_kmajor || (int64_t)a->Kpad * a->lda * 2 < (1ll << 31)) && (!a->b_kmajor || (int64_t)a->Kpad * a->ldb * 2 < (1ll << 31)),
+                      "bmt_gemm_bf16: an operand plane of 2 GiB or more (rows %lld x ld %lld / rows %lld x ld %lld)", (long long)a_rows,
+                      (long long)a->lda, (long long)b_rows, (long long)a->ldb);
     }
     splitk = a->splitk < 1 ? 1 : a->splitk;
     if (!allow_split) splitk = 1;
@@ -731,6 +855,17 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.bm = 128;
     if (force_bm == 128 || force_bm == 256) p.bm = force_bm;
     if (a->a_kmajor || a->b_kmajor || a->conv_mode || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2) p.bm = 128;
+    // the LDS-DMA pipelined kernel: row-major operands, a reduction long enough to fill its ring, and enough 256 x 128 tiles for
+    // the 256 CUs (it runs one workgroup per CU)
+    static const int force_pipe = getenv("BMT_GEMM_PIPE") ? atoi(getenv("BMT_GEMM_PIPE")) : -1;    // A/B experiments only
+    // measured (tools/microbench.py, profiles/r02_*): the 128-row pipelined tile (two workgroups per CU) beats the register-staged
+    // loop on every row-major shape of the step (+6..+19 %); the 256-row tile (one workgroup per CU) only wins for K >= 4096
+    p.pipe = 0;
+    if (!a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = 2;
+
+    if (force_pipe == 0) p.pipe = 0;
+    if (force_pipe >= 1 && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = force_pipe;   // 1: 256-row tile, 2: 128-row tile
+    if (p.pipe == 1) p.bm = 256;
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3 || a->precision == BMT_PREC_F16W2) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
@@ -781,7 +916,15 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
         return BMT_EINVAL;
     }
-    if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
+    if (p.pipe == 1) {
+        if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 2>(p, splitk, st_);
+        else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 2>(p, splitk, st_);
+        else rc = launch_pipe<1, false, 2>(p, splitk, st_);
+    } else if (p.pipe == 2) {
+        if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 1>(p, splitk, st_);
+        else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 1>(p, splitk, st_);
+        else rc = launch_pipe<1, false, 1>(p, splitk, st_);
+    } else if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
         if (a->precision == BMT_PREC_F16W2) rc = launch<2, 4, 1, false, false, 1, true>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch<1, 4, 1, false, false, 1, true>(p, splitk, st_);
         else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1, false, false, 1>(p, splitk, st_) : launch<1, 4, 1, false, false, 1>(p, splitk, st_);
