@@ -703,6 +703,221 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// =================================================================================== forward, single pass, 64-key stages
+// The single-pass forward (fp16 or bf16 operands) rebuilt around its instruction budget.  PMC / ISA of attn_fwd16_kernel
+// (profiles/r02_*): per 32-key stage a wave issues 32 MFMAs (~540 matrix-pipe cycles) next to ~270 vector, ~175 scalar and ~60 LDS
+// instructions -- the loop is issue-bound, not MFMA- or LDS-bound.  Here:
+//   * 64-key stages (the per-stage bookkeeping -- mask classification, rescale test, loop control -- is paid half as often);
+//   * K / V tiles are fetched with buffer loads: per-lane byte offsets computed once, the key offset of a stage in an SGPR,
+//     rows past Sk read as zero by the descriptor's bounds check (no clamp / 64-bit address arithmetic per stage);
+//   * the LDS images are double buffered: the next stage is written while the current one is read, ONE barrier per stage;
+//   * softmax in the log2 domain: p = exp2(fma(s, scale * log2 e, -m)) is one fma + one v_exp_f32 per score;
+//   * the two cross-lane reductions (max, sum over the lanes l ^ 16, l ^ 32 that share a query) use v_permlane16/32_swap
+//     instead of ds_bpermute round trips.
+// Same decomposition as attn_fwd16_kernel: 8 waves x 16 queries, S^T = K.Q^T with v_mfma_f32_16x16x32, P^T feeds O^T += V^T.P^T
+// from registers, V^T fragments through ds_read_b64_tr_b16 from the padded row image.
+// v_permlane16_swap / v_permlane32_swap exchange lanes between TWO registers: with both holding x, afterwards a = {x.row0, x.row0,
+// x.row2, x.row2} and b = {x.row1, x.row1, x.row3, x.row3} (rows of 16 lanes) resp. a = {x.lo32, x.lo32}, b = {x.hi32, x.hi32}
+// (tools/probes/permlane_probe.hip): op(a, b) is the reduction over lanes l ^ 16 resp. l ^ 32 without an LDS round trip.  Inline
+// asm: hipcc (ROCm 7.2) folds the builtin's two results into one when they feed a commutative op (max(r0, r1) vanished, r0 + r1
+// became r0 + r0); the `s_nop 1` covers the VALU-write -> permlane-read hazard the compiler would otherwise pad.
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float xlane_max(float x) {          // max over lanes {l, l^16, l^32, l^48}
+    float a = x, b = x;
+    swap16(a, b);
+    a = b = fmaxf(a, b);
+    swap32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float xlane_sum(float x) {
+    float a = x, b = x;
+    swap16(a, b);
+    a = b = a + b;
+    swap32(a, b);
+    return a + b;
+}
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+template <int DK, bool F16>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd64_kernel(const AttnPB p) {
+    constexpr int BC = 64, NT = 512, KS = DK / 32, DT = DK / 16, RS = pad_rs<DK>();
+    constexpr int TILE = BC * RS, STAGE = 2 * TILE;            // K image | V image
+    constexpr int NR = rows_n<DK, BC, NT>();                   // 16-byte slots per thread and operand (4 at d_k 256)
+    constexpr int SPR = DK / 8;
+    static_assert(BC * SPR % NT == 0, "whole slots per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 2 * STAGE);       // [2][64]
+    int* sFlag = reinterpret_cast<int*>(sMask + 128);                    // [2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 16 + c;
+    const bool qok = q < p.Sq;
+
+    bf16x8 qf[KS];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
+    }
+    f32x4v o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_INF, l_run = 0.f;       // running maximum in log2 units (scores are scaled by scale * log2 e)
+    const float sc2 = p.scale * LOG2E;
+    constexpr float TAU2 = RESCALE_TAU * LOG2E;
+    const int troff = tr_lane_off(RS, c, g);
+
+    // K / V rows of this (b, h): descriptors end after the last key row, so a stage that runs past Sk reads zeros there
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    int kvo[NR], vvo[NR], lso[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int s_ = tid + NT * i;
+        kvo[i] = (s_ / SPR) * (int)p.ldk * 2 + (s_ % SPR) * 16;
+        vvo[i] = (s_ / SPR) * (int)p.ldv * 2 + (s_ % SPR) * 16;
+        lso[i] = (s_ / SPR) * RS + (s_ % SPR) * 16;
+    }
+    const int ntile = (p.Sk + BC - 1) / BC;
+    u32x4 kr[NR], vr[NR];
+#define BMT_F64_FETCH(t_)                                                                              \
+    do {                                                                                               \
+        const int so_k = (t_) * BC * (int)p.ldk * 2, so_v = (t_) * BC * (int)p.ldv * 2;                \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[i], so_k, 0); \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[i], so_v, 0); \
+    } while (0)
+#define BMT_F64_STORE(t_, buf_)                                                                        \
+    do {                                                                                               \
+        char* sk_ = smem + (buf_) * STAGE;                                                             \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sk_ + lso[i]) = kr[i];        \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sk_ + TILE + lso[i]) = vr[i]; \
+        stage_mask<BC>(p, b, (t_) * BC, tid, sMask + (buf_) * 64, sFlag + (buf_));                      \
+    } while (0)
+    BMT_F64_FETCH(0);
+    BMT_F64_STORE(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        const int tn = min(t + 1, ntile - 1);              // the last stage re-fetches itself (branch-free)
+        BMT_F64_FETCH(tn);
+        const int flag = sFlag[cur];
+        if (flag != 0) {
+            const char* sK = smem + cur * STAGE;
+            const char* sV = sK + TILE;
+            const int key0 = t * BC;
+            f32x4v st[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) st[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    st[kt] = mfma16t<F16>(rowfrag_pad<DK>(sK, kt * 16 + c, 4 * ks + g), qf[ks], st[kt]);
+            __builtin_amdgcn_s_setprio(0);
+            float x[16];                                   // scores in log2 units; lane (c, g): key = key0 + 16 kt + 4 g + r, query c
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[4 * kt + r] = st[kt][r] * sc2;
+            if (flag != 2) {
+                if (p.mask != nullptr && p.mask_qs != 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = key0 + 16 * (i >> 2) + 4 * g + (i & 3);
+                        const bool ok = qok && key < p.Sk && p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
+                        x[i] = ok ? x[i] : NEG_INF;
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) {
+                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + cur * 64 + 16 * kt + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[4 * kt + r] = ((mw >> (8 * r)) & 0xffu) ? x[4 * kt + r] : NEG_INF;
+                    }
+                }
+            }
+            float tmax = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+#pragma unroll
+            for (int i = 4; i < 16; i += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(x[i], x[i + 1]), fmaxf(x[i + 2], x[i + 3])));
+            tmax = xlane_max(tmax);
+            if (__any(tmax > m_run + TAU2)) {              // stale-reference online softmax (see attn_fwd_bf16_kernel): exact
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == NEG_INF) ? 0.f : m_new));
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+                m_run = m_new;
+            }
+            const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                x[i] = __builtin_amdgcn_exp2f(x[i] - m_use);
+                psum += x[i];
+            }
+            l_run += xlane_sum(psum);
+            // B operands of O^T += V^T . P^T, one per 32-key half: reduction index kk = 8 g + j <-> key 4 g + j (j < 4) / 16 + 4 g + j - 4
+            bf16x8 pf[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                u32x4 pw;
+                pw[0] = pack_2<F16>(x[8 * hf + 0], x[8 * hf + 1]); pw[1] = pack_2<F16>(x[8 * hf + 2], x[8 * hf + 3]);
+                pw[2] = pack_2<F16>(x[8 * hf + 4], x[8 * hf + 5]); pw[3] = pack_2<F16>(x[8 * hf + 6], x[8 * hf + 7]);
+                pf[hf] = as_bf16x8(pw);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[dt] = mfma16t<F16>(trfrag<DK>(sV + troff, dt), pf[0], o[dt]);
+                o[dt] = mfma16t<F16>(trfrag<DK>(sV + troff + 32 * RS, dt), pf[1], o[dt]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        BMT_F64_STORE(tn, cur ^ 1);                        // nobody reads that image now: its readers passed the previous barrier
+        __syncthreads();
+    }
+#undef BMT_F64_FETCH
+#undef BMT_F64_STORE
+
+    if (qok) {
+        const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
+        const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + 4 * g;
+            float4 v;
+            v.x = drop_apply(dc, o[dt][0] * inv, (uint64_t)(rowoff + d + 0));
+            v.y = drop_apply(dc, o[dt][1] * inv, (uint64_t)(rowoff + d + 1));
+            v.z = drop_apply(dc, o[dt][2] * inv, (uint64_t)(rowoff + d + 2));
+            v.w = drop_apply(dc, o[dt][3] * inv, (uint64_t)(rowoff + d + 3));
+            if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
+            if (p.Owh) {
+                const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + d;
+                uint32_t h0, l0, h1, l1;
+                split_bf2(v.x, v.y, h0, l0);
+                split_bf2(v.z, v.w, h1, l1);
+                if (p.ow_f16) { l0 = pack_h2(v.x, v.y); l1 = pack_h2(v.z, v.w); }
+                u32x2 hh, ll;
+                hh[0] = h0; hh[1] = h1; ll[0] = l0; ll[1] = l1;
+                *reinterpret_cast<u32x2*>(p.Owh + po) = hh;
+                if (p.Owl) *reinterpret_cast<u32x2*>(p.Owl + po) = ll;
+            }
+        }
+        if (g == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run * LN2 + __logf(l_run);
+    }
+}
+
 // =================================================================================== backward
 // delta[b,h,q] = (1-p) * sum_d dO[b,q,h*DK+d] * O[b,q,h*DK+d]  (fp32 inputs), and the bf16 plane of dO for the MFMAs
 __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, int DK, uint16_t* dOh) {
@@ -1321,6 +1536,22 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 template <int DK, int NPASS, bool F16 = false>
 int launch_fwd(const AttnPB& p, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
+    static const int old_fwd = getenv("BMT_ATTN_FWD_OLD") ? atoi(getenv("BMT_ATTN_FWD_OLD")) : 0;      // A/B experiments only
+    if constexpr (DK >= 128 && NPASS == 1) {
+        // K / V rows are fetched with 32-bit byte offsets from the (batch, head) base
+        const bool fits = ((int64_t)p.Sk * p.ldk * 2 < (1ll << 31)) && ((int64_t)p.Sk * p.ldv * 2 < (1ll << 31));
+        if (!old_fwd && fits) {
+            const int lds = 2 * 2 * 64 * (DK * 2 + 32) + 256;
+            static bool done64 = false;
+            if (!done64) {
+                (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel<DK, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done64 = true;
+            }
+            hipLaunchKernelGGL((attn_fwd64_kernel<DK, F16>), dim3(nblk), dim3(512), lds, st, p);
+            BMT_CHECK_LAUNCH("bmt_attn_fwd_bf16");
+            return BMT_OK;
+        }
+    }
     if constexpr (DK >= 128) {        // 8 waves x 16 queries, two waves per SIMD
         const int lds = (NPASS == 3 ? 2 : 1) * (2 * 32 * (DK * 2 + 32)) + 128;
         static bool done = false;
