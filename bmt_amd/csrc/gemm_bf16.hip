@@ -52,7 +52,22 @@ struct GemmB {
     uint32_t site;
     float* ws;                           // split-K partials [split][tiles_m*128][tiles_n*128] (two-pass mode), or nullptr
     int nsplit;
+#ifdef BMT_EXP
+    int exp;                             // experiment build only (BMT_ALT_FLAGS=-DBMT_EXP, env BMT_EXP): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue,
+    int exp_shift; int exp_sleep;                       // 8 every other workgroup starts exp_sleep x 3.4 us late (env BMT_EXP_SLEEP)
+#endif
 };
+#ifdef BMT_EXP
+#define BMT_EXP_ON(bit_) ((p.exp & (bit_)) != 0)
+__device__ unsigned long long bmt_dbg[8 * 8192];      // per tile: start, loop end, staged, done, hw id
+#define BMT_STAMP(slot_)                                                                              \
+    do {                                                                                              \
+        if (BMT_EXP_ON(16) && threadIdx.x == 0 && tile_id < 8192) bmt_dbg[tile_id * 8 + (slot_)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define BMT_EXP_ON(bit_) false
+#define BMT_STAMP(slot_)
+#endif
 
 // LDS slot of (row, 16-byte slot) for rows of SPR slots
 template <int SPR>
@@ -111,6 +126,9 @@ __device__ __forceinline__ void plane_lstore(u32x4* img, int tid, const u32x4 (&
 // tools/probes/tr_probe.hip).  This removes every transposed plane from the model: weights, activations and gradients are
 // converted once, in one orientation.
 template <int COLS> constexpr int km_rs() { return COLS * 2 + 64; }
+// reduction indices per stage: 64 (128-byte rows: a full cache line per row and DMA request) wherever a ring of >= 2 stages fits
+// the LDS; the two-plane products on the 128-row tile and the three-pass product stage 32
+constexpr int gemm_bk(int npass, bool pipe, int ti) { return (npass == 1 || (npass == 2 && pipe && ti == 2)) ? 64 : 32; }
 constexpr int pipe_ring(int stage_bytes, int ti) {
     const int budget = (ti == 2 ? 163840 : 81920) - 1024;
     const int r = budget / stage_bytes;
@@ -157,7 +175,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
     static_assert(!PIPE || (WM == 4 && !AKM && !BKM && CONV == 0 && NPASS <= 2), "pipelined loop: 8 waves, row-major operands");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
-    constexpr int BK = (NPASS == 1) ? 64 : 32;
+    constexpr int BK = gemm_bk(NPASS, PIPE, TI);
     constexpr bool ALO = NPASS == 3, BLO = NPASS >= 2;
     constexpr int SPR = BK / 8;
     constexpr int BM = 32 * TI * WM, NT = 128 * WM;       // WM waves along M x 2 along N
@@ -190,6 +208,16 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    BMT_STAMP(0);
+#ifdef BMT_EXP
+    if (BMT_EXP_ON(16) && threadIdx.x == 0 && tile_id < 8192) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        bmt_dbg[tile_id * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+    if (BMT_EXP_ON(8) && (int)blockIdx.x < 512 && (((int)blockIdx.x >> p.exp_shift) & 1))
+        for (int i = 0; i < p.exp_sleep; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
     // Two register sets: the global loads of stage t+2 are issued before the MFMAs of stage t, so every load has two
     // iterations (two barriers) to land -- with 2 workgroups per CU and ~0.2 us of MFMA work per stage a single stage of
@@ -328,9 +356,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             else if (younger_ == 1) BMT_VMWAIT(LPT);                                                             \
             else BMT_VMWAIT(0);                                                                                  \
             __builtin_amdgcn_s_barrier();                                                                        \
-            if ((step_) + R - 1 < niter) BMT_DMA((step_) + R - 1, ((slot_) + R - 1) % R);                        \
+            if ((step_) + R - 1 < niter && !BMT_EXP_ON(1)) BMT_DMA((step_) + R - 1, ((slot_) + R - 1) % R);      \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            BMT_COMPUTE(slot_);                                                                                  \
+            if (!BMT_EXP_ON(2)) BMT_COMPUTE(slot_);                                                              \
         } while (0)
         const int niter = (kend - kbeg) / BK;
 #pragma unroll
@@ -389,128 +417,182 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
                     part[(int64_t)(m0 + wr * 32 * TI + i * 32 + acc_row(r, half)) * ldw + n0 + wc * 64 + j * 32 + l31] = acc[i][j][r];
         return;
     }
-    // ---------------- epilogue (same order as bmt_gemm: alpha, bias, dropout_pre, relu, dropout_post, gate, residual)
-    // fp32 C: each store instruction covers 128 contiguous bytes of two rows.  bf16 plane outputs would be 2-byte stores in
-    // that mapping, so they are staged through the (now idle) 64 KB of stage buffers as packed (hi | lo << 16) words and
-    // written out as full 16-byte row segments.
-    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
-    const unsigned f = p.flags;
-    uint32_t* ct = reinterpret_cast<uint32_t*>(smem);   // [BM][128] packed planes of this tile
-    // plane-only output with a gate: the mask is applied to whole 16-byte row segments in the write-out pass below (one vector
-    // load of the gate plane per segment instead of a 2-byte load per accumulator element); only the scale is applied here
-    const bool defer_gate = (f & BMT_EPI_GATE) && p.Chi && p.plane_vec && !p.C && !(f & BMT_EPI_RESIDUAL) &&
-                            (p.ldg % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.gate) & 15) == 0);
+    BMT_STAMP(1);
+#ifdef BMT_EXP
+    if (BMT_EXP_ON(4)) {
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
+        if (t_ == 12345.678f) p.C[0] = t_;
+        return;
+    }
+#endif
+    // ---------------- epilogue (order: alpha, bias, dropout_pre, relu, dropout_post, gate, residual), in row-segment form.
+    // The accumulators go through the (now idle) stage buffers as an fp32 [BM][128] tile; then each thread owns 8 consecutive
+    // columns (fixed for the thread: bias and column sums live in registers) and walks rows.  Every global access of a segment is
+    // a 16-byte vector (C: 2 x float4, planes: 8 x 16 bit, gate plane, residual), the flags are tested once per segment instead of
+    // once per element, and there is one bounds decision per segment.  (The element-wise form this replaces -- one divergent
+    // row / column test, six flag tests and a 64-bit index per accumulator register -- took 35 % of a K = 1024 product:
+    // tools/probes/gemm_exp.py, BMT_EXP=4.)
+    if (p.flags == BMT_EPI_ACCUM && !p.Chi) {
+        // C += alpha * acc and nothing else (weight gradients, possibly several products into one buffer): atomics straight from the
+        // accumulators -- 32 lanes of an instruction hit 32 consecutive floats of a row, which the L2 handles as one 128-byte request
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wc * 64 + j * 32 + l31;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wr * 32 * TI + i * 32 + acc_row(r, half);
+                    if (row < p.M) atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+                }
+            }
+        return;
+    }
+    float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + l31;
-            const bool cin = col < p.N;
-            if (!cin && !(p.Chi && col < p.plane_cols)) continue;
-            const float bv = (cin && (f & BMT_EPI_BIAS)) ? p.bias[col] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wr * 32 * TI + i * 32 + acc_row(r, half);
-                const int row = m0 + rl;
-                if (row >= p.M) continue;
-                float v = 0.f;
-                if (cin) {
-                    v = acc[i][j][r] * p.alpha + bv;
-                    const int64_t idx = (int64_t)row * p.ldc + col;
-                    if (f & BMT_EPI_DROP_PRE) v = drop_apply(dc, v, (uint64_t)idx);
-                    if (f & BMT_EPI_RELU) v = fmaxf(v, 0.f);
-                    if (f & BMT_EPI_DROP_POST) v = drop_apply(dc, v, (uint64_t)idx);
-                    if (f & BMT_EPI_GATE) {
-                        if (defer_gate) v *= p.gate_scale;
-                        else v = (p.gate[(int64_t)row * p.ldg + col] & 0x7fffu) ? v * p.gate_scale : 0.f;
-                    }
-                    if (f & BMT_EPI_RESIDUAL) v += p.residual[(int64_t)row * p.ldr + col];
-                    if (f & BMT_EPI_ACCUM) atomicAdd(p.C + idx, v);
-                    else if (p.C) p.C[idx] = v;
+            for (int r = 0; r < 16; ++r)
+                ct[(wr * 32 * TI + i * 32 + acc_row(r, half)) * BN + wc * 64 + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    BMT_STAMP(2);
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    const unsigned f = p.flags;
+    const int cg = (tid & 15) * 8;
+    const int col = n0 + cg;
+    const int pcols = p.Chi ? p.plane_cols : 0;
+    const bool active = col < p.N || col < pcols;
+    const bool full = col + 8 <= p.N;                                         // all 8 columns inside the product
+    const bool c_vec = p.C && full && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const bool r_vec = full && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
+    const bool g_vec = full && ((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gate) & 15) == 0);
+    float bv[8], cs8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        bv[q] = ((f & BMT_EPI_BIAS) && col + q < p.N) ? p.bias[col + q] : 0.f;
+        cs8[q] = 0.f;
+    }
+#pragma unroll 2
+    for (int ps = 0; ps < BM * 16 / NT; ++ps) {
+        const int rl = ps * (NT / 16) + (tid >> 4);
+        const int row = m0 + rl;
+        if (row >= p.M || !active) continue;
+        float v[8];
+        {
+            const float4 t0 = *reinterpret_cast<const float4*>(ct + rl * BN + cg);
+            const float4 t1 = *reinterpret_cast<const float4*>(ct + rl * BN + cg + 4);
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        }
+        const int64_t idx = (int64_t)row * p.ldc + col;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = v[q] * p.alpha + bv[q];
+        if (f & BMT_EPI_DROP_PRE) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+        }
+        if (f & BMT_EPI_RELU) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (f & BMT_EPI_DROP_POST) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+        }
+        if (f & BMT_EPI_GATE) {            // keep an element iff the saved forward output is non-zero (sign bit ignored)
+            const uint16_t* gp = p.gate + (int64_t)row * p.ldg + col;
+            if (g_vec) {
+                const u32x4 gv = *reinterpret_cast<const u32x4*>(gp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = (gv[q] & 0x00007FFFu) ? v[2 * q] * p.gate_scale : 0.f;
+                    v[2 * q + 1] = (gv[q] & 0x7FFF0000u) ? v[2 * q + 1] * p.gate_scale : 0.f;
                 }
-                if (p.Chi) {
-                    const __bf16 hv = (__bf16)v;
-                    const uint32_t hb = __builtin_bit_cast(uint16_t, hv);
-                    const uint32_t lb = p.second_f16 ? (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v)
-                                                     : (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(v - (float)hv));
-                    if (p.plane_vec) {
-                        ct[rl * 128 + wc * 64 + j * 32 + l31] = hb | (lb << 16);
-                    } else {
-                        const int64_t pi = (int64_t)row * p.ldp + col;
-                        p.Chi[pi] = (uint16_t)hb;
-                        if (p.Clo) p.Clo[pi] = (uint16_t)lb;
-                    }
-                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (col + q < p.N && (gp[q] & 0x7fffu)) ? v[q] * p.gate_scale : 0.f;
             }
         }
-    if (p.Chi && p.plane_vec) {      // uniform per launch
+        if (f & BMT_EPI_RESIDUAL) {
+            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            if (r_vec) {
+                const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (col + q < p.N) v[q] += rp[q];
+            }
+        }
+        if (!full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q >= p.N) v[q] = 0.f;                               // plane columns past N hold zeros
+        }
+        if (f & BMT_EPI_ACCUM) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q < p.N) atomicAdd(p.C + idx + q, v[q]);
+        } else if (c_vec) {
+            *reinterpret_cast<float4*>(p.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.C + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (p.C) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q < p.N) p.C[idx + q] = v[q];
+        }
+        if (p.colsum) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs8[q] += v[q];
+        }
+        if (p.Chi && col < pcols) {
+            u32x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t h_, l_;
+                split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
+                h[q] = h_;
+                l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
+            }
+            const int64_t pi = (int64_t)row * p.ldp + col;
+            if (p.plane_vec) {
+                *reinterpret_cast<u32x4*>(p.Chi + pi) = h;
+                if (p.Clo) *reinterpret_cast<u32x4*>(p.Clo + pi) = l;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (col + q < pcols) {
+                        p.Chi[pi + q] = (uint16_t)(h[q >> 1] >> (16 * (q & 1)));
+                        if (p.Clo) p.Clo[pi + q] = (uint16_t)(l[q >> 1] >> (16 * (q & 1)));
+                    }
+            }
+        }
+    }
+    BMT_STAMP(3);
+    if (p.colsum) {                  // uniform per launch.  Lanes 16 apart share a column group: fold them, then the waves through LDS
+        __syncthreads();             // every staged row has been read
+        float* cs = reinterpret_cast<float*>(smem);      // [NT / 64][128]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float t = cs8[q];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (lane < 16) cs[wid * BN + cg + q] = t;
+        }
         __syncthreads();
-        const int cg = (tid & 15) * 8;
-        const int col = n0 + cg;
-        float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of this thread's 8 columns over its rows
+        if (tid < BN && n0 + tid < p.N) {
+            float t = 0.f;
 #pragma unroll
-        for (int ps = 0; ps < BM * 16 / NT; ++ps) {
-            const int rl = ps * (NT / 16) + (tid >> 4);
-            const int row = m0 + rl;
-            if (row < p.M && col < p.plane_cols) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(ct + rl * 128 + cg);
-                const u32x4 b = *reinterpret_cast<const u32x4*>(ct + rl * 128 + cg + 4);
-                u32x4 h;
-                h[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); h[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
-                h[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); h[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
-                u32x4 gm = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                if (defer_gate) {     // keep an element iff the saved forward output is non-zero (sign bit ignored)
-                    const u32x4 gv = (col + 8 <= p.N) ? *reinterpret_cast<const u32x4*>(p.gate + (int64_t)row * p.ldg + col) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        gm[q] = ((gv[q] & 0x00007FFFu) ? 0x0000FFFFu : 0u) | ((gv[q] & 0x7FFF0000u) ? 0xFFFF0000u : 0u);
-                    if (col + 8 > p.N) {   // ragged last segment: element-wise
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c0_ = col + 2 * q;
-                            const uint32_t g0 = (c0_ < p.N && (p.gate[(int64_t)row * p.ldg + c0_] & 0x7fffu)) ? 0x0000FFFFu : 0u;
-                            const uint32_t g1 = (c0_ + 1 < p.N && (p.gate[(int64_t)row * p.ldg + c0_ + 1] & 0x7fffu)) ? 0xFFFF0000u : 0u;
-                            gm[q] = g0 | g1;
-                        }
-                    }
-                    h[0] &= gm[0]; h[1] &= gm[1]; h[2] &= gm[2]; h[3] &= gm[3];
-                }
-                if (p.colsum) {       // hi + lo of the staged value (16 significant bits), masked like the output
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t w0 = (q < 2 ? a[2 * q] : b[2 * q - 4]) & ((gm[q] & 0xFFFFu) ? 0xFFFFFFFFu : 0u);
-                        const uint32_t w1 = (q < 2 ? a[2 * q + 1] : b[2 * q - 3]) & ((gm[q] >> 16) ? 0xFFFFFFFFu : 0u);
-                        cs8[2 * q] += bf_bits2f(w0 & 0xFFFFu) + bf_bits2f(w0 >> 16);
-                        cs8[2 * q + 1] += bf_bits2f(w1 & 0xFFFFu) + bf_bits2f(w1 >> 16);
-                    }
-                }
-                *reinterpret_cast<u32x4*>(p.Chi + (int64_t)row * p.ldp + col) = h;
-                if (p.Clo) {
-                    u32x4 l;
-                    l[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
-                    l[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u); l[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
-                    l[0] &= gm[0]; l[1] &= gm[1]; l[2] &= gm[2]; l[3] &= gm[3];
-                    *reinterpret_cast<u32x4*>(p.Clo + (int64_t)row * p.ldp + col) = l;
-                }
-            }
-        }
-        if (p.colsum) {              // lanes 16 apart share a column group: fold them, then the waves through LDS
-            __syncthreads();         // every staged row has been read
-            float* cs = reinterpret_cast<float*>(smem);      // [NT / 64][128]
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float v = cs8[q];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (lane < 16) cs[wid * 128 + cg + q] = v;
-            }
-            __syncthreads();
-            if (tid < 128 && n0 + tid < p.N) {
-                float t = 0.f;
-#pragma unroll
-                for (int w_ = 0; w_ < NT / 64; ++w_) t += cs[w_ * 128 + tid];
-                atomicAdd(p.colsum + n0 + tid, t);
-            }
+            for (int w_ = 0; w_ < NT / 64; ++w_) t += cs[w_ * BN + tid];
+            atomicAdd(p.colsum + n0 + tid, t);
         }
     }
 }
@@ -521,7 +603,335 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
 }
 template <int NPASS, bool F16, int TI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_pipe_kernel(const GemmB p) {
-    gemm_bf16_tile<NPASS, 4, TI, false, false, 0, F16, true>(p, blockIdx.x, blockIdx.y);
+    // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so a workgroup stays on
+    // the XCD its tiles were ordered for); its stores drain while the next tile's operands are already on their way
+    const int ntiles = p.tiles_m * p.tiles_n;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        gemm_bf16_tile<NPASS, 4, TI, false, false, 0, F16, true>(p, t, blockIdx.y);
+        __syncthreads();          // the stage buffers (epilogue tile) are free again
+    }
+}
+
+
+// ===================================================================== 256 x 256 tile, 8 waves, two wave groups in ping-pong
+// The 128-row tiles above are bound by the L2 -> LDS path (tools/probes/gemm_exp.py: DMA alone 46 us, MFMA + LDS alone 55 us, both
+// 73 us for 8192 x 4096 x 1024; ~23 TB/s of operand tiles) and by LDS reads (1.5 KB per 32x32x16 MFMA).  This kernel follows the
+// 256 x 256 "8-phase" structure of cdna_hip_programming.md: half the operand bytes per FLOP, 0.75 KB of fragment reads per MFMA.
+//   * C^T = W . X^T: the weight rows take the MFMA's A role, the activation rows the B role, so a lane's accumulator registers
+//     are consecutive OUTPUT COLUMNS of one output row (4 per register group, 8 after one v_permlane32_swap): the epilogue
+//     stores 16-byte row segments straight from registers -- no LDS round trip, no barrier;
+//   * 8 waves = 2 (W halves of 128 rows: the two groups) x 4 (64 activation rows each); wave tile 128 x 64 = 4 x 2 accumulators
+//     of 32 x 32; a K-tile of 64 is worked in 4 phases of 8 MFMAs (quadrants (w0,x0) (w0,x1) (w1,x1) (w1,x0): 8 + 4, 4, 8, 0
+//     fragment reads), every phase = {fragment reads + this phase's share of the next K-tile's LDS-DMA} barrier {MFMAs} barrier.
+//     Group 1 runs one barrier behind group 0, so on every SIMD one wave issues MFMAs while the other reads -- the matrix pipe
+//     never waits for a barrier or for LDS latency of its own wave;
+//   * LDS: 2 K-tile slots x {W0, W1, X0, X1} half-tiles of [128 rows][64 k] (16 KB, XOR-swizzled 16-byte slots, filled by
+//     buffer_load ... lds with the swizzle on the source side) = 128 KB; K-tile t+1 is requested during phases 0 and 1 of K-tile t
+//     and waited for (vmcnt(0): nothing younger is in flight) in phase 3, one barrier before its first read;
+//   * NPASS 2 (activation fp16 x weight fp16 hi + lo) runs the K loop twice over the activation with the second weight plane --
+//     the same instruction stream, 2 K / 64 K-tiles.
+template <bool F16>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wide_kernel(const GemmB p) {
+    constexpr int HT = 16384, SLOT = 4 * HT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // tile order: XCD remap, then groups of 8 activation panels walked panel-first (the ~32 tiles an XCD runs together share
+    // 8 activation panels and 4 weight panels in its L2)
+    const int tiles_m = p.tiles_m, tiles_n = p.tiles_n;       // activation / weight panels of 256 rows
+    const int w = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+    const int per_group = 8 * tiles_n;
+    const int g = w / per_group, first_m = g * 8;
+    const int gsz = min(tiles_m - first_m, 8);
+    const int wi = w - g * per_group;
+    const int m0 = (first_m + wi % gsz) * 256, n0 = (wi / gsz) * 256;
+
+    // ---- LDS-DMA: a half-tile is 16 pieces of 1 KB (8 rows x 128 B); wave w fills pieces 2w, 2w+1 (rows 16w .. 16w+15)
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsWh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsWl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Bl ? p.Bl : p.Bh), 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+    int xvo[2], wvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * wid + 8 * j + (lane >> 3);
+        const int ks = (lane & 7) ^ ((row >> 1) & 7);
+        xvo[j] = row * (int)p.lda * 2 + ks * 16;
+        wvo[j] = row * (int)p.ldb * 2 + ks * 16;
+    }
+    const int T1 = p.Kpad / 64;
+    const int T = p.Bl ? 2 * T1 : T1;
+#define BMT_W_DMA_W(t_, slot_)                                                                                       \
+    do {                                                                                                             \
+        const bool lo_ = (t_) >= T1;                                                                                 \
+        const __amdgpu_buffer_rsrc_t rs_ = lo_ ? rsWl : rsWh;                                                        \
+        const int k_ = ((t_) - (lo_ ? T1 : 0)) * 128;                                                                \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lptr_t)(smem + (slot_) * SLOT + hf * HT + (2 * wid + j) * 1024), 16, wvo[j], \
+                                                         (n0 + 128 * hf) * (int)p.ldb * 2 + k_, 0, 0);              \
+    } while (0)
+#define BMT_W_DMA_X(t_, slot_)                                                                                       \
+    do {                                                                                                             \
+        const int k_ = ((t_) >= T1 ? (t_) - T1 : (t_)) * 128;                                                        \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(smem + (slot_) * SLOT + (2 + hf) * HT + (2 * wid + j) * 1024), 16, xvo[j], \
+                                                         (m0 + 128 * hf) * (int)p.lda * 2 + k_, 0, 0);              \
+    } while (0)
+
+    // ---- fragment addresses: lane (l31 = row of the 32-row fragment, half) reads slot (2 s + half) ^ swizzle(row) for k16 step s
+    int offW[4], offX[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int o = l31 * 128 + (((2 * s + half) ^ ((l31 >> 1) & 7)) * 16);
+        offW[s] = o + wr * HT;
+        offX[s] = o + (2 + (wc >> 1)) * HT + (wc & 1) * 8192;
+    }
+#define BMT_W_FRAG(slot_, off_, i_) as_bf16x8(*reinterpret_cast<const u32x4*>(smem + (slot_) * SLOT + (off_) + (i_) * 4096))
+#define BMT_W_BAR()                                  \
+    do {                                             \
+        __builtin_amdgcn_sched_barrier(0);           \
+        __builtin_amdgcn_s_barrier();                \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
+    bf16x8 wa[2][4], xb0[4], xb1[4];
+
+    // one K-tile in slot e (compile-time): 4 phases
+#define BMT_W_MFMA(ib_, xb_, bcol_)                                                                                  \
+    do {                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                acc[(ib_) + i][bcol_] = mfma32t<F16>(wa[i][s], xb_[s], acc[(ib_) + i][bcol_]);                       \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+    } while (0)
+#define BMT_W_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define BMT_W_KTILE(e_, t_)                                                                                          \
+    do {                                                                                                             \
+        const bool next2_ = (t_) + 2 < T;                                                                            \
+        /* phase 0: quadrant (w0, x0) */                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) xb0[s] = BMT_W_FRAG(e_, offX[s], 0);                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) wa[i][s] = BMT_W_FRAG(e_, offW[s], i);                     \
+        BMT_W_LGKM0();                                                                                               \
+        BMT_W_BAR();                                                                                                 \
+        BMT_W_MFMA(0, xb0, 0);                                                                                       \
+        BMT_W_BAR();                                                                                                 \
+        /* phase 1: (w0, x1) */                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) xb1[s] = BMT_W_FRAG(e_, offX[s], 1);                           \
+        BMT_W_LGKM0();                                                                                               \
+        BMT_W_BAR();                                                                                                 \
+        BMT_W_MFMA(0, xb1, 1);                                                                                       \
+        BMT_W_BAR();                                                                                                 \
+        /* phase 2: (w1, x1); the activation half-tiles of this slot were last read in phase 1 by both groups (their reads      \
+           retired before the barrier that ended it): K-tile t + 2 may overwrite them */                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) wa[i][s] = BMT_W_FRAG(e_, offW[s], 2 + i);                 \
+        if (next2_) BMT_W_DMA_X((t_) + 2, e_);                                                                       \
+        BMT_W_LGKM0();                                                                                               \
+        BMT_W_BAR();                                                                                                 \
+        BMT_W_MFMA(2, xb1, 1);                                                                                       \
+        BMT_W_BAR();                                                                                                 \
+        /* phase 3: (w1, x0), operands in registers.  K-tile t + 1 has landed (only this phase 2's requests are younger) before  \
+           the barrier that precedes its first read; the weight half-tiles of this slot are free now */              \
+        if (next2_) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                 \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        if (next2_) BMT_W_DMA_W((t_) + 2, e_);                                                                       \
+        BMT_W_BAR();                                                                                                 \
+        BMT_W_MFMA(2, xb0, 0);                                                                                       \
+        BMT_W_BAR();                                                                                                 \
+    } while (0)
+
+#ifdef BMT_EXP
+    const int tile_id = (int)blockIdx.x;
+#endif
+    BMT_STAMP(0);
+    BMT_W_DMA_W(0, 0);
+    BMT_W_DMA_X(0, 0);
+    if (T > 1) {
+        BMT_W_DMA_W(1, 1);
+        BMT_W_DMA_X(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BMT_W_BAR();
+    BMT_STAMP(1);
+    if (wr == 1) BMT_W_BAR();                  // group 1 runs one barrier behind group 0
+    for (int t = 0; t < T; t += 2) {
+        BMT_W_KTILE(0, t);
+        if (t + 1 < T) BMT_W_KTILE(1, t + 1);
+    }
+    if (wr == 0) BMT_W_BAR();
+    BMT_STAMP(2);
+#undef BMT_W_LGKM0
+#undef BMT_W_KTILE
+#undef BMT_W_MFMA
+#undef BMT_W_BAR
+#undef BMT_W_FRAG
+#undef BMT_W_DMA_W
+#undef BMT_W_DMA_X
+
+    // ---------------- epilogue (order: alpha, bias, dropout_pre, relu, dropout_post, gate, residual).
+    // acc[i][b][r]: output row m = m0 + 64 wc + 32 b + l31, column n = n0 + 128 wr + 32 i + 8 (r >> 2) + 4 half + (r & 3): a lane
+    // holds 4 consecutive columns of a row per register group.  Stored from there every instruction would touch 32 rows x 32 bytes
+    // (measured: 2.4 TB/s over the chip, 28 us per tile).  Each wave therefore turns its tile through a PRIVATE 8 KB LDS chunk
+    // ([32 rows][64 columns] fp32, 16-byte slots XOR-swizzled by the row, no barrier -- only the wave's own lgkmcnt) and writes
+    // 8-column row segments: an instruction covers 8 rows x 256 contiguous bytes (C) / 128 bytes (each plane).  The residual /
+    // gate segments of the next step are requested before this step's stores (the stores may alias them, so the compiler would
+    // otherwise serialise load -> store round trips).
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    const unsigned f = p.flags;
+    const int pcols = p.Chi ? p.plane_cols : 0;
+    const bool c_al = p.C && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const bool pre_r = (f & BMT_EPI_RESIDUAL) && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
+    const bool pre_g = (f & BMT_EPI_GATE) && ((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gate) & 15) == 0);
+    char* chunk = smem + SLOT + wid * 8192;                  // the second K-tile slot is idle now
+    const int cgl = (lane & 7) * 8, rsel = lane >> 3;        // this lane's 8 columns of the 64-column chunk, row within a step of 8
+    float4 rr[2][2];
+    u32x4 rg[2];
+    // step st (0 .. 15): chunk ch = st >> 2 = (b, i pair), rows 8 (st & 3) + rsel of the chunk
+    auto seg_row = [&](int st) { return m0 + 64 * wc + 32 * (st >> 3) + 8 * (st & 3) + rsel; };
+    auto seg_col = [&](int st) { return n0 + 128 * wr + 64 * ((st >> 2) & 1) + cgl; };
+    auto prefetch = [&](int st, int buf) {
+        const int row = seg_row(st), col = seg_col(st);
+        const bool ok = row < p.M && col + 8 <= p.N;
+        if (pre_r && ok) {
+            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            rr[buf][0] = *reinterpret_cast<const float4*>(rp);
+            rr[buf][1] = *reinterpret_cast<const float4*>(rp + 4);
+        }
+        if (pre_g && ok) rg[buf] = *reinterpret_cast<const u32x4*>(p.gate + (int64_t)row * p.ldg + col);
+    };
+    float bv[8];
+    prefetch(0, 0);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int b = ch >> 1, ip = ch & 1;
+        // registers -> chunk: fragment i = 2 ip + ii, register group j: 4 columns 32 ii + 8 j + 4 half .. of row l31
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = (32 * ii + 8 * j + 4 * half) >> 2;
+                float4 t;
+                t.x = acc[2 * ip + ii][b][4 * j + 0] * p.alpha; t.y = acc[2 * ip + ii][b][4 * j + 1] * p.alpha;
+                t.z = acc[2 * ip + ii][b][4 * j + 2] * p.alpha; t.w = acc[2 * ip + ii][b][4 * j + 3] * p.alpha;
+                *reinterpret_cast<float4*>(chunk + l31 * 256 + ((slot ^ (l31 & 15)) * 16)) = t;
+            }
+        if (f & BMT_EPI_BIAS) {
+            const int col = n0 + 128 * wr + 64 * ip + cgl;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bv[q] = (col + q < p.N) ? p.bias[col + q] : 0.f;
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int st = 4 * ch + s4, buf = st & 1;
+            if (st + 1 < 16) prefetch(st + 1, buf ^ 1);
+            const int rl = 8 * s4 + rsel;
+            const int row = seg_row(st), col = seg_col(st);
+            float v[8];
+            {
+                const float4 t0 = *reinterpret_cast<const float4*>(chunk + rl * 256 + (((cgl >> 2) ^ (rl & 15)) * 16));
+                const float4 t1 = *reinterpret_cast<const float4*>(chunk + rl * 256 + ((((cgl >> 2) + 1) ^ (rl & 15)) * 16));
+                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+            }
+            if (row >= p.M || (col >= p.N && col >= pcols)) continue;
+            const bool full = col + 8 <= p.N;
+            const int64_t idx = (int64_t)row * p.ldc + col;
+            if (f & BMT_EPI_BIAS) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += bv[q];
+            }
+            if (f & BMT_EPI_DROP_PRE) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+            }
+            if (f & BMT_EPI_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (f & BMT_EPI_DROP_POST) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+            }
+            if (f & BMT_EPI_GATE) {
+                if (full && pre_g) {
+                    const u32x4 gv = rg[buf];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] = (gv[q] & 0x00007FFFu) ? v[2 * q] * p.gate_scale : 0.f;
+                        v[2 * q + 1] = (gv[q] & 0x7FFF0000u) ? v[2 * q + 1] * p.gate_scale : 0.f;
+                    }
+                } else {
+                    const uint16_t* gp = p.gate + (int64_t)row * p.ldg + col;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (col + q < p.N && (gp[q] & 0x7fffu)) ? v[q] * p.gate_scale : 0.f;
+                }
+            }
+            if (f & BMT_EPI_RESIDUAL) {
+                if (full && pre_r) {
+                    const float4 t0 = rr[buf][0], t1 = rr[buf][1];
+                    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                } else {
+                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (col + q < p.N) v[q] += rp[q];
+                }
+            }
+            if (!full) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (col + q >= p.N) v[q] = 0.f;
+            }
+            if (p.C) {
+                if (full && c_al) {
+                    *reinterpret_cast<float4*>(p.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(p.C + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (col + q < p.N) p.C[idx + q] = v[q];
+                }
+            }
+            if (p.Chi && col < pcols) {
+                u32x4 h, l;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t h_, l_;
+                    split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
+                    h[q] = h_;
+                    l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
+                }
+                const int64_t pi = (int64_t)row * p.ldp + col;
+                if (p.plane_vec) {
+                    *reinterpret_cast<u32x4*>(p.Chi + pi) = h;
+                    if (p.Clo) *reinterpret_cast<u32x4*>(p.Clo + pi) = l;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (col + q < pcols) {
+                            p.Chi[pi + q] = (uint16_t)(h[q >> 1] >> (16 * (q & 1)));
+                            if (p.Clo) p.Clo[pi + q] = (uint16_t)(l[q >> 1] >> (16 * (q & 1)));
+                        }
+                }
+            }
+        }
+    }
+    BMT_STAMP(3);
 }
 
 // MANY independent GEMMs in one launch (the weight gradients of a whole step: each dW = dY^T . X is too small to fill the chip
@@ -782,7 +1192,7 @@ int launch(const GemmB& p, int splitk, hipStream_t st) {
 
 template <int NPASS, bool F16, int TI>
 int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
-    constexpr int BK = (NPASS == 1) ? 64 : 32;
+    constexpr int BK = gemm_bk(NPASS, true, TI);
     constexpr int BMr = 128 * TI;
     constexpr int stage = BMr * BK * 2 + (NPASS >= 2 ? 2 : 1) * BN * BK * 2;
     constexpr int R = pipe_ring(stage, TI);
@@ -792,12 +1202,34 @@ int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI>), dim3(p.tiles_m * p.tiles_n, splitk), dim3(512), lds, st, p);
+    static const int persist = getenv("BMT_GEMM_PERSIST") ? atoi(getenv("BMT_GEMM_PERSIST")) : 1;      // A/B experiments only
+    const int tiles = p.tiles_m * p.tiles_n, slots = bmt_device_cus() * (TI == 2 ? 1 : 2);
+    const int gx = (persist && tiles > slots && slots % 8 == 0) ? slots : tiles;
+    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI>), dim3(gx, splitk), dim3(512), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(pipelined)");
     return BMT_OK;
 }
 
+template <bool F16>
+int launch_wide(const GemmB& p, hipStream_t st) {
+    constexpr int lds = 2 * 4 * 16384;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_wide_kernel<F16>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16(256 x 256)");
+    return BMT_OK;
+}
+
 }  // namespace
+
+#ifdef BMT_EXP
+extern "C" int bmt_dbg_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bmt_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // validate the arguments and fill the kernel descriptor; splitk: in = 0 (decide here) / forced value, out = splits to launch
 static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool allow_split) {
@@ -865,14 +1297,28 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
 
     if (force_pipe == 0) p.pipe = 0;
     if (force_pipe >= 1 && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = force_pipe;   // 1: 256-row tile, 2: 128-row tile
+    // the 256 x 256 ping-pong kernel: row-major operands, plain epilogues (no column sums / accumulation / split-K)
+    static const int force_wide = getenv("BMT_GEMM_WIDE") ? atoi(getenv("BMT_GEMM_WIDE")) : -1;    // A/B experiments only
+    const bool wide_ok = p.pipe != 0 && !a->colsum && !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && a->N >= 256 &&
+                         (int64_t)(a->M + 256) * a->lda * 2 < (1ll << 31) && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31);
+    // measured (tools/microbench.py gemm, BMT_GEMM_WIDE=0/1): it wins where a launch has at least one full round of 256 x 256
+    // tiles and a reduction long enough to amortise its prologue (8192 x 4096 x 1024 two-plane 169 -> 134 us, 8192 x 2048 x 1024
+    // 87 -> 68 us); 128 tiles (half the CUs) or K = 128 (output-write bound either way) stay on the 128-row tiles
+    const int wide_tiles = bmt_cdiv(a->M, 256) * bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
+    if (wide_ok && (force_wide == 1 || (force_wide < 0 && force_pipe < 0 && wide_tiles >= bmt_device_cus() && a->Kpad >= 256))) p.pipe = 3;
+    if (p.pipe == 3) {
+        p.bm = 256;
+        p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
+        if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;      // the kernel runs its second pass iff there is a second weight plane
+    }
     if (p.pipe == 1) p.bm = 256;
     p.tiles_m = bmt_cdiv(a->M, p.bm);
-    const int bk = (a->precision == BMT_PREC_BF16X3 || a->precision == BMT_PREC_F16W2) ? 32 : 64;
+    const int bk = (a->precision == BMT_PREC_BF16X3 || (a->precision == BMT_PREC_F16W2 && p.pipe != 1)) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
     static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 256;          // A/B experiments only
     static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 4;
-    if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt) {
+    if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt && p.pipe != 3) {
         // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
         static const int sk_target = getenv("BMT_SPLITK_TARGET") ? atoi(getenv("BMT_SPLITK_TARGET")) : 512;           // A/B experiments only
         int want = sk_target / tiles, cap = ktiles / 2;
@@ -896,6 +1342,11 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.colsum = a->colsum;
     BMT_CHECK_ARG(!a->colsum || (a->C_hi && p.plane_vec && !a->C), "bmt_gemm_bf16: colsum needs 16-byte aligned plane-only output");
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
+#ifdef BMT_EXP
+    p.exp = getenv("BMT_EXP") ? atoi(getenv("BMT_EXP")) : 0;
+    p.exp_sleep = getenv("BMT_EXP_SLEEP") ? atoi(getenv("BMT_EXP_SLEEP")) : 3;
+    p.exp_shift = getenv("BMT_EXP_SHIFT") ? atoi(getenv("BMT_EXP_SHIFT")) : 3;
+#endif
     return BMT_OK;
 }
 
@@ -916,7 +1367,9 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
         return BMT_EINVAL;
     }
-    if (p.pipe == 1) {
+    if (p.pipe == 3) {
+        rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
+    } else if (p.pipe == 1) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 2>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 2>(p, splitk, st_);
         else rc = launch_pipe<1, false, 2>(p, splitk, st_);

@@ -8,7 +8,7 @@ cd $R
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 s=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$s" ] && cp "$s" gpurun_out/${TAG}_rocprofv3_kernel_stats_raw.csv
-python tools/prof_summary.py "$t" gpurun_out/${TAG}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps $STEPS --warmup 3 --no-graph --no-cpu-baseline --no-kernel-timer  ($((STEPS + 3)) eager steps incl. warm-up)"
+python tools/prof_summary.py "$t" gpurun_out/${TAG}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps $STEPS --warmup 3 --no-graph --no-cpu-baseline --no-kernel-timer  ($((STEPS + 3)) eager steps incl. warm-up)" $((STEPS + 3)) gpurun_out/${TAG}_last_step_trace.csv
 head -45 gpurun_out/${TAG}_kernel_stats.csv
 tail -2 gpurun_out/${TAG}_prof_run.log
 rm -rf gpurun_out/prof_$TAG

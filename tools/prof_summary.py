@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 --kernel-trace run (rocpd sqlite .db or *_kernel_trace.csv) into a per-kernel stats CSV:
-name, calls, total_ms, avg_us, min_us, max_us, pct.   usage: prof_summary.py <in.db|in.csv> <out.csv> [note]"""
+name, calls, total_ms, avg_us, min_us, max_us, pct.   usage: prof_summary.py <in.db|in.csv> <out.csv> [note] [steps last_step.csv]
+With ``steps`` (the number of identical eager steps in the run) and a csv input, the dispatches of the LAST step are also written in
+issue order: kernel, grid, workgroup, duration us, idle gap before it us."""
 import csv
 import re
 import sqlite3
@@ -42,5 +44,27 @@ def main():
                         f"{100 * a[1] / tot:.2f}"])
 
 
+def last_step(src, steps, dst):
+    with open(src) as f:
+        rows = list(csv.DictReader(f))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    n = len(rows) // steps
+    rows = rows[-n:]
+    with open(dst, "w", newline="") as f:
+        f.write(f"# last of {steps} eager steps: {n} dispatches, {(int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp'])) / 1e6:.3f} ms from first start to last end\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid", "workgroup", "us", "gap_us"])
+        prev = None
+        for r in rows:
+            name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            name = re.sub(r"^void ", "", name).split("(")[0][:70]
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            w.writerow([name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
+                        f"{(en - st) / 1e3:.2f}", f"{(st - prev) / 1e3:.2f}" if prev is not None else ""])
+            prev = en
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 5 and sys.argv[1].endswith(".csv"):
+        last_step(sys.argv[1], int(sys.argv[4]), sys.argv[5])
     main()
