@@ -1149,20 +1149,31 @@ __global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
 }
 
 // the vector kernel applies when there is a straight hi plane and nothing transposed, everything 16-byte aligned
-static bool planes_rows_ok(const PlaneDesc& d) {
+static bool planes_straight_ok(const PlaneDesc& d) {
     static const int old = getenv("BMT_PLANES_OLD") ? atoi(getenv("BMT_PLANES_OLD")) : 0;        // A/B experiments only
-    return !old && (d.hi || d.fh) && !d.hiT && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
+    return !old && (d.hi || d.fh) && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
            ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.hi) | reinterpret_cast<uintptr_t>(d.lo) |
              reinterpret_cast<uintptr_t>(d.fh) | reinterpret_cast<uintptr_t>(d.fl)) & 15) == 0;
 }
+static bool planes_rows_ok(const PlaneDesc& d) { return planes_straight_ok(d) && !d.hiT; }
 
 // every weight of the model in ONE launch: blockIdx.y = tensor, blockIdx.x strides over its 64x64 tiles
 __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __restrict__ table) {
     __shared__ float tile[64][65];
     const PlaneDesc d = table[blockIdx.y];
-    if (d.rows_ok) {                 // straight planes only, aligned: the 16-byte path (64 x 128 tiles)
+    if (d.rows_ok) {                 // straight planes aligned: the 16-byte path (64 x 128 tiles)
         const int ntx = (d.pcols + 127) / 128, nt = ntx * ((d.R + 63) / 64);
         for (int t = blockIdx.x; t < nt; t += gridDim.x) planes_rows_tile(d, t % ntx, t / ntx, nullptr);
+        if (d.rows_ok == 2) {        // + a transposed bf16 plane (the row-major B operand of the dX products): 64 x 64 tiles through LDS
+            PlaneDesc dt = d;
+            dt.hi = dt.lo = dt.fh = dt.fl = nullptr;
+            dt.pcols = 0;
+            const int tx_ = (d.C + 63) / 64, nt2 = tx_ * d.tiles_y;
+            for (int t = blockIdx.x; t < nt2; t += gridDim.x) {
+                planes_tile(dt, t % tx_, t / tx_, tile);
+                __syncthreads();
+            }
+        }
         return;
     }
     const int nt = d.tiles_x * d.tiles_y;
@@ -1580,7 +1591,7 @@ extern "C" int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int
     memset(&d, 0, sizeof(d));
     int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, hiT, loT, ldpT, nullptr);
     if (rc) return rc;
-    d.rows_ok = planes_rows_ok(d) ? 1 : 0;
+    d.rows_ok = planes_straight_ok(d) ? (d.hiT ? 2 : 1) : 0;
     memcpy(desc_out, &d, sizeof(d));
     return BMT_OK;
 }

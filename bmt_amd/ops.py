@@ -280,12 +280,12 @@ class _WeightPlanes:
     copy of a weight exists."""
 
     def __init__(self):
-        self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W]
+        self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W, transposed bf16 plane [K][ldT] or None]
         self.index = {}            # (id(owner), key) -> position
         self.table = None          # device descriptor table
         self.fresh_epoch = -1
         self.dirty_table = True
-        self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt]
+        self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt, transposed plane [K][sum N] or None]
 
     @staticmethod
     def _key(W):
@@ -294,9 +294,11 @@ class _WeightPlanes:
     def _put(self, W, pl, fmt):
         import weakref
         owner = W._base if W._base is not None else W
-        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach()]
+        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach(), None]
         pos = self.index.get((id(owner), self._key(W)))
         if pos is not None and pos < len(self.entries) and self.entries[pos][0]() is owner:
+            if self.entries[pos][2].any._base is None and pl.any._base is None:
+                entry[6] = self.entries[pos][6]    # a wider plane set of the same stand-alone weight keeps its transposed plane
             self.entries[pos] = entry          # re-registered (a new plane set, or now as a member of a group): same slot
         else:
             self.entries.append(entry)
@@ -333,7 +335,7 @@ class _WeightPlanes:
                 self._put(W, Planes(sl(big.hi), sl(big.lo), N, K, sl(big.fh), sl(big.fl)), fmt)
                 off += N
             bias = torch.empty(Nt, device=Ws[0].device, dtype=torch.float32) if all(b is not None for b in bs) else None
-            g = [[weakref.ref(W) for W in Ws], big, bias, -1, fmt]
+            g = [[weakref.ref(W) for W in Ws], big, bias, -1, fmt, None]
             self.groups[key] = g
             if len(self.groups) > 4096:     # models come and go in tests
                 self.groups = {k: v for k, v in self.groups.items() if all(r() is not None for r in v[0])}
@@ -365,7 +367,8 @@ class _WeightPlanes:
             for i, e in enumerate(self.entries):
                 Wd, pl = e[5], e[2]
                 _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
-                                               _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0), None, None, 0),
+                                               _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0),
+                                               _p(e[6]), None, e[6].stride(0) if e[6] is not None else 0),
                            "bmt_planes_desc")
             self.table = host.to(self.entries[0][5].device)
             self.dirty_table = False
@@ -373,6 +376,45 @@ class _WeightPlanes:
         for e in self.entries:
             e[4] = e[5]._version
         self.fresh_epoch = WEIGHT_EPOCH[0]
+
+    def get_t(self, W):
+        """the transposed bf16 plane [K][pad64(N)] of a stand-alone weight [N][K]: the row-major B operand of dX = dY . W"""
+        e = self._entry(W)
+        if e is None or e[2].hi is None:
+            self.get(W, "bwd")
+            e = self._entry(W)
+        if e[2].any._base is not None:
+            raise RuntimeError("weight planes: a member of a fused projection group was asked for its transposed plane on its own")
+        if e[6] is None:
+            N, K = W.shape
+            e[6] = torch.zeros(K, _pad64(N), device=W.device, dtype=torch.bfloat16)
+            self.dirty_table = True
+        if self.fresh_epoch != WEIGHT_EPOCH[0] or e[4] != W._version or self.dirty_table:
+            self._refresh_all()
+        return Planes(e[6], None, W.shape[1], W.shape[0])
+
+    def get_group_t(self, Ws):
+        """[K][sum N]: the transposed plane of a fused projection group (every member writes its column block)"""
+        key = tuple(id(W) for W in Ws)
+        g = self.groups.get(key)
+        if g is None or any(r() is not W for r, W in zip(g[0], Ws)) or g[1].hi is None:
+            self.get_group(Ws, tuple(None for _ in Ws), "bwd")
+            g = self.groups[key]
+        if g[5] is None:
+            K, Nt = Ws[0].shape[1], sum(W.shape[0] for W in Ws)
+            g[5] = torch.zeros(K, Nt, device=Ws[0].device, dtype=torch.bfloat16)
+            off = 0
+            for W in Ws:
+                self._entry(W)[6] = g[5][:, off:off + W.shape[0]]
+                off += W.shape[0]
+            self.dirty_table = True
+        stale = self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table
+        if not stale:
+            for W in Ws:
+                stale = stale or self._entry(W)[4] != W._version
+        if stale:
+            self._refresh_all()
+        return Planes(g[5], None, Ws[0].shape[1], g[5].shape[1])
 
     def get(self, W, fmt):
         e = self._entry(W)
@@ -410,6 +452,22 @@ FUSE_PROJECTIONS = _os.environ.get("BMT_NO_FUSE") != "1"      # Q/K/V (self-atte
 
 def weight_group(Ws, bs, fmt: str = "x3"):
     return _weights.get_group(tuple(Ws), tuple(bs), fmt) if FUSE_PROJECTIONS else None
+
+
+# dX = dY . W with W^T as a ROW-MAJOR operand (a transposed bf16 plane per weight, refreshed with the other planes once per step)
+# instead of W as stored, k-major through the transpose unit.  Alone the row-major pipelined kernel is faster (8192 x 1024 x 1024:
+# 31 vs 46 us), in the step it is not (same box, tools/gpu_ab.sh: bf16 GEMM class 1.93 vs 1.88 ms, +0.15 ms for the extra planes:
+# 11.91 vs 11.70 ms / step) -- the backward products with K = 1024 are bound by their epilogue traffic, not by the operand path.
+# Kept as an A/B switch (BMT_DX_ROWMAJOR=1).
+DX_ROW_MAJOR = _os.environ.get("BMT_DX_ROWMAJOR") == "1"
+
+
+def weight_planes_t(W: torch.Tensor) -> Planes:
+    return _weights.get_t(W)
+
+
+def weight_group_t(Ws) -> Planes:
+    return _weights.get_group_t(tuple(Ws))
 
 
 def group_static_grad(Ws):
@@ -565,7 +623,11 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     A = as_planes(dy, "bwd")
     if out is None and epi.get("out_planes") is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
-    gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
+    e = _weights._entry(W)
+    if DX_ROW_MAJOR and W.dim() == 2 and (e is None or e[2].any._base is None):
+        gemm_bf16(A, weight_planes_t(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, **epi)
+    else:
+        gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
     return out if out is not None else epi["out_planes"]
 
 
@@ -1368,7 +1430,10 @@ class MHAFn(torch.autograd.Function):
             dx = None
             if need_dx:          # [Wq;Wk;Wv] as stored ([3D][d_in]): its row is the reduction index
                 dx = torch.empty(comb.rows, gst.cols, device=dy2.device, dtype=torch.float32)
-                gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
+                if DX_ROW_MAJOR:
+                    gemm_bf16(comb, weight_group_t(Ws), dx, ldc=dx.stride(0), precision=PREC_BF16)
+                else:
+                    gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
             gW = group_static_grad(Ws)
             if gW is not None:
                 linear_dw(comb, xT, into=gW, params=Ws)
