@@ -200,6 +200,50 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def PMC_FAMILY_OF_KERNEL(name: str) -> str:
+    """kernel name in a rocprofv3 trace -> the family key of profiles/*pmc_traffic.json (tools/pmc_traffic.py)"""
+    import re
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"^void ", "", n)
+    if n.startswith("gemm_bf16_grouped_kernel"):
+        return "gemm_dw_grouped"
+    if re.match(r"gemm_bf16_kernel<1, \d, \d, false, false, \d, true", n) or re.match(r"gemm_pipe_kernel<1, true", n):
+        return "gemm_f16"
+    m = re.match(r"gemm_(?:bf16|pipe)_kernel<(\d)", n)
+    if m:
+        return {"1": "gemm_bf16", "2": "gemm_w2", "3": "gemm_x3"}[m.group(1)]
+    if n.startswith("gemm_wide_kernel<true"):
+        return "gemm_w2"            # the step's fp16 products are all two-plane (ops.POLICIES); a one-plane fp16 launch would land here too
+    if n.startswith("gemm_wide_kernel<false"):
+        return "gemm_bf16"
+    if n.startswith("attn_fwd"):
+        return "attn_fwd"
+    if n.startswith("attn_bwd_dq"):
+        return "attn_bwd_dq"
+    if n.startswith("attn_bwd_dkv"):
+        return "attn_bwd_dkv"
+    return n.split("(")[0].split("<")[0]
+
+
+# kernel class of the KernelTimer -> family key(s) of the PMC record (a backward attention launch is the dQ and the dK / dV kernel)
+def pmc_keys_of_class(cls: str):
+    if cls.startswith("attn_fwd"):
+        return ("attn_fwd",)
+    if cls.startswith("attn_bwd"):
+        return ("attn_bwd_dq", "attn_bwd_dkv")
+    if "dw_grouped" in cls:
+        return ("gemm_dw_grouped",)
+    if cls.endswith("bf16x3"):
+        return ("gemm_x3",)
+    if "(fp16 hi+lo)" in cls:
+        return ("gemm_w2",)
+    if cls.endswith("_fp16"):
+        return ("gemm_f16",)
+    if cls.endswith("_bf16"):
+        return ("gemm_bf16",)
+    return (cls,)
+
+
 def pmc_record():
     """the newest committed PMC pass (profiles/*pmc_traffic.json, written by tools/gpu_pmc_bench.sh: FETCH_SIZE / WRITE_SIZE / SQ
     counters in separate rocprofv3 --pmc passes over this same step, gfx950 FETCH correction applied).  The counters cannot be
@@ -490,7 +534,13 @@ def main():
             d = summ[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             rec, rec_note = pmc_record()
-            kern = (rec or {}).get("kernels", {}).get(dom)
+            fam = [(rec or {}).get("kernels", {}).get(k) for k in pmc_keys_of_class(dom)]
+            kern = None
+            if fam and all(fam):        # per launch of the class: the sum over its kernels (families mix encoder and decoder sizes)
+                kern = {"traffic_bytes": sum(x["traffic_bytes"] for x in fam)}
+                if all(x.get("mfma_busy") is not None and x.get("avg_us") for x in fam):
+                    kern["mfma_busy"] = sum(x["mfma_busy"] * x["avg_us"] for x in fam) / sum(x["avg_us"] for x in fam)
+                    kern["hbm_gbs"] = kern["traffic_bytes"] / sum(x["avg_us"] for x in fam) / 1e3
             passes = timer.passes.get(dom, 1)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
@@ -503,6 +553,8 @@ def main():
                                "timing": f"HIP events around every launch of the class (a split-K GEMM launch = main kernel + its epilogue kernel), {timer_steps} eagerly issued steps right after the timed region"}
             if kern and kern.get("mfma_busy") is not None:
                 out["roofline"]["mfma_busy"] = kern["mfma_busy"]
+                out["roofline"]["hbm_gbs"] = kern["hbm_gbs"]
+                out["roofline"]["pmc_families"] = list(pmc_keys_of_class(dom))
             # the north-star quantity: bi-modal ENCODER attention against the MFMA roofline.  "issued" counts what the matrix
             # pipe executes (backward: 7 products as scheduled -- S and dP are computed by both backward kernels),
             # "algorithmic" the 2 / 5 products of the math.
