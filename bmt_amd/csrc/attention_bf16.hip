@@ -1404,6 +1404,180 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// dQ with 64-key stages: the forward's lean loop (attn_fwd64_kernel) applied to attn_bwd_dq16_kernel -- K / V tiles by buffer loads
+// with the stage offset in an SGPR and rows past Sk read as zero, double-buffered LDS images and ONE barrier per stage, the
+// probabilities recomputed in the log2 domain (p = exp2(fma(s, scale log2 e, -lse log2 e))), per-stage bookkeeping paid half as often.
+template <int DK, int BC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16b_kernel(const AttnPB p) {
+    constexpr int KT = BC / 16, NT = 512, KS = DK / 32, DT = DK / 16, RS = pad_rs<DK>();
+    constexpr int TILE = BC * RS, STAGE = 2 * TILE;
+    constexpr int NR = rows_n<DK, BC, NT>();
+    constexpr int SPR = DK / 8;
+    static_assert(BC * SPR % NT == 0, "whole slots per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 2 * STAGE);       // [2][BC]
+    int* sFlag = reinterpret_cast<int*>(sMask + 2 * BC);                    // [2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 16 + c;
+    const bool qok = q < p.Sq;
+
+    bf16x8 qf[KS], dof[KS];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
+            dof[ks] = ldfrag(p.dOh + oo + 32 * ks, qok);
+        }
+    }
+    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
+    const float lse2 = qok ? p.lse[stat] * LOG2E : 0.f;
+    float delta;
+    if (p.fuse_delta) {      // see attn_bwd_dq16_kernel
+        const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + 8 * g;
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (p.Opf) {
+                const f16x8 of = __builtin_bit_cast(f16x8, ldfrag(p.Opf + po + 32 * ks, qok));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (float)dof[ks][j] * (float)of[j];
+            } else {
+                const bf16x8 oh = ldfrag(p.Oph + po + 32 * ks, qok);
+                bf16x8 ol = oh;
+                if (p.Opl) ol = ldfrag(p.Opl + po + 32 * ks, qok);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float ov = (float)oh[j];
+                    if (p.Opl) ov += (float)ol[j];
+                    acc += (float)dof[ks][j] * ov;
+                }
+            }
+        }
+        acc = xlane_sum(acc);
+        delta = acc * (1.f - p.drop_p);
+        if (qok && g == 0) p.delta[stat] = delta;
+    } else {
+        delta = qok ? p.delta[stat] : 0.f;
+    }
+    const float sc2 = p.scale * LOG2E;
+    const int troff = tr_lane_off(RS, c, g);
+
+    f32x4v dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    int kvo[NR], vvo[NR], lso[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int s_ = tid + NT * i;
+        kvo[i] = (s_ / SPR) * (int)p.ldk * 2 + (s_ % SPR) * 16;
+        vvo[i] = (s_ / SPR) * (int)p.ldv * 2 + (s_ % SPR) * 16;
+        lso[i] = (s_ / SPR) * RS + (s_ % SPR) * 16;
+    }
+    const int ntile = (p.Sk + BC - 1) / BC;
+    u32x4 kr[NR], vr[NR];
+#define BMT_DQ64_FETCH(t_)                                                                             \
+    do {                                                                                               \
+        const int so_k = (t_) * BC * (int)p.ldk * 2, so_v = (t_) * BC * (int)p.ldv * 2;                \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[i], so_k, 0); \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[i], so_v, 0); \
+    } while (0)
+#define BMT_DQ64_STORE(t_, buf_)                                                                       \
+    do {                                                                                               \
+        char* sk_ = smem + (buf_) * STAGE;                                                             \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sk_ + lso[i]) = kr[i];        \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sk_ + TILE + lso[i]) = vr[i]; \
+        stage_mask<BC>(p, b, (t_) * BC, tid, sMask + (buf_) * BC, sFlag + (buf_));                      \
+    } while (0)
+    BMT_DQ64_FETCH(0);
+    BMT_DQ64_STORE(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        const int tn = min(t + 1, ntile - 1);
+        BMT_DQ64_FETCH(tn);
+        const int flag = sFlag[cur];
+        if (flag != 0) {
+            const char* sK = smem + cur * STAGE;
+            const char* sV = sK + TILE;
+            const int key0 = t * BC;
+            f32x4v st[KT], dp[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) { st[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[kt] = st[kt]; }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    st[kt] = mfma16(rowfrag_pad<DK>(sK, kt * 16 + c, 4 * ks + g), qf[ks], st[kt]);
+                    dp[kt] = mfma16(rowfrag_pad<DK>(sV, kt * 16 + c, 4 * ks + g), dof[ks], dp[kt]);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            float ds[4 * KT];
+#pragma unroll
+            for (int i = 0; i < 4 * KT; ++i) {
+                const float pr = qok ? __builtin_amdgcn_exp2f(st[i >> 2][i & 3] * sc2 - lse2) : 0.f;
+                ds[i] = pr * (dp[i >> 2][i & 3] - delta) * p.scale;
+            }
+            if (flag != 2) {
+                if (p.mask != nullptr && p.mask_qs != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4 * KT; ++i) {
+                        const int key = key0 + 16 * (i >> 2) + 4 * g + (i & 3);
+                        const bool ok = qok && key < p.Sk && p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
+                        ds[i] = ok ? ds[i] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + cur * BC + 16 * kt + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ds[4 * kt + r] = ((mw >> (8 * r)) & 0xffu) ? ds[4 * kt + r] : 0.f;
+                    }
+                }
+            }
+            bf16x8 dsf[BC / 32];
+#pragma unroll
+            for (int hf = 0; hf < BC / 32; ++hf) {
+                u32x4 dw;
+                dw[0] = pack_bf2(ds[8 * hf + 0], ds[8 * hf + 1]); dw[1] = pack_bf2(ds[8 * hf + 2], ds[8 * hf + 3]);
+                dw[2] = pack_bf2(ds[8 * hf + 4], ds[8 * hf + 5]); dw[3] = pack_bf2(ds[8 * hf + 6], ds[8 * hf + 7]);
+                dsf[hf] = as_bf16x8(dw);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dq[dt] = mfma16(trfrag<DK>(sK + troff, dt), dsf[0], dq[dt]);
+                if constexpr (BC == 64) dq[dt] = mfma16(trfrag<DK>(sK + troff + 32 * RS, dt), dsf[BC / 32 - 1], dq[dt]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        BMT_DQ64_STORE(tn, cur ^ 1);
+        __syncthreads();
+    }
+#undef BMT_DQ64_FETCH
+#undef BMT_DQ64_STORE
+    grad_store_rows16<DK>(p.gq, dq, b, h, q, qok, g);
+    if (p.gq.hiT || p.gq.bsum) {
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+        grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
+        __syncthreads();
+        grad_tile_flush<DK, 128, NT>(tile, p.gq, b, h, qt * 128, p.Sq, tid);
+    }
+}
+
 // dK / dV, 8 waves x 16 keys (128 keys per workgroup), loop over 32-query stages.  Every wave computes S[q][key] = Q . K^T and
 // dP[q][key] = dO . V^T once (A = staged Q / dO rows, B = this wave's K / V rows held in registers) and accumulates BOTH
 // dV^T += dO^T . P and dK^T += Q^T . dS for its keys (an earlier version split the waves into a dV and a dK role: S was
@@ -1531,6 +1705,150 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// dK / dV with the lean stage loop: Q / dO tiles by buffer loads (stage offset in an SGPR, rows past Sq read as zero), double-buffered
+// LDS images with ONE barrier per 32-query stage, probabilities recomputed in the log2 domain.  Decomposition and fragment layouts as
+// in attn_bwd_dkv16_kernel (which documents them).
+// QMASK: the mask has a row per query (the decoder's causal mask); the key-padding masks of the encoder and of every cross-attention
+// are per key (kmask), and without the per-element mask addressing the d_k = 256 kernel fits its 256 registers (no spills).
+template <int DK, bool QMASK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv32_kernel(const AttnPB p) {
+    constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 128, RS = pad_rs<DK>();
+    constexpr int TP = BQ * RS, STAGE = 2 * TP;
+    constexpr int NR = rows_n<DK, BQ, NT>();
+    constexpr int SPR = DK / 8;
+    static_assert(BQ * SPR % NT == 0, "whole slots per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sStat = reinterpret_cast<float*>(smem + 2 * STAGE);       // [2 buffers][lse log2 e | delta][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nkt = (p.Sk + KBLK - 1) / KBLK;
+    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    const int kt = w % nkt, bh = w / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int key = kt * KBLK + wid * 16 + c;
+    const bool kok = key < p.Sk;
+    const int troff = tr_lane_off(RS, c, g);
+
+    bool kmask = kok;
+    if (!QMASK && kok && p.mask != nullptr) kmask = p.mask[(int64_t)b * p.mask_bs + key] != 0;
+    const bool dead = __syncthreads_or(kmask ? 1 : 0) == 0;   // every key of the workgroup masked: gradients exactly zero
+    f32x4v accv[DT], acck[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { accv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f}; acck[dt] = accv[dt]; }
+    if (!dead) {
+        bf16x8 kf[KS], vf[KS];
+        {
+            const int krow = min(key, p.Sk - 1);
+            const int64_t ko = (int64_t)b * p.bsk + (int64_t)krow * p.ldk + h * DK + 8 * g;
+            const int64_t vo = (int64_t)b * p.bsv + (int64_t)krow * p.ldv + h * DK + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kf[ks] = ldfrag(p.Kh + ko + 32 * ks, true);
+                vf[ks] = ldfrag(p.Vh + vo + 32 * ks, true);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0,
+                                                                             (int)(((int64_t)(p.Sq - 1) * p.ldq + DK) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0,
+                                                                             (int)(((int64_t)(p.Sq - 1) * p.ldo + DK) * 2), 0x00020000);
+        int qvo[NR], ovo[NR], lso[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int s_ = tid + NT * i;
+            qvo[i] = (s_ / SPR) * (int)p.ldq * 2 + (s_ % SPR) * 16;
+            ovo[i] = (s_ / SPR) * (int)p.ldo * 2 + (s_ % SPR) * 16;
+            lso[i] = (s_ / SPR) * RS + (s_ % SPR) * 16;
+        }
+        const float sc2 = p.scale * LOG2E;
+        u32x4 rq[NR], rdo[NR];
+        float rl = 0.f, rd = 0.f;
+        const int ntile = (p.Sq + BQ - 1) / BQ;
+        const int64_t stat0 = ((int64_t)b * p.H + h) * p.Sq;
+#define BMT_DKV32_FETCH(t_)                                                                            \
+    do {                                                                                               \
+        const int so_q = (t_) * BQ * (int)p.ldq * 2, so_o = (t_) * BQ * (int)p.ldo * 2;                \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) rq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qvo[i], so_q, 0);  \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) rdo[i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, ovo[i], so_o, 0); \
+        if (tid < BQ) {                                                                                \
+            const int qq_ = min((t_) * BQ + tid, p.Sq - 1);                                            \
+            rl = p.lse[stat0 + qq_] * LOG2E;                                                           \
+            rd = p.delta[stat0 + qq_];                                                                 \
+        }                                                                                              \
+    } while (0)
+#define BMT_DKV32_STORE(buf_)                                                                          \
+    do {                                                                                               \
+        char* sq_ = smem + (buf_) * STAGE;                                                             \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sq_ + lso[i]) = rq[i];       \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sq_ + TP + lso[i]) = rdo[i]; \
+        if (tid < BQ) { sStat[(buf_) * 64 + tid] = rl; sStat[(buf_) * 64 + 32 + tid] = rd; }           \
+    } while (0)
+        BMT_DKV32_FETCH(0);
+        BMT_DKV32_STORE(0);
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            const int cur = t & 1;
+            const int q0 = t * BQ;
+            BMT_DKV32_FETCH(min(t + 1, ntile - 1));
+            const char* sQ = smem + cur * STAGE;
+            const char* sdO = sQ + TP;
+            const float* sLse = sStat + cur * 64;
+            const float* sDelta = sLse + 32;
+            f32x4v sacc[2], dp[2];
+            sacc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            sacc[1] = sacc[0]; dp[0] = sacc[0]; dp[1] = sacc[0];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    sacc[qi] = mfma16(rowfrag_pad<DK>(sQ, qi * 16 + c, 4 * ks + g), kf[ks], sacc[qi]);
+                    dp[qi] = mfma16(rowfrag_pad<DK>(sdO, qi * 16 + c, 4 * ks + g), vf[ks], dp[qi]);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            float pr[8], ds[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ql_ = 16 * (i >> 2) + 4 * g + (i & 3);
+                const int qq = q0 + ql_;
+                bool ok = kmask && qq < p.Sq;
+                if constexpr (QMASK) {
+                    if (ok) ok = p.mask[(int64_t)b * p.mask_bs + (int64_t)qq * p.mask_qs + key] != 0;
+                }
+                pr[i] = ok ? __builtin_amdgcn_exp2f(sacc[i >> 2][i & 3] * sc2 - sLse[ql_]) : 0.f;
+                ds[i] = pr[i] * (dp[i >> 2][i & 3] - sDelta[ql_]) * p.scale;
+            }
+            u32x4 pw, dw;
+            pw[0] = pack_bf2(pr[0], pr[1]); pw[1] = pack_bf2(pr[2], pr[3]);
+            pw[2] = pack_bf2(pr[4], pr[5]); pw[3] = pack_bf2(pr[6], pr[7]);
+            dw[0] = pack_bf2(ds[0], ds[1]); dw[1] = pack_bf2(ds[2], ds[3]);
+            dw[2] = pack_bf2(ds[4], ds[5]); dw[3] = pack_bf2(ds[6], ds[7]);
+            const bf16x8 pf = as_bf16x8(pw), dsf = as_bf16x8(dw);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                accv[dt] = mfma16(trfrag<DK>(sdO + troff, dt), pf, accv[dt]);
+                acck[dt] = mfma16(trfrag<DK>(sQ + troff, dt), dsf, acck[dt]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            BMT_DKV32_STORE(cur ^ 1);          // nobody reads that image now: its readers passed the previous barrier
+            __syncthreads();
+        }
+#undef BMT_DKV32_FETCH
+#undef BMT_DKV32_STORE
+    }
+    grad_store_rows16<DK>(p.gv, accv, b, h, key, kok, g);
+    grad_store_rows16<DK>(p.gk, acck, b, h, key, kok, g);
+    if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [dV, dK][DK][128 + 8]
+        grad_tile_write16<DK, KBLK>(tile, accv, wid * 16, kok, c, g);
+        grad_tile_write16<DK, KBLK>(tile + DK * (KBLK + 8), acck, wid * 16, kok, c, g);
+        __syncthreads();
+        grad_tile_flush<DK, KBLK, NT>(tile, p.gv, b, h, kt * KBLK, p.Sk, tid);
+        grad_tile_flush<DK, KBLK, NT>(tile + DK * (KBLK + 8), p.gk, b, h, kt * KBLK, p.Sk, tid);
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int DK, int NPASS, bool F16 = false>
@@ -1593,7 +1911,31 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
                 (void)hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 done = true;
             }
-            hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, pf);
+            static const int old_dq = getenv("BMT_ATTN_DQ_OLD") ? atoi(getenv("BMT_ATTN_DQ_OLD")) : 0;      // A/B experiments only
+            const bool fits = ((int64_t)p.Sk * p.ldk * 2 < (1ll << 31)) && ((int64_t)p.Sk * p.ldv * 2 < (1ll << 31));
+            if (old_dq != 1 && fits) {
+                // measured (tools/microbench.py attn, BMT_ATTN_DQ_OLD): 64-key stages need 242 registers at d_k 256 and lose 3 % to the
+                // 32-key loop they came from; the 32-key stage with the lean loop is the default, 64 keys opt-in (BMT_ATTN_DQ_OLD=-1)
+                if (old_dq == -1) {
+                    const int lds64 = 2 * 2 * 64 * (DK * 2 + 32) + 256, ldsx = lds64 > lds_epi ? lds64 : lds_epi;
+                    static bool done64 = false;
+                    if (!done64) {
+                        (void)hipFuncSetAttribute((const void*)attn_bwd_dq16b_kernel<DK, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+                        done64 = true;
+                    }
+                    hipLaunchKernelGGL((attn_bwd_dq16b_kernel<DK, 64>), dim3(nblk_q), dim3(512), ldsx, st, pf);
+                } else {
+                    const int lds32 = 2 * 2 * 32 * (DK * 2 + 32) + 256, ldsx = lds32 > lds_epi ? lds32 : lds_epi;
+                    static bool done32 = false;
+                    if (!done32) {
+                        (void)hipFuncSetAttribute((const void*)attn_bwd_dq16b_kernel<DK, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+                        done32 = true;
+                    }
+                    hipLaunchKernelGGL((attn_bwd_dq16b_kernel<DK, 32>), dim3(nblk_q), dim3(512), ldsx, st, pf);
+                }
+            } else {
+                hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, pf);
+            }
         }
         {
             const int lds_loop = 2 * 32 * (DK * 2 + 32) + 2 * 32 * 4, lds_epi = 2 * DK * (128 + 8) * 2;
@@ -1603,7 +1945,29 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
                 (void)hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 done = true;
             }
-            hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k16), dim3(512), lds, st, p);
+            static const int old_dkv = getenv("BMT_ATTN_DKV_OLD") ? atoi(getenv("BMT_ATTN_DKV_OLD")) : 0;      // A/B experiments only
+            const bool fits = ((int64_t)p.Sq * p.ldq * 2 < (1ll << 31)) && ((int64_t)p.Sq * p.ldo * 2 < (1ll << 31));
+            if (!old_dkv && fits) {
+                const int lds_loop2 = 2 * 2 * 32 * (DK * 2 + 32) + 512;
+                const int lds2 = lds_loop2 > lds_epi ? lds_loop2 : lds_epi;
+                if (p.mask != nullptr && p.mask_qs != 0) {
+                    static bool done2 = false;
+                    if (!done2) {
+                        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32_kernel<DK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                        done2 = true;
+                    }
+                    hipLaunchKernelGGL((attn_bwd_dkv32_kernel<DK, true>), dim3(nblk_k16), dim3(512), lds2, st, p);
+                } else {
+                    static bool done3 = false;
+                    if (!done3) {
+                        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32_kernel<DK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                        done3 = true;
+                    }
+                    hipLaunchKernelGGL((attn_bwd_dkv32_kernel<DK, false>), dim3(nblk_k16), dim3(512), lds2, st, p);
+                }
+            } else {
+                hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k16), dim3(512), lds, st, p);
+            }
         }
     } else {
         {
