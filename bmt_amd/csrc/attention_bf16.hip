@@ -158,7 +158,13 @@ struct AttnPB {
     float scale, drop_p;
     const uint64_t* rng;
     uint32_t site;
+    const float* kmean;                    // backward, optional: fp32 [B][H * d_k] mean key over the valid keys (bmt_attn_kmean)
 };
+
+// dQ_i = sum_j dS_ij K_j with sum_j dS_ij = 0 exactly: the bf16 rounding of dS leaves a residue (sum_j round(dS_ij)) that the
+// product multiplies by the keys' common component -- 10-25 % of |dQ| where attention is near uniform over many similar keys
+// (the decoder's cross-attention, the encoder's second layer; tests/study_attn_bwd_centering.py).  The dQ kernels add up the
+// ROUNDED dS they feed to the MFMA (rs) and take rs * mean key out again in fp32: error 25 % -> 0.5 %.
 
 // stage the key-padding mask bytes of one tile and classify it: 0 = fully masked, 1 = partial, 2 = fully valid.
 // Called by every thread; result valid after the next __syncthreads().
@@ -1002,6 +1008,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
     const float lse = qok ? p.lse[stat] : 0.f;
     const float delta = qok ? p.delta[stat] : 0.f;
+    float rs = 0.f;                    // sum over keys of the bf16-rounded dS of this lane's query
 
     f32x16 dq[DT];
 #pragma unroll
@@ -1070,6 +1077,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
             pack_p<1>(ds, 0, dsf[0], unused);
             pack_p<1>(ds, 1, dsf[1], unused);
 #pragma unroll
+            for (int j = 0; j < 8; ++j) rs += (float)dsf[0][j] + (float)dsf[1][j];
+#pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
@@ -1081,6 +1090,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     }
 #undef BMT_DQ_FETCH
 #undef BMT_DQ_STORE
+    if (p.kmean != nullptr) {          // the query's keys are split over the lanes l31 and l31 + 32
+        rs += __shfl_xor(rs, 32, 64);
+        const float* km = p.kmean + ((int64_t)b * p.H + h) * DK;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] -= rs * km[dt * 32 + acc_row(r, half)];
+    }
     grad_store_rows<DK>(p.gq, dq, b, h, q, qok, half);
     if (p.gq.hiT || p.gq.bsum) {       // uniform; the loop ended on a barrier, so the stage images are free
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
@@ -1253,6 +1270,20 @@ __device__ __forceinline__ void grad_tile_write16(uint16_t* tile, const f32x4v (
 }
 
 // dQ, 8 waves x 16 queries (see attn_fwd16_kernel for the decomposition and the key permutation of the second product)
+// 16-wide dQ kernels: the keys of a query are split over the four lanes (c, g); accumulator dq[dt][r] is d = 16 dt + 4 g + r
+template <int DK>
+__device__ __forceinline__ void dq_rowsum_fix(const AttnPB& p, f32x4v (&dq)[DK / 16], float rs, int b, int h, int g) {
+    if (p.kmean == nullptr) return;
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    const float* km = p.kmean + ((int64_t)b * p.H + h) * DK + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DK / 16; ++dt) {
+        const float4 k4 = *reinterpret_cast<const float4*>(km + 16 * dt);
+        dq[dt][0] -= rs * k4.x; dq[dt][1] -= rs * k4.y; dq[dt][2] -= rs * k4.z; dq[dt][3] -= rs * k4.w;
+    }
+}
+
 template <int DK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16_kernel(const AttnPB p) {
     constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
@@ -1318,6 +1349,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         delta = qok ? p.delta[stat] : 0.f;
     }
     const int troff = tr_lane_off(pad_rs<DK>(), c, g);
+    float rs = 0.f;
 
     f32x4v dq[DT];
 #pragma unroll
@@ -1383,6 +1415,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             u32x4 dsw;
             dsw[0] = pack_bf2(ds[0], ds[1]); dsw[1] = pack_bf2(ds[2], ds[3]);
             dsw[2] = pack_bf2(ds[4], ds[5]); dsw[3] = pack_bf2(ds[6], ds[7]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rs += __uint_as_float(dsw[j] << 16) + __uint_as_float(dsw[j] & 0xFFFF0000u);
             const bf16x8 dsf = as_bf16x8(dsw);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1395,6 +1429,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef BMT_DQ16_FETCH
 #undef BMT_DQ16_STORE
+    dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
     grad_store_rows16<DK>(p.gq, dq, b, h, q, qok, g);
     if (p.gq.hiT || p.gq.bsum) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
@@ -1469,6 +1504,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const float sc2 = p.scale * LOG2E;
     const int troff = tr_lane_off(RS, c, g);
+    float rs = 0.f;
 
     f32x4v dq[DT];
 #pragma unroll
@@ -1554,6 +1590,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 u32x4 dw;
                 dw[0] = pack_bf2(ds[8 * hf + 0], ds[8 * hf + 1]); dw[1] = pack_bf2(ds[8 * hf + 2], ds[8 * hf + 3]);
                 dw[2] = pack_bf2(ds[8 * hf + 4], ds[8 * hf + 5]); dw[3] = pack_bf2(ds[8 * hf + 6], ds[8 * hf + 7]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs += __uint_as_float(dw[j] << 16) + __uint_as_float(dw[j] & 0xFFFF0000u);
                 dsf[hf] = as_bf16x8(dw);
             }
             __builtin_amdgcn_s_setprio(1);
@@ -1569,6 +1607,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef BMT_DQ64_FETCH
 #undef BMT_DQ64_STORE
+    dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
     grad_store_rows16<DK>(p.gq, dq, b, h, q, qok, g);
     if (p.gq.hiT || p.gq.bsum) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
@@ -1849,6 +1888,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// mean key per (batch, column) over the valid keys: K plane [B][Sk][ldk] (bf16), key-padding mask [B][Sk] (or none / a per-query
+// mask: every key counts).  Block = 128 columns (16 threads x 16 bytes) x 32 key groups; every load is unconditional and independent
+// (the mask byte is a multiplier) so the key loop unrolls into batches of loads in flight -- a `continue` on the mask byte made
+// every iteration a dependent L2 round trip (100 us per call instead of 7).  grid (B, ceil(D / 128)).
+__global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restrict__ Kh, int64_t ldk, int64_t bsk, const uint8_t* __restrict__ mask,
+                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out) {
+    constexpr int KG = 32;
+    __shared__ float red[KG][129];
+    __shared__ float cnt[KG];
+    const int b = blockIdx.x, ct = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 128 + ct * 8;
+    const bool cok = c0 < D;                       // D is a multiple of 8
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float n = 0.f;
+    const uint16_t* base = Kh + (int64_t)b * bsk + (cok ? c0 : 0);
+    const uint8_t* mb = mask ? mask + (int64_t)b * mask_bs : nullptr;
+#pragma unroll 8
+    for (int k = kg; k < Sk; k += KG) {
+        const float m = mb ? (mb[k] != 0 ? 1.f : 0.f) : 1.f;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)k * ldk);
+        n += m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[2 * q] += m * bf_bits2f(v[q] & 0xFFFFu);
+            a[2 * q + 1] += m * bf_bits2f(v[q] >> 16);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[kg][ct * 8 + q] = a[q];
+    if (ct == 0) cnt[kg] = n;
+    __syncthreads();
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (threadIdx.x < 128 && c < D) {
+        float total = 0.f, sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < KG; ++i) { total += cnt[i]; sum += red[i][threadIdx.x]; }
+        out[(int64_t)b * D + c] = total > 0.f ? sum / total : 0.f;
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int DK, int NPASS, bool F16 = false>
@@ -2051,10 +2130,22 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.scale = a->scale; p.drop_p = a->drop_p;
+    p.kmean = a->kmean;
     hipStream_t st = (hipStream_t)stream;
     if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, st);
     if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, st);
     if (a->dk == 128) return launch_bwd<128>(p, a->dOh_ws, st);
     if (a->dk == 256) return launch_bwd<256>(p, a->dOh_ws, st);
     return BMT_EINVAL;
+}
+
+extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk,
+                              int D, float* out, void* stream) {
+    BMT_CHECK_ARG(Kh && out && B > 0 && Sk > 0 && D > 0 && D % 8 == 0 && ldk % 8 == 0 && bsk % 8 == 0 &&
+                      (reinterpret_cast<uintptr_t>(Kh) & 15) == 0,
+                  "bmt_attn_kmean: bad args (D, ldk, bsk multiples of 8, 16-byte aligned plane)");
+    hipLaunchKernelGGL(attn_kmean_kernel, dim3(B, bmt_cdiv(D, 128)), dim3(512), 0, (hipStream_t)stream, Kh, ldk, bsk,
+                       mask_qs == 0 ? mask : nullptr, mask_bs, Sk, D, out);
+    BMT_CHECK_LAUNCH("bmt_attn_kmean");
+    return BMT_OK;
 }

@@ -876,6 +876,19 @@ def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision
     return o, lse
 
 
+ATTN_KMEAN = _os.environ.get("BMT_NO_KMEAN") != "1"      # A/B: the dQ correction by (row sum of rounded dS) x mean key
+
+
+def attn_kmean(kh: torch.Tensor, ldk: int, bsk: int, B: int, Sk: int, D: int, mask_args) -> Optional[torch.Tensor]:
+    """fp32 [B][D] mean key over the valid keys of a K plane (bmt_attn_kmean), or None when the correction is switched off"""
+    if not ATTN_KMEAN:
+        return None
+    _, mptr, mbs, mqs = mask_args
+    out = torch.empty(B, D, device=kh.device, dtype=torch.float32)
+    _lib.check(lib.bmt_attn_kmean(_p(kh), ldk, bsk, mptr, mbs, mqs, B, Sk, D, _p(out), _st()), "bmt_attn_kmean")
+    return out
+
+
 def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, drop_p=0.0):
     B, Sq, D = qh.shape
     Sk = kh.shape[1]
@@ -886,9 +899,11 @@ def attn_bwd_bf16(qh, kh, vh, o, do, lse, mask, H, drop_p=0.0):
     delta = torch.empty(B, H, Sq, device=qh.device, dtype=torch.float32)
     doh = torch.empty(B, Sq, D, device=qh.device, dtype=torch.bfloat16)
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
+    km = attn_kmean(kh, kh.stride(1), kh.stride(0), B, Sk, D, (keep, mptr, mbs, mqs))
     a = AttnBwdBf16Args(_p(qh), _p(kh), _p(vh), _p(o), _p(do), _p(lse), _p(dq), _p(dk_), _p(dv), _p(delta), _p(doh),
                         qh.stride(1), kh.stride(1), vh.stride(1), o.stride(1), qh.stride(0), kh.stride(0), vh.stride(0),
                         o.stride(0), dk_.stride(1), dk_.stride(0), mptr, mbs, mqs, B, H, Sq, Sk, dk, 1.0 / math.sqrt(dk), drop_p)
+    a.kmean = _p(km)
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     return dq, dk_, dv
 
@@ -961,6 +976,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
     ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), o.hi.stride(0)
     (qh_, qb_, _), (kh_, kb_, _), (vh_, vb_, _) = outs
+    km = attn_kmean(k.hi, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs))
     a = AttnBwdBf16Args(Qh=_p(q.hi), Kh=_p(k.hi), Vh=_p(v.hi), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
@@ -969,7 +985,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
-                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh))
+                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km))
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
     for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):

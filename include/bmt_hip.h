@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-3)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 2
+#define BMT_ABI_VERSION 3
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -229,8 +229,16 @@ typedef struct {
     uint16_t *dQT, *dKT, *dVT; int64_t gqT_ld, gkvT_ld;
     float *dbq, *dbk, *dbv;
     const uint16_t* Of;                               /* saved forward output as an fp16 plane (delta = rowsum(dO * O) reads it when set) */
+    const float* kmean;                               /* optional fp32 [B][H*dk]: mean key over the valid keys (bmt_attn_kmean).  With it dQ is
+                                                         corrected by (row sum of the bf16-rounded dS) x mean key: the rounding residue of dS
+                                                         times the keys' common component, 10-25 % of |dQ| under near-uniform attention */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
+/* out[b][c] = mean over the valid keys k of K[b][k][c] (bf16 plane, row stride ldk, batch stride bsk; mask: key-padding bytes [B][Sk]
+   when mask_qs == 0, otherwise -- no mask or one row per query -- every key counts).  No counterpart in the reference: numerical aid of
+   the bf16 backward (model/multihead_attention.py:8-26 is exact in fp32). */
+int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk, int D,
+                   float* out, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (model/blocks.py:127,131,143,150) */
 /* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */

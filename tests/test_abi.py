@@ -17,14 +17,14 @@ def test_header_declares_the_hot_path():
     syms = declared_symbols()
     for need in ("bmt_gemm_bf16", "bmt_gemm_bf16_grouped", "bmt_planes", "bmt_attn_fwd", "bmt_attn_bwd", "bmt_attn_fwd_bf16", "bmt_attn_bwd_bf16",
                  "bmt_layernorm_fwd", "bmt_layernorm_bwd", "bmt_ls_kl_fwd", "bmt_adam_step", "bmt_pad_planes", "bmt_make_targets",
-                 "bmt_prop_decode_loss", "bmt_last_error", "bmt_version"):
+                 "bmt_prop_decode_loss", "bmt_last_error", "bmt_version", "bmt_attn_kmean"):
         assert need in syms
 
 
 def test_library_loads_and_exports_everything():
     from bmt_amd import _lib
     lib = _lib.load()
-    assert lib.bmt_version() == 2
+    assert lib.bmt_version() == 3
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/bmt_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in bmt_amd/_lib.py"

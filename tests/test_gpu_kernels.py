@@ -331,6 +331,38 @@ def test_attention_backward_bf16_planes(ops, dk, H, B, Sq, Sk, kind):
         assert e < 2e-2, f"{name} dk={dk} {kind}: relative error {e:.3e}\n" + report(got, ref, name)
 
 
+@pytest.mark.parametrize("dk,H,B,Sq,Sk", [(32, 4, 2, 12, 200), (64, 2, 2, 29, 300), (128, 2, 1, 29, 333), (256, 2, 2, 29, 800), (256, 1, 1, 200, 200)])
+def test_attention_backward_keys_with_a_common_component(ops, dk, H, B, Sq, Sk, monkeypatch):
+    """near-uniform attention over keys that share a large common component (the decoder's cross-attention over the encoder
+    memory): sum_j dS_ij = 0 exactly, but the bf16-rounded dS does not sum to zero and the residue multiplies the common
+    component -- 10-25 % of |dQ| in the model (tests/study_attn_bwd_centering.py).  The dQ kernels subtract (row sum of the rounded
+    dS) x mean key: what is left is the rounding of the keys themselves.  Every kernel family (d_k 32 / 64: 32-wide MFMA tiles,
+    128 / 256: 16-wide), against the uncorrected kernels on the same inputs."""
+    D = dk * H
+    q = rnd(B, Sq, D, seed=60) * 0.2
+    common = rnd(1, 1, D, seed=61) * 1.5
+    k = common + rnd(B, Sk, D, seed=62) * 0.3
+    v = rnd(B, Sk, D, seed=63)
+    do = rnd(B, Sq, D, seed=64)
+    mask = torch.ones(B, 1, Sk, dtype=torch.bool)
+    mask[0, 0, Sk - Sk // 5:] = False
+    md = mask.to(DEV)
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q), _planes(k), _planes(v)
+    o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, md, H, precision=3)
+    dq, dk_, dv = ops.attn_bwd_bf16(qh, kh, vh, o, do.to(DEV), lse, md, H)
+    monkeypatch.setattr(ops, "ATTN_KMEAN", False)
+    dq_plain, _, _ = ops.attn_bwd_bf16(qh, kh, vh, o, do.to(DEV), lse, md, H)
+    qr, kr, vr = (t.clone().double().requires_grad_() for t in (q, k, v))
+    want = _oracle_attention(qr, kr, vr, mask, H, rounded=False)
+    (want * do.double()).sum().backward()
+    from tests.gpu_util import report
+    e_fix, e_plain = rel_err(dq, qr.grad), rel_err(dq_plain, qr.grad)
+    assert e_fix < 1.5e-2 and e_fix < 0.6 * e_plain, f"dq dk={dk}: {e_fix:.3e} corrected vs {e_plain:.3e} plain\n" + report(dq, qr.grad, "dq")
+    for name, got, ref, tol in (("dk", dk_, kr.grad, 3e-2), ("dv", dv, vr.grad, 2e-2)):
+        e = rel_err(got, ref)
+        assert e < tol, f"{name} dk={dk}: relative error {e:.3e}\n" + report(got, ref, name)
+
+
 @pytest.mark.parametrize("dk,H,B,Sq,Sk,kind", ATTN_CASES + [(256, 2, 2, 200, 336, "pad"), (128, 4, 1, 70, 257, "pad"), (256, 4, 2, 128, 64, "pad")])
 @pytest.mark.parametrize("prec,out_fmt", [(3, "x3"), (4, "f16"), (4, "x3")])
 def test_attention_plane_outputs_match_fp32_outputs(ops, dk, H, B, Sq, Sk, kind, prec, out_fmt):

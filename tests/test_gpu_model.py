@@ -23,16 +23,18 @@ def _load(module, sd):
     return module.to(DEV)
 
 
-def _check_grads(named_params, ref_grads, tol=0.35, global_tol=GRAD_REL):
-    """Backward runs single-pass bf16 (DESIGN.md "precision"): error over ALL tensors concatenated <= 3 %; per tensor
-    <= 35 % (the decoder's cross-attention query/key paths see near-uniform attention over keys with a large common
-    component, so their small gradients carry bf16 cancellation noise of 10-30 %; everything else is within a few %).  Gradients that are analytically zero (the key-projection bias: softmax is invariant to a
-    constant added to every key) come out as cancellation noise in any finite precision -- 1e-9 in the fp32 reference,
-    bf16-sized here -- and are only required to be small against the largest gradient element around them."""
+def _check_grads(named_params, ref_grads, tol=0.05, global_tol=1e-2):
+    """Backward runs single-pass bf16 (DESIGN.md "precision"): error over ALL tensors concatenated <= 1 %, per tensor <= 5 %
+    (with the dQ correction of the attention backward -- ops.ATTN_KMEAN -- the decoder's cross-attention query / key paths, whose
+    bf16 cancellation noise was 10-30 %, are within 1 %).  Gradients that are analytically zero (the key-projection bias: softmax
+    is invariant to a constant added to every key) come out as cancellation noise in any finite precision -- 1e-9 in the fp32
+    reference, bf16-sized here -- and are only required to be small against the largest gradient element around them.
+    BMT_GRAD_REPORT=1 prints every tensor's error."""
+    import os
     items = [(k, p) for k, p in named_params if k in ref_grads]
     gmax = max(float(ref_grads[k].abs().max()) for k, _ in items)
     nmax = max(float(ref_grads[k].double().norm()) for k, _ in items)
-    bad, e2, r2 = [], 0.0, 0.0
+    bad, e2, r2, rows = [], 0.0, 0.0, []
     for k, p in items:
         assert p.grad is not None, f"missing grad for {k}"
         ref = ref_grads[k].double()
@@ -44,8 +46,13 @@ def _check_grads(named_params, ref_grads, tol=0.35, global_tol=GRAD_REL):
             continue
         e2 += e * e
         r2 += n * n
+        rows.append((e / n, k, n))
         if e > tol * n:
-            bad.append(f"{k}: |err|={e:.3e} |ref|={n:.3e}\n" + report(p.grad, ref_grads[k], k))
+            bad.append(f"{k}: |err|={e:.3e} |ref|={n:.3e} ({e / n:.1%})\n" + report(p.grad, ref_grads[k], k))
+    if os.environ.get("BMT_GRAD_REPORT") == "1":
+        print(f"global relative gradient error {(e2 / max(r2, 1e-300)) ** 0.5:.3e}")
+        for r, k, n in sorted(rows, reverse=True)[:12]:
+            print(f"   {r:8.3%}  |ref| {n:.3e}  {k}")
     if r2 > 0 and (e2 / r2) ** 0.5 > global_tol:
         bad.append(f"global relative gradient error {(e2 / r2) ** 0.5:.3e} > {global_tol}")
     assert not bad, "\n".join(bad)
