@@ -286,6 +286,7 @@ class _WeightPlanes:
         self.fresh_epoch = -1
         self.dirty_table = True
         self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt, transposed plane [K][sum N] or None]
+        self.lock = __import__("threading").RLock()      # the registry is shared by every stream / thread of the process
 
     @staticmethod
     def _key(W):
@@ -444,14 +445,18 @@ _weights = _WeightPlanes()
 
 
 def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:
-    return _weights.get(W, fmt)
+    with _weights.lock:
+        return _weights.get(W, fmt)
 
 
 FUSE_PROJECTIONS = _os.environ.get("BMT_NO_FUSE") != "1"      # Q/K/V (self-attention) and K/V (cross-attention) projections as one GEMM each way
 
 
 def weight_group(Ws, bs, fmt: str = "x3"):
-    return _weights.get_group(tuple(Ws), tuple(bs), fmt) if FUSE_PROJECTIONS else None
+    if not FUSE_PROJECTIONS:
+        return None
+    with _weights.lock:
+        return _weights.get_group(tuple(Ws), tuple(bs), fmt)
 
 
 # dX = dY . W with W^T as a ROW-MAJOR operand (a transposed bf16 plane per weight, refreshed with the other planes once per step)
@@ -463,11 +468,13 @@ DX_ROW_MAJOR = _os.environ.get("BMT_DX_ROWMAJOR") == "1"
 
 
 def weight_planes_t(W: torch.Tensor) -> Planes:
-    return _weights.get_t(W)
+    with _weights.lock:
+        return _weights.get_t(W)
 
 
 def weight_group_t(Ws) -> Planes:
-    return _weights.get_group_t(tuple(Ws))
+    with _weights.lock:
+        return _weights.get_group_t(tuple(Ws))
 
 
 def group_static_grad(Ws):
@@ -499,17 +506,18 @@ def as_planes(x, fmt: str) -> Planes:
     return make_planes(x, fmt)
 
 
-_SPLITK_WS = {}          # device index -> fp32 scratch; one compute stream per device
+_SPLITK_WS = {}          # (device index, stream) -> fp32 scratch: launches of one stream are ordered, two streams must not share it
 SPLITK_WS_BYTES = 128 << 20
 
 
 def splitk_workspace(device):
-    """scratch for the GEMM's two-pass split-K (bmt_gemm_bf16_args.splitk_ws)"""
-    idx = torch.device(device).index or 0
-    ws = _SPLITK_WS.get(idx)
+    """scratch for the GEMM's two-pass split-K (bmt_gemm_bf16_args.splitk_ws) of the current stream.  A graph capture runs on its own
+    stream: its workspace comes out of the capture's memory pool on first use."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
+    ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
-        _SPLITK_WS[idx] = ws
+        _SPLITK_WS[key] = ws
     return ws
 
 
@@ -657,12 +665,13 @@ def gemm_bf16_grouped(items):
     need = int(lib.bmt_gemm_bf16_grouped_ws_bytes(n))
     # the descriptor tables live in device memory until the launch has executed; several grouped launches of one backward pass
     # (flush points) are in flight together, so the scratch buffers rotate (allocated in the eager warm-up steps, before a capture)
-    slot = _dw_ws.setdefault((dev, "turn"), [0])
+    sk = (dev, torch.cuda.current_stream().cuda_stream)
+    slot = _dw_ws.setdefault(sk + ("turn",), [0])
     slot[0] = (slot[0] + 1) % 8
-    ws = _dw_ws.get((dev, slot[0]))
+    ws = _dw_ws.get(sk + (slot[0],))
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)
-        _dw_ws[(dev, slot[0])] = ws
+        _dw_ws[sk + (slot[0],)] = ws
     _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
 
 

@@ -626,3 +626,61 @@ def test_optimizer_state_and_weight_planes_after_graph_replays(golden):
     loss.backward()
     opt2.step()
     assert int(opt2._steps[0].item()) == 7
+
+
+def test_two_models_step_concurrently_on_two_streams(golden):
+    """the per-pass state of the Python layer (ops.StepContext: queued weight-gradient products, the residual offered to a sublayer's
+    last GEMM, LayerNorm's operand planes) is keyed by (device, stream), the split-K / descriptor scratch by stream, the weight-plane
+    registry is locked: two different models running forward + backward from two threads on two streams give the gradients of the same
+    passes run one after the other (up to the order of the fp32 atomics of the bias-gradient column sums: 1e-6 of the tensor's norm --
+    state leaking between the passes shows up as errors of order one)."""
+    import threading
+    from bmt_amd import ops
+    jobs = []
+    for name, scale in (("tiny_cap.npz", 1.0), ("tiny_cap_trainemb.npz", 0.5)):
+        g = golden(name)
+        cfg = syn.cfg_tiny()
+        V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+        model = _build(cfg, V, bool(use_glove), g.sub("sd/"))
+        fs = {"rgb": g["rgb"] * scale, "flow": g["flow"], "audio": g["audio"]}
+        jobs.append((model, cfg, fs, g["captions"], torch.cuda.Stream()))
+
+    def run(job, rounds):
+        model, cfg, fs, caps, stream = job
+        out = []
+        with torch.cuda.stream(stream):
+            ctx = ops.context()
+            for _ in range(rounds):
+                model.zero_grad(set_to_none=True)
+                ctx.defer_dw = True              # the weight-gradient products of the pass are queued and issued as one grouped launch
+                _, loss, _ = _run_cap(model, cfg, fs, caps)
+                loss.backward()
+                ops.flush_dw()
+                ctx.defer_dw = False
+                out.append((float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+        stream.synchronize()
+        return out
+
+    serial = [run(j, 3) for j in jobs]           # also the warm-up: weight planes, pointer tables, allocator pools
+    results = [None, None]
+    errors = []
+
+    def worker(i):
+        try:
+            results[i] = run(jobs[i], 3)
+        except Exception as e:          # noqa: BLE001  (reported by the assertion below)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for (l0, g0), (l1, g1) in zip(serial[i], results[i]):
+            assert l0 == l1, (i, l0, l1)
+            assert g0.keys() == g1.keys()
+            for k in g0:
+                d, n = float((g0[k] - g1[k]).double().norm()), float(g0[k].double().norm())
+                assert d <= 1e-6 * n + 1e-12, f"model {i}: gradient of {k} differs between the serial and the concurrent pass ({d:.3e} of {n:.3e})"
