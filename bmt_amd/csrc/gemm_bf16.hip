@@ -1306,6 +1306,14 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.pipe = 0;
     if (!a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = 2;
 
+    // 256 x 128 tiles (one workgroup per CU, 64-deep stages also for the two-plane product): for launches that are exactly one
+    // or two rounds of 256 such tiles with a long reduction (the video stream's out-projections, Q projection and FFN-2)
+    static const int tall = getenv("BMT_GEMM_TALL") ? atoi(getenv("BMT_GEMM_TALL")) : 512;         // A/B experiments only
+    static const int tall_any = getenv("BMT_GEMM_TALL_ANY") ? atoi(getenv("BMT_GEMM_TALL_ANY")) : 0;
+    if (p.pipe == 2 && tall && a->Kpad >= tall) {
+        const int t256 = bmt_cdiv(a->M, 256) * p.tiles_n, cus = bmt_device_cus();
+        if (t256 >= cus && (t256 % cus == 0 || tall_any)) p.pipe = 1;
+    }
     if (force_pipe == 0) p.pipe = 0;
     if (force_pipe >= 1 && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = force_pipe;   // 1: 256-row tile, 2: 128-row tile
     // the 256 x 256 ping-pong kernel: row-major operands, plain epilogues (no column sums / accumulation / split-K)
