@@ -764,6 +764,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int b = bh / p.H, h = bh % p.H;
     const int q = qt * 128 + wid * 16 + c;
     const bool qok = q < p.Sq;
+    // a wave whose 16 queries all lie past Sq (the decoder: 29 queries per tile of 128) only helps to stage the tiles
+    const bool wave_on = qt * 128 + wid * 16 < p.Sq;
 
     bf16x8 qf[KS];
     {
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tn = min(t + 1, ntile - 1);              // the last stage re-fetches itself (branch-free)
         BMT_F64_FETCH(tn);
         const int flag = sFlag[cur];
-        if (flag != 0) {
+        if (flag != 0 && wave_on) {
             const char* sK = smem + cur * STAGE;
             const char* sV = sK + TILE;
             const int key0 = t * BC;
@@ -1461,6 +1463,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int b = bh / p.H, h = bh % p.H;
     const int q = qt * 128 + wid * 16 + c;
     const bool qok = q < p.Sq;
+    const bool wave_on = qt * 128 + wid * 16 < p.Sq;      // see attn_fwd64_kernel
 
     bf16x8 qf[KS], dof[KS];
     {
@@ -1545,7 +1548,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tn = min(t + 1, ntile - 1);
         BMT_DQ64_FETCH(tn);
         const int flag = sFlag[cur];
-        if (flag != 0) {
+        if (flag != 0 && wave_on) {
             const char* sK = smem + cur * STAGE;
             const char* sV = sK + TILE;
             const int key0 = t * BC;
@@ -1879,12 +1882,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     grad_store_rows16<DK>(p.gv, accv, b, h, key, kok, g);
     grad_store_rows16<DK>(p.gk, acck, b, h, key, kok, g);
     if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
-        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [dV, dK][DK][128 + 8]
+        // one [DK][128 + 8] tile at a time (dV, then dK) in the stage buffers: 70 KB of LDS instead of 139 KB (occupancy stays at one
+        // workgroup per CU at d_k = 256 -- 254 registers --, two at d_k = 128)
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+        __syncthreads();
         grad_tile_write16<DK, KBLK>(tile, accv, wid * 16, kok, c, g);
-        grad_tile_write16<DK, KBLK>(tile + DK * (KBLK + 8), acck, wid * 16, kok, c, g);
         __syncthreads();
         grad_tile_flush<DK, KBLK, NT>(tile, p.gv, b, h, kt * KBLK, p.Sk, tid);
-        grad_tile_flush<DK, KBLK, NT>(tile + DK * (KBLK + 8), p.gk, b, h, kt * KBLK, p.Sk, tid);
+        __syncthreads();
+        grad_tile_write16<DK, KBLK>(tile, acck, wid * 16, kok, c, g);
+        __syncthreads();
+        grad_tile_flush<DK, KBLK, NT>(tile, p.gk, b, h, kt * KBLK, p.Sk, tid);
     }
 }
 
@@ -2027,8 +2035,8 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             static const int old_dkv = getenv("BMT_ATTN_DKV_OLD") ? atoi(getenv("BMT_ATTN_DKV_OLD")) : 0;      // A/B experiments only
             const bool fits = ((int64_t)p.Sq * p.ldq * 2 < (1ll << 31)) && ((int64_t)p.Sq * p.ldo * 2 < (1ll << 31));
             if (!old_dkv && fits) {
-                const int lds_loop2 = 2 * 2 * 32 * (DK * 2 + 32) + 512;
-                const int lds2 = lds_loop2 > lds_epi ? lds_loop2 : lds_epi;
+                const int lds_loop2 = 2 * 2 * 32 * (DK * 2 + 32) + 512, lds_epi2 = DK * (128 + 8) * 2;
+                const int lds2 = lds_loop2 > lds_epi2 ? lds_loop2 : lds_epi2;
                 if (p.mask != nullptr && p.mask_qs != 0) {
                     static bool done2 = false;
                     if (!done2) {
