@@ -157,6 +157,25 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
     return __builtin_bit_cast(bf16x8, (v8s16)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// The same fragment from the UNPADDED image the LDS-DMA ring fills ([BK rows][128 columns], 256-byte rows): the four rows a 16-lane
+// group of a transpose read touches would share their banks, so the 16-byte slots of a row are XOR-ed with 4 (row & 3) -- applied to
+// the source address by the DMA and to the read address here.  row & 3 = (lane & 15) >> 2 for every fragment, so the swizzle folds
+// into one per-lane byte offset per fragment column base (km_sw_off), the k16 step and the second read are immediates.
+__device__ __forceinline__ int km_sw_off(int colbase, int lane) {
+    const int m = lane & 15;
+    const int cb = (colbase + 16 * ((lane >> 4) & 1) + 4 * (m & 3)) * 2;         // byte column of this lane's 8 bytes
+    return (8 * (lane >> 5) + (m >> 2)) * 256 + (((cb >> 4) ^ ((m >> 2) << 2)) << 4) + (cb & 15);
+}
+__device__ __forceinline__ bf16x8 km_frag_sw(const char* img, int off, int k16) {
+    typedef short v4s16 __attribute__((ext_vector_type(4)));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    typedef v4s16 __attribute__((address_space(3))) * lds_v4s;
+    const char* a = img + off + k16 * 256;
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)a);
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a + 4 * 256));
+    return __builtin_bit_cast(bf16x8, (v8s16)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // WM = 2: 128x128 tile, 4 waves, two workgroups per CU.  WM = 4: 256x128 tile, 8 waves, one workgroup per CU -- the same two
 // waves per SIMD, but 3/4 of the operand bytes per FLOP: the 128x128 kernel moves ~7.5 TB/s of operand tiles L2 -> LDS at
 // 29 % MFMA utilisation (profiles/r01_d_gemm_l2_pmc.txt), i.e. it is bound by the L2 -> CU fabric, not by L1, LDS or MFMA.
@@ -170,16 +189,20 @@ __device__ __forceinline__ bf16x8 km_frag(const char* img, int k16, int colbase,
 // global -> LDS by LDS-DMA (global_load_lds, no staging registers, no ds_write), a ring of R stage buffers with R - 1 tiles in
 // flight ACROSS the (single, raw) barrier of a stage, counted vmcnt -- cdna_hip_programming.md section 5 "pipelining across
 // barriers".  Everything around the loop (tile order, split-K, epilogue) is shared with the register-staged loop.
-template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false>
+// TAG: a distinct specialization per calling kernel template.  hipcc 7.2 (host pass) rejects the call of one and the same k-major
+// PIPE specialization from a second kernel template with an unexplained "substitution failure"; the device code is identical.
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false, int TAG = 0>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
-    static_assert(!PIPE || (WM == 4 && !AKM && !BKM && CONV == 0 && NPASS <= 2), "pipelined loop: 8 waves, row-major operands");
+    static_assert(!PIPE || (WM == 4 && CONV == 0 && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && TI == 1))),
+                  "pipelined loop: 8 waves; k-major operands on the one-plane 128-row tile");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = gemm_bk(NPASS, PIPE, TI);
     constexpr bool ALO = NPASS == 3, BLO = NPASS >= 2;
     constexpr int SPR = BK / 8;
     constexpr int BM = 32 * TI * WM, NT = 128 * WM;       // WM waves along M x 2 along N
-    constexpr int PA = AKM ? BK * km_rs<BM>() : BM * BK * 2, PBB = BKM ? BK * km_rs<BN>() : BN * BK * 2;   // bytes of one A / B plane tile
+    // bytes of one A / B plane tile (k-major: [BK rows][columns], padded rows in the register-staged loop, swizzled rows in the DMA ring)
+    constexpr int PA = (AKM && !PIPE) ? BK * km_rs<BM>() : BM * BK * 2, PBB = (BKM && !PIPE) ? BK * km_rs<BN>() : BN * BK * 2;
     constexpr int STAGE_BYTES = (ALO ? 2 : 1) * PA + (BLO ? 2 : 1) * PBB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -219,6 +242,15 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         for (int i = 0; i < p.exp_sleep; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
 
+    int kma_off[TI], kmb_off[2];          // k-major fragments of the DMA ring: per-lane byte offsets (km_sw_off)
+    if constexpr (PIPE && AKM) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) kma_off[i] = km_sw_off(wr * 32 * TI + i * 32, lane);
+    }
+    if constexpr (PIPE && BKM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) kmb_off[j] = km_sw_off(wc * 64 + j * 32, lane);
+    }
     // Two register sets: the global loads of stage t+2 are issued before the MFMAs of stage t, so every load has two
     // iterations (two barriers) to land -- with 2 workgroups per CU and ~0.2 us of MFMA work per stage a single stage of
     // prefetch leaves the loop waiting on HBM/L2 latency (profiles/r01_c: 16 iterations of a 24-tile GEMM took 50 us).
@@ -281,13 +313,15 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             bf16x8 ah[TI], bh[2], al[TI], bl[2];                                          \
             _Pragma("unroll") for (int i = 0; i < TI; ++i) {                              \
                 const int ia = slot_of<SPR>(wr * 32 * TI + i * 32 + l31, sl);             \
-                if constexpr (AKM) ah[i] = km_frag<BM>(reinterpret_cast<const char*>(sAh), 16 * s, wr * 32 * TI + i * 32, lane); \
+                if constexpr (AKM && PIPE) ah[i] = km_frag_sw(reinterpret_cast<const char*>(sAh), kma_off[i], 16 * s);  \
+                else if constexpr (AKM) ah[i] = km_frag<BM>(reinterpret_cast<const char*>(sAh), 16 * s, wr * 32 * TI + i * 32, lane); \
                 else ah[i] = as_bf16x8(sAh[ia]);                                          \
                 if constexpr (ALO) al[i] = as_bf16x8(sAl[ia]);                            \
             }                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                               \
                 const int ib = slot_of<SPR>(wc * 64 + i * 32 + l31, sl);                  \
-                if constexpr (BKM) bh[i] = km_frag<BN>(reinterpret_cast<const char*>(sBh), 16 * s, wc * 64 + i * 32, lane); \
+                if constexpr (BKM && PIPE) bh[i] = km_frag_sw(reinterpret_cast<const char*>(sBh), kmb_off[i], 16 * s);  \
+                else if constexpr (BKM) bh[i] = km_frag<BN>(reinterpret_cast<const char*>(sBh), 16 * s, wc * 64 + i * 32, lane); \
                 else bh[i] = as_bf16x8(sBh[ib]);                                          \
                 if constexpr (BLO) bl[i] = as_bf16x8(sBl[ib]);                            \
             }                                                                             \
@@ -315,34 +349,48 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         constexpr int R = pipe_ring(STAGE_BYTES, TI);
         const int wid_s = __builtin_amdgcn_readfirstlane(wid);
         const int rl = lane / SPR, sp = lane % SPR;             // row within the piece, slot POSITION within the row
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsBl = __builtin_amdgcn_make_buffer_rsrc((void*)(BLO ? p.Bl : p.Bh), 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+        // (k-major operand: a piece is 4 reduction rows x 256 B; lane -> row lane >> 4, slot position lane & 15, source slot
+        // position ^ 4 (row & 3); the descriptor ends after reduction row K, later rows read as zero; columns past the operand's
+        // extent are duplicates of its last 8, discarded by the epilogue)
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)b_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsBl = __builtin_amdgcn_make_buffer_rsrc((void*)(BLO ? p.Bl : p.Bh), 0, (int)b_bytes, 0x00020000);
         int avo[APW], bvo[BPW];
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            const int row = (wid_s * APW + i) * RPP + rl;
-            const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
-            avo[i] = (int)((int64_t)min(m0 + row, p.M - 1) * p.lda * 2) + ks * 16;
+            if constexpr (AKM) {
+                const int kr = lane >> 4, sl = (lane & 15) ^ (kr << 2);
+                avo[i] = ((wid_s * APW + i) * 4 + kr) * (int)p.lda * 2 + min(m0 + sl * 8, (int)p.lda - 8) * 2;
+            } else {
+                const int row = (wid_s * APW + i) * RPP + rl;
+                const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
+                avo[i] = (int)((int64_t)min(m0 + row, p.M - 1) * p.lda * 2) + ks * 16;
+            }
         }
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
-            const int row = (wid_s * BPW + i) * RPP + rl;
-            const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
-            bvo[i] = (int)((int64_t)min(n0 + row, p.N - 1) * p.ldb * 2) + ks * 16;
+            if constexpr (BKM) {
+                const int kr = lane >> 4, sl = (lane & 15) ^ (kr << 2);
+                bvo[i] = ((wid_s * BPW + i) * 4 + kr) * (int)p.ldb * 2 + min(n0 + sl * 8, (int)p.ldb - 8) * 2;
+            } else {
+                const int row = (wid_s * BPW + i) * RPP + rl;
+                const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
+                bvo[i] = (int)((int64_t)min(n0 + row, p.N - 1) * p.ldb * 2) + ks * 16;
+            }
         }
         typedef __attribute__((address_space(3))) void* lptr_t;
 #define BMT_DMA(step_, slot_)                                                                                    \
         do {                                                                                                     \
             char* base_ = smem + (slot_) * STAGE_BYTES;                                                          \
-            const int so_ = (kbeg + (step_) * BK) * 2;                                                           \
+            const int k_ = kbeg + (step_) * BK;                                                                  \
+            const int so_ = AKM ? k_ * (int)p.lda * 2 : k_ * 2, sob_ = BKM ? k_ * (int)p.ldb * 2 : k_ * 2;       \
             _Pragma("unroll") for (int i = 0; i < APW; ++i)                                                      \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base_ + (wid_s * APW + i) * 1024), 16, avo[i], so_, 0, 0);          \
             _Pragma("unroll") for (int i = 0; i < BPW; ++i)                                                      \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(base_ + PA + (wid_s * BPW + i) * 1024), 16, bvo[i], so_, 0, 0);     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(base_ + PA + (wid_s * BPW + i) * 1024), 16, bvo[i], sob_, 0, 0);    \
             if constexpr (BLO) {                                                                                 \
                 _Pragma("unroll") for (int i = 0; i < BPW; ++i)                                                  \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBl, (lptr_t)(base_ + PA + PBB + (wid_s * BPW + i) * 1024), 16, bvo[i], so_, 0, 0); \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBl, (lptr_t)(base_ + PA + PBB + (wid_s * BPW + i) * 1024), 16, bvo[i], sob_, 0, 0); \
             }                                                                                                    \
         } while (0)
 #define BMT_VMWAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
@@ -601,13 +649,13 @@ template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
     gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, CONV, F16>(p, blockIdx.x, blockIdx.y);
 }
-template <int NPASS, bool F16, int TI>
+template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_pipe_kernel(const GemmB p) {
     // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so a workgroup stays on
     // the XCD its tiles were ordered for); its stores drain while the next tile's operands are already on their way
     const int ntiles = p.tiles_m * p.tiles_n;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        gemm_bf16_tile<NPASS, 4, TI, false, false, 0, F16, true>(p, t, blockIdx.y);
+        gemm_bf16_tile<NPASS, 4, TI, AKM, BKM, 0, F16, true, 1>(p, t, (int)blockIdx.y, false);
         __syncthreads();          // the stage buffers (epilogue tile) are free again
     }
 }
@@ -946,7 +994,7 @@ struct XcdSeg {
 };
 constexpr int XCD_MAXSEG = 64;
 
-template <int NPASS, int WM, int TI, bool AKM, bool BKM>
+template <int NPASS, int WM, int TI, bool AKM, bool BKM, bool PIPE = false>
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_grouped_kernel(
     const GemmB* __restrict__ table, const XcdSeg* __restrict__ segs, const int* __restrict__ nseg) {
     const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
@@ -962,7 +1010,8 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     const int local = slot - sg.first_slot;
     if (local >= sg.count) return;                    // past the end of this XCD's list
     const GemmB p = table[sg.prob];
-    gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, sg.tile_off + local, 0, true);
+    if constexpr (PIPE) gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0, false, true, 2>(p, sg.tile_off + local, 0, true);
+    else gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, sg.tile_off + local, 0, true);
 }
 
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
@@ -1201,7 +1250,7 @@ int launch(const GemmB& p, int splitk, hipStream_t st) {
     return BMT_OK;
 }
 
-template <int NPASS, bool F16, int TI>
+template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false>
 int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int BK = gemm_bk(NPASS, true, TI);
     constexpr int BMr = 128 * TI;
@@ -1210,13 +1259,13 @@ int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int lds = (R * stage > BMr * BN * 4) ? R * stage : BMr * BN * 4;
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
     static const int persist = getenv("BMT_GEMM_PERSIST") ? atoi(getenv("BMT_GEMM_PERSIST")) : 1;      // A/B experiments only
     const int tiles = p.tiles_m * p.tiles_n, slots = bmt_device_cus() * (TI == 2 ? 1 : 2);
     const int gx = (persist && tiles > slots && slots % 8 == 0) ? slots : tiles;
-    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI>), dim3(gx, splitk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM>), dim3(gx, splitk), dim3(512), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(pipelined)");
     return BMT_OK;
 }
@@ -1383,6 +1432,11 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     const int waves8 = force8 >= 0 ? force8 : 1;
     hipStream_t st_ = (hipStream_t)stream;
     const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
+    // k-major operands through the LDS-DMA ring (swizzled unpadded images): correct (the k-major GEMM tests pass on it) but slower in
+    // the step than the register-staged loop with its two tiles of prefetch -- the ring has room for two stages only at two workgroups
+    // per CU: dX class 1.74 -> 2.06 ms, grouped dW unchanged (tools/gpu_ab.sh BMT_GEMM_KM_PIPE=0/1).  Off; kept as a switch.
+    static const int km_pipe_env = getenv("BMT_GEMM_KM_PIPE") ? atoi(getenv("BMT_GEMM_KM_PIPE")) : 0;      // A/B experiments only
+    const bool km_pipe = km_pipe_env && a->conv_mode == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0;
     const bool f16 = a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2;
     if (f16 && (akm || bkm || a->conv_mode == 2)) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
@@ -1406,6 +1460,10 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         rc = a->precision == BMT_PREC_F16W2 ? launch<2, 4, 1, false, false, 0, true>(p, splitk, st_) : launch<1, 4, 1, false, false, 0, true>(p, splitk, st_);
     } else if (a->conv_mode == 2) {   // implicit Conv1d dW
         rc = launch<1, 4, 1, true, true, 2>(p, splitk, st_);
+    } else if ((akm || bkm) && km_pipe) {    // k-major operands through the LDS-DMA ring (swizzled images, transpose reads)
+        if (akm && bkm) rc = launch_pipe<1, false, 1, true, true>(p, splitk, st_);
+        else if (bkm) rc = launch_pipe<1, false, 1, false, true>(p, splitk, st_);
+        else rc = launch_pipe<1, false, 1, true, false>(p, splitk, st_);
     } else if (akm || bkm) {                 // single-pass kernel, 128-row tiles
         if (akm && bkm) rc = waves8 ? launch<1, 4, 1, true, true>(p, splitk, st_) : launch<1, 2, 2, true, true>(p, splitk, st_);
         else if (bkm) rc = waves8 ? launch<1, 4, 1, false, true>(p, splitk, st_) : launch<1, 2, 2, false, true>(p, splitk, st_);
@@ -1539,6 +1597,19 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     free(sp);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(table)");
     constexpr int BK = 64, BMr = 128;
+    static const int km_pipe = getenv("BMT_GEMM_KM_PIPE") ? atoi(getenv("BMT_GEMM_KM_PIPE")) : 0;      // A/B experiments only (see bmt_gemm_bf16)
+    if (km_pipe) {                   // the LDS-DMA ring on swizzled k-major images
+        constexpr int stage_p = (BMr + BN) * BK * 2;
+        constexpr int lds_p = pipe_ring(stage_p, 1) * stage_p;
+        static bool done_p = false;
+        if (!done_p) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 4, 1, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_p);
+            done_p = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true, true>), dim3(8 * max_slots), dim3(512), lds_p, st, table, segs, nseg);
+        BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped");
+        return BMT_OK;
+    }
     constexpr int stage = BK * km_rs<BMr>() + BK * km_rs<BN>();
     constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;
     static bool done = false;
