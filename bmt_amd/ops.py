@@ -101,9 +101,10 @@ def precision_description() -> str:
         o = _OVERRIDE[0]
         return f"every forward GEMM {prec_name(o.gemm)}, attention forward {prec_name(o.attn)}, backward {prec_name(BWD_PRECISION)} MFMA operands; fp32 accumulate"
     e, d, x = POLICIES["enc"], POLICIES["dec"], POLICIES[None]
-    return (f"MFMA operands per site: encoder GEMMs + decoder memory K/V projections {prec_name(e.gemm)} ({prec_passes(e.gemm)} passes; encoder "
-            f"FFN-2 {prec_name(e.ffn2)}, {prec_passes(e.ffn2)} pass), attention forward {prec_name(e.attn)} (1 pass), decoder GEMMs / bridge / "
-            f"generator {prec_name(x.gemm)} (3 passes), backward {prec_name(BWD_PRECISION)} (1 pass); fp32 accumulate, softmax, LayerNorm, loss, Adam")
+    ffn2 = "" if e.ffn2 == e.gemm else f"; encoder FFN-2 {prec_name(e.ffn2)}, {prec_passes(e.ffn2)} pass(es)"
+    return (f"MFMA operands per site: encoder GEMMs + decoder memory K/V projections {prec_name(e.gemm)} ({prec_passes(e.gemm)} passes{ffn2}), "
+            f"attention forward {prec_name(e.attn)} (1 pass), decoder GEMMs / bridge / generator {prec_name(x.gemm)} (3 passes), backward "
+            f"{prec_name(BWD_PRECISION)} (1 pass); fp32 accumulate, softmax, LayerNorm, loss, Adam")
 
 
 WEIGHT_EPOCH = [0]      # bumped by the optimizer: invalidates cached weight planes
