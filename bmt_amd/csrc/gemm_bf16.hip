@@ -991,6 +991,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // on the same XCD, and an operand panel is fetched by as few XCDs as the load balance allows.
 struct XcdSeg {
     int first_slot, prob, tile_off, count;
+    int nsplit;       // reduction chunks of the problem (p.kchunk rows each); the segment's work items are chunk-major: item L = chunk
+                      // L / count of tile tile_off + L % count, so the workgroups an XCD runs together stream the SAME rows of
+                      // neighbouring tiles' operand panels (they would drift apart over a 25600-row reduction and out of the 4 MB L2)
 };
 constexpr int XCD_MAXSEG = 64;
 
@@ -1008,10 +1011,11 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     }
     const XcdSeg sg = sx[lo];
     const int local = slot - sg.first_slot;
-    if (local >= sg.count) return;                    // past the end of this XCD's list
+    if (local >= sg.count * sg.nsplit) return;        // past the end of this XCD's list
     const GemmB p = table[sg.prob];
-    if constexpr (PIPE) gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0, false, true, 2>(p, sg.tile_off + local, 0, true);
-    else gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, sg.tile_off + local, 0, true);
+    const int tile = sg.tile_off + local % sg.count, split = local / sg.count;
+    if constexpr (PIPE) gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0, false, true, 2>(p, tile, split, true);
+    else gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, tile, split, true);
 }
 
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
@@ -1515,7 +1519,12 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     BMT_CHECK_ARG(ws_bytes >= bmt_gemm_bf16_grouped_ws_bytes(nprob) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                   "bmt_gemm_bf16_grouped: workspace too small or not 16-byte aligned");
     static_assert(sizeof(GemmB) % 4 == 0, "descriptor is copied word-wise");
-    struct Prob { GemmB p; int tiles, stages; };
+    struct Prob { GemmB p; int tiles, stages, nsplit; };
+    // reduction chunk (64-row stages) of a work item; 0 = whole reductions.  Partial products accumulate with the fp32 atomics the
+    // unsplit launch uses too (C += alpha A B is the only epilogue here)
+    // measured (tools/gpu_ab.sh, whole step; PMC: the unsplit launch fetched 6 GB for ~1 GB of unique operands at 5.1 TB/s): chunks
+    // of 16 / 32 / 64 / 100 / 134 / 200 stages -> 1.48 / 1.14 / 1.02 / 1.02 / 1.06 / 1.05 ms against 1.235 ms unsplit
+    static const int chunk = getenv("BMT_GROUPED_CHUNK") ? atoi(getenv("BMT_GROUPED_CHUNK")) : 64;     // A/B experiments only
     Prob* pr = (Prob*)malloc(sizeof(Prob) * (size_t)nprob);
     int* order = (int*)malloc(sizeof(int) * (size_t)nprob);
     SegPack* sp = (SegPack*)malloc(sizeof(SegPack) * 4);
@@ -1534,6 +1543,12 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         rc = gemm_prepare(a, pr[i].p, splitk, false);
         pr[i].tiles = pr[i].p.tiles_m * pr[i].p.tiles_n;
         pr[i].stages = a->Kpad / 64;
+        pr[i].nsplit = 1;
+        if (chunk > 0 && pr[i].stages > chunk + chunk / 2) {
+            pr[i].nsplit = bmt_cdiv(pr[i].stages, chunk);
+            pr[i].p.kchunk = bmt_cdiv(pr[i].stages, pr[i].nsplit) * 64;
+            pr[i].nsplit = bmt_cdiv(a->Kpad, pr[i].p.kchunk);
+        }
         total_work += (double)pr[i].tiles * (pr[i].stages + 2);      // + prologue / epilogue of a tile
         order[i] = i;
     }
@@ -1568,8 +1583,8 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
             else for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
             if (ns[x] >= XCD_MAXSEG) { overflow = true; break; }
             XcdSeg& sg = sp[x / 2].s[x & 1][ns[x]++];
-            sg.first_slot = slots[x]; sg.prob = i; sg.tile_off = t0; sg.count = cnt;
-            slots[x] += cnt;
+            sg.first_slot = slots[x]; sg.prob = i; sg.tile_off = t0; sg.count = cnt; sg.nsplit = pr[i].nsplit;
+            slots[x] += cnt * pr[i].nsplit;
             load[x] += (double)cnt * (pr[i].stages + 2);
         }
     }

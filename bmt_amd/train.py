@@ -206,10 +206,16 @@ class CaptioningTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        # capture_error_mode="thread_local": with a process group alive, the RCCL watchdog THREAD polls the events of finished
+        # collectives (hipEventQuery); in the default global mode that call is illegal while any stream of the process captures -- it
+        # invalidates the capture and the watchdog's exception terminates the process (seen in ~1 of 8 runs of tools/dp_smoke_1gpu.py:
+        # "operation not permitted when stream is capturing").  The kernels of autograd's worker threads are still captured: capture
+        # is a property of the stream, the mode only says whose unsafe calls are errors.
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             self._static_kl, self._static_ntok = self._forward_backward(self._static_fs, self._static_caps)
         self._reduce(self._static_kl, self._static_ntok)
-        with torch.cuda.graph(g2, pool=g1.pool()):
+        torch.cuda.synchronize()                # the eager all-reduce has finished before the second capture starts
+        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             self._optimize()
         self._graphs = (g1, g2)
         return self._graphs
