@@ -68,7 +68,7 @@ class AttnBwdBf16Args(C.Structure):
                 ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64),
                 ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
-                ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp)]
+                ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32)]
 
 
 class SelectProposalsArgs(C.Structure):
@@ -82,7 +82,7 @@ PP_CORNERS, PP_TRIM, PP_FILTER = 1, 2, 4
 # name -> (restype, argtypes); every symbol include/bmt_hip.h declares
 SIGNATURES = {
     "bmt_version": (i32, []),
-    "bmt_attn_kmean": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, vp]),
+    "bmt_attn_kmean": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
     "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp]),

@@ -159,7 +159,22 @@ struct AttnPB {
     const uint64_t* rng;
     uint32_t site;
     const float* kmean;                    // backward, optional: fp32 [B][H * d_k] mean key over the valid keys (bmt_attn_kmean)
+    int qkv_f16;                           // backward, 16-wide kernels: Qh / Kh / Vh hold fp16 (the forward's planes); converted to bf16 on load
 };
+
+// 8 fp16 -> 8 bf16 (round to nearest even) in one 16-byte register slot: q / k / v exist as fp16 planes only under the fp16 attention
+// policy (4 instead of 6 bytes per element written by the projections); the backward's bf16 products convert them while staging
+__device__ __forceinline__ uint32_t h2_to_b2(uint32_t w) {
+    const f32x2_t f = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2_t);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+// (element by element from scalars: a loop that assigns r[q] of an uninitialised ext_vector came out of hipcc 7.2 with r[1..3] all
+// equal to r[0] -- the check in tools/probes/qkv_f16_bwd_check.py compares the mean-key kernel on the two plane kinds)
+__device__ __forceinline__ u32x4 h8_to_b8(u32x4 v) {
+    const uint32_t a = h2_to_b2(v[0]), b = h2_to_b2(v[1]), c = h2_to_b2(v[2]), d = h2_to_b2(v[3]);
+    return u32x4{a, b, c, d};
+}
+__device__ __forceinline__ bf16x8 h8_to_b8(bf16x8 v) { return as_bf16x8(h8_to_b8(__builtin_bit_cast(u32x4, v))); }
 
 // dQ_i = sum_j dS_ij K_j with sum_j dS_ij = 0 exactly: the bf16 rounding of dS leaves a residue (sum_j round(dS_ij)) that the
 // product multiplies by the keys' common component -- 10-25 % of |dQ| where attention is near uniform over many similar keys
@@ -1472,6 +1487,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
+            if (p.qkv_f16) qf[ks] = h8_to_b8(qf[ks]);
             dof[ks] = ldfrag(p.dOh + oo + 32 * ks, qok);
         }
     }
@@ -1536,6 +1552,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define BMT_DQ64_STORE(t_, buf_)                                                                       \
     do {                                                                                               \
         char* sk_ = smem + (buf_) * STAGE;                                                             \
+        if (p.qkv_f16) {                                                                               \
+            _Pragma("unroll") for (int i = 0; i < NR; ++i) { kr[i] = h8_to_b8(kr[i]); vr[i] = h8_to_b8(vr[i]); }  \
+        }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sk_ + lso[i]) = kr[i];        \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sk_ + TILE + lso[i]) = vr[i]; \
         stage_mask<BC>(p, b, (t_) * BC, tid, sMask + (buf_) * BC, sFlag + (buf_));                      \
@@ -1788,6 +1807,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ks = 0; ks < KS; ++ks) {
                 kf[ks] = ldfrag(p.Kh + ko + 32 * ks, true);
                 vf[ks] = ldfrag(p.Vh + vo + 32 * ks, true);
+                if (p.qkv_f16) { kf[ks] = h8_to_b8(kf[ks]); vf[ks] = h8_to_b8(vf[ks]); }
             }
         }
         const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0,
@@ -1821,6 +1841,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define BMT_DKV32_STORE(buf_)                                                                          \
     do {                                                                                               \
         char* sq_ = smem + (buf_) * STAGE;                                                             \
+        if (p.qkv_f16) {                                                                               \
+            _Pragma("unroll") for (int i = 0; i < NR; ++i) rq[i] = h8_to_b8(rq[i]);                           \
+        }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sq_ + lso[i]) = rq[i];       \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) *reinterpret_cast<u32x4*>(sq_ + TP + lso[i]) = rdo[i]; \
         if (tid < BQ) { sStat[(buf_) * 64 + tid] = rl; sStat[(buf_) * 64 + 32 + tid] = rd; }           \
@@ -1901,7 +1924,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (the mask byte is a multiplier) so the key loop unrolls into batches of loads in flight -- a `continue` on the mask byte made
 // every iteration a dependent L2 round trip (100 us per call instead of 7).  grid (B, ceil(D / 128)).
 __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restrict__ Kh, int64_t ldk, int64_t bsk, const uint8_t* __restrict__ mask,
-                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out) {
+                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out, int f16) {
     constexpr int KG = 32;
     __shared__ float red[KG][129];
     __shared__ float cnt[KG];
@@ -1915,7 +1938,8 @@ __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restr
 #pragma unroll 8
     for (int k = kg; k < Sk; k += KG) {
         const float m = mb ? (mb[k] != 0 ? 1.f : 0.f) : 1.f;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)k * ldk);
+        u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)k * ldk);
+        if (f16) v = h8_to_b8(v);          // (uniform) the fp16 plane: same values the backward kernels will multiply
         n += m;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -2139,6 +2163,8 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.scale = a->scale; p.drop_p = a->drop_p;
     p.kmean = a->kmean;
+    p.qkv_f16 = a->qkv_f16;
+    BMT_CHECK_ARG(!a->qkv_f16 || a->dk >= 128, "bmt_attn_bwd_bf16: fp16 q / k / v planes are taken by the d_k >= 128 kernels only");
     hipStream_t st = (hipStream_t)stream;
     if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, st);
     if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, st);
@@ -2148,12 +2174,12 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
 }
 
 extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk,
-                              int D, float* out, void* stream) {
+                              int D, float* out, int k_f16, void* stream) {
     BMT_CHECK_ARG(Kh && out && B > 0 && Sk > 0 && D > 0 && D % 8 == 0 && ldk % 8 == 0 && bsk % 8 == 0 &&
                       (reinterpret_cast<uintptr_t>(Kh) & 15) == 0,
                   "bmt_attn_kmean: bad args (D, ldk, bsk multiples of 8, 16-byte aligned plane)");
     hipLaunchKernelGGL(attn_kmean_kernel, dim3(B, bmt_cdiv(D, 128)), dim3(512), 0, (hipStream_t)stream, Kh, ldk, bsk,
-                       mask_qs == 0 ? mask : nullptr, mask_bs, Sk, D, out);
+                       mask_qs == 0 ? mask : nullptr, mask_bs, Sk, D, out, k_f16);
     BMT_CHECK_LAUNCH("bmt_attn_kmean");
     return BMT_OK;
 }

@@ -25,8 +25,8 @@ struct GemmB {
     int64_t lda, ldb;
     float* C;
     int64_t ldc;
-    uint16_t *Chi, *Clo;                 // output planes: Chi = bf16(c); Clo = bf16(c - hi), or fp16(c) when second_f16
-    int second_f16;
+    uint16_t *Chi, *Clo;                 // output planes: Chi = bf16(c) (fp16(c) when hi_f16: the fp16 plane alone); Clo = bf16(c - hi), or fp16(c) when second_f16
+    int second_f16, hi_f16;
     int64_t ldp;
     int plane_cols;                      // planes are written for col < plane_cols (zeros for col >= N)
     int plane_vec;                       // plane outputs 16-B aligned with ldp, plane_cols multiples of 8: staged through LDS
@@ -609,6 +609,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
                 split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
                 h[q] = h_;
                 l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
+                if (p.hi_f16) h[q] = pack_h2(v[2 * q], v[2 * q + 1]);
             }
             const int64_t pi = (int64_t)row * p.ldp + col;
             if (p.plane_vec) {
@@ -963,6 +964,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
                     h[q] = h_;
                     l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
+                    if (p.hi_f16) h[q] = pack_h2(v[2 * q], v[2 * q + 1]);
                 }
                 const int64_t pi = (int64_t)row * p.ldp + col;
                 if (p.plane_vec) {
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
             if (col < p.plane_cols) {
                 const __bf16 hv = (__bf16)out[c];
                 const int64_t pi = (int64_t)row * p.ldp + col;
-                p.Chi[pi] = __builtin_bit_cast(uint16_t, hv);
+                p.Chi[pi] = p.hi_f16 ? __builtin_bit_cast(uint16_t, (_Float16)out[c]) : __builtin_bit_cast(uint16_t, hv);
                 if (p.Clo) p.Clo[pi] = p.second_f16 ? __builtin_bit_cast(uint16_t, (_Float16)out[c])
                                                     : __builtin_bit_cast(uint16_t, (__bf16)(out[c] - (float)hv));
             }
@@ -1297,7 +1299,7 @@ extern "C" int bmt_dbg_read(unsigned long long* dst, int n) {
 
 // validate the arguments and fill the kernel descriptor; splitk: in = 0 (decide here) / forced value, out = splits to launch
 static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool allow_split) {
-    BMT_CHECK_ARG(a && a->A_hi && a->B_hi && (a->C || a->C_hi), "bmt_gemm_bf16: null pointer");
+    BMT_CHECK_ARG(a && a->A_hi && a->B_hi && (a->C || a->C_hi || a->C_f16), "bmt_gemm_bf16: null pointer");
     BMT_CHECK_ARG(a->M > 0 && a->N > 0 && a->Kpad > 0 && a->Kpad % 64 == 0, "bmt_gemm_bf16: bad sizes M=%d N=%d Kpad=%d (Kpad %% 64 != 0?)",
                   a->M, a->N, a->Kpad);
     BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || (a->precision == BMT_PREC_BF16X3 && a->A_lo && a->B_lo) ||
@@ -1330,7 +1332,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     const bool accum = (a->flags & BMT_EPI_ACCUM) != 0;
     const bool two_pass = allow_split && a->splitk_ws != nullptr;             // split-K through a workspace: any epilogue
     const unsigned nonlin = BMT_EPI_RELU | BMT_EPI_DROP_PRE | BMT_EPI_DROP_POST | BMT_EPI_GATE | BMT_EPI_BIAS | BMT_EPI_RESIDUAL;
-    BMT_CHECK_ARG(splitk == 1 || two_pass || (accum && !(a->flags & nonlin) && !a->C_hi),
+    BMT_CHECK_ARG(splitk == 1 || two_pass || (accum && !(a->flags & nonlin) && !a->C_hi && !a->C_f16),
                   "bmt_gemm_bf16: splitk>1 needs either a split-K workspace or BMT_EPI_ACCUM with no other epilogue op / plane output");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_ACCUM) || a->C, "bmt_gemm_bf16: ACCUM needs the fp32 output");
     BMT_CHECK_ARG(!(a->flags & BMT_EPI_BIAS) || a->bias, "bmt_gemm_bf16: BIAS flag without pointer");
@@ -1339,11 +1341,16 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     memset(&p, 0, sizeof(p));
     p.Ah = a->A_hi; p.Al = a->A_lo; p.Bh = a->B_hi; p.Bl = a->B_lo; p.lda = a->lda; p.ldb = a->ldb;
     p.C = a->C; p.ldc = a->ldc; p.Chi = a->C_hi; p.Clo = a->C_f16 ? a->C_f16 : a->C_lo; p.second_f16 = a->C_f16 != nullptr; p.ldp = a->ldp;
-    p.plane_cols = a->C_hi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
-    p.plane_vec = a->C_hi && al16(a->C_hi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
+    p.hi_f16 = 0;
+    if (!a->C_hi && a->C_f16) {          // the fp16 plane alone (q / k / v under the fp16 attention policy: the backward converts on load)
+        BMT_CHECK_ARG(!a->C_lo && !a->colsum, "bmt_gemm_bf16: C_f16 without C_hi excludes C_lo and colsum");
+        p.Chi = a->C_f16; p.Clo = nullptr; p.second_f16 = 0; p.hi_f16 = 1;
+    }
+    p.plane_cols = p.Chi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
+    p.plane_vec = p.Chi && al16(p.Chi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
-    p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
+    p.tiles_n = bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
     // tile height: 256 rows (8 waves, one workgroup per CU) when that still fills the chip, else 128 rows (4 waves, two per CU)
     static const int force_bm = getenv("BMT_GEMM_BM") ? atoi(getenv("BMT_GEMM_BM")) : 0;      // A/B experiments only
     // measured (tools/microbench.py gemm with BMT_GEMM_BM / BMT_GEMM_8W): the 256-row tile gains 5 % for the 3-pass kernel on
@@ -1376,11 +1383,11 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     // measured (tools/microbench.py gemm, BMT_GEMM_WIDE=0/1): it wins where a launch has at least one full round of 256 x 256
     // tiles and a reduction long enough to amortise its prologue (8192 x 4096 x 1024 two-plane 169 -> 134 us, 8192 x 2048 x 1024
     // 87 -> 68 us); 128 tiles (half the CUs) or K = 128 (output-write bound either way) stay on the 128-row tiles
-    const int wide_tiles = bmt_cdiv(a->M, 256) * bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
+    const int wide_tiles = bmt_cdiv(a->M, 256) * bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
     if (wide_ok && (force_wide == 1 || (force_wide < 0 && force_pipe < 0 && wide_tiles >= bmt_device_cus() && a->Kpad >= 256))) p.pipe = 3;
     if (p.pipe == 3) {
         p.bm = 256;
-        p.tiles_n = bmt_cdiv(a->C_hi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
+        p.tiles_n = bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
         if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;      // the kernel runs its second pass iff there is a second weight plane
     }
     if (p.pipe == 1) p.bm = 256;

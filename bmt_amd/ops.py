@@ -588,13 +588,13 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
     if accum:
         flags |= EPI_ACCUM
     op = out_planes
-    if op is not None and (op.hi is None or (op.lo is not None and op.fh is not None) or op.fl is not None):
-        raise RuntimeError("gemm_bf16: output planes are hi + (lo | fh)")
+    if op is not None and ((op.hi is None and (op.fh is None or op.lo is not None)) or (op.lo is not None and op.fh is not None) or op.fl is not None):
+        raise RuntimeError("gemm_bf16: output planes are hi + (lo | fh), or fh alone")
     if splitk is None:
         splitk = 0 if AUTO_SPLITK else 1
     a = GemmBf16Args(_p(ah), _p(al), ah.stride(0), _p(bh), _p(bl), bh.stride(0),
                      _p(C_out), ldc if C_out is not None else N, _p(op.hi) if op else None, _p(op.lo) if op else None,
-                     op.hi.stride(0) if op else 0, M, N, Kpad, alpha, flags, _p(bias), _p(residual), ldr,
+                     op.any.stride(0) if op else 0, M, N, Kpad, alpha, flags, _p(bias), _p(residual), ldr,
                      _p(gate.hi) if gate is not None else None, gate.hi.stride(0) if gate is not None else 0, gate_scale,
                      drop_p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, site, precision, splitk)
     a.C_f16 = _p(op.fh) if op else None
@@ -894,13 +894,14 @@ def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision
 ATTN_KMEAN = _os.environ.get("BMT_NO_KMEAN") != "1"      # A/B: the dQ correction by (row sum of rounded dS) x mean key
 
 
-def attn_kmean(kh: torch.Tensor, ldk: int, bsk: int, B: int, Sk: int, D: int, mask_args) -> Optional[torch.Tensor]:
-    """fp32 [B][D] mean key over the valid keys of a K plane (bmt_attn_kmean), or None when the correction is switched off"""
+def attn_kmean(kh: torch.Tensor, ldk: int, bsk: int, B: int, Sk: int, D: int, mask_args, f16: bool = False) -> Optional[torch.Tensor]:
+    """fp32 [B][D] mean key over the valid keys of a K plane (bmt_attn_kmean; f16: the plane holds fp16), or None when the correction
+    is switched off"""
     _, mptr, mbs, mqs = mask_args
     if not ATTN_KMEAN or mqs != 0:       # a mask with a row per query (the decoder's causal self-attention: <= 30 keys, error 0.5 % as it is)
         return None
     out = torch.empty(B, D, device=kh.device, dtype=torch.float32)
-    _lib.check(lib.bmt_attn_kmean(_p(kh), ldk, bsk, mptr, mbs, mqs, B, Sk, D, _p(out), _st()), "bmt_attn_kmean")
+    _lib.check(lib.bmt_attn_kmean(_p(kh), ldk, bsk, mptr, mbs, mqs, B, Sk, D, _p(out), int(f16), _st()), "bmt_attn_kmean")
     return out
 
 
@@ -967,7 +968,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     the fused projection backward; the combined plane is returned as a 4th element.
     Returns [(P, db)] * 3 (+ [P_all])."""
     dk = D // H
-    dev = q.hi.device
+    dev = q.any.device
     Mq, Mk = B * Sq, B * Sk
     outs = []
     comb = None
@@ -989,10 +990,12 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     else:
         doh = torch.empty(B, Sq, D, device=dev, dtype=torch.bfloat16)
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
-    ldq, ldk, ldv, ldop = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0), o.hi.stride(0)
+    f16 = q.hi is None         # q / k / v saved as fp16 planes only (the kernels convert while staging)
+    qa, ka, va = (q.fh, k.fh, v.fh) if f16 else (q.hi, k.hi, v.hi)
+    ldq, ldk, ldv, ldop = qa.stride(0), ka.stride(0), va.stride(0), o.hi.stride(0)
     (qh_, qb_, _), (kh_, kb_, _), (vh_, vb_, _) = outs
-    km = attn_kmean(k.hi, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs))
-    a = AttnBwdBf16Args(Qh=_p(q.hi), Kh=_p(k.hi), Vh=_p(v.hi), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
+    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16)
+    a = AttnBwdBf16Args(Qh=_p(qa), Kh=_p(ka), Vh=_p(va), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
                         mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk), drop_p=drop_p,
@@ -1000,7 +1003,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
-                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km))
+                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16))
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
     for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
@@ -1330,6 +1333,17 @@ def attn_operand_fmt(attn_prec: int) -> str:
     return {PREC_BF16X3: "x3", PREC_F16: "f16", PREC_BF16: "bwd"}[attn_prec]
 
 
+QKV_F16_ONLY = _os.environ.get("BMT_QKV_BOTH_PLANES") != "1"     # A/B: q / k / v as fp16 planes only where the backward can convert them
+
+
+def attn_train_fmt(attn_prec: int, dk: int) -> str:
+    """q / k / v planes of a TRAINING pass: under the fp16 attention policy with d_k >= 128 the fp16 plane alone -- the backward
+    kernels convert it to bf16 while staging (bmt_attn_bwd_bf16_args.qkv_f16), the projections write 2 instead of 4 bytes per element"""
+    if attn_prec == PREC_F16 and dk >= 128 and QKV_F16_ONLY:
+        return "f16only"
+    return attn_operand_fmt(attn_prec)
+
+
 def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key, pol):
     """MultiheadedAttention.forward for inference with K is V (cross-attention over the encoder memory): the key / value
     projections are taken from ``cache`` when they were computed for the same memory tensor before (greedy decoding re-uses
@@ -1376,7 +1390,7 @@ class MHAFn(torch.autograd.Function):
         same_qk, same_kv = Q is K, K is V
         prec_q = pol.gemm
         prec_kv = pol.gemm if same_qk else pol.kv_gemm       # cross-attention: K / V project the (long) other stream
-        qkv_fmt = attn_operand_fmt(pol.attn)
+        qkv_fmt = attn_train_fmt(pol.attn, D // H)
 
         # each distinct input: operand planes of the format its projection reads, holding the bf16 plane the dW product needs
         # -- one pass (none at all when the producer -- LayerNorm -- attached the planes of its output)
@@ -1421,7 +1435,8 @@ class MHAFn(torch.autograd.Function):
         train = any(ctx.needs_input_grad)
         osec = o.lo if o.lo is not None else (o.fh if o.fh is not None else none)      # delta = rowsum(dO * O) reads hi + lo, or fp16
         ctx.o_f16 = o.fh is not None
-        ctx.save_for_backward(Wq, Wk, Wv, Wo, q.hi, k.hi, v.hi, o.hi, osec, lse,
+        ctx.qkv_f16 = q.hi is None
+        ctx.save_for_backward(Wq, Wk, Wv, Wo, q.any, k.any, v.any, o.hi, osec, lse,
                               Qp.hi if train else none, Kp.hi if train else none, Vp.hi if train else none)
         return out
 
@@ -1431,7 +1446,10 @@ class MHAFn(torch.autograd.Function):
         B, Sq, Sk, D, Dq, Dk_in, Dv_in = ctx.dims
         Mq, Mk = B * Sq, B * Sk
         Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
-        q, k, v = Planes(qh, None, Mq, D), Planes(kh, None, Mk, D), Planes(vh, None, Mk, D)
+        if ctx.qkv_f16:
+            q, k, v = Planes(None, None, Mq, D, fh=qh), Planes(None, None, Mk, D, fh=kh), Planes(None, None, Mk, D, fh=vh)
+        else:
+            q, k, v = Planes(qh, None, Mq, D), Planes(kh, None, Mk, D), Planes(vh, None, Mk, D)
         osec = osec if osec.numel() else None
         o = Planes(oh, None if ctx.o_f16 else osec, Mq, D, fh=osec if ctx.o_f16 else None)
         # the inputs' own bf16 planes are the (k-major) dW operands

@@ -107,7 +107,9 @@ typedef struct {
      * output are the bias gradient of the Linear below it; asking for them disables split-K for the launch. */
     float* colsum;
     /* alternative to C_lo: the second output plane holds fp16(c) (same layout as C_hi).  A forward activation is then stored as
-     * {bf16(c) for the single-pass bf16 backward, fp16(c) for the fp16 forward consumer} -- the same bytes as hi + lo. */
+     * {bf16(c) for the single-pass bf16 backward, fp16(c) for the fp16 forward consumer} -- the same bytes as hi + lo.
+     * With C_hi == NULL the fp16 plane is the ONLY plane written (q / k / v under the fp16 attention policy, whose backward converts
+     * them on load: bmt_attn_bwd_bf16_args.qkv_f16); excludes C_lo and colsum. */
     uint16_t* C_f16;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
@@ -232,13 +234,15 @@ typedef struct {
     const float* kmean;                               /* optional fp32 [B][H*dk]: mean key over the valid keys (bmt_attn_kmean).  With it dQ is
                                                          corrected by (row sum of the bf16-rounded dS) x mean key: the rounding residue of dS
                                                          times the keys' common component, 10-25 % of |dQ| under near-uniform attention */
+    int qkv_f16;                                      /* Qh / Kh / Vh are the FORWARD's fp16 planes (d_k >= 128): converted to bf16 while staging; the
+                                                         projections then write 2 instead of 4 bytes per element of q, k and v */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* out[b][c] = mean over the valid keys k of K[b][k][c] (bf16 plane, row stride ldk, batch stride bsk; mask: key-padding bytes [B][Sk]
    when mask_qs == 0, otherwise -- no mask or one row per query -- every key counts).  No counterpart in the reference: numerical aid of
    the bf16 backward (model/multihead_attention.py:8-26 is exact in fp32). */
 int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk, int D,
-                   float* out, void* stream);
+                   float* out, int k_f16, void* stream);     /* k_f16: the plane holds fp16 */
 
 /* ---------------------------------------------------------------- LayerNorm (model/blocks.py:127,131,143,150) */
 /* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */

@@ -331,6 +331,31 @@ def test_attention_backward_bf16_planes(ops, dk, H, B, Sq, Sk, kind):
         assert e < 2e-2, f"{name} dk={dk} {kind}: relative error {e:.3e}\n" + report(got, ref, name)
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,dk", [(2, 4, 200, 200, 256), (2, 4, 12, 200, 256), (2, 8, 70, 130, 128)])
+def test_attention_backward_from_fp16_planes(ops, B, H, Sq, Sk, dk):
+    """q / k / v saved as fp16 planes only (the fp16 attention policy, d_k >= 128): the backward kernels and the mean-key kernel
+    convert them to bf16 while staging.  Same gradients as from the bf16 planes up to the double rounding fp32 -> fp16 -> bf16."""
+    D = H * dk
+    mk = lambda S, seed: ops.make_planes((rnd(B * S, D, seed=seed) * 0.5).to(DEV), "f16")
+    q, k, v = mk(Sq, 81), mk(Sk, 82), mk(Sk, 83)
+    mask = torch.ones(B, 1, Sk, dtype=torch.bool)
+    mask[0, 0, Sk - 7:] = False
+    md = mask.to(DEV)
+    o, lse = ops.attn_fwd_planes(q, k, v, B, Sq, Sk, D, md, H, precision=ops.PREC_F16, out_fmt="f16")
+    do = ops.make_planes(rnd(B * Sq, D, seed=84).to(DEV), "bwd")
+    do = ops.Planes(do.hi[:, :D].contiguous(), None, B * Sq, D)
+    ref = ops.attn_bwd_planes(q.only("hi"), k.only("hi"), v.only("hi"), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (None, None, None))
+    f16 = lambda pl: ops.Planes(None, None, pl.rows, pl.cols, fh=pl.fh)
+    got = ops.attn_bwd_planes(f16(q), f16(k), f16(v), o, do, lse, B, Sq, Sk, D, md, H, 0.0, (None, None, None))
+    for name, (a, _), (b, _) in zip(("dq", "dk", "dv"), ref[:3], got[:3]):
+        e = rel_err(b.hi.float(), a.hi.float())
+        assert e < 1e-2, f"{name}: fp16-plane backward differs from the bf16-plane backward by {e:.3e}"
+    ma = ops._mask_args(md, B, Sq, Sk)
+    km_b = ops.attn_kmean(k.hi, D, Sk * D, B, Sk, D, ma, f16=False)
+    km_h = ops.attn_kmean(k.fh, D, Sk * D, B, Sk, D, ma, f16=True)
+    assert_close(km_h, km_b, atol=2e-3, name="mean key from the fp16 plane")
+
+
 @pytest.mark.parametrize("dk,H,B,Sq,Sk", [(32, 4, 2, 12, 200), (64, 2, 2, 29, 300), (128, 2, 1, 29, 333), (256, 2, 2, 29, 800), (256, 1, 1, 200, 200)])
 def test_attention_backward_keys_with_a_common_component(ops, dk, H, B, Sq, Sk, monkeypatch):
     """near-uniform attention over keys that share a large common component (the decoder's cross-attention over the encoder
