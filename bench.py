@@ -70,7 +70,9 @@ class KernelTimer:
                 K = A.rows if akm else (B.rows if bkm else A.cols)
             nb = ops.prec_operand_bytes(prec)
             cls = ("conv_planes_" if conv is not None else "gemm_planes_") + ops.prec_name(prec)
-            return timer._timed(cls, ops.prec_passes(prec), 2.0 * M * N * K, nb[0] * M * K + nb[1] * N * K + 4.0 * M * N,
+            op = kw.get("out_planes")          # output bytes per element: 4 for the fp32 tensor, 2 per 16-bit plane actually written
+            ob = (4.0 if C_out is not None else 0.0) + (2.0 * sum(t is not None for t in (op.hi, op.lo, op.fh)) if op is not None else 0.0)
+            return timer._timed(cls, ops.prec_passes(prec), 2.0 * M * N * K, nb[0] * M * K + nb[1] * N * K + ob * M * N,
                                 lambda: raw_gb(A, B, C_out, **kw))
 
         def gemm_bf16_grouped(items):
