@@ -50,3 +50,36 @@ def test_stale_pmc_record_is_refused(tmp_path, monkeypatch):
     (tmp_path / "bmt_amd" / "csrc" / "k.hip").write_text("// v2\n")
     rec, note = bench.pmc_record()
     assert rec is None and "stale" in note
+
+
+def test_pmc_record_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py takes roofline.traffic / mfma_busy from the newest profiles/*pmc_traffic.json only when the record's csrc digest is the
+    tree's: a record taken with other kernels is refused with the reason in traffic_source."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "aaaa")
+    rec, note = bench.pmc_record()
+    assert rec is None and "no PMC pass" in note
+    (prof / "r99_pmc_traffic.json").write_text(json.dumps({"csrc_digest": "bbbb", "kernels": {}}))
+    rec, note = bench.pmc_record()
+    assert rec is None and "stale" in note and "bbbb" in note
+    (prof / "r99_pmc_traffic.json").write_text(json.dumps({"csrc_digest": "aaaa", "kernels": {"gemm_w2": {"traffic_bytes": 1.0}}}))
+    rec, note = bench.pmc_record()
+    assert rec["kernels"]["gemm_w2"]["traffic_bytes"] == 1.0 and "aaaa" in note
+
+
+def test_kernel_classes_map_to_pmc_families():
+    import bench
+    fam = bench.PMC_FAMILY_OF_KERNEL
+    assert fam("void (anonymous namespace)::gemm_pipe_kernel<2, true, 1, false, false>((anonymous namespace)::GemmB)") == "gemm_w2"
+    assert fam("gemm_wide_kernel<true>(GemmB)") == "gemm_w2"
+    assert fam("gemm_bf16_kernel<1, 4, 1, false, true, 0, false>(GemmB)") == "gemm_bf16"
+    assert fam("gemm_bf16_kernel<3, 4, 1, false, false, 0, false>(GemmB)") == "gemm_x3"
+    assert fam("gemm_bf16_grouped_kernel<1, 4, 1, true, true, false>(GemmB const*, XcdSeg const*, int const*)") == "gemm_dw_grouped"
+    assert fam("attn_bwd_dkv32_kernel<256, false>(AttnPB)") == "attn_bwd_dkv" and fam("attn_fwd64_kernel<256, true>(AttnPB)") == "attn_fwd"
+    assert bench.pmc_keys_of_class("gemm_planes_fp16 x (fp16 hi+lo)") == ("gemm_w2",)
+    assert bench.pmc_keys_of_class("attn_bwd_enc_dk256_bf16") == ("attn_bwd_dq", "attn_bwd_dkv")
+    assert bench.pmc_keys_of_class("gemm_planes_dw_grouped_bf16") == ("gemm_dw_grouped",)
