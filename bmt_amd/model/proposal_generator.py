@@ -4,7 +4,6 @@ MultimodalProposalGenerator :215-387, make_targets :389-448.
 The Conv1d stacks run as implicit GEMMs on the MFMA plane kernel (bmt_gemm_bf16 conv modes: no im2col buffer, no (B,D,S) permutes),
 target assignment / decode / YOLO loss are the HIP kernels of csrc/proposal.hip.  state_dict keys are the
 reference's (``detection_layers_{A,V}.i.conv_layers.{0,3,6}.{weight,bias}`` with the default Sequential)."""
-import ctypes as C
 
 import torch
 import torch.nn as nn

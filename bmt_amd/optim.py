@@ -6,7 +6,6 @@ launch over every parameter.  Subclasses torch.optim.Optimizer so ``state_dict()
 (``exp_avg`` / ``exp_avg_sq`` / ``step`` per parameter) and checkpoints interchange."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Iterable, List
 
 import torch

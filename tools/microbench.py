@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """kernel timings at configs[1] shapes, per operand format (HIP events, median of interleaved rounds):
     python tools/microbench.py [gemm] [attn]"""
-import math
 import os
 import sys
 
