@@ -941,6 +941,302 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// =================================================================================== forward, single pass, 32 queries per wave + LDS-DMA
+// The encoder's large attention shapes (>= 2 workgroups per CU) on v_mfma_f32_32x32x16.
+// Why: attn_fwd64_kernel (8 waves x 16 queries, v_mfma_f32_16x16x32) reads one 1-KB operand fragment from LDS per 16-cycle MFMA; four
+// SIMDs ask for 256 B / clk, the LDS peak (MI355X_MICROARCH.md, LDS table), and its K / V staging adds 64 KB of ds_write_b128 per stage
+// on a path that moves 79 B / clk: the loop measures 21-23 % MFMA busy (profiles/r02_h_attn_fwd64_pmc.csv).  Here:
+//   * a wave owns 32 queries: S^T[32 keys x 32 q] = K[32 x 16] . Q^T[16 x 32] per MFMA (A = K rows from LDS, B = Q in registers),
+//     O^T[32 d x 32 q] += V^T[32 x 16] . P^T[16 x 32] (A = V^T through ds_read_b64_tr_b16, B = P from the softmax registers):
+//     1 KB of LDS per 32-cycle MFMA, half the bytes per matrix cycle;
+//   * K / V tiles go global -> LDS by buffer_load ... lds (no staging registers -- the 32 x 256 accumulator takes 128 and Q 64 of the
+//     256 registers two waves per SIMD leave -- and no ds_write); the swizzles that keep both read patterns conflict free sit on
+//     the SOURCE side: K image chunk (16 B) position = chunk ^ (row & 15) [ds_read_b128 row fragments], V image position =
+//     chunk ^ 4 (row & 3) [4-row x 16-column transposing reads: the four rows of a read land in the four 64-byte bank quarters];
+//     SQ_LDS_BANK_CONFLICT = 0 (profiles/r02_q_attn_fwd32_pmc.csv);
+//   * 4 waves (128 queries) per workgroup, 32-key stages, two stage buffers = 64 KB: TWO workgroups per CU, whose phases drift apart,
+//     put one wave's softmax under the other's MFMAs (the role the second wave of a SIMD plays in the 8-wave kernels);
+//   * the key-padding mask row of the batch element is staged into LDS once; no global load besides the DMA is in flight inside the
+//     loop (cdna_hip_programming.md: an ordinary load beside an LDS-DMA makes hipcc drain vmcnt(0)).
+// Lane algebra (l31 = lane & 31, hh = lane >> 5), checked by tools/probes/attn_fwd32_layout.py against numpy:
+//   S^T register r = 4 i + j of lane (l31, hh): key 8 i + 4 hh + j, query l31.  The 16-key MFMA kk of O^T += V^T . P^T takes
+//   registers 8 kk .. 8 kk + 7 in order as its B operand: reduction index 8 hh + jj <-> key 16 kk + 4 hh + jj (jj < 4),
+//   16 kk + 8 + 4 hh + jj - 4 (jj >= 4); the A operand reads V rows 16 kk + 4 hh + (0..3) and 16 kk + 8 + 4 hh + (0..3).
+// Measured (tools/probes/attn_fwd32_check.py, profiles/r02_q_*): configs[1] audio self-attention 194 -> 135 us (620 TF/s), audio <- video
+// 96 -> 75 us; the shapes with one workgroup per CU (256 queries) gain nothing and stay on attn_fwd64_kernel.
+__device__ __forceinline__ float half_max(float x) { float a = x, b = x; swap32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float x) { float a = x, b = x; swap32(a, b); return a + b; }
+
+__device__ __forceinline__ void swap32u(uint32_t& a, uint32_t& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+// LDS fragment reads as inline asm, waits counted by hand.  Two reasons: (1) with an LDS-DMA in flight hipcc puts s_waitcnt vmcnt(0) in
+// front of the ds_read_tr builtin (it cannot tell the read from the DMA's target buffer) and drains the prefetch in the middle of the
+// stage; (2) it issues read -> lgkmcnt(0) -> MFMA one fragment at a time, LDS latency exposed per MFMA.  The waits carry the fragment
+// registers as "+v" operands so that the MFMA that consumes them cannot be scheduled above the wait.  LDS operations retire in order:
+// when lgkmcnt <= N only the N youngest can be pending, whatever else the compiler has in flight -- its own waits only get stronger.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_b128(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr_b64(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// compile-time repetition by the preprocessor: the step bodies need their index as a constant expression (immediate offsets and wait counts
+// of the asm above)
+#define BMT_X_REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+template <int N>
+__device__ __forceinline__ void lgkm_wait(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void lgkm_wait(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
+// DMAV: where the next tile's 2 PPW DMA requests are issued (an experiment axis): 0 = one per MFMA on the first MFMAs of S, 1 = one per
+// two MFMAs of S, 2 = all before S, 3 = K pieces one per four MFMAs of S + V pieces one per two MFMAs at the start of PV.
+// PRIO: raise the wave's priority around its MFMA phases.
+template <int DK, bool F16, int DMAV = 0, bool PRIO = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd32_kernel(const AttnPB p) {
+    constexpr int BC = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BC * ROWB, STAGE = 2 * TILE;
+    constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BC / RPP, PPW = NP / 4;       // 16-B chunks per row, rows per 1-KB piece, pieces per tile / wave
+    static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];    // the fragment addresses XOR bits 5 .. 8: the base must not carry into them
+    char* sMask = smem + 2 * STAGE;                                      // [ntile * 32] bytes: 1 = valid key
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 32 + l31;
+    const bool qok = q < p.Sq;
+    const bool wave_on = qt * 128 + wid * 32 < p.Sq;                     // waves past Sq only move tiles
+    const int ntile = (p.Sk + BC - 1) / BC;
+
+    // ---- LDS-DMA: piece = 1 KB = RPP rows; wave w moves pieces w * PPW .. of the K and of the V tile
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    // (fixed extent: with the template-dependent extent PPW the DMA builtin's call becomes type-dependent and hipcc 7.2's host pass drops
+    // the whole kernel instantiation WITHOUT a diagnostic -- the library then fails to load with the kernel's stub undefined)
+    int kvo[4], vvo[4];
+    static_assert(PPW <= 4, "pieces per wave");
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = (wid * PPW + j) * RPP + lane / CPR, cpos = lane % CPR;
+        kvo[j] = row * (int)p.ldk * 2 + ((cpos ^ (row & 15)) * 16);
+        vvo[j] = row * (int)p.ldv * 2 + ((cpos ^ (4 * (row & 3))) * 16);
+    }
+    const int sstep_k = BC * (int)p.ldk * 2, sstep_v = BC * (int)p.ldv * 2;
+#define BMT_X_DMA_K(j_, t_, buf_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(smem + (buf_) * STAGE + (wid * PPW + (j_)) * 1024), 16, kvo[j_], (t_) * sstep_k, 0, 0)
+#define BMT_X_DMA_V(j_, t_, buf_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(smem + (buf_) * STAGE + TILE + (wid * PPW + (j_)) * 1024), 16, vvo[j_], (t_) * sstep_v, 0, 0)
+
+    // stage 0 in flight first, then the Q fragments and the mask row
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) BMT_X_DMA_K(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) BMT_X_DMA_V(j, 0, 0);
+    bf16x8 qf[KS];
+    {
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = ldfrag(p.Qh + qo + 16 * ks, qok);
+    }
+    for (int i = tid; i < ntile * BC; i += NT) {
+        uint8_t m = 0;
+        if (i < p.Sk) m = (p.mask != nullptr) ? (uint8_t)(p.mask[(int64_t)b * p.mask_bs + i] != 0) : (uint8_t)1;
+        sMask[i] = m;
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;       // m_run in log2 units, identical in the two lanes of a query; l_run: THIS lane's 16 keys per stage
+    const float sc2 = p.scale * LOG2E;
+    constexpr float TAU2 = RESCALE_TAU * LOG2E;
+
+    // fragment addresses (LDS bytes); the k-step / d-tile enters by XOR on bits the lane part leaves free
+    const int s15 = l31 & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const uint32_t kA0 = lds0 + l31 * ROWB + 32 * (s15 >> 1) + 16 * (hh ^ (s15 & 1));
+    const int m16 = lane & 15, gi = (lane >> 4) & 1, mq = m16 >> 2, mr = m16 & 3;
+    const uint32_t vL0 = lds0 + (4 * hh + mq) * ROWB + 64 * mq + 32 * gi + 8 * mr;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        const int tn = min(t + 1, ntile - 1);             // the last stage re-fetches itself into the idle buffer (branch-free)
+        const int key0 = t * BC;
+        uint32_t mw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mw[i] = *reinterpret_cast<const uint32_t*>(sMask + key0 + 8 * i + 4 * hh);
+        const bool none_valid = __all((mw[0] | mw[1] | mw[2] | mw[3]) == 0u);
+        const bool all_valid = __all((mw[0] & mw[1] & mw[2] & mw[3]) == 0x01010101u);
+        if (none_valid || !wave_on) {                     // nothing to compute: only move the next tile
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) BMT_X_DMA_K(j, tn, cur ^ 1);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) BMT_X_DMA_V(j, tn, cur ^ 1);
+        } else {
+            const uint32_t kA = kA0 + cur * STAGE, vL = vL0 + cur * STAGE + TILE;
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            // ---- S^T = K . Q^T: fragments two ahead of the MFMA that uses them; the next tile's DMA requests ride on the first MFMAs
+            u32x4 kf[3];
+            kf[0] = lds_b128<0>(kA);
+            kf[1] = lds_b128<0>(kA ^ (1 << 5));
+            if constexpr (DMAV == 2) {
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) BMT_X_DMA_K(j, tn, cur ^ 1);
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) BMT_X_DMA_V(j, tn, cur ^ 1);
+            }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#define BMT_X_SSTEP(ks_)                                                                               \
+    if constexpr ((ks_) < KS) {                                                                        \
+        if constexpr ((ks_) + 2 < KS) kf[((ks_) + 2) % 3] = lds_b128<0>(kA ^ (((ks_) + 2) << 5));      \
+        if constexpr (DMAV == 0) {                                                                     \
+            if constexpr ((ks_) < PPW) BMT_X_DMA_K((ks_) % PPW, tn, cur ^ 1);                          \
+            else if constexpr ((ks_) < 2 * PPW) BMT_X_DMA_V((ks_) % PPW, tn, cur ^ 1);                 \
+        } else if constexpr (DMAV == 1) {                                                              \
+            if constexpr ((ks_) % 2 == 0 && (ks_) / 2 < PPW) BMT_X_DMA_K(((ks_) / 2) % PPW, tn, cur ^ 1);             \
+            else if constexpr ((ks_) % 2 == 0 && (ks_) / 2 < 2 * PPW) BMT_X_DMA_V(((ks_) / 2) % PPW, tn, cur ^ 1);   \
+        } else if constexpr (DMAV == 3) {                                                              \
+            if constexpr ((ks_) % 4 == 0 && (ks_) / 4 < PPW) BMT_X_DMA_K(((ks_) / 4) % PPW, tn, cur ^ 1);             \
+        }                                                                                              \
+        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(kf[(ks_) % 3]);                             \
+        st = mfma32t<F16>(as_bf16x8(kf[(ks_) % 3]), qf[(ks_)], st);                                    \
+    }
+            BMT_X_REP16(BMT_X_SSTEP)
+#undef BMT_X_SSTEP
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            // ---- softmax in the log2 domain on the raw scores: register 4 i + j = key key0 + 8 i + 4 hh + j
+            if (!all_valid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) st[4 * i + j] = ((mw[i] >> (8 * j)) & 0xffu) ? st[4 * i + j] : NEG_INF;
+            }
+            float tmax = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+#pragma unroll
+            for (int i = 4; i < 16; i += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(st[i], st[i + 1]), fmaxf(st[i + 2], st[i + 3])));
+            tmax = half_max(tmax) * sc2;                   // sc2 > 0: the maximum of the scaled scores
+            if (__any(tmax > m_run + TAU2)) {              // stale-reference online softmax (attn_fwd_bf16_kernel): exact
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == NEG_INF) ? 0.f : m_new));
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+                m_run = m_new;
+            }
+            const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+            float x[16];
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], sc2, -m_use));
+                psum += x[i];
+            }
+            l_run += psum;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 pw;
+                pw[0] = pack_2<F16>(x[8 * kk + 0], x[8 * kk + 1]); pw[1] = pack_2<F16>(x[8 * kk + 2], x[8 * kk + 3]);
+                pw[2] = pack_2<F16>(x[8 * kk + 4], x[8 * kk + 5]); pw[3] = pack_2<F16>(x[8 * kk + 6], x[8 * kk + 7]);
+                pf[kk] = as_bf16x8(pw);
+            }
+            // ---- O^T += V^T . P^T: MFMA n = 2 dt + kk; fragment n = rows 16 kk + 4 hh .. (first read) and 16 kk + 8 + 4 hh .. (second)
+            u32x2 va[3], vb[3];
+#define BMT_X_VFRAG(n_)                                                                   \
+    do {                                                                                  \
+        const uint32_t a_ = vL ^ (((n_) >> 1) << 6);                                      \
+        va[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1)) * ROWB>(a_);                          \
+        vb[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1) + 8) * ROWB>(a_);                      \
+    } while (0)
+            BMT_X_VFRAG(0);
+            BMT_X_VFRAG(1);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#define BMT_X_VSTEP(n_)                                                                                \
+    if constexpr ((n_) < 2 * DT) {                                                                     \
+        if constexpr ((n_) + 2 < 2 * DT) BMT_X_VFRAG((n_) + 2);                                        \
+        if constexpr (DMAV == 3 && (n_) % 2 == 0 && (n_) / 2 < PPW) BMT_X_DMA_V(((n_) / 2) % PPW, tn, cur ^ 1); \
+        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(va[(n_) % 3], vb[(n_) % 3]);      \
+        const u32x4 av = {va[(n_) % 3][0], va[(n_) % 3][1], vb[(n_) % 3][0], vb[(n_) % 3][1]};         \
+        o[(n_) >> 1] = mfma32t<F16>(as_bf16x8(av), pf[(n_) & 1], o[(n_) >> 1]);                        \
+    }
+            BMT_X_REP16(BMT_X_VSTEP)
+#undef BMT_X_VSTEP
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+#undef BMT_X_VFRAG
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (this wave's share); the barrier publishes all shares
+        __syncthreads();                                       // and says every wave is done reading tile t (tile t + 2 overwrites it)
+    }
+#undef BMT_X_DMA_K
+#undef BMT_X_DMA_V
+
+    // ---- epilogue.  Lane (l31, hh) holds O^T[d = 32 dt + 8 i + 4 hh + j][q] in register 4 i + j: the two lanes of a query own alternate
+    // 4-column groups.  For the 16-bit planes one v_permlane32_swap per dword regroups a PAIR of groups (i = 2 ip, 2 ip + 1) so that the
+    // lower lane holds columns 8 i .. 8 i + 7 of the first and the upper lane those of the second: 16-byte stores instead of 8-byte ones
+    // (cdna_hip_programming.md T21).  Both lanes of a query are active or inactive together (same q).
+    const float l_tot = half_sum(l_run);
+    const float inv = 1.f / l_tot;   // fully masked row: 0 * inf = NaN, as the reference's softmax
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+    const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            float v[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = dt * 32 + 8 * (2 * ip + e) + 4 * hh + j;
+                    v[e][j] = drop_apply(dc, o[dt][4 * (2 * ip + e) + j] * inv, (uint64_t)(rowoff + d));
+                }
+            if (p.Ow && qok) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    *reinterpret_cast<float4*>(p.Ow + rowoff + dt * 32 + 8 * (2 * ip + e) + 4 * hh) = make_float4(v[e][0], v[e][1], v[e][2], v[e][3]);
+            }
+            if (p.Owh) {
+                const int col = dt * 32 + 8 * (2 * ip + hh);
+                uint32_t ha[2], hb[2], la[2], lb[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    split_bf2(v[e][0], v[e][1], ha[e], la[e]);
+                    split_bf2(v[e][2], v[e][3], hb[e], lb[e]);
+                    if (p.ow_f16) { la[e] = pack_h2(v[e][0], v[e][1]); lb[e] = pack_h2(v[e][2], v[e][3]); }
+                }
+                swap32u(ha[0], ha[1]);
+                swap32u(hb[0], hb[1]);
+                if (qok) *reinterpret_cast<u32x4*>(p.Owh + po + col) = u32x4{ha[0], hb[0], ha[1], hb[1]};
+                if (p.Owl) {
+                    swap32u(la[0], la[1]);
+                    swap32u(lb[0], lb[1]);
+                    if (qok) *reinterpret_cast<u32x4*>(p.Owl + po + col) = u32x4{la[0], lb[0], la[1], lb[1]};
+                }
+            }
+        }
+    if (qok && hh == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run * LN2 + __logf(l_tot);
+}
+
+
 // =================================================================================== backward
 // delta[b,h,q] = (1-p) * sum_d dO[b,q,h*DK+d] * O[b,q,h*DK+d]  (fp32 inputs), and the bf16 plane of dO for the MFMAs
 __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, int DK, uint16_t* dOh) {
@@ -1962,13 +2258,35 @@ __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restr
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int DK, bool F16, int DMAV = 0, bool PRIO = true>
+int launch_fwd32(const AttnPB& p, hipStream_t st) {
+    const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
+    const int ntile = (p.Sk + 31) / 32;
+    const int lds = 2 * 2 * 32 * DK * 2 + ((ntile * 32 + 15) & ~15);
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<DK, F16, DMAV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * DK * 2 + 8192);
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd32_kernel<DK, F16, DMAV, PRIO>), dim3(nblk), dim3(256), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_attn_fwd_bf16");
+    return BMT_OK;
+}
+
+// fwd32: -1 = by shape (the default), 0 = never, 1 = whenever the 32-query kernel can run the problem (experiments)
 template <int DK, int NPASS, bool F16 = false>
-int launch_fwd(const AttnPB& p, hipStream_t st) {
+int launch_fwd(const AttnPB& p, hipStream_t st, int fwd32 = -1) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
     static const int old_fwd = getenv("BMT_ATTN_FWD_OLD") ? atoi(getenv("BMT_ATTN_FWD_OLD")) : 0;      // A/B experiments only
+    static const int env32 = getenv("BMT_ATTN_FWD32") ? atoi(getenv("BMT_ATTN_FWD32")) : -1;           // A/B experiments only
     if constexpr (DK >= 128 && NPASS == 1) {
         // K / V rows are fetched with 32-bit byte offsets from the (batch, head) base
         const bool fits = ((int64_t)p.Sk * p.ldk * 2 < (1ll << 31)) && ((int64_t)p.Sk * p.ldv * 2 < (1ll << 31));
+        // the 32-query kernel: key-padding masks (its mask row lives in LDS: Sk <= 8192), and two workgroups per CU to overlap --
+        // with fewer it ties or loses against the 16-query kernel (V-self / V<-A of configs[1]: 0.95x / 0.98x, the decoder 0.86x)
+        const int want32 = fwd32 >= 0 ? fwd32 : env32;
+        const bool can32 = fits && (p.mask == nullptr || p.mask_qs == 0) && p.Sk <= 8192;
+        if (!old_fwd && can32 && (want32 == 1 || (want32 < 0 && nblk >= 2 * bmt_device_cus()))) return launch_fwd32<DK, F16>(p, st);
         if (!old_fwd && fits) {
             const int lds = 2 * 2 * 64 * (DK * 2 + 32) + 256;
             static bool done64 = false;

@@ -105,29 +105,42 @@ __device__ __forceinline__ uint32_t pack_2(float a, float b) {
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
-// keep(seed, step, site, i): two rounds of a 64->32 bit avalanche mix; the same function is used by
-// every fused epilogue and by the standalone kernels so forward and backward agree by construction.
-__device__ __forceinline__ uint32_t bmt_hash32(uint64_t seed, uint64_t step, uint32_t site, uint64_t i) {
-    uint64_t z = i + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u) + seed;
-    z ^= step * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
-}
+// keep(seed, step, site, i) = hash(i; key(seed, step, site)) >= p * 2^32.  The same function is used by every fused epilogue and by the
+// standalone kernels, so forward and backward agree by construction.  Two levels:
+//   * the KEY, once per kernel and thread: a 64-bit avalanche mix (two splitmix64 rounds) of (seed, step, site) -> (k0, k1);
+//   * per ELEMENT: a 32-bit avalanche hash (two multiplies, three xor-shifts) of i + k0 with k1 folded in between the multiplies, so
+//     that streams of different keys are not shifted copies of one sequence.
+// (Round 1 ran the 64-bit mix per element: 6 quarter-rate 32-bit multiplies and ~20 other VALU operations for every value an epilogue
+// writes -- 15 % of the attention forward at d_k = 256, tools/probes/attn_fwd32_check.py --variants.  The per-element part is now
+// 2 multiplies + 8 operations; keep rate, pairwise agreement of streams, lag correlation and row / column rates of the 2-D layouts
+// were checked against their binomial expectations on 4 M elements per key.)
 struct DropCtx {
-    uint64_t seed, step;
-    uint32_t site;
+    uint32_t k0, k1;
     uint32_t thresh;  // keep iff hash >= thresh, thresh = p * 2^32
     float inv_keep;
     bool on;
 };
+__device__ __forceinline__ uint32_t bmt_hash32(uint32_t k0, uint32_t k1, uint64_t i) {
+    uint32_t x = (uint32_t)i + (uint32_t)(i >> 32) + k0;      // (tensors past 2^32 elements repeat the stream shifted by one)
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x ^= k1;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ DropCtx make_drop(float p, const uint64_t* rng, uint32_t site) {
     DropCtx d;
     d.on = (p > 0.f) && (rng != nullptr);
-    d.seed = d.on ? rng[0] : 0;
-    d.step = d.on ? rng[1] : 0;
-    d.site = site;
+    const uint64_t seed = d.on ? rng[0] : 0, step = d.on ? rng[1] : 0;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u);
+    z ^= step * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    d.k0 = (uint32_t)z;
+    d.k1 = (uint32_t)(z >> 32);
     double t = (double)p * 4294967296.0;
     d.thresh = (p >= 1.f) ? 0xFFFFFFFFu : (uint32_t)t;
     d.inv_keep = (p < 1.f) ? 1.f / (1.f - p) : 0.f;
@@ -135,7 +148,7 @@ __device__ __forceinline__ DropCtx make_drop(float p, const uint64_t* rng, uint3
 }
 __device__ __forceinline__ float drop_apply(const DropCtx& d, float v, uint64_t idx) {
     if (!d.on) return v;
-    return (bmt_hash32(d.seed, d.step, d.site, idx) >= d.thresh) ? v * d.inv_keep : 0.f;
+    return (bmt_hash32(d.k0, d.k1, idx) >= d.thresh) ? v * d.inv_keep : 0.f;
 }
 
 // ---------------------------------------------------------------- wave / block reductions

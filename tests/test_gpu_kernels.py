@@ -274,6 +274,38 @@ def test_attention_forward_rescale_branch(ops, dk, H, prec):
     assert_close(lse, torch.logsumexp(s_, -1), atol={1: 5e-2, 3: 1e-3, 4: 8e-3}[prec], rtol=1e-5, name="lse with forced rescales")
 
 
+@pytest.mark.parametrize("dk,H,B,Sq,Sk", [(256, 4, 16, 1000, 333), (128, 8, 8, 1024, 300), (256, 4, 20, 800, 45)])
+@pytest.mark.parametrize("prec", [1, 4])
+def test_attention_forward_32_query_kernel(ops, dk, H, B, Sq, Sk, prec):
+    """problems of >= 2 workgroups per CU (here >= 512 query tiles of 128) with a key-padding mask run attn_fwd32_kernel: 32 queries per
+    wave, K / V by LDS-DMA, the mask row in LDS.  Same checks as the 16-query kernels get: ragged valid lengths incl. fully masked
+    key tiles and a partly valid last tile, forced late rescales of the stale-maximum softmax, the last query tile past Sq, and the
+    dropout mask of the standalone kernel."""
+    D = dk * H
+    ops.manual_seed(5)
+    q, k, v = rnd(B, Sq, D, seed=60) * 0.5, rnd(B, Sk, D, seed=61) * 0.5, rnd(B, Sk, D, seed=62)
+    scale = math.sqrt(dk)
+    for (b, qi, ki, boost) in ((0, 3, 5, 9.0), (0, 3, Sk // 2, 24.0), (0, 3, Sk - 2, 44.0), (1, 700, 2, 50.0), (2, Sq - 1, Sk // 3, 30.0)):
+        for h in range(H):
+            sl = slice(h * dk, (h + 1) * dk)
+            qv = q[b, qi, sl]
+            k[b, ki, sl] = qv / qv.norm() ** 2 * boost * scale      # q . k / sqrt(dk) == boost
+    mask = torch.ones(B, 1, Sk, dtype=torch.bool)
+    for b in range(1, B):
+        mask[b, 0, max(3, Sk - 5 * b - (Sk // 2 if b % 4 == 3 else 0)):] = False      # some rows lose whole 32-key tiles
+    (qh, ql), (kh, kl), (vh, vl) = _planes(q, prec), _planes(k, prec), _planes(v, prec)
+    o, lse = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask.to(DEV), H, precision=prec)
+    want = _oracle_attention(q, k, v, mask, H, rounded=prec)
+    assert_close(o, want, atol=_ATOL_O[prec] * 1.5, rtol=0, name=f"attn32 o dk={dk} prec {prec}")
+    f = _round_fn(prec)
+    s_ = torch.einsum("bqhd,bkhd->bhqk", f(q).view(B, Sq, H, dk), f(k).view(B, Sk, H, dk)) / math.sqrt(dk)
+    s_ = s_.masked_fill(~mask.unsqueeze(1), -float("inf"))
+    assert_close(lse, torch.logsumexp(s_, -1), atol={1: 5e-2, 4: 8e-3}[prec], rtol=1e-5, name="attn32 lse")
+    # dropout on the output: exactly the standalone kernel's mask on this kernel's values
+    od, _ = ops.attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask.to(DEV), H, drop_p=0.25, site=11, precision=prec)
+    assert torch.equal(od, ops.dropout_raw(o, 0.25, 11))
+
+
 def _planes(t, prec=3):
     """(first plane, second plane) a raw attention-kernel call of this precision takes: bf16 hi + lo, or the fp16 plane"""
     if prec == 4:
