@@ -1,0 +1,22 @@
+"""Lane algebra of attn_fwd32_kernel (bmt_amd/csrc/attention_bf16.hip) on the CPU: the LDS image the DMA builds with its source-side
+swizzles, the row-fragment and transposing reads, and the 32x32x16 MFMA operand / result layouts reproduce K.Q^T and V^T.P^T exactly,
+with no LDS bank conflict under the documented bank model (tools/probes/attn_fwd32_layout.py is the emulator; the GPU parity of the
+kernel itself is tests/test_gpu_kernels.py::test_attention_forward_32_query_kernel)."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _emulator():
+    spec = importlib.util.spec_from_file_location("attn_fwd32_layout", os.path.join(ROOT, "tools", "probes", "attn_fwd32_layout.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("dk", [256, 128])
+def test_lane_algebra_and_banks(dk):
+    assert _emulator().check(dk)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""CPU check of the lane algebra of bmt_amd/csrc/exp/attn_fwd32.hip (no GPU, numpy only).
+"""CPU check of the lane algebra of attn_fwd32_kernel (bmt_amd/csrc/attention_bf16.hip) (no GPU, numpy only).
 
 Emulates, with the formulas of the kernel source, (1) the LDS image the LDS-DMA builds (1-KB pieces, swizzle on the source side),
 (2) the ds_read_b128 row fragments and the ds_read_b64_tr_b16 transposing reads, (3) v_mfma_f32_32x32x16 with the operand / result
