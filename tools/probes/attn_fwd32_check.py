@@ -171,6 +171,40 @@ def variants():
     Proxy.variant = 0
 
 
+def probe():
+    """what each part of the 32-query loop costs: the probe copy of the kernel with parts switched off (timing only), two / one
+    workgroup(s) per CU"""
+    shapes = [("A-self", 32, 4, 800, 800, 256), ("A<-V", 32, 4, 800, 256, 256), ("V<-A", 32, 4, 256, 800, 256)]
+    names = {0: "everything on", 1: "no DMA in the loop", 2: "no softmax arithmetic", 3: "no DMA, no softmax", 5: "no DMA, no wait / barrier",
+             7: "MFMA + fragment reads only"}
+    for base, label in ((200, "two workgroups per CU"), (300, "ONE workgroup per CU (40 KB of LDS padding)")):
+        print(label + ":", flush=True)
+        for xp in (0, 1, 2, 3, 5, 7):
+            Proxy.variant = base + xp
+            line = f"  XP {xp} ({names[xp]:28s}): "
+            for name, *sh in shapes:
+                line += f"{name} {time_one(*sh, True, drop_p=0.0):7.1f} us   "
+            print(line, flush=True)
+    Proxy.variant = 0
+    for name, *sh in shapes:
+        print(f"  product kernel {name}: no dropout {time_one(*sh, True, drop_p=0.0):7.1f} us, dropout 0.1 {time_one(*sh, True):7.1f} us", flush=True)
+
+
+def probe2():
+    """prefetch depth of the fragment reads (1 .. 4 MFMAs ahead) and MFMA ordering (PV key-half-major: no two consecutive MFMAs on
+    one accumulator; S on two accumulators) of the probe copy: whole loop (XP 0) and MFMA + fragment reads only (XP 7)"""
+    shapes = [("A-self", 32, 4, 800, 800, 256), ("A<-V", 32, 4, 800, 256, 256)]
+    for ord_, depth in ((0, 1), (0, 2), (0, 3), (0, 4), (1, 2), (1, 4), (2, 2), (3, 2), (3, 3)):
+        line = f"  order {ord_} depth {depth}: "
+        for xp in (0, 7):
+            Proxy.variant = 400 + 100 * ord_ + 10 * depth + xp
+            line += ("whole loop " if xp == 0 else "| MFMA + reads only ")
+            for name, *sh in shapes:
+                line += f"{name} {time_one(*sh, True, drop_p=0.0):7.1f} us  "
+        print(line, flush=True)
+    Proxy.variant = 0
+
+
 def time_case(name, B, H, Sq, Sk, dk, iters=20):
     D = H * dk
     g = torch.Generator().manual_seed(1)
@@ -202,6 +236,22 @@ def time_case(name, B, H, Sq, Sk, dk, iters=20):
 def main():
     if "--pmc-case" in sys.argv:         # a few launches of each kernel on the A-self shape (for a rocprofv3 --pmc pass)
         time_case("A-self", 32, 4, 800, 800, 256, iters=2)
+        return 0
+    if "--probe3" in sys.argv:          # is the fixed part of the kernel its output? (XP bit 8: no plane stores)
+        shapes = [("A-self", 32, 4, 800, 800, 256), ("A<-V", 32, 4, 800, 256, 256), ("V<-A", 32, 4, 256, 800, 256)]
+        for xp, label in ((0, "everything on"), (8, "no output stores"), (7, "MFMA + fragment reads only"), (15, "MFMA + reads, no output stores")):
+            Proxy.variant = 200 + xp
+            line = f"  XP {xp:2d} ({label:32s}): "
+            for name, *sh in shapes:
+                line += f"{name} {time_one(*sh, True, drop_p=0.0):7.1f} us   "
+            print(line, flush=True)
+        Proxy.variant = 0
+        return 0
+    if "--probe2" in sys.argv:
+        probe2()
+        return 0
+    if "--probe" in sys.argv:
+        probe()
         return 0
     if "--variants" in sys.argv:
         variants()
