@@ -83,3 +83,28 @@ def test_kernel_classes_map_to_pmc_families():
     assert bench.pmc_keys_of_class("gemm_planes_fp16 x (fp16 hi+lo)") == ("gemm_w2",)
     assert bench.pmc_keys_of_class("attn_bwd_enc_dk256_bf16") == ("attn_bwd_dq", "attn_bwd_dkv")
     assert bench.pmc_keys_of_class("gemm_planes_dw_grouped_bf16") == ("gemm_dw_grouped",)
+
+
+def test_rocm_smi_clock_parser_on_a_recorded_sample():
+    """bench.py's engine_clock_under_load reads `rocm-smi --showclocks --showpower`: the lines of a run on the GPU box
+    (profiles/r02_s_clock_under_load.txt keeps them) parse to (sclk MHz, package W); anything else parses to None"""
+    import bench
+    sample = ("GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\nGPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: 1: (1937Mhz)\n"
+              "=================================== Power Consumption ====================================\n"
+              "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1356.0\nGPU[1]\t\t: sclk clock level: 1: (2100Mhz)\n")
+    assert bench.parse_smi(sample) == (1937, 1356.0)
+    assert bench.parse_smi(sample, gpu=1) == (2100, None)
+    assert bench.parse_smi("ERROR: no AMD GPUs found\n") is None
+    rec = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_s_clock_under_load.txt")).read()
+    idle = rec.splitlines()[0].split("idle: ", 1)[1].replace(" | ", "\n")
+    assert bench.parse_smi(idle) == (99, 243.0)
+
+
+def test_clock_probe_never_raises_without_a_gpu():
+    """no GPU here: whatever rocm-smi does (absent, error text, garbage), the probe returns None or a well-formed record and the
+    steps it was given still ran"""
+    import bench
+    calls = []
+    out = bench.clock_under_load(lambda: calls.append(1), lambda: None, seconds=0.2)
+    assert calls, "the probe must drive the step"
+    assert out is None or {"sclk_mhz", "package_w", "samples", "mfma_peak_at_clock_tflops", "source"} <= set(out)

@@ -9,7 +9,7 @@ cd /tmp
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$i -o p -- python $R/bench.py --procedure $PROC --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/pmcb_$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$i -o p -- python $R/bench.py --procedure $PROC --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timer --no-clock-probe > $R/gpurun_out/pmcb_$i.log 2>&1
   echo "pass $i ($c) rc=$?"
 done
 cd $R

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -o step -- python $R/bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/trace_run.log 2>&1; echo rc=$?
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -o step -- python $R/bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-timer --no-clock-probe > $R/gpurun_out/trace_run.log 2>&1; echo rc=$?
 cd $R
 f=$(find gpurun_out/trace -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'

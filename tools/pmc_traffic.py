@@ -33,7 +33,7 @@ out = {"unit": "bytes per launch", "procedure": proc, "csrc_digest": csrc_digest
        "correction": "FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM); WRITE_SIZE (KB) x 1024 "
                      "uncorrected; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); durations under the counter pass",
        "command": f"rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES> --kernel-trace -- python bench.py "
-                  f"--procedure {proc} --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timer",
+                  f"--procedure {proc} --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timer --no-clock-probe",
        "kernels": {}}
 for k, d in agg.items():
     n = max(d["FETCH_SIZE"][0], d["WRITE_SIZE"][0])
