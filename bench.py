@@ -549,6 +549,11 @@ def main():
     exposed_ms = step.reduce_timing(False) if hasattr(step, "reduce_timing") else None
     final_loss = float(res[0] if cap else res[1])
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step ({mode})")
+    # (the same launches as the timed region, just more of them: nothing about the step's state changes before the kernel timer below)
+    clock = None
+    if world == 1 and not args.no_clock_probe:
+        clock = clock_under_load(run, sync)
+        note(f"engine clock under load: {clock}")
     timer_steps = 0
     if not args.no_kernel_timer:
         # per-kernel HIP-event timing needs individual launches: the same step, eagerly issued, right after the timed region
@@ -565,11 +570,6 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
         eager_ms = ev0.elapsed_time(ev1) / timer_steps
-
-    clock = None
-    if world == 1 and not args.no_clock_probe:
-        clock = clock_under_load(run, sync)
-        note(f"engine clock under load: {clock}")
 
     t = torch.tensor([dt, float(units_local)], dtype=torch.float64, device=dev)
     if world > 1:
