@@ -10,13 +10,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _emulator():
-    spec = importlib.util.spec_from_file_location("attn_fwd32_layout", os.path.join(ROOT, "tools", "probes", "attn_fwd32_layout.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+def _emulator(name="attn_fwd32_layout"):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "probes"))      # the backward emulator imports the forward one
+    try:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", "probes", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.pop(0)
     return mod
 
 
 @pytest.mark.parametrize("dk", [256, 128])
 def test_lane_algebra_and_banks(dk):
     assert _emulator().check(dk)
+
+
+@pytest.mark.parametrize("dk", [256, 128])
+def test_backward_dq_lane_algebra_and_banks(dk):
+    """the experimental dQ kernel (bmt_amd/csrc/exp/attn_bwd32.hip): a K image that serves row fragments AND transposing reads, V rows,
+    S^T / dP^T / dQ^T against numpy"""
+    assert _emulator("attn_bwd32_layout").check(dk)
