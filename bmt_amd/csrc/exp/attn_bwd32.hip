@@ -34,7 +34,7 @@ __device__ __forceinline__ float bfbits_hi(uint32_t w) { return __uint_as_float(
     } while (0)
 
 template <int DK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32_kernel(const AttnPB p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32_kernel(const AttnPB p, float* kq_out) {
     constexpr int BC = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BC * ROWB, STAGE = 2 * TILE, NS = 4;
     constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BC / RPP, PPW = NP / 4;
     static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dof[ks] = as_bf16x8(u32x4{w0, w1, w2, w3});
     }
     const float deltas = delta * up;
+    // 2^k(q): the dK / dV kernel derives its (one) scale from the smallest of these; a row without gradient does not take part
+    if (kq_out != nullptr && qok && hh == 0) kq_out[stat] = amax > 0.f ? up : 3.0e38f;
     const float sc2 = p.scale * LOG2E;
     f32x16 dq[DT];
 #pragma unroll
@@ -270,14 +272,272 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 template <int DK>
-int launch_dq32(const AttnPB& p, hipStream_t st) {
+int launch_dq32(const AttnPB& p, float* kq_out, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
     const int ntile = (p.Sk + 31) / 32;
     const int lds_loop = 4 * 2 * 32 * DK * 2 + ((ntile * 32 + 15) & ~15), lds_epi = DK * (128 + 8) * 2;
     const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq32_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((attn_bwd_dq32_kernel<DK>), dim3(nblk), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd_dq32_kernel<DK>), dim3(nblk), dim3(256), lds, st, p, kq_out);
     BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_dq32");
+    return BMT_OK;
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------- dK / dV
+// 32 keys per wave (K fp16 and V bf16 fragments in registers, both 32 x d_k accumulators in AGPRs), 4 waves = 128 keys per workgroup,
+// loop over 32-query stages: the Q tile (fp16) and the dO tile (bf16) come by LDS-DMA into a 4-deep ring, BOTH with the dual-purpose
+// swizzle of the dQ kernel's K image (row fragments for S / dP, transposing reads for dK^T / dV^T):
+//   S[q][key]   = Qtile . K^T     (fp16; A = Q rows from LDS, B = K registers)  -> lane (key = l31, hh) register 4 i + j: query 8 i + 4 hh + j
+//   dP[q][key]  = dOtile . V^T    (bf16; V converted once in the prologue)
+//   dV^T[d][key] += dO^T . P      (bf16; A = dO^T through the transpose unit, B = P registers 8 kk .. 8 kk + 7)
+//   dK^T[d][key] += Q^T . dS'     (fp16; dS' = dS 2^g with ONE scale per (batch, head): the reduction runs over the queries, a per-query
+//                                  scale could not be taken out again; g = min_q k(q) of the dQ kernel's row scales, so the largest row
+//                                  is where the dQ kernel put it and smaller rows lose absolute, not relative, accuracy)
+// lse (in log2 units), delta and nothing else per query are staged into LDS once (no ordinary load in the loop); rows past Sq get
+// lse = +huge (P = 0).  A masked key is a lane whose P is zero throughout: its gradient rows are written as zeros.
+// OPEN (compiler output, no GPU run yet): at d_k = 256 the kernel needs K, V (128 registers) + two gradient tiles (256) + S, dP (32) +
+// ~90 working registers = the whole 512-register file, and hipcc 7.2 spills 636 bytes per lane -- it keeps the K / V fragments in
+// scratch and reloads them every stage (32 scratch_load_dwordx4 in the loop).  Still correct (its waits are conservative, and extra
+// VMEM operations only make the counted vmcnt of the stage end stronger), but a scratch reload waits, in order, behind the DMA requests
+// issued before it: the three-tiles-ahead prefetch collapses to the latency of the newest request.  Ways out, in order of effort: pin the
+// register classes by hand (MFMAs as inline asm: K / V fragments and dK in AGPRs, dV + everything the VALU touches in VGPRs -- needs the
+// gfx950 MFMA hazard table for the s_nops the compiler no longer inserts); two passes over the queries in one launch (dV with K only,
+// then dK: no spills, S computed twice = +25 % MFMAs); d_k = 128 (configs[4]) is spill-free as it is.
+template <int DK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv32x_kernel(const AttnPB p, const float* kq) {
+    constexpr int BQ = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BQ * ROWB, STAGE = 2 * TILE, NS = 4;
+    constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BQ / RPP, PPW = NP / 4;
+    static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
+    static_assert(PPW <= 4, "pieces per wave");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int nst = (p.Sq + BQ - 1) / BQ;
+    float* sLse = reinterpret_cast<float*>(smem + NS * STAGE);          // [nst * 32] lse * log2 e (+huge past Sq)
+    float* sDel = sLse + nst * BQ;                                       // [nst * 32] delta
+    float* sRed = sDel + nst * BQ;                                       // [4] block reduction scratch
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int nkt = (p.Sk + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    const int kt = w % nkt, bh = w / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int key = kt * 128 + wid * 32 + l31;
+    const bool kin = key < p.Sk;
+    const bool kok = kin && (p.mask == nullptr || p.mask[(int64_t)b * p.mask_bs + key] != 0);
+    const bool wave_on = kt * 128 + wid * 32 < p.Sk;
+
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sq - 1) * p.ldq + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sq - 1) * p.ldo + DK) * 2), 0x00020000);
+    int qvo[4], ovo[4];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = (wid * PPW + j) * RPP + lane / CPR, cpos = lane % CPR;
+        qvo[j] = row * (int)p.ldq * 2 + ((cpos ^ kswz(row)) * 16);
+        ovo[j] = row * (int)p.ldo * 2 + ((cpos ^ kswz(row)) * 16);
+    }
+    const int sstep_q = BQ * (int)p.ldq * 2, sstep_o = BQ * (int)p.ldo * 2;
+#define BMT_B_DMA_Q(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + (slot_) * STAGE + (wid * PPW + (j_)) * 1024), 16, qvo[j_], (t_) * sstep_q, 0, 0)
+#define BMT_B_DMA_O(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + (slot_) * STAGE + TILE + (wid * PPW + (j_)) * 1024), 16, ovo[j_], (t_) * sstep_o, 0, 0)
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        const int tl = min(s, nst - 1);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) BMT_B_DMA_Q(j, tl, s);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) BMT_B_DMA_O(j, tl, s);
+    }
+    bf16x8 kf[KS], vf[KS];      // K as fp16 (B operand of S), V as bf16 (B operand of dP)
+    {
+        const int64_t ko = (int64_t)b * p.bsk + (int64_t)key * p.ldk + h * DK + 8 * hh;
+        const int64_t vo = (int64_t)b * p.bsv + (int64_t)key * p.ldv + h * DK + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = ldfrag(p.Kh + ko + 16 * ks, kin);
+            vf[ks] = h8_to_b8(ldfrag(p.Vh + vo + 16 * ks, kin));
+        }
+    }
+    const int64_t stat0 = ((int64_t)b * p.H + h) * p.Sq;
+    float gmin = 3.0e38f;
+    for (int i = tid; i < nst * BQ; i += NT) {
+        const bool in = i < p.Sq;
+        sLse[i] = in ? p.lse[stat0 + i] * LOG2E : 3.0e38f;
+        sDel[i] = in ? p.delta[stat0 + i] : 0.f;
+        if (in && kq != nullptr) gmin = fminf(gmin, kq[stat0 + i]);
+    }
+    gmin = -wave_max(-gmin);
+    if (lane == 0) sRed[wid] = gmin;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gmin = fminf(fminf(sRed[0], sRed[1]), fminf(sRed[2], sRed[3]));
+    const float up = (kq != nullptr && gmin < 1.0e38f) ? gmin : 1.f, down = 1.f / up;     // powers of two
+    const float sc2 = p.scale * LOG2E, scu = p.scale * up;
+
+    f32x16 dka[DT], dva[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const int fk = kswz(l31);
+    const uint32_t qA0 = lds0 + l31 * ROWB + 32 * (fk >> 1) + 16 * (hh ^ (fk & 1));          // row fragments of the Q tile (+ TILE: dO tile)
+    const int m16 = lane & 15, gi = (lane >> 4) & 1, mq = m16 >> 2, mr = m16 & 3;
+    const uint32_t qT0 = lds0 + (4 * hh + mq) * ROWB + 64 * mq + 32 * gi + 16 * ((mr >> 1) ^ hh) + 8 * (mr & 1);   // transposing reads
+
+    const bool compute = wave_on && __any(kok);
+    for (int t = 0; t < nst; ++t) {
+        const int slot = t % NS, slotn = (t + NS - 1) % NS;
+        const int tn = min(t + NS - 1, nst - 1);
+        if (!compute) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) BMT_B_DMA_Q(j, tn, slotn);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) BMT_B_DMA_O(j, tn, slotn);
+        } else {
+            const uint32_t qA = qA0 + slot * STAGE, oA = qA + TILE, qT = qT0 + slot * STAGE, oT = qT + TILE;
+            // this lane's 16 queries of the stage: 8 i + 4 hh + j
+            // lse of this lane's 16 queries (8 i + 4 hh + j), pinned here by asm reads (a plain load would be hoisted and lengthen its live range)
+            const uint32_t statA = lds0 + NS * STAGE + (t * BQ + 4 * hh) * 4;
+            u32x4 lsr[4];
+            lsr[0] = lds_b128<0>(statA); lsr[1] = lds_b128<32>(statA); lsr[2] = lds_b128<64>(statA); lsr[3] = lds_b128<96>(statA);
+            // (one accumulator per product here: K, V, two gradient tiles and their operands leave no room for the even / odd pairs of
+            // the dQ kernel -- 640 bytes of scratch with them)
+            f32x16 st0, dp0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st0[r] = 0.f; dp0[r] = 0.f; }
+            // ---- S = Qtile . K^T (fp16)
+            u32x4 af[3];
+            af[0] = lds_b128<0>(qA);
+            af[1] = lds_b128<0>(qA ^ (1 << 5));
+#define BMT_B_SSTEP(ks_)                                                                               \
+    if constexpr ((ks_) < KS) {                                                                        \
+        if constexpr ((ks_) + 2 < KS) af[((ks_) + 2) % 3] = lds_b128<0>(qA ^ (((ks_) + 2) << 5));      \
+        if constexpr ((ks_) < PPW) BMT_B_DMA_Q((ks_) % PPW, tn, slotn);                                \
+        else if constexpr ((ks_) < 2 * PPW) BMT_B_DMA_O((ks_) % PPW, tn, slotn);                       \
+        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(af[(ks_) % 3]);                             \
+        st0 = mfma32t<true>(as_bf16x8(af[(ks_) % 3]), kf[(ks_)], st0);                                 \
+    }
+            BMT_X_REP16(BMT_B_SSTEP)
+#undef BMT_B_SSTEP
+            // ---- P = exp2(S scale log2 e - lse), rounded to bf16 at once: the B operand of dV AND (unpacked again) the factor of dS --
+            // the fp32 probabilities would have to live through the dP block, and this kernel has no registers left for that (K, V and
+            // two gradient tiles take 384 of 512); dS carries bf16's 2^-9 from P, as every dS of the bf16 kernels does
+            lgkm_wait<0>(lsr[0]); lgkm_wait<0>(lsr[1]); lgkm_wait<0>(lsr[2]); lgkm_wait<0>(lsr[3]);
+            uint32_t pw[8];
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) {
+                const int r0 = 2 * j2;
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r0], sc2, -__uint_as_float(lsr[r0 >> 2][r0 & 3])));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r0 + 1], sc2, -__uint_as_float(lsr[(r0 + 1) >> 2][(r0 + 1) & 3])));
+                pw[j2] = kok ? pack_bf2(p0, p1) : 0u;
+            }
+            bf16x8 pf[2], dsf[2];
+            pf[0] = as_bf16x8(u32x4{pw[0], pw[1], pw[2], pw[3]});
+            pf[1] = as_bf16x8(u32x4{pw[4], pw[5], pw[6], pw[7]});
+            // ---- dP = dOtile . V^T (bf16)
+            u32x4 bfg[3];
+            bfg[0] = lds_b128<0>(oA);
+            bfg[1] = lds_b128<0>(oA ^ (1 << 5));
+#define BMT_B_PSTEP(ks_)                                                                               \
+    if constexpr ((ks_) < KS) {                                                                        \
+        if constexpr ((ks_) + 2 < KS) bfg[((ks_) + 2) % 3] = lds_b128<0>(oA ^ (((ks_) + 2) << 5));     \
+        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(bfg[(ks_) % 3]);                            \
+        dp0 = mfma32t<false>(as_bf16x8(bfg[(ks_) % 3]), vf[(ks_)], dp0);                               \
+    }
+            BMT_X_REP16(BMT_B_PSTEP)
+#undef BMT_B_PSTEP
+            // ---- dS' = P (dP - delta) scale 2^g (fp16, clamped)
+            u32x4 dlr[4];
+            const uint32_t delA = statA + nst * BQ * 4;
+            dlr[0] = lds_b128<0>(delA); dlr[1] = lds_b128<32>(delA); dlr[2] = lds_b128<64>(delA); dlr[3] = lds_b128<96>(delA);
+            lgkm_wait<0>(dlr[0]); lgkm_wait<0>(dlr[1]); lgkm_wait<0>(dlr[2]); lgkm_wait<0>(dlr[3]);
+            uint32_t dw[8];
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) {
+                const int r0 = 2 * j2;
+                float a0 = bfbits_lo(pw[j2]) * (dp0[r0] - __uint_as_float(dlr[r0 >> 2][r0 & 3])) * scu;
+                float a1 = bfbits_hi(pw[j2]) * (dp0[r0 + 1] - __uint_as_float(dlr[(r0 + 1) >> 2][(r0 + 1) & 3])) * scu;
+                a0 = fminf(fmaxf(a0, -60000.f), 60000.f);
+                a1 = fminf(fmaxf(a1, -60000.f), 60000.f);
+                dw[j2] = pack_h2(a0, a1);
+            }
+            dsf[0] = as_bf16x8(u32x4{dw[0], dw[1], dw[2], dw[3]});
+            dsf[1] = as_bf16x8(u32x4{dw[4], dw[5], dw[6], dw[7]});
+            // ---- dV^T += dO^T . P (bf16) and dK'^T += Q^T . dS' (fp16): 2 x 2 DT MFMAs, A through the transpose unit
+            u32x2 ta[3], tb[3];
+#define BMT_B_TFRAG(base_, n_)                                                            \
+    do {                                                                                  \
+        ta[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1)) * ROWB>((base_) ^ (((n_) >> 1) << 6));     \
+        tb[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1) + 8) * ROWB>((base_) ^ ((((n_) >> 1) << 6) | 32)); \
+    } while (0)
+            BMT_B_TFRAG(oT, 0);
+            BMT_B_TFRAG(oT, 1);
+#define BMT_B_VSTEP(n_)                                                                                \
+    if constexpr ((n_) < 2 * DT) {                                                                     \
+        if constexpr ((n_) + 2 < 2 * DT) BMT_B_TFRAG(oT, (n_) + 2);                                    \
+        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % 3], tb[(n_) % 3]);      \
+        const u32x4 av = {ta[(n_) % 3][0], ta[(n_) % 3][1], tb[(n_) % 3][0], tb[(n_) % 3][1]};         \
+        dva[(n_) >> 1] = mfma32t<false>(as_bf16x8(av), pf[(n_) & 1], dva[(n_) >> 1]);                  \
+    }
+            BMT_X_REP16(BMT_B_VSTEP)
+#undef BMT_B_VSTEP
+            BMT_B_TFRAG(qT, 0);
+            BMT_B_TFRAG(qT, 1);
+#define BMT_B_KSTEP(n_)                                                                                \
+    if constexpr ((n_) < 2 * DT) {                                                                     \
+        if constexpr ((n_) + 2 < 2 * DT) BMT_B_TFRAG(qT, (n_) + 2);                                    \
+        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % 3], tb[(n_) % 3]);      \
+        const u32x4 av = {ta[(n_) % 3][0], ta[(n_) % 3][1], tb[(n_) % 3][0], tb[(n_) % 3][1]};         \
+        dka[(n_) >> 1] = mfma32t<true>(as_bf16x8(av), dsf[(n_) & 1], dka[(n_) >> 1]);                  \
+    }
+            BMT_X_REP16(BMT_B_KSTEP)
+#undef BMT_B_KSTEP
+#undef BMT_B_TFRAG
+        }
+        if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        BMT_B_BAR();
+    }
+#undef BMT_B_DMA_Q
+#undef BMT_B_DMA_O
+
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dka[dt] *= down;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+    grad_store_rows<DK>(p.gk, dka, b, h, key, kin, hh);
+    if (p.gk.hiT || p.gk.bsum) {
+        grad_tile_write<DK, 128>(tile, dka, wid * 32, kin, l31, hh);
+        __syncthreads();
+        grad_tile_flush<DK, 128>(tile, p.gk, b, h, kt * 128, p.Sk, tid);
+        __syncthreads();
+    }
+    grad_store_rows<DK>(p.gv, dva, b, h, key, kin, hh);
+    if (p.gv.hiT || p.gv.bsum) {
+        grad_tile_write<DK, 128>(tile, dva, wid * 32, kin, l31, hh);
+        __syncthreads();
+        grad_tile_flush<DK, 128>(tile, p.gv, b, h, kt * 128, p.Sk, tid);
+    }
+}
+
+template <int DK>
+int launch_dkv32(const AttnPB& p, const float* kq, hipStream_t st) {
+    const int nblk = ((p.Sk + 127) / 128) * p.B * p.H;
+    const int nst = (p.Sq + 31) / 32;
+    const int lds_loop = 4 * 2 * 32 * DK * 2 + 2 * nst * 32 * 4 + 64, lds_epi = DK * (128 + 8) * 2;
+    const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32x_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn_bwd_dkv32x_kernel<DK>), dim3(nblk), dim3(256), lds, st, p, kq);
+    BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_dkv32");
     return BMT_OK;
 }
 
@@ -286,7 +546,8 @@ int launch_dq32(const AttnPB& p, hipStream_t st) {
 // the dQ half of bmt_attn_bwd_bf16 (same argument block; include/bmt_hip.h) on the experimental kernel.  Needs what the product call
 // leaves in its workspaces: delta_ws (delta = (1 - p) rowsum(dO * O)) and dOh_ws (the bf16 plane of dO) -- run the product first with
 // the same workspaces, then this entry with its own dQ outputs.  fp16 q / k / v planes (qkv_f16), d_k 128 / 256, key-padding masks.
-extern "C" int bmt_exp_attn_bwd_dq32(const bmt_attn_bwd_bf16_args* a, void* stream) {
+// kq_out (optional, fp32 [B][H][Sq]): the per-query scale 2^k(q) for bmt_exp_attn_bwd_dkv32.
+extern "C" int bmt_exp_attn_bwd_dq32(const bmt_attn_bwd_bf16_args* a, float* kq_out, void* stream) {
     BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->lse && a->delta_ws && a->dOh_ws && (a->dQ || a->dQh), "bmt_exp_attn_bwd_dq32: null pointer");
     BMT_CHECK_ARG(a->qkv_f16 && (a->dk == 128 || a->dk == 256), "bmt_exp_attn_bwd_dq32: fp16 q / k / v planes, d_k 128 / 256");
     BMT_CHECK_ARG(a->mask == nullptr || a->mask_qs == 0, "bmt_exp_attn_bwd_dq32: key-padding masks only");
@@ -303,5 +564,28 @@ extern "C" int bmt_exp_attn_bwd_dq32(const bmt_attn_bwd_bf16_args* a, void* stre
     p.kmean = a->kmean;
     p.qkv_f16 = 1;
     hipStream_t st = (hipStream_t)stream;
-    return a->dk == 256 ? launch_dq32<256>(p, st) : launch_dq32<128>(p, st);
+    return a->dk == 256 ? launch_dq32<256>(p, kq_out, st) : launch_dq32<128>(p, kq_out, st);
+}
+
+// the dK / dV half, same protocol (delta_ws and dOh_ws from a product call); kq: the row scales bmt_exp_attn_bwd_dq32 left (nullptr: dS
+// unscaled).  Sq <= 3072 (lse / delta of the (batch, head) live in LDS), no dropout-mask or per-query mask.
+extern "C" int bmt_exp_attn_bwd_dkv32(const bmt_attn_bwd_bf16_args* a, const float* kq, void* stream) {
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->lse && a->delta_ws && a->dOh_ws && (a->dK || a->dKh) && (a->dV || a->dVh),
+                  "bmt_exp_attn_bwd_dkv32: null pointer");
+    BMT_CHECK_ARG(a->qkv_f16 && (a->dk == 128 || a->dk == 256), "bmt_exp_attn_bwd_dkv32: fp16 q / k / v planes, d_k 128 / 256");
+    BMT_CHECK_ARG(a->mask == nullptr || a->mask_qs == 0, "bmt_exp_attn_bwd_dkv32: key-padding masks only");
+    BMT_CHECK_ARG(a->Sq <= 3072 && (int64_t)a->Sq * a->ldq * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31), "bmt_exp_attn_bwd_dkv32: Sq too large");
+    AttnPB p;
+    memset(&p, 0, sizeof(p));
+    p.Qh = a->Qh; p.Kh = a->Kh; p.Vh = a->Vh; p.dOh = a->dOh_ws;
+    p.lse = a->lse; p.delta = a->delta_ws;
+    p.gk = GradOut{a->dK, a->dkv_ld, a->dkv_bs, a->dKh, a->gkv_ld, a->gkv_bs, a->dKT, a->gkvT_ld, a->dbk};
+    p.gv = GradOut{a->dV, a->dkv_ld, a->dkv_bs, a->dVh, a->gkv_ld, a->gkv_bs, a->dVT, a->gkvT_ld, a->dbv};
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+    p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.scale = a->scale; p.drop_p = a->drop_p;
+    p.qkv_f16 = 1;
+    hipStream_t st = (hipStream_t)stream;
+    return a->dk == 256 ? launch_dkv32<256>(p, kq, st) : launch_dkv32<128>(p, kq, st);
 }

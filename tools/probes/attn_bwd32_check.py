@@ -22,7 +22,9 @@ from bmt_amd._lib import AttnBwdBf16Args  # noqa: E402
 
 EXP = C.CDLL(os.path.join(ROOT, "bmt_amd", "lib", "libbmt_exp.so"))
 EXP.bmt_exp_attn_bwd_dq32.restype = C.c_int
-EXP.bmt_exp_attn_bwd_dq32.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p]
+EXP.bmt_exp_attn_bwd_dq32.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_void_p]
+EXP.bmt_exp_attn_bwd_dkv32.restype = C.c_int
+EXP.bmt_exp_attn_bwd_dkv32.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_void_p]
 EXP.bmt_last_error.restype = C.c_char_p
 dev = "cuda"
 _p, _st = ops._p, ops._st
@@ -44,14 +46,14 @@ def make_args(q, k, v, o, do, lse, mask, H, dq, dk_, dv, delta, doh, km):
 def reference(q, k, v, do, mask, H):
     B, Sq, D = q.shape
     dk = D // H
-    qd = q.double().detach().requires_grad_(True)
+    qd, kd, vd = (x.double().detach().requires_grad_(True) for x in (q, k, v))
     qh = qd.view(B, Sq, H, dk).transpose(1, 2)
-    kh, vh = (x.double().view(B, -1, H, dk).transpose(1, 2) for x in (k, v))
+    kh, vh = (x.view(B, -1, H, dk).transpose(1, 2) for x in (kd, vd))
     s = (qh @ kh.transpose(-1, -2)) / dk ** 0.5
     s = s.masked_fill(~mask.view(B, 1, 1, -1), float("-inf"))
     o = (torch.softmax(s, dim=-1) @ vh).transpose(1, 2).reshape(B, Sq, D)
     (o * do.double()).sum().backward()
-    return qd.grad
+    return qd.grad, kd.grad, vd.grad
 
 
 def case(B, H, Sq, Sk, dk, g, time_it=False):
@@ -67,22 +69,32 @@ def case(B, H, Sq, Sk, dk, g, time_it=False):
     o, lse = ops.attn_fwd_bf16(q, None, k, None, v, None, mask, H, precision=ops.PREC_F16)
     f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
     dq_old, dq_new, dk_, dv = f32(B, Sq, D), torch.zeros(B, Sq, D, device=dev), f32(B, Sk, D), f32(B, Sk, D)
+    dk_new, dv_new, kq = torch.zeros(B, Sk, D, device=dev), torch.zeros(B, Sk, D, device=dev), f32(B, H, Sq)
     delta, doh = f32(B, H, Sq), torch.empty(B, Sq, D, device=dev, dtype=torch.bfloat16)
     keepm = ops._mask_args(mask, B, Sq, Sk)
     km = ops.attn_kmean(k, k.stride(1), k.stride(0), B, Sk, D, keepm, f16=True)
     a, keep = make_args(q, k, v, o, do, lse, mask, H, dq_old, dk_, dv, delta, doh, km)
     _lib.check(ops.lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     a2, keep2 = make_args(q, k, v, o, do, lse, mask, H, dq_new, dk_, dv, delta, doh, km)
-    rc = EXP.bmt_exp_attn_bwd_dq32(C.byref(a2), _st())
+    rc = EXP.bmt_exp_attn_bwd_dq32(C.byref(a2), _p(kq), _st())
     if rc != 0:
         raise RuntimeError(f"bmt_exp_attn_bwd_dq32 rc={rc}: {EXP.bmt_last_error().decode()}")
+    a3, keep3 = make_args(q, k, v, o, do, lse, mask, H, dq_new, dk_new, dv_new, delta, doh, km)
+    rc = EXP.bmt_exp_attn_bwd_dkv32(C.byref(a3), _p(kq), _st())
+    if rc != 0:
+        raise RuntimeError(f"bmt_exp_attn_bwd_dkv32 rc={rc}: {EXP.bmt_last_error().decode()}")
     torch.cuda.synchronize()
-    ref = reference(q, k, v, do, mask, H)
-    rel = lambda x: float((x.double() - ref).norm() / ref.norm())
+    ref, refk, refv = reference(q, k, v, do, mask, H)
+    rel = lambda x, r=None: float((x.double() - (ref if r is None else r)).norm() / (ref if r is None else r).norm())
     rows = lambda x: float(((x.double() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-300)).max())
     ok = bool(torch.isfinite(dq_new).all()) and rel(dq_new) <= max(1.5 * rel(dq_old), 2e-3)
     print(f"  B{B} H{H} Sq{Sq} Sk{Sk} dk{dk}: |dq-ref|/|ref| old {rel(dq_old):.2e} new {rel(dq_new):.2e}; worst row old {rows(dq_old):.2e} "
           f"new {rows(dq_new):.2e}  {'OK' if ok else 'FAIL'}", flush=True)
+    okk = bool(torch.isfinite(dk_new).all() and torch.isfinite(dv_new).all()) and rel(dk_new, refk) <= max(1.5 * rel(dk_, refk), 2e-3) \
+        and rel(dv_new, refv) <= max(1.5 * rel(dv, refv), 2e-3)
+    print(f"      |dk-ref|/|ref| old {rel(dk_, refk):.2e} new {rel(dk_new, refk):.2e};  |dv-ref|/|ref| old {rel(dv, refv):.2e} new {rel(dv_new, refv):.2e}  "
+          f"{'OK' if okk else 'FAIL'}", flush=True)
+    ok = ok and okk
     if time_it:
         def timed(f, iters=20):
             for _ in range(3):
@@ -96,10 +108,11 @@ def case(B, H, Sq, Sk, dk, g, time_it=False):
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / iters * 1e3
         t_all = timed(lambda: ops.lib.bmt_attn_bwd_bf16(C.byref(a), _st()))
-        t_new = timed(lambda: EXP.bmt_exp_attn_bwd_dq32(C.byref(a2), _st()))
-        fl = 6.0 * B * H * Sq * Sk * dk
-        print(f"      product backward (delta + dQ + dK/dV kernels) {t_all:7.1f} us; experimental dQ kernel alone {t_new:7.1f} us "
-              f"({fl / t_new / 1e6:6.1f} TF/s; the product's dQ kernel: rocprofv3 --kernel-trace of this script, attn_bwd_dq16b_kernel)", flush=True)
+        t_new = timed(lambda: EXP.bmt_exp_attn_bwd_dq32(C.byref(a2), _p(kq), _st()))
+        t_kv = timed(lambda: EXP.bmt_exp_attn_bwd_dkv32(C.byref(a3), _p(kq), _st()))
+        fl = 2.0 * B * H * Sq * Sk * dk
+        print(f"      product backward (delta + dQ + dK/dV kernels) {t_all:7.1f} us; experimental dQ {t_new:7.1f} us ({3 * fl / t_new / 1e6:6.1f} TF/s), "
+              f"dK/dV {t_kv:7.1f} us ({4 * fl / t_kv / 1e6:6.1f} TF/s); the product's kernels one by one: rocprofv3 --kernel-trace of this script", flush=True)
     return ok
 
 
