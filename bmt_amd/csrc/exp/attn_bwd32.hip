@@ -300,11 +300,148 @@ int launch_dq32(const AttnPB& p, float* kq_out, hipStream_t st) {
 // ~90 working registers = the whole 512-register file, and hipcc 7.2 spills 636 bytes per lane -- it keeps the K / V fragments in
 // scratch and reloads them every stage (32 scratch_load_dwordx4 in the loop).  Still correct (its waits are conservative, and extra
 // VMEM operations only make the counted vmcnt of the stage end stronger), but a scratch reload waits, in order, behind the DMA requests
-// issued before it: the three-tiles-ahead prefetch collapses to the latency of the newest request.  Ways out, in order of effort: pin the
-// register classes by hand (MFMAs as inline asm: K / V fragments and dK in AGPRs, dV + everything the VALU touches in VGPRs -- needs the
-// gfx950 MFMA hazard table for the s_nops the compiler no longer inserts); two passes over the queries in one launch (dV with K only,
-// then dK: no spills, S computed twice = +25 % MFMAs); d_k = 128 (configs[4]) is spill-free as it is.
-template <int DK>
+// issued before it: the three-tiles-ahead prefetch collapses to the latency of the newest request.  Ways out: the TWO-pass form below
+// (dV with K only, then dK with K and V, in one launch: 256 + 222 registers, no scratch; S is computed twice = 80 instead of 64 MFMAs per
+// stage); or pinning the register classes by hand (MFMAs as inline asm: K / V fragments and dK in AGPRs, dV + everything the VALU touches
+// in VGPRs -- needs the gfx950 MFMA hazard table for the s_nops the compiler no longer inserts).  d_k = 128 (configs[4]) is spill-free
+// in one pass.
+// one pass over the query stages of a (batch, head): DO_DV / DO_DK select the gradient products (both: one pass, 64 MFMAs per stage; the
+// two-pass kernel runs <true, false> then <false, true>: S twice = 80 MFMAs per stage pair, but K + one gradient tile (+ V in the second
+// pass) fit the register file without scratch)
+template <int DK, bool DO_DV, bool DO_DK>
+__device__ __forceinline__ void dkv_pass(const AttnPB& p, char* smem, const int nst, const bool compute, const bool kok, const int wid, const int hh,
+                                         const uint32_t lds0, const uint32_t qA0, const uint32_t qT0, const __amdgpu_buffer_rsrc_t rsQ,
+                                         const __amdgpu_buffer_rsrc_t rsO, const int (&qvo)[4], const int (&ovo)[4], const bf16x8 (&kf)[DK / 16],
+                                         const bf16x8 (&vf)[DK / 16], f32x16 (&dka)[DK / 32], f32x16 (&dva)[DK / 32], const float sc2, const float scu) {
+    constexpr int BQ = 32, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BQ * ROWB, STAGE = 2 * TILE, NS = 4;
+    constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BQ / RPP, PPW = NP / 4;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int sstep_q = BQ * (int)p.ldq * 2, sstep_o = BQ * (int)p.ldo * 2;
+#define BMT_B_DMA_Q(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + (slot_) * STAGE + (wid * PPW + (j_)) * 1024), 16, qvo[j_], (t_) * sstep_q, 0, 0)
+#define BMT_B_DMA_O(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + (slot_) * STAGE + TILE + (wid * PPW + (j_)) * 1024), 16, ovo[j_], (t_) * sstep_o, 0, 0)
+    for (int t = 0; t < nst; ++t) {
+        const int slot = t % NS, slotn = (t + NS - 1) % NS;
+        const int tn = min(t + NS - 1, nst - 1);
+        if (!compute) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) BMT_B_DMA_Q(j, tn, slotn);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) BMT_B_DMA_O(j, tn, slotn);
+        } else {
+            const uint32_t qA = qA0 + slot * STAGE, oA = qA + TILE, qT = qT0 + slot * STAGE, oT = qT + TILE;
+            // lse of this lane's 16 queries (8 i + 4 hh + j), pinned here by asm reads (a plain load would be hoisted and lengthen its live range)
+            const uint32_t statA = lds0 + NS * STAGE + (t * BQ + 4 * hh) * 4;
+            u32x4 lsr[4];
+            lsr[0] = lds_b128<0>(statA); lsr[1] = lds_b128<32>(statA); lsr[2] = lds_b128<64>(statA); lsr[3] = lds_b128<96>(statA);
+            f32x16 st0, dp0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st0[r] = 0.f; dp0[r] = 0.f; }
+            // ---- S = Qtile . K^T (fp16)
+            u32x4 af[3];
+            af[0] = lds_b128<0>(qA);
+            af[1] = lds_b128<0>(qA ^ (1 << 5));
+#define BMT_B_SSTEP(ks_)                                                                               \
+    if constexpr ((ks_) < KS) {                                                                        \
+        if constexpr ((ks_) + 2 < KS) af[((ks_) + 2) % 3] = lds_b128<0>(qA ^ (((ks_) + 2) << 5));      \
+        if constexpr ((ks_) < PPW) BMT_B_DMA_Q((ks_) % PPW, tn, slotn);                                \
+        else if constexpr ((ks_) < 2 * PPW) BMT_B_DMA_O((ks_) % PPW, tn, slotn);                       \
+        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(af[(ks_) % 3]);                             \
+        st0 = mfma32t<true>(as_bf16x8(af[(ks_) % 3]), kf[(ks_)], st0);                                 \
+    }
+            BMT_X_REP16(BMT_B_SSTEP)
+#undef BMT_B_SSTEP
+            // ---- P = exp2(S scale log2 e - lse), rounded to bf16 at once: the B operand of dV AND (unpacked again) the factor of dS --
+            // the fp32 probabilities would otherwise live through the dP block; dS carries bf16's 2^-9 from P, as every dS of the bf16 kernels does
+            lgkm_wait<0>(lsr[0]); lgkm_wait<0>(lsr[1]); lgkm_wait<0>(lsr[2]); lgkm_wait<0>(lsr[3]);
+            uint32_t pw[8];
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) {
+                const int r0 = 2 * j2;
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r0], sc2, -__uint_as_float(lsr[r0 >> 2][r0 & 3])));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r0 + 1], sc2, -__uint_as_float(lsr[(r0 + 1) >> 2][(r0 + 1) & 3])));
+                pw[j2] = kok ? pack_bf2(p0, p1) : 0u;
+            }
+            u32x2 ta[3], tb[3];
+#define BMT_B_TFRAG(base_, n_)                                                            \
+    do {                                                                                  \
+        ta[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1)) * ROWB>((base_) ^ (((n_) >> 1) << 6));     \
+        tb[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1) + 8) * ROWB>((base_) ^ ((((n_) >> 1) << 6) | 32)); \
+    } while (0)
+            if constexpr (DO_DV) {
+                // ---- dV^T += dO^T . P (bf16), A through the transpose unit
+                bf16x8 pf[2];
+                pf[0] = as_bf16x8(u32x4{pw[0], pw[1], pw[2], pw[3]});
+                pf[1] = as_bf16x8(u32x4{pw[4], pw[5], pw[6], pw[7]});
+                BMT_B_TFRAG(oT, 0);
+                BMT_B_TFRAG(oT, 1);
+#define BMT_B_VSTEP(n_)                                                                                \
+    if constexpr ((n_) < 2 * DT) {                                                                     \
+        if constexpr ((n_) + 2 < 2 * DT) BMT_B_TFRAG(oT, (n_) + 2);                                    \
+        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % 3], tb[(n_) % 3]);      \
+        const u32x4 av = {ta[(n_) % 3][0], ta[(n_) % 3][1], tb[(n_) % 3][0], tb[(n_) % 3][1]};         \
+        dva[(n_) >> 1] = mfma32t<false>(as_bf16x8(av), pf[(n_) & 1], dva[(n_) >> 1]);                  \
+    }
+                BMT_X_REP16(BMT_B_VSTEP)
+#undef BMT_B_VSTEP
+            }
+            if constexpr (DO_DK) {
+                // ---- dP = dOtile . V^T (bf16)
+                u32x4 bfg[3];
+                bfg[0] = lds_b128<0>(oA);
+                bfg[1] = lds_b128<0>(oA ^ (1 << 5));
+#define BMT_B_PSTEP(ks_)                                                                               \
+    if constexpr ((ks_) < KS) {                                                                        \
+        if constexpr ((ks_) + 2 < KS) bfg[((ks_) + 2) % 3] = lds_b128<0>(oA ^ (((ks_) + 2) << 5));     \
+        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(bfg[(ks_) % 3]);                            \
+        dp0 = mfma32t<false>(as_bf16x8(bfg[(ks_) % 3]), vf[(ks_)], dp0);                               \
+    }
+                BMT_X_REP16(BMT_B_PSTEP)
+#undef BMT_B_PSTEP
+                // ---- dS' = P (dP - delta) scale 2^g (fp16, clamped)
+                u32x4 dlr[4];
+                const uint32_t delA = statA + nst * BQ * 4;
+                dlr[0] = lds_b128<0>(delA); dlr[1] = lds_b128<32>(delA); dlr[2] = lds_b128<64>(delA); dlr[3] = lds_b128<96>(delA);
+                lgkm_wait<0>(dlr[0]); lgkm_wait<0>(dlr[1]); lgkm_wait<0>(dlr[2]); lgkm_wait<0>(dlr[3]);
+                uint32_t dw[8];
+#pragma unroll
+                for (int j2 = 0; j2 < 8; ++j2) {
+                    const int r0 = 2 * j2;
+                    float a0 = bfbits_lo(pw[j2]) * (dp0[r0] - __uint_as_float(dlr[r0 >> 2][r0 & 3])) * scu;
+                    float a1 = bfbits_hi(pw[j2]) * (dp0[r0 + 1] - __uint_as_float(dlr[(r0 + 1) >> 2][(r0 + 1) & 3])) * scu;
+                    a0 = fminf(fmaxf(a0, -60000.f), 60000.f);
+                    a1 = fminf(fmaxf(a1, -60000.f), 60000.f);
+                    dw[j2] = pack_h2(a0, a1);
+                }
+                bf16x8 dsf[2];
+                dsf[0] = as_bf16x8(u32x4{dw[0], dw[1], dw[2], dw[3]});
+                dsf[1] = as_bf16x8(u32x4{dw[4], dw[5], dw[6], dw[7]});
+                // ---- dK'^T += Q^T . dS' (fp16)
+                BMT_B_TFRAG(qT, 0);
+                BMT_B_TFRAG(qT, 1);
+#define BMT_B_KSTEP(n_)                                                                                \
+    if constexpr ((n_) < 2 * DT) {                                                                     \
+        if constexpr ((n_) + 2 < 2 * DT) BMT_B_TFRAG(qT, (n_) + 2);                                    \
+        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % 3], tb[(n_) % 3]);      \
+        const u32x4 av = {ta[(n_) % 3][0], ta[(n_) % 3][1], tb[(n_) % 3][0], tb[(n_) % 3][1]};         \
+        dka[(n_) >> 1] = mfma32t<true>(as_bf16x8(av), dsf[(n_) & 1], dka[(n_) >> 1]);                  \
+    }
+                BMT_X_REP16(BMT_B_KSTEP)
+#undef BMT_B_KSTEP
+            }
+#undef BMT_B_TFRAG
+        }
+        if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        BMT_B_BAR();
+    }
+#undef BMT_B_DMA_Q
+#undef BMT_B_DMA_O
+}
+
+// TWO: two passes over the queries in one launch (dV with K only, then dK with K and V): no scratch at d_k 256, S computed twice
+template <int DK, bool TWO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv32x_kernel(const AttnPB p, const float* kq) {
     constexpr int BQ = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BQ * ROWB, STAGE = 2 * TILE, NS = 4;
     constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BQ / RPP, PPW = NP / 4;
@@ -335,34 +472,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                          (int)(((int64_t)(p.Sq - 1) * p.ldo + DK) * 2), 0x00020000);
     int qvo[4], ovo[4];
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        const int row = (wid * PPW + j) * RPP + lane / CPR, cpos = lane % CPR;
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wid * PPW + (j % PPW)) * RPP + lane / CPR, cpos = lane % CPR;
         qvo[j] = row * (int)p.ldq * 2 + ((cpos ^ kswz(row)) * 16);
         ovo[j] = row * (int)p.ldo * 2 + ((cpos ^ kswz(row)) * 16);
     }
     const int sstep_q = BQ * (int)p.ldq * 2, sstep_o = BQ * (int)p.ldo * 2;
-#define BMT_B_DMA_Q(j_, t_, slot_) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + (slot_) * STAGE + (wid * PPW + (j_)) * 1024), 16, qvo[j_], (t_) * sstep_q, 0, 0)
-#define BMT_B_DMA_O(j_, t_, slot_) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + (slot_) * STAGE + TILE + (wid * PPW + (j_)) * 1024), 16, ovo[j_], (t_) * sstep_o, 0, 0)
-
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
-        const int tl = min(s, nst - 1);
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) BMT_B_DMA_Q(j, tl, s);
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) BMT_B_DMA_O(j, tl, s);
+    // the first NS - 1 tiles of a pass (a tile index past the end re-fetches the last tile: harmless, uniform counts)
+#define BMT_B_PRIME()                                                                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS - 1; ++s_) {                                                                  \
+        const int tl_ = min(s_, nst - 1);                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                                                      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + s_ * STAGE + (wid * PPW + j) * 1024), 16, qvo[j], tl_ * sstep_q, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                                                      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + s_ * STAGE + TILE + (wid * PPW + j) * 1024), 16, ovo[j], tl_ * sstep_o, 0, 0); \
     }
+    BMT_B_PRIME()
     bf16x8 kf[KS], vf[KS];      // K as fp16 (B operand of S), V as bf16 (B operand of dP)
-    {
-        const int64_t ko = (int64_t)b * p.bsk + (int64_t)key * p.ldk + h * DK + 8 * hh;
-        const int64_t vo = (int64_t)b * p.bsv + (int64_t)key * p.ldv + h * DK + 8 * hh;
+    const int64_t ko = (int64_t)b * p.bsk + (int64_t)key * p.ldk + h * DK + 8 * hh;
+    const int64_t vo = (int64_t)b * p.bsv + (int64_t)key * p.ldv + h * DK + 8 * hh;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = ldfrag(p.Kh + ko + 16 * ks, kin);
-            vf[ks] = h8_to_b8(ldfrag(p.Vh + vo + 16 * ks, kin));
-        }
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = ldfrag(p.Kh + ko + 16 * ks, kin);
+        if constexpr (!TWO) vf[ks] = h8_to_b8(ldfrag(p.Vh + vo + 16 * ks, kin));
     }
     const int64_t stat0 = ((int64_t)b * p.H + h) * p.Sq;
     float gmin = 3.0e38f;
@@ -380,163 +512,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float up = (kq != nullptr && gmin < 1.0e38f) ? gmin : 1.f, down = 1.f / up;     // powers of two
     const float sc2 = p.scale * LOG2E, scu = p.scale * up;
 
-    f32x16 dka[DT], dva[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
-
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     const int fk = kswz(l31);
     const uint32_t qA0 = lds0 + l31 * ROWB + 32 * (fk >> 1) + 16 * (hh ^ (fk & 1));          // row fragments of the Q tile (+ TILE: dO tile)
     const int m16 = lane & 15, gi = (lane >> 4) & 1, mq = m16 >> 2, mr = m16 & 3;
     const uint32_t qT0 = lds0 + (4 * hh + mq) * ROWB + 64 * mq + 32 * gi + 16 * ((mr >> 1) ^ hh) + 8 * (mr & 1);   // transposing reads
-
     const bool compute = wave_on && __any(kok);
-    for (int t = 0; t < nst; ++t) {
-        const int slot = t % NS, slotn = (t + NS - 1) % NS;
-        const int tn = min(t + NS - 1, nst - 1);
-        if (!compute) {
-#pragma unroll
-            for (int j = 0; j < PPW; ++j) BMT_B_DMA_Q(j, tn, slotn);
-#pragma unroll
-            for (int j = 0; j < PPW; ++j) BMT_B_DMA_O(j, tn, slotn);
-        } else {
-            const uint32_t qA = qA0 + slot * STAGE, oA = qA + TILE, qT = qT0 + slot * STAGE, oT = qT + TILE;
-            // this lane's 16 queries of the stage: 8 i + 4 hh + j
-            // lse of this lane's 16 queries (8 i + 4 hh + j), pinned here by asm reads (a plain load would be hoisted and lengthen its live range)
-            const uint32_t statA = lds0 + NS * STAGE + (t * BQ + 4 * hh) * 4;
-            u32x4 lsr[4];
-            lsr[0] = lds_b128<0>(statA); lsr[1] = lds_b128<32>(statA); lsr[2] = lds_b128<64>(statA); lsr[3] = lds_b128<96>(statA);
-            // (one accumulator per product here: K, V, two gradient tiles and their operands leave no room for the even / odd pairs of
-            // the dQ kernel -- 640 bytes of scratch with them)
-            f32x16 st0, dp0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st0[r] = 0.f; dp0[r] = 0.f; }
-            // ---- S = Qtile . K^T (fp16)
-            u32x4 af[3];
-            af[0] = lds_b128<0>(qA);
-            af[1] = lds_b128<0>(qA ^ (1 << 5));
-#define BMT_B_SSTEP(ks_)                                                                               \
-    if constexpr ((ks_) < KS) {                                                                        \
-        if constexpr ((ks_) + 2 < KS) af[((ks_) + 2) % 3] = lds_b128<0>(qA ^ (((ks_) + 2) << 5));      \
-        if constexpr ((ks_) < PPW) BMT_B_DMA_Q((ks_) % PPW, tn, slotn);                                \
-        else if constexpr ((ks_) < 2 * PPW) BMT_B_DMA_O((ks_) % PPW, tn, slotn);                       \
-        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(af[(ks_) % 3]);                             \
-        st0 = mfma32t<true>(as_bf16x8(af[(ks_) % 3]), kf[(ks_)], st0);                                 \
-    }
-            BMT_X_REP16(BMT_B_SSTEP)
-#undef BMT_B_SSTEP
-            // ---- P = exp2(S scale log2 e - lse), rounded to bf16 at once: the B operand of dV AND (unpacked again) the factor of dS --
-            // the fp32 probabilities would have to live through the dP block, and this kernel has no registers left for that (K, V and
-            // two gradient tiles take 384 of 512); dS carries bf16's 2^-9 from P, as every dS of the bf16 kernels does
-            lgkm_wait<0>(lsr[0]); lgkm_wait<0>(lsr[1]); lgkm_wait<0>(lsr[2]); lgkm_wait<0>(lsr[3]);
-            uint32_t pw[8];
-#pragma unroll
-            for (int j2 = 0; j2 < 8; ++j2) {
-                const int r0 = 2 * j2;
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r0], sc2, -__uint_as_float(lsr[r0 >> 2][r0 & 3])));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r0 + 1], sc2, -__uint_as_float(lsr[(r0 + 1) >> 2][(r0 + 1) & 3])));
-                pw[j2] = kok ? pack_bf2(p0, p1) : 0u;
-            }
-            bf16x8 pf[2], dsf[2];
-            pf[0] = as_bf16x8(u32x4{pw[0], pw[1], pw[2], pw[3]});
-            pf[1] = as_bf16x8(u32x4{pw[4], pw[5], pw[6], pw[7]});
-            // ---- dP = dOtile . V^T (bf16)
-            u32x4 bfg[3];
-            bfg[0] = lds_b128<0>(oA);
-            bfg[1] = lds_b128<0>(oA ^ (1 << 5));
-#define BMT_B_PSTEP(ks_)                                                                               \
-    if constexpr ((ks_) < KS) {                                                                        \
-        if constexpr ((ks_) + 2 < KS) bfg[((ks_) + 2) % 3] = lds_b128<0>(oA ^ (((ks_) + 2) << 5));     \
-        lgkm_wait<((ks_) + 2 < KS) ? 2 : (KS - 1 - (ks_))>(bfg[(ks_) % 3]);                            \
-        dp0 = mfma32t<false>(as_bf16x8(bfg[(ks_) % 3]), vf[(ks_)], dp0);                               \
-    }
-            BMT_X_REP16(BMT_B_PSTEP)
-#undef BMT_B_PSTEP
-            // ---- dS' = P (dP - delta) scale 2^g (fp16, clamped)
-            u32x4 dlr[4];
-            const uint32_t delA = statA + nst * BQ * 4;
-            dlr[0] = lds_b128<0>(delA); dlr[1] = lds_b128<32>(delA); dlr[2] = lds_b128<64>(delA); dlr[3] = lds_b128<96>(delA);
-            lgkm_wait<0>(dlr[0]); lgkm_wait<0>(dlr[1]); lgkm_wait<0>(dlr[2]); lgkm_wait<0>(dlr[3]);
-            uint32_t dw[8];
-#pragma unroll
-            for (int j2 = 0; j2 < 8; ++j2) {
-                const int r0 = 2 * j2;
-                float a0 = bfbits_lo(pw[j2]) * (dp0[r0] - __uint_as_float(dlr[r0 >> 2][r0 & 3])) * scu;
-                float a1 = bfbits_hi(pw[j2]) * (dp0[r0 + 1] - __uint_as_float(dlr[(r0 + 1) >> 2][(r0 + 1) & 3])) * scu;
-                a0 = fminf(fmaxf(a0, -60000.f), 60000.f);
-                a1 = fminf(fmaxf(a1, -60000.f), 60000.f);
-                dw[j2] = pack_h2(a0, a1);
-            }
-            dsf[0] = as_bf16x8(u32x4{dw[0], dw[1], dw[2], dw[3]});
-            dsf[1] = as_bf16x8(u32x4{dw[4], dw[5], dw[6], dw[7]});
-            // ---- dV^T += dO^T . P (bf16) and dK'^T += Q^T . dS' (fp16): 2 x 2 DT MFMAs, A through the transpose unit
-            u32x2 ta[3], tb[3];
-#define BMT_B_TFRAG(base_, n_)                                                            \
-    do {                                                                                  \
-        ta[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1)) * ROWB>((base_) ^ (((n_) >> 1) << 6));     \
-        tb[(n_) % 3] = lds_tr_b64<(16 * ((n_) & 1) + 8) * ROWB>((base_) ^ ((((n_) >> 1) << 6) | 32)); \
-    } while (0)
-            BMT_B_TFRAG(oT, 0);
-            BMT_B_TFRAG(oT, 1);
-#define BMT_B_VSTEP(n_)                                                                                \
-    if constexpr ((n_) < 2 * DT) {                                                                     \
-        if constexpr ((n_) + 2 < 2 * DT) BMT_B_TFRAG(oT, (n_) + 2);                                    \
-        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % 3], tb[(n_) % 3]);      \
-        const u32x4 av = {ta[(n_) % 3][0], ta[(n_) % 3][1], tb[(n_) % 3][0], tb[(n_) % 3][1]};         \
-        dva[(n_) >> 1] = mfma32t<false>(as_bf16x8(av), pf[(n_) & 1], dva[(n_) >> 1]);                  \
-    }
-            BMT_X_REP16(BMT_B_VSTEP)
-#undef BMT_B_VSTEP
-            BMT_B_TFRAG(qT, 0);
-            BMT_B_TFRAG(qT, 1);
-#define BMT_B_KSTEP(n_)                                                                                \
-    if constexpr ((n_) < 2 * DT) {                                                                     \
-        if constexpr ((n_) + 2 < 2 * DT) BMT_B_TFRAG(qT, (n_) + 2);                                    \
-        lgkm_wait<((n_) + 2 < 2 * DT) ? 4 : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % 3], tb[(n_) % 3]);      \
-        const u32x4 av = {ta[(n_) % 3][0], ta[(n_) % 3][1], tb[(n_) % 3][0], tb[(n_) % 3][1]};         \
-        dka[(n_) >> 1] = mfma32t<true>(as_bf16x8(av), dsf[(n_) & 1], dka[(n_) >> 1]);                  \
-    }
-            BMT_X_REP16(BMT_B_KSTEP)
-#undef BMT_B_KSTEP
-#undef BMT_B_TFRAG
-        }
-        if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        BMT_B_BAR();
-    }
-#undef BMT_B_DMA_Q
-#undef BMT_B_DMA_O
+    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
 
+    f32x16 acc[DT];             // two-pass: dV, then dK'; one pass: dK' (dV in acc2)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dka[dt] *= down;
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    if constexpr (TWO) {
+        dkv_pass<DK, true, false>(p, smem, nst, compute, kok, wid, hh, lds0, qA0, qT0, rsQ, rsO, qvo, ovo, kf, kf, acc, acc, sc2, scu);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        grad_store_rows<DK>(p.gv, acc, b, h, key, kin, hh);
+        if (p.gv.hiT || p.gv.bsum) {
+            grad_tile_write<DK, 128>(tile, acc, wid * 32, kin, l31, hh);
+            __syncthreads();
+            grad_tile_flush<DK, 128>(tile, p.gv, b, h, kt * 128, p.Sk, tid);
+        }
+        __syncthreads();
+        BMT_B_PRIME()
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[ks] = h8_to_b8(ldfrag(p.Vh + vo + 16 * ks, kin));
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dkv_pass<DK, false, true>(p, smem, nst, compute, kok, wid, hh, lds0, qA0, qT0, rsQ, rsO, qvo, ovo, kf, vf, acc, acc, sc2, scu);
+    } else {
+        f32x16 acc2[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
+        dkv_pass<DK, true, true>(p, smem, nst, compute, kok, wid, hh, lds0, qA0, qT0, rsQ, rsO, qvo, ovo, kf, vf, acc, acc2, sc2, scu);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        grad_store_rows<DK>(p.gv, acc2, b, h, key, kin, hh);
+        if (p.gv.hiT || p.gv.bsum) {
+            grad_tile_write<DK, 128>(tile, acc2, wid * 32, kin, l31, hh);
+            __syncthreads();
+            grad_tile_flush<DK, 128>(tile, p.gv, b, h, kt * 128, p.Sk, tid);
+            __syncthreads();
+        }
+    }
+#undef BMT_B_PRIME
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] *= down;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
-    grad_store_rows<DK>(p.gk, dka, b, h, key, kin, hh);
+    grad_store_rows<DK>(p.gk, acc, b, h, key, kin, hh);
     if (p.gk.hiT || p.gk.bsum) {
-        grad_tile_write<DK, 128>(tile, dka, wid * 32, kin, l31, hh);
+        grad_tile_write<DK, 128>(tile, acc, wid * 32, kin, l31, hh);
         __syncthreads();
         grad_tile_flush<DK, 128>(tile, p.gk, b, h, kt * 128, p.Sk, tid);
-        __syncthreads();
-    }
-    grad_store_rows<DK>(p.gv, dva, b, h, key, kin, hh);
-    if (p.gv.hiT || p.gv.bsum) {
-        grad_tile_write<DK, 128>(tile, dva, wid * 32, kin, l31, hh);
-        __syncthreads();
-        grad_tile_flush<DK, 128>(tile, p.gv, b, h, kt * 128, p.Sk, tid);
     }
 }
 
-template <int DK>
+template <int DK, bool TWO>
 int launch_dkv32(const AttnPB& p, const float* kq, hipStream_t st) {
     const int nblk = ((p.Sk + 127) / 128) * p.B * p.H;
     const int nst = (p.Sq + 31) / 32;
     const int lds_loop = 4 * 2 * 32 * DK * 2 + 2 * nst * 32 * 4 + 64, lds_epi = DK * (128 + 8) * 2;
     const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32x_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((attn_bwd_dkv32x_kernel<DK>), dim3(nblk), dim3(256), lds, st, p, kq);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32x_kernel<DK, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn_bwd_dkv32x_kernel<DK, TWO>), dim3(nblk), dim3(256), lds, st, p, kq);
     BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_dkv32");
     return BMT_OK;
 }
@@ -568,8 +615,9 @@ extern "C" int bmt_exp_attn_bwd_dq32(const bmt_attn_bwd_bf16_args* a, float* kq_
 }
 
 // the dK / dV half, same protocol (delta_ws and dOh_ws from a product call); kq: the row scales bmt_exp_attn_bwd_dq32 left (nullptr: dS
-// unscaled).  Sq <= 3072 (lse / delta of the (batch, head) live in LDS), no dropout-mask or per-query mask.
-extern "C" int bmt_exp_attn_bwd_dkv32(const bmt_attn_bwd_bf16_args* a, const float* kq, void* stream) {
+// unscaled); two_pass: dV and dK in two passes over the queries (no scratch at d_k 256, S twice).  Sq <= 3072 (lse / delta of the (batch, head)
+// live in LDS), no per-query mask.
+extern "C" int bmt_exp_attn_bwd_dkv32(const bmt_attn_bwd_bf16_args* a, const float* kq, int two_pass, void* stream) {
     BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && a->lse && a->delta_ws && a->dOh_ws && (a->dK || a->dKh) && (a->dV || a->dVh),
                   "bmt_exp_attn_bwd_dkv32: null pointer");
     BMT_CHECK_ARG(a->qkv_f16 && (a->dk == 128 || a->dk == 256), "bmt_exp_attn_bwd_dkv32: fp16 q / k / v planes, d_k 128 / 256");
@@ -587,5 +635,6 @@ extern "C" int bmt_exp_attn_bwd_dkv32(const bmt_attn_bwd_bf16_args* a, const flo
     p.scale = a->scale; p.drop_p = a->drop_p;
     p.qkv_f16 = 1;
     hipStream_t st = (hipStream_t)stream;
-    return a->dk == 256 ? launch_dkv32<256>(p, kq, st) : launch_dkv32<128>(p, kq, st);
+    if (a->dk == 256) return two_pass ? launch_dkv32<256, true>(p, kq, st) : launch_dkv32<256, false>(p, kq, st);
+    return two_pass ? launch_dkv32<128, true>(p, kq, st) : launch_dkv32<128, false>(p, kq, st);
 }

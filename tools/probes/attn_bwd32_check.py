@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""GPU check + timing of the experimental dQ kernel of the attention backward (bmt_amd/csrc/exp/attn_bwd32.hip, libbmt_exp.so) against
+"""GPU check + timing of the experimental dQ and dK/dV kernels of the attention backward (bmt_amd/csrc/exp/attn_bwd32.hip, libbmt_exp.so) against
 the product's backward and an fp64 torch reference on the same rounded operands.  NOT yet run (written after round 2's GPU budget was
 spent; the kernel's lane algebra is checked on the CPU by attn_bwd32_layout.py).
 
@@ -24,7 +24,7 @@ EXP = C.CDLL(os.path.join(ROOT, "bmt_amd", "lib", "libbmt_exp.so"))
 EXP.bmt_exp_attn_bwd_dq32.restype = C.c_int
 EXP.bmt_exp_attn_bwd_dq32.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_void_p]
 EXP.bmt_exp_attn_bwd_dkv32.restype = C.c_int
-EXP.bmt_exp_attn_bwd_dkv32.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_void_p]
+EXP.bmt_exp_attn_bwd_dkv32.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_int, C.c_void_p]
 EXP.bmt_last_error.restype = C.c_char_p
 dev = "cuda"
 _p, _st = ops._p, ops._st
@@ -80,9 +80,12 @@ def case(B, H, Sq, Sk, dk, g, time_it=False):
     if rc != 0:
         raise RuntimeError(f"bmt_exp_attn_bwd_dq32 rc={rc}: {EXP.bmt_last_error().decode()}")
     a3, keep3 = make_args(q, k, v, o, do, lse, mask, H, dq_new, dk_new, dv_new, delta, doh, km)
-    rc = EXP.bmt_exp_attn_bwd_dkv32(C.byref(a3), _p(kq), _st())
-    if rc != 0:
-        raise RuntimeError(f"bmt_exp_attn_bwd_dkv32 rc={rc}: {EXP.bmt_last_error().decode()}")
+    dk_two, dv_two = torch.zeros_like(dk_new), torch.zeros_like(dv_new)
+    a4, keep4 = make_args(q, k, v, o, do, lse, mask, H, dq_new, dk_two, dv_two, delta, doh, km)
+    for args_, two in ((a3, 0), (a4, 1)):          # one pass (spills at d_k 256) and two passes over the queries
+        rc = EXP.bmt_exp_attn_bwd_dkv32(C.byref(args_), _p(kq), two, _st())
+        if rc != 0:
+            raise RuntimeError(f"bmt_exp_attn_bwd_dkv32 rc={rc}: {EXP.bmt_last_error().decode()}")
     torch.cuda.synchronize()
     ref, refk, refv = reference(q, k, v, do, mask, H)
     rel = lambda x, r=None: float((x.double() - (ref if r is None else r)).norm() / (ref if r is None else r).norm())
@@ -94,7 +97,10 @@ def case(B, H, Sq, Sk, dk, g, time_it=False):
         and rel(dv_new, refv) <= max(1.5 * rel(dv, refv), 2e-3)
     print(f"      |dk-ref|/|ref| old {rel(dk_, refk):.2e} new {rel(dk_new, refk):.2e};  |dv-ref|/|ref| old {rel(dv, refv):.2e} new {rel(dv_new, refv):.2e}  "
           f"{'OK' if okk else 'FAIL'}", flush=True)
-    ok = ok and okk
+    same = float((dk_two - dk_new).abs().max()), float((dv_two - dv_new).abs().max())
+    ok2 = same[0] <= 1e-6 * float(dk_new.abs().max()) + 1e-30 and same[1] <= 1e-6 * float(dv_new.abs().max()) + 1e-30
+    print(f"      two-pass vs one-pass kernel: max |dk| diff {same[0]:.2e}, |dv| diff {same[1]:.2e}  {'OK' if ok2 else 'FAIL'}", flush=True)
+    ok = ok and okk and ok2
     if time_it:
         def timed(f, iters=20):
             for _ in range(3):
@@ -109,10 +115,12 @@ def case(B, H, Sq, Sk, dk, g, time_it=False):
             return e0.elapsed_time(e1) / iters * 1e3
         t_all = timed(lambda: ops.lib.bmt_attn_bwd_bf16(C.byref(a), _st()))
         t_new = timed(lambda: EXP.bmt_exp_attn_bwd_dq32(C.byref(a2), _p(kq), _st()))
-        t_kv = timed(lambda: EXP.bmt_exp_attn_bwd_dkv32(C.byref(a3), _p(kq), _st()))
+        t_kv = timed(lambda: EXP.bmt_exp_attn_bwd_dkv32(C.byref(a3), _p(kq), 0, _st()))
+        t_kv2 = timed(lambda: EXP.bmt_exp_attn_bwd_dkv32(C.byref(a4), _p(kq), 1, _st()))
         fl = 2.0 * B * H * Sq * Sk * dk
         print(f"      product backward (delta + dQ + dK/dV kernels) {t_all:7.1f} us; experimental dQ {t_new:7.1f} us ({3 * fl / t_new / 1e6:6.1f} TF/s), "
-              f"dK/dV {t_kv:7.1f} us ({4 * fl / t_kv / 1e6:6.1f} TF/s); the product's kernels one by one: rocprofv3 --kernel-trace of this script", flush=True)
+              f"dK/dV one pass {t_kv:7.1f} us ({4 * fl / t_kv / 1e6:6.1f} TF/s algorithmic), two passes {t_kv2:7.1f} us ({4 * fl / t_kv2 / 1e6:6.1f}); "
+              f"the product's kernels one by one: rocprofv3 --kernel-trace of this script", flush=True)
     return ok
 
 
