@@ -4,6 +4,7 @@
 library pins which one runs, whatever the shape -- bmt_amd/csrc/exp/attn_fwd32.hip).
 
     bash bmt_amd/csrc/exp/build.sh && python tools/probes/attn_fwd32_check.py [--no-time] > gpurun_out/attn_fwd32_check.txt
+    ... --variants | --probe | --probe2 | --probe3 [--ragged]: loop variants / the probe copy with parts switched off (profiles/r02_q_*, r02_s_*)
 
 The experiment entry takes the product's argument block, so the product's Python (ops.attn_fwd_bf16 / ops.attn_fwd_planes) drives both:
 ops.lib is wrapped by a proxy that routes bmt_attn_fwd_bf16 to the experiment entry."""
@@ -130,13 +131,16 @@ def planes_case(B, H, Sq, Sk, dk, g):
     return ok
 
 
+RAGGED = "--ragged" in sys.argv      # valid key lengths ~ U[Sk / 2, Sk] per batch element (the bench's synthetic batches) instead of full length
+
+
 def time_one(B, H, Sq, Sk, dk, exp, drop_p=0.1, iters=20):
     """us per launch of the training-path call (fp16 planes in, planes out)"""
     D = H * dk
     g = torch.Generator().manual_seed(1)
     mk = lambda S: ops.make_planes(torch.randn(B * S, D, generator=g).to(dev), "all")
     q, k, v = mk(Sq), mk(Sk), mk(Sk)
-    mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=dev)
+    mask = ragged_mask(B, Sk, g) if RAGGED else torch.ones(B, 1, Sk, dtype=torch.bool, device=dev)
     Proxy.use_exp = exp
     try:
         f = lambda: ops.attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, drop_p=drop_p, site=3, precision=ops.PREC_F16, out_fmt="f16")
