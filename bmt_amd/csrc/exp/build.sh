@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds the experiment library bmt_amd/lib/libbmt_exp.so (NOT loaded by the product; tools/probes/attn_fwd32_check.py opens it).
-# exp_lib.hip = attention_bf16.hip (included for its helpers and kernels) + the experiment drivers in one translation unit; runtime.o for
+# exp_lib.hip = attention_bf16.hip (included for its helpers and kernels) + the attention experiment drivers in one translation unit;
+# gemm_wide_km.hip = gemm_bf16.hip + the k-major 256 x 256 kernel in another; runtime.o for
 # bmt_set_error; -Bsymbolic keeps its duplicate C symbols to itself when libbmt_hip.so is loaded in the same process.
 set -e
 cd "$(dirname "$0")"
@@ -8,6 +9,8 @@ OUT=../../lib
 [ -f "$OUT/obj/runtime.o" ] || bash ../build.sh
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result"
 mkdir -p "$OUT/obj_exp"
-hipcc $FLAGS $BMT_EXP_FLAGS -c exp_lib.hip -o "$OUT/obj_exp/exp_lib.o"
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT/libbmt_exp.so" "$OUT/obj_exp/exp_lib.o" "$OUT/obj/runtime.o"
+hipcc $FLAGS $BMT_EXP_FLAGS -c exp_lib.hip -o "$OUT/obj_exp/exp_lib.o" &
+hipcc $FLAGS $BMT_EXP_FLAGS -c gemm_wide_km.hip -o "$OUT/obj_exp/gemm_wide_km.o" &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT/libbmt_exp.so" "$OUT/obj_exp/exp_lib.o" "$OUT/obj_exp/gemm_wide_km.o" "$OUT/obj/runtime.o"
 echo "built $OUT/libbmt_exp.so"

@@ -32,3 +32,23 @@ def test_backward_dq_lane_algebra_and_banks(dk):
     """the experimental dQ kernel (bmt_amd/csrc/exp/attn_bwd32.hip): a K image that serves row fragments AND transposing reads, V rows,
     S^T / dP^T / dQ^T against numpy"""
     assert _emulator("attn_bwd32_layout").check(dk)
+
+
+def test_kmajor_gemm_weight_fragments():
+    """the experimental k-major 256 x 256 GEMM (bmt_amd/csrc/exp/gemm_wide_km.hip): weight half-tile image, transposing fragment reads and
+    the MFMA operand order reproduce W^T . X^T, without bank conflicts"""
+    assert _emulator("gemm_wide_km_layout").check()
+
+
+def test_kmajor_gemm_source_is_what_the_generator_writes():
+    """exp/gemm_wide_km.hip is GENERATED from gemm_wide_kernel's text (tools/probes/make_wide_km.py): the committed file must be what the
+    generator produces from the committed product kernel (its patches assert their anchors, so a drifted product kernel fails here too)"""
+    import subprocess
+    import sys
+    path = os.path.join(ROOT, "bmt_amd", "csrc", "exp", "gemm_wide_km.hip")
+    before = open(path).read()
+    try:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "make_wide_km.py")], check=True, capture_output=True)
+        assert open(path).read() == before
+    finally:
+        open(path, "w").write(before)
