@@ -43,12 +43,5 @@ def test_kmajor_gemm_weight_fragments():
 def test_kmajor_gemm_source_is_what_the_generator_writes():
     """exp/gemm_wide_km.hip is GENERATED from gemm_wide_kernel's text (tools/probes/make_wide_km.py): the committed file must be what the
     generator produces from the committed product kernel (its patches assert their anchors, so a drifted product kernel fails here too)"""
-    import subprocess
-    import sys
-    path = os.path.join(ROOT, "bmt_amd", "csrc", "exp", "gemm_wide_km.hip")
-    before = open(path).read()
-    try:
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "make_wide_km.py")], check=True, capture_output=True)
-        assert open(path).read() == before
-    finally:
-        open(path, "w").write(before)
+    gen = _emulator("make_wide_km")
+    assert open(gen.OUT).read() == gen.generate()

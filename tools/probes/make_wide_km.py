@@ -129,6 +129,14 @@ extern "C" int bmt_exp_gemm_wide_km(const bmt_gemm_bf16_args* a, void* stream) {
     return launch_wide_km(p, (hipStream_t)stream);
 }
 '''
-out = os.path.join(ROOT, "bmt_amd", "csrc", "exp", "gemm_wide_km.hip")
-open(out, "w").write(HDR + k + TAIL)
-print("wrote", out)
+
+OUT = os.path.join(ROOT, "bmt_amd", "csrc", "exp", "gemm_wide_km.hip")
+
+
+def generate() -> str:
+    return HDR + k + TAIL
+
+
+if __name__ == "__main__":
+    open(OUT, "w").write(generate())
+    print("wrote", OUT)
