@@ -638,3 +638,25 @@ extern "C" int bmt_exp_attn_bwd_dkv32(const bmt_attn_bwd_bf16_args* a, const flo
     if (a->dk == 256) return two_pass ? launch_dkv32<256, true>(p, kq, st) : launch_dkv32<256, false>(p, kq, st);
     return two_pass ? launch_dkv32<128, true>(p, kq, st) : launch_dkv32<128, false>(p, kq, st);
 }
+
+// the whole attention backward on the experimental kernels, drop-in for bmt_attn_bwd_bf16 (same argument block): the product's delta
+// kernel (delta = (1 - p) rowsum(dO * O), and the bf16 plane of dO when dO arrives as fp32), then dQ (leaving the row scales in kq_ws,
+// fp32 [B][H][Sq]), then dK / dV.  ops.attn_bwd_planes routes here under BMT_ATTN_BWD32=1 (off by default).
+extern "C" int bmt_exp_attn_bwd_all(const bmt_attn_bwd_bf16_args* a, float* kq_ws, int two_pass, void* stream) {
+    BMT_CHECK_ARG(a && a->Qh && a->Kh && a->Vh && (a->O || a->Oh || a->Of) && a->lse && a->delta_ws && a->dOh_ws && kq_ws, "bmt_exp_attn_bwd_all: null pointer");
+    BMT_CHECK_ARG(a->qkv_f16 && (a->dk == 128 || a->dk == 256), "bmt_exp_attn_bwd_all: fp16 q / k / v planes, d_k 128 / 256");
+    BMT_CHECK_ARG(a->mask == nullptr || a->mask_qs == 0, "bmt_exp_attn_bwd_all: key-padding masks only");
+    AttnPB p;
+    memset(&p, 0, sizeof(p));
+    p.dOh = a->dOh_ws; p.O = a->O; p.Oph = a->Oh; p.Opl = a->Ol; p.Opf = a->Of; p.ldop = a->ldop; p.bsop = a->bsop;
+    p.dO = a->dO; p.delta = a->delta_ws;
+    p.ldo = a->ldo; p.bso = a->bso;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk; p.drop_p = a->drop_p;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)a->B * a->H * a->Sq;
+    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, a->dk, a->dOh_ws);
+    BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_all(delta)");
+    int rc = bmt_exp_attn_bwd_dq32(a, kq_ws, stream);
+    if (rc != BMT_OK) return rc;
+    return bmt_exp_attn_bwd_dkv32(a, kq_ws, two_pass, stream);
+}

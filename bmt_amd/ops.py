@@ -958,6 +958,27 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D, fh=of), lse
 
 
+# EXPERIMENT switch, off by default (BMT_ATTN_BWD32=1 / =2: the attention backward of fp16-plane problems through the kernels of
+# bmt_amd/csrc/exp/attn_bwd32.hip in libbmt_exp.so -- one-pass / two-pass dK/dV; built by bmt_amd/csrc/exp/build.sh).  With the switch off
+# nothing below is touched and the experiment library is never opened.
+ATTN_BWD32 = int(_os.environ.get("BMT_ATTN_BWD32", "0") or 0)
+_exp_lib = [None]
+
+
+def _attn_bwd32(a, B, H, Sq, dev):
+    if _exp_lib[0] is None:
+        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lib", "libbmt_exp.so")
+        e = C.CDLL(path)
+        e.bmt_exp_attn_bwd_all.restype = C.c_int
+        e.bmt_exp_attn_bwd_all.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_int, C.c_void_p]
+        e.bmt_last_error.restype = C.c_char_p
+        _exp_lib[0] = e
+    kq = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
+    rc = _exp_lib[0].bmt_exp_attn_bwd_all(C.byref(a), _p(kq), int(ATTN_BWD32 == 2), _st())
+    if rc != 0:
+        raise RuntimeError(f"bmt_exp_attn_bwd_all rc={rc}: {_exp_lib[0].bmt_last_error().decode()}")
+
+
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
                     fuse: Optional[str] = None):
     """attention backward (single-pass bf16 on the hi planes) with the gradients written as GEMM operands: for each of dq, dk,
@@ -1004,7 +1025,10 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16))
-    _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
+    if ATTN_BWD32 and f16 and dk in (128, 256) and mqs == 0 and Sq <= 3072 and Sk <= 8192:
+        _attn_bwd32(a, B, H, Sq, dev)
+    else:
+        _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
     for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
         if b is not None and db is None:
