@@ -94,6 +94,8 @@ HDR = '''// EXPERIMENT (exp/build.sh -> libbmt_exp.so; NOT yet run on a GPU: wri
 //   * W fragments (MFMA A operand: 32 output columns x 16 reduction rows) through ds_read_b64_tr_b16, reduction index in natural order,
 //     as inline asm under the phase's own lgkmcnt(0);
 //   * one plane, bf16 (the backward's operand format).
+// Not there yet: column sums in the epilogue (the dX launches that also produce a bias gradient, FFN-2's among them) and a way to fill the
+// chip with 8192 x 1024 outputs (128 tiles): see DESIGN.md section 7 item 3.
 #ifndef BMT_EXP_LIB
 #include "../gemm_bf16.hip"
 #endif
