@@ -160,6 +160,7 @@ def load():
 
 
 ENOENT = -3     # BMT_ENOENT: a feature file cannot be opened
+EALIGN = -4     # BMT_EALIGN: pointer / stride alignment requirement violated
 
 
 def check(rc: int, what: str):

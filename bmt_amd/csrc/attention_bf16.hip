@@ -160,6 +160,11 @@ struct AttnPB {
     uint32_t site;
     const float* kmean;                    // backward, optional: fp32 [B][H * d_k] mean key over the valid keys (bmt_attn_kmean)
     int qkv_f16;                           // backward, 16-wide kernels: Qh / Kh / Vh hold fp16 (the forward's planes); converted to bf16 on load
+    // backward, split form (attn_bwd_dq32e_kernel -> attn_bwd_dkvg_kernel): the dQ kernel leaves P and dS (bf16, [B*H][Sq][ws_pitch]) and a
+    // bf16 copy of q ([B][Sq][H * d_k]: ldqb / bsqb) in workspaces, dK / dV are two plain products over them
+    uint16_t *Pws, *dSws, *Qbws;
+    int64_t ws_pitch, ws_tile, ws_slab, ldqb, bsqb;     // (batch, head) slab bh at bh * ws_slab; in it element (q, key) of a (batch, head) slab at (key / 128) * ws_tile + q * ws_pitch + key % 128
+    int xp;                                    // experiments only: parts of a loop switched off (timing probes)
 };
 
 // 8 fp16 -> 8 bf16 (round to nearest even) in one 16-byte register slot: q / k / v exist as fp16 planes only under the fp16 attention

@@ -5,19 +5,23 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" "$OUT/obj"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result"
+SRCS="runtime gemm_bf16 attention attention_bf16 norm elementwise loss optim proposal postprocess ingest"
 pids=()
-for f in runtime gemm_bf16 attention attention_bf16 norm elementwise loss optim proposal postprocess ingest; do
+for f in $SRCS; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$f.hip" -nt "$OUT/obj/$f.o" ] || [ common.h -nt "$OUT/obj/$f.o" ] || [ ../../include/bmt_hip.h -nt "$OUT/obj/$f.o" ]; then
     hipcc $FLAGS -c "$f.hip" -o "$OUT/obj/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbmt_hip.so" "$OUT"/obj/*.o
+# (an explicit object list: a stale object of a source that no longer exists -- obj/gemm.o once -- must not be linked)
+OBJS=""; for f in $SRCS; do OBJS="$OBJS $OUT/obj/$f.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbmt_hip.so" $OBJS
 if [ -n "$BMT_ALT_FLAGS" ]; then   # A/B experiment build: same sources, extra -D flags, separate .so (BMT_LIB_PATH selects it)
   mkdir -p "$OUT/obj_alt"
-  for f in runtime gemm_bf16 attention attention_bf16 norm elementwise loss optim proposal postprocess ingest; do hipcc $FLAGS $BMT_ALT_FLAGS -c "$f.hip" -o "$OUT/obj_alt/$f.o" & done; wait
-  hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbmt_hip_alt.so" "$OUT"/obj_alt/*.o
+  for f in $SRCS; do hipcc $FLAGS $BMT_ALT_FLAGS -c "$f.hip" -o "$OUT/obj_alt/$f.o" & done; wait
+  OBJS=""; for f in $SRCS; do OBJS="$OBJS $OUT/obj_alt/$f.o"; done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbmt_hip_alt.so" $OBJS
   echo "built $OUT/libbmt_hip_alt.so ($BMT_ALT_FLAGS)"
 fi
 echo "built $OUT/libbmt_hip.so"

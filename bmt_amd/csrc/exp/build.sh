@@ -12,7 +12,7 @@ mkdir -p "$OUT/obj_exp"
 # (recompiled only when a source is newer than its object: the product files they include count as sources)
 newer() { local o=$1; shift; [ ! -f "$o" ] && return 0; for s in "$@"; do [ "$s" -nt "$o" ] && return 0; done; return 1; }
 pids=()
-if newer "$OUT/obj_exp/exp_lib.o" exp_lib.hip attn_fwd32.hip attn_bwd32.hip ../attention_bf16.hip ../common.h ../../../include/bmt_hip.h; then
+if newer "$OUT/obj_exp/exp_lib.o" exp_lib.hip attn_fwd32.hip attn_bwd32.hip attn_bwd_split.hip ../attention_bf16.hip ../common.h ../../../include/bmt_hip.h; then
   hipcc $FLAGS $BMT_EXP_FLAGS -c exp_lib.hip -o "$OUT/obj_exp/exp_lib.o" & pids+=($!)
 fi
 if newer "$OUT/obj_exp/gemm_wide_km.o" gemm_wide_km.hip ../gemm_bf16.hip ../common.h ../../../include/bmt_hip.h; then

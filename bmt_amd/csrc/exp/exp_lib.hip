@@ -2,3 +2,4 @@
 #define BMT_EXP_LIB 1
 #include "attn_fwd32.hip"
 #include "attn_bwd32.hip"
+#include "attn_bwd_split.hip"

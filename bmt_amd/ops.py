@@ -175,9 +175,17 @@ def rng_tensor(device=None) -> torch.Tensor:
     return _rng_state[key]
 
 
+_rng_seeded = set()       # devices whose dropout stream was seeded explicitly (manual_seed)
+
+
 def manual_seed(seed: int, device=None):
     t = rng_tensor(device)
     t.copy_(torch.tensor([seed, 0], dtype=torch.int64))
+    _rng_seeded.add(str(t.device))
+
+
+def rng_is_seeded(device=None) -> bool:
+    return str(rng_tensor(device).device) in _rng_seeded
 
 
 def rng_advance():
@@ -289,6 +297,8 @@ class _WeightPlanes:
         self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W, transposed bf16 plane [K][ldT] or None]
         self.index = {}            # (id(owner), key) -> position
         self.table = None          # device descriptor table
+        self._retired = []         # tables a captured hipGraph may still read (its refresh launch has the address baked in): never freed
+        self.generation = 0        # bumped when an entry a captured graph may use is replaced or dropped (its planes can be freed then)
         self.fresh_epoch = -1
         self.dirty_table = True
         self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt, transposed plane [K][sum N] or None]
@@ -307,6 +317,7 @@ class _WeightPlanes:
             if self.entries[pos][2].any._base is None and pl.any._base is None:
                 entry[6] = self.entries[pos][6]    # a wider plane set of the same stand-alone weight keeps its transposed plane
             self.entries[pos] = entry          # re-registered (a new plane set, or now as a member of a group): same slot
+            self.generation += 1               # the old planes may be freed: graphs captured over them must not be replayed
         else:
             self.entries.append(entry)
             self.index[(id(owner), self._key(W))] = len(self.entries) - 1
@@ -363,6 +374,7 @@ class _WeightPlanes:
             self.entries = alive
             self.index = {(id(e[0]()), e[1]): i for i, e in enumerate(alive)}
             self.dirty_table = True
+            self.generation += 1               # a retired table still describes the dead weights' (freed) planes
 
     def _refresh_all(self):
         self._prune()
@@ -377,6 +389,8 @@ class _WeightPlanes:
                                                _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0),
                                                _p(e[6]), None, e[6].stride(0) if e[6] is not None else 0),
                            "bmt_planes_desc")
+            if self.table is not None:
+                self._retired.append(self.table)       # (a few KB each; appended entries leave the old table valid for its graph)
             self.table = host.to(self.entries[0][5].device)
             self.dirty_table = False
         _lib.check(lib.bmt_planes_multi(_p(self.table), len(self.entries), _st()), "bmt_planes_multi")
@@ -448,6 +462,13 @@ def _merge_fmt(a: str, b: str) -> str:
 
 _FMT["all"] = ("hi", "lo", "fh", "fl")
 _weights = _WeightPlanes()
+
+
+def weights_generation() -> int:
+    """changes when a registered weight's planes were replaced or a dead model's entries were dropped: a hipGraph captured before
+    that has freed plane buffers (or a descriptor table that names them) baked in and must be re-captured, not replayed.  Newly
+    REGISTERED weights do not count: the table a graph was captured with is kept alive and stays valid for the weights it names."""
+    return _weights.generation
 
 
 def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:

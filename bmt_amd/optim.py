@@ -35,6 +35,8 @@ class _PtrTable:
         host = torch.tensor(key, dtype=torch.int64)
         if self.ptrs is not None:
             self._retired.append((self.ptrs, self.sizes))
+            if len(self._retired) > 256:      # gradients re-allocated every step (no static buffers, hence no captured graph): bounded
+                del self._retired[:128]
         self.ptrs = host.to(self.device)
         sizes = [t.numel() for t in columns[0]]
         self.sizes = torch.tensor(sizes, dtype=torch.int64).to(self.device)
@@ -111,8 +113,9 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
-_clip_tables = {}      # (device, gradient pointers) -> (table, sq, coef): one per parameter set, kept for the life of the process
-                       # (a captured optimizer graph has the table's address baked in; see _PtrTable._retired)
+_clip_tables = {}      # (device, parameter set) -> (table, sq, coef): one per parameter SET, kept for the life of the process (a captured
+                       # optimizer graph has the table's address baked in; _PtrTable.update re-uploads when a gradient pointer moves and
+                       # retires the old table, so re-allocated gradients -- zero_grad() sets them to None -- do not add entries)
 
 
 @torch.no_grad()
@@ -123,7 +126,7 @@ def clip_grad_norm_(parameters: Iterable[torch.nn.Parameter], max_norm: float) -
     if not ps:
         return torch.zeros(())
     dev = ps[0].device
-    key = (str(dev), tuple(p.grad.data_ptr() for p in ps))
+    key = (str(dev), tuple(id(p) for p in ps))
     if key not in _clip_tables:
         _clip_tables[key] = (_PtrTable(dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev))
     tab, sq, coef = _clip_tables[key]

@@ -28,7 +28,7 @@ def _ops_weights_changed():
     _ops.weights_changed()
 
 
-def _seed_dropout(seed: Optional[int], data_parallel: bool, device):
+def _seed_dropout(seed: Optional[int], data_parallel: bool, device, keep_if_seeded: bool = False):
     """dropout masks come from the library RNG in device memory (ops.rng_tensor), not from torch's: under data parallelism every
     rank must draw DIFFERENT masks (as nn.DataParallel's replicas do), so the per-rank seed is base + rank.  seed=None keeps
     the current state on a single process and derives base 0x5EED under data parallelism."""
@@ -39,6 +39,8 @@ def _seed_dropout(seed: Optional[int], data_parallel: bool, device):
         return
     if not torch.device(device).type == "cuda":
         return
+    if keep_if_seeded and seed is None and _ops.rng_is_seeded(device):
+        return      # a step built earlier in this process (MixedTrainStep's captioning step) seeded the shared stream: keep it and its counter
     _ops.manual_seed((0x5EED if seed is None else seed) + rank, device)
 
 
@@ -79,6 +81,8 @@ class CaptioningTrainStep:
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
                  static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None):
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
+        self._overlap = overlap
+        self._graph_generation = None
         _seed_dropout(seed, data_parallel, next(model.parameters()).device)
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
@@ -218,13 +222,15 @@ class CaptioningTrainStep:
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             self._optimize()
         self._graphs = (g1, g2)
+        from . import ops as _ops
+        self._graph_generation = _ops.weights_generation()
         return self._graphs
 
     def uncapture(self):
         """back to eager launches (bucket all-reduces overlapped with the backward pass again)"""
         self._graphs = None
         if self.reducer is not None:
-            self.reducer.overlap = True
+            self.reducer.overlap = self._overlap
 
     def replay(self, feature_stacks=None, caption_idx=None):
         if feature_stacks is not None:
@@ -232,6 +238,10 @@ class CaptioningTrainStep:
                 self._static_fs[k].copy_(v, non_blocking=True)
             self._static_caps.copy_(caption_idx, non_blocking=True)
         g1, g2 = self._graphs
+        from . import ops as _ops
+        if _ops.weights_generation() != self._graph_generation:
+            raise RuntimeError("the weight-plane registry changed after capture() (a weight's operand planes were re-allocated, or a model was "
+                               "garbage-collected): the captured graphs name freed buffers -- call capture() again")
         g1.replay()
         ev = self._reduce_events
         if ev is not None:
@@ -291,10 +301,10 @@ class ProposalTrainStep:
     differs per step, so this step is launched eagerly (no graph capture)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 overlap: bool = True, seed: Optional[int] = None):
+                 overlap: bool = True, seed: Optional[int] = None, keep_seed: bool = False):
         import torch.distributed as dist
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
-        _seed_dropout(seed, data_parallel, next(model.parameters()).device)
+        _seed_dropout(seed, data_parallel, next(model.parameters()).device, keep_if_seeded=keep_seed)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.optimizer = optimizer or FusedAdam(self.params, lr=cfg.lr, betas=tuple(getattr(cfg, "betas", (0.9, 0.999))),
                                                 eps=getattr(cfg, "eps", 1e-8), weight_decay=getattr(cfg, "weight_decay", 0.0))
@@ -346,7 +356,9 @@ class MixedTrainStep:
         for p in cap_model.encoder.parameters():      # frozen while the proposal step's parameter list is built
             p.requires_grad = False
         try:
-            self.prop = ProposalTrainStep(prop_model, cfg_prop, pad_idx, data_parallel=data_parallel, bucket_bytes=bucket_bytes)
+            # (the captioning step above seeded the dropout stream both steps draw from: the proposal step must not re-seed it)
+            self.prop = ProposalTrainStep(prop_model, cfg_prop, pad_idx, data_parallel=data_parallel, bucket_bytes=bucket_bytes,
+                                          keep_seed=True)
         finally:
             for p, f in self._enc_flags:
                 p.requires_grad = f

@@ -32,7 +32,7 @@ extern "C" {
 #define BMT_EINVAL (-1)   /* bad argument / unsupported shape */
 #define BMT_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
-#define BMT_EALIGN (-3)   /* pointer or stride alignment requirement violated */
+#define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
 #define BMT_ABI_VERSION 3
 

@@ -53,3 +53,13 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libbmt_hip.so")
     with pytest.raises(ImportError, match="no CPU / eager fallback"):
         _lib.load()
+
+
+def test_error_codes_are_distinct():
+    """a caller must be able to tell the BMT_E* codes apart (BMT_ENOENT and BMT_EALIGN once shared -3)."""
+    from bmt_amd import _lib
+    text = open(os.path.join(ROOT, "include", "bmt_hip.h")).read()
+    codes = dict(re.findall(r"#define (BMT_E[A-Z]+) \((-\d+)\)", text))
+    assert {"BMT_EINVAL", "BMT_EHIP", "BMT_ENOENT", "BMT_EALIGN"} <= set(codes)
+    assert len(set(codes.values())) == len(codes), codes
+    assert _lib.ENOENT == int(codes["BMT_ENOENT"]) and _lib.EALIGN == int(codes["BMT_EALIGN"])
