@@ -68,7 +68,8 @@ class AttnBwdBf16Args(C.Structure):
                 ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64),
                 ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
-                ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32)]
+                ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32),
+                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp)]
 
 
 class SelectProposalsArgs(C.Structure):
@@ -108,6 +109,7 @@ SIGNATURES = {
     "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "bmt_attn_fwd_bf16": (i32, [C.POINTER(AttnFwdBf16Args), vp]),
     "bmt_attn_bwd_bf16": (i32, [C.POINTER(AttnBwdBf16Args), vp]),
+    "bmt_attn_bwd_split_ws": (i32, [i32, i32, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "bmt_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
     "bmt_layernorm_bwd_blocks": (i32, [i32]),
     "bmt_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, i32, vp]),
@@ -153,8 +155,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 3:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 3")
+    if lib.bmt_version() != 4:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 4")
     _lib = lib
     return lib
 

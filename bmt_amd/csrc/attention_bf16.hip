@@ -138,6 +138,8 @@ struct GradOut {
     uint16_t* hi; int64_t h_ld, h_bs;      // bf16 plane, row b*S+s at hi + b*h_bs + s*h_ld   (dX operand of the projection)
     uint16_t* hiT; int64_t t_ld;           // transposed bf16 plane [D][t_ld], column b*S+s      (dW operand)
     float* bsum;                           // fp32 [D] += sum over (b,s)                          (bias gradient)
+    float* bpart;                          // split backward: the tile's column sums go to bpart[(b * tiles + tile) * bp_ld + h * d_k + d] instead
+    int64_t bp_ld;                         // (plain stores; attn_bias_finish_kernel adds the rows up into bsum: no contended atomics)
 };
 
 struct AttnPB {
@@ -2326,6 +2328,706 @@ int launch_fwd(const AttnPB& p, hipStream_t st, int fwd32 = -1) {
     return BMT_OK;
 }
 
+
+// =================================================================================== backward, split form (d_k >= 128, fp16 q / k / v planes)
+// The two-kernel backward above computes S = Q K^T and dP = dO V^T in BOTH kernels: 7 products of Sq x Sk x d_k for the 5 the mathematics
+// has.  Here the dQ kernel, which has P and dS in registers anyway, LEAVES them in HBM workspaces (bf16, one 128-key block of Sq rows
+// after the other per (batch, head): [B*H][ceil(Sk / 128)][Sq][128]) together with a bf16 copy of its q rows (scaled by the per-query
+// power of two the dS operand carries), and dK / dV are two plain products over them with no softmax arithmetic at all:
+//     dV^T[d][key] += dO^T[d x q] . P[q x key]          dK^T[d][key] += Qb^T[d x q] . dS'[q x key]
+// Measured on configs[1]'s audio self-attention (B 32, H 4, 800 x 800, d_k 256, ragged lengths; tools/probes/attn_bwd_split_check.py,
+// profiles/r03_*_split_*): 504 -> 347 us for the whole backward (video <- audio 217 -> 147, audio <- video 220 -> 200, video self 80 -> 65),
+// dQ 2.4e-3 instead of 4.7e-3 relative error (fp16 operands with per-query scales), dK / dV 3.3e-3 / 2.9e-3 instead of 4.7e-3 / 4.0e-3.
+// What bounds it now (probes + PMC in DESIGN.md): a workgroup's fixed costs -- 196 KB of q / dO / O rows in, 64 KB of Qb out before the
+// first MFMA, 64 KB per gradient tile out after the last -- move at one CU's ~10 B / clk, and the 512-register kernels cannot share a CU.
+__device__ __forceinline__ int kswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ float bfbits_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfbits_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+#define BMT_B_BAR()                              \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_b64(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ void st128(__amdgpu_buffer_rsrc_t rs, uint32_t a, uint32_t b, uint32_t c, uint32_t d, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a, b, c, d}, rs, voff + OFF, soff, 0);
+}
+
+
+// ---- gradient tile epilogue, row-major through LDS.  The tile's accumulators are G^T[d][token] with the token on the lane: written straight
+// to the plane a lane stores 8 bytes per (d-tile, register quad) at a 2-KB row stride -- 32 partial-line requests per instruction, 64
+// instructions per wave; measured on attn_bwd_dkvg_kernel (profiles/r03_h_split_probes.txt): 73 of the kernel's 154 us.  Here every wave
+// writes its registers into an image [128 tokens][d_k + 8] (ds_write_b64), the workgroup stores the image as whole 512-byte rows (16 bytes per
+// lane, consecutive lanes along d) and takes the bias column sums from the same image.
+template <int DK, int NTL>
+__device__ __forceinline__ void grad_rm_write(uint16_t* img, const f32x16 (&acc)[NTL], int trow, bool ok, int hh, int dt0) {
+    constexpr int PITCH = DK + 8;
+    uint16_t* row = img + trow * PITCH + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < NTL; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 v;
+            v[0] = ok ? pack_bf2(acc[dt][4 * i + 0], acc[dt][4 * i + 1]) : 0u;
+            v[1] = ok ? pack_bf2(acc[dt][4 * i + 2], acc[dt][4 * i + 3]) : 0u;
+            *reinterpret_cast<u32x2*>(row + (dt0 + dt) * 32 + 8 * i) = v;
+        }
+}
+// (called by all NT threads after a barrier; `red` = NT * 2 floats of LDS scratch behind the image)
+template <int DK, int NT>
+__device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, const GradOut& g, int b, int h, int tok0, int S, int tid) {
+    constexpr int PITCH = DK + 8, CPRW = DK / 8;
+    if (g.hi) {
+        uint16_t* base = g.hi + (int64_t)b * g.h_bs + (int64_t)tok0 * g.h_ld + h * DK;
+#pragma unroll 4
+        for (int c = tid; c < 128 * CPRW; c += NT) {
+            const int row = c / CPRW, col = c % CPRW;
+            if (tok0 + row < S)
+                *reinterpret_cast<u32x4*>(base + (int64_t)row * g.h_ld + col * 8) = *reinterpret_cast<const u32x4*>(img + row * PITCH + col * 8);
+        }
+    }
+    if (g.f32) {
+        float* base = g.f32 + (int64_t)b * g.f_bs + (int64_t)tok0 * g.f_ld + h * DK;
+        for (int c = tid; c < 128 * (DK / 4); c += NT) {
+            const int row = c / (DK / 4), col = c % (DK / 4);
+            if (tok0 + row < S) {
+                const u32x2 v = *reinterpret_cast<const u32x2*>(img + row * PITCH + col * 4);
+                *reinterpret_cast<float4*>(base + (int64_t)row * g.f_ld + col * 4) =
+                    make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
+            }
+        }
+    }
+    if (g.bsum) {
+        constexpr int NCW = DK / 2, NRB = NT / NCW;          // dword columns (two d values), row blocks
+        const int cw = tid % NCW, rb = tid / NCW;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int row = rb; row < 128; row += NRB) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + row * PITCH + 2 * cw);
+            s0 += __uint_as_float(v << 16);
+            s1 += __uint_as_float(v & 0xffff0000u);
+        }
+        red[2 * tid] = s0;
+        red[2 * tid + 1] = s1;
+        __syncthreads();
+        if (tid < NCW) {
+#pragma unroll
+            for (int r = 1; r < NRB; ++r) { s0 += red[2 * (tid + r * NCW)]; s1 += red[2 * (tid + r * NCW) + 1]; }
+            if (g.bpart) {      // one row of partial sums per tile: ~900 workgroups adding into the same 1024 floats took 30 us of atomics
+                *reinterpret_cast<float2*>(g.bpart + ((int64_t)b * ((S + 127) / 128) + tok0 / 128) * g.bp_ld + h * DK + 2 * cw) = make_float2(s0, s1);
+            } else {
+                atomicAdd(g.bsum + h * DK + 2 * cw, s0);
+                atomicAdd(g.bsum + h * DK + 2 * cw + 1, s1);
+            }
+        }
+    }
+}
+// the whole epilogue of one gradient tile (NT threads; the transposed plane, if anybody asks for it, still goes through the old image)
+template <int DK, int NTL, int NT>
+__device__ __forceinline__ void grad_rm_epilogue(char* smem, const GradOut& g, const f32x16 (&acc)[NTL], int b, int h, int tok0, int trow, bool ok,
+                                                 int hh, int dt0, int S, int tid) {
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+    float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
+    grad_rm_write<DK, NTL>(img, acc, trow, ok, hh, dt0);
+    __syncthreads();
+    grad_rm_flush<DK, NT>(img, red, g, b, h, tok0, S, tid);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------------ the dQ kernel, software-pipelined
+// One wave per SIMD issues in order: a stage that runs {S MFMAs} {softmax VALU} {dP MFMAs} {dS VALU} {dQ MFMAs} leaves the matrix pipe idle
+// during every VALU block (attn_bwd_dq32e_kernel: 590 instructions per 48 MFMAs, 38 % of the pipe).  Here the VALU work of a tile runs under
+// the MFMAs of its neighbours -- iteration t:
+//     phase A: S(t+1) = K . Q^T            under  dS'(t) = P(t) (dP'(t) - delta') scale  [+ the stores of P(t)]
+//     phase B: dQ'^T += K(t)^T . dS'(t)^T   under  P(t+1) = exp2(S(t+1) scale log2 e - lse)
+//     phase C: dP'(t+1) = V . dO'^T         under  the stores of dS(t), address stepping
+// and the per-element cost is cut: fragment addresses of the two swizzled images are lane constants per (k-step & 7) / (d-tile & 3, row
+// block) -- bit 8 of the address is free, so k-step >> 3 and d-tile >> 2 are immediates -- stepped by one add per stage instead of one
+// v_xor per read; V uses the K image's dual-purpose swizzle (vA = kA + TILE); the key mask is applied to the packed fp16 dS' by ANDing with a
+// 16-bit-per-key mask image in LDS (8 v_and per stage instead of 16 selects + their compares: P of a masked key may be anything, its dS'
+// is zeroed bit-wise, its P / dS columns in the workspace belong to keys whose gradients attn_bwd_dkvg_kernel zeroes); fully masked tiles at
+// the END of the key range (prefix masks) shorten the loop for the whole workgroup (ntile_run), a fully masked tile in the middle is simply
+// computed -- no wave-level skip paths (they cost hipcc 7.2 its register allocation, see attn_bwd_dkvg_kernel); the emitted dS keeps the
+// per-query scale (bf16 has the range) and the bf16 copy of q carries 2^-k(q) instead: dK = sum_q (q 2^-k) . (dS 2^k) needs no extra multiply;
+// delta = (1 - p) rowsum(dO * O) is computed in the prologue from the saved output plane (fuse_delta), nobody else needs it.
+// XP (timing probes): bit 3 = no epilogue stores, bit 4 = no loop
+template <int DK, int XP = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32p_kernel(const AttnPB p) {
+    constexpr int BC = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BC * ROWB, STAGE = 2 * TILE, NS = 4;
+    constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BC / RPP, PPW = NP / 4;
+    static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    uint16_t* sMask = reinterpret_cast<uint16_t*>(smem + NS * STAGE);    // [ntile * 32] 0xffff = valid key, 0 = masked / past Sk
+    int* sLast = reinterpret_cast<int*>(smem + NS * STAGE + (((p.Sk + BC - 1) / BC) * BC * 2 + 15) / 16 * 16);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int nqt = (p.Sq + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int qt = w % nqt, bh = w / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q = qt * 128 + wid * 32 + l31;
+    const bool qok = q < p.Sq;
+    const int ntile = (p.Sk + BC - 1) / BC;
+
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    const int64_t slab = (int64_t)bh * p.ws_slab;
+    const int slab_bytes = (int)((int64_t)p.Sq * p.ws_pitch * 2);
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Pws + slab), 0, slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dSws + slab), 0, slab_bytes, 0x00020000);
+    const int ws_tile2 = (int)p.ws_tile * 2;
+    const int wvo = qok ? (int)(((int64_t)q * p.ws_pitch + 8 * hh) * 2) : 0x7fffff00;
+    int kvo[4], vvo[4];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = (wid * PPW + j) * RPP + lane / CPR, cpos = lane % CPR;
+        kvo[j] = row * (int)p.ldk * 2 + ((cpos ^ kswz(row)) * 16);
+        vvo[j] = row * (int)p.ldv * 2 + ((cpos ^ kswz(row)) * 16);
+    }
+    const int sstep_k = BC * (int)p.ldk * 2, sstep_v = BC * (int)p.ldv * 2;
+#define BMT_P_DMA_K(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(smem + (slot_) * STAGE + (wid * PPW + (j_)) * 1024), 16, kvo[j_], (t_) * sstep_k, 0, 0)
+#define BMT_P_DMA_V(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(smem + (slot_) * STAGE + TILE + (wid * PPW + (j_)) * 1024), 16, vvo[j_], (t_) * sstep_v, 0, 0)
+
+    // ---- prologue: tiles 0, 1, 2 in flight; mask image; q, dO (-> scale, delta), lse
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        const int tl = min(s, ntile - 1);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) BMT_P_DMA_K(j, tl, s);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) BMT_P_DMA_V(j, tl, s);
+    }
+    if (tid == 0) sLast[0] = -1;
+    __syncthreads();
+    {
+        int last = -1;
+        for (int i0 = tid; i0 < ntile * BC; i0 += 4 * NT) {      // four independent (clamped, unconditional) loads per round trip
+            uint8_t mb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mb[j] = (p.mask != nullptr) ? p.mask[(int64_t)b * p.mask_bs + min(i0 + j * NT, p.Sk - 1)] : (uint8_t)1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * NT;
+                const bool m = i < p.Sk && mb[j] != 0;
+                if (i < ntile * BC) sMask[i] = m ? (uint16_t)0xffffu : (uint16_t)0;
+                if (m) last = i;
+            }
+        }
+        last = (int)wave_max((float)last);
+        if (lane == 0 && last >= 0) atomicMax(sLast, last);
+    }
+    bf16x8 qf[KS];
+    u32x4 dob[KS];
+    float dsum = 0.f;
+    {
+        // UNCONDITIONAL loads from a clamped row: a guarded load into a register array makes hipcc 7.2 branch around every load and wait
+        // vmcnt(0) behind it -- 48 serialized memory round trips, 66 of this kernel's 217 us (profiles/r03_j_split_probes.txt).  Rows past
+        // Sq carry the last row's values: nothing of theirs is stored.
+        const int qc = min(q, p.Sq - 1);
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)qc * p.ldq + h * DK + 8 * hh;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)qc * p.ldo + h * DK + 8 * hh;
+        const int64_t po = (int64_t)b * p.bsop + (int64_t)qc * p.ldop + h * DK + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = as_bf16x8(*reinterpret_cast<const u32x4*>(p.Qh + qo + 16 * ks));
+            dob[ks] = *reinterpret_cast<const u32x4*>(p.dOh + oo + 16 * ks);
+        }
+        if (p.fuse_delta) {      // (uniform branches OUTSIDE the load loops: every path is one batch of 16 loads)
+            u32x4 of[KS];
+            if (p.Opf) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) of[ks] = *reinterpret_cast<const u32x4*>(p.Opf + po + 16 * ks);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        dsum += bfbits_lo(dob[ks][j]) * h_bits2f(of[ks][j] & 0xffffu) + bfbits_hi(dob[ks][j]) * h_bits2f(of[ks][j] >> 16);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) of[ks] = *reinterpret_cast<const u32x4*>(p.Oph + po + 16 * ks);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dsum += bfbits_lo(dob[ks][j]) * bfbits_lo(of[ks][j]) + bfbits_hi(dob[ks][j]) * bfbits_hi(of[ks][j]);
+                if (p.Opl) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) of[ks] = *reinterpret_cast<const u32x4*>(p.Opl + po + 16 * ks);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dsum += bfbits_lo(dob[ks][j]) * bfbits_lo(of[ks][j]) + bfbits_hi(dob[ks][j]) * bfbits_hi(of[ks][j]);
+                }
+            }
+        }
+    }
+    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + min(q, p.Sq - 1);
+    const float lse2 = p.lse[stat] * LOG2E;
+    const float delta = p.fuse_delta ? half_sum(dsum) * (1.f - p.drop_p) : p.delta[stat];
+    float amax = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bfbits_lo(dob[ks][j])), fabsf(bfbits_hi(dob[ks][j]))));
+    amax = half_max(amax);
+    int kexp = 0;
+    if (amax > 0.f) kexp = 6 - ((int)((__float_as_uint(amax) >> 23) & 0xffu) - 127);
+    kexp = max(-60, min(60, kexp));
+    const float up = __uint_as_float((uint32_t)(127 + kexp) << 23), down = __uint_as_float((uint32_t)(127 - kexp) << 23);
+    bf16x8 dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const uint32_t w0 = pack_h2(bfbits_lo(dob[ks][0]) * up, bfbits_hi(dob[ks][0]) * up);
+        const uint32_t w1 = pack_h2(bfbits_lo(dob[ks][1]) * up, bfbits_hi(dob[ks][1]) * up);
+        const uint32_t w2 = pack_h2(bfbits_lo(dob[ks][2]) * up, bfbits_hi(dob[ks][2]) * up);
+        const uint32_t w3 = pack_h2(bfbits_lo(dob[ks][3]) * up, bfbits_hi(dob[ks][3]) * up);
+        dof[ks] = as_bf16x8(u32x4{w0, w1, w2, w3});
+    }
+    if (qok) {        // Qb = bf16(q 2^-k(q)): the A operand of dK^T = Qb^T . dS' in attn_bwd_dkvg_kernel (dS' keeps the 2^k)
+        uint16_t* qb = p.Qbws + (int64_t)b * p.bsqb + (int64_t)q * p.ldqb + h * DK + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 qv = __builtin_bit_cast(u32x4, qf[ks]);
+            const uint32_t w0 = pack_bf2(h_bits2f(qv[0] & 0xffffu) * down, h_bits2f(qv[0] >> 16) * down);
+            const uint32_t w1 = pack_bf2(h_bits2f(qv[1] & 0xffffu) * down, h_bits2f(qv[1] >> 16) * down);
+            const uint32_t w2 = pack_bf2(h_bits2f(qv[2] & 0xffffu) * down, h_bits2f(qv[2] >> 16) * down);
+            const uint32_t w3 = pack_bf2(h_bits2f(qv[3] & 0xffffu) * down, h_bits2f(qv[3] >> 16) * down);
+            *reinterpret_cast<u32x4*>(qb + 16 * ks) = u32x4{w0, w1, w2, w3};
+        }
+    }
+    const float dsc = -delta * up * p.scale;      // dS' = P ((dP' - delta') scale)
+    const float sc2 = p.scale * LOG2E;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    float rs = 0.f;
+    const h2_t ones = {(_Float16)1.f, (_Float16)1.f};
+
+    // fragment addresses (LDS bytes) as lane constants
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const int fk = kswz(l31);
+    const uint32_t kA0 = lds0 + l31 * ROWB + 32 * (fk >> 1) + 16 * (hh ^ (fk & 1));
+    const int m16 = lane & 15, gi = (lane >> 4) & 1, mq = m16 >> 2, mr = m16 & 3;
+    const uint32_t kT0 = lds0 + (4 * hh + mq) * ROWB + 64 * mq + 32 * gi + 16 * ((mr >> 1) ^ hh) + 8 * (mr & 1);
+    uint32_t kax[8], ktx[4][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kax[j] = kA0 ^ (j << 5);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ktx[j][0] = kT0 ^ (j << 6);
+        ktx[j][1] = kT0 ^ ((j << 6) | 32);
+    }
+    const uint32_t mA = lds0 + NS * STAGE + 8 * hh;          // mask image: keys 8 i + 4 hh .. + 3 of a tile = 8 bytes at key0 * 2 + 16 i + 8 hh
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ntile_run = (XP & 16) ? 0 : sLast[0] / BC + 1;                 // (0 when every key is masked)
+
+    // A dependent MFMA issues back to back with its predecessor or waits out its latency (MI355X_MICROARCH.md: any instruction between two
+    // MFMAs on one accumulator costs ~43 cycles): consecutive MFMAs here always belong to DIFFERENT accumulators -- S and dP' steps alternate
+    // (phase AC), dQ walks the d-tiles inside a 16-key step (phase B).  Fragment reads run PF steps ahead of their MFMA (one wave per SIMD:
+    // nothing else hides the LDS latency).
+    constexpr int PF = 4, RR = PF + 1;
+#define BMT_P_ROWFRAG(i_) lds_b128<(DK == 256 ? (((i_) >> 1) >> 3) * 256 : 0) + (((i_) & 1) ? TILE : 0)>(kan[((i_) >> 1) & 7])
+    float pr[16], sth[8];
+    f32x16 dp;
+#define BMT_P_EXPR(r_, src_) pr[(r_) & 15] = __builtin_amdgcn_exp2f(__builtin_fmaf((src_), sc2, -lse2))
+    if (ntile_run > 0) {
+        // ---- head: S(0) and dP'(0), the lower half of P(0); the upper half of S(0) waits in registers (as in every iteration)
+        uint32_t kan[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kan[j] = kax[j];
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+        u32x4 fr[RR];
+        fr[0] = BMT_P_ROWFRAG(0); fr[1] = BMT_P_ROWFRAG(1); fr[2] = BMT_P_ROWFRAG(2); fr[3] = BMT_P_ROWFRAG(3);
+#define BMT_P_HSTEP(i_)                                                                                \
+    if constexpr ((i_) < 2 * KS) {                                                                     \
+        if constexpr ((i_) + PF < 2 * KS) fr[((i_) + PF) % RR] = BMT_P_ROWFRAG((i_) + PF);             \
+        lgkm_wait<((i_) + PF < 2 * KS) ? PF : (2 * KS - 1 - (i_))>(fr[(i_) % RR]);                     \
+        if constexpr (((i_) & 1) == 0) st = mfma32t<true>(as_bf16x8(fr[(i_) % RR]), qf[(i_) >> 1], st); \
+        else dp = mfma32t<true>(as_bf16x8(fr[(i_) % RR]), dof[(i_) >> 1], dp);                         \
+    }
+#define BMT_P_HSTEP2(j_) BMT_P_HSTEP(2 * (j_)) BMT_P_HSTEP(2 * (j_) + 1)
+        BMT_X_REP16(BMT_P_HSTEP2)
+#undef BMT_P_HSTEP2
+#undef BMT_P_HSTEP
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { BMT_P_EXPR(r, st[r]); sth[r] = st[8 + r]; }
+    }
+
+    for (int t = 0; t < ntile_run; ++t) {
+        const int slot = t % NS, slotn = (t + NS - 1) % NS;
+        const int tn = min(t + NS - 1, ntile - 1);
+        const int tx = min(t + 1, ntile_run - 1);               // the "next" tile of the pipeline (the last iteration recomputes its own)
+        const uint32_t so = slot * STAGE, sx = (tx % NS) * STAGE;
+        uint32_t kan[8], ktc[4][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kan[j] = kax[j] + sx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ktc[j][0] = ktx[j][0] + so; ktc[j][1] = ktx[j][1] + so; }
+        const uint32_t mAt = mA + t * (BC * 2);
+        u32x2 mm[4];
+        mm[0] = lds_b64<0>(mAt); mm[1] = lds_b64<16>(mAt); mm[2] = lds_b64<32>(mAt); mm[3] = lds_b64<48>(mAt);
+        const int wso = (t >> 2) * ws_tile2 + (t & 3) * 64;
+
+        // ---- phase AC: S(t+1) and dP'(t+1), alternating, under: upper half of P(t), dS'(t), the stores of P(t) and of the first half of dS'(t)
+        float dpv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {          // dP'(t) leaves the accumulator registers before the new chain starts in them
+            dpv[r] = dp[r];
+            asm volatile("" : "+v"(dpv[r]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+        float av[16];
+        uint32_t dwv[8], pw[8], sw[8];
+        u32x4 fr[RR];
+        fr[0] = BMT_P_ROWFRAG(0); fr[1] = BMT_P_ROWFRAG(1); fr[2] = BMT_P_ROWFRAG(2); fr[3] = BMT_P_ROWFRAG(3);
+        lgkm_wait<PF>(mm[0], mm[1]); lgkm_wait<PF>(mm[2], mm[3]);
+#define BMT_P_DEL(r_)                                                                                   \
+    do {                                                                                                \
+        av[(r_) & 15] = pr[(r_) & 15] * __builtin_fmaf(dpv[(r_) & 15], p.scale, dsc);                                   \
+        if constexpr (((r_) & 1) == 1) {                                                                \
+            const float c0_ = __builtin_amdgcn_fmed3f(av[((r_) - 1) & 15], -60000.f, 60000.f);                 \
+            const float c1_ = __builtin_amdgcn_fmed3f(av[(r_) & 15], -60000.f, 60000.f);                     \
+            dwv[((r_) >> 1) & 7] = pack_h2(c0_, c1_) & mm[((r_) >> 2) & 3][((r_) >> 1) & 1];                        \
+            sw[((r_) >> 1) & 7] = pack_bf2(av[((r_) - 1) & 15], av[(r_) & 15]);                                           \
+            rs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, dwv[((r_) >> 1) & 7]), ones, rs, false);     \
+        }                                                                                               \
+    } while (0)
+    // VALU work of combined step i_ (x = step index scaled to 32 steps: d_k 128 has 16 steps, each does two slots)
+#define BMT_P_ACWORK(x_)                                                                                \
+    do {                                                                                                \
+        if constexpr ((x_) < 8) BMT_P_EXPR(8 + (x_), sth[(x_) & 7]);                                        \
+        if constexpr ((x_) >= 8 && (x_) < 16) pw[((x_) - 8) & 7] = pack_bf2(pr[(2 * ((x_) - 8)) & 15], pr[(2 * ((x_) - 8) + 1) & 15]); \
+        if constexpr (((x_) & 1) == 0) BMT_P_DEL((x_) >> 1);                                            \
+        if constexpr ((x_) == 17) { swap32u(pw[0], pw[2]); swap32u(pw[1], pw[3]); st128<0>(rsP, pw[0], pw[1], pw[2], pw[3], wvo, wso); }  \
+        if constexpr ((x_) == 19) { swap32u(pw[4], pw[6]); swap32u(pw[5], pw[7]); st128<32>(rsP, pw[4], pw[5], pw[6], pw[7], wvo, wso); } \
+        if constexpr ((x_) == 21) { swap32u(sw[0], sw[2]); swap32u(sw[1], sw[3]); st128<0>(rsS, sw[0], sw[1], sw[2], sw[3], wvo, wso); }  \
+    } while (0)
+#define BMT_P_ACSTEP(i_)                                                                               \
+    if constexpr ((i_) < 2 * KS) {                                                                     \
+        if constexpr ((i_) + PF < 2 * KS) fr[((i_) + PF) % RR] = BMT_P_ROWFRAG((i_) + PF);             \
+        if constexpr ((i_) < PPW) BMT_P_DMA_K((i_) % PPW, tn, slotn);                                  \
+        else if constexpr ((i_) < 2 * PPW) BMT_P_DMA_V((i_) % PPW, tn, slotn);                         \
+        lgkm_wait<((i_) + PF < 2 * KS) ? PF : (2 * KS - 1 - (i_))>(fr[(i_) % RR]);                     \
+        if constexpr (((i_) & 1) == 0) st = mfma32t<true>(as_bf16x8(fr[(i_) % RR]), qf[(i_) >> 1], st); \
+        else dp = mfma32t<true>(as_bf16x8(fr[(i_) % RR]), dof[(i_) >> 1], dp);                         \
+        if constexpr (KS == 16) { BMT_P_ACWORK((i_)); }                                                \
+        else { BMT_P_ACWORK(2 * (i_)); BMT_P_ACWORK(2 * (i_) + 1); }                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+#define BMT_P_ACSTEP2(j_) BMT_P_ACSTEP(2 * (j_)) BMT_P_ACSTEP(2 * (j_) + 1)
+        BMT_X_REP16(BMT_P_ACSTEP2)
+#undef BMT_P_ACSTEP2
+#undef BMT_P_ACSTEP
+#undef BMT_P_ACWORK
+#undef BMT_P_DEL
+        bf16x8 dsf[2];
+        dsf[0] = as_bf16x8(u32x4{dwv[0], dwv[1], dwv[2], dwv[3]});
+        dsf[1] = as_bf16x8(u32x4{dwv[4], dwv[5], dwv[6], dwv[7]});
+
+        // ---- phase B: dQ'^T += K(t)^T . dS'(t)^T (d-tiles inside a 16-key step: no MFMA follows one on its own accumulator) under the lower
+        // half of P(t+1) and the last store of dS'(t)
+        u32x2 ta[RR], tb[RR];
+#define BMT_P_TFRAG(n_)                                                                                       \
+    do {                                                                                                      \
+        constexpr int dt__ = (n_) % DT, kk__ = (n_) / DT;                                                     \
+        constexpr int off__ = (DK == 256 ? (dt__ >> 2) * 256 : 0) + 16 * kk__ * ROWB;                         \
+        ta[(n_) % RR] = lds_tr_b64<off__>(ktc[dt__ & 3][0]);                                                  \
+        tb[(n_) % RR] = lds_tr_b64<off__ + 8 * ROWB>(ktc[dt__ & 3][1]);                                       \
+    } while (0)
+        BMT_P_TFRAG(0); BMT_P_TFRAG(1); BMT_P_TFRAG(2); BMT_P_TFRAG(3);
+#define BMT_P_BWORK(x_)                                                                                 \
+    do {                                                                                                \
+        if constexpr ((x_) == 0) { swap32u(sw[4], sw[6]); swap32u(sw[5], sw[7]); st128<32>(rsS, sw[4], sw[5], sw[6], sw[7], wvo, wso); } \
+        if constexpr ((x_) >= 2 && (x_) < 10) BMT_P_EXPR((x_) - 2, st[((x_) - 2) & 15]);                        \
+        if constexpr ((x_) >= 8 && (x_) < 16) { sth[((x_) - 8) & 7] = st[(x_) & 15]; asm volatile("" : "+v"(sth[((x_) - 8) & 7])); } \
+    } while (0)
+#define BMT_P_BSTEP(n_)                                                                                \
+    if constexpr ((n_) < 2 * DT) {                                                                     \
+        if constexpr ((n_) + PF < 2 * DT) BMT_P_TFRAG((n_) + PF);                                      \
+        lgkm_wait<((n_) + PF < 2 * DT) ? 2 * PF : 2 * (2 * DT - 1 - (n_))>(ta[(n_) % RR], tb[(n_) % RR]); \
+        const u32x4 fv = {ta[(n_) % RR][0], ta[(n_) % RR][1], tb[(n_) % RR][0], tb[(n_) % RR][1]};     \
+        dq[(n_) % DT] = mfma32t<true>(as_bf16x8(fv), dsf[(n_) / DT], dq[(n_) % DT]);                   \
+        if constexpr (2 * DT == 16) { BMT_P_BWORK((n_)); }                                             \
+        else { BMT_P_BWORK(2 * (n_)); BMT_P_BWORK(2 * (n_) + 1); }                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+        BMT_X_REP16(BMT_P_BSTEP)
+#undef BMT_P_BSTEP
+#undef BMT_P_BWORK
+#undef BMT_P_TFRAG
+        // tile t + 2 has landed once only tile t + 3's requests (this iteration's) may be pending; loads only are counted (a store
+        // younger than them can only make the wait longer)
+        if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        BMT_B_BAR();
+    }
+#undef BMT_P_EXPR
+#undef BMT_P_ROWFRAG
+#undef BMT_P_DMA_K
+#undef BMT_P_DMA_V
+
+    if (p.kmean != nullptr) {
+        const float rst = half_sum(rs);
+        const float* km = p.kmean + ((int64_t)b * p.H + h) * DK;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] -= rst * km[dt * 32 + acc_row(r, hh)];
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] *= down;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (XP & 8) { if (dq[0][0] == 1234.5f && dq[1][1] == 3.25f) p.gq.bsum[0] = 1.f; return; }
+    grad_rm_epilogue<DK, DT, 256>(smem, p.gq, dq, b, h, qt * 128, wid * 32 + l31, qok, hh, 0, p.Sq, tid);
+    if (p.gq.hiT) {
+        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+        grad_tile_write<DK, 128>(tile, dq, wid * 32, qok, l31, hh);
+        __syncthreads();
+        GradOut gt = p.gq;
+        gt.bsum = nullptr;
+        grad_tile_flush<DK, 128>(tile, gt, b, h, qt * 128, p.Sq, tid);
+    }
+}
+
+template <int DK, int XP = 0>
+int launch_dq32p(const AttnPB& p, hipStream_t st) {
+    const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
+    const int ntile = (p.Sk + 31) / 32;
+    const int lds_loop = 4 * 2 * 32 * DK * 2 + ((ntile * 64 + 15) & ~15) + 16, lds_epi = 128 * (DK + 8) * 2 + 256 * 8;
+    const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq32p_kernel<DK, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn_bwd_dq32p_kernel<DK, XP>), dim3(nblk), dim3(256), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_split(dq, pipelined)");
+    return BMT_OK;
+}
+
+// ---- the same products on 8 waves = two per SIMD: wave (kg = wid & 3, dh = wid >> 2) owns 32 keys x HALF of d_k for both gradients (2 x 64
+// accumulator registers: two waves fit a SIMD).  Why: every operand is a ds_read_b64_tr_b16, and one wave per SIMD cannot issue them fast
+// enough (PMC of attn_bwd_dkvg_kernel, profiles/r03_f_split_pmc.csv: MFMA 23 % busy, waves issue-stalled 41 % of the time, no bank conflict;
+// with the MFMAs AND the DMA switched off the loop still takes 60 % of its time: MI355X_MICROARCH.md, LDS: 4- and 8-byte reads reach their
+// rate only from several waves per SIMD).  The P / dS fragments are read by both d-halves (+8 reads per stage and wave pair).
+template <int DK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkvg8_kernel(const AttnPB p) {
+    constexpr int BQ = 32, DT = DK / 32, DTL = DT / 2, ROWB = DK * 2, XT = BQ * ROWB, YT = BQ * 256, STAGE = 2 * XT + 2 * YT;
+    constexpr int NS = (DK == 256) ? 3 : 4;
+    constexpr int CPR = DK / 8, RPP = 64 / CPR, NPX = BQ / RPP, PPW = NPX / 8;      // X tiles: 16 (8) pieces of 1 KB over 8 waves; Y tiles: 8 pieces
+    constexpr int NDMA = 2 * PPW + 2;                                               // requests per wave and stage
+    static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int nst = (p.Sq + BQ - 1) / BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wid & 3, dh = wid >> 2;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int nkt = (p.Sk + 127) / 128;
+    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    const int kt = w % nkt, bh = w / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int key = kt * 128 + kg * 32 + l31;
+    const bool kin = key < p.Sk;
+    const bool kok = kin && (p.mask == nullptr || p.mask[(int64_t)b * p.mask_bs + key] != 0);
+    const int nst_run = __syncthreads_or((int)kok) ? nst : 0;
+
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qbws + (int64_t)b * p.bsqb + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sq - 1) * p.ldqb + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0,
+                                                                         (int)(((int64_t)(p.Sq - 1) * p.ldo + DK) * 2), 0x00020000);
+    const int64_t slab = (int64_t)bh * p.ws_slab + kt * p.ws_tile;
+    const int slab_bytes = (int)(((int64_t)p.Sq * p.ws_pitch - (p.ws_tile == 128 ? kt * 128 : 0)) * 2);
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Pws + slab), 0, slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dSws + slab), 0, slab_bytes, 0x00020000);
+    int xq[2], xo[2], yo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wid * PPW + (j % PPW)) * RPP + lane / CPR, cpos = lane % CPR;
+        xq[j] = row * (int)p.ldqb * 2 + ((cpos ^ kswz(row)) * 16);
+        xo[j] = row * (int)p.ldo * 2 + ((cpos ^ kswz(row)) * 16);
+    }
+    {
+        const int row = wid * 4 + lane / 16, cpos = lane % 16;
+        yo = row * (int)p.ws_pitch * 2 + ((cpos ^ ((row & 3) << 2)) * 16);
+    }
+    const int sstep_q = BQ * (int)p.ldqb * 2, sstep_o = BQ * (int)p.ldo * 2, sstep_y = BQ * (int)p.ws_pitch * 2;
+#define BMT_H_DMA(i_, slot_)                                                                                                              \
+    do {                                                                                                                                  \
+        if constexpr ((i_) < PPW)                                                                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + (slot_) * STAGE + (wid * PPW + (i_)) * 1024), 16, xq[(i_) % 2], 0, 0, 0); \
+        else if constexpr ((i_) < 2 * PPW)                                                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + (slot_) * STAGE + XT + (wid * PPW + (i_) - PPW) * 1024), 16, xo[((i_) - PPW) % 2], 0, 0, 0); \
+        else if constexpr ((i_) == 2 * PPW)                                                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lptr_t)(smem + (slot_) * STAGE + 2 * XT + wid * 1024), 16, yo, 0, 0, 0);       \
+        else if constexpr ((i_) == 2 * PPW + 1)                                                                                           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lptr_t)(smem + (slot_) * STAGE + 2 * XT + YT + wid * 1024), 16, yo, 0, 0, 0);  \
+    } while (0)
+#define BMT_H_ADVANCE()                                                       \
+    do {                                                                      \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) { xq[j] += sstep_q; xo[j] += sstep_o; } \
+        yo += sstep_y;                                                        \
+    } while (0)
+#define BMT_H_DMA_ALL(slot_) \
+    do { BMT_H_DMA(0, slot_); BMT_H_DMA(1, slot_); BMT_H_DMA(2, slot_); BMT_H_DMA(3, slot_); BMT_H_DMA(4, slot_); BMT_H_DMA(5, slot_); } while (0)
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        BMT_H_DMA_ALL(s);
+        BMT_H_ADVANCE();
+    }
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const int m16 = lane & 15, gi = (lane >> 4) & 1, mq = m16 >> 2, mr = m16 & 3;
+    const uint32_t xT0 = lds0 + (4 * hh + mq) * ROWB + 64 * mq + 32 * gi + 16 * ((mr >> 1) ^ hh) + 8 * (mr & 1);
+    // this wave's d-tiles are dh * DTL + (0 .. DTL - 1): residues dt & 3 = all four at d_k 256 (DTL 4, dt >> 2 = dh), two at d_k 128 (DTL 2)
+    uint32_t xa[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dt = dh * DTL + (j % DTL);
+        const uint32_t base = xT0 + (DK == 256 ? (dt >> 2) * 256 : 0);
+        xa[j][0] = base ^ ((dt & 3) << 6);
+        xa[j][1] = base ^ (((dt & 3) << 6) | 32);
+    }
+    const uint32_t yB0 = lds0 + 2 * XT + (4 * hh + mq) * 256 + 64 * (kg ^ mq) + 32 * gi + 8 * mr;
+
+    f32x16 dka[DTL], dva[DTL];
+#pragma unroll
+    for (int dt = 0; dt < DTL; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nst_run; ++t) {
+        const int slot = t % NS, slotn = (t + NS - 1) % NS;
+        {
+            const uint32_t so = slot * STAGE;
+            uint32_t xs[4][2];
+#pragma unroll
+            for (int j = 0; j < DTL; ++j) { xs[j][0] = xa[j][0] + so; xs[j][1] = xa[j][1] + so; }
+            const uint32_t yB = yB0 + so;
+            u32x2 yr[8];
+            yr[0] = lds_tr_b64<0 * 256>(yB);           yr[1] = lds_tr_b64<8 * 256>(yB);
+            yr[2] = lds_tr_b64<16 * 256>(yB);          yr[3] = lds_tr_b64<24 * 256>(yB);
+            yr[4] = lds_tr_b64<YT + 0 * 256>(yB);      yr[5] = lds_tr_b64<YT + 8 * 256>(yB);
+            yr[6] = lds_tr_b64<YT + 16 * 256>(yB);     yr[7] = lds_tr_b64<YT + 24 * 256>(yB);
+            // step m: 16-query step kk = m / (2 DTL), local d-tile (m % (2 DTL)) >> 1, m & 1 = 0: dV from the dO tile, 1: dK from the Qb tile
+            constexpr int PF = 3, RR = PF + 1, NSTEP = 4 * DTL;
+            u32x2 ta[RR], tb[RR];
+#define BMT_H_TFRAG(m_)                                                                                                   \
+    do {                                                                                                                  \
+        constexpr int kk__ = (m_) / (2 * DTL), dl__ = ((m_) % (2 * DTL)) >> 1;                                            \
+        constexpr int off__ = (((m_) & 1) ? 0 : XT) + 16 * kk__ * ROWB;                                                   \
+        ta[(m_) % RR] = lds_tr_b64<off__>(xs[dl__][0]);                                                                   \
+        tb[(m_) % RR] = lds_tr_b64<off__ + 8 * ROWB>(xs[dl__][1]);                                                        \
+    } while (0)
+            BMT_H_TFRAG(0); BMT_H_TFRAG(1); BMT_H_TFRAG(2);
+            lgkm_wait<2 * PF>(yr[0], yr[1]); lgkm_wait<2 * PF>(yr[2], yr[3]); lgkm_wait<2 * PF>(yr[4], yr[5]); lgkm_wait<2 * PF>(yr[6], yr[7]);
+            if (t == nst - 1 && (p.Sq & 31) != 0) {       // rows past Sq must not contribute whatever the ring holds there
+                const int rem = p.Sq - t * BQ;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = (i >> 1) & 1, u = i & 1;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int q0 = 16 * kk + 8 * u + 4 * hh + 2 * c;
+                        const uint32_t m = (q0 < rem ? 0xffffu : 0u) | (q0 + 1 < rem ? 0xffff0000u : 0u);
+                        yr[i][c] &= m;
+                    }
+                }
+            }
+            bf16x8 pf[2], sf[2];
+            pf[0] = as_bf16x8(u32x4{yr[0][0], yr[0][1], yr[1][0], yr[1][1]});
+            pf[1] = as_bf16x8(u32x4{yr[2][0], yr[2][1], yr[3][0], yr[3][1]});
+            sf[0] = as_bf16x8(u32x4{yr[4][0], yr[4][1], yr[5][0], yr[5][1]});
+            sf[1] = as_bf16x8(u32x4{yr[6][0], yr[6][1], yr[7][0], yr[7][1]});
+#define BMT_H_STEP(m_)                                                                                     \
+    if constexpr ((m_) < NSTEP) {                                                                          \
+        if constexpr ((m_) + PF < NSTEP) BMT_H_TFRAG((m_) + PF);                                           \
+        if constexpr ((m_) < NDMA) BMT_H_DMA((m_), slotn);                                                 \
+        lgkm_wait<((m_) + PF < NSTEP) ? 2 * PF : 2 * (NSTEP - 1 - (m_))>(ta[(m_) % RR], tb[(m_) % RR]);    \
+        const u32x4 av = {ta[(m_) % RR][0], ta[(m_) % RR][1], tb[(m_) % RR][0], tb[(m_) % RR][1]};         \
+        if constexpr (((m_) & 1) == 0) dva[((m_) % (2 * DTL)) >> 1] = mfma32t<false>(as_bf16x8(av), pf[(m_) / (2 * DTL)], dva[((m_) % (2 * DTL)) >> 1]); \
+        else dka[((m_) % (2 * DTL)) >> 1] = mfma32t<false>(as_bf16x8(av), sf[(m_) / (2 * DTL)], dka[((m_) % (2 * DTL)) >> 1]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+            BMT_X_REP16(BMT_H_STEP)
+#undef BMT_H_STEP
+#undef BMT_H_TFRAG
+        }
+        BMT_H_ADVANCE();
+        if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        BMT_B_BAR();
+    }
+#undef BMT_H_DMA_ALL
+#undef BMT_H_ADVANCE
+#undef BMT_H_DMA
+
+    if (!kok) {
+#pragma unroll
+        for (int dt = 0; dt < DTL; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    grad_rm_epilogue<DK, DTL, 512>(smem, p.gv, dva, b, h, kt * 128, kg * 32 + l31, kin, hh, dh * DTL, p.Sk, tid);
+    grad_rm_epilogue<DK, DTL, 512>(smem, p.gk, dka, b, h, kt * 128, kg * 32 + l31, kin, hh, dh * DTL, p.Sk, tid);
+}
+
+template <int DK>
+int launch_dkvg8(const AttnPB& p, hipStream_t st) {
+    const int nblk = ((p.Sk + 127) / 128) * p.B * p.H;
+    const int NS = DK == 256 ? 3 : 4;
+    const int lds_loop = NS * (2 * 32 * DK * 2 + 2 * 32 * 256), lds_epi = 128 * (DK + 8) * 2 + 512 * 8;
+    const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkvg8_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn_bwd_dkvg8_kernel<DK>), dim3(nblk), dim3(512), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_split(dkv, 8 waves)");
+    return BMT_OK;
+}
+
+// rows of per-tile column sums -> the bias gradients: out[c] += sum_r part[r][c]; grid (D / 256, chunks of rows, 3 gradients)
+__global__ __launch_bounds__(256) void attn_bias_finish_kernel(const float* pq, int rq, float* oq, const float* pk, const float* pv, int rk, float* ok,
+                                                               float* ov, int D) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const float* part = blockIdx.z == 0 ? pq : (blockIdx.z == 1 ? pk : pv);
+    float* out = blockIdx.z == 0 ? oq : (blockIdx.z == 1 ? ok : ov);
+    const int rows = blockIdx.z == 0 ? rq : rk;
+    if (c >= D || out == nullptr || part == nullptr) return;
+    float s = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += part[(int64_t)r * D + c];
+    atomicAdd(out + c, s);
+}
+
 template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
@@ -2334,6 +3036,21 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     if (!fuse) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     AttnPB pf = p;
     pf.fuse_delta = fuse ? 1 : 0;
+    if constexpr (DK >= 128) {
+        if (p.Pws != nullptr) {       // split form (bmt_attn_bwd_bf16 checked shapes and sizes): dQ + emission, dK / dV as plain products, bias sums
+            int rc = launch_dq32p<DK>(pf, st);
+            if (rc != BMT_OK) return rc;
+            rc = launch_dkvg8<DK>(pf, st);
+            if (rc != BMT_OK) return rc;
+            if (p.gq.bpart || p.gk.bpart || p.gv.bpart) {
+                const int D = p.H * DK, rq = p.B * ((p.Sq + 127) / 128), rk = p.B * ((p.Sk + 127) / 128);
+                hipLaunchKernelGGL(attn_bias_finish_kernel, dim3(bmt_cdiv(D, 256), 32, 3), dim3(256), 0, st, p.gq.bpart, rq, p.gq.bsum, p.gk.bpart,
+                                   p.gv.bpart, rk, p.gk.bsum, p.gv.bsum, D);
+            }
+            BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (split)");
+            return BMT_OK;
+        }
+    }
     const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
     const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
@@ -2488,12 +3205,50 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.kmean = a->kmean;
     p.qkv_f16 = a->qkv_f16;
     BMT_CHECK_ARG(!a->qkv_f16 || a->dk >= 128, "bmt_attn_bwd_bf16: fp16 q / k / v planes are taken by the d_k >= 128 kernels only");
+    if (a->P_ws || a->dS_ws || a->Qb_ws || a->bias_ws) {
+        BMT_CHECK_ARG(a->P_ws && a->dS_ws && a->Qb_ws && a->bias_ws, "bmt_attn_bwd_bf16: the split backward needs all four workspaces");
+        int64_t n_pds, n_qb, n_bias;
+        const bool takes = bmt_attn_bwd_split_ws(a->B, a->H, a->Sq, a->Sk, a->dk, &n_pds, &n_qb, &n_bias) == BMT_OK && a->qkv_f16 &&
+                           (a->mask == nullptr || a->mask_qs == 0) && (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) &&
+                           (int64_t)a->Sk * a->ldv * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31) && !a->dQT && !a->dKT && !a->dVT;
+        if (takes) {
+            if (!(al16(a->P_ws) && al16(a->dS_ws) && al16(a->Qb_ws) && al16(a->bias_ws))) {
+                bmt_set_error("bmt_attn_bwd_bf16: workspaces must be 16-byte aligned");
+                return BMT_EALIGN;
+            }
+            p.Pws = a->P_ws; p.dSws = a->dS_ws; p.Qbws = a->Qb_ws;
+            p.ws_pitch = 128; p.ws_tile = (int64_t)a->Sq * 128; p.ws_slab = (int64_t)((a->Sk + 127) / 128) * p.ws_tile;
+            p.ldqb = (int64_t)a->H * a->dk; p.bsqb = (int64_t)a->Sq * a->H * a->dk;
+            const int64_t D = (int64_t)a->H * a->dk, rq = (int64_t)a->B * ((a->Sq + 127) / 128), rk = (int64_t)a->B * ((a->Sk + 127) / 128);
+            if (p.gq.bsum) { p.gq.bpart = a->bias_ws; p.gq.bp_ld = D; }
+            if (p.gk.bsum) { p.gk.bpart = a->bias_ws + rq * D; p.gk.bp_ld = D; }
+            if (p.gv.bsum) { p.gv.bpart = a->bias_ws + (rq + rk) * D; p.gv.bp_ld = D; }
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, st);
     if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, st);
     if (a->dk == 128) return launch_bwd<128>(p, a->dOh_ws, st);
     if (a->dk == 256) return launch_bwd<256>(p, a->dOh_ws, st);
     return BMT_EINVAL;
+}
+
+extern "C" int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_pds, int64_t* n_qb, int64_t* n_bias) {
+    if (n_pds) *n_pds = 0;
+    if (n_qb) *n_qb = 0;
+    if (n_bias) *n_bias = 0;
+    BMT_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && n_pds && n_qb && n_bias, "bmt_attn_bwd_split_ws: bad arguments");
+    // (one 128-key block of a (batch, head) is addressed through a 32-bit byte offset; a query tile below 64 rows leaves the dQ kernel's
+    // workgroups mostly idle: the decoder's 30-query attentions stay on the two-kernel form)
+    if (!(dk == 128 || dk == 256) || Sq < 64 || (int64_t)Sq * 128 * 2 >= (1ll << 31) || Sk > 16384) {
+        bmt_set_error("bmt_attn_bwd_split_ws: the split backward takes d_k 128 / 256, Sq >= 64, Sk <= 16384");
+        return BMT_EINVAL;
+    }
+    const int64_t nkt = (Sk + 127) / 128, nqt = (Sq + 127) / 128;
+    *n_pds = (int64_t)B * H * nkt * Sq * 128;
+    *n_qb = (int64_t)B * Sq * H * dk;
+    *n_bias = ((int64_t)B * nqt + 2 * (int64_t)B * nkt) * H * dk;
+    return BMT_OK;
 }
 
 extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk,

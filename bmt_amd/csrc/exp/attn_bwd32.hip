@@ -22,16 +22,7 @@
 
 namespace {
 
-__device__ __forceinline__ int kswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ float bfbits_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bfbits_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-
-#define BMT_B_BAR()                              \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        __builtin_amdgcn_s_barrier();            \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
+// (kswz, bfbits_lo / bfbits_hi and BMT_B_BAR live in the product file now: the split backward uses them)
 
 template <int DK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32_kernel(const AttnPB p, float* kq_out) {

@@ -979,25 +979,17 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D, fh=of), lse
 
 
-# EXPERIMENT switch, off by default (BMT_ATTN_BWD32=1 / =2: the attention backward of fp16-plane problems through the kernels of
-# bmt_amd/csrc/exp/attn_bwd32.hip in libbmt_exp.so -- one-pass / two-pass dK/dV; built by bmt_amd/csrc/exp/build.sh).  With the switch off
-# nothing below is touched and the experiment library is never opened.
-ATTN_BWD32 = int(_os.environ.get("BMT_ATTN_BWD32", "0") or 0)
-_exp_lib = [None]
+ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # A/B switch: "0" keeps the two-kernel backward everywhere
 
 
-def _attn_bwd32(a, B, H, Sq, dev):
-    if _exp_lib[0] is None:
-        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lib", "libbmt_exp.so")
-        e = C.CDLL(path)
-        e.bmt_exp_attn_bwd_all.restype = C.c_int
-        e.bmt_exp_attn_bwd_all.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_int, C.c_void_p]
-        e.bmt_last_error.restype = C.c_char_p
-        _exp_lib[0] = e
-    kq = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
-    rc = _exp_lib[0].bmt_exp_attn_bwd_all(C.byref(a), _p(kq), int(ATTN_BWD32 == 2), _st())
-    if rc != 0:
-        raise RuntimeError(f"bmt_exp_attn_bwd_all rc={rc}: {_exp_lib[0].bmt_last_error().decode()}")
+def _attn_split_ws(B, H, Sq, Sk, dk, dev):
+    """workspaces of the split attention backward (bmt_attn_bwd_split_ws), or None where the two-kernel form runs (d_k < 128, fewer than
+    64 queries: the decoder).  Plain allocations: under graph capture they come from the graph's pool like every other temporary."""
+    n = [C.c_int64(0), C.c_int64(0), C.c_int64(0)]
+    if lib.bmt_attn_bwd_split_ws(B, H, Sq, Sk, dk, C.byref(n[0]), C.byref(n[1]), C.byref(n[2])) != 0:
+        return None
+    e = lambda k, dt: torch.empty(k, device=dev, dtype=dt)
+    return e(n[0].value, torch.bfloat16), e(n[0].value, torch.bfloat16), e(n[1].value, torch.bfloat16), e(n[2].value, torch.float32)
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
@@ -1046,10 +1038,10 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16))
-    if ATTN_BWD32 and f16 and dk in (128, 256) and mqs == 0 and Sq <= 3072 and Sk <= 8192:
-        _attn_bwd32(a, B, H, Sq, dev)
-    else:
-        _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
+    ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and f16 and mqs == 0) else None
+    if ws is not None:      # the split backward: P / dS / scaled-q workspaces + per-tile bias partials (scratch, freed with this call)
+        a.P_ws, a.dS_ws, a.Qb_ws, a.bias_ws = (_p(t) for t in ws)
+    _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
     for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
         if b is not None and db is None:

@@ -24,7 +24,7 @@ def test_header_declares_the_hot_path():
 def test_library_loads_and_exports_everything():
     from bmt_amd import _lib
     lib = _lib.load()
-    assert lib.bmt_version() == 3
+    assert lib.bmt_version() == 4
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/bmt_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in bmt_amd/_lib.py"
@@ -63,3 +63,15 @@ def test_error_codes_are_distinct():
     assert {"BMT_EINVAL", "BMT_EHIP", "BMT_ENOENT", "BMT_EALIGN"} <= set(codes)
     assert len(set(codes.values())) == len(codes), codes
     assert _lib.ENOENT == int(codes["BMT_ENOENT"]) and _lib.EALIGN == int(codes["BMT_EALIGN"])
+
+
+def test_attention_backward_split_workspace_query():
+    """bmt_attn_bwd_split_ws: sizes for the problems the split form takes, BMT_EINVAL (and zeros) for the ones it leaves to the two-kernel form"""
+    import ctypes as C
+    from bmt_amd import _lib
+    lib = _lib.load()
+    n = [C.c_int64(-1) for _ in range(3)]
+    assert lib.bmt_attn_bwd_split_ws(32, 4, 800, 800, 256, *(C.byref(x) for x in n)) == 0
+    assert n[0].value == 32 * 4 * 7 * 800 * 128 and n[1].value == 32 * 800 * 1024 and n[2].value == (32 * 7 + 2 * 32 * 7) * 1024
+    for bad in ((32, 4, 29, 800, 256), (2, 4, 800, 800, 64), (2, 4, 800, 20000, 256)):
+        assert lib.bmt_attn_bwd_split_ws(*bad, *(C.byref(x) for x in n)) == -1 and [x.value for x in n] == [0, 0, 0]

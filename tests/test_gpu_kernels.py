@@ -388,6 +388,60 @@ def test_attention_backward_from_fp16_planes(ops, B, H, Sq, Sk, dk):
     assert_close(km_h, km_b, atol=2e-3, name="mean key from the fp16 plane")
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,dk,short", [(2, 4, 800, 800, 256, 300), (2, 4, 256, 800, 256, 97), (2, 4, 800, 256, 256, 128), (3, 2, 130, 45, 256, None),
+                                                 (2, 8, 300, 333, 128, 100), (2, 4, 64, 256, 256, 1), (2, 2, 257, 129, 128, 33)])
+def test_attention_backward_split_form(ops, B, H, Sq, Sk, dk, short, monkeypatch):
+    """the SPLIT backward (Sq >= 64, d_k >= 128, fp16 q / k / v planes: the encoder's attentions): the dQ kernel leaves P, dS and a scaled
+    bf16 copy of q in workspaces, dK / dV are two plain products over them, the bias gradients are summed from per-tile partials.  Against
+    fp64 autograd on the fp16-rounded operands AND against the two-kernel form on the same inputs (BMT_ATTN_BWD_SPLIT=0); ragged prefix
+    masks with whole 32- and 128-key tiles masked, lengths that are no multiple of the tiles, dO spanning five decades from row to row
+    (the per-query power-of-two scale of the fp16 gradient operands), keys with a common component (the mean-key correction)."""
+    D = H * dk
+    q = rnd(B * Sq, D, seed=301) * 0.7
+    k = rnd(B * Sk, D, seed=302) * 0.7 + 0.4
+    v = rnd(B * Sk, D, seed=303)
+    g = torch.Generator().manual_seed(304)
+    rowscale = 10.0 ** (-1.0 - 5.0 * torch.rand(B * Sq, 1, generator=g))
+    do = rnd(B * Sq, D, seed=305) * rowscale
+    lens = torch.randint(Sk // 2, Sk + 1, (B,), generator=g)
+    lens[0] = Sk
+    if short is not None:
+        lens[1] = short
+    mask = (torch.arange(Sk)[None, :] < lens[:, None]).view(B, 1, Sk)
+    md = mask.to(DEV)
+    qp, kp, vp = (ops.make_planes(t.to(DEV), "f16") for t in (q, k, v))
+    f16 = lambda pl: ops.Planes(None, None, pl.rows, pl.cols, fh=pl.fh)
+    o, lse = ops.attn_fwd_planes(qp, kp, vp, B, Sq, Sk, D, md, H, precision=ops.PREC_F16, out_fmt="f16")
+    dop = ops.make_planes(do.to(DEV), "bwd")
+    dop = ops.Planes(dop.hi[:, :D].contiguous(), None, B * Sq, D)
+    biases = tuple(torch.zeros(D, device=DEV, requires_grad=True) for _ in range(3))
+
+    def run(split):
+        monkeypatch.setattr(ops, "ATTN_BWD_SPLIT", split)
+        r = ops.attn_bwd_planes(f16(qp), f16(kp), f16(vp), o, dop, lse, B, Sq, Sk, D, md, H, 0.0, biases)
+        torch.cuda.synchronize()
+        return [(pl.hi[:, :D].float().cpu(), db.cpu()) for pl, db in r[:3]]
+    new, old = run(True), run(False)
+    # fp64 autograd on what the kernels were given: fp16 q / k / v, the bf16 plane of dO
+    qr, kr, vr = (pl.fh[:, :D].double().cpu().view(B, S_, D).requires_grad_() for pl, S_ in ((qp, Sq), (kp, Sk), (vp, Sk)))
+    want = _oracle_attention(qr, kr, vr, mask, H, rounded=False)
+    (want * dop.hi.double().cpu().view(B, Sq, D)).sum().backward()
+    from tests.gpu_util import report
+    for name, (gn, bn), (go, bo), ref in zip(("dq", "dk", "dv"), new, old, (qr.grad, kr.grad, vr.grad)):
+        ref2 = ref.reshape(-1, D)
+        assert torch.isfinite(gn).all() and torch.isfinite(bn).all(), f"{name}: non-finite values"
+        en, eo = rel_err(gn, ref2), rel_err(go, ref2)
+        assert en < 6e-3 and en < 1.25 * eo + 1e-3, f"{name} (B{B} H{H} {Sq}x{Sk} d_k {dk}): split {en:.3e}, two-kernel {eo:.3e}\n" + report(gn, ref2, name)
+        bref = ref2.sum(0)
+        if name != "dk":      # (sum_j dS_ij = 0: the bias gradient of the key projection is zero up to rounding, no relative bar)
+            assert rel_err(bn, bref) < 8e-3, f"bias gradient of {name}: {rel_err(bn, bref):.3e}"
+        else:
+            assert float((bn.double() - bref).abs().max()) < 5e-3 * float(ref2.abs().max()) * (B * Sk) ** 0.5
+    # masked keys get exactly zero gradients
+    dead = (~mask.view(B, Sk)).reshape(-1)
+    assert float(new[1][0][dead].abs().max() if dead.any() else 0.0) == 0.0 and float(new[2][0][dead].abs().max() if dead.any() else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("dk,H,B,Sq,Sk", [(32, 4, 2, 12, 200), (64, 2, 2, 29, 300), (128, 2, 1, 29, 333), (256, 2, 2, 29, 800), (256, 1, 1, 200, 200)])
 def test_attention_backward_keys_with_a_common_component(ops, dk, H, B, Sq, Sk, monkeypatch):
     """near-uniform attention over keys that share a large common component (the decoder's cross-attention over the encoder

@@ -22,7 +22,7 @@ from attn_bwd32_check import make_args, reference  # noqa: E402
 
 EXP = C.CDLL(os.path.join(ROOT, "bmt_amd", "lib", "libbmt_exp.so"))
 EXP.bmt_exp_attn_bwd_split.restype = C.c_int
-EXP.bmt_exp_attn_bwd_split.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+EXP.bmt_exp_attn_bwd_split.argtypes = [C.POINTER(AttnBwdBf16Args), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
 EXP.bmt_last_error.restype = C.c_char_p
 dev = "cuda"
 _p, _st = ops._p, ops._st
@@ -57,7 +57,7 @@ def case(B, H, Sq, Sk, dk, g, time_it=False, short=None, pmc=False):
     a2, keep2 = make_args(q, k, v, o, do, lse, mask, H, dq_new, dk_new, dv_new, delta, doh, km)
 
     def run(which):
-        rc = EXP.bmt_exp_attn_bwd_split(C.byref(a2), _p(Pws), _p(dSws), _p(Qb), pitch, which, _st())
+        rc = EXP.bmt_exp_attn_bwd_split(C.byref(a2), _p(Pws), _p(dSws), _p(Qb), pitch, which, None, _st())
         if rc != 0:
             raise RuntimeError(f"bmt_exp_attn_bwd_split rc={rc}: {EXP.bmt_last_error().decode()}")
     run(7 | LAYOUT)
@@ -102,15 +102,16 @@ def case(B, H, Sq, Sk, dk, g, time_it=False, short=None, pmc=False):
     _lib.check(ops.lib.bmt_attn_bwd_bf16(C.byref(apo), _st()), "bmt_attn_bwd_bf16 (planes)")
 
     def runp(which):
-        rc = EXP.bmt_exp_attn_bwd_split(C.byref(apn), _p(Pws), _p(dSws), _p(Qb), pitch, which, _st())
+        rc = EXP.bmt_exp_attn_bwd_split(C.byref(apn), _p(Pws), _p(dSws), _p(Qb), pitch, which, _p(bws), _st())
         if rc != 0:
             raise RuntimeError(f"bmt_exp_attn_bwd_split rc={rc}: {EXP.bmt_last_error().decode()}")
     Pws.fill_(float("nan")); dSws.fill_(float("nan")); Qb.fill_(float("nan"))
+    bws = torch.full(((B * ((Sq + 127) // 128) + 2 * B * ((Sk + 127) // 128)) * D,), float("nan"), device=dev)
     refs = (ref, refk, refv)
     for kvbit, kvname in ((4, "4-wave dK/dV"), (16, "8-wave dK/dV")):
         for t_ in gn + tuple(dbn):
             t_.zero_()
-        Pws.fill_(float("nan")); dSws.fill_(float("nan")); Qb.fill_(float("nan"))
+        Pws.fill_(float("nan")); dSws.fill_(float("nan")); Qb.fill_(float("nan")); bws.fill_(float("nan"))
         runp(8 | kvbit | LAYOUT)
         torch.cuda.synchronize()
         okp = True
@@ -154,6 +155,8 @@ def case(B, H, Sq, Sk, dk, g, time_it=False, short=None, pmc=False):
             if dk == 256 and "--probes" in sys.argv:
                 probes = {3: "no DMA, no MFMA", 8: "no epilogue stores", 16: "no loop (prologue + epilogue only)", 24: "neither loop nor epilogue"}
                 print("        dK/dV probes: " + "; ".join(f"{n} {timed(lambda: runp(4 | lay | (x << 12))):6.1f}" for x, n in probes.items()), flush=True)
+                del probes[3]
+                print("        dQ    probes: " + "; ".join(f"{n} {timed(lambda: runp(8 | lay | (x << 12))):6.1f}" for x, n in probes.items()), flush=True)
         runp(8 | 4 | LAYOUT)
     return ok
 
@@ -177,7 +180,10 @@ def main():
             print(f"  {c}: EXCEPTION {e}", flush=True)
     print("PARITY", "OK" if ok else "FAILED", flush=True)
     if "--no-time" not in sys.argv:
-        for c in [(32, 4, 800, 800, 256), (32, 4, 800, 256, 256), (32, 4, 256, 800, 256), (32, 4, 256, 256, 256), (64, 8, 800, 800, 128)]:
+        shapes = [(32, 4, 800, 800, 256), (32, 4, 800, 256, 256), (32, 4, 256, 800, 256), (32, 4, 256, 256, 256), (64, 8, 800, 800, 128)]
+        if "--batch-sweep" in sys.argv:
+            shapes = [(8, 4, 800, 800, 256), (16, 4, 800, 800, 256), (32, 4, 800, 800, 256)]
+        for c in shapes:
             case(*c, g, time_it=True)
     return 0 if ok else 1
 
