@@ -2488,7 +2488,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
                                                                          (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
     const int64_t slab = (int64_t)bh * p.ws_slab;
-    const int slab_bytes = (int)((int64_t)p.Sq * p.ws_pitch * 2);
+    // (the descriptor covers the whole (batch, head) slab: the range check takes the soffset into account -- raw buffers are out of range at
+    // voffset >= num_records - soffset -- so a one-block range dropped every store to key blocks past the first; rows past Sq are kept
+    // out by their voffset instead)
+    const int slab_bytes = (int)(p.ws_slab * 2);
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Pws + slab), 0, slab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dSws + slab), 0, slab_bytes, 0x00020000);
     const int ws_tile2 = (int)p.ws_tile * 2;
@@ -3240,7 +3243,7 @@ extern "C" int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64
     BMT_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && n_pds && n_qb && n_bias, "bmt_attn_bwd_split_ws: bad arguments");
     // (one 128-key block of a (batch, head) is addressed through a 32-bit byte offset; a query tile below 64 rows leaves the dQ kernel's
     // workgroups mostly idle: the decoder's 30-query attentions stay on the two-kernel form)
-    if (!(dk == 128 || dk == 256) || Sq < 64 || (int64_t)Sq * 128 * 2 >= (1ll << 31) || Sk > 16384) {
+    if (!(dk == 128 || dk == 256) || Sq < 64 || (int64_t)((Sk + 127) / 128) * Sq * 128 * 2 >= (1ll << 31) || Sk > 16384) {
         bmt_set_error("bmt_attn_bwd_split_ws: the split backward takes d_k 128 / 256, Sq >= 64, Sk <= 16384");
         return BMT_EINVAL;
     }

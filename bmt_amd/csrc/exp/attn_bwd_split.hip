@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the (batch, head) slab of the P / dS workspaces: rows past Sq fall outside the descriptor and are dropped
     // (the descriptor covers the Sq rows of ONE 128-key tile block; the block's offset travels in the soffset, which the range check ignores)
     const int64_t slab = (int64_t)bh * p.ws_slab;
-    const int slab_bytes = (int)((int64_t)p.Sq * p.ws_pitch * 2);
+    // (the descriptor covers the whole (batch, head) slab: the range check takes the soffset into account -- raw buffers are out of range at
+    // voffset >= num_records - soffset -- so a one-block range dropped every store to key blocks past the first; rows past Sq are kept
+    // out by their voffset instead)
+    const int slab_bytes = (int)(p.ws_slab * 2);
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Pws + slab), 0, slab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dSws + slab), 0, slab_bytes, 0x00020000);
     const int ws_tile2 = (int)p.ws_tile * 2;

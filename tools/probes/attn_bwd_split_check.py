@@ -161,7 +161,7 @@ def case(B, H, Sq, Sk, dk, g, time_it=False, short=None, pmc=False):
     return ok
 
 
-LAYOUT = 256 if "--tile-major" in sys.argv else 0
+LAYOUT = 0 if "--row-major" in sys.argv else 256      # the product uses the tile-major workspaces
 
 
 def main():
