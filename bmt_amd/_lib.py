@@ -103,6 +103,8 @@ SIGNATURES = {
     "bmt_planes_desc_bytes": (i32, []),
     "bmt_planes_desc": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64]),
     "bmt_planes_multi": (i32, [vp, i32, vp]),
+    "bmt_planes_desc_tiles": (i32, [vp]),
+    "bmt_planes_multi_flat": (i32, [vp, vp, i32, i32, vp]),
     "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),

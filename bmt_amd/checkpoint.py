@@ -31,6 +31,29 @@ def _module(model):
     return model.module if hasattr(model, 'module') and isinstance(model.module, torch.nn.Module) else model
 
 
+def dropout_state(device=None):
+    """{'seed', 'step'} of the library's counter-based dropout stream on `device` (ops.rng_tensor lives in device memory so that captured
+    graphs draw fresh masks), or None on a host without a GPU.  An EXTRA key of the checkpoint dicts ('bmt_dropout_state'): the
+    reference's loaders read the keys they know and ignore it; restore_dropout_state() makes a resumed run continue the same mask
+    sequence instead of restarting it at step 0."""
+    if not torch.cuda.is_available():
+        return None
+    from . import ops
+    seed, step = (int(x) for x in ops.rng_tensor(device).tolist())
+    return {'seed': seed, 'step': step}
+
+
+def restore_dropout_state(checkpoint, device=None):
+    """the dropout stream of a checkpoint dict written by save_cap_model / save_prop_model (no-op for a reference checkpoint)"""
+    st = checkpoint.get('bmt_dropout_state') if isinstance(checkpoint, dict) else None
+    if not st or not torch.cuda.is_available():
+        return False
+    from . import ops
+    ops.manual_seed(int(st['seed']), device)
+    ops.rng_tensor(device)[1] = int(st['step'])
+    return True
+
+
 def save_cap_model(cfg, epoch, model, optimizer, val_1_loss_value, val_2_loss_value, val_1_metrics, val_2_metrics,
                    trg_voc_size):
     """save_model of epoch_loops/captioning_epoch_loops.py:68-88: same dict keys, same file name under
@@ -45,6 +68,7 @@ def save_cap_model(cfg, epoch, model, optimizer, val_1_loss_value, val_2_loss_va
         'val_1_metrics': val_1_metrics,
         'val_2_metrics': val_2_metrics,
         'trg_voc_size': trg_voc_size,
+        'bmt_dropout_state': dropout_state(next(_module(model).parameters()).device),
     }
     os.makedirs(cfg.model_checkpoint_path, exist_ok=True)
     path_to_save = os.path.join(cfg.model_checkpoint_path, CAP_FILE)
@@ -64,6 +88,7 @@ def save_prop_model(cfg, epoch, model, optimizer, scheduler, anet_metrics, best_
         'anchors': m.anchors,
         'val_anet_metrics': anet_metrics,
         'best_metric': best_metric,
+        'bmt_dropout_state': dropout_state(next(m.parameters()).device),
     }
     os.makedirs(cfg.log_path, exist_ok=True)
     path_to_save = os.path.join(cfg.log_path, PROP_FILE)

@@ -126,9 +126,12 @@ __device__ __forceinline__ void pack_p(const float (&p)[16], int s2, bf16x8& hi,
     hi = as_bf16x8(h);
     lo = as_bf16x8(l);
 }
+// UNCONDITIONAL load, then a select: `p` must be readable even when !ok (callers clamp the row: min(q, Sq - 1)).  The guarded form
+// (`if (ok) v = *p`) made hipcc 7.2 branch around every load of a fragment array and wait vmcnt(0) behind it: the 16 - 48 row loads of a
+// kernel prologue became as many serialized memory round trips (tools/exp_isa.sh listing, round 3).
 __device__ __forceinline__ bf16x8 ldfrag(const uint16_t* p, bool ok) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ok) v = *reinterpret_cast<const uint4*>(p);
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
     return as_bf16x8(v);
 }
 
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
 
     bf16x8 qh[DK / 16], ql[DK / 16];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * half;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * half;
 #pragma unroll
         for (int s = 0; s < DK / 16; ++s) {
             qh[s] = ldfrag(p.Qh + qo + 16 * s, qok);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
     if (qok) {
         const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
         const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
-        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
 #pragma unroll
         for (int dt = 0; dt < G::DT; ++dt)
 #pragma unroll
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
                 v.w = drop_apply(dc, o[dt][4 * r4 + 3] * inv, (uint64_t)(rowoff + d + 3));
                 if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
                 if (p.Owh) {      // operand planes of the out-projection, written here instead of by a conversion pass
-                    const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + d;
+                    const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + d;
                     uint32_t h0, l0, h1, l1;
                     split_bf2(v.x, v.y, h0, l0);
                     split_bf2(v.z, v.w, h1, l1);
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     bf16x8 qh[KS], ql[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qh[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (qok) {
         const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
         const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
-        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + 4 * g;
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             v.w = drop_apply(dc, o[dt][3] * inv, (uint64_t)(rowoff + d + 3));
             if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
             if (p.Owh) {
-                const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + d;
+                const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + d;
                 uint32_t h0, l0, h1, l1;
                 split_bf2(v.x, v.y, h0, l0);
                 split_bf2(v.z, v.w, h1, l1);
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     bf16x8 qf[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
     }
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (qok) {
         const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as the reference's softmax
         const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
-        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
+        const int64_t rowoff = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + 4 * g;
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             v.w = drop_apply(dc, o[dt][3] * inv, (uint64_t)(rowoff + d + 3));
             if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
             if (p.Owh) {
-                const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + d;
+                const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + d;
                 uint32_t h0, l0, h1, l1;
                 split_bf2(v.x, v.y, h0, l0);
                 split_bf2(v.z, v.w, h1, l1);
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < PPW; ++j) BMT_X_DMA_V(j, 0, 0);
     bf16x8 qf[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * hh;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = ldfrag(p.Qh + qo + 16 * ks, qok);
     }
@@ -1202,8 +1205,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float l_tot = half_sum(l_run);
     const float inv = 1.f / l_tot;   // fully masked row: 0 * inf = NaN, as the reference's softmax
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
-    const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
-    const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK;
+    const int64_t rowoff = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
+    const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -1254,8 +1257,8 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, in
     const int q = (int)(row % p.Sq);
     const int bh = (int)(row / p.Sq);
     const int b = bh / p.H, h = bh % p.H;
-    const int64_t off = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
-    const int64_t poff = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK;
+    const int64_t off = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
+    const int64_t poff = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK;
     float s = 0.f;
     for (int d = lane * 4; d < DK; d += 256) {
         float4 a;
@@ -1317,7 +1320,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     u32x4* sdOq = reinterpret_cast<u32x4*>(smem + 3 * TB + 256);
     bf16x8 qf[DK / 16];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * half;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * half;
 #pragma unroll
         for (int s = 0; s < DK / 16; ++s) qf[s] = ldfrag(p.Qh + qo + 16 * s, qok);
         u32x4 tmp[rows_n<DK, 128>()];
@@ -1626,8 +1629,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     bf16x8 qf[KS], dof[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
-        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * g;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * g;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
@@ -1641,7 +1644,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // delta_i = (1 - p_drop) * sum_d dO_id * O_id from the dO fragments this lane already holds and the matching slices of
         // the saved output planes (8 g + 32 ks .. + 8 of the row: the four lanes of a query cover it); replaces a separate pass
         // over dO and O.  Stored for the dK / dV kernel, which runs after this one.
-        const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + 8 * g;
+        const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + 8 * g;
         float acc = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -1785,8 +1788,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     bf16x8 qf[KS], dof[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * g;
-        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * g;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * g;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
@@ -1798,7 +1801,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float lse2 = qok ? p.lse[stat] * LOG2E : 0.f;
     float delta;
     if (p.fuse_delta) {      // see attn_bwd_dq16_kernel
-        const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK + 8 * g;
+        const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + 8 * g;
         float acc = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bf16x8 qf[KS];
     u32x4 dob[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * hh;
-        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * hh;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * hh;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = ldfrag(p.Qh + qo + 16 * ks, qok);
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     BMT_B_PRIME()
     bf16x8 kf[KS], vf[KS];      // K as fp16 (B operand of S), V as bf16 (B operand of dP)
-    const int64_t ko = (int64_t)b * p.bsk + (int64_t)key * p.ldk + h * DK + 8 * hh;
-    const int64_t vo = (int64_t)b * p.bsv + (int64_t)key * p.ldv + h * DK + 8 * hh;
+    const int64_t ko = (int64_t)b * p.bsk + (int64_t)min(key, p.Sk - 1) * p.ldk + h * DK + 8 * hh;
+    const int64_t vo = (int64_t)b * p.bsv + (int64_t)min(key, p.Sk - 1) * p.ldv + h * DK + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         kf[ks] = ldfrag(p.Kh + ko + 16 * ks, kin);

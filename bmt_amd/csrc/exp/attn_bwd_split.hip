@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bf16x8 qf[KS];
     u32x4 dob[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * hh;
-        const int64_t oo = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK + 8 * hh;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * hh;
+        const int64_t oo = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = ldfrag(p.Qh + qo + 16 * ks, qok);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr bool inloop = true;
     bf16x8 qf[KS];
     {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)q * p.ldq + h * DK + 8 * hh;
+        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = ldfrag(p.Qh + qo + 16 * ks, qok);
     }
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float l_tot = half_sum(l_run);
     const float inv = 1.f / l_tot;   // fully masked row: 0 * inf = NaN, as the reference's softmax
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
-    const int64_t rowoff = (int64_t)b * p.bso + (int64_t)q * p.ldo + h * DK;
-    const int64_t po = (int64_t)b * p.bsop + (int64_t)q * p.ldop + h * DK;
+    const int64_t rowoff = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
+    const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll

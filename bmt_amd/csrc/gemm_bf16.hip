@@ -1238,6 +1238,45 @@ __global__ __launch_bounds__(256) void planes_multi_kernel(const PlaneDesc* __re
     }
 }
 
+// the same work as a FLAT tile list: workgroup = one tile of one tensor, found by bisection of the prefix sums of the tensors' tile counts
+// (planes_desc_tiles; the host builds them with the table).  planes_multi_kernel gives every tensor 64 workgroups that stride over its
+// tiles: the four 4096 x 1024 FFN weights (512 tiles each) were converted by 64 workgroups apiece while the workgroups of ~60 small
+// tensors idled -- 0.50 ms per optimizer step for ~100 us of HBM traffic (profiles/r02_r_kernel_stats.csv, r03_p_kernel_stats.csv).
+__host__ __device__ inline int planes_desc_tiles(const PlaneDesc& d) {
+    if (d.rows_ok) {
+        int nt = ((d.pcols + 127) / 128) * ((d.R + 63) / 64);
+        if (d.rows_ok == 2) nt += ((d.C + 63) / 64) * d.tiles_y;
+        return nt;
+    }
+    return d.tiles_x * d.tiles_y;
+}
+__global__ __launch_bounds__(256) void planes_multi_flat_kernel(const PlaneDesc* __restrict__ table, const int* __restrict__ prefix, int n) {
+    __shared__ float tile[64][65];
+    const int t = blockIdx.x;
+    int lo = 0, hi = n;                       // prefix[i] <= t < prefix[i + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    const PlaneDesc d = table[lo];
+    int lt = t - prefix[lo];
+    if (d.rows_ok) {
+        const int ntx = (d.pcols + 127) / 128, nt = ntx * ((d.R + 63) / 64);
+        if (lt < nt) {
+            planes_rows_tile(d, lt % ntx, lt / ntx, nullptr);
+        } else {
+            lt -= nt;
+            PlaneDesc dt = d;
+            dt.hi = dt.lo = dt.fh = dt.fl = nullptr;
+            dt.pcols = 0;
+            const int tx_ = (d.C + 63) / 64;
+            planes_tile(dt, lt % tx_, lt / tx_, tile);
+        }
+        return;
+    }
+    planes_tile(d, lt % d.tiles_x, lt / d.tiles_x, tile);
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int NPASS, int WM, int TI, bool AKM = false, bool BKM = false, int CONV = 0, bool F16 = false>
@@ -1705,6 +1744,20 @@ extern "C" int bmt_planes_multi(const void* table_dev, int n_tensors, void* stre
     hipLaunchKernelGGL(planes_multi_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const PlaneDesc*>(table_dev));
     BMT_CHECK_LAUNCH("bmt_planes_multi");
+    return BMT_OK;
+}
+
+extern "C" int bmt_planes_desc_tiles(const void* desc_host) {
+    if (!desc_host) return 0;
+    PlaneDesc d;
+    memcpy(&d, desc_host, sizeof(d));
+    return planes_desc_tiles(d);
+}
+extern "C" int bmt_planes_multi_flat(const void* table_dev, const int* prefix_dev, int n_tensors, int total_tiles, void* stream) {
+    BMT_CHECK_ARG(table_dev && prefix_dev && n_tensors > 0 && total_tiles > 0, "bmt_planes_multi_flat: bad args");
+    hipLaunchKernelGGL(planes_multi_flat_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PlaneDesc*>(table_dev), prefix_dev, n_tensors);
+    BMT_CHECK_LAUNCH("bmt_planes_multi_flat");
     return BMT_OK;
 }
 

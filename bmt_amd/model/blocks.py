@@ -49,10 +49,9 @@ class VocabularyEmbedder(nn.Module):
         super(VocabularyEmbedder, self).__init__()
         self.voc_size = voc_size
         self.emb_dim = emb_dim
-        # replaced if pretrained weights are used
         self.embedder = nn.Embedding(voc_size, emb_dim)
 
-    def forward(self, x):  # x - tokens (B, seq_len)
+    def forward(self, x):
         if isinstance(self.embedder, nn.Embedding):
             return _embed(self, x, pe=None, p=0.0, site=0)
         # GloVe of another width: Sequential(Embedding, Linear, ReLU)  (blocks.py:57-61)

@@ -48,10 +48,8 @@ class Transformer(nn.Module):
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
-        # initialize embedding after, so it will replace the weights initialized previously
         self.trg_emb.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
 
-        # load the pretrained encoder from the proposal (used in ablation studies)
         if cfg.pretrained_prop_model_path is not None:
             print(f'Pretrained prop path: \n {cfg.pretrained_prop_model_path}')
             encoder_config, encoder_weights = _load_encoder_weights(cfg.pretrained_prop_model_path, 'encoder.')
@@ -137,7 +135,6 @@ class BiModalTransformer(nn.Module):
         # initialize embedding after, so it will replace the weights of the prev. initialization
         self.emb_C.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
 
-        # load the pretrained encoder from the proposal (used in ablation studies)
         if cfg.pretrained_prop_model_path is not None:
             print(f'Pretrained prop path: \n {cfg.pretrained_prop_model_path}')
             encoder_config, encoder_weights = _load_encoder_weights(cfg.pretrained_prop_model_path, 'encoder.')
@@ -179,5 +176,4 @@ class BiModalTransformer(nn.Module):
             ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
         memory = self.encode(src, masks)
         C = self.decode(trg, memory, masks)
-        # (B, Sc, Vc) <- (B, Sc, Dc)
         return self.generator(C)

@@ -29,17 +29,13 @@ class BiModalDecoderLayer(nn.Module):
 
     def __init__(self, d_model_A, d_model_V, d_model_C, d_model, dout_p, H, d_ff_C):
         super(BiModalDecoderLayer, self).__init__()
-        # self attention
         self.res_layer_self_att = ResidualConnection(d_model_C, dout_p)
         self.self_att = MultiheadedAttention(d_model_C, d_model_C, d_model_C, H, dout_p, d_model)
-        # encoder attention
         self.res_layer_enc_att_A = ResidualConnection(d_model_C, dout_p)
         self.res_layer_enc_att_V = ResidualConnection(d_model_C, dout_p)
         self.enc_att_A = MultiheadedAttention(d_model_C, d_model_A, d_model_A, H, dout_p, d_model)
         self.enc_att_V = MultiheadedAttention(d_model_C, d_model_V, d_model_V, H, dout_p, d_model)
-        # bridge
         self.bridge = BridgeConnection(2*d_model_C, d_model_C, dout_p)
-        # feed forward residual
         self.res_layer_ff = ResidualConnection(d_model_C, dout_p)
         self.feed_forward = PositionwiseFeedForward(d_model_C, d_ff_C, dout_p)
         ops.tag_policy(self, "dec")     # MFMA operand formats of this layer's products (bmt_amd.ops.POLICIES)
@@ -83,7 +79,6 @@ class BiModelDecoder(nn.Module):
         self.decoder = LayerStack(layer, N)
 
     def forward(self, x, masks):
-        # x is (C, memory)
         C, memory = self.decoder(x, masks)
         return C
 

@@ -290,7 +290,7 @@ class ProposalGenerator(nn.Module):
         self.register_load_state_dict_post_hook(ops.weights_changed)   # cached bf16 weight planes go stale
         self.cfg = cfg
         self.EPS = 1e-16
-        self.num_logits = 3  # 3: c, w, obj
+        self.num_logits = 3
         self.anchors = anchors
         self.anchors_list = anchors[cfg.modality]
         self.anchors_num = len(self.anchors_list)
@@ -383,7 +383,7 @@ class MultimodalProposalGenerator(nn.Module):
         self.cfg = cfg
         self.anchors = anchors
         self.EPS = 1e-16
-        self.num_logits = 3  # 3: c, w, obj
+        self.num_logits = 3
 
         if cfg.use_linear_embedder:
             self.emb_V = FeatureEmbedder(cfg.d_vid, cfg.d_model_video)
@@ -394,7 +394,6 @@ class MultimodalProposalGenerator(nn.Module):
         self.pos_enc_V = PositionalEncoder(cfg.d_model_video, cfg.dout_p)
         self.pos_enc_A = PositionalEncoder(cfg.d_model_audio, cfg.dout_p)
 
-        # load the pre-trained encoder from captioning module
         if cfg.pretrained_cap_model_path is not None:
             print(f'Pretrained caption path: \n {cfg.pretrained_cap_model_path}')
             encoder_config, encoder_weights = _load_cap_encoder(cfg.pretrained_cap_model_path)
@@ -412,7 +411,6 @@ class MultimodalProposalGenerator(nn.Module):
                 cfg.d_model_audio, cfg.d_model_video, cfg.d_model, cfg.dout_p, cfg.H,
                 cfg.d_ff_audio, cfg.d_ff_video, cfg.N
             )
-            # encoder initialization
             for p in self.encoder.parameters():
                 if p.dim() > 1:
                     nn.init.xavier_uniform_(p)

@@ -287,6 +287,9 @@ def pad_planes(x3: torch.Tensor, halo: int, tail: int, fmt: str) -> Planes:
     return pl
 
 
+PLANES_FLAT = _os.environ.get("BMT_PLANES_FLAT", "1") != "0"      # A/B switch: "0" = 64 workgroups per tensor (bmt_planes_multi)
+
+
 class _WeightPlanes:
     """operand planes of every weight that takes part in a GEMM ([N][pad64(K)], the plane set its site's precision needs), in
     persistent buffers, ALL refreshed by one multi-tensor launch the first time a weight is needed after the optimizer moved
@@ -297,6 +300,7 @@ class _WeightPlanes:
         self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W, transposed bf16 plane [K][ldT] or None]
         self.index = {}            # (id(owner), key) -> position
         self.table = None          # device descriptor table
+        self.prefix, self.total_tiles = None, 0      # prefix sums of the tensors' tile counts (the flat launch)
         self._retired = []         # tables a captured hipGraph may still read (its refresh launch has the address baked in): never freed
         self.generation = 0        # bumped when an entry a captured graph may use is replaced or dropped (its planes can be freed then)
         self.fresh_epoch = -1
@@ -390,10 +394,19 @@ class _WeightPlanes:
                                                _p(e[6]), None, e[6].stride(0) if e[6] is not None else 0),
                            "bmt_planes_desc")
             if self.table is not None:
-                self._retired.append(self.table)       # (a few KB each; appended entries leave the old table valid for its graph)
-            self.table = host.to(self.entries[0][5].device)
+                self._retired.append((self.table, self.prefix))       # (a few KB each; appended entries leave the old table valid for its graph)
+            pre = [0]
+            for i in range(len(self.entries)):
+                pre.append(pre[-1] + lib.bmt_planes_desc_tiles(C.c_void_p(host[i].data_ptr())))
+            dev = self.entries[0][5].device
+            self.table = host.to(dev)
+            self.prefix = torch.tensor(pre, dtype=torch.int32).to(dev)
+            self.total_tiles = pre[-1]
             self.dirty_table = False
-        _lib.check(lib.bmt_planes_multi(_p(self.table), len(self.entries), _st()), "bmt_planes_multi")
+        if PLANES_FLAT:
+            _lib.check(lib.bmt_planes_multi_flat(_p(self.table), _p(self.prefix), len(self.entries), self.total_tiles, _st()), "bmt_planes_multi_flat")
+        else:
+            _lib.check(lib.bmt_planes_multi(_p(self.table), len(self.entries), _st()), "bmt_planes_multi")
         for e in self.entries:
             e[4] = e[5]._version
         self.fresh_epoch = WEIGHT_EPOCH[0]

@@ -142,6 +142,10 @@ int bmt_planes_desc_bytes(void);
 int bmt_planes_desc(void* desc_out, const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl,
                     int64_t ldp, uint16_t* hiT, uint16_t* loT, int64_t ldpT);
 int bmt_planes_multi(const void* table_dev, int n_tensors, void* stream);
+/* the same conversion as a flat tile list (one workgroup per 64-row tile of one tensor, no idle workgroups behind small tensors):
+ * prefix_dev = int32 [n_tensors + 1] prefix sums of bmt_planes_desc_tiles over the table, total_tiles = its last entry */
+int bmt_planes_desc_tiles(const void* desc_host);
+int bmt_planes_multi_flat(const void* table_dev, const int* prefix_dev, int n_tensors, int total_tiles, void* stream);
 
 /* bf16 [R][ld] -> transposed bf16 [C][ldT], zero padded up to min(round_up(R,64), ldT) */
 int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C, uint16_t* dst, int64_t ldT, void* stream);

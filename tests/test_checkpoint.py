@@ -74,7 +74,8 @@ def test_captioning_checkpoint_layout(golden, tmp_path):
     path = ckpt.save_cap_model(cfg, 3, model, opt, 1.5, 2.5, {"m": 1}, {"m": 2}, V)
     assert os.path.basename(path) == str(g.np("cpt_cap/file"))
     cpt = ckpt.load_checkpoint(path)
-    assert list(cpt.keys()) == [str(k) for k in g.np("cpt_cap/keys")]
+    # the reference's keys in its order, then ONE extra key its loaders ignore: the dropout stream's {seed, step}
+    assert list(cpt.keys()) == [str(k) for k in g.np("cpt_cap/keys")] + ["bmt_dropout_state"]
     assert list(cpt["model_state_dict"].keys()) == [str(k) for k in g.np("cpt_cap/state_keys")]
     assert cpt["epoch"] == 3 and cpt["trg_voc_size"] == V and cpt["val_2_loss"] == 2.5
     # load back into a differently initialised model, through the prefixed and the bare layout
@@ -106,7 +107,7 @@ def test_proposal_checkpoint_layout(golden, tmp_path):
     path = ckpt.save_prop_model(cfg, 2, model, opt, None, {"f1": 0.5}, 0.5)
     assert os.path.basename(path) == str(g.np("cpt_prop/file"))
     cpt = ckpt.load_checkpoint(path)
-    assert list(cpt.keys()) == [str(k) for k in g.np("cpt_prop/keys")]
+    assert list(cpt.keys()) == [str(k) for k in g.np("cpt_prop/keys")] + ["bmt_dropout_state"]
     assert list(cpt["model_state_dict"].keys()) == [str(k) for k in g.np("cpt_prop/state_keys")]
     assert cpt["anchors"] == ANCHORS and cpt["scheduler_state_dict"] is None
     # a DataParallel-style state_dict (module.-prefixed) loads into a differently initialised un-wrapped model

@@ -684,3 +684,58 @@ def test_two_models_step_concurrently_on_two_streams(golden):
             for k in g0:
                 d, n = float((g0[k] - g1[k]).double().norm()), float(g0[k].double().norm())
                 assert d <= 1e-6 * n + 1e-12, f"model {i}: gradient of {k} differs between the serial and the concurrent pass ({d:.3e} of {n:.3e})"
+
+
+def test_full_size_properties_config4_slice():
+    """BASELINE configs[4]'s per-GPU slice at FULL size: train_cap with N = 6, H = 8 (d_k = 128), d_model 1024, B = 64, T_v = 256, T_a = 800,
+    V = 10000 (the N = 6 / H = 8 SHAPE is checked against the reference at reduced B / T by the deep_cap fixture; the CPU oracle is far too
+    slow here).  Size-independent properties: log-probabilities normalise, the eval forward is deterministic, a sample's outputs do not
+    depend on the rest of the batch nor on what its padded rows hold besides the pad marker, every trainable parameter gets a finite
+    gradient, and the loss decreases over optimizer steps on one batch -- eager and through the captured graphs."""
+    import contextlib, io
+    from bmt_amd import ops
+    from bmt_amd.model.captioning_module import BiModalTransformer
+    from bmt_amd.train import CaptioningTrainStep, make_masks
+    V, B, Tv, Ta, Tc = 10000, 64, 256, 800, 30
+    cfg = syn.make_cfg(d_model=1024, H=8, N=6, dout_p=0.1)
+    cfg.device = DEV
+    cfg.lr = 1e-4
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(DEV)
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=77)
+    fs = {k: v.to(DEV) for k, v in batch["feature_stacks"].items()}
+    caps = batch["captions"].to(DEV)
+    x = caps[:, :-1]
+    masks = make_masks(fs, x, "audio_video", syn.PAD_IDX)
+    model.eval()
+    with torch.no_grad():
+        p1 = model(fs, x, masks)
+        p2 = model(fs, x, masks)
+    assert p1.shape == (B, Tc, V) and torch.isfinite(p1).all()
+    assert torch.equal(p1, p2), "eval forward is not deterministic"
+    assert float(torch.logsumexp(p1.double(), -1).abs().max()) < 1e-4, "rows of log-probabilities do not normalise"
+    # sample 5 inside another batch, its padded feature rows filled with different values (channel 0 keeps the pad marker)
+    other = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=78)
+    fs2 = {k: v.to(DEV).clone() for k, v in other["feature_stacks"].items()}
+    caps2 = other["captions"].to(DEV).clone()
+    for k in fs2:
+        fs2[k][5] = fs[k][5]
+    caps2[5] = caps[5]
+    pad_v = fs2["rgb"][5, :, 0] == float(syn.PAD_IDX)
+    pad_a = fs2["audio"][5, :, 0] == float(syn.PAD_IDX)
+    fs2["rgb"][5, pad_v, 1:] = 7.0
+    fs2["flow"][5, pad_v, :] = -3.0
+    fs2["audio"][5, pad_a, 1:] = 5.0
+    x2 = caps2[:, :-1]
+    with torch.no_grad():
+        p3 = model(fs2, x2, make_masks(fs2, x2, "audio_video", syn.PAD_IDX))
+    assert_close(p3[5], p1[5], atol=LOGP_TOL, rtol=0, name="log-probs of a sample under a different batch and different padding")
+    ops.manual_seed(9)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True)
+    l0 = float(step(fs, caps)[0])
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
+    step.capture(fs, caps)
+    losses = [l0] + [float(step.replay()[0]) for _ in range(3)]
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    assert torch.cuda.max_memory_allocated() < 40 * 2 ** 30

@@ -88,6 +88,39 @@ def test_tiny_proposal_generator(golden):
     assert_close(preds2, g["preds_notargets"], atol=2e-3, rtol=1e-3, name="predictions (no targets)")
 
 
+@pytest.mark.parametrize("name", ["audio", "video"])
+def test_proposal_head_at_the_reference_sizes(golden, name):
+    """ONE ProposalGenerationHead per modality at the reference's REAL kernel sizes (main.py:152-157: audio D_in 128, k = 211, T = 3200, 48
+    anchors; video D_in 1024, k = 79, T = 1024, 128 anchors; model/proposal_generator.py:11-47) against what the reference itself computed
+    (tests/golden/make_golden_r3.py): the 105-row halo, reductions of 27 008 / 80 896 (tap, channel) pairs -- configs[3]'s dominant
+    launches, which the small fixtures (k <= 31) do not reach.  Same constructor seed => bit-identical weights (digest pinned)."""
+    from bmt_amd.model.proposal_generator import ProposalGenerationHead
+    from oracle import bmt_oracle as orc
+    g = golden("prop_heads_real.npz")
+    d_in, k, T, anchors, seed = (int(v) for v in g.np(f"{name}/meta"))
+    torch.manual_seed(seed)
+    head = ProposalGenerationHead([d_in, 512, 512, 3 * anchors], k, 0.1, False)
+    assert orc.state_dict_digest({kk: v.detach() for kk, v in head.state_dict().items()}) == str(g.np(f"{name}/sd_digest")), "initial weights differ"
+    head = head.to(DEV).eval()
+    gen = torch.Generator().manual_seed(seed)
+    x = (torch.randn(1, T, d_in, generator=gen).abs() * 0.25).to(DEV).requires_grad_()
+    w = torch.randn(1, T, 3 * anchors, generator=gen).to(DEV)
+    y = head(x)
+    rows = g[f"{name}/rows"].long()
+    assert_close(y[0, rows.to(DEV)], g[f"{name}/y"], atol=1e-3, rtol=1e-3, name=f"{name} head output (k = {k})")
+    (y * w).sum().backward()
+    torch.cuda.synchronize()
+    e = rel_err(x.grad[0, rows.to(DEV)], g[f"{name}/dx"])
+    assert e < 3e-2, f"{name}: input gradient, relative error {e:.3e} on the stored rows\n" + report(x.grad[0, rows.to(DEV)], g[f"{name}/dx"], "dx")
+    assert abs(float(x.grad.double().norm()) / float(g.np(f"{name}/dx_norm")) - 1.0) < 2e-2
+    names, norms = [str(n) for n in g.np(f"{name}/grad_names")], g.np(f"{name}/grad_norms")
+    params = dict(head.named_parameters())
+    for n, want in zip(names, norms):
+        got = float(params[n].grad.double().norm())
+        assert abs(got / float(want) - 1.0) < 3e-2, f"{name} {n}: |grad| {got:.5e}, reference {float(want):.5e}"
+    assert rel_err(params["conv_layers.6.bias"].grad, g[f"{name}/bias_grad_last"]) < 1e-2
+
+
 def test_initial_state_dict_matches_reference_layout(golden):
     """default Sequential indices conv_layers.{0,3,6} with dropout, {0,2,4} without (positional keys)."""
     from bmt_amd.model.proposal_generator import ProposalGenerationHead

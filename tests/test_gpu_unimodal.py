@@ -122,3 +122,23 @@ def test_fused_adam_resumes_from_torch_adam_state(golden):
     opt.step()
     assert_close(q, g["p3"], atol=1e-7, rtol=1e-6, name="resumed Adam step 3")
     assert float(opt.state_dict()["state"][0]["step"]) == 3.0
+
+
+def test_checkpoint_carries_the_dropout_stream(tmp_path):
+    """save_cap_model records {seed, step} of the device-side dropout stream under an extra key; restore_dropout_state puts a
+    resumed run back on the same mask sequence (the reference has no resume path: its loaders ignore the key)"""
+    import types
+    from bmt_amd import checkpoint as ck, ops
+    ops.manual_seed(4242, "cuda")
+    ops.rng_advance(); ops.rng_advance(); ops.rng_advance()
+    torch.cuda.synchronize()
+    model = torch.nn.Linear(4, 4).cuda()
+    opt = torch.optim.Adam(model.parameters())
+    cfg = types.SimpleNamespace(model_checkpoint_path=str(tmp_path))
+    path = ck.save_cap_model(cfg, 1, model, opt, 0.0, 0.0, {}, {}, 10)
+    cpt = ck.load_checkpoint(path)
+    assert cpt["bmt_dropout_state"] == {"seed": 4242, "step": 3}
+    ops.manual_seed(7, "cuda")
+    assert ck.restore_dropout_state(cpt, "cuda")
+    assert [int(x) for x in ops.rng_tensor("cuda").tolist()] == [4242, 3]
+    assert not ck.restore_dropout_state({"model_state_dict": {}}, "cuda")

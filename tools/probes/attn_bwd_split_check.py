@@ -125,6 +125,18 @@ def case(B, H, Sq, Sk, dk, g, time_it=False, short=None, pmc=False):
             line.append(f"{name} old {eo:.2e} new {en:.2e} (bias {ebo:.1e} / {ebn:.1e})")
         print(f"      planes + fused delta, pipelined dQ, {kvname}: " + ";  ".join(line) + f"  {'OK' if okp else 'FAIL'}", flush=True)
         ok = ok and okp
+    # is the mean-key correction still worth its kernel with fp16 dS (11 significand bits)?  dQ without it:
+    apn.kmean = None
+    gn[0].zero_()
+    runp(8 | LAYOUT)
+    torch.cuda.synchronize()
+    e_nokm = rel(gn[0].float(), ref)
+    apo.kmean = None
+    go[0].zero_()
+    _lib.check(ops.lib.bmt_attn_bwd_bf16(C.byref(apo), _st()), "bmt_attn_bwd_bf16 (planes, no kmean)")
+    torch.cuda.synchronize()
+    print(f"      dq WITHOUT the mean-key correction: split {e_nokm:.2e}, two-kernel {rel(go[0].float(), ref):.2e}", flush=True)
+    apn.kmean, apo.kmean = _p(km), _p(km)
     if pmc:          # a few launches of every kernel for rocprofv3 --pmc (tile-major workspaces)
         for _ in range(3):
             ops.lib.bmt_attn_bwd_bf16(C.byref(apo), _st())
