@@ -112,6 +112,7 @@ SIGNATURES = {
     "bmt_attn_fwd_bf16": (i32, [C.POINTER(AttnFwdBf16Args), vp]),
     "bmt_attn_bwd_bf16": (i32, [C.POINTER(AttnBwdBf16Args), vp]),
     "bmt_attn_bwd_split_ws": (i32, [i32, i32, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "bmt_attn_bwd_bias_ws": (i64, [i32, i32, i32, i32, i32]),
     "bmt_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
     "bmt_layernorm_bwd_blocks": (i32, [i32]),
     "bmt_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, i32, vp]),

@@ -281,6 +281,110 @@ __device__ __forceinline__ void grad_tile_flush(const uint16_t* tile, const Grad
     }
 }
 
+// ---- gradient tile epilogue, row-major through LDS.  The tile's accumulators are G^T[d][token] with the token on the lane: written straight
+// to the plane a lane stores 8 bytes per (d-tile, register quad) at a 2-KB row stride -- 32 partial-line requests per instruction, 64
+// instructions per wave; measured on attn_bwd_dkvg_kernel (profiles/r03_h_split_probes.txt): 73 of the kernel's 154 us.  Here every wave
+// writes its registers into an image [128 tokens][d_k + 8] (ds_write_b64), the workgroup stores the image as whole 512-byte rows (16 bytes per
+// lane, consecutive lanes along d) and takes the bias column sums from the same image.
+template <int DK, int NTL>
+__device__ __forceinline__ void grad_rm_write(uint16_t* img, const f32x16 (&acc)[NTL], int trow, bool ok, int hh, int dt0) {
+    constexpr int PITCH = DK + 8;
+    uint16_t* row = img + trow * PITCH + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < NTL; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 v;
+            v[0] = ok ? pack_bf2(acc[dt][4 * i + 0], acc[dt][4 * i + 1]) : 0u;
+            v[1] = ok ? pack_bf2(acc[dt][4 * i + 2], acc[dt][4 * i + 3]) : 0u;
+            *reinterpret_cast<u32x2*>(row + (dt0 + dt) * 32 + 8 * i) = v;
+        }
+}
+// (called by all NT threads after a barrier; `red` = NT * 2 floats of LDS scratch behind the image)
+template <int DK, int NT>
+__device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, const GradOut& g, int b, int h, int tok0, int S, int tid) {
+    constexpr int PITCH = DK + 8, CPRW = DK / 8;
+    if (g.hi) {
+        uint16_t* base = g.hi + (int64_t)b * g.h_bs + (int64_t)tok0 * g.h_ld + h * DK;
+#pragma unroll 4
+        for (int c = tid; c < 128 * CPRW; c += NT) {
+            const int row = c / CPRW, col = c % CPRW;
+            if (tok0 + row < S)
+                *reinterpret_cast<u32x4*>(base + (int64_t)row * g.h_ld + col * 8) = *reinterpret_cast<const u32x4*>(img + row * PITCH + col * 8);
+        }
+    }
+    if (g.f32) {
+        float* base = g.f32 + (int64_t)b * g.f_bs + (int64_t)tok0 * g.f_ld + h * DK;
+        for (int c = tid; c < 128 * (DK / 4); c += NT) {
+            const int row = c / (DK / 4), col = c % (DK / 4);
+            if (tok0 + row < S) {
+                const u32x2 v = *reinterpret_cast<const u32x2*>(img + row * PITCH + col * 4);
+                *reinterpret_cast<float4*>(base + (int64_t)row * g.f_ld + col * 4) =
+                    make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
+            }
+        }
+    }
+    if (g.bsum) {
+        constexpr int NCW = DK / 2, NRB = NT / NCW;          // dword columns (two d values), row blocks
+        const int cw = tid % NCW, rb = tid / NCW;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int row = rb; row < 128; row += NRB) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + row * PITCH + 2 * cw);
+            s0 += __uint_as_float(v << 16);
+            s1 += __uint_as_float(v & 0xffff0000u);
+        }
+        red[2 * tid] = s0;
+        red[2 * tid + 1] = s1;
+        __syncthreads();
+        if (tid < NCW) {
+#pragma unroll
+            for (int r = 1; r < NRB; ++r) { s0 += red[2 * (tid + r * NCW)]; s1 += red[2 * (tid + r * NCW) + 1]; }
+            if (g.bpart) {      // one row of partial sums per tile: ~900 workgroups adding into the same 1024 floats took 30 us of atomics
+                *reinterpret_cast<float2*>(g.bpart + ((int64_t)b * ((S + 127) / 128) + tok0 / 128) * g.bp_ld + h * DK + 2 * cw) = make_float2(s0, s1);
+            } else {
+                atomicAdd(g.bsum + h * DK + 2 * cw, s0);
+                atomicAdd(g.bsum + h * DK + 2 * cw + 1, s1);
+            }
+        }
+    }
+}
+// the whole epilogue of one gradient tile (NT threads; the transposed plane, if anybody asks for it, still goes through the old image)
+template <int DK, int NTL, int NT>
+__device__ __forceinline__ void grad_rm_epilogue(char* smem, const GradOut& g, const f32x16 (&acc)[NTL], int b, int h, int tok0, int trow, bool ok,
+                                                 int hh, int dt0, int S, int tid) {
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+    float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
+    grad_rm_write<DK, NTL>(img, acc, trow, ok, hh, dt0);
+    __syncthreads();
+    grad_rm_flush<DK, NT>(img, red, g, b, h, tok0, S, tid);
+    __syncthreads();
+}
+
+// the same image from the 16x16 accumulator layout of the 16-wide kernels: acc[dt][r] = G^T[d = 16 dt + 4 g + r][token = this lane's column c]
+template <int DK>
+__device__ __forceinline__ void grad_rm_write16(uint16_t* img, const f32x4 (&acc)[DK / 16], int trow, bool ok, int g) {
+    constexpr int PITCH = DK + 8;
+    uint16_t* row = img + trow * PITCH + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DK / 16; ++dt) {
+        u32x2 v;
+        v[0] = ok ? pack_bf2(acc[dt][0], acc[dt][1]) : 0u;
+        v[1] = ok ? pack_bf2(acc[dt][2], acc[dt][3]) : 0u;
+        *reinterpret_cast<u32x2*>(row + dt * 16) = v;
+    }
+}
+template <int DK, int NT>
+__device__ __forceinline__ void grad_rm_epilogue16(char* smem, const GradOut& g_, const f32x4 (&acc)[DK / 16], int b, int h, int tok0, int trow, bool ok,
+                                                   int g, int S, int tid) {
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+    float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
+    grad_rm_write16<DK>(img, acc, trow, ok, g);
+    __syncthreads();
+    grad_rm_flush<DK, NT>(img, red, g_, b, h, tok0, S, tid);
+    __syncthreads();
+}
+
 // =================================================================================== forward
 constexpr float RESCALE_TAU = 8.f;   // in units of the scaled scores (natural log): P <= e^8
 
@@ -1753,12 +1857,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef BMT_DQ16_FETCH
 #undef BMT_DQ16_STORE
     dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
-    grad_store_rows16<DK>(p.gq, dq, b, h, q, qok, g);
-    if (p.gq.hiT || p.gq.bsum) {
+    // (plane / fp32 / bias sums through the row-major LDS image: whole rows out, see grad_rm_write; the transposed plane keeps the old image)
+    __syncthreads();
+    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, tid);
+    if (p.gq.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
         grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
         __syncthreads();
-        grad_tile_flush<DK, 128, NT>(tile, p.gq, b, h, qt * 128, p.Sq, tid);
+        GradOut gt = p.gq;
+        gt.bsum = nullptr;
+        grad_tile_flush<DK, 128, NT>(tile, gt, b, h, qt * 128, p.Sq, tid);
     }
 }
 
@@ -1936,12 +2044,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef BMT_DQ64_FETCH
 #undef BMT_DQ64_STORE
     dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
-    grad_store_rows16<DK>(p.gq, dq, b, h, q, qok, g);
-    if (p.gq.hiT || p.gq.bsum) {
+    // (plane / fp32 / bias sums through the row-major LDS image: whole rows out, see grad_rm_write; the transposed plane keeps the old image)
+    __syncthreads();
+    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, tid);
+    if (p.gq.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
         grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
         __syncthreads();
-        grad_tile_flush<DK, 128, NT>(tile, p.gq, b, h, qt * 128, p.Sq, tid);
+        GradOut gt = p.gq;
+        gt.bsum = nullptr;
+        grad_tile_flush<DK, 128, NT>(tile, gt, b, h, qt * 128, p.Sq, tid);
     }
 }
 
@@ -2208,20 +2320,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef BMT_DKV32_FETCH
 #undef BMT_DKV32_STORE
     }
-    grad_store_rows16<DK>(p.gv, accv, b, h, key, kok, g);
-    grad_store_rows16<DK>(p.gk, acck, b, h, key, kok, g);
-    if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
-        // one [DK][128 + 8] tile at a time (dV, then dK) in the stage buffers: 70 KB of LDS instead of 139 KB (occupancy stays at one
-        // workgroup per CU at d_k = 256 -- 254 registers --, two at d_k = 128)
+    // one [128][DK + 8] row-major image at a time (dV, then dK) in the stage buffers: whole rows out, bias sums from the image
+    static_assert(KBLK == 128, "the row-major epilogue image holds 128 tokens");
+    __syncthreads();
+    grad_rm_epilogue16<DK, NT>(smem, p.gv, accv, b, h, kt * KBLK, wid * 16 + c, kok, g, p.Sk, tid);
+    grad_rm_epilogue16<DK, NT>(smem, p.gk, acck, b, h, kt * KBLK, wid * 16 + c, kok, g, p.Sk, tid);
+    if (p.gk.hiT || p.gv.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
-        __syncthreads();
+        GradOut gt = p.gv;
+        gt.bsum = nullptr;
         grad_tile_write16<DK, KBLK>(tile, accv, wid * 16, kok, c, g);
         __syncthreads();
-        grad_tile_flush<DK, KBLK, NT>(tile, p.gv, b, h, kt * KBLK, p.Sk, tid);
+        grad_tile_flush<DK, KBLK, NT>(tile, gt, b, h, kt * KBLK, p.Sk, tid);
         __syncthreads();
+        gt = p.gk;
+        gt.bsum = nullptr;
         grad_tile_write16<DK, KBLK>(tile, acck, wid * 16, kok, c, g);
         __syncthreads();
-        grad_tile_flush<DK, KBLK, NT>(tile, p.gk, b, h, kt * KBLK, p.Sk, tid);
+        grad_tile_flush<DK, KBLK, NT>(tile, gt, b, h, kt * KBLK, p.Sk, tid);
     }
 }
 
@@ -2296,7 +2412,8 @@ int launch_fwd(const AttnPB& p, hipStream_t st, int fwd32 = -1) {
         // with fewer it ties or loses against the 16-query kernel (V-self / V<-A of configs[1]: 0.95x / 0.98x, the decoder 0.86x)
         const int want32 = fwd32 >= 0 ? fwd32 : env32;
         const bool can32 = fits && (p.mask == nullptr || p.mask_qs == 0) && p.Sk <= 8192;
-        if (!old_fwd && can32 && (want32 == 1 || (want32 < 0 && nblk >= 2 * bmt_device_cus()))) return launch_fwd32<DK, F16>(p, st);
+        static const int minq32 = getenv("BMT_ATTN_FWD32_MINQ") ? atoi(getenv("BMT_ATTN_FWD32_MINQ")) : 1 << 30;     // A/B experiments only
+        if (!old_fwd && can32 && (want32 == 1 || (want32 < 0 && (nblk >= 2 * bmt_device_cus() || p.Sq >= minq32)))) return launch_fwd32<DK, F16>(p, st);
         if (!old_fwd && fits) {
             const int lds = 2 * 2 * 64 * (DK * 2 + 32) + 256;
             static bool done64 = false;
@@ -2367,86 +2484,6 @@ __device__ __forceinline__ void st128(__amdgpu_buffer_rsrc_t rs, uint32_t a, uin
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{a, b, c, d}, rs, voff + OFF, soff, 0);
 }
 
-
-// ---- gradient tile epilogue, row-major through LDS.  The tile's accumulators are G^T[d][token] with the token on the lane: written straight
-// to the plane a lane stores 8 bytes per (d-tile, register quad) at a 2-KB row stride -- 32 partial-line requests per instruction, 64
-// instructions per wave; measured on attn_bwd_dkvg_kernel (profiles/r03_h_split_probes.txt): 73 of the kernel's 154 us.  Here every wave
-// writes its registers into an image [128 tokens][d_k + 8] (ds_write_b64), the workgroup stores the image as whole 512-byte rows (16 bytes per
-// lane, consecutive lanes along d) and takes the bias column sums from the same image.
-template <int DK, int NTL>
-__device__ __forceinline__ void grad_rm_write(uint16_t* img, const f32x16 (&acc)[NTL], int trow, bool ok, int hh, int dt0) {
-    constexpr int PITCH = DK + 8;
-    uint16_t* row = img + trow * PITCH + 4 * hh;
-#pragma unroll
-    for (int dt = 0; dt < NTL; ++dt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x2 v;
-            v[0] = ok ? pack_bf2(acc[dt][4 * i + 0], acc[dt][4 * i + 1]) : 0u;
-            v[1] = ok ? pack_bf2(acc[dt][4 * i + 2], acc[dt][4 * i + 3]) : 0u;
-            *reinterpret_cast<u32x2*>(row + (dt0 + dt) * 32 + 8 * i) = v;
-        }
-}
-// (called by all NT threads after a barrier; `red` = NT * 2 floats of LDS scratch behind the image)
-template <int DK, int NT>
-__device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, const GradOut& g, int b, int h, int tok0, int S, int tid) {
-    constexpr int PITCH = DK + 8, CPRW = DK / 8;
-    if (g.hi) {
-        uint16_t* base = g.hi + (int64_t)b * g.h_bs + (int64_t)tok0 * g.h_ld + h * DK;
-#pragma unroll 4
-        for (int c = tid; c < 128 * CPRW; c += NT) {
-            const int row = c / CPRW, col = c % CPRW;
-            if (tok0 + row < S)
-                *reinterpret_cast<u32x4*>(base + (int64_t)row * g.h_ld + col * 8) = *reinterpret_cast<const u32x4*>(img + row * PITCH + col * 8);
-        }
-    }
-    if (g.f32) {
-        float* base = g.f32 + (int64_t)b * g.f_bs + (int64_t)tok0 * g.f_ld + h * DK;
-        for (int c = tid; c < 128 * (DK / 4); c += NT) {
-            const int row = c / (DK / 4), col = c % (DK / 4);
-            if (tok0 + row < S) {
-                const u32x2 v = *reinterpret_cast<const u32x2*>(img + row * PITCH + col * 4);
-                *reinterpret_cast<float4*>(base + (int64_t)row * g.f_ld + col * 4) =
-                    make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
-            }
-        }
-    }
-    if (g.bsum) {
-        constexpr int NCW = DK / 2, NRB = NT / NCW;          // dword columns (two d values), row blocks
-        const int cw = tid % NCW, rb = tid / NCW;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-        for (int row = rb; row < 128; row += NRB) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + row * PITCH + 2 * cw);
-            s0 += __uint_as_float(v << 16);
-            s1 += __uint_as_float(v & 0xffff0000u);
-        }
-        red[2 * tid] = s0;
-        red[2 * tid + 1] = s1;
-        __syncthreads();
-        if (tid < NCW) {
-#pragma unroll
-            for (int r = 1; r < NRB; ++r) { s0 += red[2 * (tid + r * NCW)]; s1 += red[2 * (tid + r * NCW) + 1]; }
-            if (g.bpart) {      // one row of partial sums per tile: ~900 workgroups adding into the same 1024 floats took 30 us of atomics
-                *reinterpret_cast<float2*>(g.bpart + ((int64_t)b * ((S + 127) / 128) + tok0 / 128) * g.bp_ld + h * DK + 2 * cw) = make_float2(s0, s1);
-            } else {
-                atomicAdd(g.bsum + h * DK + 2 * cw, s0);
-                atomicAdd(g.bsum + h * DK + 2 * cw + 1, s1);
-            }
-        }
-    }
-}
-// the whole epilogue of one gradient tile (NT threads; the transposed plane, if anybody asks for it, still goes through the old image)
-template <int DK, int NTL, int NT>
-__device__ __forceinline__ void grad_rm_epilogue(char* smem, const GradOut& g, const f32x16 (&acc)[NTL], int b, int h, int tok0, int trow, bool ok,
-                                                 int hh, int dt0, int S, int tid) {
-    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
-    float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
-    grad_rm_write<DK, NTL>(img, acc, trow, ok, hh, dt0);
-    __syncthreads();
-    grad_rm_flush<DK, NT>(img, red, g, b, h, tok0, S, tid);
-    __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------------------------ the dQ kernel, software-pipelined
 // One wave per SIMD issues in order: a stage that runs {S MFMAs} {softmax VALU} {dP MFMAs} {dS VALU} {dQ MFMAs} leaves the matrix pipe idle
@@ -3035,6 +3072,15 @@ __global__ __launch_bounds__(256) void attn_bias_finish_kernel(const float* pq, 
 }
 
 template <int DK>
+void launch_bias_finish(const AttnPB& p, hipStream_t st) {
+    if (!(p.gq.bpart || p.gk.bpart || p.gv.bpart)) return;
+    const int D = p.H * DK, rq = p.B * ((p.Sq + 127) / 128), rk = p.B * ((p.Sk + 127) / 128);
+    const int chunks = rk > rq ? (rk < 32 ? rk : 32) : (rq < 32 ? rq : 32);
+    hipLaunchKernelGGL(attn_bias_finish_kernel, dim3(bmt_cdiv(D, 256), chunks, 3), dim3(256), 0, st, p.gq.bpart, rq, p.gq.bsum, p.gk.bpart,
+                       p.gv.bpart, rk, p.gk.bsum, p.gv.bsum, D);
+}
+
+template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     static const int sep = getenv("BMT_ATTN_DELTA_SEPARATE") ? atoi(getenv("BMT_ATTN_DELTA_SEPARATE")) : 0;      // A/B experiments only
@@ -3048,11 +3094,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             if (rc != BMT_OK) return rc;
             rc = launch_dkvg8<DK>(pf, st);
             if (rc != BMT_OK) return rc;
-            if (p.gq.bpart || p.gk.bpart || p.gv.bpart) {
-                const int D = p.H * DK, rq = p.B * ((p.Sq + 127) / 128), rk = p.B * ((p.Sk + 127) / 128);
-                hipLaunchKernelGGL(attn_bias_finish_kernel, dim3(bmt_cdiv(D, 256), 32, 3), dim3(256), 0, st, p.gq.bpart, rq, p.gq.bsum, p.gk.bpart,
-                                   p.gv.bpart, rk, p.gk.bsum, p.gv.bsum, D);
-            }
+            launch_bias_finish<DK>(p, st);
             BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (split)");
             return BMT_OK;
         }
@@ -3061,7 +3103,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
         {
-            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 128, lds_epi = DK * (128 + 8) * 2;
+            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 128, lds_epi = 128 * (DK + 8) * 2 + 512 * 8;      // (row-major gradient image + reduction scratch)
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
             static bool done = false;
             if (!done) {
@@ -3105,7 +3147,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             static const int old_dkv = getenv("BMT_ATTN_DKV_OLD") ? atoi(getenv("BMT_ATTN_DKV_OLD")) : 0;      // A/B experiments only
             const bool fits = ((int64_t)p.Sq * p.ldq * 2 < (1ll << 31)) && ((int64_t)p.Sq * p.ldo * 2 < (1ll << 31));
             if (!old_dkv && fits) {
-                const int lds_loop2 = 2 * 2 * 32 * (DK * 2 + 32) + 512, lds_epi2 = DK * (128 + 8) * 2;
+                const int lds_loop2 = 2 * 2 * 32 * (DK * 2 + 32) + 512, lds_epi2 = 128 * (DK + 8) * 2 + 512 * 8;
                 const int lds2 = lds_loop2 > lds_epi2 ? lds_loop2 : lds_epi2;
                 if (p.mask != nullptr && p.mask_qs != 0) {
                     static bool done2 = false;
@@ -3126,6 +3168,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
                 hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k16), dim3(512), lds, st, p);
             }
         }
+        launch_bias_finish<DK>(p, st);
     } else {
         {
             const int lds_loop = 3 * 32 * DK * 2 + 256 + 128 * DK * 2, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
@@ -3211,24 +3254,30 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.kmean = a->kmean;
     p.qkv_f16 = a->qkv_f16;
     BMT_CHECK_ARG(!a->qkv_f16 || a->dk >= 128, "bmt_attn_bwd_bf16: fp16 q / k / v planes are taken by the d_k >= 128 kernels only");
-    if (a->P_ws || a->dS_ws || a->Qb_ws || a->bias_ws) {
+    if (a->bias_ws && a->dk >= 128) {      // per-tile partial column sums instead of contended atomics (every d_k >= 128 kernel), added up by a last launch
+        if (!al16(a->bias_ws)) {
+            bmt_set_error("bmt_attn_bwd_bf16: workspaces must be 16-byte aligned");
+            return BMT_EALIGN;
+        }
+        const int64_t D = (int64_t)a->H * a->dk, rq = (int64_t)a->B * ((a->Sq + 127) / 128), rk = (int64_t)a->B * ((a->Sk + 127) / 128);
+        if (p.gq.bsum) { p.gq.bpart = a->bias_ws; p.gq.bp_ld = D; }
+        if (p.gk.bsum) { p.gk.bpart = a->bias_ws + rq * D; p.gk.bp_ld = D; }
+        if (p.gv.bsum) { p.gv.bpart = a->bias_ws + (rq + rk) * D; p.gv.bp_ld = D; }
+    }
+    if (a->P_ws || a->dS_ws || a->Qb_ws) {
         BMT_CHECK_ARG(a->P_ws && a->dS_ws && a->Qb_ws && a->bias_ws, "bmt_attn_bwd_bf16: the split backward needs all four workspaces");
         int64_t n_pds, n_qb, n_bias;
         const bool takes = bmt_attn_bwd_split_ws(a->B, a->H, a->Sq, a->Sk, a->dk, &n_pds, &n_qb, &n_bias) == BMT_OK && a->qkv_f16 &&
                            (a->mask == nullptr || a->mask_qs == 0) && (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) &&
                            (int64_t)a->Sk * a->ldv * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31) && !a->dQT && !a->dKT && !a->dVT;
         if (takes) {
-            if (!(al16(a->P_ws) && al16(a->dS_ws) && al16(a->Qb_ws) && al16(a->bias_ws))) {
+            if (!(al16(a->P_ws) && al16(a->dS_ws) && al16(a->Qb_ws))) {
                 bmt_set_error("bmt_attn_bwd_bf16: workspaces must be 16-byte aligned");
                 return BMT_EALIGN;
             }
             p.Pws = a->P_ws; p.dSws = a->dS_ws; p.Qbws = a->Qb_ws;
             p.ws_pitch = 128; p.ws_tile = (int64_t)a->Sq * 128; p.ws_slab = (int64_t)((a->Sk + 127) / 128) * p.ws_tile;
             p.ldqb = (int64_t)a->H * a->dk; p.bsqb = (int64_t)a->Sq * a->H * a->dk;
-            const int64_t D = (int64_t)a->H * a->dk, rq = (int64_t)a->B * ((a->Sq + 127) / 128), rk = (int64_t)a->B * ((a->Sk + 127) / 128);
-            if (p.gq.bsum) { p.gq.bpart = a->bias_ws; p.gq.bp_ld = D; }
-            if (p.gk.bsum) { p.gk.bpart = a->bias_ws + rq * D; p.gk.bp_ld = D; }
-            if (p.gv.bsum) { p.gv.bpart = a->bias_ws + (rq + rk) * D; p.gv.bp_ld = D; }
         }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -3255,6 +3304,11 @@ extern "C" int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64
     *n_qb = (int64_t)B * Sq * H * dk;
     *n_bias = ((int64_t)B * nqt + 2 * (int64_t)B * nkt) * H * dk;
     return BMT_OK;
+}
+
+extern "C" int64_t bmt_attn_bwd_bias_ws(int B, int H, int Sq, int Sk, int dk) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || dk < 128) return 0;
+    return ((int64_t)B * ((Sq + 127) / 128) + 2 * (int64_t)B * ((Sk + 127) / 128)) * H * dk;
 }
 
 extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk,

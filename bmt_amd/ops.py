@@ -993,6 +993,7 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
 
 
 ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # A/B switch: "0" keeps the two-kernel backward everywhere
+KMEAN_SPLIT = _os.environ.get("BMT_KMEAN_SPLIT", "1") != "0"            # "0": no mean-key correction on the split form (fp16 dS)
 
 
 def _attn_split_ws(B, H, Sq, Sk, dk, dev):
@@ -1041,7 +1042,10 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     qa, ka, va = (q.fh, k.fh, v.fh) if f16 else (q.hi, k.hi, v.hi)
     ldq, ldk, ldv, ldop = qa.stride(0), ka.stride(0), va.stride(0), o.hi.stride(0)
     (qh_, qb_, _), (kh_, kb_, _), (vh_, vb_, _) = outs
-    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16)
+    ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and f16 and mqs == 0) else None
+    # the mean-key correction removes the residue of the bf16-rounded dS (8 significand bits); the split form's dQ runs on fp16 dS with
+    # per-query scales (11 bits): with KMEAN_SPLIT off its launches (8 of the step's 14, ~21 us each) are skipped there
+    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16) if (ws is None or KMEAN_SPLIT) else None
     a = AttnBwdBf16Args(Qh=_p(qa), Kh=_p(ka), Vh=_p(va), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
@@ -1051,9 +1055,13 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16))
-    ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and f16 and mqs == 0) else None
     if ws is not None:      # the split backward: P / dS / scaled-q workspaces + per-tile bias partials (scratch, freed with this call)
         a.P_ws, a.dS_ws, a.Qb_ws, a.bias_ws = (_p(t) for t in ws)
+    elif any(b_ is not None for b_ in (qb_, kb_, vb_)):      # two-kernel form (the decoder's attentions): per-tile bias partials only
+        nb = lib.bmt_attn_bwd_bias_ws(B, H, Sq, Sk, dk)
+        if nb > 0:
+            ws = (torch.empty(nb, device=dev, dtype=torch.float32),)
+            a.bias_ws = _p(ws[0])
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
     res = []
     for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):

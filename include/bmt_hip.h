@@ -240,7 +240,7 @@ typedef struct {
                                                          times the keys' common component, 10-25 % of |dQ| under near-uniform attention */
     int qkv_f16;                                      /* Qh / Kh / Vh are the FORWARD's fp16 planes (d_k >= 128): converted to bf16 while staging; the
                                                          projections then write 2 instead of 4 bytes per element of q, k and v */
-    /* ABI 4 -- workspaces of the SPLIT backward (all four or none; sizes from bmt_attn_bwd_split_ws).  With them, fp16 q / k / v planes
+    /* ABI 4 -- workspaces of the SPLIT backward (all four, or bias_ws alone, or none; sizes from bmt_attn_bwd_split_ws / bmt_attn_bwd_bias_ws).  With them, fp16 q / k / v planes
      * (qkv_f16), d_k 128 / 256, a key-padding mask (or none) and Sq >= 64 the backward runs as {dQ kernel that leaves P and dS in
      * P_ws / dS_ws and a scaled bf16 copy of q in Qb_ws} -> {dK / dV as two plain products over them} -> {bias sums from per-tile
      * partials in bias_ws}; S = Q K^T and dP = dO V^T are computed once instead of twice.  Contents are scratch: the caller may hand the
@@ -253,6 +253,9 @@ int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
  * (fp32) *n_bias.  Returns BMT_EINVAL (and zeros) for a problem the split form does not take (d_k < 128, Sq < 64, sizes past 2^31 bytes per
  * (batch, head) block): the caller then passes NULL workspaces and the two-kernel form runs. */
 int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_pds, int64_t* n_qb, int64_t* n_bias);
+/* bias_ws alone (P_ws = dS_ws = Qb_ws = NULL) is taken by every d_k >= 128 backward: the tiles' column sums are stored per tile and added
+ * up by a finishing launch instead of ~900 workgroups adding into the same H * d_k floats.  Element count (0 for d_k < 128: pass NULL): */
+int64_t bmt_attn_bwd_bias_ws(int B, int H, int Sq, int Sk, int dk);
 /* out[b][c] = mean over the valid keys k of K[b][k][c] (bf16 plane, row stride ldk, batch stride bsk; mask: key-padding bytes [B][Sk]
    when mask_qs == 0, otherwise -- no mask or one row per query -- every key counts).  No counterpart in the reference: numerical aid of
    the bf16 backward (model/multihead_attention.py:8-26 is exact in fp32). */
