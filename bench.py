@@ -482,7 +482,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 2 s of back-to-back steps under rocm-smi after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying hipGraphs")
-    ap.add_argument("--dp-mode", default="auto", choices=["auto", "graph", "overlap"],
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "graph", "overlap", "graph-overlap"],
                     help="N > 1: hipGraphs with the all-reduce exposed between them, eager launches with the all-reduce overlapped with "
                          "the backward pass, or (auto) whichever a short trial finds faster")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing protocol only (gloo, no GPU)")
@@ -556,7 +556,13 @@ def main():
                 step(*inputs)
             eager_ms = trial(lambda: step(*inputs))
             note(f"eager + overlapped all-reduce: {eager_ms:.2f} ms/step")
-        if not (world > 1 and args.dp_mode == "overlap"):
+        if world > 1 and args.dp_mode == "graph-overlap":
+            # opt-in: ONE hipGraph with the bucket all-reduces captured inside it (CaptioningTrainStep._capture_with_collectives): overlap
+            # without host work between kernels.  Not part of `auto`: a collective that cannot be captured may hang instead of raising.
+            step.capture(*inputs, warmup=2, collectives=True)
+            run = lambda: step.replay()
+            mode = "hipgraph+captured-allreduce"
+        elif not (world > 1 and args.dp_mode == "overlap"):
             try:
                 step.capture(*inputs, warmup=2)
                 graph_ms = trial(lambda: step.replay()) if eager_ms is not None else None

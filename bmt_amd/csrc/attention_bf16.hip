@@ -3295,8 +3295,9 @@ extern "C" int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64
     BMT_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && n_pds && n_qb && n_bias, "bmt_attn_bwd_split_ws: bad arguments");
     // (one 128-key block of a (batch, head) is addressed through a 32-bit byte offset; a query tile below 64 rows leaves the dQ kernel's
     // workgroups mostly idle: the decoder's 30-query attentions stay on the two-kernel form)
-    if (!(dk == 128 || dk == 256) || Sq < 64 || (int64_t)((Sk + 127) / 128) * Sq * 128 * 2 >= (1ll << 31) || Sk > 16384) {
-        bmt_set_error("bmt_attn_bwd_split_ws: the split backward takes d_k 128 / 256, Sq >= 64, Sk <= 16384");
+    // (and the dQ kernel keeps a 2-byte-per-key mask image next to its 128 KB K / V ring in LDS: Sk <= 8192)
+    if (!(dk == 128 || dk == 256) || Sq < 64 || (int64_t)((Sk + 127) / 128) * Sq * 128 * 2 >= (1ll << 31) || Sk > 8192) {
+        bmt_set_error("bmt_attn_bwd_split_ws: the split backward takes d_k 128 / 256, Sq >= 64, Sk <= 8192");
         return BMT_EINVAL;
     }
     const int64_t nkt = (Sk + 127) / 128, nqt = (Sq + 127) / 128;

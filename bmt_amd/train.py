@@ -192,13 +192,15 @@ class CaptioningTrainStep:
         return loss, n_tokens
 
     # ---- hipGraph capture -------------------------------------------------------------------------------------
-    def capture(self, feature_stacks, caption_idx, warmup: int = 2):
+    def capture(self, feature_stacks, caption_idx, warmup: int = 2, collectives: bool = False):
         """Capture {zero_grad .. backward} and {optimizer} into two graphs over STATIC input buffers (copies of the given
         batch).  ``replay(fs, caps)`` copies a new batch of the same shape into those buffers and launches
         graph 1 -> (eager) gradient all-reduce + normaliser -> graph 2.  Dropout masks still change on every replay
         (seed/step live in device memory, the step counter is advanced by a captured kernel), as do Adam's bias corrections."""
         if self.reducer is None:
             raise RuntimeError("capture() needs static gradient buffers: construct with static_grads=True")
+        if collectives:
+            return self._capture_with_collectives(feature_stacks, caption_idx, warmup)
         self.reducer.overlap = False            # collectives stay outside the captured region
         self._static_fs = {k: v.clone() for k, v in feature_stacks.items()}
         self._static_caps = caption_idx.clone()
@@ -226,6 +228,34 @@ class CaptioningTrainStep:
         self._graph_generation = _ops.weights_generation()
         return self._graphs
 
+    def _capture_with_collectives(self, feature_stacks, caption_idx, warmup):
+        """ONE graph for the whole step with the RCCL collectives INSIDE it: the bucket all-reduces are launched from the backward hooks
+        onto the communication stream exactly as in the eager `overlap` mode (weight-gradient products flushed at the encoder-layer
+        boundaries), the capture records them -- and the stream dependencies around them -- as graph nodes, so a replay overlaps each
+        bucket's all-reduce with the remaining layers' backward without any host work between kernels (the eager mode pays ~1 ms of
+        launch gaps per step for that overlap, the two-graph mode exposes the whole all-reduce).  Opt-in (`bench.py --dp-mode graph-overlap`):
+        it relies on RCCL kernels being capturable on the installation, which the 1-rank smoke (tools/dp_smoke_1gpu.py) checks."""
+        self.reducer.overlap = True
+        self._static_fs = {k: v.clone() for k, v in feature_stacks.items()}
+        self._static_caps = caption_idx.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self(self._static_fs, self._static_caps)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            kl, ntok = self._forward_backward(self._static_fs, self._static_caps)
+            self._static_loss, _ = self._reduce(kl, ntok)
+            self._static_ntok = ntok
+            self._optimize()
+        self._graphs = (g,)
+        from . import ops as _ops
+        self._graph_generation = _ops.weights_generation()
+        return self._graphs
+
     def uncapture(self):
         """back to eager launches (bucket all-reduces overlapped with the backward pass again)"""
         self._graphs = None
@@ -237,11 +267,15 @@ class CaptioningTrainStep:
             for k, v in feature_stacks.items():
                 self._static_fs[k].copy_(v, non_blocking=True)
             self._static_caps.copy_(caption_idx, non_blocking=True)
-        g1, g2 = self._graphs
         from . import ops as _ops
         if _ops.weights_generation() != self._graph_generation:
             raise RuntimeError("the weight-plane registry changed after capture() (a weight's operand planes were re-allocated, or a model was "
                                "garbage-collected): the captured graphs name freed buffers -- call capture() again")
+        if len(self._graphs) == 1:          # the whole step incl. its collectives (capture(collectives=True))
+            self._graphs[0].replay()
+            _ops_weights_changed()
+            return self._static_loss, self._static_ntok
+        g1, g2 = self._graphs
         g1.replay()
         ev = self._reduce_events
         if ev is not None:
@@ -274,7 +308,11 @@ class CaptioningTrainStep:
         r = self.reducer
         if r is None:
             return None
-        if self._graphs is not None:
+        if self._graphs is not None and len(self._graphs) == 1:
+            mode = (f"bucket all-reduces (RCCL) captured INSIDE the step's single hipGraph: launched from the backward pass onto the communication "
+                    f"stream at {self._flush_points} encoder-layer boundaries, each overlapped with the remaining layers' backward; plus one captured "
+                    "scalar all-reduce (global n_tokens)")
+        elif self._graphs is not None:
             mode = ("sum all-reduce (RCCL) of the flat fp32 gradient buckets between the backward graph and the optimizer graph (exposed), "
                     "plus one scalar all-reduce (global n_tokens)")
         else:
@@ -364,7 +402,7 @@ class MixedTrainStep:
                 p.requires_grad = f
         assert not any(id(p) in enc for p in self.prop.params)
 
-    def capture(self, feature_stacks, caption_idx, warmup: int = 2):
+    def capture(self, feature_stacks, caption_idx, warmup: int = 2, collectives: bool = False):
         return self.cap.capture(feature_stacks, caption_idx, warmup=warmup)
 
     def __call__(self, cap_batch, prop_batch):

@@ -45,3 +45,16 @@ def test_kmajor_gemm_source_is_what_the_generator_writes():
     generator produces from the committed product kernel (its patches assert their anchors, so a drifted product kernel fails here too)"""
     gen = _emulator("make_wide_km")
     assert open(gen.OUT).read() == gen.generate()
+
+
+@pytest.mark.parametrize("dk", [256, 128])
+def test_split_backward_dkv_lane_algebra_and_banks(dk):
+    """attn_bwd_dkvg8_kernel / attn_bwd_dkvg_kernel (the split backward's dK / dV products): both MFMA operands are transposing reads of
+    images whose row is the reduction index q -- the q' / dO tiles in the dual-purpose swizzle, the P / dS column blocks with
+    chunk ^ ((row & 3) << 2) -- dV^T = dO^T . P against numpy for all four key groups, without bank conflicts"""
+    assert _emulator("attn_bwd_split_layout").check(dk)
+
+
+def test_split_backward_emission_layout():
+    """the dQ kernel's P / dS emission: after the v_permlane32_swap exchange every lane holds 8 consecutive keys of its query row"""
+    assert _emulator("attn_bwd_split_layout").check_emit()

@@ -1,6 +1,6 @@
 """-m gpu: the data-parallel launch modes on one GPU through a 1-rank RCCL group with forced collectives
 (tools/dp_smoke_1gpu.py: hipGraph + eager all-reduce, eager with bucket all-reduces from the backward hooks, eager with the
-all-reduce after the backward pass), each against the single-process step."""
+all-reduce after the backward pass, and ONE hipGraph with the bucket all-reduces captured inside it), each against the single-process step."""
 import os
 import socket
 
@@ -20,6 +20,8 @@ def test_data_parallel_modes_on_a_one_rank_rccl_group():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_smoke_1gpu.py")], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_smoke_1gpu.py"), "--graph-overlap"], env=env, capture_output=True, text=True,
+                       timeout=600)
     out = r.stdout
     assert "DP-SMOKE OK" in out and "DIFFER" not in out, (r.returncode, out[-2000:], r.stderr[-2000:])
+    assert "dp_graph_overlap" in out, out[-2000:]

@@ -3,7 +3,8 @@
 all-reduces (sum over one rank = identity), in the three launch modes bench.py can take under torch.distributed.run:
   * eager, bucket all-reduces launched from the backward hooks (overlap),
   * eager, all-reduce after the backward pass,
-  * two hipGraphs with the eager all-reduce between them (what `bench.py --gpus N` runs).
+  * two hipGraphs with the eager all-reduce between them (what `bench.py --gpus N` runs),
+  * (--graph-overlap) ONE hipGraph with the bucket all-reduces captured inside it (`bench.py --dp-mode graph-overlap`).
 Each must reproduce the losses of the plain single-process step (to 1e-5 relative: the step's atomics make runs differ in
 the last fp32 bits).  Exercises NCCL/RCCL initialisation on the box,
 collectives on the flat gradient buckets from autograd's hook thread, stream ordering against the captured graphs."""
@@ -43,7 +44,7 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(dev)
         dp = mode != "single"
-        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=dp, static_grads=True, overlap=(mode == "dp_eager_overlap"),
+        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=dp, static_grads=True, overlap=(mode in ("dp_eager_overlap", "dp_graph_overlap")),
                                    seed=77)          # dropout seed = 77 + rank on every arm (rank 0 here)
         calls = [0]
         if dp:
@@ -56,8 +57,8 @@ def main():
             dist.all_reduce = counted
         losses = []
         try:
-            if mode in ("single", "dp_graph"):
-                step.capture(fs, caps, warmup=1)
+            if mode in ("single", "dp_graph", "dp_graph_overlap"):
+                step.capture(fs, caps, warmup=1, collectives=(mode == "dp_graph_overlap"))
                 for _ in range(4):
                     loss, _ = step.replay()
                     losses.append(float(loss))
@@ -75,7 +76,8 @@ def main():
 
     ref, _ = run("single")
     ok = True
-    for mode in ("dp_graph", "dp_eager_overlap", "dp_eager_after"):
+    modes = ("dp_graph", "dp_eager_overlap", "dp_eager_after") + (("dp_graph_overlap",) if "--graph-overlap" in sys.argv else ())
+    for mode in modes:
         got, n = run(mode)
         same = all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(got, ref))
         ok &= same and n > 0
