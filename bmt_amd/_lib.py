@@ -69,7 +69,11 @@ class AttnBwdBf16Args(C.Structure):
                 ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
                 ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32),
-                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp)]
+                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32)]
+
+
+class ColsumItem(C.Structure):
+    _fields_ = [("part", vp), ("out", vp), ("rows", i32), ("D", i32), ("ld", i64)]
 
 
 class SelectProposalsArgs(C.Structure):
@@ -107,6 +111,8 @@ SIGNATURES = {
     "bmt_planes_multi_flat": (i32, [vp, vp, i32, i32, vp]),
     "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "bmt_colsum_multi": (i32, [vp, i32, vp]),
+    "bmt_layernorm_bwd_partial": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "bmt_attn_fwd_bf16": (i32, [C.POINTER(AttnFwdBf16Args), vp]),

@@ -170,6 +170,7 @@ struct AttnPB {
     uint16_t *Pws, *dSws, *Qbws;
     int64_t ws_pitch, ws_tile, ws_slab, ldqb, bsqb;     // (batch, head) slab bh at bh * ws_slab; in it element (q, key) of a (batch, head) slab at (key / 128) * ws_tile + q * ws_pitch + key % 128
     int xp;                                    // experiments only: parts of a loop switched off (timing probes)
+    int defer_bias;                            // the per-tile bias sums stay in bpart: the caller adds them up (bmt_colsum_multi)
 };
 
 // 8 fp16 -> 8 bf16 (round to nearest even) in one 16-byte register slot: q / k / v exist as fp16 planes only under the fp16 attention
@@ -3073,7 +3074,7 @@ __global__ __launch_bounds__(256) void attn_bias_finish_kernel(const float* pq, 
 
 template <int DK>
 void launch_bias_finish(const AttnPB& p, hipStream_t st) {
-    if (!(p.gq.bpart || p.gk.bpart || p.gv.bpart)) return;
+    if (!(p.gq.bpart || p.gk.bpart || p.gv.bpart) || p.defer_bias) return;
     const int D = p.H * DK, rq = p.B * ((p.Sq + 127) / 128), rk = p.B * ((p.Sk + 127) / 128);
     const int chunks = rk > rq ? (rk < 32 ? rk : 32) : (rq < 32 ? rq : 32);
     hipLaunchKernelGGL(attn_bias_finish_kernel, dim3(bmt_cdiv(D, 256), chunks, 3), dim3(256), 0, st, p.gq.bpart, rq, p.gq.bsum, p.gk.bpart,
@@ -3263,6 +3264,7 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
         if (p.gq.bsum) { p.gq.bpart = a->bias_ws; p.gq.bp_ld = D; }
         if (p.gk.bsum) { p.gk.bpart = a->bias_ws + rq * D; p.gk.bp_ld = D; }
         if (p.gv.bsum) { p.gv.bpart = a->bias_ws + (rq + rk) * D; p.gv.bp_ld = D; }
+        p.defer_bias = a->defer_bias;
     }
     if (a->P_ws || a->dS_ws || a->Qb_ws) {
         BMT_CHECK_ARG(a->P_ws && a->dS_ws && a->Qb_ws && a->bias_ws, "bmt_attn_bwd_bf16: the split backward needs all four workspaces");

@@ -266,14 +266,33 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
                                  partial_ws, rows, D, stream);
 }
 
+static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
+                       int D, void* stream, bool leave_partials);
+
 extern "C" int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                      const float* mean, const float* rstd, float* dx, int64_t lddx, const float* dx_add,
                                      int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
-    BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
-    if (rows == 0) return BMT_OK;
+    BMT_CHECK_ARG(dgamma && dbeta, "bmt_layernorm_bwd: bad args");
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, rows, D, stream, false);
+}
+
+extern "C" int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                                         const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* partial_ws,
+                                         int rows, int D, void* stream) {
+    BMT_CHECK_ARG(partial_ws, "bmt_layernorm_bwd_partial: needs the partial workspace");
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true);
+}
+
+static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
+                       int D, void* stream, bool leave_partials) {
+    BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
+    if (rows == 0) return leave_partials ? 1 : BMT_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && al16(x) && al16(dy) && al16(dx) &&
                      al16(gamma) && D <= 2048 && (!dx_add || (al16(dx_add) && ldadd % 4 == 0));
+    if (!vec && leave_partials) return 1;       // (the scalar kernel adds into dgamma / dbeta directly: the caller falls back)
     if (!vec) {
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx,
                            lddx, dx_add, ldadd, dgamma, dbeta, rows, D);
@@ -291,7 +310,7 @@ extern "C" int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float*
     else BMT_LN(8);
 #undef BMT_LN
     BMT_CHECK_LAUNCH("bmt_layernorm_bwd");
-    if (partial_ws) {
+    if (partial_ws && !leave_partials) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(bmt_cdiv(2 * D, 64), bmt_cdiv((int)grid.x, 64)), dim3(256), 0, st, partial_ws, (int)grid.x, dgamma, dbeta, D);
         BMT_CHECK_LAUNCH("bmt_layernorm_bwd(reduce)");
     }

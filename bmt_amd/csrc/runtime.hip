@@ -39,7 +39,59 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (rl == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// MANY small column-sum reductions in one launch: out_i[c] += sum_r part_i[r * ld_i + c] (c < D_i).  The step has ~90 of them -- the second
+// stage of every LayerNorm's dgamma / dbeta, the per-tile bias partials of every attention backward -- each a 4-us kernel behind a 1.5-us
+// kernel boundary when launched on its own.  The items travel BY VALUE in the kernel arguments (96 x 32 bytes): nothing is read from host
+// memory when the launch executes, so it can be captured in a hipGraph.  grid (sum of ceil(D_i / 256), row slices).
+struct ColsumItem {
+    const float* part;
+    float* out;
+    int rows, ld, D, blk0;      // blk0: first blockIdx.x of this item
+};
+struct ColsumPack {
+    ColsumItem it[BMT_COLSUM_MAX_ITEMS];
+    int n;
+};
+static_assert(sizeof(ColsumPack) <= 4000, "the item pack must fit the kernel argument buffer");
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumPack pk) {
+    int i = 0;
+    while (i + 1 < pk.n && pk.it[i + 1].blk0 <= (int)blockIdx.x) ++i;      // (uniform: scalar loads from the argument segment)
+    const float* part = pk.it[i].part;
+    const int rows = pk.it[i].rows, ld = pk.it[i].ld, D = pk.it[i].D;
+    const int c = ((int)blockIdx.x - pk.it[i].blk0) * 256 + (int)threadIdx.x;
+    if (c >= D) return;
+    float s0 = 0.f, s1 = 0.f;
+    int r = blockIdx.y;
+    for (; r + (int)gridDim.y < rows; r += 2 * gridDim.y) {
+        s0 += part[(int64_t)r * ld + c];
+        s1 += part[(int64_t)(r + gridDim.y) * ld + c];
+    }
+    if (r < rows) s0 += part[(int64_t)r * ld + c];
+    atomicAdd(pk.it[i].out + c, s0 + s1);
+}
+
 }  // namespace
+
+extern "C" int bmt_colsum_multi(const bmt_colsum_item* items, int n, void* stream) {
+    BMT_CHECK_ARG(items && n > 0, "bmt_colsum_multi: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += BMT_COLSUM_MAX_ITEMS) {
+        ColsumPack pk;
+        pk.n = n - base < BMT_COLSUM_MAX_ITEMS ? n - base : BMT_COLSUM_MAX_ITEMS;
+        int blk = 0, maxrows = 1;
+        for (int i = 0; i < pk.n; ++i) {
+            const bmt_colsum_item& a = items[base + i];
+            BMT_CHECK_ARG(a.part && a.out && a.rows >= 0 && a.D > 0 && a.ld >= a.D, "bmt_colsum_multi: bad item %d", base + i);
+            pk.it[i] = ColsumItem{a.part, a.out, a.rows, (int)a.ld, a.D, blk};
+            blk += bmt_cdiv(a.D, 256);
+            if (a.rows > maxrows) maxrows = a.rows;
+        }
+        const int slices = maxrows < 16 ? maxrows : 16;
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3(blk, slices), dim3(256), 0, st, pk);
+        BMT_CHECK_LAUNCH("bmt_colsum_multi");
+    }
+    return BMT_OK;
+}
 
 extern "C" int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream) {
     BMT_CHECK_ARG(X && out && M >= 0 && N > 0, "bmt_colsum: bad args");

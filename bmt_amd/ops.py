@@ -137,13 +137,14 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "res_offer", "last_ln", "kv_cache")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
         self.pending_dw = []
         self.pending_ids = set()     # parameters whose gradient product is queued: their "gradient final" report waits for the flush
         self.pending_done = []
+        self.pending_cs = []         # queued column-sum reductions (LayerNorm dgamma / dbeta partials, attention bias partials): colsum_multi
         self.res_offer = None        # residual offered by a ResidualConnection to its sublayer's last GEMM
         self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
         self.kv_cache = None         # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory, k planes, v planes)
@@ -728,8 +729,37 @@ def flush_dw():
                           a_km=True, b_km=True)
         else:
             gemm_bf16_grouped(items)
+    cs, ctx.pending_cs = ctx.pending_cs, []
+    if cs:
+        _colsum_launch(cs)
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
         grad_done(p)
+
+
+DEFER_COLSUM = _os.environ.get("BMT_DEFER_COLSUM", "1") != "0"      # A/B switch: "0" = every small reduction is its own launch again
+
+
+def _colsum_launch(items):
+    """items: (partials tensor, column offset, out tensor, rows, ld, D): out[c] += sum_r partials[r * ld + column offset + c]"""
+    arr = (_lib.ColsumItem * len(items))()
+    for i, (part, off, out, rows, ld, D) in enumerate(items):
+        arr[i] = _lib.ColsumItem(part=part.data_ptr() + 4 * off, out=out.data_ptr(), rows=rows, D=D, ld=ld)
+    _lib.check(lib.bmt_colsum_multi(arr, len(items), _st()), "bmt_colsum_multi")
+
+
+def colsum_deferred(items, params=()):
+    """the second stage of small reductions whose partial sums are already on the stream (LayerNorm dgamma / dbeta, attention bias
+    gradients): queued next to the weight-gradient products while a backward pass defers those (StepContext.defer_dw) and issued by
+    flush_dw as ONE launch for the whole pass (~90 reductions per train_cap step, each a 4-us kernel behind a kernel boundary when
+    launched on its own); otherwise launched at once.  params: the parameters the results belong to -- their grad_done reports wait
+    for the flush, exactly as for queued weight gradients.  The queue keeps the partials' tensors alive."""
+    ctx = context()
+    params = [p for p in params if p is not None]
+    if ctx.defer_dw and DEFER_COLSUM and params:       # (a result that is handed back to autograd as a tensor must be complete now)
+        ctx.pending_cs.extend(items)
+        ctx.pending_ids.update(id(p) for p in params)
+    else:
+        _colsum_launch(items)
 
 
 def linear_dw(dy: Planes, x: Planes, into: Optional[torch.Tensor] = None, params=()) -> Optional[torch.Tensor]:
@@ -1055,14 +1085,24 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16))
+    bias_part = None
     if ws is not None:      # the split backward: P / dS / scaled-q workspaces + per-tile bias partials (scratch, freed with this call)
         a.P_ws, a.dS_ws, a.Qb_ws, a.bias_ws = (_p(t) for t in ws)
+        bias_part = ws[3]
     elif any(b_ is not None for b_ in (qb_, kb_, vb_)):      # two-kernel form (the decoder's attentions): per-tile bias partials only
         nb = lib.bmt_attn_bwd_bias_ws(B, H, Sq, Sk, dk)
         if nb > 0:
-            ws = (torch.empty(nb, device=dev, dtype=torch.float32),)
-            a.bias_ws = _p(ws[0])
+            bias_part = torch.empty(nb, device=dev, dtype=torch.float32)
+            a.bias_ws = _p(bias_part)
+    if bias_part is not None:        # the partials' sums are issued from here (with the pass's other small reductions when it defers them)
+        a.defer_bias = 1
     _lib.check(lib.bmt_attn_bwd_bf16(C.byref(a), _st()), "bmt_attn_bwd_bf16")
+    if bias_part is not None:
+        rq, rk = B * ((Sq + 127) // 128), B * ((Sk + 127) // 128)
+        items = [(bias_part, off * D, buf, rows, D, D) for buf, off, rows in ((qb_, 0, rq), (kb_, rq, rk), (vb_, rq + rk, rk)) if buf is not None]
+        static = all(b is None or static_grad(b) is not None for b in biases)
+        if items:
+            colsum_deferred(items, params=[b for b in biases if b is not None] if static else ())
     res = []
     for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
         if b is not None and db is None:
@@ -1172,9 +1212,16 @@ class ResidualNormFn(torch.autograd.Function):
         fused = sg is not None and sb is not None
         dg = sg if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
-        ws = torch.empty(max(1, lib.bmt_layernorm_bwd_blocks(rows)) * 2 * D, device=x2.device, dtype=torch.float32)
-        _lib.check(lib.bmt_layernorm_bwd_add(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(dg), _p(db),
-                                             _p(ws), rows, D, _st()), "bmt_layernorm_bwd_add")
+        nblk = max(1, lib.bmt_layernorm_bwd_blocks(rows))
+        ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
+        rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, _st())
+        if rc == 0:        # dgamma / dbeta partials of the kernel's workgroups are in ws: their sums join the pass's other small reductions
+            colsum_deferred([(ws, 0, dg, nblk, 2 * D, D), (ws, D, db, nblk, 2 * D, D)], params=(gamma, beta) if fused else ())
+        else:
+            if rc != 1:
+                _lib.check(rc, "bmt_layernorm_bwd_partial")
+            _lib.check(lib.bmt_layernorm_bwd_add(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(dg), _p(db),
+                                                 _p(ws), rows, D, _st()), "bmt_layernorm_bwd_add")
         dx = dx.view(g_n.shape)
         if fused:
             grad_done(gamma)
@@ -1224,9 +1271,16 @@ class LayerNormFn(torch.autograd.Function):
         fused = sg is not None and sb is not None          # accumulate straight into the static gradient buffers
         dg = sg if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
-        ws = torch.empty(max(1, lib.bmt_layernorm_bwd_blocks(rows)) * 2 * D, device=x2.device, dtype=torch.float32)
-        _lib.check(lib.bmt_layernorm_bwd(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, 0, _p(dg), _p(db),
-                                         _p(ws), rows, D, _st()), "bmt_layernorm_bwd")
+        nblk = max(1, lib.bmt_layernorm_bwd_blocks(rows))
+        ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
+        rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, None, 0, _p(ws), rows, D, _st())
+        if rc == 0:
+            colsum_deferred([(ws, 0, dg, nblk, 2 * D, D), (ws, D, db, nblk, 2 * D, D)], params=(gamma, beta) if fused else ())
+        else:
+            if rc != 1:
+                _lib.check(rc, "bmt_layernorm_bwd_partial")
+            _lib.check(lib.bmt_layernorm_bwd(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, 0, _p(dg), _p(db),
+                                             _p(ws), rows, D, _st()), "bmt_layernorm_bwd")
         if fused:
             grad_done(gamma)
             grad_done(beta)

@@ -154,6 +154,7 @@ class CaptioningTrainStep:
         finally:
             sctx.defer_dw = False
             sctx.pending_dw.clear()
+            sctx.pending_cs.clear()
         return kl.detach(), n_tokens
 
     def _reduce(self, kl, n_tokens):

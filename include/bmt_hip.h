@@ -152,6 +152,19 @@ int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C, uint16_t* 
 
 /* column sums: out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
 int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream);
+/* many small reductions in ONE launch: out_i[c] += sum over r < rows_i of part_i[r * ld_i + c], c < D_i (fp32).  The second stage of the
+ * LayerNorm dgamma / dbeta partials (bmt_layernorm_bwd_partial) and of the attention backward's per-tile bias sums (defer_bias): the
+ * host side queues them over a backward pass and issues them together.  `items` is read on the HOST during the call (and passed to the
+ * kernel by value, BMT_COLSUM_MAX_ITEMS per launch): capturable in a hipGraph. */
+#define BMT_COLSUM_MAX_ITEMS 96
+typedef struct {
+    const float* part;
+    float* out;
+    int rows;
+    int D;
+    int64_t ld;
+} bmt_colsum_item;
+int bmt_colsum_multi(const bmt_colsum_item* items, int n, void* stream);
 
 /*
  * bmt_attn_fwd: O = dropout( softmax(Q K^T * scale, masked) V )   per (batch, head)
@@ -247,6 +260,9 @@ typedef struct {
      * same buffers to every call on a stream. */
     uint16_t *P_ws, *dS_ws, *Qb_ws;
     float* bias_ws;
+    int defer_bias;                                   /* with bias_ws: leave the per-tile sums there (rows b * tiles + tile of [D] floats: dbq's B * ceil(Sq / 128)
+                                                         rows, then dbk's and dbv's B * ceil(Sk / 128) each) and skip the finishing launch: the caller
+                                                         adds them up itself (bmt_colsum_multi, together with other reductions) */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* element counts of the split backward's workspaces for a problem: P_ws and dS_ws (bf16) take *n_pds each, Qb_ws (bf16) *n_qb, bias_ws
@@ -277,6 +293,11 @@ int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, co
  * partial_ws: NULL -> one atomic per column per workgroup; else fp32 [bmt_layernorm_bwd_blocks(rows)][2][D] scratch for a
  * two-stage reduction (store per-workgroup partials, then sum them 64 at a time: one atomic per column per 64 workgroups). */
 int bmt_layernorm_bwd_blocks(int rows);
+/* bmt_layernorm_bwd_add WITHOUT its second stage: the dgamma / dbeta column partials of the bmt_layernorm_bwd_blocks(rows) workgroups stay
+ * in partial_ws ([blocks][2 D]: dgamma | dbeta) for the caller to reduce (bmt_colsum_multi).  Returns 1 -- and does nothing -- where the
+ * vector kernel does not apply (D > 2048, unaligned rows): the caller then uses bmt_layernorm_bwd_add. */
+int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                              float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* partial_ws, int rows, int D, void* stream);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                       float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream);
