@@ -72,6 +72,10 @@ class AttnBwdBf16Args(C.Structure):
                 ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32)]
 
 
+class CopyItem(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("n", i64)]
+
+
 class ColsumItem(C.Structure):
     _fields_ = [("part", vp), ("out", vp), ("rows", i32), ("D", i32), ("ld", i64)]
 
@@ -112,6 +116,7 @@ SIGNATURES = {
     "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "bmt_colsum_multi": (i32, [vp, i32, vp]),
+    "bmt_copy_multi": (i32, [vp, i32, vp]),
     "bmt_layernorm_bwd_partial": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),

@@ -52,6 +52,9 @@ struct GemmB {
     uint32_t site;
     float* ws;                           // split-K partials [split][tiles_m*128][tiles_n*128] (two-pass mode), or nullptr
     int nsplit;
+    int nk_loader;                       // gemm_k128_kernel: 1 = seven computing waves + a loading wave, 0 = eight waves that load their own rows
+    int nk_dbg;                          // experiments (env BMT_K128_DBG): 1 no stores, 2 no MFMAs, 4 no next-unit prefetch
+    int nk_ncw, nk_rg, nk_upw;           // gemm_k128_kernel: weight rows per resident chunk, row groups, 32-row units per row group
 #ifdef BMT_EXP
     int exp;                             // experiment build only (BMT_ALT_FLAGS=-DBMT_EXP, env BMT_EXP): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue,
     int exp_shift; int exp_sleep;                       // 8 every other workgroup starts exp_sleep x 3.4 us late (env BMT_EXP_SLEEP)
@@ -984,6 +987,304 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     BMT_STAMP(3);
 }
 
+// ===================================================================== reduction of 128 (the audio stream's projections: d_model_audio = 128)
+// M x N outputs from a reduction of 128: 2 FLOP per output byte-pair -- these launches are bound by WRITING the result (25600 x 3072 fp16
+// = 157 MB for the fused audio q|k|v), and the tile kernels above spend 102 us on it (1.5 TB/s: every 128 x 128 tile re-stages 64 KB of
+// weight planes for 32 KB of output, and its load / MFMA / store phases do not overlap; profiles/r03_v_last_step_trace.csv).  Here
+//   * a workgroup keeps a CHUNK of the weight (nk_ncw = 128 or 256 rows x 128 k, both planes: <= 128 KB) in LDS for its whole life (one
+//     LDS-DMA burst, XOR-swizzled 16-byte slots), and walks down its share of the activation rows;
+//   * a wave owns a 32-row unit: its activation fragments (8 k-steps x 16 bytes per lane) come straight from global memory into
+//     registers -- they are used for every column block of the chunk -- the next unit's are requested before this unit's work;
+//   * per 32-column block: 8 (or 16: second weight plane) MFMAs, then the block is turned through a wave-private 4 KB LDS chunk so that a
+//     store instruction writes 16 rows x 64 contiguous bytes of a 16-bit plane (128 of the fp32 output);
+//   * after the initial barrier the 8 waves never synchronise: stores, LDS turns and MFMAs of different waves overlap freely.
+// As in gemm_wide_kernel the weight rows take the MFMA's A role (C^T = W . X^T), so a lane's accumulator registers are consecutive
+// output columns of one output row.
+// Memory operations of a wave retire IN ORDER on this architecture (one vmcnt for loads and stores): a wait for any load issued after
+// a store is a wait for that store's acknowledgement from L2 / HBM -- several microseconds when every CU is writing.  Versions of this
+// kernel in which the waves that store also loaded (bias per block; then only the next unit's activation rows, requested one unit ahead
+// with a counted vmcnt) ran at 2.4 and 1.7 us per 32 x 32 block: each unit waited for the previous unit's stores to be acknowledged
+// (profiles/r03_w_k128_pmc_*.csv: 39 % of the wave time in memory waits at 90 VALU instructions per block).  So the roles are split:
+//   * waves 0-6 COMPUTE: fragments from LDS, MFMAs, the turn through their LDS chunk, stores -- they never wait on vmcnt;
+//   * wave 7 LOADS: the activation rows of the next round (7 units of 32 rows = 56 KB, LDS-DMA, swizzled like the weight chunk) into the
+//     round slot as soon as the compute waves have taken this round's rows into registers (barrier 1), waits for its own loads only, and
+//     meets them again at the end of the round (barrier 2).  Two compute waves per SIMD on three SIMDs, one beside the loader: with 4
+//     compute waves (one per SIMD, two ring slots) a block took 1750 clocks end to end and nothing overlapped it (85 us for q|k|v).
+// Instruction diet of the compute waves (the second finding: 228 VALU instructions per block against 16 MFMAs in the first version):
+// the column-block loop is unrolled (LDS offsets are immediates), the accumulator starts as the bias (alpha is 1 on this path), the
+// plane format is branched on, not selected, 32-bit store offsets, and the next block's fragments are requested before this block's
+// epilogue.
+template <bool F16, bool TWO, int NCB, bool LOADER>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k128_kernel(const GemmB p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int NCW = 32 * NCB, PLANE = NCW * 256, NPL = TWO ? 2 : 1;
+    constexpr int NCMP = LOADER ? 7 : 8;                                                         // computing waves
+    constexpr int A_OFF = NPL * PLANE, CK_OFF = A_OFF + (LOADER ? NCMP * 8192 : 0), BIAS_OFF = CK_OFF + NCMP * 4096;   // LDS: weight chunk | round slot | turn chunks | bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nch = p.tiles_n;
+    // workgroups of one row group (they read the same activation rows) are neighbours in the remapped order: same XCD, same L2
+    const int w = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int rg = w / nch, chunk = w - rg * nch;
+    const int n0 = chunk * NCW;
+    const int lrow = lane >> 4, lslot = lane & 15;          // LDS-DMA: an instruction fills 4 rows of 256 B; lane = (row, 16-byte slot)
+
+    // ---- the weight chunk: pieces of 4 rows (1 KB); rows >= N are outside the descriptor (zeros)
+    {
+        const __amdgpu_buffer_rsrc_t rsWh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsWl = __builtin_amdgcn_make_buffer_rsrc((void*)(TWO ? p.Bl : p.Bh), 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
+        for (int pc = wid; pc < NCW / 4; pc += 8) {
+            const int row = 4 * pc + lrow;
+            const int vo = (n0 + row) * (int)p.ldb * 2 + ((lslot ^ (row & 15)) * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWh, (lptr_t)(smem + pc * 1024), 16, vo, 0, 0, 0);
+            if constexpr (TWO) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWl, (lptr_t)(smem + PLANE + pc * 1024), 16, vo, 0, 0, 0);
+        }
+    }
+    float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
+    const unsigned f = p.flags;
+    if (tid < NCW) sbias[tid] = ((f & BMT_EPI_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+
+    const int units = (p.M + 31) >> 5;
+    const int u0 = rg * p.nk_upw, u_end = min(units, (rg + 1) * p.nk_upw);
+    const int rounds = (u_end - u0 + NCMP - 1) / NCMP;
+
+    if (LOADER && wid == NCMP) {
+        // ================= the loading wave: round r = units u0 + 7 r .. + 6 (rows clamped: a round may reach past the matrix)
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
+        auto fill = [&](int r) {
+            char* slot = smem + A_OFF;
+            const int row0 = 32 * (u0 + NCMP * r);
+#pragma unroll 8
+            for (int pc = 0; pc < 8 * NCMP; ++pc) {
+                const int rr = 4 * pc + lrow;                                  // row of the round's 128
+                const int row = min(row0 + rr, p.M - 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(slot + pc * 1024), 16, row * (int)p.lda * 2 + ((lslot ^ (rr & 15)) * 16), 0, 0, 0);
+            }
+        };
+        if (rounds > 0) fill(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            __syncthreads();                      // barrier 1: this round's rows are in the compute waves' registers
+            if (r + 1 < rounds) fill(r + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                      // barrier 2
+        }
+        return;
+    }
+    // ================= the computing waves
+    char* ck = smem + CK_OFF + wid * 4096;
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    const int pcols = p.Chi ? p.plane_cols : 0;
+    const int ncols = pcols > p.N ? pcols : p.N;
+    const int ncb = (min(NCW, ncols - n0) + 31) >> 5;
+    const int seg = lane & 3, rsel = lane >> 2;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, p.C ? (int)((int64_t)p.M * p.ldc * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)p.Chi, 0, p.Chi ? (int)((int64_t)p.M * p.ldp * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)p.Clo, 0, p.Clo ? (int)((int64_t)p.M * p.ldp * 2) : 0, 0x00020000);
+    const bool no_st = (p.nk_dbg & 1) != 0;
+    const bool slow_epi = (f & (BMT_EPI_DROP_PRE | BMT_EPI_DROP_POST | BMT_EPI_GATE | BMT_EPI_RESIDUAL)) != 0;
+    constexpr int CLIP = 0x7fffff00;
+    // fragment address of k-step s: + fragb[s] (+ 8192 * block, + PLANE) in the weight chunk, + 8192 * wave in a ring slot
+    int fragb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) fragb[s] = l31 * 256 + (((2 * s + half) ^ (l31 & 15)) * 16);
+    const int wr_off = l31 * 128;
+    const int ldc4 = (int)p.ldc * 4, ldp2 = (int)p.ldp * 2;
+
+    bf16x8 wh[8], wl[TWO ? 8 : 1];
+#define BMT_K128_FRAGS(cb_)                                                                                          \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                              \
+            wh[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + fragb[s] + (cb_) * 8192));                      \
+            if constexpr (TWO) wl[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + fragb[s] + (cb_) * 8192 + PLANE)); \
+        }                                                                                                            \
+    } while (0)
+
+    auto process = [&](const bf16x8 (&a)[8], int u) {
+        BMT_K128_FRAGS(0);
+        const int row_a = 32 * u + rsel;                   // pass 0 row of this lane (pass 1: + 16); a unit past u_end stores nothing
+        const int m_lim = u < u_end ? p.M : 0;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (cb < ncb) {
+                // the accumulator starts as the bias (register group j = columns 8 j + 4 half .. + 3)
+                f32x16 acc0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sbias + 32 * cb + 8 * j + 4 * half);
+                    acc0[4 * j + 0] = bq.x; acc0[4 * j + 1] = bq.y; acc0[4 * j + 2] = bq.z; acc0[4 * j + 3] = bq.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);           // the fragment reads stay in front of the MFMAs, all 16 in flight together
+                if (!(p.nk_dbg & 2)) {
+                    // one accumulator chain for both weight planes: the second wave of the SIMD fills the gaps a dependent MFMA leaves
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        if constexpr (TWO) acc0 = mfma32t<F16>(wl[s], a[s], acc0);
+                        acc0 = mfma32t<F16>(wh[s], a[s], acc0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (cb + 1 < NCB) {
+                    if (cb + 1 < ncb) BMT_K128_FRAGS(cb + 1);          // in flight during this block's epilogue
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- the block through the wave's chunk: acc[4 j + q] = column 8 j + 4 half + q of row l31
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 t;
+                    t.x = acc0[4 * j + 0]; t.y = acc0[4 * j + 1]; t.z = acc0[4 * j + 2]; t.w = acc0[4 * j + 3];
+                    *reinterpret_cast<float4*>(ck + wr_off + (((2 * j + half) ^ (l31 & 7)) * 16)) = t;
+                }
+                const int col = n0 + 32 * cb + 8 * seg;
+                const bool in_n = col < p.N;                          // N is a multiple of 8 here: a segment is inside or outside
+                const bool in_p = col < pcols;
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int rl = 16 * ps + rsel;
+                    const float4 t0 = *reinterpret_cast<const float4*>(ck + rl * 128 + (((2 * seg) ^ (rl & 7)) * 16));
+                    const float4 t1 = *reinterpret_cast<const float4*>(ck + rl * 128 + (((2 * seg + 1) ^ (rl & 7)) * 16));
+                    float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    const int row = row_a + 16 * ps;
+                    const bool rok = row < m_lim;
+                    if (f & BMT_EPI_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    if (slow_epi) {
+                        const int64_t idx = (int64_t)row * p.ldc + col;
+                        if (f & BMT_EPI_DROP_PRE) {       // (documented before the ReLU: the two commute exactly -- a mask and a positive scale)
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+                        }
+                        if (f & BMT_EPI_DROP_POST) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+                        }
+                        if ((f & BMT_EPI_GATE) && rok && in_n) {
+                            const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + (int64_t)row * p.ldg + col);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[2 * q] = (gv[q] & 0x00007FFFu) ? v[2 * q] * p.gate_scale : 0.f;
+                                v[2 * q + 1] = (gv[q] & 0x7FFF0000u) ? v[2 * q + 1] * p.gate_scale : 0.f;
+                            }
+                        }
+                        if ((f & BMT_EPI_RESIDUAL) && rok && in_n) {
+                            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+                            const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        }
+                    }
+                    if (32 * (cb + 1) > p.N - n0) {       // only the ragged last block of the matrix has segments outside N
+                        if (!in_n) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                        }
+                    }
+                    if (p.C && !no_st) {
+                        const int vo = (rok && in_n) ? row * ldc4 + col * 4 : CLIP;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsC, vo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsC, vo, 16, 0);
+                    }
+                    if (p.Chi && !no_st) {
+                        const int vo = (rok && in_p) ? row * ldp2 + col * 2 : CLIP;
+                        if (p.hi_f16) {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])}, rsH, vo, 0, 0);
+                        } else {
+                            u32x4 h, l;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint32_t h_, l_;
+                                split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
+                                h[q] = h_;
+                                l[q] = l_;
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(h, rsH, vo, 0, 0);
+                            if (p.Clo) {
+                                if (p.second_f16) l = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
+                                __builtin_amdgcn_raw_buffer_store_b128(l, rsL, vo, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (LOADER) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const int u = u0 + NCMP * r + wid;
+            bf16x8 a[8];
+            {
+                const char* ab = smem + A_OFF + wid * 8192;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(ab + fragb[s]));
+            }
+            __syncthreads();          // barrier 1 (waits for the reads above): the loading wave may overwrite the slot
+            process(a, u);
+            __syncthreads();          // barrier 2: the next round's rows have landed (the loading wave waited for them)
+        }
+    } else {
+        // every wave computes; its activation rows come straight from global memory into registers, requested TWO units ahead by hand
+        // (asm: the compiler does not track them) and waited for with a counted vmcnt that leaves the younger operations -- the other
+        // register set's loads and the stores of the last two units -- in flight.  All stores are issued unconditionally (clipped by the
+        // descriptor) so that the count is exact.
+        u32x4 n0r[8], n1r[8];
+#define BMT_K128_LD(dst_, i_) asm volatile("global_load_dwordx4 %0, %1, off offset:" #i_ "*32" : "=&v"(dst_[i_]) : "v"(ap_) : "memory")
+#define BMT_K128_LDA(dst_, uu_)                                                                                     \
+    do {                                                                                                             \
+        const int row_ = min(32 * min((uu_), units - 1) + l31, p.M - 1);                                             \
+        const uint16_t* ap_ = p.Ah + (int64_t)row_ * p.lda + 8 * half;                                               \
+        BMT_K128_LD(dst_, 0); BMT_K128_LD(dst_, 1); BMT_K128_LD(dst_, 2); BMT_K128_LD(dst_, 3);                      \
+        BMT_K128_LD(dst_, 4); BMT_K128_LD(dst_, 5); BMT_K128_LD(dst_, 6); BMT_K128_LD(dst_, 7);                      \
+    } while (0)
+#define BMT_K128_W(dst_, n_)                                                                                         \
+    asm volatile("s_waitcnt vmcnt(" #n_ ")"                                                                         \
+                 : "+v"(dst_[0]), "+v"(dst_[1]), "+v"(dst_[2]), "+v"(dst_[3]), "+v"(dst_[4]), "+v"(dst_[5]), "+v"(dst_[6]), "+v"(dst_[7])::"memory")
+#define BMT_K128_WAIT(dst_, cnt_)                                                                                    \
+    do {                                                                                                             \
+        const int c_ = (cnt_);                     /* operations younger than the loads waited for */               \
+        if (c_ >= 56) BMT_K128_W(dst_, 56);                                                                          \
+        else if (c_ >= 40) BMT_K128_W(dst_, 40);                                                                     \
+        else if (c_ >= 24) BMT_K128_W(dst_, 24);                                                                     \
+        else if (c_ >= 16) BMT_K128_W(dst_, 16);                                                                     \
+        else if (c_ >= 8) BMT_K128_W(dst_, 8);                                                                       \
+        else BMT_K128_W(dst_, 0);                                                                                    \
+    } while (0)
+        const int nst = no_st ? 0 : (p.C ? 2 : 0) + (p.Chi ? 1 : 0) + (p.Clo ? 1 : 0);      // store instructions per pass; 2 passes per block
+        const int kw = 2 * nst * ncb;                                                        // ... per unit
+        int u = u0 + wid;
+        BMT_K128_LDA(n0r, u);
+        BMT_K128_LDA(n1r, u + 8);
+        BMT_K128_W(n0r, 8);                        // the weight chunk and the first unit's rows (older than the second unit's 8 loads)
+        __syncthreads();
+        bool first = true;
+        for (; u < u_end; u += 16) {
+            bf16x8 a[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(n0r[s]);
+            if (!(p.nk_dbg & 4)) BMT_K128_LDA(n0r, u + 16);
+            process(a, u);
+            if (u + 8 >= u_end) break;
+            BMT_K128_WAIT(n1r, first ? 8 + kw : 8 + 2 * kw);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(n1r[s]);
+            if (!(p.nk_dbg & 4)) BMT_K128_LDA(n1r, u + 24);
+            process(a, u + 8);
+            BMT_K128_WAIT(n0r, 8 + 2 * kw);
+            first = false;
+        }
+#undef BMT_K128_LD
+#undef BMT_K128_LDA
+#undef BMT_K128_W
+#undef BMT_K128_WAIT
+    }
+#undef BMT_K128_FRAGS
+}
+
 // MANY independent GEMMs in one launch (the weight gradients of a whole step: each dW = dY^T . X is too small to fill the chip
 // on its own -- 64 tiles for a 1024 x 1024 weight -- which is why the single launches split their reduction and pay an
 // epilogue kernel plus the workspace traffic; together they are ~3000 tiles, enough to run every reduction unsplit).
@@ -1328,6 +1629,29 @@ int launch_wide(const GemmB& p, hipStream_t st) {
     return BMT_OK;
 }
 
+template <bool F16, bool TWO, int NCB, bool LOADER>
+int launch_k128__(const GemmB& p, hipStream_t st) {
+    constexpr int lds = (TWO ? 2 : 1) * NCB * 32 * 256 + (LOADER ? 7 * 8192 + 7 * 4096 : 8 * 4096) + NCB * 32 * 4;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm_k128_kernel<F16, TWO, NCB, LOADER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_k128_kernel<F16, TWO, NCB, LOADER>), dim3(p.tiles_n * p.nk_rg), dim3(512), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16(reduction of 128)");
+    return BMT_OK;
+}
+template <bool F16, bool TWO, int NCB>
+int launch_k128_(const GemmB& p, hipStream_t st) {
+    return p.nk_loader ? launch_k128__<F16, TWO, NCB, true>(p, st) : launch_k128__<F16, TWO, NCB, false>(p, st);
+}
+// chunk widths the kernel is built for: 128 columns with two weight planes (64 KB of LDS), 128 / 256 with one
+template <bool F16>
+int launch_k128(const GemmB& p, hipStream_t st) {
+    if (p.Bl) return launch_k128_<F16, true, 4>(p, st);
+    return (p.nk_ncw == 256 && p.nk_loader) ? launch_k128_<F16, false, 8>(p, st) : launch_k128_<F16, false, 4>(p, st);
+}
+
 }  // namespace
 
 #ifdef BMT_EXP
@@ -1430,6 +1754,36 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;      // the kernel runs its second pass iff there is a second weight plane
     }
     if (p.pipe == 1) p.bm = 256;
+    // reduction of 128 with many rows (the audio stream's projections): the weight-chunk-resident kernel
+    static const int force_k128 = getenv("BMT_GEMM_K128") ? atoi(getenv("BMT_GEMM_K128")) : -1;    // A/B experiments only
+    static const int k128_ncw = getenv("BMT_GEMM_K128_NCW") ? atoi(getenv("BMT_GEMM_K128_NCW")) : 0;
+    static const int k128_loader = getenv("BMT_GEMM_K128_LOADER") ? atoi(getenv("BMT_GEMM_K128_LOADER")) : 0;
+    if (p.pipe == 2 && force_k128 != 0 && force_pipe < 0 && a->Kpad == 128 && a->M >= 2048 && a->N >= 128 && !a->colsum &&
+        !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31) && a->alpha == 1.f &&
+        // its stores are 16-byte buffer stores clipped by 32-bit descriptors, its gate / residual loads 16-byte loads
+        a->N % 8 == 0 && (!p.Chi || (p.plane_vec && (int64_t)a->M * a->ldp * 2 < (1ll << 31))) &&
+        (!a->C || (al16(a->C) && a->ldc % 4 == 0 && (int64_t)a->M * a->ldc * 4 < (1ll << 31))) &&
+        (!(a->flags & BMT_EPI_GATE) || (al16(a->gate) && a->ldg % 8 == 0)) &&
+        (!(a->flags & BMT_EPI_RESIDUAL) || (al16(a->residual) && a->ldr % 4 == 0))) {
+        if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;
+        const int cols = p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N;
+        const int units = bmt_cdiv(a->M, 32), cus = bmt_device_cus();
+        int64_t best = -1;
+        for (int ncw = 256; ncw >= 128; ncw -= 64) {
+            if (k128_ncw && ncw != k128_ncw) continue;
+            if (ncw != 128 && (p.Bl || ncw != 256 || !k128_loader)) continue;
+            const int nch = bmt_cdiv(cols, ncw);
+            int rg = cus / nch < 1 ? 1 : cus / nch;
+            const int upw = bmt_cdiv(units, rg);
+            rg = bmt_cdiv(units, upw);
+            const int64_t cost = (int64_t)bmt_cdiv(upw, k128_loader ? 7 : 8) * ncw + ncw + ncw / 2;      // rounds of units x chunk width + the chunk's load
+            if (best < 0 || cost < best) { best = cost; p.nk_ncw = ncw; p.nk_rg = rg; p.nk_upw = upw; p.tiles_n = nch; }
+        }
+        if (best >= 0) p.pipe = 4;
+        static const int k128_dbg = getenv("BMT_K128_DBG") ? atoi(getenv("BMT_K128_DBG")) : 0;
+        p.nk_dbg = k128_dbg;
+        p.nk_loader = k128_loader;
+    }
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3 || (a->precision == BMT_PREC_F16W2 && p.pipe != 1)) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
@@ -1438,7 +1792,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     // the workspace pass than the idle CUs of an unsplit launch: threshold 256 -> 180 tiles is -0.15 ms / step
     static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 180;          // A/B experiments only
     static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 4;
-    if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt && p.pipe != 3) {
+    if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt && p.pipe != 3 && p.pipe != 4) {
         // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
         static const int sk_target = getenv("BMT_SPLITK_TARGET") ? atoi(getenv("BMT_SPLITK_TARGET")) : 512;           // A/B experiments only
         int want = sk_target / tiles, cap = ktiles / 2;
@@ -1494,6 +1848,8 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     }
     if (p.pipe == 3) {
         rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
+    } else if (p.pipe == 4) {
+        rc = f16 ? launch_k128<true>(p, st_) : launch_k128<false>(p, st_);
     } else if (p.pipe == 1) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 2>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 2>(p, splitk, st_);

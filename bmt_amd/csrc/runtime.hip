@@ -70,7 +70,38 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumPack pk) 
     atomicAdd(pk.it[i].out + c, s0 + s1);
 }
 
+// many small fp32 copies in one launch (the concatenated biases of the fused projection groups after an optimizer step): same by-value pack
+struct CopyPack {
+    struct { const float* src; float* dst; int n, blk0; } it[BMT_COLSUM_MAX_ITEMS];
+    int n;
+};
+static_assert(sizeof(CopyPack) <= 4000, "the item pack must fit the kernel argument buffer");
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyPack pk) {
+    int i = 0;
+    while (i + 1 < pk.n && pk.it[i + 1].blk0 <= (int)blockIdx.x) ++i;
+    const int c = ((int)blockIdx.x - pk.it[i].blk0) * 256 + (int)threadIdx.x;
+    if (c < pk.it[i].n) pk.it[i].dst[c] = pk.it[i].src[c];
+}
+
 }  // namespace
+
+extern "C" int bmt_copy_multi(const bmt_copy_item* items, int n, void* stream) {
+    BMT_CHECK_ARG(items && n > 0, "bmt_copy_multi: bad args");
+    for (int base = 0; base < n; base += BMT_COLSUM_MAX_ITEMS) {
+        CopyPack pk;
+        pk.n = n - base < BMT_COLSUM_MAX_ITEMS ? n - base : BMT_COLSUM_MAX_ITEMS;
+        int blk = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            const bmt_copy_item& a = items[base + i];
+            BMT_CHECK_ARG(a.src && a.dst && a.n > 0, "bmt_copy_multi: bad item %d", base + i);
+            pk.it[i].src = a.src; pk.it[i].dst = a.dst; pk.it[i].n = (int)a.n; pk.it[i].blk0 = blk;
+            blk += bmt_cdiv(a.n, 256);
+        }
+        hipLaunchKernelGGL(copy_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, pk);
+        BMT_CHECK_LAUNCH("bmt_copy_multi");
+    }
+    return BMT_OK;
+}
 
 extern "C" int bmt_colsum_multi(const bmt_colsum_item* items, int n, void* stream) {
     BMT_CHECK_ARG(items && n > 0, "bmt_colsum_multi: bad args");

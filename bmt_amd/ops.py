@@ -358,7 +358,7 @@ class _WeightPlanes:
                 self._put(W, Planes(sl(big.hi), sl(big.lo), N, K, sl(big.fh), sl(big.fl)), fmt)
                 off += N
             bias = torch.empty(Nt, device=Ws[0].device, dtype=torch.float32) if all(b is not None for b in bs) else None
-            g = [[weakref.ref(W) for W in Ws], big, bias, -1, fmt, None]
+            g = [[weakref.ref(W) for W in Ws], big, bias, -1, fmt, None, [weakref.ref(b) for b in bs] if bias is not None else None]
             self.groups[key] = g
             if len(self.groups) > 4096:     # models come and go in tests
                 self.groups = {k: v for k, v in self.groups.items() if all(r() is not None for r in v[0])}
@@ -411,6 +411,29 @@ class _WeightPlanes:
         for e in self.entries:
             e[4] = e[5]._version
         self.fresh_epoch = WEIGHT_EPOCH[0]
+        self._refresh_group_biases()
+
+    def _refresh_group_biases(self):
+        """the concatenated biases of every fused projection group in ONE launch (they were 14 torch.cat launches per optimizer step, one
+        per group at its first use); a group registered later still concatenates its own (get_group)"""
+        items, touched = [], []
+        for g in self.groups.values():
+            ws_ = [r() for r in g[0]]
+            if g[2] is None or g[3] == WEIGHT_EPOCH[0] or any(w is None for w in ws_) or g[6] is None:
+                continue
+            bs_ = [r() for r in g[6]]
+            if any(b is None or b.dtype != torch.float32 or not b.is_contiguous() for b in bs_):
+                continue
+            off = 0
+            for b in bs_:
+                items.append(_lib.CopyItem(src=b.data_ptr(), dst=g[2].data_ptr() + 4 * off, n=b.numel()))
+                off += b.numel()
+            touched.append(g)
+        if items:
+            arr = (_lib.CopyItem * len(items))(*items)
+            _lib.check(lib.bmt_copy_multi(arr, len(items), _st()), "bmt_copy_multi")
+            for g in touched:
+                g[3] = WEIGHT_EPOCH[0]
 
     def get_t(self, W):
         """the transposed bf16 plane [K][pad64(N)] of a stand-alone weight [N][K]: the row-major B operand of dX = dY . W"""

@@ -165,6 +165,13 @@ typedef struct {
     int64_t ld;
 } bmt_colsum_item;
 int bmt_colsum_multi(const bmt_colsum_item* items, int n, void* stream);
+/* many small fp32 copies (dst_i[0 .. n_i) = src_i[0 .. n_i)) in one launch, items by value as above */
+typedef struct {
+    const float* src;
+    float* dst;
+    int64_t n;
+} bmt_copy_item;
+int bmt_copy_multi(const bmt_copy_item* items, int n, void* stream);
 
 /*
  * bmt_attn_fwd: O = dropout( softmax(Q K^T * scale, masked) V )   per (batch, head)

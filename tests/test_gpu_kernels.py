@@ -56,6 +56,44 @@ def test_gemm_linear_forward(ops, M, N, K, prec):
     assert_close(y, want, name=f"linear {ops.prec_name(prec)} {M}x{N}x{K}", **tol(prec, K))
 
 
+@pytest.mark.parametrize("M,N,K", [(2100, 128, 128), (4099, 1000, 100), (6400, 3072, 128), (2048, 520, 128)])
+@pytest.mark.parametrize("prec", [BF16, F16, F16W2])
+def test_gemm_reduction_of_128(ops, M, N, K, prec):
+    """the weight-chunk-resident kernel (gemm_k128_kernel: Kpad = 128, M >= 2048 -- the audio stream's projections, d_model_audio = 128):
+    fp32 output, plane outputs (padded and not), every epilogue it shares with the tile kernels, ragged M / N / K"""
+    x, W, b, res = rnd(M, K, seed=31), rnd(N, K, seed=32) * 0.05, rnd(N, seed=33), rnd(M, N, seed=34)
+    xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV)
+    fa, fb = operand_rounding(prec)
+    base = fa(x).double() @ fb(W).double().t() + b.double()
+    t = tol(prec, K)
+    y = ops.linear_fwd(xd, Wd, bd, precision=prec)
+    assert_close(y, base, name="bias", **t)
+    y = ops.linear_fwd(xd, Wd, bd, relu=True, precision=prec)
+    assert_close(y, base.clamp(min=0), name="relu", **t)
+    y = ops.linear_fwd(xd, Wd, bd, residual=rd, ldr=N, precision=prec)
+    assert_close(y, base + res.double(), name="residual", **t)
+    gate = (rnd(M, N, seed=35) > 0).float()
+    y = ops.linear_fwd(xd, Wd, None, gate=ops.make_planes(gate.to(DEV), "bwd"), gate_scale=1.25, precision=prec)
+    assert_close(y, (base - b.double()) * gate.double() * 1.25, name="gate", **t)
+    y0 = ops.linear_fwd(xd, Wd, bd, precision=prec)
+    for out_fmt, pad in (("x3", True), ("f16", False), ("f16only", False), ("f16", True)):
+        pl = ops.linear_fwd_planes(xd, Wd, bd, precision=prec, out_fmt=out_fmt, pad=pad)
+        first = pl.hi if pl.hi is not None else pl.fh
+        assert first.shape == (M, (N + 63) // 64 * 64 if pad else N)
+        if pl.hi is not None:
+            assert torch.equal(pl.hi[:, :N], y0.to(torch.bfloat16)), out_fmt
+        if pl.fh is not None:
+            assert torch.equal(pl.fh[:, :N], y0.to(torch.float16)), out_fmt
+        if pl.lo is not None:
+            assert_close(pl.hi[:, :N].float().double() + pl.lo[:, :N].float().double(), y0, atol=1e-6, rtol=2e-5, name="hi+lo planes")
+        if pad and N % 64:
+            assert float(first[:, N:].float().abs().max()) == 0
+    # the fused dropout shares the standalone kernel's mask
+    ops.manual_seed(77)
+    fused = ops.linear_fwd(xd, Wd, bd, drop_post=True, drop_p=0.25, site=991, precision=prec)
+    assert torch.equal(fused, ops.dropout_raw(y0, 0.25, 991))
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 1024, 1024), (25600, 384, 128)])
 def test_gemm_f16w2_beats_single_pass_on_weight_rounding(ops, M, N, K):
     """the point of PREC_F16W2: the weight enters exactly (hi + lo), so against the UNROUNDED-weight product it is ~2^-11/sqrt-K-accurate

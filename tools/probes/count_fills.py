@@ -69,3 +69,17 @@ torch.zeros, torch.Tensor.zero_, torch.cat = raw_zeros, raw_zero_, raw_cat
 for (kind, w, shape), n in sorted(tally.items(), key=lambda kv: -kv[1]):
     print(f"{n:3d} x {kind:6s} {str(shape):22s} {w}")
 print("total", sum(tally.values()))
+
+# what the wrappers cannot see (fills issued from C++: autograd materialising undefined gradients, ones_like of the loss ...): the profiler's view
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    step(fs, caps)
+    torch.cuda.synchronize()
+by = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add_", "aten::add"):
+        st = [f for f in (ev.stack or []) if "bmt_amd" in f]
+        by[(ev.name, st[0] if st else "(no python frame: autograd engine)", str(ev.input_shapes[:1]))] += 1
+for (name, w, shp), n in sorted(by.items(), key=lambda kv: -kv[1])[:60]:
+    print(f"{n:3d} x {name:12s} {shp:28s} {w}")

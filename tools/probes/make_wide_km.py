@@ -8,7 +8,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(ROOT, "bmt_amd", "csrc", "gemm_bf16.hip")).read()
 a = src.index('template <bool F16>\n__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wide_kernel(const GemmB p) {')
-b = src.index('// MANY independent GEMMs in one launch')
+b = src.index('// ===================================================================== reduction of 128')
 k = src[a:b]
 
 
