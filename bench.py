@@ -602,6 +602,9 @@ def main():
         # per-kernel HIP-event timing needs individual launches: the same step, eagerly issued, right after the timed region
         timer_steps = 3
         timer.enabled = True
+        # ... on ONE stream: the timed region runs the encoder's audio and video chains on two streams (ops.fork_side_stream); an event
+        # pair around a launch would time whatever else shares the GPU with it
+        enc_streams, ops.ENC_STREAMS = ops.ENC_STREAMS, 1
         # the events must see back-to-back kernels: park the GPU behind a spin kernel first, so that the host (which needs less
         # time to issue an eager step than the GPU to run it) is a full step ahead and no launch gap lands between two events
         torch.cuda._sleep(120_000_000)          # ~50 ms of shader cycles
@@ -612,6 +615,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         timer.enabled = False
+        ops.ENC_STREAMS = enc_streams
         eager_ms = ev0.elapsed_time(ev1) / timer_steps
 
     t = torch.tensor([dt, float(units_local)], dtype=torch.float64, device=dev)
@@ -702,7 +706,8 @@ def main():
                     if pm:
                         out["attention_roofline"]["pmc"] = pm
                         out["attention_roofline"]["pmc_source"] = rec_note
-            out["kernel_timer"] = {"eager_ms_per_step": eager_ms, "timed_classes_ms_per_step": tot / timer_steps,
+            out["kernel_timer"] = {"eager_ms_per_step": eager_ms, "streams": 1, "timed_region_streams": ops.ENC_STREAMS if ops._enc_streams_ok[0] else 1,
+                                   "timed_classes_ms_per_step": tot / timer_steps,
                                    "note": "HIP events on torch's current stream around every launch of a class; the GPU is parked behind a "
                                            "spin kernel first so that launches are queued back to back"}
             out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,

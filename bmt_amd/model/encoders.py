@@ -46,6 +46,9 @@ class BiModalEncoderLayer(nn.Module):
         '''
         M1, M2 = x
         M1_mask, M2_mask = masks
+        s2 = _SESSION[0]
+        if s2 is not None and M1.is_cuda:
+            return self._forward_two_streams(M1, M2, M1_mask, M2_mask, s2)
 
         # 1. self-attention on each stream
         M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask))
@@ -58,6 +61,30 @@ class BiModalEncoderLayer(nn.Module):
         M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2)
 
         return M1m2, M2m1
+
+
+    def _forward_two_streams(self, M1, M2, M1_mask, M2_mask, s2):
+        """the same operations with the M2 chain issued on the side stream: the chains meet only where a cross-modal attention reads
+        the other modality's post-self-attention value (events), and M2's chain runs on from layer to layer without joining"""
+        s1 = torch.cuda.current_stream()
+        with torch.cuda.stream(s2):
+            M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask))
+            e2 = s2.record_event()
+        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask))
+        e1 = s1.record_event()
+        s1.wait_event(e2)
+        M2.record_stream(s1)
+        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask))
+        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1)
+        with torch.cuda.stream(s2):
+            s2.wait_event(e1)
+            M1.record_stream(s2)
+            M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask))
+            M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2)
+        return M1m2, M2m1
+
+
+_SESSION = [None]        # the side stream while a BiModalEncoder.forward is running with two streams
 
 
 class Encoder(nn.Module):
@@ -82,5 +109,19 @@ class BiModalEncoder(nn.Module):
     def forward(self, x, masks: dict):
         ''' x (A, V): (B, Sm, D); masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa)}  ->  (Av, Va) '''
         A, V = x
-        Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
+        s2 = ops.fork_side_stream() if A.is_cuda else None
+        if s2 is None:
+            Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
+            return (Av, Va)
+        # audio chain on the current stream, video chain on the side stream (ops.fork_side_stream); joined before anything downstream
+        _SESSION[0] = s2
+        try:
+            V.record_stream(s2)
+            masks['V_mask'].record_stream(s2)
+            masks['A_mask'].record_stream(s2)
+            Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
+        finally:
+            _SESSION[0] = None
+        torch.cuda.current_stream().wait_stream(s2)
+        Va.record_stream(torch.cuda.current_stream())
         return (Av, Va)

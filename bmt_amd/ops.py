@@ -154,13 +154,66 @@ _contexts = {}
 _contexts_lock = __import__("threading").Lock()
 
 
+_ctx_alias = {}           # (device, side stream) -> (device, main stream): a forked branch of ONE pass shares the pass's context
+
+
 def context() -> StepContext:
     key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    key = _ctx_alias.get(key, key)
     c = _contexts.get(key)
     if c is None:
         with _contexts_lock:
             c = _contexts.setdefault(key, StepContext())
     return c
+
+
+# ---- two compute streams for the bi-modal encoder (model/encoders.py): the audio and the video stream of a layer only meet at the
+# cross-modal attention, so the video chain is issued on a side stream (forked from / joined into the stream the model runs on, also
+# under hipGraph capture, where the fork becomes parallel branches of the graph).  What is per pass stays per pass: the side stream
+# is an alias of the main stream's StepContext (queued weight gradients and small reductions are flushed once, on the main stream,
+# after autograd has joined the streams); what is per stream is already keyed by stream (split-K and grouped-GEMM scratch).
+ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "2"))     # A/B switch: 1 = everything on one stream
+_enc_streams_ok = [True]       # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
+_side_streams = {}
+
+
+def side_stream(device=None) -> "torch.cuda.Stream":
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def fork_side_stream():
+    """side stream ordered after everything issued so far on the current stream, sharing its StepContext; None when two streams are
+    switched off.  The weight planes are refreshed first: a branch must not find them half-way through the once-per-step refresh that
+    the other branch's first GEMM triggered."""
+    if ENC_STREAMS < 2 or not _enc_streams_ok[0]:
+        return None
+    with _weights.lock:
+        _weights.ensure_fresh()
+    main = torch.cuda.current_stream()
+    s2 = side_stream()
+    if s2.cuda_stream == main.cuda_stream:
+        return None
+    dev = torch.cuda.current_device()
+    _ctx_alias[(dev, s2.cuda_stream)] = _ctx_alias.get((dev, main.cuda_stream), (dev, main.cuda_stream))
+    s2.wait_stream(main)
+    return s2
+
+
+def join_side_stream():
+    """the current stream waits for the side stream: call after a backward pass whose forward forked (autograd runs a node on the stream its
+    forward ran on and orders streams along gradient edges only -- the last nodes of the side chain write static gradient buffers and queue
+    weight-gradient operands without handing anything to a node of the main stream)"""
+    s2 = _side_streams.get(torch.cuda.current_device())
+    if s2 is not None:
+        torch.cuda.current_stream().wait_stream(s2)
+
+
+def allow_encoder_streams(ok: bool):
+    _enc_streams_ok[0] = bool(ok)
 
 
 _rng_state = {}
@@ -474,6 +527,11 @@ class _WeightPlanes:
             self._refresh_all()
         return Planes(g[5], None, Ws[0].shape[1], g[5].shape[1])
 
+    def ensure_fresh(self):
+        """the once-per-optimizer-step refresh of every registered weight's planes, now (on the current stream)"""
+        if self.entries and (self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table):
+            self._refresh_all()
+
     def get(self, W, fmt):
         e = self._entry(W)
         if e is None or not e[2].has(fmt):
@@ -529,6 +587,7 @@ def weight_group(Ws, bs, fmt: str = "x3"):
 # 11.91 vs 11.70 ms / step) -- the backward products with K = 1024 are bound by their epilogue traffic, not by the operand path.
 # Kept as an A/B switch (BMT_DX_ROWMAJOR=1).
 DX_ROW_MAJOR = _os.environ.get("BMT_DX_ROWMAJOR") == "1"
+DX_K128 = _os.environ.get("BMT_DX_K128") == "1"          # A/B switch (off: the k-major tile kernel is as fast on these -- bf16 GEMM class 1.74 vs 1.78 ms same box)
 
 
 def weight_planes_t(W: torch.Tensor) -> Planes:
@@ -696,7 +755,11 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     if out is None and epi.get("out_planes") is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
     e = _weights._entry(W)
-    if DX_ROW_MAJOR and W.dim() == 2 and (e is None or e[2].any._base is None):
+    # a reduction of 128 over many rows (dX through the audio stream's out-projections, W [128][1024]): the transposed plane [1024][128] is
+    # 256 KB and takes the product to the weight-chunk-resident kernel (gemm_k128_kernel) instead of the k-major tile kernel
+    k128 = (DX_K128 and W.dim() == 2 and _pad64(W.shape[0]) == 128 and W.shape[1] % 8 == 0 and A.rows >= 2048 and epi.get("colsum") is None
+            and (e is None or e[2].any._base is None))
+    if (DX_ROW_MAJOR or k128) and W.dim() == 2 and (e is None or e[2].any._base is None):
         gemm_bf16(A, weight_planes_t(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, **epi)
     else:
         gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)

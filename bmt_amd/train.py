@@ -138,18 +138,22 @@ class CaptioningTrainStep:
             self.optimizer.zero_grad()
         x, y = caption_idx[:, :-1], caption_idx[:, 1:]
         masks = make_masks(feature_stacks, x, self.modality, self.pad_idx)
+        from . import ops as _ops
+        # the encoder's two compute streams: not while gradient buckets are all-reduced from inside the backward pass (a bucket's
+        # "final" event is recorded on ONE stream)
+        _ops.allow_encoder_streams(self.reducer is None or self.reducer.world == 1 or not self.reducer.overlap)
         pred = model(feature_stacks, x, masks)
         n_tokens = (y != self.pad_idx).sum()
         kl = self.criterion(pred, y)
         # the weight-gradient GEMMs of the whole backward pass go out as one grouped launch -- unless gradients are all-reduced
         # bucket by bucket from the backward hooks, which needs them finished in autograd order
-        from . import ops as _ops
         sctx = _ops.context()
         # with bucket-by-bucket overlap the queue is flushed at the layer boundaries (_install_flush_points); without flush points
         # the products run where autograd reaches them, so that a bucket is final when its last hook fires
         sctx.defer_dw = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap or self._flush_points > 0)
         try:
             kl.backward()
+            _ops.join_side_stream()
             _ops.flush_dw()
         finally:
             sctx.defer_dw = False
@@ -364,8 +368,11 @@ class ProposalTrainStep:
         else:
             self.optimizer.zero_grad()
         masks = make_masks(feature_stacks, None, self.modality, self.pad_idx)
+        from . import ops as _ops
+        _ops.allow_encoder_streams(self.reducer is None or self.reducer.world == 1 or not self.reducer.overlap)
         predictions, loss, losses_A, losses_V = model(feature_stacks, targets, masks)
         loss.backward()
+        _ops.join_side_stream()
         if self.reducer is not None:
             self.reducer.finish()
         if getattr(self.cfg, "grad_clip", None) is not None:

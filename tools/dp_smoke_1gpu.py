@@ -79,7 +79,9 @@ def main():
     modes = ("dp_graph", "dp_eager_overlap", "dp_eager_after") + (("dp_graph_overlap",) if "--graph-overlap" in sys.argv else ())
     for mode in modes:
         got, n = run(mode)
-        same = all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(got, ref))
+        # 1e-4: a missing collective or a wrong normaliser is a >= 1e-2 difference; fp32 atomics (bias column sums) make the fourth step's
+        # loss of ONE configuration wander by ~3e-6 from run to run
+        same = all(abs(a - b) <= 1e-4 * abs(b) for a, b in zip(got, ref))
         ok &= same and n > 0
         print(f"{mode:18s} all_reduce calls {n:3d}  losses {'match' if same else 'DIFFER from'} the single-process step {got if not same else ''}")
     print("single            ", ref)

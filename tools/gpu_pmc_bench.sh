@@ -5,6 +5,7 @@
 #      matches the tree).   usage: tools/gpu_pmc_bench.sh <tag> [train_cap|train_prop]
 TAG=${1:-x}; PROC=${2:-train_cap}
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}
+export BMT_ENC_STREAMS=1   # kernels one at a time: isolated durations / counters (the bench's timed region forks two streams)
 cd /tmp
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel time of the eagerly issued train_cap step: rocprofv3 --kernel-trace --stats -> gpurun_out/<tag>_kernel_stats.csv (+ raw stats csv)
 TAG=${1:-x}; STEPS=${2:-6}
-mkdir -p gpurun_out; export TMPDIR=/tmp
+mkdir -p gpurun_out; export TMPDIR=/tmp; export BMT_ENC_STREAMS=1   # kernels one at a time: isolated durations / counters (the bench's timed region forks two streams)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o p -- python $R/bench.py --steps $STEPS --warmup 3 --no-graph --no-cpu-baseline --no-kernel-timer --no-clock-probe > $R/gpurun_out/${TAG}_prof_run.log 2>&1; echo "rocprof rc=$?"
 cd $R
