@@ -1791,7 +1791,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     // measured (tools/gpu_ab.sh, whole step): splitting the 200-tile products of the audio stream (25600 x 128 outputs) costs more in
     // the workspace pass than the idle CUs of an unsplit launch: threshold 256 -> 180 tiles is -0.15 ms / step
     static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 180;          // A/B experiments only
-    static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 4;
+    static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 12;
     if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt && p.pipe != 3 && p.pipe != 4) {
         // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
         static const int sk_target = getenv("BMT_SPLITK_TARGET") ? atoi(getenv("BMT_SPLITK_TARGET")) : 512;           // A/B experiments only

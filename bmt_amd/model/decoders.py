@@ -50,8 +50,21 @@ class BiModalDecoderLayer(nn.Module):
         Av, Va = memory
 
         C = self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, masks['C_mask']))
-        Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']))
-        Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']))
+        # the two encoder-decoder attentions read the same C and different memories: the video one (with its projections of the memory)
+        # on the side stream (ops.fork_side_stream), joined before the bridge
+        s2 = ops.fork_side_stream() if C.is_cuda else None
+        if s2 is None:
+            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']))
+            Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']))
+        else:
+            s1 = torch.cuda.current_stream()
+            for t in (C, Va, masks['V_mask']):
+                t.record_stream(s2)
+            with torch.cuda.stream(s2):
+                Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']))
+            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']))
+            s1.wait_stream(s2)
+            Cv.record_stream(s1)
         # (B, Sc, 2*Dc) -> bridge -> (B, Sc, Dc); no residual across the bridge
         C = self.bridge(torch.cat([Ca, Cv], dim=-1))
         C = self.res_layer_ff(C, self.feed_forward)
