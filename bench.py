@@ -317,6 +317,9 @@ def PMC_FAMILY_OF_KERNEL(name: str) -> str:
         return "gemm_w2"            # the step's fp16 products are all two-plane (ops.POLICIES); a one-plane fp16 launch would land here too
     if n.startswith("gemm_wide_kernel<false"):
         return "gemm_bf16"
+    m = re.match(r"gemm_k128_kernel<(true|false), (true|false)", n)          # <F16, TWO planes, ...>: the reduction-of-128 products
+    if m:
+        return "gemm_w2" if m.group(2) == "true" else ("gemm_f16" if m.group(1) == "true" else "gemm_bf16")
     if n.startswith("attn_fwd"):
         return "attn_fwd"
     if n.startswith("attn_bwd_dq"):

@@ -160,8 +160,7 @@ class BiModalTransformer(nn.Module):
             A = self.pos_enc_A(self.emb_A(A))
         return self.encoder((A, V), masks)
 
-    def decode(self, trg, memory, masks: dict):
-        """caption prefix + encoder memory -> decoder states (B, Sc, Dc)  (reference :172-173,182-184)"""
+    def embed_caption(self, trg):
         C = trg
         if isinstance(self.emb_C.embedder, nn.Embedding):
             pc = self.pos_enc_C
@@ -169,11 +168,30 @@ class BiModalTransformer(nn.Module):
                        p=pc.dout_p if self.training else 0.0, site=pc._site)
         else:
             C = self.pos_enc_C(self.emb_C(C))
-        return self.decoder((C, memory), masks)
+        return C
+
+    def decode(self, trg, memory, masks: dict):
+        """caption prefix + encoder memory -> decoder states (B, Sc, Dc)  (reference :172-173,182-184)"""
+        return self.decoder((self.embed_caption(trg), memory), masks)
 
     def forward(self, src: dict, trg, masks: dict):
         if self.training:
             ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
+        # the caption embedding and the first decoder layer's self-attention sublayer do not depend on the encoder: they are issued on a
+        # side stream (ops.fork_side_stream) beside it -- and so is their backward, beside the encoder's
+        s3 = ops.fork_side_stream(1) if (trg.is_cuda and hasattr(self.decoder, "decoder")) else None
+        if s3 is None:
+            memory = self.encode(src, masks)
+            C = self.decode(trg, memory, masks)
+            return self.generator(C)
+        s1 = torch.cuda.current_stream()
+        first = self.decoder.decoder.layers[0]
+        for t in (trg, masks['C_mask']):
+            t.record_stream(s3)
+        with torch.cuda.stream(s3):
+            C = first.self_attention_sublayer(self.embed_caption(trg), masks['C_mask'])
         memory = self.encode(src, masks)
-        C = self.decode(trg, memory, masks)
-        return self.generator(C)
+        s1.wait_stream(s3)
+        C.record_stream(s1)
+        C._bmt_self_att_done = True
+        return self.generator(self.decoder((C, memory), masks))

@@ -40,6 +40,9 @@ class BiModalDecoderLayer(nn.Module):
         self.feed_forward = PositionwiseFeedForward(d_model_C, d_ff_C, dout_p)
         ops.tag_policy(self, "dec")     # MFMA operand formats of this layer's products (bmt_amd.ops.POLICIES)
 
+    def self_attention_sublayer(self, C, C_mask):
+        return self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, C_mask))
+
     def forward(self, x, masks):
         '''
         x (C, memory): C: (B, Sc, Dc), memory: (Av: (B, Sa, Da), Va: (B, Sv, Dv))
@@ -49,7 +52,8 @@ class BiModalDecoderLayer(nn.Module):
         C, memory = x
         Av, Va = memory
 
-        C = self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, masks['C_mask']))
+        if not getattr(C, "_bmt_self_att_done", False):          # (BiModalTransformer.forward runs the first layer's beside the encoder)
+            C = self.self_attention_sublayer(C, masks['C_mask'])
         # the two encoder-decoder attentions read the same C and different memories: the video one (with its projections of the memory)
         # on the side stream (ops.fork_side_stream), joined before the bridge
         s2 = ops.fork_side_stream() if C.is_cuda else None

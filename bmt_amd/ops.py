@@ -177,24 +177,25 @@ _enc_streams_ok = [True]       # cleared by a train step whose gradient reducer 
 _side_streams = {}
 
 
-def side_stream(device=None) -> "torch.cuda.Stream":
+def side_stream(device=None, index: int = 0) -> "torch.cuda.Stream":
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    s = _side_streams.get(dev)
+    s = _side_streams.get((dev, index))
     if s is None:
-        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        s = _side_streams[(dev, index)] = torch.cuda.Stream(device=dev)
     return s
 
 
-def fork_side_stream():
+def fork_side_stream(index: int = 0):
     """side stream ordered after everything issued so far on the current stream, sharing its StepContext; None when two streams are
     switched off.  The weight planes are refreshed first: a branch must not find them half-way through the once-per-step refresh that
-    the other branch's first GEMM triggered."""
-    if ENC_STREAMS < 2 or not _enc_streams_ok[0]:
+    the other branch's first GEMM triggered.  index 0: the encoder's video chain / a decoder layer's video attention; 1: the decoder's
+    first self-attention sublayer, which does not depend on the encoder (model/captioning_module.py)."""
+    if ENC_STREAMS < 2 + index or not _enc_streams_ok[0]:
         return None
     with _weights.lock:
         _weights.ensure_fresh()
     main = torch.cuda.current_stream()
-    s2 = side_stream()
+    s2 = side_stream(index=index)
     if s2.cuda_stream == main.cuda_stream:
         return None
     dev = torch.cuda.current_device()
@@ -207,9 +208,10 @@ def join_side_stream():
     """the current stream waits for the side stream: call after a backward pass whose forward forked (autograd runs a node on the stream its
     forward ran on and orders streams along gradient edges only -- the last nodes of the side chain write static gradient buffers and queue
     weight-gradient operands without handing anything to a node of the main stream)"""
-    s2 = _side_streams.get(torch.cuda.current_device())
-    if s2 is not None:
-        torch.cuda.current_stream().wait_stream(s2)
+    dev = torch.cuda.current_device()
+    for (d, _), s2 in list(_side_streams.items()):
+        if d == dev:
+            torch.cuda.current_stream().wait_stream(s2)
 
 
 def allow_encoder_streams(ok: bool):
