@@ -103,6 +103,7 @@ class CaptioningTrainStep:
         self._flush_points = 0
         if data_parallel:
             self._install_flush_points()
+        self._install_early_dw()
 
     def _install_flush_points(self):
         """Overlap of the gradient all-reduce with the backward pass (eager launches, ``reducer.overlap``): the weight-gradient
@@ -126,6 +127,33 @@ class CaptioningTrainStep:
         for layer in stack:
             layer.register_forward_hook(attach)
             self._flush_points += 1
+
+    def _install_early_dw(self):
+        """without bucket-by-bucket overlap the weight-gradient products of the whole backward pass are queued for ONE grouped launch
+        at its end (1.05 ms alone on the GPU, DESIGN §6 finding 9).  When the encoder runs on two compute streams, what is queued by the
+        time the backward pass crosses into an earlier encoder layer -- later layers, decoder, generator -- is issued there on a third
+        stream (ops.flush_dw_early), beside the remaining layers' backward."""
+        from . import ops as _ops
+        stack = getattr(getattr(getattr(self.model, "encoder", None), "encoder_AV", None), "layers", None)
+        if stack is None:
+            return
+        step = self
+
+        def attach(mod, inp, out):
+            if not torch.is_grad_enabled() or (step.reducer is not None and step.reducer.overlap and step.reducer.world > 1):
+                return
+            ts = [t for t in (out if isinstance(out, (tuple, list)) else (out,)) if isinstance(t, torch.Tensor) and t.requires_grad]
+            left = [len(ts)]
+
+            def fired(g):
+                left[0] -= 1
+                if left[0] == 0:          # both chains have crossed: everything of the later layers is queued
+                    _ops.flush_dw_early()
+                return g
+            for t in ts:
+                t.register_hook(fired)
+        for layer in stack:
+            layer.register_forward_hook(attach)
 
     # ---- the three phases -------------------------------------------------------------------------------------
     def _forward_backward(self, feature_stacks, caption_idx):
