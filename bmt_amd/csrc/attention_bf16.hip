@@ -2346,8 +2346,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // mask: every key counts).  Block = 128 columns (16 threads x 16 bytes) x 32 key groups; every load is unconditional and independent
 // (the mask byte is a multiplier) so the key loop unrolls into batches of loads in flight -- a `continue` on the mask byte made
 // every iteration a dependent L2 round trip (100 us per call instead of 7).  grid (B, ceil(D / 128)).
+// ks: every ks-th key is read.  The mean key is a SHIFT, not a quantity of the mathematics: rows of dS sum to zero, so dS . (K - m) = dS . K
+// for any m, and what the correction needs from m is the keys' common component -- which the mean of every 8th key carries as well as the
+// mean of all of them, for an eighth of the 52 MB an 800-key audio memory costs to read (31 us per launch, 12 launches per step).
 __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restrict__ Kh, int64_t ldk, int64_t bsk, const uint8_t* __restrict__ mask,
-                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out, int f16) {
+                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out, int f16, int ks) {
     constexpr int KG = 32;
     __shared__ float red[KG][129];
     __shared__ float cnt[KG];
@@ -2359,7 +2362,7 @@ __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restr
     const uint16_t* base = Kh + (int64_t)b * bsk + (cok ? c0 : 0);
     const uint8_t* mb = mask ? mask + (int64_t)b * mask_bs : nullptr;
 #pragma unroll 8
-    for (int k = kg; k < Sk; k += KG) {
+    for (int k = kg * ks; k < Sk; k += KG * ks) {
         const float m = mb ? (mb[k] != 0 ? 1.f : 0.f) : 1.f;
         u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)k * ldk);
         if (f16) v = h8_to_b8(v);          // (uniform) the fp16 plane: same values the backward kernels will multiply
@@ -3319,8 +3322,10 @@ extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, cons
     BMT_CHECK_ARG(Kh && out && B > 0 && Sk > 0 && D > 0 && D % 8 == 0 && ldk % 8 == 0 && bsk % 8 == 0 &&
                       (reinterpret_cast<uintptr_t>(Kh) & 15) == 0,
                   "bmt_attn_kmean: bad args (D, ldk, bsk multiples of 8, 16-byte aligned plane)");
+    static const int ks_env = getenv("BMT_KMEAN_STRIDE") ? atoi(getenv("BMT_KMEAN_STRIDE")) : 0;      // A/B experiments only
+    const int ks = ks_env > 0 ? ks_env : (Sk >= 256 ? 8 : 1);
     hipLaunchKernelGGL(attn_kmean_kernel, dim3(B, bmt_cdiv(D, 128)), dim3(512), 0, (hipStream_t)stream, Kh, ldk, bsk,
-                       mask_qs == 0 ? mask : nullptr, mask_bs, Sk, D, out, k_f16);
+                       mask_qs == 0 ? mask : nullptr, mask_bs, Sk, D, out, k_f16, ks);
     BMT_CHECK_LAUNCH("bmt_attn_kmean");
     return BMT_OK;
 }

@@ -96,7 +96,25 @@ class BiModelDecoder(nn.Module):
         self.decoder = LayerStack(layer, N)
 
     def forward(self, x, masks):
-        C, memory = self.decoder(x, masks)
+        # the K / V projections of the two memories for every layer depend on the encoder only: issued on the side stream now, beside
+        # the first layer's self-attention (ops.prefetch_kv); not while a greedy decode keeps its own cache of them
+        C0, (Av, Va) = x
+        s4 = None
+        if Av.is_cuda and ops.KV_PREFETCH and ops.context().kv_cache is None:
+            s4 = ops.fork_side_stream(3, need=2)       # its own stream: a layer's video attention must not queue behind the next layer's projections
+            if s4 is not None:
+                for t in (Av, Va):
+                    t.record_stream(s4)
+                with torch.cuda.stream(s4):
+                    for layer in self.decoder.layers:
+                        layer.enc_att_V.prefetch_kv(Va)
+                        layer.enc_att_A.prefetch_kv(Av)
+        try:
+            C, memory = self.decoder(x, masks)
+        finally:
+            ops.drop_prefetched_kv()
+            if s4 is not None:
+                torch.cuda.current_stream().wait_stream(s4)
         return C
 
 

@@ -185,12 +185,13 @@ def side_stream(device=None, index: int = 0) -> "torch.cuda.Stream":
     return s
 
 
-def fork_side_stream(index: int = 0):
+def fork_side_stream(index: int = 0, need: int = 0):
     """side stream ordered after everything issued so far on the current stream, sharing its StepContext; None when two streams are
     switched off.  The weight planes are refreshed first: a branch must not find them half-way through the once-per-step refresh that
     the other branch's first GEMM triggered.  index 0: the encoder's video chain / a decoder layer's video attention; 1: the decoder's
-    first self-attention sublayer, which does not depend on the encoder (model/captioning_module.py)."""
-    if ENC_STREAMS < 2 + index or not _enc_streams_ok[0]:
+    first self-attention sublayer, which does not depend on the encoder (model/captioning_module.py); 3: the decoder's K / V
+    projections of the encoder memories (ops.prefetch_kv; ``need`` = the BMT_ENC_STREAMS level that switches a use on)."""
+    if ENC_STREAMS < (need or 2 + index) or not _enc_streams_ok[0]:
         return None
     with _weights.lock:
         _weights.ensure_fresh()
@@ -1607,6 +1608,54 @@ def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key, pol):
     return linear_fwd(o, Wo, bo, precision=pol.gemm).view(B, Sq, Dq)
 
 
+# ---- the K / V projections of an encoder memory, ahead of the attention that reads them.  A decoder layer's encoder-decoder attentions
+# project the SAME memory for every layer and their projections (the only large kernels of the decoder phase) depend on the encoder alone:
+# BiModelDecoder.forward issues all of them on the side stream while the first layer's self-attention runs.  Only the forward product is
+# taken out of MHAFn -- its backward (dX w.r.t. the memory, dW) works from the saved planes as before.
+KV_PREFETCH = _os.environ.get("BMT_KV_PREFETCH") == "1"      # A/B switch: off (measured: 8.80 vs 8.79 ms/step same box -- no gain)
+_kv_prefetched = {}      # (id(memory tensor), id(Wk)) -> (memory, Wk, k planes, v planes, event, stream)
+
+
+def prefetch_kv(K: torch.Tensor, Wk, bk, Wv, bv, pol, H: int) -> bool:
+    """project ``K`` (an encoder memory; K is V) with a cross-attention's key / value weights on the CURRENT stream and keep the planes for
+    the MHAFn.forward that will ask for them (take_prefetched_kv); False if this projection is not the fused one MHAFn would run."""
+    if not KV_PREFETCH or not K.is_cuda:
+        return False
+    note_use(Wk, bk, Wv, bv)
+    Kc = _f32c(K)
+    prec_kv = pol.kv_gemm
+    D = Wk.shape[0]
+    qkv_fmt = attn_train_fmt(pol.attn, D // H) if torch.is_grad_enabled() else attn_operand_fmt(pol.attn)
+    Kp = planes_of(K, act_fmt(prec_kv))
+    if Kp is None:
+        Kp = make_planes(Kc.view(-1, Kc.shape[-1]), act_fmt(prec_kv))
+        attach_planes(K, Kp)
+    r = project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
+    if r is None:
+        return False
+    st = torch.cuda.current_stream()
+    _kv_prefetched[(id(K), id(Wk))] = (K, Wk, r[0], r[1], st.record_event(), st, qkv_fmt)
+    return True
+
+
+def take_prefetched_kv(K, Wk, qkv_fmt):
+    ent = _kv_prefetched.pop((id(K), id(Wk)), None)
+    if ent is None or ent[0] is not K or ent[1] is not Wk or ent[6] != qkv_fmt:
+        return None
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream != ent[5].cuda_stream:
+        cur.wait_event(ent[4])
+        for pl in (ent[2], ent[3]):
+            for t in (pl.hi, pl.lo, pl.fh, pl.fl):
+                if t is not None:
+                    t.record_stream(cur)
+    return ent[2], ent[3]
+
+
+def drop_prefetched_kv():
+    _kv_prefetched.clear()
+
+
 class MHAFn(torch.autograd.Function):
     """MultiheadedAttention.forward model/multihead_attention.py:55-86: three input projections, the masked
     softmax-attention core with dropout on its OUTPUT (:22-23), head merge and output projection.
@@ -1646,7 +1695,7 @@ class MHAFn(torch.autograd.Function):
             if r is not None:
                 (q, k, v), fuse = r, "qkv"
         elif same_kv:
-            r = project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
+            r = take_prefetched_kv(K, Wk, qkv_fmt) or project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
             if r is not None:
                 (k, v), fuse = r, "kv"
         if q is None:

@@ -280,8 +280,10 @@ int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_pds, 
  * up by a finishing launch instead of ~900 workgroups adding into the same H * d_k floats.  Element count (0 for d_k < 128: pass NULL): */
 int64_t bmt_attn_bwd_bias_ws(int B, int H, int Sq, int Sk, int dk);
 /* out[b][c] = mean over the valid keys k of K[b][k][c] (bf16 plane, row stride ldk, batch stride bsk; mask: key-padding bytes [B][Sk]
-   when mask_qs == 0, otherwise -- no mask or one row per query -- every key counts).  No counterpart in the reference: numerical aid of
-   the bf16 backward (model/multihead_attention.py:8-26 is exact in fp32). */
+   when mask_qs == 0, otherwise -- no mask or one row per query -- every key counts).  From Sk = 256 on the mean is taken over every 8th key:
+   the vector is a shift (any value leaves dS . K unchanged in exact arithmetic since rows of dS sum to zero), what matters is that it
+   carries the keys' common component.  No counterpart in the reference: numerical aid of the 16-bit backward
+   (model/multihead_attention.py:8-26 is exact in fp32). */
 int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk, int D,
                    float* out, int k_f16, void* stream);     /* k_f16: the plane holds fp16 */
 
