@@ -184,15 +184,17 @@ class ResidualConnection(nn.Module):
         self.dropout = nn.Dropout(dout_p)
         self._site = ops.new_site()
 
-    def forward(self, x, sublayer):
-        # x (B, S, D):  x + dropout(sublayer(LN(x)))
+    def forward(self, x, sublayer, fp32_out=True):
+        # x (B, S, D):  x + dropout(sublayer(LN(x)));  fp32_out False (the bi-modal layers' calls): LN(x) is handed to the sublayer as
+        # operand planes only (ops.residual_norm)
         p = self.dout_p if self.training else 0.0
         if not ops.FUSE_RESIDUAL:
             res = sublayer(layer_norm(self.norm, x))
             return ops.DropoutAddFn.apply(x, res, p, self._site)
         # fused form (ops.ResidualNormFn): LN emits its operand planes, the sublayer's last GEMM takes the offered residual and
         # adds dropout + x in its epilogue; a sublayer that does not take the offer gets the separate kernel
-        xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm)
+        xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm,
+                                    fp32_out=fp32_out or not ops.LN_PLANES_ONLY)
         off = ops.offer_residual(xid, p, self._site)
         res = sublayer(xn)
         ops.take_residual()

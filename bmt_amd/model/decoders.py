@@ -41,7 +41,7 @@ class BiModalDecoderLayer(nn.Module):
         ops.tag_policy(self, "dec")     # MFMA operand formats of this layer's products (bmt_amd.ops.POLICIES)
 
     def self_attention_sublayer(self, C, C_mask):
-        return self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, C_mask))
+        return self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, C_mask), fp32_out=False)
 
     def forward(self, x, masks):
         '''
@@ -58,20 +58,20 @@ class BiModalDecoderLayer(nn.Module):
         # on the side stream (ops.fork_side_stream), joined before the bridge
         s2 = ops.fork_side_stream() if C.is_cuda else None
         if s2 is None:
-            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']))
-            Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']))
+            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)
+            Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
         else:
             s1 = torch.cuda.current_stream()
             for t in (C, Va, masks['V_mask']):
                 t.record_stream(s2)
             with torch.cuda.stream(s2):
-                Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']))
-            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']))
+                Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
+            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)
             s1.wait_stream(s2)
             Cv.record_stream(s1)
         # (B, Sc, 2*Dc) -> bridge -> (B, Sc, Dc); no residual across the bridge
         C = self.bridge(torch.cat([Ca, Cv], dim=-1))
-        C = self.res_layer_ff(C, self.feed_forward)
+        C = self.res_layer_ff(C, self.feed_forward, fp32_out=False)
 
         return C, memory
 

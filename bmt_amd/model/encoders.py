@@ -46,19 +46,19 @@ class BiModalEncoderLayer(nn.Module):
         '''
         M1, M2 = x
         M1_mask, M2_mask = masks
-        s2 = _SESSION[0]
+        s2 = getattr(_SESSION, "s2", None)
         if s2 is not None and M1.is_cuda:
             return self._forward_two_streams(M1, M2, M1_mask, M2_mask, s2)
 
         # 1. self-attention on each stream
-        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask))
-        M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask))
+        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask), fp32_out=False)
+        M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask), fp32_out=False)
         # 2. cross-modal attention: queries are the normalised stream, keys/values the OTHER stream as it is now
-        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask))
-        M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask))
+        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask), fp32_out=False)
+        M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask), fp32_out=False)
         # 3. feed-forward
-        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1)
-        M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2)
+        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1, fp32_out=False)
+        M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2, fp32_out=False)
 
         return M1m2, M2m1
 
@@ -68,23 +68,23 @@ class BiModalEncoderLayer(nn.Module):
         the other modality's post-self-attention value (events), and M2's chain runs on from layer to layer without joining"""
         s1 = torch.cuda.current_stream()
         with torch.cuda.stream(s2):
-            M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask))
+            M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask), fp32_out=False)
             e2 = s2.record_event()
-        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask))
+        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask), fp32_out=False)
         e1 = s1.record_event()
         s1.wait_event(e2)
         M2.record_stream(s1)
-        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask))
-        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1)
+        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask), fp32_out=False)
+        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1, fp32_out=False)
         with torch.cuda.stream(s2):
             s2.wait_event(e1)
             M1.record_stream(s2)
-            M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask))
-            M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2)
+            M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask), fp32_out=False)
+            M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2, fp32_out=False)
         return M1m2, M2m1
 
 
-_SESSION = [None]        # the side stream while a BiModalEncoder.forward is running with two streams
+_SESSION = __import__("threading").local()        # .s2: the side stream while a BiModalEncoder.forward is running with two streams (per thread)
 
 
 class Encoder(nn.Module):
@@ -114,14 +114,14 @@ class BiModalEncoder(nn.Module):
             Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
             return (Av, Va)
         # audio chain on the current stream, video chain on the side stream (ops.fork_side_stream); joined before anything downstream
-        _SESSION[0] = s2
+        _SESSION.s2 = s2
         try:
             V.record_stream(s2)
             masks['V_mask'].record_stream(s2)
             masks['A_mask'].record_stream(s2)
             Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
         finally:
-            _SESSION[0] = None
+            _SESSION.s2 = None
         torch.cuda.current_stream().wait_stream(s2)
         Va.record_stream(torch.cuda.current_stream())
         return (Av, Va)

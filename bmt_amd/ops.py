@@ -177,11 +177,14 @@ _enc_streams_ok = [True]       # cleared by a train step whose gradient reducer 
 _side_streams = {}
 
 
-def side_stream(device=None, index: int = 0) -> "torch.cuda.Stream":
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    s = _side_streams.get((dev, index))
+def side_stream(index: int = 0, main=None) -> "torch.cuda.Stream":
+    """side stream ``index`` of a main stream (default: the current one): every main stream has its own, so that two models stepping
+    from two threads on two streams of one device do not meet on a shared side stream"""
+    main = torch.cuda.current_stream() if main is None else main
+    key = (main.device.index, main.cuda_stream, index)
+    s = _side_streams.get(key)
     if s is None:
-        s = _side_streams[(dev, index)] = torch.cuda.Stream(device=dev)
+        s = _side_streams[key] = torch.cuda.Stream(device=main.device)
     return s
 
 
@@ -196,20 +199,21 @@ def fork_side_stream(index: int = 0, need: int = 0):
     with _weights.lock:
         _weights.ensure_fresh()
     main = torch.cuda.current_stream()
-    s2 = side_stream(index=index)
-    if s2.cuda_stream == main.cuda_stream:
-        return None
     dev = torch.cuda.current_device()
-    _ctx_alias[(dev, s2.cuda_stream)] = _ctx_alias.get((dev, main.cuda_stream), (dev, main.cuda_stream))
+    mkey = _ctx_alias.get((dev, main.cuda_stream))
+    if mkey is not None:          # called on a side stream (a decoder layer inside a forked branch): no nested fork
+        return None
+    s2 = side_stream(index, main)
+    _ctx_alias[(dev, s2.cuda_stream)] = (dev, main.cuda_stream)
     if index == 0:
-        _fork_main[dev] = main
+        _fork_main[(dev, main.cuda_stream)] = main
     s2.wait_stream(main)
     return s2
 
 
 EARLY_DW = _os.environ.get("BMT_EARLY_DW") == "1"      # A/B switch for flush_dw_early: off (measured 9.27-9.36 vs 8.99 ms/step same box: three
                                                       # smaller grouped launches that share the GPU with the backward cost more than the lone one)
-_fork_main = {}           # device -> the stream the last two-stream encoder pass was forked from
+_fork_main = {}           # (device, main stream handle) -> the stream object a two-stream encoder pass was forked from
 
 
 def flush_dw_early() -> bool:
@@ -221,14 +225,15 @@ def flush_dw_early() -> bool:
     if not EARLY_DW or ENC_STREAMS < 2 or not _enc_streams_ok[0]:
         return False
     dev = torch.cuda.current_device()
-    main = _fork_main.get(dev)
+    cur = torch.cuda.current_stream().cuda_stream
+    main = _fork_main.get(_ctx_alias.get((dev, cur), (dev, cur)))
     ctx = context()
     if main is None or not ctx.defer_dw or not (ctx.pending_dw or ctx.pending_cs):
         return False
-    s3 = side_stream(index=2)
-    _ctx_alias[(dev, s3.cuda_stream)] = _ctx_alias.get((dev, main.cuda_stream), (dev, main.cuda_stream))
+    s3 = side_stream(2, main)
+    _ctx_alias[(dev, s3.cuda_stream)] = (dev, main.cuda_stream)
     s3.wait_stream(main)
-    s3.wait_stream(side_stream(index=0))
+    s3.wait_stream(side_stream(0, main))
     for dyT, xT, _ in ctx.pending_dw:
         for pl in (dyT, xT):
             for t in (pl.hi, pl.lo, pl.fh, pl.fl):
@@ -242,13 +247,13 @@ def flush_dw_early() -> bool:
 
 
 def join_side_stream():
-    """the current stream waits for the side stream: call after a backward pass whose forward forked (autograd runs a node on the stream its
+    """the current stream waits for its side streams: call after a backward pass whose forward forked (autograd runs a node on the stream its
     forward ran on and orders streams along gradient edges only -- the last nodes of the side chain write static gradient buffers and queue
     weight-gradient operands without handing anything to a node of the main stream)"""
-    dev = torch.cuda.current_device()
-    for (d, _), s2 in list(_side_streams.items()):
-        if d == dev:
-            torch.cuda.current_stream().wait_stream(s2)
+    cur = torch.cuda.current_stream()
+    for (d, m, _), s2 in list(_side_streams.items()):
+        if d == cur.device.index and m == cur.cuda_stream:
+            cur.wait_stream(s2)
 
 
 def allow_encoder_streams(ok: bool):
@@ -1261,6 +1266,7 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
 # backward adds the residual stream's gradient to its own (no autograd add pass).  The residual is OFFERED to the sublayer
 # through a module-level slot; MultiheadedAttention / PositionwiseFeedForward take it, anything else leaves it and the
 # ResidualConnection falls back to the separate dropout_add kernel.
+LN_PLANES_ONLY = _os.environ.get("BMT_LN_FP32") != "1"        # A/B switch: "1" = every LayerNorm output also as fp32 values
 FUSE_RESIDUAL = _os.environ.get("BMT_NO_FUSE_RES") != "1"
 
 
@@ -1293,6 +1299,13 @@ def planes_of(t, fmt: str):
     return pl
 
 
+def _need_fp32(t):
+    """a consumer is about to read the fp32 values of ``t``: not possible for a LayerNorm output that was asked for as planes only"""
+    if getattr(t, "_bmt_no_fp32", False):
+        raise RuntimeError("this LayerNorm output exists as operand planes only (ResidualConnection(..., fp32_out=False)) and its consumer "
+                           "asked for a plane format it was not written in: call the ResidualConnection with fp32_out=True")
+
+
 def attach_planes(t, pl: Planes):
     if isinstance(t, torch.Tensor):
         t._bmt_planes, t._bmt_planes_version = pl, t._version
@@ -1305,18 +1318,18 @@ class ResidualNormFn(torch.autograd.Function):
     reads."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fmt):
+    def forward(ctx, x, gamma, beta, eps, fmt, fp32_out=True):
         note_use(gamma, beta)
         xc = _f32c(x)
         D = xc.shape[-1]
         x2 = xc.view(-1, D)
         rows = x2.shape[0]
-        y = torch.empty_like(x2)
+        y = torch.empty_like(x2)          # fp32_out False: never written (13-34 MB of stores per encoder LayerNorm nothing would read)
         pl = _alloc_planes(rows, D, fmt, x.device)
         second = pl.lo if pl.lo is not None else pl.fh
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), _p(pl.hi), _p(second),
+        _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y) if fp32_out else None, D, _p(mean), _p(rstd), _p(pl.hi), _p(second),
                                                 int(pl.fh is not None), pl.hi.stride(0), rows, D, eps, _st()), "bmt_layernorm_fwd_planes")
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
@@ -1326,7 +1339,7 @@ class ResidualNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_id, g_n):
         if g_n is None:
-            return g_id, None, None, None, None
+            return g_id, None, None, None, None, None
         x2, gamma, mean, rstd = ctx.saved_tensors
         rows, D = x2.shape
         dy2 = _f32c(g_n).view(rows, D)
@@ -1351,17 +1364,20 @@ class ResidualNormFn(torch.autograd.Function):
         if fused:
             grad_done(gamma)
             grad_done(beta)
-            return dx, None, None, None, None
-        return dx, dg, db, None, None
+            return dx, None, None, None, None, None
+        return dx, dg, db, None, None, None
 
 
-def residual_norm(x, gamma, beta, eps, prec: int = PREC_BF16X3):
+def residual_norm(x, gamma, beta, eps, prec: int = PREC_BF16X3, fp32_out: bool = True):
     """(x passed through, LayerNorm(x) carrying its operand planes as ``_bmt_planes``); prec: the forward precision of the
-    sublayer's first GEMM"""
-    xid, xn = ResidualNormFn.apply(x, gamma, beta, eps, act_fmt(prec))
+    sublayer's first GEMM.  fp32_out False: the normalised tensor's fp32 values are not written -- for sublayers that read the planes
+    (MultiheadedAttention, PositionwiseFeedForward); a consumer that would need the values raises (_need_fp32)."""
+    xid, xn = ResidualNormFn.apply(x, gamma, beta, eps, act_fmt(prec), fp32_out)
     c = context()
     attach_planes(xn, c.last_ln)
     c.last_ln = None
+    if not fp32_out:
+        xn._bmt_no_fp32 = True
     return xid, xn
 
 
@@ -1499,6 +1515,8 @@ class FFNFn(torch.autograd.Function):
         fmt = act_fmt(prec)
         xp = planes_of(x, fmt)            # LayerNorm wrote the operand planes of its output already
         if xp is None:
+            _need_fp32(x)
+        if xp is None:
             xp = make_planes(x2, fmt)
         h = linear_fwd_planes(xp, W1, b1, precision=prec, out_fmt=fmt, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
         epi = {}
@@ -1602,7 +1620,10 @@ def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key, pol):
         ent = (K, r[0], r[1])
         cache[key] = ent
     k, v = ent[1], ent[2]
-    Qp = planes_of(Q, act_fmt(pol.gemm)) or make_planes(Qc.view(-1, Dq), act_fmt(pol.gemm))
+    Qp = planes_of(Q, act_fmt(pol.gemm))
+    if Qp is None:
+        _need_fp32(Q)
+        Qp = make_planes(Qc.view(-1, Dq), act_fmt(pol.gemm))
     q = linear_fwd_planes(Qp, Wq, bq, precision=pol.gemm, out_fmt=qkv_fmt)
     o, _ = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, precision=pol.attn, out_fmt=act_fmt(pol.gemm))
     return linear_fwd(o, Wo, bo, precision=pol.gemm).view(B, Sq, Dq)
@@ -1682,6 +1703,7 @@ class MHAFn(torch.autograd.Function):
         def split(orig, x3d, prec):
             pl = planes_of(orig, act_fmt(prec))
             if pl is None:       # kept on the tensor: the encoder memory is the K / V input of every decoder layer
+                _need_fp32(orig)
                 pl = make_planes(x3d.view(-1, x3d.shape[-1]), act_fmt(prec))
                 attach_planes(orig, pl)
             return pl
