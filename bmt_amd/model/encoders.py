@@ -64,24 +64,29 @@ class BiModalEncoderLayer(nn.Module):
 
 
     def _forward_two_streams(self, M1, M2, M1_mask, M2_mask, s2):
-        """the same operations with the M2 chain issued on the side stream: the chains meet only where a cross-modal attention reads
-        the other modality's post-self-attention value (events), and M2's chain runs on from layer to layer without joining"""
+        """the same operations with one modality's chain issued on the side stream (ops.SIDE_CHAIN_AUDIO: which): the chains meet only
+        where a cross-modal attention reads the other modality's post-self-attention value (events), and the side chain runs on from
+        layer to layer without joining"""
+        from types import SimpleNamespace as NS
         s1 = torch.cuda.current_stream()
+        a = NS(x=M1, mask=M1_mask, res=self.res_layers_M1, self_att=self.self_att_M1, cross=self.bi_modal_att_M1, ffn=self.feed_forward_M1)
+        v = NS(x=M2, mask=M2_mask, res=self.res_layers_M2, self_att=self.self_att_M2, cross=self.bi_modal_att_M2, ffn=self.feed_forward_M2)
+        side, main = (a, v) if ops.SIDE_CHAIN_AUDIO else (v, a)
         with torch.cuda.stream(s2):
-            M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask), fp32_out=False)
-            e2 = s2.record_event()
-        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask), fp32_out=False)
-        e1 = s1.record_event()
-        s1.wait_event(e2)
-        M2.record_stream(s1)
-        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask), fp32_out=False)
-        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1, fp32_out=False)
+            side.x1 = side.res[0](side.x, lambda y: side.self_att(y, y, y, side.mask), fp32_out=False)
+            e_side = s2.record_event()
+        main.x1 = main.res[0](main.x, lambda y: main.self_att(y, y, y, main.mask), fp32_out=False)
+        e_main = s1.record_event()
+        s1.wait_event(e_side)
+        side.x1.record_stream(s1)
+        main.out = main.res[1](main.x1, lambda y: main.cross(y, side.x1, side.x1, side.mask), fp32_out=False)
+        main.out = main.res[2](main.out, main.ffn, fp32_out=False)
         with torch.cuda.stream(s2):
-            s2.wait_event(e1)
-            M1.record_stream(s2)
-            M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask), fp32_out=False)
-            M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2, fp32_out=False)
-        return M1m2, M2m1
+            s2.wait_event(e_main)
+            main.x1.record_stream(s2)
+            side.out = side.res[1](side.x1, lambda y: side.cross(y, main.x1, main.x1, main.mask), fp32_out=False)
+            side.out = side.res[2](side.out, side.ffn, fp32_out=False)
+        return a.out, v.out
 
 
 _SESSION = __import__("threading").local()        # .s2: the side stream while a BiModalEncoder.forward is running with two streams (per thread)
@@ -116,12 +121,12 @@ class BiModalEncoder(nn.Module):
         # audio chain on the current stream, video chain on the side stream (ops.fork_side_stream); joined before anything downstream
         _SESSION.s2 = s2
         try:
-            V.record_stream(s2)
-            masks['V_mask'].record_stream(s2)
-            masks['A_mask'].record_stream(s2)
+            for t in (A, V, masks['V_mask'], masks['A_mask']):
+                t.record_stream(s2)
             Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
         finally:
             _SESSION.s2 = None
         torch.cuda.current_stream().wait_stream(s2)
-        Va.record_stream(torch.cuda.current_stream())
+        for t in (Av, Va):
+            t.record_stream(torch.cuda.current_stream())
         return (Av, Va)

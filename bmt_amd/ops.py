@@ -173,6 +173,7 @@ def context() -> StepContext:
 # is an alias of the main stream's StepContext (queued weight gradients and small reductions are flushed once, on the main stream,
 # after autograd has joined the streams); what is per stream is already keyed by stream (split-K and grouped-GEMM scratch).
 ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "2"))     # A/B switch: 1 = everything on one stream
+SIDE_CHAIN_AUDIO = _os.environ.get("BMT_SIDE_CHAIN", "video") == "audio"     # A/B: which modality's chain runs on the side stream
 SIDE_PRIORITY = int(_os.environ.get("BMT_SIDE_PRIORITY", "0"))     # A/B: -1 = the video chain's stream at high priority
 _enc_streams_ok = [True]       # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
 _side_streams = {}
