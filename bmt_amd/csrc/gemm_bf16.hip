@@ -1784,6 +1784,19 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         p.nk_dbg = k128_dbg;
         p.nk_loader = k128_loader;
     }
+    // one column tile over many rows (the audio stream's 25600 x 128 outputs): 200 workgroups of 8 waves leave a fifth of the CUs idle and
+    // every CU with one workgroup's latency chain (38-44 us for 52 MB of operand: 1.3 TB/s); 64-row tiles are 400 workgroups of 4 waves,
+    // two or three per CU
+    static const int short_env = getenv("BMT_GEMM_SHORT") ? atoi(getenv("BMT_GEMM_SHORT")) : 0;      // A/B: bit 0 k-major (backward), bit 1 row-major fp16 (forward).  Off: measured 8.83-8.87 vs 8.77 ms/step (bf16 class 1.78 vs 1.75 ms, fp16 class 2.23 vs 2.29)
+    if (p.pipe != 3 && p.pipe != 4 && !a->conv_mode && !a->colsum && p.tiles_n == 1 && a->M >= 4096 && bmt_cdiv(a->M, 128) < bmt_device_cus() &&
+        a->splitk <= 1 && force_bm == 0) {
+        const bool km = a->a_kmajor || a->b_kmajor;
+        if (km ? (short_env & 1) != 0 && a->precision == BMT_PREC_BF16
+               : (short_env & 2) != 0 && (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2)) {
+            p.bm = 64;
+            p.pipe = 0;
+        }
+    }
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3 || (a->precision == BMT_PREC_F16W2 && p.pipe != 1)) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
@@ -1846,7 +1859,12 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
         return BMT_EINVAL;
     }
-    if (p.pipe == 3) {
+    if (p.bm == 64) {                 // 64-row tiles, 4 waves (gemm_prepare: one column tile over many rows)
+        if (f16) rc = a->precision == BMT_PREC_F16W2 ? launch<2, 2, 1, false, false, 0, true>(p, splitk, st_) : launch<1, 2, 1, false, false, 0, true>(p, splitk, st_);
+        else if (akm && bkm) rc = launch<1, 2, 1, true, true>(p, splitk, st_);
+        else if (bkm) rc = launch<1, 2, 1, false, true>(p, splitk, st_);
+        else rc = launch<1, 2, 1, true, false>(p, splitk, st_);
+    } else if (p.pipe == 3) {
         rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
     } else if (p.pipe == 4) {
         rc = f16 ? launch_k128<true>(p, st_) : launch_k128<false>(p, st_);

@@ -121,6 +121,33 @@ def test_gemm_dx_dw_layouts(ops, M, N, K):
     assert_close(dW, want, atol=2e-4 * math.sqrt(M), rtol=1e-4, name="dw")
 
 
+@pytest.mark.parametrize("M,N,K", [(6400, 128, 1024), (4100, 100, 512), (25600, 128, 576)])
+def test_gemm_one_column_tile_over_many_rows(ops, M, N, K):
+    """ONE column tile over 4096 .. 32767 rows (the audio stream's 25600 x 128 outputs; with BMT_GEMM_SHORT=3 the 64-row tiles of
+    gemm_prepare): the fp16 forward products with their epilogues, and the k-major dX product"""
+    x, W, b, res = rnd(M, K, seed=41), rnd(N, K, seed=42) * 0.05, rnd(N, seed=43), rnd(M, N, seed=44)
+    xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV)
+    for prec in (F16, F16W2):
+        fa, fb = operand_rounding(prec)
+        base = fa(x).double() @ fb(W).double().t() + b.double()
+        t = tol(prec, K)
+        assert_close(ops.linear_fwd(xd, Wd, bd, precision=prec), base, name="bias", **t)
+        assert_close(ops.linear_fwd(xd, Wd, bd, relu=True, precision=prec), base.clamp(min=0), name="relu", **t)
+        assert_close(ops.linear_fwd(xd, Wd, bd, residual=rd, ldr=N, precision=prec), base + res.double(), name="residual", **t)
+        y0 = ops.linear_fwd(xd, Wd, bd, precision=prec)
+        pl = ops.linear_fwd_planes(xd, Wd, bd, precision=prec, out_fmt="f16", pad=True)
+        assert torch.equal(pl.hi[:, :N], y0.to(torch.bfloat16)) and torch.equal(pl.fh[:, :N], y0.to(torch.float16))
+        ops.manual_seed(5)
+        fused = ops.linear_fwd(xd, Wd, bd, drop_post=True, drop_p=0.25, site=77, precision=prec)
+        assert torch.equal(fused, ops.dropout_raw(y0, 0.25, 77))
+    # dX = dY . W with W [K][N] as stored (k-major B): dY [M][K], output [M][N] -- one column tile
+    dy, Wb = rnd(M, K, seed=45), rnd(K, N, seed=46) * 0.05
+    dyP, _ = ops.grad_planes(dy.to(DEV))
+    dx = ops.linear_dx(dyP, Wb.to(DEV))
+    want = bf16_round(dy).double() @ bf16_round(Wb).double()
+    assert_close(dx, want, atol=2e-4 * math.sqrt(K), rtol=1e-4, name="dx")
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(300, 200, 1024, 4), (960, 300, 1024, 8), (130, 70, 2048, 16), (257, 129, 640, 3), (960, 300, 1024, 0)])
 @pytest.mark.parametrize("prec", [BF16, X3, F16W2])
 def test_gemm_splitk_two_pass(ops, M, N, K, splitk, prec):
