@@ -888,3 +888,30 @@ def test_grouped_weight_gradient_launch(ops):
     for a, (_, _, acc0), ref, (rows, n_out, k_in) in zip(accs, items, want, shapes):
         base = rnd(n_out, k_in, seed=70 + shapes.index((rows, n_out, k_in))).to(DEV)
         assert_close(a, ref - base, atol=3e-4 * math.sqrt(rows), rtol=1e-5, name="deferred dW")
+
+
+def test_colsum_multi_and_copy_multi(ops):
+    """many small reductions / copies in one launch (bmt_colsum_multi, bmt_copy_multi: the item list travels in the kernel arguments):
+    more items than one launch carries, ragged shapes, accumulate semantics"""
+    import ctypes as C
+    from bmt_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    items, want = [], []
+    for i in range(130):                       # > BMT_COLSUM_MAX_ITEMS: two launches
+        rows, D = 1 + (i * 7) % 40, 8 * (1 + i % 9)
+        ld = D + 8 * (i % 3)
+        part = torch.randn(rows, ld, generator=g).to(DEV)
+        out = torch.randn(D, generator=g).to(DEV)
+        want.append(out.double() + part[:, :D].double().sum(0))
+        items.append((part, 0, out, rows, ld, D))
+    ops._colsum_launch(items)
+    for (part, _, out, rows, ld, D), w in zip(items, want):
+        assert_close(out, w, atol=1e-4, rtol=1e-5, name=f"colsum rows {rows} D {D}")
+    srcs = [torch.randn(3 + 5 * i, generator=g).to(DEV) for i in range(20)]
+    dst = torch.zeros(sum(s.numel() for s in srcs), device=DEV)
+    arr, off = (_lib.CopyItem * len(srcs))(), 0
+    for a, s in zip(arr, srcs):
+        a.src, a.dst, a.n = s.data_ptr(), dst.data_ptr() + 4 * off, s.numel()
+        off += s.numel()
+    _lib.check(ops.lib.bmt_copy_multi(arr, len(srcs), ops._st()), "bmt_copy_multi")
+    assert torch.equal(dst, torch.cat(srcs))

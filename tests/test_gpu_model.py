@@ -739,3 +739,49 @@ def test_full_size_properties_config4_slice():
     losses = [l0] + [float(step.replay()[0]) for _ in range(3)]
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
     assert torch.cuda.max_memory_allocated() < 40 * 2 ** 30
+
+
+def test_two_compute_streams_change_nothing_but_the_schedule(golden, monkeypatch):
+    """the encoder's audio / video chains and a decoder layer's two memory attentions on two streams (ops.fork_side_stream) against the same
+    pass on one stream: same log-probs, same gradients up to the order of the fp32 atomics of the bias column sums"""
+    from bmt_amd import ops
+    g = golden("mid_cap.npz")
+    V, B, Tv, Ta, Tc, seed, use_glove = [int(x) for x in g.np("meta")]
+    cfg = syn.cfg_config1()
+    model = _build(cfg, V, bool(use_glove))
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=seed)
+    out = {}
+    for streams in (1, 2, 1):
+        monkeypatch.setattr(ops, "ENC_STREAMS", streams)
+        model.zero_grad(set_to_none=True)
+        pred, loss, _ = _run_cap(model, cfg, batch["feature_stacks"], batch["captions"])
+        loss.backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        out.setdefault(streams, []).append((pred.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (p1, g1), (p1b, g1b) = out[1]
+    p2, g2 = out[2][0]
+    assert torch.equal(p1, p1b), "the one-stream pass is not reproducible: the comparison below would be meaningless"
+    assert torch.equal(p1, p2), float((p1 - p2).abs().max())
+    for k in g1:
+        noise = float((g1[k] - g1b[k]).double().norm())          # run-to-run (atomics) on one stream
+        d = float((g1[k] - g2[k]).double().norm())
+        assert d <= 10 * noise + 1e-6 * float(g1[k].double().norm()) + 1e-12, (k, d, noise)
+
+
+def test_layernorm_output_as_planes_only_refuses_an_fp32_reader():
+    """ResidualConnection(..., fp32_out=False): the normalised tensor's fp32 values are never written; a consumer that cannot use the
+    planes it carries must fail loudly instead of reading them"""
+    from bmt_amd import ops
+    x = torch.randn(4, 8, 128, device=DEV)
+    gamma, beta = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    _, xn = ops.residual_norm(x, gamma, beta, 1e-5, ops.PREC_F16W2, fp32_out=False)
+    assert ops.planes_of(xn, ops.act_fmt(ops.PREC_F16W2)) is not None
+    ref = torch.nn.functional.layer_norm(x, (128,))
+    pl = ops.planes_of(xn, "f16")
+    assert float((pl.fh[:, :128].float().view(4, 8, 128) - ref).abs().max()) < 2e-3
+    with pytest.raises(RuntimeError, match="planes only"):
+        ops._need_fp32(xn)
+    _, xn32 = ops.residual_norm(x, gamma, beta, 1e-5, ops.PREC_F16W2, fp32_out=True)
+    assert float((xn32 - ref).abs().max()) < 1e-5
+    ops._need_fp32(xn32)
