@@ -135,7 +135,7 @@ class CaptioningTrainStep:
         stream (ops.flush_dw_early), beside the remaining layers' backward."""
         from . import ops as _ops
         stack = getattr(getattr(getattr(self.model, "encoder", None), "encoder_AV", None), "layers", None)
-        if stack is None:
+        if stack is None or not _ops.EARLY_DW:      # (measured slower than the lone launch at the end, DESIGN §6: an experiment switch)
             return
         step = self
 
