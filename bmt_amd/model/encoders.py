@@ -110,6 +110,8 @@ class BiModalEncoder(nn.Module):
         super(BiModalEncoder, self).__init__()
         layer_AV = BiModalEncoderLayer(d_model_A, d_model_V, d_model, dout_p, H, d_ff_A, d_ff_V)
         self.encoder_AV = LayerStack(layer_AV, N)
+        if N <= 2:           # the operand policy depends on the depth (ops.POLICIES: "enc_shallow")
+            ops.tag_policy(self.encoder_AV, "enc_shallow")
 
     def forward(self, x, masks: dict):
         ''' x (A, V): (B, Sm, D); masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa)}  ->  (Av, Va) '''
