@@ -184,9 +184,10 @@ class ResidualConnection(nn.Module):
         self.dropout = nn.Dropout(dout_p)
         self._site = ops.new_site()
 
-    def forward(self, x, sublayer, fp32_out=True):
+    def forward(self, x, sublayer, fp32_out=True, out_planes=None):
         # x (B, S, D):  x + dropout(sublayer(LN(x)));  fp32_out False (the bi-modal layers' calls): LN(x) is handed to the sublayer as
-        # operand planes only (ops.residual_norm)
+        # operand planes only (ops.residual_norm); out_planes: a plane format the READER of the result wants -- a sublayer that takes the
+        # fused residual writes it from the same epilogue (attached to the result: ops.planes_of)
         p = self.dout_p if self.training else 0.0
         if not ops.FUSE_RESIDUAL:
             res = sublayer(layer_norm(self.norm, x))
@@ -195,7 +196,7 @@ class ResidualConnection(nn.Module):
         # adds dropout + x in its epilogue; a sublayer that does not take the offer gets the separate kernel
         xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm,
                                     fp32_out=fp32_out or not ops.LN_PLANES_ONLY)
-        off = ops.offer_residual(xid, p, self._site)
+        off = ops.offer_residual(xid, p, self._site, out_planes)
         res = sublayer(xn)
         ops.take_residual()
         if off.out is None:

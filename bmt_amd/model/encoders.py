@@ -50,9 +50,10 @@ class BiModalEncoderLayer(nn.Module):
         if s2 is not None and M1.is_cuda:
             return self._forward_two_streams(M1, M2, M1_mask, M2_mask, s2)
 
-        # 1. self-attention on each stream
-        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask), fp32_out=False)
-        M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask), fp32_out=False)
+        # 1. self-attention on each stream (its result is the other stream's key / value input: written as those operand planes too)
+        kv_fmt = ops.act_fmt(ops.policy_of(self).kv_gemm)
+        M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask), fp32_out=False, out_planes=kv_fmt)
+        M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask), fp32_out=False, out_planes=kv_fmt)
         # 2. cross-modal attention: queries are the normalised stream, keys/values the OTHER stream as it is now
         M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask), fp32_out=False)
         M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask), fp32_out=False)
@@ -72,18 +73,19 @@ class BiModalEncoderLayer(nn.Module):
         a = NS(x=M1, mask=M1_mask, res=self.res_layers_M1, self_att=self.self_att_M1, cross=self.bi_modal_att_M1, ffn=self.feed_forward_M1)
         v = NS(x=M2, mask=M2_mask, res=self.res_layers_M2, self_att=self.self_att_M2, cross=self.bi_modal_att_M2, ffn=self.feed_forward_M2)
         side, main = (a, v) if ops.SIDE_CHAIN_AUDIO else (v, a)
+        kv_fmt = ops.act_fmt(ops.policy_of(self).kv_gemm)      # a self-attention's result is the other chain's key / value input
         with torch.cuda.stream(s2):
-            side.x1 = side.res[0](side.x, lambda y: side.self_att(y, y, y, side.mask), fp32_out=False)
+            side.x1 = side.res[0](side.x, lambda y: side.self_att(y, y, y, side.mask), fp32_out=False, out_planes=kv_fmt)
             e_side = s2.record_event()
-        main.x1 = main.res[0](main.x, lambda y: main.self_att(y, y, y, main.mask), fp32_out=False)
+        main.x1 = main.res[0](main.x, lambda y: main.self_att(y, y, y, main.mask), fp32_out=False, out_planes=kv_fmt)
         e_main = s1.record_event()
         s1.wait_event(e_side)
-        side.x1.record_stream(s1)
+        ops.record_stream(side.x1, s1)
         main.out = main.res[1](main.x1, lambda y: main.cross(y, side.x1, side.x1, side.mask), fp32_out=False)
         main.out = main.res[2](main.out, main.ffn, fp32_out=False)
         with torch.cuda.stream(s2):
             s2.wait_event(e_main)
-            main.x1.record_stream(s2)
+            ops.record_stream(main.x1, s2)
             side.out = side.res[1](side.x1, lambda y: side.cross(y, main.x1, main.x1, main.mask), fp32_out=False)
             side.out = side.res[2](side.out, side.ffn, fp32_out=False)
         return a.out, v.out

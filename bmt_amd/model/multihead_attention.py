@@ -86,6 +86,6 @@ class MultiheadedAttention(nn.Module):
                 self.H, p, self._site, pol)
         off = ops.take_residual()        # an enclosing ResidualConnection offers x, p, site: fused into the out-projection
         if off is None:
-            return ops.MHAFn.apply(*args, None, 0.0, 0)
-        off.out = ops.MHAFn.apply(*args, off.x, off.p, off.site)
+            return ops.MHAFn.apply(*args, None, 0.0, 0, None)
+        off.out = ops.MHAFn.apply(*args, off.x, off.p, off.site, off.planes_fmt)
         return off.out

@@ -1272,19 +1272,22 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
 # backward adds the residual stream's gradient to its own (no autograd add pass).  The residual is OFFERED to the sublayer
 # through a module-level slot; MultiheadedAttention / PositionwiseFeedForward take it, anything else leaves it and the
 # ResidualConnection falls back to the separate dropout_add kernel.
+OUT_PLANES = _os.environ.get("BMT_OUT_PLANES", "1") != "0"      # A/B switch: a sublayer's last GEMM also writes the operand planes its result's reader needs
 LN_PLANES_ONLY = _os.environ.get("BMT_LN_FP32") != "1"        # A/B switch: "1" = every LayerNorm output also as fp32 values
 FUSE_RESIDUAL = _os.environ.get("BMT_NO_FUSE_RES") != "1"
 
 
 class ResidualOffer:
-    __slots__ = ("x", "p", "site", "out")
+    __slots__ = ("x", "p", "site", "out", "planes_fmt")
 
     def __init__(self, x, p, site):
         self.x, self.p, self.site, self.out = x, p, site, None
+        self.planes_fmt = None       # the taker also writes its result as operand planes of this format (attached to the result)
 
 
-def offer_residual(x, p, site) -> ResidualOffer:
+def offer_residual(x, p, site, planes_fmt=None) -> ResidualOffer:
     off = ResidualOffer(x, p, site)
+    off.planes_fmt = planes_fmt if OUT_PLANES else None
     context().res_offer = off
     return off
 
@@ -1310,6 +1313,17 @@ def _need_fp32(t):
     if getattr(t, "_bmt_no_fp32", False):
         raise RuntimeError("this LayerNorm output exists as operand planes only (ResidualConnection(..., fp32_out=False)) and its consumer "
                            "asked for a plane format it was not written in: call the ResidualConnection with fp32_out=True")
+
+
+def record_stream(t, stream):
+    """Tensor.record_stream for ``t`` AND the operand planes attached to it (written by its producer on the producer's stream, read by a
+    consumer on ``stream``: the caching allocator must not reuse them for the producer's stream while that reader is pending)"""
+    t.record_stream(stream)
+    pl = getattr(t, "_bmt_planes", None)
+    if pl is not None:
+        for x in (pl.hi, pl.lo, pl.fh, pl.fl):
+            if x is not None:
+                x.record_stream(stream)
 
 
 def attach_planes(t, pl: Planes):
@@ -1693,7 +1707,7 @@ class MHAFn(torch.autograd.Function):
     intermediates are the module's input/output.  pol: the Policy of the enclosing layer (ops.POLICIES)."""
 
     @staticmethod
-    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, pol, res=None, res_p=0.0, res_site=0):
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, pol, res=None, res_p=0.0, res_site=0, out_fmt=None):
         note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         Qc, Kc, Vc = _f32c(Q), _f32c(K), _f32c(V)
         B, Sq, Dq = Qc.shape
@@ -1736,7 +1750,13 @@ class MHAFn(torch.autograd.Function):
         if res is not None:              # x_res + dropout(out-projection) in the projection's epilogue (ResidualConnection)
             r2 = _f32c(res).view(-1, Dq)
             epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        opl = None
+        if out_fmt is not None and Dq % 64 == 0:      # the reader of this result (the other modality's cross-attention) wants it as planes
+            opl = _alloc_planes(B * Sq, Dq, out_fmt, Qc.device)
+            epi["out_planes"] = opl
         out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, Sq, Dq)
+        if opl is not None:
+            attach_planes(out, opl)
         ctx.H, ctx.p, ctx.site = H, p, site
         ctx.res = (res is not None, res_p, res_site)
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
@@ -1846,7 +1866,7 @@ class MHAFn(torch.autograd.Function):
                     dxv, dWv = lin_bwd_planes(Pv, Wvp, VT, need_dx=needV)
                     dK = dxk.view(B, Sk, Dk_in) if needK else None
                     dV = dxv.view(B, Sk, Dv_in) if needV else None
-        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None
+        return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None, None
 
 
 class GeneratorFn(torch.autograd.Function):
