@@ -243,6 +243,7 @@ class PositionwiseFeedForward(nn.Module):
         pol = ops.policy_of(self)
         off = ops.take_residual()
         if off is None:
-            return ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, pol, None, 0.0, 0)
-        off.out = ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, pol, off.x, off.p, off.site)
+            return ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, pol, None, 0.0, 0, None)
+        off.out = ops.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p, self._site, pol, off.x, off.p, off.site,
+                                  off.planes_fmt)
         return off.out

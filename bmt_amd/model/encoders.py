@@ -58,8 +58,8 @@ class BiModalEncoderLayer(nn.Module):
         M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask), fp32_out=False)
         M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask), fp32_out=False)
         # 3. feed-forward
-        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1, fp32_out=False)
-        M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2, fp32_out=False)
+        M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
+        M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
 
         return M1m2, M2m1
 
@@ -82,12 +82,12 @@ class BiModalEncoderLayer(nn.Module):
         s1.wait_event(e_side)
         ops.record_stream(side.x1, s1)
         main.out = main.res[1](main.x1, lambda y: main.cross(y, side.x1, side.x1, side.mask), fp32_out=False)
-        main.out = main.res[2](main.out, main.ffn, fp32_out=False)
+        main.out = main.res[2](main.out, main.ffn, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
         with torch.cuda.stream(s2):
             s2.wait_event(e_main)
             ops.record_stream(main.x1, s2)
             side.out = side.res[1](side.x1, lambda y: side.cross(y, main.x1, main.x1, main.mask), fp32_out=False)
-            side.out = side.res[2](side.out, side.ffn, fp32_out=False)
+            side.out = side.res[2](side.out, side.ffn, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
         return a.out, v.out
 
 
@@ -114,6 +114,8 @@ class BiModalEncoder(nn.Module):
         self.encoder_AV = LayerStack(layer_AV, N)
         if N <= 2:           # the operand policy depends on the depth (ops.POLICIES: "enc_shallow")
             ops.tag_policy(self.encoder_AV, "enc_shallow")
+        # the last layer's results are a decoder's memories: read there as key / value operand planes, written by the last GEMM
+        self.encoder_AV.layers[-1].memory_planes_fmt = ops.act_fmt(ops.POLICIES["dec"].kv_gemm)
 
     def forward(self, x, masks: dict):
         ''' x (A, V): (B, Sm, D); masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa)}  ->  (Av, Va) '''
@@ -132,5 +134,5 @@ class BiModalEncoder(nn.Module):
             _SESSION.s2 = None
         torch.cuda.current_stream().wait_stream(s2)
         for t in (Av, Va):
-            t.record_stream(torch.cuda.current_stream())
+            ops.record_stream(t, torch.cuda.current_stream())
         return (Av, Va)

@@ -1527,7 +1527,7 @@ class FFNFn(torch.autograd.Function):
     only ever exists as a bf16 plane.  pol: the Policy of the enclosing layer."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p, site, pol, res=None, res_p=0.0, res_site=0):
+    def forward(ctx, x, W1, b1, W2, b2, p, site, pol, res=None, res_p=0.0, res_site=0, out_fmt=None):
         note_use(W1, b1, W2, b2)
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
@@ -1543,6 +1543,10 @@ class FFNFn(torch.autograd.Function):
         if res is not None:              # x_res + dropout(fc2(h)) in fc2's epilogue (ResidualConnection)
             r2 = _f32c(res).view(-1, W2.shape[0])
             epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        opl = None
+        if out_fmt is not None and W2.shape[0] % 64 == 0:       # the reader of this result (the decoder: its memory) wants it as planes
+            opl = _alloc_planes(x2.shape[0], W2.shape[0], out_fmt, xc.device)
+            epi["out_planes"] = opl
         y = linear_fwd(h, W2, b2, precision=pol.ffn2, **epi)
         ctx.p = p
         ctx.h = h.only("hi")             # the backward reads bf16 planes only
@@ -1550,7 +1554,10 @@ class FFNFn(torch.autograd.Function):
         ctx.res = (res is not None, res_p, res_site)
         ctx.params = (W1, b1, W2, b2)
         ctx.save_for_backward(W1, W2)
-        return y.view(*xc.shape[:-1], W2.shape[0])
+        y = y.view(*xc.shape[:-1], W2.shape[0])
+        if opl is not None:
+            attach_planes(y, opl)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -1581,7 +1588,7 @@ class FFNFn(torch.autograd.Function):
         dx, dW1 = lin_bwd_planes(dhP, W1p, ctx.xp, need_dx=ctx.needs_input_grad[0])
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], W1.shape[1])
-        return dx, dW1, db1, dW2, db2, None, None, None, (dy if has_res else None), None, None
+        return dx, dW1, db1, dW2, db2, None, None, None, (dy if has_res else None), None, None, None
 
 
 def project_group(Xp: Planes, Ws, bs, prec: int, out_fmt: str):
