@@ -23,7 +23,11 @@ import os
 import sys
 import time
 
-import torch
+# kernel arguments in device memory (the HIP runtime's default on this ROCm; stated here so that an environment that switches it off does
+# not silently cost the ~400 small launches of a step 0.4 ms: measured 9.11 vs 8.73 ms/step with it forced off, same box)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
