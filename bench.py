@@ -812,7 +812,7 @@ def main():
                         out["attention_roofline"]["pmc"] = pm
                         out["attention_roofline"]["pmc_source"] = rec_note
             out["kernel_timer"] = {"valid": valid, "gates": gate_notes, "passes_run": timer_passes, "steps": used_steps,
-                                   "eager_ms_per_step": eager_ms, "streams": 1, "timed_region_streams": ops.ENC_STREAMS if ops._enc_streams_ok[0] else 1,
+                                   "eager_ms_per_step": eager_ms, "streams": 1, "timed_region_streams": ops.encoder_streams_in_use(),
                                    "timed_classes_ms_per_step": tot,
                                    "note": "HIP events on torch's current stream around every launch of a class and around every step; two untimed "
                                            "eager steps first (allocator), then the GPU is parked behind a spin kernel so that launches are queued "

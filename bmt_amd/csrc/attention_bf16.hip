@@ -3169,6 +3169,12 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
                     hipLaunchKernelGGL((attn_bwd_dkv32_kernel<DK, false>), dim3(nblk_k16), dim3(512), lds2, st, p);
                 }
             } else {
+                // this kernel finishes through grad_tile_flush, which adds the column sums into bsum with atomics and never writes the
+                // per-tile partial rows: they are cleared here, so that whoever sums them afterwards (attn_bias_finish_kernel, or the
+                // caller's bmt_colsum_multi under defer_bias) adds zeros instead of whatever the workspace held
+                const size_t part_bytes = (size_t)p.B * ((p.Sk + 127) / 128) * p.H * DK * sizeof(float);
+                if (p.gk.bpart) (void)hipMemsetAsync(p.gk.bpart, 0, part_bytes, st);
+                if (p.gv.bpart) (void)hipMemsetAsync(p.gv.bpart, 0, part_bytes, st);
                 hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k16), dim3(512), lds, st, p);
             }
         }

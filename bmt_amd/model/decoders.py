@@ -115,6 +115,8 @@ class BiModelDecoder(nn.Module):
             ops.drop_prefetched_kv()
             if s4 is not None:
                 torch.cuda.current_stream().wait_stream(s4)
+        if C.is_cuda:
+            ops.end_of_forward()
         return C
 
 

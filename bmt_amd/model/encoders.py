@@ -135,4 +135,5 @@ class BiModalEncoder(nn.Module):
         torch.cuda.current_stream().wait_stream(s2)
         for t in (Av, Va):
             ops.record_stream(t, torch.cuda.current_stream())
+        ops.end_of_forward()
         return (Av, Va)

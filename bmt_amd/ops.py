@@ -141,7 +141,7 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
@@ -152,6 +152,7 @@ class StepContext:
         self.res_offer = None        # residual offered by a ResidualConnection to its sublayer's last GEMM
         self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
         self.kv_cache = None         # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory, k planes, v planes)
+        self.allow_streams = True    # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
 
 
 _contexts = {}
@@ -179,7 +180,6 @@ def context() -> StepContext:
 ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "2"))     # A/B switch: 1 = everything on one stream
 SIDE_CHAIN_AUDIO = _os.environ.get("BMT_SIDE_CHAIN", "video") == "audio"     # A/B: which modality's chain runs on the side stream
 SIDE_PRIORITY = int(_os.environ.get("BMT_SIDE_PRIORITY", "0"))     # A/B: -1 = the video chain's stream at high priority
-_enc_streams_ok = [True]       # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
 _side_streams = {}
 
 
@@ -200,7 +200,7 @@ def fork_side_stream(index: int = 0, need: int = 0):
     the other branch's first GEMM triggered.  index 0: the encoder's video chain / a decoder layer's video attention; 1: the decoder's
     first self-attention sublayer, which does not depend on the encoder (model/captioning_module.py); 3: the decoder's K / V
     projections of the encoder memories (ops.prefetch_kv; ``need`` = the BMT_ENC_STREAMS level that switches a use on)."""
-    if ENC_STREAMS < (need or 2 + index) or not _enc_streams_ok[0]:
+    if ENC_STREAMS < (need or 2 + index) or not context().allow_streams:
         return None
     with _weights.lock:
         _weights.ensure_fresh()
@@ -228,7 +228,7 @@ def flush_dw_early() -> bool:
     launch of the layers already differentiated runs beside the backward of the remaining ones instead of alone at the end.  The
     operands are recorded on that stream (the caching allocator must not hand them to a later allocation of their own stream while
     the launch is pending)."""
-    if not EARLY_DW or ENC_STREAMS < 2 or not _enc_streams_ok[0]:
+    if not EARLY_DW or ENC_STREAMS < 2 or not context().allow_streams:
         return False
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream().cuda_stream
@@ -252,18 +252,45 @@ def flush_dw_early() -> bool:
     return True
 
 
-def join_side_stream():
+def join_side_stream(release: bool = True):
     """the current stream waits for its side streams: call after a backward pass whose forward forked (autograd runs a node on the stream its
     forward ran on and orders streams along gradient edges only -- the last nodes of the side chain write static gradient buffers and queue
-    weight-gradient operands without handing anything to a node of the main stream)"""
+    weight-gradient operands without handing anything to a node of the main stream).  ``release``: the pass is over -- its side streams stop
+    being aliases of this stream's StepContext (torch hands out stream handles from a pool of 32 per priority: an alias that outlived its
+    pass could make a LATER main stream with the same handle resolve to this pass's context)."""
     cur = torch.cuda.current_stream()
     for (d, m, _), s2 in list(_side_streams.items()):
         if d == cur.device.index and m == cur.cuda_stream:
             cur.wait_stream(s2)
+    if release:
+        release_side_streams(cur)
+
+
+def release_side_streams(main=None):
+    """forget the context aliases of ``main``'s side streams (the stream objects stay cached for the next pass)"""
+    main = torch.cuda.current_stream() if main is None else main
+    mkey = (main.device.index, main.cuda_stream)
+    for k in [k for k, v in _ctx_alias.items() if v == mkey]:
+        _ctx_alias.pop(k, None)
+    _fork_main.pop(mkey, None)
+
+
+def end_of_forward():
+    """a forward pass that no backward pass will follow (torch.no_grad: inference, greedy decoding) is over once its side streams are
+    joined: drop their aliases now -- with autograd on they live until the train step's join_side_stream (backward nodes of the side
+    chain look the pass's context up through them)"""
+    if not torch.is_grad_enabled():
+        release_side_streams()
 
 
 def allow_encoder_streams(ok: bool):
-    _enc_streams_ok[0] = bool(ok)
+    """two compute streams for the pass(es) of the CURRENT stream's context (per context, not per process: one train step switching
+    the fork off must not switch it off for another model stepping on another stream)"""
+    context().allow_streams = bool(ok)
+
+
+def encoder_streams_in_use() -> int:
+    return ENC_STREAMS if context().allow_streams else 1
 
 
 _rng_state = {}
@@ -272,8 +299,14 @@ _site_counter = [0]
 
 def rng_tensor(device=None) -> torch.Tensor:
     """Per-device {seed, step} pair read by every dropout site (device memory => graph-replayable)."""
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    dev = None if device is None else torch.device(device)
+    if dev is None or dev.type != "cuda":
+        # the dropout stream lives in GPU memory: a host device (a CPU-resident model on its way into a checkpoint) names the current GPU's
+        # stream -- never a host tensor cached under a GPU's key, which every later dropout kernel would have been handed (ADVICE r3)
+        dev = torch.device("cuda", torch.cuda.current_device())
+    elif dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = dev.index
     if key not in _rng_state:
         _rng_state[key] = torch.tensor([0x5EED, 0], dtype=torch.int64, device=dev)
     return _rng_state[key]
@@ -1162,14 +1195,34 @@ ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # A/B sw
 KMEAN_SPLIT = _os.environ.get("BMT_KMEAN_SPLIT", "1") != "0"            # "0": no mean-key correction on the split form (fp16 dS)
 
 
+_SCRATCH = {}            # (device index, stream handle, capturing?, name) -> 1-D tensor: scratch that lives inside ONE library call
+
+
+def stream_scratch(name: str, numel: int, dtype, device) -> torch.Tensor:
+    """scratch of the CURRENT stream that no kernel reads after the library call that wrote it (the P / dS / scaled-q workspaces of the split
+    attention backward: 2 x 183 MB + 52 MB for the audio self-attention): one buffer per (device, stream, name), grown to the largest request
+    and re-used by every later call -- launches of a stream are ordered, so the next writer cannot overtake the last reader.  No allocator
+    call per launch (an eager step issued 56 of them, each a place for the host to stall between two kernels: round 3's driver-run
+    roofline).  A hipGraph capture has its own entries (its stream is capturing: the buffer comes out of the graph's private pool and
+    stays with the graph)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream,
+           torch.cuda.is_current_stream_capturing(), name)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < numel or t.dtype != dtype:
+        t = _SCRATCH[key] = torch.empty(max(int(numel), 1), device=dev, dtype=dtype)
+    return t[:numel]
+
+
 def _attn_split_ws(B, H, Sq, Sk, dk, dev):
     """workspaces of the split attention backward (bmt_attn_bwd_split_ws), or None where the two-kernel form runs (d_k < 128, fewer than
-    64 queries: the decoder).  Plain allocations: under graph capture they come from the graph's pool like every other temporary."""
+    64 queries: the decoder).  P, dS and the scaled copy of q are scratch of the call (stream_scratch); the per-tile bias partials are read
+    by the pass's deferred column-sum launch (colsum_deferred), so they are a plain allocation that lives until then."""
     n = [C.c_int64(0), C.c_int64(0), C.c_int64(0)]
     if lib.bmt_attn_bwd_split_ws(B, H, Sq, Sk, dk, C.byref(n[0]), C.byref(n[1]), C.byref(n[2])) != 0:
         return None
-    e = lambda k, dt: torch.empty(k, device=dev, dtype=dt)
-    return e(n[0].value, torch.bfloat16), e(n[0].value, torch.bfloat16), e(n[1].value, torch.bfloat16), e(n[2].value, torch.float32)
+    return (stream_scratch("attn_P", n[0].value, torch.bfloat16, dev), stream_scratch("attn_dS", n[0].value, torch.bfloat16, dev),
+            stream_scratch("attn_Qb", n[1].value, torch.bfloat16, dev), torch.empty(n[2].value, device=dev, dtype=torch.float32))
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,

@@ -439,7 +439,7 @@ class MixedTrainStep:
         assert not any(id(p) in enc for p in self.prop.params)
 
     def capture(self, feature_stacks, caption_idx, warmup: int = 2, collectives: bool = False):
-        return self.cap.capture(feature_stacks, caption_idx, warmup=warmup)
+        return self.cap.capture(feature_stacks, caption_idx, warmup=warmup, collectives=collectives)
 
     def __call__(self, cap_batch, prop_batch):
         """cap_batch = (feature_stacks, caption_idx) or None to replay the captured batch; prop_batch = (feature_stacks, targets).
