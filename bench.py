@@ -19,6 +19,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -430,6 +431,95 @@ def pmc_record():
     return rec, f"profiles/{name} (csrc {have}): FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 --pmc passes over the eagerly issued step"
 
 
+def graph_overlap_trial(args, world, rank, local_rank, dev, timeout_s=None):
+    """can this installation capture RCCL collectives inside a hipGraph and replay them?  Tried where a hang costs nothing: every rank starts
+    a CHILD process (same GPU, its own process group on its own port) that builds a small captioning step, captures it with
+    capture(collectives=True), replays it and exits; a child that has not finished within the bound is killed.  Returns (ok on EVERY rank,
+    reason).  The parents only exchange one port number before and one flag after."""
+    import socket
+    import subprocess
+    import torch.distributed as dist
+    timeout_s = timeout_s or args.trial_timeout
+    port_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port_t[0] = sk.getsockname()[1]
+    dist.broadcast(port_t, src=0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port_t[0])), RANK=str(rank), LOCAL_RANK=str(local_rank),
+               WORLD_SIZE=str(world))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in [k for k in env if k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC", "GROUP_", "ROLE_"))]:
+        env.pop(k)      # (under torchrun the rendezvous store is the AGENT's: TORCHELASTIC_USE_AGENT_STORE makes rank 0 a client of it -- the
+                        # children have no agent, their rank 0 must host the store on the trial's port)
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-overlap-trial", "--gpus", str(world)] + (["--dry-run"] if args.dry_run else [])
+    ok, why = 0, "?"
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout_s)
+            ok = int(p.returncode == 0 and "TRIAL OK" in out)
+            why = "captured and replayed" if ok else f"child exit code {p.returncode}: {(err or out).strip()[-200:]}"
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, 9)          # the child is its own session / process group: exactly the processes started here
+            except OSError:
+                p.kill()
+            p.communicate()
+            why = f"no result within {timeout_s} s (killed)"
+    except OSError as exc:
+        why = f"could not start the trial: {exc}"
+    flag = torch.tensor([ok], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    allok = bool(int(flag[0]))
+    return allok, (why if (allok or not ok) else "another rank's trial failed")
+
+
+def graph_overlap_trial_child(args):
+    """the child of graph_overlap_trial: a small captioning step over this rank's GPU and a process group of the children, captured WITH its
+    collectives and replayed.  --dry-run: the same protocol over gloo without a GPU (tests/test_bench_launcher.py); BMT_TRIAL_HANG=1 makes it
+    hang on purpose (the parent's time bound is what is tested)."""
+    import torch.distributed as dist
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BMT_TRIAL_HANG") == "1":
+        time.sleep(3600)
+    if args.dry_run:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        assert int(t[0]) == world
+        print("TRIAL OK", flush=True)
+        os._exit(0)
+    import contextlib
+    import io
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from bmt_amd import synthetic as syn
+    from bmt_amd.model.captioning_module import BiModalTransformer
+    from bmt_amd.train import CaptioningTrainStep
+    V, Tv, Ta, Tc, B = 1000, 64, 200, 12, 8
+    cfg = syn.cfg_config0(dout_p=0.1)
+    cfg.device = str(dev)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = BiModalTransformer(cfg, syn.FakeTrainDataset(V, syn.make_glove(V, cfg.d_model_caps))).to(dev)
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=5 + rank)
+    fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
+    caps = batch["captions"].to(dev)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=True, static_grads=True, overlap=True, seed=77, bucket_bytes=1 << 20,
+                               collective=args.dp_collective)
+    step.capture(fs, caps, warmup=1, collectives=True)
+    for _ in range(3):
+        loss, _ = step.replay()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss))
+    dist.barrier()
+    print("TRIAL OK", flush=True)
+    sys.stdout.flush()
+    os._exit(0)
+
+
 def kernel_timer_pass(step, inputs, timer, ops, n_steps, warm=2):
     """n_steps eagerly issued steps with HIP events around every launch of a kernel class (KernelTimer) and around every step; returns
     the median step time in ms.
@@ -488,6 +578,9 @@ def dry_run(args, world, rank):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    trial_res = None
+    if world > 1 and args.dp_mode == "auto":      # the child-process trial that guards the captured-allreduce mode: same protocol, gloo children
+        trial_res = graph_overlap_trial(args, world, rank, rank, torch.device("cpu"))
     for _ in range(args.warmup):
         time.sleep(0.001)
     if world > 1:
@@ -508,7 +601,8 @@ def dry_run(args, world, rank):
         units = float(t[1])
     if rank == 0:
         print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "dry_run": True, "value": units * args.steps / dt, "unit": "units/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3}))
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "captured_allreduce_trial": trial_res}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -530,7 +624,7 @@ def build_cap(args, dev, rank, world):
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}      # inputs resident in HBM before timing
     caps = batch["captions"].to(dev)
     units_local = int((caps[:, 1:] != syn.PAD_IDX).sum())
-    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000, collective=args.dp_collective)
     desc = {"metric": "caption tokens/sec/node (train_cap B=32/GPU, d=1024)", "unit": "caption tokens/s",
             "workload": "configs[1]: train_cap, N=2 d_model=1024 H=4 d_aud=128 d_vid=1024 d_caps=300 T_v=256 T_a=800 T_c=30 V=10000, "
                         "dropout 0.1, Adam, GloVe frozen",
@@ -558,7 +652,7 @@ def build_prop(args, dev, rank, world):
     batch = syn.make_prop_batch(cfg, B, Tv, Ta, seed=11 + rank)
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
     tg = batch["targets"].to(dev)
-    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000)
+    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000, collective=args.dp_collective)
     # heads 348.7 + 322.9 GF and encoder 230.0 GF forward per sample at (T_a, T_v) = (3200, 1024); the frozen
     # encoder has no backward, the heads have 2x their forward
     heads, enc = (348.7 + 322.9) * 1e9, 230.0e9
@@ -586,11 +680,18 @@ def main():
                     help="N > 1: hipGraphs with the all-reduce exposed between them, eager launches with the all-reduce overlapped with "
                          "the backward pass, or (auto) whichever a short trial finds faster")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing protocol only (gloo, no GPU)")
+    ap.add_argument("--dp-collective", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="N > 1: a bucket's gradient sum as one all-reduce, or as reduce-scatter + all-gather (SURVEY 5: world-1 simultaneous "
+                         "point-to-point transfers per half on the xGMI mesh)")
+    ap.add_argument("--trial-timeout", type=int, default=240, help="seconds the child-process trial of the captured-allreduce mode may take")
+    ap.add_argument("--graph-overlap-trial", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker()
+    if args.graph_overlap_trial:
+        return graph_overlap_trial_child(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
@@ -647,35 +748,55 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
         return float(v[0])
 
+    mode_trials = {}
     if cap and not args.no_graph:
-        eager_ms = None
-        if world > 1 and args.dp_mode in ("auto", "overlap"):
-            # N > 1 has two ways to run the step: eager launches with the bucket all-reduces overlapped with the backward pass, or
-            # hipGraphs with the all-reduce exposed between them.  Both are timed briefly; the faster one is measured.
+        # N == 1: the captured step.  N > 1 (--dp-mode auto) has three ways to run it; each is timed briefly (max over ranks) and the fastest
+        # is what the timed region measures:
+        #   eager+overlap                bucket all-reduces launched from the backward pass, every kernel issued from Python
+        #   hipgraph                     two hipGraphs, the all-reduce of the flat buckets exposed between them
+        #   hipgraph+captured-allreduce  ONE hipGraph with the bucket all-reduces captured inside it: overlap with no host work between
+        #                                kernels.  A collective that cannot be captured on an installation may HANG instead of raising, so
+        #                                this mode enters the comparison only after a trial in CHILD processes (one per rank, their own
+        #                                process group) has captured and replayed it within a time bound (graph_overlap_trial).
+        want = {"auto": ("eager", "graph", "graph-overlap"), "overlap": ("eager",), "graph": ("graph",),
+                "graph-overlap": ("graph-overlap",)}[args.dp_mode] if world > 1 else ("graph",)
+        if world > 1 and "graph-overlap" in want and args.dp_mode == "auto":
+            ok, why = graph_overlap_trial(args, world, rank, local_rank, dev)
+            note(f"captured-allreduce trial in child processes: {'ok' if ok else 'NOT usable'} ({why})")
+            if not ok:
+                want = tuple(m for m in want if m != "graph-overlap")
+                mode_trials["hipgraph+captured-allreduce"] = f"not tried: {why}"
+        if "eager" in want:
             for _ in range(2):
                 step(*inputs)
-            eager_ms = trial(lambda: step(*inputs))
-            note(f"eager + overlapped all-reduce: {eager_ms:.2f} ms/step")
-        if world > 1 and args.dp_mode == "graph-overlap":
-            # opt-in: ONE hipGraph with the bucket all-reduces captured inside it (CaptioningTrainStep._capture_with_collectives): overlap
-            # without host work between kernels.  Not part of `auto`: a collective that cannot be captured may hang instead of raising.
-            step.capture(*inputs, warmup=2, collectives=True)
-            run = lambda: step.replay()
-            mode = "hipgraph+captured-allreduce"
-        elif not (world > 1 and args.dp_mode == "overlap"):
+            mode_trials["eager+overlap"] = trial(lambda: step(*inputs))
+            note(f"eager + overlapped all-reduce: {mode_trials['eager+overlap']:.2f} ms/step")
+        captured = None
+        for m in ("graph-overlap", "graph"):        # ("graph" last: when it wins or ties, its capture is the one that stays)
+            if m not in want:
+                continue
+            name = "hipgraph+captured-allreduce" if m == "graph-overlap" else "hipgraph"
             try:
-                step.capture(*inputs, warmup=2)
-                graph_ms = trial(lambda: step.replay()) if eager_ms is not None else None
-                if graph_ms is not None:
-                    note(f"hipGraphs + exposed all-reduce: {graph_ms:.2f} ms/step")
-                if eager_ms is not None and eager_ms < graph_ms:
-                    step.uncapture()
-                else:
-                    run = lambda: step.replay()
-                    mode = "hipgraph"
+                step.capture(*inputs, warmup=2, collectives=(m == "graph-overlap"))
+                captured = name
+                mode_trials[name] = trial(lambda: step.replay()) if len(want) > 1 else 0.0
+                if len(want) > 1:
+                    note(f"{name}: {mode_trials[name]:.2f} ms/step")
             except Exception as exc:      # noqa: BLE001 -- e.g. a collective that refuses capture: keep measuring, say so
-                note(f"graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
+                note(f"{name}: capture failed ({type(exc).__name__}: {exc})")
+                mode_trials[name] = f"capture failed: {type(exc).__name__}"
                 torch.cuda.synchronize()
+                step.uncapture()
+                captured = None
+        timed = {k: v for k, v in mode_trials.items() if isinstance(v, float)}
+        best = min(timed, key=timed.get) if timed else None
+        if best is None or best == "eager+overlap":
+            step.uncapture()
+        else:
+            if captured != best:          # the winner's graphs were replaced by a later capture: capture it again
+                step.capture(*inputs, warmup=1, collectives=(best == "hipgraph+captured-allreduce"))
+            run = lambda: step.replay()
+            mode = best
         if mode == "eager" and world > 1:
             mode = "eager+overlap"
     for _ in range(args.warmup):
@@ -741,6 +862,7 @@ def main():
             out["engine_clock_under_load"] = clock
         if world > 1:
             out["allreduce_exposed_ms"] = exposed_ms
+            out["launch_mode_trials_ms"] = mode_trials
             out["allreduce"] = getattr(step, "reduce_description", lambda: None)()
         if not args.no_kernel_timer:
             summ, used_steps = timer.summary()         # per class and STEP: launches, ms (sum of per-launch medians), flops, bytes

@@ -26,10 +26,22 @@ class GradientReducer:
     accumulates straight into communication buffers and the optimizer reads the reduced values in place."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 process_group: Optional[dist.ProcessGroup] = None, overlap: bool = True, groups=None):
+                 process_group: Optional[dist.ProcessGroup] = None, overlap: bool = True, groups=None, collective: str = "allreduce"):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.overlap = overlap
+        # how a bucket's gradient sum is formed (SURVEY.md section 5):
+        #   "allreduce": one sum all-reduce per bucket (RCCL picks ring / tree and its channel count);
+        #   "rs_ag":     reduce-scatter + all-gather -- every rank reduces 1/world of the bucket and hands its shard to every peer; on the
+        #                fully connected xGMI mesh both halves are world-1 simultaneous point-to-point transfers of 1/world of the bucket,
+        #                one per link, instead of a ring's world-1 dependent steps.
+        # Both leave the same sum in the same flat buffer (tests/test_parallel_gloo.py); which is faster on 8 GPUs is the driver's run to say
+        # (bench.py --dp-collective).
+        if collective not in ("allreduce", "rs_ag"):
+            raise ValueError(f"GradientReducer: unknown collective {collective!r}")
+        self.collective = collective
+        self._stream_ordered = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in params if p.requires_grad]
         # reverse registration order ~ the order autograd finishes gradients (generator -> decoder -> encoder)
         order = list(reversed(params))
@@ -68,16 +80,36 @@ class GradientReducer:
             p._bmt_static_grad = True
             p._bmt_on_grad = self._on_grad
         self._handles = []
+        self._second = []
         self.zero_grad()
 
     def _make_bucket(self, ps):
         n = sum(p.numel() for p in ps)
-        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        # (padded to a multiple of the world size -- of 8 floats per rank, so that shards stay 32-byte aligned -- for the reduce-scatter
+        # form: the pad belongs to no parameter and stays zero)
+        quantum = max(1, self.world) * 8
+        flat = torch.zeros((n + quantum - 1) // quantum * quantum, dtype=torch.float32, device=ps[0].device)
         views, off = [], 0
         for p in ps:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.buckets.append({"params": ps, "flat": flat, "views": views, "pending": len(ps)})
+        shard = None
+        if self.collective == "rs_ag" and self.world > 1:
+            shard = torch.zeros(flat.numel() // self.world, dtype=torch.float32, device=flat.device)
+        self.buckets.append({"params": ps, "flat": flat, "views": views, "pending": len(ps), "shard": shard})
+
+    def _reduce_bucket(self, b):
+        """launch the sum of one bucket over the ranks (asynchronously): the handles go to self._handles, and -- where two collectives of
+        one bucket cannot simply be queued behind each other -- the second half to self._second"""
+        if self.collective == "allreduce" or self.world == 1:
+            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        h = dist.reduce_scatter_tensor(b["shard"], b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self._stream_ordered:        # RCCL: collectives of a group run in issue order on the communication stream
+            self._handles.append(h)
+            self._handles.append(dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True))
+        else:                           # gloo (the CPU tests): asynchronous works may overtake each other -- gather once the scatter is done
+            self._second.append((h, b))
 
     def zero_grad(self):
         """in-place zero of the flat buffers (one memset per bucket); keeps p.grad bound to its bucket view"""
@@ -89,6 +121,7 @@ class GradientReducer:
                     p.grad = v
                 p._bmt_uses = 0
         self._handles = []
+        self._second = []
 
     def _on_grad(self, p):
         bi, si = self._slot[p]
@@ -100,17 +133,21 @@ class GradientReducer:
             p.grad = v
         b["pending"] -= 1
         if b["pending"] == 0 and self.world > 1 and self.overlap:
-            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce_bucket(b)
 
     def finish(self):
         """wait for the in-flight buckets (and reduce any bucket whose hooks did not all fire, e.g. unused parameters)"""
         if self.world > 1:
             for b in self.buckets:
                 if b["pending"] != 0 or not self.overlap:
-                    self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._reduce_bucket(b)
+            for h, b in self._second:
+                h.wait()
+                self._handles.append(dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True))
             for h in self._handles:
                 h.wait()
         self._handles = []
+        self._second = []
 
     def remove(self):
         for h in self._hooks:

@@ -79,7 +79,7 @@ class CaptioningTrainStep:
     backward graph instead (no collective is ever captured)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None):
+                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None, collective: str = "allreduce"):
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
         self._overlap = overlap
         self._graph_generation = None
@@ -91,8 +91,8 @@ class CaptioningTrainStep:
         self.criterion = LabelSmoothing(cfg.smoothing, pad_idx)
         self.data_parallel = data_parallel
         from . import ops as _ops
-        self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, groups=_ops.fused_weight_groups(model)) \
-            if (data_parallel or static_grads) else None
+        self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, groups=_ops.fused_weight_groups(model),
+                                       collective=collective) if (data_parallel or static_grads) else None
         self.modality = getattr(cfg, 'modality', 'audio_video')
         self.grad_scale = torch.ones(1, device=params[0].device, dtype=torch.float32)
         if hasattr(self.optimizer, "grad_scale"):
@@ -352,7 +352,8 @@ class CaptioningTrainStep:
             mode = (f"bucket all-reduces (RCCL) launched from the backward pass on the communication stream: the queued weight-gradient "
                     f"products are flushed at {self._flush_points} encoder-layer boundaries and each finished bucket reduces under the "
                     "remaining layers' backward; plus one scalar all-reduce (global n_tokens)")
-        return {"payload_mb": sum(b["flat"].numel() for b in r.buckets) * 4 / 1e6, "buckets": len(r.buckets), "mode": mode}
+        how = {"allreduce": "sum all-reduce per bucket", "rs_ag": "reduce-scatter + all-gather per bucket"}[r.collective]
+        return {"payload_mb": sum(b["flat"].numel() for b in r.buckets) * 4 / 1e6, "buckets": len(r.buckets), "collective": how, "mode": mode}
 
 
 class ProposalTrainStep:
@@ -372,7 +373,7 @@ class ProposalTrainStep:
     differs per step, so this step is launched eagerly (no graph capture)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 overlap: bool = True, seed: Optional[int] = None, keep_seed: bool = False):
+                 overlap: bool = True, seed: Optional[int] = None, keep_seed: bool = False, collective: str = "allreduce"):
         import torch.distributed as dist
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
         _seed_dropout(seed, data_parallel, next(model.parameters()).device, keep_if_seeded=keep_seed)
@@ -380,7 +381,7 @@ class ProposalTrainStep:
         self.optimizer = optimizer or FusedAdam(self.params, lr=cfg.lr, betas=tuple(getattr(cfg, "betas", (0.9, 0.999))),
                                                 eps=getattr(cfg, "eps", 1e-8), weight_decay=getattr(cfg, "weight_decay", 0.0))
         self.data_parallel = data_parallel
-        self.reducer = GradientReducer(self.params, bucket_bytes=bucket_bytes, overlap=overlap) if data_parallel else None
+        self.reducer = GradientReducer(self.params, bucket_bytes=bucket_bytes, overlap=overlap, collective=collective) if data_parallel else None
         self.world = dist.get_world_size() if (data_parallel and dist.is_initialized()) else 1
         self.modality = getattr(cfg, 'modality', 'audio_video')
         # data parallel: the loss means use the global cell counts (sum of the per-rank losses == full-batch loss)

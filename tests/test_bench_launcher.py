@@ -26,6 +26,19 @@ def test_self_launch_two_ranks_dry_run():
     assert out["ms_per_step"] >= 1.9 and abs(out["value"] * out["ms_per_step"] * 1e-3 - 300.0) < 1e-6
 
 
+def test_captured_allreduce_trial_runs_in_child_processes_and_is_bounded():
+    """--dp-mode auto (N > 1) tries the one-graph mode with the collectives captured inside it only after child processes -- one per rank,
+    their own process group -- have shown that it works within a time bound; a child that hangs is killed and the mode is left out (the
+    protocol over gloo: port broadcast, children's rendezvous, the flag's MIN over ranks)"""
+    r, out = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["captured_allreduce_trial"][0] is True, out
+    r, out = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run", "--trial-timeout", "3"], env={"BMT_TRIAL_HANG": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    ok, why = out["captured_allreduce_trial"]
+    assert ok is False and "killed" in why, out
+
+
 def test_single_process_dry_run_and_world_mismatch():
     r, out = _run(["--dry-run", "--steps", "2", "--warmup", "0"])
     assert r.returncode == 0 and out["n_gpus"] == 1

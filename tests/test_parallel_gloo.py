@@ -41,7 +41,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_path, bucket_bytes):
+def _worker(rank, world, port, out_path, bucket_bytes, collective="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,7 +52,7 @@ def _worker(rank, world, port, out_path, bucket_bytes):
     lo, hi = rank * B // world, (rank + 1) * B // world
     fs = {k: v[lo:hi] for k, v in batch["feature_stacks"].items()}
     caps = batch["captions"][lo:hi]
-    red = GradientReducer(model.parameters(), bucket_bytes=bucket_bytes)
+    red = GradientReducer(model.parameters(), bucket_bytes=bucket_bytes, collective=collective)
     assert len(red.buckets) > 1
     for it in range(2):          # second iteration checks zero_grad / re-arming of the buckets
         red.zero_grad()
@@ -66,10 +66,12 @@ def _worker(rank, world, port, out_path, bucket_bytes):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [64 << 10, 256 << 10])
-def test_two_rank_gradient_sum_equals_full_batch(tmp_path, bucket_bytes):
+@pytest.mark.parametrize("bucket_bytes,collective", [(64 << 10, "allreduce"), (256 << 10, "allreduce"), (64 << 10, "rs_ag")])
+def test_two_rank_gradient_sum_equals_full_batch(tmp_path, bucket_bytes, collective):
+    """(collective "rs_ag": every bucket as reduce-scatter + all-gather -- SURVEY.md section 5's form for the point-to-point xGMI mesh --
+    leaves the same sums in the same flat buffers)"""
     out = str(tmp_path / "grads.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out, bucket_bytes), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, bucket_bytes, collective), nprocs=2, join=True)
     got = torch.load(out)
     cfg = syn.cfg_tiny(dout_p=0.0)
     model = OracleCaptioner(cfg)
