@@ -142,6 +142,13 @@ SIGNATURES = {
     "bmt_log_softmax_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "bmt_ls_kl_fwd": (i32, [vp, i64, vp, vp, vp, i32, i32, f32, i64, vp]),
     "bmt_ls_kl_bwd": (i32, [vp, vp, i64, vp, vp, i32, i32, f32, i64, vp]),
+    "bmt_log_softmax_fwd_stats": (i32, [vp, i64, i32, i32, vp, vp]),
+    "bmt_ls_kl_fwd_stats": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, f32, i64, vp]),
+    "bmt_gen_lskl_bwd": (i32, [vp, i64, vp, vp, vp, i32, i32, f32, i64, vp, i64, vp, vp]),
+    "bmt_zero": (i32, [vp, i64, vp]),
+    "bmt_caption_shift": (i32, [vp, i64, i32, i32, i64, vp, vp, vp, vp]),
+    "bmt_loss_finish": (i32, [vp, vp, vp, vp, vp]),
+    "bmt_layernorm_bwd_partial2": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
     "bmt_adam_step": (i32, [vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp, vp]),
     "bmt_grad_sqnorm": (i32, [vp, vp, i32, i64, vp, f32, vp, vp]),
     "bmt_scale_tensors": (i32, [vp, vp, i32, i64, vp, vp]),
@@ -169,8 +176,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 4:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 4")
+    if lib.bmt_version() != 5:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 5")
     _lib = lib
     return lib
 

@@ -171,6 +171,13 @@ struct AttnPB {
     int64_t ws_pitch, ws_tile, ws_slab, ldqb, bsqb;     // (batch, head) slab bh at bh * ws_slab; in it element (q, key) of a (batch, head) slab at (key / 128) * ws_tile + q * ws_pitch + key % 128
     int xp;                                    // experiments only: parts of a loop switched off (timing probes)
     int defer_bias;                            // the per-tile bias sums stay in bpart: the caller adds them up (bmt_colsum_multi)
+    // split backward: which 32-query groups have a non-zero dO at all.  qlive[(b * H + h) * ceil(Sq / 128) + tile] = bit w set iff rows
+    // tile * 128 + 32 w .. + 31 of head h carry a non-zero gradient; written by the dQ kernel (which has those rows in registers anyway),
+    // read by the dK / dV kernel.  Padded positions of a sequence get EXACTLY zero gradient in the encoder (their keys are masked everywhere
+    // downstream), a quarter of the query rows under configs[1]'s ragged lengths: a dQ tile without a live row skips its key loop and
+    // emits nothing, the dK / dV loop ends at the last live 32-query stage.  Data-driven, so a caller whose padded rows DO carry gradient
+    // loses nothing but the shortcut.  nullptr: off.
+    int* qlive;
 };
 
 // 8 fp16 -> 8 bf16 (round to nearest even) in one 16-byte register slot: q / k / v exist as fp16 planes only under the fp16 attention
@@ -2562,7 +2569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < PPW; ++j) BMT_P_DMA_V(j, tl, s);
     }
-    if (tid == 0) sLast[0] = -1;
+    if (tid == 0) { sLast[0] = -1; sLast[1] = 0; }
     __syncthreads();
     {
         int last = -1;
@@ -2634,6 +2641,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bfbits_lo(dob[ks][j])), fabsf(bfbits_hi(dob[ks][j]))));
     amax = half_max(amax);
+    if (__ballot(qok && amax > 0.f) != 0ull && lane == 0) atomicOr(&sLast[1], 1 << wid);      // this wave's 32 queries carry gradient
     int kexp = 0;
     if (amax > 0.f) kexp = 6 - ((int)((__float_as_uint(amax) >> 23) & 0xffu) - 127);
     kexp = max(-60, min(60, kexp));
@@ -2687,7 +2695,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int ntile_run = (XP & 16) ? 0 : sLast[0] / BC + 1;                 // (0 when every key is masked)
+    // (0 when every key is masked -- or, with p.qlive, when no query of the tile has a non-zero dO: dQ = 0 exactly, and the P / dS blocks of
+    // these rows are never read: attn_bwd_dkvg8_kernel skips or wipes the stages whose live bit is clear)
+    const int livemask = sLast[1];
+    if (p.qlive != nullptr && tid == 0) p.qlive[(int64_t)bh * nqt + qt] = livemask;
+    const int ntile_run = ((XP & 16) || (p.qlive != nullptr && livemask == 0)) ? 0 : sLast[0] / BC + 1;
 
     // A dependent MFMA issues back to back with its predecessor or waits out its latency (MI355X_MICROARCH.md: any instruction between two
     // MFMAs on one accumulator costs ~43 cycles): consecutive MFMAs here always belong to DIFFERENT accumulators -- S and dP' steps alternate
@@ -2901,7 +2913,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int key = kt * 128 + kg * 32 + l31;
     const bool kin = key < p.Sk;
     const bool kok = kin && (p.mask == nullptr || p.mask[(int64_t)b * p.mask_bs + key] != 0);
-    const int nst_run = __syncthreads_or((int)kok) ? nst : 0;
+    // live 32-query stages of this (batch, head) (AttnPB.qlive: bit t = stage t has a non-zero dO): the loop ends behind the last live
+    // one; a dead stage BEFORE it (never in this model: padding is a suffix) runs with its P / dS fragments wiped -- nobody wrote them
+    uint64_t smask = ~0ull;
+    if (p.qlive != nullptr) {
+        smask = 0ull;
+        const int nqt = (p.Sq + 127) / 128;
+        for (int i = 0; i < nqt; ++i) smask |= (uint64_t)(uint32_t)(p.qlive[(int64_t)bh * nqt + i] & 15) << (4 * i);
+    }
+    const int live_end = smask == 0ull ? 0 : 64 - __builtin_clzll(smask);
+    const int nst_run = __syncthreads_or((int)kok) ? min(nst, live_end) : 0;
 
     typedef __attribute__((address_space(3))) void* lptr_t;
     const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qbws + (int64_t)b * p.bsqb + h * DK), 0,
@@ -2997,8 +3018,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
             BMT_H_TFRAG(0); BMT_H_TFRAG(1); BMT_H_TFRAG(2);
             lgkm_wait<2 * PF>(yr[0], yr[1]); lgkm_wait<2 * PF>(yr[2], yr[3]); lgkm_wait<2 * PF>(yr[4], yr[5]); lgkm_wait<2 * PF>(yr[6], yr[7]);
-            if (t == nst - 1 && (p.Sq & 31) != 0) {       // rows past Sq must not contribute whatever the ring holds there
-                const int rem = p.Sq - t * BQ;
+            const bool live_t = (smask >> t) & 1ull;
+            if ((t == nst - 1 && (p.Sq & 31) != 0) || !live_t) {       // rows past Sq (and the rows of a dead stage) must not contribute whatever the ring holds there
+                const int rem = live_t ? p.Sq - t * BQ : 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int kk = (i >> 1) & 1, u = i & 1;
@@ -3289,6 +3311,10 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
             p.Pws = a->P_ws; p.dSws = a->dS_ws; p.Qbws = a->Qb_ws;
             p.ws_pitch = 128; p.ws_tile = (int64_t)a->Sq * 128; p.ws_slab = (int64_t)((a->Sk + 127) / 128) * p.ws_tile;
             p.ldqb = (int64_t)a->H * a->dk; p.bsqb = (int64_t)a->Sq * a->H * a->dk;
+            // the live-query bits sit behind the scaled copy of q in Qb_ws (bmt_attn_bwd_split_ws sized it for them); one 64-bit mask
+            // per (batch, head) in the dK / dV kernel: 64 stages of 32 queries
+            static const int qskip = getenv("BMT_ATTN_QSKIP") ? atoi(getenv("BMT_ATTN_QSKIP")) : 1;      // A/B experiments only
+            p.qlive = (qskip && a->Sq <= 2048) ? reinterpret_cast<int*>(a->Qb_ws + (int64_t)a->B * p.bsqb) : nullptr;
         }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -3313,7 +3339,7 @@ extern "C" int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64
     }
     const int64_t nkt = (Sk + 127) / 128, nqt = (Sq + 127) / 128;
     *n_pds = (int64_t)B * H * nkt * Sq * 128;
-    *n_qb = (int64_t)B * Sq * H * dk;
+    *n_qb = (int64_t)B * Sq * H * dk + (((int64_t)2 * B * H * nqt + 7) & ~(int64_t)7);      // + one int of live-query bits per (batch, head, query tile)
     *n_bias = ((int64_t)B * nqt + 2 * (int64_t)B * nkt) * H * dk;
     return BMT_OK;
 }

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                       int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, float* dx, int64_t lddx,
                                                       const float* dx_add, int64_t ldadd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      float* __restrict__ partial, int rows_per_wave, int rows, int D) {
+                                                      float* __restrict__ partial, int rows_per_wave, int rows, int D,
+                                                      const float* __restrict__ dx_add2, int64_t ldadd2) {
     extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][3 waves][NV*256]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float4 ag[NV], ab[NV], gm[NV];
@@ -134,6 +135,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 o.z = rs * (g[i].z - c1 - xh[i].z * c2); o.w = rs * (g[i].w - c1 - xh[i].w * c2);
                 if (dx_add) {
                     const float4 p = ld4(dx_add + (int64_t)row * ldadd + c);
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                if (dx_add2) {      // a THIRD consumer of the normalised tensor's input (the other modality's key / value projection)
+                    const float4 p = ld4(dx_add2 + (int64_t)row * ldadd2 + c);
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 *reinterpret_cast<float4*>(dxr + c) = o;
@@ -268,7 +273,7 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
 
 static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
-                       int D, void* stream, bool leave_partials);
+                       int D, void* stream, bool leave_partials, const float* dx_add2 = nullptr, int64_t ldadd2 = 0);
 
 extern "C" int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                      const float* mean, const float* rstd, float* dx, int64_t lddx, const float* dx_add,
@@ -284,15 +289,22 @@ extern "C" int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const fl
     return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true);
 }
 
+extern "C" int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                                          const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2,
+                                          int64_t ldadd2, float* partial_ws, int rows, int D, void* stream) {
+    BMT_CHECK_ARG(partial_ws, "bmt_layernorm_bwd_partial2: needs the partial workspace");
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2);
+}
+
 static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
-                       int D, void* stream, bool leave_partials) {
+                       int D, void* stream, bool leave_partials, const float* dx_add2, int64_t ldadd2) {
     BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
     if (rows == 0) return leave_partials ? 1 : BMT_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && al16(x) && al16(dy) && al16(dx) &&
-                     al16(gamma) && D <= 2048 && (!dx_add || (al16(dx_add) && ldadd % 4 == 0));
-    if (!vec && leave_partials) return 1;       // (the scalar kernel adds into dgamma / dbeta directly: the caller falls back)
+                     al16(gamma) && D <= 2048 && (!dx_add || (al16(dx_add) && ldadd % 4 == 0)) && (!dx_add2 || (al16(dx_add2) && ldadd2 % 4 == 0));
+    if (!vec && (leave_partials || dx_add2)) return 1;       // (the scalar kernel adds into dgamma / dbeta directly and knows one addend: the caller falls back)
     if (!vec) {
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx,
                            lddx, dx_add, ldadd, dgamma, dbeta, rows, D);
@@ -303,7 +315,7 @@ static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ld
     const int nv = bmt_cdiv(D, 256);
 #define BMT_LN(NV)                                                                                                         \
     hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 2 * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
-                       dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D)
+                       dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D, dx_add2, ldadd2)
     if (nv <= 1) BMT_LN(1);
     else if (nv <= 2) BMT_LN(2);
     else if (nv <= 4) BMT_LN(4);

@@ -140,3 +140,78 @@ extern "C" int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out,
     BMT_CHECK_LAUNCH("bmt_colsum");
     return BMT_OK;
 }
+
+// ---------------------------------------------------------------- small step-protocol kernels (replace ATen fills / copies / reductions)
+namespace {
+
+// zero fill, 16 bytes per thread and trip: the flat gradient arena of a step (202 MB at config[1]) in ONE launch instead of a fill per bucket
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, int64_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
+}
+__global__ __launch_bounds__(256) void zero_tail_kernel(unsigned char* __restrict__ p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
+// training_loop's caption bookkeeping (epoch_loops/captioning_epoch_loops.py:130-134) in one launch of one workgroup:
+//   x = caption_idx[:, :-1], y = caption_idx[:, 1:] (contiguous int64 copies), n_tokens = (y != pad_idx).sum()
+__global__ __launch_bounds__(256) void caption_shift_kernel(const int64_t* __restrict__ caps, int64_t ld, int B, int T1, int64_t pad,
+                                                             int64_t* __restrict__ x, int64_t* __restrict__ y, int64_t* __restrict__ n_tokens) {
+    __shared__ int cnt[4];
+    const int T = T1 - 1;
+    int mine = 0;
+    for (int i = threadIdx.x; i < B * T; i += 256) {
+        const int b = i / T, t = i % T;
+        const int64_t a = caps[(int64_t)b * ld + t], c = caps[(int64_t)b * ld + t + 1];
+        x[i] = a;
+        y[i] = c;
+        mine += (c != pad) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) n_tokens[0] = (int64_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+}
+
+// loss = sum-KL / n_tokens and the gradient scale 1 / n_tokens the optimizer multiplies in (captioning_epoch_loops.py:135)
+__global__ void loss_finish_kernel(const float* __restrict__ kl, const int64_t* __restrict__ n_tokens, float* __restrict__ loss,
+                                   float* __restrict__ grad_scale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float n = (float)n_tokens[0];
+        if (loss) loss[0] = kl[0] / n;
+        if (grad_scale) grad_scale[0] = 1.0f / n;
+    }
+}
+
+}  // namespace
+
+extern "C" int bmt_zero(void* p, int64_t nbytes, void* stream) {
+    BMT_CHECK_ARG(p && nbytes >= 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "bmt_zero: null or unaligned (16 bytes) pointer");
+    if (nbytes == 0) return BMT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n16 = nbytes / 16;
+    if (n16 > 0) {
+        int64_t blocks = (n16 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(p), n16);
+    }
+    if (nbytes % 16) hipLaunchKernelGGL(zero_tail_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<unsigned char*>(p) + n16 * 16, (int)(nbytes % 16));
+    BMT_CHECK_LAUNCH("bmt_zero");
+    return BMT_OK;
+}
+
+extern "C" int bmt_caption_shift(const int64_t* caption_idx, int64_t ld, int B, int T1, int64_t pad_idx, int64_t* x, int64_t* y,
+                                 int64_t* n_tokens, void* stream) {
+    BMT_CHECK_ARG(caption_idx && x && y && n_tokens && B > 0 && T1 > 1 && ld >= T1, "bmt_caption_shift: bad args");
+    hipLaunchKernelGGL(caption_shift_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, caption_idx, ld, B, T1, pad_idx, x, y, n_tokens);
+    BMT_CHECK_LAUNCH("bmt_caption_shift");
+    return BMT_OK;
+}
+
+extern "C" int bmt_loss_finish(const float* kl, const int64_t* n_tokens, float* loss, float* grad_scale, void* stream) {
+    BMT_CHECK_ARG(kl && n_tokens && (loss || grad_scale), "bmt_loss_finish: bad args");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl, n_tokens, loss, grad_scale);
+    BMT_CHECK_LAUNCH("bmt_loss_finish");
+    return BMT_OK;
+}

@@ -12,4 +12,4 @@ class LabelSmoothing(nn.Module):
         self.pad_idx = pad_idx
 
     def forward(self, pred, target):  # pred (B, S, V) log-probs, target (B, S)
-        return ops.LabelSmoothingFn.apply(pred, target, float(self.smoothing), int(self.pad_idx))
+        return ops.label_smoothing(pred, target, float(self.smoothing), int(self.pad_idx))

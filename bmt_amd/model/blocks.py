@@ -184,18 +184,32 @@ class ResidualConnection(nn.Module):
         self.dropout = nn.Dropout(dout_p)
         self._site = ops.new_site()
 
-    def forward(self, x, sublayer, fp32_out=True, out_planes=None):
+    def prenorm(self, x, fp32_out=True):
+        """the LayerNorm half of forward() ahead of time, for a caller that hands ``x`` to ANOTHER consumer as well (the bi-modal encoder layer:
+        a stream's post-self-attention value is this connection's input and the other modality's key / value input): returns (pre, x_kv) --
+        ``pre`` goes to forward(None, sublayer, pre=pre), ``x_kv`` is x for the other consumer, tied to the same autograd node so that the three
+        gradients of x meet in the LayerNorm backward kernel (ops.ResidualNormFn).  (None, x) when the fused form is off."""
+        if not ops.FUSE_RESIDUAL or not x.is_cuda:
+            return None, x
+        xid, xn, xkv = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm,
+                                         fp32_out=fp32_out or not ops.LN_PLANES_ONLY, kv_alias=True)
+        return (xid, xn), xkv
+
+    def forward(self, x, sublayer, fp32_out=True, out_planes=None, pre=None):
         # x (B, S, D):  x + dropout(sublayer(LN(x)));  fp32_out False (the bi-modal layers' calls): LN(x) is handed to the sublayer as
         # operand planes only (ops.residual_norm); out_planes: a plane format the READER of the result wants -- a sublayer that takes the
-        # fused residual writes it from the same epilogue (attached to the result: ops.planes_of)
+        # fused residual writes it from the same epilogue (attached to the result: ops.planes_of); pre: the result of prenorm(x)
         p = self.dout_p if self.training else 0.0
         if not ops.FUSE_RESIDUAL:
             res = sublayer(layer_norm(self.norm, x))
             return ops.DropoutAddFn.apply(x, res, p, self._site)
         # fused form (ops.ResidualNormFn): LN emits its operand planes, the sublayer's last GEMM takes the offered residual and
         # adds dropout + x in its epilogue; a sublayer that does not take the offer gets the separate kernel
-        xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm,
-                                    fp32_out=fp32_out or not ops.LN_PLANES_ONLY)
+        if pre is not None:
+            xid, xn = pre
+        else:
+            xid, xn = ops.residual_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, ops.policy_of(self).gemm,
+                                        fp32_out=fp32_out or not ops.LN_PLANES_ONLY)
         off = ops.offer_residual(xid, p, self._site, out_planes)
         res = sublayer(xn)
         ops.take_residual()

@@ -54,9 +54,12 @@ class BiModalEncoderLayer(nn.Module):
         kv_fmt = ops.act_fmt(ops.policy_of(self).kv_gemm)
         M1 = self.res_layers_M1[0](M1, lambda y: self.self_att_M1(y, y, y, M1_mask), fp32_out=False, out_planes=kv_fmt)
         M2 = self.res_layers_M2[0](M2, lambda y: self.self_att_M2(y, y, y, M2_mask), fp32_out=False, out_planes=kv_fmt)
-        # 2. cross-modal attention: queries are the normalised stream, keys/values the OTHER stream as it is now
-        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2, M2, M2_mask), fp32_out=False)
-        M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1, M1, M1_mask), fp32_out=False)
+        # 2. cross-modal attention: queries are the normalised stream, keys/values the OTHER stream as it is now.  A stream's value has three
+        # consumers (residual, LayerNorm, the other stream's key / value projections): all three leave ONE autograd node (prenorm)
+        pre1, M1kv = self.res_layers_M1[1].prenorm(M1, fp32_out=False)
+        pre2, M2kv = self.res_layers_M2[1].prenorm(M2, fp32_out=False)
+        M1m2 = self.res_layers_M1[1](M1, lambda y: self.bi_modal_att_M1(y, M2kv, M2kv, M2_mask), fp32_out=False, pre=pre1)
+        M2m1 = self.res_layers_M2[1](M2, lambda y: self.bi_modal_att_M2(y, M1kv, M1kv, M1_mask), fp32_out=False, pre=pre2)
         # 3. feed-forward
         M1m2 = self.res_layers_M1[2](M1m2, self.feed_forward_M1, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
         M2m1 = self.res_layers_M2[2](M2m1, self.feed_forward_M2, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
@@ -74,19 +77,23 @@ class BiModalEncoderLayer(nn.Module):
         v = NS(x=M2, mask=M2_mask, res=self.res_layers_M2, self_att=self.self_att_M2, cross=self.bi_modal_att_M2, ffn=self.feed_forward_M2)
         side, main = (a, v) if ops.SIDE_CHAIN_AUDIO else (v, a)
         kv_fmt = ops.act_fmt(ops.policy_of(self).kv_gemm)      # a self-attention's result is the other chain's key / value input
+        # (a chain's post-self-attention value has three consumers -- residual, LayerNorm, the OTHER chain's key / value projections: prenorm
+        # ties them to one autograd node, whose backward kernel adds the three gradients; x1kv is x1 for the other chain)
         with torch.cuda.stream(s2):
             side.x1 = side.res[0](side.x, lambda y: side.self_att(y, y, y, side.mask), fp32_out=False, out_planes=kv_fmt)
+            side.pre, side.x1kv = side.res[1].prenorm(side.x1, fp32_out=False)
             e_side = s2.record_event()
         main.x1 = main.res[0](main.x, lambda y: main.self_att(y, y, y, main.mask), fp32_out=False, out_planes=kv_fmt)
+        main.pre, main.x1kv = main.res[1].prenorm(main.x1, fp32_out=False)
         e_main = s1.record_event()
         s1.wait_event(e_side)
-        ops.record_stream(side.x1, s1)
-        main.out = main.res[1](main.x1, lambda y: main.cross(y, side.x1, side.x1, side.mask), fp32_out=False)
+        ops.record_stream(side.x1kv, s1)
+        main.out = main.res[1](main.x1, lambda y: main.cross(y, side.x1kv, side.x1kv, side.mask), fp32_out=False, pre=main.pre)
         main.out = main.res[2](main.out, main.ffn, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
         with torch.cuda.stream(s2):
             s2.wait_event(e_main)
-            ops.record_stream(main.x1, s2)
-            side.out = side.res[1](side.x1, lambda y: side.cross(y, main.x1, main.x1, main.mask), fp32_out=False)
+            ops.record_stream(main.x1kv, s2)
+            side.out = side.res[1](side.x1, lambda y: side.cross(y, main.x1kv, main.x1kv, main.mask), fp32_out=False, pre=side.pre)
             side.out = side.res[2](side.out, side.ffn, fp32_out=False, out_planes=getattr(self, "memory_planes_fmt", None))
         return a.out, v.out
 

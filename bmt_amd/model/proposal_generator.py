@@ -58,7 +58,7 @@ class ConvKFn(torch.autograd.Function):
         Dout, _, k = W.shape
         pad = k // 2
         halo = max(pad, getattr(xc, "_bmt_halo", pad))
-        prec = ops.policy_of("head").gemm
+        prec = ops.policy_of("head_conv").gemm
         kmax = 2 * halo + 1
         X = ConvKFn._padded(xc, halo, kmax, ops.act_fmt(prec))
         cin = X.hi.shape[1]

@@ -69,6 +69,11 @@ POLICIES = {
     # tests/test_gpu_proposal.py at round 2: inside the 1e-3 bar but with < 2x margin, and exp() turns it into 1e-3 relative on
     # the predicted lengths.)
     "head": Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "head"),
+    # ... except a head's FIRST layer, the k-tap Conv1d (k up to 211 taps over 1024 channels: 90 % of a head's FLOPs, the dominant class of
+    # train_prop): fp16 activation x split fp16 weight, two MFMA passes instead of three.  The 1 x 1 layers behind it -- directly under the
+    # sigmoid / exp of the predictions -- stay split-bf16.  BMT_HEAD_CONV=x3 restores three passes (A/B; tests/test_gpu_proposal.py holds the
+    # predictions to 1e-3 either way)
+    "head_conv": Policy(PREC_F16W2 if _os.environ.get("BMT_HEAD_CONV", "w2") != "x3" else PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "head_conv"),
     None: Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
 }
 _OVERRIDE = [None]      # a Policy applied to EVERY site (A/B measurements, tests), or None
@@ -141,7 +146,7 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
@@ -153,6 +158,8 @@ class StepContext:
         self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
         self.kv_cache = None         # dict while bmt_amd.decode.greedy_decoder runs: id(attention module) -> (memory, k planes, v planes)
         self.allow_streams = True    # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
+        self.last_gen = None         # GenHandle of the GeneratorFn.forward that just ran (picked up by model.generators.Generator)
+        self.gen_handles = []        # handles whose loss took the fused backward: flush_dw settles their parameters' use counts
 
 
 _contexts = {}
@@ -336,6 +343,14 @@ def new_site() -> int:
 
 
 # ----------------------------------------------------------------------------- raw launches
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """t[...] = 0 in one library launch (bmt_zero): contiguous CUDA tensors whose storage starts on a 16-byte boundary"""
+    if not t.is_cuda or not t.is_contiguous() or t.data_ptr() % 16:
+        return t.zero_()
+    _lib.check(lib.bmt_zero(_p(t), t.numel() * t.element_size(), _st()), "bmt_zero")
+    return t
+
+
 _SPLITK_TARGET = int(_os.environ.get("BMT_SPLITK_TARGET", "512"))     # workgroups a split launch aims for (A/B experiments)
 
 
@@ -903,6 +918,11 @@ def flush_dw():
         _colsum_launch(cs)
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
         grad_done(p)
+    hs, ctx.gen_handles = ctx.gen_handles, []
+    for h in hs:              # the generator's parameters were counted twice (GeneratorFn + FusedGenLossFn) and only the fused node ran
+        if not h.ran:
+            grad_done(h.W)
+            grad_done(h.b)
 
 
 DEFER_COLSUM = _os.environ.get("BMT_DEFER_COLSUM", "1") != "0"      # A/B switch: "0" = every small reduction is its own launch again
@@ -1385,13 +1405,15 @@ def attach_planes(t, pl: Planes):
 
 
 class ResidualNormFn(torch.autograd.Function):
-    """x -> (x, LayerNorm(x)): the two branches of a ResidualConnection leave one node, so that their gradients meet again
-    in ONE kernel (dx = g_residual + LN backward(g_norm)).  The forward kernel also writes the operand planes of the
+    """x -> (x, LayerNorm(x) [, x again]): the branches of a ResidualConnection leave one node, so that their gradients meet again
+    in ONE kernel (dx = g_residual + LN backward(g_norm) [+ g_kv]).  The forward kernel also writes the operand planes of the
     normalised output (bf16 hi + the second plane the sublayer's first GEMM reads: bf16 lo or fp16), which is all that GEMM
-    reads."""
+    reads.  ``kv_alias``: a third output, x once more, for a consumer outside the ResidualConnection -- the OTHER modality's
+    cross-attention reads a stream's post-self-attention value as its key / value input (model/encoders.py:63-79), and autograd
+    would add that consumer's gradient to this node's with a kernel of its own (8 adds of 13-34 MB per step at config[1])."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fmt, fp32_out=True):
+    def forward(ctx, x, gamma, beta, eps, fmt, fp32_out=True, kv_alias=False):
         note_use(gamma, beta)
         xc = _f32c(x)
         D = xc.shape[-1]
@@ -1406,17 +1428,29 @@ class ResidualNormFn(torch.autograd.Function):
                                                 int(pl.fh is not None), pl.hi.stride(0), rows, D, eps, _st()), "bmt_layernorm_fwd_planes")
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
+        ctx.kv_alias = bool(kv_alias)
         context().last_ln = pl
+        if kv_alias:
+            return xc.view_as(xc), y.view(xc.shape), xc.view_as(xc)
         return xc.view_as(xc), y.view(xc.shape)
 
     @staticmethod
-    def backward(ctx, g_id, g_n):
-        if g_n is None:
-            return g_id, None, None, None, None, None
+    def backward(ctx, g_id, g_n, g_kv=None):
+        nout = 7
         x2, gamma, mean, rstd = ctx.saved_tensors
         rows, D = x2.shape
+        if g_n is None:
+            if g_id is not None and g_kv is not None:
+                a, b = _f32c(g_id), _f32c(g_kv)
+                out = torch.empty_like(a)
+                _lib.check(lib.bmt_add(_p(a), _p(b), _p(out), a.numel(), _st()), "bmt_add")
+                return (out,) + (None,) * (nout - 1)
+            return (g_id if g_id is not None else g_kv,) + (None,) * (nout - 1)
         dy2 = _f32c(g_n).view(rows, D)
         add = _f32c(g_id).view(rows, D) if g_id is not None else None
+        add2 = _f32c(g_kv).view(rows, D) if g_kv is not None else None
+        if add is None and add2 is not None:
+            add, add2 = add2, None
         dx = torch.empty_like(x2)
         beta = ctx.beta
         sg, sb = static_grad(gamma), static_grad(beta)
@@ -1425,7 +1459,14 @@ class ResidualNormFn(torch.autograd.Function):
         db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         nblk = max(1, lib.bmt_layernorm_bwd_blocks(rows))
         ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
-        rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, _st())
+        if add2 is not None:
+            rc = lib.bmt_layernorm_bwd_partial2(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), rows, D, _st())
+            if rc == 1:            # (shapes the vector kernel does not take: one addend by the kernel, the other by a separate add)
+                tmp = torch.empty_like(add)
+                _lib.check(lib.bmt_add(_p(add), _p(add2), _p(tmp), add.numel(), _st()), "bmt_add")
+                add, add2 = tmp, None
+        if add2 is None:
+            rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, _st())
         if rc == 0:        # dgamma / dbeta partials of the kernel's workgroups are in ws: their sums join the pass's other small reductions
             colsum_deferred([(ws, 0, dg, nblk, 2 * D, D), (ws, D, db, nblk, 2 * D, D)], params=(gamma, beta) if fused else ())
         else:
@@ -1437,20 +1478,29 @@ class ResidualNormFn(torch.autograd.Function):
         if fused:
             grad_done(gamma)
             grad_done(beta)
-            return dx, None, None, None, None, None
-        return dx, dg, db, None, None, None
+            return (dx,) + (None,) * (nout - 1)
+        return (dx, dg, db) + (None,) * (nout - 3)
 
 
-def residual_norm(x, gamma, beta, eps, prec: int = PREC_BF16X3, fp32_out: bool = True):
-    """(x passed through, LayerNorm(x) carrying its operand planes as ``_bmt_planes``); prec: the forward precision of the
-    sublayer's first GEMM.  fp32_out False: the normalised tensor's fp32 values are not written -- for sublayers that read the planes
-    (MultiheadedAttention, PositionwiseFeedForward); a consumer that would need the values raises (_need_fp32)."""
-    xid, xn = ResidualNormFn.apply(x, gamma, beta, eps, act_fmt(prec), fp32_out)
+def residual_norm(x, gamma, beta, eps, prec: int = PREC_BF16X3, fp32_out: bool = True, kv_alias: bool = False):
+    """(x passed through, LayerNorm(x) carrying its operand planes as ``_bmt_planes`` [, x once more for an outside consumer]); prec: the
+    forward precision of the sublayer's first GEMM.  fp32_out False: the normalised tensor's fp32 values are not written -- for sublayers
+    that read the planes (MultiheadedAttention, PositionwiseFeedForward); a consumer that would need the values raises (_need_fp32).
+    kv_alias: see ResidualNormFn -- the third tensor carries the operand planes attached to ``x`` (a self-attention's result written as the
+    other chain's key / value operand)."""
+    outs = ResidualNormFn.apply(x, gamma, beta, eps, act_fmt(prec), fp32_out, kv_alias)
+    xid, xn = outs[0], outs[1]
     c = context()
     attach_planes(xn, c.last_ln)
     c.last_ln = None
     if not fp32_out:
         xn._bmt_no_fp32 = True
+    if kv_alias:
+        xkv = outs[2]
+        pl = getattr(x, "_bmt_planes", None)
+        if pl is not None and getattr(x, "_bmt_planes_version", x._version) == x._version:
+            attach_planes(xkv, pl)
+        return xid, xn, xkv
     return xid, xn
 
 
@@ -1929,6 +1979,27 @@ class MHAFn(torch.autograd.Function):
         return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None, None
 
 
+FUSE_GEN_LOSS = _os.environ.get("BMT_FUSE_GEN_LOSS", "1") != "0"      # A/B switch: "0" = the generator and the loss as separate autograd nodes
+
+
+class GenHandle:
+    """what a Generator's output carries for a LabelSmoothing that is applied to it directly (K7 as one forward and one backward kernel):
+    the generator's autograd-tracked input and parameters, the 2-D log-probabilities and their row sums"""
+    __slots__ = ("x", "W", "b", "logp", "rowsum", "version", "ran")
+
+    def __init__(self, x, W, b, logp, rowsum):
+        self.x, self.W, self.b, self.logp, self.rowsum = x, W, b, logp, rowsum
+        self.version, self.ran = None, False
+
+
+def generator_handle(pred) -> Optional["GenHandle"]:
+    """the GenHandle of ``pred`` if it is a Generator's untouched output (same values: tensor version unchanged)"""
+    h = getattr(pred, "_bmt_gen", None)
+    if h is None or h.version != pred._version or h.logp.numel() != pred.numel():
+        return None
+    return h
+
+
 class GeneratorFn(torch.autograd.Function):
     """log_softmax(linear(x))   Generator.forward model/generators.py:18-19."""
 
@@ -1939,13 +2010,18 @@ class GeneratorFn(torch.autograd.Function):
         x2 = xc.view(-1, xc.shape[-1])
         V = W.shape[0]
         logp = linear_fwd(x2, W, b, precision=policy_of(None).gemm)
-        _lib.check(lib.bmt_log_softmax_fwd(_p(logp), logp.stride(0), logp.shape[0], V, _st()), "bmt_log_softmax_fwd")
+        # log-softmax with the row in registers (one read, one write) + the rows' sums, which are all LabelSmoothing needs of the tensor
+        rowsum = torch.empty(logp.shape[0], device=logp.device, dtype=torch.float32)
+        _lib.check(lib.bmt_log_softmax_fwd_stats(_p(logp), logp.stride(0), logp.shape[0], V, _p(rowsum), _st()), "bmt_log_softmax_fwd_stats")
         ctx.save_for_backward(x2, W, logp)
         ctx.params = (W, b)
+        ctx.handle = GenHandle(x, W, b, logp, rowsum)
+        context().last_gen = ctx.handle
         return logp.view(*xc.shape[:-1], V)
 
     @staticmethod
     def backward(ctx, dlogp):
+        ctx.handle.ran = True
         x2, W, logp = ctx.saved_tensors
         V = W.shape[0]
         d2 = _f32c(dlogp).view(-1, V)
@@ -1959,6 +2035,78 @@ class GeneratorFn(torch.autograd.Function):
         return dx, dW, db
 
 
+def generator(x, W, b):
+    """Generator.forward: the log-probabilities, carrying a GenHandle for a loss applied to them directly"""
+    out = GeneratorFn.apply(x, W, b)
+    c = context()
+    h, c.last_gen = c.last_gen, None
+    if h is not None and isinstance(out, torch.Tensor):
+        h.version = out._version
+        out._bmt_gen = h
+    return out
+
+
+def _ls_kl_forward(p2, t, smoothing, pad_idx, rowsum=None):
+    """(loss 0-dim, row workspace) of LabelSmoothing.forward over 2-D log-probabilities; with the rows' sums in ONE launch"""
+    rows, V = p2.shape
+    loss = torch.empty((), device=p2.device, dtype=torch.float32)
+    ws = torch.empty(rows + 1, device=p2.device, dtype=torch.float32)
+    if rowsum is not None:
+        _lib.check(lib.bmt_ls_kl_fwd_stats(_p(p2), p2.stride(0), _p(t), _p(rowsum), _p(loss), _p(ws), rows, V, smoothing, pad_idx, _st()),
+                   "bmt_ls_kl_fwd_stats")
+    else:
+        _lib.check(lib.bmt_ls_kl_fwd(_p(p2), p2.stride(0), _p(t), _p(loss), _p(ws), rows, V, smoothing, pad_idx, _st()), "bmt_ls_kl_fwd")
+    return loss, ws
+
+
+class FusedGenLossFn(torch.autograd.Function):
+    """LabelSmoothing(Generator(x)) as ONE autograd node over the generator's input and parameters (model/generators.py:18-19 +
+    loss/label_smoothing.py:12-32): the forward reads the log-probabilities the generator already wrote (row sums + two gathers per row),
+    the backward goes from them straight to the bf16 operand plane of d loss / d logits and its column sums (bmt_gen_lskl_bwd) and on to
+    dX / dW -- the (B*Tc, V) tensor is read once and written once as 16 bits, instead of ls_kl_bwd -> log_softmax_bwd -> plane conversion.
+    The gradient bypasses the log-probability tensor's own node (GeneratorFn), which still serves any OTHER consumer of the tensor."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, target, smoothing, pad_idx, handle):
+        note_use(W, b)
+        logp = handle.logp
+        t = target.contiguous().view(-1).long()
+        loss, ws = _ls_kl_forward(logp, t, smoothing, pad_idx, handle.rowsum)
+        xc = _f32c(x)
+        ctx.save_for_backward(t, ws, logp, W, xc.view(-1, xc.shape[-1]))
+        ctx.meta = (smoothing, pad_idx, x.shape)
+        ctx.params = (W, b)
+        ctx.handle = handle
+        context().gen_handles.append(handle)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        t, ws, logp, W, x2 = ctx.saved_tensors
+        smoothing, pad_idx, xshape = ctx.meta
+        Wp, bp = ctx.params
+        rows, V = logp.shape
+        gs = _f32c(g).reshape(1)
+        P = Planes(torch.empty(rows, _pad64(V), device=logp.device, dtype=torch.bfloat16), None, rows, V)
+        gb = static_grad(bp)
+        cs = gb if gb is not None else (torch.zeros(V, device=logp.device, dtype=torch.float32) if bp is not None else None)
+        _lib.check(lib.bmt_gen_lskl_bwd(_p(logp), logp.stride(0), _p(t), _p(ws), _p(gs), rows, V, smoothing, pad_idx, _p(P.hi), P.hi.stride(0),
+                                        _p(cs), _st()), "bmt_gen_lskl_bwd")
+        if gb is not None:
+            grad_done(bp)
+        dx = linear_dx(P, Wp).view(xshape) if ctx.needs_input_grad[0] else None
+        dW, _ = wgrad(Wp, None, P, bwd_planes(x2))
+        return dx, dW, (None if gb is not None else cs), None, None, None, None
+
+
+def label_smoothing(pred, target, smoothing: float, pad_idx: int):
+    """LabelSmoothing.forward; on a Generator's untouched output (training) the fused node above"""
+    h = generator_handle(pred) if FUSE_GEN_LOSS else None
+    if h is not None and torch.is_grad_enabled() and pred.requires_grad and pred.is_cuda and h.logp.shape[1] > 2:
+        return FusedGenLossFn.apply(h.x, h.W, h.b, target, smoothing, pad_idx, h)
+    return LabelSmoothingFn.apply(pred, target, smoothing, pad_idx)
+
+
 class LabelSmoothingFn(torch.autograd.Function):
     """LabelSmoothing.forward loss/label_smoothing.py:12-32 (sum-KL incl. the flat-index-0 pad quirk)."""
 
@@ -1967,11 +2115,8 @@ class LabelSmoothingFn(torch.autograd.Function):
         V = pred.shape[-1]
         p2 = _f32c(pred).view(-1, V)
         t = target.contiguous().view(-1).long()
-        rows = p2.shape[0]
-        loss = torch.empty((), device=pred.device, dtype=torch.float32)
-        ws = torch.empty(rows + 1, device=pred.device, dtype=torch.float32)
-        _lib.check(lib.bmt_ls_kl_fwd(_p(p2), p2.stride(0), _p(t), _p(loss), _p(ws), rows, V, smoothing, pad_idx, _st()),
-                   "bmt_ls_kl_fwd")
+        h = generator_handle(pred)
+        loss, ws = _ls_kl_forward(p2, t, smoothing, pad_idx, h.rowsum if h is not None else None)
         ctx.save_for_backward(t, ws)
         ctx.shape, ctx.smoothing, ctx.pad_idx = pred.shape, smoothing, pad_idx
         return loss
@@ -2035,6 +2180,32 @@ class EmbedFn(torch.autograd.Function):
         _lib.check(lib.bmt_prep_embed_bwd(_p(idc), _p(dyc), _p(dW), B, S, D, V, scale, p, _p(rng_tensor()) if p > 0 else None, site,
                                           _st()), "bmt_prep_embed_bwd")
         return None, dW, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- step protocol (training_loop's bookkeeping as library launches)
+def caption_shift(caption_idx: torch.Tensor, pad_idx: int):
+    """(x, y, n_tokens) = (caption_idx[:, :-1], caption_idx[:, 1:], (y != pad_idx).sum()) of epoch_loops/captioning_epoch_loops.py:130-134 in
+    ONE launch: x, y contiguous int64 (B, Tc), n_tokens an int64 0-dim tensor.  (Sliced views went through three ``.contiguous()`` copies --
+    masks, embedding, loss -- and the count through a compare + a reduction: five framework kernels at the head of the step.)"""
+    if not caption_idx.is_cuda or caption_idx.dtype != torch.int64 or caption_idx.dim() != 2 or caption_idx.stride(1) != 1 or caption_idx.shape[1] < 2:
+        x, y = caption_idx[:, :-1], caption_idx[:, 1:]
+        return x, y, (y != pad_idx).sum()
+    B, T1 = caption_idx.shape
+    xy = torch.empty(2, B, T1 - 1, device=caption_idx.device, dtype=torch.int64)
+    n = torch.empty(1, device=caption_idx.device, dtype=torch.int64)
+    _lib.check(lib.bmt_caption_shift(_p(caption_idx), caption_idx.stride(0), B, T1, int(pad_idx), _p(xy[0]), _p(xy[1]), _p(n), _st()), "bmt_caption_shift")
+    return xy[0], xy[1], n.view(())
+
+
+def loss_finish(kl: torch.Tensor, n_tokens: torch.Tensor, grad_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """loss = kl / n_tokens (captioning_epoch_loops.py:135) and, into ``grad_scale`` (fp32 [1], optional), 1 / n_tokens -- one launch"""
+    if not kl.is_cuda or kl.dtype != torch.float32 or n_tokens.dtype != torch.int64 or kl.numel() != 1 or n_tokens.numel() != 1:
+        if grad_scale is not None:
+            grad_scale.copy_((1.0 / n_tokens.to(torch.float32)).reshape(1))
+        return kl / n_tokens
+    loss = torch.empty((), device=kl.device, dtype=torch.float32)
+    _lib.check(lib.bmt_loss_finish(_p(kl), _p(n_tokens), _p(loss), _p(grad_scale), _st()), "bmt_loss_finish")
+    return loss
 
 
 # ----------------------------------------------------------------------------- masks (bit-exact, no autograd)

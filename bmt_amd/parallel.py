@@ -61,16 +61,25 @@ class GradientReducer:
             units.append(u)
             placed.update(id(x) for x in u)
         self.buckets: List[dict] = []
-        cur, cur_bytes = [], 0
+        cur, cur_bytes, groups_of_params = [], 0, []
         for u in units:
             nbytes = sum(p.numel() for p in u) * 4
             if cur and cur_bytes + nbytes > bucket_bytes:
-                self._make_bucket(cur)
+                groups_of_params.append(cur)
                 cur, cur_bytes = [], 0
             cur.extend(u)
             cur_bytes += nbytes
         if cur:
-            self._make_bucket(cur)
+            groups_of_params.append(cur)
+        # ONE allocation for every bucket of a device (the flat buffers are consecutive slices of it): zero_grad is one fill over the arena
+        # instead of one per bucket (8 launches at the head of every step at config[1])
+        quantum = max(1, self.world) * 8
+        sizes = [(sum(p.numel() for p in ps) + quantum - 1) // quantum * quantum for ps in groups_of_params]
+        self._arena = torch.zeros(sum(sizes), dtype=torch.float32, device=params[0].device) if params else None
+        off = 0
+        for ps, n in zip(groups_of_params, sizes):
+            self._make_bucket(ps, self._arena[off:off + n])
+            off += n
         self._slot = {}   # Parameter (hashed by identity) -> (bucket index, slot in bucket)
         for bi, b in enumerate(self.buckets):
             for si, p in enumerate(b["params"]):
@@ -83,12 +92,11 @@ class GradientReducer:
         self._second = []
         self.zero_grad()
 
-    def _make_bucket(self, ps):
-        n = sum(p.numel() for p in ps)
-        # (padded to a multiple of the world size -- of 8 floats per rank, so that shards stay 32-byte aligned -- for the reduce-scatter
-        # form: the pad belongs to no parameter and stays zero)
-        quantum = max(1, self.world) * 8
-        flat = torch.zeros((n + quantum - 1) // quantum * quantum, dtype=torch.float32, device=ps[0].device)
+    def _make_bucket(self, ps, flat):
+        # (flat: this bucket's slice of the arena, padded to a multiple of the world size -- of 8 floats per rank, so that shards stay
+        # 32-byte aligned -- for the reduce-scatter form: the pad belongs to no parameter and stays zero)
+        if any(p.device != flat.device for p in ps):
+            raise RuntimeError("GradientReducer: the parameters of one reducer live on one device")
         views, off = [], 0
         for p in ps:
             views.append(flat[off:off + p.numel()].view_as(p))
@@ -112,9 +120,14 @@ class GradientReducer:
             self._second.append((h, b))
 
     def zero_grad(self):
-        """in-place zero of the flat buffers (one memset per bucket); keeps p.grad bound to its bucket view"""
+        """in-place zero of the flat buffers (one fill over the arena they are slices of); keeps p.grad bound to its bucket view"""
+        if self._arena is not None:
+            if self._arena.is_cuda:      # one library launch (bmt_zero) over the whole arena
+                from . import ops as _ops
+                _ops.zero_(self._arena)
+            else:
+                self._arena.zero_()
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"] = len(b["params"])
             for p, v in zip(b["params"], b["views"]):
                 if p.grad is not v:

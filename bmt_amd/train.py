@@ -95,6 +95,7 @@ class CaptioningTrainStep:
                                        collective=collective) if (data_parallel or static_grads) else None
         self.modality = getattr(cfg, 'modality', 'audio_video')
         self.grad_scale = torch.ones(1, device=params[0].device, dtype=torch.float32)
+        self._one = torch.ones((), device=params[0].device, dtype=torch.float32)        # the root gradient of every backward pass
         if hasattr(self.optimizer, "grad_scale"):
             self.optimizer.grad_scale = self.grad_scale
         self._fused_scale = hasattr(self.optimizer, "grad_scale")
@@ -164,14 +165,13 @@ class CaptioningTrainStep:
             self.reducer.zero_grad()
         else:
             self.optimizer.zero_grad()
-        x, y = caption_idx[:, :-1], caption_idx[:, 1:]
-        masks = make_masks(feature_stacks, x, self.modality, self.pad_idx)
         from . import ops as _ops
+        x, y, n_tokens = _ops.caption_shift(caption_idx, self.pad_idx)
+        masks = make_masks(feature_stacks, x, self.modality, self.pad_idx)
         # the encoder's two compute streams: not while gradient buckets are all-reduced from inside the backward pass (a bucket's
         # "final" event is recorded on ONE stream)
         _ops.allow_encoder_streams(self.reducer is None or self.reducer.world == 1 or not self.reducer.overlap)
         pred = model(feature_stacks, x, masks)
-        n_tokens = (y != self.pad_idx).sum()
         kl = self.criterion(pred, y)
         # the weight-gradient GEMMs of the whole backward pass go out as one grouped launch -- unless gradients are all-reduced
         # bucket by bucket from the backward hooks, which needs them finished in autograd order
@@ -180,13 +180,14 @@ class CaptioningTrainStep:
         # the products run where autograd reaches them, so that a bucket is final when its last hook fires
         sctx.defer_dw = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap or self._flush_points > 0)
         try:
-            kl.backward()
+            kl.backward(gradient=self._one if self._one.device == kl.device and kl.dim() == 0 else None)      # (no fill kernel for the root gradient)
             _ops.join_side_stream()
             _ops.flush_dw()
         finally:
             sctx.defer_dw = False
             sctx.pending_dw.clear()
             sctx.pending_cs.clear()
+            sctx.gen_handles.clear()
         return kl.detach(), n_tokens
 
     def _reduce(self, kl, n_tokens):
@@ -194,8 +195,8 @@ class CaptioningTrainStep:
         if self.reducer is not None:
             self.reducer.finish()
         n_global = global_sum(n_tokens) if self.data_parallel else n_tokens
-        self.grad_scale.copy_((1.0 / n_global.to(torch.float32)).reshape(1))
-        return kl / n_global, n_global
+        from . import ops as _ops
+        return _ops.loss_finish(kl, n_global, self.grad_scale), n_global
 
     def _optimize(self):
         if not self._fused_scale or self.cfg.grad_clip is not None:

@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 4
+#define BMT_ABI_VERSION 5
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -273,7 +273,10 @@ typedef struct {
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* element counts of the split backward's workspaces for a problem: P_ws and dS_ws (bf16) take *n_pds each, Qb_ws (bf16) *n_qb, bias_ws
- * (fp32) *n_bias.  Returns BMT_EINVAL (and zeros) for a problem the split form does not take (d_k < 128, Sq < 64, sizes past 2^31 bytes per
+ * (fp32) *n_bias.  (ABI 5: *n_qb includes, behind the scaled copy of q, one int per (batch, head, 128-query tile) of LIVE-QUERY bits -- which
+ * 32-query groups have a non-zero dO at all.  The dQ kernel finds that out from the rows it holds anyway; a tile without a live row skips its
+ * key loop, the dK / dV kernel's query loop ends at the last live stage.  Padded positions get exactly zero gradient in the encoder: a
+ * quarter of the query rows of configs[1]'s ragged batches.  Data-driven -- nothing is assumed about the caller's padding.)  Returns BMT_EINVAL (and zeros) for a problem the split form does not take (d_k < 128, Sq < 64, sizes past 2^31 bytes per
  * (batch, head) block): the caller then passes NULL workspaces and the two-kernel form runs. */
 int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_pds, int64_t* n_qb, int64_t* n_bias);
 /* bias_ws alone (P_ws = dS_ws = Qb_ws = NULL) is taken by every d_k >= 128 backward: the tiles' column sums are stored per tile and added
@@ -307,6 +310,12 @@ int bmt_layernorm_bwd_blocks(int rows);
  * vector kernel does not apply (D > 2048, unaligned rows): the caller then uses bmt_layernorm_bwd_add. */
 int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                               float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* partial_ws, int rows, int D, void* stream);
+/* bmt_layernorm_bwd_partial with a SECOND addend: dx = dx_add + dx_add2 + LN backward.  The input of a ResidualConnection's LayerNorm that
+ * is also the key / value input of the other modality's cross-attention (model/encoders.py:63-79) has three consumers; their gradients meet
+ * in this kernel instead of in an add kernel of autograd's (ABI 5).  Returns 1 where the vector kernel does not apply. */
+int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                               float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2, int64_t ldadd2,
+                               float* partial_ws, int rows, int D, void* stream);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                       float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream);
@@ -363,6 +372,32 @@ int bmt_ls_kl_fwd(const float* pred, int64_t ldp, const int64_t* target, float* 
  * filled -- its trailing int carries the pad-row decision) */
 int bmt_ls_kl_bwd(const int64_t* target, float* dpred, int64_t ldp, const float* gscale_dev, const float* row_ws,
                   int rows, int V, float smoothing, int64_t pad_idx, void* stream);
+/* K7 in one pass each way (ABI 5; model/generators.py:18-19 + loss/label_smoothing.py:12-32 as ONE forward and ONE backward kernel over
+ * the (B*Tc, V) tensor):
+ *   bmt_log_softmax_fwd_stats  log_softmax in place with the row in registers (one HBM read, one write) and rowsum[r] = sum_c logp[r][c]
+ *                              (rowsum may be NULL);
+ *   bmt_ls_kl_fwd_stats        LabelSmoothing.forward from those row sums and two gathers per row -- one launch of one workgroup; row_ws as
+ *                              bmt_ls_kl_fwd leaves it ([rows] row losses + the int pad-row flag);
+ *   bmt_gen_lskl_bwd           d(loss * *gscale_dev) / d(logits) from the saved log-probabilities: dlogits = g (softmax * rowsum(dist) - dist),
+ *                              written as the bf16 operand plane hi [rows][ldh] (ldh >= round_up(V, 64), pad columns zeroed) that the
+ *                              generator's dX / dW products read, its column sums (the generator's bias gradient) ADDED into colsum[V]
+ *                              (optional).  Replaces bmt_ls_kl_bwd -> bmt_log_softmax_bwd -> bmt_planes. */
+int bmt_log_softmax_fwd_stats(float* x, int64_t ldx, int rows, int V, float* rowsum, void* stream);
+int bmt_ls_kl_fwd_stats(const float* pred, int64_t ldp, const int64_t* target, const float* rowsum, float* loss, float* row_ws, int rows, int V,
+                        float smoothing, int64_t pad_idx, void* stream);
+int bmt_gen_lskl_bwd(const float* logp, int64_t ldp, const int64_t* target, const float* row_ws, const float* gscale_dev, int rows, int V,
+                     float smoothing, int64_t pad_idx, uint16_t* hi, int64_t ldh, float* colsum, void* stream);
+
+/* ---------------------------------------------------------------- step protocol (ABI 5): what training_loop does between the kernels
+ * (epoch_loops/captioning_epoch_loops.py:128-135), as library launches instead of framework fills / copies / reductions */
+/* p[0 .. nbytes) = 0 (p 16-byte aligned): optimizer.zero_grad() over the flat gradient arena in one launch */
+int bmt_zero(void* p, int64_t nbytes, void* stream);
+/* x = caption_idx[:, :-1], y = caption_idx[:, 1:] as contiguous int64 [B][T1 - 1] and n_tokens[0] = (y != pad_idx).sum(); caption_idx [B][T1]
+ * with row stride ld */
+int bmt_caption_shift(const int64_t* caption_idx, int64_t ld, int B, int T1, int64_t pad_idx, int64_t* x, int64_t* y, int64_t* n_tokens,
+                      void* stream);
+/* loss[0] = kl[0] / n_tokens[0], grad_scale[0] = 1 / n_tokens[0] (either output may be NULL): loss = criterion(pred, y) / n_tokens */
+int bmt_loss_finish(const float* kl, const int64_t* n_tokens, float* loss, float* grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (K11) */
 /* torch.optim.Adam semantics (scripts/train_captioning_module.py:46-48) over n_tensors tensors.

@@ -24,7 +24,7 @@ def test_header_declares_the_hot_path():
 def test_library_loads_and_exports_everything():
     from bmt_amd import _lib
     lib = _lib.load()
-    assert lib.bmt_version() == 4
+    assert lib.bmt_version() == 5
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/bmt_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in bmt_amd/_lib.py"
@@ -72,6 +72,7 @@ def test_attention_backward_split_workspace_query():
     lib = _lib.load()
     n = [C.c_int64(-1) for _ in range(3)]
     assert lib.bmt_attn_bwd_split_ws(32, 4, 800, 800, 256, *(C.byref(x) for x in n)) == 0
-    assert n[0].value == 32 * 4 * 7 * 800 * 128 and n[1].value == 32 * 800 * 1024 and n[2].value == (32 * 7 + 2 * 32 * 7) * 1024
+    # (Qb_ws: the scaled copy of q + one int of live-query bits per (batch, head, 128-query tile), rounded up to 16 bytes)
+    assert n[0].value == 32 * 4 * 7 * 800 * 128 and n[1].value == 32 * 800 * 1024 + 2 * 32 * 4 * 7 and n[2].value == (32 * 7 + 2 * 32 * 7) * 1024
     for bad in ((32, 4, 29, 800, 256), (2, 4, 800, 800, 64), (2, 4, 800, 9000, 256)):
         assert lib.bmt_attn_bwd_split_ws(*bad, *(C.byref(x) for x in n)) == -1 and [x.value for x in n] == [0, 0, 0]

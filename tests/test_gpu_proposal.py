@@ -37,7 +37,12 @@ def test_conv1d_heads_vs_torch_conv(B, S, Din, Dout, k):
     w = torch.randn(B, S, Dout, generator=g)
     xd, Wd, bd = x.to(DEV).requires_grad_(), W.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
     y = ConvKFn.apply(xd, Wd, bd, True, 0.0, 0)
-    xr, Wr, br = x.double().requires_grad_(), W.double().requires_grad_(), b.double().requires_grad_()
+    from bmt_amd import ops
+    # (the k-tap layer of a head runs fp16 activation x split fp16 weight -- ops.POLICIES["head_conv"]: the oracle gets the activation rounded
+    # to fp16, so that only the accumulation order and the dropped lo.lo term differ, as for every single-plane operand in test_gpu_kernels.py)
+    f16_act = ops.policy_of("head_conv").gemm == ops.PREC_F16W2
+    xr = (x.half().double() if f16_act else x.double()).requires_grad_()
+    Wr, br = W.double().requires_grad_(), b.double().requires_grad_()
     want = torch.relu(torch.nn.functional.conv1d(xr.permute(0, 2, 1), Wr, br, padding=k // 2)).permute(0, 2, 1)
     assert_close(y, want, atol=3e-4, name=f"conv k={k}")
     (y * w.to(DEV)).sum().backward()

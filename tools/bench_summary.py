@@ -9,10 +9,13 @@ for k, v in d.get("kernel_classes", {}).items():
     print(f"  {k:52s} {v['ms_per_step']:.3f} ms  {v['tflops']:7.1f} TF/s  x{v['launches_per_step']:.0f}")
 kt = d.get("kernel_timer")
 if kt:
-    print(f"  eager {kt['eager_ms_per_step']:.3f} ms/step, timed classes {kt['timed_classes_ms_per_step']:.3f}")
+    print(f"  eager {kt['eager_ms_per_step']:.3f} ms/step, timed classes {kt['timed_classes_ms_per_step']:.3f}, gates {kt.get('gates')}, passes {kt.get('passes_run')}")
 r = d.get("roofline")
 if r:
-    print(f"  roofline: {r['kernel']}: {r['achieved']:.0f} TF/s = {r['frac']:.3f} (issued {r['frac_issued']:.3f}), traffic {r.get('traffic')}")
+    if r.get("valid", True) and r.get("achieved") is not None:
+        print(f"  roofline: {r['kernel']}: {r['achieved']:.0f} TF/s = {r['frac']:.3f} (issued {r['frac_issued']:.3f}), traffic {r.get('traffic')}")
+    else:
+        print(f"  roofline INVALID: {r.get('invalid_because')}")
 a = d.get("attention_roofline")
 if a:
     print(f"  attention_roofline: algorithmic {a['algorithmic']:.0f} TF/s = {a['frac_algorithmic']:.3f}, issued {a['frac_issued']:.3f}, {a['ms_per_step']:.3f} ms/step")
