@@ -799,6 +799,16 @@ def main():
             mode = best
         if mode == "eager" and world > 1:
             mode = "eager+overlap"
+    if (not cap) and not args.no_graph and world == 1:
+        # train_prop on one GPU: the whole step (zero_grad .. Adam) as one hipGraph over a batch padded to a fixed number of target rows
+        # (ProposalTrainStep.capture); N > 1 launches eagerly (the obj / noobj counts and the gradients are all-reduced from inside the step)
+        try:
+            step.capture(*inputs, warmup=2)
+            run = lambda: step.replay()
+            mode = "hipgraph"
+        except Exception as exc:      # noqa: BLE001
+            note(f"train_prop: graph capture failed ({type(exc).__name__}: {exc}); eager launches")
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         res = run()
     sync()

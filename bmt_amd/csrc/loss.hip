@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void ls_kl_stats_kernel(const float* __restric
 // sums): 38 + 38 + 38 MB written and 38 + 76 + 38 MB read become 38 MB read and 19 MB written.
 // grid (ceil(pcols / 512), ceil(rows / RB)); a thread owns two adjacent columns over RB rows
 constexpr int GENB_RB = 32;
+template <bool VEC2>
 __global__ __launch_bounds__(256) void gen_lskl_bwd_kernel(const float* __restrict__ logp, int64_t ldp, const int64_t* __restrict__ target,
                                                             const float* __restrict__ row_ws, const float* __restrict__ gscale, int rows, int V,
                                                             int pcols, float smoothing, int64_t pad_idx, uint16_t* __restrict__ hi, int64_t ldh,
@@ -219,7 +220,9 @@ __global__ __launch_bounds__(256) void gen_lskl_bwd_kernel(const float* __restri
         float o0 = 0.f, o1 = 0.f;
         if (c0 < V && !(t == pad_idx && flag)) {
             const float R = (t == pad_idx) ? (float)(V - 1) * u : 1.f;
-            const float2 lp = (c0 + 1 < V) ? *reinterpret_cast<const float2*>(logp + (int64_t)r * ldp + c0) : make_float2(logp[(int64_t)r * ldp + c0], 0.f);
+            float2 lp;
+            if (VEC2 && c0 + 1 < V) lp = *reinterpret_cast<const float2*>(logp + (int64_t)r * ldp + c0);
+            else lp = make_float2(logp[(int64_t)r * ldp + c0], (c0 + 1 < V) ? logp[(int64_t)r * ldp + c0 + 1] : 0.f);
             float d0 = (c0 == pad_idx) ? 0.f : (c0 == t ? conf : u);
             float d1 = (c0 + 1 == pad_idx) ? 0.f : (c0 + 1 == t ? conf : u);
             o0 = g * (expf(lp.x) * R - d0);
@@ -324,10 +327,14 @@ extern "C" int bmt_gen_lskl_bwd(const float* logp, int64_t ldp, const int64_t* t
     BMT_CHECK_ARG(logp && target && row_ws && gscale_dev && hi && rows > 0 && V > 2, "bmt_gen_lskl_bwd: bad args");
     BMT_CHECK_ARG(pad_idx >= 0 && pad_idx < V, "bmt_gen_lskl_bwd: pad_idx out of range");
     const int pcols = (V + 63) / 64 * 64;
-    BMT_CHECK_ARG(ldh >= pcols && ldh % 2 == 0 && ldp % 2 == 0 && ((reinterpret_cast<uintptr_t>(hi) & 3) == 0) && ((reinterpret_cast<uintptr_t>(logp) & 7) == 0),
-                  "bmt_gen_lskl_bwd: plane row stride %lld < %d, or unaligned rows", (long long)ldh, pcols);
-    hipLaunchKernelGGL(gen_lskl_bwd_kernel, dim3(bmt_cdiv(pcols, 512), bmt_cdiv(rows, GENB_RB)), dim3(256), 0, (hipStream_t)stream, logp, ldp, target,
-                       row_ws, gscale_dev, rows, V, pcols, smoothing, pad_idx, hi, ldh, colsum);
+    BMT_CHECK_ARG(ldh >= pcols && ldh % 2 == 0 && ((reinterpret_cast<uintptr_t>(hi) & 3) == 0),
+                  "bmt_gen_lskl_bwd: plane row stride %lld < %d (or odd), or a plane that is not 4-byte aligned", (long long)ldh, pcols);
+    const bool vec2 = ldp % 2 == 0 && ((reinterpret_cast<uintptr_t>(logp) & 7) == 0);      // 8-byte loads of two adjacent log-probabilities
+    const dim3 grid(bmt_cdiv(pcols, 512), bmt_cdiv(rows, GENB_RB));
+    if (vec2) hipLaunchKernelGGL(gen_lskl_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, logp, ldp, target, row_ws, gscale_dev, rows, V, pcols,
+                                 smoothing, pad_idx, hi, ldh, colsum);
+    else hipLaunchKernelGGL(gen_lskl_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, logp, ldp, target, row_ws, gscale_dev, rows, V, pcols,
+                            smoothing, pad_idx, hi, ldh, colsum);
     BMT_CHECK_LAUNCH("bmt_gen_lskl_bwd");
     return BMT_OK;
 }

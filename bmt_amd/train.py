@@ -390,6 +390,58 @@ class ProposalTrainStep:
         if hasattr(self.optimizer, "grad_scale"):
             self.optimizer.grad_scale = None
 
+    # ---- hipGraph capture: the step is static once the number of target rows is (the reference's batches carry a different number of
+    # events each: targets are padded to ``max_events`` rows with batch index -1, which bmt_make_targets skips)
+    @staticmethod
+    def pad_targets(targets: torch.Tensor, max_events: int) -> torch.Tensor:
+        n = targets.shape[0]
+        if n > max_events:
+            raise ValueError(f"{n} target events, the captured step holds {max_events}")
+        out = torch.zeros(max_events, 4, device=targets.device, dtype=torch.float32)
+        out[:, 0] = -1.0
+        out[:, 2] = 1.0
+        out[:n] = targets
+        return out
+
+    def capture(self, feature_stacks, targets, max_events: Optional[int] = None, warmup: int = 2):
+        """capture {zero_grad .. backward .. Adam} of one step over static copies of the batch into ONE hipGraph; ``replay(fs, targets)``
+        copies a batch of the same shape (any number of events <= max_events) in and launches it.  Single process only (under data
+        parallelism the obj / noobj counts and the gradients are all-reduced from inside the step: launch that eagerly)."""
+        if self.world > 1:
+            raise RuntimeError("ProposalTrainStep.capture: single-process only")
+        if self.reducer is None:       # static gradient buffers: what the captured kernels write and the captured Adam reads
+            self.reducer = GradientReducer(self.params, overlap=False)
+        max_events = max(int(max_events or 0), targets.shape[0])
+        self._static_fs = {k: v.clone() for k, v in feature_stacks.items()}
+        self._static_tg = self.pad_targets(targets, max_events)
+        self._max_events = max_events
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self(self._static_fs, self._static_tg)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._static_out = self(self._static_fs, self._static_tg)
+        self._graph = g
+        from . import ops as _ops
+        self._graph_generation = _ops.weights_generation()
+        return g
+
+    def replay(self, feature_stacks=None, targets=None):
+        if feature_stacks is not None:
+            for k, v in feature_stacks.items():
+                self._static_fs[k].copy_(v, non_blocking=True)
+            self._static_tg.copy_(self.pad_targets(targets, self._max_events), non_blocking=True)
+        from . import ops as _ops
+        if _ops.weights_generation() != self._graph_generation:
+            raise RuntimeError("the weight-plane registry changed after capture(): call capture() again")
+        self._graph.replay()
+        _ops_weights_changed()
+        return self._static_out
+
     def __call__(self, feature_stacks, targets):
         model = self.model
         model.train()

@@ -28,26 +28,6 @@ def test_lane_algebra_and_banks(dk):
 
 
 @pytest.mark.parametrize("dk", [256, 128])
-def test_backward_dq_lane_algebra_and_banks(dk):
-    """the experimental dQ kernel (bmt_amd/csrc/exp/attn_bwd32.hip): a K image that serves row fragments AND transposing reads, V rows,
-    S^T / dP^T / dQ^T against numpy"""
-    assert _emulator("attn_bwd32_layout").check(dk)
-
-
-def test_kmajor_gemm_weight_fragments():
-    """the experimental k-major 256 x 256 GEMM (bmt_amd/csrc/exp/gemm_wide_km.hip): weight half-tile image, transposing fragment reads and
-    the MFMA operand order reproduce W^T . X^T, without bank conflicts"""
-    assert _emulator("gemm_wide_km_layout").check()
-
-
-def test_kmajor_gemm_source_is_what_the_generator_writes():
-    """exp/gemm_wide_km.hip is GENERATED from gemm_wide_kernel's text (tools/probes/make_wide_km.py): the committed file must be what the
-    generator produces from the committed product kernel (its patches assert their anchors, so a drifted product kernel fails here too)"""
-    gen = _emulator("make_wide_km")
-    assert open(gen.OUT).read() == gen.generate()
-
-
-@pytest.mark.parametrize("dk", [256, 128])
 def test_split_backward_dkv_lane_algebra_and_banks(dk):
     """attn_bwd_dkvg8_kernel / attn_bwd_dkvg_kernel (the split backward's dK / dV products): both MFMA operands are transposing reads of
     images whose row is the reduction index q -- the q' / dO tiles in the dual-purpose swizzle, the P / dS column blocks with

@@ -255,3 +255,48 @@ def test_split_backward_skips_queries_without_gradient(ops, B, H, Sq, Sk, dk, ze
     dead = (dop.hi.float().cpu().view(B * Sq, H, dk).abs().amax(-1) == 0)          # (row, head)
     dq = got[0][0].view(B * Sq, H, dk)
     assert float(dq[dead].abs().max() if dead.any() else 0.0) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- train_prop under hipGraph
+def test_captured_proposal_step_equals_the_eager_step(golden):
+    """ProposalTrainStep.capture: the whole train_prop step (zero_grad .. Adam) as one hipGraph over a batch whose targets are padded to a
+    fixed number of rows (batch index -1: skipped by the target assignment).  Two models from the same state_dict, dropout off: eager steps
+    on one, capture + replays on the other (the capture's warm-up steps are steps too) -- same losses and weights to fp32 atomics noise;
+    a replay with FEWER events than the capture held equals the eager step on those events."""
+    import copy
+    from bmt_amd import synthetic as syn
+    from bmt_amd.model.proposal_generator import MultimodalProposalGenerator
+    from bmt_amd.train import ProposalTrainStep
+    from tests.test_gpu_proposal import _prop_cfg
+    g = golden("tiny_prop.npz")
+    cfg = _prop_cfg()
+    cfg.lr, cfg.grad_clip = 1e-3, None
+    anchors = {"audio": [float(a) for a in g.np("anchors_audio")], "video": [float(a) for a in g.np("anchors_video")]}
+
+    def make():
+        torch.manual_seed(0)
+        m = MultimodalProposalGenerator(cfg, anchors)
+        m.load_state_dict(g.sub("sd/"))
+        m = m.to(DEV)
+        for mod in m.modules():
+            if hasattr(mod, "dout_p"):
+                mod.dout_p = 0.0
+        return m
+    fs = {k: g[k].to(DEV) for k in ("rgb", "flow", "audio")}
+    tg = g["targets"].to(DEV)
+    fewer = tg[: max(1, tg.shape[0] - 2)]
+    ma, mb = make(), make()
+    sa, sb = ProposalTrainStep(ma, cfg, pad_idx=1), ProposalTrainStep(mb, cfg, pad_idx=1)
+    la = [float(sa(fs, tg)[1]) for _ in range(4)] + [float(sa(fs, fewer)[1])]
+    sb.capture(fs, tg, max_events=tg.shape[0] + 5, warmup=2)           # = eager steps 1, 2, and the capture pass itself runs nothing
+    lb = [float(sb.replay()[1]) for _ in range(2)] + [float(sb.replay(fs, fewer)[1])]
+    torch.cuda.synchronize()
+    for a, b in zip(la[2:], lb):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (la, lb)
+    for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert float((pa - pb).abs().max()) < 5e-4, k
+    # padded targets on the eager path too: same assignment as the unpadded ones
+    mc = make()
+    sc = ProposalTrainStep(mc, cfg, pad_idx=1)
+    l_pad = float(sc(fs, ProposalTrainStep.pad_targets(tg, tg.shape[0] + 7))[1])
+    assert abs(l_pad - la[0]) < 1e-5 * max(1.0, abs(la[0]))

@@ -1,4 +1,4 @@
-// EXPERIMENT driver (not part of libbmt_hip.so; built by exp/build.sh into bmt_amd/lib/libbmt_exp.so, driven by
+// EXPERIMENT driver (not part of libbmt_hip.so; built by tools/experiments/build.sh into tools/experiments/libbmt_exp.so, driven by
 // tools/probes/attn_fwd32_check.py): the instruction-placement variants of attn_fwd32_kernel (attention_bf16.hip) and a switch back to
 // the 16-query kernel, behind the product's argument block -- old and new kernel, and every variant, timed in ONE process on one box.
 //   variant v < 8: DMAV = v % 4 (where the next tile's DMA requests are issued), PRIO = v < 4 (s_setprio around the MFMA phases);
@@ -8,7 +8,7 @@
 //   variant 300 + XP: the same with 40 KB of extra LDS per workgroup: ONE workgroup per CU instead of two;
 //   variant 400 + 100 ORD + 10 DEPTH + XP: prefetch depth of the fragment reads and MFMA ordering of the probe copy (XP 0 or 7).
 // Result (profiles/r02_q_attn_fwd32_variants.txt): the eight variants are within +-3 % of each other on every shape.
-#include "../attention_bf16.hip"
+// (attention_bf16.hip is included by exp_lib.hip ahead of this file)
 
 namespace {
 int g_variant = 0;

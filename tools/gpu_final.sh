@@ -9,6 +9,6 @@ tail -4 gpurun_out/${TAG}_gputest.log; echo "pytest rc=$rc"
 bash tools/gpu_pmc_bench.sh $TAG 2>&1 | tail -6
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 timeout 150 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; cat gpurun_out/${TAG}_bench.json
-timeout 60 python tools/probes/attn_fwd32_check.py > gpurun_out/${TAG}_attn_fwd32_check.txt 2>&1; echo "attn check rc=$?"; tail -7 gpurun_out/${TAG}_attn_fwd32_check.txt
+timeout 120 python tools/probes/attn_fwd32_check.py > gpurun_out/${TAG}_attn_fwd32_check.txt 2>&1; echo "attn check rc=$?"; tail -7 gpurun_out/${TAG}_attn_fwd32_check.txt
 bash tools/gpu_prof.sh $TAG 6 2>&1 | head -30
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

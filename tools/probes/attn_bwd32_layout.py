@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""CPU check of the lane algebra of the 32-query attention backward dQ kernel (bmt_amd/csrc/exp/attn_bwd32.hip; no GPU, numpy only).
+"""CPU check of the lane algebra of the 32-query attention backward dQ kernel (round 2's experiment, since removed; kept for kswz / mfma, which tools/probes/attn_bwd_split_layout.py uses for the product's split backward; no GPU, numpy only).
 
 Same emulation as attn_fwd32_layout.py (LDS image built by the LDS-DMA with source-side swizzles, ds_read_b128 row fragments,
 ds_read_b64_tr_b16 transposing reads, v_mfma_f32_32x32x16 operand / result layouts, bank model).  What is new here:

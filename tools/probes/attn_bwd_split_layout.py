@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""CPU check of the lane algebra of attn_bwd_dkvg_kernel (bmt_amd/csrc/exp/attn_bwd_split.hip; numpy only): both operands of
+"""CPU check of the lane algebra of attn_bwd_dkvg_kernel (bmt_amd/csrc/attention_bf16.hip; numpy only): both operands of
 dV^T[d][key] += dO^T[d x q] . P[q x key] (and dK^T += Qb^T . dS) are transposing reads of row-major images whose ROW is the reduction
 index q.  X image (32 q x d_k, dual-purpose swizzle of the dQ kernel's K image) -> A fragments as in attn_bwd32_layout.py; Y image
 (32 q x 128 keys, 256-byte rows, 16-byte chunk position = chunk ^ ((row & 3) << 2) applied by the DMA's source addresses) -> B fragments:

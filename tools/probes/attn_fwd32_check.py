@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""GPU check + timing of the experimental attention forward (bmt_amd/csrc/exp/attn_fwd32.hip, libbmt_exp.so) against the product
+"""GPU check + timing of the experimental attention forward (tools/experiments/attn_fwd32.hip, libbmt_exp.so) against the product
 16-query kernel and an fp32 torch reference on the same rounded operands (both kernels live in attention_bf16.hip; the experiment
-library pins which one runs, whatever the shape -- bmt_amd/csrc/exp/attn_fwd32.hip).
+library pins which one runs, whatever the shape -- tools/experiments/attn_fwd32.hip).
 
-    bash bmt_amd/csrc/exp/build.sh && python tools/probes/attn_fwd32_check.py [--no-time] > gpurun_out/attn_fwd32_check.txt
+    bash tools/experiments/build.sh && python tools/probes/attn_fwd32_check.py [--no-time] > gpurun_out/attn_fwd32_check.txt
     ... --variants | --probe | --probe2 | --probe3 [--ragged]: loop variants / the probe copy with parts switched off (profiles/r02_q_*, r02_s_*)
 
 The experiment entry takes the product's argument block, so the product's Python (ops.attn_fwd_bf16 / ops.attn_fwd_planes) drives both:
@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from bmt_amd import _lib, ops  # noqa: E402
 
-EXP = C.CDLL(os.path.join(ROOT, "bmt_amd", "lib", "libbmt_exp.so"))
+import subprocess
+subprocess.run(["bash", os.path.join(ROOT, "tools", "experiments", "build.sh")], check=True, stdout=subprocess.DEVNULL)      # on demand
+EXP = C.CDLL(os.path.join(ROOT, "tools", "experiments", "libbmt_exp.so"))
 EXP.bmt_exp_attn_fwd32.restype = C.c_int
 EXP.bmt_exp_attn_fwd32.argtypes = [C.POINTER(_lib.AttnFwdBf16Args), C.c_void_p]
 EXP.bmt_last_error.restype = C.c_char_p
