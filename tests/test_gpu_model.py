@@ -23,8 +23,10 @@ def _load(module, sd):
     return module.to(DEV)
 
 
-def _check_grads(named_params, ref_grads, tol=0.05, global_tol=1e-2):
-    """Backward runs single-pass bf16 (DESIGN.md "precision"): error over ALL tensors concatenated <= 1 %, per tensor <= 5 %
+def _check_grads(named_params, ref_grads, tol=0.045, global_tol=8e-3):
+    """Backward runs single-pass bf16 (DESIGN.md "precision"): error over ALL tensors concatenated <= 0.8 %, per tensor <= 4.5 % -- the
+    bars follow what is measured (round 4, BMT_GRAD_REPORT=1 over every captioning fixture, gpurun_out/r04_b_grad_report.txt: overall
+    0.24-0.66 %, worst tensor 3.55 % = decoder.layers.0.enc_att_A.linear_K2d.weight of the deep fixture, every other tensor <= 2.8 %)
     (with the dQ correction of the attention backward -- ops.ATTN_KMEAN -- the decoder's cross-attention query / key paths, whose
     bf16 cancellation noise was 10-30 %, are within 1 %).  Gradients that are analytically zero (the key-projection bias: softmax
     is invariant to a constant added to every key) come out as cancellation noise in any finite precision -- 1e-9 in the fp32
