@@ -146,6 +146,8 @@ SIGNATURES = {
     "bmt_ls_kl_fwd_stats": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, f32, i64, vp]),
     "bmt_gen_lskl_bwd": (i32, [vp, i64, vp, vp, vp, i32, i32, f32, i64, vp, i64, vp, vp]),
     "bmt_zero": (i32, [vp, i64, vp]),
+    "bmt_cat2": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, vp]),
+    "bmt_split2": (i32, [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp]),
     "bmt_caption_shift": (i32, [vp, i64, i32, i32, i64, vp, vp, vp, vp]),
     "bmt_loss_finish": (i32, [vp, vp, vp, vp, vp]),
     "bmt_layernorm_bwd_partial2": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),

@@ -175,6 +175,40 @@ extern "C" int bmt_dropout(const float* x, float* y, int64_t n, float drop_p, co
     return BMT_OK;
 }
 
+namespace {
+// out[r][0 .. Da) = a[r][:], out[r][Da .. Da + Db) = b[r][:]  (cat along the last dimension) / the inverse split: the decoder layer's
+// torch.cat([Ca, Cv], -1) in front of the bridge (model/decoders.py:83) and the two halves of its gradient
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void cat2_kernel(float* __restrict__ a, int64_t lda, int Da, float* __restrict__ b, int64_t ldb, int Db,
+                                                    float* __restrict__ o, int64_t ldo, int rows) {
+    const int W = Da + Db;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * W; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / W), c = (int)(i % W);
+        float* src = c < Da ? a + (int64_t)r * lda + c : b + (int64_t)r * ldb + (c - Da);
+        if (SPLIT) *src = o[(int64_t)r * ldo + c];
+        else o[(int64_t)r * ldo + c] = *src;
+    }
+}
+}  // namespace
+
+extern "C" int bmt_cat2(const float* a, int64_t lda, int Da, const float* b, int64_t ldb, int Db, float* out, int64_t ldo, int rows, void* stream) {
+    BMT_CHECK_ARG(a && b && out && rows >= 0 && Da > 0 && Db > 0 && lda >= Da && ldb >= Db && ldo >= Da + Db, "bmt_cat2: bad args");
+    if (rows == 0) return BMT_OK;
+    hipLaunchKernelGGL(cat2_kernel<false>, dim3(grid_for((int64_t)rows * (Da + Db))), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(a), lda, Da,
+                       const_cast<float*>(b), ldb, Db, out, ldo, rows);
+    BMT_CHECK_LAUNCH("bmt_cat2");
+    return BMT_OK;
+}
+
+extern "C" int bmt_split2(const float* in, int64_t ldi, float* a, int64_t lda, int Da, float* b, int64_t ldb, int Db, int rows, void* stream) {
+    BMT_CHECK_ARG(a && b && in && rows >= 0 && Da > 0 && Db > 0 && lda >= Da && ldb >= Db && ldi >= Da + Db, "bmt_split2: bad args");
+    if (rows == 0) return BMT_OK;
+    hipLaunchKernelGGL(cat2_kernel<true>, dim3(grid_for((int64_t)rows * (Da + Db))), dim3(256), 0, (hipStream_t)stream, a, lda, Da, b, ldb, Db,
+                       const_cast<float*>(in), ldi, rows);
+    BMT_CHECK_LAUNCH("bmt_split2");
+    return BMT_OK;
+}
+
 extern "C" int bmt_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
     BMT_CHECK_ARG(a && b && out && n >= 0, "bmt_add: bad args");
     if (n == 0) return BMT_OK;

@@ -50,30 +50,45 @@ class BiModalDecoderLayer(nn.Module):
         returns (C, memory) so the layer threads through LayerStack
         '''
         C, memory = x
-        Av, Va = memory
+        Av, Va = memory.take() if isinstance(memory, _LayerMemories) else memory
 
         if not getattr(C, "_bmt_self_att_done", False):          # (BiModalTransformer.forward runs the first layer's beside the encoder)
             C = self.self_attention_sublayer(C, masks['C_mask'])
         # the two encoder-decoder attentions read the same C and different memories: the video one (with its projections of the memory)
         # on the side stream (ops.fork_side_stream), joined before the bridge
         s2 = ops.fork_side_stream() if C.is_cuda else None
+        C_a, C_v = ops.fanout(C, 2)         # (two consumers: their gradients are added by a library launch, not by autograd's)
         if s2 is None:
-            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)
-            Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
+            Ca = self.res_layer_enc_att_A(C_a, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)
+            Cv = self.res_layer_enc_att_V(C_v, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
         else:
             s1 = torch.cuda.current_stream()
             for t in (C, Va, masks['V_mask']):
                 t.record_stream(s2)
             with torch.cuda.stream(s2):
-                Cv = self.res_layer_enc_att_V(C, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
-            Ca = self.res_layer_enc_att_A(C, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)
+                Cv = self.res_layer_enc_att_V(C_v, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
+            Ca = self.res_layer_enc_att_A(C_a, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)
             s1.wait_stream(s2)
             Cv.record_stream(s1)
         # (B, Sc, 2*Dc) -> bridge -> (B, Sc, Dc); no residual across the bridge
-        C = self.bridge(torch.cat([Ca, Cv], dim=-1))
+        C = self.bridge(ops.cat2(Ca, Cv))
         C = self.res_layer_ff(C, self.feed_forward, fp32_out=False)
 
         return C, memory
+
+
+class _LayerMemories(tuple):
+    """the encoder memories (Av, Va) as a decoder stack threads them through its layers, with one alias pair per layer behind it
+    (ops.fanout): layer k reads pair k, so that the N layers' gradients w.r.t. a memory are added by library launches in ONE autograd node.
+    Still the (Av, Va) tuple the reference's layers pass along (model/decoders.py:55-92)."""
+
+    def __new__(cls, Av, Va, n):
+        self = super().__new__(cls, (Av, Va))
+        self._pairs = list(zip(ops.fanout(Av, n), ops.fanout(Va, n)))
+        return self
+
+    def take(self):
+        return self._pairs.pop(0) if self._pairs else (self[0], self[1])
 
 
 class Decoder(nn.Module):
@@ -109,6 +124,8 @@ class BiModelDecoder(nn.Module):
                     for layer in self.decoder.layers:
                         layer.enc_att_V.prefetch_kv(Va)
                         layer.enc_att_A.prefetch_kv(Av)
+        if Av.is_cuda and torch.is_grad_enabled() and len(self.decoder.layers) > 1 and ops.context().kv_cache is None:
+            x = (C0, _LayerMemories(Av, Va, len(self.decoder.layers)))
         try:
             C, memory = self.decoder(x, masks)
         finally:

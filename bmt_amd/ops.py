@@ -46,11 +46,12 @@ def prec_operand_bytes(prec: int):
 class Policy:
     """forward operand formats of one module family: ``gemm`` for its projections / FFN, ``kv_gemm`` for the key / value projections
     of a CROSS-attention (their input is the long encoder memory), ``attn`` for the attention core"""
-    __slots__ = ("gemm", "kv_gemm", "attn", "name", "ffn2")
+    __slots__ = ("gemm", "kv_gemm", "attn", "name", "ffn2", "ffn1")
 
-    def __init__(self, gemm, kv_gemm, attn, name, ffn2=None):
+    def __init__(self, gemm, kv_gemm, attn, name, ffn2=None, ffn1=None):
         self.gemm, self.kv_gemm, self.attn, self.name = gemm, kv_gemm, attn, name
         self.ffn2 = gemm if ffn2 is None else ffn2      # the second product of a PositionwiseFeedForward
+        self.ffn1 = gemm if ffn1 is None else ffn1      # the first
 
 
 # max |d log-prob| vs the fp32 reference on the mid fixture with this table: 3.7e-4 (CPU emulation, tests/study_precision_policy.py;
@@ -63,7 +64,8 @@ POLICIES = {
     # ... of an encoder of at most two layers (configs[0], [1], [3]: model/encoders.py tags by depth): FFN-2 on one fp16 plane.  The rounding
     # of the weight it admits accumulates with depth -- fine at N = 2 (log-probs 3.8e-4 against 3.7e-4 on the mid fixture), over the bar at the
     # six layers of configs[4] (see above), which keep two planes everywhere
-    "enc_shallow": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc_shallow", ffn2=PREC_F16 if _os.environ.get("BMT_FFN2_TWO_PLANES") != "1" else None),
+    "enc_shallow": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc_shallow", ffn2=PREC_F16 if _os.environ.get("BMT_FFN2_TWO_PLANES") != "1" else None,
+                          ffn1=PREC_F16 if _os.environ.get("BMT_FFN1_ONE_PLANE") == "1" else None),
     "dec": Policy(PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),      # bi-modal decoder layers
     # Conv1d stacks of the proposal heads: split-bf16.  (fp16 activation x split weight leaves 6-8e-4 abs on the head outputs,
     # tests/test_gpu_proposal.py at round 2: inside the 1e-3 bar but with < 2x margin, and exp() turns it into 1e-3 relative on
@@ -1634,7 +1636,7 @@ class FFNFn(torch.autograd.Function):
         note_use(W1, b1, W2, b2)
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
-        prec = pol.gemm
+        prec = pol.ffn1
         fmt = act_fmt(prec)
         xp = planes_of(x, fmt)            # LayerNorm wrote the operand planes of its output already
         if xp is None:
@@ -2180,6 +2182,74 @@ class EmbedFn(torch.autograd.Function):
         _lib.check(lib.bmt_prep_embed_bwd(_p(idc), _p(dyc), _p(dW), B, S, D, V, scale, p, _p(rng_tensor()) if p > 0 else None, site,
                                           _st()), "bmt_prep_embed_bwd")
         return None, dW, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- fan-in / fan-out of the autograd graph as library launches
+class Cat2Fn(torch.autograd.Function):
+    """torch.cat([a, b], dim=-1) of two (..., D) fp32 tensors (the decoder layer's Ca | Cv in front of the bridge, model/decoders.py:83): one
+    launch forward, one backward -- the two halves of the gradient leave as CONTIGUOUS tensors (autograd's narrow() views went through four
+    ``.contiguous()`` copies per layer on their way into the LayerNorm / plane-conversion kernels)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ac, bc = _f32c(a), _f32c(b)
+        Da, Db = ac.shape[-1], bc.shape[-1]
+        rows = ac.numel() // Da
+        out = torch.empty(*ac.shape[:-1], Da + Db, device=ac.device, dtype=torch.float32)
+        _lib.check(lib.bmt_cat2(_p(ac), Da, Da, _p(bc), Db, Db, _p(out), Da + Db, rows, _st()), "bmt_cat2")
+        ctx.dims = (ac.shape, bc.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sa, sb = ctx.dims
+        gc = _f32c(g)
+        Da, Db = sa[-1], sb[-1]
+        ga = torch.empty(sa, device=g.device, dtype=torch.float32)
+        gb = torch.empty(sb, device=g.device, dtype=torch.float32)
+        _lib.check(lib.bmt_split2(_p(gc), Da + Db, _p(ga), Da, Da, _p(gb), Db, Db, ga.numel() // Da, _st()), "bmt_split2")
+        return ga, gb
+
+
+def cat2(a, b):
+    if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[:-1] == b.shape[:-1]:
+        return Cat2Fn.apply(a, b)
+    return torch.cat([a, b], dim=-1)
+
+
+class FanoutFn(torch.autograd.Function):
+    """x -> n aliases of x for n consumers: their gradients are added by library launches (bmt_add) in this node instead of by autograd's
+    accumulation kernels (the encoder memories feed every decoder layer's key / value projections; a decoder layer's caption state feeds
+    both encoder-decoder attentions)"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for i, g in enumerate(gs[1:]):
+            a, b = _f32c(acc), _f32c(g)
+            out = torch.empty_like(a)
+            _lib.check(lib.bmt_add(_p(a), _p(b), _p(out), a.numel(), _st()), "bmt_add")
+            acc = out
+        return acc, None
+
+
+def fanout(x, n: int):
+    """n tensors that are x, for n consumers (planes attached to x travel with every alias)"""
+    if n <= 1 or not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()):
+        return (x,) * max(n, 1)
+    outs = FanoutFn.apply(x, n)
+    pl = getattr(x, "_bmt_planes", None)
+    if pl is not None and getattr(x, "_bmt_planes_version", x._version) == x._version:
+        for o in outs:
+            attach_planes(o, pl)
+    return outs
 
 
 # ----------------------------------------------------------------------------- step protocol (training_loop's bookkeeping as library launches)

@@ -350,6 +350,10 @@ int bmt_dropout_add(const float* x, const float* res, float* out, int64_t n, flo
                     uint32_t site, void* stream);
 /* out = a + b (n elements) ; out may alias a */
 int bmt_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* ABI 5: out[r] = a[r] | b[r] (concatenation along the last dimension, rows with strides lda / ldb / ldo) and its inverse: the decoder
+ * layer's torch.cat([Ca, Cv], -1) in front of the bridge (model/decoders.py:83) and the two halves of that tensor's gradient */
+int bmt_cat2(const float* a, int64_t lda, int Da, const float* b, int64_t ldb, int Db, float* out, int64_t ldo, int rows, void* stream);
+int bmt_split2(const float* in, int64_t ldi, float* a, int64_t lda, int Da, float* b, int64_t ldb, int Db, int rows, void* stream);
 /* rng[1] += 1 (advance the dropout step counter on device; graph-capturable) */
 int bmt_rng_advance(uint64_t* rng, void* stream);
 /* out[i0][i1][i2] (contiguous) (+)= in[i0*s0 + i1*s1 + i2*s2]  -- Conv1d weight re-layout
