@@ -145,6 +145,10 @@ SIGNATURES = {
     "bmt_log_softmax_fwd_stats": (i32, [vp, i64, i32, i32, vp, vp]),
     "bmt_ls_kl_fwd_stats": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, f32, i64, vp]),
     "bmt_gen_lskl_bwd": (i32, [vp, i64, vp, vp, vp, i32, i32, f32, i64, vp, i64, vp, vp]),
+    "bmt_planes_gate": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, f32, vp]),
+    "bmt_pad_planes_gate": (i32, [vp, vp, f32, i32, i32, i32, i32, i32, vp, i64, vp, vp]),
+    "bmt_conv_weight_planes": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "bmt_conv_weight_grad": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
     "bmt_zero": (i32, [vp, i64, vp]),
     "bmt_cat2": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, vp]),
     "bmt_split2": (i32, [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp]),

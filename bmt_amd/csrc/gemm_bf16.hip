@@ -1385,6 +1385,8 @@ struct PlaneDesc {
     int tiles_x, tiles_y;
     float drop_p; uint32_t drop_site; const uint64_t* drop_rng;     // optional: the source is masked (inverted dropout) first
     int rows_ok;                                                    // bmt_planes_desc: eligible for the 16-byte row kernel
+    const float* gate; int64_t ldgate; float gate_scale;            // optional: v = gate[r][c] != 0 ? v * gate_scale : 0 (relu / dropout derivative
+                                                                    // from the saved forward output: bmt_planes_gate)
 };
 
 __device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, float (*tile)[65]) {
@@ -1396,6 +1398,7 @@ __device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, 
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
         float v = (r < d.R && c < d.C) ? d.src[(int64_t)r * d.ld + c] : 0.f;
+        if (d.gate && r < d.R && c < d.C) v = d.gate[(int64_t)r * d.ldgate + c] != 0.f ? v * d.gate_scale : 0.f;
         if (dc.on) v = drop_apply(dc, v, (uint64_t)((int64_t)r * d.C + c));      // element index of the [R][C] tensor
         csum += v;
         tile[ty * 16 + i][tx] = v;
@@ -1459,6 +1462,18 @@ __device__ __forceinline__ void planes_rows_tile(const PlaneDesc& d, int bx, int
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = (c0 + q < d.C) ? d.src[(int64_t)r * d.ld + c0 + q] : 0.f;     // ragged edge / zero padding
+            }
+            if (d.gate) {
+                if (c0 + 8 <= d.C && (d.ldgate & 3) == 0) {
+                    const float4 a = *reinterpret_cast<const float4*>(d.gate + (int64_t)r * d.ldgate + c0);
+                    const float4 b = *reinterpret_cast<const float4*>(d.gate + (int64_t)r * d.ldgate + c0 + 4);
+                    const float gq[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gq[q] != 0.f ? v[q] * d.gate_scale : 0.f;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (c0 + q < d.C && d.gate[(int64_t)r * d.ldgate + c0 + q] != 0.f) ? v[q] * d.gate_scale : 0.f;
+                }
             }
             if (dc.on) {
 #pragma unroll
@@ -2067,6 +2082,7 @@ static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, u
     d.src = src; d.ld = ld; d.R = R; d.C = C; d.hi = hi; d.lo = lo; d.fh = fh; d.fl = fl; d.ldp = ldp; d.hiT = hiT; d.loT = loT; d.ldpT = ldpT;
     d.colsum = colsum;
     d.drop_p = 0.f; d.drop_site = 0; d.drop_rng = nullptr;
+    d.gate = nullptr; d.ldgate = 0; d.gate_scale = 1.f;
     d.pcols = (hi || fh) ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
     d.pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
     d.tiles_x = bmt_cdiv(d.pcols > C ? d.pcols : C, 64);
@@ -2096,6 +2112,21 @@ extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, ui
     if (planes_rows_ok(d)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
     BMT_CHECK_LAUNCH("bmt_planes_dropout");
+    return BMT_OK;
+}
+
+// planes (+ column sums) of  dz = (gate != 0) ? src * gate_scale : 0  -- the gradient through relu (/ dropout before it) taken from the saved
+// forward output, without a dz tensor: bmt_gate -> bmt_planes + bmt_colsum in one pass (the 1 x 1 layers of the proposal heads, ABI 5)
+extern "C" int bmt_planes_gate(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
+                               float* colsum, const float* gate, int64_t ldgate, float gate_scale, void* stream) {
+    PlaneDesc d;
+    int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, nullptr, nullptr, 0, colsum);
+    if (rc) return rc;
+    BMT_CHECK_ARG(gate && ldgate >= C, "bmt_planes_gate: bad gate");
+    d.gate = gate; d.ldgate = ldgate; d.gate_scale = gate_scale;
+    if (planes_rows_ok(d) && al16(gate)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
+    BMT_CHECK_LAUNCH("bmt_planes_gate");
     return BMT_OK;
 }
 
@@ -2206,5 +2237,139 @@ extern "C" int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int
     const int64_t total = ((int64_t)B * (S + 2 * halo) + tail) * (ldp / 8);
     hipLaunchKernelGGL(pad_planes_kernel, dim3((unsigned)bmt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, B, S, C, halo, tail, hi, lo, lo_f16, ldp);
     BMT_CHECK_LAUNCH("bmt_pad_planes");
+    return BMT_OK;
+}
+
+
+// ---------------------------------------------------------------- the same with the relu / dropout derivative folded in, and the column sums
+// halo-padded bf16 plane of  dz = (y != 0) ? dy * scale : 0  (ConvKFn.backward: the gradient operand of the implicit Conv1d's dX and dW)
+// plus colsum[c] += sum over (b, s) of the bf16-rounded dz -- the convolution's bias gradient -- from the same pass: bmt_gate ->
+// bmt_pad_planes -> bmt_colsum over (B, S, C) fp32 became one read of dy and y.  Block = 64 plane rows; a thread owns one 8-column group
+// and walks the rows of its row lane.
+namespace {
+__global__ __launch_bounds__(256) void pad_planes_gate_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale, int B, int S, int C,
+                                                               int halo, int tail, uint16_t* __restrict__ hi, int64_t ldp, float* __restrict__ colsum) {
+    __shared__ float red[256][9];
+    const int groups = (int)(ldp / 8), lanes = 256 / groups;          // (launch: groups <= 256)
+    const int grp = threadIdx.x % groups, lane = threadIdx.x / groups;
+    const int64_t rows = (int64_t)B * (S + 2 * halo) + tail;
+    const int SP = S + 2 * halo, c0 = grp * 8;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lane < lanes) {
+        for (int64_t r = (int64_t)blockIdx.x * 64 + lane; r < rows && r < (int64_t)(blockIdx.x + 1) * 64; r += lanes) {
+            const int b = (int)(r / SP), s = (int)(r % SP) - halo;
+            u32x4 h = {0u, 0u, 0u, 0u};
+            if (b < B && s >= 0 && s < S && c0 < C) {
+                const int64_t o = ((int64_t)b * S + s) * C + c0;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C && y[o + j] != 0.f) ? dy[o + j] * scale : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = pack_bf2(v[2 * j], v[2 * j + 1]);
+                    h[j] = w;
+                    part[2 * j] += __uint_as_float(w << 16);
+                    part[2 * j + 1] += __uint_as_float(w & 0xffff0000u);
+                }
+            }
+            *reinterpret_cast<u32x4*>(hi + r * ldp + c0) = h;
+        }
+    }
+    if (colsum) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = part[j];
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = 0.f;
+                for (int l = 0; l < lanes; ++l) t += red[l * groups + grp][j];
+                if (c0 + j < C && t != 0.f) atomicAdd(colsum + c0 + j, t);
+            }
+        }
+    }
+}
+
+// Conv1d weight [N][C][k] (state_dict layout, contiguous) <-> the tap-major operand [N][k][cin_pad] of the implicit GEMM:
+//   TO_PLANES:  planes[n][tap * cin_pad + c] = W[n][c][tap]  (c >= C: zero), any of the four planes, row stride ldp
+//   else:       G[n][c][tap] += dWp[n][tap * cin_pad + c]     (the weight gradient back into the parameter's layout)
+// One workgroup per (n, 64-channel block): the (64 x k) sub-matrix goes through LDS, both sides are read / written in contiguous runs.
+// Replaces zeros + a permuting copy + bmt_planes (forward) and a strided framework add (backward): 612 MB of fp32 weights per step at
+// configs[3] were moved four times.
+template <bool TO_PLANES>
+__global__ __launch_bounds__(256) void conv_weight_kernel(float* __restrict__ W, int N, int C, int k, int cin_pad, uint16_t* __restrict__ hi,
+                                                           uint16_t* __restrict__ lo, uint16_t* __restrict__ fh, uint16_t* __restrict__ fl, int64_t ldp,
+                                                           float* __restrict__ dWp, int64_t ldw) {
+    extern __shared__ float tile[];                   // [64][k + 1]
+    const int n = blockIdx.x, c0 = blockIdx.y * 64, kp = k + 1;
+    const int nc = min(64, cin_pad - c0);             // channels of this block (zero padded past C)
+    if (TO_PLANES) {
+        for (int i = threadIdx.x; i < 64 * k; i += 256) {
+            const int c = i / k, t = i % k;
+            tile[c * kp + t] = (c0 + c < C) ? W[((int64_t)n * C + c0 + c) * k + t] : 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < k * nc; i += 256) {
+            const int t = i / nc, c = i % nc;
+            const float v = tile[c * kp + t];
+            const int64_t o = (int64_t)n * ldp + (int64_t)t * cin_pad + c0 + c;
+            if (hi) {
+                const __bf16 h = (__bf16)v;
+                hi[o] = __builtin_bit_cast(uint16_t, h);
+                if (lo) lo[o] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+            }
+            if (fh) {
+                const _Float16 h = (_Float16)v;
+                fh[o] = __builtin_bit_cast(uint16_t, h);
+                if (fl) fl[o] = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)h));
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < k * nc; i += 256) {
+            const int t = i / nc, c = i % nc;
+            tile[c * kp + t] = dWp[(int64_t)n * ldw + (int64_t)t * cin_pad + c0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * k; i += 256) {
+            const int c = i / k, t = i % k;
+            if (c0 + c < C) W[((int64_t)n * C + c0 + c) * k + t] += tile[c * kp + t];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int bmt_pad_planes_gate(const float* dy, const float* y, float scale, int B, int S, int C, int halo, int tail, uint16_t* hi, int64_t ldp,
+                                   float* colsum, void* stream) {
+    BMT_CHECK_ARG(dy && y && hi && B > 0 && S > 0 && C > 0 && halo >= 0 && tail >= 0 && ldp >= C && ldp % 8 == 0 && ldp / 8 <= 256,
+                  "bmt_pad_planes_gate: bad args (row stride a multiple of 8, at most 2048)");
+    if (!al16(hi)) { bmt_set_error("bmt_pad_planes_gate: the plane must be 16-byte aligned"); return BMT_EALIGN; }
+    const int64_t rows = (int64_t)B * (S + 2 * halo) + tail;
+    hipLaunchKernelGGL(pad_planes_gate_kernel, dim3((unsigned)bmt_cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, B, S, C, halo, tail, hi,
+                       ldp, colsum);
+    BMT_CHECK_LAUNCH("bmt_pad_planes_gate");
+    return BMT_OK;
+}
+
+extern "C" int bmt_conv_weight_planes(const float* W, int N, int C, int k, int cin_pad, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl,
+                                      int64_t ldp, void* stream) {
+    BMT_CHECK_ARG(W && (hi || fh) && N > 0 && C > 0 && k > 0 && cin_pad >= C && cin_pad % 64 == 0 && ldp >= (int64_t)k * cin_pad && k <= 600,
+                  "bmt_conv_weight_planes: bad args (cin_pad a multiple of 64 >= C, ldp >= k * cin_pad, k <= 600)");
+    BMT_CHECK_ARG((!lo || hi) && (!fl || fh), "bmt_conv_weight_planes: a lo plane without its hi plane");
+    const size_t lds = (size_t)64 * (k + 1) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)conv_weight_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(conv_weight_kernel<true>, dim3(N, cin_pad / 64), dim3(256), lds, (hipStream_t)stream, const_cast<float*>(W), N, C, k, cin_pad, hi, lo,
+                       fh, fl, ldp, nullptr, 0);
+    BMT_CHECK_LAUNCH("bmt_conv_weight_planes");
+    return BMT_OK;
+}
+
+extern "C" int bmt_conv_weight_grad(const float* dWp, int64_t ldw, int N, int C, int k, int cin_pad, float* grad, void* stream) {
+    BMT_CHECK_ARG(dWp && grad && N > 0 && C > 0 && k > 0 && cin_pad >= C && cin_pad % 64 == 0 && ldw >= (int64_t)k * cin_pad && k <= 600,
+                  "bmt_conv_weight_grad: bad args");
+    const size_t lds = (size_t)64 * (k + 1) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)conv_weight_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(conv_weight_kernel<false>, dim3(N, cin_pad / 64), dim3(256), lds, (hipStream_t)stream, grad, N, C, k, cin_pad, nullptr, nullptr,
+                       nullptr, nullptr, 0, const_cast<float*>(dWp), ldw);
+    BMT_CHECK_LAUNCH("bmt_conv_weight_grad");
     return BMT_OK;
 }

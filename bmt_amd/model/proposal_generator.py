@@ -24,6 +24,12 @@ def _copy3d(src, s0, s1, s2, n0, n1, n2, out=None, accumulate=False):
 def _conv_weight_planes(Wsrc, cin_pad, fmt):
     """[N][C][k]-indexed source (any strides) -> planes [N][k * cin_pad] in tap-major order (reduction index = tap * cin_pad + c)"""
     N, Cc, k = Wsrc.shape
+    if Wsrc.is_cuda and Wsrc.is_contiguous() and Wsrc.dtype == torch.float32 and cin_pad % 64 == 0 and k <= 600:
+        # the parameter as stored: one pass through LDS (bmt_conv_weight_planes) instead of zeros + a permuting copy + a plane conversion
+        pl = ops._alloc_planes(N, k * cin_pad, fmt, Wsrc.device)
+        _lib.check(lib.bmt_conv_weight_planes(_p(Wsrc.detach()), N, Cc, k, cin_pad, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0), _st()),
+                   "bmt_conv_weight_planes")
+        return pl
     Wp = torch.zeros(N, k, cin_pad, device=Wsrc.device, dtype=torch.float32)
     Wp[:, :, :Cc] = Wsrc.permute(0, 2, 1)
     return ops.make_planes(Wp.view(N, k * cin_pad), fmt)
@@ -71,6 +77,8 @@ class ConvKFn(torch.autograd.Function):
                       conv={"mode": 1, "M": B * S, "cin": cin, "rows": X.rows - off, "S": S, "halo": halo})
         ctx.save_for_backward(xc, W, y if (relu or p > 0) else None)
         ctx.relu, ctx.p, ctx.site, ctx.halo = relu, p, site, halo
+        ctx.weight, ctx.bias = W, b
+        ops.note_use(W, b)
         return y.view(B, S, Dout)
 
     @staticmethod
@@ -80,16 +88,30 @@ class ConvKFn(torch.autograd.Function):
         Dout, _, k = W.shape
         pad, halo = k // 2, ctx.halo
         dyc = _f32c(dy)
-        if ctx.relu:
-            dz = torch.empty_like(dyc)
-            _lib.check(lib.bmt_gate(_p(dyc), _p(y), 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0, _p(dz), dyc.numel(), _st()), "bmt_gate")
-        elif ctx.p > 0:
-            dz = ops.dropout_raw(dyc, ctx.p, ctx.site)
+        gb = ops.static_grad(ctx.bias)
+        db_done = False
+        if ctx.relu and ops.FUSE_GATE and ops._pad64(Dout) // 8 <= 256:
+            # dz = (y != 0) ? dy / (1 - p) : 0 never exists in fp32: its halo-padded bf16 plane and its column sums (the bias gradient) come
+            # out of ONE pass over dy and y (bmt_pad_planes_gate) instead of gate -> pad_planes -> colsum over three (B, S, 512) fp32 tensors
+            tail = 64 + 2 * halo + 1
+            rows = B * (S + 2 * halo) + tail
+            G = ops.Planes(torch.empty(rows, ops._pad64(Dout), device=dy.device, dtype=torch.bfloat16), None, rows, Dout)
+            db = gb if gb is not None else torch.zeros(Dout, device=dy.device, dtype=torch.float32)
+            _lib.check(lib.bmt_pad_planes_gate(_p(dyc), _p(y), 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0, B, S, Dout, halo, tail, _p(G.hi), G.hi.stride(0),
+                                               _p(db), _st()), "bmt_pad_planes_gate")
+            db_done = True
+            dz = None
         else:
-            dz = dyc
-        dz3 = dz.view(B, S, Dout)
-        # gradient planes, halo-padded like the activations (zero halo rows: they add nothing to dW and give dX its padding)
-        G = ops.pad_planes(dz3, halo, 64 + 2 * halo + 1, "bwd")
+            if ctx.relu:
+                dz = torch.empty_like(dyc)
+                _lib.check(lib.bmt_gate(_p(dyc), _p(y), 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0, _p(dz), dyc.numel(), _st()), "bmt_gate")
+            elif ctx.p > 0:
+                dz = ops.dropout_raw(dyc, ctx.p, ctx.site)
+            else:
+                dz = dyc
+            dz3 = dz.view(B, S, Dout)
+            # gradient planes, halo-padded like the activations (zero halo rows: they add nothing to dW and give dX its padding)
+            G = ops.pad_planes(dz3, halo, 64 + 2 * halo + 1, "bwd")
         off = halo - pad
         dx = None
         if ctx.needs_input_grad[0]:
@@ -114,8 +136,20 @@ class ConvKFn(torch.autograd.Function):
         ops.gemm_bf16(ops.Planes(G.hi[pad:], None, rows_red, Dout), ops.Planes(Xw.hi, None, rows_red, cin), dWp,
                       ldc=k * cin, precision=ops.PREC_BF16, a_km=True, b_km=True, splitk=sk,
                       conv={"mode": 2, "N": k * cin, "cin": cin, "rows": Xw.rows})
-        dW = dWp.view(Dout, k, cin)[:, :, :Din].permute(0, 2, 1)
-        db = ops.colsum(dz.view(-1, Dout))
+        gW = ops.static_grad(ctx.weight)
+        if k <= 600:          # the gradient back into the parameter's [Dout][Din][k] layout through LDS, added in place (bmt_conv_weight_grad)
+            dW = gW if gW is not None else torch.zeros(Dout, Din, k, device=dy.device, dtype=torch.float32)
+            _lib.check(lib.bmt_conv_weight_grad(_p(dWp), k * cin, Dout, Din, k, cin, _p(dW), _st()), "bmt_conv_weight_grad")
+            if gW is not None:
+                ops.grad_done(ctx.weight)
+                dW = None
+        else:
+            dW = dWp.view(Dout, k, cin)[:, :, :Din].permute(0, 2, 1)
+        if not db_done:
+            db = ops.colsum(dz.view(-1, Dout))
+        elif gb is not None:
+            ops.grad_done(ctx.bias)
+            db = None
         return dx, dW, db, None, None, None, None
 
 

@@ -66,7 +66,9 @@ POLICIES = {
     # six layers of configs[4] (see above), which keep two planes everywhere
     "enc_shallow": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc_shallow", ffn2=PREC_F16 if _os.environ.get("BMT_FFN2_TWO_PLANES") != "1" else None,
                           ffn1=PREC_F16 if _os.environ.get("BMT_FFN1_ONE_PLANE") == "1" else None),
-    "dec": Policy(PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),      # bi-modal decoder layers
+    # bi-modal decoder layers (BMT_DEC_GEMM=w2: their own GEMMs on fp16 x split-fp16, two passes -- an A/B switch; measured in round 4:
+    # see DESIGN.md section 6)
+    "dec": Policy(PREC_F16W2 if _os.environ.get("BMT_DEC_GEMM") == "w2" else PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),
     # Conv1d stacks of the proposal heads: split-bf16.  (fp16 activation x split weight leaves 6-8e-4 abs on the head outputs,
     # tests/test_gpu_proposal.py at round 2: inside the 1e-3 bar but with < 2x margin, and exp() turns it into 1e-3 relative on
     # the predicted lengths.)
@@ -76,7 +78,7 @@ POLICIES = {
     # sigmoid / exp of the predictions -- stay split-bf16.  BMT_HEAD_CONV=x3 restores three passes (A/B; tests/test_gpu_proposal.py holds the
     # predictions to 1e-3 either way)
     "head_conv": Policy(PREC_F16W2 if _os.environ.get("BMT_HEAD_CONV", "w2") != "x3" else PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "head_conv"),
-    None: Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
+    None: Policy(PREC_F16W2 if _os.environ.get("BMT_X_GEMM") == "w2" else PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
 }
 _OVERRIDE = [None]      # a Policy applied to EVERY site (A/B measurements, tests), or None
 
@@ -413,13 +415,19 @@ def _alloc_planes(rows: int, cols: int, fmt: str, device, ld: Optional[int] = No
     return Planes(bufs.get("hi"), bufs.get("lo"), rows, cols, bufs.get("fh"), bufs.get("fl"))
 
 
-def make_planes(x2: torch.Tensor, fmt: str = "x3", colsum=None, drop=None) -> Planes:
+def make_planes(x2: torch.Tensor, fmt: str = "x3", colsum=None, drop=None, gate=None) -> Planes:
     """one pass over fp32 x2 [R,C] -> Planes [R][pad64(C)] of the given set; colsum (optional fp32 [C]) += column sums of x2
     (atomic).  drop = (p, site): the planes (and column sums) are those of dropout(x2) with the mask of that site over a
-    contiguous [R][C] tensor."""
+    contiguous [R][C] tensor.  gate = (y [R,C] fp32, scale): those of (y != 0) ? x2 * scale : 0 -- the gradient through a relu (and a
+    dropout in front of it) from the saved forward output, without materialising it (bmt_planes_gate)."""
     R, Cc = x2.shape
     pl = _alloc_planes(R, Cc, fmt, x2.device)
     ld = pl.any.stride(0)
+    if gate is not None:
+        y2, gscale = gate
+        _lib.check(lib.bmt_planes_gate(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, _p(colsum), _p(y2), y2.stride(0),
+                                       float(gscale), _st()), "bmt_planes_gate")
+        return pl
     if drop is not None and drop[0] > 0.0:
         _lib.check(lib.bmt_planes_dropout(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, None, None, 0, _p(colsum),
                                           drop[0], _p(rng_tensor()), drop[1], _st()), "bmt_planes_dropout")
@@ -1610,6 +1618,22 @@ class LinearActFn(torch.autograd.Function):
         N = W.shape[0]
         dy2 = _f32c(dy).view(-1, N)
         p = ctx.p if ctx.drop_mode != "none" else 0.0
+        if ctx.relu and FUSE_GATE:
+            # dz = (y != 0) ? dy / (1 - p) : 0 never exists: its bf16 plane and column sums (the bias gradient) come out of one pass over dy and y
+            Wp, bp = ctx.params
+            bp = bp if ctx.has_bias else None
+            gb = static_grad(bp)
+            cs = gb if gb is not None else (torch.zeros(N, device=dy2.device, dtype=torch.float32) if bp is not None else None)
+            P = make_planes(dy2, "bwd", colsum=cs, gate=(y, 1.0 / (1.0 - p) if p > 0 else 1.0))
+            if gb is not None:
+                grad_done(bp)
+            dx = linear_dx(P, Wp) if ctx.needs_input_grad[0] else None
+            dW = None
+            if ctx.needs_input_grad[1]:
+                dW, _ = wgrad(Wp, None, P, bwd_planes(x2))
+            if dx is not None:
+                dx = dx.view(*dy.shape[:-1], W.shape[1])
+            return dx, dW, (None if gb is not None else cs), None, None, None, None
         if ctx.relu:
             dz = torch.empty_like(dy2)
             _lib.check(lib.bmt_gate(_p(dy2), _p(y), 1.0 / (1.0 - p) if p > 0 else 1.0, _p(dz), dy2.numel(), _st()), "bmt_gate")
@@ -1981,6 +2005,7 @@ class MHAFn(torch.autograd.Function):
         return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None, None
 
 
+FUSE_GATE = _os.environ.get("BMT_FUSE_GATE", "1") != "0"      # A/B switch: "0" = relu / dropout derivative as its own kernel + an fp32 dz tensor again
 FUSE_GEN_LOSS = _os.environ.get("BMT_FUSE_GEN_LOSS", "1") != "0"      # A/B switch: "0" = the generator and the loss as separate autograd nodes
 
 

@@ -125,6 +125,20 @@ int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, s
  * lo = bf16(x - hi) or (lo_f16) fp16(x) */
 int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp,
                    void* stream);
+/* ABI 5 -- the proposal heads' backward without its fp32 intermediates:
+ *   bmt_planes_gate       planes (+ column sums added into colsum[C], optional) of dz = (gate != 0) ? src * gate_scale : 0: the gradient
+ *                         through relu (and a dropout in front of it) from the saved forward output, no dz tensor (bmt_gate -> bmt_planes);
+ *   bmt_pad_planes_gate   the halo-padded bf16 plane of the same dz for a (B, S, C) gradient (bmt_pad_planes layout) + its column sums;
+ *   bmt_conv_weight_planes  Conv1d weight [N][C][k] (contiguous) -> operand planes [N][k * cin_pad], tap-major, channels zero padded:
+ *                         planes[n][tap * cin_pad + c] = W[n][c][tap] (any of hi / lo / fh / fl, row stride ldp);
+ *   bmt_conv_weight_grad  the inverse for the weight gradient: grad[n][c][tap] += dWp[n * ldw + tap * cin_pad + c]. */
+int bmt_planes_gate(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp, float* colsum,
+                    const float* gate, int64_t ldgate, float gate_scale, void* stream);
+int bmt_pad_planes_gate(const float* dy, const float* y, float scale, int B, int S, int C, int halo, int tail, uint16_t* hi, int64_t ldp,
+                        float* colsum, void* stream);
+int bmt_conv_weight_planes(const float* W, int N, int C, int k, int cin_pad, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
+                           void* stream);
+int bmt_conv_weight_grad(const float* dWp, int64_t ldw, int N, int C, int k, int cin_pad, float* grad, void* stream);
 /* fp32 [R][C] (row stride ld) -> bf16 planes: hi/lo [R][ldp] and/or transposed hiT/loT [C][ldpT]; any output may be NULL
  * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
 int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh /* fp16(x), optional */,

@@ -300,3 +300,50 @@ def test_captured_proposal_step_equals_the_eager_step(golden):
     sc = ProposalTrainStep(mc, cfg, pad_idx=1)
     l_pad = float(sc(fs, ProposalTrainStep.pad_targets(tg, tg.shape[0] + 7))[1])
     assert abs(l_pad - la[0]) < 1e-5 * max(1.0, abs(la[0]))
+
+
+# ---------------------------------------------------------------------------------------------- proposal heads: backward without fp32 intermediates
+@pytest.mark.parametrize("R,C", [(70, 512), (300, 144), (33, 20), (4100, 384)])
+def test_planes_through_a_relu_gate(ops, R, C):
+    """bmt_planes_gate: planes and column sums of (y != 0) ? dy * scale : 0 == bmt_gate followed by bmt_planes"""
+    dy, y = rnd(R, C, seed=R).to(DEV), torch.relu(rnd(R, C, seed=C)).to(DEV)
+    cs = torch.zeros(C, device=DEV)
+    pl = ops.make_planes(dy, "x3", colsum=cs, gate=(y, 1.25))
+    dz = torch.where(y != 0, dy * 1.25, torch.zeros_like(dy))
+    cs0 = torch.zeros(C, device=DEV)
+    want = ops.make_planes(dz, "x3", colsum=cs0)
+    assert torch.equal(pl.hi, want.hi) and torch.equal(pl.lo, want.lo)
+    assert_close(cs, cs0, atol=1e-4, rtol=1e-5, name="column sums")
+
+
+@pytest.mark.parametrize("B,S,C,halo", [(2, 40, 512, 15), (3, 17, 144, 2), (1, 100, 64, 39), (2, 9, 20, 0)])
+def test_padded_planes_through_a_relu_gate(ops, B, S, C, halo):
+    from bmt_amd import _lib
+    dy, y = rnd(B, S, C, seed=S).to(DEV), torch.relu(rnd(B, S, C, seed=C)).to(DEV)
+    tail = 64 + 2 * halo + 1
+    rows = B * (S + 2 * halo) + tail
+    hi = torch.full((rows, ops._pad64(C)), 3.0, device=DEV, dtype=torch.bfloat16)
+    db = torch.zeros(C, device=DEV)
+    _lib.check(ops.lib.bmt_pad_planes_gate(ops._p(dy), ops._p(y), 2.0, B, S, C, halo, tail, ops._p(hi), hi.stride(0), ops._p(db), ops._st()), "ppg")
+    dz = torch.where(y != 0, dy * 2.0, torch.zeros_like(dy))
+    want = ops.pad_planes(dz, halo, tail, "bwd")
+    assert torch.equal(hi, want.hi)
+    assert_close(db, want.hi.float().sum(0)[:C], atol=2e-3, rtol=1e-4, name="bias gradient (sums of the bf16 values)")
+
+
+@pytest.mark.parametrize("N,C,k,cin", [(16, 24, 5, 64), (512, 128, 211, 128), (40, 1024, 79, 1024), (9, 48, 1, 64)])
+def test_conv_weight_relayout(ops, N, C, k, cin):
+    """bmt_conv_weight_planes / bmt_conv_weight_grad against the permute they replace"""
+    from bmt_amd import _lib
+    from bmt_amd.model.proposal_generator import _conv_weight_planes
+    W = rnd(N, C, k, seed=k).to(DEV)
+    got = _conv_weight_planes(W, cin, "w2")
+    Wp = torch.zeros(N, k, cin, device=DEV)
+    Wp[:, :, :C] = W.permute(0, 2, 1)
+    want = ops.make_planes(Wp.view(N, k * cin), "w2")
+    for a, b in ((got.hi, want.hi), (got.fh, want.fh), (got.fl, want.fl)):
+        assert torch.equal(a, b)
+    dWp = rnd(N, k * cin, seed=7).to(DEV)
+    g = torch.ones(N, C, k, device=DEV)
+    _lib.check(ops.lib.bmt_conv_weight_grad(ops._p(dWp), k * cin, N, C, k, cin, ops._p(g), ops._st()), "cwg")
+    assert torch.equal(g, 1.0 + dWp.view(N, k, cin)[:, :, :C].permute(0, 2, 1))

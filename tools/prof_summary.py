@@ -48,8 +48,14 @@ def last_step(src, steps, dst):
     with open(src) as f:
         rows = list(csv.DictReader(f))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    n = len(rows) // steps
-    rows = rows[-n:]
+    # one optimizer step = what lies between two launches of the Adam kernel (the dispatch count divided by the number of steps also
+    # counts the first step's one-off launches: weight-plane registration, optimizer state)
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    if len(adam) >= 2:
+        rows = rows[adam[-2] + 1:adam[-1] + 1]
+    else:
+        rows = rows[-(len(rows) // steps):]
+    n = len(rows)
     with open(dst, "w", newline="") as f:
         f.write(f"# last of {steps} eager steps: {n} dispatches, {(int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp'])) / 1e6:.3f} ms from first start to last end\n")
         w = csv.writer(f)
