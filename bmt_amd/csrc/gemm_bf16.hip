@@ -2249,21 +2249,36 @@ extern "C" int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int
 namespace {
 __global__ __launch_bounds__(256) void pad_planes_gate_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale, int B, int S, int C,
                                                                int halo, int tail, uint16_t* __restrict__ hi, int64_t ldp, float* __restrict__ colsum) {
-    __shared__ float red[256][9];
-    const int groups = (int)(ldp / 8), lanes = 256 / groups;          // (launch: groups <= 256)
-    const int grp = threadIdx.x % groups, lane = threadIdx.x / groups;
-    const int64_t rows = (int64_t)B * (S + 2 * halo) + tail;
-    const int SP = S + 2 * halo, c0 = grp * 8;
+    // block = 64 plane rows x 128 columns (the geometry of planes_rows_tile): a thread owns 8 columns of 4 rows, 16-byte loads / stores
+    __shared__ float cs[16][129];
+    const int tid = threadIdx.x;
+    const int cg = (tid & 15) * 8, rt = tid >> 4;
+    const int c0 = blockIdx.x * 128 + cg;
+    const int64_t rows = (int64_t)B * (S + 2 * halo) + tail, r0 = (int64_t)blockIdx.y * 64;
+    const int SP = S + 2 * halo;
+    const bool vec = (C % 8 == 0);
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (lane < lanes) {
-        for (int64_t r = (int64_t)blockIdx.x * 64 + lane; r < rows && r < (int64_t)(blockIdx.x + 1) * 64; r += lanes) {
+    if (c0 < ldp) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int64_t r = r0 + ps * 16 + rt;
+            if (r >= rows) continue;
             const int b = (int)(r / SP), s = (int)(r % SP) - halo;
             u32x4 h = {0u, 0u, 0u, 0u};
             if (b < B && s >= 0 && s < S && c0 < C) {
                 const int64_t o = ((int64_t)b * S + s) * C + c0;
-                float v[8];
+                float v[8], g[8];
+                if (vec) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(dy + o), a1 = *reinterpret_cast<const float4*>(dy + o + 4);
+                    const float4 g0 = *reinterpret_cast<const float4*>(y + o), g1 = *reinterpret_cast<const float4*>(y + o + 4);
+                    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+                    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C && y[o + j] != 0.f) ? dy[o + j] * scale : 0.f;
+                    for (int j = 0; j < 8; ++j) { v[j] = (c0 + j < C) ? dy[o + j] : 0.f; g[j] = (c0 + j < C) ? y[o + j] : 0.f; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = g[j] != 0.f ? v[j] * scale : 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t w = pack_bf2(v[2 * j], v[2 * j + 1]);
@@ -2277,15 +2292,13 @@ __global__ __launch_bounds__(256) void pad_planes_gate_kernel(const float* __res
     }
     if (colsum) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = part[j];
+        for (int q = 0; q < 8; ++q) cs[rt][cg + q] = part[q];
         __syncthreads();
-        if (lane == 0) {
+        if (tid < 128 && blockIdx.x * 128 + tid < C) {
+            float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float t = 0.f;
-                for (int l = 0; l < lanes; ++l) t += red[l * groups + grp][j];
-                if (c0 + j < C && t != 0.f) atomicAdd(colsum + c0 + j, t);
-            }
+            for (int i = 0; i < 16; ++i) t += cs[i][tid];
+            if (t != 0.f) atomicAdd(colsum + blockIdx.x * 128 + tid, t);
         }
     }
 }
@@ -2340,12 +2353,13 @@ __global__ __launch_bounds__(256) void conv_weight_kernel(float* __restrict__ W,
 
 extern "C" int bmt_pad_planes_gate(const float* dy, const float* y, float scale, int B, int S, int C, int halo, int tail, uint16_t* hi, int64_t ldp,
                                    float* colsum, void* stream) {
-    BMT_CHECK_ARG(dy && y && hi && B > 0 && S > 0 && C > 0 && halo >= 0 && tail >= 0 && ldp >= C && ldp % 8 == 0 && ldp / 8 <= 256,
-                  "bmt_pad_planes_gate: bad args (row stride a multiple of 8, at most 2048)");
+    BMT_CHECK_ARG(dy && y && hi && B > 0 && S > 0 && C > 0 && halo >= 0 && tail >= 0 && ldp >= C && ldp % 8 == 0,
+                  "bmt_pad_planes_gate: bad args (row stride a multiple of 8)");
+    BMT_CHECK_ARG(C % 8 != 0 || (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y)) & 15) == 0), "bmt_pad_planes_gate: 16-byte aligned tensors");
     if (!al16(hi)) { bmt_set_error("bmt_pad_planes_gate: the plane must be 16-byte aligned"); return BMT_EALIGN; }
     const int64_t rows = (int64_t)B * (S + 2 * halo) + tail;
-    hipLaunchKernelGGL(pad_planes_gate_kernel, dim3((unsigned)bmt_cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, B, S, C, halo, tail, hi,
-                       ldp, colsum);
+    hipLaunchKernelGGL(pad_planes_gate_kernel, dim3((unsigned)bmt_cdiv(ldp, 128), (unsigned)bmt_cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                       scale, B, S, C, halo, tail, hi, ldp, colsum);
     BMT_CHECK_LAUNCH("bmt_pad_planes_gate");
     return BMT_OK;
 }

@@ -4,6 +4,8 @@
 //   decode + loss         model/proposal_generator.py:281-335  (sigmoid / exp / grid add, masked MSE + BCE means)
 // The Conv1d stacks themselves run on the MFMA GEMM (bmt_conv1d in gemm.hip).  Everything here is elementwise /
 // gather-scatter and HBM-bound: coalesced over the (B,S,3A) head output, block reduction + one atomic per block.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -105,6 +107,90 @@ __global__ __launch_bounds__(256) void decode_loss_kernel(const float* __restric
     }
 }
 
+// The same two kernels with both sides coalesced (ABI 5 default): the head output x is (B, S, A, 3) -- anchors fastest -- while predictions,
+// masks and targets are (B, A, S) -- positions fastest: the element-per-thread kernels above scatter 12-byte prediction stores and
+// single-byte mask loads S elements apart (81 us for 29 MB at configs[3]: 0.7 TB/s).  Here a workgroup owns 32 positions of one video:
+// the (32 x A x 3) block of x goes through LDS (row stride padded to an odd number of words), the loop runs positions-fastest.
+constexpr int PROP_TS = 32;
+__global__ __launch_bounds__(256) void decode_loss_tiled_kernel(const float* __restrict__ x, const float* __restrict__ anchors, int B, int S, int A,
+                                                                 float stride, const uint8_t* __restrict__ obj, const uint8_t* __restrict__ noobj,
+                                                                 const float* __restrict__ tx, const float* __restrict__ tw,
+                                                                 float* __restrict__ preds, float* __restrict__ sums) {
+    extern __shared__ float xs[];                 // [PROP_TS][A * 3 + 1]
+    __shared__ float red[4];
+    const int b = blockIdx.y, s0 = blockIdx.x * PROP_TS, W = A * 3, WP = W + 1;
+    const int ns = min(PROP_TS, S - s0);
+    const float* src = x + ((int64_t)b * S + s0) * W;
+    for (int i = threadIdx.x; i < ns * W; i += 256) xs[(i / W) * WP + i % W] = src[i];
+    __syncthreads();
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < A * PROP_TS; j += 256) {
+        const int a = j / PROP_TS, sl = j % PROP_TS;
+        if (sl >= ns) continue;
+        const int s = s0 + sl;
+        const float c = xs[sl * WP + a * 3 + 0], l = xs[sl * WP + a * 3 + 1], o = xs[sl * WP + a * 3 + 2];
+        const float sc = sigmoidf_(c), so = sigmoidf_(o);
+        const int64_t pidx = ((int64_t)b * A + a) * S + s;
+        preds[pidx * 3 + 0] = (sc + (float)s) * stride;
+        preds[pidx * 3 + 1] = (anchors[a] * expf(l)) * stride;
+        preds[pidx * 3 + 2] = so;
+        if (obj) {
+            if (obj[pidx]) {
+                const float dx = sc - tx[pidx], dw = l - tw[pidx];
+                acc[0] += dx * dx; acc[1] += dw * dw;
+                acc[2] += -fmaxf(logf(so), -100.f);
+                acc[4] += 1.f;
+            }
+            if (noobj[pidx]) {
+                acc[3] += -fmaxf(logf(1.f - so), -100.f);
+                acc[5] += 1.f;
+            }
+        }
+    }
+    if (obj) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float v = block_sum_256(acc[k], red);
+            if (threadIdx.x == 0 && v != 0.f) atomicAdd(sums + k, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_tiled_kernel(const float* __restrict__ x, int B, int S, int A, const uint8_t* __restrict__ obj,
+                                                              const uint8_t* __restrict__ noobj, const float* __restrict__ tx,
+                                                              const float* __restrict__ tw, const float* __restrict__ sums, float obj_coeff,
+                                                              float noobj_coeff, const float* __restrict__ gscale, float* __restrict__ dx) {
+    extern __shared__ float xs[];                 // [PROP_TS][A * 3 + 1]: x in, dx out
+    const int b = blockIdx.y, s0 = blockIdx.x * PROP_TS, W = A * 3, WP = W + 1;
+    const int ns = min(PROP_TS, S - s0);
+    const float g = gscale[0];
+    const float inv_obj = 1.f / sums[4], inv_noobj = 1.f / sums[5];
+    const float* src = x + ((int64_t)b * S + s0) * W;
+    for (int i = threadIdx.x; i < ns * W; i += 256) xs[(i / W) * WP + i % W] = src[i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < A * PROP_TS; j += 256) {
+        const int a = j / PROP_TS, sl = j % PROP_TS;
+        if (sl >= ns) continue;
+        const int64_t pidx = ((int64_t)b * A + a) * S + s0 + sl;
+        float* e = xs + sl * WP + a * 3;
+        float dc = 0.f, dl = 0.f, dob = 0.f;
+        const float so = sigmoidf_(e[2]);
+        if (obj[pidx]) {
+            const float sc = sigmoidf_(e[0]);
+            dc = 2.f * (sc - tx[pidx]) * inv_obj * sc * (1.f - sc);
+            dl = 2.f * (e[1] - tw[pidx]) * inv_obj;
+            if (logf(so) > -100.f) dob += obj_coeff * inv_obj * (-(1.f - so));
+        }
+        if (noobj[pidx]) {
+            if (logf(1.f - so) > -100.f) dob += noobj_coeff * inv_noobj * so;
+        }
+        e[0] = dc * g; e[1] = dl * g; e[2] = dob * g;          // (each element of the block belongs to exactly one thread)
+    }
+    __syncthreads();
+    float* dst = dx + ((int64_t)b * S + s0) * W;
+    for (int i = threadIdx.x; i < ns * W; i += 256) dst[i] = xs[(i / W) * WP + i % W];
+}
+
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float obj_coeff, float noobj_coeff, float* __restrict__ losses) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float lx = sums[0] / sums[4], lw = sums[1] / sums[4], lo = sums[2] / sums[4], ln = sums[3] / sums[5];
@@ -177,7 +263,13 @@ extern "C" int bmt_prop_decode_loss(const float* x, const float* anchors, int B,
         bmt_set_error("bmt_prop_decode_loss: memset failed");
         return BMT_EHIP;
     }
-    hipLaunchKernelGGL(decode_loss_kernel, dim3(grid_for((int64_t)B * S * A)), dim3(256), 0, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds, loss_ws);
+    static const int tiled = getenv("BMT_PROP_TILED") ? atoi(getenv("BMT_PROP_TILED")) : 1;      // A/B experiments only
+    const size_t lds = (size_t)PROP_TS * (A * 3 + 1) * sizeof(float);
+    if (tiled && lds <= 60 * 1024 && B <= 65535)
+        hipLaunchKernelGGL(decode_loss_tiled_kernel, dim3(bmt_cdiv(S, PROP_TS), B), dim3(256), lds, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds,
+                           loss_ws);
+    else
+        hipLaunchKernelGGL(decode_loss_kernel, dim3(grid_for((int64_t)B * S * A)), dim3(256), 0, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds, loss_ws);
     BMT_CHECK_LAUNCH("bmt_prop_decode_loss");
     return BMT_OK;
 }
@@ -193,7 +285,13 @@ extern "C" int bmt_prop_loss_bwd(const float* x, int B, int S, int A, const uint
                                  const float* tw, const float* loss_ws, float obj_coeff, float noobj_coeff, const float* gscale_dev,
                                  float* dx, void* stream) {
     BMT_CHECK_ARG(x && obj && noobj && tx && tw && loss_ws && gscale_dev && dx && B > 0 && S > 0 && A > 0, "bmt_prop_loss_bwd: bad args");
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((int64_t)B * S * A)), dim3(256), 0, (hipStream_t)stream, x, B, S, A, obj, noobj, tx, tw, loss_ws, obj_coeff, noobj_coeff, gscale_dev, dx);
+    static const int tiled = getenv("BMT_PROP_TILED") ? atoi(getenv("BMT_PROP_TILED")) : 1;      // A/B experiments only
+    const size_t lds = (size_t)PROP_TS * (A * 3 + 1) * sizeof(float);
+    if (tiled && lds <= 60 * 1024 && B <= 65535)
+        hipLaunchKernelGGL(loss_bwd_tiled_kernel, dim3(bmt_cdiv(S, PROP_TS), B), dim3(256), lds, (hipStream_t)stream, x, B, S, A, obj, noobj, tx, tw, loss_ws,
+                           obj_coeff, noobj_coeff, gscale_dev, dx);
+    else
+        hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((int64_t)B * S * A)), dim3(256), 0, (hipStream_t)stream, x, B, S, A, obj, noobj, tx, tw, loss_ws, obj_coeff, noobj_coeff, gscale_dev, dx);
     BMT_CHECK_LAUNCH("bmt_prop_loss_bwd");
     return BMT_OK;
 }
