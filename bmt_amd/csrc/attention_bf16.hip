@@ -2527,7 +2527,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int hh = lane >> 5, l31 = lane & 31;
     const int nqt = (p.Sq + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
-    const int qt = w % nqt, bh = w / nqt;
+    // work order: (batch, head)-major, so that the query tiles of a (batch, head) run together and share its K / V in their XCD's L2 --
+    // EXCEPT the remnant tile of a sequence whose length is no multiple of 128 (800 = 6 x 128 + 32): those go to the END of every XCD's
+    // range.  896 workgroups on 256 CUs at one per CU were 3.5 rounds with full-cost workgroups in the half round; now each XCD runs
+    // 96 full tiles = exactly 3 rounds of its 32 CUs and then 16 remnant tiles, which hold 32 rows and -- padded positions -- are dead in
+    // most batch elements (AttnPB.qlive: no key loop at all).  Only when the ranges divide evenly (else the plain order).
+    int qt, bh;
+    {
+        const int total = nqt * p.B * p.H, chunk = total >> 3, nfull = p.Sq / 128;
+        if (nfull > 0 && nfull < nqt && (total & 7) == 0 && chunk % nqt == 0) {
+            const int c = w / chunk, i = w % chunk, per = chunk / nqt;
+            if (i < per * nfull) { bh = c * per + i / nfull; qt = i % nfull; }
+            else { bh = c * per + (i - per * nfull); qt = nfull; }
+        } else {
+            qt = w % nqt; bh = w / nqt;
+        }
+    }
     const int b = bh / p.H, h = bh % p.H;
     const int q = qt * 128 + wid * 32 + l31;
     const bool qok = q < p.Sq;
@@ -2908,7 +2923,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hh = lane >> 5, l31 = lane & 31;
     const int nkt = (p.Sk + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
-    const int kt = w % nkt, bh = w / nkt;
+    // (the remnant key block of a sequence whose length is no multiple of 128 goes to the end of every XCD's range, as in
+    // attn_bwd_dq32p_kernel: it is beyond the valid keys -- and leaves at once -- in most batch elements)
+    int kt, bh;
+    {
+        const int total = nkt * p.B * p.H, chunk = total >> 3, nfull = p.Sk / 128;
+        if (nfull > 0 && nfull < nkt && (total & 7) == 0 && chunk % nkt == 0) {
+            const int c = w / chunk, i = w % chunk, per = chunk / nkt;
+            if (i < per * nfull) { bh = c * per + i / nfull; kt = i % nfull; }
+            else { bh = c * per + (i - per * nfull); kt = nfull; }
+        } else {
+            kt = w % nkt; bh = w / nkt;
+        }
+    }
     const int b = bh / p.H, h = bh % p.H;
     const int key = kt * 128 + kg * 32 + l31;
     const bool kin = key < p.Sk;
