@@ -178,6 +178,7 @@ struct AttnPB {
     // emits nothing, the dK / dV loop ends at the last live 32-query stage.  Data-driven, so a caller whose padded rows DO carry gradient
     // loses nothing but the shortcut.  nullptr: off.
     int* qlive;
+    int remnant_last;                          // split backward: the remnant tile of a sequence at the end of every XCD's work range (A/B switch)
 };
 
 // 8 fp16 -> 8 bf16 (round to nearest even) in one 16-byte register slot: q / k / v exist as fp16 planes only under the fp16 attention
@@ -2535,7 +2536,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int qt, bh;
     {
         const int total = nqt * p.B * p.H, chunk = total >> 3, nfull = p.Sq / 128;
-        if (nfull > 0 && nfull < nqt && (total & 7) == 0 && chunk % nqt == 0) {
+        if (p.remnant_last && nfull > 0 && nfull < nqt && (total & 7) == 0 && chunk % nqt == 0) {
             const int c = w / chunk, i = w % chunk, per = chunk / nqt;
             if (i < per * nfull) { bh = c * per + i / nfull; qt = i % nfull; }
             else { bh = c * per + (i - per * nfull); qt = nfull; }
@@ -2928,7 +2929,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int kt, bh;
     {
         const int total = nkt * p.B * p.H, chunk = total >> 3, nfull = p.Sk / 128;
-        if (nfull > 0 && nfull < nkt && (total & 7) == 0 && chunk % nkt == 0) {
+        if (p.remnant_last && nfull > 0 && nfull < nkt && (total & 7) == 0 && chunk % nkt == 0) {
             const int c = w / chunk, i = w % chunk, per = chunk / nkt;
             if (i < per * nfull) { bh = c * per + i / nfull; kt = i % nfull; }
             else { bh = c * per + (i - per * nfull); kt = nfull; }
@@ -3342,6 +3343,8 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
             // per (batch, head) in the dK / dV kernel: 64 stages of 32 queries
             static const int qskip = getenv("BMT_ATTN_QSKIP") ? atoi(getenv("BMT_ATTN_QSKIP")) : 1;      // A/B experiments only
             p.qlive = (qskip && a->Sq <= 2048) ? reinterpret_cast<int*>(a->Qb_ws + (int64_t)a->B * p.bsqb) : nullptr;
+            static const int remnant_last = getenv("BMT_ATTN_REMNANT_LAST") ? atoi(getenv("BMT_ATTN_REMNANT_LAST")) : 0;      // A/B: measured WORSE (attention-backward class 1.57-1.60 vs 1.48-1.50 ms same box, profiles/r04_g_ab_remnant.txt): off
+            p.remnant_last = remnant_last;
         }
     }
     hipStream_t st = (hipStream_t)stream;

@@ -1,14 +1,14 @@
 #!/bin/bash
-# ISA census of one experiment kernel without a GPU: compiles <file> (an experiment .hip meant for exp_lib.hip's translation unit) behind the
-# product's attention_bf16.hip + attn_bwd32.hip, prints registers / scratch and the instruction mix of its MFMA loops.
-#   usage: tools/exp_isa.sh bmt_amd/csrc/exp/attn_bwd_split.hip dkvg_kernelILi256 [extra -D flags]
+# ISA census of one kernel without a GPU: compiles <file> (an experiment .hip meant for tools/experiments/exp_lib.hip's translation unit, or
+# /dev/null for a kernel of the product's own attention_bf16.hip) behind the product's attention_bf16.hip, prints registers / scratch and the
+# instruction mix of its MFMA loops.
+#   usage: tools/exp_isa.sh tools/experiments/attn_fwd32.hip attn_fwd32 [extra -D flags]      tools/exp_isa.sh /dev/null dkvg8_kernelILi256
 F=$(realpath "$1"); K=$2; shift 2
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d /tmp/expisa.XXXX)
 cat > $T/tu.hip <<EOT
 #define BMT_EXP_LIB 1
 #include "$R/bmt_amd/csrc/attention_bf16.hip"
-#include "$R/bmt_amd/csrc/exp/attn_bwd32.hip"
 #include "$F"
 EOT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc --cuda-device-only -I$R/bmt_amd/csrc "$@" -Rpass-analysis=kernel-resource-usage -S $T/tu.hip -o $T/tu.s 2> $T/res.txt || { grep -v "remark:\|argument unused" $T/res.txt | head -30; exit 1; }
