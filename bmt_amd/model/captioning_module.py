@@ -132,7 +132,7 @@ class BiModalTransformer(nn.Module):
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
-        # initialize embedding after, so it will replace the weights of the prev. initialization
+        # (order matters for bit-identical initial weights: xavier over every matrix first, then the word vectors -- model/captioning_module.py:139-145)
         self.emb_C.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
 
         if cfg.pretrained_prop_model_path is not None:
