@@ -155,6 +155,7 @@ SIGNATURES = {
     "bmt_caption_shift": (i32, [vp, i64, i32, i32, i64, vp, vp, vp, vp]),
     "bmt_loss_finish": (i32, [vp, vp, vp, vp, vp]),
     "bmt_layernorm_bwd_partial2": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
+    "bmt_layernorm_bwd_emit": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, f32, vp, u32, i32, i32, vp]),
     "bmt_adam_step": (i32, [vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp, vp]),
     "bmt_grad_sqnorm": (i32, [vp, vp, i32, i64, vp, f32, vp, vp]),
     "bmt_scale_tensors": (i32, [vp, vp, i32, i64, vp, vp]),

@@ -88,14 +88,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                       const float* __restrict__ rstd, float* dx, int64_t lddx,
                                                       const float* dx_add, int64_t ldadd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ partial, int rows_per_wave, int rows, int D,
-                                                      const float* __restrict__ dx_add2, int64_t ldadd2) {
-    extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][3 waves][NV*256]
+                                                      const float* __restrict__ dx_add2, int64_t ldadd2,
+                                                      uint16_t* __restrict__ gp_hi, int64_t gp_ld, float gp_drop_p, const uint64_t* __restrict__ gp_rng,
+                                                      uint32_t gp_site) {
+    // gp_hi (optional): the bf16 operand plane of dropout_site(dx) -- what the PREVIOUS sublayer's last GEMM backward reads as its upstream
+    // gradient (x_out = x + dropout(sublayer(LN x)): d x_out reaches that GEMM through the residual dropout's mask) -- and, in the third
+    // block of the workgroup's partials, its column sums (that GEMM's bias gradient): the separate conversion pass over dx is gone
+    extern __shared__ __attribute__((aligned(16))) float sred[];   // [2 or 3][3 waves][NV*256]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float4 ag[NV], ab[NV], gm[NV];
+    const DropCtx dcx = make_drop(gp_drop_p, gp_rng, gp_site);
+    float4 ag[NV], ab[NV], gm[NV], am[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         ab[i] = ag[i];
+        am[i] = ag[i];
         const int c = lane * 4 + 256 * i;
         gm[i] = (c < D) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -142,17 +149,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 *reinterpret_cast<float4*>(dxr + c) = o;
+                if (gp_hi) {
+                    float4 m = o;
+                    if (dcx.on) {
+                        const uint64_t e0 = (uint64_t)((int64_t)row * D + c);
+                        m.x = drop_apply(dcx, m.x, e0); m.y = drop_apply(dcx, m.y, e0 + 1);
+                        m.z = drop_apply(dcx, m.z, e0 + 2); m.w = drop_apply(dcx, m.w, e0 + 3);
+                    }
+                    *reinterpret_cast<uint2*>(gp_hi + (int64_t)row * gp_ld + c) = make_uint2(pack_bf2(m.x, m.y), pack_bf2(m.z, m.w));
+                    am[i].x += m.x; am[i].y += m.y; am[i].z += m.z; am[i].w += m.w;
+                }
             }
         }
     }
     // reduce the 4 waves' column partials through LDS; wave 0 issues the atomics
     float* sg = sred;                     // [3][NV*256]
     float* sb = sred + 3 * NV * 256;
+    float* sm = sred + 6 * NV * 256;      // (only with gp_hi: the launch sizes the LDS for it)
     if (wid > 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             *reinterpret_cast<float4*>(sg + (wid - 1) * NV * 256 + lane * 4 + 256 * i) = ag[i];
             *reinterpret_cast<float4*>(sb + (wid - 1) * NV * 256 + lane * 4 + 256 * i) = ab[i];
+            if (gp_hi) *reinterpret_cast<float4*>(sm + (wid - 1) * NV * 256 + lane * 4 + 256 * i) = am[i];
         }
     }
     __syncthreads();
@@ -170,9 +189,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
                 }
                 if (partial) {   // two-stage: plain stores of this workgroup's column partials, summed by ln_bwd_reduce_kernel
-                    float* pr = partial + (int64_t)blockIdx.x * 2 * D;
+                    float* pr = partial + (int64_t)blockIdx.x * (gp_hi ? 3 : 2) * D;
                     *reinterpret_cast<float4*>(pr + c) = tg;
                     *reinterpret_cast<float4*>(pr + D + c) = tb;
+                    if (gp_hi) {
+                        float4 tm = am[i];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) {
+                            const float4 a = *reinterpret_cast<float4*>(sm + w * NV * 256 + lane * 4 + 256 * i);
+                            tm.x += a.x; tm.y += a.y; tm.z += a.z; tm.w += a.w;
+                        }
+                        *reinterpret_cast<float4*>(pr + 2 * D + c) = tm;
+                    }
                     continue;
                 }
                 atomicAdd(dgamma + c + 0, tg.x); atomicAdd(dgamma + c + 1, tg.y);
@@ -271,9 +299,11 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
                                  partial_ws, rows, D, stream);
 }
 
+struct LnGradPlane { uint16_t* hi; int64_t ld; float drop_p; const uint64_t* rng; uint32_t site; };
 static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
-                       int D, void* stream, bool leave_partials, const float* dx_add2 = nullptr, int64_t ldadd2 = 0);
+                       int D, void* stream, bool leave_partials, const float* dx_add2 = nullptr, int64_t ldadd2 = 0,
+                       const LnGradPlane* gp = nullptr);
 
 extern "C" int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                      const float* mean, const float* rstd, float* dx, int64_t lddx, const float* dx_add,
@@ -296,15 +326,29 @@ extern "C" int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const f
     return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2);
 }
 
+// bmt_layernorm_bwd_partial2 that ALSO emits the bf16 operand plane of dropout_site(dx) and its column partials (ABI 5): partial_ws is
+// [blocks][3 D] then -- dgamma | dbeta | column sums of the masked dx.  gp_hi [rows][gp_ld] (gp_ld >= D, D a multiple of 64: no pad columns).
+extern "C" int bmt_layernorm_bwd_emit(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2,
+                                      int64_t ldadd2, float* partial_ws, uint16_t* gp_hi, int64_t gp_ld, float drop_p, const uint64_t* rng,
+                                      uint32_t site, int rows, int D, void* stream) {
+    BMT_CHECK_ARG(partial_ws && gp_hi && gp_ld >= D && D % 64 == 0 && gp_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(gp_hi) & 7) == 0,
+                  "bmt_layernorm_bwd_emit: needs the partial workspace and an 8-byte aligned plane with D a multiple of 64");
+    BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_layernorm_bwd_emit: bad dropout arguments");
+    const LnGradPlane gp{gp_hi, gp_ld, drop_p, rng, site};
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2,
+                       &gp);
+}
+
 static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
-                       int D, void* stream, bool leave_partials, const float* dx_add2, int64_t ldadd2) {
+                       int D, void* stream, bool leave_partials, const float* dx_add2, int64_t ldadd2, const LnGradPlane* gp) {
     BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
     if (rows == 0) return leave_partials ? 1 : BMT_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && al16(x) && al16(dy) && al16(dx) &&
                      al16(gamma) && D <= 2048 && (!dx_add || (al16(dx_add) && ldadd % 4 == 0)) && (!dx_add2 || (al16(dx_add2) && ldadd2 % 4 == 0));
-    if (!vec && (leave_partials || dx_add2)) return 1;       // (the scalar kernel adds into dgamma / dbeta directly and knows one addend: the caller falls back)
+    if (!vec && (leave_partials || dx_add2 || gp)) return 1;       // (the scalar kernel adds into dgamma / dbeta directly and knows one addend: the caller falls back)
     if (!vec) {
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx,
                            lddx, dx_add, ldadd, dgamma, dbeta, rows, D);
@@ -314,8 +358,9 @@ static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ld
     dim3 grid(bmt_layernorm_bwd_blocks(rows)), block(256);
     const int nv = bmt_cdiv(D, 256);
 #define BMT_LN(NV)                                                                                                         \
-    hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 2 * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
-                       dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D, dx_add2, ldadd2)
+    hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, (gp ? 3 : 2) * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
+                       dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D, dx_add2, ldadd2,           \
+                       gp ? gp->hi : nullptr, gp ? gp->ld : 0, gp ? gp->drop_p : 0.f, gp ? gp->rng : nullptr, gp ? gp->site : 0u)
     if (nv <= 1) BMT_LN(1);
     else if (nv <= 2) BMT_LN(2);
     else if (nv <= 4) BMT_LN(4);

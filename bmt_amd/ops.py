@@ -1070,6 +1070,36 @@ def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=Non
     return P, gb is not None
 
 
+LN_EMIT_GRAD_PLANE = _os.environ.get("BMT_LN_EMIT", "1") != "0"      # A/B switch: "0" = every upstream gradient goes through its own conversion pass again
+
+
+def request_grad_plane(out: torch.Tensor, p: float, site: int):
+    """forward side: ``out = x + dropout_site(sublayer(LN x))`` was written by a sublayer's last GEMM.  Whoever differentiates ``out``'s FIRST
+    use -- the next ResidualConnection's LayerNorm -- may hand back, next to d out, the bf16 operand plane of dropout_site(d out) and its
+    column partials: exactly what this sublayer's backward would otherwise build in a pass of its own (ResidualNormFn.backward,
+    bmt_layernorm_bwd_emit).  A note on the tensor; nobody is obliged to honour it."""
+    if LN_EMIT_GRAD_PLANE and isinstance(out, torch.Tensor) and out.is_cuda and out.shape[-1] % 64 == 0:
+        out._bmt_gp_req = (float(p), int(site))
+
+
+def grad_planes_from(dout: torch.Tensor, dy2: torch.Tensor, bias: Optional[torch.Tensor], drop):
+    """grad_planes(dy2, bias, drop) -- or, when ``dout`` arrives with the plane its producer already built for exactly this dropout site
+    (ResidualNormFn.backward), that plane and the queued reduction of its column partials into the bias gradient"""
+    gp = getattr(dout, "_bmt_gplane", None)
+    if gp is not None:
+        pl, p, site, ws, nblk = gp
+        want = (p, site) if p > 0.0 else None
+        D = dy2.shape[1]
+        gb = static_grad(bias)
+        if (drop == want or (drop is not None and want is not None and tuple(drop) == want)) and pl.rows == dy2.shape[0] and pl.cols == D \
+                and (bias is None or gb is not None) and getattr(dout, "_bmt_gplane_version", -1) == dout._version:
+            if bias is not None:
+                colsum_deferred([(ws, 2 * D, gb, nblk, 3 * D, D)], params=(bias,))
+                grad_done(bias)
+            return pl, True
+    return grad_planes(dy2, bias, drop=drop)
+
+
 def bwd_planes(x) -> Planes:
     """operand of x for the dW product (its bf16 hi plane, k-major): x fp32 tensor or Planes"""
     if isinstance(x, Planes):
@@ -1439,6 +1469,7 @@ class ResidualNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
         ctx.kv_alias = bool(kv_alias)
+        ctx.gp_req = getattr(x, "_bmt_gp_req", None) if D % 64 == 0 else None      # (request_grad_plane: the producer of x wants dropout(dx) as a plane)
         context().last_ln = pl
         if kv_alias:
             return xc.view_as(xc), y.view(xc.shape), xc.view_as(xc)
@@ -1468,23 +1499,38 @@ class ResidualNormFn(torch.autograd.Function):
         dg = sg if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         nblk = max(1, lib.bmt_layernorm_bwd_blocks(rows))
-        ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
-        if add2 is not None:
-            rc = lib.bmt_layernorm_bwd_partial2(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), rows, D, _st())
-            if rc == 1:            # (shapes the vector kernel does not take: one addend by the kernel, the other by a separate add)
-                tmp = torch.empty_like(add)
-                _lib.check(lib.bmt_add(_p(add), _p(add2), _p(tmp), add.numel(), _st()), "bmt_add")
-                add, add2 = tmp, None
-        if add2 is None:
-            rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, _st())
+        req = ctx.gp_req if LN_EMIT_GRAD_PLANE else None
+        gplane, wld, rc = None, 2 * D, -1
+        if req is not None:      # dx AND the operand plane of dropout_site(dx) for the sublayer that produced x (+ its column partials)
+            ws = torch.empty(nblk * 3 * D, device=x2.device, dtype=torch.float32)
+            gph = torch.empty(rows, D, device=x2.device, dtype=torch.bfloat16)
+            use_drop = req[0] > 0.0
+            rc = lib.bmt_layernorm_bwd_emit(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), _p(gph), D,
+                                            req[0] if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, req[1], rows, D, _st())
+            if rc == 0:
+                gplane, wld = (Planes(gph, None, rows, D), req[0], req[1], ws, nblk), 3 * D
+            elif rc != 1:
+                _lib.check(rc, "bmt_layernorm_bwd_emit")
+        if rc != 0:
+            ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
+            if add2 is not None:
+                rc = lib.bmt_layernorm_bwd_partial2(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), rows, D, _st())
+                if rc == 1:            # (shapes the vector kernel does not take: one addend by the kernel, the other by a separate add)
+                    tmp = torch.empty_like(add)
+                    _lib.check(lib.bmt_add(_p(add), _p(add2), _p(tmp), add.numel(), _st()), "bmt_add")
+                    add, add2 = tmp, None
+            if add2 is None:
+                rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, _st())
         if rc == 0:        # dgamma / dbeta partials of the kernel's workgroups are in ws: their sums join the pass's other small reductions
-            colsum_deferred([(ws, 0, dg, nblk, 2 * D, D), (ws, D, db, nblk, 2 * D, D)], params=(gamma, beta) if fused else ())
+            colsum_deferred([(ws, 0, dg, nblk, wld, D), (ws, D, db, nblk, wld, D)], params=(gamma, beta) if fused else ())
         else:
             if rc != 1:
                 _lib.check(rc, "bmt_layernorm_bwd_partial")
             _lib.check(lib.bmt_layernorm_bwd_add(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(dg), _p(db),
                                                  _p(ws), rows, D, _st()), "bmt_layernorm_bwd_add")
         dx = dx.view(g_n.shape)
+        if gplane is not None:
+            dx._bmt_gplane, dx._bmt_gplane_version = gplane, dx._version
         if fused:
             grad_done(gamma)
             grad_done(beta)
@@ -1686,6 +1732,8 @@ class FFNFn(torch.autograd.Function):
         y = y.view(*xc.shape[:-1], W2.shape[0])
         if opl is not None:
             attach_planes(y, opl)
+        if res is not None:
+            request_grad_plane(y, res_p, res_site)
         return y
 
     @staticmethod
@@ -1701,7 +1749,7 @@ class FFNFn(torch.autograd.Function):
             dy2, drop = drop_grad(dy2, b2p, res_p, res_site)
         # dH never exists in fp32: the fc2 dX GEMM writes its bf16 plane (relu / dropout derivative applied to whole row
         # segments from the saved hidden plane) and its column sums -- fc1's bias gradient -- from the same epilogue
-        P2, b2_done = grad_planes(dy2, b2p, drop=drop)
+        P2, b2_done = grad_planes_from(dy, dy2, b2p, drop) if has_res else grad_planes(dy2, b2p, drop=drop)
         M_, Dff = h.rows, h.cols
         gb1 = static_grad(b1p)
         cs = gb1 if gb1 is not None else torch.zeros(Dff, device=dy2.device, dtype=torch.float32)
@@ -1893,6 +1941,8 @@ class MHAFn(torch.autograd.Function):
         out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, Sq, Dq)
         if opl is not None:
             attach_planes(out, opl)
+        if res is not None:
+            request_grad_plane(out, res_p, res_site)
         ctx.H, ctx.p, ctx.site = H, p, site
         ctx.res = (res is not None, res_p, res_site)
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
@@ -1930,7 +1980,7 @@ class MHAFn(torch.autograd.Function):
             dy2, drop = drop_grad(dy2, bop, res_p, res_site)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
         if D % 64 == 0:                  # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
-            P_, bias_done = grad_planes(dy2, bop, drop=drop)
+            P_, bias_done = grad_planes_from(dout, dy2, bop, drop) if has_res else grad_planes(dy2, bop, drop=drop)
             do = linear_dx(P_, Wop, out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
                            drop_post=True, drop_p=ctx.p, site=ctx.site)
             dWo, dbo = wgrad(Wop, None if bias_done else bop, P_, o, dy2_for_bias=dy2)

@@ -330,6 +330,14 @@ int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int
 int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                                float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2, int64_t ldadd2,
                                float* partial_ws, int rows, int D, void* stream);
+/* ... and with the NEXT consumer's operand conversion folded in (ABI 5): besides dx the kernel writes gp_hi [rows][gp_ld] = bf16 of
+ * dropout(dx) under the mask of (drop_p, rng, site) over the contiguous [rows][D] index space -- the upstream-gradient operand of the
+ * previous sublayer's last GEMM backward (x_out = x + dropout(sublayer(LN x))) -- and leaves that plane's column partials (the GEMM's bias
+ * gradient) as a THIRD block of partial_ws, which is [blocks][3 D] here: dgamma | dbeta | column sums.  D a multiple of 64.  Returns 1
+ * where the vector kernel does not apply. */
+int bmt_layernorm_bwd_emit(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2, int64_t ldadd2, float* partial_ws,
+                           uint16_t* gp_hi, int64_t gp_ld, float drop_p, const uint64_t* rng, uint32_t site, int rows, int D, void* stream);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                       float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream);
