@@ -17,3 +17,8 @@ python tools/bench_summary.py gpurun_out/${TAG}_bench_train_prop.json | head -10
 bash tools/gpu_prof.sh $TAG 6 2>&1 | head -40
 bash tools/gpu_timeline.sh $TAG 2>&1 | tail -4
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+# the rows either side of the path and the deep configuration, with the same tree (numbers for DESIGN.md section 6)
+timeout 200 python tools/deep_config_step.py 2>&1 | grep -v amdgpu | tail -1 | tee gpurun_out/${TAG}_deep_config_step.txt
+timeout 120 python tools/decode_bench.py > gpurun_out/${TAG}_decode_bench.json 2>/dev/null; tail -c 600 gpurun_out/${TAG}_decode_bench.json; echo
+timeout 120 python tools/postprocess_bench.py > gpurun_out/${TAG}_postprocess_bench.json 2>/dev/null; tail -c 400 gpurun_out/${TAG}_postprocess_bench.json; echo
+timeout 120 python tools/ingest_bench.py > gpurun_out/${TAG}_ingest_bench.json 2>/dev/null; tail -c 400 gpurun_out/${TAG}_ingest_bench.json; echo

@@ -42,6 +42,14 @@ for s, e, wg, n in ev:
         k = a // BIN; nxt = min(e, (k + 1) * BIN)
         act[k] += nxt - a; wgs[k] += (nxt - a) * min(wg, 512); names[k][n] += nxt - a; a = nxt
 print(f"# GPU busy (>= 1 kernel) {union / 1e6:.3f} ms of {span / 1e3:.3f}")
+# every kernel of the replay by name: what a captured step consists of (no framework kernel is among them)
+cnt = collections.Counter(); dur = collections.Counter()
+for s_, e_, _, n_ in ev:
+    cnt[n_] += 1; dur[n_] += e_ - s_
+fw = sum(c for n_, c in cnt.items() if n_.startswith(("at::", "void at::", "__amd_rocclr")))
+print(f"# kernels of the replay: {len(cnt)} distinct names, {fw} launches of framework / runtime kernels (at::*, __amd_rocclr_*)")
+for n_, c in sorted(cnt.items(), key=lambda kv: -dur[kv[0]]):
+    print(f"#   {c:4d} x {n_:42s} {dur[n_] / 1e3:9.1f} us")
 print("t_ms  busy  kernels_in_flight  workgroups_in_flight(capped 512/kernel)  top kernels")
 for k in range(nb):
     top = ", ".join(f"{n}:{v / BIN:.2f}" for n, v in names[k].most_common(3))
