@@ -19,7 +19,7 @@ for r in last:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     g = lambda k: int(r.get(k, 1) or 1)
     wg = (g("Grid_Size_X") * g("Grid_Size_Y") * g("Grid_Size_Z")) // max(1, g("Workgroup_Size_X") * g("Workgroup_Size_Y") * g("Workgroup_Size_Z"))
-    ev.append((s, e, wg, r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0][:40]))
+    ev.append((s, e, wg, r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0][:40]))
 span = (t1 - t0) / 1e3
 print(f"# last replay: {len(ev)} dispatches, span {span / 1e3:.3f} ms, sum of kernel durations {sum(e - s for s, e, _, _ in ev) / 1e6:.3f} ms")
 BIN = 100_000
@@ -47,7 +47,8 @@ cnt = collections.Counter(); dur = collections.Counter()
 for s_, e_, _, n_ in ev:
     cnt[n_] += 1; dur[n_] += e_ - s_
 fw = sum(c for n_, c in cnt.items() if n_.startswith(("at::", "void at::", "__amd_rocclr")))
-print(f"# kernels of the replay: {len(cnt)} distinct names, {fw} launches of framework / runtime kernels (at::*, __amd_rocclr_*)")
+print(f"# kernels from the replay's first launch to the end of the trace: {len(cnt)} distinct names, {fw} launches of framework / runtime kernels "
+      f"(at::*, __amd_rocclr_*; the bench reads the loss back after the last replay: 2 copies that are not graph nodes)")
 for n_, c in sorted(cnt.items(), key=lambda kv: -dur[kv[0]]):
     print(f"#   {c:4d} x {n_:42s} {dur[n_] / 1e3:9.1f} us")
 print("t_ms  busy  kernels_in_flight  workgroups_in_flight(capped 512/kernel)  top kernels")
