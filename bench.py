@@ -624,7 +624,8 @@ def build_cap(args, dev, rank, world):
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}      # inputs resident in HBM before timing
     caps = batch["captions"].to(dev)
     units_local = int((caps[:, 1:] != syn.PAD_IDX).sum())
-    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000, collective=args.dp_collective)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000, collective=args.dp_collective,
+                               microbatches=args.microbatches)
     desc = {"metric": "caption tokens/sec/node (train_cap B=32/GPU, d=1024)", "unit": "caption tokens/s",
             "workload": "configs[1]: train_cap, N=2 d_model=1024 H=4 d_aud=128 d_vid=1024 d_caps=300 T_v=256 T_a=800 T_c=30 V=10000, "
                         "dropout 0.1, Adam, GloVe frozen",
@@ -671,6 +672,9 @@ def main():
     ap.add_argument("--procedure", default="train_cap", choices=["train_cap", "train_prop"],
                     help="train_cap = BASELINE.json's metric (configs[1]); train_prop = configs[3]")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); default 32 (train_cap) / 16 (train_prop)")
+    ap.add_argument("--microbatches", type=int, default=int(os.environ.get("BMT_MICROBATCHES", "1")),
+                    help="train_cap: parts of the per-GPU batch that are differentiated side by side on compute streams of their own "
+                         "(bmt_amd.train.CaptioningTrainStep(microbatches=...)); 1 = one pass over the whole batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-steps", type=int, default=7, help="eagerly issued steps of the per-kernel HIP-event pass (>= 5)")
@@ -864,7 +868,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "launch_mode": mode,
             "dtype": ops.precision_description(), "data": "synthetic",
             "config": {"workload": desc["workload"], "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "trainable_params": desc["n_params"], desc["units_name"]: units_all, "final_loss": final_loss},
+                       "trainable_params": desc["n_params"], desc["units_name"]: units_all, "final_loss": final_loss,
+                       "parts_in_flight": (step._parts_in_flight(inputs[1]) if hasattr(step, "_parts_in_flight") else 1)},
             "algorithmic_tflops": flops_step / (ms_per_step * 1e-3) / 1e12,
             "mfma_peak_frac": flops_step / (ms_per_step * 1e-3) / 1e12 / (MFMA_BF16_DENSE_PEAK_TFLOPS * world),
         }

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("BMT_LIB_PATH") or os.path.join(_HERE, "lib", "libbmt_
 PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16W2 = 1, 3, 4, 5
 EPI_BIAS, EPI_RELU, EPI_DROP_PRE, EPI_DROP_POST, EPI_RESIDUAL, EPI_GATE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
-vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+vp, i32, i64, f32, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 
 
 class GemmBf16Args(C.Structure):
@@ -137,6 +137,7 @@ SIGNATURES = {
     "bmt_dropout_add": (i32, [vp, vp, vp, i64, f32, vp, u32, vp]),
     "bmt_add": (i32, [vp, vp, vp, i64, vp]),
     "bmt_rng_advance": (i32, [vp, vp]),
+    "bmt_rng_derive": (i32, [vp, vp, u64, vp]),
     "bmt_copy3d": (i32, [vp, i64, i64, i64, vp, i32, i32, i32, i32, vp]),
     "bmt_log_softmax_fwd": (i32, [vp, i64, i32, i32, vp]),
     "bmt_log_softmax_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
@@ -183,8 +184,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 5:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 5")
+    if lib.bmt_version() != 6:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 6")
     _lib = lib
     return lib
 

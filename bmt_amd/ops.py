@@ -150,7 +150,8 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
+                 "rng", "enc_gate", "enc_done", "mark_enc")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
@@ -164,6 +165,11 @@ class StepContext:
         self.allow_streams = True    # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
         self.last_gen = None         # GenHandle of the GeneratorFn.forward that just ran (picked up by model.generators.Generator)
         self.gen_handles = []        # handles whose loss took the fused backward: flush_dw settles their parameters' use counts
+        # a batch stepped in parts that are in flight together (train.CaptioningTrainStep(microbatches=...)): every part runs under its own context
+        self.rng = None              # this part's {seed, step} pair (bmt_rng_derive); None = the device's
+        self.enc_gate = None         # event the part's encoder forward waits for (the previous part's encoder forward: staggering)
+        self.mark_enc = False        # record ...
+        self.enc_done = None         # ... the event "this part's encoder forward has been issued" here
 
 
 _contexts = {}
@@ -310,6 +316,10 @@ _site_counter = [0]
 
 def rng_tensor(device=None) -> torch.Tensor:
     """Per-device {seed, step} pair read by every dropout site (device memory => graph-replayable)."""
+    if device is None and _contexts:
+        r = context().rng
+        if r is not None:
+            return r
     dev = None if device is None else torch.device(device)
     if dev is None or dev.type != "cuda":
         # the dropout stream lives in GPU memory: a host device (a CPU-resident model on its way into a checkpoint) names the current GPU's
@@ -337,7 +347,23 @@ def rng_is_seeded(device=None) -> bool:
 
 
 def rng_advance():
+    """a new forward pass draws new masks.  (Not for a part of a batch: its stream is re-derived from the device's once per step.)"""
+    if _contexts and context().rng is not None:
+        return
     _lib.check(lib.bmt_rng_advance(_p(rng_tensor()), _st()), "bmt_rng_advance")
+
+
+def rng_derive(out: torch.Tensor, salt: int) -> torch.Tensor:
+    """out (int64[2], CUDA) = the device's dropout stream with the seed of part ``salt`` (bmt_rng_derive); issued on the current stream"""
+    base = rng_tensor(out.device)
+    _lib.check(lib.bmt_rng_derive(_p(base), _p(out), int(salt), _st()), "bmt_rng_derive")
+    return out
+
+
+def add_(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """out = a + b, fp32, in one library launch (bmt_add)"""
+    _lib.check(lib.bmt_add(_p(a), _p(b), _p(out), out.numel(), _st()), "bmt_add")
+    return out
 
 
 def new_site() -> int:
@@ -672,6 +698,12 @@ def weights_generation() -> int:
     that has freed plane buffers (or a descriptor table that names them) baked in and must be re-captured, not replayed.  Newly
     REGISTERED weights do not count: the table a graph was captured with is kept alive and stays valid for the weights it names."""
     return _weights.generation
+
+
+def weights_registry_signature():
+    """changes with EVERY change of the registry, registrations included (weights_generation does not count those): equal before and after a
+    step = the step found every operand plane, group and table it needed already built"""
+    return (_weights.generation, len(_weights.entries), len(_weights.groups), bool(_weights.dirty_table))
 
 
 def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:
@@ -1026,7 +1058,9 @@ def wgrad(W, b, dyP: Planes, xP: Planes, dy2_for_bias=None, bias_sum=None):
         if bias_sum is None:
             bias_sum = colsum(dy2_for_bias)
         if gb is not None:
-            gb.add_(bias_sum)
+            # (atomic accumulation behind the queue of this pass's small reductions: parts of a batch in flight on different streams add to
+            # the same buffer)
+            colsum_deferred([(bias_sum, 0, gb, 1, bias_sum.numel(), bias_sum.numel())], params=(b,))
             grad_done(b)
         else:
             db = bias_sum
@@ -2243,6 +2277,9 @@ class EmbedFn(torch.autograd.Function):
                                       site, _st()), "bmt_prep_embed")
         ctx.save_for_backward(idc)
         ctx.meta = (V, D, scale, p, site)
+        ctx.weight = W
+        if W.requires_grad:
+            note_use(W)
         return out
 
     @staticmethod
@@ -2252,10 +2289,17 @@ class EmbedFn(torch.autograd.Function):
         (idc,) = ctx.saved_tensors
         V, D, scale, p, site = ctx.meta
         B, S = idc.shape
-        dW = torch.zeros(V, D, device=dy.device, dtype=torch.float32)
+        gW = static_grad(ctx.weight)
+        if gW is not None and (gW.shape != (V, D) or gW.dtype != torch.float32):
+            gW = None
+        # (the kernel scatters with atomics: a static gradient buffer takes them directly -- no zero-filled temporary, no accumulation pass)
+        dW = gW if gW is not None else torch.zeros(V, D, device=dy.device, dtype=torch.float32)
         dyc = _f32c(dy)
         _lib.check(lib.bmt_prep_embed_bwd(_p(idc), _p(dyc), _p(dW), B, S, D, V, scale, p, _p(rng_tensor()) if p > 0 else None, site,
                                           _st()), "bmt_prep_embed_bwd")
+        if gW is not None:
+            grad_done(ctx.weight)
+            return None, None, None, None, None, None
         return None, dW, None, None, None, None
 
 

@@ -79,9 +79,14 @@ class CaptioningTrainStep:
     backward graph instead (no collective is ever captured)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None, collective: str = "allreduce"):
+                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None, collective: str = "allreduce",
+                 microbatches: int = 1):
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
         self._overlap = overlap
+        # microbatches = M > 1 (needs static gradient buffers): the batch is differentiated in M parts of consecutive samples that are IN FLIGHT
+        # TOGETHER, each on compute streams of its own (_forward_backward_parts) -- same loss, same gradient sums, one optimizer step
+        self.microbatches = max(1, int(microbatches))
+        self._part_streams, self._part_rng, self._parts_generation = [], [], None
         self._graph_generation = None
         _seed_dropout(seed, data_parallel, next(model.parameters()).device)
         params = [p for p in model.parameters() if p.requires_grad]
@@ -157,8 +162,122 @@ class CaptioningTrainStep:
             layer.register_forward_hook(attach)
 
     # ---- the three phases -------------------------------------------------------------------------------------
+    def _parts_in_flight(self, caption_idx) -> int:
+        """how many parts this step's batch is differentiated in (1 = the plain pass)"""
+        r = self.reducer
+        if self.microbatches <= 1 or r is None or not caption_idx.is_cuda:
+            return 1
+        if r.world > 1 and r.overlap:       # buckets reduced from inside the backward pass: completion in autograd order, on ONE stream
+            return 1
+        return min(self.microbatches, int(caption_idx.shape[0]))
+
+    def _forward_backward_parts(self, feature_stacks, caption_idx, M: int):
+        """The batch in M parts of consecutive samples, IN FLIGHT TOGETHER.  One pass over a batch has a phase that cannot fill the GPU
+        -- decoder, generator and loss, forward and backward: ~170 launches over B x 29 rows between the encoder's forward and its backward
+        (replay timeline) -- and nothing else of the same pass is independent of it.  Another part's encoder is: part i runs
+        on compute streams of its own (its own StepContext: scratch, queues, dropout stream), its encoder forward is ordered behind part
+        i-1's (events), and from there on the GPU has a decoder phase and an encoder phase to run side by side.  Every per-row
+        computation is what the plain pass does; gradients are sums over rows, accumulated into the same static buffers (atomics), and
+        the weight-gradient products / small reductions of all parts leave as ONE grouped launch at the end.  Dropout: part i draws from
+        the device's stream re-seeded for i (bmt_rng_derive), element indices count from the part's first row."""
+        from . import ops as _ops
+        model = self.model
+        model.train()
+        main = torch.cuda.current_stream()
+        dev = caption_idx.device
+        self.reducer.zero_grad()
+        x, y, n_tokens = _ops.caption_shift(caption_idx, self.pad_idx)
+        with _ops._weights.lock:            # the once-per-step refresh of the weights' operand planes: before any part forks
+            _ops._weights.ensure_fresh()
+        _ops.rng_advance()                  # one step of the device's dropout stream per optimizer step, whatever the number of parts
+        while len(self._part_streams) < M - 1:
+            self._part_streams.append(torch.cuda.Stream(device=dev))
+        while len(self._part_rng) < M:
+            self._part_rng.append(torch.zeros(2, dtype=torch.int64, device=dev))
+        for i in range(M):
+            _ops.rng_derive(self._part_rng[i], i)
+        B = int(caption_idx.shape[0])
+        cuts = [(B * i) // M for i in range(M + 1)]
+        # one compute stream only (ops.ENC_STREAMS = 1: the kernel timer's and the profilers' eager steps): the same parts, the same
+        # launches, one after the other on the current stream
+        # ... and so is the FIRST step of a model (or the first after its operand-plane registry changed): a weight's planes, a positional table,
+        # a pointer table are built by whoever meets them first, on ITS stream -- a second part must not find them half built
+        serial = _ops.ENC_STREAMS < 2 or self._parts_generation != _ops.weights_registry_signature()
+        streams = [main] * M if serial else [main] + self._part_streams[:M - 1]
+        self._parts_last = (M, "one after the other" if serial else "in flight together")
+        start = main.record_event()
+        ctxs, kls = [], []
+
+        def forward(i, st, prev_done):
+            lo, hi = cuts[i], cuts[i + 1]
+            if st is not main:
+                st.wait_event(start)
+            ctx = _ops.context()
+            if not any(ctx is c for c in ctxs):
+                ctxs.append(ctx)
+            ctx.rng, ctx.enc_gate, ctx.mark_enc, ctx.enc_done = self._part_rng[i], prev_done, (not serial) and i + 1 < M, None
+            ctx.defer_dw = True
+            _ops.allow_encoder_streams(True)
+            fs = {k: v[lo:hi] for k, v in feature_stacks.items()}
+            xi, yi = x[lo:hi], y[lo:hi]
+            if st is not main:
+                for t in list(fs.values()) + [xi, yi]:
+                    t.record_stream(st)
+            masks = make_masks(fs, xi, self.modality, self.pad_idx)
+            pred = model(fs, xi, masks)
+            kls.append(self.criterion(pred, yi))
+            return ctx.enc_done
+
+        def backward(kl):
+            kl.backward(gradient=self._one if kl.dim() == 0 else None)
+            _ops.join_side_stream()
+
+        try:
+            if serial:
+                for i in range(M):
+                    forward(i, main, None)
+                    backward(kls[-1])
+            else:
+                prev_done = None
+                for i, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        prev_done = forward(i, st, prev_done)
+                for st, kl in zip(streams, kls):
+                    with torch.cuda.stream(st):
+                        backward(kl)
+            c0 = ctxs[0]
+            for st, ctx in zip(streams[1:], ctxs[1:]):      # (serial: one context, nothing to merge)
+                main.wait_stream(st)
+                c0.pending_dw.extend(ctx.pending_dw)
+                c0.pending_cs.extend(ctx.pending_cs)
+                c0.pending_done.extend(ctx.pending_done)
+                c0.pending_ids.update(ctx.pending_ids)
+                c0.gen_handles.extend(ctx.gen_handles)
+            _ops.flush_dw()
+            kl = kls[0].detach()
+            for k in kls[1:]:
+                kd = k.detach()
+                if not serial:
+                    kd.record_stream(main)
+                kl = _ops.add_(torch.empty_like(kl), kl, kd)
+        finally:
+            for ctx in ctxs:
+                ctx.defer_dw = False
+                ctx.pending_dw.clear()
+                ctx.pending_cs.clear()
+                ctx.pending_done.clear()
+                ctx.pending_ids.clear()
+                ctx.gen_handles.clear()
+                ctx.rng = ctx.enc_gate = ctx.enc_done = None
+                ctx.mark_enc = False
+        self._parts_generation = _ops.weights_registry_signature()
+        return kl, n_tokens
+
     def _forward_backward(self, feature_stacks, caption_idx):
         """zero_grad -> masks -> forward -> sum-KL -> backward.  Returns (sum-KL, local non-pad token count)."""
+        M = self._parts_in_flight(caption_idx)
+        if M > 1:
+            return self._forward_backward_parts(feature_stacks, caption_idx, M)
         model = self.model
         model.train()
         if self.reducer is not None:
@@ -233,6 +352,8 @@ class CaptioningTrainStep:
         (seed/step live in device memory, the step counter is advanced by a captured kernel), as do Adam's bias corrections."""
         if self.reducer is None:
             raise RuntimeError("capture() needs static gradient buffers: construct with static_grads=True")
+        if self.microbatches > 1:
+            warmup = max(warmup, 2)             # the first step of a model runs its parts one after the other (_forward_backward_parts)
         if collectives:
             return self._capture_with_collectives(feature_stacks, caption_idx, warmup)
         self.reducer.overlap = False            # collectives stay outside the captured region

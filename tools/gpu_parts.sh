@@ -1,0 +1,23 @@
+#!/bin/bash
+# the batch in parts (CaptioningTrainStep(microbatches=M)): parity tests, then the captured step at M = 1, 2, 3 on ONE box (twice, interleaved),
+# the half batch alone, and the replay timeline at M = 2.     usage: tools/gpu_parts.sh <tag>
+TAG=${1:-parts}
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parts.py tests/test_abi.py -x -q -m gpu -s > gpurun_out/${TAG}_parts_tests.log 2>&1; echo "tests rc=$?"
+tail -15 gpurun_out/${TAG}_parts_tests.log
+run() { env $1 timeout 400 python bench.py --no-cpu-baseline --no-kernel-timer --no-clock-probe --steps 20 --warmup 5 $2 2>gpurun_out/${TAG}_err.log | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); print('$1 $2'.ljust(50), f\"{d['ms_per_step']:.3f} ms/step  {d['value']:.0f} tok/s  loss {d['config']['final_loss']:.4f} parts {d['config'].get('parts_in_flight')}\")
+except Exception as e: print('$1 $2 FAILED', e)
+"; }
+for round in 1 2; do
+  run "BMT_MICROBATCHES=1" ""
+  run "BMT_MICROBATCHES=2" ""
+  run "BMT_MICROBATCHES=3" ""
+done 2>&1 | tee gpurun_out/${TAG}_ab_parts.txt
+run "BMT_MICROBATCHES=1" "--batch 16" | tee -a gpurun_out/${TAG}_ab_parts.txt
+run "BMT_MICROBATCHES=4" "" | tee -a gpurun_out/${TAG}_ab_parts.txt
+tail -5 gpurun_out/${TAG}_err.log
+BMT_MICROBATCHES=2 bash tools/gpu_timeline.sh ${TAG}_m2
+head -40 gpurun_out/${TAG}_m2_timeline.txt | cut -c1-150
