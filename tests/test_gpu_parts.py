@@ -81,9 +81,22 @@ def test_a_batch_in_parts_is_the_same_pass(M, B):
     kl1, n1, g1 = _grads_after_pass(1, cfg, V, fs, caps)
     klM, nM, gM = _grads_after_pass(M, cfg, V, fs, caps)
     assert n1 == nM
-    assert abs(kl1 - klM) <= 2e-5 * abs(kl1), (kl1, klM)
-    worst = _compare(g1, gM, 2e-4)
-    print(f"\nM={M} B={B}: sum-KL {kl1:.6f} / {klM:.6f}, worst gradient tensor differs by {worst:.2e} of its norm")
+    # (a) against the plain passes over the parts' own samples, added up: the same launches on the same shapes -- fp32 summation order only
+    cuts = [(B * i) // M for i in range(M + 1)]
+    kls, gs = 0.0, None
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        k, _, g = _grads_after_pass(1, cfg, V, {n_: v[lo:hi].contiguous() for n_, v in fs.items()}, caps[lo:hi].contiguous())
+        kls += k
+        gs = g if gs is None else {n_: gs[n_] + g[n_] for n_ in gs}
+    assert abs(kls - klM) <= 2e-5 * abs(kls), (kls, klM)
+    worst_sum = _compare(gs, gM, 2e-4)
+    # (b) against the plain pass over the whole batch: kernels are chosen by shape (tile forms, the attention kernels' grid-dependent variants), so
+    # operand roundings differ from a B-row launch to a B/M-row launch -- the difference is rounding noise of the 16-bit operands, far below the
+    # backward's own error against fp32 (tests/test_gpu_model.py::_check_grads: 0.8 % overall, 4.5 % per tensor)
+    assert abs(kl1 - klM) <= 1e-3 * abs(kl1), (kl1, klM)
+    worst = _compare(g1, gM, 2e-2)
+    print(f"\nM={M} B={B}: sum-KL {kl1:.6f} / {klM:.6f}; worst gradient tensor: {worst_sum:.2e} of its norm against the parts' plain passes added up, "
+          f"{worst:.2e} against the plain pass over the batch")
 
 
 def test_parts_with_a_trainable_embedding():
