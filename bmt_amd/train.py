@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from .loss.label_smoothing import LabelSmoothing
@@ -68,6 +70,13 @@ def make_masks(feature_stacks: Dict[str, torch.Tensor], captions: Optional[torch
     else:
         raise ValueError(f'unknown modality {modality}')
     return masks
+
+
+# A/B switches of the batch-in-parts step (CaptioningTrainStep(microbatches=M)): part i's encoder forward ordered behind part i-1's; every part's
+# two-stream encoder (0 = a part is ONE stream)
+_PARTS_STAGGER = os.environ.get("BMT_PARTS_STAGGER", "1") != "0"
+_PARTS_SIDE_STREAMS = os.environ.get("BMT_PARTS_SIDE", "1") != "0"
+_PARTS_NO_RECORD = os.environ.get("BMT_PARTS_NO_RECORD") == "1"        # (bisecting a capture problem only)
 
 
 class CaptioningTrainStep:
@@ -215,12 +224,13 @@ class CaptioningTrainStep:
             ctx = _ops.context()
             if not any(ctx is c for c in ctxs):
                 ctxs.append(ctx)
-            ctx.rng, ctx.enc_gate, ctx.mark_enc, ctx.enc_done = self._part_rng[i], prev_done, (not serial) and i + 1 < M, None
+            stagger = (not serial) and _PARTS_STAGGER
+            ctx.rng, ctx.enc_gate, ctx.mark_enc, ctx.enc_done = self._part_rng[i], prev_done if stagger else None, stagger and i + 1 < M, None
             ctx.defer_dw = True
-            _ops.allow_encoder_streams(True)
+            _ops.allow_encoder_streams(_PARTS_SIDE_STREAMS)
             fs = {k: v[lo:hi] for k, v in feature_stacks.items()}
             xi, yi = x[lo:hi], y[lo:hi]
-            if st is not main:
+            if st is not main and not _PARTS_NO_RECORD:
                 for t in list(fs.values()) + [xi, yi]:
                     t.record_stream(st)
             masks = make_masks(fs, xi, self.modality, self.pad_idx)
@@ -257,7 +267,7 @@ class CaptioningTrainStep:
             kl = kls[0].detach()
             for k in kls[1:]:
                 kd = k.detach()
-                if not serial:
+                if not serial and not _PARTS_NO_RECORD:
                     kd.record_stream(main)
                 kl = _ops.add_(torch.empty_like(kl), kl, kd)
         finally:

@@ -9,7 +9,7 @@ from bmt_amd.train import CaptioningTrainStep
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1
-V, Tv, Ta, Tc = 10000, 256, 800, 30
+V, Tv, Ta, Tc = (500, 48, 150, 12) if (len(sys.argv) > 4 and sys.argv[4] == "tiny") else (10000, 256, 800, 30)
 dev = torch.device("cuda:0")
 cfg = syn.cfg_config1(dout_p=p)
 cfg.device = str(dev)
@@ -27,7 +27,7 @@ def say(*a):
 
 
 say(f"M={M} B={B} dropout={p}")
-for i in range(3):
+for i in range(0 if os.environ.get("PARTS_DEBUG_NO_EAGER") else 3):
     loss, n = step(fs, caps)
     torch.cuda.synchronize()
     say(f"eager step {i}: loss {float(loss):.4f} n {int(n)} mode {getattr(step, '_parts_last', None)}")
