@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     *reinterpret_cast<uint2*>(gp_hi + (int64_t)row * gp_ld + c) = make_uint2(pack_bf2(m.x, m.y), pack_bf2(m.z, m.w));
                     am[i].x += m.x; am[i].y += m.y; am[i].z += m.z; am[i].w += m.w;
                 }
+            } else if (gp_hi && c < ((D + 63) & ~63)) {      // the plane's reduction padding (D = 300 -> columns 300 .. 319): zeros
+                *reinterpret_cast<uint2*>(gp_hi + (int64_t)row * gp_ld + c) = make_uint2(0u, 0u);
             }
         }
     }
@@ -327,13 +329,13 @@ extern "C" int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const f
 }
 
 // bmt_layernorm_bwd_partial2 that ALSO emits the bf16 operand plane of dropout_site(dx) and its column partials (ABI 5): partial_ws is
-// [blocks][3 D] then -- dgamma | dbeta | column sums of the masked dx.  gp_hi [rows][gp_ld] (gp_ld >= D, D a multiple of 64: no pad columns).
+// [blocks][3 D] then -- dgamma | dbeta | column sums of the masked dx.  gp_hi [rows][gp_ld] (gp_ld >= round_up(D, 64); columns D .. round_up(D, 64) - 1 are written as zeros: the consuming GEMM's reduction padding).
 extern "C" int bmt_layernorm_bwd_emit(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
                                       const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2,
                                       int64_t ldadd2, float* partial_ws, uint16_t* gp_hi, int64_t gp_ld, float drop_p, const uint64_t* rng,
                                       uint32_t site, int rows, int D, void* stream) {
-    BMT_CHECK_ARG(partial_ws && gp_hi && gp_ld >= D && D % 64 == 0 && gp_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(gp_hi) & 7) == 0,
-                  "bmt_layernorm_bwd_emit: needs the partial workspace and an 8-byte aligned plane with D a multiple of 64");
+    BMT_CHECK_ARG(partial_ws && gp_hi && gp_ld >= ((D + 63) & ~63) && D % 4 == 0 && gp_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(gp_hi) & 7) == 0,
+                  "bmt_layernorm_bwd_emit: needs the partial workspace and an 8-byte aligned plane of at least round_up(D, 64) columns, D a multiple of 4");
     BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_layernorm_bwd_emit: bad dropout arguments");
     const LnGradPlane gp{gp_hi, gp_ld, drop_p, rng, site};
     return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2,

@@ -784,6 +784,23 @@ def splitk_workspace(device):
     return ws
 
 
+_SPLITK_CNT = {}
+SPLITK_COUNTERS = 4096
+
+
+def splitk_counters(device):
+    """per-tile arrival counters of the current stream's split-K launches (bmt_gemm_bf16_args.splitk_counters): zero between launches -- the
+    kernel that finds a counter at nsplit - 1 finishes the tile and puts it back -- so they are zeroed once, here (bmt_zero: under a graph
+    capture that is one more node at the stream's first split launch, not a framework fill)"""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
+    c = _SPLITK_CNT.get(key)
+    if c is None:
+        c = torch.empty(SPLITK_COUNTERS, device=device, dtype=torch.int32)
+        zero_(c)
+        _SPLITK_CNT[key] = c
+    return c
+
+
 AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
 DW_ATOMIC = _os.environ.get("BMT_DW_ATOMIC") == "1"     # A/B: weight gradients accumulate with fp32 atomics instead of workspace + epilogue
 
@@ -864,6 +881,8 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
     if splitk != 1 and two_pass:
         ws = splitk_workspace(ah.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
+        cnt = splitk_counters(ah.device)
+        a.splitk_counters, a.splitk_counters_n = _p(cnt), cnt.numel()
     _lib.check(lib.bmt_gemm_bf16(C.byref(a), _st()), "bmt_gemm_bf16")
 
 
@@ -1104,6 +1123,7 @@ def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=Non
     return P, gb is not None
 
 
+LN_EMIT_ANY_WIDTH = _os.environ.get("BMT_LN_EMIT_ANY", "1") != "0"      # A/B switch: "0" = only widths that are multiples of 64 (the encoder's; not the decoder's 300)
 LN_EMIT_GRAD_PLANE = _os.environ.get("BMT_LN_EMIT", "1") != "0"      # A/B switch: "0" = every upstream gradient goes through its own conversion pass again
 
 
@@ -1112,7 +1132,7 @@ def request_grad_plane(out: torch.Tensor, p: float, site: int):
     use -- the next ResidualConnection's LayerNorm -- may hand back, next to d out, the bf16 operand plane of dropout_site(d out) and its
     column partials: exactly what this sublayer's backward would otherwise build in a pass of its own (ResidualNormFn.backward,
     bmt_layernorm_bwd_emit).  A note on the tensor; nobody is obliged to honour it."""
-    if LN_EMIT_GRAD_PLANE and isinstance(out, torch.Tensor) and out.is_cuda and out.shape[-1] % 64 == 0:
+    if LN_EMIT_GRAD_PLANE and isinstance(out, torch.Tensor) and out.is_cuda and out.shape[-1] % (4 if LN_EMIT_ANY_WIDTH else 64) == 0:
         out._bmt_gp_req = (float(p), int(site))
 
 
@@ -1537,9 +1557,9 @@ class ResidualNormFn(torch.autograd.Function):
         gplane, wld, rc = None, 2 * D, -1
         if req is not None:      # dx AND the operand plane of dropout_site(dx) for the sublayer that produced x (+ its column partials)
             ws = torch.empty(nblk * 3 * D, device=x2.device, dtype=torch.float32)
-            gph = torch.empty(rows, D, device=x2.device, dtype=torch.bfloat16)
+            gph = torch.empty(rows, _pad64(D), device=x2.device, dtype=torch.bfloat16)      # (the kernel writes the pad columns too)
             use_drop = req[0] > 0.0
-            rc = lib.bmt_layernorm_bwd_emit(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), _p(gph), D,
+            rc = lib.bmt_layernorm_bwd_emit(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), _p(gph), _pad64(D),
                                             req[0] if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, req[1], rows, D, _st())
             if rc == 0:
                 gplane, wld = (Planes(gph, None, rows, D), req[0], req[1], ws, nblk), 3 * D

@@ -215,17 +215,10 @@ class CaptioningTrainStep:
         streams = [main] * M if serial else [main] + self._part_streams[:M - 1]
         self._parts_last = (M, "one after the other" if serial else "in flight together")
         start = main.record_event()
-        if not serial:
-            # every stream a part will use enters the pass HERE, behind an event of the stream the step was called on.  Under hipGraph capture
-            # that makes each of them a direct child of the capture's origin stream: a stream pulled into a capture by an event of a stream that
-            # was itself pulled in (a part's stream forking its own side stream) crashed hipStreamEndCapture (ROCm 7.2; tools/gpu_parts_bisect.sh)
-            for st in streams[1:]:
-                st.wait_event(start)
-                if _PARTS_SIDE_STREAMS:
-                    _ops.side_stream(0, st).wait_event(start)
-                    for (d, m, _), s2 in list(_ops._side_streams.items()):
-                        if d == st.device.index and m == st.cuda_stream:
-                            s2.wait_event(start)
+        # a part's own two-stream encoder: not under hipGraph capture -- a stream pulled into a capture by an event of a stream that was itself
+        # pulled in (a part's stream forking its side stream) crashes hipStreamEndCapture on ROCm 7.2, also when every stream is first made a direct
+        # child of the origin stream (tools/gpu_parts_bisect.sh, profiles/r04_i_parts_bisect.txt); a captured part is ONE stream
+        side_ok = _PARTS_SIDE_STREAMS and not torch.cuda.is_current_stream_capturing()
         ctxs, kls = [], []
 
         def forward(i, st, prev_done):
@@ -238,7 +231,7 @@ class CaptioningTrainStep:
             stagger = (not serial) and _PARTS_STAGGER
             ctx.rng, ctx.enc_gate, ctx.mark_enc, ctx.enc_done = self._part_rng[i], prev_done if stagger else None, stagger and i + 1 < M, None
             ctx.defer_dw = True
-            _ops.allow_encoder_streams(_PARTS_SIDE_STREAMS)
+            _ops.allow_encoder_streams(side_ok)
             fs = {k: v[lo:hi] for k, v in feature_stacks.items()}
             xi, yi = x[lo:hi], y[lo:hi]
             if st is not main and not _PARTS_NO_RECORD:
@@ -269,9 +262,6 @@ class CaptioningTrainStep:
             c0 = ctxs[0]
             for st, ctx in zip(streams[1:], ctxs[1:]):      # (serial: one context, nothing to merge)
                 main.wait_stream(st)
-                for (d, m, _), s2 in list(_ops._side_streams.items()):      # (joined into st already; once more, directly, for the capture's books)
-                    if d == st.device.index and m == st.cuda_stream:
-                        main.wait_stream(s2)
                 c0.pending_dw.extend(ctx.pending_dw)
                 c0.pending_cs.extend(ctx.pending_cs)
                 c0.pending_done.extend(ctx.pending_done)

@@ -111,6 +111,11 @@ typedef struct {
      * With C_hi == NULL the fp16 plane is the ONLY plane written (q / k / v under the fp16 attention policy, whose backward converts
      * them on load: bmt_attn_bwd_bf16_args.qkv_f16); excludes C_lo and colsum. */
     uint16_t* C_f16;
+    /* ABI 6, optional: splitk_counters_n ints, ZERO when first handed to the library and touched by nobody else (one array per stream, like
+     * the workspace).  With it a two-pass split-K launch of at most splitk_counters_n tiles is ONE kernel: every split stores its partial
+     * tile, bumps the tile's counter, and the workgroup that finds it at nsplit - 1 sums the partials in split order, runs the epilogue for
+     * the tile and puts the counter back to zero -- the same values as the second kernel (same order of additions), one launch less. */
+    int32_t* splitk_counters; int splitk_counters_n;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight
@@ -333,7 +338,7 @@ int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, in
 /* ... and with the NEXT consumer's operand conversion folded in (ABI 5): besides dx the kernel writes gp_hi [rows][gp_ld] = bf16 of
  * dropout(dx) under the mask of (drop_p, rng, site) over the contiguous [rows][D] index space -- the upstream-gradient operand of the
  * previous sublayer's last GEMM backward (x_out = x + dropout(sublayer(LN x))) -- and leaves that plane's column partials (the GEMM's bias
- * gradient) as a THIRD block of partial_ws, which is [blocks][3 D] here: dgamma | dbeta | column sums.  D a multiple of 64.  Returns 1
+ * gradient) as a THIRD block of partial_ws, which is [blocks][3 D] here: dgamma | dbeta | column sums.  D a multiple of 4 (ABI 6: any such width; gp_ld >= round_up(D, 64), the pad columns are written as zeros).  Returns 1
  * where the vector kernel does not apply. */
 int bmt_layernorm_bwd_emit(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                            float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2, int64_t ldadd2, float* partial_ws,

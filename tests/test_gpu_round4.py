@@ -349,11 +349,12 @@ def test_conv_weight_relayout(ops, N, C, k, cin):
     assert torch.equal(g, 1.0 + dWp.view(N, k, cin)[:, :, :C].permute(0, 2, 1))
 
 
-@pytest.mark.parametrize("rows,D,p", [(300, 128, 0.1), (4100, 1024, 0.1), (70, 1024, 0.0), (50, 300, 0.1)])
+@pytest.mark.parametrize("rows,D,p", [(300, 128, 0.1), (4100, 1024, 0.1), (70, 1024, 0.0), (50, 300, 0.1), (928, 300, 0.1), (33, 20, 0.0), (9, 260, 0.1)])
 def test_layernorm_backward_emits_the_next_consumers_gradient_plane(ops, rows, D, p):
     """ops.request_grad_plane: the producer of a ResidualConnection's input asks for dropout_site(d x) as an operand plane; the LayerNorm
     backward (bmt_layernorm_bwd_emit) writes it with dx and leaves its column partials -- bit-identical to the separate conversion pass over
-    dx (same mask: same (seed, step, site, element)), which it replaces.  D = 300 (no multiple of 64): the note is not taken."""
+    dx (same mask: same (seed, step, site, element)), which it replaces.  D = 300 / 20 (the decoder's width; no multiple of 64): the plane's
+    pad columns up to the next multiple of 64 come out as zeros."""
     ops.manual_seed(123)
     g = torch.Generator().manual_seed(rows)
     x = (torch.randn(rows, D, generator=g) * 2 + 0.3).to(DEV).requires_grad_()
@@ -369,15 +370,13 @@ def test_layernorm_backward_emits_the_next_consumers_gradient_plane(ops, rows, D
     torch.cuda.synchronize()
     dx = seen["g"]
     gp = getattr(dx, "_bmt_gplane", None)
-    if D % 64 != 0:
-        assert gp is None
-        return
     assert gp is not None, "the LayerNorm backward did not hand the plane back"
     pl, gp_p, gp_site, ws, nblk = gp
     assert (gp_p, gp_site) == (p, site)
     cs = torch.zeros(D, device=DEV)
     want = ops.make_planes(dx.view(rows, D), "bwd", colsum=cs, drop=(p, site) if p > 0 else None)
-    assert torch.equal(pl.hi, want.hi[:, :D])
+    assert pl.hi.shape == want.hi.shape and torch.equal(pl.hi, want.hi)          # (pad columns included: zeros in both)
+    assert pl.hi.shape[1] % 64 == 0 and not bool(pl.hi[:, D:].any())
     got_cs = ws.view(nblk, 3 * D)[:, 2 * D:].sum(0)
     assert_close(got_cs, cs, atol=2e-3, rtol=1e-4, name="column partials of the masked gradient")
     # and the consumer side: the plane is taken for the matching dropout site, not for another one
