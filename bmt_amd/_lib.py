@@ -25,8 +25,7 @@ class GemmBf16Args(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32),
-                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp),
-                ("splitk_counters", vp), ("splitk_counters_n", i32)]
+                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp)]
 
 
 class AttnFwdArgs(C.Structure):

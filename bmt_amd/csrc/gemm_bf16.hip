@@ -52,7 +52,6 @@ struct GemmB {
     uint32_t site;
     float* ws;                           // split-K partials [split][tiles_m*128][tiles_n*128] (two-pass mode), or nullptr
     int nsplit;
-    int* sk_cnt;                         // two-pass split-K in ONE kernel: per-tile arrival counters (zero between launches), or nullptr
     int nk_loader;                       // gemm_k128_kernel: 1 = seven computing waves + a loading wave, 0 = eight waves that load their own rows
     int nk_dbg;                          // experiments (env BMT_K128_DBG): 1 no stores, 2 no MFMAs, 4 no next-unit prefetch
     int nk_ncw, nk_rg, nk_upw;           // gemm_k128_kernel: weight rows per resident chunk, row groups, 32-row units per row group
@@ -195,8 +194,6 @@ __device__ __forceinline__ bf16x8 km_frag_sw(const char* img, int off, int k16) 
 // barriers".  Everything around the loop (tile order, split-K, epilogue) is shared with the register-staged loop.
 // TAG: a distinct specialization per calling kernel template.  hipcc 7.2 (host pass) rejects the call of one and the same k-major
 // PIPE specialization from a second kernel template with an unexplained "substitution failure"; the device code is identical.
-__device__ void splitk_finish_group(const GemmB& p, int row, int c0);      // (below, next to the second-pass kernel)
-
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false, int TAG = 0>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
@@ -469,30 +466,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     part[(int64_t)(m0 + wr * 32 * TI + i * 32 + acc_row(r, half)) * ldw + n0 + wc * 64 + j * 32 + l31] = acc[i][j][r];
-        if (p.sk_cnt == nullptr) return;
-        // ... or no second kernel: the split that arrives LAST at this tile's counter finishes the tile.  Release (the partial tile is
-        // visible device-wide: the splits of a tile run on different XCDs, each with an L2 of its own) -> count -> acquire -> the second
-        // pass over the tile's 128-column block, exactly as splitk_epilogue_kernel does it (sum in split order, same epilogue).
-        __threadfence();
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            const int tile_lin = tm * p.tiles_n + tn;
-            const int seen = atomicAdd(p.sk_cnt + tile_lin, 1);
-            const int last = seen == p.nsplit - 1;
-            if (last) p.sk_cnt[tile_lin] = 0;            // nobody else touches it before the next launch
-            *flag = last;
-        }
-        __syncthreads();
-        const int last = *flag;
-        __syncthreads();                                  // (the flag's word belongs to the next tile's stage buffers in the persistent kernels)
-        if (!last) return;
-        __threadfence();
-        constexpr int CG = BN / 4;
-        for (int g = tid; g < BM * CG; g += NT) {
-            const int row = m0 + g / CG, c0 = n0 + (g % CG) * 4;
-            if (row < p.M) splitk_finish_group(p, row, c0);
-        }
         return;
     }
     BMT_STAMP(1);
@@ -1355,13 +1328,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
     const int ncg = (pc + 3) / 4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)p.M * ncg) return;
-    splitk_finish_group(p, (int)(idx / ncg), (int)(idx % ncg) * 4);
-}
-
-// one output row's 4 consecutive columns [c0, c0 + 4): partials summed in split order, then the GEMM's epilogue
-__device__ void splitk_finish_group(const GemmB& p, const int row, const int c0) {
-    const int pc = p.Chi ? max(p.plane_cols, p.N) : p.N;
-    if (c0 >= pc) return;
+    const int row = (int)(idx / ncg), c0 = (int)(idx % ncg) * 4;
     const int64_t ldw = (int64_t)p.tiles_n * BN;
     const int64_t slab = (int64_t)p.tiles_m * p.bm * ldw;
     const float* src = p.ws + (int64_t)row * ldw + c0;
@@ -1872,8 +1839,6 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     BMT_CHECK_ARG(splitk == 1 || two_pass || accum, "bmt_gemm_bf16: split-K workspace too small");
     if (a->colsum && splitk > 1) splitk = 1, p.kchunk = a->Kpad;      // column sums come from the main kernel's epilogue only
     if (splitk > 1 && two_pass) { p.ws = a->splitk_ws; p.nsplit = splitk; }
-    static const int sk_fused = getenv("BMT_SPLITK_FUSED") ? atoi(getenv("BMT_SPLITK_FUSED")) : 1;      // A/B: 0 = always the second kernel
-    p.sk_cnt = (p.ws && sk_fused && a->splitk_counters && tiles <= a->splitk_counters_n) ? a->splitk_counters : nullptr;
     p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr;
     p.gate = a->gate; p.ldg = a->ldg; p.gate_scale = a->gate_scale;
     p.colsum = a->colsum;
@@ -1945,7 +1910,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     } else if (p.bm == 256) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 2>(p, splitk, st_) : launch<1, 4, 2>(p, splitk, st_);
     else if (waves8) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1>(p, splitk, st_) : launch<1, 4, 1>(p, splitk, st_);
     else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 2, 2>(p, splitk, st_) : launch<1, 2, 2>(p, splitk, st_);
-    if (rc != BMT_OK || p.ws == nullptr || p.sk_cnt != nullptr) return rc;
+    if (rc != BMT_OK || p.ws == nullptr) return rc;
     const int pc = p.Chi ? (p.plane_cols > p.N ? p.plane_cols : p.N) : p.N;
     const int64_t groups = (int64_t)p.M * ((pc + 3) / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)bmt_cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream, p);
@@ -1957,8 +1922,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
 // and are written by small kernels whose ARGUMENTS carry them: nothing is read from host memory when the launch executes, so the
 // sequence can be captured in a hipGraph and replayed (a memcpy node would re-read a host buffer that may have changed).
 struct GemmPack {
-    static constexpr int CAP = 13;
-    GemmB d[CAP];
+    GemmB d[14];
     int n, base;
 };
 static_assert(sizeof(GemmPack) <= 4000, "descriptor pack must fit the kernel argument buffer");
@@ -2066,8 +2030,8 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
     int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
     GemmPack pk;
-    for (int base = 0; base < nprob; base += GemmPack::CAP) {
-        pk.n = nprob - base < GemmPack::CAP ? nprob - base : GemmPack::CAP;
+    for (int base = 0; base < nprob; base += 14) {
+        pk.n = nprob - base < 14 ? nprob - base : 14;
         pk.base = base;
         for (int i = 0; i < pk.n; ++i) pk.d[i] = pr[base + i].p;
         hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table);

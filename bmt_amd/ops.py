@@ -784,23 +784,6 @@ def splitk_workspace(device):
     return ws
 
 
-_SPLITK_CNT = {}
-SPLITK_COUNTERS = 4096
-
-
-def splitk_counters(device):
-    """per-tile arrival counters of the current stream's split-K launches (bmt_gemm_bf16_args.splitk_counters): zero between launches -- the
-    kernel that finds a counter at nsplit - 1 finishes the tile and puts it back -- so they are zeroed once, here (bmt_zero: under a graph
-    capture that is one more node at the stream's first split launch, not a framework fill)"""
-    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
-    c = _SPLITK_CNT.get(key)
-    if c is None:
-        c = torch.empty(SPLITK_COUNTERS, device=device, dtype=torch.int32)
-        zero_(c)
-        _SPLITK_CNT[key] = c
-    return c
-
-
 AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
 DW_ATOMIC = _os.environ.get("BMT_DW_ATOMIC") == "1"     # A/B: weight gradients accumulate with fp32 atomics instead of workspace + epilogue
 
@@ -881,8 +864,6 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
     if splitk != 1 and two_pass:
         ws = splitk_workspace(ah.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
-        cnt = splitk_counters(ah.device)
-        a.splitk_counters, a.splitk_counters_n = _p(cnt), cnt.numel()
     _lib.check(lib.bmt_gemm_bf16(C.byref(a), _st()), "bmt_gemm_bf16")
 
 

@@ -111,11 +111,6 @@ typedef struct {
      * With C_hi == NULL the fp16 plane is the ONLY plane written (q / k / v under the fp16 attention policy, whose backward converts
      * them on load: bmt_attn_bwd_bf16_args.qkv_f16); excludes C_lo and colsum. */
     uint16_t* C_f16;
-    /* ABI 6, optional: splitk_counters_n ints, ZERO when first handed to the library and touched by nobody else (one array per stream, like
-     * the workspace).  With it a two-pass split-K launch of at most splitk_counters_n tiles is ONE kernel: every split stores its partial
-     * tile, bumps the tile's counter, and the workgroup that finds it at nsplit - 1 sums the partials in split order, runs the epilogue for
-     * the tile and puts the counter back to zero -- the same values as the second kernel (same order of additions), one launch less. */
-    int32_t* splitk_counters; int splitk_counters_n;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight

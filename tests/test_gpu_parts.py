@@ -125,7 +125,7 @@ def test_parts_one_after_the_other_on_one_stream(monkeypatch):
 
 
 def test_captured_parts_replay_the_eager_trajectory():
-    """three optimizer steps: eager M = 2 against a captured M = 2 step's replays (dropout off), and against the plain pass's losses"""
+    """four optimizer steps: eager M = 2 against a captured M = 2 step's replays (dropout off), and against the plain pass's losses"""
     from bmt_amd.train import CaptioningTrainStep
     V, B = 500, 4
     cfg = syn.cfg_config1(dout_p=0.0)
@@ -136,21 +136,21 @@ def test_captured_parts_replay_the_eager_trajectory():
         step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True, microbatches=M, seed=11)
         ls = []
         if captured:
-            step.capture(fs, caps, warmup=1)
-            ls.append(None)
+            step.capture(fs, caps, warmup=1)            # (two eager warm-up steps whatever is asked for: a model's first step runs its parts in turn)
+            ls += [None, None]
             for _ in range(2):
                 loss, _ = step.replay()
                 ls.append(float(loss))
         else:
-            for _ in range(3):
+            for _ in range(4):
                 loss, _ = step(fs, caps)
                 ls.append(float(loss))
         losses[name] = ls
     print("\n", losses)
     for a, b in zip(losses["plain"], losses["parts"]):
-        assert abs(a - b) < 2e-3          # (Adam's first steps amplify summation-order noise: tests/study_adam_drift.py)
-    for a, b in zip(losses["parts"][1:], losses["parts, captured"][1:]):
-        assert abs(a - b) < 2e-3
+        assert abs(a - b) < 3e-3          # (Adam's first steps amplify summation-order noise: tests/study_adam_drift.py)
+    for a, b in zip(losses["parts"][2:], losses["parts, captured"][2:]):
+        assert abs(a - b) < 3e-3
 
 
 def test_parts_under_dropout_draw_their_own_masks():
