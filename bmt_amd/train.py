@@ -76,6 +76,7 @@ def make_masks(feature_stacks: Dict[str, torch.Tensor], captions: Optional[torch
 # two-stream encoder (0 = a part is ONE stream)
 _PARTS_STAGGER = os.environ.get("BMT_PARTS_STAGGER", "1") != "0"
 _PARTS_SIDE_STREAMS = os.environ.get("BMT_PARTS_SIDE", "1") != "0"
+_ONE_GRAPH = os.environ.get("BMT_ONE_GRAPH", "0") == "1"                # A/B switch: a single-process step as ONE hipGraph instead of {forward, backward} + {optimizer}
 _PARTS_NO_RECORD = os.environ.get("BMT_PARTS_NO_RECORD") == "1"        # (bisecting a capture problem only)
 
 
@@ -368,7 +369,8 @@ class CaptioningTrainStep:
             raise RuntimeError("capture() needs static gradient buffers: construct with static_grads=True")
         if self.microbatches > 1:
             warmup = max(warmup, 2)             # the first step of a model runs its parts one after the other (_forward_backward_parts)
-        if collectives:
+        if collectives or (_ONE_GRAPH and (not self.data_parallel or self.reducer.world == 1)):
+            # (one process: nothing sits between the backward pass and the optimizer but the loss normaliser's launch -- the same single graph)
             return self._capture_with_collectives(feature_stacks, caption_idx, warmup)
         self.reducer.overlap = False            # collectives stay outside the captured region
         self._static_fs = {k: v.clone() for k, v in feature_stacks.items()}
