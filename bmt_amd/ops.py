@@ -1504,7 +1504,7 @@ class ResidualNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
         ctx.kv_alias = bool(kv_alias)
-        ctx.gp_req = getattr(x, "_bmt_gp_req", None) if D % 64 == 0 else None      # (request_grad_plane: the producer of x wants dropout(dx) as a plane)
+        ctx.gp_req = getattr(x, "_bmt_gp_req", None) if D % (4 if LN_EMIT_ANY_WIDTH else 64) == 0 else None      # (request_grad_plane: the producer of x wants dropout(dx) as a plane)
         context().last_ln = pl
         if kv_alias:
             return xc.view_as(xc), y.view(xc.shape), xc.view_as(xc)

@@ -24,5 +24,5 @@ timeout 120 python tools/postprocess_bench.py > gpurun_out/${TAG}_postprocess_be
 timeout 120 python tools/ingest_bench.py > gpurun_out/${TAG}_ingest_bench.json 2>/dev/null; tail -c 400 gpurun_out/${TAG}_ingest_bench.json; echo
 # cheap same-box A/Bs of Python-level switches (no csrc change: the PMC record above stays valid whichever way they go)
 if [ -n "$FINAL_AB" ]; then
-  bash tools/gpu_ab.sh "X=0" "BMT_ONE_GRAPH=1" "BMT_KV_PREFETCH=1" 2>&1 | tee gpurun_out/${TAG}_ab_onegraph_prefetch.txt
+  bash tools/gpu_ab.sh "X=0" "BMT_ONE_GRAPH=1" "BMT_KV_PREFETCH=1" "BMT_LN_EMIT_ANY=0" 2>&1 | tee gpurun_out/${TAG}_ab_onegraph_prefetch_lnany.txt
 fi
