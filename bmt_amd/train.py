@@ -77,7 +77,6 @@ def make_masks(feature_stacks: Dict[str, torch.Tensor], captions: Optional[torch
 _PARTS_STAGGER = os.environ.get("BMT_PARTS_STAGGER", "1") != "0"
 _PARTS_SIDE_STREAMS = os.environ.get("BMT_PARTS_SIDE", "1") != "0"
 _ONE_GRAPH = os.environ.get("BMT_ONE_GRAPH", "0") == "1"                # A/B switch: a single-process step as ONE hipGraph instead of {forward, backward} + {optimizer}
-_PARTS_NO_RECORD = os.environ.get("BMT_PARTS_NO_RECORD") == "1"        # (bisecting a capture problem only)
 
 
 class CaptioningTrainStep:
@@ -235,7 +234,7 @@ class CaptioningTrainStep:
             _ops.allow_encoder_streams(side_ok)
             fs = {k: v[lo:hi] for k, v in feature_stacks.items()}
             xi, yi = x[lo:hi], y[lo:hi]
-            if st is not main and not _PARTS_NO_RECORD:
+            if st is not main:
                 for t in list(fs.values()) + [xi, yi]:
                     t.record_stream(st)
             masks = make_masks(fs, xi, self.modality, self.pad_idx)
@@ -272,7 +271,7 @@ class CaptioningTrainStep:
             kl = kls[0].detach()
             for k in kls[1:]:
                 kd = k.detach()
-                if not serial and not _PARTS_NO_RECORD:
+                if not serial:
                     kd.record_stream(main)
                 kl = _ops.add_(torch.empty_like(kl), kl, kd)
         finally:
