@@ -913,6 +913,7 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
 # launches split their reductions 8 ways and pay an epilogue kernel and the workspace traffic for it; together the step's ~50
 # weight gradients are ~3000 tiles and every reduction runs unsplit.
 GROUPED_DW = _os.environ.get("BMT_NO_GROUPED_DW") != "1"
+COLSUM_BESIDE_DW = _os.environ.get("BMT_COLSUM_BESIDE_DW", "0") == "1"      # A/B switch: the queued small reductions on the side stream, beside the grouped dW launch
 _dw_ws = {}
 
 
@@ -948,6 +949,18 @@ def flush_dw():
     items, ctx.pending_dw = ctx.pending_dw, []
     done, ctx.pending_done = ctx.pending_done, []
     ctx.pending_ids.clear()
+    cs, ctx.pending_cs = ctx.pending_cs, []
+    beside = None
+    if cs and items and len(items) > 1 and GROUPED_DW and COLSUM_BESIDE_DW and ENC_STREAMS >= 2 and ctx.allow_streams \
+            and (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream) not in _ctx_alias:
+        # the pass's small reductions (one launch, ~40 us of a few hundred workgroups) beside the grouped weight-gradient launch instead of
+        # behind it: different outputs (bias / LayerNorm gradients vs weight gradients), both read what the backward pass left
+        main = torch.cuda.current_stream()
+        beside = side_stream(0, main)
+        beside.wait_stream(main)
+        with torch.cuda.stream(beside):
+            _colsum_launch(cs)
+        cs = None
     if items:
         if len(items) == 1 or not GROUPED_DW:
             for dyT, xT, into in items:
@@ -955,9 +968,10 @@ def flush_dw():
                           a_km=True, b_km=True)
         else:
             gemm_bf16_grouped(items)
-    cs, ctx.pending_cs = ctx.pending_cs, []
     if cs:
         _colsum_launch(cs)
+    if beside is not None:
+        torch.cuda.current_stream().wait_stream(beside)
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
         grad_done(p)
     hs, ctx.gen_handles = ctx.gen_handles, []
