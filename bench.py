@@ -370,8 +370,6 @@ def PMC_FAMILY_OF_KERNEL(name: str) -> str:
     n = re.sub(r"^void ", "", n)
     if n.startswith("gemm_bf16_grouped_kernel"):
         return "gemm_dw_grouped"
-    if n.startswith("gemm_wide_km_grouped_kernel"):      # the 256 x 256 tiles of the same grouped call: its own launch, its own family
-        return "gemm_dw_grouped_wide"
     if re.match(r"gemm_bf16_kernel<1, \d, \d, false, false, \d, true", n) or re.match(r"gemm_pipe_kernel<1, true", n):
         return "gemm_f16"
     m = re.match(r"gemm_(?:bf16|pipe)_kernel<(\d)", n)
@@ -400,7 +398,7 @@ def pmc_keys_of_class(cls: str):
     if cls.startswith("attn_bwd"):
         return ("attn_bwd_dq", "attn_bwd_dkv")
     if "dw_grouped" in cls:
-        return ("gemm_dw_grouped_wide", "gemm_dw_grouped")      # one grouped call = the 256-wide tiles' launch + the 128-wide tiles' launch
+        return ("gemm_dw_grouped",)
     if cls.endswith("bf16x3"):
         return ("gemm_x3",)
     if "(fp16 hi+lo)" in cls:
@@ -898,8 +896,6 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             rec, rec_note = pmc_record()
             fam = [(rec or {}).get("kernels", {}).get(k) for k in pmc_keys_of_class(dom)]
-            if "dw_grouped" in dom:         # (either tile kind may have no problem in a given model)
-                fam = [x for x in fam if x]
             kern = None
             if fam and all(fam):        # per launch of the class: the sum over its kernels (families mix encoder and decoder sizes)
                 kern = {"traffic_bytes": sum(x["traffic_bytes"] for x in fam)}

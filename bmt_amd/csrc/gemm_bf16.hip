@@ -1321,202 +1321,6 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     else gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, tile, split, true);
 }
 
-// ===================================================================== 256 x 256 tile for the weight gradients: both operands k-major
-// dW[n][k] += sum_r dY[r][n] X[r][k] over a chunk of rows, in the 8-phase structure of gemm_wide_kernel: half the operand bytes per FLOP
-// of the 128 x 128 tile (its grouped launch fetched 3.9 GB for ~1 GB of unique operands) and 1.5 transposing reads per MFMA instead of 3.
-//   * a half-tile is [64 reduction rows][128 columns] as stored (256-byte rows), DMA'd in 1-KB pieces of 4 rows, 16-byte slots XOR-ed with
-//     4 (row & 3) on the source side -- the image km_frag_sw / km_sw_off read (the four rows of a transposing read fall into the four
-//     64-byte bank quarters);
-//   * MFMA A = dY columns (output rows n), B = X columns (output columns k): a lane's accumulator registers are 4 consecutive n of one k,
-//     the 32 lanes of a half-wave 32 consecutive k -- the atomics of the epilogue are 128-byte contiguous requests, straight from registers;
-//   * fragment reads are inline asm (hipcc drains the DMA queue -- vmcnt(0) -- in front of a ds_read_tr builtin) behind the phase's own
-//     lgkmcnt(0);
-//   * one work item = (tile, chunk of p.kchunk rows) of a problem, found through the XCD segment lists exactly as gemm_bf16_grouped_kernel does.
-template <int OFF>
-__device__ __forceinline__ u32x2 gw_tr_b64(uint32_t addr) {
-    u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
-template <int S>
-__device__ __forceinline__ bf16x8 gw_km_frag(uint32_t addr) {      // reduction indices 16 S .. 16 S + 15 of this lane's column (km_frag_sw)
-    const u32x2 lo = gw_tr_b64<S * 4096>(addr), hi = gw_tr_b64<S * 4096 + 1024>(addr);
-    return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-}
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wide_km_grouped_kernel(
-    const GemmB* __restrict__ table, const XcdSeg* __restrict__ segs, const int* __restrict__ nseg) {
-    constexpr int HT = 16384, SLOT = 4 * HT;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    const XcdSeg* sx = segs + x * XCD_MAXSEG;
-    int lo = 0, hi = nseg[x] - 1;
-    if (hi < 0) return;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (sx[mid].first_slot <= slot) lo = mid;
-        else hi = mid - 1;
-    }
-    const XcdSeg sg = sx[lo];
-    const int local = slot - sg.first_slot;
-    if (local >= sg.count * sg.nsplit) return;
-    const GemmB p = table[sg.prob];
-    const int tile = sg.tile_off + local % sg.count, split = local / sg.count;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
-    const int half = lane >> 5, l31 = lane & 31;
-    // tile -> (row panel of 256 dY columns, column panel of 256 X columns): groups of 8 row panels walked column by column
-    const int per_group = 8 * p.tiles_n;
-    const int g = tile / per_group, first_m = g * 8;
-    const int gsz = min(p.tiles_m - first_m, 8);
-    const int wi = tile - g * per_group;
-    const int m0 = (first_m + wi % gsz) * 256, n0 = (wi / gsz) * 256;
-    const int kbeg = split * p.kchunk;
-    const int kend = min(p.Kpad, kbeg + p.kchunk);
-    const int T = (kend - kbeg) / 64;
-
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.krows * p.lda * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)((int64_t)p.krows * p.ldb * 2), 0x00020000);
-    int avo[2][2], bvo[2][2];
-    {
-        const int kr = lane >> 4, sl = (lane & 15) ^ (kr << 2);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = (2 * wid + j) * 4 + kr;
-                avo[hf][j] = row * (int)p.lda * 2 + min(m0 + 128 * hf + sl * 8, (int)p.lda - 8) * 2;
-                bvo[hf][j] = row * (int)p.ldb * 2 + min(n0 + 128 * hf + sl * 8, (int)p.ldb - 8) * 2;
-            }
-    }
-#define BMT_K_DMA_A(t_, slot_)                                                                                       \
-    do {                                                                                                             \
-        const int so_ = (kbeg + (t_) * 64) * (int)p.lda * 2;                                                          \
-        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf)                                                             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + (slot_) * SLOT + hf * HT + (2 * wid + j) * 1024), 16, avo[hf][j], so_, 0, 0); \
-    } while (0)
-#define BMT_K_DMA_B(t_, slot_)                                                                                       \
-    do {                                                                                                             \
-        const int so_ = (kbeg + (t_) * 64) * (int)p.ldb * 2;                                                          \
-        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf)                                                             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + (slot_) * SLOT + (2 + hf) * HT + (2 * wid + j) * 1024), 16, bvo[hf][j], so_, 0, 0); \
-    } while (0)
-
-    // fragment addresses (LDS byte addresses of K-tile slot 0; slot 1 is + SLOT, past the 16-bit immediate): A fragment i = dY columns
-    // 128 wr + 32 i .., B fragment b = X columns 64 wc + 32 b ..
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    uint32_t adA[2][4], adB[2][2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) adA[e][i] = lds0 + e * SLOT + wr * HT + km_sw_off(32 * i, lane);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) adB[e][b] = lds0 + e * SLOT + (2 + (wc >> 1)) * HT + km_sw_off((wc & 1) * 64 + 32 * b, lane);
-    }
-#define BMT_K_BAR()                                  \
-    do {                                             \
-        __builtin_amdgcn_sched_barrier(0);           \
-        __builtin_amdgcn_s_barrier();                \
-        __builtin_amdgcn_sched_barrier(0);           \
-    } while (0)
-#define BMT_K_FRAGS4(dst_, ad_) \
-    do { dst_[0] = gw_km_frag<0>(ad_); dst_[1] = gw_km_frag<1>(ad_); dst_[2] = gw_km_frag<2>(ad_); dst_[3] = gw_km_frag<3>(ad_); } while (0)
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
-    bf16x8 wa[2][4], xb0[4], xb1[4];
-#define BMT_K_MFMA(ib_, xb_, bcol_)                                                                                  \
-    do {                                                                                                             \
-        __builtin_amdgcn_s_setprio(1);                                                                               \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-                acc[(ib_) + i][bcol_] = mfma32t<false>(wa[i][s], xb_[s], acc[(ib_) + i][bcol_]);                     \
-        __builtin_amdgcn_s_setprio(0);                                                                               \
-    } while (0)
-#define BMT_K_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define BMT_K_KTILE(e_, t_)                                                                                          \
-    do {                                                                                                             \
-        const bool next2_ = (t_) + 2 < T;                                                                            \
-        /* phase 0: (A fragments 0, 1) x B fragment 0 */                                                             \
-        BMT_K_FRAGS4(xb0, adB[e_][0]);                                                                               \
-        BMT_K_FRAGS4(wa[0], adA[e_][0]);                                                                             \
-        BMT_K_FRAGS4(wa[1], adA[e_][1]);                                                                             \
-        BMT_K_LGKM0();                                                                                               \
-        BMT_K_BAR();                                                                                                 \
-        BMT_K_MFMA(0, xb0, 0);                                                                                       \
-        BMT_K_BAR();                                                                                                 \
-        /* phase 1: (A 0, 1) x B 1 */                                                                                \
-        BMT_K_FRAGS4(xb1, adB[e_][1]);                                                                               \
-        BMT_K_LGKM0();                                                                                               \
-        BMT_K_BAR();                                                                                                 \
-        BMT_K_MFMA(0, xb1, 1);                                                                                       \
-        BMT_K_BAR();                                                                                                 \
-        /* phase 2: (A 2, 3) x B 1; the B half-tiles of this slot were last read in phase 1: K-tile t + 2 may overwrite them */ \
-        BMT_K_FRAGS4(wa[0], adA[e_][2]);                                                                             \
-        BMT_K_FRAGS4(wa[1], adA[e_][3]);                                                                             \
-        if (next2_) BMT_K_DMA_B((t_) + 2, e_);                                                                       \
-        BMT_K_LGKM0();                                                                                               \
-        BMT_K_BAR();                                                                                                 \
-        BMT_K_MFMA(2, xb1, 1);                                                                                       \
-        BMT_K_BAR();                                                                                                 \
-        /* phase 3: (A 2, 3) x B 0 from registers; K-tile t + 1 has landed (only this phase 2's requests are younger); the A          \
-           half-tiles of this slot are free */                                                                       \
-        if (next2_) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                 \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
-        if (next2_) BMT_K_DMA_A((t_) + 2, e_);                                                                       \
-        BMT_K_BAR();                                                                                                 \
-        BMT_K_MFMA(2, xb0, 0);                                                                                       \
-        BMT_K_BAR();                                                                                                 \
-    } while (0)
-
-    BMT_K_DMA_A(0, 0);
-    BMT_K_DMA_B(0, 0);
-    if (T > 1) {
-        BMT_K_DMA_A(1, 1);
-        BMT_K_DMA_B(1, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    BMT_K_BAR();
-    if (wr == 1) BMT_K_BAR();                  // group 1 runs one barrier behind group 0
-    for (int t = 0; t < T; t += 2) {
-        BMT_K_KTILE(0, t);
-        if (t + 1 < T) BMT_K_KTILE(1, t + 1);
-    }
-    if (wr == 0) BMT_K_BAR();
-#undef BMT_K_LGKM0
-#undef BMT_K_KTILE
-#undef BMT_K_MFMA
-#undef BMT_K_BAR
-#undef BMT_K_FRAGS4
-#undef BMT_K_DMA_A
-#undef BMT_K_DMA_B
-    // C += alpha * acc: acc[i][b][r] is output row n = m0 + 128 wr + 32 i + acc_row(r, half), column k = n0 + 64 wc + 32 b + l31
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + 64 * wc + 32 * b + l31;
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 128 * wr + 32 * i + acc_row(r, half);
-                if (row < p.M) atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[i][b][r] * p.alpha);
-            }
-        }
-}
-
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
 // and run the same epilogue as the GEMM kernel.  One writer per element: ACCUM is a plain read-modify-write.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
@@ -2142,7 +1946,7 @@ __global__ void gemm_segs_write_kernel(const SegPack pk, XcdSeg* __restrict__ se
 }
 
 extern "C" size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob) {
-    return nprob <= 0 ? 0 : (size_t)nprob * sizeof(GemmB) + 2 * (8 * XCD_MAXSEG * sizeof(XcdSeg) + 8 * sizeof(int)) + 512;      // two segment tables: 256- and 128-wide tiles
+    return nprob <= 0 ? 0 : (size_t)nprob * sizeof(GemmB) + 8 * XCD_MAXSEG * sizeof(XcdSeg) + 8 * sizeof(int) + 512;
 }
 
 extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream) {
@@ -2150,21 +1954,18 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     BMT_CHECK_ARG(ws_bytes >= bmt_gemm_bf16_grouped_ws_bytes(nprob) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                   "bmt_gemm_bf16_grouped: workspace too small or not 16-byte aligned");
     static_assert(sizeof(GemmB) % 4 == 0, "descriptor is copied word-wise");
-    struct Prob { GemmB p; int tiles, stages, nsplit, wide; };
+    struct Prob { GemmB p; int tiles, stages, nsplit; };
     // reduction chunk (64-row stages) of a work item; 0 = whole reductions.  Partial products accumulate with the fp32 atomics the
     // unsplit launch uses too (C += alpha A B is the only epilogue here)
     // measured (tools/gpu_ab.sh, whole step; PMC: the unsplit launch fetched 6 GB for ~1 GB of unique operands at 5.1 TB/s): chunks
     // of 16 / 32 / 64 / 100 / 134 / 200 stages -> 1.48 / 1.14 / 1.02 / 1.02 / 1.06 / 1.05 ms against 1.235 ms unsplit
     static const int chunk = getenv("BMT_GROUPED_CHUNK") ? atoi(getenv("BMT_GROUPED_CHUNK")) : 64;     // A/B experiments only
-    // problems whose output is (nearly) whole 256 x 256 tiles go to gemm_wide_km_grouped_kernel, the others (an extent of 128: the audio
-    // stream's weights; 300: the decoder's) stay on the 128 x 128 tile
-    static const int dw_wide = getenv("BMT_DW_WIDE") ? atoi(getenv("BMT_DW_WIDE")) : 1;                 // A/B: 0 = every problem on 128 x 128 tiles
-    static const int chunk_w = getenv("BMT_GROUPED_CHUNK_WIDE") ? atoi(getenv("BMT_GROUPED_CHUNK_WIDE")) : 64;
     Prob* pr = (Prob*)malloc(sizeof(Prob) * (size_t)nprob);
     int* order = (int*)malloc(sizeof(int) * (size_t)nprob);
     SegPack* sp = (SegPack*)malloc(sizeof(SegPack) * 4);
     if (!pr || !order || !sp) { free(pr); free(order); free(sp); bmt_set_error("bmt_gemm_bf16_grouped: out of host memory"); return BMT_EINVAL; }
     int rc = BMT_OK;
+    double total_work = 0.0;
     for (int i = 0; i < nprob && rc == BMT_OK; ++i) {
         const bmt_gemm_bf16_args* a = args + i;
         if (!(a->precision == BMT_PREC_BF16 && a->a_kmajor && a->b_kmajor && a->conv_mode == 0 && a->C && !a->C_hi && !a->colsum)) {
@@ -2175,29 +1976,59 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         }
         int splitk = 1;
         rc = gemm_prepare(a, pr[i].p, splitk, false);
-        const int64_t pad128 = (int64_t)bmt_cdiv(a->M, 128) * bmt_cdiv(a->N, 128) * 4, pad256 = (int64_t)bmt_cdiv(a->M, 256) * bmt_cdiv(a->N, 256) * 16;
-        pr[i].wide = dw_wide && a->M >= 256 && a->N >= 256 && pad256 * 10 <= pad128 * 11 && a->lda % 8 == 0 && a->ldb % 8 == 0 &&
-                     (int64_t)a->K * a->lda * 2 < (1ll << 31) && (int64_t)a->K * a->ldb * 2 < (1ll << 31);
-        if (pr[i].wide) {
-            pr[i].p.bm = 256;
-            pr[i].p.tiles_m = bmt_cdiv(a->M, 256);
-            pr[i].p.tiles_n = bmt_cdiv(a->N, 256);
-        }
         pr[i].tiles = pr[i].p.tiles_m * pr[i].p.tiles_n;
         pr[i].stages = a->Kpad / 64;
         pr[i].nsplit = 1;
-        const int ch = pr[i].wide ? chunk_w : chunk;
-        if (ch > 0 && pr[i].stages > ch + ch / 2) {
-            pr[i].nsplit = bmt_cdiv(pr[i].stages, ch);
+        if (chunk > 0 && pr[i].stages > chunk + chunk / 2) {
+            pr[i].nsplit = bmt_cdiv(pr[i].stages, chunk);
             pr[i].p.kchunk = bmt_cdiv(pr[i].stages, pr[i].nsplit) * 64;
             pr[i].nsplit = bmt_cdiv(a->Kpad, pr[i].p.kchunk);
         }
+        total_work += (double)pr[i].tiles * (pr[i].stages + 2);      // + prologue / epilogue of a tile
+        order[i] = i;
     }
     if (rc != BMT_OK) { free(pr); free(order); free(sp); return rc; }
+    // largest problems first (stable insertion sort: nprob is small)
+    auto work = [&](int i) { return (double)pr[i].tiles * (pr[i].stages + 2); };
+    for (int i = 1; i < nprob; ++i) {
+        const int o = order[i];
+        int j = i - 1;
+        while (j >= 0 && work(order[j]) < work(o)) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = o;
+    }
+    // pack onto the 8 XCDs: a problem goes to the least loaded XCD; one that is more than ~60 % of an XCD's fair share is cut
+    // into 2, 4 or 8 contiguous tile ranges first (placed independently)
+    static const int spread = getenv("BMT_GROUPED_SPREAD") ? atoi(getenv("BMT_GROUPED_SPREAD")) : 0;       // A/B: every problem over all 8 XCDs
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double share = total_work / 8.0;
+    bool overflow = false;
+    for (int oi = 0; oi < nprob && !overflow; ++oi) {
+        const int i = order[oi];
+        int parts = 1;
+        while (parts < 8 && work(i) / parts > 0.6 * share) parts *= 2;
+        if (spread) parts = 8;
+        if (parts > pr[i].tiles) parts = 1;
+        const int per = (pr[i].tiles + parts - 1) / parts;
+        for (int part = 0; part < parts; ++part) {
+            const int t0 = part * per, cnt = (t0 + per <= pr[i].tiles) ? per : pr[i].tiles - t0;
+            if (cnt <= 0) break;
+            int x = 0;
+            if (spread) x = part;
+            else for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+            if (ns[x] >= XCD_MAXSEG) { overflow = true; break; }
+            XcdSeg& sg = sp[x / 2].s[x & 1][ns[x]++];
+            sg.first_slot = slots[x]; sg.prob = i; sg.tile_off = t0; sg.count = cnt; sg.nsplit = pr[i].nsplit;
+            slots[x] += cnt * pr[i].nsplit;
+            load[x] += (double)cnt * (pr[i].stages + 2);
+        }
+    }
+    if (overflow) { free(pr); free(order); free(sp); bmt_set_error("bmt_gemm_bf16_grouped: too many segments for one XCD"); return BMT_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     GemmB* table = reinterpret_cast<GemmB*>(ws);
     char* tail = reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15);
-    constexpr size_t SEG_AREA = 8 * XCD_MAXSEG * sizeof(XcdSeg) + 8 * sizeof(int);
+    XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
+    int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
     GemmPack pk;
     for (int base = 0; base < nprob; base += 14) {
         pk.n = nprob - base < 14 ? nprob - base : 14;
@@ -2205,77 +2036,17 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         for (int i = 0; i < pk.n; ++i) pk.d[i] = pr[base + i].p;
         hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table);
     }
-    auto work = [&](int i) { return (double)pr[i].tiles * (pr[i].stages + 2); };      // (+ prologue / epilogue of a tile)
-    static const int spread = getenv("BMT_GROUPED_SPREAD") ? atoi(getenv("BMT_GROUPED_SPREAD")) : 0;       // A/B: every problem over all 8 XCDs
-    int max_slots_kind[2] = {0, 0};
-    for (int kind = 1; kind >= 0 && rc == BMT_OK; --kind) {           // 1: the 256-wide tiles (launched first), 0: the 128-wide ones
-        int n = 0;
-        double total_work = 0.0;
-        for (int i = 0; i < nprob; ++i)
-            if (pr[i].wide == kind) { order[n++] = i; total_work += work(i); }
-        if (n == 0) continue;
-        // largest problems first (stable insertion sort: nprob is small)
-        for (int i = 1; i < n; ++i) {
-            const int o = order[i];
-            int j = i - 1;
-            while (j >= 0 && work(order[j]) < work(o)) { order[j + 1] = order[j]; --j; }
-            order[j + 1] = o;
-        }
-        // pack onto the 8 XCDs: a problem goes to the least loaded XCD; one that is more than ~60 % of an XCD's fair share is cut
-        // into 2, 4 or 8 contiguous tile ranges first (placed independently)
-        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const double share = total_work / 8.0;
-        for (int oi = 0; oi < n && rc == BMT_OK; ++oi) {
-            const int i = order[oi];
-            int parts = 1;
-            while (parts < 8 && work(i) / parts > 0.6 * share) parts *= 2;
-            if (spread) parts = 8;
-            if (parts > pr[i].tiles) parts = 1;
-            const int per = (pr[i].tiles + parts - 1) / parts;
-            for (int part = 0; part < parts; ++part) {
-                const int t0 = part * per, cnt = (t0 + per <= pr[i].tiles) ? per : pr[i].tiles - t0;
-                if (cnt <= 0) break;
-                int x = 0;
-                if (spread) x = part;
-                else for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
-                if (ns[x] >= XCD_MAXSEG) { rc = BMT_EINVAL; bmt_set_error("bmt_gemm_bf16_grouped: too many segments for one XCD"); break; }
-                XcdSeg& sg = sp[x / 2].s[x & 1][ns[x]++];
-                sg.first_slot = slots[x]; sg.prob = i; sg.tile_off = t0; sg.count = cnt; sg.nsplit = pr[i].nsplit;
-                slots[x] += cnt * pr[i].nsplit;
-                load[x] += (double)cnt * (pr[i].stages + 2);
-            }
-        }
-        if (rc != BMT_OK) break;
-        XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail + kind * SEG_AREA);
-        int* nseg = reinterpret_cast<int*>(tail + kind * SEG_AREA + 8 * XCD_MAXSEG * sizeof(XcdSeg));
-        for (int x = 0; x < 8; ++x) max_slots_kind[kind] = slots[x] > max_slots_kind[kind] ? slots[x] : max_slots_kind[kind];
-        for (int q = 0; q < 4; ++q) {
-            sp[q].n[0] = ns[2 * q]; sp[q].n[1] = ns[2 * q + 1]; sp[q].xcd0 = 2 * q;
-            hipLaunchKernelGGL(gemm_segs_write_kernel, dim3(2), dim3(64), 0, st, sp[q], segs, nseg);
-        }
+    int max_slots = 0;
+    for (int x = 0; x < 8; ++x) max_slots = slots[x] > max_slots ? slots[x] : max_slots;
+    for (int q = 0; q < 4; ++q) {
+        sp[q].n[0] = ns[2 * q]; sp[q].n[1] = ns[2 * q + 1]; sp[q].xcd0 = 2 * q;
+        hipLaunchKernelGGL(gemm_segs_write_kernel, dim3(2), dim3(64), 0, st, sp[q], segs, nseg);
     }
     free(pr);
     free(order);
     free(sp);
-    if (rc != BMT_OK) return rc;
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(table)");
     constexpr int BK = 64, BMr = 128;
-    if (max_slots_kind[1] > 0) {
-        XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail + SEG_AREA);
-        int* nseg = reinterpret_cast<int*>(tail + SEG_AREA + 8 * XCD_MAXSEG * sizeof(XcdSeg));
-        static bool done_w = false;
-        if (!done_w) {
-            (void)hipFuncSetAttribute((const void*)gemm_wide_km_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 16384);
-            done_w = true;
-        }
-        hipLaunchKernelGGL(gemm_wide_km_grouped_kernel, dim3(8 * max_slots_kind[1]), dim3(512), 2 * 4 * 16384, st, table, segs, nseg);
-        BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(256 x 256 tiles)");
-    }
-    if (max_slots_kind[0] == 0) return BMT_OK;
-    const int max_slots = max_slots_kind[0];
-    XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
-    int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
     static const int km_pipe = getenv("BMT_GEMM_KM_PIPE") ? atoi(getenv("BMT_GEMM_KM_PIPE")) : 0;      // A/B experiments only (see bmt_gemm_bf16)
     if (km_pipe) {                   // the LDS-DMA ring on swizzled k-major images
         constexpr int stage_p = (BMr + BN) * BK * 2;

@@ -95,8 +95,7 @@ def test_kernel_classes_map_to_pmc_families():
     assert fam("attn_bwd_dkv32_kernel<256, false>(AttnPB)") == "attn_bwd_dkv" and fam("attn_fwd64_kernel<256, true>(AttnPB)") == "attn_fwd"
     assert bench.pmc_keys_of_class("gemm_planes_fp16 x (fp16 hi+lo)") == ("gemm_w2",)
     assert bench.pmc_keys_of_class("attn_bwd_enc_dk256_bf16") == ("attn_bwd_dq", "attn_bwd_dkv")
-    assert fam("gemm_wide_km_grouped_kernel(GemmB const*, XcdSeg const*, int const*)") == "gemm_dw_grouped_wide"
-    assert bench.pmc_keys_of_class("gemm_planes_dw_grouped_bf16") == ("gemm_dw_grouped_wide", "gemm_dw_grouped")
+    assert bench.pmc_keys_of_class("gemm_planes_dw_grouped_bf16") == ("gemm_dw_grouped",)
 
 
 def test_rocm_smi_clock_parser_on_a_recorded_sample():
