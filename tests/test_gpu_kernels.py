@@ -863,8 +863,8 @@ def test_gemm_plane_output_with_vector_gate_and_column_sums(ops, M, N, K):
 def test_grouped_weight_gradient_launch(ops):
     """bmt_gemm_bf16_grouped: the weight gradients of several layers (different shapes, ragged reduction lengths and widths) in one
     launch, accumulated into live buffers -- against one split-K launch per problem."""
-    # (from (8192, 4096, 1024) on: outputs of whole 256 x 256 tiles -- gemm_wide_km_grouped_kernel -- with ragged reductions (5000 rows: the last
-    # K-tile is part zeros), one and two K-tiles, an odd number of them, and extents that are not multiples of 256)
+    # (from (8192, 4096, 1024) on: large outputs with ragged reductions -- 5000 rows: the last stage is part zeros --, one and two stages, an odd
+    # number of them, extents that are not multiples of the tile; the set the 256 x 256-tile experiment of round 4 was checked on)
     shapes = [(8192, 1024, 1024), (960, 300, 1024), (1000, 128, 512), (257, 130, 70), (64, 10000, 300), (25600, 1024, 128), (5000, 3072, 128),
               (8192, 4096, 1024), (5000, 3072, 1024), (700, 512, 768), (100, 256, 256), (64, 256, 512), (3000, 1000, 2040), (12800, 2048, 1024)]
     items, want = [], []
