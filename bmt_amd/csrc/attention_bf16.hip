@@ -1883,7 +1883,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // with the stage offset in an SGPR and rows past Sk read as zero, double-buffered LDS images and ONE barrier per stage, the
 // probabilities recomputed in the log2 domain (p = exp2(fma(s, scale log2 e, -lse log2 e))), per-stage bookkeeping paid half as often.
 template <int DK, int BC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16b_kernel(const AttnPB p) {
+__device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& p, const int bid) {
     constexpr int KT = BC / 16, NT = 512, KS = DK / 32, DT = DK / 16, RS = pad_rs<DK>();
     constexpr int TILE = BC * RS, STAGE = 2 * TILE;
     constexpr int NR = rows_n<DK, BC, NT>();
@@ -1896,7 +1896,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int nqt = (p.Sq + 127) / 128;
-    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
+    const int w = xcd_remap(bid, nqt * p.B * p.H);
     const int qt = w % nqt, bh = w / nqt;
     const int b = bh / p.H, h = bh % p.H;
     const int q = qt * 128 + wid * 16 + c;
@@ -2065,6 +2065,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         grad_tile_flush<DK, 128, NT>(tile, gt, b, h, qt * 128, p.Sq, tid);
     }
 }
+template <int DK, int BC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16b_kernel(const AttnPB p) {
+    attn_bwd_dq16b_body<DK, BC>(p, (int)blockIdx.x);
+}
 
 // dK / dV, 8 waves x 16 keys (128 keys per workgroup), loop over 32-query stages.  Every wave computes S[q][key] = Q . K^T and
 // dP[q][key] = dO . V^T once (A = staged Q / dO rows, B = this wave's K / V rows held in registers) and accumulates BOTH
@@ -2199,7 +2203,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // QMASK: the mask has a row per query (the decoder's causal mask); the key-padding masks of the encoder and of every cross-attention
 // are per key (kmask), and without the per-element mask addressing the d_k = 256 kernel fits its 256 registers (no spills).
 template <int DK, bool QMASK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv32_kernel(const AttnPB p) {
+__device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& p, const int bid) {
     constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 128, RS = pad_rs<DK>();
     constexpr int TP = BQ * RS, STAGE = 2 * TP;
     constexpr int NR = rows_n<DK, BQ, NT>();
@@ -2211,7 +2215,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int nkt = (p.Sk + KBLK - 1) / KBLK;
-    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    const int w = xcd_remap(bid, nkt * p.B * p.H);
     const int kt = w % nkt, bh = w / nkt;
     const int b = bh / p.H, h = bh % p.H;
     const int key = kt * KBLK + wid * 16 + c;
@@ -2348,6 +2352,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         grad_tile_flush<DK, KBLK, NT>(tile, gt, b, h, kt * KBLK, p.Sk, tid);
     }
+}
+template <int DK, bool QMASK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv32_kernel(const AttnPB p) {
+    attn_bwd_dkv32_body<DK, QMASK>(p, (int)blockIdx.x);
+}
+// the two kernels of the two-kernel backward in ONE launch: workgroups [0, nq) are the dQ kernel's, the rest the dK / dV kernel's.  Neither
+// reads what the other writes once delta comes from its own small kernel (attn_delta_bf16_kernel), and on the shapes this form serves -- the
+// decoder's 30-query attentions -- the dQ kernel is B x H workgroups walking the whole key range one after the other (latency: ~50 us over
+// 800 keys on half the CUs) while the dK / dV kernel streams 2 x Sk x d_k of keys and gradients (HBM): side by side they take the longer of the
+// two instead of the sum.
+template <int DK, bool QMASK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_pair_kernel(const AttnPB p, const int nq) {
+    if ((int)blockIdx.x < nq) attn_bwd_dq16b_body<DK, 32>(p, (int)blockIdx.x);
+    else attn_bwd_dkv32_body<DK, QMASK>(p, (int)blockIdx.x - nq);
 }
 
 // mean key per (batch, column) over the valid keys: K plane [B][Sk][ldk] (bf16), key-padding mask [B][Sk] (or none / a per-query
@@ -3138,7 +3156,12 @@ template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     static const int sep = getenv("BMT_ATTN_DELTA_SEPARATE") ? atoi(getenv("BMT_ATTN_DELTA_SEPARATE")) : 0;      // A/B experiments only
-    const bool fuse = DK >= 128 && !sep && p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr);
+    // the two-kernel form as ONE launch (attn_bwd_pair_kernel): delta from its own kernel, then dQ and dK / dV workgroups side by side
+    static const int pair_env = getenv("BMT_ATTN_BWD_PAIR") ? atoi(getenv("BMT_ATTN_BWD_PAIR")) : 1;            // A/B: 0 = two launches
+    const bool pair = DK >= 128 && pair_env && p.Pws == nullptr && !getenv("BMT_ATTN_DQ_OLD") && !getenv("BMT_ATTN_DKV_OLD") &&
+                      (int64_t)p.Sk * p.ldk * 2 < (1ll << 31) && (int64_t)p.Sk * p.ldv * 2 < (1ll << 31) &&
+                      (int64_t)p.Sq * p.ldq * 2 < (1ll << 31) && (int64_t)p.Sq * p.ldo * 2 < (1ll << 31);
+    const bool fuse = DK >= 128 && !sep && !pair && p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr);
     if (!fuse) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     AttnPB pf = p;
     pf.fuse_delta = fuse ? 1 : 0;
@@ -3156,6 +3179,24 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
     const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
+        if (pair) {
+            const int lds_epi = 128 * (DK + 8) * 2 + 512 * 8;
+            const int lds_dq = 2 * 2 * 32 * (DK * 2 + 32) + 256, lds_dkv = 2 * 2 * 32 * (DK * 2 + 32) + 512;
+            int lds = lds_dq > lds_dkv ? lds_dq : lds_dkv;
+            lds = lds > lds_epi ? lds : lds_epi;
+            const bool qmask = p.mask != nullptr && p.mask_qs != 0;
+            static bool done_p[2] = {false, false};
+            if (!done_p[qmask]) {
+                if (qmask) (void)hipFuncSetAttribute((const void*)attn_bwd_pair_kernel<DK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                else (void)hipFuncSetAttribute((const void*)attn_bwd_pair_kernel<DK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done_p[qmask] = true;
+            }
+            if (qmask) hipLaunchKernelGGL((attn_bwd_pair_kernel<DK, true>), dim3(nblk_q + nblk_k16), dim3(512), lds, st, pf, nblk_q);
+            else hipLaunchKernelGGL((attn_bwd_pair_kernel<DK, false>), dim3(nblk_q + nblk_k16), dim3(512), lds, st, pf, nblk_q);
+            launch_bias_finish<DK>(p, st);
+            BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (dQ and dK / dV in one launch)");
+            return BMT_OK;
+        }
         {
             const int lds_loop = 2 * 32 * (DK * 2 + 32) + 128, lds_epi = 128 * (DK + 8) * 2 + 512 * 8;      // (row-major gradient image + reduction scratch)
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
