@@ -384,6 +384,8 @@ def PMC_FAMILY_OF_KERNEL(name: str) -> str:
         return "gemm_w2" if m.group(2) == "true" else ("gemm_f16" if m.group(1) == "true" else "gemm_bf16")
     if n.startswith("attn_fwd"):
         return "attn_fwd"
+    if n.startswith("attn_bwd_pair"):        # the two-kernel form's dQ and dK / dV workgroups in one launch (the decoder's attentions)
+        return "attn_bwd_pair"
     if n.startswith("attn_bwd_dq"):
         return "attn_bwd_dq"
     if n.startswith("attn_bwd_dkv"):

@@ -115,17 +115,21 @@ class BiModelDecoder(nn.Module):
         # the first layer's self-attention (ops.prefetch_kv); not while a greedy decode keeps its own cache of them
         C0, (Av, Va) = x
         s4 = None
+        mems = None
+        if Av.is_cuda and torch.is_grad_enabled() and len(self.decoder.layers) > 1 and ops.context().kv_cache is None:
+            mems = _LayerMemories(Av, Va, len(self.decoder.layers))
+            x = (C0, mems)
         if Av.is_cuda and ops.KV_PREFETCH and ops.context().kv_cache is None:
             s4 = ops.fork_side_stream(3, need=2)       # its own stream: a layer's video attention must not queue behind the next layer's projections
             if s4 is not None:
                 for t in (Av, Va):
                     t.record_stream(s4)
                 with torch.cuda.stream(s4):
-                    for layer in self.decoder.layers:
-                        layer.enc_att_V.prefetch_kv(Va)
-                        layer.enc_att_A.prefetch_kv(Av)
-        if Av.is_cuda and torch.is_grad_enabled() and len(self.decoder.layers) > 1 and ops.context().kv_cache is None:
-            x = (C0, _LayerMemories(Av, Va, len(self.decoder.layers)))
+                    for i, layer in enumerate(self.decoder.layers):
+                        # (the tensors layer i will be handed: its alias pair of the memories when the stack threads them through ops.fanout)
+                        Ai, Vi = mems._pairs[i] if (mems is not None and i < len(mems._pairs)) else (Av, Va)
+                        layer.enc_att_V.prefetch_kv(Vi)
+                        layer.enc_att_A.prefetch_kv(Ai)
         try:
             C, memory = self.decoder(x, masks)
         finally:
