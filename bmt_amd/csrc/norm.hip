@@ -78,8 +78,75 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
 }
 
+// the same computation with the row held in registers (D <= 2048, 16-byte aligned rows): ONE read of x instead of three (sum, variance,
+// output) -- same additions in the same order, so the same bits.  NV = ceil(D / 256) float4 groups per lane.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
+                                                          float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                          int64_t ldp, int pcols, int lo_f16) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float* yr = y ? y + (int64_t)row * ldy : nullptr;
+    uint16_t* hr = hi ? hi + (int64_t)row * ldp : nullptr;
+    uint16_t* lr = lo ? lo + (int64_t)row * ldp : nullptr;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = (c < D) ? ld4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < D) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            const float4 g = ld4(gamma + c), b = ld4(beta + c);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+            if (yr) *reinterpret_cast<float4*>(yr + c) = o;
+            if (hr) {
+                uint32_t h0, l0, h1, l1;
+                split_bf2(o.x, o.y, h0, l0);
+                split_bf2(o.z, o.w, h1, l1);
+                if (lo_f16) { l0 = pack_h2(o.x, o.y); l1 = pack_h2(o.z, o.w); }
+                *reinterpret_cast<uint2*>(hr + c) = make_uint2(h0, h1);
+                if (lr) *reinterpret_cast<uint2*>(lr + c) = make_uint2(l0, l1);
+            }
+        }
+    }
+    if (hr)
+        for (int c = D + lane; c < pcols; c += 64) {
+            hr[c] = 0;
+            if (lr) lr[c] = 0;
+        }
+}
+
 // rows each wave sweeps: sized so that a launch has ~512 workgroups (2 per CU); runtime parameter
-__host__ __device__ inline int ln_bwd_rows_per_wave(int rows) { const int r = (rows + 2047) / 2048; return r < 1 ? 1 : r; }
+static int ln_bwd_rows_per_wave(int rows) {
+    static const int waves = getenv("BMT_LN_BWD_WAVES") ? atoi(getenv("BMT_LN_BWD_WAVES")) : 2048;      // A/B: waves a launch aims for (2048 = 512 workgroups)
+    const int w = waves < 256 ? 256 : waves;
+    const int r = (rows + w - 1) / w;
+    return r < 1 ? 1 : r;
+}
 
 // NV = ceil(D / 256): float4 column groups per lane
 template <int NV>
@@ -280,7 +347,16 @@ extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (!y || (ldy % 4 == 0 && al16(y))) && al16(x) && al16(gamma) && al16(beta) &&
                      (!hi || ((ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0));
     dim3 grid(bmt_cdiv(rows, 4)), block(256);
-    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
+    static const int reg_env = getenv("BMT_LN_FWD_REG") ? atoi(getenv("BMT_LN_FWD_REG")) : 1;      // A/B: 0 = the three-read kernel
+#define BMT_LNF(NV) hipLaunchKernelGGL(ln_fwd_reg_kernel<NV>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16)
+    if (vec && reg_env && D <= 2048) {
+        const int nv = bmt_cdiv(D, 256);
+        if (nv <= 1) BMT_LNF(1);
+        else if (nv <= 2) BMT_LNF(2);
+        else if (nv <= 4) BMT_LNF(4);
+        else BMT_LNF(8);
+    } else if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
+#undef BMT_LNF
     else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
     BMT_CHECK_LAUNCH("bmt_layernorm_fwd");
     return BMT_OK;
