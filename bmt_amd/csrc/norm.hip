@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
 
 // rows each wave sweeps: sized so that a launch has ~512 workgroups (2 per CU); runtime parameter
 static int ln_bwd_rows_per_wave(int rows) {
-    static const int waves = getenv("BMT_LN_BWD_WAVES") ? atoi(getenv("BMT_LN_BWD_WAVES")) : 2048;      // A/B: waves a launch aims for (2048 = 512 workgroups)
+    static const int waves = getenv("BMT_LN_BWD_WAVES") ? atoi(getenv("BMT_LN_BWD_WAVES")) : 4096;      // waves a launch aims for: 4096 = 1024 workgroups (measured: 2048 / 4096 / 8192 -> 8.49-8.50 / 8.44-8.45 / 8.52-8.54 ms per step, profiles/r04_q_ab_ln.txt)
     const int w = waves < 256 ? 256 : waves;
     const int r = (rows + w - 1) / w;
     return r < 1 ? 1 : r;
