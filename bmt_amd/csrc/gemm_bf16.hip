@@ -1014,13 +1014,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // the column-block loop is unrolled (LDS offsets are immediates), the accumulator starts as the bias (alpha is 1 on this path), the
 // plane format is branched on, not selected, 32-bit store offsets, and the next block's fragments are requested before this block's
 // epilogue.
-template <bool F16, bool TWO, int NCB, bool LOADER>
+// PAIR: two 32-column blocks go through the wave's (8-KB) chunk together and leave as 8 rows x 64 columns per store instruction -- whole
+// 128-byte lines of a 16-bit plane, 256 bytes of a row of C -- instead of 16 rows x 32 columns (64-byte half lines: the launch wrote its
+// result at ~2.5 TB/s; gemm_wide_kernel's epilogue saw the same ceiling with 32-byte segments).
+template <bool F16, bool TWO, int NCB, bool LOADER, bool PAIR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k128_kernel(const GemmB p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int NCW = 32 * NCB, PLANE = NCW * 256, NPL = TWO ? 2 : 1;
     constexpr int NCMP = LOADER ? 7 : 8;                                                         // computing waves
-    constexpr int A_OFF = NPL * PLANE, CK_OFF = A_OFF + (LOADER ? NCMP * 8192 : 0), BIAS_OFF = CK_OFF + NCMP * 4096;   // LDS: weight chunk | round slot | turn chunks | bias
+    constexpr int CKB = PAIR ? 8192 : 4096;                                                      // a wave's turn chunk: [32 rows][32 | 64 columns] fp32
+    constexpr int A_OFF = NPL * PLANE, CK_OFF = A_OFF + (LOADER ? NCMP * 8192 : 0), BIAS_OFF = CK_OFF + NCMP * CKB;   // LDS: weight chunk | round slot | turn chunks | bias
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -1075,7 +1079,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
     // ================= the computing waves
-    char* ck = smem + CK_OFF + wid * 4096;
+    char* ck = smem + CK_OFF + wid * CKB;
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
     const int pcols = p.Chi ? p.plane_cols : 0;
     const int ncols = pcols > p.N ? pcols : p.N;
@@ -1107,6 +1111,118 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         BMT_K128_FRAGS(0);
         const int row_a = 32 * u + rsel;                   // pass 0 row of this lane (pass 1: + 16); a unit past u_end stores nothing
         const int m_lim = u < u_end ? p.M : 0;
+        if constexpr (PAIR) {
+            const int seg8 = lane & 7, rsel8 = lane >> 3;      // this lane's 8 columns of the pair's 64, its row within a pass of 8
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb += 2) {
+                if (cb < ncb) {
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {           // the pair's two blocks, one accumulator after the other (no extra registers)
+                        if (cb + hb < ncb) {
+                            f32x16 acc0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float4 bq = *reinterpret_cast<const float4*>(sbias + 32 * (cb + hb) + 8 * j + 4 * half);
+                                acc0[4 * j + 0] = bq.x; acc0[4 * j + 1] = bq.y; acc0[4 * j + 2] = bq.z; acc0[4 * j + 3] = bq.w;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (!(p.nk_dbg & 2)) {
+#pragma unroll
+                                for (int s = 0; s < 8; ++s) {
+                                    if constexpr (TWO) acc0 = mfma32t<F16>(wl[s], a[s], acc0);
+                                    acc0 = mfma32t<F16>(wh[s], a[s], acc0);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (cb + hb + 1 < NCB) {
+                                if (cb + hb + 1 < ncb) BMT_K128_FRAGS(cb + hb + 1);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            // chunk row l31 (256 B = 16 slots of 16 B, slot ^ (row & 15)): columns 32 hb + 8 j + 4 half .. + 3
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float4 t;
+                                t.x = acc0[4 * j + 0]; t.y = acc0[4 * j + 1]; t.z = acc0[4 * j + 2]; t.w = acc0[4 * j + 3];
+                                *reinterpret_cast<float4*>(ck + l31 * 256 + (((8 * hb + 2 * j + half) ^ (l31 & 15)) * 16)) = t;
+                            }
+                        }
+                    }
+                    const int col = n0 + 32 * cb + 8 * seg8;
+                    const bool in_n = col < p.N;
+                    const bool in_p = col < pcols;
+                    const bool in_pair = 8 * seg8 < 32 * min(2, ncb - cb);       // (an odd last block: the pair's second half was not computed)
+#pragma unroll 2
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int rl = 8 * ps + rsel8;
+                        const float4 t0 = *reinterpret_cast<const float4*>(ck + rl * 256 + (((2 * seg8) ^ (rl & 15)) * 16));
+                        const float4 t1 = *reinterpret_cast<const float4*>(ck + rl * 256 + (((2 * seg8 + 1) ^ (rl & 15)) * 16));
+                        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        const int row = 32 * u + rl;
+                        const bool rok = row < m_lim && in_pair;
+                        if (f & BMT_EPI_RELU) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        if (slow_epi) {
+                            const int64_t idx = (int64_t)row * p.ldc + col;
+                            if (f & BMT_EPI_DROP_PRE) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+                            }
+                            if (f & BMT_EPI_DROP_POST) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+                            }
+                            if ((f & BMT_EPI_GATE) && rok && in_n) {
+                                const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + (int64_t)row * p.ldg + col);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    v[2 * q] = (gv[q] & 0x00007FFFu) ? v[2 * q] * p.gate_scale : 0.f;
+                                    v[2 * q + 1] = (gv[q] & 0x7FFF0000u) ? v[2 * q + 1] * p.gate_scale : 0.f;
+                                }
+                            }
+                            if ((f & BMT_EPI_RESIDUAL) && rok && in_n) {
+                                const float* rp = p.residual + (int64_t)row * p.ldr + col;
+                                const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                            }
+                        }
+                        if (32 * (cb + 2) > p.N - n0) {
+                            if (!in_n) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                            }
+                        }
+                        if (p.C && !no_st) {
+                            const int vo = (rok && in_n) ? row * ldc4 + col * 4 : CLIP;
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsC, vo, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsC, vo, 16, 0);
+                        }
+                        if (p.Chi && !no_st) {
+                            const int vo = (rok && in_p) ? row * ldp2 + col * 2 : CLIP;
+                            if (p.hi_f16) {
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])}, rsH, vo, 0, 0);
+                            } else {
+                                u32x4 h, l;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    uint32_t h_, l_;
+                                    split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
+                                    h[q] = h_;
+                                    l[q] = l_;
+                                }
+                                __builtin_amdgcn_raw_buffer_store_b128(h, rsH, vo, 0, 0);
+                                if (p.Clo) {
+                                    if (p.second_f16) l = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
+                                    __builtin_amdgcn_raw_buffer_store_b128(l, rsL, vo, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             if (cb < ncb) {
@@ -1255,7 +1371,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else BMT_K128_W(dst_, 0);                                                                                    \
     } while (0)
         const int nst = no_st ? 0 : (p.C ? 2 : 0) + (p.Chi ? 1 : 0) + (p.Clo ? 1 : 0);      // store instructions per pass; 2 passes per block
-        const int kw = 2 * nst * ncb;                                                        // ... per unit
+        const int kw = PAIR ? 4 * nst * ((ncb + 1) >> 1) : 2 * nst * ncb;                    // ... per unit (PAIR: 4 passes per pair of blocks)
         int u = u0 + wid;
         BMT_K128_LDA(n0r, u);
         BMT_K128_LDA(n1r, u + 8);
@@ -1646,6 +1762,20 @@ int launch_wide(const GemmB& p, hipStream_t st) {
 
 template <bool F16, bool TWO, int NCB, bool LOADER>
 int launch_k128__(const GemmB& p, hipStream_t st) {
+    static const int pair_env = getenv("BMT_GEMM_K128_PAIR") ? atoi(getenv("BMT_GEMM_K128_PAIR")) : 1;      // A/B: 0 = 32-column blocks one at a time
+    if constexpr (!LOADER) {
+        if (pair_env) {
+            constexpr int lds2 = (TWO ? 2 : 1) * NCB * 32 * 256 + 8 * 8192 + NCB * 32 * 4;
+            static bool done2 = false;
+            if (!done2) {
+                (void)hipFuncSetAttribute((const void*)gemm_k128_kernel<F16, TWO, NCB, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                done2 = true;
+            }
+            hipLaunchKernelGGL((gemm_k128_kernel<F16, TWO, NCB, false, true>), dim3(p.tiles_n * p.nk_rg), dim3(512), lds2, st, p);
+            BMT_CHECK_LAUNCH("bmt_gemm_bf16(reduction of 128, paired blocks)");
+            return BMT_OK;
+        }
+    }
     constexpr int lds = (TWO ? 2 : 1) * NCB * 32 * 256 + (LOADER ? 7 * 8192 + 7 * 4096 : 8 * 4096) + NCB * 32 * 4;
     static bool done = false;
     if (!done) {
