@@ -9,7 +9,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void adam_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, int n_tensors,
                                                     const int64_t* __restrict__ step_dev, float lr, float beta1, float beta2, float eps,
-                                                    float weight_decay, const float* __restrict__ grad_scale) {
+                                                    float weight_decay, const float* __restrict__ grad_scale, int vec) {
     __shared__ float s_bc[2];
     const int t = blockIdx.y;
     if (threadIdx.x == 0) {
@@ -26,6 +26,33 @@ __global__ __launch_bounds__(256) void adam_kernel(void* const* __restrict__ ptr
     float* m = reinterpret_cast<float*>(ptrs[2 * n_tensors + t]);
     float* v = reinterpret_cast<float*>(ptrs[3 * n_tensors + t]);
     const int64_t n = sizes[t];
+    // four elements per thread and instruction where the tensor allows it (16-byte aligned, a multiple of 4 elements: every weight matrix and
+    // all but a few odd-sized vectors) -- the same arithmetic per element
+    if (vec && (n & 3) == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(p);
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const float4 gq = g4[i], pq = p4[i], mq = m4[i], vq = v4[i];
+            float ge[4] = {gq.x * gs, gq.y * gs, gq.z * gs, gq.w * gs};
+            const float pe[4] = {pq.x, pq.y, pq.z, pq.w}, me[4] = {mq.x, mq.y, mq.z, mq.w}, ve[4] = {vq.x, vq.y, vq.z, vq.w};
+            float po[4], mo[4], vo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (weight_decay != 0.f) ge[q] = __fmaf_rn(weight_decay, pe[q], ge[q]);
+                mo[q] = me[q] + (ge[q] - me[q]) * (1.f - beta1);
+                vo[q] = ve[q] * beta2 + (1.f - beta2) * ge[q] * ge[q];
+                const float denom = sqrtf(vo[q]) / bc2_sqrt + eps;
+                po[q] = pe[q] - step_size * (mo[q] / denom);
+            }
+            p4[i] = make_float4(po[0], po[1], po[2], po[3]);
+            m4[i] = make_float4(mo[0], mo[1], mo[2], mo[3]);
+            v4[i] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * gs;
         const float pi = p[i];
@@ -84,8 +111,9 @@ extern "C" int bmt_adam_step(void* const* ptrs, const int64_t* sizes, int n_tens
     BMT_CHECK_ARG(ptrs && sizes && step_dev && n_tensors > 0 && n_tensors <= 65535 && max_size > 0, "bmt_adam_step: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, st, step_dev);
+    static const int vec = getenv("BMT_ADAM_VEC") ? atoi(getenv("BMT_ADAM_VEC")) : 1;      // A/B: 0 = one element per thread and instruction
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(max_size), n_tensors), dim3(256), 0, st, ptrs, sizes, n_tensors, step_dev, lr, beta1,
-                       beta2, eps, weight_decay, grad_scale_dev);
+                       beta2, eps, weight_decay, grad_scale_dev, vec);
     BMT_CHECK_LAUNCH("bmt_adam_step");
     return BMT_OK;
 }
