@@ -197,7 +197,7 @@ __device__ __forceinline__ bf16x8 km_frag_sw(const char* img, int off, int k16) 
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false, int TAG = 0>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
-    static_assert(!PIPE || (WM == 4 && CONV == 0 && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && TI == 1))),
+    static_assert(!PIPE || (WM == 4 && (CONV == 0 || (CONV == 1 && TI == 1)) && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && TI == 1))),
                   "pipelined loop: 8 waves; k-major operands on the one-plane 128-row tile");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = gemm_bk(NPASS, PIPE, TI);
@@ -367,7 +367,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             } else {
                 const int row = (wid_s * APW + i) * RPP + rl;
                 const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
-                avo[i] = (int)((int64_t)min(m0 + row, p.M - 1) * p.lda * 2) + ks * 16;
+                int grow = min(m0 + row, p.M - 1);
+                if constexpr (CONV == 1) grow += 2 * (grow / p.conv_S) * p.conv_halo;      // output row b S + s reads plane row (+ tap, per step)
+                avo[i] = (int)((int64_t)grow * p.lda * 2) + ks * 16;
             }
         }
 #pragma unroll
@@ -386,7 +388,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         do {                                                                                                     \
             char* base_ = smem + (slot_) * STAGE_BYTES;                                                          \
             const int k_ = kbeg + (step_) * BK;                                                                  \
-            const int so_ = AKM ? k_ * (int)p.lda * 2 : k_ * 2, sob_ = BKM ? k_ * (int)p.ldb * 2 : k_ * 2;       \
+            const int so_ = (CONV == 1) ? ((k_ / p.conv_cin) * (int)p.lda + k_ % p.conv_cin) * 2 : (AKM ? k_ * (int)p.lda * 2 : k_ * 2);  \
+            const int sob_ = BKM ? k_ * (int)p.ldb * 2 : k_ * 2;                                                 \
             _Pragma("unroll") for (int i = 0; i < APW; ++i)                                                      \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base_ + (wid_s * APW + i) * 1024), 16, avo[i], so_, 0, 0);          \
             _Pragma("unroll") for (int i = 0; i < BPW; ++i)                                                      \
@@ -653,13 +656,13 @@ template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_bf16_kernel(const GemmB p) {
     gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, CONV, F16>(p, blockIdx.x, blockIdx.y);
 }
-template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false>
+template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false, int CONV = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_pipe_kernel(const GemmB p) {
     // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so a workgroup stays on
     // the XCD its tiles were ordered for); its stores drain while the next tile's operands are already on their way
     const int ntiles = p.tiles_m * p.tiles_n;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        gemm_bf16_tile<NPASS, 4, TI, AKM, BKM, 0, F16, true, 1>(p, t, (int)blockIdx.y, false);
+        gemm_bf16_tile<NPASS, 4, TI, AKM, BKM, CONV, F16, true, 1>(p, t, (int)blockIdx.y, false);
         __syncthreads();          // the stage buffers (epilogue tile) are free again
     }
 }
@@ -1727,7 +1730,7 @@ int launch(const GemmB& p, int splitk, hipStream_t st) {
     return BMT_OK;
 }
 
-template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false>
+template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false, int CONV = 0>
 int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int BK = gemm_bk(NPASS, true, TI);
     constexpr int BMr = 128 * TI;
@@ -1736,13 +1739,13 @@ int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
     constexpr int lds = (R * stage > BMr * BN * 4) ? R * stage : BMr * BN * 4;
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
     static const int persist = getenv("BMT_GEMM_PERSIST") ? atoi(getenv("BMT_GEMM_PERSIST")) : 1;      // A/B experiments only
     const int tiles = p.tiles_m * p.tiles_n, slots = bmt_device_cus() * (TI == 2 ? 1 : 2);
     const int gx = (persist && tiles > slots && slots % 8 == 0) ? slots : tiles;
-    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM>), dim3(gx, splitk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM, CONV>), dim3(gx, splitk), dim3(512), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(pipelined)");
     return BMT_OK;
 }
@@ -2000,6 +2003,8 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     static const int km_pipe_env = getenv("BMT_GEMM_KM_PIPE") ? atoi(getenv("BMT_GEMM_KM_PIPE")) : 0;      // A/B experiments only
     const bool km_pipe = km_pipe_env && a->conv_mode == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0;
     const bool f16 = a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2;
+    // implicit Conv1d forward / dX on the LDS-DMA pipelined loop (the A rows shift by a tap per step: one scalar offset)
+    static const int conv_pipe = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 0;      // A/B experiments
     if (f16 && (akm || bkm || a->conv_mode == 2)) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
         return BMT_EINVAL;
@@ -2021,6 +2026,10 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 1>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 1>(p, splitk, st_);
         else rc = launch_pipe<1, false, 1>(p, splitk, st_);
+    } else if (a->conv_mode == 1 && conv_pipe && a->precision != BMT_PREC_BF16X3) {      // ... through the LDS-DMA ring (128-row tile, two workgroups per CU)
+        if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_);
+        else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);
+        else rc = launch_pipe<1, false, 1, false, false, 1>(p, splitk, st_);
     } else if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
         if (a->precision == BMT_PREC_F16W2) rc = launch<2, 4, 1, false, false, 1, true>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch<1, 4, 1, false, false, 1, true>(p, splitk, st_);
