@@ -197,7 +197,7 @@ __device__ __forceinline__ bf16x8 km_frag_sw(const char* img, int off, int k16) 
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false, int TAG = 0>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
-    static_assert(!PIPE || (WM == 4 && (CONV == 0 || (CONV == 1 && TI == 1)) && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && TI == 1))),
+    static_assert(!PIPE || (WM == 4 && (CONV == 0 || CONV == 1) && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && TI == 1))),
                   "pipelined loop: 8 waves; k-major operands on the one-plane 128-row tile");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = gemm_bk(NPASS, PIPE, TI);
@@ -1885,11 +1885,17 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         const int t256 = bmt_cdiv(a->M, 256) * p.tiles_n, cus = bmt_device_cus();
         if (t256 >= cus && (t256 % cus == 0 || tall_any)) p.pipe = 1;
     }
+    // implicit Conv1d forward on the pipelined loop (bmt_gemm_bf16: BMT_CONV_PIPE): 2 = 256 x 128 tiles (64 reduction indices per step) where
+    // that is at least one tile per CU
+    static const int conv_pipe_p = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 0;
+    if (conv_pipe_p == 2 && a->conv_mode == 1 && (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2) &&
+        bmt_cdiv(a->M, 256) * p.tiles_n >= bmt_device_cus())
+        p.pipe = 1;
     if (force_pipe == 0) p.pipe = 0;
     if (force_pipe >= 1 && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = force_pipe;   // 1: 256-row tile, 2: 128-row tile
     // the 256 x 256 ping-pong kernel: row-major operands, plain epilogues (no column sums / accumulation / split-K)
     static const int force_wide = getenv("BMT_GEMM_WIDE") ? atoi(getenv("BMT_GEMM_WIDE")) : -1;    // A/B experiments only
-    const bool wide_ok = p.pipe != 0 && !a->colsum && !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && a->N >= 256 &&
+    const bool wide_ok = p.pipe != 0 && !a->conv_mode && !a->colsum && !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && a->N >= 256 &&
                          (int64_t)(a->M + 256) * a->lda * 2 < (1ll << 31) && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31);
     // measured (tools/microbench.py gemm, BMT_GEMM_WIDE=0/1): it wins where a launch has at least one full round of 256 x 256
     // tiles and a reduction long enough to amortise its prologue (8192 x 4096 x 1024 two-plane 169 -> 134 us, 8192 x 2048 x 1024
@@ -2018,6 +2024,9 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
     } else if (p.pipe == 4) {
         rc = f16 ? launch_k128<true>(p, st_) : launch_k128<false>(p, st_);
+    } else if (a->conv_mode == 1 && conv_pipe && f16) {      // the Conv1d forward products through the LDS-DMA ring: 128-row tile (two workgroups per CU) / 256-row tile
+        if (p.bm == 256) rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 2, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 2, false, false, 1>(p, splitk, st_);
+        else rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);
     } else if (p.pipe == 1) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 2>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 2>(p, splitk, st_);
@@ -2026,10 +2035,6 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 1>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 1>(p, splitk, st_);
         else rc = launch_pipe<1, false, 1>(p, splitk, st_);
-    } else if (a->conv_mode == 1 && conv_pipe && a->precision != BMT_PREC_BF16X3) {      // ... through the LDS-DMA ring (128-row tile, two workgroups per CU)
-        if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_);
-        else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);
-        else rc = launch_pipe<1, false, 1, false, false, 1>(p, splitk, st_);
     } else if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
         if (a->precision == BMT_PREC_F16W2) rc = launch<2, 4, 1, false, false, 1, true>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch<1, 4, 1, false, false, 1, true>(p, splitk, st_);
