@@ -1887,8 +1887,9 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     }
     // implicit Conv1d forward on the pipelined loop (bmt_gemm_bf16: BMT_CONV_PIPE): 2 = 256 x 128 tiles (64 reduction indices per step) where
     // that is at least one tile per CU
-    static const int conv_pipe_p = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 0;
-    if (conv_pipe_p == 2 && a->conv_mode == 1 && (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2) &&
+    static const int conv_pipe_p = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 2;
+    if (conv_pipe_p >= 2 && a->conv_mode == 1 && !a->a_kmajor && !a->b_kmajor &&
+        (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2 || (conv_pipe_p >= 3 && a->precision == BMT_PREC_BF16)) &&
         bmt_cdiv(a->M, 256) * p.tiles_n >= bmt_device_cus())
         p.pipe = 1;
     if (force_pipe == 0) p.pipe = 0;
@@ -2010,7 +2011,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     const bool km_pipe = km_pipe_env && a->conv_mode == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0;
     const bool f16 = a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2;
     // implicit Conv1d forward / dX on the LDS-DMA pipelined loop (the A rows shift by a tap per step: one scalar offset)
-    static const int conv_pipe = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 0;      // A/B experiments
+    static const int conv_pipe = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 2;      // 0: register-staged loop; 1: 128-row tiles; 2: 256-row tiles where they fill the chip (measured: train_prop 57.9 / 57.1 / 53.8 ms, profiles/r04_t_ab_conv_pipe2.txt); 3: also the dX products
     if (f16 && (akm || bkm || a->conv_mode == 2)) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
         return BMT_EINVAL;
@@ -2024,6 +2025,8 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
     } else if (p.pipe == 4) {
         rc = f16 ? launch_k128<true>(p, st_) : launch_k128<false>(p, st_);
+    } else if (a->conv_mode == 1 && conv_pipe >= 3 && a->precision == BMT_PREC_BF16 && p.bm == 256 && !akm && !bkm) {      // (the dX products: A/B)
+        rc = launch_pipe<1, false, 2, false, false, 1>(p, splitk, st_);
     } else if (a->conv_mode == 1 && conv_pipe && f16) {      // the Conv1d forward products through the LDS-DMA ring: 128-row tile (two workgroups per CU) / 256-row tile
         if (p.bm == 256) rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 2, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 2, false, false, 1>(p, splitk, st_);
         else rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);
