@@ -197,7 +197,7 @@ __device__ __forceinline__ bf16x8 km_frag_sw(const char* img, int off, int k16) 
 template <int NPASS, int WM, int TI, bool AKM, bool BKM, int CONV = 0, bool F16 = false, bool PIPE = false, int TAG = 0>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id, const int split_id, const bool raw_order = false) {
     static_assert(NPASS == 1 || (!AKM && !BKM), "k-major operands: single-pass kernel only");
-    static_assert(!PIPE || (WM == 4 && (CONV == 0 || CONV == 1) && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && TI == 1))),
+    static_assert(!PIPE || (WM == 4 && (CONV == 0 || CONV == 1) && NPASS <= 2 && (!(AKM || BKM) || (NPASS == 1 && (TI == 1 || (!AKM && BKM))))),
                   "pipelined loop: 8 waves; k-major operands on the one-plane 128-row tile");
     static_assert(CONV == 0 || (CONV == 1 && !AKM && !BKM) || (CONV == 2 && AKM && BKM), "conv modes: row-major A, or k-major A and B");
     constexpr int BK = gemm_bk(NPASS, PIPE, TI);
@@ -1892,11 +1892,18 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2 || (conv_pipe_p >= 3 && a->precision == BMT_PREC_BF16)) &&
         bmt_cdiv(a->M, 256) * p.tiles_n >= bmt_device_cus())
         p.pipe = 1;
+    // dX = dY . W (the weight plane k-major) on the pipelined 256 x 128 tile: row-major gradient rows by LDS-DMA as in the forward, the weight's
+    // [64 reduction rows][128 columns] image by the k-major DMA + transposing reads, a ring of three steps at one workgroup per CU
+    static const int dx_pipe = getenv("BMT_DX_PIPE") ? atoi(getenv("BMT_DX_PIPE")) : 0;      // A/B experiments
+    if (dx_pipe && a->b_kmajor && !a->a_kmajor && !a->conv_mode && a->precision == BMT_PREC_BF16 && a->Kpad >= 256 && a->splitk <= 1 &&
+        a->lda % 8 == 0 && a->ldb % 8 == 0 && bmt_cdiv(a->M, 256) * p.tiles_n >= bmt_device_cus() &&
+        (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->K * a->ldb * 2 < (1ll << 31))
+        p.pipe = 1;
     if (force_pipe == 0) p.pipe = 0;
     if (force_pipe >= 1 && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = force_pipe;   // 1: 256-row tile, 2: 128-row tile
     // the 256 x 256 ping-pong kernel: row-major operands, plain epilogues (no column sums / accumulation / split-K)
     static const int force_wide = getenv("BMT_GEMM_WIDE") ? atoi(getenv("BMT_GEMM_WIDE")) : -1;    // A/B experiments only
-    const bool wide_ok = p.pipe != 0 && !a->conv_mode && !a->colsum && !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && a->N >= 256 &&
+    const bool wide_ok = p.pipe != 0 && !a->conv_mode && !a->a_kmajor && !a->b_kmajor && !a->colsum && !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && a->N >= 256 &&
                          (int64_t)(a->M + 256) * a->lda * 2 < (1ll << 31) && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31);
     // measured (tools/microbench.py gemm, BMT_GEMM_WIDE=0/1): it wins where a launch has at least one full round of 256 x 256
     // tiles and a reduction long enough to amortise its prologue (8192 x 4096 x 1024 two-plane 169 -> 134 us, 8192 x 2048 x 1024
@@ -2030,6 +2037,8 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     } else if (a->conv_mode == 1 && conv_pipe && f16) {      // the Conv1d forward products through the LDS-DMA ring: 128-row tile (two workgroups per CU) / 256-row tile
         if (p.bm == 256) rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 2, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 2, false, false, 1>(p, splitk, st_);
         else rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);
+    } else if (p.pipe == 1 && bkm && !akm) {      // dX on the pipelined 256 x 128 tile (gemm_prepare: BMT_DX_PIPE)
+        rc = launch_pipe<1, false, 2, false, true>(p, splitk, st_);
     } else if (p.pipe == 1) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 2>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 2>(p, splitk, st_);

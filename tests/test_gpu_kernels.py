@@ -833,6 +833,30 @@ def test_planes_of_a_dropped_gradient(ops, R, C):
     assert_close(cs1, cs0, atol=1e-4, rtol=1e-5, name="colsum")
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 1024), (8192, 1024, 3072), (8200, 4096, 1024), (25600, 1024, 320)])
+def test_dx_of_the_encoder_sized_products(ops, M, N, K):
+    """dX = dY . W at the encoder's sizes (M rows, N outputs, reduction K): fp32 output against fp64 on the bf16-rounded operands, and the
+    plane-only output with a gate and column sums against the fp32 one -- the shapes that fill the chip with 256-row tiles (the pipelined
+    dX tile of BMT_DX_PIPE) as well as the 128-row tiles'"""
+    dy, W = rnd(M, K, seed=21).to(DEV), (rnd(K, N, seed=22) * 0.05).to(DEV)
+    dyP = ops.make_planes(dy, "bwd")
+    dx = ops.linear_dx(dyP, W)
+    want = bf16_round(dy.cpu()).double() @ bf16_round(W.cpu()).double()
+    assert_close(dx, want, atol=2e-4 * math.sqrt(K), rtol=1e-4, name="dx")
+    hid = torch.relu(rnd(M, N, seed=23)).to(DEV)
+    hid[:, ::7] = 0
+    h = ops.make_planes(hid, "bwd")
+    gated = ops.linear_dx(dyP, W, gate=h, gate_scale=1.25)
+    op = ops.Planes(torch.full((M, ops._pad64(N)), 3.0, device=DEV, dtype=torch.bfloat16), None, M, N)
+    cs = torch.zeros(N, device=DEV)
+    ops.linear_dx(dyP, W, out_planes=op, gate=h, gate_scale=1.25, colsum=cs)
+    got = op.hi[:, :N].float()
+    assert torch.equal(got == 0, gated == 0)
+    assert_close(got, gated, atol=1e-6, rtol=2 ** -7, name="gated plane output")
+    ref = gated.double().sum(0)
+    assert_close(cs, ref, atol=2e-3 * float(ref.abs().max()) + 1e-3, name="column sums")
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 4096, 1024), (130, 200, 96), (128, 1024, 64)])
 def test_gemm_plane_output_with_vector_gate_and_column_sums(ops, M, N, K):
     """dX GEMM of the FFN backward: plane-only output, relu/dropout gate applied per 16-byte segment from the saved hidden plane,
