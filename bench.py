@@ -412,7 +412,7 @@ def pmc_keys_of_class(cls: str):
     return (cls,)
 
 
-def pmc_record():
+def pmc_record(procedure=None):
     """the newest committed PMC pass (profiles/*pmc_traffic.json, written by tools/gpu_pmc_bench.sh: FETCH_SIZE / WRITE_SIZE / SQ
     counters in separate rocprofv3 --pmc passes over this same step, gfx950 FETCH correction applied).  The counters cannot be
     read from inside the process that runs the step, so this is a recorded measurement; it is REFUSED when the kernel sources
@@ -427,6 +427,9 @@ def pmc_record():
             rec = json.load(f)
     except (OSError, ValueError):
         return None, f"profiles/{name}: unreadable"
+    # a record is a pass over ONE procedure's step: the other procedure's launches (other shapes, the Conv1d kernels) are not in it
+    if procedure is not None and rec.get("procedure") not in (None, procedure):
+        return None, f"profiles/{name} is a pass over the {rec.get('procedure')} step; none committed for {procedure} (tools/gpu_pmc_bench.sh <tag> {procedure})"
     want, have = rec.get("csrc_digest"), csrc_digest()
     if want != have:
         return None, f"profiles/{name} was taken with kernel sources {want}, the tree is {have}: stale, refused"
@@ -896,7 +899,7 @@ def main():
             dom = max(cand, key=lambda k: cand[k]["ms"])
             d = cand[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            rec, rec_note = pmc_record()
+            rec, rec_note = pmc_record(args.procedure)
             fam = [(rec or {}).get("kernels", {}).get(k) for k in pmc_keys_of_class(dom)]
             kern = None
             if fam and all(fam):        # per launch of the class: the sum over its kernels (families mix encoder and decoder sizes)

@@ -82,6 +82,11 @@ def test_pmc_record_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     (prof / "r99_pmc_traffic.json").write_text(json.dumps({"csrc_digest": "aaaa", "kernels": {"gemm_w2": {"traffic_bytes": 1.0}}}))
     rec, note = bench.pmc_record()
     assert rec["kernels"]["gemm_w2"]["traffic_bytes"] == 1.0 and "aaaa" in note
+    # ... and to the procedure it was taken over: a train_cap pass says nothing about train_prop's launches
+    (prof / "r99_pmc_traffic.json").write_text(json.dumps({"csrc_digest": "aaaa", "procedure": "train_cap", "kernels": {"gemm_w2": {"traffic_bytes": 1.0}}}))
+    assert bench.pmc_record("train_cap")[0] is not None
+    rec, note = bench.pmc_record("train_prop")
+    assert rec is None and "train_prop" in note
 
 
 def test_kernel_classes_map_to_pmc_families():
