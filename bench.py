@@ -370,6 +370,12 @@ def PMC_FAMILY_OF_KERNEL(name: str) -> str:
     n = re.sub(r"^void ", "", n)
     if n.startswith("gemm_bf16_grouped_kernel"):
         return "gemm_dw_grouped"
+    # implicit Conv1d launches (CONV, the sixth template argument, is 1 or 2): families of their own -- the proposal heads' k-tap products
+    m = re.match(r"gemm_(?:bf16_kernel<(\d), \d, \d, (?:true|false), (?:true|false), ([12])|pipe_kernel<(\d), (?:true|false), \d, (?:true|false), (?:true|false), ([12]))", n)
+    if m:
+        npass = m.group(1) or m.group(3)
+        f16 = ("true>" in n.split("(")[0][-8:]) if n.startswith("gemm_bf16_kernel") else bool(re.match(r"gemm_pipe_kernel<\d, true", n))
+        return {"1": "conv_f16" if f16 else "conv_bf16", "2": "conv_w2", "3": "conv_x3"}[npass]
     if re.match(r"gemm_bf16_kernel<1, \d, \d, false, false, \d, true", n) or re.match(r"gemm_pipe_kernel<1, true", n):
         return "gemm_f16"
     m = re.match(r"gemm_(?:bf16|pipe)_kernel<(\d)", n)
@@ -399,6 +405,12 @@ def pmc_keys_of_class(cls: str):
         return ("attn_fwd",)
     if cls.startswith("attn_bwd"):
         return ("attn_bwd_dq", "attn_bwd_dkv")
+    if cls.startswith("conv_"):
+        if cls.endswith("bf16x3"):
+            return ("conv_x3",)
+        if "(fp16 hi+lo)" in cls:
+            return ("conv_w2",)
+        return ("conv_f16",) if cls.endswith("_fp16") else ("conv_bf16",)
     if "dw_grouped" in cls:
         return ("gemm_dw_grouped",)
     if cls.endswith("bf16x3"):
@@ -421,15 +433,22 @@ def pmc_record(procedure=None):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None, "no PMC pass committed"
-    name = os.path.basename(files[-1])
-    try:
-        with open(files[-1]) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None, f"profiles/{name}: unreadable"
-    # a record is a pass over ONE procedure's step: the other procedure's launches (other shapes, the Conv1d kernels) are not in it
-    if procedure is not None and rec.get("procedure") not in (None, procedure):
-        return None, f"profiles/{name} is a pass over the {rec.get('procedure')} step; none committed for {procedure} (tools/gpu_pmc_bench.sh <tag> {procedure})"
+    # a record is a pass over ONE procedure's step (the other procedure's launches -- other shapes, the Conv1d kernels -- are not in it): the
+    # newest one taken over this procedure
+    rec = name = None
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                r = json.load(f)
+        except (OSError, ValueError):
+            if path == files[-1] and procedure is None:
+                return None, f"profiles/{os.path.basename(path)}: unreadable"
+            continue
+        if procedure is None or r.get("procedure") in (None, procedure):
+            rec, name = r, os.path.basename(path)
+            break
+    if rec is None:
+        return None, f"no PMC pass over the {procedure} step committed (tools/gpu_pmc_bench.sh <tag> {procedure})"
     want, have = rec.get("csrc_digest"), csrc_digest()
     if want != have:
         return None, f"profiles/{name} was taken with kernel sources {want}, the tree is {have}: stale, refused"

@@ -93,6 +93,12 @@ def test_kernel_classes_map_to_pmc_families():
     import bench
     fam = bench.PMC_FAMILY_OF_KERNEL
     assert fam("void (anonymous namespace)::gemm_pipe_kernel<2, true, 1, false, false>((anonymous namespace)::GemmB)") == "gemm_w2"
+    assert fam("void (anonymous namespace)::gemm_pipe_kernel<2, true, 2, false, false, 1>((anonymous namespace)::GemmB)") == "conv_w2"
+    assert fam("void (anonymous namespace)::gemm_pipe_kernel<2, true, 2, false, false, 0>((anonymous namespace)::GemmB)") == "gemm_w2"
+    assert fam("gemm_bf16_kernel<1, 4, 1, true, true, 2, false>(GemmB)") == "conv_bf16"
+    assert fam("gemm_bf16_kernel<3, 4, 1, false, false, 1, false>(GemmB)") == "conv_x3"
+    assert fam("gemm_bf16_kernel<1, 4, 1, false, true, 0, false>(GemmB)") == "gemm_bf16"
+    assert bench.pmc_keys_of_class("conv_planes_fp16 x (fp16 hi+lo)") == ("conv_w2",) and bench.pmc_keys_of_class("conv_planes_bf16") == ("conv_bf16",)
     assert fam("gemm_wide_kernel<true>(GemmB)") == "gemm_w2"
     assert fam("gemm_bf16_kernel<1, 4, 1, false, true, 0, false>(GemmB)") == "gemm_bf16"
     assert fam("gemm_bf16_kernel<3, 4, 1, false, false, 0, false>(GemmB)") == "gemm_x3"
