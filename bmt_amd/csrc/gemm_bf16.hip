@@ -37,6 +37,7 @@ struct GemmB {
     int conv_cin;                        // > 0: implicit Conv1d, channels per tap (padded width of the activation plane); see bmt_gemm_bf16_args
     int conv_rows;                       // rows of the halo-padded activation plane reachable from its base pointer
     int conv_S, conv_halo;               // sequence length and halo rows on each side of a sequence
+    int conv_tap_minor;                  // Conv1d dW: column tiles in (channel block, tap) order instead of (tap, channel block)
     int krows;                           // k-major operands: valid rows (the true reduction length); rows [krows, Kpad) read as 0
     float alpha;
     unsigned flags;
@@ -223,7 +224,19 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     const int gsz = min(p.tiles_m - first_m, GM);
     const int wi = w - g * per_group;
     const int tm = first_m + wi % gsz, tn = wi / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM;
+    int n0_ = tn * BN;
+    if constexpr (CONV == 2) {
+        // Conv1d dW: output column block = (tap, 128 channels).  Walk the TAPS of one channel block before the next channel block, so that the
+        // tiles an XCD runs together read the same rows of the activation plane, shifted by a tap each: one fetch serves a whole run of taps
+        // (tap-major order shared a block between two taps only: the launch fetched 3.5 GB at 4.6 TB/s, profiles/r04_w_prop_pmc_traffic.json)
+        const int nb = p.conv_cin / BN;
+        if (p.conv_tap_minor && nb > 0 && p.tiles_n % nb == 0) {
+            const int taps = p.tiles_n / nb;
+            n0_ = (tn % taps) * p.conv_cin + (tn / taps) * BN;
+        }
+    }
+    const int n0 = n0_;
     const int kbeg = split_id * p.kchunk;
     const int kend = min(p.Kpad, kbeg + p.kchunk);
 
@@ -1861,6 +1874,8 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.plane_vec = p.Chi && al16(p.Chi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
+    static const int tap_minor = getenv("BMT_CONV_DW_TAP_MINOR") ? atoi(getenv("BMT_CONV_DW_TAP_MINOR")) : 1;      // A/B: 0 = tap-major column tiles
+    p.conv_tap_minor = (a->conv_mode == 2 && a->conv_cin % BN == 0) ? tap_minor : 0;
     p.tiles_n = bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
     // tile height: 256 rows (8 waves, one workgroup per CU) when that still fills the chip, else 128 rows (4 waves, two per CU)
     static const int force_bm = getenv("BMT_GEMM_BM") ? atoi(getenv("BMT_GEMM_BM")) : 0;      // A/B experiments only
