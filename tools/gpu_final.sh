@@ -12,6 +12,9 @@ cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 grep "bench\]" gpurun_out/${TAG}_bench.err | tail -5
 python tools/bench_summary.py gpurun_out/${TAG}_bench.json
+# train_prop has a PMC record of its own (bench.py takes the newest record taken over the procedure it runs)
+bash tools/gpu_pmc_bench.sh ${TAG}_prop train_prop 2>&1 | grep -i "conv\|pass"
+cp gpurun_out/${TAG}_prop_pmc_traffic.json profiles/${TAG}_prop_pmc_traffic.json
 timeout 300 python bench.py --procedure train_prop --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_train_prop.json 2> gpurun_out/${TAG}_prop.err; echo "train_prop rc=$?"
 python tools/bench_summary.py gpurun_out/${TAG}_bench_train_prop.json | head -10
 bash tools/gpu_prof.sh $TAG 6 2>&1 | head -40
