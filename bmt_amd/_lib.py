@@ -25,7 +25,8 @@ class GemmBf16Args(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32),
-                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp)]
+                ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp),
+                ("rows_dev", vp)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -54,7 +55,7 @@ class AttnFwdBf16Args(C.Structure):
                 ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
                 ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32),
-                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64), ("Of", vp)]
+                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64), ("Of", vp), ("q_off", vp), ("k_off", vp)]
 
 
 class AttnBwdBf16Args(C.Structure):
@@ -69,7 +70,7 @@ class AttnBwdBf16Args(C.Structure):
                 ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
                 ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32),
-                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32)]
+                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32), ("q_off", vp), ("k_off", vp)]
 
 
 class CopyItem(C.Structure):
@@ -91,12 +92,12 @@ PP_CORNERS, PP_TRIM, PP_FILTER = 1, 2, 4
 # name -> (restype, argtypes); every symbol include/bmt_hip.h declares
 SIGNATURES = {
     "bmt_version": (i32, []),
-    "bmt_attn_kmean": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
+    "bmt_attn_kmean": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp, vp]),
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
-    "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp]),
-    "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp]),
-    "bmt_layernorm_bwd_add": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp]),
+    "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp, vp]),
+    "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp, vp]),
+    "bmt_layernorm_bwd_add": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp, vp]),
     "bmt_npy_shape": (i32, [C.c_char_p, vp, vp, vp]),
     "bmt_npy_read_rows": (i32, [C.c_char_p, i64, i64, vp, i64, vp, vp]),
     "bmt_pad_batch": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
@@ -107,17 +108,17 @@ SIGNATURES = {
     "bmt_device_cus": (i32, []),
     "bmt_gemm_bf16": (i32, [C.POINTER(GemmBf16Args), vp]),
     "bmt_pad_planes": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i64, vp]),
-    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp]),
+    "bmt_planes": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp]),
     "bmt_planes_desc_bytes": (i32, []),
     "bmt_planes_desc": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64]),
     "bmt_planes_multi": (i32, [vp, i32, vp]),
     "bmt_planes_desc_tiles": (i32, [vp]),
     "bmt_planes_multi_flat": (i32, [vp, vp, i32, i32, vp]),
     "bmt_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
-    "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "bmt_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp, vp]),
     "bmt_colsum_multi": (i32, [vp, i32, vp]),
     "bmt_copy_multi": (i32, [vp, i32, vp]),
-    "bmt_layernorm_bwd_partial": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, vp]),
+    "bmt_layernorm_bwd_partial": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, vp, vp]),
     "bmt_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "bmt_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "bmt_attn_fwd_bf16": (i32, [C.POINTER(AttnFwdBf16Args), vp]),
@@ -128,6 +129,8 @@ SIGNATURES = {
     "bmt_layernorm_bwd_blocks": (i32, [i32]),
     "bmt_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, i32, vp]),
     "bmt_prep_features": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, u32, vp]),
+    "bmt_pack_rows": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "bmt_prep_features_packed": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, u32, vp, vp, vp]),
     "bmt_prep_embed": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, u32, vp]),
     "bmt_prep_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, u32, vp]),
     "bmt_mask_from_features": (i32, [vp, i64, i64, f32, vp, i32, i32, vp]),
@@ -155,8 +158,8 @@ SIGNATURES = {
     "bmt_split2": (i32, [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp]),
     "bmt_caption_shift": (i32, [vp, i64, i32, i32, i64, vp, vp, vp, vp]),
     "bmt_loss_finish": (i32, [vp, vp, vp, vp, vp]),
-    "bmt_layernorm_bwd_partial2": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
-    "bmt_layernorm_bwd_emit": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, f32, vp, u32, i32, i32, vp]),
+    "bmt_layernorm_bwd_partial2": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp, vp]),
+    "bmt_layernorm_bwd_emit": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, f32, vp, u32, i32, i32, vp, vp]),
     "bmt_adam_step": (i32, [vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, vp, vp]),
     "bmt_grad_sqnorm": (i32, [vp, vp, i32, i64, vp, f32, vp, vp]),
     "bmt_scale_tensors": (i32, [vp, vp, i32, i64, vp, vp]),
@@ -184,8 +187,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 6:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 6")
+    if lib.bmt_version() != 7:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 7")
     _lib = lib
     return lib
 

@@ -178,8 +178,57 @@ struct AttnPB {
     // emits nothing, the dK / dV loop ends at the last live 32-query stage.  Data-driven, so a caller whose padded rows DO carry gradient
     // loses nothing but the shortcut.  nullptr: off.
     int* qlive;
-    int remnant_last;                          // split backward: the remnant tile of a sequence at the end of every XCD's work range (A/B switch)
+    // PACKED ROWS (ABI 7; bmt_attn_fwd_bf16_args.q_off / k_off): the valid positions of a ragged batch are stored compacted -- sample b's query
+    // rows are rows q_off[b] .. q_off[b + 1] - 1 of every query-side plane (its key rows k_off[b] ..), nothing is masked.  SqP / SkP keep the
+    // PADDED extents the launch was sized for: they map workgroups to (batch, head, tile) and index what stays per padded position
+    // (lse, delta, the split backward's workspaces, the per-tile bias partials); attn_rebase turns Sq / Sk into this sample's lengths.
+    const int *q_off, *k_off;
+    int SqP, SkP;
+    int64_t drop_off;                          // element index of this sample's first output row in the dropout mask's index space (attn_rebase)
 };
+
+// packed rows: make `p` describe sample b alone -- base pointers at its first row, batch strides 0, Sq / Sk = its lengths.  A no-op for
+// padded callers (q_off == k_off == nullptr: SqP == Sq, SkP == Sk as the host set them).
+__device__ __forceinline__ void attn_rebase(AttnPB& p, int b) {
+    if (p.q_off != nullptr) {
+        const int r0 = p.q_off[b];
+        p.Sq = p.q_off[b + 1] - r0;
+        const int64_t oq = (int64_t)r0 * p.ldq, oo = (int64_t)r0 * p.ldo, op = (int64_t)r0 * p.ldop;
+        p.Qh += oq;
+        if (p.Ql) p.Ql += oq;
+        if (p.dOh) p.dOh += oo;
+        if (p.O) p.O += oo;
+        if (p.dO) p.dO += oo;
+        if (p.Ow) p.Ow += oo;
+        if (p.Oph) p.Oph += op;
+        if (p.Opl) p.Opl += op;
+        if (p.Opf) p.Opf += op;
+        if (p.Owh) p.Owh += op;
+        if (p.Owl) p.Owl += op;
+        if (p.gq.f32) p.gq.f32 += (int64_t)r0 * p.gq.f_ld;
+        if (p.gq.hi) p.gq.hi += (int64_t)r0 * p.gq.h_ld;
+        p.bsq = 0; p.bso = 0; p.bsop = 0; p.gq.f_bs = 0; p.gq.h_bs = 0;
+        p.drop_off = oo;                     // the output dropout's mask is indexed by the element of the whole (packed) tensor
+    }
+    if (p.k_off != nullptr) {
+        const int r0 = p.k_off[b];
+        p.Sk = p.k_off[b + 1] - r0;
+        const int64_t ok = (int64_t)r0 * p.ldk, ov = (int64_t)r0 * p.ldv;
+        p.Kh += ok;
+        if (p.Kl) p.Kl += ok;
+        p.Vh += ov;
+        if (p.Vl) p.Vl += ov;
+        if (p.gk.f32) p.gk.f32 += (int64_t)r0 * p.gk.f_ld;
+        if (p.gk.hi) p.gk.hi += (int64_t)r0 * p.gk.h_ld;
+        if (p.gv.f32) p.gv.f32 += (int64_t)r0 * p.gv.f_ld;
+        if (p.gv.hi) p.gv.hi += (int64_t)r0 * p.gv.h_ld;
+        p.bsk = 0; p.bsv = 0; p.gk.f_bs = 0; p.gk.h_bs = 0; p.gv.f_bs = 0; p.gv.h_bs = 0;
+    }
+}
+// byte extent of `rows` rows of a (batch, head)'s plane slice (row stride ld elements, DK of them used): what a buffer descriptor over it
+// may read; no rows -> nothing
+__device__ __forceinline__ int plane_extent(int rows, int64_t ld, int DK) { return rows > 0 ? (int)(((int64_t)(rows - 1) * ld + DK) * 2) : 0; }
+
 
 // 8 fp16 -> 8 bf16 (round to nearest even) in one 16-byte register slot: q / k / v exist as fp16 planes only under the fp16 attention
 // policy (4 instead of 6 bytes per element written by the projections); the backward's bf16 products convert them while staging
@@ -311,7 +360,8 @@ __device__ __forceinline__ void grad_rm_write(uint16_t* img, const f32x16 (&acc)
 }
 // (called by all NT threads after a barrier; `red` = NT * 2 floats of LDS scratch behind the image)
 template <int DK, int NT>
-__device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, const GradOut& g, int b, int h, int tok0, int S, int tid) {
+__device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, const GradOut& g, int b, int h, int tok0, int S, int SP, int tid) {
+    // S: rows of this (batch) sequence that exist; SP: the PADDED sequence length the per-tile partial rows are laid out for (packed rows: SP >= S)
     constexpr int PITCH = DK + 8, CPRW = DK / 8;
     if (g.hi) {
         uint16_t* base = g.hi + (int64_t)b * g.h_bs + (int64_t)tok0 * g.h_ld + h * DK;
@@ -350,7 +400,7 @@ __device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, c
 #pragma unroll
             for (int r = 1; r < NRB; ++r) { s0 += red[2 * (tid + r * NCW)]; s1 += red[2 * (tid + r * NCW) + 1]; }
             if (g.bpart) {      // one row of partial sums per tile: ~900 workgroups adding into the same 1024 floats took 30 us of atomics
-                *reinterpret_cast<float2*>(g.bpart + ((int64_t)b * ((S + 127) / 128) + tok0 / 128) * g.bp_ld + h * DK + 2 * cw) = make_float2(s0, s1);
+                *reinterpret_cast<float2*>(g.bpart + ((int64_t)b * ((SP + 127) / 128) + tok0 / 128) * g.bp_ld + h * DK + 2 * cw) = make_float2(s0, s1);
             } else {
                 atomicAdd(g.bsum + h * DK + 2 * cw, s0);
                 atomicAdd(g.bsum + h * DK + 2 * cw + 1, s1);
@@ -361,12 +411,12 @@ __device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, c
 // the whole epilogue of one gradient tile (NT threads; the transposed plane, if anybody asks for it, still goes through the old image)
 template <int DK, int NTL, int NT>
 __device__ __forceinline__ void grad_rm_epilogue(char* smem, const GradOut& g, const f32x16 (&acc)[NTL], int b, int h, int tok0, int trow, bool ok,
-                                                 int hh, int dt0, int S, int tid) {
+                                                 int hh, int dt0, int S, int SP, int tid) {
     uint16_t* img = reinterpret_cast<uint16_t*>(smem);
     float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
     grad_rm_write<DK, NTL>(img, acc, trow, ok, hh, dt0);
     __syncthreads();
-    grad_rm_flush<DK, NT>(img, red, g, b, h, tok0, S, tid);
+    grad_rm_flush<DK, NT>(img, red, g, b, h, tok0, S, SP, tid);
     __syncthreads();
 }
 
@@ -385,12 +435,12 @@ __device__ __forceinline__ void grad_rm_write16(uint16_t* img, const f32x4 (&acc
 }
 template <int DK, int NT>
 __device__ __forceinline__ void grad_rm_epilogue16(char* smem, const GradOut& g_, const f32x4 (&acc)[DK / 16], int b, int h, int tok0, int trow, bool ok,
-                                                   int g, int S, int tid) {
+                                                   int g, int S, int SP, int tid) {
     uint16_t* img = reinterpret_cast<uint16_t*>(smem);
     float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
     grad_rm_write16<DK>(img, acc, trow, ok, g);
     __syncthreads();
-    grad_rm_flush<DK, NT>(img, red, g_, b, h, tok0, S, tid);
+    grad_rm_flush<DK, NT>(img, red, g_, b, h, tok0, S, SP, tid);
     __syncthreads();
 }
 
@@ -884,7 +934,8 @@ __device__ __forceinline__ float xlane_sum(float x) {
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 template <int DK, bool F16>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd64_kernel(const AttnPB p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd64_kernel(const AttnPB pin) {
+    AttnPB p = pin;
     constexpr int BC = 64, NT = 512, KS = DK / 32, DT = DK / 16, RS = pad_rs<DK>();
     constexpr int TILE = BC * RS, STAGE = 2 * TILE;            // K image | V image
     constexpr int NR = rows_n<DK, BC, NT>();                   // 16-byte slots per thread and operand (4 at d_k 256)
@@ -900,6 +951,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
     const int qt = w % nqt, bh = w / nqt;
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (qt * 128 >= p.Sq) return;            // (a query tile past the sample's length)
     const int q = qt * 128 + wid * 16 + c;
     const bool qok = q < p.Sq;
     // a wave whose 16 queries all lie past Sq (the decoder: 29 queries per tile of 128) only helps to stage the tiles
@@ -920,10 +973,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int troff = tr_lane_off(RS, c, g);
 
     // K / V rows of this (b, h): descriptors end after the last key row, so a stage that runs past Sk reads zeros there
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     int kvo[NR], vvo[NR], lso[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -1043,10 +1094,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + 4 * g;
             float4 v;
-            v.x = drop_apply(dc, o[dt][0] * inv, (uint64_t)(rowoff + d + 0));
-            v.y = drop_apply(dc, o[dt][1] * inv, (uint64_t)(rowoff + d + 1));
-            v.z = drop_apply(dc, o[dt][2] * inv, (uint64_t)(rowoff + d + 2));
-            v.w = drop_apply(dc, o[dt][3] * inv, (uint64_t)(rowoff + d + 3));
+            v.x = drop_apply(dc, o[dt][0] * inv, (uint64_t)(p.drop_off + rowoff + d + 0));
+            v.y = drop_apply(dc, o[dt][1] * inv, (uint64_t)(p.drop_off + rowoff + d + 1));
+            v.z = drop_apply(dc, o[dt][2] * inv, (uint64_t)(p.drop_off + rowoff + d + 2));
+            v.w = drop_apply(dc, o[dt][3] * inv, (uint64_t)(p.drop_off + rowoff + d + 3));
             if (p.Ow) *reinterpret_cast<float4*>(p.Ow + rowoff + d) = v;
             if (p.Owh) {
                 const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + d;
@@ -1060,7 +1111,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (p.Owl) *reinterpret_cast<u32x2*>(p.Owl + po) = ll;
             }
         }
-        if (g == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run * LN2 + __logf(l_run);
+        if (g == 0) p.lsew[((int64_t)b * p.H + h) * p.SqP + q] = m_run * LN2 + __logf(l_run);
     }
 }
 
@@ -1121,7 +1172,8 @@ __device__ __forceinline__ void lgkm_wait(u32x2& a, u32x2& b) { asm volatile("s_
 // two MFMAs of S, 2 = all before S, 3 = K pieces one per four MFMAs of S + V pieces one per two MFMAs at the start of PV.
 // PRIO: raise the wave's priority around its MFMA phases.
 template <int DK, bool F16, int DMAV = 0, bool PRIO = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd32_kernel(const AttnPB p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd32_kernel(const AttnPB pin) {
+    AttnPB p = pin;
     constexpr int BC = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BC * ROWB, STAGE = 2 * TILE;
     constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BC / RPP, PPW = NP / 4;       // 16-B chunks per row, rows per 1-KB piece, pieces per tile / wave
     static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
@@ -1135,6 +1187,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
     const int qt = w % nqt, bh = w / nqt;
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (qt * 128 >= p.Sq) return;            // (a query tile past the sample's length)
     const int q = qt * 128 + wid * 32 + l31;
     const bool qok = q < p.Sq;
     const bool wave_on = qt * 128 + wid * 32 < p.Sq;                     // waves past Sq only move tiles
@@ -1142,10 +1196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- LDS-DMA: piece = 1 KB = RPP rows; wave w moves pieces w * PPW .. of the K and of the V tile
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     // (fixed extent: with the template-dependent extent PPW the DMA builtin's call becomes type-dependent and hipcc 7.2's host pass drops
     // the whole kernel instantiation WITHOUT a diagnostic -- the library then fails to load with the kernel's stub undefined)
     int kvo[4], vvo[4];
@@ -1330,7 +1382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int d = dt * 32 + 8 * (2 * ip + e) + 4 * hh + j;
-                    v[e][j] = drop_apply(dc, o[dt][4 * (2 * ip + e) + j] * inv, (uint64_t)(rowoff + d));
+                    v[e][j] = drop_apply(dc, o[dt][4 * (2 * ip + e) + j] * inv, (uint64_t)(p.drop_off + rowoff + d));
                 }
             if (p.Ow && qok) {
 #pragma unroll
@@ -1356,13 +1408,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-    if (qok && hh == 0) p.lsew[((int64_t)b * p.H + h) * p.Sq + q] = m_run * LN2 + __logf(l_tot);
+    if (qok && hh == 0) p.lsew[((int64_t)b * p.H + h) * p.SqP + q] = m_run * LN2 + __logf(l_tot);
 }
 
 
 // =================================================================================== backward
 // delta[b,h,q] = (1-p) * sum_d dO[b,q,h*DK+d] * O[b,q,h*DK+d]  (fp32 inputs), and the bf16 plane of dO for the MFMAs
-__global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, int DK, uint16_t* dOh) {
+__global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB pin, int DK, uint16_t* dOh) {
+    AttnPB p = pin;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
     const int64_t total = (int64_t)p.B * p.H * p.Sq;
@@ -1370,6 +1423,9 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const AttnPB p, in
     const int q = (int)(row % p.Sq);
     const int bh = (int)(row / p.Sq);
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows (delta stays indexed by the padded position: row)
+    if (q >= p.Sq) return;
+    dOh += p.drop_off;                       // (= this sample's first row x ldo: the same offset as the fp32 output's)
     const int64_t off = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK;
     const int64_t poff = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK;
     float s = 0.f;
@@ -1868,7 +1924,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
     // (plane / fp32 / bias sums through the row-major LDS image: whole rows out, see grad_rm_write; the transposed plane keeps the old image)
     __syncthreads();
-    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, tid);
+    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, p.SqP, tid);
     if (p.gq.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
         grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
@@ -1883,7 +1939,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // with the stage offset in an SGPR and rows past Sk read as zero, double-buffered LDS images and ONE barrier per stage, the
 // probabilities recomputed in the log2 domain (p = exp2(fma(s, scale log2 e, -lse log2 e))), per-stage bookkeeping paid half as often.
 template <int DK, int BC>
-__device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& p, const int bid) {
+__device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& pin, const int bid) {
+    AttnPB p = pin;
     constexpr int KT = BC / 16, NT = 512, KS = DK / 32, DT = DK / 16, RS = pad_rs<DK>();
     constexpr int TILE = BC * RS, STAGE = 2 * TILE;
     constexpr int NR = rows_n<DK, BC, NT>();
@@ -1899,6 +1956,12 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& p, const int b
     const int w = xcd_remap(bid, nqt * p.B * p.H);
     const int qt = w % nqt, bh = w / nqt;
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (qt * 128 >= p.Sq) {                  // a query tile past the sample's length: a zero row of bias partials, nothing else
+        if (p.gq.bpart != nullptr)
+            for (int d = tid; d < DK; d += NT) p.gq.bpart[((int64_t)b * nqt + qt) * p.gq.bp_ld + h * DK + d] = 0.f;
+        return;
+    }
     const int q = qt * 128 + wid * 16 + c;
     const bool qok = q < p.Sq;
     const bool wave_on = qt * 128 + wid * 16 < p.Sq;      // see attn_fwd64_kernel
@@ -1914,7 +1977,7 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& p, const int b
             dof[ks] = ldfrag(p.dOh + oo + 32 * ks, qok);
         }
     }
-    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
+    const int64_t stat = ((int64_t)b * p.H + h) * p.SqP + q;
     const float lse2 = qok ? p.lse[stat] * LOG2E : 0.f;
     float delta;
     if (p.fuse_delta) {      // see attn_bwd_dq16_kernel
@@ -1952,10 +2015,8 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& p, const int b
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     int kvo[NR], vvo[NR], lso[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -2055,7 +2116,7 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& p, const int b
     dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
     // (plane / fp32 / bias sums through the row-major LDS image: whole rows out, see grad_rm_write; the transposed plane keeps the old image)
     __syncthreads();
-    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, tid);
+    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, p.SqP, tid);
     if (p.gq.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
         grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
@@ -2203,7 +2264,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // QMASK: the mask has a row per query (the decoder's causal mask); the key-padding masks of the encoder and of every cross-attention
 // are per key (kmask), and without the per-element mask addressing the d_k = 256 kernel fits its 256 registers (no spills).
 template <int DK, bool QMASK>
-__device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& p, const int bid) {
+__device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& pin, const int bid) {
+    AttnPB p = pin;
     constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 128, RS = pad_rs<DK>();
     constexpr int TP = BQ * RS, STAGE = 2 * TP;
     constexpr int NR = rows_n<DK, BQ, NT>();
@@ -2218,6 +2280,14 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& p, const int b
     const int w = xcd_remap(bid, nkt * p.B * p.H);
     const int kt = w % nkt, bh = w / nkt;
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (kt * KBLK >= p.Sk) {                 // a key block past the sample's length: zero rows of bias partials, nothing else
+        for (int d = tid; d < DK; d += NT) {
+            if (p.gk.bpart != nullptr) p.gk.bpart[((int64_t)b * nkt + kt) * p.gk.bp_ld + h * DK + d] = 0.f;
+            if (p.gv.bpart != nullptr) p.gv.bpart[((int64_t)b * nkt + kt) * p.gv.bp_ld + h * DK + d] = 0.f;
+        }
+        return;
+    }
     const int key = kt * KBLK + wid * 16 + c;
     const bool kok = key < p.Sk;
     const int troff = tr_lane_off(RS, c, g);
@@ -2241,10 +2311,8 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& p, const int b
                 if (p.qkv_f16) { kf[ks] = h8_to_b8(kf[ks]); vf[ks] = h8_to_b8(vf[ks]); }
             }
         }
-        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0,
-                                                                             (int)(((int64_t)(p.Sq - 1) * p.ldq + DK) * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0,
-                                                                             (int)(((int64_t)(p.Sq - 1) * p.ldo + DK) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0, plane_extent(p.Sq, p.ldq, DK), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0, plane_extent(p.Sq, p.ldo, DK), 0x00020000);
         int qvo[NR], ovo[NR], lso[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -2257,14 +2325,14 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& p, const int b
         u32x4 rq[NR], rdo[NR];
         float rl = 0.f, rd = 0.f;
         const int ntile = (p.Sq + BQ - 1) / BQ;
-        const int64_t stat0 = ((int64_t)b * p.H + h) * p.Sq;
+        const int64_t stat0 = ((int64_t)b * p.H + h) * p.SqP;
 #define BMT_DKV32_FETCH(t_)                                                                            \
     do {                                                                                               \
         const int so_q = (t_) * BQ * (int)p.ldq * 2, so_o = (t_) * BQ * (int)p.ldo * 2;                \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) rq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qvo[i], so_q, 0);  \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) rdo[i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, ovo[i], so_o, 0); \
         if (tid < BQ) {                                                                                \
-            const int qq_ = min((t_) * BQ + tid, p.Sq - 1);                                            \
+            const int qq_ = max(0, min((t_) * BQ + tid, p.Sq - 1));                                    \
             rl = p.lse[stat0 + qq_] * LOG2E;                                                           \
             rd = p.delta[stat0 + qq_];                                                                 \
         }                                                                                              \
@@ -2336,8 +2404,8 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& p, const int b
     // one [128][DK + 8] row-major image at a time (dV, then dK) in the stage buffers: whole rows out, bias sums from the image
     static_assert(KBLK == 128, "the row-major epilogue image holds 128 tokens");
     __syncthreads();
-    grad_rm_epilogue16<DK, NT>(smem, p.gv, accv, b, h, kt * KBLK, wid * 16 + c, kok, g, p.Sk, tid);
-    grad_rm_epilogue16<DK, NT>(smem, p.gk, acck, b, h, kt * KBLK, wid * 16 + c, kok, g, p.Sk, tid);
+    grad_rm_epilogue16<DK, NT>(smem, p.gv, accv, b, h, kt * KBLK, wid * 16 + c, kok, g, p.Sk, p.SkP, tid);
+    grad_rm_epilogue16<DK, NT>(smem, p.gk, acck, b, h, kt * KBLK, wid * 16 + c, kok, g, p.Sk, p.SkP, tid);
     if (p.gk.hiT || p.gv.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
         GradOut gt = p.gv;
@@ -2376,7 +2444,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // for any m, and what the correction needs from m is the keys' common component -- which the mean of every 8th key carries as well as the
 // mean of all of them, for an eighth of the 52 MB an 800-key audio memory costs to read (31 us per launch, 12 launches per step).
 __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restrict__ Kh, int64_t ldk, int64_t bsk, const uint8_t* __restrict__ mask,
-                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out, int f16, int ks) {
+                                                         int64_t mask_bs, int Sk, int D, float* __restrict__ out, int f16, int ks,
+                                                         const int* __restrict__ k_off) {
     constexpr int KG = 32;
     __shared__ float red[KG][129];
     __shared__ float cnt[KG];
@@ -2385,7 +2454,12 @@ __global__ __launch_bounds__(512) void attn_kmean_kernel(const uint16_t* __restr
     const bool cok = c0 < D;                       // D is a multiple of 8
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float n = 0.f;
-    const uint16_t* base = Kh + (int64_t)b * bsk + (cok ? c0 : 0);
+    int64_t boff = (int64_t)b * bsk;
+    if (k_off != nullptr) {                        // packed rows: this sample's keys are rows k_off[b] .. k_off[b + 1] - 1, all valid
+        boff = (int64_t)k_off[b] * ldk;
+        Sk = k_off[b + 1] - k_off[b];
+    }
+    const uint16_t* base = Kh + boff + (cok ? c0 : 0);
     const uint8_t* mb = mask ? mask + (int64_t)b * mask_bs : nullptr;
 #pragma unroll 8
     for (int k = kg * ks; k < Sk; k += KG * ks) {
@@ -2455,6 +2529,10 @@ int launch_fwd(const AttnPB& p, hipStream_t st, int fwd32 = -1) {
             BMT_CHECK_LAUNCH("bmt_attn_fwd_bf16");
             return BMT_OK;
         }
+    }
+    if (p.q_off || p.k_off) {
+        bmt_set_error("bmt_attn_fwd_bf16: packed rows are not taken by this shape's kernel");
+        return BMT_EINVAL;
     }
     if constexpr (DK >= 128) {        // 8 waves x 16 queries, two waves per SIMD
         const int lds = (NPASS == 3 ? 2 : 1) * (2 * 32 * (DK * 2 + 32)) + 128;
@@ -2533,7 +2611,8 @@ __device__ __forceinline__ void st128(__amdgpu_buffer_rsrc_t rs, uint32_t a, uin
 // delta = (1 - p) rowsum(dO * O) is computed in the prologue from the saved output plane (fuse_delta), nobody else needs it.
 // XP (timing probes): bit 3 = no epilogue stores, bit 4 = no loop
 template <int DK, int XP = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32p_kernel(const AttnPB p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32p_kernel(const AttnPB pin) {
+    AttnPB p = pin;
     constexpr int BC = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BC * ROWB, STAGE = 2 * TILE, NS = 4;
     constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BC / RPP, PPW = NP / 4;
     static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
@@ -2546,32 +2625,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int hh = lane >> 5, l31 = lane & 31;
     const int nqt = (p.Sq + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
-    // work order: (batch, head)-major, so that the query tiles of a (batch, head) run together and share its K / V in their XCD's L2 --
-    // EXCEPT the remnant tile of a sequence whose length is no multiple of 128 (800 = 6 x 128 + 32): those go to the END of every XCD's
-    // range.  896 workgroups on 256 CUs at one per CU were 3.5 rounds with full-cost workgroups in the half round; now each XCD runs
-    // 96 full tiles = exactly 3 rounds of its 32 CUs and then 16 remnant tiles, which hold 32 rows and -- padded positions -- are dead in
-    // most batch elements (AttnPB.qlive: no key loop at all).  Only when the ranges divide evenly (else the plain order).
-    int qt, bh;
-    {
-        const int total = nqt * p.B * p.H, chunk = total >> 3, nfull = p.Sq / 128;
-        if (p.remnant_last && nfull > 0 && nfull < nqt && (total & 7) == 0 && chunk % nqt == 0) {
-            const int c = w / chunk, i = w % chunk, per = chunk / nqt;
-            if (i < per * nfull) { bh = c * per + i / nfull; qt = i % nfull; }
-            else { bh = c * per + (i - per * nfull); qt = nfull; }
-        } else {
-            qt = w % nqt; bh = w / nqt;
-        }
-    }
+    // work order: (batch, head)-major, so that the query tiles of a (batch, head) run together and share its K / V in their XCD's L2
+    const int qt = w % nqt, bh = w / nqt;
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (qt * 128 >= p.Sq) {                  // a query tile past the sample's length: no live query, a zero row of bias partials, nothing else
+        if (p.qlive != nullptr && tid == 0) p.qlive[(int64_t)bh * nqt + qt] = 0;
+        if (p.gq.bpart != nullptr)
+            for (int d = tid; d < DK; d += NT) p.gq.bpart[((int64_t)b * nqt + qt) * p.gq.bp_ld + h * DK + d] = 0.f;
+        return;
+    }
     const int q = qt * 128 + wid * 32 + l31;
     const bool qok = q < p.Sq;
     const int ntile = (p.Sk + BC - 1) / BC;
 
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldk + DK) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sk - 1) * p.ldv + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     const int64_t slab = (int64_t)bh * p.ws_slab;
     // (the descriptor covers the whole (batch, head) slab: the range check takes the soffset into account -- raw buffers are out of range at
     // voffset >= num_records - soffset -- so a one-block range dropped every store to key blocks past the first; rows past Sq are kept
@@ -2666,7 +2736,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     }
-    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + min(q, p.Sq - 1);
+    const int64_t stat = ((int64_t)b * p.H + h) * p.SqP + min(q, p.Sq - 1);
     const float lse2 = p.lse[stat] * LOG2E;
     const float delta = p.fuse_delta ? half_sum(dsum) * (1.f - p.drop_p) : p.delta[stat];
     float amax = 0.f;
@@ -2675,7 +2745,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bfbits_lo(dob[ks][j])), fabsf(bfbits_hi(dob[ks][j]))));
     amax = half_max(amax);
-    if (__ballot(qok && amax > 0.f) != 0ull && lane == 0) atomicOr(&sLast[1], 1 << wid);      // this wave's 32 queries carry gradient
+    if (__ballot(qok && !(amax == 0.f)) != 0ull && lane == 0) atomicOr(&sLast[1], 1 << wid);      // this wave's 32 queries carry gradient (a NaN row counts: it must propagate)
     int kexp = 0;
     if (amax > 0.f) kexp = 6 - ((int)((__float_as_uint(amax) >> 23) & 0xffu) - 127);
     kexp = max(-60, min(60, kexp));
@@ -2898,7 +2968,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (XP & 8) { if (dq[0][0] == 1234.5f && dq[1][1] == 3.25f) p.gq.bsum[0] = 1.f; return; }
-    grad_rm_epilogue<DK, DT, 256>(smem, p.gq, dq, b, h, qt * 128, wid * 32 + l31, qok, hh, 0, p.Sq, tid);
+    grad_rm_epilogue<DK, DT, 256>(smem, p.gq, dq, b, h, qt * 128, wid * 32 + l31, qok, hh, 0, p.Sq, p.SqP, tid);
     if (p.gq.hiT) {
         uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
         grad_tile_write<DK, 128>(tile, dq, wid * 32, qok, l31, hh);
@@ -2927,14 +2997,14 @@ int launch_dq32p(const AttnPB& p, hipStream_t st) {
 // with the MFMAs AND the DMA switched off the loop still takes 60 % of its time: MI355X_MICROARCH.md, LDS: 4- and 8-byte reads reach their
 // rate only from several waves per SIMD).  The P / dS fragments are read by both d-halves (+8 reads per stage and wave pair).
 template <int DK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkvg8_kernel(const AttnPB p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkvg8_kernel(const AttnPB pin) {
+    AttnPB p = pin;
     constexpr int BQ = 32, DT = DK / 32, DTL = DT / 2, ROWB = DK * 2, XT = BQ * ROWB, YT = BQ * 256, STAGE = 2 * XT + 2 * YT;
     constexpr int NS = (DK == 256) ? 3 : 4;
     constexpr int CPR = DK / 8, RPP = 64 / CPR, NPX = BQ / RPP, PPW = NPX / 8;      // X tiles: 16 (8) pieces of 1 KB over 8 waves; Y tiles: 8 pieces
     constexpr int NDMA = 2 * PPW + 2;                                               // requests per wave and stage
     static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int nst = (p.Sq + BQ - 1) / BQ;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2942,20 +3012,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hh = lane >> 5, l31 = lane & 31;
     const int nkt = (p.Sk + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
-    // (the remnant key block of a sequence whose length is no multiple of 128 goes to the end of every XCD's range, as in
-    // attn_bwd_dq32p_kernel: it is beyond the valid keys -- and leaves at once -- in most batch elements)
-    int kt, bh;
-    {
-        const int total = nkt * p.B * p.H, chunk = total >> 3, nfull = p.Sk / 128;
-        if (p.remnant_last && nfull > 0 && nfull < nkt && (total & 7) == 0 && chunk % nkt == 0) {
-            const int c = w / chunk, i = w % chunk, per = chunk / nkt;
-            if (i < per * nfull) { bh = c * per + i / nfull; kt = i % nfull; }
-            else { bh = c * per + (i - per * nfull); kt = nfull; }
-        } else {
-            kt = w % nkt; bh = w / nkt;
-        }
-    }
+    const int kt = w % nkt, bh = w / nkt;
     const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (kt * 128 >= p.Sk) {                  // a key block past the sample's length: zero rows of bias partials, nothing else
+        for (int d = tid; d < DK; d += 512) {
+            if (p.gk.bpart != nullptr) p.gk.bpart[((int64_t)b * nkt + kt) * p.gk.bp_ld + h * DK + d] = 0.f;
+            if (p.gv.bpart != nullptr) p.gv.bpart[((int64_t)b * nkt + kt) * p.gv.bp_ld + h * DK + d] = 0.f;
+        }
+        return;
+    }
+    const int nst = (p.Sq + BQ - 1) / BQ;
     const int key = kt * 128 + kg * 32 + l31;
     const bool kin = key < p.Sk;
     const bool kok = kin && (p.mask == nullptr || p.mask[(int64_t)b * p.mask_bs + key] != 0);
@@ -2964,17 +3031,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint64_t smask = ~0ull;
     if (p.qlive != nullptr) {
         smask = 0ull;
-        const int nqt = (p.Sq + 127) / 128;
+        const int nqt = (p.SqP + 127) / 128;
         for (int i = 0; i < nqt; ++i) smask |= (uint64_t)(uint32_t)(p.qlive[(int64_t)bh * nqt + i] & 15) << (4 * i);
     }
     const int live_end = smask == 0ull ? 0 : 64 - __builtin_clzll(smask);
     const int nst_run = __syncthreads_or((int)kok) ? min(nst, live_end) : 0;
 
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qbws + (int64_t)b * p.bsqb + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sq - 1) * p.ldqb + DK) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0,
-                                                                         (int)(((int64_t)(p.Sq - 1) * p.ldo + DK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qbws + (int64_t)b * p.bsqb + h * DK), 0, plane_extent(p.Sq, p.ldqb, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0, plane_extent(p.Sq, p.ldo, DK), 0x00020000);
     const int64_t slab = (int64_t)bh * p.ws_slab + kt * p.ws_tile;
     const int slab_bytes = (int)(((int64_t)p.Sq * p.ws_pitch - (p.ws_tile == 128 ? kt * 128 : 0)) * 2);
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Pws + slab), 0, slab_bytes, 0x00020000);
@@ -3114,8 +3179,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    grad_rm_epilogue<DK, DTL, 512>(smem, p.gv, dva, b, h, kt * 128, kg * 32 + l31, kin, hh, dh * DTL, p.Sk, tid);
-    grad_rm_epilogue<DK, DTL, 512>(smem, p.gk, dka, b, h, kt * 128, kg * 32 + l31, kin, hh, dh * DTL, p.Sk, tid);
+    grad_rm_epilogue<DK, DTL, 512>(smem, p.gv, dva, b, h, kt * 128, kg * 32 + l31, kin, hh, dh * DTL, p.Sk, p.SkP, tid);
+    grad_rm_epilogue<DK, DTL, 512>(smem, p.gk, dka, b, h, kt * 128, kg * 32 + l31, kin, hh, dh * DTL, p.Sk, p.SkP, tid);
 }
 
 template <int DK>
@@ -3161,6 +3226,10 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const bool pair = DK >= 128 && pair_env && p.Pws == nullptr && !getenv("BMT_ATTN_DQ_OLD") && !getenv("BMT_ATTN_DKV_OLD") &&
                       (int64_t)p.Sk * p.ldk * 2 < (1ll << 31) && (int64_t)p.Sk * p.ldv * 2 < (1ll << 31) &&
                       (int64_t)p.Sq * p.ldq * 2 < (1ll << 31) && (int64_t)p.Sq * p.ldo * 2 < (1ll << 31);
+    if ((p.q_off || p.k_off) && !(p.Pws != nullptr || pair)) {
+        bmt_set_error("bmt_attn_bwd_bf16: packed rows need the split or the paired backward (d_k >= 128)");
+        return BMT_EINVAL;
+    }
     const bool fuse = DK >= 128 && !sep && !pair && p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr);
     if (!fuse) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
     AttnPB pf = p;
@@ -3318,6 +3387,10 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off;
+    BMT_CHECK_ARG(!(a->q_off || a->k_off) || (a->dk >= 128 && a->precision != BMT_PREC_BF16X3 && (!a->k_off || !a->mask) && (a->mask == nullptr || a->mask_qs == 0) &&
+                                              (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) && (int64_t)a->Sk * a->ldv * 2 < (1ll << 31)),
+                  "bmt_attn_fwd_bf16: packed rows (q_off / k_off) are taken by the one-pass d_k >= 128 kernels, without a mask over packed keys");
     p.scale = a->scale; p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
     hipStream_t st = (hipStream_t)stream;
 #define BMT_FWD(D) \
@@ -3351,6 +3424,12 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off;
+    BMT_CHECK_ARG(!(a->q_off || a->k_off) || (a->dk >= 128 && (!a->k_off || !a->mask) && (a->mask == nullptr || a->mask_qs == 0) && !a->dQT && !a->dKT && !a->dVT &&
+                                              !a->O && !a->dO && (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) && (int64_t)a->Sk * a->ldv * 2 < (1ll << 31) &&
+                                              (int64_t)a->Sq * a->ldq * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31)),
+                  "bmt_attn_bwd_bf16: packed rows (q_off / k_off) are taken by the d_k >= 128 kernels over plane operands, without a mask over packed "
+                  "keys or transposed outputs");
     p.scale = a->scale; p.drop_p = a->drop_p;
     p.kmean = a->kmean;
     p.qkv_f16 = a->qkv_f16;
@@ -3384,8 +3463,6 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
             // per (batch, head) in the dK / dV kernel: 64 stages of 32 queries
             static const int qskip = getenv("BMT_ATTN_QSKIP") ? atoi(getenv("BMT_ATTN_QSKIP")) : 1;      // A/B experiments only
             p.qlive = (qskip && a->Sq <= 2048) ? reinterpret_cast<int*>(a->Qb_ws + (int64_t)a->B * p.bsqb) : nullptr;
-            static const int remnant_last = getenv("BMT_ATTN_REMNANT_LAST") ? atoi(getenv("BMT_ATTN_REMNANT_LAST")) : 0;      // A/B: measured WORSE (attention-backward class 1.57-1.60 vs 1.48-1.50 ms same box, profiles/r04_g_ab_remnant.txt): off
-            p.remnant_last = remnant_last;
         }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -3421,14 +3498,14 @@ extern "C" int64_t bmt_attn_bwd_bias_ws(int B, int H, int Sq, int Sk, int dk) {
 }
 
 extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk,
-                              int D, float* out, int k_f16, void* stream) {
+                              int D, float* out, int k_f16, const int* k_off, void* stream) {
     BMT_CHECK_ARG(Kh && out && B > 0 && Sk > 0 && D > 0 && D % 8 == 0 && ldk % 8 == 0 && bsk % 8 == 0 &&
                       (reinterpret_cast<uintptr_t>(Kh) & 15) == 0,
                   "bmt_attn_kmean: bad args (D, ldk, bsk multiples of 8, 16-byte aligned plane)");
     static const int ks_env = getenv("BMT_KMEAN_STRIDE") ? atoi(getenv("BMT_KMEAN_STRIDE")) : 0;      // A/B experiments only
     const int ks = ks_env > 0 ? ks_env : (Sk >= 256 ? 8 : 1);
     hipLaunchKernelGGL(attn_kmean_kernel, dim3(B, bmt_cdiv(D, 128)), dim3(512), 0, (hipStream_t)stream, Kh, ldk, bsk,
-                       mask_qs == 0 ? mask : nullptr, mask_bs, Sk, D, out, k_f16, ks);
+                       (mask_qs == 0 && !k_off) ? mask : nullptr, mask_bs, Sk, D, out, k_f16, ks, k_off);
     BMT_CHECK_LAUNCH("bmt_attn_kmean");
     return BMT_OK;
 }

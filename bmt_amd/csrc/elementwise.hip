@@ -43,6 +43,84 @@ __global__ __launch_bounds__(256) void prep_features_kernel(const float* __restr
     }
 }
 
+// ---- packed rows (bmt_pack_rows, bmt_prep_features_packed): the valid positions of a ragged batch, compacted in (b, t) order
+// count: off[B + 1 + b] = number of valid positions of sample b (scratch half of `off`)
+__global__ __launch_bounds__(256) void pack_count_kernel(const uint8_t* __restrict__ mask, int64_t mask_bs, int B, int S, int* __restrict__ off) {
+    __shared__ int red[4];
+    const int b = blockIdx.x;
+    int c = 0;
+    for (int t = threadIdx.x; t < S; t += 256) c += mask[(int64_t)b * mask_bs + t] != 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) off[B + 1 + b] = red[0] + red[1] + red[2] + red[3];
+}
+// place: off[b] = valid positions of the samples before b (off[B] = their total), row_map[off[b] + i] = b * S + t of the i-th valid position
+__global__ __launch_bounds__(256) void pack_place_kernel(const uint8_t* __restrict__ mask, int64_t mask_bs, int B, int S, int* __restrict__ off,
+                                                          int* __restrict__ row_map) {
+    __shared__ int red[4];
+    __shared__ int wcnt[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int* cnt = off + B + 1;
+    int c = 0;
+    for (int i = threadIdx.x; i < b; i += 256) c += cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) red[wid] = c;
+    __syncthreads();
+    const int start = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        off[b] = start;
+        if (b == B - 1) off[B] = start + cnt[b];
+    }
+    int run = start;
+    for (int t0 = 0; t0 < S; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const bool v = t < S && mask[(int64_t)b * mask_bs + t] != 0;
+        const unsigned long long bal = __ballot(v);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();                      // (the previous round's wcnt has been read)
+        if (lane == 0) wcnt[wid] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wid; ++w) wbase += wcnt[w];
+        if (v) row_map[run + wbase + before] = b * S + t;
+        run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void prep_features_packed_kernel(const float* __restrict__ a, const float* __restrict__ b2,
+                                                                    const float* __restrict__ pe, float* __restrict__ out, int S, int D,
+                                                                    float drop_p, const uint64_t* rng, uint32_t site,
+                                                                    const int* __restrict__ row_map, const int* __restrict__ rows_dev, int cap) {
+    const DropCtx dc = make_drop(drop_p, rng, site);
+    const int n = min(cap, *rows_dev);
+    const int64_t total = (int64_t)n * D;
+    if constexpr (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+            const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+            const int src = row_map[r];
+            const int64_t so = (int64_t)src * D + c;
+            float4 v = ld4(a + so);
+            if (b2) { const float4 w = ld4(b2 + so); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+            const float4 p = ld4(pe + (int64_t)(src % S) * D + c);
+            v.x = drop_apply(dc, v.x + p.x, (uint64_t)i + 0); v.y = drop_apply(dc, v.y + p.y, (uint64_t)i + 1);
+            v.z = drop_apply(dc, v.z + p.z, (uint64_t)i + 2); v.w = drop_apply(dc, v.w + p.w, (uint64_t)i + 3);
+            *reinterpret_cast<float4*>(out + i) = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+            const int src = row_map[r];
+            float v = a[(int64_t)src * D + c];
+            if (b2) v += b2[(int64_t)src * D + c];
+            out[i] = drop_apply(dc, v + pe[(int64_t)(src % S) * D + c], (uint64_t)i);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void prep_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ W,
                                                           const float* __restrict__ pe, float* __restrict__ out, int B, int S, int D,
                                                           int V, float emb_scale, float drop_p, const uint64_t* rng, uint32_t site) {
@@ -146,6 +224,25 @@ extern "C" int bmt_prep_features(const float* a, const float* b2, const float* p
     if (vec) hipLaunchKernelGGL(prep_features_kernel<true>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, a, b2, pe, out, B, S, D, drop_p, rng, site);
     else hipLaunchKernelGGL(prep_features_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b2, pe, out, B, S, D, drop_p, rng, site);
     BMT_CHECK_LAUNCH("bmt_prep_features");
+    return BMT_OK;
+}
+
+extern "C" int bmt_pack_rows(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, void* stream) {
+    BMT_CHECK_ARG(mask && off && row_map && B > 0 && S > 0 && mask_bs >= S && (int64_t)B * S < (1ll << 31), "bmt_pack_rows: bad args");
+    hipLaunchKernelGGL(pack_count_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, mask_bs, B, S, off);
+    hipLaunchKernelGGL(pack_place_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, mask_bs, B, S, off, row_map);
+    BMT_CHECK_LAUNCH("bmt_pack_rows");
+    return BMT_OK;
+}
+
+extern "C" int bmt_prep_features_packed(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D, float drop_p,
+                                        const uint64_t* rng, uint32_t site, const int* row_map, const int* rows_dev, void* stream) {
+    BMT_CHECK_ARG(a && pe && out && row_map && rows_dev && B > 0 && S > 0 && D > 0, "bmt_prep_features_packed: bad args");
+    const int64_t total = (int64_t)B * S * D;
+    const bool vec = (D % 4 == 0) && al16(a) && al16(pe) && al16(out) && (!b2 || al16(b2));
+    if (vec) hipLaunchKernelGGL(prep_features_packed_kernel<true>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, a, b2, pe, out, S, D, drop_p, rng, site, row_map, rows_dev, B * S);
+    else hipLaunchKernelGGL(prep_features_packed_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b2, pe, out, S, D, drop_p, rng, site, row_map, rows_dev, B * S);
+    BMT_CHECK_LAUNCH("bmt_prep_features_packed");
     return BMT_OK;
 }
 

@@ -56,6 +56,8 @@ struct GemmB {
     int nk_loader;                       // gemm_k128_kernel: 1 = seven computing waves + a loading wave, 0 = eight waves that load their own rows
     int nk_dbg;                          // experiments (env BMT_K128_DBG): 1 no stores, 2 no MFMAs, 4 no next-unit prefetch
     int nk_ncw, nk_rg, nk_upw;           // gemm_k128_kernel: weight rows per resident chunk, row groups, 32-row units per row group
+    const int* rows_dev;                 // packed rows (bmt_gemm_bf16_args.rows_dev): the rows actually present, in device memory; the launch is sized for M
+                                         // (k-major A: for krows) and every kernel takes min(M, *rows_dev) -- graph-static grids over data-dependent extents
 #ifdef BMT_EXP
     int exp;                             // experiment build only (BMT_ALT_FLAGS=-DBMT_EXP, env BMT_EXP): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue,
     int exp_shift; int exp_sleep;                       // 8 every other workgroup starts exp_sleep x 3.4 us late (env BMT_EXP_SLEEP)
@@ -214,14 +216,28 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     const int wr = wid >> 1, wc = wid & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
+    // packed rows: the rows (row-major A) / reduction rows (k-major A: the weight gradients) actually present come from device memory; the
+    // tile order is built over the tiles that exist, so that the workgroups that leave at once are the LAST of every XCD's share
+    int Mr = p.M, krows = p.krows, Kp = p.Kpad, tiles_m = p.tiles_m;
+    if (p.rows_dev != nullptr) {
+        const int nrows = *p.rows_dev;
+        if constexpr (AKM) {
+            krows = min(krows, nrows);
+            if (raw_order) Kp = (krows + 63) & ~63;        // (the grouped launch accumulates with atomics: a chunk past the rows adds nothing)
+        } else {
+            Mr = min(Mr, nrows);
+            tiles_m = (Mr + BM - 1) / BM;
+        }
+    }
     // tile order: XCD remap, then groups of 8 row panels walked column by column
-    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ntiles = tiles_m * p.tiles_n;
+    if (!raw_order && tile_id >= ntiles) return;
     const int w = raw_order ? tile_id : xcd_remap(tile_id, ntiles);      // raw: the caller already placed this tile on its XCD
     const int GM = 8;
     const int per_group = GM * p.tiles_n;
     const int g = w / per_group;
     const int first_m = g * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
+    const int gsz = min(tiles_m - first_m, GM);
     const int wi = w - g * per_group;
     const int tm = first_m + wi % gsz, tn = wi / gsz;
     const int m0 = tm * BM;
@@ -238,7 +254,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     }
     const int n0 = n0_;
     const int kbeg = split_id * p.kchunk;
-    const int kend = min(p.Kpad, kbeg + p.kchunk);
+    const int kend = min(Kp, kbeg + p.kchunk);
+    if (kbeg >= kend) return;            // (packed rows, grouped launch: this reduction chunk lies past the rows present)
 
     f32x16 acc[TI][2];
 #pragma unroll
@@ -280,19 +297,19 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 #pragma unroll
             for (int i = 0; i < NRA; ++i) {
                 const int c = tid + NT * i;
-                const int row = min(m0 + c / SPR, p.M - 1);
+                const int row = min(m0 + c / SPR, Mr - 1);
                 avo[i] = (int)((int64_t)(row + 2 * (row / p.conv_S) * p.conv_halo) * p.lda * 2) + (c % SPR) * 16;
             }
         } else if constexpr (AKM) plane_voff_km<BM, BK, NT>(p.lda, m0, 0, tid, avo);
-        else plane_voff<SPR, BM, NT>(p.lda, m0, p.M, tid, avo);
+        else plane_voff<SPR, BM, NT>(p.lda, m0, Mr, tid, avo);
         if constexpr (CONV == 2) plane_voff_km<BN, BK, NT>(p.ldb, n0 % p.conv_cin, n0 / p.conv_cin, tid, bvo);
         else if constexpr (BKM) plane_voff_km<BN, BK, NT>(p.ldb, n0, 0, tid, bvo);
         else plane_voff<SPR, BN, NT>(p.ldb, n0, p.N, tid, bvo);
     }
     // extents: row-major planes end after their last row; k-major planes after reduction row K (later rows read as zero); the
     // Conv1d activation plane after the rows reachable from its (advanced) base pointer
-    const int64_t a_bytes = (CONV == 1 ? (int64_t)p.conv_rows : (AKM ? (int64_t)p.krows : (int64_t)p.M)) * p.lda * 2;
-    const int64_t b_bytes = (CONV == 2 ? (int64_t)p.conv_rows : (BKM ? (int64_t)p.krows : (int64_t)p.N)) * p.ldb * 2;
+    const int64_t a_bytes = (CONV == 1 ? (int64_t)p.conv_rows : (AKM ? (int64_t)krows : (int64_t)Mr)) * p.lda * 2;
+    const int64_t b_bytes = (CONV == 2 ? (int64_t)p.conv_rows : (BKM ? (int64_t)krows : (int64_t)p.N)) * p.ldb * 2;
     const __amdgpu_buffer_rsrc_t rsAh = plane_rsrc(p.Ah, a_bytes), rsAl = plane_rsrc(ALO ? p.Al : p.Ah, a_bytes);
     const __amdgpu_buffer_rsrc_t rsBh = plane_rsrc(p.Bh, b_bytes), rsBl = plane_rsrc(BLO ? p.Bl : p.Bh, b_bytes);
     // stage image: A hi | B hi | [A lo] | [B lo]
@@ -380,7 +397,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             } else {
                 const int row = (wid_s * APW + i) * RPP + rl;
                 const int ks = (SPR == 8) ? (sp ^ ((row >> 1) & 7)) : (sp ^ ((row >> 2) & 3));
-                int grow = min(m0 + row, p.M - 1);
+                int grow = min(m0 + row, Mr - 1);
                 if constexpr (CONV == 1) grow += 2 * (grow / p.conv_S) * p.conv_halo;      // output row b S + s reads plane row (+ tap, per step)
                 avo[i] = (int)((int64_t)grow * p.lda * 2) + ks * 16;
             }
@@ -517,7 +534,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wr * 32 * TI + i * 32 + acc_row(r, half);
-                    if (row < p.M) atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+                    if (row < Mr) atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
                 }
             }
         return;
@@ -552,7 +569,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     for (int ps = 0; ps < BM * 16 / NT; ++ps) {
         const int rl = ps * (NT / 16) + (tid >> 4);
         const int row = m0 + rl;
-        if (row >= p.M || !active) continue;
+        if (row >= Mr || !active) continue;
         float v[8];
         {
             const float4 t0 = *reinterpret_cast<const float4*>(ct + rl * BN + cg);
@@ -673,7 +690,8 @@ template <int NPASS, bool F16, int TI, bool AKM = false, bool BKM = false, int C
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TI == 2 ? 2 : 4, TI == 2 ? 2 : 4))) void gemm_pipe_kernel(const GemmB p) {
     // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so a workgroup stays on
     // the XCD its tiles were ordered for); its stores drain while the next tile's operands are already on their way
-    const int ntiles = p.tiles_m * p.tiles_n;
+    int ntiles = p.tiles_m * p.tiles_n;
+    if (p.rows_dev != nullptr && !AKM) ntiles = ((min(p.M, *p.rows_dev) + 128 * TI - 1) / (128 * TI)) * p.tiles_n;      // packed rows: the tiles that exist
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         gemm_bf16_tile<NPASS, 4, TI, AKM, BKM, CONV, F16, true, 1>(p, t, (int)blockIdx.y, false);
         __syncthreads();          // the stage buffers (epilogue tile) are free again
@@ -709,7 +727,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // tile order: XCD remap, then groups of 8 activation panels walked panel-first (the ~32 tiles an XCD runs together share
     // 8 activation panels and 4 weight panels in its L2)
-    const int tiles_m = p.tiles_m, tiles_n = p.tiles_n;       // activation / weight panels of 256 rows
+    int Mr = p.M, tiles_m = p.tiles_m;                        // activation / weight panels of 256 rows
+    const int tiles_n = p.tiles_n;
+    if (p.rows_dev != nullptr) {                              // packed rows: the rows present are in device memory (see gemm_bf16_tile)
+        Mr = min(Mr, *p.rows_dev);
+        tiles_m = (Mr + 255) / 256;
+    }
+    if ((int)blockIdx.x >= tiles_m * tiles_n) return;
     const int w = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
     const int per_group = 8 * tiles_n;
     const int g = w / per_group, first_m = g * 8;
@@ -719,7 +743,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- LDS-DMA: a half-tile is 16 pieces of 1 KB (8 rows x 128 B); wave w fills pieces 2w, 2w+1 (rows 16w .. 16w+15)
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)Mr * p.lda * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsWh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bh, 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsWl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Bl ? p.Bl : p.Bh), 0, (int)((int64_t)p.N * p.ldb * 2), 0x00020000);
     int xvo[2], wvo[2];
@@ -875,7 +899,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto seg_col = [&](int st) { return n0 + 128 * wr + 64 * ((st >> 2) & 1) + cgl; };
     auto prefetch = [&](int st, int buf) {
         const int row = seg_row(st), col = seg_col(st);
-        const bool ok = row < p.M && col + 8 <= p.N;
+        const bool ok = row < Mr && col + 8 <= p.N;
         if (pre_r && ok) {
             const float* rp = p.residual + (int64_t)row * p.ldr + col;
             rr[buf][0] = *reinterpret_cast<const float4*>(rp);
@@ -916,7 +940,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float4 t1 = *reinterpret_cast<const float4*>(chunk + rl * 256 + ((((cgl >> 2) + 1) ^ (rl & 15)) * 16));
                 v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
             }
-            if (row >= p.M || (col >= p.N && col >= pcols)) continue;
+            if (row >= Mr || (col >= p.N && col >= pcols)) continue;
             const bool full = col + 8 <= p.N;
             const int64_t idx = (int64_t)row * p.ldc + col;
             if (f & BMT_EPI_BIAS) {
@@ -1066,20 +1090,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned f = p.flags;
     if (tid < NCW) sbias[tid] = ((f & BMT_EPI_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
 
-    const int units = (p.M + 31) >> 5;
-    const int u0 = rg * p.nk_upw, u_end = min(units, (rg + 1) * p.nk_upw);
+    int Mr = p.M, upw = p.nk_upw;
+    if (p.rows_dev != nullptr) {            // packed rows: the rows present are in device memory; the row groups share what is there
+        Mr = min(Mr, *p.rows_dev);
+        upw = (((Mr + 31) >> 5) + p.nk_rg - 1) / p.nk_rg;
+    }
+    const int units = (Mr + 31) >> 5;
+    const int u0 = rg * upw, u_end = min(units, (rg + 1) * upw);
     const int rounds = (u_end - u0 + NCMP - 1) / NCMP;
 
     if (LOADER && wid == NCMP) {
         // ================= the loading wave: round r = units u0 + 7 r .. + 6 (rows clamped: a round may reach past the matrix)
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)Mr * p.lda * 2), 0x00020000);
         auto fill = [&](int r) {
             char* slot = smem + A_OFF;
             const int row0 = 32 * (u0 + NCMP * r);
 #pragma unroll 8
             for (int pc = 0; pc < 8 * NCMP; ++pc) {
                 const int rr = 4 * pc + lrow;                                  // row of the round's 128
-                const int row = min(row0 + rr, p.M - 1);
+                const int row = min(row0 + rr, Mr - 1);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(slot + pc * 1024), 16, row * (int)p.lda * 2 + ((lslot ^ (rr & 15)) * 16), 0, 0, 0);
             }
         };
@@ -1126,7 +1155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto process = [&](const bf16x8 (&a)[8], int u) {
         BMT_K128_FRAGS(0);
         const int row_a = 32 * u + rsel;                   // pass 0 row of this lane (pass 1: + 16); a unit past u_end stores nothing
-        const int m_lim = u < u_end ? p.M : 0;
+        const int m_lim = u < u_end ? Mr : 0;
         if constexpr (PAIR) {
             const int seg8 = lane & 7, rsel8 = lane >> 3;      // this lane's 8 columns of the pair's 64, its row within a pass of 8
 #pragma unroll
@@ -1368,7 +1397,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define BMT_K128_LD(dst_, i_) asm volatile("global_load_dwordx4 %0, %1, off offset:" #i_ "*32" : "=&v"(dst_[i_]) : "v"(ap_) : "memory")
 #define BMT_K128_LDA(dst_, uu_)                                                                                     \
     do {                                                                                                             \
-        const int row_ = min(32 * min((uu_), units - 1) + l31, p.M - 1);                                             \
+        const int row_ = max(0, min(32 * min((uu_), units - 1) + l31, Mr - 1));                                             \
         const uint16_t* ap_ = p.Ah + (int64_t)row_ * p.lda + 8 * half;                                               \
         BMT_K128_LD(dst_, 0); BMT_K128_LD(dst_, 1); BMT_K128_LD(dst_, 2); BMT_K128_LD(dst_, 3);                      \
         BMT_K128_LD(dst_, 4); BMT_K128_LD(dst_, 5); BMT_K128_LD(dst_, 6); BMT_K128_LD(dst_, 7);                      \
@@ -1461,6 +1490,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)p.M * ncg) return;
     const int row = (int)(idx / ncg), c0 = (int)(idx % ncg) * 4;
+    if (p.rows_dev != nullptr && row >= *p.rows_dev) return;      // packed rows: the tiles past the rows present wrote no partials
     const int64_t ldw = (int64_t)p.tiles_n * BN;
     const int64_t slab = (int64_t)p.tiles_m * p.bm * ldw;
     const float* src = p.ws + (int64_t)row * ldw + c0;
@@ -1519,9 +1549,12 @@ struct PlaneDesc {
     int rows_ok;                                                    // bmt_planes_desc: eligible for the 16-byte row kernel
     const float* gate; int64_t ldgate; float gate_scale;            // optional: v = gate[r][c] != 0 ? v * gate_scale : 0 (relu / dropout derivative
                                                                     // from the saved forward output: bmt_planes_gate)
+    const int* rows_dev;                                            // optional (packed rows): only rows < *rows_dev exist; the launch is sized for R
 };
 
-__device__ __forceinline__ void planes_tile(const PlaneDesc& d, int bx, int by, float (*tile)[65]) {
+__device__ __forceinline__ void planes_tile(const PlaneDesc& d_, int bx, int by, float (*tile)[65]) {
+    PlaneDesc d = d_;
+    if (d.rows_dev != nullptr) d.R = min(d.R, *d.rows_dev);
     const int r0 = by * 64, c0 = bx * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 row groups
     float csum = 0.f;
@@ -1575,7 +1608,9 @@ __global__ __launch_bounds__(256) void planes_kernel(const PlaneDesc d) {
 // converts 8 consecutive columns of a row, two 16-byte loads in, one 16-byte store per plane out (planes_tile moves 4 / 2 bytes
 // per access because its thread mapping serves the LDS transpose).  Block = 64 rows x 128 columns; column sums: 8 partials per
 // thread, folded over the 16 row-threads of a column group through LDS, one atomic per column per block.
-__device__ __forceinline__ void planes_rows_tile(const PlaneDesc& d, int bx, int by, float (*cs)[129]) {
+__device__ __forceinline__ void planes_rows_tile(const PlaneDesc& d_, int bx, int by, float (*cs)[129]) {
+    PlaneDesc d = d_;
+    if (d.rows_dev != nullptr) d.R = min(d.R, *d.rows_dev);
     const int tid = threadIdx.x;
     const int cg = (tid & 15) * 8, rt = tid >> 4;
     const int c0 = bx * 128 + cg, r0 = by * 64;
@@ -1873,6 +1908,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.plane_cols = p.Chi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
     p.plane_vec = p.Chi && al16(p.Chi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
+    p.rows_dev = a->rows_dev;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
     static const int tap_minor = getenv("BMT_CONV_DW_TAP_MINOR") ? atoi(getenv("BMT_CONV_DW_TAP_MINOR")) : 1;      // A/B: 0 = tap-major column tiles
     p.conv_tap_minor = (a->conv_mode == 2 && a->conv_cin % BN == 0) ? tap_minor : 0;
@@ -2254,6 +2290,7 @@ static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, u
     d.colsum = colsum;
     d.drop_p = 0.f; d.drop_site = 0; d.drop_rng = nullptr;
     d.gate = nullptr; d.ldgate = 0; d.gate_scale = 1.f;
+    d.rows_dev = nullptr;
     d.pcols = (hi || fh) ? (int)(((C + 63) / 64 * 64) < ldp ? ((C + 63) / 64 * 64) : ldp) : 0;
     d.pcolsT = hiT ? (int)(((R + 63) / 64 * 64) < ldpT ? ((R + 63) / 64 * 64) : ldpT) : 0;
     d.tiles_x = bmt_cdiv(d.pcols > C ? d.pcols : C, 64);
@@ -2262,10 +2299,12 @@ static int fill_desc(PlaneDesc& d, const float* src, int64_t ld, int R, int C, u
 }
 
 extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
-                          uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, void* stream) {
+                          uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, const int* rows_dev, void* stream) {
     PlaneDesc d;
     int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, hiT, loT, ldpT, colsum);
     if (rc) return rc;
+    BMT_CHECK_ARG(!rows_dev || !hiT, "bmt_planes: packed rows (rows_dev) with a transposed plane");
+    d.rows_dev = rows_dev;
     if (planes_rows_ok(d)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(planes_kernel, dim3(d.tiles_x, d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
     BMT_CHECK_LAUNCH("bmt_planes");
@@ -2274,10 +2313,12 @@ extern "C" int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* 
 
 extern "C" int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
                                   uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site,
-                                  void* stream) {
+                                  const int* rows_dev, void* stream) {
     PlaneDesc d;
     int rc = fill_desc(d, src, ld, R, C, hi, lo, fh, fl, ldp, hiT, loT, ldpT, colsum);
     if (rc) return rc;
+    BMT_CHECK_ARG(!rows_dev || !hiT, "bmt_planes_dropout: packed rows (rows_dev) with a transposed plane");
+    d.rows_dev = rows_dev;
     BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_planes_dropout: bad dropout arguments");
     d.drop_p = drop_p; d.drop_site = site; d.drop_rng = rng;
     if (planes_rows_ok(d)) hipLaunchKernelGGL(planes_rows_kernel, dim3(bmt_cdiv(d.pcols, 128), bmt_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, d);

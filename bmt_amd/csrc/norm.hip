@@ -16,9 +16,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                       const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
                                                       float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                      int64_t ldp, int pcols, int lo_f16) {
+                                                      int64_t ldp, int pcols, int lo_f16, const int* __restrict__ rows_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rows_dev != nullptr) rows = min(rows, *rows_dev);      // packed rows: the count is data (bmt_gemm_bf16_args.rows_dev)
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * ldx;
     float* yr = y ? y + (int64_t)row * ldy : nullptr;
@@ -85,9 +86,10 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
                                                           const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
                                                           float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                          int64_t ldp, int pcols, int lo_f16) {
+                                                          int64_t ldp, int pcols, int lo_f16, const int* __restrict__ rows_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rows_dev != nullptr) rows = min(rows, *rows_dev);
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * ldx;
     float* yr = y ? y + (int64_t)row * ldy : nullptr;
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                       float* __restrict__ partial, int rows_per_wave, int rows, int D,
                                                       const float* __restrict__ dx_add2, int64_t ldadd2,
                                                       uint16_t* __restrict__ gp_hi, int64_t gp_ld, float gp_drop_p, const uint64_t* __restrict__ gp_rng,
-                                                      uint32_t gp_site) {
+                                                      uint32_t gp_site, const int* __restrict__ rows_dev) {
+    if (rows_dev != nullptr) rows = min(rows, *rows_dev);      // packed rows: workgroups past the count leave zero partials
     // gp_hi (optional): the bf16 operand plane of dropout_site(dx) -- what the PREVIOUS sublayer's last GEMM backward reads as its upstream
     // gradient (x_out = x + dropout(sublayer(LN x)): d x_out reaches that GEMM through the residual dropout's mask) -- and, in the third
     // block of the workgroup's partials, its column sums (that GEMM's bias gradient): the separate conversion pass over dx is gone
@@ -308,9 +311,11 @@ __global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const float* __restr
                                                              int64_t ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              float* dx, int64_t lddx, const float* dx_add, int64_t ldadd,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D,
+                                                             const int* __restrict__ rows_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rows_dev != nullptr) rows = min(rows, *rows_dev);
     if (row >= rows) return;
     const float mu = mean[row], rs = rstd[row];
     const float* xr = x + (int64_t)row * ldx;
@@ -337,7 +342,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                                         float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp, int rows, int D,
-                                        float eps, void* stream) {
+                                        float eps, const int* rows_dev, void* stream) {
     BMT_CHECK_ARG(x && gamma && beta && (y || hi) && rows >= 0 && D > 0, "bmt_layernorm_fwd: bad args");
     BMT_CHECK_ARG(!lo || hi, "bmt_layernorm_fwd_planes: lo plane without hi plane");
     BMT_CHECK_ARG(!hi || ldp >= D, "bmt_layernorm_fwd_planes: plane row stride %lld < D=%d", (long long)ldp, D);
@@ -348,16 +353,16 @@ extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float
                      (!hi || ((ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0));
     dim3 grid(bmt_cdiv(rows, 4)), block(256);
     static const int reg_env = getenv("BMT_LN_FWD_REG") ? atoi(getenv("BMT_LN_FWD_REG")) : 1;      // A/B: 0 = the three-read kernel
-#define BMT_LNF(NV) hipLaunchKernelGGL(ln_fwd_reg_kernel<NV>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16)
+#define BMT_LNF(NV) hipLaunchKernelGGL(ln_fwd_reg_kernel<NV>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16, rows_dev)
     if (vec && reg_env && D <= 2048) {
         const int nv = bmt_cdiv(D, 256);
         if (nv <= 1) BMT_LNF(1);
         else if (nv <= 2) BMT_LNF(2);
         else if (nv <= 4) BMT_LNF(4);
         else BMT_LNF(8);
-    } else if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
+    } else if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16, rows_dev);
 #undef BMT_LNF
-    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16, rows_dev);
     BMT_CHECK_LAUNCH("bmt_layernorm_fwd");
     return BMT_OK;
 }
@@ -365,7 +370,7 @@ extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float
 extern "C" int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                                  float* mean, float* rstd, int rows, int D, float eps, void* stream) {
     BMT_CHECK_ARG(y, "bmt_layernorm_fwd: bad args");
-    return bmt_layernorm_fwd_planes(x, ldx, gamma, beta, y, ldy, mean, rstd, nullptr, nullptr, 0, 0, rows, D, eps, stream);
+    return bmt_layernorm_fwd_planes(x, ldx, gamma, beta, y, ldy, mean, rstd, nullptr, nullptr, 0, 0, rows, D, eps, nullptr, stream);
 }
 
 extern "C" int bmt_layernorm_bwd_blocks(int rows) { return rows <= 0 ? 0 : bmt_cdiv(rows, 4 * ln_bwd_rows_per_wave(rows)); }
@@ -374,34 +379,38 @@ extern "C" int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
                                  const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                                  float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
     return bmt_layernorm_bwd_add(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, accumulate_dx ? dx : nullptr, lddx, dgamma, dbeta,
-                                 partial_ws, rows, D, stream);
+                                 partial_ws, rows, D, nullptr, stream);
 }
 
 struct LnGradPlane { uint16_t* hi; int64_t ld; float drop_p; const uint64_t* rng; uint32_t site; };
 static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
                        int D, void* stream, bool leave_partials, const float* dx_add2 = nullptr, int64_t ldadd2 = 0,
-                       const LnGradPlane* gp = nullptr);
+                       const LnGradPlane* gp = nullptr, const int* rows_dev = nullptr);
 
 extern "C" int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                      const float* mean, const float* rstd, float* dx, int64_t lddx, const float* dx_add,
-                                     int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream) {
+                                     int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows, int D, const int* rows_dev,
+                                     void* stream) {
     BMT_CHECK_ARG(dgamma && dbeta, "bmt_layernorm_bwd: bad args");
-    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, rows, D, stream, false);
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, rows, D, stream, false, nullptr, 0, nullptr,
+                       rows_dev);
 }
 
 extern "C" int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
                                          const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* partial_ws,
-                                         int rows, int D, void* stream) {
+                                         int rows, int D, const int* rows_dev, void* stream) {
     BMT_CHECK_ARG(partial_ws, "bmt_layernorm_bwd_partial: needs the partial workspace");
-    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true);
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, nullptr, 0, nullptr,
+                       rows_dev);
 }
 
 extern "C" int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
                                           const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2,
-                                          int64_t ldadd2, float* partial_ws, int rows, int D, void* stream) {
+                                          int64_t ldadd2, float* partial_ws, int rows, int D, const int* rows_dev, void* stream) {
     BMT_CHECK_ARG(partial_ws, "bmt_layernorm_bwd_partial2: needs the partial workspace");
-    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2);
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2,
+                       nullptr, rows_dev);
 }
 
 // bmt_layernorm_bwd_partial2 that ALSO emits the bf16 operand plane of dropout_site(dx) and its column partials (ABI 5): partial_ws is
@@ -409,18 +418,18 @@ extern "C" int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const f
 extern "C" int bmt_layernorm_bwd_emit(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
                                       const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2,
                                       int64_t ldadd2, float* partial_ws, uint16_t* gp_hi, int64_t gp_ld, float drop_p, const uint64_t* rng,
-                                      uint32_t site, int rows, int D, void* stream) {
+                                      uint32_t site, int rows, int D, const int* rows_dev, void* stream) {
     BMT_CHECK_ARG(partial_ws && gp_hi && gp_ld >= ((D + 63) & ~63) && D % 4 == 0 && gp_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(gp_hi) & 7) == 0,
                   "bmt_layernorm_bwd_emit: needs the partial workspace and an 8-byte aligned plane of at least round_up(D, 64) columns, D a multiple of 4");
     BMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "bmt_layernorm_bwd_emit: bad dropout arguments");
     const LnGradPlane gp{gp_hi, gp_ld, drop_p, rng, site};
     return ln_bwd_impl(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ldadd, nullptr, nullptr, partial_ws, rows, D, stream, true, dx_add2, ldadd2,
-                       &gp);
+                       &gp, rows_dev);
 }
 
 static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* partial_ws, int rows,
-                       int D, void* stream, bool leave_partials, const float* dx_add2, int64_t ldadd2, const LnGradPlane* gp) {
+                       int D, void* stream, bool leave_partials, const float* dx_add2, int64_t ldadd2, const LnGradPlane* gp, const int* rows_dev) {
     BMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows >= 0 && D > 0, "bmt_layernorm_bwd: bad args");
     if (rows == 0) return leave_partials ? 1 : BMT_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -429,7 +438,7 @@ static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ld
     if (!vec && (leave_partials || dx_add2 || gp)) return 1;       // (the scalar kernel adds into dgamma / dbeta directly and knows one addend: the caller falls back)
     if (!vec) {
         hipLaunchKernelGGL(ln_bwd_scalar_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx,
-                           lddx, dx_add, ldadd, dgamma, dbeta, rows, D);
+                           lddx, dx_add, ldadd, dgamma, dbeta, rows, D, rows_dev);
         BMT_CHECK_LAUNCH("bmt_layernorm_bwd(scalar)");
         return BMT_OK;
     }
@@ -438,7 +447,7 @@ static int ln_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ld
 #define BMT_LN(NV)                                                                                                         \
     hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, (gp ? 3 : 2) * 3 * NV * 256 * sizeof(float), st, dy, lddy, x, ldx, gamma, mean, rstd, \
                        dx, lddx, dx_add, ldadd, dgamma, dbeta, partial_ws, ln_bwd_rows_per_wave(rows), rows, D, dx_add2, ldadd2,           \
-                       gp ? gp->hi : nullptr, gp ? gp->ld : 0, gp ? gp->drop_p : 0.f, gp ? gp->rng : nullptr, gp ? gp->site : 0u)
+                       gp ? gp->hi : nullptr, gp ? gp->ld : 0, gp ? gp->drop_p : 0.f, gp ? gp->rng : nullptr, gp ? gp->site : 0u, rows_dev)
     if (nv <= 1) BMT_LN(1);
     else if (nv <= 2) BMT_LN(2);
     else if (nv <= 4) BMT_LN(4);

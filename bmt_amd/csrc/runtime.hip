@@ -26,8 +26,9 @@ namespace {
 // ---------------------------------------------------------------- column sums (bias gradients)
 // grid: (ceil(N/64), row chunks); block 256 = 4 row-lanes x 64 columns; atomic accumulate of chunk partials.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx, int M, int N,
-                                                      float* __restrict__ out, int rows_per_blk) {
+                                                      float* __restrict__ out, int rows_per_blk, const int* __restrict__ rows_dev) {
     __shared__ float red[4][64];
+    if (rows_dev != nullptr) M = min(M, *rows_dev);      // packed rows (bmt_gemm_bf16_args.rows_dev)
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     const int rbeg = blockIdx.y * rows_per_blk, rend = min(M, rbeg + rows_per_blk);
@@ -124,7 +125,7 @@ extern "C" int bmt_colsum_multi(const bmt_colsum_item* items, int n, void* strea
     return BMT_OK;
 }
 
-extern "C" int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream) {
+extern "C" int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, const int* rows_dev, void* stream) {
     BMT_CHECK_ARG(X && out && M >= 0 && N > 0, "bmt_colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) {
@@ -136,7 +137,7 @@ extern "C" int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out,
     if (M == 0) return BMT_OK;
     const int rows_per_blk = 256;
     dim3 grid(bmt_cdiv(N, 64), bmt_cdiv(M, rows_per_blk));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, X, ldx, M, N, out, rows_per_blk);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, X, ldx, M, N, out, rows_per_blk, rows_dev);
     BMT_CHECK_LAUNCH("bmt_colsum");
     return BMT_OK;
 }

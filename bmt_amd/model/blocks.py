@@ -143,12 +143,13 @@ class PositionalEncoder(nn.Module):
             self._pe_dev[key] = self.pos_enc_mat[0].to(device=device, dtype=torch.float32).contiguous()
         return self._pe_dev[key]
 
-    def forward(self, x, fuse_add=None):
+    def forward(self, x, fuse_add=None, pack=None):
         """x + PE[:S] then dropout (blocks.py:101-107).  ``fuse_add`` (optional second tensor added to x first)
-        lets the caller fold the rgb+flow add of captioning_module.py:165 into the same pass."""
+        lets the caller fold the rgb+flow add of captioning_module.py:165 into the same pass.  ``pack`` (ops.RowPack): the result holds
+        the VALID rows only, compacted -- row r is position row_map[r] of the padded batch, with that position's table row."""
         B, S, d_model = x.shape
         p = self.dout_p if self.training else 0.0
-        return ops.PrepFeaturesFn.apply(x, fuse_add, self.table(x.device), p, self._site)
+        return ops.PrepFeaturesFn.apply(x, fuse_add, self.table(x.device), p, self._site, pack)
 
     def __deepcopy__(self, memo):
         new = PositionalEncoder.__new__(PositionalEncoder)

@@ -148,11 +148,33 @@ class BiModalTransformer(nn.Module):
             for param in self.encoder.parameters():
                 param.requires_grad = cfg.finetune_prop_encoder
 
-    def encode(self, src: dict, masks: dict):
-        """features -> encoder memory (Av, Va): rgb + flow, (optional) linear embedders, positional tables, dropout, bi-modal
-        encoder (reference :165-181).  Independent of the caption prefix: greedy decoding calls it once (bmt_amd.decode)."""
+    def row_packs(self, src: dict, masks: dict):
+        """(audio RowPack, video RowPack) when this forward pass can run on PACKED ROWS (ops.PACK_ROWS: the valid positions of the two
+        streams compacted, padded positions never computed -- exact, see bmt_amd.ops), else None: the streams enter the encoder straight
+        from the feature stacks (no embedder in between), and every attention that would meet packed rows -- the encoder's, the
+        decoder's encoder-decoder attentions -- runs on the kernels that take them (d_k 128 / 256, a one-pass operand format)."""
         A = src['audio']
-        if isinstance(self.emb_V, Identity):
+        if not (ops.PACK_ROWS and ops.FUSE_RESIDUAL and ops.LN_PLANES_ONLY and A.is_cuda and isinstance(self.emb_V, Identity)
+                and isinstance(self.emb_A, Identity) and hasattr(self.encoder, "encoder_AV") and hasattr(self.decoder, "decoder")):
+            return None
+        if ops.context().kv_cache is not None or any(t.requires_grad for t in src.values()):
+            return None
+        atts = [a for l in self.encoder.encoder_AV.layers for a in (l.self_att_M1, l.self_att_M2, l.bi_modal_att_M1, l.bi_modal_att_M2)]
+        atts += [a for l in self.decoder.decoder.layers for a in (l.enc_att_A, l.enc_att_V)]
+        for a in atts:
+            if a.d_k not in (128, 256) or ops.policy_of(a).attn == ops.PREC_BF16X3:
+                return None
+        return ops.pack_rows(masks['A_mask']), ops.pack_rows(masks['V_mask'])
+
+    def encode(self, src: dict, masks: dict, packs=None):
+        """features -> encoder memory (Av, Va): rgb + flow, (optional) linear embedders, positional tables, dropout, bi-modal
+        encoder (reference :165-181).  Independent of the caption prefix: greedy decoding calls it once (bmt_amd.decode).
+        packs = row_packs(...): the two streams (and the memories returned) hold packed rows."""
+        A = src['audio']
+        if packs is not None:
+            V = self.pos_enc_V(src['rgb'], fuse_add=src['flow'], pack=packs[1])
+            A = self.pos_enc_A(A, pack=packs[0])
+        elif isinstance(self.emb_V, Identity):
             V = self.pos_enc_V(src['rgb'], fuse_add=src['flow'])
             A = self.pos_enc_A(A)
         else:
@@ -174,13 +196,13 @@ class BiModalTransformer(nn.Module):
         """caption prefix + encoder memory -> decoder states (B, Sc, Dc)  (reference :172-173,182-184)"""
         return self.decoder((self.embed_caption(trg), memory), masks)
 
-    def _encode_staged(self, src, masks):
+    def _encode_staged(self, src, masks, packs=None):
         """encode() between the two events of a batch that is stepped in parts (ops.StepContext.enc_gate / enc_done, set by
         train.CaptioningTrainStep): this part's encoder waits for the previous part's, and says when its own has been issued"""
         ctx = ops.context() if next(iter(src.values())).is_cuda else None
         if ctx is not None and ctx.enc_gate is not None:
             torch.cuda.current_stream().wait_event(ctx.enc_gate)
-        memory = self.encode(src, masks)
+        memory = self.encode(src, masks, packs)
         if ctx is not None and ctx.mark_enc:
             ctx.enc_done = torch.cuda.current_stream().record_event()
         return memory
@@ -190,9 +212,10 @@ class BiModalTransformer(nn.Module):
             ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
         # the caption embedding and the first decoder layer's self-attention sublayer do not depend on the encoder: they are issued on a
         # side stream (ops.fork_side_stream) beside it -- and so is their backward, beside the encoder's
+        packs = self.row_packs(src, masks)
         s3 = ops.fork_side_stream(1) if (trg.is_cuda and hasattr(self.decoder, "decoder")) else None
         if s3 is None:
-            memory = self._encode_staged(src, masks)
+            memory = self._encode_staged(src, masks, packs)
             C = self.decode(trg, memory, masks)
             return self.generator(C)
         s1 = torch.cuda.current_stream()
@@ -201,7 +224,7 @@ class BiModalTransformer(nn.Module):
             t.record_stream(s3)
         with torch.cuda.stream(s3):
             C = first.self_attention_sublayer(self.embed_caption(trg), masks['C_mask'])
-        memory = self._encode_staged(src, masks)
+        memory = self._encode_staged(src, masks, packs)
         s1.wait_stream(s3)
         C.record_stream(s1)
         C._bmt_self_att_done = True

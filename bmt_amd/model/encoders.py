@@ -135,7 +135,7 @@ class BiModalEncoder(nn.Module):
         _SESSION.s2 = s2
         try:
             for t in (A, V, masks['V_mask'], masks['A_mask']):
-                t.record_stream(s2)
+                ops.record_stream(t, s2)
             Av, Va = self.encoder_AV((A, V), (masks['A_mask'], masks['V_mask']))
         finally:
             _SESSION.s2 = None

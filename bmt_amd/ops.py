@@ -395,6 +395,79 @@ def _pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+# ----------------------------------------------------------------------------- packed rows
+# A ragged batch is padded to (B, S, .) and the padded positions carry no information: forward they are only ever read as MASKED keys /
+# values (model/multihead_attention.py:17), backward their gradient is exactly zero in every tensor.  Under PACK_ROWS the encoder's streams
+# hold the valid rows only, compacted in (b, t) order (bmt_pack_rows builds the layout from the mask -- a hole inside a sequence is as
+# good as a padded tail): tensors keep their (B, S, D) SHAPE as a capacity, the number of rows that exist lives in device memory
+# (RowPack.rows_ptr) and every row-wise kernel takes min(capacity, that count) when it runs -- the launch sequence stays shape-static
+# (hipGraph) over data-dependent extents -- the attention kernels take a sample's rows from RowPack.off[b] and nothing is masked.
+# The layout travels with the data: fp32 tensors carry it as ``_bmt_pack``, operand planes as ``Planes.pack``.
+PACK_ROWS = _os.environ.get("BMT_PACK_ROWS", "1") != "0"      # A/B switch: "0" = every padded position is computed as the reference does
+
+
+class RowPack:
+    """layout of the valid rows of one modality's batch: ``off`` int32 [2 B + 2] (off[b] = first packed row of sample b, off[B] = number of
+    valid rows; the rest is scratch), ``row_map`` int32 [B S] (packed row -> b S + t)"""
+    __slots__ = ("off", "row_map", "B", "S")
+
+    def __init__(self, off, row_map, B, S):
+        self.off, self.row_map, self.B, self.S = off, row_map, B, S
+
+    @property
+    def cap(self) -> int:
+        return self.B * self.S
+
+    @property
+    def rows_ptr(self):
+        return C.c_void_p(self.off.data_ptr() + 4 * self.B)
+
+    @property
+    def off_ptr(self):
+        return C.c_void_p(self.off.data_ptr())
+
+    def record_stream(self, stream):
+        self.off.record_stream(stream)
+        self.row_map.record_stream(stream)
+
+
+def pack_rows(mask: torch.Tensor) -> RowPack:
+    """RowPack of a key-padding mask (B, 1, S) / (B, S), bool or uint8 (bmt_pack_rows; two tiny launches)"""
+    m = mask.reshape(mask.shape[0], mask.shape[-1])
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    if m.stride(1) != 1:
+        m = m.contiguous()
+    B, S = m.shape
+    off = torch.empty(2 * B + 2, device=m.device, dtype=torch.int32)
+    row_map = torch.empty(B * S, device=m.device, dtype=torch.int32)
+    _lib.check(lib.bmt_pack_rows(_p(m), m.stride(0), B, S, _p(off), _p(row_map), _st()), "bmt_pack_rows")
+    return RowPack(off, row_map, B, S)
+
+
+def pack_of(t) -> Optional["RowPack"]:
+    return getattr(t, "_bmt_pack", None)
+
+
+def carry_pack(pack, *tensors):
+    """mark tensors (capacity-shaped) as holding packed rows in ``pack``'s layout"""
+    if pack is not None:
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                t._bmt_pack = pack
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def _rows_dev(pack):
+    return pack.rows_ptr if pack is not None else None
+
+
+def _check_pack(pack, rows: int):
+    if pack is not None and pack.cap != rows:
+        raise RuntimeError(f"packed rows: a tensor of {rows} rows carries the layout of a batch of {pack.cap}")
+    return pack
+
+
 class Planes:
     """16-bit operand planes of an fp32 [rows, cols] tensor, row stride padded to a multiple of 64 with zeros (the reduction
     extent of the consuming GEMM); any subset of
@@ -402,10 +475,11 @@ class Planes:
         lo = bf16(x - hi)     split-bf16 forward operand (PREC_BF16X3)
         fh = fp16(x)          fp16 forward operand (PREC_F16 / PREC_F16W2)
         fl = fp16(x - fh)     weights of a PREC_F16W2 product"""
-    __slots__ = ("hi", "lo", "fh", "fl", "rows", "cols")
+    __slots__ = ("hi", "lo", "fh", "fl", "rows", "cols", "pack")
 
-    def __init__(self, hi, lo, rows, cols, fh=None, fl=None):
+    def __init__(self, hi, lo, rows, cols, fh=None, fl=None, pack=None):
         self.hi, self.lo, self.fh, self.fl, self.rows, self.cols = hi, lo, fh, fl, rows, cols
+        self.pack = pack        # RowPack: ``rows`` is the capacity, the rows that exist are counted in device memory (packed rows)
 
     @property
     def any(self):
@@ -417,7 +491,7 @@ class Planes:
     def only(self, *names):
         """a view holding just the named planes (what a backward pass keeps alive)"""
         return Planes(*(getattr(self, n) if n in names else None for n in ("hi", "lo")), self.rows, self.cols,
-                      *(getattr(self, n) if n in names else None for n in ("fh", "fl")))
+                      *(getattr(self, n) if n in names else None for n in ("fh", "fl")), pack=self.pack)
 
 
 # plane sets by consumer: "bwd" single-pass bf16; "x3" split-bf16 activation / weight; "f16" fp16 activation (+ bf16 for the
@@ -441,24 +515,28 @@ def _alloc_planes(rows: int, cols: int, fmt: str, device, ld: Optional[int] = No
     return Planes(bufs.get("hi"), bufs.get("lo"), rows, cols, bufs.get("fh"), bufs.get("fl"))
 
 
-def make_planes(x2: torch.Tensor, fmt: str = "x3", colsum=None, drop=None, gate=None) -> Planes:
+def make_planes(x2: torch.Tensor, fmt: str = "x3", colsum=None, drop=None, gate=None, pack=None) -> Planes:
     """one pass over fp32 x2 [R,C] -> Planes [R][pad64(C)] of the given set; colsum (optional fp32 [C]) += column sums of x2
     (atomic).  drop = (p, site): the planes (and column sums) are those of dropout(x2) with the mask of that site over a
     contiguous [R][C] tensor.  gate = (y [R,C] fp32, scale): those of (y != 0) ? x2 * scale : 0 -- the gradient through a relu (and a
     dropout in front of it) from the saved forward output, without materialising it (bmt_planes_gate)."""
     R, Cc = x2.shape
     pl = _alloc_planes(R, Cc, fmt, x2.device)
+    pl.pack = _check_pack(pack, R)
+    rd = _rows_dev(pack)
     ld = pl.any.stride(0)
     if gate is not None:
+        if pack is not None:
+            raise RuntimeError("make_planes: the gate form does not take packed rows")
         y2, gscale = gate
         _lib.check(lib.bmt_planes_gate(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, _p(colsum), _p(y2), y2.stride(0),
                                        float(gscale), _st()), "bmt_planes_gate")
         return pl
     if drop is not None and drop[0] > 0.0:
         _lib.check(lib.bmt_planes_dropout(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, None, None, 0, _p(colsum),
-                                          drop[0], _p(rng_tensor()), drop[1], _st()), "bmt_planes_dropout")
+                                          drop[0], _p(rng_tensor()), drop[1], rd, _st()), "bmt_planes_dropout")
     else:
-        _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, None, None, 0, _p(colsum), _st()),
+        _lib.check(lib.bmt_planes(_p(x2), x2.stride(0), R, Cc, _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), ld, None, None, 0, _p(colsum), rd, _st()),
                    "bmt_planes")
     return pl
 
@@ -760,13 +838,14 @@ def fused_weight_groups(model):
     return out
 
 
-def as_planes(x, fmt: str) -> Planes:
-    """x: an fp32 [R,C] tensor or Planes; converts (one pass) unless the planes the consumer needs are already there"""
+def as_planes(x, fmt: str, pack=None) -> Planes:
+    """x: an fp32 [R,C] tensor or Planes; converts (one pass) unless the planes the consumer needs are already there.  pack: the RowPack of
+    a tensor that holds packed rows (Planes carry their own)"""
     if isinstance(x, Planes):
         if not x.has(fmt):
             raise RuntimeError(f"operand planes {[n for n in ('hi', 'lo', 'fh', 'fl') if getattr(x, n) is not None]} do not serve a '{fmt}' consumer")
         return x
-    return make_planes(x, fmt)
+    return make_planes(x, fmt, pack=pack if pack is not None else pack_of(x))
 
 
 _SPLITK_WS = {}          # (device index, stream) -> fp32 scratch: launches of one stream are ordered, two streams must not share it
@@ -861,6 +940,15 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
         a.N = N
         a.conv_mode, a.conv_cin, a.conv_rows = conv["mode"], conv["cin"], conv["rows"]
         a.conv_S, a.conv_halo = conv.get("S", 1), conv.get("halo", 0)
+    # packed rows: the activation operand's layout bounds the product's rows (a weight gradient: its reduction) by a device-side count
+    pk = A.pack if A.pack is not None else (B.pack if (a_km and b_km) else None)
+    if pk is not None:
+        if conv is not None:
+            raise RuntimeError("gemm_bf16: packed rows with an implicit convolution")
+        _check_pack(pk, Ktrue if a_km else M)
+        a.rows_dev = pk.rows_ptr.value
+        if op is not None and not a_km:
+            op.pack = pk
     if splitk != 1 and two_pass:
         ws = splitk_workspace(ah.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
@@ -929,6 +1017,9 @@ def gemm_bf16_grouped(items):
         a.M, a.N, a.Kpad, a.K = A.cols, B.cols, _pad64(rows), rows
         a.alpha, a.gate_scale, a.flags, a.precision, a.splitk = 1.0, 1.0, EPI_ACCUM, PREC_BF16, 1
         a.a_kmajor, a.b_kmajor = 1, 1
+        pk = A.pack if A.pack is not None else B.pack
+        if pk is not None:             # packed rows: the reduction runs over the rows that exist (a device-side count)
+            a.rows_dev = _check_pack(pk, rows).rows_ptr.value
     dev = items[0][2].device
     need = int(lib.bmt_gemm_bf16_grouped_ws_bytes(n))
     # the descriptor tables live in device memory until the launch has executed; several grouped launches of one backward pass
@@ -1060,6 +1151,7 @@ def grad_done(p: Optional[torch.Tensor]):
 
 
 def wgrad(W, b, dyP: Planes, xP: Planes, dy2_for_bias=None, bias_sum=None):
+    # (packed rows: dyP.pack bounds the reduction of the product and of the bias column sums)
     """weight and bias gradient of a Linear: returns (dW, db) tensors for autograd, or (None, None) after accumulating into
     the parameters' static buffers.  bias_sum: an already computed column sum (from grad_planes) or None."""
     gW = static_grad(W)
@@ -1070,7 +1162,7 @@ def wgrad(W, b, dyP: Planes, xP: Planes, dy2_for_bias=None, bias_sum=None):
     if b is not None:
         gb = static_grad(b)
         if bias_sum is None:
-            bias_sum = colsum(dy2_for_bias)
+            bias_sum = colsum(dy2_for_bias, pack=dyP.pack)
         if gb is not None:
             # (atomic accumulation behind the queue of this pass's small reductions: parts of a batch in flight on different streams add to
             # the same buffer)
@@ -1091,28 +1183,28 @@ def drop_grad(dy2: torch.Tensor, b, p: float, site: int):
     return dropout_raw(dy2, p, site), None
 
 
-def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bool = True, drop=None, **dx_epi):
+def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bool = True, drop=None, pack=None, **dx_epi):
     """backward of y = x W^T + b given dy2 [M,N]: one pass builds the gradient's operand plane (+ bias column sums),
     then dX = dY.W and dW += dY^T.X.  x_for_dw: the layer input, fp32 or Planes with a bf16 hi plane.  Returns
     (dx or None, dW or None, db or None); dW/db are None when they were accumulated straight into the parameters' static
     gradient buffers."""
-    P, bias_done = grad_planes(dy2, b, drop=drop)
+    P, bias_done = grad_planes(dy2, b, drop=drop, pack=pack)
     assert drop is None or bias_done or b is None       # (drop_grad guarantees it: the bias sum must see the masked gradient)
     dx = linear_dx(P, W, **dx_epi) if need_dx else None
     dW = db = None
     if need_dw:
-        dW, db = wgrad(W, None if bias_done else b, P, bwd_planes(x_for_dw), dy2_for_bias=dy2)
+        dW, db = wgrad(W, None if bias_done else b, P, bwd_planes(x_for_dw, pack=pack), dy2_for_bias=dy2)
     elif b is not None and not bias_done:
-        db = colsum(dy2)
+        db = colsum(dy2, pack=pack)
     return dx, dW, db
 
 
-def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=None):
+def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=None, pack=None):
     """(bf16 plane of an upstream gradient -- the A operand of dX and, k-major, of dW --, bias-gradient handled?) in ONE pass
     over it; when ``bias`` has a static gradient buffer its column sums are accumulated into that buffer by the same pass.
     drop = (p, site): the gradient first goes through that dropout site's mask (backward of ``x + dropout(y)`` w.r.t. y)."""
     gb = static_grad(bias)
-    P = make_planes(dy2, "bwd", colsum=gb, drop=drop)
+    P = make_planes(dy2, "bwd", colsum=gb, drop=drop, pack=pack)
     if gb is not None:
         grad_done(bias)
     return P, gb is not None
@@ -1131,7 +1223,7 @@ def request_grad_plane(out: torch.Tensor, p: float, site: int):
         out._bmt_gp_req = (float(p), int(site))
 
 
-def grad_planes_from(dout: torch.Tensor, dy2: torch.Tensor, bias: Optional[torch.Tensor], drop):
+def grad_planes_from(dout: torch.Tensor, dy2: torch.Tensor, bias: Optional[torch.Tensor], drop, pack=None):
     """grad_planes(dy2, bias, drop) -- or, when ``dout`` arrives with the plane its producer already built for exactly this dropout site
     (ResidualNormFn.backward), that plane and the queued reduction of its column partials into the bias gradient"""
     gp = getattr(dout, "_bmt_gplane", None)
@@ -1141,27 +1233,27 @@ def grad_planes_from(dout: torch.Tensor, dy2: torch.Tensor, bias: Optional[torch
         D = dy2.shape[1]
         gb = static_grad(bias)
         if (drop == want or (drop is not None and want is not None and tuple(drop) == want)) and pl.rows == dy2.shape[0] and pl.cols == D \
-                and (bias is None or gb is not None) and getattr(dout, "_bmt_gplane_version", -1) == dout._version:
+                and (bias is None or gb is not None) and getattr(dout, "_bmt_gplane_version", -1) == dout._version and pl.pack is pack:
             if bias is not None:
                 colsum_deferred([(ws, 2 * D, gb, nblk, 3 * D, D)], params=(bias,))
                 grad_done(bias)
             return pl, True
-    return grad_planes(dy2, bias, drop=drop)
+    return grad_planes(dy2, bias, drop=drop, pack=pack)
 
 
-def bwd_planes(x) -> Planes:
+def bwd_planes(x, pack=None) -> Planes:
     """operand of x for the dW product (its bf16 hi plane, k-major): x fp32 tensor or Planes"""
     if isinstance(x, Planes):
         if x.hi is None:
             raise RuntimeError("the backward needs the bf16 plane of a saved activation")
         return x
-    return make_planes(x, "bwd")
+    return make_planes(x, "bwd", pack=pack)
 
 
-def colsum(x2: torch.Tensor) -> torch.Tensor:
+def colsum(x2: torch.Tensor, pack=None) -> torch.Tensor:
     M, N = x2.shape
     out = torch.empty(N, device=x2.device, dtype=torch.float32)
-    _lib.check(lib.bmt_colsum(_p(x2), x2.stride(0), M, N, _p(out), 0, _st()), "bmt_colsum")
+    _lib.check(lib.bmt_colsum(_p(x2), x2.stride(0), M, N, _p(out), 0, _rows_dev(_check_pack(pack, M)), _st()), "bmt_colsum")
     return out
 
 
@@ -1236,14 +1328,15 @@ def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision
 ATTN_KMEAN = _os.environ.get("BMT_NO_KMEAN") != "1"      # A/B: the dQ correction by (row sum of rounded dS) x mean key
 
 
-def attn_kmean(kh: torch.Tensor, ldk: int, bsk: int, B: int, Sk: int, D: int, mask_args, f16: bool = False) -> Optional[torch.Tensor]:
+def attn_kmean(kh: torch.Tensor, ldk: int, bsk: int, B: int, Sk: int, D: int, mask_args, f16: bool = False, kpack=None) -> Optional[torch.Tensor]:
     """fp32 [B][D] mean key over the valid keys of a K plane (bmt_attn_kmean; f16: the plane holds fp16), or None when the correction
     is switched off"""
     _, mptr, mbs, mqs = mask_args
     if not ATTN_KMEAN or mqs != 0:       # a mask with a row per query (the decoder's causal self-attention: <= 30 keys, error 0.5 % as it is)
         return None
     out = torch.empty(B, D, device=kh.device, dtype=torch.float32)
-    _lib.check(lib.bmt_attn_kmean(_p(kh), ldk, bsk, mptr, mbs, mqs, B, Sk, D, _p(out), int(f16), _st()), "bmt_attn_kmean")
+    _lib.check(lib.bmt_attn_kmean(_p(kh), ldk, bsk, mptr, mbs, mqs, B, Sk, D, _p(out), int(f16), kpack.off_ptr if kpack is not None else None, _st()),
+               "bmt_attn_kmean")
     return out
 
 
@@ -1287,6 +1380,11 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     ol = _plane_buf(B * Sq, D, dev) if out_fmt == "x3" else None
     of = _plane_buf(B * Sq, D, dev, torch.float16) if out_fmt == "f16" else None
     lse = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
+    qpack, kpack = _check_pack(q.pack, B * Sq), _check_pack(k.pack, B * Sk)
+    if kpack is not v.pack:
+        raise RuntimeError("attn_fwd_planes: keys and values in different row layouts")
+    if kpack is not None:
+        mask = None          # packed keys: every one of a sample's k_off[b + 1] - k_off[b] rows is a valid key
     keep, mptr, mbs, mqs = _mask_args(mask, B, Sq, Sk)
     use_drop = drop_p > 0.0
     ldq, ldk, ldv, ldop = qa.stride(0), ka.stride(0), va.stride(0), oh.stride(0)
@@ -1295,9 +1393,10 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
                         ldq=ldq, ldk=ldk, ldv=ldv, ldo=D, bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D,
                         mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk),
                         drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=precision,
-                        Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop, Of=_p(of))
+                        Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop, Of=_p(of),
+                        q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None)
     _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
-    return Planes(oh, ol, B * Sq, D, fh=of), lse
+    return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
 
 ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # A/B switch: "0" keeps the two-kernel backward everywhere
@@ -1346,11 +1445,14 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     dk = D // H
     dev = q.any.device
     Mq, Mk = B * Sq, B * Sk
+    qpack, kpack = _check_pack(q.pack, Mq), _check_pack(k.pack, Mk)
+    if kpack is not None:
+        mask = None          # packed keys: nothing is masked (attn_fwd_planes)
     outs = []
     comb = None
     if fuse in ("qkv", "kv") and D % 64 == 0 and (fuse == "kv" or Mq == Mk):
         n = 3 if fuse == "qkv" else 2
-        comb = Planes(_plane_buf(Mk, n * D, dev), None, Mk, n * D)
+        comb = Planes(_plane_buf(Mk, n * D, dev), None, Mk, n * D, pack=kpack)
     for idx, (M, b) in enumerate(((Mq, biases[0]), (Mk, biases[1]), (Mk, biases[2]))):
         slot = None if comb is None else (idx if fuse == "qkv" else idx - 1)
         hi = comb.hi[:, slot * D:(slot + 1) * D] if (slot is not None and slot >= 0) else _plane_buf(M, D, dev)
@@ -1373,7 +1475,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and f16 and mqs == 0) else None
     # the mean-key correction removes the residue of the bf16-rounded dS (8 significand bits); the split form's dQ runs on fp16 dS with
     # per-query scales (11 bits): with KMEAN_SPLIT off its launches (8 of the step's 14, ~21 us each) are skipped there
-    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16) if (ws is None or KMEAN_SPLIT) else None
+    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16, kpack=kpack) if (ws is None or KMEAN_SPLIT) else None
     a = AttnBwdBf16Args(Qh=_p(qa), Kh=_p(ka), Vh=_p(va), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
@@ -1382,7 +1484,8 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
-                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16))
+                        dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16),
+                        q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None)
     bias_part = None
     if ws is not None:      # the split backward: P / dS / scaled-q workspaces + per-tile bias partials (scratch, freed with this call)
         a.P_ws, a.dS_ws, a.Qb_ws, a.bias_ws = (_p(t) for t in ws)
@@ -1402,10 +1505,10 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
         if items:
             colsum_deferred(items, params=[b for b in biases if b is not None] if static else ())
     res = []
-    for (hi, _, db), M, b in zip(outs, (Mq, Mk, Mk), biases):
+    for (hi, _, db), M, b, pk in zip(outs, (Mq, Mk, Mk), biases, (qpack, kpack, kpack)):
         if b is not None and db is None:
             grad_done(b)
-        res.append((Planes(hi, None, M, D), db))
+        res.append((Planes(hi, None, M, D, pack=pk), db))
     if comb is not None:
         res.append(comb)
     return res
@@ -1481,6 +1584,9 @@ def record_stream(t, stream):
     """Tensor.record_stream for ``t`` AND the operand planes attached to it (written by its producer on the producer's stream, read by a
     consumer on ``stream``: the caching allocator must not reuse them for the producer's stream while that reader is pending)"""
     t.record_stream(stream)
+    pk = pack_of(t)
+    if pk is not None:
+        pk.record_stream(stream)
     pl = getattr(t, "_bmt_planes", None)
     if pl is not None:
         for x in (pl.hi, pl.lo, pl.fh, pl.fl):
@@ -1509,14 +1615,17 @@ class ResidualNormFn(torch.autograd.Function):
         x2 = xc.view(-1, D)
         rows = x2.shape[0]
         y = torch.empty_like(x2)          # fp32_out False: never written (13-34 MB of stores per encoder LayerNorm nothing would read)
+        pack = _check_pack(pack_of(x), rows)
         pl = _alloc_planes(rows, D, fmt, x.device)
+        pl.pack = pack
         second = pl.lo if pl.lo is not None else pl.fh
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y) if fp32_out else None, D, _p(mean), _p(rstd), _p(pl.hi), _p(second),
-                                                int(pl.fh is not None), pl.hi.stride(0), rows, D, eps, _st()), "bmt_layernorm_fwd_planes")
+                                                int(pl.fh is not None), pl.hi.stride(0), rows, D, eps, _rows_dev(pack), _st()), "bmt_layernorm_fwd_planes")
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
+        ctx.pack = pack
         ctx.kv_alias = bool(kv_alias)
         ctx.gp_req = getattr(x, "_bmt_gp_req", None) if D % (4 if LN_EMIT_ANY_WIDTH else 64) == 0 else None      # (request_grad_plane: the producer of x wants dropout(dx) as a plane)
         context().last_ln = pl
@@ -1549,34 +1658,36 @@ class ResidualNormFn(torch.autograd.Function):
         db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         nblk = max(1, lib.bmt_layernorm_bwd_blocks(rows))
         req = ctx.gp_req if LN_EMIT_GRAD_PLANE else None
+        pack = ctx.pack
+        rd = _rows_dev(pack)
         gplane, wld, rc = None, 2 * D, -1
         if req is not None:      # dx AND the operand plane of dropout_site(dx) for the sublayer that produced x (+ its column partials)
             ws = torch.empty(nblk * 3 * D, device=x2.device, dtype=torch.float32)
             gph = torch.empty(rows, _pad64(D), device=x2.device, dtype=torch.bfloat16)      # (the kernel writes the pad columns too)
             use_drop = req[0] > 0.0
             rc = lib.bmt_layernorm_bwd_emit(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), _p(gph), _pad64(D),
-                                            req[0] if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, req[1], rows, D, _st())
+                                            req[0] if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, req[1], rows, D, rd, _st())
             if rc == 0:
-                gplane, wld = (Planes(gph, None, rows, D), req[0], req[1], ws, nblk), 3 * D
+                gplane, wld = (Planes(gph, None, rows, D, pack=pack), req[0], req[1], ws, nblk), 3 * D
             elif rc != 1:
                 _lib.check(rc, "bmt_layernorm_bwd_emit")
         if rc != 0:
             ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
             if add2 is not None:
-                rc = lib.bmt_layernorm_bwd_partial2(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), rows, D, _st())
+                rc = lib.bmt_layernorm_bwd_partial2(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(add2), D, _p(ws), rows, D, rd, _st())
                 if rc == 1:            # (shapes the vector kernel does not take: one addend by the kernel, the other by a separate add)
                     tmp = torch.empty_like(add)
                     _lib.check(lib.bmt_add(_p(add), _p(add2), _p(tmp), add.numel(), _st()), "bmt_add")
                     add, add2 = tmp, None
             if add2 is None:
-                rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, _st())
+                rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(ws), rows, D, rd, _st())
         if rc == 0:        # dgamma / dbeta partials of the kernel's workgroups are in ws: their sums join the pass's other small reductions
             colsum_deferred([(ws, 0, dg, nblk, wld, D), (ws, D, db, nblk, wld, D)], params=(gamma, beta) if fused else ())
         else:
             if rc != 1:
                 _lib.check(rc, "bmt_layernorm_bwd_partial")
             _lib.check(lib.bmt_layernorm_bwd_add(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, _p(add), D, _p(dg), _p(db),
-                                                 _p(ws), rows, D, _st()), "bmt_layernorm_bwd_add")
+                                                 _p(ws), rows, D, rd, _st()), "bmt_layernorm_bwd_add")
         dx = dx.view(g_n.shape)
         if gplane is not None:
             dx._bmt_gplane, dx._bmt_gplane_version = gplane, dx._version
@@ -1594,6 +1705,7 @@ def residual_norm(x, gamma, beta, eps, prec: int = PREC_BF16X3, fp32_out: bool =
     kv_alias: see ResidualNormFn -- the third tensor carries the operand planes attached to ``x`` (a self-attention's result written as the
     other chain's key / value operand)."""
     outs = ResidualNormFn.apply(x, gamma, beta, eps, act_fmt(prec), fp32_out, kv_alias)
+    carry_pack(pack_of(x), *outs)
     xid, xn = outs[0], outs[1]
     c = context()
     attach_planes(xn, c.last_ln)
@@ -1642,7 +1754,7 @@ class LayerNormFn(torch.autograd.Function):
         db = sb if fused else torch.zeros(D, device=x2.device, dtype=torch.float32)
         nblk = max(1, lib.bmt_layernorm_bwd_blocks(rows))
         ws = torch.empty(nblk * 2 * D, device=x2.device, dtype=torch.float32)
-        rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, None, 0, _p(ws), rows, D, _st())
+        rc = lib.bmt_layernorm_bwd_partial(_p(dy2), D, _p(x2), D, _p(gamma), _p(mean), _p(rstd), _p(dx), D, None, 0, _p(ws), rows, D, None, _st())
         if rc == 0:
             colsum_deferred([(ws, 0, dg, nblk, 2 * D, D), (ws, D, db, nblk, 2 * D, D)], params=(gamma, beta) if fused else ())
         else:
@@ -1757,11 +1869,14 @@ class FFNFn(torch.autograd.Function):
         x2 = xc.view(-1, xc.shape[-1])
         prec = pol.ffn1
         fmt = act_fmt(prec)
+        pack = _check_pack(pack_of(x), x2.shape[0])
         xp = planes_of(x, fmt)            # LayerNorm wrote the operand planes of its output already
         if xp is None:
             _need_fp32(x)
         if xp is None:
-            xp = make_planes(x2, fmt)
+            xp = make_planes(x2, fmt, pack=pack)
+        if xp.pack is not pack:
+            raise RuntimeError("FFNFn: the operand planes attached to the input are in another row layout than the input")
         h = linear_fwd_planes(xp, W1, b1, precision=prec, out_fmt=fmt, pad=True, relu=True, drop_post=True, drop_p=p, site=site)
         epi = {}
         if res is not None:              # x_res + dropout(fc2(h)) in fc2's epilogue (ResidualConnection)
@@ -1775,10 +1890,12 @@ class FFNFn(torch.autograd.Function):
         ctx.p = p
         ctx.h = h.only("hi")             # the backward reads bf16 planes only
         ctx.xp = xp.only("hi")
+        ctx.pack = pack
         ctx.res = (res is not None, res_p, res_site)
         ctx.params = (W1, b1, W2, b2)
         ctx.save_for_backward(W1, W2)
         y = y.view(*xc.shape[:-1], W2.shape[0])
+        carry_pack(pack, y)
         if opl is not None:
             attach_planes(y, opl)
         if res is not None:
@@ -1798,7 +1915,7 @@ class FFNFn(torch.autograd.Function):
             dy2, drop = drop_grad(dy2, b2p, res_p, res_site)
         # dH never exists in fp32: the fc2 dX GEMM writes its bf16 plane (relu / dropout derivative applied to whole row
         # segments from the saved hidden plane) and its column sums -- fc1's bias gradient -- from the same epilogue
-        P2, b2_done = grad_planes_from(dy, dy2, b2p, drop) if has_res else grad_planes(dy2, b2p, drop=drop)
+        P2, b2_done = grad_planes_from(dy, dy2, b2p, drop, pack=ctx.pack) if has_res else grad_planes(dy2, b2p, drop=drop, pack=ctx.pack)
         M_, Dff = h.rows, h.cols
         gb1 = static_grad(b1p)
         cs = gb1 if gb1 is not None else torch.zeros(Dff, device=dy2.device, dtype=torch.float32)
@@ -1831,7 +1948,7 @@ def project_group(Xp: Planes, Ws, bs, prec: int, out_fmt: str):
     for W in Ws:
         N = W.shape[0]
         sl = lambda t: None if t is None else t[:, off:off + N]
-        outs.append(Planes(sl(big.hi), sl(big.lo), Xp.rows, N, sl(big.fh), sl(big.fl)))
+        outs.append(Planes(sl(big.hi), sl(big.lo), Xp.rows, N, sl(big.fh), sl(big.fl), pack=Xp.pack))
         off += N
     return outs
 
@@ -1953,12 +2070,18 @@ class MHAFn(torch.autograd.Function):
 
         # each distinct input: operand planes of the format its projection reads, holding the bf16 plane the dW product needs
         # -- one pass (none at all when the producer -- LayerNorm -- attached the planes of its output)
+        qpack, kpack = _check_pack(pack_of(Q), B * Sq), _check_pack(pack_of(K), B * Sk)
+        if pack_of(V) is not kpack:
+            raise RuntimeError("MHAFn: keys and values in different row layouts")
+
         def split(orig, x3d, prec):
             pl = planes_of(orig, act_fmt(prec))
             if pl is None:       # kept on the tensor: the encoder memory is the K / V input of every decoder layer
                 _need_fp32(orig)
-                pl = make_planes(x3d.view(-1, x3d.shape[-1]), act_fmt(prec))
+                pl = make_planes(x3d.view(-1, x3d.shape[-1]), act_fmt(prec), pack=pack_of(orig))
                 attach_planes(orig, pl)
+            if pl.pack is not pack_of(orig):
+                raise RuntimeError("MHAFn: the operand planes attached to an input are in another row layout than the input")
             return pl
         Qp = split(Q, Qc, prec_q)
         Kp = Qp if same_qk else split(K, Kc, prec_kv)
@@ -1988,11 +2111,13 @@ class MHAFn(torch.autograd.Function):
             opl = _alloc_planes(B * Sq, Dq, out_fmt, Qc.device)
             epi["out_planes"] = opl
         out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, Sq, Dq)
+        carry_pack(qpack, out)
         if opl is not None:
             attach_planes(out, opl)
         if res is not None:
             request_grad_plane(out, res_p, res_site)
         ctx.H, ctx.p, ctx.site = H, p, site
+        ctx.packs = (qpack, kpack)
         ctx.res = (res is not None, res_p, res_site)
         ctx.same_qk, ctx.same_kv = same_qk, same_kv
         ctx.fuse = fuse
@@ -2014,14 +2139,15 @@ class MHAFn(torch.autograd.Function):
         B, Sq, Sk, D, Dq, Dk_in, Dv_in = ctx.dims
         Mq, Mk = B * Sq, B * Sk
         Wqp, bqp, Wkp, bkp, Wvp, bvp, Wop, bop = ctx.params
+        qpack, kpack = ctx.packs
         if ctx.qkv_f16:
-            q, k, v = Planes(None, None, Mq, D, fh=qh), Planes(None, None, Mk, D, fh=kh), Planes(None, None, Mk, D, fh=vh)
+            q, k, v = Planes(None, None, Mq, D, fh=qh, pack=qpack), Planes(None, None, Mk, D, fh=kh, pack=kpack), Planes(None, None, Mk, D, fh=vh, pack=kpack)
         else:
-            q, k, v = Planes(qh, None, Mq, D), Planes(kh, None, Mk, D), Planes(vh, None, Mk, D)
+            q, k, v = Planes(qh, None, Mq, D, pack=qpack), Planes(kh, None, Mk, D, pack=kpack), Planes(vh, None, Mk, D, pack=kpack)
         osec = osec if osec.numel() else None
-        o = Planes(oh, None if ctx.o_f16 else osec, Mq, D, fh=osec if ctx.o_f16 else None)
+        o = Planes(oh, None if ctx.o_f16 else osec, Mq, D, fh=osec if ctx.o_f16 else None, pack=qpack)
         # the inputs' own bf16 planes are the (k-major) dW operands
-        QT, KT, VT = Planes(QTh, None, Mq, Dq), Planes(KTh, None, Mk, Dk_in), Planes(VTh, None, Mk, Dv_in)
+        QT, KT, VT = Planes(QTh, None, Mq, Dq, pack=qpack), Planes(KTh, None, Mk, Dk_in, pack=kpack), Planes(VTh, None, Mk, Dv_in, pack=kpack)
         dy2 = _f32c(dout).view(-1, Dq)
         has_res, res_p, res_site = ctx.res
         drop = None
@@ -2029,12 +2155,12 @@ class MHAFn(torch.autograd.Function):
             dy2, drop = drop_grad(dy2, bop, res_p, res_site)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
         if D % 64 == 0:                  # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
-            P_, bias_done = grad_planes_from(dout, dy2, bop, drop) if has_res else grad_planes(dy2, bop, drop=drop)
+            P_, bias_done = grad_planes_from(dout, dy2, bop, drop, pack=qpack) if has_res else grad_planes(dy2, bop, drop=drop, pack=qpack)
             do = linear_dx(P_, Wop, out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
                            drop_post=True, drop_p=ctx.p, site=ctx.site)
             dWo, dbo = wgrad(Wop, None if bias_done else bop, P_, o, dy2_for_bias=dy2)
         else:
-            do, dWo, dbo = lin_bwd(dy2, Wop, bop, o, drop=drop, drop_post=True, drop_p=ctx.p, site=ctx.site)
+            do, dWo, dbo = lin_bwd(dy2, Wop, bop, o, drop=drop, pack=qpack, drop_post=True, drop_p=ctx.p, site=ctx.site)
         res = attn_bwd_planes(q, k, v, o, do, lse, B, Sq, Sk, D, ctx.mask, ctx.H, ctx.p, (bqp, bkp, bvp), fuse=ctx.fuse)
         (Pq, dbq), (Pk, dbk), (Pv, dbv) = res[:3]
         comb = res[3] if len(res) > 3 else None
@@ -2061,7 +2187,7 @@ class MHAFn(torch.autograd.Function):
             for W in Ws:
                 N = W.shape[0]
                 g1 = static_grad(W)
-                dWs.append(linear_dw(Planes(comb.hi[:, off:off + N], None, comb.rows, N), xT, into=g1, params=(W,)))
+                dWs.append(linear_dw(Planes(comb.hi[:, off:off + N], None, comb.rows, N, pack=comb.pack), xT, into=g1, params=(W,)))
                 if g1 is not None:
                     grad_done(W)
                 off += N
@@ -2263,20 +2389,31 @@ class PrepFeaturesFn(torch.autograd.Function):
     """dropout((a [+ b]) + PE)   model/captioning_module.py:165,174-175 + model/blocks.py:101-107."""
 
     @staticmethod
-    def forward(ctx, a, b, pe, p, site):
+    def forward(ctx, a, b, pe, p, site, pack=None):
         ac = _f32c(a)
         bc = None if b is None else _f32c(b)
         B, S, D = ac.shape
         out = torch.empty_like(ac)
-        _lib.check(lib.bmt_prep_features(_p(ac), _p(bc), _p(pe), _p(out), B, S, D, p, _p(rng_tensor()) if p > 0 else None, site,
-                                         _st()), "bmt_prep_features")
+        ctx.packed = pack is not None
+        if pack is not None:          # the valid rows only, compacted (RowPack); the features are data, nothing flows back
+            _check_pack(pack, B * S)
+            if any(ctx.needs_input_grad[:2]):
+                raise RuntimeError("packed rows: feature stacks that require gradients (run with ops.PACK_ROWS = False)")
+            _lib.check(lib.bmt_prep_features_packed(_p(ac), _p(bc), _p(pe), _p(out), B, S, D, p, _p(rng_tensor()) if p > 0 else None, site,
+                                                    _p(pack.row_map), pack.rows_ptr, _st()), "bmt_prep_features_packed")
+            carry_pack(pack, out)
+        else:
+            _lib.check(lib.bmt_prep_features(_p(ac), _p(bc), _p(pe), _p(out), B, S, D, p, _p(rng_tensor()) if p > 0 else None, site,
+                                             _st()), "bmt_prep_features")
         ctx.p, ctx.site, ctx.has_b = p, site, b is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.packed:
+            return None, None, None, None, None, None
         d = dropout_raw(_f32c(dy), ctx.p, ctx.site) if ctx.p > 0 else dy
-        return d, (d if ctx.has_b else None), None, None, None
+        return d, (d if ctx.has_b else None), None, None, None, None
 
 
 class EmbedFn(torch.autograd.Function):
@@ -2379,6 +2516,7 @@ def fanout(x, n: int):
     if n <= 1 or not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()):
         return (x,) * max(n, 1)
     outs = FanoutFn.apply(x, n)
+    carry_pack(pack_of(x), *outs)
     pl = getattr(x, "_bmt_planes", None)
     if pl is not None and getattr(x, "_bmt_planes_version", x._version) == x._version:
         for o in outs:

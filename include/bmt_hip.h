@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 6
+#define BMT_ABI_VERSION 7
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -111,6 +111,12 @@ typedef struct {
      * With C_hi == NULL the fp16 plane is the ONLY plane written (q / k / v under the fp16 attention policy, whose backward converts
      * them on load: bmt_attn_bwd_bf16_args.qkv_f16); excludes C_lo and colsum. */
     uint16_t* C_f16;
+    /* ABI 7 -- PACKED ROWS.  The padded positions of a ragged batch carry no information (masked keys everywhere downstream, exactly zero
+     * gradient): the encoder's row-wise tensors hold the valid rows only, compacted (bmt_pack_rows), and HOW MANY there are this step is
+     * data.  rows_dev (optional, device int32): the launch is sized for M rows (k-major A -- a weight gradient: for K reduction rows)
+     * and every kernel works on min(M | K, *rows_dev) of them, read when it runs -- the same launch (a hipGraph node) serves every batch.
+     * Rows past the count are neither read (they may hold anything) nor written; column sums (colsum) leave them out. */
+    const int* rows_dev;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight
@@ -143,13 +149,14 @@ int bmt_conv_weight_grad(const float* dWp, int64_t ldw, int N, int C, int k, int
  * (lo only with hi, loT only with hiT); padding up to the next multiple of 64 (bounded by the row stride) is zero-filled. */
 int bmt_planes(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh /* fp16(x), optional */,
                uint16_t* fl /* fp16(x - fh), optional */, int64_t ldp, uint16_t* hiT, uint16_t* loT, int64_t ldpT,
-               float* colsum /* optional: colsum[c] += sum_r src[r][c] (atomic) */, void* stream);
+               float* colsum /* optional: colsum[c] += sum_r src[r][c] (atomic) */,
+               const int* rows_dev /* optional, device: only rows < *rows_dev exist (packed rows, see bmt_gemm_bf16_args); not with hiT */, void* stream);
 /* bmt_planes of dropout(src): the fp32 source is masked with the library's counter-based dropout (site, element index
  * r * C + c -- the mask bmt_dropout / the GEMM epilogues draw for a contiguous [R][C] tensor) before it is split; colsum sums
  * the masked values.  Backward of `x + dropout(sub)` fused into the gradient's operand conversion. */
 int bmt_planes_dropout(const float* src, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, uint16_t* fh, uint16_t* fl, int64_t ldp,
                        uint16_t* hiT, uint16_t* loT, int64_t ldpT, float* colsum, float drop_p, const uint64_t* rng, uint32_t site,
-                       void* stream);
+                       const int* rows_dev, void* stream);
 /* the same for MANY tensors in one launch (all weights of a model after an optimizer step): the caller fills a host table of
  * bmt_planes_desc_bytes()-sized descriptors with bmt_planes_desc, uploads it, and passes the device pointer. */
 int bmt_planes_desc_bytes(void);
@@ -165,7 +172,8 @@ int bmt_planes_multi_flat(const void* table_dev, const int* prefix_dev, int n_te
 int bmt_transpose_bf16(const uint16_t* src, int64_t ld, int R, int C, uint16_t* dst, int64_t ldT, void* stream);
 
 /* column sums: out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
-int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream);
+int bmt_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
+               const int* rows_dev /* optional, device (ABI 7): only rows < *rows_dev are summed */, void* stream);
 /* many small reductions in ONE launch: out_i[c] += sum over r < rows_i of part_i[r * ld_i + c], c < D_i (fp32).  The second stage of the
  * LayerNorm dgamma / dbeta partials (bmt_layernorm_bwd_partial) and of the attention backward's per-tile bias sums (defer_bias): the
  * host side queues them over a backward pass and issues them together.  `items` is read on the HOST during the call (and passed to the
@@ -252,6 +260,11 @@ typedef struct {
     int precision;
     uint16_t *Oh, *Ol; int64_t ldop, bsop;            /* optional plane outputs */
     uint16_t* Of;                                     /* alternative to Ol: fp16(o) plane (consumer: an fp16-policy out-projection) */
+    /* ABI 7 -- PACKED ROWS (bmt_pack_rows): with q_off (int32 [B + 1], device) the query-side planes (Q, O / Oh / Ol / Of) hold the valid
+     * rows of the batch compacted -- sample b's queries are rows q_off[b] .. q_off[b + 1] - 1, the batch strides are ignored; with k_off the
+     * same for K / V (mask must be NULL: every packed key is valid).  Sq / Sk stay the PADDED lengths (they size the launch and index lse,
+     * which keeps its [B, H, Sq] layout by position within the sample).  Taken by the one-pass d_k >= 128 kernels. */
+    const int *q_off, *k_off;
 } bmt_attn_fwd_bf16_args;
 int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* args, void* stream);
 
@@ -284,6 +297,8 @@ typedef struct {
     int defer_bias;                                   /* with bias_ws: leave the per-tile sums there (rows b * tiles + tile of [D] floats: dbq's B * ceil(Sq / 128)
                                                          rows, then dbk's and dbv's B * ceil(Sk / 128) each) and skip the finishing launch: the caller
                                                          adds them up itself (bmt_colsum_multi, together with other reductions) */
+    const int *q_off, *k_off;                         /* ABI 7: packed rows as in bmt_attn_fwd_bf16_args -- q side: Q, O planes, dOh_ws, dQh; k side: K, V, dKh, dVh.  lse, delta_ws,
+                                                         the split backward's workspaces and the per-tile bias partials keep their padded layouts */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* element counts of the split backward's workspaces for a problem: P_ws and dS_ws (bf16) take *n_pds each, Qb_ws (bf16) *n_qb, bias_ws
@@ -302,7 +317,8 @@ int64_t bmt_attn_bwd_bias_ws(int B, int H, int Sq, int Sk, int dk);
    carries the keys' common component.  No counterpart in the reference: numerical aid of the 16-bit backward
    (model/multihead_attention.py:8-26 is exact in fp32). */
 int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, const uint8_t* mask, int64_t mask_bs, int64_t mask_qs, int B, int Sk, int D,
-                   float* out, int k_f16, void* stream);     /* k_f16: the plane holds fp16 */
+                   float* out, int k_f16 /* the plane holds fp16 */,
+                   const int* k_off /* optional (ABI 7): packed rows -- sample b's keys are rows k_off[b] .. k_off[b + 1] - 1, bsk and mask ignored */, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (model/blocks.py:127,131,143,150) */
 /* y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D (biased variance).  mean/rstd: [rows] saved for backward. */
@@ -313,7 +329,8 @@ int bmt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
  * them directly, no separate conversion pass. */
 int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                              float* mean, float* rstd, uint16_t* hi, uint16_t* lo, int lo_f16 /* lo receives fp16(y) instead */,
-                             int64_t ldp, int rows, int D, float eps, void* stream);
+                             int64_t ldp, int rows, int D, float eps,
+                             const int* rows_dev /* optional, device: rows = min(rows, *rows_dev) when the kernel runs (packed rows, ABI 7) */, void* stream);
 /* dx (+)= LN backward; dgamma/dbeta += column reductions (accumulate into pre-zeroed or live grads).
  * dx[i] = (accumulate_dx ? dx[i] : 0) + ...
  * partial_ws: NULL -> one atomic per column per workgroup; else fp32 [bmt_layernorm_bwd_blocks(rows)][2][D] scratch for a
@@ -323,13 +340,14 @@ int bmt_layernorm_bwd_blocks(int rows);
  * in partial_ws ([blocks][2 D]: dgamma | dbeta) for the caller to reduce (bmt_colsum_multi).  Returns 1 -- and does nothing -- where the
  * vector kernel does not apply (D > 2048, unaligned rows): the caller then uses bmt_layernorm_bwd_add. */
 int bmt_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
-                              float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* partial_ws, int rows, int D, void* stream);
+                              float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* partial_ws, int rows, int D,
+                              const int* rows_dev /* optional (ABI 7): as in bmt_layernorm_fwd_planes; workgroups past the count leave zero partials */, void* stream);
 /* bmt_layernorm_bwd_partial with a SECOND addend: dx = dx_add + dx_add2 + LN backward.  The input of a ResidualConnection's LayerNorm that
  * is also the key / value input of the other modality's cross-attention (model/encoders.py:63-79) has three consumers; their gradients meet
  * in this kernel instead of in an add kernel of autograd's (ABI 5).  Returns 1 where the vector kernel does not apply. */
 int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                                float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2, int64_t ldadd2,
-                               float* partial_ws, int rows, int D, void* stream);
+                               float* partial_ws, int rows, int D, const int* rows_dev, void* stream);
 /* ... and with the NEXT consumer's operand conversion folded in (ABI 5): besides dx the kernel writes gp_hi [rows][gp_ld] = bf16 of
  * dropout(dx) under the mask of (drop_p, rng, site) over the contiguous [rows][D] index space -- the upstream-gradient operand of the
  * previous sublayer's last GEMM backward (x_out = x + dropout(sublayer(LN x))) -- and leaves that plane's column partials (the GEMM's bias
@@ -337,7 +355,8 @@ int bmt_layernorm_bwd_partial2(const float* dy, int64_t lddy, const float* x, in
  * where the vector kernel does not apply. */
 int bmt_layernorm_bwd_emit(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                            float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, const float* dx_add2, int64_t ldadd2, float* partial_ws,
-                           uint16_t* gp_hi, int64_t gp_ld, float drop_p, const uint64_t* rng, uint32_t site, int rows, int D, void* stream);
+                           uint16_t* gp_hi, int64_t gp_ld, float drop_p, const uint64_t* rng, uint32_t site, int rows, int D, const int* rows_dev,
+                           void* stream);
 int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate_dx,
                       float* dgamma, float* dbeta, float* partial_ws, int rows, int D, void* stream);
@@ -345,13 +364,22 @@ int bmt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
  * autograd would form with a separate add kernel is produced by the LayerNorm backward itself. */
 int bmt_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
                           const float* rstd, float* dx, int64_t lddx, const float* dx_add, int64_t ldadd, float* dgamma,
-                          float* dbeta, float* partial_ws, int rows, int D, void* stream);
+                          float* dbeta, float* partial_ws, int rows, int D, const int* rows_dev, void* stream);
 
 /* ---------------------------------------------------------------- input prep / elementwise (K8) */
 /* out[b,s,:] = dropout( (a[b,s,:] (+ b2[b,s,:])) * in_scale + PE[s,:] )      model/captioning_module.py:165,174-176, blocks.py:101-107
  * PE is the reference's table (sin on even j, cos on odd j, exponent j/D for both), passed in as fp32 [>=S, D]. */
 int bmt_prep_features(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D,
                       float drop_p, const uint64_t* rng, uint32_t site, void* stream);
+/* ABI 7 -- PACKED ROWS (epoch_loops/captioning_epoch_loops.py:105-112 derives the masks; model/multihead_attention.py:17 is the only place the
+ * reference reads a padded position: as a masked key).  bmt_pack_rows turns a key-padding mask (uint8 [B][S], batch stride mask_bs, 1 = valid)
+ * into the layout of the valid rows: off[b] (int32 [2 B + 2]: B + 1 offsets, then scratch) = number of valid positions of the samples before b -- off[B] = their total, the
+ * `rows_dev` of every row-wise kernel --, row_map[r] (int32 [B * S]) = b * S + t of packed row r (in (b, t) order; derived from the mask,
+ * so a hole inside a sequence is as good as a padded tail).  bmt_prep_features_packed is bmt_prep_features writing packed rows:
+ * out[r] = dropout(a[row_map[r]] (+ b2[row_map[r]]) + PE[row_map[r] % S]) for r < off[B]; the dropout mask is indexed by the packed element. */
+int bmt_pack_rows(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, void* stream);
+int bmt_prep_features_packed(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D, float drop_p,
+                             const uint64_t* rng, uint32_t site, const int* row_map, const int* rows_dev, void* stream);
 /* out[b,s,:] = dropout( W[ids[b,s],:] * emb_scale + PE[s,:] )                model/blocks.py:42-46 + pos enc */
 int bmt_prep_embed(const int64_t* ids, const float* W, const float* pe, float* out, int B, int S, int D, int V,
                    float emb_scale, float drop_p, const uint64_t* rng, uint32_t site, void* stream);

@@ -786,7 +786,7 @@ def test_layernorm_forward_writes_its_operand_planes(ops, rows, D):
         lo = torch.full((rows, ld), 7.0, device=DEV, dtype=torch.float16 if f16 else torch.bfloat16)
         m, r = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
         _lib.check(lib.bmt_layernorm_fwd_planes(ops._p(x), D, ops._p(gamma), ops._p(beta), ops._p(y) if with_y else None, D, ops._p(m),
-                                                ops._p(r), ops._p(hi), ops._p(lo), int(f16), ld, rows, D, 1e-5, ops._st()), "ln planes")
+                                                ops._p(r), ops._p(hi), ops._p(lo), int(f16), ld, rows, D, 1e-5, None, ops._st()), "ln planes")
         if with_y:
             assert torch.equal(y, y0)
         assert torch.equal(m, m0) and torch.equal(r, r0)
@@ -808,7 +808,7 @@ def test_layernorm_backward_adds_the_residual_gradient(ops, rows, D):
         dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
         ws = torch.empty(max(1, lib.bmt_layernorm_bwd_blocks(rows)) * 2 * D, device=DEV)
         _lib.check(lib.bmt_layernorm_bwd_add(ops._p(dy), D, ops._p(x), D, ops._p(gamma), ops._p(mean), ops._p(rstd), ops._p(dx), D,
-                                             ops._p(a), D, ops._p(dg), ops._p(db), ops._p(ws), rows, D, ops._st()), "ln bwd add")
+                                             ops._p(a), D, ops._p(dg), ops._p(db), ops._p(ws), rows, D, None, ops._st()), "ln bwd add")
         outs.append((dx, dg, db))
     assert torch.equal(outs[1][0], outs[0][0] + add)              # one fp32 add, same rounding as the separate kernel
     assert_close(outs[1][1], outs[0][1], atol=1e-4, rtol=1e-5, name="dgamma")
