@@ -56,6 +56,7 @@ struct GemmB {
     int nk_loader;                       // gemm_k128_kernel: 1 = seven computing waves + a loading wave, 0 = eight waves that load their own rows
     int nk_dbg;                          // experiments (env BMT_K128_DBG): 1 no stores, 2 no MFMAs, 4 no next-unit prefetch
     int nk_ncw, nk_rg, nk_upw;           // gemm_k128_kernel: weight rows per resident chunk, row groups, 32-row units per row group
+    int rows_is_k;                       // rows_dev bounds the REDUCTION (A k-major: a weight gradient), not the output rows
     const int* rows_dev;                 // packed rows (bmt_gemm_bf16_args.rows_dev): the rows actually present, in device memory; the launch is sized for M
                                          // (k-major A: for krows) and every kernel takes min(M, *rows_dev) -- graph-static grids over data-dependent extents
 #ifdef BMT_EXP
@@ -1490,7 +1491,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)p.M * ncg) return;
     const int row = (int)(idx / ncg), c0 = (int)(idx % ncg) * 4;
-    if (p.rows_dev != nullptr && row >= *p.rows_dev) return;      // packed rows: the tiles past the rows present wrote no partials
+    if (p.rows_dev != nullptr && !p.rows_is_k && row >= *p.rows_dev) return;      // packed rows: the tiles past the rows present wrote no partials
     const int64_t ldw = (int64_t)p.tiles_n * BN;
     const int64_t slab = (int64_t)p.tiles_m * p.bm * ldw;
     const float* src = p.ws + (int64_t)row * ldw + c0;
@@ -1908,7 +1909,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.plane_cols = p.Chi ? (int)((a->N + 63) / 64 * 64 < a->ldp ? (a->N + 63) / 64 * 64 : a->ldp) : 0;
     p.plane_vec = p.Chi && al16(p.Chi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
-    p.rows_dev = a->rows_dev;
+    p.rows_dev = a->rows_dev; p.rows_is_k = a->a_kmajor != 0;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
     static const int tap_minor = getenv("BMT_CONV_DW_TAP_MINOR") ? atoi(getenv("BMT_CONV_DW_TAP_MINOR")) : 1;      // A/B: 0 = tap-major column tiles
     p.conv_tap_minor = (a->conv_mode == 2 && a->conv_cin % BN == 0) ? tap_minor : 0;
@@ -2128,8 +2129,9 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
 // ---- grouped launch (see gemm_bf16_grouped_kernel).  The descriptor table and the per-XCD segment lists live in device memory
 // and are written by small kernels whose ARGUMENTS carry them: nothing is read from host memory when the launch executes, so the
 // sequence can be captured in a hipGraph and replayed (a memcpy node would re-read a host buffer that may have changed).
+constexpr int GEMM_PACK_N = 13;      // descriptors per table-writer launch (they travel in its kernel arguments)
 struct GemmPack {
-    GemmB d[14];
+    GemmB d[GEMM_PACK_N];
     int n, base;
 };
 static_assert(sizeof(GemmPack) <= 4000, "descriptor pack must fit the kernel argument buffer");
@@ -2237,8 +2239,8 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
     int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
     GemmPack pk;
-    for (int base = 0; base < nprob; base += 14) {
-        pk.n = nprob - base < 14 ? nprob - base : 14;
+    for (int base = 0; base < nprob; base += GEMM_PACK_N) {
+        pk.n = nprob - base < GEMM_PACK_N ? nprob - base : GEMM_PACK_N;
         pk.base = base;
         for (int i = 0; i < pk.n; ++i) pk.d[i] = pr[base + i].p;
         hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table);

@@ -137,7 +137,7 @@ def test_gemm_families_under_a_device_side_row_count(ops, M, N, K, prec, kind, f
         assert bool((got[n:] == 7.0).all()), "rows past the count were written"
 
 
-@pytest.mark.parametrize("rows,n", [(8192, 6100), (25600, 19508), (600, 0), (600, 600)])
+@pytest.mark.parametrize("rows,n", [(8192, 6100), (25600, 19508), (600, 0), (600, 600), (600, 150)])
 def test_weight_gradients_reduce_over_the_rows_that_exist(ops, rows, n):
     """dW = dY^T . X through the grouped launch (and the single launch): the reduction stops at the device-side count; rows past it hold NaN"""
     N, K = 384, 256
@@ -361,7 +361,7 @@ def test_model_on_packed_rows_against_the_oracle_and_the_padded_path(ops, holes)
         loss_d.backward()
     finally:
         ops.PACK_ROWS = True
-    assert_close(pred, pred_d.detach(), atol=2e-4, name="packed vs padded log-probs")
+    assert_close(pred, pred_d.detach(), atol=5e-4 if holes else 2e-4, name="packed vs padded log-probs")      # (a hole shifts the key tiles of its sample: fp16 roundings fall differently)
     num = sum(float((gpacked[k].double() - q.grad.double()).norm() ** 2) for k, q in model.named_parameters() if q.grad is not None)
     den = sum(float(q.grad.double().norm() ** 2) for k, q in model.named_parameters() if q.grad is not None)
     assert (num / den) ** 0.5 < 5e-3, f"packed vs padded gradients differ by {(num / den) ** 0.5:.3e}"
