@@ -256,11 +256,16 @@ def cpu_baseline(timeout_s=240):
     best = max(good, key=lambda r: r["value"])
     if len(runs) > 1:
         best["sample"] += "; thread counts tried: " + ", ".join(f"{r.get('cores')} -> {r['value']:.1f} tokens/s" if r.get("value") else f"{r.get('cores')} -> no result" for r in runs)
-    # what the number is worth: the PORT is slower than the thing it stands in for -- the reference itself, imported unmodified, ran this
-    # step in 12.07 s = ~80 tokens/s on 8 cores of the build container (survey-time measurement)
-    best["sample"] += ("; NOTE the port (autograd over the oracle's restatement) is slower than the reference itself, which ran this step in "
-                       "12.07 s = ~80 caption tokens/s on 8 host cores at survey time (BASELINE.md section 2): a stated baseline, not a target")
-    best["reference_itself_tokens_per_s"] = {"value": 80.0, "cores": 8, "where": "build container, survey time (BASELINE.md section 2); never runs on the GPU box"}
+    # what the number is worth: the PORT is slower than the thing it stands in for -- the reference itself, imported unmodified, ran a step of
+    # this configuration in 12.07 s on 8 cores of the build container (survey time).  On THIS batch's token count:
+    toks = None
+    import re
+    m = re.search(r"(\d+) tokens/step", best.get("sample", ""))
+    if m:
+        toks = int(m.group(1))
+        best["reference_itself"] = {"s_per_step": 12.07, "cores": 8, "tokens_per_step": toks, "tokens_per_s_on_this_batch": toks / 12.07,
+                                    "where": "build container, survey time (BASELINE.md section 2: 12.07 s per B=32 step); never runs on the GPU box"}
+    best["sample"] += "; a stated baseline, not a target"
     return best
 
 
@@ -532,7 +537,7 @@ def graph_overlap_trial_child(args):
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
     caps = batch["captions"].to(dev)
     step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=True, static_grads=True, overlap=True, seed=77, bucket_bytes=1 << 20,
-                               collective=args.dp_collective)
+                               collective="allreduce" if args.dp_collective == "auto" else args.dp_collective)
     step.capture(fs, caps, warmup=1, collectives=True)
     for _ in range(3):
         loss, _ = step.replay()
@@ -623,10 +628,19 @@ def dry_run(args, world, rank):
         dt, units = float(tmax[0]), float(tsum[1])
     else:
         units = float(t[1])
+    ranks_seen, rank_devices = 1, [{"rank": 0, "local_rank": 0, "device": "cpu"}]
+    if world > 1:
+        ones = torch.ones(1)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones[0])))
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, {"rank": rank, "local_rank": rank, "device": "cpu"})
     if rank == 0:
+        colls = ["allreduce", "rs_ag"] if args.dp_collective == "auto" else [args.dp_collective]
         print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "dry_run": True, "value": units * args.steps / dt, "unit": "units/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "captured_allreduce_trial": trial_res}))
+                          "captured_allreduce_trial": trial_res, "rccl_ranks_seen": ranks_seen, "rank_devices": rank_devices,
+                          "allreduce_exposed_ms": None, "dp_collective": colls[0], "dp_collectives_tried": colls if world > 1 else []}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -648,12 +662,19 @@ def build_cap(args, dev, rank, world):
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}      # inputs resident in HBM before timing
     caps = batch["captions"].to(dev)
     units_local = int((caps[:, 1:] != syn.PAD_IDX).sum())
-    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000, collective=args.dp_collective,
-                               microbatches=args.microbatches)
+    step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, static_grads=True, seed=1000,
+                               collective="allreduce" if args.dp_collective == "auto" else args.dp_collective)
+    # how much of the padded batch is real: the encoder runs on the valid rows only (bmt_amd.ops.PACK_ROWS); every FLOP figure of this line
+    # stays the PADDED-DENSE count of SURVEY.md 8d, so skipped padding reads as speed, never as skipped work
+    va, vv = int(batch["La"].sum()), int(batch["Lv"].sum())
     desc = {"metric": "caption tokens/sec/node (train_cap B=32/GPU, d=1024)", "unit": "caption tokens/s",
             "workload": "configs[1]: train_cap, N=2 d_model=1024 H=4 d_aud=128 d_vid=1024 d_caps=300 T_v=256 T_a=800 T_c=30 V=10000, "
                         "dropout 0.1, Adam, GloVe frozen",
             "B": B, "n_params": n_params, "units_name": "tokens_per_step",
+            "valid_rows": {"audio": va, "audio_padded": B * Ta, "video": vv, "video_padded": B * Tv, "fraction": (va + vv) / float(B * (Ta + Tv)),
+                           "packed": bool(ops.PACK_ROWS),
+                           "note": "valid (non-padded) positions of this rank's synthetic batch; with packed rows the encoder's row-wise kernels and "
+                                   "attention queries run over these only -- algorithmic_tflops and every roofline figure keep the padded-dense FLOP count"},
             # algorithmic flops of the padded-dense step: 3.257 TFLOP per B=32 train step at V~10k
             "flops_step": 3.257e12 * (B / 32.0)}
     return step, (fs, caps), units_local, desc
@@ -677,7 +698,8 @@ def build_prop(args, dev, rank, world):
     batch = syn.make_prop_batch(cfg, B, Tv, Ta, seed=11 + rank)
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
     tg = batch["targets"].to(dev)
-    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000, collective=args.dp_collective)
+    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000,
+                             collective="allreduce" if args.dp_collective == "auto" else args.dp_collective)
     # heads 348.7 + 322.9 GF and encoder 230.0 GF forward per sample at (T_a, T_v) = (3200, 1024); the frozen
     # encoder has no backward, the heads have 2x their forward
     heads, enc = (348.7 + 322.9) * 1e9, 230.0e9
@@ -696,9 +718,6 @@ def main():
     ap.add_argument("--procedure", default="train_cap", choices=["train_cap", "train_prop"],
                     help="train_cap = BASELINE.json's metric (configs[1]); train_prop = configs[3]")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); default 32 (train_cap) / 16 (train_prop)")
-    ap.add_argument("--microbatches", type=int, default=int(os.environ.get("BMT_MICROBATCHES", "1")),
-                    help="train_cap: parts of the per-GPU batch that are differentiated side by side on compute streams of their own "
-                         "(bmt_amd.train.CaptioningTrainStep(microbatches=...)); 1 = one pass over the whole batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-steps", type=int, default=7, help="eagerly issued steps of the per-kernel HIP-event pass (>= 5)")
@@ -708,9 +727,9 @@ def main():
                     help="N > 1: hipGraphs with the all-reduce exposed between them, eager launches with the all-reduce overlapped with "
                          "the backward pass, or (auto) whichever a short trial finds faster")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing protocol only (gloo, no GPU)")
-    ap.add_argument("--dp-collective", default="allreduce", choices=["allreduce", "rs_ag"],
-                    help="N > 1: a bucket's gradient sum as one all-reduce, or as reduce-scatter + all-gather (SURVEY 5: world-1 simultaneous "
-                         "point-to-point transfers per half on the xGMI mesh)")
+    ap.add_argument("--dp-collective", default="auto", choices=["auto", "allreduce", "rs_ag"],
+                    help="N > 1: a bucket's gradient sum as one all-reduce, as reduce-scatter + all-gather (SURVEY 5: world-1 simultaneous "
+                         "point-to-point transfers per half on the xGMI mesh), or (auto) whichever the launch-mode trials find faster")
     ap.add_argument("--trial-timeout", type=int, default=240, help="seconds the child-process trial of the captured-allreduce mode may take")
     ap.add_argument("--graph-overlap-trial", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -794,37 +813,51 @@ def main():
             if not ok:
                 want = tuple(m for m in want if m != "graph-overlap")
                 mode_trials["hipgraph+captured-allreduce"] = f"not tried: {why}"
+        # ... each with a bucket's sum as ONE all-reduce or as reduce-scatter + all-gather (--dp-collective auto: both are tried)
+        colls = (("allreduce", "rs_ag") if args.dp_collective == "auto" else (args.dp_collective,)) if world > 1 else (None,)
+        key = lambda name, c: name if len(colls) == 1 else f"{name}/{c}"
+
+        def use(c):
+            if c is not None and getattr(step, "reducer", None) is not None:
+                step.reducer.set_collective(c)
         if "eager" in want:
-            for _ in range(2):
-                step(*inputs)
-            mode_trials["eager+overlap"] = trial(lambda: step(*inputs))
-            note(f"eager + overlapped all-reduce: {mode_trials['eager+overlap']:.2f} ms/step")
+            for c in colls:
+                use(c)
+                for _ in range(2):
+                    step(*inputs)
+                mode_trials[key("eager+overlap", c)] = trial(lambda: step(*inputs))
+                note(f"{key('eager+overlap', c)}: {mode_trials[key('eager+overlap', c)]:.2f} ms/step")
         captured = None
+        n_trials = len(want) * len(colls)
         for m in ("graph-overlap", "graph"):        # ("graph" last: when it wins or ties, its capture is the one that stays)
             if m not in want:
                 continue
-            name = "hipgraph+captured-allreduce" if m == "graph-overlap" else "hipgraph"
-            try:
-                step.capture(*inputs, warmup=2, collectives=(m == "graph-overlap"))
-                captured = name
-                mode_trials[name] = trial(lambda: step.replay()) if len(want) > 1 else 0.0
-                if len(want) > 1:
-                    note(f"{name}: {mode_trials[name]:.2f} ms/step")
-            except Exception as exc:      # noqa: BLE001 -- e.g. a collective that refuses capture: keep measuring, say so
-                note(f"{name}: capture failed ({type(exc).__name__}: {exc})")
-                mode_trials[name] = f"capture failed: {type(exc).__name__}"
-                torch.cuda.synchronize()
-                step.uncapture()
-                captured = None
+            for c in colls:
+                name = key("hipgraph+captured-allreduce" if m == "graph-overlap" else "hipgraph", c)
+                try:
+                    use(c)
+                    step.capture(*inputs, warmup=2, collectives=(m == "graph-overlap"))
+                    captured = name
+                    mode_trials[name] = trial(lambda: step.replay()) if n_trials > 1 else 0.0
+                    if n_trials > 1:
+                        note(f"{name}: {mode_trials[name]:.2f} ms/step")
+                except Exception as exc:      # noqa: BLE001 -- e.g. a collective that refuses capture: keep measuring, say so
+                    note(f"{name}: capture failed ({type(exc).__name__}: {exc})")
+                    mode_trials[name] = f"capture failed: {type(exc).__name__}"
+                    torch.cuda.synchronize()
+                    step.uncapture()
+                    captured = None
         timed = {k: v for k, v in mode_trials.items() if isinstance(v, float)}
         best = min(timed, key=timed.get) if timed else None
-        if best is None or best == "eager+overlap":
+        best_mode, _, best_coll = (best or "").partition("/")
+        use(best_coll or (colls[0] if colls[0] is not None else None))
+        if best is None or best_mode == "eager+overlap":
             step.uncapture()
         else:
             if captured != best:          # the winner's graphs were replaced by a later capture: capture it again
-                step.capture(*inputs, warmup=1, collectives=(best == "hipgraph+captured-allreduce"))
+                step.capture(*inputs, warmup=1, collectives=(best_mode == "hipgraph+captured-allreduce"))
             run = lambda: step.replay()
-            mode = best
+            mode = best_mode
         if mode == "eager" and world > 1:
             mode = "eager+overlap"
     if (not cap) and not args.no_graph and world == 1:
@@ -872,6 +905,16 @@ def main():
             if not gate_notes:
                 break
 
+    ranks_seen, rank_devices = 1, None
+    if world > 1:          # who took part, as the collective library and the ranks themselves report it
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones[0])))
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     t = torch.tensor([dt, float(units_local)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
@@ -892,8 +935,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "launch_mode": mode,
             "dtype": ops.precision_description(), "data": "synthetic",
             "config": {"workload": desc["workload"], "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "trainable_params": desc["n_params"], desc["units_name"]: units_all, "final_loss": final_loss,
-                       "parts_in_flight": (step._parts_in_flight(inputs[1]) if hasattr(step, "_parts_in_flight") else 1)},
+                       "trainable_params": desc["n_params"], desc["units_name"]: units_all, "final_loss": final_loss},
+            "valid_row_fraction": (desc.get("valid_rows") or {}).get("fraction"), "valid_rows": desc.get("valid_rows"),
             "algorithmic_tflops": flops_step / (ms_per_step * 1e-3) / 1e12,
             "mfma_peak_frac": flops_step / (ms_per_step * 1e-3) / 1e12 / (MFMA_BF16_DENSE_PEAK_TFLOPS * world),
         }
@@ -903,6 +946,9 @@ def main():
             out["allreduce_exposed_ms"] = exposed_ms
             out["launch_mode_trials_ms"] = mode_trials
             out["allreduce"] = getattr(step, "reduce_description", lambda: None)()
+            out["dp_collective"] = getattr(getattr(step, "reducer", None), "collective", None)
+            out["rccl_ranks_seen"] = ranks_seen          # sum all-reduce of ones over the process group: what RCCL itself counts
+            out["rank_devices"] = rank_devices
         if not args.no_kernel_timer:
             summ, used_steps = timer.summary()         # per class and STEP: launches, ms (sum of per-launch medians), flops, bytes
             valid = not gate_notes
@@ -953,6 +999,7 @@ def main():
             if enc:
                 ms = sum(v["ms"] for v in enc.values())
                 alg = sum(v["flops"] for v in enc.values())
+                alg2 = sum(v["flops"] * (1.0 if k.startswith("attn_fwd") else 0.8) for k, v in enc.items())
                 # (the two-kernel backward computes S and dP in both kernels: 7 products for the 5 of the math; the split form issues the 5)
                 issued = sum(v["flops"] * (timer.passes.get(k, 1) if k.startswith("attn_fwd") else (1.0 if k.endswith("_split") else 1.4))
                              for k, v in enc.items())
@@ -962,6 +1009,10 @@ def main():
                     "bound": "mfma", "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "algorithmic": alg / (ms * 1e-3) / 1e12, "issued": issued / (ms * 1e-3) / 1e12,
                     "frac_algorithmic": alg / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    # the same time against SURVEY.md 8d's own count (backward = 2 x forward: 4 products, the recomputed S = Q K^T not counted)
+                    "frac_algorithmic_bwd_2x_fwd": alg2 / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    "flop_conventions": "frac_algorithmic: forward 2 products + backward 5 (incl. the recomputed scores) over PADDED (B, S, S) -- "
+                                        "padding is not computed under packed rows; frac_algorithmic_bwd_2x_fwd: backward counted as 4 products",
                     "frac_issued": issued / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
                     "ms_per_step": ms, "ms_per_step_forward": sum(v["ms"] for k, v in enc.items() if k.startswith("attn_fwd")),
                     "ms_per_step_backward": sum(v["ms"] for k, v in enc.items() if k.startswith("attn_bwd")),

@@ -140,7 +140,6 @@ SIGNATURES = {
     "bmt_dropout_add": (i32, [vp, vp, vp, i64, f32, vp, u32, vp]),
     "bmt_add": (i32, [vp, vp, vp, i64, vp]),
     "bmt_rng_advance": (i32, [vp, vp]),
-    "bmt_rng_derive": (i32, [vp, vp, u64, vp]),
     "bmt_copy3d": (i32, [vp, i64, i64, i64, vp, i32, i32, i32, i32, vp]),
     "bmt_log_softmax_fwd": (i32, [vp, i64, i32, i32, vp]),
     "bmt_log_softmax_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),

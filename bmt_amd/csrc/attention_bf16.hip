@@ -1776,165 +1776,6 @@ __device__ __forceinline__ void dq_rowsum_fix(const AttnPB& p, f32x4v (&dq)[DK /
     }
 }
 
-template <int DK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16_kernel(const AttnPB p) {
-    constexpr int BC = 32, NT = 512, KS = DK / 32, DT = DK / 16;
-    constexpr int TB = BC * DK * 2, KP = BC * pad_rs<DK>();
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                                          // padded rows: S^T row fragments AND the K^T fragments of dQ
-    char* sV = smem + KP;
-    uint8_t* sMask = reinterpret_cast<uint8_t*>(smem + 2 * KP);
-    int* sFlag = reinterpret_cast<int*>(sMask + 64);
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int nqt = (p.Sq + 127) / 128;
-    const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
-    const int qt = w % nqt, bh = w / nqt;
-    const int b = bh / p.H, h = bh % p.H;
-    const int q = qt * 128 + wid * 16 + c;
-    const bool qok = q < p.Sq;
-    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
-
-    bf16x8 qf[KS], dof[KS];
-    {
-        const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * g;
-        const int64_t oo = (int64_t)b * p.bso + (int64_t)min(q, p.Sq - 1) * p.ldo + h * DK + 8 * g;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = ldfrag(p.Qh + qo + 32 * ks, qok);
-            dof[ks] = ldfrag(p.dOh + oo + 32 * ks, qok);
-        }
-    }
-    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + q;
-    const float lse = qok ? p.lse[stat] : 0.f;
-    float delta;
-    if (p.fuse_delta) {
-        // delta_i = (1 - p_drop) * sum_d dO_id * O_id from the dO fragments this lane already holds and the matching slices of
-        // the saved output planes (8 g + 32 ks .. + 8 of the row: the four lanes of a query cover it); replaces a separate pass
-        // over dO and O.  Stored for the dK / dV kernel, which runs after this one.
-        const int64_t po = (int64_t)b * p.bsop + (int64_t)min(q, p.Sq - 1) * p.ldop + h * DK + 8 * g;
-        float acc = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (p.Opf) {
-                const f16x8 of = __builtin_bit_cast(f16x8, ldfrag(p.Opf + po + 32 * ks, qok));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc += (float)dof[ks][j] * (float)of[j];
-            } else {
-                const bf16x8 oh = ldfrag(p.Oph + po + 32 * ks, qok);
-                bf16x8 ol = oh;
-                if (p.Opl) ol = ldfrag(p.Opl + po + 32 * ks, qok);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float ov = (float)oh[j];
-                    if (p.Opl) ov += (float)ol[j];
-                    acc += (float)dof[ks][j] * ov;
-                }
-            }
-        }
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
-        delta = acc * (1.f - p.drop_p);
-        if (qok && g == 0) p.delta[stat] = delta;
-    } else {
-        delta = qok ? p.delta[stat] : 0.f;
-    }
-    const int troff = tr_lane_off(pad_rs<DK>(), c, g);
-    float rs = 0.f;
-
-    f32x4v dq[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-    u32x4 kv[rows_n<DK, BC, NT>()], vv[rows_n<DK, BC, NT>()];
-    const int ntile = (p.Sk + BC - 1) / BC;
-#define BMT_DQ16_FETCH(key0_)                                                           \
-    do {                                                                                \
-        tile_gload<DK, BC, NT>(p.Kh + koff, p.ldk, (key0_), p.Sk, tid, kv);             \
-        tile_gload<DK, BC, NT>(p.Vh + voff, p.ldv, (key0_), p.Sk, tid, vv);             \
-    } while (0)
-#define BMT_DQ16_STORE(key0_)                                                           \
-    do {                                                                                \
-        tile_lstore_pad<DK, BC, NT>(sK, tid, kv);                                       \
-        tile_lstore_pad<DK, BC, NT>(sV, tid, vv);                                       \
-        stage_mask<BC>(p, b, (key0_), tid, sMask, sFlag);                               \
-    } while (0)
-    BMT_DQ16_FETCH(0);
-    BMT_DQ16_STORE(0);
-    __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
-        const int key0 = t * BC;
-        const int kn = min(key0 + BC, (ntile - 1) * BC);
-        BMT_DQ16_FETCH(kn);
-        const int flag = sFlag[0];
-        if (flag != 0) {
-            f32x4v st[2], dp[2];
-            st[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            st[1] = st[0]; dp[0] = st[0]; dp[1] = st[0];
-            __builtin_amdgcn_s_setprio(1);      // MFMA clusters outrank the other wave's loads / VALU on this SIMD: +4 % (forward: -2 %, not used there)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    st[kt] = mfma16(rowfrag_pad<DK>(sK, kt * 16 + c, 4 * ks + g), qf[ks], st[kt]);
-                    dp[kt] = mfma16(rowfrag_pad<DK>(sV, kt * 16 + c, 4 * ks + g), dof[ks], dp[kt]);
-                }
-            __builtin_amdgcn_s_setprio(0);
-            float ds[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float pr = qok ? __expf(st[i >> 2][i & 3] * p.scale - lse) : 0.f;
-                ds[i] = pr * (dp[i >> 2][i & 3] - delta) * p.scale;
-            }
-            if (flag != 2) {
-                if (p.mask != nullptr && p.mask_qs != 0) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int key = key0 + 16 * (i >> 2) + 4 * g + (i & 3);
-                        const bool ok = qok && key < p.Sk && p.mask[(int64_t)b * p.mask_bs + (int64_t)q * p.mask_qs + key] != 0;
-                        ds[i] = ok ? ds[i] : 0.f;
-                    }
-                } else {
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sMask + 16 * kt + 4 * g);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ds[4 * kt + r] = ((mw >> (8 * r)) & 0xffu) ? ds[4 * kt + r] : 0.f;
-                    }
-                }
-            }
-            u32x4 dsw;
-            dsw[0] = pack_bf2(ds[0], ds[1]); dsw[1] = pack_bf2(ds[2], ds[3]);
-            dsw[2] = pack_bf2(ds[4], ds[5]); dsw[3] = pack_bf2(ds[6], ds[7]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rs += __uint_as_float(dsw[j] << 16) + __uint_as_float(dsw[j] & 0xFFFF0000u);
-            const bf16x8 dsf = as_bf16x8(dsw);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma16(trfrag<DK>(sK + troff, dt), dsf, dq[dt]);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-        BMT_DQ16_STORE(kn);
-        __syncthreads();
-    }
-#undef BMT_DQ16_FETCH
-#undef BMT_DQ16_STORE
-    dq_rowsum_fix<DK>(p, dq, rs, b, h, g);
-    // (plane / fp32 / bias sums through the row-major LDS image: whole rows out, see grad_rm_write; the transposed plane keeps the old image)
-    __syncthreads();
-    grad_rm_epilogue16<DK, NT>(smem, p.gq, dq, b, h, qt * 128, wid * 16 + c, qok, g, p.Sq, p.SqP, tid);
-    if (p.gq.hiT) {
-        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
-        grad_tile_write16<DK, 128>(tile, dq, wid * 16, qok, c, g);
-        __syncthreads();
-        GradOut gt = p.gq;
-        gt.bsum = nullptr;
-        grad_tile_flush<DK, 128, NT>(tile, gt, b, h, qt * 128, p.Sq, tid);
-    }
-}
-
 // dQ with 64-key stages: the forward's lean loop (attn_fwd64_kernel) applied to attn_bwd_dq16_kernel -- K / V tiles by buffer loads
 // with the stage offset in an SGPR and rows past Sk read as zero, double-buffered LDS images and ONE barrier per stage, the
 // probabilities recomputed in the log2 domain (p = exp2(fma(s, scale log2 e, -lse log2 e))), per-stage bookkeeping paid half as often.
@@ -2126,138 +1967,12 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& pin, const int
         grad_tile_flush<DK, 128, NT>(tile, gt, b, h, qt * 128, p.Sq, tid);
     }
 }
-template <int DK, int BC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq16b_kernel(const AttnPB p) {
-    attn_bwd_dq16b_body<DK, BC>(p, (int)blockIdx.x);
-}
-
 // dK / dV, 8 waves x 16 keys (128 keys per workgroup), loop over 32-query stages.  Every wave computes S[q][key] = Q . K^T and
 // dP[q][key] = dO . V^T once (A = staged Q / dO rows, B = this wave's K / V rows held in registers) and accumulates BOTH
 // dV^T += dO^T . P and dK^T += Q^T . dS for its keys (an earlier version split the waves into a dV and a dK role: S was
 // computed twice and the Q / dO fragments were read by twice as many waves).  The lane's 8 probabilities are queries
 // {4g..4g+3} and {16+4g..} of the stage -> B operand of the second products with the same permutation of the reduction index
 // as in the forward kernel; the A operands come through the transpose unit from the same padded Q / dO images.
-template <int DK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv16_kernel(const AttnPB p) {
-    constexpr int BQ = 32, NT = 512, KS = DK / 32, DT = DK / 16, KBLK = 128;
-    constexpr int TP = BQ * pad_rs<DK>();
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;                          // padded rows: A operands of S / dP by row, of dK / dV through the transpose unit
-    char* sdO = smem + TP;
-    float* sLse = reinterpret_cast<float*>(smem + 2 * TP);
-    float* sDelta = sLse + BQ;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int nkt = (p.Sk + KBLK - 1) / KBLK;
-    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
-    const int kt = w % nkt, bh = w / nkt;
-    const int b = bh / p.H, h = bh % p.H;
-    const int key = kt * KBLK + wid * 16 + c;
-    const bool kok = key < p.Sk;
-    const int troff = tr_lane_off(pad_rs<DK>(), c, g);
-    const uint16_t* Qb = p.Qh + (int64_t)b * p.bsq + h * DK;
-    const uint16_t* dOb = p.dOh + (int64_t)b * p.bso + h * DK;
-
-    bool kmask = kok;
-    if (kok && p.mask != nullptr && p.mask_qs == 0) kmask = p.mask[(int64_t)b * p.mask_bs + key] != 0;
-    const bool dead = __syncthreads_or(kmask ? 1 : 0) == 0;   // every key of the workgroup masked: gradients exactly zero
-    f32x4v accv[DT], acck[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { accv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f}; acck[dt] = accv[dt]; }
-    if (!dead) {
-        bf16x8 kf[KS], vf[KS];       // this lane's K and V row fragments: B operands, loop invariant
-        {
-            const int krow = min(key, p.Sk - 1);
-            const int64_t ko = (int64_t)b * p.bsk + (int64_t)krow * p.ldk + h * DK + 8 * g;
-            const int64_t vo = (int64_t)b * p.bsv + (int64_t)krow * p.ldv + h * DK + 8 * g;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                kf[ks] = ldfrag(p.Kh + ko + 32 * ks, true);
-                vf[ks] = ldfrag(p.Vh + vo + 32 * ks, true);
-            }
-        }
-        u32x4 rq[rows_n<DK, BQ, NT>()], rdo[rows_n<DK, BQ, NT>()];
-        float rl = 0.f, rd = 0.f;
-        const int ntile = (p.Sq + BQ - 1) / BQ;
-#define BMT_DKV16_FETCH(q0_)                                                            \
-    do {                                                                                \
-        tile_gload<DK, BQ, NT>(Qb, p.ldq, (q0_), p.Sq, tid, rq);                        \
-        tile_gload<DK, BQ, NT>(dOb, p.ldo, (q0_), p.Sq, tid, rdo);                      \
-        {                                                                               \
-            const int qq_ = min((q0_) + (tid & (BQ - 1)), p.Sq - 1);                    \
-            const int64_t stat_ = ((int64_t)b * p.H + h) * p.Sq + qq_;                  \
-            rl = p.lse[stat_];                                                          \
-            rd = p.delta[stat_];                                                        \
-        }                                                                               \
-    } while (0)
-#define BMT_DKV16_STORE()                                                               \
-    do {                                                                                \
-        tile_lstore_pad<DK, BQ, NT>(sQ, tid, rq);                                       \
-        tile_lstore_pad<DK, BQ, NT>(sdO, tid, rdo);                                     \
-        if (tid < BQ) { sLse[tid] = rl; sDelta[tid] = rd; }                             \
-    } while (0)
-        BMT_DKV16_FETCH(0);
-        BMT_DKV16_STORE();
-        __syncthreads();
-        for (int t = 0; t < ntile; ++t) {
-            const int q0 = t * BQ;
-            BMT_DKV16_FETCH(min(q0 + BQ, (ntile - 1) * BQ));
-            f32x4v sacc[2], dp[2];
-            sacc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            sacc[1] = sacc[0]; dp[0] = sacc[0]; dp[1] = sacc[0];
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) {
-                    sacc[qi] = mfma16(rowfrag_pad<DK>(sQ, qi * 16 + c, 4 * ks + g), kf[ks], sacc[qi]);
-                    dp[qi] = mfma16(rowfrag_pad<DK>(sdO, qi * 16 + c, 4 * ks + g), vf[ks], dp[qi]);
-                }
-            __builtin_amdgcn_s_setprio(0);
-            float pr[8], ds[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ql_ = 16 * (i >> 2) + 4 * g + (i & 3);
-                const int qq = q0 + ql_;
-                bool ok = kmask && qq < p.Sq;
-                if (ok && p.mask != nullptr && p.mask_qs != 0)
-                    ok = p.mask[(int64_t)b * p.mask_bs + (int64_t)qq * p.mask_qs + key] != 0;
-                pr[i] = ok ? __expf(sacc[i >> 2][i & 3] * p.scale - sLse[ql_]) : 0.f;
-                ds[i] = pr[i] * (dp[i >> 2][i & 3] - sDelta[ql_]) * p.scale;
-            }
-            u32x4 pw, dw;
-            pw[0] = pack_bf2(pr[0], pr[1]); pw[1] = pack_bf2(pr[2], pr[3]);
-            pw[2] = pack_bf2(pr[4], pr[5]); pw[3] = pack_bf2(pr[6], pr[7]);
-            dw[0] = pack_bf2(ds[0], ds[1]); dw[1] = pack_bf2(ds[2], ds[3]);
-            dw[2] = pack_bf2(ds[4], ds[5]); dw[3] = pack_bf2(ds[6], ds[7]);
-            const bf16x8 pf = as_bf16x8(pw), dsf = as_bf16x8(dw);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                accv[dt] = mfma16(trfrag<DK>(sdO + troff, dt), pf, accv[dt]);
-                acck[dt] = mfma16(trfrag<DK>(sQ + troff, dt), dsf, acck[dt]);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
-            BMT_DKV16_STORE();
-            __syncthreads();
-        }
-#undef BMT_DKV16_FETCH
-#undef BMT_DKV16_STORE
-    }
-    grad_store_rows16<DK>(p.gv, accv, b, h, key, kok, g);
-    grad_store_rows16<DK>(p.gk, acck, b, h, key, kok, g);
-    if (p.gk.hiT || p.gk.bsum || p.gv.hiT || p.gv.bsum) {
-        uint16_t* tile = reinterpret_cast<uint16_t*>(smem);       // [dV, dK][DK][128 + 8]
-        grad_tile_write16<DK, KBLK>(tile, accv, wid * 16, kok, c, g);
-        grad_tile_write16<DK, KBLK>(tile + DK * (KBLK + 8), acck, wid * 16, kok, c, g);
-        __syncthreads();
-        grad_tile_flush<DK, KBLK, NT>(tile, p.gv, b, h, kt * KBLK, p.Sk, tid);
-        grad_tile_flush<DK, KBLK, NT>(tile + DK * (KBLK + 8), p.gk, b, h, kt * KBLK, p.Sk, tid);
-    }
-}
-
 // dK / dV with the lean stage loop: Q / dO tiles by buffer loads (stage offset in an SGPR, rows past Sq read as zero), double-buffered
 // LDS images with ONE barrier per 32-query stage, probabilities recomputed in the log2 domain.  Decomposition and fragment layouts as
 // in attn_bwd_dkv16_kernel (which documents them).
@@ -2421,10 +2136,6 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& pin, const int
         grad_tile_flush<DK, KBLK, NT>(tile, gt, b, h, kt * KBLK, p.Sk, tid);
     }
 }
-template <int DK, bool QMASK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv32_kernel(const AttnPB p) {
-    attn_bwd_dkv32_body<DK, QMASK>(p, (int)blockIdx.x);
-}
 // the two kernels of the two-kernel backward in ONE launch: workgroups [0, nq) are the dQ kernel's, the rest the dK / dV kernel's.  Neither
 // reads what the other writes once delta comes from its own small kernel (attn_delta_bf16_kernel), and on the shapes this form serves -- the
 // decoder's 30-query attentions -- the dQ kernel is B x H workgroups walking the whole key range one after the other (latency: ~50 us over
@@ -2503,22 +2214,17 @@ int launch_fwd32(const AttnPB& p, hipStream_t st) {
     return BMT_OK;
 }
 
-// fwd32: -1 = by shape (the default), 0 = never, 1 = whenever the 32-query kernel can run the problem (experiments)
 template <int DK, int NPASS, bool F16 = false>
-int launch_fwd(const AttnPB& p, hipStream_t st, int fwd32 = -1) {
+int launch_fwd(const AttnPB& p, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
-    static const int old_fwd = getenv("BMT_ATTN_FWD_OLD") ? atoi(getenv("BMT_ATTN_FWD_OLD")) : 0;      // A/B experiments only
-    static const int env32 = getenv("BMT_ATTN_FWD32") ? atoi(getenv("BMT_ATTN_FWD32")) : -1;           // A/B experiments only
     if constexpr (DK >= 128 && NPASS == 1) {
         // K / V rows are fetched with 32-bit byte offsets from the (batch, head) base
         const bool fits = ((int64_t)p.Sk * p.ldk * 2 < (1ll << 31)) && ((int64_t)p.Sk * p.ldv * 2 < (1ll << 31));
         // the 32-query kernel: key-padding masks (its mask row lives in LDS: Sk <= 8192), and two workgroups per CU to overlap --
         // with fewer it ties or loses against the 16-query kernel (V-self / V<-A of configs[1]: 0.95x / 0.98x, the decoder 0.86x)
-        const int want32 = fwd32 >= 0 ? fwd32 : env32;
         const bool can32 = fits && (p.mask == nullptr || p.mask_qs == 0) && p.Sk <= 8192;
-        static const int minq32 = getenv("BMT_ATTN_FWD32_MINQ") ? atoi(getenv("BMT_ATTN_FWD32_MINQ")) : 1 << 30;     // A/B experiments only
-        if (!old_fwd && can32 && (want32 == 1 || (want32 < 0 && (nblk >= 2 * bmt_device_cus() || p.Sq >= minq32)))) return launch_fwd32<DK, F16>(p, st);
-        if (!old_fwd && fits) {
+        if (can32 && nblk >= 2 * bmt_device_cus()) return launch_fwd32<DK, F16>(p, st);
+        if (fits) {
             const int lds = 2 * 2 * 64 * (DK * 2 + 32) + 256;
             static bool done64 = false;
             if (!done64) {
@@ -3220,22 +2926,13 @@ void launch_bias_finish(const AttnPB& p, hipStream_t st) {
 template <int DK>
 int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
-    static const int sep = getenv("BMT_ATTN_DELTA_SEPARATE") ? atoi(getenv("BMT_ATTN_DELTA_SEPARATE")) : 0;      // A/B experiments only
-    // the two-kernel form as ONE launch (attn_bwd_pair_kernel): delta from its own kernel, then dQ and dK / dV workgroups side by side
-    static const int pair_env = getenv("BMT_ATTN_BWD_PAIR") ? atoi(getenv("BMT_ATTN_BWD_PAIR")) : 1;            // A/B: 0 = two launches
-    const bool pair = DK >= 128 && pair_env && p.Pws == nullptr && !getenv("BMT_ATTN_DQ_OLD") && !getenv("BMT_ATTN_DKV_OLD") &&
-                      (int64_t)p.Sk * p.ldk * 2 < (1ll << 31) && (int64_t)p.Sk * p.ldv * 2 < (1ll << 31) &&
-                      (int64_t)p.Sq * p.ldq * 2 < (1ll << 31) && (int64_t)p.Sq * p.ldo * 2 < (1ll << 31);
-    if ((p.q_off || p.k_off) && !(p.Pws != nullptr || pair)) {
-        bmt_set_error("bmt_attn_bwd_bf16: packed rows need the split or the paired backward (d_k >= 128)");
-        return BMT_EINVAL;
-    }
-    const bool fuse = DK >= 128 && !sep && !pair && p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr);
-    if (!fuse) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
-    AttnPB pf = p;
-    pf.fuse_delta = fuse ? 1 : 0;
+    const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {
-        if (p.Pws != nullptr) {       // split form (bmt_attn_bwd_bf16 checked shapes and sizes): dQ + emission, dK / dV as plain products, bias sums
+        if (p.Pws != nullptr) {       // split form (bmt_attn_bwd_bf16 checked shapes and sizes): dQ + emission (delta = rowsum(dO * O) in its prologue), dK / dV
+                                      // as plain products, bias sums
+            AttnPB pf = p;
+            pf.fuse_delta = (p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr)) ? 1 : 0;
+            if (!pf.fuse_delta) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
             int rc = launch_dq32p<DK>(pf, st);
             if (rc != BMT_OK) return rc;
             rc = launch_dkvg8<DK>(pf, st);
@@ -3244,102 +2941,38 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (split)");
             return BMT_OK;
         }
-    }
-    const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H, nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
-    const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
-    if constexpr (DK >= 128) {        // 8 waves x 16 queries / keys, two waves per SIMD
-        if (pair) {
-            const int lds_epi = 128 * (DK + 8) * 2 + 512 * 8;
-            const int lds_dq = 2 * 2 * 32 * (DK * 2 + 32) + 256, lds_dkv = 2 * 2 * 32 * (DK * 2 + 32) + 512;
-            int lds = lds_dq > lds_dkv ? lds_dq : lds_dkv;
-            lds = lds > lds_epi ? lds : lds_epi;
-            const bool qmask = p.mask != nullptr && p.mask_qs != 0;
-            static bool done_p[2] = {false, false};
-            if (!done_p[qmask]) {
-                if (qmask) (void)hipFuncSetAttribute((const void*)attn_bwd_pair_kernel<DK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                else (void)hipFuncSetAttribute((const void*)attn_bwd_pair_kernel<DK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                done_p[qmask] = true;
-            }
-            if (qmask) hipLaunchKernelGGL((attn_bwd_pair_kernel<DK, true>), dim3(nblk_q + nblk_k16), dim3(512), lds, st, pf, nblk_q);
-            else hipLaunchKernelGGL((attn_bwd_pair_kernel<DK, false>), dim3(nblk_q + nblk_k16), dim3(512), lds, st, pf, nblk_q);
-            launch_bias_finish<DK>(p, st);
-            BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (dQ and dK / dV in one launch)");
-            return BMT_OK;
+        // the two-kernel form as ONE launch (attn_bwd_pair_kernel: the decoder's 30-query attentions, per-query masks): delta from its own
+        // small kernel, then dQ and dK / dV workgroups side by side.  Operand rows are fetched with 32-bit byte offsets from the (batch, head) base
+        if (!((int64_t)p.Sk * p.ldk * 2 < (1ll << 31) && (int64_t)p.Sk * p.ldv * 2 < (1ll << 31) && (int64_t)p.Sq * p.ldq * 2 < (1ll << 31) &&
+              (int64_t)p.Sq * p.ldo * 2 < (1ll << 31))) {
+            bmt_set_error("bmt_attn_bwd_bf16: a sample's plane slice of 2 GiB or more");
+            return BMT_EINVAL;
         }
-        {
-            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 128, lds_epi = 128 * (DK + 8) * 2 + 512 * 8;      // (row-major gradient image + reduction scratch)
-            const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-            static bool done = false;
-            if (!done) {
-                (void)hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                done = true;
-            }
-            static const int old_dq = getenv("BMT_ATTN_DQ_OLD") ? atoi(getenv("BMT_ATTN_DQ_OLD")) : 0;      // A/B experiments only
-            const bool fits = ((int64_t)p.Sk * p.ldk * 2 < (1ll << 31)) && ((int64_t)p.Sk * p.ldv * 2 < (1ll << 31));
-            if (old_dq != 1 && fits) {
-                // measured (tools/microbench.py attn, BMT_ATTN_DQ_OLD): 64-key stages need 242 registers at d_k 256 and lose 3 % to the
-                // 32-key loop they came from; the 32-key stage with the lean loop is the default, 64 keys opt-in (BMT_ATTN_DQ_OLD=-1)
-                if (old_dq == -1) {
-                    const int lds64 = 2 * 2 * 64 * (DK * 2 + 32) + 256, ldsx = lds64 > lds_epi ? lds64 : lds_epi;
-                    static bool done64 = false;
-                    if (!done64) {
-                        (void)hipFuncSetAttribute((const void*)attn_bwd_dq16b_kernel<DK, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
-                        done64 = true;
-                    }
-                    hipLaunchKernelGGL((attn_bwd_dq16b_kernel<DK, 64>), dim3(nblk_q), dim3(512), ldsx, st, pf);
-                } else {
-                    const int lds32 = 2 * 2 * 32 * (DK * 2 + 32) + 256, ldsx = lds32 > lds_epi ? lds32 : lds_epi;
-                    static bool done32 = false;
-                    if (!done32) {
-                        (void)hipFuncSetAttribute((const void*)attn_bwd_dq16b_kernel<DK, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
-                        done32 = true;
-                    }
-                    hipLaunchKernelGGL((attn_bwd_dq16b_kernel<DK, 32>), dim3(nblk_q), dim3(512), ldsx, st, pf);
-                }
-            } else {
-                hipLaunchKernelGGL((attn_bwd_dq16_kernel<DK>), dim3(nblk_q), dim3(512), lds, st, pf);
-            }
+        hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
+        const int nblk_k16 = ((p.Sk + 127) / 128) * p.B * p.H;
+        const int lds_epi = 128 * (DK + 8) * 2 + 512 * 8;
+        const int lds_dq = 2 * 2 * 32 * (DK * 2 + 32) + 256, lds_dkv = 2 * 2 * 32 * (DK * 2 + 32) + 512;
+        int lds = lds_dq > lds_dkv ? lds_dq : lds_dkv;
+        lds = lds > lds_epi ? lds : lds_epi;
+        const bool qmask = p.mask != nullptr && p.mask_qs != 0;
+        static bool done_p[2] = {false, false};
+        if (!done_p[qmask]) {
+            if (qmask) (void)hipFuncSetAttribute((const void*)attn_bwd_pair_kernel<DK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            else (void)hipFuncSetAttribute((const void*)attn_bwd_pair_kernel<DK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done_p[qmask] = true;
         }
-        {
-            const int lds_loop = 2 * 32 * (DK * 2 + 32) + 2 * 32 * 4, lds_epi = 2 * DK * (128 + 8) * 2;
-            const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-            static bool done = false;
-            if (!done) {
-                (void)hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                done = true;
-            }
-            static const int old_dkv = getenv("BMT_ATTN_DKV_OLD") ? atoi(getenv("BMT_ATTN_DKV_OLD")) : 0;      // A/B experiments only
-            const bool fits = ((int64_t)p.Sq * p.ldq * 2 < (1ll << 31)) && ((int64_t)p.Sq * p.ldo * 2 < (1ll << 31));
-            if (!old_dkv && fits) {
-                const int lds_loop2 = 2 * 2 * 32 * (DK * 2 + 32) + 512, lds_epi2 = 128 * (DK + 8) * 2 + 512 * 8;
-                const int lds2 = lds_loop2 > lds_epi2 ? lds_loop2 : lds_epi2;
-                if (p.mask != nullptr && p.mask_qs != 0) {
-                    static bool done2 = false;
-                    if (!done2) {
-                        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32_kernel<DK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                        done2 = true;
-                    }
-                    hipLaunchKernelGGL((attn_bwd_dkv32_kernel<DK, true>), dim3(nblk_k16), dim3(512), lds2, st, p);
-                } else {
-                    static bool done3 = false;
-                    if (!done3) {
-                        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv32_kernel<DK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                        done3 = true;
-                    }
-                    hipLaunchKernelGGL((attn_bwd_dkv32_kernel<DK, false>), dim3(nblk_k16), dim3(512), lds2, st, p);
-                }
-            } else {
-                // this kernel finishes through grad_tile_flush, which adds the column sums into bsum with atomics and never writes the
-                // per-tile partial rows: they are cleared here, so that whoever sums them afterwards (attn_bias_finish_kernel, or the
-                // caller's bmt_colsum_multi under defer_bias) adds zeros instead of whatever the workspace held
-                const size_t part_bytes = (size_t)p.B * ((p.Sk + 127) / 128) * p.H * DK * sizeof(float);
-                if (p.gk.bpart) (void)hipMemsetAsync(p.gk.bpart, 0, part_bytes, st);
-                if (p.gv.bpart) (void)hipMemsetAsync(p.gv.bpart, 0, part_bytes, st);
-                hipLaunchKernelGGL((attn_bwd_dkv16_kernel<DK>), dim3(nblk_k16), dim3(512), lds, st, p);
-            }
-        }
+        if (qmask) hipLaunchKernelGGL((attn_bwd_pair_kernel<DK, true>), dim3(nblk_q + nblk_k16), dim3(512), lds, st, p, nblk_q);
+        else hipLaunchKernelGGL((attn_bwd_pair_kernel<DK, false>), dim3(nblk_q + nblk_k16), dim3(512), lds, st, p, nblk_q);
         launch_bias_finish<DK>(p, st);
+        BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (dQ and dK / dV in one launch)");
+        return BMT_OK;
     } else {
+        if (p.q_off || p.k_off) {
+            bmt_set_error("bmt_attn_bwd_bf16: packed rows need d_k >= 128");
+            return BMT_EINVAL;
+        }
+        hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
+        const int nblk_k = ((p.Sk + 63) / 64) * p.B * p.H;
         {
             const int lds_loop = 3 * 32 * DK * 2 + 256 + 128 * DK * 2, lds_epi = DK * (128 + 8) * 2;   // stage images / transposed gradient tile
             const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
@@ -3461,8 +3094,7 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
             p.ldqb = (int64_t)a->H * a->dk; p.bsqb = (int64_t)a->Sq * a->H * a->dk;
             // the live-query bits sit behind the scaled copy of q in Qb_ws (bmt_attn_bwd_split_ws sized it for them); one 64-bit mask
             // per (batch, head) in the dK / dV kernel: 64 stages of 32 queries
-            static const int qskip = getenv("BMT_ATTN_QSKIP") ? atoi(getenv("BMT_ATTN_QSKIP")) : 1;      // A/B experiments only
-            p.qlive = (qskip && a->Sq <= 2048) ? reinterpret_cast<int*>(a->Qb_ws + (int64_t)a->B * p.bsqb) : nullptr;
+            p.qlive = a->Sq <= 2048 ? reinterpret_cast<int*>(a->Qb_ws + (int64_t)a->B * p.bsqb) : nullptr;
         }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -3502,8 +3134,7 @@ extern "C" int bmt_attn_kmean(const uint16_t* Kh, int64_t ldk, int64_t bsk, cons
     BMT_CHECK_ARG(Kh && out && B > 0 && Sk > 0 && D > 0 && D % 8 == 0 && ldk % 8 == 0 && bsk % 8 == 0 &&
                       (reinterpret_cast<uintptr_t>(Kh) & 15) == 0,
                   "bmt_attn_kmean: bad args (D, ldk, bsk multiples of 8, 16-byte aligned plane)");
-    static const int ks_env = getenv("BMT_KMEAN_STRIDE") ? atoi(getenv("BMT_KMEAN_STRIDE")) : 0;      // A/B experiments only
-    const int ks = ks_env > 0 ? ks_env : (Sk >= 256 ? 8 : 1);
+    const int ks = Sk >= 256 ? 8 : 1;
     hipLaunchKernelGGL(attn_kmean_kernel, dim3(B, bmt_cdiv(D, 128)), dim3(512), 0, (hipStream_t)stream, Kh, ldk, bsk,
                        (mask_qs == 0 && !k_off) ? mask : nullptr, mask_bs, Sk, D, out, k_f16, ks, k_off);
     BMT_CHECK_LAUNCH("bmt_attn_kmean");

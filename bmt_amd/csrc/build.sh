@@ -17,11 +17,4 @@ for p in "${pids[@]}"; do wait "$p"; done
 # (an explicit object list: a stale object of a source that no longer exists -- obj/gemm.o once -- must not be linked)
 OBJS=""; for f in $SRCS; do OBJS="$OBJS $OUT/obj/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbmt_hip.so" $OBJS
-if [ -n "$BMT_ALT_FLAGS" ]; then   # A/B experiment build: same sources, extra -D flags, separate .so (BMT_LIB_PATH selects it)
-  mkdir -p "$OUT/obj_alt"
-  for f in $SRCS; do hipcc $FLAGS $BMT_ALT_FLAGS -c "$f.hip" -o "$OUT/obj_alt/$f.o" & done; wait
-  OBJS=""; for f in $SRCS; do OBJS="$OBJS $OUT/obj_alt/$f.o"; done
-  hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbmt_hip_alt.so" $OBJS
-  echo "built $OUT/libbmt_hip_alt.so ($BMT_ALT_FLAGS)"
-fi
 echo "built $OUT/libbmt_hip.so"

@@ -191,15 +191,6 @@ __global__ void rng_advance_kernel(uint64_t* rng) {
 
 // the dropout stream of one part of a batch that is stepped in parts (micro-batches in flight together): the device's step counter with a seed
 // of its own, so that element i of two parts never shares a mask
-__global__ void rng_derive_kernel(const uint64_t* __restrict__ base, uint64_t* __restrict__ out, uint64_t salt) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint64_t z = base[0] + salt * 0x9E3779B97F4A7C15ull;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        out[0] = salt ? (z ^ (z >> 31)) : base[0];
-        out[1] = base[1];
-    }
-}
 
 // out[i0][i1][i2] (contiguous) (+)= in[i0*s0 + i1*s1 + i2*s2]
 __global__ __launch_bounds__(256) void copy3d_kernel(const float* __restrict__ in, int64_t s0, int64_t s1, int64_t s2,
@@ -333,12 +324,6 @@ extern "C" int bmt_rng_advance(uint64_t* rng, void* stream) {
     return BMT_OK;
 }
 
-extern "C" int bmt_rng_derive(const uint64_t* base, uint64_t* out, uint64_t salt, void* stream) {
-    BMT_CHECK_ARG(base && out && base != out, "bmt_rng_derive: bad args");
-    hipLaunchKernelGGL(rng_derive_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, base, out, salt);
-    BMT_CHECK_LAUNCH("bmt_rng_derive");
-    return BMT_OK;
-}
 
 extern "C" int bmt_copy3d(const float* in, int64_t s0, int64_t s1, int64_t s2, float* out, int n0, int n1, int n2, int accumulate,
                           void* stream) {

@@ -53,28 +53,11 @@ struct GemmB {
     uint32_t site;
     float* ws;                           // split-K partials [split][tiles_m*128][tiles_n*128] (two-pass mode), or nullptr
     int nsplit;
-    int nk_loader;                       // gemm_k128_kernel: 1 = seven computing waves + a loading wave, 0 = eight waves that load their own rows
-    int nk_dbg;                          // experiments (env BMT_K128_DBG): 1 no stores, 2 no MFMAs, 4 no next-unit prefetch
-    int nk_ncw, nk_rg, nk_upw;           // gemm_k128_kernel: weight rows per resident chunk, row groups, 32-row units per row group
+    int nk_rg, nk_upw;                   // gemm_k128_kernel: row groups, 32-row units per row group
     int rows_is_k;                       // rows_dev bounds the REDUCTION (A k-major: a weight gradient), not the output rows
     const int* rows_dev;                 // packed rows (bmt_gemm_bf16_args.rows_dev): the rows actually present, in device memory; the launch is sized for M
                                          // (k-major A: for krows) and every kernel takes min(M, *rows_dev) -- graph-static grids over data-dependent extents
-#ifdef BMT_EXP
-    int exp;                             // experiment build only (BMT_ALT_FLAGS=-DBMT_EXP, env BMT_EXP): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue,
-    int exp_shift; int exp_sleep;                       // 8 every other workgroup starts exp_sleep x 3.4 us late (env BMT_EXP_SLEEP)
-#endif
 };
-#ifdef BMT_EXP
-#define BMT_EXP_ON(bit_) ((p.exp & (bit_)) != 0)
-__device__ unsigned long long bmt_dbg[8 * 8192];      // per tile: start, loop end, staged, done, hw id
-#define BMT_STAMP(slot_)                                                                              \
-    do {                                                                                              \
-        if (BMT_EXP_ON(16) && threadIdx.x == 0 && tile_id < 8192) bmt_dbg[tile_id * 8 + (slot_)] = __builtin_readcyclecounter(); \
-    } while (0)
-#else
-#define BMT_EXP_ON(bit_) false
-#define BMT_STAMP(slot_)
-#endif
 
 // LDS slot of (row, 16-byte slot) for rows of SPR slots
 template <int SPR>
@@ -265,16 +248,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    BMT_STAMP(0);
-#ifdef BMT_EXP
-    if (BMT_EXP_ON(16) && threadIdx.x == 0 && tile_id < 8192) {
-        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        bmt_dbg[tile_id * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
-    }
-    if (BMT_EXP_ON(8) && (int)blockIdx.x < 512 && (((int)blockIdx.x >> p.exp_shift) & 1))
-        for (int i = 0; i < p.exp_sleep; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 
     int kma_off[TI], kmb_off[2];          // k-major fragments of the DMA ring: per-lane byte offsets (km_sw_off)
     if constexpr (PIPE && AKM) {
@@ -441,9 +414,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             else if (younger_ == 1) BMT_VMWAIT(LPT);                                                             \
             else BMT_VMWAIT(0);                                                                                  \
             __builtin_amdgcn_s_barrier();                                                                        \
-            if ((step_) + R - 1 < niter && !BMT_EXP_ON(1)) BMT_DMA((step_) + R - 1, ((slot_) + R - 1) % R);      \
+            if ((step_) + R - 1 < niter) BMT_DMA((step_) + R - 1, ((slot_) + R - 1) % R);      \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            if (!BMT_EXP_ON(2)) BMT_COMPUTE(slot_);                                                              \
+            BMT_COMPUTE(slot_);                                                              \
         } while (0)
         const int niter = (kend - kbeg) / BK;
 #pragma unroll
@@ -502,27 +475,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
                     part[(int64_t)(m0 + wr * 32 * TI + i * 32 + acc_row(r, half)) * ldw + n0 + wc * 64 + j * 32 + l31] = acc[i][j][r];
         return;
     }
-    BMT_STAMP(1);
-#ifdef BMT_EXP
-    if (BMT_EXP_ON(4)) {
-        float t_ = 0.f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
-        if (t_ == 12345.678f) p.C[0] = t_;
-        return;
-    }
-#endif
     // ---------------- epilogue (order: alpha, bias, dropout_pre, relu, dropout_post, gate, residual), in row-segment form.
     // The accumulators go through the (now idle) stage buffers as an fp32 [BM][128] tile; then each thread owns 8 consecutive
     // columns (fixed for the thread: bias and column sums live in registers) and walks rows.  Every global access of a segment is
     // a 16-byte vector (C: 2 x float4, planes: 8 x 16 bit, gate plane, residual), the flags are tested once per segment instead of
     // once per element, and there is one bounds decision per segment.  (The element-wise form this replaces -- one divergent
     // row / column test, six flag tests and a 64-bit index per accumulator register -- took 35 % of a K = 1024 product:
-    // tools/probes/gemm_exp.py, BMT_EXP=4.)
+    // the probes of round 2.)
     if (p.flags == BMT_EPI_ACCUM && !p.Chi) {
         // C += alpha * acc and nothing else (weight gradients, possibly several products into one buffer): atomics straight from the
         // accumulators -- 32 lanes of an instruction hit 32 consecutive floats of a row, which the L2 handles as one 128-byte request
@@ -549,7 +508,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             for (int r = 0; r < 16; ++r)
                 ct[(wr * 32 * TI + i * 32 + acc_row(r, half)) * BN + wc * 64 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    BMT_STAMP(2);
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
     const unsigned f = p.flags;
     const int cg = (tid & 15) * 8;
@@ -662,7 +620,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
             }
         }
     }
-    BMT_STAMP(3);
     if (p.colsum) {                  // uniform per launch.  Lanes 16 apart share a column group: fold them, then the waves through LDS
         __syncthreads();             // every staged row has been read
         float* cs = reinterpret_cast<float*>(smem);      // [NT / 64][128]
@@ -847,10 +804,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         BMT_W_BAR();                                                                                                 \
     } while (0)
 
-#ifdef BMT_EXP
-    const int tile_id = (int)blockIdx.x;
-#endif
-    BMT_STAMP(0);
     BMT_W_DMA_W(0, 0);
     BMT_W_DMA_X(0, 0);
     if (T > 1) {
@@ -861,14 +814,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     BMT_W_BAR();
-    BMT_STAMP(1);
     if (wr == 1) BMT_W_BAR();                  // group 1 runs one barrier behind group 0
     for (int t = 0; t < T; t += 2) {
         BMT_W_KTILE(0, t);
         if (t + 1 < T) BMT_W_KTILE(1, t + 1);
     }
     if (wr == 0) BMT_W_BAR();
-    BMT_STAMP(2);
 #undef BMT_W_LGKM0
 #undef BMT_W_KTILE
 #undef BMT_W_MFMA
@@ -1025,47 +976,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
-    BMT_STAMP(3);
 }
 
 // ===================================================================== reduction of 128 (the audio stream's projections: d_model_audio = 128)
 // M x N outputs from a reduction of 128: 2 FLOP per output byte-pair -- these launches are bound by WRITING the result (25600 x 3072 fp16
 // = 157 MB for the fused audio q|k|v), and the tile kernels above spend 102 us on it (1.5 TB/s: every 128 x 128 tile re-stages 64 KB of
 // weight planes for 32 KB of output, and its load / MFMA / store phases do not overlap; profiles/r03_v_last_step_trace.csv).  Here
-//   * a workgroup keeps a CHUNK of the weight (nk_ncw = 128 or 256 rows x 128 k, both planes: <= 128 KB) in LDS for its whole life (one
-//     LDS-DMA burst, XOR-swizzled 16-byte slots), and walks down its share of the activation rows;
+//   * a workgroup keeps a CHUNK of the weight (128 rows x 128 k, both planes: 64 KB) in LDS for its whole life (one LDS-DMA burst,
+//     XOR-swizzled 16-byte slots), and walks down its share of the activation rows;
 //   * a wave owns a 32-row unit: its activation fragments (8 k-steps x 16 bytes per lane) come straight from global memory into
-//     registers -- they are used for every column block of the chunk -- the next unit's are requested before this unit's work;
-//   * per 32-column block: 8 (or 16: second weight plane) MFMAs, then the block is turned through a wave-private 4 KB LDS chunk so that a
-//     store instruction writes 16 rows x 64 contiguous bytes of a 16-bit plane (128 of the fp32 output);
+//     registers -- they are used for every column block of the chunk -- requested by hand TWO units ahead with a counted vmcnt;
+//   * per 32-column block: 8 (or 16: second weight plane) MFMAs on one accumulator that starts as the bias; two blocks go through the
+//     wave's private 8-KB LDS chunk together and leave as 8 rows x 64 columns per store instruction -- whole 128-byte lines of a 16-bit
+//     plane, 256 bytes of a row of C (16 rows x 32 columns, 64-byte half lines, wrote at ~2.5 TB/s; round 4);
 //   * after the initial barrier the 8 waves never synchronise: stores, LDS turns and MFMAs of different waves overlap freely.
 // As in gemm_wide_kernel the weight rows take the MFMA's A role (C^T = W . X^T), so a lane's accumulator registers are consecutive
 // output columns of one output row.
 // Memory operations of a wave retire IN ORDER on this architecture (one vmcnt for loads and stores): a wait for any load issued after
-// a store is a wait for that store's acknowledgement from L2 / HBM -- several microseconds when every CU is writing.  Versions of this
-// kernel in which the waves that store also loaded (bias per block; then only the next unit's activation rows, requested one unit ahead
-// with a counted vmcnt) ran at 2.4 and 1.7 us per 32 x 32 block: each unit waited for the previous unit's stores to be acknowledged
-// (profiles/r03_w_k128_pmc_*.csv: 39 % of the wave time in memory waits at 90 VALU instructions per block).  So the roles are split:
-//   * waves 0-6 COMPUTE: fragments from LDS, MFMAs, the turn through their LDS chunk, stores -- they never wait on vmcnt;
-//   * wave 7 LOADS: the activation rows of the next round (7 units of 32 rows = 56 KB, LDS-DMA, swizzled like the weight chunk) into the
-//     round slot as soon as the compute waves have taken this round's rows into registers (barrier 1), waits for its own loads only, and
-//     meets them again at the end of the round (barrier 2).  Two compute waves per SIMD on three SIMDs, one beside the loader: with 4
-//     compute waves (one per SIMD, two ring slots) a block took 1750 clocks end to end and nothing overlapped it (85 us for q|k|v).
-// Instruction diet of the compute waves (the second finding: 228 VALU instructions per block against 16 MFMAs in the first version):
-// the column-block loop is unrolled (LDS offsets are immediates), the accumulator starts as the bias (alpha is 1 on this path), the
-// plane format is branched on, not selected, 32-bit store offsets, and the next block's fragments are requested before this block's
-// epilogue.
-// PAIR: two 32-column blocks go through the wave's (8-KB) chunk together and leave as 8 rows x 64 columns per store instruction -- whole
-// 128-byte lines of a 16-bit plane, 256 bytes of a row of C -- instead of 16 rows x 32 columns (64-byte half lines: the launch wrote its
-// result at ~2.5 TB/s; gemm_wide_kernel's epilogue saw the same ceiling with 32-byte segments).
-template <bool F16, bool TWO, int NCB, bool LOADER, bool PAIR = false>
+// a store is a wait for that store's acknowledgement from L2 / HBM -- several microseconds when every CU is writing -- hence the counted
+// waits that leave the stores of the last two units in flight.  (Round 3 also ran a variant with seven computing waves and a loading wave;
+// the eight-wave form with hand-counted prefetch measured faster and is the one kept: profiles/r03_w_k128_pmc_*.csv.)
+// Instruction diet: the column-block loop is unrolled (LDS offsets are immediates), the plane format is branched on, not selected, 32-bit
+// store offsets, the next block's fragments are requested before this block's epilogue.
+template <bool F16, bool TWO, int NCB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k128_kernel(const GemmB p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int NCW = 32 * NCB, PLANE = NCW * 256, NPL = TWO ? 2 : 1;
-    constexpr int NCMP = LOADER ? 7 : 8;                                                         // computing waves
-    constexpr int CKB = PAIR ? 8192 : 4096;                                                      // a wave's turn chunk: [32 rows][32 | 64 columns] fp32
-    constexpr int A_OFF = NPL * PLANE, CK_OFF = A_OFF + (LOADER ? NCMP * 8192 : 0), BIAS_OFF = CK_OFF + NCMP * CKB;   // LDS: weight chunk | round slot | turn chunks | bias
+    constexpr int CKB = 8192;                                                                    // a wave's turn chunk: [32 rows][64 columns] fp32 (two blocks)
+    constexpr int CK_OFF = NPL * PLANE, BIAS_OFF = CK_OFF + 8 * CKB;                              // LDS: weight chunk | turn chunks | bias
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -1098,33 +1037,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int units = (Mr + 31) >> 5;
     const int u0 = rg * upw, u_end = min(units, (rg + 1) * upw);
-    const int rounds = (u_end - u0 + NCMP - 1) / NCMP;
-
-    if (LOADER && wid == NCMP) {
-        // ================= the loading wave: round r = units u0 + 7 r .. + 6 (rows clamped: a round may reach past the matrix)
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ah, 0, (int)((int64_t)Mr * p.lda * 2), 0x00020000);
-        auto fill = [&](int r) {
-            char* slot = smem + A_OFF;
-            const int row0 = 32 * (u0 + NCMP * r);
-#pragma unroll 8
-            for (int pc = 0; pc < 8 * NCMP; ++pc) {
-                const int rr = 4 * pc + lrow;                                  // row of the round's 128
-                const int row = min(row0 + rr, Mr - 1);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(slot + pc * 1024), 16, row * (int)p.lda * 2 + ((lslot ^ (rr & 15)) * 16), 0, 0, 0);
-            }
-        };
-        if (rounds > 0) fill(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int r = 0; r < rounds; ++r) {
-            __syncthreads();                      // barrier 1: this round's rows are in the compute waves' registers
-            if (r + 1 < rounds) fill(r + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                      // barrier 2
-        }
-        return;
-    }
-    // ================= the computing waves
     char* ck = smem + CK_OFF + wid * CKB;
     const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
     const int pcols = p.Chi ? p.plane_cols : 0;
@@ -1134,7 +1046,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, p.C ? (int)((int64_t)p.M * p.ldc * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)p.Chi, 0, p.Chi ? (int)((int64_t)p.M * p.ldp * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)p.Clo, 0, p.Clo ? (int)((int64_t)p.M * p.ldp * 2) : 0, 0x00020000);
-    const bool no_st = (p.nk_dbg & 1) != 0;
     const bool slow_epi = (f & (BMT_EPI_DROP_PRE | BMT_EPI_DROP_POST | BMT_EPI_GATE | BMT_EPI_RESIDUAL)) != 0;
     constexpr int CLIP = 0x7fffff00;
     // fragment address of k-step s: + fragb[s] (+ 8192 * block, + PLANE) in the weight chunk, + 8192 * wave in a ring slot
@@ -1157,167 +1068,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         BMT_K128_FRAGS(0);
         const int row_a = 32 * u + rsel;                   // pass 0 row of this lane (pass 1: + 16); a unit past u_end stores nothing
         const int m_lim = u < u_end ? Mr : 0;
-        if constexpr (PAIR) {
-            const int seg8 = lane & 7, rsel8 = lane >> 3;      // this lane's 8 columns of the pair's 64, its row within a pass of 8
+        const int seg8 = lane & 7, rsel8 = lane >> 3;      // this lane's 8 columns of the pair's 64, its row within a pass of 8
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb += 2) {
-                if (cb < ncb) {
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {           // the pair's two blocks, one accumulator after the other (no extra registers)
-                        if (cb + hb < ncb) {
-                            f32x16 acc0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float4 bq = *reinterpret_cast<const float4*>(sbias + 32 * (cb + hb) + 8 * j + 4 * half);
-                                acc0[4 * j + 0] = bq.x; acc0[4 * j + 1] = bq.y; acc0[4 * j + 2] = bq.z; acc0[4 * j + 3] = bq.w;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (!(p.nk_dbg & 2)) {
-#pragma unroll
-                                for (int s = 0; s < 8; ++s) {
-                                    if constexpr (TWO) acc0 = mfma32t<F16>(wl[s], a[s], acc0);
-                                    acc0 = mfma32t<F16>(wh[s], a[s], acc0);
-                                }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (cb + hb + 1 < NCB) {
-                                if (cb + hb + 1 < ncb) BMT_K128_FRAGS(cb + hb + 1);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            // chunk row l31 (256 B = 16 slots of 16 B, slot ^ (row & 15)): columns 32 hb + 8 j + 4 half .. + 3
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float4 t;
-                                t.x = acc0[4 * j + 0]; t.y = acc0[4 * j + 1]; t.z = acc0[4 * j + 2]; t.w = acc0[4 * j + 3];
-                                *reinterpret_cast<float4*>(ck + l31 * 256 + (((8 * hb + 2 * j + half) ^ (l31 & 15)) * 16)) = t;
-                            }
-                        }
-                    }
-                    const int col = n0 + 32 * cb + 8 * seg8;
-                    const bool in_n = col < p.N;
-                    const bool in_p = col < pcols;
-                    const bool in_pair = 8 * seg8 < 32 * min(2, ncb - cb);       // (an odd last block: the pair's second half was not computed)
-#pragma unroll 2
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const int rl = 8 * ps + rsel8;
-                        const float4 t0 = *reinterpret_cast<const float4*>(ck + rl * 256 + (((2 * seg8) ^ (rl & 15)) * 16));
-                        const float4 t1 = *reinterpret_cast<const float4*>(ck + rl * 256 + (((2 * seg8 + 1) ^ (rl & 15)) * 16));
-                        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                        const int row = 32 * u + rl;
-                        const bool rok = row < m_lim && in_pair;
-                        if (f & BMT_EPI_RELU) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                        }
-                        if (slow_epi) {
-                            const int64_t idx = (int64_t)row * p.ldc + col;
-                            if (f & BMT_EPI_DROP_PRE) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
-                            }
-                            if (f & BMT_EPI_DROP_POST) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
-                            }
-                            if ((f & BMT_EPI_GATE) && rok && in_n) {
-                                const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + (int64_t)row * p.ldg + col);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    v[2 * q] = (gv[q] & 0x00007FFFu) ? v[2 * q] * p.gate_scale : 0.f;
-                                    v[2 * q + 1] = (gv[q] & 0x7FFF0000u) ? v[2 * q + 1] * p.gate_scale : 0.f;
-                                }
-                            }
-                            if ((f & BMT_EPI_RESIDUAL) && rok && in_n) {
-                                const float* rp = p.residual + (int64_t)row * p.ldr + col;
-                                const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-                                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                            }
-                        }
-                        if (32 * (cb + 2) > p.N - n0) {
-                            if (!in_n) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] = 0.f;
-                            }
-                        }
-                        if (p.C && !no_st) {
-                            const int vo = (rok && in_n) ? row * ldc4 + col * 4 : CLIP;
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsC, vo, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsC, vo, 16, 0);
-                        }
-                        if (p.Chi && !no_st) {
-                            const int vo = (rok && in_p) ? row * ldp2 + col * 2 : CLIP;
-                            if (p.hi_f16) {
-                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])}, rsH, vo, 0, 0);
-                            } else {
-                                u32x4 h, l;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    uint32_t h_, l_;
-                                    split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
-                                    h[q] = h_;
-                                    l[q] = l_;
-                                }
-                                __builtin_amdgcn_raw_buffer_store_b128(h, rsH, vo, 0, 0);
-                                if (p.Clo) {
-                                    if (p.second_f16) l = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
-                                    __builtin_amdgcn_raw_buffer_store_b128(l, rsL, vo, 0, 0);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
+        for (int cb = 0; cb < NCB; cb += 2) {
             if (cb < ncb) {
-                // the accumulator starts as the bias (register group j = columns 8 j + 4 half .. + 3)
-                f32x16 acc0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 bq = *reinterpret_cast<const float4*>(sbias + 32 * cb + 8 * j + 4 * half);
-                    acc0[4 * j + 0] = bq.x; acc0[4 * j + 1] = bq.y; acc0[4 * j + 2] = bq.z; acc0[4 * j + 3] = bq.w;
-                }
-                __builtin_amdgcn_sched_barrier(0);           // the fragment reads stay in front of the MFMAs, all 16 in flight together
-                if (!(p.nk_dbg & 2)) {
-                    // one accumulator chain for both weight planes: the second wave of the SIMD fills the gaps a dependent MFMA leaves
+                for (int hb = 0; hb < 2; ++hb) {           // the pair's two blocks, one accumulator after the other (no extra registers)
+                    if (cb + hb < ncb) {
+                        f32x16 acc0;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        if constexpr (TWO) acc0 = mfma32t<F16>(wl[s], a[s], acc0);
-                        acc0 = mfma32t<F16>(wh[s], a[s], acc0);
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 bq = *reinterpret_cast<const float4*>(sbias + 32 * (cb + hb) + 8 * j + 4 * half);
+                            acc0[4 * j + 0] = bq.x; acc0[4 * j + 1] = bq.y; acc0[4 * j + 2] = bq.z; acc0[4 * j + 3] = bq.w;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        {
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) {
+                                if constexpr (TWO) acc0 = mfma32t<F16>(wl[s], a[s], acc0);
+                                acc0 = mfma32t<F16>(wh[s], a[s], acc0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (cb + hb + 1 < NCB) {
+                            if (cb + hb + 1 < ncb) BMT_K128_FRAGS(cb + hb + 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // chunk row l31 (256 B = 16 slots of 16 B, slot ^ (row & 15)): columns 32 hb + 8 j + 4 half .. + 3
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float4 t;
+                            t.x = acc0[4 * j + 0]; t.y = acc0[4 * j + 1]; t.z = acc0[4 * j + 2]; t.w = acc0[4 * j + 3];
+                            *reinterpret_cast<float4*>(ck + l31 * 256 + (((8 * hb + 2 * j + half) ^ (l31 & 15)) * 16)) = t;
+                        }
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (cb + 1 < NCB) {
-                    if (cb + 1 < ncb) BMT_K128_FRAGS(cb + 1);          // in flight during this block's epilogue
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- the block through the wave's chunk: acc[4 j + q] = column 8 j + 4 half + q of row l31
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float4 t;
-                    t.x = acc0[4 * j + 0]; t.y = acc0[4 * j + 1]; t.z = acc0[4 * j + 2]; t.w = acc0[4 * j + 3];
-                    *reinterpret_cast<float4*>(ck + wr_off + (((2 * j + half) ^ (l31 & 7)) * 16)) = t;
-                }
-                const int col = n0 + 32 * cb + 8 * seg;
-                const bool in_n = col < p.N;                          // N is a multiple of 8 here: a segment is inside or outside
+                const int col = n0 + 32 * cb + 8 * seg8;
+                const bool in_n = col < p.N;
                 const bool in_p = col < pcols;
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int rl = 16 * ps + rsel;
-                    const float4 t0 = *reinterpret_cast<const float4*>(ck + rl * 128 + (((2 * seg) ^ (rl & 7)) * 16));
-                    const float4 t1 = *reinterpret_cast<const float4*>(ck + rl * 128 + (((2 * seg + 1) ^ (rl & 7)) * 16));
+                const bool in_pair = 8 * seg8 < 32 * min(2, ncb - cb);       // (an odd last block: the pair's second half was not computed)
+#pragma unroll 2
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rl = 8 * ps + rsel8;
+                    const float4 t0 = *reinterpret_cast<const float4*>(ck + rl * 256 + (((2 * seg8) ^ (rl & 15)) * 16));
+                    const float4 t1 = *reinterpret_cast<const float4*>(ck + rl * 256 + (((2 * seg8 + 1) ^ (rl & 15)) * 16));
                     float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                    const int row = row_a + 16 * ps;
-                    const bool rok = row < m_lim;
+                    const int row = 32 * u + rl;
+                    const bool rok = row < m_lim && in_pair;
                     if (f & BMT_EPI_RELU) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                     }
                     if (slow_epi) {
                         const int64_t idx = (int64_t)row * p.ldc + col;
-                        if (f & BMT_EPI_DROP_PRE) {       // (documented before the ReLU: the two commute exactly -- a mask and a positive scale)
+                        if (f & BMT_EPI_DROP_PRE) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
                         }
@@ -1339,18 +1143,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                         }
                     }
-                    if (32 * (cb + 1) > p.N - n0) {       // only the ragged last block of the matrix has segments outside N
+                    if (32 * (cb + 2) > p.N - n0) {
                         if (!in_n) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = 0.f;
                         }
                     }
-                    if (p.C && !no_st) {
+                    if (p.C) {
                         const int vo = (rok && in_n) ? row * ldc4 + col * 4 : CLIP;
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsC, vo, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsC, vo, 16, 0);
                     }
-                    if (p.Chi && !no_st) {
+                    if (p.Chi) {
                         const int vo = (rok && in_p) ? row * ldp2 + col * 2 : CLIP;
                         if (p.hi_f16) {
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])}, rsH, vo, 0, 0);
@@ -1374,76 +1178,59 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-    if constexpr (LOADER) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int r = 0; r < rounds; ++r) {
-            const int u = u0 + NCMP * r + wid;
-            bf16x8 a[8];
-            {
-                const char* ab = smem + A_OFF + wid * 8192;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(ab + fragb[s]));
-            }
-            __syncthreads();          // barrier 1 (waits for the reads above): the loading wave may overwrite the slot
-            process(a, u);
-            __syncthreads();          // barrier 2: the next round's rows have landed (the loading wave waited for them)
-        }
-    } else {
-        // every wave computes; its activation rows come straight from global memory into registers, requested TWO units ahead by hand
-        // (asm: the compiler does not track them) and waited for with a counted vmcnt that leaves the younger operations -- the other
-        // register set's loads and the stores of the last two units -- in flight.  All stores are issued unconditionally (clipped by the
-        // descriptor) so that the count is exact.
-        u32x4 n0r[8], n1r[8];
+    // every wave computes; its activation rows come straight from global memory into registers, requested TWO units ahead by hand
+    // (asm: the compiler does not track them) and waited for with a counted vmcnt that leaves the younger operations -- the other
+    // register set's loads and the stores of the last two units -- in flight.  All stores are issued unconditionally (clipped by the
+    // descriptor) so that the count is exact.
+    u32x4 n0r[8], n1r[8];
 #define BMT_K128_LD(dst_, i_) asm volatile("global_load_dwordx4 %0, %1, off offset:" #i_ "*32" : "=&v"(dst_[i_]) : "v"(ap_) : "memory")
 #define BMT_K128_LDA(dst_, uu_)                                                                                     \
-    do {                                                                                                             \
-        const int row_ = max(0, min(32 * min((uu_), units - 1) + l31, Mr - 1));                                             \
-        const uint16_t* ap_ = p.Ah + (int64_t)row_ * p.lda + 8 * half;                                               \
-        BMT_K128_LD(dst_, 0); BMT_K128_LD(dst_, 1); BMT_K128_LD(dst_, 2); BMT_K128_LD(dst_, 3);                      \
-        BMT_K128_LD(dst_, 4); BMT_K128_LD(dst_, 5); BMT_K128_LD(dst_, 6); BMT_K128_LD(dst_, 7);                      \
-    } while (0)
+do {                                                                                                             \
+    const int row_ = max(0, min(32 * min((uu_), units - 1) + l31, Mr - 1));                                             \
+    const uint16_t* ap_ = p.Ah + (int64_t)row_ * p.lda + 8 * half;                                               \
+    BMT_K128_LD(dst_, 0); BMT_K128_LD(dst_, 1); BMT_K128_LD(dst_, 2); BMT_K128_LD(dst_, 3);                      \
+    BMT_K128_LD(dst_, 4); BMT_K128_LD(dst_, 5); BMT_K128_LD(dst_, 6); BMT_K128_LD(dst_, 7);                      \
+} while (0)
 #define BMT_K128_W(dst_, n_)                                                                                         \
-    asm volatile("s_waitcnt vmcnt(" #n_ ")"                                                                         \
-                 : "+v"(dst_[0]), "+v"(dst_[1]), "+v"(dst_[2]), "+v"(dst_[3]), "+v"(dst_[4]), "+v"(dst_[5]), "+v"(dst_[6]), "+v"(dst_[7])::"memory")
+asm volatile("s_waitcnt vmcnt(" #n_ ")"                                                                         \
+             : "+v"(dst_[0]), "+v"(dst_[1]), "+v"(dst_[2]), "+v"(dst_[3]), "+v"(dst_[4]), "+v"(dst_[5]), "+v"(dst_[6]), "+v"(dst_[7])::"memory")
 #define BMT_K128_WAIT(dst_, cnt_)                                                                                    \
-    do {                                                                                                             \
-        const int c_ = (cnt_);                     /* operations younger than the loads waited for */               \
-        if (c_ >= 56) BMT_K128_W(dst_, 56);                                                                          \
-        else if (c_ >= 40) BMT_K128_W(dst_, 40);                                                                     \
-        else if (c_ >= 24) BMT_K128_W(dst_, 24);                                                                     \
-        else if (c_ >= 16) BMT_K128_W(dst_, 16);                                                                     \
-        else if (c_ >= 8) BMT_K128_W(dst_, 8);                                                                       \
-        else BMT_K128_W(dst_, 0);                                                                                    \
-    } while (0)
-        const int nst = no_st ? 0 : (p.C ? 2 : 0) + (p.Chi ? 1 : 0) + (p.Clo ? 1 : 0);      // store instructions per pass; 2 passes per block
-        const int kw = PAIR ? 4 * nst * ((ncb + 1) >> 1) : 2 * nst * ncb;                    // ... per unit (PAIR: 4 passes per pair of blocks)
-        int u = u0 + wid;
-        BMT_K128_LDA(n0r, u);
-        BMT_K128_LDA(n1r, u + 8);
-        BMT_K128_W(n0r, 8);                        // the weight chunk and the first unit's rows (older than the second unit's 8 loads)
-        __syncthreads();
-        bool first = true;
-        for (; u < u_end; u += 16) {
-            bf16x8 a[8];
+do {                                                                                                             \
+    const int c_ = (cnt_);                     /* operations younger than the loads waited for */               \
+    if (c_ >= 56) BMT_K128_W(dst_, 56);                                                                          \
+    else if (c_ >= 40) BMT_K128_W(dst_, 40);                                                                     \
+    else if (c_ >= 24) BMT_K128_W(dst_, 24);                                                                     \
+    else if (c_ >= 16) BMT_K128_W(dst_, 16);                                                                     \
+    else if (c_ >= 8) BMT_K128_W(dst_, 8);                                                                       \
+    else BMT_K128_W(dst_, 0);                                                                                    \
+} while (0)
+    const int nst = (p.C ? 2 : 0) + (p.Chi ? 1 : 0) + (p.Clo ? 1 : 0);      // store instructions per pass; 2 passes per block
+    const int kw = 4 * nst * ((ncb + 1) >> 1);                                            // ... per unit (4 passes per pair of blocks)
+    int u = u0 + wid;
+    BMT_K128_LDA(n0r, u);
+    BMT_K128_LDA(n1r, u + 8);
+    BMT_K128_W(n0r, 8);                        // the weight chunk and the first unit's rows (older than the second unit's 8 loads)
+    __syncthreads();
+    bool first = true;
+    for (; u < u_end; u += 16) {
+        bf16x8 a[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(n0r[s]);
-            if (!(p.nk_dbg & 4)) BMT_K128_LDA(n0r, u + 16);
-            process(a, u);
-            if (u + 8 >= u_end) break;
-            BMT_K128_WAIT(n1r, first ? 8 + kw : 8 + 2 * kw);
+        for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(n0r[s]);
+        BMT_K128_LDA(n0r, u + 16);
+        process(a, u);
+        if (u + 8 >= u_end) break;
+        BMT_K128_WAIT(n1r, first ? 8 + kw : 8 + 2 * kw);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(n1r[s]);
-            if (!(p.nk_dbg & 4)) BMT_K128_LDA(n1r, u + 24);
-            process(a, u + 8);
-            BMT_K128_WAIT(n0r, 8 + 2 * kw);
-            first = false;
-        }
+        for (int s = 0; s < 8; ++s) a[s] = as_bf16x8(n1r[s]);
+        BMT_K128_LDA(n1r, u + 24);
+        process(a, u + 8);
+        BMT_K128_WAIT(n0r, 8 + 2 * kw);
+        first = false;
+    }
 #undef BMT_K128_LD
 #undef BMT_K128_LDA
 #undef BMT_K128_W
 #undef BMT_K128_WAIT
-    }
 #undef BMT_K128_FRAGS
 }
 
@@ -1689,8 +1476,7 @@ __global__ __launch_bounds__(256) void planes_rows_kernel(const PlaneDesc d) {
 
 // the vector kernel applies when there is a straight hi plane and nothing transposed, everything 16-byte aligned
 static bool planes_straight_ok(const PlaneDesc& d) {
-    static const int old = getenv("BMT_PLANES_OLD") ? atoi(getenv("BMT_PLANES_OLD")) : 0;        // A/B experiments only
-    return !old && (d.hi || d.fh) && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
+    return (d.hi || d.fh) && (d.ld % 4 == 0) && (d.ldp % 8 == 0) && (d.pcols % 8 == 0) &&
            ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.hi) | reinterpret_cast<uintptr_t>(d.lo) |
              reinterpret_cast<uintptr_t>(d.fh) | reinterpret_cast<uintptr_t>(d.fl)) & 15) == 0;
 }
@@ -1791,9 +1577,8 @@ int launch_pipe(const GemmB& p, int splitk, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    static const int persist = getenv("BMT_GEMM_PERSIST") ? atoi(getenv("BMT_GEMM_PERSIST")) : 1;      // A/B experiments only
     const int tiles = p.tiles_m * p.tiles_n, slots = bmt_device_cus() * (TI == 2 ? 1 : 2);
-    const int gx = (persist && tiles > slots && slots % 8 == 0) ? slots : tiles;
+    const int gx = (tiles > slots && slots % 8 == 0) ? slots : tiles;          // persistent: a workgroup per slot walks the tiles
     hipLaunchKernelGGL((gemm_pipe_kernel<NPASS, F16, TI, AKM, BKM, CONV>), dim3(gx, splitk), dim3(512), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(pipelined)");
     return BMT_OK;
@@ -1812,50 +1597,28 @@ int launch_wide(const GemmB& p, hipStream_t st) {
     return BMT_OK;
 }
 
-template <bool F16, bool TWO, int NCB, bool LOADER>
-int launch_k128__(const GemmB& p, hipStream_t st) {
-    static const int pair_env = getenv("BMT_GEMM_K128_PAIR") ? atoi(getenv("BMT_GEMM_K128_PAIR")) : 1;      // A/B: 0 = 32-column blocks one at a time
-    if constexpr (!LOADER) {
-        if (pair_env) {
-            constexpr int lds2 = (TWO ? 2 : 1) * NCB * 32 * 256 + 8 * 8192 + NCB * 32 * 4;
-            static bool done2 = false;
-            if (!done2) {
-                (void)hipFuncSetAttribute((const void*)gemm_k128_kernel<F16, TWO, NCB, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                done2 = true;
-            }
-            hipLaunchKernelGGL((gemm_k128_kernel<F16, TWO, NCB, false, true>), dim3(p.tiles_n * p.nk_rg), dim3(512), lds2, st, p);
-            BMT_CHECK_LAUNCH("bmt_gemm_bf16(reduction of 128, paired blocks)");
-            return BMT_OK;
-        }
-    }
-    constexpr int lds = (TWO ? 2 : 1) * NCB * 32 * 256 + (LOADER ? 7 * 8192 + 7 * 4096 : 8 * 4096) + NCB * 32 * 4;
+// the weight-chunk-resident kernel: 128-column chunks (64 KB of LDS with two weight planes), eight computing waves, two 32-column blocks
+// through a wave's LDS chunk together
+template <bool F16, bool TWO>
+int launch_k128_(const GemmB& p, hipStream_t st) {
+    constexpr int NCB = 4;
+    constexpr int lds = (TWO ? 2 : 1) * NCB * 32 * 256 + 8 * 8192 + NCB * 32 * 4;
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_k128_kernel<F16, TWO, NCB, LOADER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_k128_kernel<F16, TWO, NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_k128_kernel<F16, TWO, NCB, LOADER>), dim3(p.tiles_n * p.nk_rg), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_k128_kernel<F16, TWO, NCB>), dim3(p.tiles_n * p.nk_rg), dim3(512), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(reduction of 128)");
     return BMT_OK;
 }
-template <bool F16, bool TWO, int NCB>
-int launch_k128_(const GemmB& p, hipStream_t st) {
-    return p.nk_loader ? launch_k128__<F16, TWO, NCB, true>(p, st) : launch_k128__<F16, TWO, NCB, false>(p, st);
-}
-// chunk widths the kernel is built for: 128 columns with two weight planes (64 KB of LDS), 128 / 256 with one
 template <bool F16>
 int launch_k128(const GemmB& p, hipStream_t st) {
-    if (p.Bl) return launch_k128_<F16, true, 4>(p, st);
-    return (p.nk_ncw == 256 && p.nk_loader) ? launch_k128_<F16, false, 8>(p, st) : launch_k128_<F16, false, 4>(p, st);
+    return p.Bl ? launch_k128_<F16, true>(p, st) : launch_k128_<F16, false>(p, st);
 }
 
 }  // namespace
 
-#ifdef BMT_EXP
-extern "C" int bmt_dbg_read(unsigned long long* dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bmt_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 // validate the arguments and fill the kernel descriptor; splitk: in = 0 (decide here) / forced value, out = splits to launch
 static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool allow_split) {
@@ -1911,68 +1674,37 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
     p.rows_dev = a->rows_dev; p.rows_is_k = a->a_kmajor != 0;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
-    static const int tap_minor = getenv("BMT_CONV_DW_TAP_MINOR") ? atoi(getenv("BMT_CONV_DW_TAP_MINOR")) : 1;      // A/B: 0 = tap-major column tiles
-    p.conv_tap_minor = (a->conv_mode == 2 && a->conv_cin % BN == 0) ? tap_minor : 0;
+    // Conv1d dW: the taps of a channel block before the next channel block (halves the launch's HBM fetch, profiles/r04_x_ab_conv_dw_order.txt)
+    p.conv_tap_minor = (a->conv_mode == 2 && a->conv_cin % BN == 0) ? 1 : 0;
     p.tiles_n = bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, BN);
-    // tile height: 256 rows (8 waves, one workgroup per CU) when that still fills the chip, else 128 rows (4 waves, two per CU)
-    static const int force_bm = getenv("BMT_GEMM_BM") ? atoi(getenv("BMT_GEMM_BM")) : 0;      // A/B experiments only
-    // measured (tools/microbench.py gemm with BMT_GEMM_BM / BMT_GEMM_8W): the 256-row tile gains 5 % for the 3-pass kernel on
-    // K >= 512 shapes and loses 2-8 % elsewhere; the 8-wave 128-row tile (below) beats both, so 256 rows is opt-in only
+    // Which kernel (every choice below was measured against its alternatives on the shapes of the step; DESIGN.md section 6 has the numbers):
+    //   pipe 0  register-staged loop on 128-row tiles, 8 waves: k-major operands (every dX / dW), the three-pass product, Conv1d dW
+    //   pipe 2  LDS-DMA pipelined loop on 128-row tiles, two workgroups per CU: every other row-major product
+    //   pipe 1  ... on 256 x 128 tiles, one workgroup per CU: launches that are whole rounds of 256 such tiles with a reduction >= 512, and
+    //           the Conv1d forward where that is at least one tile per CU
+    //   pipe 3  the 256 x 256 ping-pong kernel: >= one round of its tiles, reduction >= 256, plain epilogue
+    //   pipe 4  the weight-chunk-resident kernel: a reduction of exactly 128 over >= 2048 rows (the audio stream's projections)
     p.bm = 128;
-    if (force_bm == 128 || force_bm == 256) p.bm = force_bm;
-    if (a->a_kmajor || a->b_kmajor || a->conv_mode || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2) p.bm = 128;
-    // the LDS-DMA pipelined kernel: row-major operands, a reduction long enough to fill its ring, and enough 256 x 128 tiles for
-    // the 256 CUs (it runs one workgroup per CU)
-    static const int force_pipe = getenv("BMT_GEMM_PIPE") ? atoi(getenv("BMT_GEMM_PIPE")) : -1;    // A/B experiments only
-    // measured (tools/microbench.py, profiles/r02_*): the 128-row pipelined tile (two workgroups per CU) beats the register-staged
-    // loop on every row-major shape of the step (+6..+19 %); the 256-row tile (one workgroup per CU) only wins for K >= 4096
     p.pipe = 0;
     if (!a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = 2;
-
-    // 256 x 128 tiles (one workgroup per CU, 64-deep stages also for the two-plane product): for launches that are exactly one
-    // or two rounds of 256 such tiles with a long reduction (the video stream's out-projections, Q projection and FFN-2)
-    static const int tall = getenv("BMT_GEMM_TALL") ? atoi(getenv("BMT_GEMM_TALL")) : 512;         // A/B experiments only
-    static const int tall_any = getenv("BMT_GEMM_TALL_ANY") ? atoi(getenv("BMT_GEMM_TALL_ANY")) : 0;
-    if (p.pipe == 2 && tall && a->Kpad >= tall) {
+    if (p.pipe == 2 && a->Kpad >= 512) {
         const int t256 = bmt_cdiv(a->M, 256) * p.tiles_n, cus = bmt_device_cus();
-        if (t256 >= cus && (t256 % cus == 0 || tall_any)) p.pipe = 1;
+        if (t256 >= cus && t256 % cus == 0) p.pipe = 1;
     }
-    // implicit Conv1d forward on the pipelined loop (bmt_gemm_bf16: BMT_CONV_PIPE): 2 = 256 x 128 tiles (64 reduction indices per step) where
-    // that is at least one tile per CU
-    static const int conv_pipe_p = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 2;
-    if (conv_pipe_p >= 2 && a->conv_mode == 1 && !a->a_kmajor && !a->b_kmajor &&
-        (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2 || (conv_pipe_p >= 3 && a->precision == BMT_PREC_BF16)) &&
+    if (a->conv_mode == 1 && !a->a_kmajor && !a->b_kmajor && (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2) &&
         bmt_cdiv(a->M, 256) * p.tiles_n >= bmt_device_cus())
         p.pipe = 1;
-    // dX = dY . W (the weight plane k-major) on the pipelined 256 x 128 tile: row-major gradient rows by LDS-DMA as in the forward, the weight's
-    // [64 reduction rows][128 columns] image by the k-major DMA + transposing reads, a ring of three steps at one workgroup per CU
-    static const int dx_pipe = getenv("BMT_DX_PIPE") ? atoi(getenv("BMT_DX_PIPE")) : 0;      // A/B experiments
-    if (dx_pipe && a->b_kmajor && !a->a_kmajor && !a->conv_mode && a->precision == BMT_PREC_BF16 && a->Kpad >= 256 && a->splitk <= 1 &&
-        a->lda % 8 == 0 && a->ldb % 8 == 0 && bmt_cdiv(a->M, 256) * p.tiles_n >= bmt_device_cus() &&
-        (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->K * a->ldb * 2 < (1ll << 31))
-        p.pipe = 1;
-    if (force_pipe == 0) p.pipe = 0;
-    if (force_pipe >= 1 && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = force_pipe;   // 1: 256-row tile, 2: 128-row tile
-    // the 256 x 256 ping-pong kernel: row-major operands, plain epilogues (no column sums / accumulation / split-K)
-    static const int force_wide = getenv("BMT_GEMM_WIDE") ? atoi(getenv("BMT_GEMM_WIDE")) : -1;    // A/B experiments only
     const bool wide_ok = p.pipe != 0 && !a->conv_mode && !a->a_kmajor && !a->b_kmajor && !a->colsum && !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && a->N >= 256 &&
                          (int64_t)(a->M + 256) * a->lda * 2 < (1ll << 31) && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31);
-    // measured (tools/microbench.py gemm, BMT_GEMM_WIDE=0/1): it wins where a launch has at least one full round of 256 x 256
-    // tiles and a reduction long enough to amortise its prologue (8192 x 4096 x 1024 two-plane 169 -> 134 us, 8192 x 2048 x 1024
-    // 87 -> 68 us); 128 tiles (half the CUs) or K = 128 (output-write bound either way) stay on the 128-row tiles
     const int wide_tiles = bmt_cdiv(a->M, 256) * bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
-    if (wide_ok && (force_wide == 1 || (force_wide < 0 && force_pipe < 0 && wide_tiles >= bmt_device_cus() && a->Kpad >= 256))) p.pipe = 3;
+    if (wide_ok && wide_tiles >= bmt_device_cus() && a->Kpad >= 256) p.pipe = 3;
     if (p.pipe == 3) {
         p.bm = 256;
         p.tiles_n = bmt_cdiv(p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N, 256);
         if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;      // the kernel runs its second pass iff there is a second weight plane
     }
     if (p.pipe == 1) p.bm = 256;
-    // reduction of 128 with many rows (the audio stream's projections): the weight-chunk-resident kernel
-    static const int force_k128 = getenv("BMT_GEMM_K128") ? atoi(getenv("BMT_GEMM_K128")) : -1;    // A/B experiments only
-    static const int k128_ncw = getenv("BMT_GEMM_K128_NCW") ? atoi(getenv("BMT_GEMM_K128_NCW")) : 0;
-    static const int k128_loader = getenv("BMT_GEMM_K128_LOADER") ? atoi(getenv("BMT_GEMM_K128_LOADER")) : 0;
-    if (p.pipe == 2 && force_k128 != 0 && force_pipe < 0 && a->Kpad == 128 && a->M >= 2048 && a->N >= 128 && !a->colsum &&
+    if (p.pipe == 2 && a->Kpad == 128 && a->M >= 2048 && a->N >= 128 && !a->colsum &&
         !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31) && a->alpha == 1.f &&
         // its stores are 16-byte buffer stores clipped by 32-bit descriptors, its gate / residual loads 16-byte loads
         a->N % 8 == 0 && (!p.Chi || (p.plane_vec && (int64_t)a->M * a->ldp * 2 < (1ll << 31))) &&
@@ -1980,49 +1712,23 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         (!(a->flags & BMT_EPI_GATE) || (al16(a->gate) && a->ldg % 8 == 0)) &&
         (!(a->flags & BMT_EPI_RESIDUAL) || (al16(a->residual) && a->ldr % 4 == 0))) {
         if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;
+        // 128-column weight chunks; the row groups (workgroups of one chunk) share the 32-row units of the activation
         const int cols = p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N;
         const int units = bmt_cdiv(a->M, 32), cus = bmt_device_cus();
-        int64_t best = -1;
-        for (int ncw = 256; ncw >= 128; ncw -= 64) {
-            if (k128_ncw && ncw != k128_ncw) continue;
-            if (ncw != 128 && (p.Bl || ncw != 256 || !k128_loader)) continue;
-            const int nch = bmt_cdiv(cols, ncw);
-            int rg = cus / nch < 1 ? 1 : cus / nch;
-            const int upw = bmt_cdiv(units, rg);
-            rg = bmt_cdiv(units, upw);
-            const int64_t cost = (int64_t)bmt_cdiv(upw, k128_loader ? 7 : 8) * ncw + ncw + ncw / 2;      // rounds of units x chunk width + the chunk's load
-            if (best < 0 || cost < best) { best = cost; p.nk_ncw = ncw; p.nk_rg = rg; p.nk_upw = upw; p.tiles_n = nch; }
-        }
-        if (best >= 0) p.pipe = 4;
-        static const int k128_dbg = getenv("BMT_K128_DBG") ? atoi(getenv("BMT_K128_DBG")) : 0;
-        p.nk_dbg = k128_dbg;
-        p.nk_loader = k128_loader;
-    }
-    // one column tile over many rows (the audio stream's 25600 x 128 outputs): 200 workgroups of 8 waves leave a fifth of the CUs idle and
-    // every CU with one workgroup's latency chain (38-44 us for 52 MB of operand: 1.3 TB/s); 64-row tiles are 400 workgroups of 4 waves,
-    // two or three per CU
-    static const int short_env = getenv("BMT_GEMM_SHORT") ? atoi(getenv("BMT_GEMM_SHORT")) : 0;      // A/B: bit 0 k-major (backward), bit 1 row-major fp16 (forward).  Off: measured 8.83-8.87 vs 8.77 ms/step (bf16 class 1.78 vs 1.75 ms, fp16 class 2.23 vs 2.29)
-    if (p.pipe != 3 && p.pipe != 4 && !a->conv_mode && !a->colsum && p.tiles_n == 1 && a->M >= 4096 && bmt_cdiv(a->M, 128) < bmt_device_cus() &&
-        a->splitk <= 1 && force_bm == 0) {
-        const bool km = a->a_kmajor || a->b_kmajor;
-        if (km ? (short_env & 1) != 0 && a->precision == BMT_PREC_BF16
-               : (short_env & 2) != 0 && (a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2)) {
-            p.bm = 64;
-            p.pipe = 0;
-        }
+        const int nch = bmt_cdiv(cols, 128);
+        int rg = cus / nch < 1 ? 1 : cus / nch;
+        const int upw = bmt_cdiv(units, rg);
+        p.nk_rg = bmt_cdiv(units, upw); p.nk_upw = upw; p.tiles_n = nch;
+        p.pipe = 4;
     }
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3 || (a->precision == BMT_PREC_F16W2 && p.pipe != 1)) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
-    // measured (tools/gpu_ab.sh, whole step): splitting the 200-tile products of the audio stream (25600 x 128 outputs) costs more in
-    // the workspace pass than the idle CUs of an unsplit launch: threshold 256 -> 180 tiles is -0.15 ms / step
-    static const int sk_tiles = getenv("BMT_SPLITK_TILES") ? atoi(getenv("BMT_SPLITK_TILES")) : 180;          // A/B experiments only
-    static const int sk_kt = getenv("BMT_SPLITK_MIN_KTILES") ? atoi(getenv("BMT_SPLITK_MIN_KTILES")) : 12;
-    if (a->splitk == 0 && two_pass && tiles < sk_tiles && ktiles >= sk_kt && p.pipe != 3 && p.pipe != 4) {
-        // automatic: fill ~2 workgroups per CU, keep at least 2 stages per split
-        static const int sk_target = getenv("BMT_SPLITK_TARGET") ? atoi(getenv("BMT_SPLITK_TARGET")) : 512;           // A/B experiments only
-        int want = sk_target / tiles, cap = ktiles / 2;
+    // split-K (two passes through the workspace) for launches of fewer than 180 tiles with >= 12 stages: ~2 workgroups per CU, at least two
+    // stages per split.  (Splitting the 200-tile products of the audio stream costs more in the workspace pass than their idle CUs.)
+    if (a->splitk == 0 && two_pass && tiles < 180 && ktiles >= 12 && p.pipe != 3 && p.pipe != 4) {
+        int want = 512 / tiles, cap = ktiles / 2;
         if (want > 32) want = 32;
         splitk = want < cap ? want : cap;
         if (splitk < 1) splitk = 1;
@@ -2043,11 +1749,6 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.colsum = a->colsum;
     BMT_CHECK_ARG(!a->colsum || (a->C_hi && p.plane_vec && !a->C), "bmt_gemm_bf16: colsum needs 16-byte aligned plane-only output");
     p.drop_p = a->drop_p; p.rng = a->rng; p.site = a->site;
-#ifdef BMT_EXP
-    p.exp = getenv("BMT_EXP") ? atoi(getenv("BMT_EXP")) : 0;
-    p.exp_sleep = getenv("BMT_EXP_SLEEP") ? atoi(getenv("BMT_EXP_SLEEP")) : 3;
-    p.exp_shift = getenv("BMT_EXP_SHIFT") ? atoi(getenv("BMT_EXP_SHIFT")) : 3;
-#endif
     return BMT_OK;
 }
 
@@ -2056,41 +1757,22 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     int splitk = 0;
     int rc = gemm_prepare(a, p, splitk, true);
     if (rc != BMT_OK) return rc;
-    // 128-row tile: 8 waves of 32x64 (4 waves per SIMD across two workgroups) hide the stage loop's LDS / barrier latency
-    // better than 4 waves of 64x64 -- 25600x1024x128 forward 81 -> 57 us, 8192x1024x1024 x1 38 -> 33 us, whole step -6 %; also on
-    // the very large grids (FFN fc2 dX, 2048 tiles of 16 stages: 156 -> 127 us; whole step 15.25 -> 14.97 ms same box)
-    static const int force8 = getenv("BMT_GEMM_8W") ? atoi(getenv("BMT_GEMM_8W")) : -1;          // A/B experiments only
-    const int waves8 = force8 >= 0 ? force8 : 1;
     hipStream_t st_ = (hipStream_t)stream;
     const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
-    // k-major operands through the LDS-DMA ring (swizzled unpadded images): correct (the k-major GEMM tests pass on it) but slower in
-    // the step than the register-staged loop with its two tiles of prefetch -- the ring has room for two stages only at two workgroups
-    // per CU: dX class 1.74 -> 2.06 ms, grouped dW unchanged (tools/gpu_ab.sh BMT_GEMM_KM_PIPE=0/1).  Off; kept as a switch.
-    static const int km_pipe_env = getenv("BMT_GEMM_KM_PIPE") ? atoi(getenv("BMT_GEMM_KM_PIPE")) : 0;      // A/B experiments only
-    const bool km_pipe = km_pipe_env && a->conv_mode == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0;
     const bool f16 = a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2;
-    // implicit Conv1d forward / dX on the LDS-DMA pipelined loop (the A rows shift by a tap per step: one scalar offset)
-    static const int conv_pipe = getenv("BMT_CONV_PIPE") ? atoi(getenv("BMT_CONV_PIPE")) : 2;      // 0: register-staged loop; 1: 128-row tiles; 2: 256-row tiles where they fill the chip (measured: train_prop 57.9 / 57.1 / 53.8 ms, profiles/r04_t_ab_conv_pipe2.txt); 3: also the dX products
     if (f16 && (akm || bkm || a->conv_mode == 2)) {
         bmt_set_error("bmt_gemm_bf16: the fp16 precisions take row-major operands (forward products) only");
         return BMT_EINVAL;
     }
-    if (p.bm == 64) {                 // 64-row tiles, 4 waves (gemm_prepare: one column tile over many rows)
-        if (f16) rc = a->precision == BMT_PREC_F16W2 ? launch<2, 2, 1, false, false, 0, true>(p, splitk, st_) : launch<1, 2, 1, false, false, 0, true>(p, splitk, st_);
-        else if (akm && bkm) rc = launch<1, 2, 1, true, true>(p, splitk, st_);
-        else if (bkm) rc = launch<1, 2, 1, false, true>(p, splitk, st_);
-        else rc = launch<1, 2, 1, true, false>(p, splitk, st_);
-    } else if (p.pipe == 3) {
+    // (the register-staged kernels run 8 waves of 32 x 64 on a 128-row tile: four waves per SIMD across two workgroups hide the stage
+    // loop's LDS / barrier latency better than 4 waves of 64 x 64 did -- whole step -6 % in round 1)
+    if (p.pipe == 3) {
         rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
     } else if (p.pipe == 4) {
         rc = f16 ? launch_k128<true>(p, st_) : launch_k128<false>(p, st_);
-    } else if (a->conv_mode == 1 && conv_pipe >= 3 && a->precision == BMT_PREC_BF16 && p.bm == 256 && !akm && !bkm) {      // (the dX products: A/B)
-        rc = launch_pipe<1, false, 2, false, false, 1>(p, splitk, st_);
-    } else if (a->conv_mode == 1 && conv_pipe && f16) {      // the Conv1d forward products through the LDS-DMA ring: 128-row tile (two workgroups per CU) / 256-row tile
+    } else if (a->conv_mode == 1 && f16) {      // the Conv1d forward through the LDS-DMA ring (the A rows shift by a tap per step: one scalar offset)
         if (p.bm == 256) rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 2, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 2, false, false, 1>(p, splitk, st_);
         else rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);
-    } else if (p.pipe == 1 && bkm && !akm) {      // dX on the pipelined 256 x 128 tile (gemm_prepare: BMT_DX_PIPE)
-        rc = launch_pipe<1, false, 2, false, true>(p, splitk, st_);
     } else if (p.pipe == 1) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 2>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 2>(p, splitk, st_);
@@ -2099,25 +1781,21 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         if (a->precision == BMT_PREC_F16W2) rc = launch_pipe<2, true, 1>(p, splitk, st_);
         else if (a->precision == BMT_PREC_F16) rc = launch_pipe<1, true, 1>(p, splitk, st_);
         else rc = launch_pipe<1, false, 1>(p, splitk, st_);
-    } else if (a->conv_mode == 1) {          // implicit Conv1d forward / dX: 8-wave 128-row tiles
-        if (a->precision == BMT_PREC_F16W2) rc = launch<2, 4, 1, false, false, 1, true>(p, splitk, st_);
-        else if (a->precision == BMT_PREC_F16) rc = launch<1, 4, 1, false, false, 1, true>(p, splitk, st_);
-        else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1, false, false, 1>(p, splitk, st_) : launch<1, 4, 1, false, false, 1>(p, splitk, st_);
-    } else if (f16) {                 // fp16 forward policy: 8-wave 128-row tiles
-        rc = a->precision == BMT_PREC_F16W2 ? launch<2, 4, 1, false, false, 0, true>(p, splitk, st_) : launch<1, 4, 1, false, false, 0, true>(p, splitk, st_);
-    } else if (a->conv_mode == 2) {   // implicit Conv1d dW
+    } else if (a->conv_mode == 1) {          // implicit Conv1d forward (split-bf16) / dX
+        rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1, false, false, 1>(p, splitk, st_) : launch<1, 4, 1, false, false, 1>(p, splitk, st_);
+    } else if (a->conv_mode == 2) {          // implicit Conv1d dW
         rc = launch<1, 4, 1, true, true, 2>(p, splitk, st_);
-    } else if ((akm || bkm) && km_pipe) {    // k-major operands through the LDS-DMA ring (swizzled images, transpose reads)
-        if (akm && bkm) rc = launch_pipe<1, false, 1, true, true>(p, splitk, st_);
-        else if (bkm) rc = launch_pipe<1, false, 1, false, true>(p, splitk, st_);
-        else rc = launch_pipe<1, false, 1, true, false>(p, splitk, st_);
-    } else if (akm || bkm) {                 // single-pass kernel, 128-row tiles
-        if (akm && bkm) rc = waves8 ? launch<1, 4, 1, true, true>(p, splitk, st_) : launch<1, 2, 2, true, true>(p, splitk, st_);
-        else if (bkm) rc = waves8 ? launch<1, 4, 1, false, true>(p, splitk, st_) : launch<1, 2, 2, false, true>(p, splitk, st_);
-        else rc = waves8 ? launch<1, 4, 1, true, false>(p, splitk, st_) : launch<1, 2, 2, true, false>(p, splitk, st_);
-    } else if (p.bm == 256) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 2>(p, splitk, st_) : launch<1, 4, 2>(p, splitk, st_);
-    else if (waves8) rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 4, 1>(p, splitk, st_) : launch<1, 4, 1>(p, splitk, st_);
-    else rc = a->precision == BMT_PREC_BF16X3 ? launch<3, 2, 2>(p, splitk, st_) : launch<1, 2, 2>(p, splitk, st_);
+    } else if (akm || bkm) {                 // k-major operands: the register-staged loop with its two tiles of prefetch (the LDS-DMA ring has room
+                                             // for two stages only at two workgroups per CU and lost: dX class 1.74 -> 2.06 ms, round 3)
+        if (akm && bkm) rc = launch<1, 4, 1, true, true>(p, splitk, st_);
+        else if (bkm) rc = launch<1, 4, 1, false, true>(p, splitk, st_);
+        else rc = launch<1, 4, 1, true, false>(p, splitk, st_);
+    } else if (a->precision == BMT_PREC_BF16X3) {
+        rc = launch<3, 4, 1>(p, splitk, st_);
+    } else {
+        bmt_set_error("bmt_gemm_bf16: no kernel for this operand combination");
+        return BMT_EINVAL;
+    }
     if (rc != BMT_OK || p.ws == nullptr) return rc;
     const int pc = p.Chi ? (p.plane_cols > p.N ? p.plane_cols : p.N) : p.N;
     const int64_t groups = (int64_t)p.M * ((pc + 3) / 4);
@@ -2168,7 +1846,7 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     // unsplit launch uses too (C += alpha A B is the only epilogue here)
     // measured (tools/gpu_ab.sh, whole step; PMC: the unsplit launch fetched 6 GB for ~1 GB of unique operands at 5.1 TB/s): chunks
     // of 16 / 32 / 64 / 100 / 134 / 200 stages -> 1.48 / 1.14 / 1.02 / 1.02 / 1.06 / 1.05 ms against 1.235 ms unsplit
-    static const int chunk = getenv("BMT_GROUPED_CHUNK") ? atoi(getenv("BMT_GROUPED_CHUNK")) : 64;     // A/B experiments only
+    constexpr int chunk = 64;
     Prob* pr = (Prob*)malloc(sizeof(Prob) * (size_t)nprob);
     int* order = (int*)malloc(sizeof(int) * (size_t)nprob);
     SegPack* sp = (SegPack*)malloc(sizeof(SegPack) * 4);
@@ -2207,7 +1885,6 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     }
     // pack onto the 8 XCDs: a problem goes to the least loaded XCD; one that is more than ~60 % of an XCD's fair share is cut
     // into 2, 4 or 8 contiguous tile ranges first (placed independently)
-    static const int spread = getenv("BMT_GROUPED_SPREAD") ? atoi(getenv("BMT_GROUPED_SPREAD")) : 0;       // A/B: every problem over all 8 XCDs
     double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double share = total_work / 8.0;
@@ -2216,15 +1893,13 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         const int i = order[oi];
         int parts = 1;
         while (parts < 8 && work(i) / parts > 0.6 * share) parts *= 2;
-        if (spread) parts = 8;
         if (parts > pr[i].tiles) parts = 1;
         const int per = (pr[i].tiles + parts - 1) / parts;
         for (int part = 0; part < parts; ++part) {
             const int t0 = part * per, cnt = (t0 + per <= pr[i].tiles) ? per : pr[i].tiles - t0;
             if (cnt <= 0) break;
             int x = 0;
-            if (spread) x = part;
-            else for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+            for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
             if (ns[x] >= XCD_MAXSEG) { overflow = true; break; }
             XcdSeg& sg = sp[x / 2].s[x & 1][ns[x]++];
             sg.first_slot = slots[x]; sg.prob = i; sg.tile_off = t0; sg.count = cnt; sg.nsplit = pr[i].nsplit;
@@ -2256,19 +1931,6 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     free(sp);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(table)");
     constexpr int BK = 64, BMr = 128;
-    static const int km_pipe = getenv("BMT_GEMM_KM_PIPE") ? atoi(getenv("BMT_GEMM_KM_PIPE")) : 0;      // A/B experiments only (see bmt_gemm_bf16)
-    if (km_pipe) {                   // the LDS-DMA ring on swizzled k-major images
-        constexpr int stage_p = (BMr + BN) * BK * 2;
-        constexpr int lds_p = pipe_ring(stage_p, 1) * stage_p;
-        static bool done_p = false;
-        if (!done_p) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 4, 1, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_p);
-            done_p = true;
-        }
-        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true, true>), dim3(8 * max_slots), dim3(512), lds_p, st, table, segs, nseg);
-        BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped");
-        return BMT_OK;
-    }
     constexpr int stage = BK * km_rs<BMr>() + BK * km_rs<BN>();
     constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;
     static bool done = false;
@@ -2584,7 +2246,11 @@ extern "C" int bmt_conv_weight_planes(const float* W, int N, int C, int k, int c
                   "bmt_conv_weight_planes: bad args (cin_pad a multiple of 64 >= C, ldp >= k * cin_pad, k <= 600)");
     BMT_CHECK_ARG((!lo || hi) && (!fl || fh), "bmt_conv_weight_planes: a lo plane without its hi plane");
     const size_t lds = (size_t)64 * (k + 1) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)conv_weight_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)conv_weight_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        bmt_set_error("conv weight re-layout: %zu bytes of LDS per workgroup for k = %d taps are more than this device offers", lds, k);
+        return BMT_EINVAL;
+    }
     hipLaunchKernelGGL(conv_weight_kernel<true>, dim3(N, cin_pad / 64), dim3(256), lds, (hipStream_t)stream, const_cast<float*>(W), N, C, k, cin_pad, hi, lo,
                        fh, fl, ldp, nullptr, 0);
     BMT_CHECK_LAUNCH("bmt_conv_weight_planes");
@@ -2595,7 +2261,11 @@ extern "C" int bmt_conv_weight_grad(const float* dWp, int64_t ldw, int N, int C,
     BMT_CHECK_ARG(dWp && grad && N > 0 && C > 0 && k > 0 && cin_pad >= C && cin_pad % 64 == 0 && ldw >= (int64_t)k * cin_pad && k <= 600,
                   "bmt_conv_weight_grad: bad args");
     const size_t lds = (size_t)64 * (k + 1) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)conv_weight_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)conv_weight_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        bmt_set_error("conv weight re-layout: %zu bytes of LDS per workgroup for k = %d taps are more than this device offers", lds, k);
+        return BMT_EINVAL;
+    }
     hipLaunchKernelGGL(conv_weight_kernel<false>, dim3(N, cin_pad / 64), dim3(256), lds, (hipStream_t)stream, grad, N, C, k, cin_pad, nullptr, nullptr,
                        nullptr, nullptr, 0, const_cast<float*>(dWp), ldw);
     BMT_CHECK_LAUNCH("bmt_conv_weight_grad");

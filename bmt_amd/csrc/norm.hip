@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
 
 // rows each wave sweeps: sized so that a launch has ~512 workgroups (2 per CU); runtime parameter
 static int ln_bwd_rows_per_wave(int rows) {
-    static const int waves = getenv("BMT_LN_BWD_WAVES") ? atoi(getenv("BMT_LN_BWD_WAVES")) : 4096;      // waves a launch aims for: 4096 = 1024 workgroups (measured: 2048 / 4096 / 8192 -> 8.49-8.50 / 8.44-8.45 / 8.52-8.54 ms per step, profiles/r04_q_ab_ln.txt)
+    const int waves = 4096;      // waves a launch aims for: 4096 = 1024 workgroups (measured: 2048 / 4096 / 8192 -> 8.49-8.50 / 8.44-8.45 / 8.52-8.54 ms per step, profiles/r04_q_ab_ln.txt)
     const int w = waves < 256 ? 256 : waves;
     const int r = (rows + w - 1) / w;
     return r < 1 ? 1 : r;
@@ -352,9 +352,8 @@ extern "C" int bmt_layernorm_fwd_planes(const float* x, int64_t ldx, const float
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (!y || (ldy % 4 == 0 && al16(y))) && al16(x) && al16(gamma) && al16(beta) &&
                      (!hi || ((ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0));
     dim3 grid(bmt_cdiv(rows, 4)), block(256);
-    static const int reg_env = getenv("BMT_LN_FWD_REG") ? atoi(getenv("BMT_LN_FWD_REG")) : 1;      // A/B: 0 = the three-read kernel
 #define BMT_LNF(NV) hipLaunchKernelGGL(ln_fwd_reg_kernel<NV>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, hi, lo, ldp, pcols, lo_f16, rows_dev)
-    if (vec && reg_env && D <= 2048) {
+    if (vec && D <= 2048) {
         const int nv = bmt_cdiv(D, 256);
         if (nv <= 1) BMT_LNF(1);
         else if (nv <= 2) BMT_LNF(2);

@@ -111,7 +111,7 @@ extern "C" int bmt_adam_step(void* const* ptrs, const int64_t* sizes, int n_tens
     BMT_CHECK_ARG(ptrs && sizes && step_dev && n_tensors > 0 && n_tensors <= 65535 && max_size > 0, "bmt_adam_step: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, st, step_dev);
-    static const int vec = getenv("BMT_ADAM_VEC") ? atoi(getenv("BMT_ADAM_VEC")) : 1;      // A/B: 0 = one element per thread and instruction
+    const int vec = 1;      // four elements per thread and instruction wherever the tensor allows (0: one)
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(max_size), n_tensors), dim3(256), 0, st, ptrs, sizes, n_tensors, step_dev, lr, beta1,
                        beta2, eps, weight_decay, grad_scale_dev, vec);
     BMT_CHECK_LAUNCH("bmt_adam_step");

@@ -263,7 +263,7 @@ extern "C" int bmt_prop_decode_loss(const float* x, const float* anchors, int B,
         bmt_set_error("bmt_prop_decode_loss: memset failed");
         return BMT_EHIP;
     }
-    static const int tiled = getenv("BMT_PROP_TILED") ? atoi(getenv("BMT_PROP_TILED")) : 1;      // A/B experiments only
+    const bool tiled = true;      // (the element-per-thread kernels serve head shapes whose tile does not fit the LDS)
     const size_t lds = (size_t)PROP_TS * (A * 3 + 1) * sizeof(float);
     if (tiled && lds <= 60 * 1024 && B <= 65535)
         hipLaunchKernelGGL(decode_loss_tiled_kernel, dim3(bmt_cdiv(S, PROP_TS), B), dim3(256), lds, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds,
@@ -285,7 +285,7 @@ extern "C" int bmt_prop_loss_bwd(const float* x, int B, int S, int A, const uint
                                  const float* tw, const float* loss_ws, float obj_coeff, float noobj_coeff, const float* gscale_dev,
                                  float* dx, void* stream) {
     BMT_CHECK_ARG(x && obj && noobj && tx && tw && loss_ws && gscale_dev && dx && B > 0 && S > 0 && A > 0, "bmt_prop_loss_bwd: bad args");
-    static const int tiled = getenv("BMT_PROP_TILED") ? atoi(getenv("BMT_PROP_TILED")) : 1;      // A/B experiments only
+    const bool tiled = true;      // (the element-per-thread kernels serve head shapes whose tile does not fit the LDS)
     const size_t lds = (size_t)PROP_TS * (A * 3 + 1) * sizeof(float);
     if (tiled && lds <= 60 * 1024 && B <= 65535)
         hipLaunchKernelGGL(loss_bwd_tiled_kernel, dim3(bmt_cdiv(S, PROP_TS), B), dim3(256), lds, (hipStream_t)stream, x, B, S, A, obj, noobj, tx, tw, loss_ws,

@@ -196,17 +196,6 @@ class BiModalTransformer(nn.Module):
         """caption prefix + encoder memory -> decoder states (B, Sc, Dc)  (reference :172-173,182-184)"""
         return self.decoder((self.embed_caption(trg), memory), masks)
 
-    def _encode_staged(self, src, masks, packs=None):
-        """encode() between the two events of a batch that is stepped in parts (ops.StepContext.enc_gate / enc_done, set by
-        train.CaptioningTrainStep): this part's encoder waits for the previous part's, and says when its own has been issued"""
-        ctx = ops.context() if next(iter(src.values())).is_cuda else None
-        if ctx is not None and ctx.enc_gate is not None:
-            torch.cuda.current_stream().wait_event(ctx.enc_gate)
-        memory = self.encode(src, masks, packs)
-        if ctx is not None and ctx.mark_enc:
-            ctx.enc_done = torch.cuda.current_stream().record_event()
-        return memory
-
     def forward(self, src: dict, trg, masks: dict):
         if self.training:
             ops.rng_advance()   # every forward pass draws fresh dropout masks, as nn.Dropout does
@@ -215,7 +204,7 @@ class BiModalTransformer(nn.Module):
         packs = self.row_packs(src, masks)
         s3 = ops.fork_side_stream(1) if (trg.is_cuda and hasattr(self.decoder, "decoder")) else None
         if s3 is None:
-            memory = self._encode_staged(src, masks, packs)
+            memory = self.encode(src, masks, packs)
             C = self.decode(trg, memory, masks)
             return self.generator(C)
         s1 = torch.cuda.current_stream()
@@ -224,7 +213,7 @@ class BiModalTransformer(nn.Module):
             t.record_stream(s3)
         with torch.cuda.stream(s3):
             C = first.self_attention_sublayer(self.embed_caption(trg), masks['C_mask'])
-        memory = self._encode_staged(src, masks, packs)
+        memory = self.encode(src, masks, packs)
         s1.wait_stream(s3)
         C.record_stream(s1)
         C._bmt_self_att_done = True

@@ -111,31 +111,11 @@ class BiModelDecoder(nn.Module):
         self.decoder = LayerStack(layer, N)
 
     def forward(self, x, masks):
-        # the K / V projections of the two memories for every layer depend on the encoder only: issued on the side stream now, beside
-        # the first layer's self-attention (ops.prefetch_kv); not while a greedy decode keeps its own cache of them
         C0, (Av, Va) = x
-        s4 = None
-        mems = None
         if Av.is_cuda and torch.is_grad_enabled() and len(self.decoder.layers) > 1 and ops.context().kv_cache is None:
-            mems = _LayerMemories(Av, Va, len(self.decoder.layers))
-            x = (C0, mems)
-        if Av.is_cuda and ops.KV_PREFETCH and ops.context().kv_cache is None:
-            s4 = ops.fork_side_stream(3, need=2)       # its own stream: a layer's video attention must not queue behind the next layer's projections
-            if s4 is not None:
-                for t in (Av, Va):
-                    t.record_stream(s4)
-                with torch.cuda.stream(s4):
-                    for i, layer in enumerate(self.decoder.layers):
-                        # (the tensors layer i will be handed: its alias pair of the memories when the stack threads them through ops.fanout)
-                        Ai, Vi = mems._pairs[i] if (mems is not None and i < len(mems._pairs)) else (Av, Va)
-                        layer.enc_att_V.prefetch_kv(Vi)
-                        layer.enc_att_A.prefetch_kv(Ai)
-        try:
-            C, memory = self.decoder(x, masks)
-        finally:
-            ops.drop_prefetched_kv()
-            if s4 is not None:
-                torch.cuda.current_stream().wait_stream(s4)
+            # one alias pair of the memories per layer: the layers' gradients w.r.t. a memory are added by library launches in one node
+            x = (C0, _LayerMemories(Av, Va, len(self.decoder.layers)))
+        C, memory = self.decoder(x, masks)
         if C.is_cuda:
             ops.end_of_forward()
         return C

@@ -68,14 +68,14 @@ class BiModalEncoderLayer(nn.Module):
 
 
     def _forward_two_streams(self, M1, M2, M1_mask, M2_mask, s2):
-        """the same operations with one modality's chain issued on the side stream (ops.SIDE_CHAIN_AUDIO: which): the chains meet only
+        """the same operations with the VIDEO chain issued on the side stream: the chains meet only
         where a cross-modal attention reads the other modality's post-self-attention value (events), and the side chain runs on from
         layer to layer without joining"""
         from types import SimpleNamespace as NS
         s1 = torch.cuda.current_stream()
         a = NS(x=M1, mask=M1_mask, res=self.res_layers_M1, self_att=self.self_att_M1, cross=self.bi_modal_att_M1, ffn=self.feed_forward_M1)
         v = NS(x=M2, mask=M2_mask, res=self.res_layers_M2, self_att=self.self_att_M2, cross=self.bi_modal_att_M2, ffn=self.feed_forward_M2)
-        side, main = (a, v) if ops.SIDE_CHAIN_AUDIO else (v, a)
+        side, main = v, a
         kv_fmt = ops.act_fmt(ops.policy_of(self).kv_gemm)      # a self-attention's result is the other chain's key / value input
         # (a chain's post-self-attention value has three consumers -- residual, LayerNorm, the OTHER chain's key / value projections: prenorm
         # ties them to one autograd node, whose backward kernel adds the three gradients; x1kv is x1 for the other chain)

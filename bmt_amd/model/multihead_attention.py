@@ -63,11 +63,6 @@ class MultiheadedAttention(nn.Module):
 
         assert self.d_model % H == 0
 
-    def prefetch_kv(self, memory):
-        """the key / value projections of ``memory`` for a later forward(Q, memory, memory, mask), on the current stream (ops.prefetch_kv)"""
-        return ops.prefetch_kv(memory, self.linear_K2d.weight, self.linear_K2d.bias, self.linear_V2d.weight, self.linear_V2d.bias,
-                               ops.policy_of(self), self.H)
-
     def forward(self, Q, K, V, mask):
         ''' Q, K, V: (B, Sq, Dq), (B, Sk, Dk), (B, Sv, Dv); mask: (B, 1, Sk) or (B, Sq, Sk) '''
         p = self.dout_p if self.training else 0.0

@@ -64,21 +64,20 @@ POLICIES = {
     # ... of an encoder of at most two layers (configs[0], [1], [3]: model/encoders.py tags by depth): FFN-2 on one fp16 plane.  The rounding
     # of the weight it admits accumulates with depth -- fine at N = 2 (log-probs 3.8e-4 against 3.7e-4 on the mid fixture), over the bar at the
     # six layers of configs[4] (see above), which keep two planes everywhere
-    "enc_shallow": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc_shallow", ffn2=PREC_F16 if _os.environ.get("BMT_FFN2_TWO_PLANES") != "1" else None,
-                          ffn1=PREC_F16 if _os.environ.get("BMT_FFN1_ONE_PLANE") == "1" else None),
-    # bi-modal decoder layers (BMT_DEC_GEMM=w2: their own GEMMs on fp16 x split-fp16, two passes -- an A/B switch; measured in round 4:
-    # see DESIGN.md section 6)
-    "dec": Policy(PREC_F16W2 if _os.environ.get("BMT_DEC_GEMM") == "w2" else PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),
+    "enc_shallow": Policy(PREC_F16W2, PREC_F16W2, PREC_F16, "enc_shallow", ffn2=PREC_F16),
+    # bi-modal decoder layers: their own GEMMs split-bf16 (fp16 x split-fp16 there leaves the 1e-3 bar: 9.3e-4 / 9.4e-4 on the mid fixture
+    # and configs[0], round 4), the key / value projections of the long encoder memories as the encoder's
+    "dec": Policy(PREC_BF16X3, PREC_F16W2, PREC_F16, "dec"),
     # Conv1d stacks of the proposal heads: split-bf16.  (fp16 activation x split weight leaves 6-8e-4 abs on the head outputs,
     # tests/test_gpu_proposal.py at round 2: inside the 1e-3 bar but with < 2x margin, and exp() turns it into 1e-3 relative on
     # the predicted lengths.)
     "head": Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "head"),
     # ... except a head's FIRST layer, the k-tap Conv1d (k up to 211 taps over 1024 channels: 90 % of a head's FLOPs, the dominant class of
     # train_prop): fp16 activation x split fp16 weight, two MFMA passes instead of three.  The 1 x 1 layers behind it -- directly under the
-    # sigmoid / exp of the predictions -- stay split-bf16.  BMT_HEAD_CONV=x3 restores three passes (A/B; tests/test_gpu_proposal.py holds the
-    # predictions to 1e-3 either way)
-    "head_conv": Policy(PREC_F16W2 if _os.environ.get("BMT_HEAD_CONV", "w2") != "x3" else PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "head_conv"),
-    None: Policy(PREC_F16W2 if _os.environ.get("BMT_X_GEMM") == "w2" else PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
+    # sigmoid / exp of the predictions -- stay split-bf16 (model/proposal_generator.py tags the heads by the encoder's depth: under a deep
+    # encoder the k-tap layer keeps three passes too)
+    "head_conv": Policy(PREC_F16W2, PREC_BF16X3, PREC_BF16X3, "head_conv"),
+    None: Policy(PREC_BF16X3, PREC_BF16X3, PREC_BF16X3, "x3"),    # everything else: bridge, generator, embedders, uni-modal models
 }
 _OVERRIDE = [None]      # a Policy applied to EVERY site (A/B measurements, tests), or None
 
@@ -150,8 +149,7 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
-                 "rng", "enc_gate", "enc_done", "mark_enc")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
@@ -165,11 +163,6 @@ class StepContext:
         self.allow_streams = True    # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
         self.last_gen = None         # GenHandle of the GeneratorFn.forward that just ran (picked up by model.generators.Generator)
         self.gen_handles = []        # handles whose loss took the fused backward: flush_dw settles their parameters' use counts
-        # a batch stepped in parts that are in flight together (train.CaptioningTrainStep(microbatches=...)): every part runs under its own context
-        self.rng = None              # this part's {seed, step} pair (bmt_rng_derive); None = the device's
-        self.enc_gate = None         # event the part's encoder forward waits for (the previous part's encoder forward: staggering)
-        self.mark_enc = False        # record ...
-        self.enc_done = None         # ... the event "this part's encoder forward has been issued" here
 
 
 _contexts = {}
@@ -194,9 +187,7 @@ def context() -> StepContext:
 # under hipGraph capture, where the fork becomes parallel branches of the graph).  What is per pass stays per pass: the side stream
 # is an alias of the main stream's StepContext (queued weight gradients and small reductions are flushed once, on the main stream,
 # after autograd has joined the streams); what is per stream is already keyed by stream (split-K and grouped-GEMM scratch).
-ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "2"))     # A/B switch: 1 = everything on one stream
-SIDE_CHAIN_AUDIO = _os.environ.get("BMT_SIDE_CHAIN", "video") == "audio"     # A/B: which modality's chain runs on the side stream
-SIDE_PRIORITY = int(_os.environ.get("BMT_SIDE_PRIORITY", "0"))     # A/B: -1 = the video chain's stream at high priority
+ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "2"))     # switch: 1 = everything on one stream (the profilers' and the kernel timer's eager steps)
 _side_streams = {}
 
 
@@ -207,17 +198,16 @@ def side_stream(index: int = 0, main=None) -> "torch.cuda.Stream":
     key = (main.device.index, main.cuda_stream, index)
     s = _side_streams.get(key)
     if s is None:
-        s = _side_streams[key] = torch.cuda.Stream(device=main.device, priority=SIDE_PRIORITY if index == 0 else 0)
+        s = _side_streams[key] = torch.cuda.Stream(device=main.device)
     return s
 
 
-def fork_side_stream(index: int = 0, need: int = 0):
+def fork_side_stream(index: int = 0):
     """side stream ordered after everything issued so far on the current stream, sharing its StepContext; None when two streams are
     switched off.  The weight planes are refreshed first: a branch must not find them half-way through the once-per-step refresh that
     the other branch's first GEMM triggered.  index 0: the encoder's video chain / a decoder layer's video attention; 1: the decoder's
-    first self-attention sublayer, which does not depend on the encoder (model/captioning_module.py); 3: the decoder's K / V
-    projections of the encoder memories (ops.prefetch_kv; ``need`` = the BMT_ENC_STREAMS level that switches a use on)."""
-    if ENC_STREAMS < (need or 2 + index) or not context().allow_streams:
+    first self-attention sublayer, which does not depend on the encoder (model/captioning_module.py)."""
+    if ENC_STREAMS < 2 + index or not context().allow_streams:
         return None
     with _weights.lock:
         _weights.ensure_fresh()
@@ -228,45 +218,8 @@ def fork_side_stream(index: int = 0, need: int = 0):
         return None
     s2 = side_stream(index, main)
     _ctx_alias[(dev, s2.cuda_stream)] = (dev, main.cuda_stream)
-    if index == 0:
-        _fork_main[(dev, main.cuda_stream)] = main
     s2.wait_stream(main)
     return s2
-
-
-EARLY_DW = _os.environ.get("BMT_EARLY_DW") == "1"      # A/B switch for flush_dw_early: off (measured 9.27-9.36 vs 8.99 ms/step same box: three
-                                                      # smaller grouped launches that share the GPU with the backward cost more than the lone one)
-_fork_main = {}           # (device, main stream handle) -> the stream object a two-stream encoder pass was forked from
-
-
-def flush_dw_early() -> bool:
-    """issue what is queued so far (weight-gradient products, small reductions) on a THIRD stream, behind everything the two compute
-    streams have been given up to now: called from the backward pass at the encoder-layer boundaries (train.py), so that the grouped
-    launch of the layers already differentiated runs beside the backward of the remaining ones instead of alone at the end.  The
-    operands are recorded on that stream (the caching allocator must not hand them to a later allocation of their own stream while
-    the launch is pending)."""
-    if not EARLY_DW or ENC_STREAMS < 2 or not context().allow_streams:
-        return False
-    dev = torch.cuda.current_device()
-    cur = torch.cuda.current_stream().cuda_stream
-    main = _fork_main.get(_ctx_alias.get((dev, cur), (dev, cur)))
-    ctx = context()
-    if main is None or not ctx.defer_dw or not (ctx.pending_dw or ctx.pending_cs):
-        return False
-    s3 = side_stream(2, main)
-    _ctx_alias[(dev, s3.cuda_stream)] = (dev, main.cuda_stream)
-    s3.wait_stream(main)
-    s3.wait_stream(side_stream(0, main))
-    for dyT, xT, _ in ctx.pending_dw:
-        for pl in (dyT, xT):
-            for t in (pl.hi, pl.lo, pl.fh, pl.fl):
-                if t is not None:
-                    t.record_stream(s3)
-    for it in ctx.pending_cs:
-        it[0].record_stream(s3)
-    with torch.cuda.stream(s3):
-        flush_dw()
-    return True
 
 
 def join_side_stream(release: bool = True):
@@ -289,7 +242,6 @@ def release_side_streams(main=None):
     mkey = (main.device.index, main.cuda_stream)
     for k in [k for k, v in _ctx_alias.items() if v == mkey]:
         _ctx_alias.pop(k, None)
-    _fork_main.pop(mkey, None)
 
 
 def end_of_forward():
@@ -316,10 +268,6 @@ _site_counter = [0]
 
 def rng_tensor(device=None) -> torch.Tensor:
     """Per-device {seed, step} pair read by every dropout site (device memory => graph-replayable)."""
-    if device is None and _contexts:
-        r = context().rng
-        if r is not None:
-            return r
     dev = None if device is None else torch.device(device)
     if dev is None or dev.type != "cuda":
         # the dropout stream lives in GPU memory: a host device (a CPU-resident model on its way into a checkpoint) names the current GPU's
@@ -347,17 +295,8 @@ def rng_is_seeded(device=None) -> bool:
 
 
 def rng_advance():
-    """a new forward pass draws new masks.  (Not for a part of a batch: its stream is re-derived from the device's once per step.)"""
-    if _contexts and context().rng is not None:
-        return
+    """a new forward pass draws new masks"""
     _lib.check(lib.bmt_rng_advance(_p(rng_tensor()), _st()), "bmt_rng_advance")
-
-
-def rng_derive(out: torch.Tensor, salt: int) -> torch.Tensor:
-    """out (int64[2], CUDA) = the device's dropout stream with the seed of part ``salt`` (bmt_rng_derive); issued on the current stream"""
-    base = rng_tensor(out.device)
-    _lib.check(lib.bmt_rng_derive(_p(base), _p(out), int(salt), _st()), "bmt_rng_derive")
-    return out
 
 
 def add_(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -381,7 +320,7 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-_SPLITK_TARGET = int(_os.environ.get("BMT_SPLITK_TARGET", "512"))     # workgroups a split launch aims for (A/B experiments)
+_SPLITK_TARGET = 512     # workgroups a split launch aims for
 
 
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
@@ -553,9 +492,6 @@ def pad_planes(x3: torch.Tensor, halo: int, tail: int, fmt: str) -> Planes:
     return pl
 
 
-PLANES_FLAT = _os.environ.get("BMT_PLANES_FLAT", "1") != "0"      # A/B switch: "0" = 64 workgroups per tensor (bmt_planes_multi)
-
-
 class _WeightPlanes:
     """operand planes of every weight that takes part in a GEMM ([N][pad64(K)], the plane set its site's precision needs), in
     persistent buffers, ALL refreshed by one multi-tensor launch the first time a weight is needed after the optimizer moved
@@ -563,7 +499,7 @@ class _WeightPlanes:
     copy of a weight exists."""
 
     def __init__(self):
-        self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W, transposed bf16 plane [K][ldT] or None]
+        self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W]
         self.index = {}            # (id(owner), key) -> position
         self.table = None          # device descriptor table
         self.prefix, self.total_tiles = None, 0      # prefix sums of the tensors' tile counts (the flat launch)
@@ -571,7 +507,7 @@ class _WeightPlanes:
         self.generation = 0        # bumped when an entry a captured graph may use is replaced or dropped (its planes can be freed then)
         self.fresh_epoch = -1
         self.dirty_table = True
-        self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt, transposed plane [K][sum N] or None]
+        self.groups = {}           # ids -> [weakrefs, Planes [sum N][Kpad], bias, epoch, fmt, (unused), weakrefs of the biases]
         self.lock = __import__("threading").RLock()      # the registry is shared by every stream / thread of the process
 
     @staticmethod
@@ -581,11 +517,9 @@ class _WeightPlanes:
     def _put(self, W, pl, fmt):
         import weakref
         owner = W._base if W._base is not None else W
-        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach(), None]
+        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach()]
         pos = self.index.get((id(owner), self._key(W)))
         if pos is not None and pos < len(self.entries) and self.entries[pos][0]() is owner:
-            if self.entries[pos][2].any._base is None and pl.any._base is None:
-                entry[6] = self.entries[pos][6]    # a wider plane set of the same stand-alone weight keeps its transposed plane
             self.entries[pos] = entry          # re-registered (a new plane set, or now as a member of a group): same slot
             self.generation += 1               # the old planes may be freed: graphs captured over them must not be replayed
         else:
@@ -657,7 +591,7 @@ class _WeightPlanes:
                 Wd, pl = e[5], e[2]
                 _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
                                                _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0),
-                                               _p(e[6]), None, e[6].stride(0) if e[6] is not None else 0),
+                                               None, None, 0),
                            "bmt_planes_desc")
             if self.table is not None:
                 self._retired.append((self.table, self.prefix))       # (a few KB each; appended entries leave the old table valid for its graph)
@@ -669,10 +603,7 @@ class _WeightPlanes:
             self.prefix = torch.tensor(pre, dtype=torch.int32).to(dev)
             self.total_tiles = pre[-1]
             self.dirty_table = False
-        if PLANES_FLAT:
-            _lib.check(lib.bmt_planes_multi_flat(_p(self.table), _p(self.prefix), len(self.entries), self.total_tiles, _st()), "bmt_planes_multi_flat")
-        else:
-            _lib.check(lib.bmt_planes_multi(_p(self.table), len(self.entries), _st()), "bmt_planes_multi")
+        _lib.check(lib.bmt_planes_multi_flat(_p(self.table), _p(self.prefix), len(self.entries), self.total_tiles, _st()), "bmt_planes_multi_flat")
         for e in self.entries:
             e[4] = e[5]._version
         self.fresh_epoch = WEIGHT_EPOCH[0]
@@ -699,45 +630,6 @@ class _WeightPlanes:
             _lib.check(lib.bmt_copy_multi(arr, len(items), _st()), "bmt_copy_multi")
             for g in touched:
                 g[3] = WEIGHT_EPOCH[0]
-
-    def get_t(self, W):
-        """the transposed bf16 plane [K][pad64(N)] of a stand-alone weight [N][K]: the row-major B operand of dX = dY . W"""
-        e = self._entry(W)
-        if e is None or e[2].hi is None:
-            self.get(W, "bwd")
-            e = self._entry(W)
-        if e[2].any._base is not None:
-            raise RuntimeError("weight planes: a member of a fused projection group was asked for its transposed plane on its own")
-        if e[6] is None:
-            N, K = W.shape
-            e[6] = torch.zeros(K, _pad64(N), device=W.device, dtype=torch.bfloat16)
-            self.dirty_table = True
-        if self.fresh_epoch != WEIGHT_EPOCH[0] or e[4] != W._version or self.dirty_table:
-            self._refresh_all()
-        return Planes(e[6], None, W.shape[1], W.shape[0])
-
-    def get_group_t(self, Ws):
-        """[K][sum N]: the transposed plane of a fused projection group (every member writes its column block)"""
-        key = tuple(id(W) for W in Ws)
-        g = self.groups.get(key)
-        if g is None or any(r() is not W for r, W in zip(g[0], Ws)) or g[1].hi is None:
-            self.get_group(Ws, tuple(None for _ in Ws), "bwd")
-            g = self.groups[key]
-        if g[5] is None:
-            K, Nt = Ws[0].shape[1], sum(W.shape[0] for W in Ws)
-            g[5] = torch.zeros(K, Nt, device=Ws[0].device, dtype=torch.bfloat16)
-            off = 0
-            for W in Ws:
-                self._entry(W)[6] = g[5][:, off:off + W.shape[0]]
-                off += W.shape[0]
-            self.dirty_table = True
-        stale = self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table
-        if not stale:
-            for W in Ws:
-                stale = stale or self._entry(W)[4] != W._version
-        if stale:
-            self._refresh_all()
-        return Planes(g[5], None, Ws[0].shape[1], g[5].shape[1])
 
     def ensure_fresh(self):
         """the once-per-optimizer-step refresh of every registered weight's planes, now (on the current stream)"""
@@ -789,7 +681,7 @@ def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:
         return _weights.get(W, fmt)
 
 
-FUSE_PROJECTIONS = _os.environ.get("BMT_NO_FUSE") != "1"      # Q/K/V (self-attention) and K/V (cross-attention) projections as one GEMM each way
+FUSE_PROJECTIONS = True      # Q/K/V (self-attention) and K/V (cross-attention) projections as one GEMM each way
 
 
 def weight_group(Ws, bs, fmt: str = "x3"):
@@ -797,25 +689,6 @@ def weight_group(Ws, bs, fmt: str = "x3"):
         return None
     with _weights.lock:
         return _weights.get_group(tuple(Ws), tuple(bs), fmt)
-
-
-# dX = dY . W with W^T as a ROW-MAJOR operand (a transposed bf16 plane per weight, refreshed with the other planes once per step)
-# instead of W as stored, k-major through the transpose unit.  Alone the row-major pipelined kernel is faster (8192 x 1024 x 1024:
-# 31 vs 46 us), in the step it is not (same box, tools/gpu_ab.sh: bf16 GEMM class 1.93 vs 1.88 ms, +0.15 ms for the extra planes:
-# 11.91 vs 11.70 ms / step) -- the backward products with K = 1024 are bound by their epilogue traffic, not by the operand path.
-# Kept as an A/B switch (BMT_DX_ROWMAJOR=1).
-DX_ROW_MAJOR = _os.environ.get("BMT_DX_ROWMAJOR") == "1"
-DX_K128 = _os.environ.get("BMT_DX_K128") == "1"          # A/B switch (off: the k-major tile kernel is as fast on these -- bf16 GEMM class 1.74 vs 1.78 ms same box)
-
-
-def weight_planes_t(W: torch.Tensor) -> Planes:
-    with _weights.lock:
-        return _weights.get_t(W)
-
-
-def weight_group_t(Ws) -> Planes:
-    with _weights.lock:
-        return _weights.get_group_t(tuple(Ws))
 
 
 def group_static_grad(Ws):
@@ -864,7 +737,6 @@ def splitk_workspace(device):
 
 
 AUTO_SPLITK = True       # let the library split the reduction of GEMMs that cannot fill the chip
-DW_ATOMIC = _os.environ.get("BMT_DW_ATOMIC") == "1"     # A/B: weight gradients accumulate with fp32 atomics instead of workspace + epilogue
 
 
 def _operands(A: Planes, B: Planes, prec: int):
@@ -982,15 +854,8 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     A = as_planes(dy, "bwd")
     if out is None and epi.get("out_planes") is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
-    e = _weights._entry(W)
-    # a reduction of 128 over many rows (dX through the audio stream's out-projections, W [128][1024]): the transposed plane [1024][128] is
-    # 256 KB and takes the product to the weight-chunk-resident kernel (gemm_k128_kernel) instead of the k-major tile kernel
-    k128 = (DX_K128 and W.dim() == 2 and _pad64(W.shape[0]) == 128 and W.shape[1] % 8 == 0 and A.rows >= 2048 and epi.get("colsum") is None
-            and (e is None or e[2].any._base is None))
-    if (DX_ROW_MAJOR or k128) and W.dim() == 2 and (e is None or e[2].any._base is None):
-        gemm_bf16(A, weight_planes_t(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, **epi)
-    else:
-        gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
+    # (row-major dX through transposed weight planes was measured three times -- rounds 2, 3, 4 -- and never won in the step: DESIGN.md section 6)
+    gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
     return out if out is not None else epi["out_planes"]
 
 
@@ -1000,8 +865,7 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
 # queues them (DEFER_DW) and ``flush_dw`` issues ONE launch over all of them.  Alone a 1024 x 1024 weight is 64 tiles -- the single
 # launches split their reductions 8 ways and pay an epilogue kernel and the workspace traffic for it; together the step's ~50
 # weight gradients are ~3000 tiles and every reduction runs unsplit.
-GROUPED_DW = _os.environ.get("BMT_NO_GROUPED_DW") != "1"
-COLSUM_BESIDE_DW = _os.environ.get("BMT_COLSUM_BESIDE_DW", "0") == "1"      # A/B switch: the queued small reductions on the side stream, beside the grouped dW launch
+GROUPED_DW = True        # the queued weight-gradient products of a pass as one grouped launch
 _dw_ws = {}
 
 
@@ -1041,17 +905,6 @@ def flush_dw():
     done, ctx.pending_done = ctx.pending_done, []
     ctx.pending_ids.clear()
     cs, ctx.pending_cs = ctx.pending_cs, []
-    beside = None
-    if cs and items and len(items) > 1 and GROUPED_DW and COLSUM_BESIDE_DW and ENC_STREAMS >= 2 and ctx.allow_streams \
-            and (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream) not in _ctx_alias:
-        # the pass's small reductions (one launch, ~40 us of a few hundred workgroups) beside the grouped weight-gradient launch instead of
-        # behind it: different outputs (bias / LayerNorm gradients vs weight gradients), both read what the backward pass left
-        main = torch.cuda.current_stream()
-        beside = side_stream(0, main)
-        beside.wait_stream(main)
-        with torch.cuda.stream(beside):
-            _colsum_launch(cs)
-        cs = None
     if items:
         if len(items) == 1 or not GROUPED_DW:
             for dyT, xT, into in items:
@@ -1061,8 +914,6 @@ def flush_dw():
             gemm_bf16_grouped(items)
     if cs:
         _colsum_launch(cs)
-    if beside is not None:
-        torch.cuda.current_stream().wait_stream(beside)
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
         grad_done(p)
     hs, ctx.gen_handles = ctx.gen_handles, []
@@ -1070,9 +921,6 @@ def flush_dw():
         if not h.ran:
             grad_done(h.W)
             grad_done(h.b)
-
-
-DEFER_COLSUM = _os.environ.get("BMT_DEFER_COLSUM", "1") != "0"      # A/B switch: "0" = every small reduction is its own launch again
 
 
 def _colsum_launch(items):
@@ -1091,7 +939,7 @@ def colsum_deferred(items, params=()):
     for the flush, exactly as for queued weight gradients.  The queue keeps the partials' tensors alive."""
     ctx = context()
     params = [p for p in params if p is not None]
-    if ctx.defer_dw and DEFER_COLSUM and params:       # (a result that is handed back to autograd as a tensor must be complete now)
+    if ctx.defer_dw and params:       # (a result that is handed back to autograd as a tensor must be complete now)
         ctx.pending_cs.extend(items)
         ctx.pending_ids.update(id(p) for p in params)
     else:
@@ -1109,10 +957,9 @@ def linear_dw(dy: Planes, x: Planes, into: Optional[torch.Tensor] = None, params
         return None
     N, K, M = dy.cols, x.cols, dy.rows
     sk = _splitk_for(N, K, M)
-    atomic = sk > 1 and DW_ATOMIC and into is not None      # two-pass split-K has one writer per element: no zero-fill, no atomics
-    acc = into is not None or atomic
-    dW = into if into is not None else (torch.zeros if atomic else torch.empty)(N, K, device=dy.hi.device, dtype=torch.float32)
-    gemm_bf16(dy, x, dW, ldc=dW.stride(0), accum=acc, splitk=sk, precision=PREC_BF16, a_km=True, b_km=True, two_pass=not atomic)
+    # (two-pass split-K has one writer per element: no zero-fill, no atomics)
+    dW = into if into is not None else torch.empty(N, K, device=dy.hi.device, dtype=torch.float32)
+    gemm_bf16(dy, x, dW, ldc=dW.stride(0), accum=into is not None, splitk=sk, precision=PREC_BF16, a_km=True, b_km=True)
     return None if into is not None else dW
 
 
@@ -1210,8 +1057,7 @@ def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=Non
     return P, gb is not None
 
 
-LN_EMIT_ANY_WIDTH = _os.environ.get("BMT_LN_EMIT_ANY", "1") != "0"      # A/B switch: "0" = only widths that are multiples of 64 (the encoder's; not the decoder's 300)
-LN_EMIT_GRAD_PLANE = _os.environ.get("BMT_LN_EMIT", "1") != "0"      # A/B switch: "0" = every upstream gradient goes through its own conversion pass again
+LN_EMIT_GRAD_PLANE = _os.environ.get("BMT_LN_EMIT", "1") != "0"      # switch: "0" = every upstream gradient goes through its own conversion pass again
 
 
 def request_grad_plane(out: torch.Tensor, p: float, site: int):
@@ -1219,7 +1065,7 @@ def request_grad_plane(out: torch.Tensor, p: float, site: int):
     use -- the next ResidualConnection's LayerNorm -- may hand back, next to d out, the bf16 operand plane of dropout_site(d out) and its
     column partials: exactly what this sublayer's backward would otherwise build in a pass of its own (ResidualNormFn.backward,
     bmt_layernorm_bwd_emit).  A note on the tensor; nobody is obliged to honour it."""
-    if LN_EMIT_GRAD_PLANE and isinstance(out, torch.Tensor) and out.is_cuda and out.shape[-1] % (4 if LN_EMIT_ANY_WIDTH else 64) == 0:
+    if LN_EMIT_GRAD_PLANE and isinstance(out, torch.Tensor) and out.is_cuda and out.shape[-1] % 4 == 0:
         out._bmt_gp_req = (float(p), int(site))
 
 
@@ -1325,7 +1171,7 @@ def attn_fwd_bf16(qh, ql, kh, kl, vh, vl, mask, H, drop_p=0.0, site=0, precision
     return o, lse
 
 
-ATTN_KMEAN = _os.environ.get("BMT_NO_KMEAN") != "1"      # A/B: the dQ correction by (row sum of rounded dS) x mean key
+ATTN_KMEAN = _os.environ.get("BMT_NO_KMEAN") != "1"      # switch: the dQ correction by (row sum of rounded dS) x mean key
 
 
 def attn_kmean(kh: torch.Tensor, ldk: int, bsk: int, B: int, Sk: int, D: int, mask_args, f16: bool = False, kpack=None) -> Optional[torch.Tensor]:
@@ -1399,8 +1245,7 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
 
-ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # A/B switch: "0" keeps the two-kernel backward everywhere
-KMEAN_SPLIT = _os.environ.get("BMT_KMEAN_SPLIT", "1") != "0"            # "0": no mean-key correction on the split form (fp16 dS)
+ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # switch: "0" keeps the two-kernel backward everywhere
 
 
 _SCRATCH = {}            # (device index, stream handle, capturing?, name) -> 1-D tensor: scratch that lives inside ONE library call
@@ -1420,6 +1265,14 @@ def stream_scratch(name: str, numel: int, dtype, device) -> torch.Tensor:
     if t is None or t.numel() < numel or t.dtype != dtype:
         t = _SCRATCH[key] = torch.empty(max(int(numel), 1), device=dev, dtype=dtype)
     return t[:numel]
+
+
+def release_scratch(capturing: Optional[bool] = None):
+    """drop the per-stream scratch buffers (all of them, or those of captured / eager launches only): several GB at configs[1] -- two
+    183-MB P / dS workspaces + 52 MB per stream and launch kind.  Scratch that a hipGraph was captured over belongs to that graph: release it
+    only after the graph is gone (CaptioningTrainStep.uncapture does)."""
+    for k in [k for k in _SCRATCH if capturing is None or k[2] == capturing]:
+        del _SCRATCH[k]
 
 
 def _attn_split_ws(B, H, Sq, Sk, dk, dev):
@@ -1473,9 +1326,9 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     ldq, ldk, ldv, ldop = qa.stride(0), ka.stride(0), va.stride(0), o.hi.stride(0)
     (qh_, qb_, _), (kh_, kb_, _), (vh_, vb_, _) = outs
     ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and f16 and mqs == 0) else None
-    # the mean-key correction removes the residue of the bf16-rounded dS (8 significand bits); the split form's dQ runs on fp16 dS with
-    # per-query scales (11 bits): with KMEAN_SPLIT off its launches (8 of the step's 14, ~21 us each) are skipped there
-    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16, kpack=kpack) if (ws is None or KMEAN_SPLIT) else None
+    # the mean-key correction removes the residue of the bf16-rounded dS (8 significand bits); kept on the split form too, whose dQ runs on
+    # fp16 dS with per-query scales (without it one tensor of the deep fixture goes from < 2 % to 4.4 %: DESIGN.md section 2)
+    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16, kpack=kpack)
     a = AttnBwdBf16Args(Qh=_p(qa), Kh=_p(ka), Vh=_p(va), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
@@ -1537,9 +1390,8 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
 # backward adds the residual stream's gradient to its own (no autograd add pass).  The residual is OFFERED to the sublayer
 # through a module-level slot; MultiheadedAttention / PositionwiseFeedForward take it, anything else leaves it and the
 # ResidualConnection falls back to the separate dropout_add kernel.
-OUT_PLANES = _os.environ.get("BMT_OUT_PLANES", "1") != "0"      # A/B switch: a sublayer's last GEMM also writes the operand planes its result's reader needs
-LN_PLANES_ONLY = _os.environ.get("BMT_LN_FP32") != "1"        # A/B switch: "1" = every LayerNorm output also as fp32 values
-FUSE_RESIDUAL = _os.environ.get("BMT_NO_FUSE_RES") != "1"
+LN_PLANES_ONLY = True         # a LayerNorm output asked for as planes (fp32_out=False) is not written as fp32 values as well
+FUSE_RESIDUAL = _os.environ.get("BMT_NO_FUSE_RES") != "1"      # switch: "1" = LayerNorm / dropout_add / add as separate kernels
 
 
 class ResidualOffer:
@@ -1552,7 +1404,7 @@ class ResidualOffer:
 
 def offer_residual(x, p, site, planes_fmt=None) -> ResidualOffer:
     off = ResidualOffer(x, p, site)
-    off.planes_fmt = planes_fmt if OUT_PLANES else None
+    off.planes_fmt = planes_fmt
     context().res_offer = off
     return off
 
@@ -1627,7 +1479,7 @@ class ResidualNormFn(torch.autograd.Function):
         ctx.beta = beta
         ctx.pack = pack
         ctx.kv_alias = bool(kv_alias)
-        ctx.gp_req = getattr(x, "_bmt_gp_req", None) if D % (4 if LN_EMIT_ANY_WIDTH else 64) == 0 else None      # (request_grad_plane: the producer of x wants dropout(dx) as a plane)
+        ctx.gp_req = getattr(x, "_bmt_gp_req", None) if D % 4 == 0 else None      # (request_grad_plane: the producer of x wants dropout(dx) as a plane)
         context().last_ln = pl
         if kv_alias:
             return xc.view_as(xc), y.view(xc.shape), xc.view_as(xc)
@@ -1825,7 +1677,7 @@ class LinearActFn(torch.autograd.Function):
         N = W.shape[0]
         dy2 = _f32c(dy).view(-1, N)
         p = ctx.p if ctx.drop_mode != "none" else 0.0
-        if ctx.relu and FUSE_GATE:
+        if ctx.relu:
             # dz = (y != 0) ? dy / (1 - p) : 0 never exists: its bf16 plane and column sums (the bias gradient) come out of one pass over dy and y
             Wp, bp = ctx.params
             bp = bp if ctx.has_bias else None
@@ -1841,10 +1693,7 @@ class LinearActFn(torch.autograd.Function):
             if dx is not None:
                 dx = dx.view(*dy.shape[:-1], W.shape[1])
             return dx, dW, (None if gb is not None else cs), None, None, None, None
-        if ctx.relu:
-            dz = torch.empty_like(dy2)
-            _lib.check(lib.bmt_gate(_p(dy2), _p(y), 1.0 / (1.0 - p) if p > 0 else 1.0, _p(dz), dy2.numel(), _st()), "bmt_gate")
-        elif p > 0:
+        if p > 0:
             dz = dropout_raw(dy2, p, ctx.site)
         else:
             dz = dy2
@@ -1958,7 +1807,7 @@ def attn_operand_fmt(attn_prec: int) -> str:
     return {PREC_BF16X3: "x3", PREC_F16: "f16", PREC_BF16: "bwd"}[attn_prec]
 
 
-QKV_F16_ONLY = _os.environ.get("BMT_QKV_BOTH_PLANES") != "1"     # A/B: q / k / v as fp16 planes only where the backward can convert them
+QKV_F16_ONLY = True      # q / k / v as fp16 planes only where the backward can convert them
 
 
 def attn_train_fmt(attn_prec: int, dk: int) -> str:
@@ -1997,54 +1846,6 @@ def mha_infer(Q, K, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, cache, key, pol):
     q = linear_fwd_planes(Qp, Wq, bq, precision=pol.gemm, out_fmt=qkv_fmt)
     o, _ = attn_fwd_planes(q, k, v, B, Sq, Sk, D, mask, H, precision=pol.attn, out_fmt=act_fmt(pol.gemm))
     return linear_fwd(o, Wo, bo, precision=pol.gemm).view(B, Sq, Dq)
-
-
-# ---- the K / V projections of an encoder memory, ahead of the attention that reads them.  A decoder layer's encoder-decoder attentions
-# project the SAME memory for every layer and their projections (the only large kernels of the decoder phase) depend on the encoder alone:
-# BiModelDecoder.forward issues all of them on the side stream while the first layer's self-attention runs.  Only the forward product is
-# taken out of MHAFn -- its backward (dX w.r.t. the memory, dW) works from the saved planes as before.
-KV_PREFETCH = _os.environ.get("BMT_KV_PREFETCH") == "1"      # A/B switch: off (measured: 8.80 vs 8.79 ms/step same box -- no gain)
-_kv_prefetched = {}      # (id(memory tensor), id(Wk)) -> (memory, Wk, k planes, v planes, event, stream)
-
-
-def prefetch_kv(K: torch.Tensor, Wk, bk, Wv, bv, pol, H: int) -> bool:
-    """project ``K`` (an encoder memory; K is V) with a cross-attention's key / value weights on the CURRENT stream and keep the planes for
-    the MHAFn.forward that will ask for them (take_prefetched_kv); False if this projection is not the fused one MHAFn would run."""
-    if not KV_PREFETCH or not K.is_cuda:
-        return False
-    note_use(Wk, bk, Wv, bv)
-    Kc = _f32c(K)
-    prec_kv = pol.kv_gemm
-    D = Wk.shape[0]
-    qkv_fmt = attn_train_fmt(pol.attn, D // H) if torch.is_grad_enabled() else attn_operand_fmt(pol.attn)
-    Kp = planes_of(K, act_fmt(prec_kv))
-    if Kp is None:
-        Kp = make_planes(Kc.view(-1, Kc.shape[-1]), act_fmt(prec_kv))
-        attach_planes(K, Kp)
-    r = project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
-    if r is None:
-        return False
-    st = torch.cuda.current_stream()
-    _kv_prefetched[(id(K), id(Wk))] = (K, Wk, r[0], r[1], st.record_event(), st, qkv_fmt)
-    return True
-
-
-def take_prefetched_kv(K, Wk, qkv_fmt):
-    ent = _kv_prefetched.pop((id(K), id(Wk)), None)
-    if ent is None or ent[0] is not K or ent[1] is not Wk or ent[6] != qkv_fmt:
-        return None
-    cur = torch.cuda.current_stream()
-    if cur.cuda_stream != ent[5].cuda_stream:
-        cur.wait_event(ent[4])
-        for pl in (ent[2], ent[3]):
-            for t in (pl.hi, pl.lo, pl.fh, pl.fl):
-                if t is not None:
-                    t.record_stream(cur)
-    return ent[2], ent[3]
-
-
-def drop_prefetched_kv():
-    _kv_prefetched.clear()
 
 
 class MHAFn(torch.autograd.Function):
@@ -2093,7 +1894,7 @@ class MHAFn(torch.autograd.Function):
             if r is not None:
                 (q, k, v), fuse = r, "qkv"
         elif same_kv:
-            r = take_prefetched_kv(K, Wk, qkv_fmt) or project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
+            r = project_group(Kp, (Wk, Wv), (bk, bv), prec_kv, qkv_fmt)
             if r is not None:
                 (k, v), fuse = r, "kv"
         if q is None:
@@ -2173,10 +1974,7 @@ class MHAFn(torch.autograd.Function):
             dx = None
             if need_dx:          # [Wq;Wk;Wv] as stored ([3D][d_in]): its row is the reduction index
                 dx = torch.empty(comb.rows, gst.cols, device=dy2.device, dtype=torch.float32)
-                if DX_ROW_MAJOR:
-                    gemm_bf16(comb, weight_group_t(Ws), dx, ldc=dx.stride(0), precision=PREC_BF16)
-                else:
-                    gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
+                gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
             gW = group_static_grad(Ws)
             if gW is not None:
                 linear_dw(comb, xT, into=gW, params=Ws)
@@ -2230,8 +2028,8 @@ class MHAFn(torch.autograd.Function):
         return dQ, dK, dV, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None, None
 
 
-FUSE_GATE = _os.environ.get("BMT_FUSE_GATE", "1") != "0"      # A/B switch: "0" = relu / dropout derivative as its own kernel + an fp32 dz tensor again
-FUSE_GEN_LOSS = _os.environ.get("BMT_FUSE_GEN_LOSS", "1") != "0"      # A/B switch: "0" = the generator and the loss as separate autograd nodes
+FUSE_GATE = True         # relu / dropout derivative inside the gradient's plane conversion (no fp32 dz tensor)
+FUSE_GEN_LOSS = _os.environ.get("BMT_FUSE_GEN_LOSS", "1") != "0"      # switch: "0" = the generator and the loss as separate autograd nodes
 
 
 class GenHandle:
@@ -2329,7 +2127,10 @@ class FusedGenLossFn(torch.autograd.Function):
         ctx.meta = (smoothing, pad_idx, x.shape)
         ctx.params = (W, b)
         ctx.handle = handle
-        context().gen_handles.append(handle)
+        hs = context().gen_handles
+        if len(hs) >= 8:          # (a caller that never settles them -- plain loss.backward() loops -- must not accumulate handles: ADVICE r4)
+            del hs[:-7]
+        hs.append(handle)
         return loss
 
     @staticmethod
@@ -2348,6 +2149,8 @@ class FusedGenLossFn(torch.autograd.Function):
             grad_done(bp)
         dx = linear_dx(P, Wp).view(xshape) if ctx.needs_input_grad[0] else None
         dW, _ = wgrad(Wp, None, P, bwd_planes(x2))
+        h = ctx.handle          # this pass is done with the log-probabilities: the handle keeps the parameters only (38 MB at configs[1])
+        h.x = h.logp = h.rowsum = None
         return dx, dW, (None if gb is not None else cs), None, None, None, None
 
 

@@ -106,6 +106,16 @@ class GradientReducer:
             shard = torch.zeros(flat.numel() // self.world, dtype=torch.float32, device=flat.device)
         self.buckets.append({"params": ps, "flat": flat, "views": views, "pending": len(ps), "shard": shard})
 
+    def set_collective(self, collective: str):
+        """switch how a bucket's sum is formed (between steps; a captured hipGraph keeps what it was captured with)"""
+        if collective not in ("allreduce", "rs_ag"):
+            raise ValueError(f"GradientReducer: unknown collective {collective!r}")
+        self.collective = collective
+        if collective == "rs_ag" and self.world > 1:
+            for b in self.buckets:
+                if b["shard"] is None:
+                    b["shard"] = torch.zeros(b["flat"].numel() // self.world, dtype=torch.float32, device=b["flat"].device)
+
     def _reduce_bucket(self, b):
         """launch the sum of one bucket over the ranks (asynchronously): the handles go to self._handles, and -- where two collectives of
         one bucket cannot simply be queued behind each other -- the second half to self._second"""
@@ -135,6 +145,9 @@ class GradientReducer:
                 p._bmt_uses = 0
         self._handles = []
         self._second = []
+        if self._arena is not None and self._arena.is_cuda:      # a new step: nothing of the last one is left to settle
+            from . import ops as _ops
+            _ops.context().gen_handles.clear()
 
     def _on_grad(self, p):
         bi, si = self._slot[p]

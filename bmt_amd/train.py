@@ -72,13 +72,6 @@ def make_masks(feature_stacks: Dict[str, torch.Tensor], captions: Optional[torch
     return masks
 
 
-# A/B switches of the batch-in-parts step (CaptioningTrainStep(microbatches=M)): part i's encoder forward ordered behind part i-1's; every part's
-# two-stream encoder (0 = a part is ONE stream)
-_PARTS_STAGGER = os.environ.get("BMT_PARTS_STAGGER", "1") != "0"
-_PARTS_SIDE_STREAMS = os.environ.get("BMT_PARTS_SIDE", "1") != "0"
-_ONE_GRAPH = os.environ.get("BMT_ONE_GRAPH", "0") == "1"                # A/B switch: a single-process step as ONE hipGraph instead of {forward, backward} + {optimizer}
-
-
 class CaptioningTrainStep:
     """One optimizer step of the captioning model.
 
@@ -88,14 +81,9 @@ class CaptioningTrainStep:
     backward graph instead (no collective is ever captured)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None, collective: str = "allreduce",
-                 microbatches: int = 1):
+                 static_grads: bool = False, overlap: bool = True, seed: Optional[int] = None, collective: str = "allreduce"):
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
         self._overlap = overlap
-        # microbatches = M > 1 (needs static gradient buffers): the batch is differentiated in M parts of consecutive samples that are IN FLIGHT
-        # TOGETHER, each on compute streams of its own (_forward_backward_parts) -- same loss, same gradient sums, one optimizer step
-        self.microbatches = max(1, int(microbatches))
-        self._part_streams, self._part_rng, self._parts_generation = [], [], None
         self._graph_generation = None
         _seed_dropout(seed, data_parallel, next(model.parameters()).device)
         params = [p for p in model.parameters() if p.requires_grad]
@@ -118,7 +106,6 @@ class CaptioningTrainStep:
         self._flush_points = 0
         if data_parallel:
             self._install_flush_points()
-        self._install_early_dw()
 
     def _install_flush_points(self):
         """Overlap of the gradient all-reduce with the backward pass (eager launches, ``reducer.overlap``): the weight-gradient
@@ -143,155 +130,9 @@ class CaptioningTrainStep:
             layer.register_forward_hook(attach)
             self._flush_points += 1
 
-    def _install_early_dw(self):
-        """without bucket-by-bucket overlap the weight-gradient products of the whole backward pass are queued for ONE grouped launch
-        at its end (1.05 ms alone on the GPU, DESIGN §6 finding 9).  When the encoder runs on two compute streams, what is queued by the
-        time the backward pass crosses into an earlier encoder layer -- later layers, decoder, generator -- is issued there on a third
-        stream (ops.flush_dw_early), beside the remaining layers' backward."""
-        from . import ops as _ops
-        stack = getattr(getattr(getattr(self.model, "encoder", None), "encoder_AV", None), "layers", None)
-        if stack is None or not _ops.EARLY_DW:      # (measured slower than the lone launch at the end, DESIGN §6: an experiment switch)
-            return
-        step = self
-
-        def attach(mod, inp, out):
-            if not torch.is_grad_enabled() or (step.reducer is not None and step.reducer.overlap and step.reducer.world > 1):
-                return
-            ts = [t for t in (out if isinstance(out, (tuple, list)) else (out,)) if isinstance(t, torch.Tensor) and t.requires_grad]
-            left = [len(ts)]
-
-            def fired(g):
-                left[0] -= 1
-                if left[0] == 0:          # both chains have crossed: everything of the later layers is queued
-                    _ops.flush_dw_early()
-                return g
-            for t in ts:
-                t.register_hook(fired)
-        for layer in stack:
-            layer.register_forward_hook(attach)
-
     # ---- the three phases -------------------------------------------------------------------------------------
-    def _parts_in_flight(self, caption_idx) -> int:
-        """how many parts this step's batch is differentiated in (1 = the plain pass)"""
-        r = self.reducer
-        if self.microbatches <= 1 or r is None or not caption_idx.is_cuda:
-            return 1
-        if r.world > 1 and r.overlap:       # buckets reduced from inside the backward pass: completion in autograd order, on ONE stream
-            return 1
-        return min(self.microbatches, int(caption_idx.shape[0]))
-
-    def _forward_backward_parts(self, feature_stacks, caption_idx, M: int):
-        """The batch in M parts of consecutive samples, IN FLIGHT TOGETHER.  One pass over a batch has a phase that cannot fill the GPU
-        -- decoder, generator and loss, forward and backward: ~170 launches over B x 29 rows between the encoder's forward and its backward
-        (replay timeline) -- and nothing else of the same pass is independent of it.  Another part's encoder is: part i runs
-        on compute streams of its own (its own StepContext: scratch, queues, dropout stream), its encoder forward is ordered behind part
-        i-1's (events), and from there on the GPU has a decoder phase and an encoder phase to run side by side.  Every per-row
-        computation is what the plain pass does; gradients are sums over rows, accumulated into the same static buffers (atomics), and
-        the weight-gradient products / small reductions of all parts leave as ONE grouped launch at the end.  Dropout: part i draws from
-        the device's stream re-seeded for i (bmt_rng_derive), element indices count from the part's first row."""
-        from . import ops as _ops
-        model = self.model
-        model.train()
-        main = torch.cuda.current_stream()
-        dev = caption_idx.device
-        self.reducer.zero_grad()
-        x, y, n_tokens = _ops.caption_shift(caption_idx, self.pad_idx)
-        with _ops._weights.lock:            # the once-per-step refresh of the weights' operand planes: before any part forks
-            _ops._weights.ensure_fresh()
-        _ops.rng_advance()                  # one step of the device's dropout stream per optimizer step, whatever the number of parts
-        while len(self._part_streams) < M - 1:
-            self._part_streams.append(torch.cuda.Stream(device=dev))
-        while len(self._part_rng) < M:
-            self._part_rng.append(torch.zeros(2, dtype=torch.int64, device=dev))
-        for i in range(M):
-            _ops.rng_derive(self._part_rng[i], i)
-        B = int(caption_idx.shape[0])
-        cuts = [(B * i) // M for i in range(M + 1)]
-        # one compute stream only (ops.ENC_STREAMS = 1: the kernel timer's and the profilers' eager steps): the same parts, the same
-        # launches, one after the other on the current stream
-        # ... and so is the FIRST step of a model (or the first after its operand-plane registry changed): a weight's planes, a positional table,
-        # a pointer table are built by whoever meets them first, on ITS stream -- a second part must not find them half built
-        serial = _ops.ENC_STREAMS < 2 or self._parts_generation != _ops.weights_registry_signature()
-        streams = [main] * M if serial else [main] + self._part_streams[:M - 1]
-        self._parts_last = (M, "one after the other" if serial else "in flight together")
-        start = main.record_event()
-        # a part's own two-stream encoder: not under hipGraph capture -- a stream pulled into a capture by an event of a stream that was itself
-        # pulled in (a part's stream forking its side stream) crashes hipStreamEndCapture on ROCm 7.2, also when every stream is first made a direct
-        # child of the origin stream (tools/gpu_parts_bisect.sh, profiles/r04_i_parts_bisect.txt); a captured part is ONE stream
-        side_ok = _PARTS_SIDE_STREAMS and not torch.cuda.is_current_stream_capturing()
-        ctxs, kls = [], []
-
-        def forward(i, st, prev_done):
-            lo, hi = cuts[i], cuts[i + 1]
-            if st is not main:
-                st.wait_event(start)
-            ctx = _ops.context()
-            if not any(ctx is c for c in ctxs):
-                ctxs.append(ctx)
-            stagger = (not serial) and _PARTS_STAGGER
-            ctx.rng, ctx.enc_gate, ctx.mark_enc, ctx.enc_done = self._part_rng[i], prev_done if stagger else None, stagger and i + 1 < M, None
-            ctx.defer_dw = True
-            _ops.allow_encoder_streams(side_ok)
-            fs = {k: v[lo:hi] for k, v in feature_stacks.items()}
-            xi, yi = x[lo:hi], y[lo:hi]
-            if st is not main:
-                for t in list(fs.values()) + [xi, yi]:
-                    t.record_stream(st)
-            masks = make_masks(fs, xi, self.modality, self.pad_idx)
-            pred = model(fs, xi, masks)
-            kls.append(self.criterion(pred, yi))
-            return ctx.enc_done
-
-        def backward(kl):
-            kl.backward(gradient=self._one if kl.dim() == 0 else None)
-            _ops.join_side_stream()
-
-        try:
-            if serial:
-                for i in range(M):
-                    forward(i, main, None)
-                    backward(kls[-1])
-            else:
-                prev_done = None
-                for i, st in enumerate(streams):
-                    with torch.cuda.stream(st):
-                        prev_done = forward(i, st, prev_done)
-                for st, kl in zip(streams, kls):
-                    with torch.cuda.stream(st):
-                        backward(kl)
-            c0 = ctxs[0]
-            for st, ctx in zip(streams[1:], ctxs[1:]):      # (serial: one context, nothing to merge)
-                main.wait_stream(st)
-                c0.pending_dw.extend(ctx.pending_dw)
-                c0.pending_cs.extend(ctx.pending_cs)
-                c0.pending_done.extend(ctx.pending_done)
-                c0.pending_ids.update(ctx.pending_ids)
-                c0.gen_handles.extend(ctx.gen_handles)
-            _ops.flush_dw()
-            kl = kls[0].detach()
-            for k in kls[1:]:
-                kd = k.detach()
-                if not serial:
-                    kd.record_stream(main)
-                kl = _ops.add_(torch.empty_like(kl), kl, kd)
-        finally:
-            for ctx in ctxs:
-                ctx.defer_dw = False
-                ctx.pending_dw.clear()
-                ctx.pending_cs.clear()
-                ctx.pending_done.clear()
-                ctx.pending_ids.clear()
-                ctx.gen_handles.clear()
-                ctx.rng = ctx.enc_gate = ctx.enc_done = None
-                ctx.mark_enc = False
-        self._parts_generation = _ops.weights_registry_signature()
-        return kl, n_tokens
-
     def _forward_backward(self, feature_stacks, caption_idx):
         """zero_grad -> masks -> forward -> sum-KL -> backward.  Returns (sum-KL, local non-pad token count)."""
-        M = self._parts_in_flight(caption_idx)
-        if M > 1:
-            return self._forward_backward_parts(feature_stacks, caption_idx, M)
         model = self.model
         model.train()
         if self.reducer is not None:
@@ -366,10 +207,7 @@ class CaptioningTrainStep:
         (seed/step live in device memory, the step counter is advanced by a captured kernel), as do Adam's bias corrections."""
         if self.reducer is None:
             raise RuntimeError("capture() needs static gradient buffers: construct with static_grads=True")
-        if self.microbatches > 1:
-            warmup = max(warmup, 2)             # the first step of a model runs its parts one after the other (_forward_backward_parts)
-        if collectives or (_ONE_GRAPH and (not self.data_parallel or self.reducer.world == 1)):
-            # (one process: nothing sits between the backward pass and the optimizer but the loss normaliser's launch -- the same single graph)
+        if collectives:
             return self._capture_with_collectives(feature_stacks, caption_idx, warmup)
         self.reducer.overlap = False            # collectives stay outside the captured region
         self._static_fs = {k: v.clone() for k, v in feature_stacks.items()}
@@ -428,7 +266,11 @@ class CaptioningTrainStep:
 
     def uncapture(self):
         """back to eager launches (bucket all-reduces overlapped with the backward pass again)"""
+        had = self._graphs is not None
         self._graphs = None
+        if had:          # the per-stream scratch the graphs were captured over goes with them
+            from . import ops as _ops
+            _ops.release_scratch(capturing=True)
         if self.reducer is not None:
             self.reducer.overlap = self._overlap
 
@@ -545,6 +387,9 @@ class ProposalTrainStep:
         parallelism the obj / noobj counts and the gradients are all-reduced from inside the step: launch that eagerly)."""
         if self.world > 1:
             raise RuntimeError("ProposalTrainStep.capture: single-process only")
+        if getattr(self.cfg, "grad_clip", None) is not None:
+            raise RuntimeError("ProposalTrainStep.capture: cfg.grad_clip needs the gradient norm on the host (clip_grad_norm_), which a hipGraph "
+                               "cannot capture; launch the step eagerly or set cfg.grad_clip = None")
         if self.reducer is None:       # static gradient buffers: what the captured kernels write and the captured Adam reads
             self.reducer = GradientReducer(self.params, overlap=False)
         max_events = max(int(max_events or 0), targets.shape[0])
@@ -567,6 +412,8 @@ class ProposalTrainStep:
         return g
 
     def replay(self, feature_stacks=None, targets=None):
+        if (feature_stacks is None) != (targets is None):
+            raise ValueError("ProposalTrainStep.replay: give a batch as (feature_stacks, targets), or neither to replay the captured one")
         if feature_stacks is not None:
             for k, v in feature_stacks.items():
                 self._static_fs[k].copy_(v, non_blocking=True)

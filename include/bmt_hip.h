@@ -406,10 +406,6 @@ int bmt_cat2(const float* a, int64_t lda, int Da, const float* b, int64_t ldb, i
 int bmt_split2(const float* in, int64_t ldi, float* a, int64_t lda, int Da, float* b, int64_t ldb, int Db, int rows, void* stream);
 /* rng[1] += 1 (advance the dropout step counter on device; graph-capturable) */
 int bmt_rng_advance(uint64_t* rng, void* stream);
-/* ABI 6: out = {seed of its own derived from (base seed, salt), base step} -- the dropout stream of part `salt` of a batch whose parts are in
- * flight together (bmt_amd.train.CaptioningTrainStep(microbatches=...)); salt 0 copies the base stream.  No counterpart in the reference:
- * nn.Dropout draws from torch's global generator (model/blocks.py:131) */
-int bmt_rng_derive(const uint64_t* base, uint64_t* out, uint64_t salt, void* stream);
 /* out[i0][i1][i2] (contiguous) (+)= in[i0*s0 + i1*s1 + i2*s2]  -- Conv1d weight re-layout
  * ([Dout][Din][k] state_dict layout <-> the tap-major layouts the implicit-convolution GEMM consumes) */
 int bmt_copy3d(const float* in, int64_t s0, int64_t s1, int64_t s2, float* out, int n0, int n1, int n2, int accumulate,

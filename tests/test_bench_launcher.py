@@ -24,6 +24,14 @@ def test_self_launch_two_ranks_dry_run():
     assert out and out["dry_run"] and out["n_gpus"] == 2 and out["steps"] == 3
     # max over ranks of the wall time (rank 1 sleeps 2 ms per step), sum over ranks of the units (100 + 200)
     assert out["ms_per_step"] >= 1.9 and abs(out["value"] * out["ms_per_step"] * 1e-3 - 300.0) < 1e-6
+    # the evidence that N ranks took part travels in the line itself: what the collective library counts (a sum all-reduce of ones), every
+    # rank's device, the exposed all-reduce time and the bucket collective (--dp-collective auto tries both forms)
+    assert out["rccl_ranks_seen"] == 2
+    assert sorted(d["rank"] for d in out["rank_devices"]) == [0, 1] and all("device" in d for d in out["rank_devices"])
+    assert "allreduce_exposed_ms" in out and out["dp_collective"] in ("allreduce", "rs_ag")
+    assert out["dp_collectives_tried"] == ["allreduce", "rs_ag"]
+    r, out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--dp-collective", "rs_ag"])
+    assert r.returncode == 0 and out["dp_collective"] == "rs_ag" and out["dp_collectives_tried"] == ["rs_ag"]
 
 
 def test_captured_allreduce_trial_runs_in_child_processes_and_is_bounded():

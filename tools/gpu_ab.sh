@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on ONE box: bench.py (train_cap, hipgraph, no CPU baseline) under each of the given environment settings, twice, interleaved.
-# usage: tools/gpu_ab.sh "<env A>" "<env B>" ...      e.g. tools/gpu_ab.sh "BMT_DX_KMAJOR=1" "BMT_DX_KMAJOR=0"
+# usage: tools/gpu_ab.sh "<env A>" "<env B>" ...      e.g. tools/gpu_ab.sh "BMT_PACK_ROWS=1" "BMT_PACK_ROWS=0"
 mkdir -p gpurun_out
 for round in 1 2; do
   for e in "$@"; do

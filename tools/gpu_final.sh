@@ -25,7 +25,3 @@ timeout 200 python tools/deep_config_step.py 2>&1 | grep -v amdgpu | tail -1 | t
 timeout 120 python tools/decode_bench.py > gpurun_out/${TAG}_decode_bench.json 2>/dev/null; tail -c 600 gpurun_out/${TAG}_decode_bench.json; echo
 timeout 120 python tools/postprocess_bench.py > gpurun_out/${TAG}_postprocess_bench.json 2>/dev/null; tail -c 400 gpurun_out/${TAG}_postprocess_bench.json; echo
 timeout 120 python tools/ingest_bench.py > gpurun_out/${TAG}_ingest_bench.json 2>/dev/null; tail -c 400 gpurun_out/${TAG}_ingest_bench.json; echo
-# cheap same-box A/Bs of Python-level switches (no csrc change: the PMC record above stays valid whichever way they go)
-if [ -n "$FINAL_AB" ]; then
-  bash tools/gpu_ab.sh "X=0" "BMT_ONE_GRAPH=1" "BMT_KV_PREFETCH=1" "BMT_LN_EMIT_ANY=0" 2>&1 | tee gpurun_out/${TAG}_ab_onegraph_prefetch_lnany.txt
-fi
