@@ -94,6 +94,7 @@ SIGNATURES = {
     "bmt_version": (i32, []),
     "bmt_attn_kmean": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp, vp]),
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
+    "bmt_gemm_small_outputs": (C.c_longlong, []),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
     "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp, vp]),
     "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp, vp]),

@@ -1241,6 +1241,213 @@ do {                                                                            
 // packs the problems onto XCDs (whole problems, large ones in 2-8 contiguous parts): XCD x = workgroup index mod 8 works through
 // its own list of segments {first slot, problem, first tile, tile count}, a tile's neighbours in the L2-friendly order run
 // on the same XCD, and an operand panel is fetched by as few XCDs as the load balance allows.
+// ---- small products (round 5): a decoder layer's own GEMMs -- 928 rows, 300 ... 1200 columns, reductions of 300 ... 1200 -- and the greedy
+// decoder's.  On 128 x 128 tiles such a product is 24 ... 80 workgroups walking a chain of dependent stages (one CU moves ~25 GB/s with two
+// stages in flight), or a split reduction plus a second kernel; both cost 20 ... 30 us for microseconds of MFMA work, and the decoder is a
+// chain of ~40 of them with nothing else to run beside it (profiles/r05_d_replay_dispatches.csv).  Here every WAVE is on its own: a 32 x 32
+// output tile and a range of the reduction, operands staged 64 reduction indices at a time through a wave-private LDS area (coalesced
+// 16-byte loads, eight lanes per 128-byte line of a plane row, two chunks ahead in two register sets; ds_write_b128 into the swizzled
+// [32 rows][8 slots] image the MFMA fragments are read from) -- no barrier in the loop.  Two groupings of a workgroup's four waves, chosen
+// by the host (GemmB.nk_rg): 4 = one tile, the REDUCTION split over the waves, summed through LDS (long reductions over few tiles: the
+// hand-over stays inside a workgroup, so no device-scope release / acquire between XCDs, which is what made the one-kernel split-K lose
+// in round 4); 1 = a 64 x 64 block of four tiles, each wave the whole reduction of its own (short reductions).  (A first version fetched
+// the MFMA fragments straight from the planes -- lane (row, half) its own 16 bytes -- and was slower than the kernels it replaces:
+// 64 scattered 16-byte requests per instruction cost the texture path ~4x a coalesced one, profiles/r05_g_gemm_small_time.txt.)
+// Full epilogue, same order of operations as gemm_bf16_tile's.
+template <int NPASS, bool F16>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p) {
+    constexpr bool ALO = NPASS == 3, BLO = NPASS >= 2;
+    constexpr int NPL = 2 + (ALO ? 1 : 0) + (BLO ? 1 : 0);       // planes staged per chunk: A hi | B hi | [A lo] | [B lo]
+    constexpr int WBYTES = NPL * 4096;                            // a wave's area: [plane][32 rows][8 slots of 16 B], swizzled (slot_of<8>)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
+    char* const wbase = smem + wid * WBYTES;
+    int Mr = p.M;
+    if (p.rows_dev != nullptr) Mr = min(Mr, *p.rows_dev);
+    const int ncols = p.Chi ? max(p.plane_cols, p.N) : p.N;      // columns that are written (planes: zeros past N)
+    const bool ksplit = p.nk_rg == 4;
+    const int bm = blockIdx.x % p.tiles_m, bn = blockIdx.x / p.tiles_m;
+    const int m0 = ksplit ? bm * 32 : bm * 64 + 32 * (wid >> 1), n0 = ksplit ? bn * 32 : bn * 64 + 32 * (wid & 1);
+    if ((ksplit ? m0 : bm * 64) >= Mr) return;                    // (whole workgroup)
+    if (!ksplit && (m0 >= Mr || n0 >= ncols)) return;             // a wave of the 64 x 64 block past the extents: it shares nothing
+    const int nch = p.Kpad / 64, per = ksplit ? (nch + 3) / 4 : nch;
+    const int c0 = ksplit ? wid * per : 0, c1 = min(nch, c0 + per);
+    const int64_t a_bytes = (int64_t)Mr * p.lda * 2, b_bytes = (int64_t)p.N * p.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rsAh = plane_rsrc(p.Ah, a_bytes), rsAl = plane_rsrc(ALO ? p.Al : p.Ah, a_bytes);
+    const __amdgpu_buffer_rsrc_t rsBh = plane_rsrc(p.Bh, b_bytes), rsBl = plane_rsrc(BLO ? p.Bl : p.Bh, b_bytes);
+    constexpr int OOB = 0x7ffffff0;                               // past any plane (< 2 GiB, checked by the host): reads as zero
+    int voa[4], vob[4], lds_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + (lane >> 3), piece = lane & 7;
+        voa[i] = (m0 + row < Mr) ? (int)((int64_t)(m0 + row) * p.lda * 2) + piece * 16 : OOB;
+        vob[i] = (n0 + row < p.N) ? (int)((int64_t)(n0 + row) * p.ldb * 2) + piece * 16 : OOB;
+        lds_w[i] = slot_of<8>(row, piece) * 16;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    u32x4 rg[2][NPL][4];
+#define BMT_SM_LOAD(set_, c_)                                                                       \
+    do {                                                                                            \
+        const bool in_ = (c_) < c1;                        /* wave-uniform */                       \
+        const int so_ = (c_) * 128;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+            const int va_ = in_ ? voa[i] : OOB, vb_ = in_ ? vob[i] : OOB;                           \
+            rg[set_][0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, va_, so_, 0);              \
+            rg[set_][1][i] = __builtin_amdgcn_raw_buffer_load_b128(rsBh, vb_, so_, 0);              \
+            if constexpr (ALO) rg[set_][2][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, va_, so_, 0); \
+            if constexpr (BLO) rg[set_][NPL - 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rsBl, vb_, so_, 0); \
+        }                                                                                           \
+    } while (0)
+#define BMT_SM_STAGE(set_)                                                                          \
+    do {   /* LDS operations of a wave execute in order: these writes follow the previous chunk's fragment reads */ \
+        _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + pl * 4096 + lds_w[i]) = rg[set_][pl][i]; \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
+            const int fo_ = slot_of<8>(l31, 2 * u + half) * 16;                                     \
+            const bf16x8 ah_ = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + fo_));            \
+            const bf16x8 bh_ = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + 4096 + fo_));     \
+            if constexpr (ALO) acc = mfma32t<F16>(as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + 2 * 4096 + fo_)), bh_, acc); \
+            if constexpr (BLO) acc = mfma32t<F16>(ah_, as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + (NPL - 1) * 4096 + fo_)), acc); \
+            acc = mfma32t<F16>(ah_, bh_, acc);                                                      \
+        }                                                                                           \
+    } while (0)
+    // branch-free inside the loop: a chunk past the wave's range is fetched out of range (zeros, no memory access) and multiplied anyway, so
+    // that the compiler's vmcnt counts are exact (with a conditional load it waits for the YOUNGER set before touching the older one)
+    if (c0 < c1) {
+        BMT_SM_LOAD(0, c0);
+        BMT_SM_LOAD(1, c0 + 1);
+        for (int c = c0; c < c1; c += 2) {
+            BMT_SM_STAGE(0);
+            BMT_SM_LOAD(0, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            BMT_SM_STAGE(1);
+            BMT_SM_LOAD(1, c + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef BMT_SM_LOAD
+#undef BMT_SM_STAGE
+    // ---- the wave's 32 x 32 partial as fp32 [32][36] in its own area; reduction split: the four partials meet behind one barrier
+    float* const mine = reinterpret_cast<float*>(wbase);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[acc_row(r, half) * 36 + l31] = acc[r];
+    if (ksplit) {
+        __syncthreads();
+        if (wid >= 2) return;
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- epilogue (order: alpha, bias, dropout_pre, relu, dropout_post, gate, residual): a lane = one row x 8 consecutive columns; reduction
+    // split: waves 0 / 1 take rows 0-15 / 16-31 of the summed tile; 64 x 64 block: every wave its own tile, 16 rows at a time
+    const unsigned f = p.flags;
+    const int nparts = ksplit ? 4 : 1, niter = ksplit ? 1 : 2, cg = (lane & 3) * 8, col = n0 + cg;
+    const int pcols = p.Chi ? p.plane_cols : 0;
+    const bool col_on = col < p.N || col < pcols, full = col + 8 <= p.N;
+    const bool c_vec = p.C && full && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const DropCtx dc = make_drop(p.drop_p, p.rng, p.site);
+    float bv[8], cs8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        bv[q] = ((f & BMT_EPI_BIAS) && col + q < p.N) ? p.bias[col + q] : 0.f;
+        cs8[q] = 0.f;
+    }
+    for (int it = 0; it < niter; ++it) {
+        const int rl = (ksplit ? wid * 16 : it * 16) + (lane >> 2), row = m0 + rl;
+        if (row >= Mr || !col_on) continue;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        for (int w_ = 0; w_ < nparts; ++w_) {
+            const float* src = reinterpret_cast<const float*>(ksplit ? smem + w_ * WBYTES : wbase) + rl * 36 + cg;
+            const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
+            v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+        }
+        const int64_t idx = (int64_t)row * p.ldc + col;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = v[q] * p.alpha + bv[q];
+        if (f & BMT_EPI_DROP_PRE) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+        }
+        if (f & BMT_EPI_RELU) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (f & BMT_EPI_DROP_POST) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+        }
+        if (f & BMT_EPI_GATE) {            // keep an element iff the saved forward output is non-zero (sign bit ignored)
+            const uint16_t* gp = p.gate + (int64_t)row * p.ldg + col;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (col + q < p.N && (gp[q] & 0x7fffu)) ? v[q] * p.gate_scale : 0.f;
+        }
+        if (f & BMT_EPI_RESIDUAL) {
+            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q < p.N) v[q] += rp[q];
+        }
+        if (!full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q >= p.N) v[q] = 0.f;                               // plane columns past N hold zeros
+        }
+        if (f & BMT_EPI_ACCUM) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q < p.N) atomicAdd(p.C + idx + q, v[q]);
+        } else if (c_vec) {
+            *reinterpret_cast<float4*>(p.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.C + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (p.C) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (col + q < p.N) p.C[idx + q] = v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cs8[q] += v[q];
+        if (p.Chi && col < pcols) {
+            u32x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t h_, l_;
+                split_bf2(v[2 * q], v[2 * q + 1], h_, l_);
+                h[q] = h_;
+                l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
+                if (p.hi_f16) h[q] = pack_h2(v[2 * q], v[2 * q + 1]);
+            }
+            const int64_t pi = (int64_t)row * p.ldp + col;
+            if (p.plane_vec) {
+                *reinterpret_cast<u32x4*>(p.Chi + pi) = h;
+                if (p.Clo) *reinterpret_cast<u32x4*>(p.Clo + pi) = l;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (col + q < pcols) {
+                        p.Chi[pi + q] = (uint16_t)(h[q >> 1] >> (16 * (q & 1)));
+                        if (p.Clo) p.Clo[pi + q] = (uint16_t)(l[q >> 1] >> (16 * (q & 1)));
+                    }
+            }
+        }
+    }
+    if (p.colsum) {                  // uniform per launch.  A wave's rows live in lanes 4 apart: fold them, one atomic per column and wave
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float t = cs8[q];
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (lane < 4 && col + q < p.N) atomicAdd(p.colsum + col + q, t);
+        }
+    }
+}
+
 struct XcdSeg {
     int first_slot, prob, tile_off, count;
     int nsplit;       // reduction chunks of the problem (p.kchunk rows each); the segment's work items are chunk-major: item L = chunk
@@ -1617,8 +1824,23 @@ int launch_k128(const GemmB& p, hipStream_t st) {
     return p.Bl ? launch_k128_<F16, true>(p, st) : launch_k128_<F16, false>(p, st);
 }
 
+template <int NPASS, bool F16>
+int launch_small(const GemmB& p, hipStream_t st) {
+    constexpr int lds = 4 * (2 + (NPASS == 3 ? 1 : 0) + (NPASS >= 2 ? 1 : 0)) * 4096;
+    hipLaunchKernelGGL((gemm_small_kernel<NPASS, F16>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_gemm_bf16(32 x 32 tiles)");
+    return BMT_OK;
+}
+
 }  // namespace
 
+
+// products of at most this many outputs run on gemm_small_kernel (a build with -DBMT_SMALL_TILE_OUTPUTS=0 is the A/B arm without it:
+// tools/gpu_r5.sh ablib)
+#ifndef BMT_SMALL_TILE_OUTPUTS
+#define BMT_SMALL_TILE_OUTPUTS (3ll << 19)
+#endif
+extern "C" long long bmt_gemm_small_outputs(void) { return BMT_SMALL_TILE_OUTPUTS; }
 
 // validate the arguments and fill the kernel descriptor; splitk: in = 0 (decide here) / forced value, out = splits to launch
 static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool allow_split) {
@@ -1684,6 +1906,8 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     //           the Conv1d forward where that is at least one tile per CU
     //   pipe 3  the 256 x 256 ping-pong kernel: >= one round of its tiles, reduction >= 256, plain epilogue
     //   pipe 4  the weight-chunk-resident kernel: a reduction of exactly 128 over >= 2048 rows (the audio stream's projections)
+    //   pipe 5  32 x 32 tiles, one per workgroup, the reduction over its waves: three-pass and one-pass bf16 products of <= 1.5 M outputs
+    //           (a decoder layer's own GEMMs forward, and their dX with the weight plane transposed)
     p.bm = 128;
     p.pipe = 0;
     if (!a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->precision != BMT_PREC_BF16X3) p.pipe = 2;
@@ -1721,13 +1945,23 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         p.nk_rg = bmt_cdiv(units, upw); p.nk_upw = upw; p.tiles_n = nch;
         p.pipe = 4;
     }
+    // pipe 5: the three-pass product over few rows (a decoder layer's own GEMMs, the greedy decoder's): 32 x 32 tiles, reduction over the waves
+    if ((p.pipe == 0 || p.pipe == 2) && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->splitk <= 1 && (int64_t)a->M * a->N <= BMT_SMALL_TILE_OUTPUTS &&
+        (a->precision == BMT_PREC_BF16X3 || a->precision == BMT_PREC_BF16)) {      // (one bf16 pass: the small dX products, weight plane transposed)
+        // long reductions over few tiles: one 32 x 32 tile per workgroup, the reduction over its four waves; else 64 x 64 blocks
+        const int cols = p.Chi ? (p.plane_cols > a->N ? p.plane_cols : a->N) : a->N;
+        p.pipe = 5;
+        p.nk_rg = (a->Kpad >= 512 && bmt_cdiv(a->M, 32) * bmt_cdiv(cols, 32) <= 2 * bmt_device_cus()) ? 4 : 1;
+        p.bm = p.nk_rg == 4 ? 32 : 64;
+        p.tiles_n = bmt_cdiv(cols, p.bm);
+    }
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     const int bk = (a->precision == BMT_PREC_BF16X3 || (a->precision == BMT_PREC_F16W2 && p.pipe != 1)) ? 32 : 64;
     const int ktiles = a->Kpad / bk;
     const int tiles = p.tiles_m * p.tiles_n;
     // split-K (two passes through the workspace) for launches of fewer than 180 tiles with >= 12 stages: ~2 workgroups per CU, at least two
     // stages per split.  (Splitting the 200-tile products of the audio stream costs more in the workspace pass than their idle CUs.)
-    if (a->splitk == 0 && two_pass && tiles < 180 && ktiles >= 12 && p.pipe != 3 && p.pipe != 4) {
+    if (a->splitk == 0 && two_pass && tiles < 180 && ktiles >= 12 && p.pipe != 3 && p.pipe != 4 && p.pipe != 5) {
         int want = 512 / tiles, cap = ktiles / 2;
         if (want > 32) want = 32;
         splitk = want < cap ? want : cap;
@@ -1770,6 +2004,8 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
         rc = f16 ? launch_wide<true>(p, st_) : launch_wide<false>(p, st_);
     } else if (p.pipe == 4) {
         rc = f16 ? launch_k128<true>(p, st_) : launch_k128<false>(p, st_);
+    } else if (p.pipe == 5) {
+        rc = a->precision == BMT_PREC_BF16X3 ? launch_small<3, false>(p, st_) : launch_small<1, false>(p, st_);
     } else if (a->conv_mode == 1 && f16) {      // the Conv1d forward through the LDS-DMA ring (the A rows shift by a tap per step: one scalar offset)
         if (p.bm == 256) rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 2, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 2, false, false, 1>(p, splitk, st_);
         else rc = a->precision == BMT_PREC_F16W2 ? launch_pipe<2, true, 1, false, false, 1>(p, splitk, st_) : launch_pipe<1, true, 1, false, false, 1>(p, splitk, st_);

@@ -496,7 +496,8 @@ class _WeightPlanes:
     """operand planes of every weight that takes part in a GEMM ([N][pad64(K)], the plane set its site's precision needs), in
     persistent buffers, ALL refreshed by one multi-tensor launch the first time a weight is needed after the optimizer moved
     them (WEIGHT_EPOCH) -- instead of ~200 small launches.  The backward GEMMs read the bf16 hi plane k-major, so no transposed
-    copy of a weight exists."""
+    copy of a weight exists -- except for the weights of SMALL dX products (a decoder layer's own: get_t), whose row-major form runs
+    on the 32 x 32 tile kernel."""
 
     def __init__(self):
         self.entries = []          # [weakref(owner), key, Planes, fmt, version, detached W]
@@ -517,7 +518,7 @@ class _WeightPlanes:
     def _put(self, W, pl, fmt):
         import weakref
         owner = W._base if W._base is not None else W
-        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach()]
+        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach(), None]      # [6]: transposed bf16 plane [K][pad64(N)] (get_t), or None
         pos = self.index.get((id(owner), self._key(W)))
         if pos is not None and pos < len(self.entries) and self.entries[pos][0]() is owner:
             self.entries[pos] = entry          # re-registered (a new plane set, or now as a member of a group): same slot
@@ -591,7 +592,7 @@ class _WeightPlanes:
                 Wd, pl = e[5], e[2]
                 _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
                                                _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0),
-                                               None, None, 0),
+                                               _p(e[6]), None, e[6].stride(0) if e[6] is not None else 0),
                            "bmt_planes_desc")
             if self.table is not None:
                 self._retired.append((self.table, self.prefix))       # (a few KB each; appended entries leave the old table valid for its graph)
@@ -635,6 +636,34 @@ class _WeightPlanes:
         """the once-per-optimizer-step refresh of every registered weight's planes, now (on the current stream)"""
         if self.entries and (self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table):
             self._refresh_all()
+
+    def get_t(self, W):
+        """the transposed bf16 plane [K][pad64(N)] of a weight (the row-major B operand of a small dX = dY . W), refreshed with the others"""
+        self.get(W, "bwd")
+        e = self._entry(W)
+        if e[6] is None:
+            N, K = W.shape
+            e[6] = torch.zeros(K, _pad64(N), device=W.device, dtype=torch.bfloat16)
+            self.dirty_table = True
+            self._refresh_all()
+        return Planes(e[6], None, W.shape[1], W.shape[0])
+
+    def get_group_t(self, Ws):
+        """... of a fused projection group: [K][pad64(sum N)], member i in the column block of its rows in the group's planes"""
+        got = self.get_group(Ws, tuple(None for _ in Ws), "bwd")
+        if got is None:
+            return None
+        g = self.groups[tuple(id(W) for W in Ws)]
+        if g[5] is None or any(self._entry(W)[6] is None for W in Ws):
+            K, Nt = Ws[0].shape[1], sum(W.shape[0] for W in Ws)
+            g[5] = torch.zeros(K, _pad64(Nt), device=Ws[0].device, dtype=torch.bfloat16)
+            off = 0
+            for W in Ws:
+                self._entry(W)[6] = g[5][:, off:off + W.shape[0]]
+                off += W.shape[0]
+            self.dirty_table = True
+            self._refresh_all()
+        return Planes(g[5], None, Ws[0].shape[1], sum(W.shape[0] for W in Ws))
 
     def get(self, W, fmt):
         e = self._entry(W)
@@ -682,6 +711,21 @@ def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:
 
 
 FUSE_PROJECTIONS = True      # Q/K/V (self-attention) and K/V (cross-attention) projections as one GEMM each way
+
+
+SMALL_DX_OUTPUTS = int(lib.bmt_gemm_small_outputs())      # dX products of at most this many outputs run row-major on the 32 x 32 tile kernel (csrc/gemm_bf16.hip, pipe 5)
+
+
+def weight_planes_t(W: torch.Tensor) -> Planes:
+    with _weights.lock:
+        return _weights.get_t(W)
+
+
+def weight_group_t(Ws):
+    if not FUSE_PROJECTIONS:
+        return None
+    with _weights.lock:
+        return _weights.get_group_t(tuple(Ws))
 
 
 def weight_group(Ws, bs, fmt: str = "x3"):
@@ -854,8 +898,13 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     A = as_planes(dy, "bwd")
     if out is None and epi.get("out_planes") is None:
         out = torch.empty(A.rows, W.shape[1], device=W.device, dtype=torch.float32)
-    # (row-major dX through transposed weight planes was measured three times -- rounds 2, 3, 4 -- and never won in the step: DESIGN.md section 6)
-    gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
+    # (row-major dX through transposed weight planes was measured three times on the ENCODER's products -- rounds 2, 3, 4 -- and never won in
+    # the step: DESIGN.md section 6.  The decoder's, <= 1.5 M outputs each, are another regime: 24 ... 80 tiles of 128 x 128 with a split
+    # reduction and a second kernel against one launch of 32 x 32 tiles, round 5)
+    if A.rows * W.shape[1] <= SMALL_DX_OUTPUTS and W.dim() == 2 and W.is_contiguous():
+        gemm_bf16(A, weight_planes_t(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, **epi)
+    else:
+        gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
     return out if out is not None else epi["out_planes"]
 
 
@@ -1974,7 +2023,11 @@ class MHAFn(torch.autograd.Function):
             dx = None
             if need_dx:          # [Wq;Wk;Wv] as stored ([3D][d_in]): its row is the reduction index
                 dx = torch.empty(comb.rows, gst.cols, device=dy2.device, dtype=torch.float32)
-                gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
+                gT = weight_group_t(Ws) if comb.rows * gst.cols <= SMALL_DX_OUTPUTS else None
+                if gT is not None and comb.hi.shape[1] == gT.hi.shape[1]:      # small: row-major on the 32 x 32 tile kernel
+                    gemm_bf16(comb, gT, dx, ldc=dx.stride(0), precision=PREC_BF16)
+                else:
+                    gemm_bf16(comb, gst, dx, ldc=dx.stride(0), precision=PREC_BF16, b_km=True)
             gW = group_static_grad(Ws)
             if gW is not None:
                 linear_dw(comb, xT, into=gW, params=Ws)

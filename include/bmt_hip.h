@@ -126,6 +126,12 @@ int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
  * bmt_gemm_bf16_grouped_ws_bytes(nprob) bytes, 16-byte aligned, that must stay untouched until the launch has executed; it is
  * filled by kernels that carry the descriptors in their arguments, so the call can be captured in a hipGraph. */
 size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob);
+
+/* Products of at most this many outputs (M x N) with row-major operands in BMT_PREC_BF16X3 or BMT_PREC_BF16 and splitk 0 / 1 run on 32 x 32
+ * tiles, one per workgroup, with the reduction split over the workgroup's waves (one launch, no split-K workspace pass): a decoder layer's own
+ * nn.Linear products (model/decoders.py:60-95: 928 rows at configs[1]) and, with the weight's plane transposed, their dX.  A caller that
+ * keeps transposed weight planes for dX asks here which products qualify; 0 = the library was built without the kernel. */
+long long bmt_gemm_small_outputs(void);
 int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream);
 /* x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C): hi = bf16(x) and, optionally,
  * lo = bf16(x - hi) or (lo_f16) fp16(x) */

@@ -235,6 +235,51 @@ def test_gemm_epilogues(ops):
     assert_close(cs, res.double().sum(0), atol=1e-4, name="colsum")
 
 
+@pytest.mark.parametrize("M,N,K", [(928, 900, 300), (928, 300, 1024), (928, 300, 1200), (928, 1024, 300), (928, 1200, 300), (32, 1024, 300), (29, 10, 1500),
+                                   (928, 300, 600), (1, 300, 300)])
+def test_gemm_small_tiles_at_the_decoders_shapes(ops, M, N, K):
+    """the three-pass product of <= 1.5 M outputs runs on 32 x 32 tiles with the reduction split over a workgroup's waves
+    (gemm_small_kernel): every epilogue operation, both output forms and the column sums at the shapes of a decoder layer"""
+    x, W, b, res = rnd(M, K, seed=21), rnd(N, K, seed=22) * 0.2, rnd(N, seed=23), rnd(M, N, seed=24)
+    xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV)
+    base = x.double() @ W.double().t() + b.double()
+    t = tol(X3, K)
+    assert_close(ops.linear_fwd(xd, Wd, bd, precision=X3), base, name="plain", **t)
+    assert_close(ops.linear_fwd(xd, Wd, bd, relu=True, residual=rd, ldr=N, alpha=1.0, precision=X3), base.clamp(min=0) + res.double(), name="relu+residual", **t)
+    gate = (rnd(M, N, seed=25) > 0).float()
+    y = ops.linear_fwd(xd, Wd, None, gate=ops.make_planes(gate.to(DEV), "bwd"), gate_scale=0.5, precision=X3)
+    assert_close(y, (x.double() @ W.double().t()) * gate.double() * 0.5, name="gate", **t)
+    # planes + column sums without an fp32 output (a dX-style consumer)
+    A, Bw = ops.as_planes(xd, ops.act_fmt(X3)), ops.weight_planes(Wd, ops.weight_fmt(X3))
+    op = ops._alloc_planes(M, N, "x3", DEV, ld=ops._pad64(N))
+    op.hi.fill_(3.0)
+    op.lo.fill_(3.0)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm_bf16(A, Bw, None, bias=bd, out_planes=op, precision=X3, colsum=cs)
+    y = ops.linear_fwd(xd, Wd, bd, precision=X3)
+    assert torch.equal(op.hi[:, :N], y.to(torch.bfloat16))
+    assert_close(op.hi[:, :N].float().double() + op.lo[:, :N].float().double(), y, atol=1e-6, rtol=2e-5, name="hi+lo planes")
+    assert float(op.hi[:, N:].float().abs().max() if op.hi.shape[1] > N else 0.0) == 0.0
+    assert_close(cs, y.double().sum(0), atol=2e-3 * math.sqrt(M), rtol=1e-5, name="column sums")
+    # accumulate into an existing buffer
+    acc = rd.clone()
+    ops.gemm_bf16(A, Bw, acc, ldc=N, accum=True, precision=X3)
+    assert_close(acc, res.double() + x.double() @ W.double().t(), name="accumulate", **t)
+    # dropout: the same mask as the standalone kernel
+    ops.manual_seed(77)
+    plain = ops.linear_fwd(xd, Wd, None, precision=X3)
+    fused = ops.linear_fwd(xd, Wd, None, drop_post=True, drop_p=0.25, site=991, precision=X3)
+    assert torch.equal(fused, ops.dropout_raw(plain, 0.25, 991))
+    # dX = dY . W of the same layer: one bf16 pass, row-major through the weight's transposed plane (ops.weight_planes_t)
+    dy = rnd(M, N, seed=26)
+    dx = ops.linear_dx(ops.make_planes(dy.to(DEV), "bwd"), Wd)
+    assert_close(dx, bf16_round(dy).double() @ bf16_round(W).double(), atol=2e-4 * math.sqrt(N), rtol=1e-4, name="dx")
+    Wd.add_(1.0)                     # the transposed plane follows the weight (refreshed with the others after an optimizer step)
+    ops.weights_changed()
+    dx2 = ops.linear_dx(ops.make_planes(dy.to(DEV), "bwd"), Wd)
+    assert_close(dx2, bf16_round(dy).double() @ bf16_round(W + 1.0).double(), atol=4e-4 * math.sqrt(N), rtol=1e-4, name="dx after the weight moved")
+
+
 @pytest.mark.parametrize("prec", [X3, F16W2])
 def test_gemm_dropout_epilogue_matches_standalone(ops, prec):
     """the fused dropout epilogue and bmt_dropout share one RNG: same site => same mask."""

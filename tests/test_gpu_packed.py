@@ -76,7 +76,8 @@ GEMM_CASES = [  # (M, N, K, precision, kind) -- one per kernel family of the enc
     (8192, 1024, 1024, "w2", "fwd"),      # gemm_pipe_kernel, 256 x 128 tiles
     (25600, 128, 1024, "w2", "fwd"),      # gemm_pipe_kernel, 128-row tiles
     (8192, 1024, 4096, "f16", "fwd"),     # one fp16 plane (FFN-2 of a shallow encoder)
-    (928, 300, 600, "x3", "fwd"),         # the register-staged three-pass kernel + split-K epilogue
+    (928, 300, 600, "x3", "fwd"),         # gemm_small_kernel (32 x 32 tiles: the decoder's three-pass products)
+    (4000, 512, 600, "x3", "fwd"),        # the register-staged three-pass kernel + split-K epilogue
     (8192, 1024, 1024, "bwd", "dx"),      # dX = dY . W, the weight k-major
     (25600, 128, 1024, "bwd", "dx"),      # ... split over the reduction (few tiles)
     (8192, 1024, 4096, "bwd", "dxcs"),    # ... as a plane with its column sums (FFN-2's dX: the bias gradient of FFN-1)

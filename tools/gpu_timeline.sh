@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$TAG -o step -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-clock-probe > $R/gpurun_out/${TAG}_tl_run.log 2>&1; echo rc=$?
 cd $R
 f=$(find /tmp/tl_$TAG -name "*kernel_trace.csv" | head -1)
-python - "$f" > gpurun_out/${TAG}_timeline.txt <<'PY'
+python - "$f" gpurun_out/${TAG}_replay_dispatches.csv > gpurun_out/${TAG}_timeline.txt <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -51,6 +51,17 @@ print(f"# kernels from the replay's first launch to the end of the trace: {len(c
       f"(at::*, __amd_rocclr_*; the bench reads the loss back after the last replay: 2 copies that are not graph nodes)")
 for n_, c in sorted(cnt.items(), key=lambda kv: -dur[kv[0]]):
     print(f"#   {c:4d} x {n_:42s} {dur[n_] / 1e3:9.1f} us")
+# every dispatch of the replay: start / end relative to the first launch, queue, workgroups (the critical path is read off this list)
+with open(sys.argv[2], "w") as fo:
+    fo.write("start_us,end_us,dur_us,queue,workgroups,kernel\n")
+    q = {}
+    for r in last:
+        s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        g = lambda k: int(r.get(k, 1) or 1)
+        wg = (g("Grid_Size_X") * g("Grid_Size_Y") * g("Grid_Size_Z")) // max(1, g("Workgroup_Size_X") * g("Workgroup_Size_Y") * g("Workgroup_Size_Z"))
+        qi = q.setdefault(r.get("Queue_Id", "0"), len(q))
+        n = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0][:60]
+        fo.write(f"{s / 1e3:.2f},{e / 1e3:.2f},{(e - s) / 1e3:.2f},{qi},{wg},\"{n}\"\n")
 print("t_ms  busy  kernels_in_flight  workgroups_in_flight(capped 512/kernel)  top kernels")
 for k in range(nb):
     top = ", ".join(f"{n}:{v / BIN:.2f}" for n, v in names[k].most_common(3))
