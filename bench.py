@@ -97,8 +97,10 @@ class KernelTimer:
         def gemm_bf16_grouped(items):
             if not timer.enabled:
                 return raw_gg(items)
-            fl = sum(2.0 * A.cols * B.cols * A.rows for A, B, _ in items)
-            by = sum(2.0 * A.rows * (A.cols + B.cols) + 4.0 * A.cols * B.cols for A, B, _ in items)
+            fl = sum(2.0 * it[0].cols * it[1].cols * it[0].rows for it in items)
+            by = sum(2.0 * it[0].rows * (it[0].cols + it[1].cols) + 4.0 * it[0].cols * it[1].cols for it in items)
+            if len(items[0]) > 3:                  # the gradient of an encoder memory (ops.RawMemoryFn): one product per sample, packed output rows
+                return timer._timed("gemm_planes_memory_grad_grouped_bf16", 1, fl, by, lambda: raw_gg(items))
             return timer._timed("gemm_planes_dw_grouped_bf16", 1, fl, by, lambda: raw_gg(items))     # the step's weight gradients, one launch
 
         def attn_fwd_planes(q, k, v, B_, Sq, Sk, D, mask, H, **kw):
@@ -122,6 +124,17 @@ class KernelTimer:
                                 B_ * D * (2.0 * (Sq + 2 * Sk) + 6.0 * Sq + 2.0 * (Sq + 2 * Sk)),
                                 lambda: raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw))
 
+        raw_gbt = ops.gemm_batched
+
+        def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, *a, **kw):
+            if not timer.enabled:
+                return raw_gbt(prec, M, N, Kpad, nb_o, nb_i, *a, **kw)
+            nb, n = ops.prec_operand_bytes(prec), nb_o * nb_i
+            ob = (4.0 if kw.get("C_") else 0.0) + 2.0 * sum(kw.get(k) is not None for k in ("p1", "p2"))
+            return timer._timed("gemm_small_batched_" + ops.prec_name(prec), ops.prec_passes(prec), 2.0 * M * N * Kpad * n,
+                                n * (nb[0] * M * Kpad + nb[1] * N * Kpad + ob * M * N), lambda: raw_gbt(prec, M, N, Kpad, nb_o, nb_i, *a, **kw))
+
+        ops.gemm_batched = gemm_batched
         ops.gemm_bf16, ops.gemm_bf16_grouped = gemm_bf16, gemm_bf16_grouped
         ops.attn_fwd_planes, ops.attn_bwd_planes = attn_fwd_planes, attn_bwd_planes
 

@@ -26,7 +26,13 @@ class GemmBf16Args(C.Structure):
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32),
                 ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp),
-                ("rows_dev", vp)]
+                ("rows_dev", vp), ("c_row_dev", vp), ("m_dev", vp)]
+
+
+class GemmBatch(C.Structure):
+    _fields_ = [("nb_outer", i32), ("nb_inner", i32), ("a_off_o", i64), ("a_off_i", i64), ("b_off_o", i64), ("b_off_i", i64),
+                ("b_rows_dev", vp), ("c_off_o", i64), ("c_off_i", i64), ("p_off_o", i64), ("p_off_i", i64), ("p2_off_o", i64), ("p2_off_i", i64),
+                ("ldp2", i64), ("bias_off_i", i64), ("drop_off_o", i64), ("drop_off_i", i64)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -95,6 +101,10 @@ SIGNATURES = {
     "bmt_attn_kmean": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp, vp]),
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
     "bmt_gemm_small_outputs": (C.c_longlong, []),
+    "bmt_gemm_small_batched": (i32, [C.POINTER(GemmBf16Args), C.POINTER(GemmBatch), vp]),
+    "bmt_memory_transposed": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "bmt_raw_softmax_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp]),
+    "bmt_raw_softmax_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, i64, i64, vp]),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
     "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp, vp]),
     "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp, vp]),
@@ -187,8 +197,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 7:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 7")
+    if lib.bmt_version() != 8:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 8")
     _lib = lib
     return lib
 

@@ -55,6 +55,7 @@ struct GemmB {
     int nsplit;
     int nk_rg, nk_upw;                   // gemm_k128_kernel: row groups, 32-row units per row group
     int rows_is_k;                       // rows_dev bounds the REDUCTION (A k-major: a weight gradient), not the output rows
+    const int *c_row_dev, *m_dev;        // grouped launch, packed OUTPUT rows: C starts *c_row_dev rows lower, only *m_dev of the M rows exist
     const int* rows_dev;                 // packed rows (bmt_gemm_bf16_args.rows_dev): the rows actually present, in device memory; the launch is sized for M
                                          // (k-major A: for krows) and every kernel takes min(M, *rows_dev) -- graph-static grids over data-dependent extents
 };
@@ -225,6 +226,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     const int wi = w - g * per_group;
     const int tm = first_m + wi % gsz, tn = wi / gsz;
     const int m0 = tm * BM;
+    if constexpr (AKM) {
+        if (p.m_dev != nullptr) {            // (grouped launch: the output's rows are data too)
+            Mr = min(Mr, *p.m_dev);
+            if (m0 >= Mr) return;
+        }
+    }
     int n0_ = tn * BN;
     if constexpr (CONV == 2) {
         // Conv1d dW: output column block = (tap, 128 channels).  Walk the TAPS of one channel block before the next channel block, so that the
@@ -483,6 +490,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     // row / column test, six flag tests and a 64-bit index per accumulator register -- took 35 % of a K = 1024 product:
     // the probes of round 2.)
     if (p.flags == BMT_EPI_ACCUM && !p.Chi) {
+        float* const Cacc = p.c_row_dev ? p.C + (int64_t)(*p.c_row_dev) * p.ldc : p.C;
         // C += alpha * acc and nothing else (weight gradients, possibly several products into one buffer): atomics straight from the
         // accumulators -- 32 lanes of an instruction hit 32 consecutive floats of a row, which the L2 handles as one 128-byte request
 #pragma unroll
@@ -494,7 +502,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wr * 32 * TI + i * 32 + acc_row(r, half);
-                    if (row < Mr) atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+                    if (row < Mr) atomicAdd(Cacc + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
                 }
             }
         return;
@@ -1254,8 +1262,36 @@ do {                                                                            
 // the MFMA fragments straight from the planes -- lane (row, half) its own 16 bytes -- and was slower than the kernels it replaces:
 // 64 scattered 16-byte requests per instruction cost the texture path ~4x a coalesced one, profiles/r05_g_gemm_small_time.txt.)
 // Full epilogue, same order of operations as gemm_bf16_tile's.
+struct SmallBatch {                  // bmt_gemm_small_batched: product (o, i) = blockIdx.y / nb_inner, % nb_inner at these element offsets; nb_inner 0 = one product
+    int nb_inner;
+    int64_t a_off_o, a_off_i, b_off_o, b_off_i, c_off_o, c_off_i, p_off_o, p_off_i, p2_off_o, p2_off_i, ldp2, bias_off_i, drop_off_o, drop_off_i;
+    const int* b_rows_dev;
+};
+
 template <int NPASS, bool F16>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p) {
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const SmallBatch bt) {
+    GemmB p = p_;
+    int64_t drop_base = 0, ldp2 = p.ldp;
+    if (bt.nb_inner > 0) {
+        const int by = blockIdx.y, bo = by / bt.nb_inner, bi = by - bo * bt.nb_inner;
+        const int64_t ao = bo * bt.a_off_o + bi * bt.a_off_i;
+        int64_t bof = bo * bt.b_off_o + bi * bt.b_off_i;
+        if (bt.b_rows_dev != nullptr) {          // a packed memory: this sample's rows
+            const int r0 = bt.b_rows_dev[bo];
+            p.N = min(p.N, bt.b_rows_dev[bo + 1] - r0);
+            bof += (int64_t)r0 * p.ldb;
+        }
+        p.Ah += ao; p.Bh += bof;
+        if (p.Al) p.Al += ao;
+        if (p.Bl) p.Bl += bof;
+        if (p.C) p.C += bo * bt.c_off_o + bi * bt.c_off_i;
+        if (p.Chi) p.Chi += bo * bt.p_off_o + bi * bt.p_off_i;
+        if (p.Clo) p.Clo += bo * bt.p2_off_o + bi * bt.p2_off_i;
+        if (bt.ldp2) ldp2 = bt.ldp2;
+        if (p.bias) p.bias += bi * bt.bias_off_i;
+        if (p.colsum) p.colsum += bi * bt.bias_off_i;
+        drop_base = bo * bt.drop_off_o + bi * bt.drop_off_i;
+    }
     constexpr bool ALO = NPASS == 3, BLO = NPASS >= 2;
     constexpr int NPL = 2 + (ALO ? 1 : 0) + (BLO ? 1 : 0);       // planes staged per chunk: A hi | B hi | [A lo] | [B lo]
     constexpr int WBYTES = NPL * 4096;                            // a wave's area: [plane][32 rows][8 slots of 16 B], swizzled (slot_of<8>)
@@ -1268,7 +1304,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p) {
     const bool ksplit = p.nk_rg == 4;
     const int bm = blockIdx.x % p.tiles_m, bn = blockIdx.x / p.tiles_m;
     const int m0 = ksplit ? bm * 32 : bm * 64 + 32 * (wid >> 1), n0 = ksplit ? bn * 32 : bn * 64 + 32 * (wid & 1);
-    if ((ksplit ? m0 : bm * 64) >= Mr) return;                    // (whole workgroup)
+    if ((ksplit ? m0 : bm * 64) >= Mr || (ksplit && n0 >= ncols)) return;      // (whole workgroup)
     if (!ksplit && (m0 >= Mr || n0 >= ncols)) return;             // a wave of the 64 x 64 block past the extents: it shares nothing
     const int nch = p.Kpad / 64, per = ksplit ? (nch + 3) / 4 : nch;
     const int c0 = ksplit ? wid * per : 0, c1 = min(nch, c0 + per);
@@ -1371,7 +1407,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p) {
         for (int q = 0; q < 8; ++q) v[q] = v[q] * p.alpha + bv[q];
         if (f & BMT_EPI_DROP_PRE) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(drop_base + idx + q));
         }
         if (f & BMT_EPI_RELU) {
 #pragma unroll
@@ -1379,7 +1415,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p) {
         }
         if (f & BMT_EPI_DROP_POST) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(idx + q));
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(dc, v[q], (uint64_t)(drop_base + idx + q));
         }
         if (f & BMT_EPI_GATE) {            // keep an element iff the saved forward output is non-zero (sign bit ignored)
             const uint16_t* gp = p.gate + (int64_t)row * p.ldg + col;
@@ -1421,16 +1457,16 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p) {
                 l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
                 if (p.hi_f16) h[q] = pack_h2(v[2 * q], v[2 * q + 1]);
             }
-            const int64_t pi = (int64_t)row * p.ldp + col;
+            const int64_t pi = (int64_t)row * p.ldp + col, pi2 = (int64_t)row * ldp2 + col;
             if (p.plane_vec) {
                 *reinterpret_cast<u32x4*>(p.Chi + pi) = h;
-                if (p.Clo) *reinterpret_cast<u32x4*>(p.Clo + pi) = l;
+                if (p.Clo) *reinterpret_cast<u32x4*>(p.Clo + pi2) = l;
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     if (col + q < pcols) {
                         p.Chi[pi + q] = (uint16_t)(h[q >> 1] >> (16 * (q & 1)));
-                        if (p.Clo) p.Clo[pi + q] = (uint16_t)(l[q >> 1] >> (16 * (q & 1)));
+                        if (p.Clo) p.Clo[pi2 + q] = (uint16_t)(l[q >> 1] >> (16 * (q & 1)));
                     }
             }
         }
@@ -1825,9 +1861,11 @@ int launch_k128(const GemmB& p, hipStream_t st) {
 }
 
 template <int NPASS, bool F16>
-int launch_small(const GemmB& p, hipStream_t st) {
+int launch_small(const GemmB& p, hipStream_t st, const SmallBatch* bt = nullptr, int nbatch = 1) {
     constexpr int lds = 4 * (2 + (NPASS == 3 ? 1 : 0) + (NPASS >= 2 ? 1 : 0)) * 4096;
-    hipLaunchKernelGGL((gemm_small_kernel<NPASS, F16>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    SmallBatch none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((gemm_small_kernel<NPASS, F16>), dim3(p.tiles_m * p.tiles_n, nbatch), dim3(256), lds, st, p, bt ? *bt : none);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(32 x 32 tiles)");
     return BMT_OK;
 }
@@ -1895,6 +1933,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     p.plane_vec = p.Chi && al16(p.Chi) && (!p.Clo || al16(p.Clo)) && (a->ldp % 8 == 0) && (p.plane_cols % 8 == 0);
     p.M = a->M; p.N = a->N; p.Kpad = a->Kpad; p.krows = a->K;
     p.rows_dev = a->rows_dev; p.rows_is_k = a->a_kmajor != 0;
+    p.c_row_dev = a->c_row_dev; p.m_dev = a->m_dev;
     p.conv_cin = a->conv_cin; p.conv_rows = a->conv_rows; p.conv_S = a->conv_S > 0 ? a->conv_S : 1; p.conv_halo = a->conv_halo;
     // Conv1d dW: the taps of a channel block before the next channel block (halves the launch's HBM fetch, profiles/r04_x_ab_conv_dw_order.txt)
     p.conv_tap_minor = (a->conv_mode == 2 && a->conv_cin % BN == 0) ? 1 : 0;
@@ -1991,6 +2030,7 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     int splitk = 0;
     int rc = gemm_prepare(a, p, splitk, true);
     if (rc != BMT_OK) return rc;
+    BMT_CHECK_ARG(!a->c_row_dev && !a->m_dev, "bmt_gemm_bf16: c_row_dev / m_dev belong to bmt_gemm_bf16_grouped");
     hipStream_t st_ = (hipStream_t)stream;
     const bool akm = a->a_kmajor != 0, bkm = a->b_kmajor != 0;
     const bool f16 = a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_F16W2;
@@ -2040,10 +2080,45 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
     return BMT_OK;
 }
 
+extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gemm_batch* b, void* stream) {
+    BMT_CHECK_ARG(a && b && b->nb_outer > 0 && b->nb_inner > 0 && (int64_t)b->nb_outer * b->nb_inner <= 65535, "bmt_gemm_small_batched: bad batch");
+    BMT_CHECK_ARG(BMT_SMALL_TILE_OUTPUTS > 0, "bmt_gemm_small_batched: the library was built without the 32 x 32 tile kernel");
+    BMT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->splitk <= 1 && !a->rows_dev && !a->c_row_dev && !a->m_dev &&
+                      !(a->flags & (BMT_EPI_RESIDUAL | BMT_EPI_GATE | BMT_EPI_ACCUM)),
+                  "bmt_gemm_small_batched: row-major operands, no split, no residual / gate / accumulate");
+    BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_BF16X3,
+                  "bmt_gemm_small_batched: BMT_PREC_BF16, BMT_PREC_F16 or BMT_PREC_BF16X3");
+    GemmB p;
+    int splitk = 1;
+    int rc = gemm_prepare(a, p, splitk, false);
+    if (rc != BMT_OK) return rc;
+    // every product writes exactly its N columns (a neighbour's may follow); 16-byte plane stores need aligned offsets
+    if (p.Chi) p.plane_cols = a->N;
+    const int64_t ldp2 = b->ldp2 ? b->ldp2 : a->ldp;
+    p.plane_vec = p.plane_vec && (a->N % 8 == 0) && (ldp2 % 8 == 0) && !((b->p_off_o | b->p_off_i | b->p2_off_o | b->p2_off_i) & 7);
+    const int cols = a->N, nb = b->nb_outer * b->nb_inner;
+    p.pipe = 5;
+    p.nk_rg = (a->Kpad >= 512 && (int64_t)bmt_cdiv(a->M, 32) * bmt_cdiv(cols, 32) * nb <= 4 * bmt_device_cus()) ? 4 : 1;
+    p.bm = p.nk_rg == 4 ? 32 : 64;
+    p.tiles_m = bmt_cdiv(a->M, p.bm);
+    p.tiles_n = bmt_cdiv(cols, p.bm);
+    SmallBatch bt;
+    bt.nb_inner = b->nb_inner;
+    bt.a_off_o = b->a_off_o; bt.a_off_i = b->a_off_i; bt.b_off_o = b->b_off_o; bt.b_off_i = b->b_off_i;
+    bt.c_off_o = b->c_off_o; bt.c_off_i = b->c_off_i; bt.p_off_o = b->p_off_o; bt.p_off_i = b->p_off_i;
+    bt.p2_off_o = b->p2_off_o; bt.p2_off_i = b->p2_off_i; bt.ldp2 = b->ldp2;
+    bt.bias_off_i = b->bias_off_i; bt.drop_off_o = b->drop_off_o; bt.drop_off_i = b->drop_off_i;
+    bt.b_rows_dev = b->b_rows_dev;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->precision == BMT_PREC_BF16X3) return launch_small<3, false>(p, st, &bt, nb);
+    if (a->precision == BMT_PREC_F16) return launch_small<1, true>(p, st, &bt, nb);
+    return launch_small<1, false>(p, st, &bt, nb);
+}
+
 // ---- grouped launch (see gemm_bf16_grouped_kernel).  The descriptor table and the per-XCD segment lists live in device memory
 // and are written by small kernels whose ARGUMENTS carry them: nothing is read from host memory when the launch executes, so the
 // sequence can be captured in a hipGraph and replayed (a memcpy node would re-read a host buffer that may have changed).
-constexpr int GEMM_PACK_N = 13;      // descriptors per table-writer launch (they travel in its kernel arguments)
+constexpr int GEMM_PACK_N = 12;      // descriptors per table-writer launch (they travel in its kernel arguments)
 struct GemmPack {
     GemmB d[GEMM_PACK_N];
     int n, base;

@@ -84,7 +84,9 @@ class _LayerMemories(tuple):
 
     def __new__(cls, Av, Va, n):
         self = super().__new__(cls, (Av, Va))
-        self._pairs = list(zip(ops.fanout(Av, n), ops.fanout(Va, n)))
+        # (a memory prepared for the reassociated cross-attention hands its gradient over in its own node, ops.RawMemoryFn: no aliases)
+        al = lambda x: (x,) * n if getattr(x, "_bmt_rawmem", None) is not None else ops.fanout(x, n)
+        self._pairs = list(zip(al(Av), al(Va)))
         return self
 
     def take(self):
@@ -112,6 +114,13 @@ class BiModelDecoder(nn.Module):
 
     def forward(self, x, masks):
         C0, (Av, Va) = x
+        layers = self.decoder.layers
+        if Av.is_cuda and len(layers) > 0 and isinstance(layers[0], BiModalDecoderLayer):
+            # the layers' cross-attentions against the raw memories (29 queries per sample: the key / value projections reassociated onto
+            # the queries, ops.RawCrossAttnFn) where the memories are packed; otherwise the memories come back as they are
+            Av = ops.raw_memory(Av, len(layers), layers[0].enc_att_A.H, C0.shape[1], ops.policy_of(layers[0].enc_att_A))
+            Va = ops.raw_memory(Va, len(layers), layers[0].enc_att_V.H, C0.shape[1], ops.policy_of(layers[0].enc_att_V))
+            x = (C0, (Av, Va))
         if Av.is_cuda and torch.is_grad_enabled() and len(self.decoder.layers) > 1 and ops.context().kv_cache is None:
             # one alias pair of the memories per layer: the layers' gradients w.r.t. a memory are added by library launches in one node
             x = (C0, _LayerMemories(Av, Va, len(self.decoder.layers)))

@@ -79,8 +79,10 @@ class MultiheadedAttention(nn.Module):
                 self.linear_V2d.weight, self.linear_V2d.bias,
                 self.linear_d2Q.weight, self.linear_d2Q.bias,
                 self.H, p, self._site, pol)
+        # a decoder layer's attention over an encoder memory that came prepared for the reassociated form (ops.raw_memory): no key / value projections
+        fn = ops.RawCrossAttnFn if (K is V and ops.raw_form_ok(getattr(K, "_bmt_rawmem", None), Q, self, pol)) else ops.MHAFn
         off = ops.take_residual()        # an enclosing ResidualConnection offers x, p, site: fused into the out-projection
         if off is None:
-            return ops.MHAFn.apply(*args, None, 0.0, 0, None)
-        off.out = ops.MHAFn.apply(*args, off.x, off.p, off.site, off.planes_fmt)
+            return fn.apply(*args, None, 0.0, 0, None)
+        off.out = fn.apply(*args, off.x, off.p, off.site, off.planes_fmt)
         return off.out

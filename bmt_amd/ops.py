@@ -518,7 +518,7 @@ class _WeightPlanes:
     def _put(self, W, pl, fmt):
         import weakref
         owner = W._base if W._base is not None else W
-        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach(), None]      # [6]: transposed bf16 plane [K][pad64(N)] (get_t), or None
+        entry = [weakref.ref(owner), self._key(W), pl, fmt, None, W.detach(), None, None]      # [6], [7]: transposed bf16 planes hi, lo [K][pad64(N)] (get_t), or None
         pos = self.index.get((id(owner), self._key(W)))
         if pos is not None and pos < len(self.entries) and self.entries[pos][0]() is owner:
             self.entries[pos] = entry          # re-registered (a new plane set, or now as a member of a group): same slot
@@ -592,7 +592,7 @@ class _WeightPlanes:
                 Wd, pl = e[5], e[2]
                 _lib.check(lib.bmt_planes_desc(C.c_void_p(host[i].data_ptr()), _p(Wd), Wd.stride(0), Wd.shape[0], Wd.shape[1],
                                                _p(pl.hi), _p(pl.lo), _p(pl.fh), _p(pl.fl), pl.any.stride(0),
-                                               _p(e[6]), None, e[6].stride(0) if e[6] is not None else 0),
+                                               _p(e[6]), _p(e[7]), e[6].stride(0) if e[6] is not None else 0),
                            "bmt_planes_desc")
             if self.table is not None:
                 self._retired.append((self.table, self.prefix))       # (a few KB each; appended entries leave the old table valid for its graph)
@@ -637,33 +637,46 @@ class _WeightPlanes:
         if self.entries and (self.fresh_epoch != WEIGHT_EPOCH[0] or self.dirty_table):
             self._refresh_all()
 
-    def get_t(self, W):
-        """the transposed bf16 plane [K][pad64(N)] of a weight (the row-major B operand of a small dX = dY . W), refreshed with the others"""
-        self.get(W, "bwd")
+    def get_t(self, W, lo=False):
+        """the transposed bf16 plane(s) [K][pad64(N)] of a weight (the row-major B operand of a small dX = dY . W; with ``lo`` the split pair of a
+        three-pass product against W^T), refreshed with the others"""
+        self.get(W, "x3" if lo else "bwd")
         e = self._entry(W)
-        if e[6] is None:
+        if e[6] is None or (lo and e[7] is None):
+            if e[2].any._base is not None:
+                raise RuntimeError("weight planes: transposed planes of a member of a fused projection group: ask the group (get_group_t)")
             N, K = W.shape
-            e[6] = torch.zeros(K, _pad64(N), device=W.device, dtype=torch.bfloat16)
+            if e[6] is None:
+                e[6] = torch.zeros(K, _pad64(N), device=W.device, dtype=torch.bfloat16)
+            if lo and e[7] is None:
+                e[7] = torch.zeros(K, _pad64(N), device=W.device, dtype=torch.bfloat16)
             self.dirty_table = True
             self._refresh_all()
-        return Planes(e[6], None, W.shape[1], W.shape[0])
+        return Planes(e[6], e[7] if lo else None, W.shape[1], W.shape[0])
 
-    def get_group_t(self, Ws):
+    def get_group_t(self, Ws, lo=False, bs=None, fmt="bwd"):
         """... of a fused projection group: [K][pad64(sum N)], member i in the column block of its rows in the group's planes"""
-        got = self.get_group(Ws, tuple(None for _ in Ws), "bwd")
+        got = self.get_group(Ws, tuple(None for _ in Ws) if bs is None else tuple(bs), "x3" if lo else fmt)
         if got is None:
             return None
         g = self.groups[tuple(id(W) for W in Ws)]
-        if g[5] is None or any(self._entry(W)[6] is None for W in Ws):
+        while len(g) < 8:
+            g.append(None)
+        if g[5] is None or (lo and g[7] is None) or any(self._entry(W)[6] is None or (lo and self._entry(W)[7] is None) for W in Ws):
             K, Nt = Ws[0].shape[1], sum(W.shape[0] for W in Ws)
-            g[5] = torch.zeros(K, _pad64(Nt), device=Ws[0].device, dtype=torch.bfloat16)
+            if g[5] is None:
+                g[5] = torch.zeros(K, _pad64(Nt), device=Ws[0].device, dtype=torch.bfloat16)
+            if lo and g[7] is None:
+                g[7] = torch.zeros(K, _pad64(Nt), device=Ws[0].device, dtype=torch.bfloat16)
             off = 0
             for W in Ws:
-                self._entry(W)[6] = g[5][:, off:off + W.shape[0]]
+                e = self._entry(W)
+                e[6] = g[5][:, off:off + W.shape[0]]
+                e[7] = g[7][:, off:off + W.shape[0]] if g[7] is not None else None
                 off += W.shape[0]
             self.dirty_table = True
             self._refresh_all()
-        return Planes(g[5], None, Ws[0].shape[1], sum(W.shape[0] for W in Ws))
+        return Planes(g[5], g[7] if lo else None, Ws[0].shape[1], sum(W.shape[0] for W in Ws))
 
     def get(self, W, fmt):
         e = self._entry(W)
@@ -721,11 +734,11 @@ def weight_planes_t(W: torch.Tensor) -> Planes:
         return _weights.get_t(W)
 
 
-def weight_group_t(Ws):
+def weight_group_t(Ws, lo=False, bs=None):
     if not FUSE_PROJECTIONS:
         return None
     with _weights.lock:
-        return _weights.get_group_t(tuple(Ws))
+        return _weights.get_group_t(tuple(Ws), lo=lo, bs=bs)
 
 
 def weight_group(Ws, bs, fmt: str = "x3"):
@@ -901,7 +914,7 @@ def linear_dx(dy, W: torch.Tensor, out: Optional[torch.Tensor] = None, **epi):
     # (row-major dX through transposed weight planes was measured three times on the ENCODER's products -- rounds 2, 3, 4 -- and never won in
     # the step: DESIGN.md section 6.  The decoder's, <= 1.5 M outputs each, are another regime: 24 ... 80 tiles of 128 x 128 with a split
     # reduction and a second kernel against one launch of 32 x 32 tiles, round 5)
-    if A.rows * W.shape[1] <= SMALL_DX_OUTPUTS and W.dim() == 2 and W.is_contiguous():
+    if A.rows * W.shape[1] <= SMALL_DX_OUTPUTS and W.dim() == 2 and W.is_contiguous() and W.shape[0] <= 2048:      # (the generator's dX reduces over the vocabulary: split)
         gemm_bf16(A, weight_planes_t(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, **epi)
     else:
         gemm_bf16(A, weight_planes(W, "bwd"), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, b_km=True, **epi)
@@ -922,7 +935,10 @@ def gemm_bf16_grouped(items):
     """items: [(dY planes [rows][N_out], X planes [rows][K_in], dW fp32 [N_out][K_in] accumulated in place)] -> one launch"""
     n = len(items)
     arr = (GemmBf16Args * n)()
-    for a, (A, B, Cm) in zip(arr, items):
+    for a, item in zip(arr, items):
+        A, B, Cm = item[:3]
+        if len(item) > 3:              # (first output row, rows that exist) in device memory: the product's output is a packed row range
+            a.c_row_dev, a.m_dev = item[3]
         rows = A.rows
         assert B.rows == rows, (A.rows, B.rows)
         a.A_hi, a.lda, a.B_hi, a.ldb = A.hi.data_ptr(), A.hi.stride(0), B.hi.data_ptr(), B.hi.stride(0)
@@ -2342,6 +2358,297 @@ def cat2(a, b):
     if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[:-1] == b.shape[:-1]:
         return Cat2Fn.apply(a, b)
     return torch.cat([a, b], dim=-1)
+
+
+# ----------------------------------------------------------------------------- cross-attention against the RAW encoder memory
+# model/multihead_attention.py:62-84 projects the encoder memory X (6 242 + 19 508 valid rows at configs[1]) to keys and values in every
+# decoder layer -- the only large products of the decoder, their dX and a share of the weight-gradient launch behind them -- for 29 queries
+# per sample.  With so few queries the products reassociate:
+#     S_h = q_h K_h^T = (q_h W_k,h) X^T   (+ q_h . b_k: constant along the keys, the softmax does not see it)
+#     O_h = P_h V_h   = (P_h X) W_v,h^T + b_v
+# so the attention runs against X itself (one key / value plane for all heads, width d_memory) and K, V, dK, dV never exist.  Everything is
+# a small product on the 32 x 32 tile kernel (bmt_gemm_small_batched, batch = (sample, head)), with the softmax as its own pass between
+# them; the memory's gradient, sum over layers and heads of dS^T Q' + P^T dO', is ONE product per sample at the end of the decoder's
+# backward (reduction over (layer, kind, head, query): the two operand stacks are laid out for it).  Operand formats (the study of
+# tests/study_cross_attention_reassociation.py): the per-head block products q_h W_k,h and (P_h X) W_v,h^T split-bf16 (three passes), the two
+# products against the memory one fp16 pass, backward one bf16 pass.  RAW_MEMORY switch: "0" = keys and values are projected, as before.
+RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
+
+
+class RawMemoryState:
+    """what the decoder layers share about ONE encoder memory during a step: its packed planes, the transposed per-sample copies, and the two
+    operand stacks of the memory's gradient -- A [B][L][2][H][32][Skp] (kind 0: dS, kind 1: P), Bk [B][L][2][H][32][dm] (kind 0: Q' = q W_k,
+    kind 1: dO'), bf16, rows t >= Tq zero."""
+    __slots__ = ("pack", "x", "B", "S", "dm", "L", "H", "Tq", "Skp", "xt_f16", "xtc_bf", "astack", "bstack", "next_layer", "events", "used")
+
+    def a_block(self, l, kind):          # element offset of (b = 0, l, kind, h = 0) in the A stack; strides (sample, head)
+        return ((l * 2 + kind) * self.H) * 32 * self.Skp, self.L * 2 * self.H * 32 * self.Skp, 32 * self.Skp
+
+    def b_block(self, l, kind):
+        return ((l * 2 + kind) * self.H) * 32 * self.dm, self.L * 2 * self.H * 32 * self.dm, 32 * self.dm
+
+    def tensors(self):
+        return [t for t in (self.xt_f16, self.xtc_bf, self.astack, self.bstack, self.x.hi, self.x.fh) if t is not None]
+
+
+def _addr(t: torch.Tensor, elems: int = 0) -> int:
+    return t.data_ptr() + elems * t.element_size()
+
+
+def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, ah, al, lda, bh, bl, ldb, *, a_off=(0, 0), b_off=(0, 0), b_rows=None, C_=None, ldc=0, c_off=(0, 0),
+                 p1=None, p2=None, p2_f16=False, ldp=0, p_off=(0, 0), ldp2=0, p2_off=None, bias=None, bias_off_i=0, colsum=None, alpha=1.0,
+                 drop_p=0.0, site=0, drop_off=(0, 0)):
+    """nb_o x nb_i small products of one shape in one launch (bmt_gemm_small_batched).  ah / al / bh / bl / C_ / p1 / p2: ADDRESSES (ints;
+    ``_addr``) of product (0, 0)'s operands and outputs; x_off = (per outer index, per inner index) element offsets."""
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_DROP_POST if drop_p > 0.0 else 0)
+    a = GemmBf16Args(ah, al, lda, bh, bl, ldb, C_, ldc, p1, None if p2_f16 else p2, ldp, M, N, Kpad, alpha, flags,
+                     _p(bias), None, 0, None, 0, 1.0, drop_p, _p(rng_tensor()) if drop_p > 0.0 else None, site, prec, 1)
+    if p2_f16:
+        a.C_f16 = p2
+    a.colsum = _p(colsum)
+    p2_off = p_off if p2_off is None else p2_off
+    bt = _lib.GemmBatch(nb_o, nb_i, a_off[0], a_off[1], b_off[0], b_off[1], b_rows, c_off[0], c_off[1], p_off[0], p_off[1], p2_off[0], p2_off[1], ldp2,
+                        bias_off_i, drop_off[0], drop_off[1])
+    _lib.check(lib.bmt_gemm_small_batched(C.byref(a), C.byref(bt), _st()), "bmt_gemm_small_batched")
+
+
+def raw_form_ok(st: "RawMemoryState", Q, mha, pol) -> bool:
+    """does this MultiheadedAttention call fit the reassociated form the state was prepared for?"""
+    return (st is not None and Q.dim() == 3 and Q.shape[0] == st.B and Q.shape[1] == st.Tq and mha.H == st.H and mha.d_model_K == st.dm and
+            mha.d_model % mha.H == 0 and (mha.d_model // mha.H) % 64 == 0 and pol.gemm == PREC_BF16X3 and pol.attn == PREC_F16 and
+            (not torch.is_grad_enabled() or st.astack is not None or not (Q.requires_grad or mha.linear_Q2d.weight.requires_grad)))
+
+
+def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> torch.Tensor:
+    """``mem`` (a packed encoder memory) as the decoder layers' key / value input for the reassociated cross-attention: an alias that carries the
+    step's RawMemoryState, or ``mem`` itself where the form does not apply (not packed, more than 32 queries, inference, another operand
+    policy than split-bf16 products around fp16 attention, switched off)"""
+    pk = pack_of(mem)
+    if pol is not None and not (pol.gemm == PREC_BF16X3 and pol.attn == PREC_F16):
+        return mem
+    if not torch.is_grad_enabled():      # inference projects keys and values: greedy decoding computes them once per caption (ops.mha_infer), and a
+        return mem                       # full forward pass under no_grad runs the same kernels as that cached form (tests/test_gpu_model.py)
+    if not (RAW_MEMORY and SMALL_DX_OUTPUTS > 0 and pk is not None and isinstance(mem, torch.Tensor) and mem.is_cuda and mem.dim() == 3 and
+            mem.dtype == torch.float32 and mem.shape[-1] % 64 == 0 and 0 < Tq <= 32 and n_layers > 0 and context().kv_cache is None):
+        return mem
+    B, S, dm = mem.shape
+    x = planes_of(mem, "f16")
+    if x is None:
+        _need_fp32(mem)
+        x = make_planes(_f32c(mem).view(-1, dm), "f16", pack=pk)
+        attach_planes(mem, x)
+    if x.pack is not pk:
+        return mem
+    st = RawMemoryState()
+    st.pack, st.x, st.B, st.S, st.dm, st.L, st.H, st.Tq, st.Skp = pk, x, B, S, dm, n_layers, H, Tq, _pad64(S)
+    st.next_layer, st.events, st.used = 0, [], False
+    train = mem.requires_grad and torch.is_grad_enabled()
+    dev = mem.device
+    st.xt_f16 = torch.empty(B, dm, st.Skp, device=dev, dtype=torch.float16)
+    st.xtc_bf = torch.empty(B, dm, st.Skp, device=dev, dtype=torch.bfloat16) if train else None
+    mean = torch.empty(B, dm, device=dev, dtype=torch.float32) if train else None
+    _lib.check(lib.bmt_memory_transposed(_p(x.fh), x.fh.stride(0), pk.off_ptr, B, dm, st.Skp, _p(st.xt_f16), _p(st.xtc_bf), _p(mean), _st()),
+               "bmt_memory_transposed")
+    st.astack = torch.empty(B, n_layers, 2, H, 32, st.Skp, device=dev, dtype=torch.bfloat16) if train else None
+    st.bstack = zero_(torch.empty(B, n_layers, 2, H, 32, dm, device=dev, dtype=torch.bfloat16))       # rows t >= Tq are never written: finite zeros
+    out = RawMemoryFn.apply(mem, st) if train else mem.view_as(mem)
+    carry_pack(pk, out)
+    attach_planes(out, x)
+    out._bmt_rawmem = st
+    return out
+
+
+class RawMemoryFn(torch.autograd.Function):
+    """memory -> its alias for the decoder layers; backward: the memory's gradient from the operand stacks the layers' backward passes filled,
+    dX_b = sum over (layer, kind, head, query) of A_b[.]^T Bk_b[.] -- one product per sample, reduction 2 L H 32, written into the packed rows
+    of sample b (bmt_gemm_bf16_grouped with the output's first row and row count in device memory)"""
+
+    @staticmethod
+    def forward(ctx, mem, st):
+        ctx.st = st
+        ctx.set_materialize_grads(False)
+        return mem.view_as(mem)
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        cur = torch.cuda.current_stream()
+        for ev in st.events:             # the layers' backward passes ran on their forward's streams and hand nothing over through autograd
+            cur.wait_event(ev)
+        st.events = []
+        if not st.used:
+            return g, None
+        for t in st.tensors():
+            t.record_stream(cur)
+        B, S, dm, K = st.B, st.S, st.dm, st.L * 2 * st.H * 32
+        dmem = zero_(torch.empty(B, S, dm, device=st.astack.device, dtype=torch.float32))
+        A2, B2, out2 = st.astack.view(B, K, st.Skp), st.bstack.view(B, K, dm), dmem.view(B * S, dm)
+        off = st.pack.off.data_ptr()
+        items = [(Planes(A2[b], None, K, S), Planes(B2[b], None, K, dm), out2, (off + 4 * b, off + 4 * (B + 1 + b))) for b in range(B)]
+        gemm_bf16_grouped(items)
+        if g is not None:                # (a consumer outside the reassociated form read the alias too)
+            a, b_ = _f32c(dmem), _f32c(g)
+            _lib.check(lib.bmt_add(_p(a), _p(b_), _p(a), a.numel(), _st()), "bmt_add")
+        return dmem, None
+
+
+def _blockdiag_dw(dy: Planes, x: Planes, W: torch.Tensor, H: int):
+    """dW[h] = dy[:, h-th column block]^T . x[:, h-th column block] for the H row blocks of W: into its static gradient buffer (returns None), or
+    as a tensor"""
+    gW = static_grad(W)
+    tgt = gW if gW is not None else torch.zeros_like(W)
+    nb, kb, M = W.shape[0] // H, x.cols // H, dy.rows
+    for h in range(H):
+        linear_dw(Planes(dy.hi[:, h * nb:(h + 1) * nb], None, M, nb), Planes(x.hi[:, h * kb:(h + 1) * kb], None, M, kb), into=tgt[h * nb:(h + 1) * nb],
+                  params=(W,) if gW is not None else ())
+    if gW is not None:
+        grad_done(W)
+        return None
+    return tgt
+
+
+class RawCrossAttnFn(torch.autograd.Function):
+    """MultiheadedAttention.forward (model/multihead_attention.py:55-86) for a decoder layer's attention over an encoder memory, in the
+    reassociated form above.  Same arguments as MHAFn (K is V: the RawMemoryState-carrying alias of the memory)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, pol, res=None, res_p=0.0, res_site=0, out_fmt=None):
+        st = K._bmt_rawmem
+        note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        Qc = _f32c(Q)
+        B, Tq, Dq = Qc.shape
+        D, dm, Skp, dk = Wq.shape[0], st.dm, st.Skp, Wq.shape[0] // H
+        M = B * Tq
+        dev = Qc.device
+        l = st.next_layer
+        st.next_layer += 1
+        st.used = True
+        cur = torch.cuda.current_stream()
+        for t in st.tensors():
+            t.record_stream(cur)
+        X3 = PREC_BF16X3
+        Qp = planes_of(Q, "x3")
+        if Qp is None:
+            _need_fp32(Q)
+            Qp = make_planes(Qc.view(-1, Dq), "x3")
+            attach_planes(Q, Qp)
+        q = linear_fwd_planes(Qp, Wq, bq, precision=X3, out_fmt="x3")                         # [M][D] hi + lo
+        # the memory's two projections as one weight group (what the projected form and greedy decoding register too): member planes
+        grp, _ = weight_group((Wk, Wv), (bk, bv), "x3")
+        gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))                                 # [dm][2 D] hi + lo: columns [0, D) = W_k^T
+        train = any(ctx.needs_input_grad[:3]) or Wq.requires_grad
+        # Q'[(b, t)][h dm + d] = q_h W_k,h: fp16 (the A operand of S) in the natural layout, bf16 into the B stack (b, l, 0, h)
+        qf = torch.empty(M, H * dm, device=dev, dtype=torch.float16)
+        bo_, bsb, bsh = st.b_block(l, 0)
+        gemm_batched(X3, Tq, dm, D // H, B, H, _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
+                     a_off=(Tq * D, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(bsb, bsh), p2=_addr(qf), p2_f16=True,
+                     ldp2=H * dm, p2_off=(Tq * H * dm, dm))
+        # S = Q' X^T against the sample's packed rows
+        S_ = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
+        gemm_batched(PREC_F16, Tq, st.S, dm, B, H, _addr(qf), None, H * dm, _addr(st.x.fh), None, st.x.fh.stride(0),
+                     a_off=(Tq * H * dm, dm), b_rows=st.pack.off_ptr, C_=_addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 32 * Skp))
+        Pf = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float16)
+        ao, asb, ash = st.a_block(l, 1) if st.astack is not None else (0, 0, 0)
+        _lib.check(lib.bmt_raw_softmax_fwd(_p(S_), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), _p(Pf),
+                                           C.c_void_p(_addr(st.astack, ao)) if st.astack is not None else None, asb, ash, _st()), "bmt_raw_softmax_fwd")
+        # O' = P X (natural layout, split-bf16 planes: the A operand of the value block product)
+        Op = _alloc_planes(M, H * dm, "x3", dev, ld=H * dm)
+        gemm_batched(PREC_F16, Tq, dm, Skp, B, H, _addr(Pf), None, Skp, _addr(st.xt_f16), None, Skp,
+                     a_off=(H * 32 * Skp, 32 * Skp), b_off=(dm * Skp, 0), p1=_addr(Op.hi), p2=_addr(Op.lo), ldp=H * dm, p_off=(Tq * H * dm, dm))
+        # concat_h(O'_h W_v,h^T + b_v), dropout on the attention output (model/multihead_attention.py:22-23), as split-bf16 planes
+        o = _alloc_planes(M, D, "x3", dev, ld=D)
+        gv_hi, gv_lo = grp.hi[D:], grp.lo[D:]                                               # W_v's rows of the group
+        gemm_batched(X3, M, dk, dm, 1, H, _addr(Op.hi), _addr(Op.lo), H * dm, _addr(gv_hi), _addr(gv_lo), gv_hi.stride(0),
+                     a_off=(0, dm), b_off=(0, dk * gv_hi.stride(0)), p1=_addr(o.hi), p2=_addr(o.lo), ldp=D, p_off=(0, dk), ldc=D,
+                     bias=bv, bias_off_i=dk, drop_p=p, site=site, drop_off=(0, dk))
+        epi = {}
+        if res is not None:
+            r2 = _f32c(res).view(-1, Dq)
+            epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        opl = None
+        if out_fmt is not None and Dq % 64 == 0:
+            opl = _alloc_planes(M, Dq, out_fmt, dev)
+            epi["out_planes"] = opl
+        out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, Tq, Dq)
+        if opl is not None:
+            attach_planes(out, opl)
+        if res is not None:
+            request_grad_plane(out, res_p, res_site)
+        ctx.st, ctx.l, ctx.H, ctx.p, ctx.site = st, l, H, p, site
+        ctx.res = (res is not None, res_p, res_site)
+        ctx.dims = (B, Tq, Dq, D)
+        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        none = torch.empty(0, device=dev)
+        ctx.save_for_backward(Wq, Wk, Wv, Wo, q.hi if train else none, Pf if train else none, Op.hi if train else none, o.hi if train else none,
+                              Qp.hi if train else none)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Wq_, Wk_, Wv_, Wo_, qh, Pf, Oph, oh, QTh = ctx.saved_tensors
+        st, l, H, p = ctx.st, ctx.l, ctx.H, ctx.p
+        B, Tq, Dq, D = ctx.dims
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo = ctx.params
+        dm, Skp, dk, M = st.dm, st.Skp, D // H, B * Tq
+        dev = dout.device
+        cur = torch.cuda.current_stream()
+        for t in st.tensors():
+            t.record_stream(cur)
+        dy2 = _f32c(dout).view(-1, Dq)
+        has_res, res_p, res_site = ctx.res
+        drop = None
+        if has_res:
+            dy2, drop = drop_grad(dy2, bo, res_p, res_site)
+        # out-projection: dX with the attention-output dropout mask re-applied = gradient of concat_h(out_h); its column sums = db_v
+        P_, bias_done = grad_planes_from(dout, dy2, bo, drop) if has_res else grad_planes(dy2, bo, drop=drop)
+        gbv = static_grad(bv)
+        dbv_t = gbv if gbv is not None else torch.zeros(D, device=dev, dtype=torch.float32)
+        do = linear_dx(P_, Wo, out_planes=Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D), drop_post=True, drop_p=p, site=ctx.site,
+                       colsum=dbv_t)
+        if gbv is not None:
+            grad_done(bv)
+        dWo, dbo = wgrad(Wo, None if bias_done else bo, P_, Planes(oh, None, M, D), dy2_for_bias=dy2)
+        grp, _ = weight_group((Wk, Wv), (bk, bv), "x3")
+        gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))
+        # dO'_h = do_h W_v,h  -> B stack (b, l, 1, h)
+        bo_, bsb, bsh = st.b_block(l, 1)
+        gemm_batched(PREC_BF16, Tq, dm, dk, B, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
+                     a_off=(Tq * D, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(bsb, bsh))
+        dWv = _blockdiag_dw(do, Planes(Oph, None, M, H * dm), Wv, H)
+        # dP = dO' X^T
+        dP = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
+        gemm_batched(PREC_BF16, Tq, st.S, dm, B, H, _addr(st.bstack, bo_), None, dm, _addr(st.x.hi), None, st.x.hi.stride(0),
+                     a_off=(bsb, bsh), b_rows=st.pack.off_ptr, C_=_addr(dP), ldc=Skp, c_off=(H * 32 * Skp, 32 * Skp))
+        ao, asb, ash = st.a_block(l, 0)
+        _lib.check(lib.bmt_raw_softmax_bwd(_p(Pf), _p(dP), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _st()),
+                   "bmt_raw_softmax_bwd")
+        # dQ' = dS (X - mean key): natural layout, bf16
+        dQp = Planes(torch.empty(M, H * dm, device=dev, dtype=torch.bfloat16), None, M, H * dm)
+        gemm_batched(PREC_BF16, Tq, dm, Skp, B, H, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
+                     a_off=(asb, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, dm))
+        # dq_h = dQ'_h W_k,h^T (+ its column sums = db_q)
+        gbq = static_grad(bq)
+        dbq_t = gbq if gbq is not None else torch.zeros(D, device=dev, dtype=torch.float32)
+        dq = Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D)
+        gemm_batched(PREC_BF16, M, dk, dm, 1, H, _addr(dQp.hi), None, H * dm, _addr(grp.hi), None, grp.hi.stride(0),
+                     a_off=(0, dm), b_off=(0, dk * grp.hi.stride(0)), p1=_addr(dq.hi), ldp=D, p_off=(0, dk), colsum=dbq_t, bias_off_i=dk)
+        if gbq is not None:
+            grad_done(bq)
+        dWk = _blockdiag_dw(Planes(qh, None, M, D), dQp, Wk, H)
+        dbk = None
+        if bk is not None:               # the key bias does not reach the output: its gradient is exactly zero
+            if static_grad(bk) is not None:
+                grad_done(bk)
+            else:
+                dbk = torch.zeros_like(bk)
+        needQ = ctx.needs_input_grad[0]
+        dxq, dWq = lin_bwd_planes(dq, Wq, Planes(QTh, None, M, Dq), need_dx=needQ)
+        dQ = dxq.view(B, Tq, Dq) if needQ else None
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        st.events.append(ev)
+        return (dQ, None, None, None, dWq, None if gbq is not None else dbq_t, dWk, dbk, dWv, None if gbv is not None else dbv_t, dWo, dbo,
+                None, None, None, None, (dout if has_res else None), None, None, None)
 
 
 class FanoutFn(torch.autograd.Function):

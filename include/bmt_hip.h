@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 7
+#define BMT_ABI_VERSION 8
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -117,6 +117,11 @@ typedef struct {
      * and every kernel works on min(M | K, *rows_dev) of them, read when it runs -- the same launch (a hipGraph node) serves every batch.
      * Rows past the count are neither read (they may hold anything) nor written; column sums (colsum) leave them out. */
     const int* rows_dev;
+    /* ABI 8, bmt_gemm_bf16_grouped only (a product whose OUTPUT lives in a packed row layout: the gradient of a packed encoder memory,
+     * dX_b = dS_b^T . Q'_b of the decoder's cross-attention against the raw memory): the output rows start c_row_dev[0] rows below C and
+     * only the first m_dev[0] of the M rows exist -- both read from device memory when the launch runs.  NULL = as before. */
+    const int* c_row_dev;
+    const int* m_dev;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight
@@ -133,6 +138,39 @@ size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob);
  * keeps transposed weight planes for dX asks here which products qualify; 0 = the library was built without the kernel. */
 long long bmt_gemm_small_outputs(void);
 int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream);
+
+/* ABI 8 -- MANY small products of one shape in one launch on the 32 x 32 tile kernel (row-major operands; BMT_PREC_BF16, BMT_PREC_F16 or
+ * BMT_PREC_BF16X3; epilogue: alpha, bias, dropout, relu, column sums; no residual / gate / accumulate).  `args` describes ONE product
+ * (M, N, Kpad, planes, outputs, strides); product (o, i), 0 <= o < nb_outer, 0 <= i < nb_inner, reads and writes at the element offsets
+ * o * x_off_o + i * x_off_i from those pointers.  What it replaces: the per-(sample, head) products of attention() when the heads' key /
+ * value projections are reassociated onto the queries (model/multihead_attention.py:8-26, 62-84 with K = X W_k^T never formed):
+ * S = (q W_k,h) X^T, O' = P X, and the per-head block products q_h W_k,h / O'_h W_v,h^T around them.
+ *   b_rows_dev  optional, device int32 [nb_outer + 1]: the B operand of outer index o is rows b_rows_dev[o] .. b_rows_dev[o + 1] of B_hi
+ *               (a packed encoder memory: bmt_pack_rows' `off`), N = their number (at most args->N); columns past it are not written;
+ *   p2_*, ldp2  the second output plane (C_lo / C_f16) has its own row stride and offsets (ldp2 = 0: those of C_hi);
+ *   bias_off_i  column offset of bias and colsum per inner index;  drop_off_*: dropout element index = offset + row * ldc + col. */
+typedef struct {
+    int nb_outer, nb_inner;
+    int64_t a_off_o, a_off_i, b_off_o, b_off_i;
+    const int* b_rows_dev;
+    int64_t c_off_o, c_off_i, p_off_o, p_off_i, p2_off_o, p2_off_i, ldp2;
+    int64_t bias_off_i, drop_off_o, drop_off_i;
+} bmt_gemm_batch;
+int bmt_gemm_small_batched(const bmt_gemm_bf16_args* args, const bmt_gemm_batch* batch, void* stream);
+/* ... and the kernels between those products (csrc/raw_memory.hip).  `off` = bmt_pack_rows' offsets of the memory (int32, off[b] = first
+ * packed row of sample b, off[B] = the row count), Skp = the padded key extent of the per-sample buffers (a multiple of 64, >= every length):
+ *   bmt_memory_transposed  packed fp16 plane X [rows][ld] -> xt_f16[b][d][k] = fp16(X) and xtc_bf[b][d][k] = bf16(X - mean key of sample b)
+ *                          (either may be NULL; the second takes a workspace for the samples' mean keys), zeros for k >= the sample's length;
+ *   bmt_raw_softmax_fwd    S fp32 [B][H][32][Skp] (unscaled scores, rows t < Tq <= 32) -> P = softmax over the sample's keys of S * scale as
+ *                          fp16 [B][H][32][Skp] and, optionally, bf16 at p_bf + b * p_bf_sb + h * p_bf_sh + t * Skp; rows t >= Tq and keys past
+ *                          the length are zeros.  A sample without a valid key gives zeros (the reference gives NaN);
+ *   bmt_raw_softmax_bwd    dS = P o (dP - rowsum(P o dP)) * scale as bf16 at ds_bf + b * ds_sb + h * ds_sh + t * Skp. */
+int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const int* off, int B, int D, int Skp, uint16_t* xt_f16, uint16_t* xtc_bf,
+                          float* mean_ws /* B * D floats, needed with xtc_bf */, void* stream);
+int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb,
+                        int64_t p_bf_sh, void* stream);
+int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* ds_bf, int64_t ds_sb,
+                        int64_t ds_sh, void* stream);
 /* x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C): hi = bf16(x) and, optionally,
  * lo = bf16(x - hi) or (lo_f16) fp16(x) */
 int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp,

@@ -14,6 +14,8 @@ ALLOWED = {
     "BMT_LIB_PATH": ("another build of libbmt_hip.so (bmt_amd/_lib.py)", "tests/test_abi.py::test_missing_library_fails_loudly"),
     "BMT_PACK_ROWS": ("0: every padded position is computed, as the reference does",
                       "tests/test_gpu_packed.py::test_model_on_packed_rows_against_the_oracle_and_the_padded_path"),
+    "BMT_RAW_MEMORY": ("0: the decoder's cross-attentions project the encoder memories to keys and values, as the reference does",
+                       "tests/test_gpu_raw_memory.py::test_model_with_and_without_projected_keys_and_values"),
     "BMT_ENC_STREAMS": ("1: the whole pass on one stream", "tests/test_gpu_model.py::test_two_compute_streams_change_nothing_but_the_schedule"),
     "BMT_ATTN_BWD_SPLIT": ("0: the two-kernel attention backward everywhere", "tests/test_gpu_kernels.py::test_attention_backward_split_form"),
     "BMT_NO_FUSE_RES": ("1: LayerNorm / dropout_add / add as separate kernels",

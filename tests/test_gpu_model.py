@@ -454,6 +454,7 @@ def test_fused_residual_block_equals_the_separate_kernels(golden):
     first_site = ops._site_counter[0]
     for fused in (True, False):
         ops.FUSE_RESIDUAL = fused
+        ops.RAW_MEMORY = False                       # (the separate kernels run on padded rows, where the decoder projects keys and values: the same in both arms)
         try:
             ops._site_counter[0] = first_site        # both models draw the same dropout masks (site ids are per module instance)
             model = _build(cfg, V, bool(use_glove))
@@ -463,6 +464,7 @@ def test_fused_residual_block_equals_the_separate_kernels(golden):
             res[fused] = (pred.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
         finally:
             ops.FUSE_RESIDUAL = True
+            ops.RAW_MEMORY = True
     assert_close(res[True][0], res[False][0], atol=2e-5, name="log-probs fused vs separate")
     # gradients: the backward products take bf16 operands, so an fp32 1-ulp difference upstream (fma contraction in the fused
     # epilogue) flips bf16 roundings: tensors agree to bf16 noise, not bit for bit.  A wrong mask or a lost residual gradient

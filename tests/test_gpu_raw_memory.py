@@ -1,0 +1,302 @@
+"""-m gpu: the decoder's cross-attention against the RAW encoder memory (bmt_amd.ops.RawCrossAttnFn, ABI 8).
+
+model/multihead_attention.py:62-84 projects the memory to keys and values; with 29 queries per sample the products reassociate --
+S_h = (q_h W_k,h) X^T, O_h = (P_h X) W_v,h^T + b_v -- and K, V, dK, dV never exist.  The form must be indistinguishable from the reference's:
+every check is against fp64 autograd over the reference's own formulas (operands as they are: the bars are the operand formats' -- fp16 products
+against the memory, split-bf16 block products, bf16 backward), and the whole model against the CPU oracle and against its own projected form."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from bmt_amd import synthetic as syn
+from tests.gpu_util import assert_close, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bmt_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def amax(t):
+    return float(t.float().abs().max()) if t.numel() else 0.0
+
+
+def _mask(B, S, seed, holes=False):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(S // 3, 1), S + 1, (B,), generator=g)
+    lens[0] = S
+    m = torch.arange(S)[None, :] < lens[:, None]
+    if holes:
+        for b in range(1, B, 2):
+            m[b, int(torch.randint(0, max(int(lens[b]) - 1, 1), (1,), generator=g))] = False
+    return m.view(B, 1, S)
+
+
+def _packed(ops, x, m):
+    """(packed copy of the padded (B, S, D) tensor x under mask m with its RowPack attached, row indices of the valid positions)"""
+    B, S, D = x.shape
+    rows = torch.nonzero(m.view(-1)).view(-1)
+    xp = torch.zeros(B, S, D)
+    xp.view(-1, D)[:rows.numel()] = x.view(-1, D)[rows]
+    xp = xp.to(DEV)
+    pk = ops.pack_rows(m.to(DEV))
+    ops.carry_pack(pk, xp)
+    return xp, rows
+
+
+# ------------------------------------------------------------------------------------------ the kernels between the products
+@pytest.mark.parametrize("B,S,D", [(3, 70, 128), (4, 256, 1024), (2, 800, 128), (5, 33, 192)])
+def test_memory_transposed(ops, B, S, D):
+    m = _mask(B, S, seed=B + S, holes=True)
+    x = rnd(B, S, D, seed=1) + 0.7                      # a common component: the mean key is not small
+    xp, rows = _packed(ops, x, m)
+    pl = ops.make_planes(xp.view(-1, D), "f16", pack=ops.pack_of(xp))
+    Skp = ops._pad64(S)
+    xt = torch.full((B, D, Skp), 3.0, device=DEV, dtype=torch.float16)
+    xc = torch.full((B, D, Skp), 3.0, device=DEV, dtype=torch.bfloat16)
+    ws = torch.empty(B, D, device=DEV)
+    ops._lib.check(ops.lib.bmt_memory_transposed(ops._p(pl.fh), pl.fh.stride(0), ops.pack_of(xp).off_ptr, B, D, Skp, ops._p(xt), ops._p(xc), ops._p(ws), ops._st()), "t")
+    mm = m.view(B, S)
+    for b in range(B):
+        xb = x[b][mm[b]].to(torch.float16)               # (len, D): the sample's valid rows in order
+        n = xb.shape[0]
+        assert torch.equal(xt[b, :, :n].cpu(), xb.t()), b
+        assert amax(xt[b, :, n:]) == 0.0
+        want = (xb.float() - xb.float().mean(0, keepdim=True)).t()
+        assert_close(xc[b, :, :n].float(), want.double(), atol=2e-2, rtol=2 ** -8, name=f"centred sample {b}")
+        assert amax(xc[b, :, n:]) == 0.0
+
+
+@pytest.mark.parametrize("B,H,Tq,S", [(3, 4, 29, 256), (2, 2, 30, 800), (4, 4, 5, 70)])
+def test_raw_softmax_forward_and_backward(ops, B, H, Tq, S):
+    m = _mask(B, S, seed=7 * B + S, holes=True)
+    pk = ops.pack_rows(m.to(DEV))
+    lens = m.view(B, S).sum(1)
+    Skp, scale = ops._pad64(S), 1.0 / 16.0
+    Sc = (rnd(B, H, 32, Skp, seed=2) * 8.0).to(DEV)
+    Sc[:, :, :, S:] = float("nan")                       # never read: past every length
+    Pf = torch.full((B, H, 32, Skp), 3.0, device=DEV, dtype=torch.float16)
+    stack = torch.full((B, 2, H, 32, Skp), 3.0, device=DEV, dtype=torch.bfloat16)      # a stack with two row blocks per sample: P goes to block 1
+    sb, sh = 2 * H * 32 * Skp, 32 * Skp
+    ops._lib.check(ops.lib.bmt_raw_softmax_fwd(ops._p(Sc), pk.off_ptr, B, H, Tq, Skp, scale, ops._p(Pf),
+                                               ops.C.c_void_p(stack.data_ptr() + 2 * H * 32 * Skp), sb, sh, ops._st()), "f")
+    dP = rnd(B, H, 32, Skp, seed=3).to(DEV)
+    ops._lib.check(ops.lib.bmt_raw_softmax_bwd(ops._p(Pf), ops._p(dP), pk.off_ptr, B, H, Tq, Skp, scale, ops._p(stack), sb, sh, ops._st()), "b")
+    for b in range(B):
+        n = int(lens[b])
+        s = Sc[b, :, :Tq, :n].double().cpu() * scale
+        P = torch.softmax(s, -1)
+        assert_close(Pf[b, :, :Tq, :n].float(), P, atol=1e-3, rtol=2e-3, name="P")
+        assert amax(Pf[b, :, :, n:]) == 0.0 and amax(Pf[b, :, Tq:]) == 0.0
+        assert torch.equal(stack[b, 1, :, :Tq, :n].float().cpu(), Pf[b, :, :Tq, :n].float().to(torch.bfloat16).float().cpu()) or \
+            rel_err(stack[b, 1, :, :Tq, :n].float().cpu(), P.float()) < 5e-3
+        Pq = Pf[b, :, :Tq, :n].double().cpu()
+        d = dP[b, :, :Tq, :n].double().cpu()
+        dS = Pq * (d - (Pq * d).sum(-1, keepdim=True)) * scale
+        assert_close(stack[b, 0, :, :Tq, :n].float(), dS, atol=2e-4, rtol=2 ** -7, name="dS")
+        assert amax(stack[b, 0, :, :, n:]) == 0.0 and amax(stack[b, 0, :, Tq:]) == 0.0
+
+
+def test_batched_small_products(ops):
+    """bmt_gemm_small_batched: (sample, head) products at offsets, a packed B operand with device-side rows, two output planes with their own
+    geometry, bias and column sums per inner index"""
+    B, H, Tq, dm, dk, S = 3, 4, 29, 128, 64, 70
+    m = _mask(B, S, seed=11, holes=True)
+    lens = m.view(B, S).sum(1)
+    X = rnd(B, S, dm, seed=1) * 0.5
+    xp, rows = _packed(ops, X, m)
+    pk = ops.pack_of(xp)
+    xpl = ops.make_planes(xp.view(-1, dm), "f16", pack=pk)
+    q = (rnd(B * Tq, H * dm, seed=2) * 0.5).to(DEV)
+    qpl = ops.make_planes(q, "f16")
+    Skp = ops._pad64(S)
+    # S[b][h][t][k] = q[(b, t)][h dm : (h + 1) dm] . X_b[k]
+    S_ = torch.full((B, H, 32, Skp), 7.0, device=DEV)
+    ops.gemm_batched(ops.PREC_F16, Tq, S, dm, B, H, ops._addr(qpl.fh), None, H * dm, ops._addr(xpl.fh), None, xpl.fh.stride(0),
+                     a_off=(Tq * H * dm, dm), b_rows=pk.off_ptr, C_=ops._addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 32 * Skp))
+    mm = m.view(B, S)
+    for b in range(B):
+        n = int(lens[b])
+        xb = X[b][mm[b]].to(torch.float16).double()
+        want = torch.einsum("thd,kd->htk", q[b * Tq:(b + 1) * Tq].cpu().view(Tq, H, dm).to(torch.float16).double(), xb)
+        assert_close(S_[b, :, :Tq, :n], want, atol=2e-3, rtol=1e-4, name=f"S sample {b}")
+        assert bool((S_[b, :, Tq:] == 7.0).all()) and bool((S_[b, :, :, n:] == 7.0).all())
+    # block products over the heads with two planes, bias and column sums: out[:, h dk : (h + 1) dk] = A[:, h dm : (h + 1) dm] W[h dk : (h + 1) dk]^T + b
+    M = B * Tq
+    A = (rnd(M, H * dm, seed=3) * 0.5).to(DEV)
+    W = (rnd(H * dk, dm, seed=4) * 0.2).to(DEV)
+    bias = rnd(H * dk, seed=5).to(DEV)
+    Apl, Wpl = ops.make_planes(A, "x3"), ops.make_planes(W, "x3")
+    o = ops._alloc_planes(M, H * dk, "x3", DEV, ld=H * dk)
+    cs = torch.zeros(H * dk, device=DEV)
+    ops.gemm_batched(ops.PREC_BF16X3, M, dk, dm, 1, H, ops._addr(Apl.hi), ops._addr(Apl.lo), H * dm, ops._addr(Wpl.hi), ops._addr(Wpl.lo), Wpl.hi.stride(0),
+                     a_off=(0, dm), b_off=(0, dk * Wpl.hi.stride(0)), p1=ops._addr(o.hi), p2=ops._addr(o.lo), ldp=H * dk, p_off=(0, dk), bias=bias,
+                     bias_off_i=dk, colsum=cs)
+    want = torch.cat([A[:, h * dm:(h + 1) * dm].double().cpu() @ W[h * dk:(h + 1) * dk].double().cpu().t() for h in range(H)], 1) + bias.double().cpu()
+    got = o.hi.float().double().cpu() + o.lo.float().double().cpu()
+    assert_close(got, want, atol=3e-4, rtol=3e-5, name="block products (hi + lo)")
+    assert_close(cs, want.sum(0), atol=2e-2, rtol=1e-4, name="column sums")
+
+
+# ------------------------------------------------------------------------------------------ one attention module, both forms, against fp64
+def _reference_mha(Q, X, m, P, H):
+    """model/multihead_attention.py:55-86 in fp64 (dropout off); X padded (B, S, dm), m (B, 1, S)"""
+    q = Q @ P["Wq"].t() + P["bq"]
+    k = X @ P["Wk"].t() + P["bk"]
+    v = X @ P["Wv"].t() + P["bv"]
+    B, Tq, D = q.shape
+    dk = D // H
+    sp = lambda t: t.view(B, -1, H, dk).transpose(1, 2)
+    s = sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dk)
+    s = s.masked_fill(m.unsqueeze(1) == 0, -float("inf"))
+    o = (torch.softmax(s, -1) @ sp(v)).transpose(1, 2).reshape(B, Tq, D)
+    return o @ P["Wo"].t() + P["bo"]
+
+
+@pytest.mark.parametrize("dm,S,holes", [(128, 800, False), (1024, 256, True), (128, 100, True)])
+def test_cross_attention_against_the_raw_memory(ops, dm, S, holes):
+    from bmt_amd.model.multihead_attention import MultiheadedAttention
+    B, Tq, Dq, D, H, L = 4, 29, 300, 1024, 4, 2
+    torch.manual_seed(0)
+    att = ops.tag_policy(MultiheadedAttention(Dq, dm, dm, H, 0.0, D), "dec").to(DEV)
+    with torch.no_grad():
+        att.linear_K2d.bias.normal_(0, 0.5)              # a key bias that matters if it is (wrongly) kept or dropped in the wrong place
+    m = _mask(B, S, seed=S + dm, holes=holes)
+    X = rnd(B, S, dm, seed=1) * 0.7 + 0.3
+    Q = rnd(B, Tq, Dq, seed=2)
+    G = rnd(B, Tq, Dq, seed=3) * 0.1
+    # fp64 reference
+    P64 = {n: getattr(att, ln).__getattr__(pn).detach().double().cpu().requires_grad_(True)
+           for n, ln, pn in (("Wq", "linear_Q2d", "weight"), ("bq", "linear_Q2d", "bias"), ("Wk", "linear_K2d", "weight"), ("bk", "linear_K2d", "bias"),
+                             ("Wv", "linear_V2d", "weight"), ("bv", "linear_V2d", "bias"), ("Wo", "linear_d2Q", "weight"), ("bo", "linear_d2Q", "bias"))}
+    Q64, X64 = Q.double().requires_grad_(True), X.double().requires_grad_(True)
+    y64 = _reference_mha(Q64, X64, m, P64, H)
+    y64.backward(G.double())
+    # the reassociated form on the packed memory (layer 1 of a two-layer state: layer 0's slots stay empty)
+    xp, rows = _packed(ops, X, m)
+    xp.requires_grad_(True)
+    Qd = Q.to(DEV).requires_grad_(True)
+    mem = ops.raw_memory(xp, L, H, Tq, ops.policy_of(att))
+    assert getattr(mem, "_bmt_rawmem", None) is not None
+    mem._bmt_rawmem.next_layer = 1
+    ops.zero_(mem._bmt_rawmem.astack)                    # (the unused layer's rows of the stacks: finite)
+    y = att(Qd, mem, mem, m.to(DEV))
+    assert mem._bmt_rawmem.used and mem._bmt_rawmem.next_layer == 2, "the reassociated form did not run"
+    y.backward(G.to(DEV))
+    torch.cuda.synchronize()
+    assert_close(y, y64.detach(), atol=2e-3 * float(y64.detach().abs().max()), rtol=0, name="output")
+    e = {}
+    e["dQ"] = rel_err(Qd.grad.cpu(), Q64.grad.float())
+    gx = torch.zeros(B * S, dm)
+    gx[rows] = xp.grad.view(-1, dm)[:rows.numel()].cpu()
+    e["dX"] = rel_err(gx.view(B, S, dm), X64.grad.float())
+    for n, ln, pn in (("Wq", "linear_Q2d", "weight"), ("bq", "linear_Q2d", "bias"), ("Wk", "linear_K2d", "weight"), ("Wv", "linear_V2d", "weight"),
+                      ("bv", "linear_V2d", "bias"), ("Wo", "linear_d2Q", "weight"), ("bo", "linear_d2Q", "bias")):
+        e[n] = rel_err(getattr(att, ln).__getattr__(pn).grad.cpu(), P64[n].grad.float())
+    print("\nreassociated cross-attention vs fp64:", {k: f"{v:.2e}" for k, v in e.items()})
+    assert float(att.linear_K2d.bias.grad.abs().max()) == 0.0 and float(P64["bk"].grad.abs().max()) < 1e-12      # exactly zero, both
+    assert max(e.values()) < 2e-2, e
+    # and the projected form of the same module (what ran before round 5): same bars, and the two agree
+    att2 = copy.deepcopy(att)
+    for p_ in att2.parameters():
+        p_.grad = None
+    xp2, _ = _packed(ops, X, m)
+    xp2.requires_grad_(True)
+    Q2 = Q.to(DEV).requires_grad_(True)
+    y2 = att2(Q2, xp2, xp2, m.to(DEV))
+    y2.backward(G.to(DEV))
+    assert_close(y, y2.detach(), atol=3e-3 * float(y64.detach().abs().max()), rtol=0, name="reassociated vs projected output")
+    n = rows.numel()                                    # (the projected form leaves the rows past the count unwritten)
+    assert rel_err(Qd.grad, Q2.grad) < 3e-2 and rel_err(xp.grad.view(-1, dm)[:n], xp2.grad.view(-1, dm)[:n]) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------ the whole model
+@pytest.mark.parametrize("holes", [False, True])
+def test_model_with_and_without_projected_keys_and_values(ops, holes):
+    """the captioning model (two layers, d_k 128, a ragged batch, optionally with masks that are not suffixes) with the decoder's cross-attentions
+    against the raw memories and with keys and values projected (RAW_MEMORY off: the reference's formulation, what BMT_RAW_MEMORY=0 selects): both
+    within 1e-3 of the CPU oracle's log-probabilities and inside its gradient bars, and within the operand formats' noise of each other"""
+    from oracle import bmt_oracle as orc
+    from tests.test_gpu_model import _check_grads
+    from tests.test_gpu_packed import _build, _poison_allocator, _run
+    cfg = syn.make_cfg(d_model=512, H=4, N=2, d_aud=128, d_vid=256, d_model_caps=64, dout_p=0.0)
+    V, B, Tv, Ta, Tc = 60, 4, 90, 210, 11
+    model = _build(cfg, V)
+    batch = syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=99)
+    fs, caps = batch["feature_stacks"], batch["captions"]
+    if holes:
+        for b, t in ((1, 3), (1, 4), (2, 0), (3, 17)):
+            fs["rgb"][b, t, 0] = float(syn.PAD_IDX)
+        for b, t in ((0, 100), (2, 1), (3, 0), (3, 1)):
+            fs["audio"][b, t, 0] = float(syn.PAD_IDX)
+    p = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    oloss, opred, _ = orc.train_cap_loss(p, cfg, fs, caps, syn.PAD_IDX, cfg.smoothing)
+    oloss.backward()
+    trainable = {k for k, q in model.named_parameters() if q.requires_grad}
+    ograds = {k: v.grad for k, v in p.items() if v.grad is not None and k in trainable}
+    preds, grads = {}, {}
+    calls = [0]
+    fwd = ops.RawCrossAttnFn.forward
+
+    def counting(*a, **kw):
+        calls[0] += 1
+        return fwd(*a, **kw)
+    for raw in (True, False):
+        model.zero_grad()
+        ops.RAW_MEMORY = raw
+        ops.RawCrossAttnFn.forward = staticmethod(counting)
+        try:
+            _poison_allocator()
+            pred, loss, masks, packs = _run(model, cfg, fs, caps)
+            assert packs is not None
+            loss.backward()
+        finally:
+            ops.RAW_MEMORY = True
+            ops.RawCrossAttnFn.forward = staticmethod(fwd)
+        assert calls[0] == 4, calls      # two layers x two memories in the raw arm, none added by the projected arm
+        err = float((pred.detach().cpu() - opred.detach()).abs().max())
+        print(f"\nraw memory {raw} (holes={holes}): max |dlogp| vs the oracle = {err:.3e}")
+        assert_close(pred, opred.detach(), atol=1e-3, name=f"log-probs, raw memory {raw}")
+        _check_grads([(k, q) for k, q in model.named_parameters() if k in trainable], ograds)
+        preds[raw] = pred.detach().float().cpu()
+        grads[raw] = {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.grad is not None}
+    assert float((preds[True] - preds[False]).abs().max()) < 6e-4
+    num = sum(float((grads[True][k].double() - grads[False][k].double()).norm() ** 2) for k in grads[False])
+    den = sum(float(grads[False][k].double().norm() ** 2) for k in grads[False])
+    assert (num / den) ** 0.5 < 1e-2, f"raw memory vs projected gradients differ by {(num / den) ** 0.5:.3e}"
+
+
+def test_captured_step_with_the_raw_memory_form(ops):
+    """the step as hipGraphs with the reassociated cross-attentions inside: losses of replays over different batches equal the eager step's"""
+    from bmt_amd.train import CaptioningTrainStep
+    from tests.test_gpu_packed import _build
+    cfg = syn.make_cfg(d_model=512, H=4, N=2, d_aud=128, d_vid=256, d_model_caps=64, dout_p=0.0, lr=1e-4)
+    V, B, Tv, Ta, Tc = 60, 4, 90, 210, 11
+    batches = [syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=s) for s in (5, 6, 7)]
+    dev = lambda b: ({k: v.to(DEV) for k, v in b["feature_stacks"].items()}, b["captions"].to(DEV))
+    losses = {}
+    for mode in ("eager", "graph"):
+        model = _build(cfg, V)
+        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True, seed=3)
+        if mode == "graph":
+            step.capture(*dev(batches[0]))
+            model.load_state_dict(_build(cfg, V).state_dict())        # (the capture's warm-up steps moved the weights)
+        out = []
+        for b in batches:
+            loss, _ = (step.replay(*dev(b)) if mode == "graph" else step(*dev(b)))
+            out.append(float(loss))
+        losses[mode] = out
+    print("\nraw memory, eager vs graph losses:", losses)
+    assert abs(losses["eager"][0] - losses["graph"][0]) < 2e-3, losses     # (first step: identical weights and dropout stream)
+    assert all(math.isfinite(x) for x in losses["graph"])

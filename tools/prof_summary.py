@@ -65,7 +65,12 @@ def last_step(src, steps, dst):
             name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
             name = re.sub(r"^void ", "", name).split("(")[0][:70]
             st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-            w.writerow([name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
+            gx = r.get("Grid_Size_X", r.get("Grid_Size", ""))
+            try:                       # threads of the whole grid (x * y * z): batched launches put the batch in y
+                gx = int(gx) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+            except ValueError:
+                pass
+            w.writerow([name, gx, r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
                         f"{(en - st) / 1e3:.2f}", f"{(st - prev) / 1e3:.2f}" if prev is not None else ""])
             prev = en
 
