@@ -1266,7 +1266,14 @@ struct SmallBatch {                  // bmt_gemm_small_batched: product (o, i) =
     int nb_inner;
     int64_t a_off_o, a_off_i, b_off_o, b_off_i, c_off_o, c_off_i, p_off_o, p_off_i, p2_off_o, p2_off_i, ldp2, bias_off_i, drop_off_o, drop_off_i;
     const int* b_rows_dev;
+    int a_div, c_div, p_div, p2_div;     // row r of A / C / the planes at (r / div) * qs + (r % div) * ld when div > 0
+    int64_t a_qs, c_qs, p_qs, p2_qs;
 };
+
+// element offset of row r under the block-row addressing of SmallBatch
+__device__ __forceinline__ int64_t small_row(int r, int div, int64_t qs, int64_t ld) {
+    return div > 0 ? (int64_t)(r / div) * qs + (int64_t)(r % div) * ld : (int64_t)r * ld;
+}
 
 template <int NPASS, bool F16>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const SmallBatch bt) {
@@ -1308,7 +1315,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
     if (!ksplit && (m0 >= Mr || n0 >= ncols)) return;             // a wave of the 64 x 64 block past the extents: it shares nothing
     const int nch = p.Kpad / 64, per = ksplit ? (nch + 3) / 4 : nch;
     const int c0 = ksplit ? wid * per : 0, c1 = min(nch, c0 + per);
-    const int64_t a_bytes = (int64_t)Mr * p.lda * 2, b_bytes = (int64_t)p.N * p.ldb * 2;
+    // (block rows: the rows are not one contiguous range; the descriptor ends just below the out-of-range offset the masked lanes use)
+    const int64_t a_bytes = bt.a_div > 0 ? 0x7ffffff0 : (int64_t)Mr * p.lda * 2, b_bytes = (int64_t)p.N * p.ldb * 2;
     const __amdgpu_buffer_rsrc_t rsAh = plane_rsrc(p.Ah, a_bytes), rsAl = plane_rsrc(ALO ? p.Al : p.Ah, a_bytes);
     const __amdgpu_buffer_rsrc_t rsBh = plane_rsrc(p.Bh, b_bytes), rsBl = plane_rsrc(BLO ? p.Bl : p.Bh, b_bytes);
     constexpr int OOB = 0x7ffffff0;                               // past any plane (< 2 GiB, checked by the host): reads as zero
@@ -1316,14 +1324,15 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + (lane >> 3), piece = lane & 7;
-        voa[i] = (m0 + row < Mr) ? (int)((int64_t)(m0 + row) * p.lda * 2) + piece * 16 : OOB;
+        voa[i] = (m0 + row < Mr) ? (int)(small_row(m0 + row, bt.a_div, bt.a_qs, p.lda) * 2) + piece * 16 : OOB;
         vob[i] = (n0 + row < p.N) ? (int)((int64_t)(n0 + row) * p.ldb * 2) + piece * 16 : OOB;
         lds_w[i] = slot_of<8>(row, piece) * 16;
     }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    u32x4 rg[2][NPL][4];
+    constexpr int NS = 2;                                         // chunks in flight per wave (four of them for the one-pass products: slower, fewer waves per SIMD)
+    u32x4 rg[NS][NPL][4];
 #define BMT_SM_LOAD(set_, c_)                                                                       \
     do {                                                                                            \
         const bool in_ = (c_) < c1;                        /* wave-uniform */                       \
@@ -1341,27 +1350,34 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
         _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + pl * 4096 + lds_w[i]) = rg[set_][pl][i]; \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
+        /* every fragment of the chunk first (one LDS round trip), then the MFMA chain */           \
+        bf16x8 fa_[4], fb_[4], fal_[4], fbl_[4];                                                    \
         _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
             const int fo_ = slot_of<8>(l31, 2 * u + half) * 16;                                     \
-            const bf16x8 ah_ = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + fo_));            \
-            const bf16x8 bh_ = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + 4096 + fo_));     \
-            if constexpr (ALO) acc = mfma32t<F16>(as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + 2 * 4096 + fo_)), bh_, acc); \
-            if constexpr (BLO) acc = mfma32t<F16>(ah_, as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + (NPL - 1) * 4096 + fo_)), acc); \
-            acc = mfma32t<F16>(ah_, bh_, acc);                                                      \
+            fa_[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + fo_));                      \
+            fb_[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + 4096 + fo_));               \
+            if constexpr (ALO) fal_[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + 2 * 4096 + fo_)); \
+            if constexpr (BLO) fbl_[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + (NPL - 1) * 4096 + fo_)); \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
+            if constexpr (ALO) acc = mfma32t<F16>(fal_[u], fb_[u], acc);                            \
+            if constexpr (BLO) acc = mfma32t<F16>(fa_[u], fbl_[u], acc);                            \
+            acc = mfma32t<F16>(fa_[u], fb_[u], acc);                                                \
         }                                                                                           \
     } while (0)
     // branch-free inside the loop: a chunk past the wave's range is fetched out of range (zeros, no memory access) and multiplied anyway, so
     // that the compiler's vmcnt counts are exact (with a conditional load it waits for the YOUNGER set before touching the older one)
     if (c0 < c1) {
-        BMT_SM_LOAD(0, c0);
-        BMT_SM_LOAD(1, c0 + 1);
-        for (int c = c0; c < c1; c += 2) {
-            BMT_SM_STAGE(0);
-            BMT_SM_LOAD(0, c + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            BMT_SM_STAGE(1);
-            BMT_SM_LOAD(1, c + 3);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) BMT_SM_LOAD(j, c0 + j);
+        for (int c = c0; c < c1; c += NS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                BMT_SM_STAGE(j);
+                BMT_SM_LOAD(j, c + NS + j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #undef BMT_SM_LOAD
@@ -1402,7 +1418,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
             const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
             v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
         }
-        const int64_t idx = (int64_t)row * p.ldc + col;
+        const int64_t idx = (int64_t)row * p.ldc + col, cidx = small_row(row, bt.c_div, bt.c_qs, p.ldc) + col;      // (idx: the dropout's element index)
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = v[q] * p.alpha + bv[q];
         if (f & BMT_EPI_DROP_PRE) {
@@ -1436,14 +1452,14 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
         if (f & BMT_EPI_ACCUM) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (col + q < p.N) atomicAdd(p.C + idx + q, v[q]);
+                if (col + q < p.N) atomicAdd(p.C + cidx + q, v[q]);
         } else if (c_vec) {
-            *reinterpret_cast<float4*>(p.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(p.C + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            *reinterpret_cast<float4*>(p.C + cidx) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.C + cidx + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else if (p.C) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (col + q < p.N) p.C[idx + q] = v[q];
+                if (col + q < p.N) p.C[cidx + q] = v[q];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) cs8[q] += v[q];
@@ -1457,7 +1473,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
                 l[q] = p.second_f16 ? pack_h2(v[2 * q], v[2 * q + 1]) : l_;
                 if (p.hi_f16) h[q] = pack_h2(v[2 * q], v[2 * q + 1]);
             }
-            const int64_t pi = (int64_t)row * p.ldp + col, pi2 = (int64_t)row * ldp2 + col;
+            const int64_t pi = small_row(row, bt.p_div, bt.p_qs, p.ldp) + col, pi2 = small_row(row, bt.p2_div, bt.p2_qs, ldp2) + col;
             if (p.plane_vec) {
                 *reinterpret_cast<u32x4*>(p.Chi + pi) = h;
                 if (p.Clo) *reinterpret_cast<u32x4*>(p.Clo + pi2) = l;
@@ -2083,14 +2099,16 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
 extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gemm_batch* b, void* stream) {
     BMT_CHECK_ARG(a && b && b->nb_outer > 0 && b->nb_inner > 0 && (int64_t)b->nb_outer * b->nb_inner <= 65535, "bmt_gemm_small_batched: bad batch");
     BMT_CHECK_ARG(BMT_SMALL_TILE_OUTPUTS > 0, "bmt_gemm_small_batched: the library was built without the 32 x 32 tile kernel");
-    BMT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->splitk <= 1 && !a->rows_dev && !a->c_row_dev && !a->m_dev &&
+    BMT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && !a->conv_mode && (a->splitk <= 1 || a->splitk == 4) && !a->rows_dev && !a->c_row_dev && !a->m_dev &&
                       !(a->flags & (BMT_EPI_RESIDUAL | BMT_EPI_GATE | BMT_EPI_ACCUM)),
                   "bmt_gemm_small_batched: row-major operands, no split, no residual / gate / accumulate");
     BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_BF16X3,
                   "bmt_gemm_small_batched: BMT_PREC_BF16, BMT_PREC_F16 or BMT_PREC_BF16X3");
     GemmB p;
     int splitk = 1;
-    int rc = gemm_prepare(a, p, splitk, false);
+    bmt_gemm_bf16_args a1 = *a;
+    a1.splitk = 1;
+    int rc = gemm_prepare(&a1, p, splitk, false);
     if (rc != BMT_OK) return rc;
     // every product writes exactly its N columns (a neighbour's may follow); 16-byte plane stores need aligned offsets
     if (p.Chi) p.plane_cols = a->N;
@@ -2098,7 +2116,9 @@ extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gem
     p.plane_vec = p.plane_vec && (a->N % 8 == 0) && (ldp2 % 8 == 0) && !((b->p_off_o | b->p_off_i | b->p2_off_o | b->p2_off_i) & 7);
     const int cols = a->N, nb = b->nb_outer * b->nb_inner;
     p.pipe = 5;
-    p.nk_rg = (a->Kpad >= 512 && (int64_t)bmt_cdiv(a->M, 32) * bmt_cdiv(cols, 32) * nb <= 4 * bmt_device_cus()) ? 4 : 1;
+    // splitk 0: the library chooses (the reduction over a workgroup's waves for long reductions over few tiles; measured per product at
+    // configs[1]'s shapes: profiles/r05_s_raw_products_time.txt); 1 / 4: the caller does (64 x 64 blocks / one tile per workgroup)
+    p.nk_rg = a->splitk == 4 ? 4 : (a->splitk == 1 ? 1 : ((a->Kpad >= 512 && (int64_t)bmt_cdiv(a->M, 32) * bmt_cdiv(cols, 32) * nb <= 2 * bmt_device_cus()) ? 4 : 1));
     p.bm = p.nk_rg == 4 ? 32 : 64;
     p.tiles_m = bmt_cdiv(a->M, p.bm);
     p.tiles_n = bmt_cdiv(cols, p.bm);
@@ -2109,6 +2129,10 @@ extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gem
     bt.p2_off_o = b->p2_off_o; bt.p2_off_i = b->p2_off_i; bt.ldp2 = b->ldp2;
     bt.bias_off_i = b->bias_off_i; bt.drop_off_o = b->drop_off_o; bt.drop_off_i = b->drop_off_i;
     bt.b_rows_dev = b->b_rows_dev;
+    bt.a_div = b->a_div; bt.c_div = b->c_div; bt.p_div = b->p_div; bt.p2_div = b->p2_div;
+    bt.a_qs = b->a_qs; bt.c_qs = b->c_qs; bt.p_qs = b->p_qs; bt.p2_qs = b->p2_qs;
+    BMT_CHECK_ARG(b->a_div >= 0 && b->c_div >= 0 && b->p_div >= 0 && b->p2_div >= 0 && !((b->a_qs | b->p_qs | b->p2_qs) & 7) && !(b->c_qs & 3),
+                  "bmt_gemm_small_batched: block-row strides must keep 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     if (a->precision == BMT_PREC_BF16X3) return launch_small<3, false>(p, st, &bt, nb);
     if (a->precision == BMT_PREC_F16) return launch_small<1, true>(p, st, &bt, nb);

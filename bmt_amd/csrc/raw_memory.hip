@@ -15,27 +15,27 @@ namespace {
 //   xtc_bf  bf16(X - mean_b)       the B operand of dQ' = dS . X: sum_k dS[q][k] = 0 exactly, so the sample's mean key drops out of the
 //                                  product -- and with it the systematic error of a ROUNDED dS that does not sum to zero (the mean-key
 //                                  correction of the attention backward, bmt_attn_kmean, built into the operand)
-// two launches: the column means of every sample (workgroup = (64 columns, sample): four row groups stride over the keys), then 64 x 64
+// two launches: the column sums of every sample (64 x 64 tiles, atomics into a workspace the caller zeroed), then 64 x 64
 // tiles through LDS (workgroup = (64 columns, 64 keys, sample): 16-byte loads along the rows, 16-byte stores along the keys)
 __global__ __launch_bounds__(256) void memory_mean_kernel(const uint16_t* __restrict__ X, int64_t ld, const int* __restrict__ off, int D, int Skp,
-                                                           float* __restrict__ mean) {
+                                                           float* __restrict__ sum) {
+    // workgroup = (64 columns, 64 keys, sample): column sums of its keys, added into sum[b][d] (zeroed by the caller)
     __shared__ float colsum[4][64];
-    const int b = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int b = blockIdx.z, d0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
     const int r0 = off[b], len = min(off[b + 1] - r0, Skp);
+    if (k0 >= len) return;
     const int c = tid & 63, rg = tid >> 6;
-    float s0 = 0.f, s1 = 0.f;
+    float s = 0.f;
     if (d0 + c < D) {
-        int k = rg;
-        for (; k + 4 < len; k += 8) {
-            s0 += h_bits2f(X[(int64_t)(r0 + k) * ld + d0 + c]);
-            s1 += h_bits2f(X[(int64_t)(r0 + k + 4) * ld + d0 + c]);
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int k = k0 + rg + 4 * i;
+            if (k < len) s += h_bits2f(X[(int64_t)(r0 + k) * ld + d0 + c]);
         }
-        for (; k < len; k += 4) s0 += h_bits2f(X[(int64_t)(r0 + k) * ld + d0 + c]);
     }
-    colsum[rg][c] = s0 + s1;
+    colsum[rg][c] = s;
     __syncthreads();
-    if (tid < 64 && d0 + tid < D)
-        mean[(int64_t)b * D + d0 + tid] = len > 0 ? (colsum[0][tid] + colsum[1][tid] + colsum[2][tid] + colsum[3][tid]) / (float)len : 0.f;
+    if (tid < 64 && d0 + tid < D) atomicAdd(sum + (int64_t)b * D + d0 + tid, (colsum[0][tid] + colsum[1][tid]) + (colsum[2][tid] + colsum[3][tid]));
 }
 
 __global__ __launch_bounds__(256) void memory_transposed_kernel(const uint16_t* __restrict__ X, int64_t ld, const int* __restrict__ off, int D, int Skp,
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void memory_transposed_kernel(const uint16_t* 
     for (int ps = 0; ps < 2; ++ps) {                          // 64 columns x 8 pieces of 8 keys
         const int dc = ps * 32 + (tid >> 3), d = d0 + dc, kk = piece * 8;
         if (d >= D || k0 + kk >= Skp) continue;
-        const float mu = xtc_bf ? mean[(int64_t)b * D + d] : 0.f;
+        const float mu = (xtc_bf && len > 0) ? mean[(int64_t)b * D + d] / (float)len : 0.f;      // (mean = the column SUM over the sample's keys)
         uint16_t f[8], c_[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void memory_transposed_kernel(const uint16_t* 
 // rows t >= Tq and keys >= the sample's length are written as zeros (they are reduction padding of the products that follow)
 __global__ __launch_bounds__(256) void raw_softmax_fwd_kernel(const float* __restrict__ S, const int* __restrict__ off, int H, int Tq, int Skp, float scale,
                                                                uint16_t* __restrict__ p_f16, uint16_t* __restrict__ p_bf, int64_t sb, int64_t sh, int nrows) {
+    constexpr int NV = 16;                                    // keys per lane held in registers: Skp <= 1024
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nrows) return;
     const int t = row & 31, bh = row >> 5, b = bh / H, h = bh - b * H;
@@ -91,22 +92,34 @@ __global__ __launch_bounds__(256) void raw_softmax_fwd_kernel(const float* __res
     uint16_t* pf = p_f16 + (int64_t)row * Skp;
     uint16_t* pb = p_bf ? p_bf + b * sb + h * sh + (int64_t)t * Skp : nullptr;
     const bool live = t < Tq && len > 0;
+    float v[NV];
     float m = -INFINITY;
-    if (live)
-        for (int k = lane; k < len; k += 64) m = fmaxf(m, s[k]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = lane + 64 * i;
+        v[i] = (live && k < len) ? s[k] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     const float sc = scale * 1.4426950408889634f;            // exp(x * scale) = exp2(x * scale * log2 e)
     float sum = 0.f;
-    if (live)
-        for (int k = lane; k < len; k += 64) sum += exp2f((s[k] - m) * sc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = (live && lane + 64 * i < len) ? exp2f((v[i] - m) * sc) : 0.f;
+        sum += v[i];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = live ? 1.f / sum : 0.f;
-    for (int k = lane; k < Skp; k += 64) {
-        const float p = (live && k < len) ? exp2f((s[k] - m) * sc) * inv : 0.f;
-        pf[k] = __builtin_bit_cast(uint16_t, (_Float16)p);
-        if (pb) pb[k] = (uint16_t)f2bf_bits(p);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = lane + 64 * i;
+        if (k < Skp) {
+            const float p = v[i] * inv;
+            pf[k] = __builtin_bit_cast(uint16_t, (_Float16)p);
+            if (pb) pb[k] = (uint16_t)f2bf_bits(p);
+        }
     }
 }
 
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(256) void raw_softmax_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void raw_softmax_bwd_kernel(const uint16_t* __restrict__ p_f16, const float* __restrict__ dP, const int* __restrict__ off,
                                                                int H, int Tq, int Skp, float scale, uint16_t* __restrict__ ds_bf, int64_t sb, int64_t sh,
                                                                int nrows) {
+    constexpr int NV = 16;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nrows) return;
     const int t = row & 31, bh = row >> 5, b = bh / H, h = bh - b * H;
@@ -123,12 +137,23 @@ __global__ __launch_bounds__(256) void raw_softmax_bwd_kernel(const uint16_t* __
     const float* dp = dP + (int64_t)row * Skp;
     uint16_t* ds = ds_bf + b * sb + h * sh + (int64_t)t * Skp;
     const bool live = t < Tq && len > 0;
+    float pv[NV], dv[NV];
     float delta = 0.f;
-    if (live)
-        for (int k = lane; k < len; k += 64) delta += h_bits2f(pf[k]) * dp[k];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = lane + 64 * i;
+        const bool in = live && k < len;
+        pv[i] = in ? h_bits2f(pf[k]) : 0.f;
+        dv[i] = in ? dp[k] : 0.f;
+        delta += pv[i] * dv[i];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
-    for (int k = lane; k < Skp; k += 64) ds[k] = (uint16_t)f2bf_bits((live && k < len) ? h_bits2f(pf[k]) * (dp[k] - delta) * scale : 0.f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = lane + 64 * i;
+        if (k < Skp) ds[k] = (uint16_t)f2bf_bits(pv[i] * (dv[i] - delta) * scale);
+    }
 }
 
 }  // namespace
@@ -138,8 +163,8 @@ extern "C" int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const in
     BMT_CHECK_ARG(x_f16 && off && (xt_f16 || xtc_bf) && B > 0 && D > 0 && Skp > 0 && Skp % 64 == 0 && ld >= D && ld % 8 == 0 &&
                       (reinterpret_cast<uintptr_t>(x_f16) & 15) == 0,
                   "bmt_memory_transposed: bad arguments (Skp a multiple of 64; the plane 16-byte aligned with a row stride that is a multiple of 8)");
-    BMT_CHECK_ARG(!xtc_bf || mean_ws, "bmt_memory_transposed: the centred plane needs the mean workspace (B * D floats)");
-    if (xtc_bf) hipLaunchKernelGGL(memory_mean_kernel, dim3(bmt_cdiv(D, 64), B), dim3(256), 0, (hipStream_t)stream, x_f16, ld, off, D, Skp, mean_ws);
+    BMT_CHECK_ARG(!xtc_bf || mean_ws, "bmt_memory_transposed: the centred plane needs the workspace for the column sums (B * D floats, ZEROED by the caller)");
+    if (xtc_bf) hipLaunchKernelGGL(memory_mean_kernel, dim3(bmt_cdiv(D, 64), Skp / 64, B), dim3(256), 0, (hipStream_t)stream, x_f16, ld, off, D, Skp, mean_ws);
     hipLaunchKernelGGL(memory_transposed_kernel, dim3(bmt_cdiv(D, 64), Skp / 64, B), dim3(256), 0, (hipStream_t)stream, x_f16, ld, off, D, Skp, mean_ws, xt_f16,
                        xtc_bf);
     BMT_CHECK_LAUNCH("bmt_memory_transposed");
@@ -148,7 +173,8 @@ extern "C" int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const in
 
 extern "C" int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf,
                                    int64_t p_bf_sb, int64_t p_bf_sh, void* stream) {
-    BMT_CHECK_ARG(S && off && p_f16 && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0, "bmt_raw_softmax_fwd: bad arguments (at most 32 queries per sample and head)");
+    BMT_CHECK_ARG(S && off && p_f16 && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0 && Skp <= 1024,
+                  "bmt_raw_softmax_fwd: bad arguments (at most 32 queries per sample and head, at most 1024 keys per sample)");
     const int nrows = B * H * 32;
     hipLaunchKernelGGL(raw_softmax_fwd_kernel, dim3(bmt_cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, S, off, H, Tq, Skp, scale, p_f16, p_bf, p_bf_sb, p_bf_sh,
                        nrows);
@@ -158,7 +184,7 @@ extern "C" int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H,
 
 extern "C" int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* ds_bf,
                                    int64_t ds_sb, int64_t ds_sh, void* stream) {
-    BMT_CHECK_ARG(p_f16 && dP && off && ds_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0, "bmt_raw_softmax_bwd: bad arguments");
+    BMT_CHECK_ARG(p_f16 && dP && off && ds_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0 && Skp <= 1024, "bmt_raw_softmax_bwd: bad arguments");
     const int nrows = B * H * 32;
     hipLaunchKernelGGL(raw_softmax_bwd_kernel, dim3(bmt_cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, p_f16, dP, off, H, Tq, Skp, scale, ds_bf, ds_sb, ds_sh,
                        nrows);

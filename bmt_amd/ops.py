@@ -2397,18 +2397,20 @@ def _addr(t: torch.Tensor, elems: int = 0) -> int:
 
 def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, ah, al, lda, bh, bl, ldb, *, a_off=(0, 0), b_off=(0, 0), b_rows=None, C_=None, ldc=0, c_off=(0, 0),
                  p1=None, p2=None, p2_f16=False, ldp=0, p_off=(0, 0), ldp2=0, p2_off=None, bias=None, bias_off_i=0, colsum=None, alpha=1.0,
-                 drop_p=0.0, site=0, drop_off=(0, 0)):
+                 drop_p=0.0, site=0, drop_off=(0, 0), a_div=(0, 0), c_div=(0, 0), p_div=(0, 0), p2_div=None, split=0):
     """nb_o x nb_i small products of one shape in one launch (bmt_gemm_small_batched).  ah / al / bh / bl / C_ / p1 / p2: ADDRESSES (ints;
-    ``_addr``) of product (0, 0)'s operands and outputs; x_off = (per outer index, per inner index) element offsets."""
+    ``_addr``) of product (0, 0)'s operands and outputs; x_off = (per outer index, per inner index) element offsets; x_div = (rows per block, elements
+    between blocks): row r of that operand / output lives at (r // rows) * elements + (r % rows) * ld (p2_div defaults to p_div)."""
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_DROP_POST if drop_p > 0.0 else 0)
     a = GemmBf16Args(ah, al, lda, bh, bl, ldb, C_, ldc, p1, None if p2_f16 else p2, ldp, M, N, Kpad, alpha, flags,
-                     _p(bias), None, 0, None, 0, 1.0, drop_p, _p(rng_tensor()) if drop_p > 0.0 else None, site, prec, 1)
+                     _p(bias), None, 0, None, 0, 1.0, drop_p, _p(rng_tensor()) if drop_p > 0.0 else None, site, prec, split)
     if p2_f16:
         a.C_f16 = p2
     a.colsum = _p(colsum)
     p2_off = p_off if p2_off is None else p2_off
+    p2_div = p_div if p2_div is None else p2_div
     bt = _lib.GemmBatch(nb_o, nb_i, a_off[0], a_off[1], b_off[0], b_off[1], b_rows, c_off[0], c_off[1], p_off[0], p_off[1], p2_off[0], p2_off[1], ldp2,
-                        bias_off_i, drop_off[0], drop_off[1])
+                        bias_off_i, drop_off[0], drop_off[1], a_div[0], c_div[0], p_div[0], p2_div[0], a_div[1], c_div[1], p_div[1], p2_div[1])
     _lib.check(lib.bmt_gemm_small_batched(C.byref(a), C.byref(bt), _st()), "bmt_gemm_small_batched")
 
 
@@ -2429,7 +2431,8 @@ def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> t
     if not torch.is_grad_enabled():      # inference projects keys and values: greedy decoding computes them once per caption (ops.mha_infer), and a
         return mem                       # full forward pass under no_grad runs the same kernels as that cached form (tests/test_gpu_model.py)
     if not (RAW_MEMORY and SMALL_DX_OUTPUTS > 0 and pk is not None and isinstance(mem, torch.Tensor) and mem.is_cuda and mem.dim() == 3 and
-            mem.dtype == torch.float32 and mem.shape[-1] % 64 == 0 and 0 < Tq <= 32 and n_layers > 0 and context().kv_cache is None):
+            mem.dtype == torch.float32 and mem.shape[-1] % 64 == 0 and 0 < Tq <= 32 and n_layers > 0 and mem.shape[1] <= 1024 and
+            context().kv_cache is None):
         return mem
     B, S, dm = mem.shape
     x = planes_of(mem, "f16")
@@ -2446,11 +2449,14 @@ def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> t
     dev = mem.device
     st.xt_f16 = torch.empty(B, dm, st.Skp, device=dev, dtype=torch.float16)
     st.xtc_bf = torch.empty(B, dm, st.Skp, device=dev, dtype=torch.bfloat16) if train else None
-    mean = torch.empty(B, dm, device=dev, dtype=torch.float32) if train else None
-    _lib.check(lib.bmt_memory_transposed(_p(x.fh), x.fh.stride(0), pk.off_ptr, B, dm, st.Skp, _p(st.xt_f16), _p(st.xtc_bf), _p(mean), _st()),
+    # one zeroed allocation: the B stack (rows t >= Tq are never written: finite zeros) and the workspace of the samples' key sums behind it
+    nb_ = B * n_layers * 2 * H * 32 * dm
+    raw = zero_(torch.empty(2 * nb_ + 4 * B * dm, device=dev, dtype=torch.uint8))
+    st.bstack = raw[:2 * nb_].view(torch.bfloat16).view(B, n_layers, 2, H, 32, dm)
+    ksum = raw[2 * nb_:].view(torch.float32)
+    _lib.check(lib.bmt_memory_transposed(_p(x.fh), x.fh.stride(0), pk.off_ptr, B, dm, st.Skp, _p(st.xt_f16), _p(st.xtc_bf), _p(ksum), _st()),
                "bmt_memory_transposed")
     st.astack = torch.empty(B, n_layers, 2, H, 32, st.Skp, device=dev, dtype=torch.bfloat16) if train else None
-    st.bstack = zero_(torch.empty(B, n_layers, 2, H, 32, dm, device=dev, dtype=torch.bfloat16))       # rows t >= Tq are never written: finite zeros
     out = RawMemoryFn.apply(mem, st) if train else mem.view_as(mem)
     carry_pack(pk, out)
     attach_planes(out, x)
@@ -2540,21 +2546,24 @@ class RawCrossAttnFn(torch.autograd.Function):
         # Q'[(b, t)][h dm + d] = q_h W_k,h: fp16 (the A operand of S) in the natural layout, bf16 into the B stack (b, l, 0, h)
         qf = torch.empty(M, H * dm, device=dev, dtype=torch.float16)
         bo_, bsb, bsh = st.b_block(l, 0)
-        gemm_batched(X3, Tq, dm, D // H, B, H, _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
-                     a_off=(Tq * D, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(bsb, bsh), p2=_addr(qf), p2_f16=True,
-                     ldp2=H * dm, p2_off=(Tq * H * dm, dm))
+        # (one product per head over all the samples' rows: a weight tile is fetched once, not once per sample; row (b, t) -> block b of the stack)
+        gemm_batched(X3, M, dm, D // H, 1, H, _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
+                     a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb), p2=_addr(qf), p2_f16=True,
+                     ldp2=H * dm, p2_off=(0, dm), p2_div=(0, 0))
         # S = Q' X^T against the sample's packed rows
         S_ = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
-        gemm_batched(PREC_F16, Tq, st.S, dm, B, H, _addr(qf), None, H * dm, _addr(st.x.fh), None, st.x.fh.stride(0),
-                     a_off=(Tq * H * dm, dm), b_rows=st.pack.off_ptr, C_=_addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 32 * Skp))
+        # (one product per sample over the H Tq queries of all heads -- row (h, t): the memory's rows are fetched once for the four heads)
+        gemm_batched(PREC_F16, H * Tq, st.S, dm, B, 1, _addr(qf), None, H * dm, _addr(st.x.fh), None, st.x.fh.stride(0),
+                     a_off=(Tq * H * dm, 0), a_div=(Tq, dm), b_rows=st.pack.off_ptr, C_=_addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
         Pf = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float16)
         ao, asb, ash = st.a_block(l, 1) if st.astack is not None else (0, 0, 0)
         _lib.check(lib.bmt_raw_softmax_fwd(_p(S_), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), _p(Pf),
                                            C.c_void_p(_addr(st.astack, ao)) if st.astack is not None else None, asb, ash, _st()), "bmt_raw_softmax_fwd")
         # O' = P X (natural layout, split-bf16 planes: the A operand of the value block product)
         Op = _alloc_planes(M, H * dm, "x3", dev, ld=H * dm)
-        gemm_batched(PREC_F16, Tq, dm, Skp, B, H, _addr(Pf), None, Skp, _addr(st.xt_f16), None, Skp,
-                     a_off=(H * 32 * Skp, 32 * Skp), b_off=(dm * Skp, 0), p1=_addr(Op.hi), p2=_addr(Op.lo), ldp=H * dm, p_off=(Tq * H * dm, dm))
+        gemm_batched(PREC_F16, H * Tq, dm, Skp, B, 1, _addr(Pf), None, Skp, _addr(st.xt_f16), None, Skp,
+                     a_off=(H * 32 * Skp, 0), a_div=(Tq, 32 * Skp), b_off=(dm * Skp, 0), p1=_addr(Op.hi), p2=_addr(Op.lo), ldp=H * dm,
+                     p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
         # concat_h(O'_h W_v,h^T + b_v), dropout on the attention output (model/multihead_attention.py:22-23), as split-bf16 planes
         o = _alloc_planes(M, D, "x3", dev, ld=D)
         gv_hi, gv_lo = grp.hi[D:], grp.lo[D:]                                               # W_v's rows of the group
@@ -2612,20 +2621,20 @@ class RawCrossAttnFn(torch.autograd.Function):
         gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))
         # dO'_h = do_h W_v,h  -> B stack (b, l, 1, h)
         bo_, bsb, bsh = st.b_block(l, 1)
-        gemm_batched(PREC_BF16, Tq, dm, dk, B, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
-                     a_off=(Tq * D, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(bsb, bsh))
+        gemm_batched(PREC_BF16, M, dm, dk, 1, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
+                     a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb))
         dWv = _blockdiag_dw(do, Planes(Oph, None, M, H * dm), Wv, H)
         # dP = dO' X^T
         dP = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
-        gemm_batched(PREC_BF16, Tq, st.S, dm, B, H, _addr(st.bstack, bo_), None, dm, _addr(st.x.hi), None, st.x.hi.stride(0),
-                     a_off=(bsb, bsh), b_rows=st.pack.off_ptr, C_=_addr(dP), ldc=Skp, c_off=(H * 32 * Skp, 32 * Skp))
+        gemm_batched(PREC_BF16, H * Tq, st.S, dm, B, 1, _addr(st.bstack, bo_), None, dm, _addr(st.x.hi), None, st.x.hi.stride(0),
+                     a_off=(bsb, 0), a_div=(Tq, bsh), b_rows=st.pack.off_ptr, C_=_addr(dP), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
         ao, asb, ash = st.a_block(l, 0)
         _lib.check(lib.bmt_raw_softmax_bwd(_p(Pf), _p(dP), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _st()),
                    "bmt_raw_softmax_bwd")
         # dQ' = dS (X - mean key): natural layout, bf16
         dQp = Planes(torch.empty(M, H * dm, device=dev, dtype=torch.bfloat16), None, M, H * dm)
-        gemm_batched(PREC_BF16, Tq, dm, Skp, B, H, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
-                     a_off=(asb, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, dm))
+        gemm_batched(PREC_BF16, H * Tq, dm, Skp, B, 1, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
+                     a_off=(asb, 0), a_div=(Tq, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
         # dq_h = dQ'_h W_k,h^T (+ its column sums = db_q)
         gbq = static_grad(bq)
         dbq_t = gbq if gbq is not None else torch.zeros(D, device=dev, dtype=torch.float32)

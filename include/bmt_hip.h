@@ -155,6 +155,10 @@ typedef struct {
     const int* b_rows_dev;
     int64_t c_off_o, c_off_i, p_off_o, p_off_i, p2_off_o, p2_off_i, ldp2;
     int64_t bias_off_i, drop_off_o, drop_off_i;
+    /* row r of the A operand / of an output lives at (r / x_div) * x_qs + (r % x_div) * ld instead of r * ld when x_div > 0: blocks of x_div
+     * rows that are x_qs elements apart (the queries of one head inside a (sample, query) x (head, d) tensor; the 32-row blocks of a stack) */
+    int a_div, c_div, p_div, p2_div;
+    int64_t a_qs, c_qs, p_qs, p2_qs;
 } bmt_gemm_batch;
 int bmt_gemm_small_batched(const bmt_gemm_bf16_args* args, const bmt_gemm_batch* batch, void* stream);
 /* ... and the kernels between those products (csrc/raw_memory.hip).  `off` = bmt_pack_rows' offsets of the memory (int32, off[b] = first
@@ -166,7 +170,7 @@ int bmt_gemm_small_batched(const bmt_gemm_bf16_args* args, const bmt_gemm_batch*
  *                          the length are zeros.  A sample without a valid key gives zeros (the reference gives NaN);
  *   bmt_raw_softmax_bwd    dS = P o (dP - rowsum(P o dP)) * scale as bf16 at ds_bf + b * ds_sb + h * ds_sh + t * Skp. */
 int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const int* off, int B, int D, int Skp, uint16_t* xt_f16, uint16_t* xtc_bf,
-                          float* mean_ws /* B * D floats, needed with xtc_bf */, void* stream);
+                          float* mean_ws /* B * D floats, ZEROED by the caller: needed with xtc_bf */, void* stream);
 int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb,
                         int64_t p_bf_sh, void* stream);
 int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* ds_bf, int64_t ds_sb,

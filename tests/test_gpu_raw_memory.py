@@ -65,7 +65,7 @@ def test_memory_transposed(ops, B, S, D):
     Skp = ops._pad64(S)
     xt = torch.full((B, D, Skp), 3.0, device=DEV, dtype=torch.float16)
     xc = torch.full((B, D, Skp), 3.0, device=DEV, dtype=torch.bfloat16)
-    ws = torch.empty(B, D, device=DEV)
+    ws = torch.zeros(B, D, device=DEV)
     ops._lib.check(ops.lib.bmt_memory_transposed(ops._p(pl.fh), pl.fh.stride(0), ops.pack_of(xp).off_ptr, B, D, Skp, ops._p(xt), ops._p(xc), ops._p(ws), ops._st()), "t")
     mm = m.view(B, S)
     for b in range(B):
@@ -121,10 +121,10 @@ def test_batched_small_products(ops):
     q = (rnd(B * Tq, H * dm, seed=2) * 0.5).to(DEV)
     qpl = ops.make_planes(q, "f16")
     Skp = ops._pad64(S)
-    # S[b][h][t][k] = q[(b, t)][h dm : (h + 1) dm] . X_b[k]
+    # S[b][h][t][k] = q[(b, t)][h dm : (h + 1) dm] . X_b[k]: one product per sample over the H Tq rows (h, t), block rows on both sides
     S_ = torch.full((B, H, 32, Skp), 7.0, device=DEV)
-    ops.gemm_batched(ops.PREC_F16, Tq, S, dm, B, H, ops._addr(qpl.fh), None, H * dm, ops._addr(xpl.fh), None, xpl.fh.stride(0),
-                     a_off=(Tq * H * dm, dm), b_rows=pk.off_ptr, C_=ops._addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 32 * Skp))
+    ops.gemm_batched(ops.PREC_F16, H * Tq, S, dm, B, 1, ops._addr(qpl.fh), None, H * dm, ops._addr(xpl.fh), None, xpl.fh.stride(0),
+                     a_off=(Tq * H * dm, 0), a_div=(Tq, dm), b_rows=pk.off_ptr, C_=ops._addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
     mm = m.view(B, S)
     for b in range(B):
         n = int(lens[b])
