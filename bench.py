@@ -388,6 +388,11 @@ def PMC_FAMILY_OF_KERNEL(name: str) -> str:
     n = re.sub(r"^void ", "", n)
     if n.startswith("gemm_bf16_grouped_kernel"):
         return "gemm_dw_grouped"
+    if n.startswith("gemm_memory_grad_kernel"):       # the same body over the per-sample products of an encoder memory's gradient (ops.RawMemoryFn)
+        return "gemm_memory_grad"
+    m = re.match(r"gemm_small_kernel<(\d), (true|false)", n)      # 32 x 32 tiles: the decoder's small products, plain and batched
+    if m:
+        return "gemm_small_x3" if m.group(1) == "3" else ("gemm_small_f16" if m.group(2) == "true" else "gemm_small_bf16")
     # implicit Conv1d launches (CONV, the sixth template argument, is 1 or 2): families of their own -- the proposal heads' k-tap products
     m = re.match(r"gemm_(?:bf16_kernel<(\d), \d, \d, (?:true|false), (?:true|false), ([12])|pipe_kernel<(\d), (?:true|false), \d, (?:true|false), (?:true|false), ([12]))", n)
     if m:
@@ -431,14 +436,18 @@ def pmc_keys_of_class(cls: str):
         return ("conv_f16",) if cls.endswith("_fp16") else ("conv_bf16",)
     if "dw_grouped" in cls:
         return ("gemm_dw_grouped",)
+    if "memory_grad" in cls:
+        return ("gemm_memory_grad",)
+    if cls.startswith("gemm_small_batched"):
+        return ("gemm_small_x3",) if cls.endswith("bf16x3") else (("gemm_small_f16",) if cls.endswith("_fp16") else ("gemm_small_bf16",))
     if cls.endswith("bf16x3"):
-        return ("gemm_x3",)
+        return ("gemm_x3", "gemm_small_x3")      # (the class is by operand format: the decoder's products on 32 x 32 tiles + the generator's on 128-row tiles)
     if "(fp16 hi+lo)" in cls:
         return ("gemm_w2",)
     if cls.endswith("_fp16"):
         return ("gemm_f16",)
     if cls.endswith("_bf16"):
-        return ("gemm_bf16",)
+        return ("gemm_bf16", "gemm_small_bf16")
     return (cls,)
 
 

@@ -1529,6 +1529,27 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(TI == 
     else gemm_bf16_tile<NPASS, WM, TI, AKM, BKM, 0>(p, tile, split, true);
 }
 
+// the same launch under another name for the per-sample products of an encoder memory's gradient (output rows placed by device-side offsets:
+// bmt_gemm_bf16_args.c_row_dev): kernel statistics and counters keep the step's weight-gradient launch apart from them
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_memory_grad_kernel(const GemmB* __restrict__ table,
+                                                                                                            const XcdSeg* __restrict__ segs,
+                                                                                                            const int* __restrict__ nseg) {
+    const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const XcdSeg* sx = segs + x * XCD_MAXSEG;
+    int lo = 0, hi = nseg[x] - 1;
+    if (hi < 0) return;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (sx[mid].first_slot <= slot) lo = mid;
+        else hi = mid - 1;
+    }
+    const XcdSeg sg = sx[lo];
+    const int local = slot - sg.first_slot;
+    if (local >= sg.count * sg.nsplit) return;
+    const GemmB p = table[sg.prob];
+    gemm_bf16_tile<1, 4, 1, true, true, 0>(p, sg.tile_off + local % sg.count, local / sg.count, true);
+}
+
 // second pass of the two-pass split-K: sum the partials of one output element group (4 consecutive columns) in split order
 // and run the same epilogue as the GEMM kernel.  One writer per element: ACCUM is a plain read-modify-write.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmB p) {
@@ -2188,8 +2209,10 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     if (!pr || !order || !sp) { free(pr); free(order); free(sp); bmt_set_error("bmt_gemm_bf16_grouped: out of host memory"); return BMT_EINVAL; }
     int rc = BMT_OK;
     double total_work = 0.0;
+    bool placed = false;                 // some output is a packed row range (c_row_dev): the launch runs under its own kernel name
     for (int i = 0; i < nprob && rc == BMT_OK; ++i) {
         const bmt_gemm_bf16_args* a = args + i;
+        placed = placed || a->c_row_dev != nullptr;
         if (!(a->precision == BMT_PREC_BF16 && a->a_kmajor && a->b_kmajor && a->conv_mode == 0 && a->C && !a->C_hi && !a->colsum)) {
             bmt_set_error("bmt_gemm_bf16_grouped: problem %d: the grouped launch takes single-pass GEMMs with both operands k-major and "
                           "fp32 output", i);
@@ -2273,7 +2296,16 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 4, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(8 * max_slots), dim3(512), lds, st, table, segs, nseg);
+    if (placed) {
+        static bool done2 = false;
+        if (!done2) {
+            (void)hipFuncSetAttribute((const void*)gemm_memory_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done2 = true;
+        }
+        hipLaunchKernelGGL(gemm_memory_grad_kernel, dim3(8 * max_slots), dim3(512), lds, st, table, segs, nseg);
+    } else {
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 4, 1, true, true>), dim3(8 * max_slots), dim3(512), lds, st, table, segs, nseg);
+    }
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped");
     return BMT_OK;
 }
