@@ -1435,14 +1435,28 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
         }
         if (f & BMT_EPI_GATE) {            // keep an element iff the saved forward output is non-zero (sign bit ignored)
             const uint16_t* gp = p.gate + (int64_t)row * p.ldg + col;
+            if (full && ((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gate) & 15) == 0)) {      // one 16-byte load instead of eight 2-byte ones
+                const u32x4 gv = *reinterpret_cast<const u32x4*>(gp);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (col + q < p.N && (gp[q] & 0x7fffu)) ? v[q] * p.gate_scale : 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = (gv[q] & 0x00007FFFu) ? v[2 * q] * p.gate_scale : 0.f;
+                    v[2 * q + 1] = (gv[q] & 0x7FFF0000u) ? v[2 * q + 1] * p.gate_scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (col + q < p.N && (gp[q] & 0x7fffu)) ? v[q] * p.gate_scale : 0.f;
+            }
         }
         if (f & BMT_EPI_RESIDUAL) {
             const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            if (full && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)) {
+                const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (col + q < p.N) v[q] += rp[q];
+                for (int q = 0; q < 8; ++q)
+                    if (col + q < p.N) v[q] += rp[q];
+            }
         }
         if (!full) {
 #pragma unroll

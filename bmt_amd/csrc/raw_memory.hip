@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void memory_transposed_kernel(const uint16_t* 
 // rows t >= Tq and keys >= the sample's length are written as zeros (they are reduction padding of the products that follow)
 __global__ __launch_bounds__(256) void raw_softmax_fwd_kernel(const float* __restrict__ S, const int* __restrict__ off, int H, int Tq, int Skp, float scale,
                                                                uint16_t* __restrict__ p_f16, uint16_t* __restrict__ p_bf, int64_t sb, int64_t sh, int nrows) {
-    constexpr int NV = 16;                                    // keys per lane held in registers: Skp <= 1024
+    constexpr int NG = 2;                                     // groups of 8 consecutive keys per lane: Skp <= 1024; 16-byte accesses
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nrows) return;
     const int t = row & 31, bh = row >> 5, b = bh / H, h = bh - b * H;
@@ -92,34 +92,50 @@ __global__ __launch_bounds__(256) void raw_softmax_fwd_kernel(const float* __res
     uint16_t* pf = p_f16 + (int64_t)row * Skp;
     uint16_t* pb = p_bf ? p_bf + b * sb + h * sh + (int64_t)t * Skp : nullptr;
     const bool live = t < Tq && len > 0;
-    float v[NV];
+    float v[NG][8];
     float m = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        v[i] = (live && k < len) ? s[k] : -INFINITY;
-        m = fmaxf(m, v[i]);
+    for (int g = 0; g < NG; ++g) {
+        const int k0 = (lane + 64 * g) * 8;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (live && k0 < len) {                               // (a group that straddles the length: its tail may hold anything)
+            a0 = *reinterpret_cast<const float4*>(s + k0);
+            a1 = *reinterpret_cast<const float4*>(s + k0 + 4);
+        }
+        const float t8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[g][q] = (live && k0 + q < len) ? t8[q] : -INFINITY;
+            m = fmaxf(m, v[g][q]);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     const float sc = scale * 1.4426950408889634f;            // exp(x * scale) = exp2(x * scale * log2 e)
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = (live && lane + 64 * i < len) ? exp2f((v[i] - m) * sc) : 0.f;
-        sum += v[i];
-    }
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[g][q] = (live && (lane + 64 * g) * 8 + q < len) ? exp2f((v[g][q] - m) * sc) : 0.f;
+            sum += v[g][q];
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = live ? 1.f / sum : 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        if (k < Skp) {
-            const float p = v[i] * inv;
-            pf[k] = __builtin_bit_cast(uint16_t, (_Float16)p);
-            if (pb) pb[k] = (uint16_t)f2bf_bits(p);
+    for (int g = 0; g < NG; ++g) {
+        const int k0 = (lane + 64 * g) * 8;
+        if (k0 >= Skp) continue;
+        u32x4 f, bfv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float p0 = v[g][2 * q] * inv, p1 = v[g][2 * q + 1] * inv;
+            f[q] = pack_h2(p0, p1);
+            bfv[q] = pack_bf2(p0, p1);
         }
+        *reinterpret_cast<u32x4*>(pf + k0) = f;
+        if (pb) *reinterpret_cast<u32x4*>(pb + k0) = bfv;
     }
 }
 
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(256) void raw_softmax_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void raw_softmax_bwd_kernel(const uint16_t* __restrict__ p_f16, const float* __restrict__ dP, const int* __restrict__ off,
                                                                int H, int Tq, int Skp, float scale, uint16_t* __restrict__ ds_bf, int64_t sb, int64_t sh,
                                                                int nrows) {
-    constexpr int NV = 16;
+    constexpr int NG = 2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nrows) return;
     const int t = row & 31, bh = row >> 5, b = bh / H, h = bh - b * H;
@@ -137,22 +153,37 @@ __global__ __launch_bounds__(256) void raw_softmax_bwd_kernel(const uint16_t* __
     const float* dp = dP + (int64_t)row * Skp;
     uint16_t* ds = ds_bf + b * sb + h * sh + (int64_t)t * Skp;
     const bool live = t < Tq && len > 0;
-    float pv[NV], dv[NV];
+    float pv[NG][8], dv[NG][8];
     float delta = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        const bool in = live && k < len;
-        pv[i] = in ? h_bits2f(pf[k]) : 0.f;
-        dv[i] = in ? dp[k] : 0.f;
-        delta += pv[i] * dv[i];
+    for (int g = 0; g < NG; ++g) {
+        const int k0 = (lane + 64 * g) * 8;
+        u32x4 ph = {0u, 0u, 0u, 0u};
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (live && k0 < len) {
+            ph = *reinterpret_cast<const u32x4*>(pf + k0);
+            a0 = *reinterpret_cast<const float4*>(dp + k0);
+            a1 = *reinterpret_cast<const float4*>(dp + k0 + 4);
+        }
+        const float t8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool in = live && k0 + q < len;
+            pv[g][q] = in ? h_bits2f((ph[q >> 1] >> (16 * (q & 1))) & 0xffffu) : 0.f;
+            dv[g][q] = in ? t8[q] : 0.f;
+            delta += pv[g][q] * dv[g][q];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        if (k < Skp) ds[k] = (uint16_t)f2bf_bits(pv[i] * (dv[i] - delta) * scale);
+    for (int g = 0; g < NG; ++g) {
+        const int k0 = (lane + 64 * g) * 8;
+        if (k0 >= Skp) continue;
+        u32x4 o_;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o_[q] = pack_bf2(pv[g][2 * q] * (dv[g][2 * q] - delta) * scale, pv[g][2 * q + 1] * (dv[g][2 * q + 1] - delta) * scale);
+        *reinterpret_cast<u32x4*>(ds + k0) = o_;
     }
 }
 
@@ -173,8 +204,9 @@ extern "C" int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const in
 
 extern "C" int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf,
                                    int64_t p_bf_sb, int64_t p_bf_sh, void* stream) {
-    BMT_CHECK_ARG(S && off && p_f16 && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0 && Skp <= 1024,
-                  "bmt_raw_softmax_fwd: bad arguments (at most 32 queries per sample and head, at most 1024 keys per sample)");
+    BMT_CHECK_ARG(S && off && p_f16 && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0 && Skp <= 1024 && Skp % 8 == 0 &&
+                      !((reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(p_f16) | reinterpret_cast<uintptr_t>(p_bf)) & 15) && !((p_bf_sb | p_bf_sh) & 7),
+                  "bmt_raw_softmax_fwd: bad arguments (at most 32 queries per sample and head, Skp a multiple of 8 and at most 1024, 16-byte aligned buffers)");
     const int nrows = B * H * 32;
     hipLaunchKernelGGL(raw_softmax_fwd_kernel, dim3(bmt_cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, S, off, H, Tq, Skp, scale, p_f16, p_bf, p_bf_sb, p_bf_sh,
                        nrows);
@@ -184,7 +216,9 @@ extern "C" int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H,
 
 extern "C" int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* ds_bf,
                                    int64_t ds_sb, int64_t ds_sh, void* stream) {
-    BMT_CHECK_ARG(p_f16 && dP && off && ds_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0 && Skp <= 1024, "bmt_raw_softmax_bwd: bad arguments");
+    BMT_CHECK_ARG(p_f16 && dP && off && ds_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32 && Skp > 0 && Skp <= 1024 && Skp % 8 == 0 &&
+                      !((reinterpret_cast<uintptr_t>(dP) | reinterpret_cast<uintptr_t>(p_f16) | reinterpret_cast<uintptr_t>(ds_bf)) & 15) && !((ds_sb | ds_sh) & 7),
+                  "bmt_raw_softmax_bwd: bad arguments (Skp a multiple of 8, at most 1024; 16-byte aligned buffers)");
     const int nrows = B * H * 32;
     hipLaunchKernelGGL(raw_softmax_bwd_kernel, dim3(bmt_cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, p_f16, dP, off, H, Tq, Skp, scale, ds_bf, ds_sb, ds_sh,
                        nrows);
