@@ -187,7 +187,8 @@ def context() -> StepContext:
 # under hipGraph capture, where the fork becomes parallel branches of the graph).  What is per pass stays per pass: the side stream
 # is an alias of the main stream's StepContext (queued weight gradients and small reductions are flushed once, on the main stream,
 # after autograd has joined the streams); what is per stream is already keyed by stream (split-K and grouped-GEMM scratch).
-ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "2"))     # switch: 1 = everything on one stream (the profilers' and the kernel timer's eager steps)
+ENC_STREAMS = int(_os.environ.get("BMT_ENC_STREAMS", "3"))     # switch: 1 = everything on one stream (the profilers' and the kernel timer's eager steps);
+                                                               # 2 = without the first decoder layer's self-attention sublayer beside the encoder (round 5: 7.17 / 7.21 -> 7.13 / 7.19 ms)
 _side_streams = {}
 
 
