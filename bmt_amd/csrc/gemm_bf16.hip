@@ -1286,7 +1286,7 @@ __device__ __forceinline__ int64_t small_row(int r, int div, int64_t qs, int64_t
 
 template <int NPASS, bool F16, bool AF32 = false>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const SmallBatch bt) {
-    static_assert(!AF32 || (NPASS == 1 && !F16), "the fp32 A operand feeds the one-pass bf16 product");
+    static_assert(!AF32 || ((NPASS == 1 || NPASS == 3) && !F16), "the fp32 A operand feeds a bf16 product: one pass, or split (hi + lo made while staging)");
     GemmB p = p_;
     int64_t drop_base = 0, ldp2 = p.ldp;
     if (bt.nb_inner > 0) {
@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
             } else                                                                                  \
             rg[set_][0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, va_, so_, 0);              \
             rg[set_][1][i] = __builtin_amdgcn_raw_buffer_load_b128(rsBh, vb_, so_, 0);              \
-            if constexpr (ALO) rg[set_][2][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, va_, so_, 0); \
+            if constexpr (ALO && !AF32) rg[set_][2][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, va_, so_, 0); \
             if constexpr (BLO) rg[set_][NPL - 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rsBl, vb_, so_, 0); \
         }                                                                                           \
     } while (0)
@@ -1382,10 +1382,16 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
                     _Pragma("unroll") for (int q = 0; q < 8; ++q)                                   \
                         f_[q] = drop_apply(adc, f_[q], (uint64_t)((int64_t)row_ * bt.a_cols + c0_ + q)); \
                 }                                                                                   \
-                u32x4 w_;                                                                           \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) w_[q] = pack_bf2(f_[2 * q], f_[2 * q + 1]); \
+                u32x4 w_, wl_;                                                                      \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+                    uint32_t h2_, l2_;                                                              \
+                    split_bf2(f_[2 * q], f_[2 * q + 1], h2_, l2_);      /* hi = bf16(x), lo = bf16(x - hi) */ \
+                    w_[q] = h2_;                                                                    \
+                    wl_[q] = l2_;                                                                   \
+                }                                                                                   \
                 _Pragma("unroll") for (int q = 0; q < 8; ++q) cs_[q] += f_[q];                      \
                 rg[set_][0][i] = w_;                                                                \
+                if constexpr (ALO) rg[set_][2][i] = wl_;                                            \
                 if (a_side && bt.a_plane != nullptr && (c_) < c1 && row_ < Mr)                      \
                     *reinterpret_cast<u32x4*>(bt.a_plane + (int64_t)row_ * bt.a_ldp + c0_) = w_;    \
             }                                                                                       \
@@ -2190,11 +2196,11 @@ extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gem
     BMT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && !a->conv_mode && (a->splitk <= 1 || a->splitk == 4) && !a->rows_dev && !a->c_row_dev && !a->m_dev &&
                       (single || !(a->flags & (BMT_EPI_RESIDUAL | BMT_EPI_GATE | BMT_EPI_ACCUM))),
                   "bmt_gemm_small_batched: row-major operands, no split; residual / gate / accumulate only for a single product");
-    BMT_CHECK_ARG(!b->a_f32 || (single && a->precision == BMT_PREC_BF16 && b->a_div == 0 && b->a_cols > 0 && b->a_cols % 4 == 0 && b->a_cols <= a->Kpad &&
+    BMT_CHECK_ARG(!b->a_f32 || (single && (a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_BF16X3) && b->a_div == 0 && b->a_cols > 0 && b->a_cols % 4 == 0 && b->a_cols <= a->Kpad &&
                                 b->a_f32_ld >= b->a_cols && b->a_f32_ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->a_f32) & 15) &&
                                 (!b->a_plane || (b->a_ldp >= a->Kpad && b->a_ldp % 8 == 0 && !(reinterpret_cast<uintptr_t>(b->a_plane) & 15))) &&
                                 b->a_drop_p >= 0.f && b->a_drop_p < 1.f && (b->a_drop_p == 0.f || a->rng)),
-                  "bmt_gemm_small_batched: an fp32 A operand takes a single one-pass bf16 product, a width that is a multiple of 4 and 16-byte aligned rows");
+                  "bmt_gemm_small_batched: an fp32 A operand takes a single bf16 product (one pass or split), a width that is a multiple of 4 and 16-byte aligned rows");
     BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_BF16X3,
                   "bmt_gemm_small_batched: BMT_PREC_BF16, BMT_PREC_F16 or BMT_PREC_BF16X3");
     GemmB p;
@@ -2229,7 +2235,7 @@ extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gem
     BMT_CHECK_ARG(b->a_div >= 0 && b->c_div >= 0 && b->p_div >= 0 && b->p2_div >= 0 && !((b->a_qs | b->p_qs | b->p2_qs) & 7) && !(b->c_qs & 3),
                   "bmt_gemm_small_batched: block-row strides must keep 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-    if (a->precision == BMT_PREC_BF16X3) return launch_small<3, false>(p, st, &bt, nb);
+    if (a->precision == BMT_PREC_BF16X3) return b->a_f32 ? launch_small<3, false, true>(p, st, &bt, nb) : launch_small<3, false>(p, st, &bt, nb);
     if (a->precision == BMT_PREC_F16) return launch_small<1, true>(p, st, &bt, nb);
     if (b->a_f32) return launch_small<1, false, true>(p, st, &bt, nb);
     return launch_small<1, false>(p, st, &bt, nb);

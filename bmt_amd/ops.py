@@ -1773,12 +1773,24 @@ class LinearActFn(torch.autograd.Function):
         xc = _f32c(x)
         K = xc.shape[-1]
         x2 = xc.view(-1, K)
-        y = linear_fwd(x2, W, b, precision=policy_of(None).gemm, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"),
-                       drop_p=p, site=site)
+        prec = policy_of(None).gemm
+        epi = dict(relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"), drop_p=p, site=site)
+        xsave = x2
+        if (FUSE_GRAD_DX and prec == PREC_BF16X3 and 0 < x2.shape[0] * W.shape[0] <= SMALL_DX_OUTPUTS and K % 4 == 0 and x2.data_ptr() % 16 == 0 and
+                planes_of(x, "x3") is None):
+            # a small product (the bridge): the 32 x 32 tile kernel splits the fp32 input into hi + lo while staging it and leaves the bf16 plane
+            # the weight gradient will read -- no conversion launch here, none in the backward pass
+            hi = torch.empty(x2.shape[0], _pad64(K), device=x2.device, dtype=torch.bfloat16)
+            y = torch.empty(x2.shape[0], W.shape[0], device=x2.device, dtype=torch.float32)
+            gemm_bf16(Planes(hi, hi, x2.shape[0], K), weight_planes(W, "x3"), y, ldc=y.stride(0), bias=b, precision=prec, a_f32=(x2, None, None), **epi)
+            xsave = hi
+        else:
+            y = linear_fwd(x2, W, b, precision=prec, **epi)
         ctx.relu, ctx.drop_mode, ctx.p, ctx.site = relu, drop_mode, p, site
         ctx.has_bias = b is not None
         ctx.params = (W, b)
-        ctx.save_for_backward(x2, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
+        ctx.x_is_plane = xsave is not x2
+        ctx.save_for_backward(xsave, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
         return y.view(*xc.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -1786,6 +1798,8 @@ class LinearActFn(torch.autograd.Function):
         x2, W, y = ctx.saved_tensors
         N = W.shape[0]
         dy2 = _f32c(dy).view(-1, N)
+        if ctx.x_is_plane:               # (the forward left the input's bf16 plane, the weight gradient's operand, instead of the input)
+            x2 = Planes(x2, None, x2.shape[0], W.shape[1])
         p = ctx.p if ctx.drop_mode != "none" else 0.0
         if ctx.relu:
             # dz = (y != 0) ? dy / (1 - p) : 0 never exists: its bf16 plane and column sums (the bias gradient) come out of one pass over dy and y

@@ -159,7 +159,8 @@ typedef struct {
      * rows that are x_qs elements apart (the queries of one head inside a (sample, query) x (head, d) tensor; the 32-row blocks of a stack) */
     int a_div, c_div, p_div, p2_div;
     int64_t a_qs, c_qs, p_qs, p2_qs;
-    /* a single BMT_PREC_BF16 product whose A operand is still fp32 (an upstream gradient dY [M][a_cols], row stride a_f32_ld): converted while
+    /* a single BMT_PREC_BF16 (or BMT_PREC_BF16X3: hi + lo made on the way) product whose A operand is still fp32 (an upstream gradient dY, or a
+     * LayerNorm output in front of a Linear; [M][a_cols], row stride a_f32_ld): converted while
      * it is staged -- what bmt_planes / bmt_planes_dropout would do in a launch of their own -- through the dropout mask (a_drop_p, a_drop_site;
      * args->rng) if any; a_plane (optional, [M][a_ldp >= Kpad]) receives bf16(dropout(dY)), zero padded, and a_colsum (optional, [a_cols])
      * += its column sums: the k-major operand and the bias gradient of the same Linear's weight-gradient product.  args->A_hi is ignored. */

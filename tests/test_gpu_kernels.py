@@ -328,6 +328,31 @@ def test_small_dx_converts_its_own_upstream_gradient(ops, M, C_, K, p_drop):
     assert_close(outs[1][1], outs[0][1], atol=2e-3 * float(outs[0][1].abs().max()) + 1e-3, name="output column sums")
 
 
+@pytest.mark.parametrize("M,K,N", [(928, 600, 300), (37, 64, 128), (928, 300, 1200)])
+def test_small_split_product_splits_its_own_fp32_input(ops, M, K, N):
+    """LinearActFn (the bridge: relu(dropout(x W^T + b))) on a small product: the 32 x 32 tile kernel makes hi + lo of the fp32 input while staging it
+    and leaves the bf16 plane for the weight gradient -- same output bit for bit, same gradients, as with the conversion pass in front"""
+    x = rnd(M, K, seed=41).to(DEV)
+    W = (rnd(N, K, seed=42) * 0.2).to(DEV)
+    b = rnd(N, seed=43).to(DEV)
+    g = rnd(M, N, seed=44).to(DEV)
+    ops.manual_seed(9)
+    res = []
+    old = ops.FUSE_GRAD_DX
+    for fused in (False, True):
+        ops.FUSE_GRAD_DX = fused
+        try:
+            xs, Ws, bs = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.LinearActFn.apply(xs, Ws, bs, True, "pre", 0.1, 777)
+            y.backward(g)
+            res.append((y.detach().clone(), xs.grad.clone(), Ws.grad.clone(), bs.grad.clone()))
+        finally:
+            ops.FUSE_GRAD_DX = old
+    assert torch.equal(res[0][0], res[1][0]), float((res[0][0] - res[1][0]).abs().max())
+    for a, c, name in zip(res[0][1:], res[1][1:], ("dx", "dW", "db")):
+        assert_close(c, a, atol=1e-5 * float(a.abs().max()) + 1e-7, rtol=1e-5, name=name)
+
+
 @pytest.mark.parametrize("prec", [X3, F16W2])
 def test_gemm_dropout_epilogue_matches_standalone(ops, prec):
     """the fused dropout epilogue and bmt_dropout share one RNG: same site => same mask."""
