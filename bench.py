@@ -462,7 +462,10 @@ def pmc_record(procedure=None):
         return None, "no PMC pass committed"
     # a record is a pass over ONE procedure's step (the other procedure's launches -- other shapes, the Conv1d kernels -- are not in it): the
     # newest one taken over this procedure
+    # ... taken with THIS tree's kernel sources (file names are tags, not dates: "r05_end" sorts before "r05_z")
     rec = name = None
+    have = csrc_digest()
+    newest = None
     for path in reversed(files):
         try:
             with open(path) as f:
@@ -472,11 +475,16 @@ def pmc_record(procedure=None):
                 return None, f"profiles/{os.path.basename(path)}: unreadable"
             continue
         if procedure is None or r.get("procedure") in (None, procedure):
-            rec, name = r, os.path.basename(path)
-            break
+            if newest is None:
+                newest = (r, os.path.basename(path))
+            if r.get("csrc_digest") == have:
+                rec, name = r, os.path.basename(path)
+                break
+    if rec is None and newest is not None:
+        rec, name = newest
     if rec is None:
         return None, f"no PMC pass over the {procedure} step committed (tools/gpu_pmc_bench.sh <tag> {procedure})"
-    want, have = rec.get("csrc_digest"), csrc_digest()
+    want = rec.get("csrc_digest")
     if want != have:
         return None, f"profiles/{name} was taken with kernel sources {want}, the tree is {have}: stale, refused"
     return rec, f"profiles/{name} (csrc {have}): FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 --pmc passes over the eagerly issued step"

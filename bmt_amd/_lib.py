@@ -33,9 +33,7 @@ class GemmBatch(C.Structure):
     _fields_ = [("nb_outer", i32), ("nb_inner", i32), ("a_off_o", i64), ("a_off_i", i64), ("b_off_o", i64), ("b_off_i", i64),
                 ("b_rows_dev", vp), ("c_off_o", i64), ("c_off_i", i64), ("p_off_o", i64), ("p_off_i", i64), ("p2_off_o", i64), ("p2_off_i", i64),
                 ("ldp2", i64), ("bias_off_i", i64), ("drop_off_o", i64), ("drop_off_i", i64),
-                ("a_div", i32), ("c_div", i32), ("p_div", i32), ("p2_div", i32), ("a_qs", i64), ("c_qs", i64), ("p_qs", i64), ("p2_qs", i64),
-                ("a_f32", vp), ("a_f32_ld", i64), ("a_ldp", i64), ("a_cols", i32), ("a_plane", vp), ("a_colsum", vp), ("a_drop_p", f32),
-                ("a_drop_site", u32)]
+                ("a_div", i32), ("c_div", i32), ("p_div", i32), ("p2_div", i32), ("a_qs", i64), ("c_qs", i64), ("p_qs", i64), ("p2_qs", i64)]
 
 
 class AttnFwdArgs(C.Structure):

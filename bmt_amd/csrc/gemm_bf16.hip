@@ -1268,15 +1268,6 @@ struct SmallBatch {                  // bmt_gemm_small_batched: product (o, i) =
     const int* b_rows_dev;
     int a_div, c_div, p_div, p2_div;     // row r of A / C / the planes at (r / div) * qs + (r % div) * ld when div > 0
     int64_t a_qs, c_qs, p_qs, p2_qs;
-    // the A operand as fp32 (an upstream gradient: bmt_gemm_batch.a_f32): converted to bf16 while it is staged; the workgroups of the first
-    // column block also write its plane (the k-major operand of the weight gradient) and add its column sums (the bias gradient)
-    const float* a_f32;
-    int64_t a_f32_ld, a_ldp;
-    int a_cols;
-    uint16_t* a_plane;
-    float* a_colsum;
-    float a_drop_p;
-    uint32_t a_drop_site;
 };
 
 // element offset of row r under the block-row addressing of SmallBatch
@@ -1284,9 +1275,8 @@ __device__ __forceinline__ int64_t small_row(int r, int div, int64_t qs, int64_t
     return div > 0 ? (int64_t)(r / div) * qs + (int64_t)(r % div) * ld : (int64_t)r * ld;
 }
 
-template <int NPASS, bool F16, bool AF32 = false>
+template <int NPASS, bool F16>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const SmallBatch bt) {
-    static_assert(!AF32 || ((NPASS == 1 || NPASS == 3) && !F16), "the fp32 A operand feeds a bf16 product: one pass, or split (hi + lo made while staging)");
     GemmB p = p_;
     int64_t drop_base = 0, ldp2 = p.ldp;
     if (bt.nb_inner > 0) {
@@ -1326,16 +1316,15 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
     const int nch = p.Kpad / 64, per = ksplit ? (nch + 3) / 4 : nch;
     const int c0 = ksplit ? wid * per : 0, c1 = min(nch, c0 + per);
     // (block rows: the rows are not one contiguous range; the descriptor ends just below the out-of-range offset the masked lanes use)
-    const int64_t a_bytes = AF32 ? (int64_t)Mr * bt.a_f32_ld * 4 : (bt.a_div > 0 ? 0x7ffffff0 : (int64_t)Mr * p.lda * 2), b_bytes = (int64_t)p.N * p.ldb * 2;
-    const __amdgpu_buffer_rsrc_t rsAh = plane_rsrc(AF32 ? reinterpret_cast<const uint16_t*>(bt.a_f32) : p.Ah, a_bytes), rsAl = plane_rsrc(ALO ? p.Al : p.Ah, a_bytes);
+    const int64_t a_bytes = bt.a_div > 0 ? 0x7ffffff0 : (int64_t)Mr * p.lda * 2, b_bytes = (int64_t)p.N * p.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rsAh = plane_rsrc(p.Ah, a_bytes), rsAl = plane_rsrc(ALO ? p.Al : p.Ah, a_bytes);
     const __amdgpu_buffer_rsrc_t rsBh = plane_rsrc(p.Bh, b_bytes), rsBl = plane_rsrc(BLO ? p.Bl : p.Bh, b_bytes);
     constexpr int OOB = 0x7ffffff0;                               // past any plane (< 2 GiB, checked by the host): reads as zero
     int voa[4], vob[4], lds_w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + (lane >> 3), piece = lane & 7;
-        if constexpr (AF32) voa[i] = (m0 + row < Mr) ? (int)((int64_t)(m0 + row) * bt.a_f32_ld * 4) + piece * 32 : OOB;
-        else voa[i] = (m0 + row < Mr) ? (int)(small_row(m0 + row, bt.a_div, bt.a_qs, p.lda) * 2) + piece * 16 : OOB;
+        voa[i] = (m0 + row < Mr) ? (int)(small_row(m0 + row, bt.a_div, bt.a_qs, p.lda) * 2) + piece * 16 : OOB;
         vob[i] = (n0 + row < p.N) ? (int)((int64_t)(n0 + row) * p.ldb * 2) + piece * 16 : OOB;
         lds_w[i] = slot_of<8>(row, piece) * 16;
     }
@@ -1344,67 +1333,20 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     constexpr int NS = 2;                                         // chunks in flight per wave (four of them for the one-pass products: slower, fewer waves per SIMD)
     u32x4 rg[NS][NPL][4];
-    u32x4 rga[AF32 ? NS : 1][AF32 ? 8 : 1];                     // fp32 A: 8 columns per lane and row = two 16-byte loads
-    // the plane / column sums of an fp32 A operand are written once: by the waves of the first column block
-    const bool a_side = AF32 && n0 == 0 && (bt.a_plane != nullptr || bt.a_colsum != nullptr);
-    const DropCtx adc = make_drop(AF32 ? bt.a_drop_p : 0.f, p.rng, bt.a_drop_site);
 #define BMT_SM_LOAD(set_, c_)                                                                       \
     do {                                                                                            \
         const bool in_ = (c_) < c1;                        /* wave-uniform */                       \
         const int so_ = (c_) * 128;                                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
             const int va_ = in_ ? voa[i] : OOB, vb_ = in_ ? vob[i] : OOB;                           \
-            if constexpr (AF32) {          /* columns past the tensor's width do not exist (no padding in an fp32 tensor) */ \
-                const int c0_ = (c_) * 64 + (lane & 7) * 8;                                         \
-                rga[set_][2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, (in_ && c0_ < bt.a_cols) ? voa[i] : OOB, 2 * so_, 0);          \
-                rga[set_][2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, (in_ && c0_ + 4 < bt.a_cols) ? voa[i] + 16 : OOB, 2 * so_, 0); \
-            } else                                                                                  \
             rg[set_][0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, va_, so_, 0);              \
             rg[set_][1][i] = __builtin_amdgcn_raw_buffer_load_b128(rsBh, vb_, so_, 0);              \
-            if constexpr (ALO && !AF32) rg[set_][2][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, va_, so_, 0); \
+            if constexpr (ALO) rg[set_][2][i] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, va_, so_, 0); \
             if constexpr (BLO) rg[set_][NPL - 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rsBl, vb_, so_, 0); \
         }                                                                                           \
     } while (0)
-#define BMT_SM_STAGE(set_, c_)                                                                      \
+#define BMT_SM_STAGE(set_)                                                                          \
     do {   /* LDS operations of a wave execute in order: these writes follow the previous chunk's fragment reads */ \
-        if constexpr (AF32) {   /* fp32 -> (dropout) -> bf16; first column block: + the plane and the column sums */ \
-            float cs_[8];                                                                           \
-            _Pragma("unroll") for (int q = 0; q < 8; ++q) cs_[q] = 0.f;                             \
-            const int c0_ = (c_) * 64 + (lane & 7) * 8;                                             \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
-                const int row_ = m0 + i * 8 + (lane >> 3);                                          \
-                float f_[8];                                                                        \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
-                    f_[q] = __uint_as_float(rga[set_][2 * i][q]);                                   \
-                    f_[4 + q] = __uint_as_float(rga[set_][2 * i + 1][q]);                           \
-                }                                                                                   \
-                if (adc.on) {                                                                       \
-                    _Pragma("unroll") for (int q = 0; q < 8; ++q)                                   \
-                        f_[q] = drop_apply(adc, f_[q], (uint64_t)((int64_t)row_ * bt.a_cols + c0_ + q)); \
-                }                                                                                   \
-                u32x4 w_, wl_;                                                                      \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
-                    uint32_t h2_, l2_;                                                              \
-                    split_bf2(f_[2 * q], f_[2 * q + 1], h2_, l2_);      /* hi = bf16(x), lo = bf16(x - hi) */ \
-                    w_[q] = h2_;                                                                    \
-                    wl_[q] = l2_;                                                                   \
-                }                                                                                   \
-                _Pragma("unroll") for (int q = 0; q < 8; ++q) cs_[q] += f_[q];                      \
-                rg[set_][0][i] = w_;                                                                \
-                if constexpr (ALO) rg[set_][2][i] = wl_;                                            \
-                if (a_side && bt.a_plane != nullptr && (c_) < c1 && row_ < Mr)                      \
-                    *reinterpret_cast<u32x4*>(bt.a_plane + (int64_t)row_ * bt.a_ldp + c0_) = w_;    \
-            }                                                                                       \
-            if (a_side && bt.a_colsum != nullptr && (c_) < c1) {                                    \
-                _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                     \
-                    float t_ = cs_[q];                                                              \
-                    t_ += __shfl_xor(t_, 8, 64);                                                    \
-                    t_ += __shfl_xor(t_, 16, 64);                                                   \
-                    t_ += __shfl_xor(t_, 32, 64);                                                   \
-                    if (lane < 8 && c0_ + q < bt.a_cols) atomicAdd(bt.a_colsum + c0_ + q, t_);      \
-                }                                                                                   \
-            }                                                                                       \
-        }                                                                                           \
         _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + pl * 4096 + lds_w[i]) = rg[set_][pl][i]; \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
@@ -1432,7 +1374,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmB p_, const S
         for (int c = c0; c < c1; c += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                BMT_SM_STAGE(j, c + j);
+                BMT_SM_STAGE(j);
                 BMT_SM_LOAD(j, c + NS + j);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1969,12 +1911,12 @@ int launch_k128(const GemmB& p, hipStream_t st) {
     return p.Bl ? launch_k128_<F16, true>(p, st) : launch_k128_<F16, false>(p, st);
 }
 
-template <int NPASS, bool F16, bool AF32 = false>
+template <int NPASS, bool F16>
 int launch_small(const GemmB& p, hipStream_t st, const SmallBatch* bt = nullptr, int nbatch = 1) {
     constexpr int lds = 4 * (2 + (NPASS == 3 ? 1 : 0) + (NPASS >= 2 ? 1 : 0)) * 4096;
     SmallBatch none;
     memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL((gemm_small_kernel<NPASS, F16, AF32>), dim3(p.tiles_m * p.tiles_n, nbatch), dim3(256), lds, st, p, bt ? *bt : none);
+    hipLaunchKernelGGL((gemm_small_kernel<NPASS, F16>), dim3(p.tiles_m * p.tiles_n, nbatch), dim3(256), lds, st, p, bt ? *bt : none);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16(32 x 32 tiles)");
     return BMT_OK;
 }
@@ -2192,15 +2134,9 @@ extern "C" int bmt_gemm_bf16(const bmt_gemm_bf16_args* a, void* stream) {
 extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gemm_batch* b, void* stream) {
     BMT_CHECK_ARG(a && b && b->nb_outer > 0 && b->nb_inner > 0 && (int64_t)b->nb_outer * b->nb_inner <= 65535, "bmt_gemm_small_batched: bad batch");
     BMT_CHECK_ARG(BMT_SMALL_TILE_OUTPUTS > 0, "bmt_gemm_small_batched: the library was built without the 32 x 32 tile kernel");
-    const bool single = b->nb_outer == 1 && b->nb_inner == 1;
     BMT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && !a->conv_mode && (a->splitk <= 1 || a->splitk == 4) && !a->rows_dev && !a->c_row_dev && !a->m_dev &&
-                      (single || !(a->flags & (BMT_EPI_RESIDUAL | BMT_EPI_GATE | BMT_EPI_ACCUM))),
-                  "bmt_gemm_small_batched: row-major operands, no split; residual / gate / accumulate only for a single product");
-    BMT_CHECK_ARG(!b->a_f32 || (single && (a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_BF16X3) && b->a_div == 0 && b->a_cols > 0 && b->a_cols % 4 == 0 && b->a_cols <= a->Kpad &&
-                                b->a_f32_ld >= b->a_cols && b->a_f32_ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->a_f32) & 15) &&
-                                (!b->a_plane || (b->a_ldp >= a->Kpad && b->a_ldp % 8 == 0 && !(reinterpret_cast<uintptr_t>(b->a_plane) & 15))) &&
-                                b->a_drop_p >= 0.f && b->a_drop_p < 1.f && (b->a_drop_p == 0.f || a->rng)),
-                  "bmt_gemm_small_batched: an fp32 A operand takes a single bf16 product (one pass or split), a width that is a multiple of 4 and 16-byte aligned rows");
+                      !(a->flags & (BMT_EPI_RESIDUAL | BMT_EPI_GATE | BMT_EPI_ACCUM)),
+                  "bmt_gemm_small_batched: row-major operands, no split, no residual / gate / accumulate");
     BMT_CHECK_ARG(a->precision == BMT_PREC_BF16 || a->precision == BMT_PREC_F16 || a->precision == BMT_PREC_BF16X3,
                   "bmt_gemm_small_batched: BMT_PREC_BF16, BMT_PREC_F16 or BMT_PREC_BF16X3");
     GemmB p;
@@ -2210,10 +2146,10 @@ extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gem
     int rc = gemm_prepare(&a1, p, splitk, false);
     if (rc != BMT_OK) return rc;
     // every product writes exactly its N columns (a neighbour's may follow); 16-byte plane stores need aligned offsets
-    if (p.Chi && !single) p.plane_cols = a->N;      // (a single product pads its planes to the next multiple of 64 with zeros, as bmt_gemm_bf16 does)
+    if (p.Chi) p.plane_cols = a->N;
     const int64_t ldp2 = b->ldp2 ? b->ldp2 : a->ldp;
-    p.plane_vec = p.plane_vec && (single || a->N % 8 == 0) && (ldp2 % 8 == 0) && !((b->p_off_o | b->p_off_i | b->p2_off_o | b->p2_off_i) & 7);
-    const int cols = (p.Chi && p.plane_cols > a->N) ? p.plane_cols : a->N, nb = b->nb_outer * b->nb_inner;
+    p.plane_vec = p.plane_vec && (a->N % 8 == 0) && (ldp2 % 8 == 0) && !((b->p_off_o | b->p_off_i | b->p2_off_o | b->p2_off_i) & 7);
+    const int cols = a->N, nb = b->nb_outer * b->nb_inner;
     p.pipe = 5;
     // splitk 0: the library chooses (the reduction over a workgroup's waves for long reductions over few tiles; measured per product at
     // configs[1]'s shapes: profiles/r05_s_raw_products_time.txt); 1 / 4: the caller does (64 x 64 blocks / one tile per workgroup)
@@ -2230,14 +2166,11 @@ extern "C" int bmt_gemm_small_batched(const bmt_gemm_bf16_args* a, const bmt_gem
     bt.b_rows_dev = b->b_rows_dev;
     bt.a_div = b->a_div; bt.c_div = b->c_div; bt.p_div = b->p_div; bt.p2_div = b->p2_div;
     bt.a_qs = b->a_qs; bt.c_qs = b->c_qs; bt.p_qs = b->p_qs; bt.p2_qs = b->p2_qs;
-    bt.a_f32 = b->a_f32; bt.a_f32_ld = b->a_f32_ld; bt.a_ldp = b->a_ldp; bt.a_cols = b->a_cols; bt.a_plane = b->a_plane; bt.a_colsum = b->a_colsum;
-    bt.a_drop_p = b->a_drop_p; bt.a_drop_site = b->a_drop_site;
     BMT_CHECK_ARG(b->a_div >= 0 && b->c_div >= 0 && b->p_div >= 0 && b->p2_div >= 0 && !((b->a_qs | b->p_qs | b->p2_qs) & 7) && !(b->c_qs & 3),
                   "bmt_gemm_small_batched: block-row strides must keep 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-    if (a->precision == BMT_PREC_BF16X3) return b->a_f32 ? launch_small<3, false, true>(p, st, &bt, nb) : launch_small<3, false>(p, st, &bt, nb);
+    if (a->precision == BMT_PREC_BF16X3) return launch_small<3, false>(p, st, &bt, nb);
     if (a->precision == BMT_PREC_F16) return launch_small<1, true>(p, st, &bt, nb);
-    if (b->a_f32) return launch_small<1, false, true>(p, st, &bt, nb);
     return launch_small<1, false>(p, st, &bt, nb);
 }
 

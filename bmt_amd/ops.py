@@ -813,7 +813,7 @@ def _operands(A: Planes, B: Planes, prec: int):
 def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
               drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None,
               out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False, conv=None, two_pass: bool = True,
-              colsum: Optional[torch.Tensor] = None, a_f32=None):
+              colsum: Optional[torch.Tensor] = None):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded).
     a_km / b_km: that operand is given K-MAJOR -- its plane has the reduction index as the row ([K rows][M or N columns]), i.e.
     it is the transpose of what the product needs, read through the hardware transpose unit (single-pass bf16 only).
@@ -879,21 +879,6 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
         a.rows_dev = pk.rows_ptr.value
         if op is not None and not a_km:
             op.pack = pk
-    if a_f32 is not None:
-        # a small one-pass product whose A operand is still fp32 (grad_dx): the 32 x 32 tile kernel converts it while staging and writes A's
-        # plane -- ``A.hi``, not yet written -- and its column sums on the way (bmt_gemm_batch.a_f32)
-        src, cs, drop = a_f32
-        bt = _lib.GemmBatch()
-        bt.nb_outer = bt.nb_inner = 1
-        bt.a_f32, bt.a_f32_ld, bt.a_cols = src.data_ptr(), src.stride(0), src.shape[1]
-        bt.a_plane, bt.a_ldp = ah.data_ptr(), ah.stride(0)
-        bt.a_colsum = None if cs is None else cs.data_ptr()
-        if drop is not None and drop[0] > 0.0:
-            bt.a_drop_p, bt.a_drop_site = float(drop[0]), int(drop[1])
-            a.rng = _p(rng_tensor())
-        a.splitk = 0
-        _lib.check(lib.bmt_gemm_small_batched(C.byref(a), C.byref(bt), _st()), "bmt_gemm_small_batched")
-        return
     if splitk != 1 and two_pass:
         ws = splitk_workspace(ah.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
@@ -1116,44 +1101,15 @@ def lin_bwd(dy2: torch.Tensor, W, b, x_for_dw, need_dx: bool = True, need_dw: bo
     then dX = dY.W and dW += dY^T.X.  x_for_dw: the layer input, fp32 or Planes with a bf16 hi plane.  Returns
     (dx or None, dW or None, db or None); dW/db are None when they were accumulated straight into the parameters' static
     gradient buffers."""
-    if need_dx:
-        P, bias_done, dx = grad_dx(None, dy2, b, drop, W, pack=pack, **dx_epi)
-    else:
-        (P, bias_done), dx = grad_planes(dy2, b, drop=drop, pack=pack), None
+    P, bias_done = grad_planes(dy2, b, drop=drop, pack=pack)
     assert drop is None or bias_done or b is None       # (drop_grad guarantees it: the bias sum must see the masked gradient)
+    dx = linear_dx(P, W, **dx_epi) if need_dx else None
     dW = db = None
     if need_dw:
         dW, db = wgrad(W, None if bias_done else b, P, bwd_planes(x_for_dw, pack=pack), dy2_for_bias=dy2)
     elif b is not None and not bias_done:
         db = colsum(dy2, pack=pack)
     return dx, dW, db
-
-
-FUSE_GRAD_DX = True      # a small dX product converts its fp32 upstream gradient itself (no conversion launch in front of it)
-
-
-def grad_dx(dout, dy2: torch.Tensor, bias, drop, W: torch.Tensor, pack=None, **dx_epi):
-    """(P, bias handled?, dX result) -- the operand plane of an upstream gradient dY (+ the bias gradient: its column sums) AND dX = dY . W.
-    Where the product is small (a decoder layer's own) ONE launch does both: the 32 x 32 tile kernel converts the fp32 gradient while staging
-    it -- through the dropout mask ``drop`` = (p, site), if any -- and its first column block writes the plane and the sums
-    (bmt_gemm_batch.a_f32); otherwise grad_planes / grad_planes_from, then linear_dx.  dout: the gradient tensor as autograd delivered it
-    (it may carry a plane its producer already built: grad_planes_from), or None."""
-    M, Cc = dy2.shape
-    gb = static_grad(bias)
-    fuse = (FUSE_GRAD_DX and SMALL_DX_OUTPUTS > 0 and pack is None and (dout is None or getattr(dout, "_bmt_gplane", None) is None) and
-            M * W.shape[1] <= SMALL_DX_OUTPUTS and W.dim() == 2 and W.is_contiguous() and W.shape[0] <= 2048 and W.shape[0] == Cc and Cc % 4 == 0 and
-            dy2.is_contiguous() and dy2.data_ptr() % 16 == 0 and (bias is None or gb is not None) and dx_epi.get("residual") is None)
-    if not fuse:
-        P, done = grad_planes_from(dout, dy2, bias, drop, pack=pack) if dout is not None else grad_planes(dy2, bias, drop=drop, pack=pack)
-        return P, done, linear_dx(P, W, **dx_epi)
-    P = _alloc_planes(M, Cc, "bwd", dy2.device)
-    out = dx_epi.pop("out", None)
-    if out is None and dx_epi.get("out_planes") is None:
-        out = torch.empty(M, W.shape[1], device=W.device, dtype=torch.float32)
-    gemm_bf16(P, weight_planes_t(W), out, ldc=out.stride(0) if out is not None else 0, precision=PREC_BF16, a_f32=(dy2, gb, drop), **dx_epi)
-    if gb is not None:
-        grad_done(bias)
-    return P, gb is not None or bias is None, (out if out is not None else dx_epi["out_planes"])
 
 
 def grad_planes(dy2: torch.Tensor, bias: Optional[torch.Tensor] = None, drop=None, pack=None):
@@ -1773,24 +1729,12 @@ class LinearActFn(torch.autograd.Function):
         xc = _f32c(x)
         K = xc.shape[-1]
         x2 = xc.view(-1, K)
-        prec = policy_of(None).gemm
-        epi = dict(relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"), drop_p=p, site=site)
-        xsave = x2
-        if (FUSE_GRAD_DX and prec == PREC_BF16X3 and 0 < x2.shape[0] * W.shape[0] <= SMALL_DX_OUTPUTS and K % 4 == 0 and x2.data_ptr() % 16 == 0 and
-                planes_of(x, "x3") is None):
-            # a small product (the bridge): the 32 x 32 tile kernel splits the fp32 input into hi + lo while staging it and leaves the bf16 plane
-            # the weight gradient will read -- no conversion launch here, none in the backward pass
-            hi = torch.empty(x2.shape[0], _pad64(K), device=x2.device, dtype=torch.bfloat16)
-            y = torch.empty(x2.shape[0], W.shape[0], device=x2.device, dtype=torch.float32)
-            gemm_bf16(Planes(hi, hi, x2.shape[0], K), weight_planes(W, "x3"), y, ldc=y.stride(0), bias=b, precision=prec, a_f32=(x2, None, None), **epi)
-            xsave = hi
-        else:
-            y = linear_fwd(x2, W, b, precision=prec, **epi)
+        y = linear_fwd(x2, W, b, precision=policy_of(None).gemm, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"),
+                       drop_p=p, site=site)
         ctx.relu, ctx.drop_mode, ctx.p, ctx.site = relu, drop_mode, p, site
         ctx.has_bias = b is not None
         ctx.params = (W, b)
-        ctx.x_is_plane = xsave is not x2
-        ctx.save_for_backward(xsave, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
+        ctx.save_for_backward(x2, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
         return y.view(*xc.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -1798,8 +1742,6 @@ class LinearActFn(torch.autograd.Function):
         x2, W, y = ctx.saved_tensors
         N = W.shape[0]
         dy2 = _f32c(dy).view(-1, N)
-        if ctx.x_is_plane:               # (the forward left the input's bf16 plane, the weight gradient's operand, instead of the input)
-            x2 = Planes(x2, None, x2.shape[0], W.shape[1])
         p = ctx.p if ctx.drop_mode != "none" else 0.0
         if ctx.relu:
             # dz = (y != 0) ? dy / (1 - p) : 0 never exists: its bf16 plane and column sums (the bias gradient) come out of one pass over dy and y
@@ -1888,12 +1830,12 @@ class FFNFn(torch.autograd.Function):
             dy2, drop = drop_grad(dy2, b2p, res_p, res_site)
         # dH never exists in fp32: the fc2 dX GEMM writes its bf16 plane (relu / dropout derivative applied to whole row
         # segments from the saved hidden plane) and its column sums -- fc1's bias gradient -- from the same epilogue
+        P2, b2_done = grad_planes_from(dy, dy2, b2p, drop, pack=ctx.pack) if has_res else grad_planes(dy2, b2p, drop=drop, pack=ctx.pack)
         M_, Dff = h.rows, h.cols
         gb1 = static_grad(b1p)
         cs = gb1 if gb1 is not None else torch.zeros(Dff, device=dy2.device, dtype=torch.float32)
         dhP = Planes(torch.empty(M_, _pad64(Dff), device=dy2.device, dtype=torch.bfloat16), None, M_, Dff)
-        P2, b2_done, _ = grad_dx(dy if has_res else None, dy2, b2p, drop, W2p, pack=ctx.pack, out_planes=dhP, gate=h, gate_scale=gscale,
-                                 colsum=cs if b1p is not None else None)
+        linear_dx(P2, W2p, out_planes=dhP, gate=h, gate_scale=gscale, colsum=cs if b1p is not None else None)
         dW2, db2 = wgrad(W2p, None if b2_done else b2p, P2, h, dy2_for_bias=dy2)
         db1 = None
         if b1p is not None:
@@ -2080,9 +2022,9 @@ class MHAFn(torch.autograd.Function):
             dy2, drop = drop_grad(dy2, bop, res_p, res_site)
         # out-projection: the dX epilogue re-applies the attention-output dropout mask -> gradient w.r.t. the pre-dropout output
         if D % 64 == 0:                  # dO is only ever an MFMA operand: bf16 plane, no fp32 copy
-            P_, bias_done, do = grad_dx(dout if has_res else None, dy2, bop, drop, Wop, pack=qpack,
-                                        out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
-                                        drop_post=True, drop_p=ctx.p, site=ctx.site)
+            P_, bias_done = grad_planes_from(dout, dy2, bop, drop, pack=qpack) if has_res else grad_planes(dy2, bop, drop=drop, pack=qpack)
+            do = linear_dx(P_, Wop, out_planes=Planes(torch.empty(Mq, D, device=dy2.device, dtype=torch.bfloat16), None, Mq, D),
+                           drop_post=True, drop_p=ctx.p, site=ctx.site)
             dWo, dbo = wgrad(Wop, None if bias_done else bop, P_, o, dy2_for_bias=dy2)
         else:
             do, dWo, dbo = lin_bwd(dy2, Wop, bop, o, drop=drop, pack=qpack, drop_post=True, drop_p=ctx.p, site=ctx.site)
@@ -2668,10 +2610,11 @@ class RawCrossAttnFn(torch.autograd.Function):
         if has_res:
             dy2, drop = drop_grad(dy2, bo, res_p, res_site)
         # out-projection: dX with the attention-output dropout mask re-applied = gradient of concat_h(out_h); its column sums = db_v
+        P_, bias_done = grad_planes_from(dout, dy2, bo, drop) if has_res else grad_planes(dy2, bo, drop=drop)
         gbv = static_grad(bv)
         dbv_t = gbv if gbv is not None else torch.zeros(D, device=dev, dtype=torch.float32)
-        P_, bias_done, do = grad_dx(dout if has_res else None, dy2, bo, drop, Wo, out_planes=Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D),
-                                    drop_post=True, drop_p=p, site=ctx.site, colsum=dbv_t)
+        do = linear_dx(P_, Wo, out_planes=Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D), drop_post=True, drop_p=p, site=ctx.site,
+                       colsum=dbv_t)
         if gbv is not None:
             grad_done(bv)
         dWo, dbo = wgrad(Wo, None if bias_done else bo, P_, Planes(oh, None, M, D), dy2_for_bias=dy2)

@@ -159,18 +159,6 @@ typedef struct {
      * rows that are x_qs elements apart (the queries of one head inside a (sample, query) x (head, d) tensor; the 32-row blocks of a stack) */
     int a_div, c_div, p_div, p2_div;
     int64_t a_qs, c_qs, p_qs, p2_qs;
-    /* a single BMT_PREC_BF16 (or BMT_PREC_BF16X3: hi + lo made on the way) product whose A operand is still fp32 (an upstream gradient dY, or a
-     * LayerNorm output in front of a Linear; [M][a_cols], row stride a_f32_ld): converted while
-     * it is staged -- what bmt_planes / bmt_planes_dropout would do in a launch of their own -- through the dropout mask (a_drop_p, a_drop_site;
-     * args->rng) if any; a_plane (optional, [M][a_ldp >= Kpad]) receives bf16(dropout(dY)), zero padded, and a_colsum (optional, [a_cols])
-     * += its column sums: the k-major operand and the bias gradient of the same Linear's weight-gradient product.  args->A_hi is ignored. */
-    const float* a_f32;
-    int64_t a_f32_ld, a_ldp;
-    int a_cols;
-    uint16_t* a_plane;
-    float* a_colsum;
-    float a_drop_p;
-    uint32_t a_drop_site;
 } bmt_gemm_batch;
 int bmt_gemm_small_batched(const bmt_gemm_bf16_args* args, const bmt_gemm_batch* batch, void* stream);
 /* ... and the kernels between those products (csrc/raw_memory.hip).  `off` = bmt_pack_rows' offsets of the memory (int32, off[b] = first

@@ -280,79 +280,6 @@ def test_gemm_small_tiles_at_the_decoders_shapes(ops, M, N, K):
     assert_close(dx2, bf16_round(dy).double() @ bf16_round(W + 1.0).double(), atol=4e-4 * math.sqrt(N), rtol=1e-4, name="dx after the weight moved")
 
 
-@pytest.mark.parametrize("M,C_,K", [(928, 300, 1200), (928, 1200, 300), (928, 1024, 300), (928, 300, 1024), (37, 64, 128), (928, 600, 300)])
-@pytest.mark.parametrize("p_drop", [0.0, 0.2])
-def test_small_dx_converts_its_own_upstream_gradient(ops, M, C_, K, p_drop):
-    """ops.grad_dx: the 32 x 32 tile kernel takes the fp32 gradient dY [M, C] as its A operand -- dropout mask, bf16 plane, bias column sums and
-    dX = dY . W in one launch -- against the separate conversion pass (bmt_planes_dropout) followed by the same product: the plane and the
-    product bit for bit (same roundings, same tiles), the column sums to fp32 summation order"""
-    dy = (rnd(M, C_, seed=31) * 0.3).to(DEV)
-    W = (rnd(C_, K, seed=32) * 0.2).to(DEV)
-    ops.manual_seed(5)
-    drop = (p_drop, 4711) if p_drop > 0 else None
-
-    def bias_param():
-        b = torch.nn.Parameter(torch.zeros(C_, device=DEV))
-        b.grad = torch.zeros(C_, device=DEV)
-        b._bmt_static_grad = True
-        return b
-    b1, b2 = bias_param(), bias_param()
-    old = ops.FUSE_GRAD_DX
-    try:
-        ops.FUSE_GRAD_DX = False
-        P1, done1, dx1 = ops.grad_dx(None, dy, b1, drop, W)
-        ops.FUSE_GRAD_DX = True
-        P2, done2, dx2 = ops.grad_dx(None, dy, b2, drop, W)
-    finally:
-        ops.FUSE_GRAD_DX = old
-    assert done1 and done2
-    assert torch.equal(P1.hi, P2.hi), "operand planes differ"
-    assert torch.equal(dx1, dx2), float((dx1 - dx2).abs().max())
-    assert_close(b2.grad, b1.grad, atol=1e-4 * math.sqrt(M), rtol=1e-5, name="bias gradient (column sums)")
-    want = dy.double().cpu() if drop is None else ops.dropout_raw(dy, *drop).double().cpu()
-    assert_close(b2.grad, want.sum(0), atol=2e-4 * math.sqrt(M), rtol=1e-5, name="column sums vs torch")
-    assert_close(dx2, bf16_round(want.float()).double() @ bf16_round(W.cpu()).double(), atol=2e-4 * math.sqrt(C_), rtol=1e-4, name="dx")
-    # with an output plane, a gate and output column sums (the FFN's second Linear backward)
-    h = ops.make_planes((rnd(M, K, seed=33) > 0).float().to(DEV), "bwd")
-    outs = []
-    for fused in (False, True):
-        ops.FUSE_GRAD_DX = fused
-        try:
-            op = ops.Planes(torch.full((M, ops._pad64(K)), 3.0, device=DEV, dtype=torch.bfloat16), None, M, K)
-            cs = torch.zeros(K, device=DEV)
-            ops.grad_dx(None, dy, bias_param(), drop, W, out_planes=op, gate=h, gate_scale=1.25, colsum=cs)
-            outs.append((op.hi.clone(), cs))
-        finally:
-            ops.FUSE_GRAD_DX = old
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert_close(outs[1][1], outs[0][1], atol=2e-3 * float(outs[0][1].abs().max()) + 1e-3, name="output column sums")
-
-
-@pytest.mark.parametrize("M,K,N", [(928, 600, 300), (37, 64, 128), (928, 300, 1200)])
-def test_small_split_product_splits_its_own_fp32_input(ops, M, K, N):
-    """LinearActFn (the bridge: relu(dropout(x W^T + b))) on a small product: the 32 x 32 tile kernel makes hi + lo of the fp32 input while staging it
-    and leaves the bf16 plane for the weight gradient -- same output bit for bit, same gradients, as with the conversion pass in front"""
-    x = rnd(M, K, seed=41).to(DEV)
-    W = (rnd(N, K, seed=42) * 0.2).to(DEV)
-    b = rnd(N, seed=43).to(DEV)
-    g = rnd(M, N, seed=44).to(DEV)
-    ops.manual_seed(9)
-    res = []
-    old = ops.FUSE_GRAD_DX
-    for fused in (False, True):
-        ops.FUSE_GRAD_DX = fused
-        try:
-            xs, Ws, bs = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
-            y = ops.LinearActFn.apply(xs, Ws, bs, True, "pre", 0.1, 777)
-            y.backward(g)
-            res.append((y.detach().clone(), xs.grad.clone(), Ws.grad.clone(), bs.grad.clone()))
-        finally:
-            ops.FUSE_GRAD_DX = old
-    assert torch.equal(res[0][0], res[1][0]), float((res[0][0] - res[1][0]).abs().max())
-    for a, c, name in zip(res[0][1:], res[1][1:], ("dx", "dW", "db")):
-        assert_close(c, a, atol=1e-5 * float(a.abs().max()) + 1e-7, rtol=1e-5, name=name)
-
-
 @pytest.mark.parametrize("prec", [X3, F16W2])
 def test_gemm_dropout_epilogue_matches_standalone(ops, prec):
     """the fused dropout epilogue and bmt_dropout share one RNG: same site => same mask."""
