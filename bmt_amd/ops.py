@@ -2380,7 +2380,7 @@ class RawMemoryState:
     """what the decoder layers share about ONE encoder memory during a step: its packed planes, the transposed per-sample copies, and the two
     operand stacks of the memory's gradient -- A [B][L][2][H][32][Skp] (kind 0: dS, kind 1: P), Bk [B][L][2][H][32][dm] (kind 0: Q' = q W_k,
     kind 1: dO'), bf16, rows t >= Tq zero."""
-    __slots__ = ("pack", "x", "B", "S", "dm", "L", "H", "Tq", "Skp", "xt_f16", "xtc_bf", "astack", "bstack", "next_layer", "events", "used")
+    __slots__ = ("pack", "x", "B", "S", "dm", "L", "H", "Tq", "Skp", "xt_f16", "xtc_bf", "astack", "bstack", "next_layer", "events", "used", "done")
 
     def a_block(self, l, kind):          # element offset of (b = 0, l, kind, h = 0) in the A stack; strides (sample, head)
         return ((l * 2 + kind) * self.H) * 32 * self.Skp, self.L * 2 * self.H * 32 * self.Skp, 32 * self.Skp
@@ -2445,7 +2445,7 @@ def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> t
         return mem
     st = RawMemoryState()
     st.pack, st.x, st.B, st.S, st.dm, st.L, st.H, st.Tq, st.Skp = pk, x, B, S, dm, n_layers, H, Tq, _pad64(S)
-    st.next_layer, st.events, st.used = 0, [], False
+    st.next_layer, st.events, st.used, st.done = 0, [], False, set()
     train = mem.requires_grad and torch.is_grad_enabled()
     dev = mem.device
     st.xt_f16 = torch.empty(B, dm, st.Skp, device=dev, dtype=torch.float16)
@@ -2488,6 +2488,9 @@ class RawMemoryFn(torch.autograd.Function):
         for t in st.tensors():
             t.record_stream(cur)
         B, S, dm, K = st.B, st.S, st.dm, st.L * 2 * st.H * 32
+        for l in range(st.L):            # a layer that did not take this form (or whose backward did not run) left its rows of the A stack unwritten:
+            if l not in st.done:         # zeros there (its rows of the B stack are zeros already; 0 x garbage must not be NaN)
+                st.astack[:, l].zero_()
         dmem = zero_(torch.empty(B, S, dm, device=st.astack.device, dtype=torch.float32))
         A2, B2, out2 = st.astack.view(B, K, st.Skp), st.bstack.view(B, K, dm), dmem.view(B * S, dm)
         off = st.pack.off.data_ptr()
@@ -2654,6 +2657,7 @@ class RawCrossAttnFn(torch.autograd.Function):
         needQ = ctx.needs_input_grad[0]
         dxq, dWq = lin_bwd_planes(dq, Wq, Planes(QTh, None, M, Dq), need_dx=needQ)
         dQ = dxq.view(B, Tq, Dq) if needQ else None
+        st.done.add(l)
         ev = torch.cuda.Event()
         ev.record(cur)
         st.events.append(ev)

@@ -190,7 +190,7 @@ def test_cross_attention_against_the_raw_memory(ops, dm, S, holes):
     mem = ops.raw_memory(xp, L, H, Tq, ops.policy_of(att))
     assert getattr(mem, "_bmt_rawmem", None) is not None
     mem._bmt_rawmem.next_layer = 1
-    ops.zero_(mem._bmt_rawmem.astack)                    # (the unused layer's rows of the stacks: finite)
+    mem._bmt_rawmem.astack.fill_(float("nan"))           # (the unused layer's rows of the A stack hold anything: RawMemoryFn zeroes what no layer wrote)
     y = att(Qd, mem, mem, m.to(DEV))
     assert mem._bmt_rawmem.used and mem._bmt_rawmem.next_layer == 2, "the reassociated form did not run"
     y.backward(G.to(DEV))
