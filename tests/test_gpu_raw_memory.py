@@ -221,6 +221,37 @@ def test_cross_attention_against_the_raw_memory(ops, dm, S, holes):
     assert rel_err(Qd.grad, Q2.grad) < 3e-2 and rel_err(xp.grad.view(-1, dm)[:n], xp2.grad.view(-1, dm)[:n]) < 3e-2
 
 
+@pytest.mark.parametrize("dm,S", [(128, 300), (1024, 256)])
+def test_cross_attention_dropout_masks_are_those_of_the_projected_form(ops, dm, S):
+    """training mode: the dropout on the attention output (model/multihead_attention.py:22-23) is drawn in the value block product's epilogue and
+    re-applied in the out-projection's dX -- the SAME mask (site, element index) the projected form's attention kernel draws, forward and backward:
+    output and gradients of the two forms agree as they do without dropout (a wrong index on either side would show at the size of p)"""
+    from bmt_amd.model.multihead_attention import MultiheadedAttention
+    B, Tq, Dq, D, H, p = 4, 29, 300, 1024, 4, 0.3
+    torch.manual_seed(1)
+    att = ops.tag_policy(MultiheadedAttention(Dq, dm, dm, H, p, D), "dec").to(DEV).train()
+    att2 = copy.deepcopy(att)                            # (same dropout site)
+    m = _mask(B, S, seed=3 * S + dm, holes=True)
+    X, Q, G = rnd(B, S, dm, seed=1) * 0.7 + 0.3, rnd(B, Tq, Dq, seed=2), rnd(B, Tq, Dq, seed=3) * 0.1
+    ops.manual_seed(77)
+    out = []
+    for raw, mod in ((True, att), (False, att2)):
+        xp, rows = _packed(ops, X, m)
+        xp.requires_grad_(True)
+        Qd = Q.to(DEV).requires_grad_(True)
+        mem = ops.raw_memory(xp, 1, H, Tq, ops.policy_of(mod)) if raw else xp
+        assert (getattr(mem, "_bmt_rawmem", None) is not None) == raw
+        y = mod(Qd, mem, mem, m.to(DEV))
+        y.backward(G.to(DEV))
+        n = rows.numel()
+        out.append((y.detach(), Qd.grad.clone(), xp.grad.view(-1, dm)[:n].clone(), mod.linear_V2d.weight.grad.clone(), mod.linear_Q2d.weight.grad.clone()))
+    scale = float(out[1][0].abs().max())
+    assert_close(out[0][0], out[1][0], atol=3e-3 * scale, rtol=0, name="output under dropout, raw memory vs projected")
+    for a, b_, name in zip(out[0][1:], out[1][1:], ("dQ", "dX", "dW_v", "dW_q")):
+        e = rel_err(a, b_)
+        assert e < 3e-2, f"{name}: raw memory vs projected under dropout {e:.3e}"
+
+
 # ------------------------------------------------------------------------------------------ the whole model
 @pytest.mark.parametrize("holes", [False, True])
 def test_model_with_and_without_projected_keys_and_values(ops, holes):
