@@ -77,7 +77,8 @@ class AttnBwdBf16Args(C.Structure):
                 ("dQh", vp), ("dKh", vp), ("dVh", vp), ("gq_ld", i64), ("gq_bs", i64), ("gkv_ld", i64), ("gkv_bs", i64),
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
                 ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32),
-                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32), ("q_off", vp), ("k_off", vp)]
+                ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32), ("q_off", vp), ("k_off", vp),
+                ("rc_ws", vp)]
 
 
 class CopyItem(C.Structure):
@@ -136,6 +137,7 @@ SIGNATURES = {
     "bmt_attn_fwd_bf16": (i32, [C.POINTER(AttnFwdBf16Args), vp]),
     "bmt_attn_bwd_bf16": (i32, [C.POINTER(AttnBwdBf16Args), vp]),
     "bmt_attn_bwd_split_ws": (i32, [i32, i32, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "bmt_attn_bwd_rc_ws": (i32, [i32, i32, i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
     "bmt_attn_bwd_bias_ws": (i64, [i32, i32, i32, i32, i32]),
     "bmt_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
     "bmt_layernorm_bwd_blocks": (i32, [i32]),
@@ -198,8 +200,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 8:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 8")
+    if lib.bmt_version() != 9:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 9")
     _lib = lib
     return lib
 

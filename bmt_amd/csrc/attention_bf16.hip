@@ -178,6 +178,7 @@ struct AttnPB {
     // emits nothing, the dK / dV loop ends at the last live 32-query stage.  Data-driven, so a caller whose padded rows DO carry gradient
     // loses nothing but the shortcut.  nullptr: off.
     int* qlive;
+    float* qamax;                              // recompute form: qamax[(b * H + h) * ceil(Sq / 128) + tile] = max |dO| over the tile's rows of head h (written by the dQ kernel)
     // PACKED ROWS (ABI 7; bmt_attn_fwd_bf16_args.q_off / k_off): the valid positions of a ragged batch are stored compacted -- sample b's query
     // rows are rows q_off[b] .. q_off[b + 1] - 1 of every query-side plane (its key rows k_off[b] ..), nothing is masked.  SqP / SkP keep the
     // PADDED extents the launch was sized for: they map workgroups to (batch, head, tile) and index what stays per padded position
@@ -2316,7 +2317,11 @@ __device__ __forceinline__ void st128(__amdgpu_buffer_rsrc_t rs, uint32_t a, uin
 // per-query scale (bf16 has the range) and the bf16 copy of q carries 2^-k(q) instead: dK = sum_q (q 2^-k) . (dS 2^k) needs no extra multiply;
 // delta = (1 - p) rowsum(dO * O) is computed in the prologue from the saved output plane (fuse_delta), nobody else needs it.
 // XP (timing probes): bit 3 = no epilogue stores, bit 4 = no loop
-template <int DK, int XP = 0>
+// EMIT = false (round 6, the recompute form: attn_bwd_dkvr_kernel rebuilds P and dS from q / k / v / dO itself): nothing is emitted -- no P / dS
+// workspace stores, no scaled copy of q -- and the kernel leaves what the key-side kernel needs instead: delta per query (AttnPB.delta) and
+// the largest |dO| of the tile's rows (AttnPB.qamax, next to the live-query bits: the key side scales its fp16 dS by one power of two per
+// (batch, head)).
+template <int DK, int XP = 0, bool EMIT = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq32p_kernel(const AttnPB pin) {
     AttnPB p = pin;
     constexpr int BC = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BC * ROWB, STAGE = 2 * TILE, NS = 4;
@@ -2337,6 +2342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (qt * 128 >= p.Sq) {                  // a query tile past the sample's length: no live query, a zero row of bias partials, nothing else
         if (p.qlive != nullptr && tid == 0) p.qlive[(int64_t)bh * nqt + qt] = 0;
+        if (p.qamax != nullptr && tid == 0) p.qamax[(int64_t)bh * nqt + qt] = 0.f;
         if (p.gq.bpart != nullptr)
             for (int d = tid; d < DK; d += NT) p.gq.bpart[((int64_t)b * nqt + qt) * p.gq.bp_ld + h * DK + d] = 0.f;
         return;
@@ -2379,7 +2385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < PPW; ++j) BMT_P_DMA_V(j, tl, s);
     }
-    if (tid == 0) { sLast[0] = -1; sLast[1] = 0; }
+    if (tid == 0) { sLast[0] = -1; sLast[1] = 0; sLast[2] = 0; }
     __syncthreads();
     {
         int last = -1;
@@ -2452,6 +2458,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bfbits_lo(dob[ks][j])), fabsf(bfbits_hi(dob[ks][j]))));
     amax = half_max(amax);
     if (__ballot(qok && !(amax == 0.f)) != 0ull && lane == 0) atomicOr(&sLast[1], 1 << wid);      // this wave's 32 queries carry gradient (a NaN row counts: it must propagate)
+    if constexpr (!EMIT) {
+        // (non-negative floats order as their bit patterns; a NaN row makes the largest pattern: the key side's scale clamps)
+        const float wmax = wave_max(qok ? amax : 0.f);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(&sLast[2]), __float_as_uint(wmax));
+        if (qok && hh == 0 && p.delta != nullptr) p.delta[stat] = delta;
+    }
     int kexp = 0;
     if (amax > 0.f) kexp = 6 - ((int)((__float_as_uint(amax) >> 23) & 0xffu) - 127);
     kexp = max(-60, min(60, kexp));
@@ -2465,7 +2477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const uint32_t w3 = pack_h2(bfbits_lo(dob[ks][3]) * up, bfbits_hi(dob[ks][3]) * up);
         dof[ks] = as_bf16x8(u32x4{w0, w1, w2, w3});
     }
-    if (qok) {        // Qb = bf16(q 2^-k(q)): the A operand of dK^T = Qb^T . dS' in attn_bwd_dkvg_kernel (dS' keeps the 2^k)
+    if (EMIT && qok) {        // Qb = bf16(q 2^-k(q)): the A operand of dK^T = Qb^T . dS' in attn_bwd_dkvg_kernel (dS' keeps the 2^k)
         uint16_t* qb = p.Qbws + (int64_t)b * p.bsqb + (int64_t)q * p.ldqb + h * DK + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -2509,6 +2521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // these rows are never read: attn_bwd_dkvg8_kernel skips or wipes the stages whose live bit is clear)
     const int livemask = sLast[1];
     if (p.qlive != nullptr && tid == 0) p.qlive[(int64_t)bh * nqt + qt] = livemask;
+    if (!EMIT && p.qamax != nullptr && tid == 0) p.qamax[(int64_t)bh * nqt + qt] = __uint_as_float((uint32_t)sLast[2]);
     const int ntile_run = ((XP & 16) || (p.qlive != nullptr && livemask == 0)) ? 0 : sLast[0] / BC + 1;
 
     // A dependent MFMA issues back to back with its predecessor or waits out its latency (MI355X_MICROARCH.md: any instruction between two
@@ -2583,7 +2596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float c0_ = __builtin_amdgcn_fmed3f(av[((r_) - 1) & 15], -60000.f, 60000.f);                 \
             const float c1_ = __builtin_amdgcn_fmed3f(av[(r_) & 15], -60000.f, 60000.f);                     \
             dwv[((r_) >> 1) & 7] = pack_h2(c0_, c1_) & mm[((r_) >> 2) & 3][((r_) >> 1) & 1];                        \
-            sw[((r_) >> 1) & 7] = pack_bf2(av[((r_) - 1) & 15], av[(r_) & 15]);                                           \
+            if constexpr (EMIT) sw[((r_) >> 1) & 7] = pack_bf2(av[((r_) - 1) & 15], av[(r_) & 15]);                       \
             rs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, dwv[((r_) >> 1) & 7]), ones, rs, false);     \
         }                                                                                               \
     } while (0)
@@ -2591,11 +2604,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define BMT_P_ACWORK(x_)                                                                                \
     do {                                                                                                \
         if constexpr ((x_) < 8) BMT_P_EXPR(8 + (x_), sth[(x_) & 7]);                                        \
-        if constexpr ((x_) >= 8 && (x_) < 16) pw[((x_) - 8) & 7] = pack_bf2(pr[(2 * ((x_) - 8)) & 15], pr[(2 * ((x_) - 8) + 1) & 15]); \
+        if constexpr (EMIT && (x_) >= 8 && (x_) < 16) pw[((x_) - 8) & 7] = pack_bf2(pr[(2 * ((x_) - 8)) & 15], pr[(2 * ((x_) - 8) + 1) & 15]); \
         if constexpr (((x_) & 1) == 0) BMT_P_DEL((x_) >> 1);                                            \
-        if constexpr ((x_) == 17) { swap32u(pw[0], pw[2]); swap32u(pw[1], pw[3]); st128<0>(rsP, pw[0], pw[1], pw[2], pw[3], wvo, wso); }  \
-        if constexpr ((x_) == 19) { swap32u(pw[4], pw[6]); swap32u(pw[5], pw[7]); st128<32>(rsP, pw[4], pw[5], pw[6], pw[7], wvo, wso); } \
-        if constexpr ((x_) == 21) { swap32u(sw[0], sw[2]); swap32u(sw[1], sw[3]); st128<0>(rsS, sw[0], sw[1], sw[2], sw[3], wvo, wso); }  \
+        if constexpr (EMIT && (x_) == 17) { swap32u(pw[0], pw[2]); swap32u(pw[1], pw[3]); st128<0>(rsP, pw[0], pw[1], pw[2], pw[3], wvo, wso); }  \
+        if constexpr (EMIT && (x_) == 19) { swap32u(pw[4], pw[6]); swap32u(pw[5], pw[7]); st128<32>(rsP, pw[4], pw[5], pw[6], pw[7], wvo, wso); } \
+        if constexpr (EMIT && (x_) == 21) { swap32u(sw[0], sw[2]); swap32u(sw[1], sw[3]); st128<0>(rsS, sw[0], sw[1], sw[2], sw[3], wvo, wso); }  \
     } while (0)
 #define BMT_P_ACSTEP(i_)                                                                               \
     if constexpr ((i_) < 2 * KS) {                                                                     \
@@ -2632,7 +2645,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         BMT_P_TFRAG(0); BMT_P_TFRAG(1); BMT_P_TFRAG(2); BMT_P_TFRAG(3);
 #define BMT_P_BWORK(x_)                                                                                 \
     do {                                                                                                \
-        if constexpr ((x_) == 0) { swap32u(sw[4], sw[6]); swap32u(sw[5], sw[7]); st128<32>(rsS, sw[4], sw[5], sw[6], sw[7], wvo, wso); } \
+        if constexpr (EMIT && (x_) == 0) { swap32u(sw[4], sw[6]); swap32u(sw[5], sw[7]); st128<32>(rsS, sw[4], sw[5], sw[6], sw[7], wvo, wso); } \
         if constexpr ((x_) >= 2 && (x_) < 10) BMT_P_EXPR((x_) - 2, st[((x_) - 2) & 15]);                        \
         if constexpr ((x_) >= 8 && (x_) < 16) { sth[((x_) - 8) & 7] = st[(x_) & 15]; asm volatile("" : "+v"(sth[((x_) - 8) & 7])); } \
     } while (0)
@@ -2685,15 +2698,337 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template <int DK, int XP = 0>
+template <int DK, int XP = 0, bool EMIT = true>
 int launch_dq32p(const AttnPB& p, hipStream_t st) {
     const int nblk = ((p.Sq + 127) / 128) * p.B * p.H;
     const int ntile = (p.Sk + 31) / 32;
     const int lds_loop = 4 * 2 * 32 * DK * 2 + ((ntile * 64 + 15) & ~15) + 16, lds_epi = 128 * (DK + 8) * 2 + 256 * 8;
     const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq32p_kernel<DK, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((attn_bwd_dq32p_kernel<DK, XP>), dim3(nblk), dim3(256), lds, st, p);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq32p_kernel<DK, XP, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn_bwd_dq32p_kernel<DK, XP, EMIT>), dim3(nblk), dim3(256), lds, st, p);
     BMT_CHECK_LAUNCH("bmt_exp_attn_bwd_split(dq, pipelined)");
+    return BMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------ the key side, recomputing (round 6)
+// attn_bwd_dq32p_kernel<.., EMIT = false> -> attn_bwd_dkvr_kernel: the split backward WITHOUT its P / dS round trip.  The emitting form wrote
+// P and dS' (bf16, 2 x Sq x Sk x 2 bytes per (batch, head): 145 MB per launch of configs[1]'s audio self-attention) and a scaled copy of q, and
+// attn_bwd_dkvg8_kernel read them back (profiles/r05_z_pmc_traffic.json: 488.6 MB moved per attention for ~237 MB of operands and gradients):
+// both kernels ran HBM-shaped at 2.7 / 3.4 TB/s.  Bytes were the bound, so recomputing S = Q K^T and dP = dO V^T on the key side is nearly free:
+// this kernel is the MIRROR IMAGE of the dQ kernel -- a wave owns 32 KEYS, the query side streams through LDS in 32-query stages (the fp16 q
+// tile and the bf16 dO tile by LDS-DMA, the dual-purpose swizzle of the dQ kernel's K image: row fragments for S / dP, transposing reads for
+// the two gradient products), and BOTH gradients accumulate in registers:
+//     S[q x key] = Q . K^T   (fp16)        dP[q x key] = dO . V^T   (bf16: dO is a bf16 plane)
+//     dV^T[d x key] += dO^T[d x q] . P[q x key]       (bf16, P <= 1)
+//     dK^T[d x key] += Q^T[d x q]  . dS'[q x key]     (fp16: q is an fp16 plane; dS' = dS 2^g with ONE power of two per (batch, head), from the
+//                                                      largest |dO| the dQ kernel saw: a sum over queries needs no per-query scale -- a row whose
+//                                                      dO is five decades below the largest contributes five decades less to the sum)
+// S leaves the MFMA with the KEY on the lane and the queries along the registers, which is exactly the B operand of the two gradient
+// products (reduction over the queries, registers 8 kk .. 8 kk + 7 in order): P and dS' never leave the registers.  The softmax statistics
+// vary along the REGISTERS here (register r of lane half hh = query 8 (r >> 2) + 4 hh + (r & 3) of the stage): lse log2 e and -delta scale 2^g
+// of all the sample's queries are staged into LDS once (rows past Sq: lse = +huge, delta = 0, so P = dS' = 0 whatever the ring holds), a lane
+// reads its 2 x 16 values per stage as 8 ds_read_b128.  Nothing is masked in the loop: a key's column of dK / dV depends on no other key, a
+// key that is masked or past Sk has its column zeroed / not stored at the end.
+// Registers decide the rest.  dK and dV of 32 keys x d_k 256 are 2 x 128 accumulator registers -- the whole AGPR half of a 512-register wave --
+// and with K AND V fragments in registers as well (2 x 64) hipcc 7.2 shuttled accumulator tiles between the register files (352 v_accvgpr
+// moves per stage) and spilled V fragments, whose scratch reloads count in vmcnt next to the DMA ring.  So: V stays in registers (64), the
+// workgroup's 128 K rows sit in LDS (64 KB, the same swizzled image, read as the B operand of S: one more ds_read_b128 per S step), the
+// stage ring is two deep (64 KB) and a stage is finished before the next one starts:
+//     phase AC: S(t), dP(t) alternating (no MFMA follows one on its own accumulator); the DMA of stage t + 1 rides on the first steps
+//     VALU    : P, dS' of registers 0 .. 7 (the first 16-query step's operands)
+//     phase B0: dV, dK over queries 0 .. 15 of the stage, alternating, under the VALU of registers 8 .. 15
+//     phase B1: dV, dK over queries 16 .. 31
+// 4 products of 2 Sq Sk d_k on this side + 3 on the dQ side = 7 for the mathematics' 5: MFMA work bought with HBM bytes.
+#define BMT_X_REP32(M) BMT_X_REP16(M) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+template <int N>
+__device__ __forceinline__ void lgkm_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+// LDS reads issued behind step i's fragments when steps i + 1 .. min(i + pf, n - 1) have been prefetched: one fragment per step, two on even steps
+// S and dP accumulate in ARCHITECTURAL registers, by inline asm: dK and dV fill the accumulator file (256), and hipcc 7.2 -- which prefers the
+// accumulator file for every MFMA result -- made room for S / dP there by moving gradient tiles out and back (320 v_accvgpr moves per stage).
+// A chain's links take the accumulator whole as C (no wait states between them: cdna_hip_programming.md section 5.7, item 2); the first
+// link starts from the inline constant 0 (early-clobber: the result must not share registers with its operands); the readers after the
+// last link wait 16 states (mfma_v_done).
+template <bool F16, bool FIRST>
+__device__ __forceinline__ void mfma_v(f32x16& c, const u32x4& a, const u32x4& b) {
+    if constexpr (FIRST) {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+    } else {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+}
+__device__ __forceinline__ void mfma_v_done(f32x16& a, f32x16& b) { asm volatile("s_nop 15" : "+v"(a), "+v"(b)); }
+constexpr int dkvr_younger(int i, int pf, int n) {
+    int c = 0;
+    for (int s = i + 1; s <= i + pf && s < n; ++s) c += 1 + ((s & 1) == 0 ? 1 : 0);
+    return c;
+}
+
+template <int DK, int XP = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkvr_kernel(const AttnPB pin) {
+    AttnPB p = pin;
+    constexpr int BQ = 32, NT = 256, KS = DK / 16, DT = DK / 32, ROWB = DK * 2, TILE = BQ * ROWB, STAGE = 2 * TILE, NS = 2;
+    constexpr int KBLK = 128 * ROWB;                                       // the workgroup's K rows
+    constexpr int CPR = DK / 8, RPP = 64 / CPR, NP = BQ / RPP, PPW = NP / 4, KPW = (128 / RPP) / 4;
+    static_assert(DK == 128 || DK == 256, "d_k 128 / 256");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [ring: NS stages][K block][statistics]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int nkt = (p.Sk + 127) / 128, nqt = (p.SqP + 127) / 128, nstP = (p.SqP + BQ - 1) / BQ;
+    const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
+    // work order: (batch, head)-major -- the key blocks of a (batch, head) run together and share its q / dO rows in their XCD's L2
+    const int kt = w % nkt, bh = w / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
+    if (kt * 128 >= p.Sk) {                  // a key block past the sample's length: zero rows of bias partials, nothing else
+        for (int d = tid; d < DK; d += NT) {
+            if (p.gk.bpart != nullptr) p.gk.bpart[((int64_t)b * nkt + kt) * p.gk.bp_ld + h * DK + d] = 0.f;
+            if (p.gv.bpart != nullptr) p.gv.bpart[((int64_t)b * nkt + kt) * p.gv.bp_ld + h * DK + d] = 0.f;
+        }
+        return;
+    }
+    const int nst = (p.Sq + BQ - 1) / BQ;
+    const int key = kt * 128 + wid * 32 + l31;
+    const bool kin = key < p.Sk;
+    const bool kok = kin && (p.mask == nullptr || p.mask[(int64_t)b * p.mask_bs + key] != 0);
+    // live 32-query stages (AttnPB.qlive, written by the dQ kernel): the loop ends behind the last one -- a dead stage has dO = 0, hence dP = delta = 0
+    // and contributes exactly nothing, so dead stages in front of a live one are simply computed
+    uint64_t smask = ~0ull;
+    float am = 0.f;
+    if (p.qlive != nullptr) {
+        smask = 0ull;
+        for (int i = 0; i < nqt; ++i) smask |= (uint64_t)(uint32_t)(p.qlive[(int64_t)bh * nqt + i] & 15) << (4 * i);
+    }
+    for (int i = 0; i < nqt; ++i) am = fmaxf(am, p.qamax[(int64_t)bh * nqt + i]);
+    const int live_end = smask == 0ull ? 0 : 64 - __builtin_clzll(smask);
+    const int nst_run = ((XP & 16) || !__syncthreads_or((int)kok)) ? 0 : min(nst, live_end);
+    // one power of two per (batch, head) puts the largest |dO| at 2^6 .. 2^7: dS' = P (dP - delta) scale 2^g stays inside fp16 (clamped at +-60000)
+    int kexp = 0;
+    if (am > 0.f) kexp = 6 - ((int)((__float_as_uint(am) >> 23) & 0xffu) - 127);
+    kexp = max(-60, min(60, kexp));
+    const float up = __uint_as_float((uint32_t)(127 + kexp) << 23), down = __uint_as_float((uint32_t)(127 - kexp) << 23);
+    const float sg = p.scale * up, sc2 = p.scale * LOG2E;
+
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0, plane_extent(p.Sq, p.ldq, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0, plane_extent(p.Sq, p.ldo, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    // LDS-DMA pieces (1 KB = RPP rows): wave w moves pieces w, w + 4, w + 8, .. of each tile, so that the rows of its pieces differ by multiples of
+    // 4 RPP -- the swizzle term of piece j is then the first piece's (d_k 128: rows 16 j apart) or the first piece's ^ 32 bytes for odd j
+    // (d_k 256: rows 8 j apart flip bit 1 of (row >> 2) & 3) and the row term goes into the scalar offset: two offset registers per tile
+    // instead of one per piece
+    static_assert(PPW <= 4, "pieces per wave");
+    constexpr int ODD = DK == 256 ? 32 : 0;
+    int qv0, ov0, kv0, qv1, ov1, kv1;
+    {
+        const int row = wid * RPP + lane / CPR, cpos = lane % CPR;
+        const int cs = (cpos ^ kswz(row)) * 16;
+        qv0 = row * (int)p.ldq * 2 + cs; qv1 = row * (int)p.ldq * 2 + (cs ^ ODD);
+        ov0 = row * (int)p.ldo * 2 + cs; ov1 = row * (int)p.ldo * 2 + (cs ^ ODD);
+        kv0 = row * (int)p.ldk * 2 + cs; kv1 = row * (int)p.ldk * 2 + (cs ^ ODD);
+    }
+    const int sstep_q = BQ * (int)p.ldq * 2, sstep_o = BQ * (int)p.ldo * 2;
+    const int pstep_q = 4 * RPP * (int)p.ldq * 2, pstep_o = 4 * RPP * (int)p.ldo * 2, pstep_k = 4 * RPP * (int)p.ldk * 2;
+#define BMT_R_DMA_Q(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + (slot_) * STAGE + (wid + 4 * (j_)) * 1024), 16, ((j_) & 1) ? qv1 : qv0, (t_) * sstep_q + (j_) * pstep_q, 0, 0)
+#define BMT_R_DMA_O(j_, t_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + (slot_) * STAGE + TILE + (wid + 4 * (j_)) * 1024), 16, ((j_) & 1) ? ov1 : ov0, (t_) * sstep_o + (j_) * pstep_o, 0, 0)
+
+    // ---- prologue: the K block and stage 0 in flight; the softmax statistics of every query; this wave's V rows
+    {
+        const int kbase = kt * 128 * (int)p.ldk * 2;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j)      // (rows past Sk: out of the descriptor's range, zeros)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(smem + NS * STAGE + (wid + 4 * j) * 1024), 16, (j & 1) ? kv1 : kv0, kbase + j * pstep_k, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) BMT_R_DMA_Q(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) BMT_R_DMA_O(j, 0, 0);
+    float* l2s = reinterpret_cast<float*>(smem + NS * STAGE + KBLK);     // [nstP * 32] lse log2 e  (+huge past Sq)
+    float* dcs = l2s + nstP * BQ;                                         // [nstP * 32] -delta scale 2^g  (0 past Sq)
+    {
+        const int64_t sbase = ((int64_t)b * p.H + h) * p.SqP;
+        for (int i = tid; i < nst * BQ; i += NT) {
+            const bool ok = i < p.Sq;
+            const int64_t si = sbase + min(i, p.Sq - 1);
+            const float l = p.lse[si], d = p.delta[si];
+            l2s[i] = ok ? l * LOG2E : 1e30f;
+            dcs[i] = ok ? -d * sg : 0.f;
+        }
+    }
+    u32x4 vf[KS];
+    {
+        // (UNCONDITIONAL loads from a clamped row, as everywhere: a key past Sk carries the last key's values, its columns are never stored)
+        const int kc = min(key, p.Sk - 1);
+        const int64_t vo = (int64_t)b * p.bsv + (int64_t)kc * p.ldv + h * DK + 8 * hh;
+        u32x4 vr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vr[ks] = *reinterpret_cast<const u32x4*>(p.Vh + vo + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[ks] = h8_to_b8(vr[ks]);      // dP = dO . V^T runs in bf16 (dO is a bf16 plane)
+    }
+    f32x16 dka[DT], dva[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+
+    // fragment addresses (LDS bytes): the dQ kernel's algebra with the roles exchanged (rows of a stage image = queries).  Every address is
+    // (lane constant + stage offset) ^ (step bits 5 .. 7), formed per read -- one v_xor -- instead of being kept in 16 + 16 registers
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const int fk = kswz(l31);
+    const uint32_t kA0 = lds0 + l31 * ROWB + 32 * (fk >> 1) + 16 * (hh ^ (fk & 1));
+    const uint32_t kB0 = kA0 + NS * STAGE + wid * 32 * ROWB;          // this lane's key row in the K block (same row & 15, same swizzle)
+    const int m16 = lane & 15, gi = (lane >> 4) & 1, mq = m16 >> 2, mr = m16 & 3;
+    const uint32_t kT0 = lds0 + (4 * hh + mq) * ROWB + 64 * mq + 32 * gi + 16 * ((mr >> 1) ^ hh) + 8 * (mr & 1);
+    const uint32_t lA = lds0 + NS * STAGE + KBLK + 16 * hh;      // this lane's statistics: queries 8 i + 4 hh .. + 3 of stage t at lA + t * 128 + 32 i
+    const uint32_t dA = lA + nstP * BQ * 4;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr int PF = 4, RR = PF + 1;
+#define BMT_R_ROWFRAG(i_) lds_b128<(DK == 256 ? (((i_) >> 1) >> 3) * 256 : 0) + (((i_) & 1) ? TILE : 0)>(kAs ^ ((((i_) >> 1) & 7) << 5))
+#define BMT_R_KFRAG(ks_) lds_b128<(DK == 256 ? ((ks_) >> 3) * 256 : 0)>(kB0 ^ (((ks_) & 7) << 5))
+    // register r of the S / dP accumulators -> P, dS'.  x_ even: P; x_ odd: dS' (and, on the odd register of a pair, the two packed words)
+#define BMT_R_PS(x_)                                                                                                            \
+    do {                                                                                                                        \
+        constexpr int r__ = ((x_) >> 1) & 15;                                                                                  \
+        if constexpr (((x_) & 1) == 0) {                                                                                       \
+            pr[r__ & 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r__], sc2, -__uint_as_float(ls[r__ >> 2][r__ & 3])));       \
+        } else {                                                                                                               \
+            av[r__ & 1] = __builtin_amdgcn_fmed3f(pr[r__ & 1] * __builtin_fmaf(dp[r__], sg, __uint_as_float(dc[r__ >> 2][r__ & 3])), -60000.f, 60000.f); \
+            if constexpr ((r__ & 1) == 1) {                                                                                    \
+                pfw[r__ >> 1] = pack_bf2(pr[0], pr[1]);                                                                        \
+                sfw[r__ >> 1] = pack_h2(av[0], av[1]);                                                                         \
+            }                                                                                                                  \
+        }                                                                                                                      \
+    } while (0)
+
+    for (int t = 0; t < nst_run; ++t) {
+        const int slot = t & 1, slotn = slot ^ 1;
+        const int tn = min(t + 1, nst - 1);                  // the last stage re-fetches itself into the idle slot (branch-free)
+        const uint32_t so = slot * STAGE;
+        f32x16 st, dp;
+        {
+            const uint32_t kAs = kA0 + so;
+            u32x4 fr[RR], fkk[RR];         // step i's stage fragment (even: q rows, odd: dO rows) in fr[i % RR]; an even step's K fragment in fkk[(i / 2) % RR]
+            fr[0] = BMT_R_ROWFRAG(0); fkk[0] = BMT_R_KFRAG(0);
+            fr[1] = BMT_R_ROWFRAG(1);
+            fr[2] = BMT_R_ROWFRAG(2); fkk[1] = BMT_R_KFRAG(1);
+            fr[3] = BMT_R_ROWFRAG(3);
+#define BMT_R_ACSTEP(i_)                                                                               \
+    if constexpr ((i_) < 2 * KS) {                                                                     \
+        if constexpr ((i_) + PF < 2 * KS) {                                                            \
+            fr[((i_) + PF) % RR] = BMT_R_ROWFRAG((i_) + PF);                                           \
+            if constexpr ((((i_) + PF) & 1) == 0) fkk[(((i_) + PF) >> 1) % RR] = BMT_R_KFRAG(((i_) + PF) >> 1); \
+        }                                                                                              \
+        if constexpr ((i_) < PPW) BMT_R_DMA_Q((i_) % PPW, tn, slotn);                                  \
+        else if constexpr ((i_) < 2 * PPW) BMT_R_DMA_O((i_) % PPW, tn, slotn);                         \
+        if constexpr (((i_) & 1) == 0) {                                                               \
+            lgkm_wait2<dkvr_younger((i_), PF, 2 * KS)>(fr[(i_) % RR], fkk[((i_) >> 1) % RR]);          \
+            mfma_v<true, (i_) == 0>(st, fr[(i_) % RR], fkk[((i_) >> 1) % RR]);                         \
+        } else {                                                                                       \
+            lgkm_wait<dkvr_younger((i_), PF, 2 * KS)>(fr[(i_) % RR]);                                  \
+            mfma_v<false, (i_) == 1>(dp, fr[(i_) % RR], vf[(i_) >> 1]);                                \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+            BMT_X_REP32(BMT_R_ACSTEP)
+#undef BMT_R_ACSTEP
+            mfma_v_done(st, dp);
+        }
+        uint32_t pfw[8], sfw[8];           // P as bf16 pairs, dS' as fp16 pairs: word w = registers 2 w, 2 w + 1
+        float pr[2], av[2];
+        u32x4 ls[4], dc[4];                // this lane's statistics of the stage: queries 8 i + 4 hh .. + 3 in ls[i] / dc[i]
+        {
+            const uint32_t lAt = lA + t * (BQ * 4), dAt = dA + t * (BQ * 4);
+            ls[0] = lds_b128<0>(lAt); ls[1] = lds_b128<32>(lAt); ls[2] = lds_b128<64>(lAt); ls[3] = lds_b128<96>(lAt);
+            dc[0] = lds_b128<0>(dAt); dc[1] = lds_b128<32>(dAt); dc[2] = lds_b128<64>(dAt); dc[3] = lds_b128<96>(dAt);
+        }
+        const uint32_t kTs = kT0 + so;
+        constexpr int NSTEP = 4 * DT;
+        u32x2 ta[RR], tb[RR];
+        // step m: product m & 1 (0: dV from the dO tile, 1: dK from the q tile), d-tile (m >> 1) % DT, 16-query step (m >> 1) / DT
+#define BMT_R_TFRAG(m_)                                                                                       \
+    do {                                                                                                      \
+        constexpr int dt__ = ((m_) >> 1) % DT, kk__ = ((m_) >> 1) / DT;                                       \
+        constexpr int off__ = (((m_) & 1) ? 0 : TILE) + (DK == 256 ? (dt__ >> 2) * 256 : 0) + 16 * kk__ * ROWB; \
+        ta[(m_) % RR] = lds_tr_b64<off__>(kTs ^ ((dt__ & 3) << 6));                                           \
+        tb[(m_) % RR] = lds_tr_b64<off__ + 8 * ROWB>(kTs ^ (((dt__ & 3) << 6) | 32));                         \
+    } while (0)
+        BMT_R_TFRAG(0); BMT_R_TFRAG(1); BMT_R_TFRAG(2); BMT_R_TFRAG(3);
+        lgkm_wait4<2 * PF>(ls[0], ls[1], ls[2], ls[3]);          // (LDS operations retire in order: the statistics are older than the fragments)
+        lgkm_wait4<2 * PF>(dc[0], dc[1], dc[2], dc[3]);
+#define BMT_R_V1(x_) if constexpr ((x_) < 16) { BMT_R_PS(x_); }
+        BMT_X_REP16(BMT_R_V1)
+#undef BMT_R_V1
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 pf[2], sf[2];
+        pf[0] = as_bf16x8(u32x4{pfw[0], pfw[1], pfw[2], pfw[3]});
+        sf[0] = as_bf16x8(u32x4{sfw[0], sfw[1], sfw[2], sfw[3]});
+        // VALU work of step m_ < NSTEP / 2: the 16 half-steps of registers 8 .. 15 spread over the first half's steps
+#define BMT_R_BSTEP(m_)                                                                                \
+    if constexpr ((m_) < NSTEP) {                                                                      \
+        if constexpr ((m_) == NSTEP / 2) {                                                             \
+            pf[1] = as_bf16x8(u32x4{pfw[4], pfw[5], pfw[6], pfw[7]});                                  \
+            sf[1] = as_bf16x8(u32x4{sfw[4], sfw[5], sfw[6], sfw[7]});                                  \
+        }                                                                                              \
+        if constexpr ((m_) + PF < NSTEP) BMT_R_TFRAG((m_) + PF);                                       \
+        lgkm_wait<((m_) + PF < NSTEP) ? 2 * PF : 2 * (NSTEP - 1 - (m_))>(ta[(m_) % RR], tb[(m_) % RR]); \
+        const u32x4 fv = {ta[(m_) % RR][0], ta[(m_) % RR][1], tb[(m_) % RR][0], tb[(m_) % RR][1]};     \
+        if constexpr (((m_) & 1) == 0) dva[((m_) >> 1) % DT] = mfma32t<false>(as_bf16x8(fv), pf[((m_) >> 1) / DT], dva[((m_) >> 1) % DT]); \
+        else dka[((m_) >> 1) % DT] = mfma32t<true>(as_bf16x8(fv), sf[((m_) >> 1) / DT], dka[((m_) >> 1) % DT]); \
+        if constexpr ((m_) < NSTEP / 2) {                                                              \
+            if constexpr (NSTEP == 32) { BMT_R_PS(16 + (m_)); }                                        \
+            else { BMT_R_PS(16 + 2 * (m_)); BMT_R_PS(16 + 2 * (m_) + 1); }                             \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+        BMT_X_REP32(BMT_R_BSTEP)
+#undef BMT_R_BSTEP
+#undef BMT_R_TFRAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage t + 1 has landed (this wave's share); the barrier publishes all shares
+        BMT_B_BAR();                                          // and says every wave is done reading stage t (stage t + 2 overwrites it)
+    }
+#undef BMT_R_PS
+#undef BMT_R_ROWFRAG
+#undef BMT_R_KFRAG
+#undef BMT_R_DMA_Q
+#undef BMT_R_DMA_O
+
+    if (!kok) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dka[dt] *= down;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (XP & 8) { if (dka[0][0] == 1234.5f && dva[1][1] == 3.25f) p.gk.bsum[0] = 1.f; return; }
+    grad_rm_epilogue<DK, DT, 256>(smem, p.gv, dva, b, h, kt * 128, wid * 32 + l31, kin, hh, 0, p.Sk, p.SkP, tid);
+    grad_rm_epilogue<DK, DT, 256>(smem, p.gk, dka, b, h, kt * 128, wid * 32 + l31, kin, hh, 0, p.Sk, p.SkP, tid);
+}
+
+template <int DK, int XP = 0>
+int launch_dkvr(const AttnPB& p, hipStream_t st) {
+    const int nblk = ((p.Sk + 127) / 128) * p.B * p.H;
+    const int nstP = (p.Sq + 31) / 32;
+    const int lds_loop = 2 * 2 * 32 * DK * 2 + 128 * DK * 2 + nstP * 32 * 8, lds_epi = 128 * (DK + 8) * 2 + 256 * 8;
+    const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkvr_kernel<DK, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn_bwd_dkvr_kernel<DK, XP>), dim3(nblk), dim3(256), lds, st, p);
+    BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (recompute form, dK / dV)");
     return BMT_OK;
 }
 
@@ -2928,6 +3263,19 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     const int nblk_q = ((p.Sq + 127) / 128) * p.B * p.H;
     if constexpr (DK >= 128) {
+        if (p.Pws == nullptr && p.qamax != nullptr) {      // recompute form (round 6): the dQ kernel emits nothing but delta, the live-query bits and
+                                                           // max |dO|; the key side rebuilds P and dS from q / k / v / dO
+            AttnPB pf = p;
+            pf.fuse_delta = (p.dO == nullptr && p.O == nullptr && (p.Oph != nullptr || p.Opf != nullptr)) ? 1 : 0;
+            if (!pf.fuse_delta) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
+            int rc = launch_dq32p<DK, 0, false>(pf, st);
+            if (rc != BMT_OK) return rc;
+            rc = launch_dkvr<DK>(pf, st);
+            if (rc != BMT_OK) return rc;
+            launch_bias_finish<DK>(p, st);
+            BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (recompute)");
+            return BMT_OK;
+        }
         if (p.Pws != nullptr) {       // split form (bmt_attn_bwd_bf16 checked shapes and sizes): dQ + emission (delta = rowsum(dO * O) in its prologue), dK / dV
                                       // as plain products, bias sums
             AttnPB pf = p;
@@ -3097,6 +3445,23 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
             p.qlive = a->Sq <= 2048 ? reinterpret_cast<int*>(a->Qb_ws + (int64_t)a->B * p.bsqb) : nullptr;
         }
     }
+    if (a->rc_ws) {
+        BMT_CHECK_ARG(!a->P_ws && !a->dS_ws && !a->Qb_ws && a->bias_ws, "bmt_attn_bwd_bf16: rc_ws goes with bias_ws and without the emitting form's workspaces");
+        int64_t n_rc, n_bias;
+        const bool takes = bmt_attn_bwd_rc_ws(a->B, a->H, a->Sq, a->Sk, a->dk, &n_rc, &n_bias) == BMT_OK && a->qkv_f16 &&
+                           (a->mask == nullptr || a->mask_qs == 0) && (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) &&
+                           (int64_t)a->Sk * a->ldv * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31) &&
+                           (int64_t)a->Sq * a->ldq * 2 < (1ll << 31) && !a->dQT && !a->dKT && !a->dVT;
+        BMT_CHECK_ARG(takes, "bmt_attn_bwd_bf16: rc_ws given for a problem the recompute form does not take (fp16 q / k / v planes, d_k 128 / 256, "
+                             "64 <= Sq <= 2048, Sk <= 8192, a key-padding mask or none, no transposed outputs)");
+        if ((reinterpret_cast<uintptr_t>(a->rc_ws) & 15) != 0) {
+            bmt_set_error("bmt_attn_bwd_bf16: workspaces must be 16-byte aligned");
+            return BMT_EALIGN;
+        }
+        const int64_t nqt = (a->Sq + 127) / 128;
+        p.qlive = a->rc_ws;
+        p.qamax = reinterpret_cast<float*>(a->rc_ws + (int64_t)a->B * a->H * nqt);
+    }
     hipStream_t st = (hipStream_t)stream;
     if (a->dk == 32) return launch_bwd<32>(p, a->dOh_ws, st);
     if (a->dk == 64) return launch_bwd<64>(p, a->dOh_ws, st);
@@ -3120,6 +3485,23 @@ extern "C" int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64
     const int64_t nkt = (Sk + 127) / 128, nqt = (Sq + 127) / 128;
     *n_pds = (int64_t)B * H * nkt * Sq * 128;
     *n_qb = (int64_t)B * Sq * H * dk + (((int64_t)2 * B * H * nqt + 7) & ~(int64_t)7);      // + one int of live-query bits per (batch, head, query tile)
+    *n_bias = ((int64_t)B * nqt + 2 * (int64_t)B * nkt) * H * dk;
+    return BMT_OK;
+}
+
+extern "C" int bmt_attn_bwd_rc_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_rc, int64_t* n_bias) {
+    if (n_rc) *n_rc = 0;
+    if (n_bias) *n_bias = 0;
+    BMT_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && n_rc && n_bias, "bmt_attn_bwd_rc_ws: bad arguments");
+    // (the key side keeps lse and delta of all the sample's queries in LDS behind its 128-KB stage ring and one live bit per 32-query stage in
+    // a 64-bit word: Sq <= 2048; the dQ kernel keeps a 2-byte-per-key mask image next to its K / V ring: Sk <= 8192; below 64 queries the dQ
+    // kernel's 128-query workgroups are mostly idle -- the decoder's 30-query attentions stay on the two-kernel form)
+    if (!(dk == 128 || dk == 256) || Sq < 64 || Sq > 2048 || Sk > 8192) {
+        bmt_set_error("bmt_attn_bwd_rc_ws: the recompute form takes d_k 128 / 256, 64 <= Sq <= 2048, Sk <= 8192");
+        return BMT_EINVAL;
+    }
+    const int64_t nkt = (Sk + 127) / 128, nqt = (Sq + 127) / 128;
+    *n_rc = ((int64_t)2 * B * H * nqt + 3) & ~(int64_t)3;       // live-query bits (int32) + max |dO| (fp32) per (batch, head, 128-query tile)
     *n_bias = ((int64_t)B * nqt + 2 * (int64_t)B * nkt) * H * dk;
     return BMT_OK;
 }

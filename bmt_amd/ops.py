@@ -1311,7 +1311,10 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
 
-ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"      # switch: "0" keeps the two-kernel backward everywhere
+# switch: "0" keeps the two-kernel backward everywhere; "emit" = the split form that leaves P and dS in HBM workspaces (rounds 3-5); default
+# (round 6) = the split form whose key side recomputes them (attn_bwd_dkvr_kernel), falling back to "emit" for shapes it does not take
+ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"
+ATTN_BWD_RECOMPUTE = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "emit"
 
 
 _SCRATCH = {}            # (device index, stream handle, capturing?, name) -> 1-D tensor: scratch that lives inside ONE library call
@@ -1350,6 +1353,16 @@ def _attn_split_ws(B, H, Sq, Sk, dk, dev):
         return None
     return (stream_scratch("attn_P", n[0].value, torch.bfloat16, dev), stream_scratch("attn_dS", n[0].value, torch.bfloat16, dev),
             stream_scratch("attn_Qb", n[1].value, torch.bfloat16, dev), torch.empty(n[2].value, device=dev, dtype=torch.float32))
+
+
+def _attn_rc_ws(B, H, Sq, Sk, dk, dev):
+    """workspaces of the RECOMPUTE form of the split attention backward (bmt_attn_bwd_rc_ws): one int of live-query bits and one float of
+    max |dO| per (batch, head, 128-query tile) -- scratch of the call -- and the per-tile bias partials (read by the pass's deferred
+    column-sum launch: a plain allocation).  None where the form does not apply."""
+    n = [C.c_int64(0), C.c_int64(0)]
+    if lib.bmt_attn_bwd_rc_ws(B, H, Sq, Sk, dk, C.byref(n[0]), C.byref(n[1])) != 0:
+        return None
+    return stream_scratch("attn_rc", n[0].value, torch.int32, dev), torch.empty(n[1].value, device=dev, dtype=torch.float32)
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
@@ -1391,7 +1404,8 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     qa, ka, va = (q.fh, k.fh, v.fh) if f16 else (q.hi, k.hi, v.hi)
     ldq, ldk, ldv, ldop = qa.stride(0), ka.stride(0), va.stride(0), o.hi.stride(0)
     (qh_, qb_, _), (kh_, kb_, _), (vh_, vb_, _) = outs
-    ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and f16 and mqs == 0) else None
+    rc = _attn_rc_ws(B, H, Sq, Sk, dk, dev) if (ATTN_BWD_SPLIT and ATTN_BWD_RECOMPUTE and f16 and mqs == 0) else None
+    ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (rc is None and ATTN_BWD_SPLIT and f16 and mqs == 0) else None
     # the mean-key correction removes the residue of the bf16-rounded dS (8 significand bits); kept on the split form too, whose dQ runs on
     # fp16 dS with per-query scales (without it one tensor of the deep fixture goes from < 2 % to 4.4 %: DESIGN.md section 2)
     km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16, kpack=kpack)
@@ -1406,7 +1420,10 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16),
                         q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None)
     bias_part = None
-    if ws is not None:      # the split backward: P / dS / scaled-q workspaces + per-tile bias partials (scratch, freed with this call)
+    if rc is not None:      # the split backward, recompute form: live bits / max |dO| + per-tile bias partials
+        a.rc_ws, a.bias_ws = _p(rc[0]), _p(rc[1])
+        bias_part = rc[1]
+    elif ws is not None:    # the split backward, emitting form: P / dS / scaled-q workspaces + per-tile bias partials (scratch, freed with this call)
         a.P_ws, a.dS_ws, a.Qb_ws, a.bias_ws = (_p(t) for t in ws)
         bias_part = ws[3]
     elif any(b_ is not None for b_ in (qb_, kb_, vb_)):      # two-kernel form (the decoder's attentions): per-tile bias partials only

@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 8
+#define BMT_ABI_VERSION 9
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -347,6 +347,13 @@ typedef struct {
                                                          adds them up itself (bmt_colsum_multi, together with other reductions) */
     const int *q_off, *k_off;                         /* ABI 7: packed rows as in bmt_attn_fwd_bf16_args -- q side: Q, O planes, dOh_ws, dQh; k side: K, V, dKh, dVh.  lse, delta_ws,
                                                          the split backward's workspaces and the per-tile bias partials keep their padded layouts */
+    /* ABI 9 -- the RECOMPUTE form of the split backward: rc_ws (int32, *n_rc elements from bmt_attn_bwd_rc_ws) + bias_ws, P_ws = dS_ws = Qb_ws =
+     * NULL.  {dQ kernel: S, dP', dQ -- emits nothing but delta (delta_ws), one word of live-query bits and the largest |dO| per (batch, head,
+     * 128-query tile) into rc_ws} -> {key-side kernel: a wave keeps 32 keys' K and V rows in registers, streams the q / dO rows through LDS,
+     * rebuilds S, P, dP and dS (one power-of-two scale per (batch, head) on the fp16 dS) and accumulates dK and dV} -> bias sums.  7 products of
+     * Sq x Sk x d_k instead of 5, and none of the 2 x Sq x Sk x 2 bytes per (batch, head) written and read back (model/multihead_attention.py:8-26's
+     * autograd).  Same eligibility as the emitting form plus Sq <= 2048; an ineligible problem with rc_ws set is an error. */
+    int* rc_ws;
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* element counts of the split backward's workspaces for a problem: P_ws and dS_ws (bf16) take *n_pds each, Qb_ws (bf16) *n_qb, bias_ws
@@ -356,6 +363,9 @@ int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
  * quarter of the query rows of configs[1]'s ragged batches.  Data-driven -- nothing is assumed about the caller's padding.)  Returns BMT_EINVAL (and zeros) for a problem the split form does not take (d_k < 128, Sq < 64, sizes past 2^31 bytes per
  * (batch, head) block): the caller then passes NULL workspaces and the two-kernel form runs. */
 int bmt_attn_bwd_split_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_pds, int64_t* n_qb, int64_t* n_bias);
+/* ABI 9: element counts of the recompute form's workspaces: rc_ws (int32) *n_rc, bias_ws (fp32) *n_bias.  BMT_EINVAL (and zeros) for a problem
+ * it does not take (d_k not 128 / 256, Sq < 64 or > 2048, Sk > 8192): the caller then uses the emitting form or the two-kernel form. */
+int bmt_attn_bwd_rc_ws(int B, int H, int Sq, int Sk, int dk, int64_t* n_rc, int64_t* n_bias);
 /* bias_ws alone (P_ws = dS_ws = Qb_ws = NULL) is taken by every d_k >= 128 backward: the tiles' column sums are stored per tile and added
  * up by a finishing launch instead of ~900 workgroups adding into the same H * d_k floats.  Element count (0 for d_k < 128: pass NULL): */
 int64_t bmt_attn_bwd_bias_ws(int B, int H, int Sq, int Sk, int dk);

@@ -24,7 +24,7 @@ def test_header_declares_the_hot_path():
 def test_library_loads_and_exports_everything():
     from bmt_amd import _lib
     lib = _lib.load()
-    assert lib.bmt_version() == 8
+    assert lib.bmt_version() == 9
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/bmt_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in bmt_amd/_lib.py"
@@ -76,3 +76,16 @@ def test_attention_backward_split_workspace_query():
     assert n[0].value == 32 * 4 * 7 * 800 * 128 and n[1].value == 32 * 800 * 1024 + 2 * 32 * 4 * 7 and n[2].value == (32 * 7 + 2 * 32 * 7) * 1024
     for bad in ((32, 4, 29, 800, 256), (2, 4, 800, 800, 64), (2, 4, 800, 9000, 256)):
         assert lib.bmt_attn_bwd_split_ws(*bad, *(C.byref(x) for x in n)) == -1 and [x.value for x in n] == [0, 0, 0]
+
+
+def test_recompute_backward_workspace_sizes():
+    """bmt_attn_bwd_rc_ws (ABI 9): one int of live-query bits + one float of max |dO| per (batch, head, 128-query tile), the per-tile bias
+    partials of the three gradients; BMT_EINVAL (and zeros) for the problems the recompute form leaves to the other forms"""
+    import ctypes as C
+    from bmt_amd import _lib
+    lib = _lib.load()
+    n = [C.c_int64(-1), C.c_int64(-1)]
+    assert lib.bmt_attn_bwd_rc_ws(32, 4, 800, 256, 256, *(C.byref(x) for x in n)) == 0
+    assert n[0].value == 2 * 32 * 4 * 7 and n[1].value == (32 * 7 + 2 * 32 * 2) * 1024
+    for bad in ((32, 4, 30, 800, 256), (2, 4, 800, 800, 64), (1, 1, 4096, 128, 128), (1, 1, 128, 16384, 128)):
+        assert lib.bmt_attn_bwd_rc_ws(*bad, *(C.byref(x) for x in n)) == -1 and [x.value for x in n] == [0, 0]

@@ -499,11 +499,15 @@ def test_attention_backward_from_fp16_planes(ops, B, H, Sq, Sk, dk):
     assert_close(km_h, km_b, atol=2e-3, name="mean key from the fp16 plane")
 
 
+@pytest.mark.parametrize("form", ["recompute", "emit"])
 @pytest.mark.parametrize("B,H,Sq,Sk,dk,short", [(2, 4, 800, 800, 256, 300), (2, 4, 256, 800, 256, 97), (2, 4, 800, 256, 256, 128), (3, 2, 130, 45, 256, None),
                                                  (2, 8, 300, 333, 128, 100), (2, 4, 64, 256, 256, 1), (2, 2, 257, 129, 128, 33)])
-def test_attention_backward_split_form(ops, B, H, Sq, Sk, dk, short, monkeypatch):
-    """the SPLIT backward (Sq >= 64, d_k >= 128, fp16 q / k / v planes: the encoder's attentions): the dQ kernel leaves P, dS and a scaled
-    bf16 copy of q in workspaces, dK / dV are two plain products over them, the bias gradients are summed from per-tile partials.  Against
+def test_attention_backward_split_form(ops, B, H, Sq, Sk, dk, short, form, monkeypatch):
+    """the SPLIT backward (Sq >= 64, d_k >= 128, fp16 q / k / v planes: the encoder's attentions), both forms.  "emit" (rounds 3-5): the dQ
+    kernel leaves P, dS and a scaled bf16 copy of q in workspaces, dK / dV are two plain products over them.  "recompute" (round 6, the
+    default): the dQ kernel leaves delta, live-query bits and max |dO| only, the key-side kernel keeps V rows in registers and the K block in
+    LDS, streams q / dO and rebuilds S, P, dP and dS (one power-of-two scale per (batch, head) on the fp16 dS).  In both the bias
+    gradients are summed from per-tile partials.  Against
     fp64 autograd on the fp16-rounded operands AND against the two-kernel form on the same inputs (BMT_ATTN_BWD_SPLIT=0); ragged prefix
     masks with whole 32- and 128-key tiles masked, lengths that are no multiple of the tiles, dO spanning five decades from row to row
     (the per-query power-of-two scale of the fp16 gradient operands), keys with a common component (the mean-key correction)."""
@@ -528,11 +532,12 @@ def test_attention_backward_split_form(ops, B, H, Sq, Sk, dk, short, monkeypatch
     biases = tuple(torch.zeros(D, device=DEV, requires_grad=True) for _ in range(3))
 
     def run(split):
-        monkeypatch.setattr(ops, "ATTN_BWD_SPLIT", split)
+        monkeypatch.setattr(ops, "ATTN_BWD_SPLIT", split is not False)
+        monkeypatch.setattr(ops, "ATTN_BWD_RECOMPUTE", split == "recompute")
         r = ops.attn_bwd_planes(f16(qp), f16(kp), f16(vp), o, dop, lse, B, Sq, Sk, D, md, H, 0.0, biases)
         torch.cuda.synchronize()
         return [(pl.hi[:, :D].float().cpu(), db.cpu()) for pl, db in r[:3]]
-    new, old = run(True), run(False)
+    new, old = run(form), run(False)
     # fp64 autograd on what the kernels were given: fp16 q / k / v, the bf16 plane of dO
     qr, kr, vr = (pl.fh[:, :D].double().cpu().view(B, S_, D).requires_grad_() for pl, S_ in ((qp, Sq), (kp, Sk), (vp, Sk)))
     want = _oracle_attention(qr, kr, vr, mask, H, rounded=False)

@@ -198,15 +198,17 @@ def _attention_fp64(q, k, v, mask, H):
     return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Sq, D)
 
 
+@pytest.mark.parametrize("form", ["recompute", "emit"])
 @pytest.mark.parametrize("B,H,Sq,Sk,dk,zero", [(2, 4, 800, 800, 256, "suffix"), (2, 4, 256, 800, 256, "suffix"), (2, 2, 300, 200, 128, "hole"),
                                                 (2, 4, 800, 256, 256, "all"), (3, 2, 130, 45, 256, "head")])
-def test_split_backward_skips_queries_without_gradient(ops, B, H, Sq, Sk, dk, zero):
+def test_split_backward_skips_queries_without_gradient(ops, B, H, Sq, Sk, dk, zero, form, monkeypatch):
     """the dQ kernel notes which 32-query groups have a non-zero dO (padded positions of the encoder: a suffix of every sequence); a 128-query
     tile without one skips its key loop and leaves no P / dS, the dK / dV kernel ends its query loop at the last live stage and wipes the
     fragments of a dead stage before it.  suffix: the real pattern (different lengths per batch element); hole: dead tiles and dead 32-row
     groups BEFORE live ones; all: no gradient at all; head: one head's columns of dO zero, the others not (the bits are per head).  Against
-    fp64 autograd on the kernels' operands, and bit-identical to the same launch with the shortcut switched off (BMT_ATTN_QSKIP=0 is read once
-    per process, so the reference here is the two-kernel form and fp64)."""
+    fp64 autograd on the kernels' operands.  Both split forms: "emit" (P and dS through HBM workspaces) and "recompute" (round 6: the key side
+    rebuilds them; a dead stage in front of a live one is simply computed there -- dO = 0 makes its dP, delta and dS exactly zero)."""
+    monkeypatch.setattr(ops, "ATTN_BWD_RECOMPUTE", form == "recompute")
     D = H * dk
     q = rnd(B * Sq, D, seed=401) * 0.7
     k = rnd(B * Sk, D, seed=402) * 0.7 + 0.4
