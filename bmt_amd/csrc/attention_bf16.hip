@@ -345,6 +345,16 @@ __device__ __forceinline__ void grad_tile_flush(const uint16_t* tile, const Grad
 // instructions per wave; measured on attn_bwd_dkvg_kernel (profiles/r03_h_split_probes.txt): 73 of the kernel's 154 us.  Here every wave
 // writes its registers into an image [128 tokens][d_k + 8] (ds_write_b64), the workgroup stores the image as whole 512-byte rows (16 bytes per
 // lane, consecutive lanes along d) and takes the bias column sums from the same image.
+// a workgroup barrier for LDS hand-overs inside an epilogue: __syncthreads() is a fence too -- it waits vmcnt(0), i.e. until every global
+// store the wave has issued is acknowledged -- and the epilogues below issue a gradient tile's 64 KB of row stores right before their
+// barriers: each tile's stores were drained twice on the critical path of a workgroup that owns its CU alone (round 6).  LDS writes are
+// complete at lgkmcnt(0); the "memory" clobbers keep the compiler's LDS accesses on their side of the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int DK, int NTL>
 __device__ __forceinline__ void grad_rm_write(uint16_t* img, const f32x16 (&acc)[NTL], int trow, bool ok, int hh, int dt0) {
     constexpr int PITCH = DK + 8;
@@ -396,7 +406,7 @@ __device__ __forceinline__ void grad_rm_flush(const uint16_t* img, float* red, c
         }
         red[2 * tid] = s0;
         red[2 * tid + 1] = s1;
-        __syncthreads();
+        lds_barrier();
         if (tid < NCW) {
 #pragma unroll
             for (int r = 1; r < NRB; ++r) { s0 += red[2 * (tid + r * NCW)]; s1 += red[2 * (tid + r * NCW) + 1]; }
@@ -416,9 +426,9 @@ __device__ __forceinline__ void grad_rm_epilogue(char* smem, const GradOut& g, c
     uint16_t* img = reinterpret_cast<uint16_t*>(smem);
     float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
     grad_rm_write<DK, NTL>(img, acc, trow, ok, hh, dt0);
-    __syncthreads();
+    lds_barrier();
     grad_rm_flush<DK, NT>(img, red, g, b, h, tok0, S, SP, tid);
-    __syncthreads();
+    lds_barrier();
 }
 
 // the same image from the 16x16 accumulator layout of the 16-wide kernels: acc[dt][r] = G^T[d = 16 dt + 4 g + r][token = this lane's column c]
@@ -440,9 +450,9 @@ __device__ __forceinline__ void grad_rm_epilogue16(char* smem, const GradOut& g_
     uint16_t* img = reinterpret_cast<uint16_t*>(smem);
     float* red = reinterpret_cast<float*>(smem + 128 * (DK + 8) * 2);
     grad_rm_write16<DK>(img, acc, trow, ok, g);
-    __syncthreads();
+    lds_barrier();
     grad_rm_flush<DK, NT>(img, red, g_, b, h, tok0, S, SP, tid);
-    __syncthreads();
+    lds_barrier();
 }
 
 // =================================================================================== forward
@@ -2769,6 +2779,12 @@ constexpr int dkvr_younger(int i, int pf, int n) {
     return c;
 }
 
+#ifndef BMT_DKVR_XP          // build-variant probes (BMT_VARIANT_FLAGS, csrc/build.sh): XP bit 3 = no epilogue, bit 4 = no loop; PF = fragment prefetch depth
+#define BMT_DKVR_XP 0
+#endif
+#ifndef BMT_DKVR_PF
+#define BMT_DKVR_PF 4
+#endif
 template <int DK, int XP = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkvr_kernel(const AttnPB pin) {
     AttnPB p = pin;
@@ -2895,7 +2911,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    constexpr int PF = 4, RR = PF + 1;
+    constexpr int PF = BMT_DKVR_PF, RR = PF + 1;
 #define BMT_R_ROWFRAG(i_) lds_b128<(DK == 256 ? (((i_) >> 1) >> 3) * 256 : 0) + (((i_) & 1) ? TILE : 0)>(kAs ^ ((((i_) >> 1) & 7) << 5))
 #define BMT_R_KFRAG(ks_) lds_b128<(DK == 256 ? ((ks_) >> 3) * 256 : 0)>(kB0 ^ (((ks_) & 7) << 5))
     // register r of the S / dP accumulators -> P, dS'.  x_ even: P; x_ odd: dS' (and, on the odd register of a pair, the two packed words)
@@ -2921,10 +2937,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             const uint32_t kAs = kA0 + so;
             u32x4 fr[RR], fkk[RR];         // step i's stage fragment (even: q rows, odd: dO rows) in fr[i % RR]; an even step's K fragment in fkk[(i / 2) % RR]
-            fr[0] = BMT_R_ROWFRAG(0); fkk[0] = BMT_R_KFRAG(0);
-            fr[1] = BMT_R_ROWFRAG(1);
-            fr[2] = BMT_R_ROWFRAG(2); fkk[1] = BMT_R_KFRAG(1);
-            fr[3] = BMT_R_ROWFRAG(3);
+#define BMT_R_ACPRE(i_)                                                                               \
+    if constexpr ((i_) < PF) {                                                                         \
+        fr[(i_) % RR] = BMT_R_ROWFRAG(i_);                                                             \
+        if constexpr (((i_) & 1) == 0) fkk[((i_) >> 1) % RR] = BMT_R_KFRAG((i_) >> 1);                 \
+    }
+            BMT_X_REP16(BMT_R_ACPRE)
+#undef BMT_R_ACPRE
 #define BMT_R_ACSTEP(i_)                                                                               \
     if constexpr ((i_) < 2 * KS) {                                                                     \
         if constexpr ((i_) + PF < 2 * KS) {                                                            \
@@ -2965,7 +2984,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ta[(m_) % RR] = lds_tr_b64<off__>(kTs ^ ((dt__ & 3) << 6));                                           \
         tb[(m_) % RR] = lds_tr_b64<off__ + 8 * ROWB>(kTs ^ (((dt__ & 3) << 6) | 32));                         \
     } while (0)
-        BMT_R_TFRAG(0); BMT_R_TFRAG(1); BMT_R_TFRAG(2); BMT_R_TFRAG(3);
+#define BMT_R_BPRE(m_) if constexpr ((m_) < PF) { BMT_R_TFRAG(m_); }
+        BMT_X_REP16(BMT_R_BPRE)
+#undef BMT_R_BPRE
         lgkm_wait4<2 * PF>(ls[0], ls[1], ls[2], ls[3]);          // (LDS operations retire in order: the statistics are older than the fragments)
         lgkm_wait4<2 * PF>(dc[0], dc[1], dc[2], dc[3]);
 #define BMT_R_V1(x_) if constexpr ((x_) < 16) { BMT_R_PS(x_); }
@@ -3270,7 +3291,7 @@ int launch_bwd(const AttnPB& p, uint16_t* dOh, hipStream_t st) {
             if (!pf.fuse_delta) hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(bmt_cdiv(rows, 4)), dim3(256), 0, st, p, DK, dOh);
             int rc = launch_dq32p<DK, 0, false>(pf, st);
             if (rc != BMT_OK) return rc;
-            rc = launch_dkvr<DK>(pf, st);
+            rc = launch_dkvr<DK, BMT_DKVR_XP>(pf, st);
             if (rc != BMT_OK) return rc;
             launch_bias_finish<DK>(p, st);
             BMT_CHECK_LAUNCH("bmt_attn_bwd_bf16 (recompute)");

@@ -1311,10 +1311,11 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
 
-# switch: "0" keeps the two-kernel backward everywhere; "emit" = the split form that leaves P and dS in HBM workspaces (rounds 3-5); default
-# (round 6) = the split form whose key side recomputes them (attn_bwd_dkvr_kernel), falling back to "emit" for shapes it does not take
+# switch: "0" keeps the two-kernel backward everywhere; default = the split form that leaves P and dS in HBM workspaces (rounds 3-5);
+# "recompute" (round 6) = the split form whose key side rebuilds them (attn_bwd_dkvr_kernel: 32 % less HBM traffic per attention, 7 products
+# instead of 5; measured 1 % SLOWER in the step -- 7.09 vs 7.02 ms, profiles/r06_d_ab_attn_bwd_forms.txt -- so it is the option, not the default)
 ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"
-ATTN_BWD_RECOMPUTE = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "emit"
+ATTN_BWD_RECOMPUTE = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") == "recompute"
 
 
 _SCRATCH = {}            # (device index, stream handle, capturing?, name) -> 1-D tensor: scratch that lives inside ONE library call
