@@ -547,7 +547,10 @@ def test_attention_backward_split_form(ops, B, H, Sq, Sk, dk, short, form, monke
         ref2 = ref.reshape(-1, D)
         assert torch.isfinite(gn).all() and torch.isfinite(bn).all(), f"{name}: non-finite values"
         en, eo = rel_err(gn, ref2), rel_err(go, ref2)
-        assert en < 6e-3 and en < 1.25 * eo + 1e-3, f"{name} (B{B} H{H} {Sq}x{Sk} d_k {dk}): split {en:.3e}, two-kernel {eo:.3e}\n" + report(gn, ref2, name)
+        # (the recompute form's dP = dO . V^T runs on bf16 V like the two-kernel form's: where attention is peaked -- one valid key: P = 1,
+        # dP = delta up to rounding -- dS is the difference of two nearly equal numbers and inherits V's 2^-9; the emitting form keeps fp16 V there)
+        bar = 6e-3 if form == "emit" else max(6e-3, 1.05 * eo)
+        assert en < bar and en < 1.25 * eo + 1e-3, f"{name} (B{B} H{H} {Sq}x{Sk} d_k {dk}): split {en:.3e}, two-kernel {eo:.3e}\n" + report(gn, ref2, name)
         bref = ref2.sum(0)
         if name != "dk":      # (sum_j dS_ij = 0: the bias gradient of the key projection is zero up to rounding, no relative bar)
             assert rel_err(bn, bref) < 8e-3, f"bias gradient of {name}: {rel_err(bn, bref):.3e}"
