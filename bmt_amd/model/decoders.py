@@ -64,7 +64,7 @@ class BiModalDecoderLayer(nn.Module):
         else:
             s1 = torch.cuda.current_stream()
             for t in (C, Va, masks['V_mask']):
-                t.record_stream(s2)
+                ops.record_stream(t, s2)        # (the tensor, its row pack and its attached operand planes: all read by the side stream's kernels)
             with torch.cuda.stream(s2):
                 Cv = self.res_layer_enc_att_V(C_v, lambda y: self.enc_att_V(y, Va, Va, masks['V_mask']), fp32_out=False)
             Ca = self.res_layer_enc_att_A(C_a, lambda y: self.enc_att_A(y, Av, Av, masks['A_mask']), fp32_out=False)

@@ -114,9 +114,13 @@ def precision_description() -> str:
         return f"every forward GEMM {prec_name(o.gemm)}, attention forward {prec_name(o.attn)}, backward {prec_name(BWD_PRECISION)} MFMA operands; fp32 accumulate"
     e, d, x, sh = POLICIES["enc"], POLICIES["dec"], POLICIES[None], POLICIES["enc_shallow"]
     ffn2 = "" if sh.ffn2 == sh.gemm else f"; FFN-2 of an encoder of <= 2 layers {prec_name(sh.ffn2)}, {prec_passes(sh.ffn2)} pass"
-    return (f"MFMA operands per site: encoder GEMMs + decoder memory K/V projections {prec_name(e.gemm)} ({prec_passes(e.gemm)} passes{ffn2}), "
+    raw = globals().get("RAW_MEMORY", False)
+    mem = (f"the decoder's cross-attentions run against the raw encoder memories (no K/V projections: per-head block products {prec_name(x.gemm)}, "
+           f"the two products against the memory {prec_name(e.attn)})" if raw else f"decoder memory K/V projections {prec_name(e.gemm)}")
+    return (f"MFMA operands per site: encoder GEMMs {prec_name(e.gemm)} ({prec_passes(e.gemm)} passes{ffn2}), {mem}, "
             f"attention forward {prec_name(e.attn)} (1 pass), decoder GEMMs / bridge / generator {prec_name(x.gemm)} (3 passes), backward "
-            f"{prec_name(BWD_PRECISION)} (1 pass); fp32 accumulate, softmax, LayerNorm, loss, Adam")
+            f"{prec_name(BWD_PRECISION)} (1 pass; the encoder's attention backward on fp16 q / k / v with power-of-two scaled fp16 gradients); "
+            f"fp32 accumulate, softmax, LayerNorm, loss, Adam")
 
 
 WEIGHT_EPOCH = [0]      # bumped by the optimizer: invalidates cached weight planes
@@ -1318,7 +1322,25 @@ ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"
 ATTN_BWD_RECOMPUTE = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") == "recompute"
 
 
-_SCRATCH = {}            # (device index, stream handle, capturing?, name) -> 1-D tensor: scratch that lives inside ONE library call
+_SCRATCH = {}            # (device index, stream handle, capture owner | None, name) -> 1-D tensor: scratch that lives inside ONE library call
+_SCRATCH_OWNER = [None]  # the step whose hipGraph capture is running (scratch_owner): a captured launch's scratch belongs to THAT step's graphs
+
+
+class scratch_owner:
+    """``with scratch_owner(token):`` -- scratch requested by captured launches inside belongs to ``token`` (a train step); release_scratch(owner=
+    token) frees exactly those buffers.  (Round 5 keyed captured scratch by stream only: one step's uncapture() freed buffers a second
+    captured step on the same stream still replayed into.)"""
+
+    def __init__(self, token):
+        self.token = token
+
+    def __enter__(self):
+        self.prev, _SCRATCH_OWNER[0] = _SCRATCH_OWNER[0], self.token
+        return self
+
+    def __exit__(self, *exc):
+        _SCRATCH_OWNER[0] = self.prev
+        return False
 
 
 def stream_scratch(name: str, numel: int, dtype, device) -> torch.Tensor:
@@ -1329,19 +1351,20 @@ def stream_scratch(name: str, numel: int, dtype, device) -> torch.Tensor:
     roofline).  A hipGraph capture has its own entries (its stream is capturing: the buffer comes out of the graph's private pool and
     stays with the graph)."""
     dev = torch.device(device)
+    cap = torch.cuda.is_current_stream_capturing()
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream,
-           torch.cuda.is_current_stream_capturing(), name)
+           (_SCRATCH_OWNER[0] if _SCRATCH_OWNER[0] is not None else "captured") if cap else None, name)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < numel or t.dtype != dtype:
         t = _SCRATCH[key] = torch.empty(max(int(numel), 1), device=dev, dtype=dtype)
     return t[:numel]
 
 
-def release_scratch(capturing: Optional[bool] = None):
-    """drop the per-stream scratch buffers (all of them, or those of captured / eager launches only): several GB at configs[1] -- two
-    183-MB P / dS workspaces + 52 MB per stream and launch kind.  Scratch that a hipGraph was captured over belongs to that graph: release it
-    only after the graph is gone (CaptioningTrainStep.uncapture does)."""
-    for k in [k for k in _SCRATCH if capturing is None or k[2] == capturing]:
+def release_scratch(capturing: Optional[bool] = None, owner=None):
+    """drop per-stream scratch buffers: all of them, those of captured / eager launches only, or -- ``owner`` -- those captured under
+    scratch_owner(owner).  Several GB at configs[1]: two 183-MB P / dS workspaces + 52 MB per stream and launch kind.  Scratch that a hipGraph
+    was captured over belongs to that graph: release it only after the graph is gone (a train step's uncapture() releases ITS OWN)."""
+    for k in [k for k in _SCRATCH if (owner is not None and k[2] == owner) or (owner is None and (capturing is None or (k[2] is not None) == capturing))]:
         del _SCRATCH[k]
 
 
@@ -2407,7 +2430,7 @@ class RawMemoryState:
         return ((l * 2 + kind) * self.H) * 32 * self.dm, self.L * 2 * self.H * 32 * self.dm, 32 * self.dm
 
     def tensors(self):
-        return [t for t in (self.xt_f16, self.xtc_bf, self.astack, self.bstack, self.x.hi, self.x.fh) if t is not None]
+        return [t for t in (self.xt_f16, self.xtc_bf, self.astack, self.bstack, self.x.hi, self.x.fh, self.pack.off, self.pack.row_map) if t is not None]
 
 
 def _addr(t: torch.Tensor, elems: int = 0) -> int:
@@ -2435,9 +2458,13 @@ def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, ah, al, lda, bh, bl, ldb, *, a_of
 
 def raw_form_ok(st: "RawMemoryState", Q, mha, pol) -> bool:
     """does this MultiheadedAttention call fit the reassociated form the state was prepared for?"""
-    return (st is not None and Q.dim() == 3 and Q.shape[0] == st.B and Q.shape[1] == st.Tq and mha.H == st.H and mha.d_model_K == st.dm and
-            mha.d_model % mha.H == 0 and (mha.d_model // mha.H) % 64 == 0 and pol.gemm == PREC_BF16X3 and pol.attn == PREC_F16 and
-            (not torch.is_grad_enabled() or st.astack is not None or not (Q.requires_grad or mha.linear_Q2d.weight.requires_grad)))
+    # (a state has one slot per decoder layer in its operand stacks: an attention call beyond them -- a layer re-executed by a checkpoint
+    # recompute, a memory alias handed to an extra attention -- falls back to the projected form instead of writing past the stacks; and a
+    # call that will need a backward at all -- the queries or ANY parameter of the module -- needs the state's gradient stacks)
+    return (st is not None and st.next_layer < st.L and Q.dim() == 3 and Q.shape[0] == st.B and Q.shape[1] == st.Tq and mha.H == st.H and
+            mha.d_model_K == st.dm and mha.d_model % mha.H == 0 and (mha.d_model // mha.H) % 64 == 0 and pol.gemm == PREC_BF16X3 and
+            pol.attn == PREC_F16 and
+            (not torch.is_grad_enabled() or st.astack is not None or not (Q.requires_grad or any(p_.requires_grad for p_ in mha.parameters()))))
 
 
 def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> torch.Tensor:
@@ -2449,6 +2476,10 @@ def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> t
         return mem
     if not torch.is_grad_enabled():      # inference projects keys and values: greedy decoding computes them once per caption (ops.mha_infer), and a
         return mem                       # full forward pass under no_grad runs the same kernels as that cached form (tests/test_gpu_model.py)
+    if not (isinstance(mem, torch.Tensor) and mem.requires_grad):
+        # a memory without a gradient (a frozen encoder: cfg.finetune_prop_encoder = False) has no operand stacks, and every training call
+        # would fall back to the projected form (raw_form_ok): do not prepare transposed copies and a zeroed B stack nobody reads
+        return mem
     if not (RAW_MEMORY and SMALL_DX_OUTPUTS > 0 and pk is not None and isinstance(mem, torch.Tensor) and mem.is_cuda and mem.dim() == 3 and
             mem.dtype == torch.float32 and mem.shape[-1] % 64 == 0 and 0 < Tq <= 32 and n_layers > 0 and mem.shape[1] <= 1024 and
             context().kv_cache is None):
@@ -2564,7 +2595,7 @@ class RawCrossAttnFn(torch.autograd.Function):
         # the memory's two projections as one weight group (what the projected form and greedy decoding register too): member planes
         grp, _ = weight_group((Wk, Wv), (bk, bv), "x3")
         gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))                                 # [dm][2 D] hi + lo: columns [0, D) = W_k^T
-        train = any(ctx.needs_input_grad[:3]) or Wq.requires_grad
+        train = any(ctx.needs_input_grad)      # (the queries, the memory or ANY of the module's parameters: a partly frozen module saves what its backward reads)
         # Q'[(b, t)][h dm + d] = q_h W_k,h: fp16 (the A operand of S) in the natural layout, bf16 into the B stack (b, l, 0, h)
         qf = torch.empty(M, H * dm, device=dev, dtype=torch.float16)
         bo_, bsb, bsh = st.b_block(l, 0)

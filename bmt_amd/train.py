@@ -225,14 +225,14 @@ class CaptioningTrainStep:
         # invalidates the capture and the watchdog's exception terminates the process (seen in ~1 of 8 runs of tools/dp_smoke_1gpu.py:
         # "operation not permitted when stream is capturing").  The kernels of autograd's worker threads are still captured: capture
         # is a property of the stream, the mode only says whose unsafe calls are errors.
-        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+        from . import ops as _ops
+        with _ops.scratch_owner(id(self)), torch.cuda.graph(g1, capture_error_mode="thread_local"):
             self._static_kl, self._static_ntok = self._forward_backward(self._static_fs, self._static_caps)
         self._reduce(self._static_kl, self._static_ntok)
         torch.cuda.synchronize()                # the eager all-reduce has finished before the second capture starts
-        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+        with _ops.scratch_owner(id(self)), torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             self._optimize()
         self._graphs = (g1, g2)
-        from . import ops as _ops
         self._graph_generation = _ops.weights_generation()
         return self._graphs
 
@@ -254,7 +254,8 @@ class CaptioningTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        from . import ops as _ops
+        with _ops.scratch_owner(id(self)), torch.cuda.graph(g, capture_error_mode="thread_local"):
             kl, ntok = self._forward_backward(self._static_fs, self._static_caps)
             self._static_loss, _ = self._reduce(kl, ntok)
             self._static_ntok = ntok
@@ -270,7 +271,7 @@ class CaptioningTrainStep:
         self._graphs = None
         if had:          # the per-stream scratch the graphs were captured over goes with them
             from . import ops as _ops
-            _ops.release_scratch(capturing=True)
+            _ops.release_scratch(owner=id(self))
         if self.reducer is not None:
             self.reducer.overlap = self._overlap
 
@@ -404,10 +405,10 @@ class ProposalTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        from . import ops as _ops
+        with _ops.scratch_owner(id(self)), torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_out = self(self._static_fs, self._static_tg)
         self._graph = g
-        from . import ops as _ops
         self._graph_generation = _ops.weights_generation()
         return g
 
