@@ -108,6 +108,8 @@ SIGNATURES = {
     "bmt_raw_softmax_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp]),
     "bmt_raw_softmax_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, i64, i64, vp]),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
+    "bmt_gemm_bf16_grouped_tables": (i32, [vp, i32, vp, C.c_size_t, C.POINTER(i32), vp]),
+    "bmt_gemm_bf16_grouped_run": (i32, [vp, i32, C.POINTER(i32), vp]),
     "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp, vp]),
     "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp, vp]),
     "bmt_layernorm_bwd_add": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp, vp]),

@@ -2206,7 +2206,29 @@ extern "C" size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob) {
     return nprob <= 0 ? 0 : (size_t)nprob * sizeof(GemmB) + 8 * XCD_MAXSEG * sizeof(XcdSeg) + 8 * sizeof(int) + 512;
 }
 
+// ABI 9: the grouped launch in two calls, so that the ~25 table-writer launches (4 us each, dependent on nothing but the buffers' addresses)
+// can sit on ANOTHER stream than the product -- a stream the caller forks from the step's beginning: inside a captured step they then run
+// beside the forward pass instead of in front of the grouped launch on the critical path (profiles/r05_zz_replay_dispatches.csv: ~100 us of
+// tiny kernels before the weight-gradient launch, ~50 us before each memory-gradient launch).  launch[0] = grid slots, launch[1] = 1 when an
+// output is a packed row range: what bmt_gemm_bf16_grouped_run needs besides the workspace.
+static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, hipStream_t st);
+static int grouped_run(void* ws, int nprob, const int* launch, hipStream_t st);
+
+extern "C" int bmt_gemm_bf16_grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, void* stream) {
+    BMT_CHECK_ARG(launch != nullptr, "bmt_gemm_bf16_grouped_tables: launch is NULL");
+    return grouped_tables(args, nprob, ws, ws_bytes, launch, (hipStream_t)stream);
+}
+extern "C" int bmt_gemm_bf16_grouped_run(void* ws, int nprob, const int* launch, void* stream) {
+    BMT_CHECK_ARG(ws && launch && nprob > 0 && launch[0] > 0, "bmt_gemm_bf16_grouped_run: bad arguments");
+    return grouped_run(ws, nprob, launch, (hipStream_t)stream);
+}
 extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream) {
+    int launch[2] = {0, 0};
+    const int rc = grouped_tables(args, nprob, ws, ws_bytes, launch, (hipStream_t)stream);
+    return rc != BMT_OK ? rc : grouped_run(ws, nprob, launch, (hipStream_t)stream);
+}
+
+static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, hipStream_t st) {
     BMT_CHECK_ARG(args && ws && nprob > 0 && nprob <= 4096, "bmt_gemm_bf16_grouped: bad arguments");
     BMT_CHECK_ARG(ws_bytes >= bmt_gemm_bf16_grouped_ws_bytes(nprob) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                   "bmt_gemm_bf16_grouped: workspace too small or not 16-byte aligned");
@@ -2280,7 +2302,6 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
         }
     }
     if (overflow) { free(pr); free(order); free(sp); bmt_set_error("bmt_gemm_bf16_grouped: too many segments for one XCD"); return BMT_EINVAL; }
-    hipStream_t st = (hipStream_t)stream;
     GemmB* table = reinterpret_cast<GemmB*>(ws);
     char* tail = reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15);
     XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
@@ -2302,6 +2323,18 @@ extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, 
     free(order);
     free(sp);
     BMT_CHECK_LAUNCH("bmt_gemm_bf16_grouped(table)");
+    launch[0] = max_slots;
+    launch[1] = placed ? 1 : 0;
+    return BMT_OK;
+}
+
+static int grouped_run(void* ws, int nprob, const int* launch, hipStream_t st) {
+    const int max_slots = launch[0];
+    const bool placed = launch[1] != 0;
+    GemmB* table = reinterpret_cast<GemmB*>(ws);
+    char* tail = reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15);
+    XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
+    int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
     constexpr int BK = 64, BMr = 128;
     constexpr int stage = BK * km_rs<BMr>() + BK * km_rs<BN>();
     constexpr int lds = (2 * stage > BMr * BN * 4) ? 2 * stage : BMr * BN * 4;

@@ -153,7 +153,8 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles")
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
+                 "step_start")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
@@ -167,6 +168,7 @@ class StepContext:
         self.allow_streams = True    # cleared by a train step whose gradient reducer needs autograd-order completion on ONE stream
         self.last_gen = None         # GenHandle of the GeneratorFn.forward that just ran (picked up by model.generators.Generator)
         self.gen_handles = []        # handles whose loss took the fused backward: flush_dw settles their parameters' use counts
+        self.step_start = None       # event at the beginning of the pass in flight (mark_step_start): what the table stream of a grouped launch waits for
 
 
 _contexts = {}
@@ -936,6 +938,47 @@ GROUPED_DW = True        # the queued weight-gradient products of a pass as one 
 _dw_ws = {}
 
 
+EARLY_TABLES = True       # the descriptor tables of a grouped launch are written on a stream forked from the step's beginning (mark_step_start)
+_table_streams = {}       # (device, main stream handle) -> the stream the table writers of its grouped launches run on
+
+
+def mark_step_start():
+    """call at the beginning of a train step (before zero_grad): records the event the table writers of the step's grouped launches wait
+    for INSTEAD of the work in front of the launch.  A grouped launch's ~25 descriptor-table writers (a few microseconds each, launch-bound)
+    depend on nothing but buffer addresses; issued behind the backward pass they sat on the step's critical path (~100 us in front of the
+    weight-gradient launch, ~50 us in front of each memory-gradient launch: profiles/r05_zz_replay_dispatches.csv).  Forked from this event
+    they are, inside a captured step, a branch of the graph that starts with the replay and runs beside the forward pass."""
+    c = context()
+    ev = torch.cuda.Event()
+    ev.record()
+    c.step_start = ev
+
+
+def clear_step_start():
+    context().step_start = None
+
+
+_table_ws = {}            # device index -> {"turn": int, "bufs": [16 byte tensors]}: descriptor-table buffers of the EARLY path
+
+
+def _early_table_ws(dev, need):
+    """a table buffer that may be written at the BEGINNING of a step although it is asked for at its end.  Under a hipGraph capture an
+    allocation made where the launch is issued comes from the graph's private pool and may be the memory of a forward-pass temporary that
+    was freed earlier in the capture -- written at the replay's start it would be overwritten by that temporary (first GPU run of this
+    path: garbage descriptors, a memory fault).  These buffers are therefore allocated OUTSIDE any capture (the eager warm-up steps that
+    precede one reach this function first), once per device, and rotate; None while capturing without them."""
+    d = torch.device(dev)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    pool = _table_ws.get(idx)
+    size = max(int(need), 256 << 10)
+    if pool is None or pool["bufs"][0].numel() < size:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        pool = _table_ws[idx] = {"turn": 0, "bufs": [torch.empty(size, dtype=torch.uint8, device=d) for _ in range(16)]}
+    pool["turn"] = (pool["turn"] + 1) % len(pool["bufs"])
+    return pool["bufs"][pool["turn"]]
+
+
 def gemm_bf16_grouped(items):
     """items: [(dY planes [rows][N_out], X planes [rows][K_in], dW fp32 [N_out][K_in] accumulated in place)] -> one launch"""
     n = len(items)
@@ -965,7 +1008,28 @@ def gemm_bf16_grouped(items):
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)
         _dw_ws[sk + (slot[0],)] = ws
-    _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
+    ev = context().step_start if EARLY_TABLES else None
+    tws = _early_table_ws(dev, need) if ev is not None else None
+    if tws is None:
+        _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
+        return
+    # tables on the table stream, ordered behind the step's beginning only (and behind this stream's earlier grouped launches: stream order);
+    # the product on the current stream, behind the tables
+    ws = tws
+    cur = torch.cuda.current_stream()
+    ts = _table_streams.get(sk)
+    if ts is None:
+        if torch.cuda.is_current_stream_capturing():       # (no stream creation inside a capture: the eager warm-up steps made it)
+            _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
+            return
+        ts = _table_streams[sk] = torch.cuda.Stream(device=dev)
+    ts.wait_event(ev)
+    ws.record_stream(ts)
+    launch = (C.c_int * 2)()
+    with torch.cuda.stream(ts):
+        _lib.check(lib.bmt_gemm_bf16_grouped_tables(arr, n, _p(ws), ws.numel(), launch, C.c_void_p(ts.cuda_stream)), "bmt_gemm_bf16_grouped_tables")
+    cur.wait_stream(ts)
+    _lib.check(lib.bmt_gemm_bf16_grouped_run(_p(ws), n, launch, _st()), "bmt_gemm_bf16_grouped_run")
 
 
 def flush_dw():

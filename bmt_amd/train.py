@@ -135,11 +135,12 @@ class CaptioningTrainStep:
         """zero_grad -> masks -> forward -> sum-KL -> backward.  Returns (sum-KL, local non-pad token count)."""
         model = self.model
         model.train()
+        from . import ops as _ops
+        _ops.mark_step_start()          # (the table writers of this pass's grouped launches fork from here)
         if self.reducer is not None:
             self.reducer.zero_grad()
         else:
             self.optimizer.zero_grad()
-        from . import ops as _ops
         x, y, n_tokens = _ops.caption_shift(caption_idx, self.pad_idx)
         masks = make_masks(feature_stacks, x, self.modality, self.pad_idx)
         # the encoder's two compute streams: not while gradient buckets are all-reduced from inside the backward pass (a bucket's
@@ -162,6 +163,7 @@ class CaptioningTrainStep:
             sctx.pending_dw.clear()
             sctx.pending_cs.clear()
             sctx.gen_handles.clear()
+            _ops.clear_step_start()
         return kl.detach(), n_tokens
 
     def _reduce(self, kl, n_tokens):

@@ -138,6 +138,12 @@ size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob);
  * keeps transposed weight planes for dX asks here which products qualify; 0 = the library was built without the kernel. */
 long long bmt_gemm_small_outputs(void);
 int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream);
+/* ABI 9 -- the same launch as two calls: _tables writes the descriptor table and the per-XCD segment lists into ws (~25 launches of a few
+ * microseconds, on `stream`: a stream of the caller's choice, e.g. one forked from the beginning of the step, so that they do not sit in
+ * front of the product on its critical path) and returns what the product launch needs in launch[2]; _run launches the product on ITS
+ * stream.  The caller orders the two (an event between the streams) and keeps ws untouched until the product has executed. */
+int bmt_gemm_bf16_grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, void* stream);
+int bmt_gemm_bf16_grouped_run(void* ws, int nprob, const int* launch, void* stream);
 
 /* ABI 8 -- MANY small products of one shape in one launch on the 32 x 32 tile kernel (row-major operands; BMT_PREC_BF16, BMT_PREC_F16 or
  * BMT_PREC_BF16X3; epilogue: alpha, bias, dropout, relu, column sums; no residual / gate / accumulate).  `args` describes ONE product
