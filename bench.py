@@ -723,7 +723,23 @@ def dry_run(args, world, rank):
         dist.all_gather_object(rank_devices, {"rank": rank, "local_rank": rank, "device": "cpu"})
     if rank == 0:
         colls = ["allreduce", "rs_ag"] if args.dp_collective == "auto" else [args.dp_collective]
+        flush_map = None
+        if args.procedure == "train_cap":
+            # which gradient bucket becomes final at which flush point of the overlapped backward pass (the configs[1] model on the CPU: the
+            # bucket layout is pure arithmetic over the parameter list), so that a multi-GPU line can be checked against SURVEY.md 8e's budget
+            # (exposed communication + imbalance <= 25 % of the step) from the line alone: bytes_after_last_layer_flush is what no backward
+            # work is left to hide
+            import contextlib, io
+            from bmt_amd import ops as _ops, parallel as _par, synthetic as syn
+            from bmt_amd.model.captioning_module import BiModalTransformer
+            cfg = syn.cfg_config1(dout_p=0.1)
+            cfg.device = "cpu"
+            torch.manual_seed(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = BiModalTransformer(cfg, syn.FakeTrainDataset(10000, syn.make_glove(10000, cfg.d_model_caps)))
+            flush_map = _par.bucket_flush_map(model, 32 << 20, _ops.fused_weight_groups(model))
         print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "dry_run": True, "value": units * args.steps / dt, "unit": "units/s",
+                          "dp_flush_map": flush_map,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "captured_allreduce_trial": trial_res, "rccl_ranks_seen": ranks_seen, "rank_devices": rank_devices,
                           "allreduce_exposed_ms": None, "dp_collective": colls[0], "dp_collectives_tried": colls if world > 1 else []}))

@@ -163,7 +163,8 @@ class PositionalEncoder(nn.Module):
 
 
 class Transpose(nn.Module):
-    """LayerNorm expects (B, S, D) but receives (B, D, S); Conv1d expects (B, D, S) but receives (B, S, D)"""
+    """swaps the last two axes between the channel-last layout of LayerNorm and the channel-first layout of nn.Conv1d (reference blocks.py:110-120;
+    the proposal heads here convolve channel-last activations directly, so the module only exists for layer_norm=True heads and state_dict parity)"""
 
     def __init__(self):
         super(Transpose, self).__init__()
@@ -253,7 +254,7 @@ class PositionwiseFeedForward(nn.Module):
         self._site = ops.new_site()
 
     def forward(self, x):
-        '''In, Out: (B, S, D)'''
+        """fc2(dropout(relu(fc1(x)))) on (B, T, D); the hidden activation exists as operand planes only"""
         p = self.dout_p if self.training else 0.0
         pol = ops.policy_of(self)
         off = ops.take_residual()

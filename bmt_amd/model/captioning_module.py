@@ -66,7 +66,7 @@ class Transformer(nn.Module):
                 param.requires_grad = cfg.finetune_prop_encoder
 
     def forward(self, src: dict, trg, masks: dict):
-        ''' src (B, Ss, d_feat) trg (B, St) src_mask (B, 1, Ss) trg_mask (B, St, St) -> (B, St, voc_size) '''
+        """one modality's features (B, T, d_feat) + caption prefix (B, T_c) under a key-padding mask (B, 1, T) and the caption's causal mask (B, T_c, T_c) -> log-probabilities (B, T_c, vocabulary)"""
         if self.training:
             ops.rng_advance()
         if self.modality == 'audio':
@@ -89,15 +89,13 @@ class Transformer(nn.Module):
 
 
 class BiModalTransformer(nn.Module):
-    '''
-    Forward:
-        Inputs:
-            src {'rgb'&'flow' (B, Sv, Dv), 'audio': (B, Sa, Da)}
-            trg (C): ((B, Sc))
-            masks: {'V_mask': (B, 1, Sv), 'A_mask': (B, 1, Sa), 'C_mask' (B, Sc, Sc))}
-        Output:
-            C: (B, Sc, Vc) log-probabilities
-    '''
+    """The flagship model of the path (reference model/captioning_module.py:101-187): features of two modalities in, per-token log-probabilities out.
+
+    ``forward(src, trg, masks)``: ``src`` is the dict of padded feature stacks the dataset hands over -- 'rgb' and 'flow' (B, T_v, d_vid), summed
+    before anything else, and 'audio' (B, T_a, d_aud); ``trg`` the caption prefix (B, T_c) of token ids; ``masks`` the dict built by make_masks
+    ('V_mask' / 'A_mask': key-padding masks (B, 1, T), 'C_mask': padding AND causality (B, T_c, T_c)).  Returns (B, T_c, vocabulary) log-probabilities.
+    What runs underneath: the valid rows of the two streams packed (ops.RowPack), encoder and decoder on libbmt_hip.so's kernels through
+    bmt_amd.ops, the first decoder layer's self-attention on a third stream beside the encoder."""
 
     def __init__(self, cfg, train_dataset):
         super(BiModalTransformer, self).__init__()

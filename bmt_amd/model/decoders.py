@@ -44,11 +44,9 @@ class BiModalDecoderLayer(nn.Module):
         return self.res_layer_self_att(C, lambda y: self.self_att(y, y, y, C_mask), fp32_out=False)
 
     def forward(self, x, masks):
-        '''
-        x (C, memory): C: (B, Sc, Dc), memory: (Av: (B, Sa, Da), Va: (B, Sv, Dv))
-        masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa); C_mask (B, Sc, Sc)}
-        returns (C, memory) so the layer threads through LayerStack
-        '''
+        """one bi-modal decoder layer.  ``x`` is the pair LayerStack threads from layer to layer: the caption stream C (B, T_c, d_caps) and the encoder
+        memories (audio-attended-by-video, video-attended-by-audio); ``masks`` the dict of make_masks.  Self-attention under C_mask, the two
+        encoder-decoder attentions (the video one on the side stream), bridge, feed-forward; the pair comes back with the new C."""
         C, memory = x
         Av, Va = memory.take() if isinstance(memory, _LayerMemories) else memory
 

@@ -20,7 +20,7 @@ class EncoderLayer(nn.Module):
         self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dout_p=0.0)
 
     def forward(self, x, src_mask):
-        ''' x: (B, S, d_model), src_mask: (B, 1, S) -> (B, S, d_model) '''
+        """self-attention + feed-forward on one stream (B, T, d_model) under its key-padding mask; shape unchanged"""
         x = self.res_layers[0](x, lambda y: self.self_att(y, y, y, src_mask))
         x = self.res_layers[1](x, self.feed_forward)
         return x
@@ -41,9 +41,9 @@ class BiModalEncoderLayer(nn.Module):
         ops.tag_policy(self, "enc")     # MFMA operand formats of this layer's products (bmt_amd.ops.POLICIES)
 
     def forward(self, x, masks):
-        '''
-        x (M1, M2): (B, Sm, Dm); masks (M1, M2): (B, 1, Sm)  ->  M1m2 (B, Sm1, Dm1), M2m1 (B, Sm2, Dm2)
-        '''
+        """one bi-modal encoder layer on the pair of streams (audio, video): each stream's self-attention, then each attends the OTHER stream's
+        post-self-attention values (queries normalised, keys / values not), then its feed-forward; ``masks`` is the pair of key-padding
+        masks in the same order.  Returns the pair of updated streams, shapes unchanged."""
         M1, M2 = x
         M1_mask, M2_mask = masks
         s2 = getattr(_SESSION, "s2", None)
@@ -125,7 +125,7 @@ class BiModalEncoder(nn.Module):
         self.encoder_AV.layers[-1].memory_planes_fmt = ops.act_fmt(ops.POLICIES["dec"].kv_gemm)
 
     def forward(self, x, masks: dict):
-        ''' x (A, V): (B, Sm, D); masks: {V_mask: (B, 1, Sv); A_mask: (B, 1, Sa)}  ->  (Av, Va) '''
+        """the stack of bi-modal layers on (audio, video); the masks dict is reordered into the layers' (audio, video) pair.  Returns the two memories"""
         A, V = x
         s2 = ops.fork_side_stream() if A.is_cuda else None
         if s2 is None:

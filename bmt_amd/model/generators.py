@@ -12,5 +12,5 @@ class Generator(nn.Module):
         print('Using vanilla Generator')
 
     def forward(self, x):
-        ''' x: (B, Sc, Dc) -> (B, Sc, voc_size) log-probabilities '''
+        """decoder states (B, T_c, d_caps) -> log-softmax over the vocabulary (B, T_c, V)"""
         return ops.generator(x, self.linear.weight, self.linear.bias)

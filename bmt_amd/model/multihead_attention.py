@@ -64,7 +64,7 @@ class MultiheadedAttention(nn.Module):
         assert self.d_model % H == 0
 
     def forward(self, Q, K, V, mask):
-        ''' Q, K, V: (B, Sq, Dq), (B, Sk, Dk), (B, Sv, Dv); mask: (B, 1, Sk) or (B, Sq, Sk) '''
+        """queries (B, T_q, D_q) against keys / values (B, T_k, D_k / D_v) under a key-padding (B, 1, T_k) or per-query (B, T_q, T_k) mask -> (B, T_q, D_q)"""
         p = self.dout_p if self.training else 0.0
         pol = ops.policy_of(self)         # operand formats of this module's sites (set by the enclosing encoder / decoder layer)
         kv_cache = ops.context().kv_cache

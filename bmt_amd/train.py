@@ -93,8 +93,9 @@ class CaptioningTrainStep:
         self.criterion = LabelSmoothing(cfg.smoothing, pad_idx)
         self.data_parallel = data_parallel
         from . import ops as _ops
+        from .parallel import flush_stages
         self.reducer = GradientReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, groups=_ops.fused_weight_groups(model),
-                                       collective=collective) if (data_parallel or static_grads) else None
+                                       collective=collective, stage_of=flush_stages(model)[0]) if (data_parallel or static_grads) else None
         self.modality = getattr(cfg, 'modality', 'audio_video')
         self.grad_scale = torch.ones(1, device=params[0].device, dtype=torch.float32)
         self._one = torch.ones((), device=params[0].device, dtype=torch.float32)        # the root gradient of every backward pass

@@ -22,6 +22,13 @@ def test_self_launch_two_ranks_dry_run():
     r, out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert out and out["dry_run"] and out["n_gpus"] == 2 and out["steps"] == 3
+    # the bucket -> flush-point map of the overlapped backward pass (round 6): every byte of the 50.4 M gradients lands at exactly one flush
+    # point, buckets never straddle two stages, and what is final only at the end of the pass is encoder layer 0 alone
+    fm = out["dp_flush_map"]
+    assert fm["stage_aligned_buckets"] and len(fm["flush_points"]) == 3 and sum(fm["bytes_final_at_point"]) == fm["total_bytes"] == 201772320
+    assert all(b["final_at"] in (0, 1, 2) for b in fm["buckets"]) and sum(b["bytes"] for b in fm["buckets"]) == fm["total_bytes"]
+    assert all(("layers.0." in b["first"]) == ("layers.0." in b["last"]) == (b["final_at"] == 2) for b in fm["buckets"] if "encoder" in b["first"])
+    assert fm["bytes_after_last_layer_flush"] == fm["bytes_final_at_point"][-1] and 0.3 < fm["fraction_after_last_layer_flush"] < 0.4
     # max over ranks of the wall time (rank 1 sleeps 2 ms per step), sum over ranks of the units (100 + 200)
     assert out["ms_per_step"] >= 1.9 and abs(out["value"] * out["ms_per_step"] * 1e-3 - 300.0) < 1e-6
     # the evidence that N ranks took part travels in the line itself: what the collective library counts (a sum all-reduce of ones), every

@@ -193,3 +193,43 @@ def test_shard_proposal_batch_rebases_targets():
         assert fs["rgb"].shape[0] == 2 and set(tg[:, 0].tolist()) <= {0.0, 1.0}
         seen += tg.shape[0]
     assert seen == batch["targets"].shape[0]
+
+
+def test_buckets_follow_the_flush_stages():
+    """round 6: a gradient bucket holds parameters of ONE flush stage (generator + decoder | encoder layer k), so that its all-reduce starts at
+    that stage's flush point instead of waiting for a later layer's; bucketize / bucket_flush_map are pure arithmetic over the parameters"""
+    import torch.nn as nn
+    from bmt_amd import parallel
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = nn.ModuleList([nn.Linear(64, 64) for _ in range(3)])
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = nn.Module()
+            self.encoder.encoder_AV = Enc()
+            self.decoder = nn.Linear(64, 32)
+            self.generator = nn.Linear(32, 16)
+    m = M()
+    stage, points = parallel.flush_stages(m)
+    assert len(points) == 4 and stage[id(m.generator.weight)] == 0 and stage[id(m.encoder.encoder_AV.layers[2].weight)] == 1 \
+        and stage[id(m.encoder.encoder_AV.layers[0].bias)] == 3
+    big = 1 << 30
+    plain = parallel.bucketize(list(m.parameters()), big)
+    assert len(plain) == 1                                     # everything fits one bucket ...
+    aligned = parallel.bucketize(list(m.parameters()), big, None, stage)
+    assert len(aligned) == 4                                   # ... but a bucket never mixes stages
+    for ps in aligned:
+        assert len({stage[id(p)] for p in ps}) == 1
+    assert [id(p) for ps in aligned for p in ps] == [id(p) for p in reversed(list(m.parameters()))]      # order unchanged
+    fm = parallel.bucket_flush_map(m, big)
+    assert fm["bytes_final_at_point"] == [4 * (64 * 32 + 32 + 32 * 16 + 16)] + [4 * (64 * 64 + 64)] * 3
+    fm0 = parallel.bucket_flush_map(m, big, aligned=False)
+    assert fm0["bytes_final_at_point"][-1] == fm0["total_bytes"]      # one bucket: everything waits for the end
+    # the reducer's buckets are the same lists
+    red = parallel.GradientReducer(list(m.parameters()), bucket_bytes=big, stage_of=stage)
+    assert [[id(p) for p in b["params"]] for b in red.buckets] == [[id(p) for p in ps] for ps in aligned]
+    red.remove()
