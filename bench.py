@@ -810,7 +810,7 @@ def build_prop(args, dev, rank, world):
     batch = syn.make_prop_batch(cfg, B, Tv, Ta, seed=11 + rank)
     fs = {k: v.to(dev) for k, v in batch["feature_stacks"].items()}
     tg = batch["targets"].to(dev)
-    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000,
+    step = ProposalTrainStep(model, cfg, syn.PAD_IDX, data_parallel=world > 1, seed=1000, static_grads=True,
                              collective="allreduce" if args.dp_collective == "auto" else args.dp_collective)
     # heads 348.7 + 322.9 GF and encoder 230.0 GF forward per sample at (T_a, T_v) = (3200, 1024); the frozen
     # encoder has no backward, the heads have 2x their forward

@@ -181,6 +181,8 @@ SIGNATURES = {
     "bmt_targets_init": (i32, [vp, vp, vp, vp, i64, vp]),
     "bmt_make_targets": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "bmt_prop_decode_loss": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "bmt_prop_decode_loss2": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, i64, vp, i32, vp]),
+    "bmt_prop_loss_finalize_multi": (i32, [vp, i32, i32, vp, vp, f32, f32, vp, vp, vp]),
     "bmt_prop_loss_finalize": (i32, [vp, f32, f32, vp, vp]),
     "bmt_prop_loss_bwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]),
 }

@@ -70,7 +70,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __global__ __launch_bounds__(256) void decode_loss_kernel(const float* __restrict__ x, const float* __restrict__ anchors, int B, int S, int A,
                                                            float stride, const uint8_t* __restrict__ obj, const uint8_t* __restrict__ noobj,
                                                            const float* __restrict__ tx, const float* __restrict__ tw,
-                                                           float* __restrict__ preds, float* __restrict__ sums) {
+                                                           float* __restrict__ preds, float* __restrict__ sums, int64_t pred_bs) {
     __shared__ float red[4];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int64_t total = (int64_t)B * S * A;
@@ -82,9 +82,10 @@ __global__ __launch_bounds__(256) void decode_loss_kernel(const float* __restric
         const float c = x[i * 3 + 0], l = x[i * 3 + 1], o = x[i * 3 + 2];
         const float sc = sigmoidf_(c), so = sigmoidf_(o);
         const int64_t pidx = ((int64_t)b * A + a) * S + s;   // (B, A, S) order of predictions / masks
-        preds[pidx * 3 + 0] = (sc + (float)s) * stride;
-        preds[pidx * 3 + 1] = (anchors[a] * expf(l)) * stride;
-        preds[pidx * 3 + 2] = so;
+        float* pp = preds + (int64_t)b * pred_bs + ((int64_t)a * S + s) * 3;      // (pred_bs: a head's slice of the generator's prediction buffer)
+        pp[0] = (sc + (float)s) * stride;
+        pp[1] = (anchors[a] * expf(l)) * stride;
+        pp[2] = so;
         if (obj) {
             if (obj[pidx]) {
                 const float dx = sc - tx[pidx], dw = l - tw[pidx];
@@ -115,7 +116,7 @@ constexpr int PROP_TS = 32;
 __global__ __launch_bounds__(256) void decode_loss_tiled_kernel(const float* __restrict__ x, const float* __restrict__ anchors, int B, int S, int A,
                                                                  float stride, const uint8_t* __restrict__ obj, const uint8_t* __restrict__ noobj,
                                                                  const float* __restrict__ tx, const float* __restrict__ tw,
-                                                                 float* __restrict__ preds, float* __restrict__ sums) {
+                                                                 float* __restrict__ preds, float* __restrict__ sums, int64_t pred_bs) {
     extern __shared__ float xs[];                 // [PROP_TS][A * 3 + 1]
     __shared__ float red[4];
     const int b = blockIdx.y, s0 = blockIdx.x * PROP_TS, W = A * 3, WP = W + 1;
@@ -131,9 +132,10 @@ __global__ __launch_bounds__(256) void decode_loss_tiled_kernel(const float* __r
         const float c = xs[sl * WP + a * 3 + 0], l = xs[sl * WP + a * 3 + 1], o = xs[sl * WP + a * 3 + 2];
         const float sc = sigmoidf_(c), so = sigmoidf_(o);
         const int64_t pidx = ((int64_t)b * A + a) * S + s;
-        preds[pidx * 3 + 0] = (sc + (float)s) * stride;
-        preds[pidx * 3 + 1] = (anchors[a] * expf(l)) * stride;
-        preds[pidx * 3 + 2] = so;
+        float* pp = preds + (int64_t)b * pred_bs + ((int64_t)a * S + s) * 3;
+        pp[0] = (sc + (float)s) * stride;
+        pp[1] = (anchors[a] * expf(l)) * stride;
+        pp[2] = so;
         if (obj) {
             if (obj[pidx]) {
                 const float dx = sc - tx[pidx], dw = l - tw[pidx];
@@ -256,10 +258,16 @@ extern "C" int bmt_make_targets(const float* targets, int n, const float* anchor
 
 extern "C" int bmt_prop_decode_loss(const float* x, const float* anchors, int B, int S, int A, float stride, const uint8_t* obj,
                                     const uint8_t* noobj, const float* tx, const float* tw, float* preds, float* loss_ws, void* stream) {
-    BMT_CHECK_ARG(x && anchors && preds && B > 0 && S > 0 && A > 0, "bmt_prop_decode_loss: bad args");
+    return bmt_prop_decode_loss2(x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds, (int64_t)A * S * 3, loss_ws, 0, stream);
+}
+
+extern "C" int bmt_prop_decode_loss2(const float* x, const float* anchors, int B, int S, int A, float stride, const uint8_t* obj,
+                                     const uint8_t* noobj, const float* tx, const float* tw, float* preds, int64_t pred_bs, float* loss_ws,
+                                     int ws_zeroed, void* stream) {
+    BMT_CHECK_ARG(x && anchors && preds && B > 0 && S > 0 && A > 0 && pred_bs >= (int64_t)A * S * 3, "bmt_prop_decode_loss: bad args");
     BMT_CHECK_ARG(!obj || (noobj && tx && tw && loss_ws), "bmt_prop_decode_loss: targets given without all of noobj/tx/tw/loss_ws");
     hipStream_t st = (hipStream_t)stream;
-    if (obj && hipMemsetAsync(loss_ws, 0, 8 * sizeof(float), st) != hipSuccess) {
+    if (obj && !ws_zeroed && hipMemsetAsync(loss_ws, 0, 8 * sizeof(float), st) != hipSuccess) {
         bmt_set_error("bmt_prop_decode_loss: memset failed");
         return BMT_EHIP;
     }
@@ -267,10 +275,49 @@ extern "C" int bmt_prop_decode_loss(const float* x, const float* anchors, int B,
     const size_t lds = (size_t)PROP_TS * (A * 3 + 1) * sizeof(float);
     if (tiled && lds <= 60 * 1024 && B <= 65535)
         hipLaunchKernelGGL(decode_loss_tiled_kernel, dim3(bmt_cdiv(S, PROP_TS), B), dim3(256), lds, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds,
-                           loss_ws);
+                           loss_ws, pred_bs);
     else
-        hipLaunchKernelGGL(decode_loss_kernel, dim3(grid_for((int64_t)B * S * A)), dim3(256), 0, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds, loss_ws);
+        hipLaunchKernelGGL(decode_loss_kernel, dim3(grid_for((int64_t)B * S * A)), dim3(256), 0, st, x, anchors, B, S, A, stride, obj, noobj, tx, tw, preds, loss_ws,
+                           pred_bs);
     BMT_CHECK_LAUNCH("bmt_prop_decode_loss");
+    return BMT_OK;
+}
+
+// every head of a generator at once (round 6): head i's sums ws[i][0..5] -> losses[i][0..4] as loss_finalize_kernel does, and the column
+// sums over all heads / the first n_first heads (modality A) / the others into sums[3][5] -- what the generator returns (total loss, the
+// per-modality dictionaries of loss terms) without one finalize launch per head and ~100 scalar adds of the framework's
+__global__ void loss_finalize_multi_kernel(float* __restrict__ ws, int n_heads, int n_first, const float* __restrict__ counts_first,
+                                           const float* __restrict__ counts_second, float obj_coeff, float noobj_coeff,
+                                           float* __restrict__ losses, float* __restrict__ sums) {
+    __shared__ float sl[64][5];
+    const int i = threadIdx.x;
+    float l[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n_heads) {
+        float* w = ws + 8 * i;
+        const float* cn = i < n_first ? counts_first : counts_second;
+        if (cn != nullptr) { w[4] = cn[0]; w[5] = cn[1]; }          // data parallel: LOCAL sums over GLOBAL cell counts (the backward reads them here)
+        l[0] = w[0] / w[4]; l[1] = w[1] / w[4]; l[2] = w[2] / w[4]; l[3] = w[3] / w[5];
+        l[4] = (l[0] + l[1]) + (obj_coeff * l[2] + noobj_coeff * l[3]);
+        for (int c = 0; c < 5; ++c) losses[5 * i + c] = l[c];
+    }
+    if (i < 64) for (int c = 0; c < 5; ++c) sl[i][c] = l[c];
+    __syncthreads();
+    if (i < 5) {            // sums[g][c]: g = 1 the first n_first heads, 2 the rest -- running sums in head order, as the reference's -- and
+        float a = 0.f, b = 0.f;      // g = 0 their sum (total_loss = total_loss_A + total_loss_V, reference :377)
+        for (int h = 0; h < n_first; ++h) a += sl[h][i];
+        for (int h = n_first; h < n_heads; ++h) b += sl[h][i];
+        sums[5 + i] = a;
+        sums[10 + i] = b;
+        sums[i] = a + b;
+    }
+}
+
+extern "C" int bmt_prop_loss_finalize_multi(float* loss_ws, int n_heads, int n_first, const float* counts_first, const float* counts_second,
+                                            float obj_coeff, float noobj_coeff, float* losses, float* sums, void* stream) {
+    BMT_CHECK_ARG(loss_ws && losses && sums && n_heads > 0 && n_heads <= 64 && n_first >= 0 && n_first <= n_heads, "bmt_prop_loss_finalize_multi: bad args");
+    hipLaunchKernelGGL(loss_finalize_multi_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_ws, n_heads, n_first, counts_first, counts_second,
+                       obj_coeff, noobj_coeff, losses, sums);
+    BMT_CHECK_LAUNCH("bmt_prop_loss_finalize_multi");
     return BMT_OK;
 }
 

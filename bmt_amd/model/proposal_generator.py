@@ -237,25 +237,38 @@ class _PropLossFn(torch.autograd.Function):
     """decode + masked MSE/BCE of one head (reference :281-335); returns (predictions, total loss, 4 loss terms)."""
 
     @staticmethod
-    def forward(ctx, x, anchors_dev, stride, tgt, obj_coeff, noobj_coeff, counts=None):
+    def forward(ctx, x, anchors_dev, stride, tgt, obj_coeff, noobj_coeff, counts=None, hb=None):
         xc = _f32c(x)
         B, S, D = xc.shape
         A = anchors_dev.numel()
-        preds = torch.empty(B, A * S, 3, device=x.device, dtype=torch.float32)
+        if hb is not None:
+            # this head's slice of the generator's result and its row of the generator's loss workspace (_HeadBatch): no per-head
+            # allocation / fill / finalize launch; the loss VALUE lands in the row when the generator finalizes all heads at once
+            i = hb.take(A * S)
+            preds = hb.preds[:, hb.offs[i]:hb.offs[i] + A * S]
+            pred_bs = hb.preds.stride(0)
+        else:
+            preds = torch.empty(B, A * S, 3, device=x.device, dtype=torch.float32)
+            pred_bs = A * S * 3
         if tgt is None:
-            _lib.check(lib.bmt_prop_decode_loss(_p(xc), _p(anchors_dev), B, S, A, float(stride), None, None, None, None, _p(preds),
-                                                None, _st()), "bmt_prop_decode_loss")
+            _lib.check(lib.bmt_prop_decode_loss2(_p(xc), _p(anchors_dev), B, S, A, float(stride), None, None, None, None, _p(preds), pred_bs,
+                                                 None, 0, _st()), "bmt_prop_decode_loss")
             ctx.has_t = False
-            return preds, torch.zeros((), device=x.device), torch.zeros(4, device=x.device)
+            z = ops.zero_(torch.empty(5, device=x.device, dtype=torch.float32))
+            return preds, z[4], z[:4]
         obj, noobj, tx, tw = tgt[:4]
-        ws = torch.empty(8, device=x.device, dtype=torch.float32)
-        losses = torch.empty(5, device=x.device, dtype=torch.float32)
-        _lib.check(lib.bmt_prop_decode_loss(_p(xc), _p(anchors_dev), B, S, A, float(stride), _p(obj), _p(noobj), _p(tx), _p(tw),
-                                            _p(preds), _p(ws), _st()), "bmt_prop_decode_loss")
-        if counts is not None:       # data parallel: LOCAL sums over GLOBAL obj / noobj cell counts (the per-rank losses add up
-            ws[4:6].copy_(counts)    # to the full-batch means of reference :316-321)
-        _lib.check(lib.bmt_prop_loss_finalize(_p(ws), float(obj_coeff), float(noobj_coeff), _p(losses), _st()),
-                   "bmt_prop_loss_finalize")
+        if hb is not None:
+            ws, losses = hb.ws[i], hb.losses[i]
+        else:
+            ws = torch.empty(8, device=x.device, dtype=torch.float32)
+            losses = torch.empty(5, device=x.device, dtype=torch.float32)
+        _lib.check(lib.bmt_prop_decode_loss2(_p(xc), _p(anchors_dev), B, S, A, float(stride), _p(obj), _p(noobj), _p(tx), _p(tw),
+                                             _p(preds), pred_bs, _p(ws), int(hb is not None), _st()), "bmt_prop_decode_loss")
+        if hb is None:
+            if counts is not None:       # data parallel: LOCAL sums over GLOBAL obj / noobj cell counts (the per-rank losses add up
+                ws[4:6].copy_(counts)    # to the full-batch means of reference :316-321)
+            _lib.check(lib.bmt_prop_loss_finalize(_p(ws), float(obj_coeff), float(noobj_coeff), _p(losses), _st()),
+                       "bmt_prop_loss_finalize")
         ctx.has_t = True
         ctx.save_for_backward(xc, obj, noobj, tx, tw, ws)
         ctx.coeffs = (float(obj_coeff), float(noobj_coeff), A)
@@ -265,7 +278,7 @@ class _PropLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpreds, dloss, dterms):
         if not ctx.has_t:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         xc, obj, noobj, tx, tw, ws = ctx.saved_tensors
         oc, nc, A = ctx.coeffs
         B, S, _ = xc.shape
@@ -273,14 +286,59 @@ class _PropLossFn(torch.autograd.Function):
         g = _f32c(dloss).reshape(1)
         _lib.check(lib.bmt_prop_loss_bwd(_p(xc), B, S, A, _p(obj), _p(noobj), _p(tx), _p(tw), _p(ws), oc, nc, _p(g), _p(dx), _st()),
                    "bmt_prop_loss_bwd")
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
+
+
+class _HeadBatch:
+    """what the heads of ONE generator forward pass share (round 6): the result buffer (B, sum over heads of A * S, 3) -- every head's
+    decode kernel writes its slice, the reference's three torch.cat (model/proposal_generator.py:380-383) never run --, one zeroed loss
+    workspace [n_heads][8] (one fill instead of a memset per head), the per-head losses [n_heads][5] and the sums [3][5] over all heads /
+    the first modality's / the second's that bmt_prop_loss_finalize_multi leaves (instead of a finalize launch per head and the ~100
+    scalar adds of ``total_loss += loss`` / ``_add_dict``)."""
+
+    def __init__(self, B, sizes, n_first, device, with_loss):
+        self.n, self.n_first, self.next = len(sizes), n_first, 0
+        self.offs = [0]
+        for n_ in sizes:
+            self.offs.append(self.offs[-1] + n_)
+        self.preds = torch.empty(B, self.offs[-1], 3, device=device, dtype=torch.float32)
+        if with_loss:
+            raw = ops.zero_(torch.empty(self.n * 8 + self.n * 5 + 16, device=device, dtype=torch.float32))
+            self.ws = raw[:self.n * 8].view(self.n, 8)
+            self.losses = raw[self.n * 8:self.n * 13].view(self.n, 5)
+            self.sums = raw[self.n * 13:self.n * 13 + 15].view(3, 5)
+        else:
+            self.ws = self.losses = self.sums = None
+
+    def take(self, n_rows):
+        i = self.next
+        if i >= self.n or self.offs[i + 1] - self.offs[i] != n_rows:
+            raise RuntimeError("_HeadBatch: the heads ran in another order / with other sizes than the batch was laid out for")
+        self.next += 1
+        return i
+
+
+class _SumHeadLossesFn(torch.autograd.Function):
+    """total loss = sum of the heads' losses (reference :363-378), as ONE launch that also finalizes every head's loss from its sums
+    (_HeadBatch); backward hands the upstream gradient to every head unchanged (d total / d loss_i = 1)."""
+
+    @staticmethod
+    def forward(ctx, hb, counts_first, counts_second, obj_coeff, noobj_coeff, *head_losses):
+        _lib.check(lib.bmt_prop_loss_finalize_multi(_p(hb.ws), hb.n, hb.n_first, _p(counts_first), _p(counts_second), float(obj_coeff),
+                                                    float(noobj_coeff), _p(hb.losses), _p(hb.sums), _st()), "bmt_prop_loss_finalize_multi")
+        ctx.n = len(head_losses)
+        return hb.sums[0, 4]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, None, None) + (g,) * ctx.n
 
 
 _LOSS_KEYS = ('loss_x', 'loss_w', 'loss_conf_obj', 'loss_conf_noobj')
 _ANCHORS_DEV = {}        # (anchors, stride, device) -> fp32 [A] tensor of anchor / stride
 
 
-def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache, count_reduce=None):
+def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache, count_reduce=None, hb=None):
     """shared body of forward_modality (:272-337) / kernel_size_forward (:123-184).  count_reduce (data parallel): sums the
     {obj, noobj} cell counts of this modality's target assignment over the ranks, once per step (the heads share it)."""
     anchors_num = len(anchors_list)
@@ -309,7 +367,7 @@ def _head_forward(x, targets, detection, stride, anchors_list, cfg, tgt_cache, c
         tgt_cache[key] = (anchors_dev, tgt)
     anchors_dev, tgt = tgt_cache[key]
     preds, loss, terms = _PropLossFn.apply(x, anchors_dev, stride, tgt, cfg.obj_coeff, cfg.noobj_coeff,
-                                           None if tgt is None else tgt[4])
+                                           None if tgt is None else tgt[4], hb)
     if targets is None:
         return preds, 0, {}
     return preds, loss, {k: terms[i] for i, k in enumerate(_LOSS_KEYS)}
@@ -397,9 +455,9 @@ class ProposalGenerator(nn.Module):
         self.mse_loss = nn.MSELoss()
         _tag_heads_by_depth(self, len(self.encoder.enc_layers))
 
-    def kernel_size_forward(self, x, layer, stride, targets, _cache=None):
+    def kernel_size_forward(self, x, layer, stride, targets, _cache=None, _hb=None):
         return _head_forward(x, targets, layer, stride, self.anchors_list, self.cfg, {} if _cache is None else _cache,
-                             getattr(self, "count_reduce", None))
+                             getattr(self, "count_reduce", None), _hb)
 
     def forward(self, x, targets, masks):
         if self.training:
@@ -414,19 +472,21 @@ class ProposalGenerator(nn.Module):
             x = self.pos_enc(self.emb(x['audio']))
             x = self.encoder(x, masks['A_mask'])
 
-        all_predictions = []
-        sum_losses_dict = {}
-        total_loss = 0
         cache = {}
         x._bmt_halo = max(self.cfg.kernel_sizes[self.cfg.modality]) // 2     # the heads share one halo-padded copy (ConvKFn)
+        # the heads write their predictions into ONE result buffer and their loss sums into one workspace (_HeadBatch); the total loss and
+        # the dictionary of loss-term sums come out of one finalizing launch (reference :170-184: cat + running sums)
+        hb = _HeadBatch(x.shape[0], [self.anchors_num * x.shape[1]] * len(self.detection_layers), len(self.detection_layers), x.device,
+                        targets is not None)
+        head_losses = []
         for layer in self.detection_layers:
-            predictions, loss, loss_dict = self.kernel_size_forward(x, layer, stride, targets, cache)
-            total_loss += loss
-            all_predictions.append(predictions)
-            sum_losses_dict = _add_dict(loss_dict, sum_losses_dict)
-
-        all_predictions = torch.cat(all_predictions, dim=1)
-        return all_predictions, total_loss, sum_losses_dict
+            _, loss, _ = self.kernel_size_forward(x, layer, stride, targets, cache, hb)
+            head_losses.append(loss)
+        if targets is None:
+            return hb.preds, 0, {}
+        counts = next(iter(cache.values()))[1][4]
+        total_loss = _SumHeadLossesFn.apply(hb, counts, None, self.cfg.obj_coeff, self.cfg.noobj_coeff, *head_losses)
+        return hb.preds, total_loss, {k: hb.sums[1, i] for i, k in enumerate(_LOSS_KEYS)}
 
 
 class MultimodalProposalGenerator(nn.Module):
@@ -483,9 +543,9 @@ class MultimodalProposalGenerator(nn.Module):
         self.mse_loss = nn.MSELoss()
         _tag_heads_by_depth(self, len(self.encoder.encoder_AV.layers))
 
-    def forward_modality(self, x, targets, detection, stride, anchors_list, _cache=None):
+    def forward_modality(self, x, targets, detection, stride, anchors_list, _cache=None, _hb=None):
         return _head_forward(x, targets, detection, stride, anchors_list, self.cfg, {} if _cache is None else _cache,
-                             getattr(self, "count_reduce", None))
+                             getattr(self, "count_reduce", None), _hb)
 
     def forward(self, x, targets, masks):
         if self.training:
@@ -501,29 +561,24 @@ class MultimodalProposalGenerator(nn.Module):
         Av._bmt_halo = max(self.cfg.kernel_sizes['audio']) // 2
         Va._bmt_halo = max(self.cfg.kernel_sizes['video']) // 2
 
-        all_predictions_A, all_predictions_V = [], []
-        sum_losses_dict_A, sum_losses_dict_V = {}, {}
-        total_loss_A = 0
-        total_loss_V = 0
         cache_A, cache_V = {}, {}   # the 10 heads of a modality share one target assignment (same anchors, stride, grid)
-
+        # every head writes its predictions into its slice of ONE result buffer (audio heads first, then video: the order of the reference's
+        # concatenations :380-383) and its loss sums into one workspace; the total loss and the two dictionaries of loss-term sums come out
+        # of one finalizing launch (_HeadBatch, _SumHeadLossesFn) -- no torch.cat, no per-head fills / finalize launches / scalar adds
+        nA, nV = len(self.detection_layers_A), len(self.detection_layers_V)
+        sizes = [len(self.anchors['audio']) * Av.shape[1]] * nA + [len(self.anchors['video']) * Va.shape[1]] * nV
+        hb = _HeadBatch(Av.shape[0], sizes, nA, Av.device, targets is not None)
+        head_losses = []
         for layer in self.detection_layers_A:
-            props_A, loss_A, losses_A = self.forward_modality(
-                Av, targets, layer, self.cfg.strides['audio'], self.anchors['audio'], cache_A)
-            total_loss_A += loss_A
-            all_predictions_A.append(props_A)
-            sum_losses_dict_A = _add_dict(losses_A, sum_losses_dict_A)
-
+            _, loss_A, _ = self.forward_modality(Av, targets, layer, self.cfg.strides['audio'], self.anchors['audio'], cache_A, hb)
+            head_losses.append(loss_A)
         for layer in self.detection_layers_V:
-            props_V, loss_V, losses_V = self.forward_modality(
-                Va, targets, layer, self.cfg.strides['video'], self.anchors['video'], cache_V)
-            total_loss_V += loss_V
-            all_predictions_V.append(props_V)
-            sum_losses_dict_V = _add_dict(losses_V, sum_losses_dict_V)
-
-        all_predictions_A = torch.cat(all_predictions_A, dim=1)
-        all_predictions_V = torch.cat(all_predictions_V, dim=1)
-        total_loss = total_loss_A + total_loss_V
-        all_predictions = torch.cat([all_predictions_A, all_predictions_V], dim=1)
-
-        return all_predictions, total_loss, sum_losses_dict_A, sum_losses_dict_V
+            _, loss_V, _ = self.forward_modality(Va, targets, layer, self.cfg.strides['video'], self.anchors['video'], cache_V, hb)
+            head_losses.append(loss_V)
+        if targets is None:
+            return hb.preds, 0, {}, {}
+        cnt_A, cnt_V = next(iter(cache_A.values()))[1][4], next(iter(cache_V.values()))[1][4]
+        total_loss = _SumHeadLossesFn.apply(hb, cnt_A, cnt_V, self.cfg.obj_coeff, self.cfg.noobj_coeff, *head_losses)
+        sum_losses_dict_A = {k: hb.sums[1, i] for i, k in enumerate(_LOSS_KEYS)}
+        sum_losses_dict_V = {k: hb.sums[2, i] for i, k in enumerate(_LOSS_KEYS)}
+        return hb.preds, total_loss, sum_losses_dict_A, sum_losses_dict_V

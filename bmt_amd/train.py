@@ -356,7 +356,11 @@ class ProposalTrainStep:
     differs per step, so this step is launched eagerly (no graph capture)."""
 
     def __init__(self, model, cfg, pad_idx: int, optimizer=None, data_parallel: bool = False, bucket_bytes: int = 32 << 20,
-                 overlap: bool = True, seed: Optional[int] = None, keep_seed: bool = False, collective: str = "allreduce"):
+                 overlap: bool = True, seed: Optional[int] = None, keep_seed: bool = False, collective: str = "allreduce",
+                 static_grads: bool = False):
+        """``static_grads`` (implied by ``data_parallel`` and by capture()): every ``p.grad`` is a view into one flat arena that the
+        weight-gradient kernels accumulate into directly -- no per-parameter zero fills, no dW temporaries, no autograd accumulation adds
+        (~250 framework launches per eagerly issued configs[3] step otherwise)."""
         import torch.distributed as dist
         self.model, self.cfg, self.pad_idx = model, cfg, pad_idx
         _seed_dropout(seed, data_parallel, next(model.parameters()).device, keep_if_seeded=keep_seed)
@@ -364,7 +368,7 @@ class ProposalTrainStep:
         self.optimizer = optimizer or FusedAdam(self.params, lr=cfg.lr, betas=tuple(getattr(cfg, "betas", (0.9, 0.999))),
                                                 eps=getattr(cfg, "eps", 1e-8), weight_decay=getattr(cfg, "weight_decay", 0.0))
         self.data_parallel = data_parallel
-        self.reducer = GradientReducer(self.params, bucket_bytes=bucket_bytes, overlap=overlap, collective=collective) if data_parallel else None
+        self.reducer = GradientReducer(self.params, bucket_bytes=bucket_bytes, overlap=overlap, collective=collective) if (data_parallel or static_grads) else None
         self.world = dist.get_world_size() if (data_parallel and dist.is_initialized()) else 1
         self.modality = getattr(cfg, 'modality', 'audio_video')
         # data parallel: the loss means use the global cell counts (sum of the per-rank losses == full-batch loss)

@@ -551,6 +551,18 @@ int bmt_make_targets(const float* targets, int n, const float* anchors, int A, i
 int bmt_prop_decode_loss(const float* x, const float* anchors, int B, int S, int A, float stride,
                          const uint8_t* obj, const uint8_t* noobj, const float* tx, const float* tw,
                          float* preds, float* loss_ws, void* stream);
+/* ABI 9: the same with the predictions written into a SLICE of a larger buffer (batch element b at preds + b * pred_bs: the generator's
+ * (B, sum over heads of A * S, 3) result -- the reference concatenates the heads' predictions, model/proposal_generator.py:380-383) and,
+ * ws_zeroed != 0, into a loss_ws the caller has zeroed already (one fill for all heads). */
+int bmt_prop_decode_loss2(const float* x, const float* anchors, int B, int S, int A, float stride,
+                          const uint8_t* obj, const uint8_t* noobj, const float* tx, const float* tw,
+                          float* preds, int64_t pred_bs, float* loss_ws, int ws_zeroed, void* stream);
+/* ABI 9: bmt_prop_loss_finalize for n_heads heads at once (loss_ws [n_heads][8], losses [n_heads][5]) + the sums over all heads, the first
+ * n_first heads and the others into sums [3][5] (overwritten): the generator's total loss and per-modality loss-term sums
+ * (model/proposal_generator.py:363-378).  counts_first / counts_second (optional, device, 2 floats each): the GLOBAL {obj, noobj} cell counts
+ * of the two modalities under data parallelism, written into loss_ws[i][4..5] before the means are taken. */
+int bmt_prop_loss_finalize_multi(float* loss_ws, int n_heads, int n_first, const float* counts_first, const float* counts_second,
+                                 float obj_coeff, float noobj_coeff, float* losses, float* sums, void* stream);
 /* losses[0..3] = {mse_x, mse_w, bce_obj, bce_noobj} (means), losses[4] = total with coefficients */
 int bmt_prop_loss_finalize(const float* loss_ws, float obj_coeff, float noobj_coeff, float* losses, void* stream);
 /* dx[B,S,A*3] = d total / d x * (*gscale_dev) */
