@@ -56,7 +56,7 @@ class ConvKFn(torch.autograd.Function):
         return pl
 
     @staticmethod
-    def forward(ctx, x, W, b, relu, p, site, policy="head_conv"):
+    def forward(ctx, x, W, b, relu, p, site, policy="head_conv", out_fmt=None):
         xc = _f32c(x)
         if xc is not x and hasattr(x, "_bmt_halo"):
             xc._bmt_halo = x._bmt_halo
@@ -73,13 +73,19 @@ class ConvKFn(torch.autograd.Function):
         adv = lambda t: None if t is None else t[off:]
         A = ops.Planes(adv(X.hi), adv(X.lo), B * S, Din, adv(X.fh))
         y = torch.empty(B * S, Dout, device=x.device, dtype=torch.float32)
-        ops.gemm_bf16(A, Wp, y, ldc=Dout, bias=b, relu=relu, drop_pre=p > 0, drop_p=p, site=site, precision=prec,
+        opl = None
+        if out_fmt is not None and Dout % 64 == 0:      # the next layer's operand planes straight from this product's epilogue (round 6)
+            opl = ops._alloc_planes(B * S, Dout, out_fmt, x.device)
+        ops.gemm_bf16(A, Wp, y, ldc=Dout, bias=b, relu=relu, drop_pre=p > 0, drop_p=p, site=site, precision=prec, out_planes=opl,
                       conv={"mode": 1, "M": B * S, "cin": cin, "rows": X.rows - off, "S": S, "halo": halo})
         ctx.save_for_backward(xc, W, y if (relu or p > 0) else None)
         ctx.relu, ctx.p, ctx.site, ctx.halo = relu, p, site, halo
         ctx.weight, ctx.bias = W, b
         ops.note_use(W, b)
-        return y.view(B, S, Dout)
+        out = y.view(B, S, Dout)
+        if opl is not None:
+            ops.attach_planes(out, opl)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -150,7 +156,7 @@ class ConvKFn(torch.autograd.Function):
         elif gb is not None:
             ops.grad_done(ctx.bias)
             db = None
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, None
 
 
 class ProposalGenerationHead(nn.Module):
@@ -194,17 +200,22 @@ class ProposalGenerationHead(nn.Module):
     def forward(self, x):
         # (B, S, D) in, (B, S, d) out; the reference's two permutes (:41,:45) are folded into the GEMM addressing
         p = self.dout_p if self.training else 0.0
-        for (ln_idx, conv_idx, has_drop, has_relu), site in zip(self._stages, self._sites):
+        n_st = len(self._stages)
+        for si, ((ln_idx, conv_idx, has_drop, has_relu), site) in enumerate(zip(self._stages, self._sites)):
             if ln_idx is not None:
                 x = layer_norm(self.conv_layers[ln_idx], x)
             conv = self.conv_layers[conv_idx]
             pp = p if has_drop else 0.0
+            # the next stage is a 1-tap layer fed directly (no LayerNorm in between): this stage's epilogue writes its operand planes
+            nxt = self._stages[si + 1] if si + 1 < n_st else None
+            out_fmt = ops.act_fmt(ops.policy_of(None).gemm) if (nxt is not None and nxt[0] is None and
+                                                                 self.conv_layers[nxt[1]].kernel_size[0] == 1) else None
             if conv.kernel_size[0] == 1:
-                x = ops.LinearActFn.apply(x, conv.weight[:, :, 0], conv.bias, has_relu, "pre" if has_drop else "none", pp, site)
+                x = ops.LinearActFn.apply(x, conv.weight[:, :, 0], conv.bias, has_relu, "pre" if has_drop else "none", pp, site, out_fmt)
             else:
                 # (operand policy of the k-tap layer: fp16 x split-fp16 under a shallow encoder, split-bf16 -- "head" -- under a deep one,
                 # set by the generator that owns the heads: ops.POLICIES)
-                x = ConvKFn.apply(x, conv.weight, conv.bias, has_relu, pp, site, getattr(self, "bmt_conv_policy", "head_conv"))
+                x = ConvKFn.apply(x, conv.weight, conv.bias, has_relu, pp, site, getattr(self, "bmt_conv_policy", "head_conv"), out_fmt)
         return x
 
 
@@ -238,6 +249,7 @@ class _PropLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchors_dev, stride, tgt, obj_coeff, noobj_coeff, counts=None, hb=None):
+        ctx.set_materialize_grads(False)      # (the predictions and the loss terms take no gradient: no zero tensors made up for them)
         xc = _f32c(x)
         B, S, D = xc.shape
         A = anchors_dev.numel()
@@ -277,7 +289,7 @@ class _PropLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpreds, dloss, dterms):
-        if not ctx.has_t:
+        if not ctx.has_t or dloss is None:
             return None, None, None, None, None, None, None, None
         xc, obj, noobj, tx, tw, ws = ctx.saved_tensors
         oc, nc, A = ctx.coeffs

@@ -1097,13 +1097,29 @@ def linear_dw(dy: Planes, x: Planes, into: Optional[torch.Tensor] = None, params
     return None if into is not None else dW
 
 
+def param_of(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """the PARAMETER behind ``p``: p itself, or -- for a whole-extent contiguous view of a parameter with a static gradient buffer (the
+    [N][K] face ``conv.weight[:, :, 0]`` of a kernel-size-1 Conv1d weight [N][K][1]: the proposal heads' second and third layers) -- that
+    parameter.  Without this a view has no static buffer: its dW came back as a tensor and autograd's select backward turned it into
+    a zero fill + a strided copy + an accumulation add per layer and step (120 framework launches per configs[3] step, round 6)."""
+    if p is None or getattr(p, "_bmt_static_grad", False):
+        return p
+    b = getattr(p, "_base", None)
+    if b is not None and getattr(b, "_bmt_static_grad", False) and p.numel() == b.numel() and p.is_contiguous() and b.is_contiguous() \
+            and p.data_ptr() == b.data_ptr():
+        return b
+    return p
+
+
 def static_grad(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """the persistent gradient buffer of a parameter, if bmt_amd.parallel.GradientReducer bound one (``p.grad`` is then a
     view into a flat bucket that is zeroed once per step): weight / bias gradients are accumulated straight into it by
-    the GEMM epilogue / column-sum atomics -- no dW temporary, no zero-fill, no ``grad += dW`` pass."""
-    if p is None or not getattr(p, "_bmt_static_grad", False) or p.grad is None or not p.grad.is_contiguous():
+    the GEMM epilogue / column-sum atomics -- no dW temporary, no zero-fill, no ``grad += dW`` pass.  For a whole-extent view of such a
+    parameter (param_of): the buffer in the view's shape."""
+    q = param_of(p)
+    if q is None or not getattr(q, "_bmt_static_grad", False) or q.grad is None or not q.grad.is_contiguous():
         return None
-    return p.grad
+    return q.grad if q is p else q.grad.view(p.shape)
 
 
 def note_use(*params):
@@ -1111,6 +1127,7 @@ def note_use(*params):
     buffer takes part in this step's graph, so that ``grad_done`` reports it to the reducer only after the LAST of its
     backward contributions (a parameter shared by two modules must not have its bucket all-reduced after the first)."""
     for p in params:   # (counts are reset by GradientReducer.zero_grad, so forwards outside a training step are harmless)
+        p = param_of(p)
         if p is not None and getattr(p, "_bmt_static_grad", False):
             p._bmt_uses = getattr(p, "_bmt_uses", 0) + 1
 
@@ -1118,6 +1135,7 @@ def note_use(*params):
 def grad_done(p: Optional[torch.Tensor]):
     """one backward contribution to p has been accumulated into its static buffer; when it was the last one, tell the
     reducer that p's gradient is final (replaces autograd's post-accumulate hook for fused accumulation)"""
+    p = param_of(p)
     cb = getattr(p, "_bmt_on_grad", None) if p is not None else None
     if cb is None:
         return
@@ -1136,7 +1154,7 @@ def wgrad(W, b, dyP: Planes, xP: Planes, dy2_for_bias=None, bias_sum=None):
     """weight and bias gradient of a Linear: returns (dW, db) tensors for autograd, or (None, None) after accumulating into
     the parameters' static buffers.  bias_sum: an already computed column sum (from grad_planes) or None."""
     gW = static_grad(W)
-    dW = linear_dw(dyP, xP, into=gW, params=(W,))
+    dW = linear_dw(dyP, xP, into=gW, params=(param_of(W),))
     if gW is not None:
         grad_done(W)
     db = None
@@ -1829,22 +1847,39 @@ class LinearActFn(torch.autograd.Function):
     after (FFN hidden, blocks.py:168-171) the ReLU, fused in the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu, drop_mode, p, site):
+    def forward(ctx, x, W, b, relu, drop_mode, p, site, out_fmt=None):
+        """out_fmt (round 6): also write the result's operand planes in the epilogue and attach them to it -- the next Linear of a chain (the
+        proposal heads' 1-tap layers) finds them instead of converting the fp32 result in a pass of its own; and the input's bf16 plane,
+        not its fp32 values, is what the backward keeps for the weight gradient (no second conversion pass there either)."""
         note_use(W, b)
         xc = _f32c(x)
         K = xc.shape[-1]
         x2 = xc.view(-1, K)
-        y = linear_fwd(x2, W, b, precision=policy_of(None).gemm, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"),
-                       drop_p=p, site=site)
+        prec = policy_of(None).gemm
+        xp = planes_of(x, act_fmt(prec))
+        if xp is None or xp.rows != x2.shape[0] or xp.pack is not None:
+            xp = make_planes(x2, act_fmt(prec))
+        epi = {}
+        opl = None
+        if out_fmt is not None and W.shape[0] % 64 == 0:
+            opl = _alloc_planes(x2.shape[0], W.shape[0], out_fmt, x2.device)
+            epi["out_planes"] = opl
+        y = linear_fwd(xp, W, b, precision=prec, relu=relu, drop_pre=(drop_mode == "pre"), drop_post=(drop_mode == "post"),
+                       drop_p=p, site=site, **epi)
         ctx.relu, ctx.drop_mode, ctx.p, ctx.site = relu, drop_mode, p, site
         ctx.has_bias = b is not None
         ctx.params = (W, b)
-        ctx.save_for_backward(x2, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
-        return y.view(*xc.shape[:-1], W.shape[0])
+        ctx.xdims = (x2.shape[0], K)
+        ctx.save_for_backward(xp.hi, W, y if (relu or (p > 0 and drop_mode != "none")) else None)
+        out = y.view(*xc.shape[:-1], W.shape[0])
+        if opl is not None:
+            attach_planes(out, opl)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W, y = ctx.saved_tensors
+        xh, W, y = ctx.saved_tensors
+        x2 = Planes(xh, None, ctx.xdims[0], ctx.xdims[1])
         N = W.shape[0]
         dy2 = _f32c(dy).view(-1, N)
         p = ctx.p if ctx.drop_mode != "none" else 0.0
@@ -1863,7 +1898,7 @@ class LinearActFn(torch.autograd.Function):
                 dW, _ = wgrad(Wp, None, P, bwd_planes(x2))
             if dx is not None:
                 dx = dx.view(*dy.shape[:-1], W.shape[1])
-            return dx, dW, (None if gb is not None else cs), None, None, None, None
+            return dx, dW, (None if gb is not None else cs), None, None, None, None, None
         if p > 0:
             dz = dropout_raw(dy2, p, ctx.site)
         else:
@@ -1873,7 +1908,7 @@ class LinearActFn(torch.autograd.Function):
                              need_dw=ctx.needs_input_grad[1])
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], W.shape[1])
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, None
 
 
 class FFNFn(torch.autograd.Function):

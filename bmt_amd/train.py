@@ -444,7 +444,9 @@ class ProposalTrainStep:
         from . import ops as _ops
         _ops.allow_encoder_streams(self.reducer is None or self.reducer.world == 1 or not self.reducer.overlap)
         predictions, loss, losses_A, losses_V = model(feature_stacks, targets, masks)
-        loss.backward()
+        if not hasattr(self, "_one") or self._one.device != loss.device:
+            self._one = torch.ones((), device=loss.device, dtype=torch.float32)
+        loss.backward(gradient=self._one if loss.dim() == 0 and loss.dtype == torch.float32 else None)      # (no fill kernel for the root gradient)
         _ops.join_side_stream()
         if self.reducer is not None:
             self.reducer.finish()
