@@ -833,6 +833,8 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="train_cap: distinct pre-staged synthetic batches the timed region rotates through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="train_cap, captured: copy each batch into the static input buffers in front of its own replay "
+                    "instead of beside the previous step's optimizer graph")
     ap.add_argument("--timer-steps", type=int, default=7, help="eagerly issued steps of the per-kernel HIP-event pass (>= 5)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 2 s of back-to-back steps under rocm-smi after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying hipGraphs")
@@ -973,7 +975,9 @@ def main():
             if captured != best:          # the winner's graphs were replaced by a later capture: capture it again
                 step.capture(*inputs, warmup=1, collectives=(best_mode == "hipgraph+captured-allreduce"))
             run = lambda: step.replay()
-            run_with = lambda inp: step.replay(*inp)       # (copies the batch into the graphs' static input buffers, then replays)
+            # (the batch is copied into the graphs' static input buffers; the NEXT step's batch is announced with the call, so that its copy runs
+            # beside this step's optimizer graph: CaptioningTrainStep.replay)
+            run_with = lambda inp, nxt=None: step.replay(*inp, next_batch=nxt)
             mode = best_mode
         if mode == "eager" and world > 1:
             mode = "eager+overlap"
@@ -989,6 +993,7 @@ def main():
             note(f"train_prop: graph capture failed ({type(exc).__name__}: {exc}); eager launches")
             torch.cuda.synchronize()
     rot = desc.get("batches") or [inputs]          # train_cap: NB pre-staged batches, handed to the step in turn
+    prefetch = cap and mode.startswith("hipgraph") and len(rot) > 1 and not args.no_prefetch
     for i in range(args.warmup):
         res = run_with(rot[i % len(rot)])
     sync()
@@ -997,7 +1002,10 @@ def main():
         step.reduce_timing(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        res = run_with(rot[i % len(rot)])
+        if prefetch:       # (the last step announces a batch too: every timed step carries one input copy, as without the prefetch)
+            res = run_with(rot[i % len(rot)], rot[(i + 1) % len(rot)])
+        else:
+            res = run_with(rot[i % len(rot)])
     sync()
     dt = time.perf_counter() - t0
     if desc.get("units_each"):                     # the units the timed steps processed: each step's own batch
@@ -1073,7 +1081,9 @@ def main():
             out["executed_tflops"] = fx_mean / (ms_per_step * 1e-3) / 1e12
             out["frac_executed"] = out["executed_tflops"] / (MFMA_BF16_DENSE_PEAK_TFLOPS * world)
             out["timed_region"] = (f"{args.steps} steps over {nb_rot} pre-staged batches in rotation, each handed to the step as device tensors "
-                                   "(captured mode: copied into the graphs' static input buffers, ~80 MB, inside the timed region); the loss stays on the "
+                                   "(captured mode: copied into the graphs' static input buffers, ~80 MB per step, inside the timed region"
+                                   + ("; each step announces the next step's batch, whose copy runs on a copy stream beside that step's optimizer "
+                                      "graph -- a data loader's prefetch" if prefetch else "") + "); the loss stays on the "
                                    "device and is read once after the last step (the reference reads loss.item() every step: "
                                    "epoch_loops/captioning_epoch_loops.py:143)")
         if clock is not None:

@@ -110,6 +110,7 @@ SIGNATURES = {
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
     "bmt_gemm_bf16_grouped_tables": (i32, [vp, i32, vp, C.c_size_t, C.POINTER(i32), vp]),
     "bmt_gemm_bf16_grouped_run": (i32, [vp, i32, C.POINTER(i32), vp]),
+    "bmt_gemm_bf16_grouped_image": (i32, [vp, i32, vp, C.c_size_t, C.POINTER(i32)]),
     "bmt_planes_dropout": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, i64, vp, f32, vp, u32, vp, vp]),
     "bmt_layernorm_fwd_planes": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp, vp]),
     "bmt_layernorm_bwd_add": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp, vp]),
@@ -169,6 +170,7 @@ SIGNATURES = {
     "bmt_conv_weight_planes": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp]),
     "bmt_conv_weight_grad": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
     "bmt_zero": (i32, [vp, i64, vp]),
+    "bmt_copy_h2d_async": (i32, [vp, vp, i64, vp]),
     "bmt_cat2": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, vp]),
     "bmt_split2": (i32, [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp]),
     "bmt_caption_shift": (i32, [vp, i64, i32, i32, i64, vp, vp, vp, vp]),
@@ -204,8 +206,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 9:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 9")
+    if lib.bmt_version() != 10:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 10")
     _lib = lib
     return lib
 

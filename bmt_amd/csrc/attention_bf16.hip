@@ -1179,6 +1179,9 @@ __device__ __forceinline__ void lgkm_wait(u32x4& a) { asm volatile("s_waitcnt lg
 template <int N>
 __device__ __forceinline__ void lgkm_wait(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 
+#ifndef BMT_FWD32_XP          // build-variant timing probes (BMT_VARIANT_FLAGS, csrc/build.sh)
+#define BMT_FWD32_XP 0
+#endif
 // DMAV: where the next tile's 2 PPW DMA requests are issued (an experiment axis): 0 = one per MFMA on the first MFMAs of S, 1 = one per
 // two MFMAs of S, 2 = all before S, 3 = K pieces one per four MFMAs of S + V pieces one per two MFMAs at the start of PV.
 // PRIO: raise the wave's priority around its MFMA phases.
@@ -1220,16 +1223,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         vvo[j] = row * (int)p.ldv * 2 + ((cpos ^ (4 * (row & 3))) * 16);
     }
     const int sstep_k = BC * (int)p.ldk * 2, sstep_v = BC * (int)p.ldv * 2;
-#define BMT_X_DMA_K(j_, t_, buf_) \
+#define BMT_X_DMA_K_(j_, t_, buf_) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(smem + (buf_) * STAGE + (wid * PPW + (j_)) * 1024), 16, kvo[j_], (t_) * sstep_k, 0, 0)
-#define BMT_X_DMA_V(j_, t_, buf_) \
+#define BMT_X_DMA_V_(j_, t_, buf_) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(smem + (buf_) * STAGE + TILE + (wid * PPW + (j_)) * 1024), 16, vvo[j_], (t_) * sstep_v, 0, 0)
+    // (timing probes, build variants only: BMT_FWD32_XP bit 0 = the loop moves no tile -- every stage computes on what the prologue staged;
+    // bit 1 = the loop computes nothing -- tiles move, barriers stay)
+#define BMT_X_DMA_K(j_, t_, buf_) do { if constexpr (!(BMT_FWD32_XP & 1)) BMT_X_DMA_K_(j_, t_, buf_); } while (0)
+#define BMT_X_DMA_V(j_, t_, buf_) do { if constexpr (!(BMT_FWD32_XP & 1)) BMT_X_DMA_V_(j_, t_, buf_); } while (0)
 
     // stage 0 in flight first, then the Q fragments and the mask row
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) BMT_X_DMA_K(j, 0, 0);
+    for (int j = 0; j < PPW; ++j) BMT_X_DMA_K_(j, 0, 0);
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) BMT_X_DMA_V(j, 0, 0);
+    for (int j = 0; j < PPW; ++j) BMT_X_DMA_V_(j, 0, 0);
+    if constexpr (BMT_FWD32_XP & 1) {      // (both buffers hold data: the stages alternate between them)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) BMT_X_DMA_K_(j, 0, 1);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) BMT_X_DMA_V_(j, 0, 1);
+    }
     bf16x8 qf[KS];
     {
         const int64_t qo = (int64_t)b * p.bsq + (int64_t)min(q, p.Sq - 1) * p.ldq + h * DK + 8 * hh;
@@ -1269,7 +1282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < 4; ++i) mw[i] = *reinterpret_cast<const uint32_t*>(sMask + key0 + 8 * i + 4 * hh);
         const bool none_valid = __all((mw[0] | mw[1] | mw[2] | mw[3]) == 0u);
         const bool all_valid = __all((mw[0] & mw[1] & mw[2] & mw[3]) == 0x01010101u);
-        if (none_valid || !wave_on) {                     // nothing to compute: only move the next tile
+        if (none_valid || !wave_on || (BMT_FWD32_XP & 2)) {                     // nothing to compute: only move the next tile
 #pragma unroll
             for (int j = 0; j < PPW; ++j) BMT_X_DMA_K(j, tn, cur ^ 1);
 #pragma unroll
@@ -1373,6 +1386,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef BMT_X_DMA_K
 #undef BMT_X_DMA_V
+#undef BMT_X_DMA_K_
+#undef BMT_X_DMA_V_
 
     // ---- epilogue.  Lane (l31, hh) holds O^T[d = 32 dt + 8 i + 4 hh + j][q] in register 4 i + j: the two lanes of a query own alternate
     // 4-column groups.  For the 16-bit planes one v_permlane32_swap per dword regroups a PAIR of groups (i = 2 ip, 2 ip + 1) so that the

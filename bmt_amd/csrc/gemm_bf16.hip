@@ -2211,12 +2211,21 @@ extern "C" size_t bmt_gemm_bf16_grouped_ws_bytes(int nprob) {
 // beside the forward pass instead of in front of the grouped launch on the critical path (profiles/r05_zz_replay_dispatches.csv: ~100 us of
 // tiny kernels before the weight-gradient launch, ~50 us before each memory-gradient launch).  launch[0] = grid slots, launch[1] = 1 when an
 // output is a packed row range: what bmt_gemm_bf16_grouped_run needs besides the workspace.
-static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, hipStream_t st);
+static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, hipStream_t st, void* host_image);
 static int grouped_run(void* ws, int nprob, const int* launch, hipStream_t st);
 
 extern "C" int bmt_gemm_bf16_grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, void* stream) {
     BMT_CHECK_ARG(launch != nullptr, "bmt_gemm_bf16_grouped_tables: launch is NULL");
-    return grouped_tables(args, nprob, ws, ws_bytes, launch, (hipStream_t)stream);
+    return grouped_tables(args, nprob, ws, ws_bytes, launch, (hipStream_t)stream, nullptr);
+}
+// ABI 10 -- the SAME bytes _tables leaves in ws (descriptor table | per-XCD segment lists | segment counts), written into HOST memory
+// instead: no launch, no device access.  For a caller that moves them itself -- a captured step copies them into a table buffer of its own
+// ONCE, at capture time, on a stream that is not capturing (the addresses a captured launch works on never change: profiles/r06_o_*: the
+// ~11 table-writer launches per grouped launch, wherever their graph branch forks from, execute where they were captured -- in front of the
+// product), and replays _run alone.
+extern "C" int bmt_gemm_bf16_grouped_image(const bmt_gemm_bf16_args* args, int nprob, void* host_image, size_t bytes, int* launch) {
+    BMT_CHECK_ARG(launch != nullptr && host_image != nullptr, "bmt_gemm_bf16_grouped_image: NULL argument");
+    return grouped_tables(args, nprob, host_image, bytes, launch, nullptr, host_image);
 }
 extern "C" int bmt_gemm_bf16_grouped_run(void* ws, int nprob, const int* launch, void* stream) {
     BMT_CHECK_ARG(ws && launch && nprob > 0 && launch[0] > 0, "bmt_gemm_bf16_grouped_run: bad arguments");
@@ -2224,11 +2233,11 @@ extern "C" int bmt_gemm_bf16_grouped_run(void* ws, int nprob, const int* launch,
 }
 extern "C" int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, void* stream) {
     int launch[2] = {0, 0};
-    const int rc = grouped_tables(args, nprob, ws, ws_bytes, launch, (hipStream_t)stream);
+    const int rc = grouped_tables(args, nprob, ws, ws_bytes, launch, (hipStream_t)stream, nullptr);
     return rc != BMT_OK ? rc : grouped_run(ws, nprob, launch, (hipStream_t)stream);
 }
 
-static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, hipStream_t st) {
+static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, hipStream_t st, void* host_image) {
     BMT_CHECK_ARG(args && ws && nprob > 0 && nprob <= 4096, "bmt_gemm_bf16_grouped: bad arguments");
     BMT_CHECK_ARG(ws_bytes >= bmt_gemm_bf16_grouped_ws_bytes(nprob) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                   "bmt_gemm_bf16_grouped: workspace too small or not 16-byte aligned");
@@ -2306,6 +2315,22 @@ static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, s
     char* tail = reinterpret_cast<char*>(ws) + (((size_t)nprob * sizeof(GemmB) + 15) & ~(size_t)15);
     XcdSeg* segs = reinterpret_cast<XcdSeg*>(tail);
     int* nseg = reinterpret_cast<int*>(tail + 8 * XCD_MAXSEG * sizeof(XcdSeg));
+    int max_slots = 0;
+    for (int x = 0; x < 8; ++x) max_slots = slots[x] > max_slots ? slots[x] : max_slots;
+    if (host_image != nullptr) {         // (ws IS the host image: table, segs and nseg point into it)
+        memset(host_image, 0, bmt_gemm_bf16_grouped_ws_bytes(nprob));
+        for (int i = 0; i < nprob; ++i) table[i] = pr[i].p;
+        for (int x = 0; x < 8; ++x) {
+            for (int i = 0; i < ns[x]; ++i) segs[x * XCD_MAXSEG + i] = sp[x / 2].s[x & 1][i];
+            nseg[x] = ns[x];
+        }
+        free(pr);
+        free(order);
+        free(sp);
+        launch[0] = max_slots;
+        launch[1] = placed ? 1 : 0;
+        return BMT_OK;
+    }
     GemmPack pk;
     for (int base = 0; base < nprob; base += GEMM_PACK_N) {
         pk.n = nprob - base < GEMM_PACK_N ? nprob - base : GEMM_PACK_N;
@@ -2313,8 +2338,6 @@ static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, s
         for (int i = 0; i < pk.n; ++i) pk.d[i] = pr[base + i].p;
         hipLaunchKernelGGL(gemm_table_write_kernel, dim3(pk.n), dim3(64), 0, st, pk, table);
     }
-    int max_slots = 0;
-    for (int x = 0; x < 8; ++x) max_slots = slots[x] > max_slots ? slots[x] : max_slots;
     for (int q = 0; q < 4; ++q) {
         sp[q].n[0] = ns[2 * q]; sp[q].n[1] = ns[2 * q + 1]; sp[q].xcd0 = 2 * q;
         hipLaunchKernelGGL(gemm_segs_write_kernel, dim3(2), dim3(64), 0, st, sp[q], segs, nseg);

@@ -202,6 +202,18 @@ extern "C" int bmt_zero(void* p, int64_t nbytes, void* stream) {
     return BMT_OK;
 }
 
+// ABI 10: host (pinned) -> device bytes on `stream` (hipMemcpyAsync): what carries a grouped launch's table image (bmt_gemm_bf16_grouped_image)
+// to the device -- on a stream of the caller's choice, e.g. one that is NOT part of an ongoing capture
+extern "C" int bmt_copy_h2d_async(void* dst, const void* src_host, int64_t nbytes, void* stream) {
+    BMT_CHECK_ARG(dst && src_host && nbytes > 0, "bmt_copy_h2d_async: bad arguments");
+    const hipError_t e = hipMemcpyAsync(dst, src_host, (size_t)nbytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        bmt_set_error("bmt_copy_h2d_async: %s", hipGetErrorString(e));
+        return BMT_EHIP;
+    }
+    return BMT_OK;
+}
+
 extern "C" int bmt_caption_shift(const int64_t* caption_idx, int64_t ld, int B, int T1, int64_t pad_idx, int64_t* x, int64_t* y,
                                  int64_t* n_tokens, void* stream) {
     BMT_CHECK_ARG(caption_idx && x && y && n_tokens && B > 0 && T1 > 1 && ld >= T1, "bmt_caption_shift: bad args");

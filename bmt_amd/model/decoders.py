@@ -113,6 +113,8 @@ class BiModelDecoder(nn.Module):
     def forward(self, x, masks):
         C0, (Av, Va) = x
         layers = self.decoder.layers
+        if Av.is_cuda:
+            ops.run_deferred_beside()       # (the gradient arena's zero fill of a train step: beside this launch-bound phase)
         if Av.is_cuda and len(layers) > 0 and isinstance(layers[0], BiModalDecoderLayer):
             # the layers' cross-attentions against the raw memories (29 queries per sample: the key / value projections reassociated onto
             # the queries, ops.RawCrossAttnFn) where the memories are packed; otherwise the memories come back as they are

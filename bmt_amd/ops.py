@@ -154,7 +154,7 @@ class StepContext:
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
     __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
-                 "step_start")
+                 "step_start", "planes_ready", "planes_waited", "deferred", "deferred_join")
 
     def __init__(self):
         self.defer_dw = False        # queue the weight-gradient products of this backward pass for grouped launches (flush_dw)
@@ -169,6 +169,10 @@ class StepContext:
         self.last_gen = None         # GenHandle of the GeneratorFn.forward that just ran (picked up by model.generators.Generator)
         self.gen_handles = []        # handles whose loss took the fused backward: flush_dw settles their parameters' use counts
         self.step_start = None       # event at the beginning of the pass in flight (mark_step_start): what the table stream of a grouped launch waits for
+        self.planes_ready = None     # event behind the weight-plane refresh that mark_step_start issued on the refresh stream (EARLY_REFRESH), or None
+        self.planes_waited = set()   # handles of the streams that wait for it already
+        self.deferred = None         # a launch of this pass that only has to happen before its backward (defer_beside): the gradient arena's zero fill
+        self.deferred_join = None    # the stream it was issued on (join_deferred waits for it)
 
 
 _contexts = {}
@@ -727,6 +731,7 @@ def weights_registry_signature():
 
 def weight_planes(W: torch.Tensor, fmt: str = "x3") -> Planes:
     with _weights.lock:
+        _await_planes()
         return _weights.get(W, fmt)
 
 
@@ -738,6 +743,7 @@ SMALL_DX_OUTPUTS = int(lib.bmt_gemm_small_outputs())      # dX products of at mo
 
 def weight_planes_t(W: torch.Tensor) -> Planes:
     with _weights.lock:
+        _await_planes()
         return _weights.get_t(W)
 
 
@@ -745,6 +751,7 @@ def weight_group_t(Ws, lo=False, bs=None):
     if not FUSE_PROJECTIONS:
         return None
     with _weights.lock:
+        _await_planes()
         return _weights.get_group_t(tuple(Ws), lo=lo, bs=bs)
 
 
@@ -752,6 +759,7 @@ def weight_group(Ws, bs, fmt: str = "x3"):
     if not FUSE_PROJECTIONS:
         return None
     with _weights.lock:
+        _await_planes()
         return _weights.get_group(tuple(Ws), tuple(bs), fmt)
 
 
@@ -938,45 +946,97 @@ GROUPED_DW = True        # the queued weight-gradient products of a pass as one 
 _dw_ws = {}
 
 
-EARLY_TABLES = True       # the descriptor tables of a grouped launch are written on a stream forked from the step's beginning (mark_step_start)
-_table_streams = {}       # (device, main stream handle) -> the stream the table writers of its grouped launches run on
-
-
 def mark_step_start():
-    """call at the beginning of a train step (before zero_grad): records the event the table writers of the step's grouped launches wait
-    for INSTEAD of the work in front of the launch.  A grouped launch's ~25 descriptor-table writers (a few microseconds each, launch-bound)
-    depend on nothing but buffer addresses; issued behind the backward pass they sat on the step's critical path (~100 us in front of the
-    weight-gradient launch, ~50 us in front of each memory-gradient launch: profiles/r05_zz_replay_dispatches.csv).  Forked from this event
-    they are, inside a captured step, a branch of the graph that starts with the replay and runs beside the forward pass."""
+    """call at the beginning of a train step (before zero_grad): records the event that work which depends on nothing but the step's
+    beginning is forked from -- the refresh of the weights' operand planes (EARLY_REFRESH)."""
     c = context()
     ev = torch.cuda.Event()
     ev.record()
     c.step_start = ev
+    c.planes_ready, c.planes_waited = None, set()
+    if EARLY_REFRESH:
+        _early_refresh(c, ev)
 
 
 def clear_step_start():
-    context().step_start = None
+    c = context()
+    c.step_start = None
+    c.planes_ready, c.planes_waited = None, set()
 
 
-_table_ws = {}            # device index -> {"turn": int, "bufs": [16 byte tensors]}: descriptor-table buffers of the EARLY path
+EARLY_REFRESH = True      # the once-per-step refresh of the weights' operand planes runs on its own stream from the step's beginning
+_refresh_streams = {}     # device index -> that stream (created outside captures: the eager warm-up steps reach mark_step_start first)
 
 
-def _early_table_ws(dev, need):
-    """a table buffer that may be written at the BEGINNING of a step although it is asked for at its end.  Under a hipGraph capture an
-    allocation made where the launch is issued comes from the graph's private pool and may be the memory of a forward-pass temporary that
-    was freed earlier in the capture -- written at the replay's start it would be overwritten by that temporary (first GPU run of this
-    path: garbage descriptors, a memory fault).  These buffers are therefore allocated OUTSIDE any capture (the eager warm-up steps that
-    precede one reach this function first), once per device, and rotate; None while capturing without them."""
-    d = torch.device(dev)
-    idx = d.index if d.index is not None else torch.cuda.current_device()
-    pool = _table_ws.get(idx)
-    size = max(int(need), 256 << 10)
-    if pool is None or pool["bufs"][0].numel() < size:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        pool = _table_ws[idx] = {"turn": 0, "bufs": [torch.empty(size, dtype=torch.uint8, device=d) for _ in range(16)]}
-    pool["turn"] = (pool["turn"] + 1) % len(pool["bufs"])
-    return pool["bufs"][pool["turn"]]
+def _early_refresh(c, ev):
+    """The refresh (planes_multi_flat_kernel: ~110 us, 202 MB of fp32 weights in, ~300 MB of planes out) used to run where the pass first
+    forked a side stream -- alone on the chip, with the pass's own launch-bound prologue (row packs, feature preparation, the first
+    LayerNorms: ~90 us of 6 us kernels that read no weight) queued behind it (profiles/r06_n_replay_dispatches.csv, t = 31 ... 143 us).
+    Issued here on a stream that waits for nothing but the step's beginning it runs BESIDE that prologue; a stream waits for it where it
+    first asks for a weight's planes (_await_planes, from every accessor of the registry).  Only with a built table (the first eager step
+    registers weights as it meets them and refreshes in line, as before)."""
+    w = _weights
+    with w.lock:
+        if not w.entries or w.dirty_table or w.fresh_epoch == WEIGHT_EPOCH[0]:
+            return
+        dev = torch.cuda.current_device()
+        rs = _refresh_streams.get(dev)
+        if rs is None:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            rs = _refresh_streams[dev] = torch.cuda.Stream(device=dev)
+        rs.wait_event(ev)
+        with torch.cuda.stream(rs):
+            w._refresh_all()
+        ready = torch.cuda.Event()
+        ready.record(rs)
+        c.planes_ready = ready
+
+
+def _await_planes():
+    """the current stream behind the early refresh of this pass, once (called with the registry's lock held, before planes are handed out)"""
+    c = context()
+    ev = c.planes_ready
+    if ev is None:
+        return
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream in c.planes_waited:
+        return
+    cur.wait_event(ev)
+    c.planes_waited.add(cur.cuda_stream)
+
+
+CONST_TABLES = True       # a CAPTURED grouped launch reads descriptor tables that were written once, when it was captured
+_const_tables = {}        # device index -> {"free": [(device table, pinned image)], "stream": copy stream, "owned": {owner token: [pairs]}}
+_CONST_TABLE_BYTES = 256 << 10
+_CONST_TABLE_PAIRS = 12
+
+
+def _const_tables_prepare(idx: int, need: int):
+    """(eager launches reach this before any capture does -- the warm-up steps of capture()) table buffers a captured grouped launch can
+    OWN: device memory from outside every graph's private pool (inside a capture an allocation may be the memory of a temporary the capture
+    freed earlier, and a table written before the replay starts would be overwritten by it), a pinned image to fill, a stream to copy on."""
+    pool = _const_tables.get(idx)
+    if pool is None:
+        pool = _const_tables[idx] = {"free": [], "stream": torch.cuda.Stream(device=idx), "owned": {}}
+    size = max(int(need), _CONST_TABLE_BYTES)
+    pool["free"] = [pr for pr in pool["free"] if pr[0].numel() >= size]
+    n_owned = sum(len(v) for v in pool["owned"].values())
+    while len(pool["free"]) < _CONST_TABLE_PAIRS and len(pool["free"]) + n_owned < 8 * _CONST_TABLE_PAIRS:
+        pool["free"].append((torch.empty(size, dtype=torch.uint8, device=torch.device("cuda", idx)),
+                             torch.empty(size, dtype=torch.uint8, pin_memory=True)))
+
+
+def release_const_tables(owner):
+    """the table buffers of the launches captured under scratch_owner(owner) go back to the pool (its graphs are gone)"""
+    for pool in _const_tables.values():
+        pool["free"].extend(pool["owned"].pop(owner, []))
+
+
+def finish_capture():
+    """call after a capture, before the first replay: the table images of its grouped launches have arrived"""
+    for pool in _const_tables.values():
+        pool["stream"].synchronize()
 
 
 def gemm_bf16_grouped(items):
@@ -1001,35 +1061,90 @@ def gemm_bf16_grouped(items):
     need = int(lib.bmt_gemm_bf16_grouped_ws_bytes(n))
     # the descriptor tables live in device memory until the launch has executed; several grouped launches of one backward pass
     # (flush points) are in flight together, so the scratch buffers rotate (allocated in the eager warm-up steps, before a capture)
-    sk = (dev, torch.cuda.current_stream().cuda_stream)
-    slot = _dw_ws.setdefault(sk + ("turn",), [0])
-    slot[0] = (slot[0] + 1) % 8
-    ws = _dw_ws.get(sk + (slot[0],))
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)
-        _dw_ws[sk + (slot[0],)] = ws
-    ev = context().step_start if EARLY_TABLES else None
-    tws = _early_table_ws(dev, need) if ev is not None else None
-    if tws is None:
+    def in_line():       # tables written by kernels in front of the product, into a rotating scratch buffer of the stream
+        sk = (dev, torch.cuda.current_stream().cuda_stream)
+        slot = _dw_ws.setdefault(sk + ("turn",), [0])
+        slot[0] = (slot[0] + 1) % 8
+        ws = _dw_ws.get(sk + (slot[0],))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 64 << 10), dtype=torch.uint8, device=dev)
+            _dw_ws[sk + (slot[0],)] = ws
         _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
-        return
-    # tables on the table stream, ordered behind the step's beginning only (and behind this stream's earlier grouped launches: stream order);
-    # the product on the current stream, behind the tables
-    ws = tws
-    cur = torch.cuda.current_stream()
-    ts = _table_streams.get(sk)
-    if ts is None:
-        if torch.cuda.is_current_stream_capturing():       # (no stream creation inside a capture: the eager warm-up steps made it)
-            _lib.check(lib.bmt_gemm_bf16_grouped(arr, n, _p(ws), ws.numel(), _st()), "bmt_gemm_bf16_grouped")
-            return
-        ts = _table_streams[sk] = torch.cuda.Stream(device=dev)
-    ts.wait_event(ev)
-    ws.record_stream(ts)
+
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if not torch.cuda.is_current_stream_capturing():
+        if CONST_TABLES:
+            _const_tables_prepare(idx, need)
+        return in_line()
+    # captured: the ~11 table-writer launches (descriptors in their kernel arguments, a few microseconds each) would execute in front of the
+    # product at every replay -- ~55 us before the weight-gradient launch, ~45 us before each memory-gradient launch
+    # (profiles/r06_n_replay_dispatches.csv; forked onto another stream they still ran where they were captured,
+    # profiles/r06_o_replay_dispatches.csv) -- for tables that are the same at every replay: a captured launch's buffers never move.  So the
+    # image is built on the host NOW, copied into a table this launch owns on a stream that is NOT capturing, and the graph holds the
+    # product alone (finish_capture() waits for the copies).
+    pool = _const_tables.get(idx) if CONST_TABLES else None
+    pair = None
+    if pool is not None and pool["free"] and pool["free"][-1][0].numel() >= need:
+        pair = pool["free"].pop()
+        pool["owned"].setdefault(_SCRATCH_OWNER[0] if _SCRATCH_OWNER[0] is not None else "captured", []).append(pair)
+    if pair is None:
+        return in_line()
+    dtab, himg = pair
     launch = (C.c_int * 2)()
-    with torch.cuda.stream(ts):
-        _lib.check(lib.bmt_gemm_bf16_grouped_tables(arr, n, _p(ws), ws.numel(), launch, C.c_void_p(ts.cuda_stream)), "bmt_gemm_bf16_grouped_tables")
-    cur.wait_stream(ts)
-    _lib.check(lib.bmt_gemm_bf16_grouped_run(_p(ws), n, launch, _st()), "bmt_gemm_bf16_grouped_run")
+    _lib.check(lib.bmt_gemm_bf16_grouped_image(arr, n, C.c_void_p(himg.data_ptr()), himg.numel(), launch), "bmt_gemm_bf16_grouped_image")
+    _lib.check(lib.bmt_copy_h2d_async(_p(dtab), C.c_void_p(himg.data_ptr()), need, C.c_void_p(pool["stream"].cuda_stream)), "bmt_copy_h2d_async")
+    _lib.check(lib.bmt_gemm_bf16_grouped_run(_p(dtab), n, launch, _st()), "bmt_gemm_bf16_grouped_run")
+
+
+DEFER_ZERO = True         # the gradient arena's zero fill beside the decoder's forward instead of at the head of the step
+
+
+def defer_beside(fn):
+    """``fn()`` issues work of this pass that nothing needs before the backward pass starts (the zero fill of the gradient arena: 202 MB,
+    60-100 us of HBM writes at the head of a step, in front of everything -- profiles/r06_p_replay_dispatches.csv).  It runs where the
+    pass calls run_deferred_beside() -- the decoder's entry: ~0.6 ms of launch-bound small kernels that leave the chip's bandwidth idle --
+    on the auxiliary stream, or in line at join_deferred() if the model never got there."""
+    context().deferred = fn
+
+
+def run_deferred_beside():
+    c = context()
+    fn, c.deferred = c.deferred, None
+    if fn is None:
+        return
+    aux = _aux_stream()
+    if aux is None:
+        fn()
+        return
+    aux.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(aux):
+        fn()
+    c.deferred_join = aux
+
+
+def join_deferred():
+    """before the backward pass: the deferred launch has been issued, and the current stream is behind it"""
+    c = context()
+    fn, c.deferred = c.deferred, None
+    if fn is not None:
+        fn()
+    aux, c.deferred_join = c.deferred_join, None
+    if aux is not None:
+        torch.cuda.current_stream().wait_stream(aux)
+
+
+COLSUM_BESIDE_DW = True
+_aux_streams = {}         # device index -> a stream for small launches that run beside a large one of the same pass (created outside captures)
+
+
+def _aux_stream():
+    dev = torch.cuda.current_device()
+    s = _aux_streams.get(dev)
+    if s is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        s = _aux_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def flush_dw():
@@ -1039,6 +1154,15 @@ def flush_dw():
     done, ctx.pending_done = ctx.pending_done, []
     ctx.pending_ids.clear()
     cs, ctx.pending_cs = ctx.pending_cs, []
+    # the queued column sums (LayerNorm / bias partials -> their gradients) touch nothing the weight-gradient products touch: beside the grouped
+    # launch on the auxiliary stream instead of alone behind it (45 us with one kernel in flight, profiles/r06_n_replay_dispatches.csv)
+    aux = _aux_stream() if (cs and len(items) > 1 and GROUPED_DW and COLSUM_BESIDE_DW) else None
+    if aux is not None:
+        cur = torch.cuda.current_stream()
+        aux.wait_stream(cur)
+        with torch.cuda.stream(aux):
+            _colsum_launch(cs)
+        cs = []
     if items:
         if len(items) == 1 or not GROUPED_DW:
             for dyT, xT, into in items:
@@ -1046,6 +1170,8 @@ def flush_dw():
                           a_km=True, b_km=True)
         else:
             gemm_bf16_grouped(items)
+    if aux is not None:
+        cur.wait_stream(aux)
     if cs:
         _colsum_launch(cs)
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them

@@ -179,12 +179,18 @@ class GradientReducer:
         else:                           # gloo (the CPU tests): asynchronous works may overtake each other -- gather once the scatter is done
             self._second.append((h, b))
 
-    def zero_grad(self):
-        """in-place zero of the flat buffers (one fill over the arena they are slices of); keeps p.grad bound to its bucket view"""
+    def zero_grad(self, defer: bool = False):
+        """in-place zero of the flat buffers (one fill over the arena they are slices of); keeps p.grad bound to its bucket view.  ``defer``:
+        the fill is handed to the pass (ops.defer_beside) and issued beside its forward instead of in front of it -- the caller joins it
+        before the backward pass (ops.join_deferred)."""
         if self._arena is not None:
             if self._arena.is_cuda:      # one library launch (bmt_zero) over the whole arena
                 from . import ops as _ops
-                _ops.zero_(self._arena)
+                if defer:
+                    arena = self._arena
+                    _ops.defer_beside(lambda: _ops.zero_(arena))
+                else:
+                    _ops.zero_(self._arena)
             else:
                 self._arena.zero_()
         for b in self.buckets:

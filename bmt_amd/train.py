@@ -139,7 +139,7 @@ class CaptioningTrainStep:
         from . import ops as _ops
         _ops.mark_step_start()          # (the table writers of this pass's grouped launches fork from here)
         if self.reducer is not None:
-            self.reducer.zero_grad()
+            self.reducer.zero_grad(defer=_ops.DEFER_ZERO)      # (issued beside the decoder's forward, joined before backward() below)
         else:
             self.optimizer.zero_grad()
         x, y, n_tokens = _ops.caption_shift(caption_idx, self.pad_idx)
@@ -156,6 +156,7 @@ class CaptioningTrainStep:
         # the products run where autograd reaches them, so that a bucket is final when its last hook fires
         sctx.defer_dw = self.reducer is not None and (self.reducer.world == 1 or not self.reducer.overlap or self._flush_points > 0)
         try:
+            _ops.join_deferred()
             kl.backward(gradient=self._one if self._one.device == kl.device and kl.dim() == 0 else None)      # (no fill kernel for the root gradient)
             _ops.join_side_stream()
             _ops.flush_dw()
@@ -235,6 +236,7 @@ class CaptioningTrainStep:
         torch.cuda.synchronize()                # the eager all-reduce has finished before the second capture starts
         with _ops.scratch_owner(id(self)), torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             self._optimize()
+        _ops.finish_capture()                   # (the table images of the captured grouped launches are on the device)
         self._graphs = (g1, g2)
         self._graph_generation = _ops.weights_generation()
         return self._graphs
@@ -263,8 +265,8 @@ class CaptioningTrainStep:
             self._static_loss, _ = self._reduce(kl, ntok)
             self._static_ntok = ntok
             self._optimize()
+        _ops.finish_capture()
         self._graphs = (g,)
-        from . import ops as _ops
         self._graph_generation = _ops.weights_generation()
         return self._graphs
 
@@ -275,14 +277,33 @@ class CaptioningTrainStep:
         if had:          # the per-stream scratch the graphs were captured over goes with them
             from . import ops as _ops
             _ops.release_scratch(owner=id(self))
+            _ops.release_const_tables(id(self))
         if self.reducer is not None:
             self.reducer.overlap = self._overlap
 
-    def replay(self, feature_stacks=None, caption_idx=None):
+    def _stage(self, feature_stacks, caption_idx):
+        for k, v in feature_stacks.items():
+            self._static_fs[k].copy_(v, non_blocking=True)
+        self._static_caps.copy_(caption_idx, non_blocking=True)
+
+    def replay(self, feature_stacks=None, caption_idx=None, next_batch=None):
+        """one captured step over the given batch (None: the batch the static buffers hold).  ``next_batch`` = (feature_stacks, caption_idx) of
+        the step AFTER this one, complete when this call is made: it is copied into the static input buffers as soon as this step's
+        forward / backward graph -- their last reader -- has run, on a copy stream, i.e. beside this step's gradient reduction and optimizer
+        graph instead of in front of the next replay (~80 MB in four copies, 55 us at configs[1]: profiles/r06_p_replay_dispatches.csv);
+        the next call finds its batch staged (same tensor objects) and only waits for that copy.  The prefetch a data loader does."""
+        cur = torch.cuda.current_stream()
+        staged, self._staged = getattr(self, "_staged", None), None
         if feature_stacks is not None:
-            for k, v in feature_stacks.items():
-                self._static_fs[k].copy_(v, non_blocking=True)
-            self._static_caps.copy_(caption_idx, non_blocking=True)
+            if (staged is not None and staged[1] is caption_idx and len(staged[0]) == len(feature_stacks) and
+                    all(staged[0].get(k) is v for k, v in feature_stacks.items())):
+                cur.wait_event(staged[2])
+            else:
+                if staged is not None:          # (another batch than the one announced: its copy must not land on top of this one)
+                    cur.wait_event(staged[2])
+                self._stage(feature_stacks, caption_idx)
+        elif staged is not None:
+            cur.wait_event(staged[2])
         from . import ops as _ops
         if _ops.weights_generation() != self._graph_generation:
             raise RuntimeError("the weight-plane registry changed after capture() (a weight's operand planes were re-allocated, or a model was "
@@ -293,6 +314,18 @@ class CaptioningTrainStep:
             return self._static_loss, self._static_ntok
         g1, g2 = self._graphs
         g1.replay()
+        if next_batch is not None and len(self._graphs) == 2:
+            if getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream()
+            cs = self._copy_stream
+            cs.wait_stream(cur)                 # behind the forward / backward graph (and whatever produced the next batch before this call)
+            with torch.cuda.stream(cs):
+                self._stage(*next_batch)
+                done = torch.cuda.Event()
+                done.record(cs)
+            for t in list(next_batch[0].values()) + [next_batch[1]]:
+                t.record_stream(cs)
+            self._staged = (dict(next_batch[0]), next_batch[1], done)
         ev = self._reduce_events
         if ev is not None:
             s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -415,6 +448,7 @@ class ProposalTrainStep:
         from . import ops as _ops
         with _ops.scratch_owner(id(self)), torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_out = self(self._static_fs, self._static_tg)
+        _ops.finish_capture()
         self._graph = g
         self._graph_generation = _ops.weights_generation()
         return g
@@ -436,18 +470,22 @@ class ProposalTrainStep:
     def __call__(self, feature_stacks, targets):
         model = self.model
         model.train()
-        if self.reducer is not None:
-            self.reducer.zero_grad()
-        else:
-            self.optimizer.zero_grad()
-        masks = make_masks(feature_stacks, None, self.modality, self.pad_idx)
         from . import ops as _ops
-        _ops.allow_encoder_streams(self.reducer is None or self.reducer.world == 1 or not self.reducer.overlap)
-        predictions, loss, losses_A, losses_V = model(feature_stacks, targets, masks)
-        if not hasattr(self, "_one") or self._one.device != loss.device:
-            self._one = torch.ones((), device=loss.device, dtype=torch.float32)
-        loss.backward(gradient=self._one if loss.dim() == 0 and loss.dtype == torch.float32 else None)      # (no fill kernel for the root gradient)
-        _ops.join_side_stream()
+        _ops.mark_step_start()          # (the weight-plane refresh and the table writers of grouped launches fork from here)
+        try:
+            if self.reducer is not None:
+                self.reducer.zero_grad()
+            else:
+                self.optimizer.zero_grad()
+            masks = make_masks(feature_stacks, None, self.modality, self.pad_idx)
+            _ops.allow_encoder_streams(self.reducer is None or self.reducer.world == 1 or not self.reducer.overlap)
+            predictions, loss, losses_A, losses_V = model(feature_stacks, targets, masks)
+            if not hasattr(self, "_one") or self._one.device != loss.device:
+                self._one = torch.ones((), device=loss.device, dtype=torch.float32)
+            loss.backward(gradient=self._one if loss.dim() == 0 and loss.dtype == torch.float32 else None)      # (no fill kernel for the root gradient)
+            _ops.join_side_stream()
+        finally:
+            _ops.clear_step_start()
         if self.reducer is not None:
             self.reducer.finish()
         if getattr(self.cfg, "grad_clip", None) is not None:

@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 9
+#define BMT_ABI_VERSION 10
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -144,6 +144,12 @@ int bmt_gemm_bf16_grouped(const bmt_gemm_bf16_args* args, int nprob, void* ws, s
  * stream.  The caller orders the two (an event between the streams) and keeps ws untouched until the product has executed. */
 int bmt_gemm_bf16_grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, size_t ws_bytes, int* launch, void* stream);
 int bmt_gemm_bf16_grouped_run(void* ws, int nprob, const int* launch, void* stream);
+/* ABI 10 -- the bytes _tables leaves in ws (descriptor table | per-XCD segment lists | counts), written into HOST memory of
+ * bmt_gemm_bf16_grouped_ws_bytes(nprob) bytes instead: no launch, no device access.  A captured step copies them into a device table of its
+ * own once, at capture time, on a stream that is not capturing (bmt_copy_h2d_async) -- the addresses its launch works on never change --
+ * and its graph holds _run alone: the ~11 table-writer launches of _tables execute where they were captured, in front of the product
+ * (profiles/r06_o_replay_dispatches.csv), wherever their branch of the graph forks from. */
+int bmt_gemm_bf16_grouped_image(const bmt_gemm_bf16_args* args, int nprob, void* host_image, size_t bytes, int* launch);
 
 /* ABI 8 -- MANY small products of one shape in one launch on the 32 x 32 tile kernel (row-major operands; BMT_PREC_BF16, BMT_PREC_F16 or
  * BMT_PREC_BF16X3; epilogue: alpha, bias, dropout, relu, column sums; no residual / gate / accumulate).  `args` describes ONE product
@@ -510,6 +516,8 @@ int bmt_gen_lskl_bwd(const float* logp, int64_t ldp, const int64_t* target, cons
  * (epoch_loops/captioning_epoch_loops.py:128-135), as library launches instead of framework fills / copies / reductions */
 /* p[0 .. nbytes) = 0 (p 16-byte aligned): optimizer.zero_grad() over the flat gradient arena in one launch */
 int bmt_zero(void* p, int64_t nbytes, void* stream);
+/* ABI 10: nbytes from (pinned) host memory to the device on `stream` (hipMemcpyAsync) */
+int bmt_copy_h2d_async(void* dst, const void* src_host, int64_t nbytes, void* stream);
 /* x = caption_idx[:, :-1], y = caption_idx[:, 1:] as contiguous int64 [B][T1 - 1] and n_tokens[0] = (y != pad_idx).sum(); caption_idx [B][T1]
  * with row stride ld */
 int bmt_caption_shift(const int64_t* caption_idx, int64_t ld, int B, int T1, int64_t pad_idx, int64_t* x, int64_t* y, int64_t* n_tokens,

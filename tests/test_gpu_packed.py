@@ -391,3 +391,30 @@ def test_captured_step_on_packed_rows_follows_the_batch(ops):
     for a, b in zip(losses["eager"][:1], losses["graph"][:1]):        # (first step: identical weights; later ones differ by Adam's state of the warm-up)
         assert abs(a - b) < 2e-3, (losses)
     assert all(math.isfinite(x) for x in losses["graph"])
+
+
+def test_captured_step_prefetches_the_announced_batch(ops):
+    """CaptioningTrainStep.replay(..., next_batch=): the next step's batch is copied into the static input buffers beside this step's optimizer
+    graph; the losses are those of replays that copy their own batch, also when the batch that arrives is NOT the one that was announced"""
+    from bmt_amd.train import CaptioningTrainStep
+    cfg = syn.make_cfg(d_model=512, H=4, N=1, d_aud=128, d_vid=256, d_model_caps=64, dout_p=0.0, lr=1e-4)
+    V, B, Tv, Ta, Tc = 60, 4, 90, 210, 11
+    batches = [syn.make_cap_batch(cfg, B, Tv, Ta, Tc, V, seed=s) for s in (5, 6, 7, 8)]
+    devb = [({k: v.to(DEV) for k, v in b["feature_stacks"].items()}, b["captions"].to(DEV)) for b in batches]
+    losses = {}
+    for mode in ("plain", "prefetch", "wrong announcement"):
+        model = _build(cfg, V)
+        step = CaptioningTrainStep(model, cfg, syn.PAD_IDX, static_grads=True, seed=3)
+        step.capture(*devb[0])
+        out = []
+        for i, b in enumerate(devb):
+            nxt = devb[(i + 1) % len(devb)] if mode == "prefetch" else (devb[(i + 2) % len(devb)] if mode != "plain" else None)
+            loss, _ = step.replay(*b, next_batch=nxt)
+            out.append(float(loss))
+        torch.cuda.synchronize()
+        losses[mode] = out
+        step.uncapture()
+    print("\nlosses:", losses)
+    for mode in ("prefetch", "wrong announcement"):
+        for a, b in zip(losses["plain"], losses[mode]):
+            assert abs(a - b) < 1e-4 * max(1.0, abs(a)), losses

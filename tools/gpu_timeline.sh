@@ -12,7 +12,14 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "rng_advance" in r["Kernel_Name"]]
-last = rows[idx[-1]:] if idx else rows
+# the last replay = everything that starts after the previous step's Adam has finished (branches of the captured step that fork from its
+# beginning -- the weight-plane refresh, descriptor tables -- may start before its first kernel on the main stream does)
+ad = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] and idx and i < idx[-1]]
+if idx and ad:
+    cut = int(rows[ad[-1]]["End_Timestamp"])
+    last = [r for r in rows[ad[-1] + 1:] if int(r["Start_Timestamp"]) >= cut]
+else:
+    last = rows[idx[-1]:] if idx else rows
 t0 = int(last[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in last)
 ev = []
 for r in last:

@@ -23,12 +23,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--order", default="random", choices=("random", "desc", "asc", "equal"),
+                    help="the samples' lengths as drawn, sorted (longest / shortest sample first), or all equal to their rms (same executed FLOPs)")
+    ap.add_argument("--forms", default="recompute,emit,two-kernel")
     args = ap.parse_args()
     B, H, dk = args.B, 4, 256
     D = H * dk
     g = torch.Generator().manual_seed(7)
     Lv = torch.randint(128, 257, (B,), generator=g)
     Lv[0] = 256
+    if args.order == "desc":
+        Lv = torch.sort(Lv, descending=True).values
+    elif args.order == "asc":
+        Lv = torch.sort(Lv).values
+    elif args.order == "equal":
+        Lv = torch.full_like(Lv, int(round(float((Lv.double() ** 2).mean().sqrt()))))
     La = torch.round(Lv.float() * 800 / 256).long()
     shapes = [("A-self", 800, 800, La, La), ("V-self", 256, 256, Lv, Lv), ("A<-V", 800, 256, La, Lv), ("V<-A", 256, 800, Lv, La)]
     for name, Sq, Sk, Lq, Lk in shapes:
@@ -45,7 +54,7 @@ def main():
         dop = ops.Planes(dop.hi[:, :D].contiguous(), None, B * Sq, D)
         flops = float((Lq.double() * Lk.double()).sum()) * D * 2
         res = {}
-        for form in ("recompute", "emit", "two-kernel"):
+        for form in args.forms.split(","):
             ops.ATTN_BWD_SPLIT = form != "two-kernel"
             ops.ATTN_BWD_RECOMPUTE = form == "recompute"
             for _ in range(3):
@@ -65,11 +74,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         tf = e0.elapsed_time(e1) / args.reps * 1e3
-        ref = res["emit"][1]
-        diffs = " ".join(f"{n} {float((a - b).norm() / (b.norm() + 1e-30)):.2e}" for n, a, b in zip(("dq", "dk", "dv"), res["recompute"][1], ref))
-        print(f"{name:7s} {Sq}x{Sk}: fwd {tf:7.1f} us ({2 * flops / tf * 1e-6:6.1f} TF/s)  bwd recompute {res['recompute'][0]:7.1f} us "
-              f"({5 * flops / res['recompute'][0] * 1e-6:6.1f} TF/s on 5 products)  emit {res['emit'][0]:7.1f}  two-kernel {res['two-kernel'][0]:7.1f}"
-              f"   recompute vs emit: {diffs}", flush=True)
+        if set(res) >= {"recompute", "emit", "two-kernel"}:
+            ref = res["emit"][1]
+            diffs = " ".join(f"{n} {float((a - b).norm() / (b.norm() + 1e-30)):.2e}" for n, a, b in zip(("dq", "dk", "dv"), res["recompute"][1], ref))
+            print(f"{name:7s} {Sq}x{Sk}: fwd {tf:7.1f} us ({2 * flops / tf * 1e-6:6.1f} TF/s)  bwd recompute {res['recompute'][0]:7.1f} us "
+                  f"({5 * flops / res['recompute'][0] * 1e-6:6.1f} TF/s on 5 products)  emit {res['emit'][0]:7.1f}  two-kernel {res['two-kernel'][0]:7.1f}"
+                  f"   recompute vs emit: {diffs}", flush=True)
+        else:
+            print(f"{name:7s} {Sq}x{Sk} order={args.order}: fwd {tf:7.1f} us ({2 * flops / tf * 1e-6:6.1f} TF/s)  " +
+                  "  ".join(f"bwd {f} {res[f][0]:7.1f} us ({5 * flops / res[f][0] * 1e-6:6.1f} TF/s)" for f in res), flush=True)
 
 
 if __name__ == "__main__":
