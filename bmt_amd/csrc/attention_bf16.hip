@@ -184,9 +184,13 @@ struct AttnPB {
     // PADDED extents the launch was sized for: they map workgroups to (batch, head, tile) and index what stays per padded position
     // (lse, delta, the split backward's workspaces, the per-tile bias partials); attn_rebase turns Sq / Sk into this sample's lengths.
     const int *q_off, *k_off;
+    const int* b_order;                        // (ABI 10) work items are numbered with sample b_order[i] in place of sample i (attn_sample)
     int SqP, SkP;
     int64_t drop_off;                          // element index of this sample's first output row in the dropout mask's index space (attn_rebase)
 };
+
+// the sample a work item's sample-major index stands for: the launch's own numbering, or the caller's balanced order (bmt_pack_rows_ordered)
+__device__ __forceinline__ int attn_sample(const AttnPB& p, int i) { return p.b_order != nullptr ? p.b_order[i] : i; }
 
 // packed rows: make `p` describe sample b alone -- base pointers at its first row, batch strides 0, Sq / Sk = its lengths.  A no-op for
 // padded callers (q_off == k_off == nullptr: SqP == Sq, SkP == Sk as the host set them).
@@ -960,8 +964,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int g = lane >> 4, c = lane & 15;
     const int nqt = (p.Sq + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
-    const int qt = w % nqt, bh = w / nqt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int qt = w % nqt, bhw = w / nqt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (qt * 128 >= p.Sq) return;            // (a query tile past the sample's length)
     const int q = qt * 128 + wid * 16 + c;
@@ -1199,8 +1203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hh = lane >> 5, l31 = lane & 31;
     const int nqt = (p.Sq + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
-    const int qt = w % nqt, bh = w / nqt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int qt = w % nqt, bhw = w / nqt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (qt * 128 >= p.Sq) return;            // (a query tile past the sample's length)
     const int q = qt * 128 + wid * 32 + l31;
@@ -1821,8 +1825,8 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& pin, const int
     const int g = lane >> 4, c = lane & 15;
     const int nqt = (p.Sq + 127) / 128;
     const int w = xcd_remap(bid, nqt * p.B * p.H);
-    const int qt = w % nqt, bh = w / nqt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int qt = w % nqt, bhw = w / nqt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (qt * 128 >= p.Sq) {                  // a query tile past the sample's length: a zero row of bias partials, nothing else
         if (p.gq.bpart != nullptr)
@@ -2019,8 +2023,8 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& pin, const int
     const int g = lane >> 4, c = lane & 15;
     const int nkt = (p.Sk + KBLK - 1) / KBLK;
     const int w = xcd_remap(bid, nkt * p.B * p.H);
-    const int kt = w % nkt, bh = w / nkt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int kt = w % nkt, bhw = w / nkt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (kt * KBLK >= p.Sk) {                 // a key block past the sample's length: zero rows of bias partials, nothing else
         for (int d = tid; d < DK; d += NT) {
@@ -2362,8 +2366,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nqt = (p.Sq + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nqt * p.B * p.H);
     // work order: (batch, head)-major, so that the query tiles of a (batch, head) run together and share its K / V in their XCD's L2
-    const int qt = w % nqt, bh = w / nqt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int qt = w % nqt, bhw = w / nqt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (qt * 128 >= p.Sq) {                  // a query tile past the sample's length: no live query, a zero row of bias partials, nothing else
         if (p.qlive != nullptr && tid == 0) p.qlive[(int64_t)bh * nqt + qt] = 0;
@@ -2815,8 +2819,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nkt = (p.Sk + 127) / 128, nqt = (p.SqP + 127) / 128, nstP = (p.SqP + BQ - 1) / BQ;
     const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
     // work order: (batch, head)-major -- the key blocks of a (batch, head) run together and share its q / dO rows in their XCD's L2
-    const int kt = w % nkt, bh = w / nkt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int kt = w % nkt, bhw = w / nkt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (kt * 128 >= p.Sk) {                  // a key block past the sample's length: zero rows of bias partials, nothing else
         for (int d = tid; d < DK; d += NT) {
@@ -3089,8 +3093,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hh = lane >> 5, l31 = lane & 31;
     const int nkt = (p.Sk + 127) / 128;
     const int w = xcd_remap(blockIdx.x, nkt * p.B * p.H);
-    const int kt = w % nkt, bh = w / nkt;
-    const int b = bh / p.H, h = bh % p.H;
+    const int kt = w % nkt, bhw = w / nkt;
+    const int h = bhw % p.H, b = attn_sample(p, bhw / p.H), bh = b * p.H + h;
     attn_rebase(p, b);                       // packed rows: this sample's rows and lengths
     if (kt * 128 >= p.Sk) {                  // a key block past the sample's length: zero rows of bias partials, nothing else
         for (int d = tid; d < DK; d += 512) {
@@ -3404,7 +3408,7 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
-    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off;
+    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off; p.b_order = a->b_order;
     BMT_CHECK_ARG(!(a->q_off || a->k_off) || (a->dk >= 128 && a->precision != BMT_PREC_BF16X3 && (!a->k_off || !a->mask) && (a->mask == nullptr || a->mask_qs == 0) &&
                                               (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) && (int64_t)a->Sk * a->ldv * 2 < (1ll << 31)),
                   "bmt_attn_fwd_bf16: packed rows (q_off / k_off) are taken by the one-pass d_k >= 128 kernels, without a mask over packed keys");
@@ -3441,7 +3445,7 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
-    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off;
+    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off; p.b_order = a->b_order;
     BMT_CHECK_ARG(!(a->q_off || a->k_off) || (a->dk >= 128 && (!a->k_off || !a->mask) && (a->mask == nullptr || a->mask_qs == 0) && !a->dQT && !a->dKT && !a->dVT &&
                                               !a->O && !a->dO && (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) && (int64_t)a->Sk * a->ldv * 2 < (1ll << 31) &&
                                               (int64_t)a->Sq * a->ldq * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31)),

@@ -57,12 +57,34 @@ __global__ __launch_bounds__(256) void pack_count_kernel(const uint8_t* __restri
     if (threadIdx.x == 0) off[B + 1 + b] = red[0] + red[1] + red[2] + red[3];
 }
 // place: off[b] = valid positions of the samples before b (off[B] = their total), row_map[off[b] + i] = b * S + t of the i-th valid position
+// order (optional, int32 [B]; block 0 writes it): the samples in the order the attention kernels walk them (bmt_attn_*_args.b_order) -- a
+// kernel's (batch, head, tile) work items are numbered sample-major and XCD x runs the x-th eighth of them (xcd_remap), i.e. B / 8 whole
+// samples whose lengths are whatever the batch put there: at configs[1] (32 samples, lengths ~ U[T / 2, T], cost ~ length^2) the busiest XCD
+// carries 1.2 - 1.4x the mean (profiles/r06_s_attn_order.txt: audio self-attention backward 399 us as drawn, 350 dealt out, 346 with equal
+// lengths).  Here the samples are ranked by length and dealt to the eight XCD ranges in serpentine order (rank r: round r / 8, range r % 8
+// forward in even rounds, backward in odd ones), each range longest first.
 __global__ __launch_bounds__(256) void pack_place_kernel(const uint8_t* __restrict__ mask, int64_t mask_bs, int B, int S, int* __restrict__ off,
-                                                          int* __restrict__ row_map) {
+                                                          int* __restrict__ row_map, int* __restrict__ order) {
     __shared__ int red[4];
     __shared__ int wcnt[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int* cnt = off + B + 1;
+    if (order != nullptr && b == 0 && (int)threadIdx.x < B) {
+        const int j = threadIdx.x, cj = cnt[j];
+        int rank = 0;
+        for (int i = 0; i < B; ++i) {
+            const int ci = cnt[i];
+            rank += (ci > cj || (ci == cj && i < j)) ? 1 : 0;
+        }
+        const int rounds = B >> 3, rem = B & 7;                 // full rounds; samples of the last, partial round
+        const int round = rank >> 3, pos = rank & 7, g = (round & 1) ? 7 - pos : pos;
+        int base = 0;
+        for (int gg = 0; gg < g; ++gg) {                         // range gg holds one sample per full round + one of the partial round's, if it got one
+            const int pp = (rounds & 1) ? 7 - gg : gg;           // (the position that maps to range gg in the partial round)
+            base += rounds + (pp < rem ? 1 : 0);
+        }
+        order[base + round] = j;
+    }
     int c = 0;
     for (int i = threadIdx.x; i < b; i += 256) c += cnt[i];
 #pragma unroll
@@ -218,12 +240,16 @@ extern "C" int bmt_prep_features(const float* a, const float* b2, const float* p
     return BMT_OK;
 }
 
-extern "C" int bmt_pack_rows(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, void* stream) {
+extern "C" int bmt_pack_rows_ordered(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, int* order, void* stream) {
     BMT_CHECK_ARG(mask && off && row_map && B > 0 && S > 0 && mask_bs >= S && (int64_t)B * S < (1ll << 31), "bmt_pack_rows: bad args");
+    BMT_CHECK_ARG(order == nullptr || B <= 256, "bmt_pack_rows_ordered: the balanced sample order is built for at most 256 samples");
     hipLaunchKernelGGL(pack_count_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, mask_bs, B, S, off);
-    hipLaunchKernelGGL(pack_place_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, mask_bs, B, S, off, row_map);
+    hipLaunchKernelGGL(pack_place_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, mask_bs, B, S, off, row_map, order);
     BMT_CHECK_LAUNCH("bmt_pack_rows");
     return BMT_OK;
+}
+extern "C" int bmt_pack_rows(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, void* stream) {
+    return bmt_pack_rows_ordered(mask, mask_bs, B, S, off, row_map, nullptr, stream);
 }
 
 extern "C" int bmt_prep_features_packed(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D, float drop_p,

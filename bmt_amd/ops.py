@@ -358,11 +358,12 @@ PACK_ROWS = _os.environ.get("BMT_PACK_ROWS", "1") != "0"      # A/B switch: "0" 
 
 class RowPack:
     """layout of the valid rows of one modality's batch: ``off`` int32 [2 B + 2] (off[b] = first packed row of sample b, off[B] = number of
-    valid rows; the rest is scratch), ``row_map`` int32 [B S] (packed row -> b S + t)"""
-    __slots__ = ("off", "row_map", "B", "S")
+    valid rows; the rest is scratch), ``row_map`` int32 [B S] (packed row -> b S + t), ``order`` int32 [B] or None (the samples in the
+    length-balanced order the attention kernels walk them: bmt_pack_rows_ordered)"""
+    __slots__ = ("off", "row_map", "B", "S", "order")
 
-    def __init__(self, off, row_map, B, S):
-        self.off, self.row_map, self.B, self.S = off, row_map, B, S
+    def __init__(self, off, row_map, B, S, order=None):
+        self.off, self.row_map, self.B, self.S, self.order = off, row_map, B, S, order
 
     @property
     def cap(self) -> int:
@@ -379,6 +380,8 @@ class RowPack:
     def record_stream(self, stream):
         self.off.record_stream(stream)
         self.row_map.record_stream(stream)
+        if self.order is not None:
+            self.order.record_stream(stream)
 
 
 def pack_rows(mask: torch.Tensor) -> RowPack:
@@ -391,8 +394,21 @@ def pack_rows(mask: torch.Tensor) -> RowPack:
     B, S = m.shape
     off = torch.empty(2 * B + 2, device=m.device, dtype=torch.int32)
     row_map = torch.empty(B * S, device=m.device, dtype=torch.int32)
-    _lib.check(lib.bmt_pack_rows(_p(m), m.stride(0), B, S, _p(off), _p(row_map), _st()), "bmt_pack_rows")
-    return RowPack(off, row_map, B, S)
+    order = torch.empty(B, device=m.device, dtype=torch.int32) if (BALANCED_ORDER and 8 < B <= 256) else None
+    _lib.check(lib.bmt_pack_rows_ordered(_p(m), m.stride(0), B, S, _p(off), _p(row_map), _p(order), _st()), "bmt_pack_rows_ordered")
+    return RowPack(off, row_map, B, S, order)
+
+
+BALANCED_ORDER = True     # the attention kernels walk the samples of a packed batch in the length-balanced order of its query-side row pack
+
+
+def _sample_order(qpack, kpack):
+    """bmt_attn_*_args.b_order for an attention over packed rows: the query side's order (a sample's cost is (its queries) x (its keys); the
+    two modalities' lengths of a video go together -- and any permutation is correct)"""
+    pk = qpack if qpack is not None else kpack
+    if pk is None or pk.order is None or not BALANCED_ORDER:
+        return None
+    return C.c_void_p(pk.order.data_ptr())
 
 
 def pack_of(t) -> Optional["RowPack"]:
@@ -1518,7 +1534,8 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
                         mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk),
                         drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=precision,
                         Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop, Of=_p(of),
-                        q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None)
+                        q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None,
+                        b_order=_sample_order(qpack, kpack))
     _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
     return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
@@ -1650,7 +1667,8 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16),
-                        q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None)
+                        q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None,
+                        b_order=_sample_order(qpack, kpack))
     bias_part = None
     if rc is not None:      # the split backward, recompute form: live bits / max |dO| + per-tile bias partials
         a.rc_ws, a.bias_ws = _p(rc[0]), _p(rc[1])

@@ -325,6 +325,10 @@ typedef struct {
      * same for K / V (mask must be NULL: every packed key is valid).  Sq / Sk stay the PADDED lengths (they size the launch and index lse,
      * which keeps its [B, H, Sq] layout by position within the sample).  Taken by the one-pass d_k >= 128 kernels. */
     const int *q_off, *k_off;
+    /* ABI 10 (optional, device int32 [B], a permutation of 0 .. B - 1; packed rows only): the launch's work items (batch, head, tile) are
+     * numbered with sample b_order[i] in place of sample i -- which sample a workgroup (and, through the XCD-contiguous numbering, an XCD)
+     * works on, not what it computes (bmt_pack_rows_ordered builds a length-balanced one). */
+    const int* b_order;
 } bmt_attn_fwd_bf16_args;
 int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* args, void* stream);
 
@@ -366,6 +370,7 @@ typedef struct {
      * Sq x Sk x d_k instead of 5, and none of the 2 x Sq x Sk x 2 bytes per (batch, head) written and read back (model/multihead_attention.py:8-26's
      * autograd).  Same eligibility as the emitting form plus Sq <= 2048; an ineligible problem with rc_ws set is an error. */
     int* rc_ws;
+    const int* b_order;                               /* ABI 10: as in bmt_attn_fwd_bf16_args */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* element counts of the split backward's workspaces for a problem: P_ws and dS_ws (bf16) take *n_pds each, Qb_ws (bf16) *n_qb, bias_ws
@@ -448,6 +453,10 @@ int bmt_prep_features(const float* a, const float* b2, const float* pe, float* o
  * so a hole inside a sequence is as good as a padded tail).  bmt_prep_features_packed is bmt_prep_features writing packed rows:
  * out[r] = dropout(a[row_map[r]] (+ b2[row_map[r]]) + PE[row_map[r] % S]) for r < off[B]; the dropout mask is indexed by the packed element. */
 int bmt_pack_rows(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, void* stream);
+/* ABI 10 -- ... and `order` (optional, int32 [B], B <= 256): a permutation of the samples that balances the attention kernels' work over the
+ * eight XCDs -- ranked by valid length, dealt to the eight contiguous ranges of the sample-major work order in serpentine order, each range
+ * longest first (bmt_attn_fwd_bf16_args.b_order / bmt_attn_bwd_bf16_args.b_order).  Results do not depend on it. */
+int bmt_pack_rows_ordered(const uint8_t* mask, int64_t mask_bs, int B, int S, int* off, int* row_map, int* order, void* stream);
 int bmt_prep_features_packed(const float* a, const float* b2, const float* pe, float* out, int B, int S, int D, float drop_p,
                              const uint64_t* rng, uint32_t site, const int* row_map, const int* rows_dev, void* stream);
 /* out[b,s,:] = dropout( W[ids[b,s],:] * emb_scale + PE[s,:] )                model/blocks.py:42-46 + pos enc */

@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--B", type=int, default=32)
-    ap.add_argument("--order", default="random", choices=("random", "desc", "asc", "equal"),
+    ap.add_argument("--order", default="random", choices=("random", "desc", "asc", "equal", "snake"),
                     help="the samples' lengths as drawn, sorted (longest / shortest sample first), or all equal to their rms (same executed FLOPs)")
     ap.add_argument("--forms", default="recompute,emit,two-kernel")
     args = ap.parse_args()
@@ -36,6 +36,10 @@ def main():
         Lv = torch.sort(Lv, descending=True).values
     elif args.order == "asc":
         Lv = torch.sort(Lv).values
+    elif args.order == "snake":      # samples 4x .. 4x + 3 (the (batch, head) range one XCD works through) with balanced sums, longest first
+        sv = torch.sort(Lv, descending=True).values
+        n8 = B // 8
+        Lv = torch.stack([torch.sort(torch.stack([sv[r * 8 + (g if r % 2 == 0 else 7 - g)] for r in range(n8)]), descending=True).values for g in range(8)]).reshape(-1)
     elif args.order == "equal":
         Lv = torch.full_like(Lv, int(round(float((Lv.double() ** 2).mean().sqrt()))))
     La = torch.round(Lv.float() * 800 / 256).long()
