@@ -15,6 +15,8 @@ from tests.gpu_util import assert_close, rel_err, report
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 LOGP_TOL = 1e-3
+GRAD_NORM_TOL = 0.02       # |norm - reference norm| / reference norm of a parameter's gradient on the seeded fixtures (measured, round 6: worst 5.7e-3 on
+                           # configs[0], 3.6e-3 mid, 3.9e-3 full length; the elementwise bars are _check_grads')
 GRAD_REL = 3e-2
 
 
@@ -188,15 +190,18 @@ def test_seeded_captioning_model(golden, name, cfgfn):
     names = [str(s) for s in g.np("grad_names")]
     norms = g.np("grad_norms")
     params = dict(model.named_parameters())
-    bad = []
+    bad, worst = [], 0.0
     nmax = float(max(norms))
     for n, ref_norm in zip(names, norms):
         mine = float(params[n].grad.double().norm())
         if ref_norm < 1e-4 * nmax:          # analytically zero (key-projection biases): bf16 cancellation noise only
             if mine > 2e-2 * nmax:
                 bad.append(f"{n}: should be ~0, |grad|={mine:.4e}")
-        elif abs(mine - ref_norm) > 0.10 * ref_norm:
-            bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
+        else:
+            worst = max(worst, abs(mine - ref_norm) / ref_norm)
+            if abs(mine - ref_norm) > GRAD_NORM_TOL * ref_norm:
+                bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
+    print(f"worst relative error of a gradient norm: {worst:.3e} (bar {GRAD_NORM_TOL})")
     assert not bad, "\n".join(bad)
     _check_grads(model.named_parameters(), g.sub("grad/"))
 
@@ -483,7 +488,7 @@ def test_fused_residual_block_equals_the_separate_kernels(golden):
 # ---------------------------------------------------------------- round-2 parity cases (tests/golden/make_golden_r2.py)
 def test_full_length_captioning_model(golden):
     """configs[1] at its TRUE lengths (T_v=256, T_a=800, T_c=30, V=10000; 13 key tiles / 7 query tiles in the attention
-    kernels), B=2: log-probs within 1e-3 of the reference CPU path, gradient norms within 10 %"""
+    kernels), B=2: log-probs within 1e-3 of the reference CPU path, gradient norms within 2 %"""
     from oracle import bmt_oracle as orc
     from tests.test_oracle_golden import check_full_cap_pred
     g = golden("full_cap.npz")
@@ -502,14 +507,17 @@ def test_full_length_captioning_model(golden):
     loss.backward()
     params = dict(model.named_parameters())
     norms = g.np("grad_norms")
-    nmax, bad = float(max(norms)), []
+    nmax, bad, worst = float(max(norms)), [], 0.0
     for n, ref_norm in zip([str(s) for s in g.np("grad_names")], norms):
         mine = float(params[n].grad.double().norm())
         if ref_norm < 1e-4 * nmax:
             if mine > 2e-2 * nmax:
                 bad.append(f"{n}: should be ~0, |grad|={mine:.4e}")
-        elif abs(mine - ref_norm) > 0.10 * ref_norm:
-            bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
+        else:
+            worst = max(worst, abs(mine - ref_norm) / ref_norm)
+            if abs(mine - ref_norm) > GRAD_NORM_TOL * ref_norm:
+                bad.append(f"{n}: |grad|={mine:.4e} reference {ref_norm:.4e}")
+    print(f"worst relative error of a gradient norm: {worst:.3e} (bar {GRAD_NORM_TOL})")
     assert not bad, "\n".join(bad)
     _check_grads(model.named_parameters(), g.sub("grad/"))
 
