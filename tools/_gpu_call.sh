@@ -1,1 +1,3 @@
-timeout 900 python -m pytest tests/test_gpu_model.py -q -x -s -p no:cacheprovider -k "seeded_captioning or full_length or operand_policies or full_cap" 2>&1 | grep -i "worst relative\|passed\|failed\|error" | head -20
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_packed.py -q -x -p no:cacheprovider -k "graph or captured or replay" 2>&1 | tail -5
+bash tools/gpu_ab_attr.sh "o.SPLIT_TAIL = False" "pass" 2>&1 | tee gpurun_out/r06_u_ab_split_tail.txt
+bash tools/gpu_timeline.sh r06_u
