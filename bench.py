@@ -1062,7 +1062,7 @@ def main():
             "metric": desc["metric"], "value": value, "unit": desc["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "launch_mode": mode,
-            "dtype": ops.precision_description(), "data": "synthetic",
+            "dtype": ops.precision_description(args.procedure), "data": "synthetic",
             "config": {"workload": desc["workload"], "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "trainable_params": desc["n_params"], desc["units_name"]: units_all, "final_loss": final_loss},
             "valid_row_fraction": (desc.get("valid_rows") or {}).get("fraction"), "valid_rows": desc.get("valid_rows"),

@@ -397,9 +397,9 @@ def _load_cap_encoder(path, strip='module.encoder.'):
 
 def _tag_heads_by_depth(model, n_layers):
     """the operand policy of the heads' k-tap Conv1d depends on what feeds them (ops.POLICIES, as for the encoder's FFN-2): over an encoder
-    of at most two layers (configs[3]) fp16 activation x split-fp16 weight -- the predictions stay within 1e-3 of the reference with margin
-    (tests/test_gpu_proposal.py, real kernel sizes); the six-layer encoder of configs[4] leaves its own error on the activations and
-    exp() turns the sum into 1e-3 relative on two predicted lengths of 13 440 (deep fixture, round 4): those heads keep three bf16 passes."""
+    of at most two layers (configs[3]) one fp16 pass -- the predictions stay within 1e-3 of the reference with margin
+    (tests/test_gpu_proposal.py, real kernel sizes: 3e-5); the six-layer encoder of configs[4] leaves its own error on the activations and
+    exp() turns the sum into 1e-3 relative on two predicted lengths of 13 440 (deep fixture, round 4, two passes): those heads keep three bf16 passes."""
     if n_layers > 2:
         for m in model.modules():
             if isinstance(m, ProposalGenerationHead):

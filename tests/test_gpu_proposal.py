@@ -38,11 +38,12 @@ def test_conv1d_heads_vs_torch_conv(B, S, Din, Dout, k):
     xd, Wd, bd = x.to(DEV).requires_grad_(), W.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
     y = ConvKFn.apply(xd, Wd, bd, True, 0.0, 0)
     from bmt_amd import ops
-    # (the k-tap layer of a head runs fp16 activation x split fp16 weight -- ops.POLICIES["head_conv"]: the oracle gets the activation rounded
-    # to fp16, so that only the accumulation order and the dropped lo.lo term differ, as for every single-plane operand in test_gpu_kernels.py)
-    f16_act = ops.policy_of("head_conv").gemm == ops.PREC_F16W2
-    xr = (x.half().double() if f16_act else x.double()).requires_grad_()
-    Wr, br = W.double().requires_grad_(), b.double().requires_grad_()
+    # (the k-tap layer of a head runs one fp16 pass -- ops.POLICIES["head_conv"]: the oracle gets the operands that are single planes rounded to
+    # fp16, so that only the accumulation order differs, as for every single-plane operand in test_gpu_kernels.py; the distance to the
+    # reference's own fp32 result is test_proposal_head_at_the_reference_sizes' and the model fixtures' subject)
+    prec = ops.policy_of("head_conv").gemm
+    xr = (x.half().double() if prec in (ops.PREC_F16W2, ops.PREC_F16) else x.double()).requires_grad_()
+    Wr, br = (W.half().double() if prec == ops.PREC_F16 else W.double()).requires_grad_(), b.double().requires_grad_()
     want = torch.relu(torch.nn.functional.conv1d(xr.permute(0, 2, 1), Wr, br, padding=k // 2)).permute(0, 2, 1)
     assert_close(y, want, atol=3e-4, name=f"conv k={k}")
     (y * w.to(DEV)).sum().backward()
