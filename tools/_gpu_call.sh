@@ -1,2 +1,2 @@
-timeout 1500 python -m pytest tests/test_gpu_proposal.py tests/test_gpu_round4.py tests/test_gpu_unimodal.py tests/test_gpu_postprocess.py -q -p no:cacheprovider --maxfail=10 2>&1 | grep -v "Warning\|warn" | tail -8
-timeout 600 python bench.py --procedure train_prop --steps 10 --warmup 3 > gpurun_out/r06_x_bench_train_prop.json 2> gpurun_out/r06_x_bench_train_prop.err; python tools/bench_summary.py gpurun_out/r06_x_bench_train_prop.json | head -30
+R=$PWD
+bash tools/gpu_ab.sh "BMT_LIB_PATH=$R/bmt_amd/lib/libbmt_hip.so" "BMT_LIB_PATH=$R/bmt_amd/lib/libbmt_hip_sk2.so" "BMT_LIB_PATH=$R/bmt_amd/lib/libbmt_hip_sk4.so" 2>&1 | sed "s#$R/bmt_amd/lib/##" | tee gpurun_out/r06_z_ab_splitk_audio_dx.txt
