@@ -1548,11 +1548,13 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
 
-# switch: "0" keeps the two-kernel backward everywhere; default = the split form that leaves P and dS in HBM workspaces (rounds 3-5);
-# "recompute" (round 6) = the split form whose key side rebuilds them (attn_bwd_dkvr_kernel: 32 % less HBM traffic per attention, 7 products
-# instead of 5; measured 1 % SLOWER in the step -- 7.09 vs 7.02 ms, profiles/r06_d_ab_attn_bwd_forms.txt -- so it is the option, not the default)
-ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") != "0"
-ATTN_BWD_RECOMPUTE = _os.environ.get("BMT_ATTN_BWD_SPLIT", "1") == "recompute"
+# switch: "0" keeps the two-kernel backward everywhere; "emit" = the split form that leaves P and dS in HBM workspaces (rounds 3-5);
+# default (round 6) = the split form whose key side rebuilds them (attn_bwd_dkvr_kernel: 7 products instead of 5, none of the 2 x Sq x Sk x 2
+# bytes per (batch, head) written and read back -- 249 MB moved per encoder attention backward instead of 409, profiles/r06_e_attn_bwd_forms_pmc.txt --
+# and none of the 2 x 183 + 52 MB of workspaces per stream).  In the step the two are level: 7.09 vs 7.02 ms when the form was built
+# (profiles/r06_d_ab_attn_bwd_forms.txt), 6.96 / 6.97 vs 6.97 / 6.98 ms with the samples walked in balanced order (profiles/r06_aa_ab_attn_bwd_forms.txt)
+ATTN_BWD_SPLIT = _os.environ.get("BMT_ATTN_BWD_SPLIT", "recompute") != "0"
+ATTN_BWD_RECOMPUTE = _os.environ.get("BMT_ATTN_BWD_SPLIT", "recompute") == "recompute"
 
 
 _SCRATCH = {}            # (device index, stream handle, capture owner | None, name) -> 1-D tensor: scratch that lives inside ONE library call

@@ -17,7 +17,7 @@ ALLOWED = {
     "BMT_RAW_MEMORY": ("0: the decoder's cross-attentions project the encoder memories to keys and values, as the reference does",
                        "tests/test_gpu_raw_memory.py::test_model_with_and_without_projected_keys_and_values"),
     "BMT_ENC_STREAMS": ("1: the whole pass on one stream", "tests/test_gpu_model.py::test_two_compute_streams_change_nothing_but_the_schedule"),
-    "BMT_ATTN_BWD_SPLIT": ("0: the two-kernel attention backward everywhere; recompute: the split form whose key side rebuilds P / dS",
+    "BMT_ATTN_BWD_SPLIT": ("0: the two-kernel attention backward everywhere; emit: the split form that leaves P / dS in HBM workspaces",
                            "tests/test_gpu_kernels.py::test_attention_backward_split_form"),
     "BMT_NO_FUSE_RES": ("1: LayerNorm / dropout_add / add as separate kernels",
                         "tests/test_gpu_model.py::test_fused_residual_block_equals_the_separate_kernels"),
