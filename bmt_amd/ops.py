@@ -986,6 +986,7 @@ def clear_step_start():
     c = context()
     c.step_start = None
     c.planes_ready, c.planes_waited = None, set()
+    c.deferred, c.deferred_join = None, None      # (a pass that raised before its backward must not leave its zero fill to the next one)
 
 
 EARLY_REFRESH = True      # the once-per-step refresh of the weights' operand planes runs on its own stream from the step's beginning

@@ -64,3 +64,49 @@ def test_balanced_sample_order_is_a_permutation_dealt_in_serpentine(ops, B):
         cost = (L.double() ** 2)
         spread = lambda o: float(max(sum(cost[j] for j in o[i * n8:(i + 1) * n8]) for i in range(8)) / (cost.sum() / 8))
         assert spread(got) <= spread(list(range(B))) + 1e-9 and spread(got) < 1.1
+
+
+def test_captured_grouped_launch_reads_tables_written_at_capture_time(ops):
+    """ops.gemm_bf16_grouped under a capture: the descriptor image is built on the host (bmt_gemm_bf16_grouped_image), copied into a table the
+    launch owns on a stream that is not capturing, and the graph holds the product alone -- replays give what the eager launch (tables written
+    by kernels in front of it) gives, also after the operands' CONTENTS changed (the addresses are what the tables hold)"""
+    from tests.gpu_util import assert_close
+    import math
+
+    def rnd(*shape, seed=0):
+        return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    shapes = [(2048, 256, 128), (700, 130, 70), (5000, 512, 1024)]
+    dys = [(rnd(r, n, seed=3 + i) * 0.1).to(DEV) for i, (r, n, k) in enumerate(shapes)]
+    xs = [rnd(r, k, seed=30 + i).to(DEV) for i, (r, n, k) in enumerate(shapes)]
+    planes = lambda: [(ops.make_planes(dy, "bwd"), ops.make_planes(x, "bwd")) for dy, x in zip(dys, xs)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        accs = [torch.zeros(n, k, device=DEV) for (r, n, k) in shapes]
+        pl = planes()
+        ops.gemm_bf16_grouped([(a, b, c) for (a, b), c in zip(pl, accs)])          # eager: registers the pool a capture takes its tables from
+        torch.cuda.synchronize()
+        want = [a.clone() for a in accs]
+        for a in accs:
+            a.zero_()
+        free_before = len(ops._const_tables[torch.cuda.current_device()]["free"])
+        g = torch.cuda.CUDAGraph()
+        with ops.scratch_owner("grouped-test"), torch.cuda.graph(g, stream=s):
+            ops.gemm_bf16_grouped([(a, b, c) for (a, b), c in zip(pl, accs)])
+        ops.finish_capture()
+        assert len(ops._const_tables[torch.cuda.current_device()]["free"]) == free_before - 1
+        g.replay()
+        torch.cuda.synchronize()
+        for a, w, (r, n, k) in zip(accs, want, shapes):
+            assert_close(a, w, atol=2e-4 * math.sqrt(r), rtol=1e-5, name=f"captured grouped dW {n}x{k}")
+        # new contents in the same buffers: the replay follows them
+        for (a, b), dy, x in zip(pl, dys, xs):
+            a.hi.copy_(ops.make_planes(dy * 2.0, "bwd").hi)
+        for a in accs:
+            a.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for a, w, (r, n, k) in zip(accs, want, shapes):
+            assert_close(a, 2.0 * w, atol=4e-4 * math.sqrt(r), rtol=1e-5, name=f"captured grouped dW, new contents {n}x{k}")
+        del g
+        ops.release_const_tables("grouped-test")
+        assert len(ops._const_tables[torch.cuda.current_device()]["free"]) == free_before

@@ -18,6 +18,7 @@ cp gpurun_out/${TAG}_prop_pmc_traffic.json profiles/${TAG}_prop_pmc_traffic.json
 timeout 300 python bench.py --procedure train_prop --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_train_prop.json 2> gpurun_out/${TAG}_prop.err; echo "train_prop rc=$?"
 python tools/bench_summary.py gpurun_out/${TAG}_bench_train_prop.json | head -10
 bash tools/gpu_prof.sh $TAG 6 2>&1 | head -40
+bash tools/gpu_prof.sh ${TAG}_prop 6 train_prop 2>&1 | head -30
 bash tools/gpu_timeline.sh $TAG 2>&1 | tail -4
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 # the rows either side of the path and the deep configuration, with the same tree (numbers for DESIGN.md section 6)
