@@ -137,7 +137,7 @@ class CaptioningTrainStep:
         model = self.model
         model.train()
         from . import ops as _ops
-        _ops.mark_step_start()          # (the table writers of this pass's grouped launches fork from here)
+        _ops.mark_step_start()          # (the refresh of the weights' operand planes forks from here: ops.EARLY_REFRESH)
         if self.reducer is not None:
             self.reducer.zero_grad(defer=_ops.DEFER_ZERO)      # (issued beside the decoder's forward, joined before backward() below)
         else:
@@ -471,7 +471,7 @@ class ProposalTrainStep:
         model = self.model
         model.train()
         from . import ops as _ops
-        _ops.mark_step_start()          # (the weight-plane refresh and the table writers of grouped launches fork from here)
+        _ops.mark_step_start()          # (the refresh of the weights' operand planes forks from here: ops.EARLY_REFRESH)
         try:
             if self.reducer is not None:
                 self.reducer.zero_grad()
