@@ -62,7 +62,7 @@ class AttnFwdBf16Args(C.Structure):
                 ("mask", vp), ("mask_bs", i64), ("mask_qs", i64),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("dk", i32),
                 ("scale", f32), ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32),
-                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64), ("Of", vp), ("q_off", vp), ("k_off", vp), ("b_order", vp)]
+                ("Oh", vp), ("Ol", vp), ("ldop", i64), ("bsop", i64), ("Of", vp), ("q_off", vp), ("k_off", vp), ("b_order", vp), ("kv_shared", i32)]
 
 
 class AttnBwdBf16Args(C.Structure):
@@ -78,7 +78,7 @@ class AttnBwdBf16Args(C.Structure):
                 ("dQT", vp), ("dKT", vp), ("dVT", vp), ("gqT_ld", i64), ("gkvT_ld", i64),
                 ("dbq", vp), ("dbk", vp), ("dbv", vp), ("Of", vp), ("kmean", vp), ("qkv_f16", i32),
                 ("P_ws", vp), ("dS_ws", vp), ("Qb_ws", vp), ("bias_ws", vp), ("defer_bias", i32), ("q_off", vp), ("k_off", vp),
-                ("rc_ws", vp), ("b_order", vp)]
+                ("rc_ws", vp), ("b_order", vp), ("kv_shared", i32)]
 
 
 class CopyItem(C.Structure):

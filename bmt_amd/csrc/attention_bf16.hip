@@ -185,6 +185,8 @@ struct AttnPB {
     // (lse, delta, the split backward's workspaces, the per-tile bias partials); attn_rebase turns Sq / Sk into this sample's lengths.
     const int *q_off, *k_off;
     const int* b_order;                        // (ABI 10) work items are numbered with sample b_order[i] in place of sample i (attn_sample)
+    int kvh;                                   // (ABI 10) elements between two heads' columns in the K / V planes: d_k, or 0 = ONE key / value plane of width
+                                               // d_k shared by the heads (attention against an un-projected input: ops.MHAFn's rank path)
     int SqP, SkP;
     int64_t drop_off;                          // element index of this sample's first output row in the dropout mask's index space (attn_rebase)
 };
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_kernel(const AttnPB p) {
     const int q = qt * 128 + wid * 32 + l31;
     const bool qok = q < p.Sq;
 
-    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+    const int64_t koff = (int64_t)b * p.bsk + h * p.kvh, voff = (int64_t)b * p.bsv + h * p.kvh;
 
     bf16x8 qh[DK / 16], ql[DK / 16];
     {
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int b = bh / p.H, h = bh % p.H;
     const int q = qt * 128 + wid * 16 + c;
     const bool qok = q < p.Sq;
-    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+    const int64_t koff = (int64_t)b * p.bsk + h * p.kvh, voff = (int64_t)b * p.bsv + h * p.kvh;
 
     bf16x8 qh[KS], ql[KS];
     {
@@ -988,8 +990,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int troff = tr_lane_off(RS, c, g);
 
     // K / V rows of this (b, h): descriptors end after the last key row, so a stage that runs past Sk reads zeros there
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * p.kvh), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * p.kvh), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     int kvo[NR], vvo[NR], lso[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -1214,8 +1216,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- LDS-DMA: piece = 1 KB = RPP rows; wave w moves pieces w * PPW .. of the K and of the V tile
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * p.kvh), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * p.kvh), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     // (fixed extent: with the template-dependent extent PPW the DMA builtin's call becomes type-dependent and hipcc 7.2's host pass drops
     // the whole kernel instantiation WITHOUT a diagnostic -- the library then fails to load with the kernel's stub undefined)
     int kvo[4], vvo[4];
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
     const int b = bh / p.H, h = bh % p.H;
     const int q = qt * 128 + wid * 32 + l31;
     const bool qok = q < p.Sq;
-    const int64_t koff = (int64_t)b * p.bsk + h * DK, voff = (int64_t)b * p.bsv + h * DK;
+    const int64_t koff = (int64_t)b * p.bsk + h * p.kvh, voff = (int64_t)b * p.bsv + h * p.kvh;
 
     // Q fragments stay in registers; the dO rows of this workgroup's 128 queries live in LDS (swizzled like K) and are read
     // as B operands.  Holding both in registers needs dq (128) + Q (64) + dO (64) + S, dP (32) = 288 accumulator-file
@@ -1614,7 +1616,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_bf16_kernel(const AttnPB p
 #undef BMT_DQ_STORE
     if (p.kmean != nullptr) {          // the query's keys are split over the lanes l31 and l31 + 32
         rs += __shfl_xor(rs, 32, 64);
-        const float* km = p.kmean + ((int64_t)b * p.H + h) * DK;
+        const float* km = p.kmean + (p.kvh != 0 ? ((int64_t)b * p.H + h) : (int64_t)b) * DK      /* (shared keys: ONE mean key per sample) */;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -1672,9 +1674,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_bf16_kernel(const AttnPB 
     if (!dead) {
     {
         u32x4 tmp[rows_n<DK, KB>()];
-        tile_gload<DK, KB>(p.Kh + (int64_t)b * p.bsk + h * DK, p.ldk, kt * KB, p.Sk, tid, tmp);
+        tile_gload<DK, KB>(p.Kh + (int64_t)b * p.bsk + h * p.kvh, p.ldk, kt * KB, p.Sk, tid, tmp);
         tile_lstore<DK, KB>(sK, tid, tmp);
-        tile_gload<DK, KB>(p.Vh + (int64_t)b * p.bsv + h * DK, p.ldv, kt * KB, p.Sk, tid, tmp);
+        tile_gload<DK, KB>(p.Vh + (int64_t)b * p.bsv + h * p.kvh, p.ldv, kt * KB, p.Sk, tid, tmp);
         tile_lstore<DK, KB>(sV, tid, tmp);
     }
     const int myrow = kgrp * 32 + l31;
@@ -1798,7 +1800,7 @@ __device__ __forceinline__ void dq_rowsum_fix(const AttnPB& p, f32x4v (&dq)[DK /
     if (p.kmean == nullptr) return;
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
-    const float* km = p.kmean + ((int64_t)b * p.H + h) * DK + 4 * g;
+    const float* km = p.kmean + (p.kvh != 0 ? ((int64_t)b * p.H + h) : (int64_t)b) * DK      /* (shared keys: ONE mean key per sample) */ + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < DK / 16; ++dt) {
         const float4 k4 = *reinterpret_cast<const float4*>(km + 16 * dt);
@@ -1886,8 +1888,8 @@ __device__ __forceinline__ void attn_bwd_dq16b_body(const AttnPB& pin, const int
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * p.kvh), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * p.kvh), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     int kvo[NR], vvo[NR], lso[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -2047,8 +2049,8 @@ __device__ __forceinline__ void attn_bwd_dkv32_body(const AttnPB& pin, const int
         bf16x8 kf[KS], vf[KS];
         {
             const int krow = min(key, p.Sk - 1);
-            const int64_t ko = (int64_t)b * p.bsk + (int64_t)krow * p.ldk + h * DK + 8 * g;
-            const int64_t vo = (int64_t)b * p.bsv + (int64_t)krow * p.ldv + h * DK + 8 * g;
+            const int64_t ko = (int64_t)b * p.bsk + (int64_t)krow * p.ldk + h * p.kvh + 8 * g;
+            const int64_t vo = (int64_t)b * p.bsv + (int64_t)krow * p.ldv + h * p.kvh + 8 * g;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 kf[ks] = ldfrag(p.Kh + ko + 32 * ks, true);
@@ -2381,8 +2383,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ntile = (p.Sk + BC - 1) / BC;
 
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * DK), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * p.kvh), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Vh + (int64_t)b * p.bsv + h * p.kvh), 0, plane_extent(p.Sk, p.ldv, DK), 0x00020000);
     const int64_t slab = (int64_t)bh * p.ws_slab;
     // (the descriptor covers the whole (batch, head) slab: the range check takes the soffset into account -- raw buffers are out of range at
     // voffset >= num_records - soffset -- so a one-block range dropped every store to key blocks past the first; rows past Sq are kept
@@ -2705,7 +2707,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     if (p.kmean != nullptr) {
         const float rst = half_sum(rs);
-        const float* km = p.kmean + ((int64_t)b * p.H + h) * DK;
+        const float* km = p.kmean + (p.kvh != 0 ? ((int64_t)b * p.H + h) : (int64_t)b) * DK      /* (shared keys: ONE mean key per sample) */;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -2854,7 +2856,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef __attribute__((address_space(3))) void* lptr_t;
     const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Qh + (int64_t)b * p.bsq + h * DK), 0, plane_extent(p.Sq, p.ldq, DK), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dOh + (int64_t)b * p.bso + h * DK), 0, plane_extent(p.Sq, p.ldo, DK), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * DK), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Kh + (int64_t)b * p.bsk + h * p.kvh), 0, plane_extent(p.Sk, p.ldk, DK), 0x00020000);
     // LDS-DMA pieces (1 KB = RPP rows): wave w moves pieces w, w + 4, w + 8, .. of each tile, so that the rows of its pieces differ by multiples of
     // 4 RPP -- the swizzle term of piece j is then the first piece's (d_k 128: rows 16 j apart) or the first piece's ^ 32 bytes for odd j
     // (d_k 256: rows 8 j apart flip bit 1 of (row >> 2) & 3) and the row term goes into the scalar offset: two offset registers per tile
@@ -2903,7 +2905,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
         // (UNCONDITIONAL loads from a clamped row, as everywhere: a key past Sk carries the last key's values, its columns are never stored)
         const int kc = min(key, p.Sk - 1);
-        const int64_t vo = (int64_t)b * p.bsv + (int64_t)kc * p.ldv + h * DK + 8 * hh;
+        const int64_t vo = (int64_t)b * p.bsv + (int64_t)kc * p.ldv + h * p.kvh + 8 * hh;
         u32x4 vr[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) vr[ks] = *reinterpret_cast<const u32x4*>(p.Vh + vo + 16 * ks);
@@ -3408,7 +3410,7 @@ extern "C" int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* a, void* stream) 
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
-    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off; p.b_order = a->b_order;
+    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off; p.b_order = a->b_order; p.kvh = a->kv_shared ? 0 : a->dk;
     BMT_CHECK_ARG(!(a->q_off || a->k_off) || (a->dk >= 128 && a->precision != BMT_PREC_BF16X3 && (!a->k_off || !a->mask) && (a->mask == nullptr || a->mask_qs == 0) &&
                                               (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) && (int64_t)a->Sk * a->ldv * 2 < (1ll << 31)),
                   "bmt_attn_fwd_bf16: packed rows (q_off / k_off) are taken by the one-pass d_k >= 128 kernels, without a mask over packed keys");
@@ -3445,7 +3447,7 @@ extern "C" int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* a, void* stream) 
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_qs = a->mask_qs;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
-    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off; p.b_order = a->b_order;
+    p.SqP = a->Sq; p.SkP = a->Sk; p.q_off = a->q_off; p.k_off = a->k_off; p.b_order = a->b_order; p.kvh = a->kv_shared ? 0 : a->dk;
     BMT_CHECK_ARG(!(a->q_off || a->k_off) || (a->dk >= 128 && (!a->k_off || !a->mask) && (a->mask == nullptr || a->mask_qs == 0) && !a->dQT && !a->dKT && !a->dVT &&
                                               !a->O && !a->dO && (int64_t)a->Sk * a->ldk * 2 < (1ll << 31) && (int64_t)a->Sk * a->ldv * 2 < (1ll << 31) &&
                                               (int64_t)a->Sq * a->ldq * 2 < (1ll << 31) && (int64_t)a->Sq * a->ldo * 2 < (1ll << 31)),

@@ -1514,7 +1514,8 @@ def _plane_buf(rows: int, cols: int, device, dtype=torch.bfloat16) -> torch.Tens
     return (torch.empty if ld == cols else torch.zeros)(rows, ld, device=device, dtype=dtype)
 
 
-def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop_p=0.0, site=0, precision=PREC_BF16X3, out_fmt: str = "x3"):
+def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop_p=0.0, site=0, precision=PREC_BF16X3, out_fmt: str = "x3",
+                    kv_shared: bool = False):
     """attention core over projection planes; the post-dropout output is written as operand planes of the out-projection
     (``out_fmt``: "x3" = bf16 hi + lo, "f16" = bf16 hi + fp16, "bwd" = bf16 hi) -- no fp32 copy.
     precision: PREC_BF16X3 (hi + lo planes of q / k / v), PREC_F16 (their fp16 planes) or PREC_BF16.
@@ -1544,7 +1545,7 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
                         drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=precision,
                         Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop, Of=_p(of),
                         q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None,
-                        b_order=_sample_order(qpack, kpack))
+                        b_order=_sample_order(qpack, kpack), kv_shared=int(kv_shared))
     _lib.check(lib.bmt_attn_fwd_bf16(C.byref(a), _st()), "bmt_attn_fwd_bf16")
     return Planes(oh, ol, B * Sq, D, fh=of, pack=qpack), lse
 
@@ -1626,7 +1627,7 @@ def _attn_rc_ws(B, H, Sq, Sk, dk, dev):
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
-                    fuse: Optional[str] = None):
+                    fuse: Optional[str] = None, kv_shared: bool = False):
     """attention backward (single-pass bf16 on the hi planes) with the gradients written as GEMM operands: for each of dq, dk,
     dv the bf16 plane (the A operand of the projection's dX and, k-major, of its dW) and the bias gradient (column sums).
     o: the saved output planes (hi + lo, or hi + fh: delta = rowsum(dO * O) reads the most precise form present).
@@ -1668,7 +1669,8 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     ws = _attn_split_ws(B, H, Sq, Sk, dk, dev) if (rc is None and ATTN_BWD_SPLIT and f16 and mqs == 0) else None
     # the mean-key correction removes the residue of the bf16-rounded dS (8 significand bits); kept on the split form too, whose dQ runs on
     # fp16 dS with per-query scales (without it one tensor of the deep fixture goes from < 2 % to 4.4 %: DESIGN.md section 2)
-    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, D, (keep, mptr, mbs, mqs), f16=f16, kpack=kpack)
+    # (kv_shared: ONE key / value plane of width d_k for all heads -- one mean key per sample)
+    km = attn_kmean(ka, ldk, Sk * ldk, B, Sk, dk if kv_shared else D, (keep, mptr, mbs, mqs), f16=f16, kpack=kpack)
     a = AttnBwdBf16Args(Qh=_p(qa), Kh=_p(ka), Vh=_p(va), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
@@ -1679,7 +1681,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
                         dQT=None, dKT=None, dVT=None, gqT_ld=0, gkvT_ld=0,
                         dbq=_p(qb_), dbk=_p(kb_), dbv=_p(vb_), Of=_p(o.fh), kmean=_p(km), qkv_f16=int(f16),
                         q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None,
-                        b_order=_sample_order(qpack, kpack))
+                        b_order=_sample_order(qpack, kpack), kv_shared=int(kv_shared))
     bias_part = None
     if rc is not None:      # the split backward, recompute form: live bits / max |dO| + per-tile bias partials
         a.rc_ws, a.bias_ws = _p(rc[0]), _p(rc[1])

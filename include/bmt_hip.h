@@ -329,6 +329,10 @@ typedef struct {
      * numbered with sample b_order[i] in place of sample i -- which sample a workgroup (and, through the XCD-contiguous numbering, an XCD)
      * works on, not what it computes (bmt_pack_rows_ordered builds a length-balanced one). */
     const int* b_order;
+    /* ABI 10: 1 = K and V are ONE plane of width dk each, shared by the H heads (ldk / ldv rows of dk columns; no per-head column offset) --
+     * attention against an un-projected input whose width is the head dimension: S_h = q'_h X^T, O'_h = P_h X.  Q, O and every gradient
+     * keep their per-head column blocks (the key-side gradients come out per head: the caller sums them).  d_k >= 128 plane kernels. */
+    int kv_shared;
 } bmt_attn_fwd_bf16_args;
 int bmt_attn_fwd_bf16(const bmt_attn_fwd_bf16_args* args, void* stream);
 
@@ -371,6 +375,7 @@ typedef struct {
      * autograd).  Same eligibility as the emitting form plus Sq <= 2048; an ineligible problem with rc_ws set is an error. */
     int* rc_ws;
     const int* b_order;                               /* ABI 10: as in bmt_attn_fwd_bf16_args */
+    int kv_shared;                                    /* ABI 10: as in bmt_attn_fwd_bf16_args (dK / dV per head in their column blocks) */
 } bmt_attn_bwd_bf16_args;
 int bmt_attn_bwd_bf16(const bmt_attn_bwd_bf16_args* args, void* stream);
 /* element counts of the split backward's workspaces for a problem: P_ws and dS_ws (bf16) take *n_pds each, Qb_ws (bf16) *n_qb, bias_ws

@@ -110,3 +110,42 @@ def test_captured_grouped_launch_reads_tables_written_at_capture_time(ops):
         del g
         ops.release_const_tables("grouped-test")
         assert len(ops._const_tables[torch.cuda.current_device()]["free"]) == free_before
+
+
+@pytest.mark.parametrize("B,H,S,dk,packed", [(12, 4, 300, 128, True), (3, 4, 200, 128, False), (24, 4, 800, 128, True)])
+def test_attention_with_one_key_value_plane_shared_by_the_heads(ops, B, H, S, dk, packed):
+    """bmt_attn_*_args.kv_shared: K = V = ONE plane of width d_k for all heads (the encoder's self-attention over an input narrower than a
+    head: S_h = q'_h X^T, O'_h = P_h X) against the same kernels over that plane replicated into H column blocks: outputs, lse, dQ and the
+    per-head dK / dV blocks agree to the bit (same operands, same order)"""
+    g = torch.Generator().manual_seed(S + dk)
+    D = H * dk
+    L = torch.randint(S // 2, S + 1, (B,), generator=g)
+    mask = (torch.arange(S)[None, :] < L[:, None]).view(B, 1, S)
+    pk = ops.pack_rows(mask.to(DEV)) if packed else None
+    n = int(L.sum()) if packed else B * S
+    x = torch.randn(B * S, dk, generator=g) * 0.8
+    q = torch.randn(B * S, D, generator=g) * 0.5
+    do = torch.randn(B * S, D, generator=g) * 1e-2
+    if not packed:
+        do = (do.view(B, S, D) * mask.view(B, S, 1)).view(B * S, D)
+
+    def f16only(t, pack):
+        pl = ops.make_planes(t.to(DEV), "f16", pack=pack)
+        return ops.Planes(None, None, pl.rows, pl.cols, fh=pl.fh, pack=pack)
+    qP, xP = f16only(q, pk), f16only(x, pk)
+    xrep = f16only(x.repeat(1, H), pk)
+    m = None if packed else mask.to(DEV)
+    o1, lse1 = ops.attn_fwd_planes(qP, xP, xP, B, S, S, D, m, H, precision=ops.PREC_F16, out_fmt="f16", kv_shared=True)
+    o2, lse2 = ops.attn_fwd_planes(qP, xrep, xrep, B, S, S, D, m, H, precision=ops.PREC_F16, out_fmt="f16")
+    torch.cuda.synchronize()
+    rows = slice(0, n)
+    assert torch.equal(o1.fh[rows], o2.fh[rows]) and torch.equal(o1.hi[rows], o2.hi[rows])
+    for b in range(B):          # (lse keeps its padded [B, H, S] layout; positions past a sample's length are never written)
+        assert torch.equal(lse1[b, :, :int(L[b])], lse2[b, :, :int(L[b])])
+    dpl = ops.make_planes(do.to(DEV), "bwd", pack=pk)
+    doP = ops.Planes(dpl.hi[:, :D].contiguous(), None, B * S, D, pack=pk)
+    r1 = ops.attn_bwd_planes(qP, xP, xP, o1, doP, lse1, B, S, S, D, m, H, 0.0, (None, None, None), kv_shared=True)
+    r2 = ops.attn_bwd_planes(qP, xrep, xrep, o2, doP, lse2, B, S, S, D, m, H, 0.0, (None, None, None))
+    torch.cuda.synchronize()
+    for name, (a, _), (b, _) in zip(("dq", "dk", "dv"), r1[:3], r2[:3]):
+        assert torch.equal(a.hi[rows, :D], b.hi[rows, :D]), name
