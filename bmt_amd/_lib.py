@@ -26,7 +26,7 @@ class GemmBf16Args(C.Structure):
                 ("drop_p", f32), ("rng", vp), ("site", u32), ("precision", i32), ("splitk", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("a_kmajor", i32), ("b_kmajor", i32), ("K", i32),
                 ("conv_mode", i32), ("conv_cin", i32), ("conv_rows", i32), ("conv_S", i32), ("conv_halo", i32), ("colsum", vp), ("C_f16", vp),
-                ("rows_dev", vp), ("c_row_dev", vp), ("m_dev", vp)]
+                ("rows_dev", vp), ("c_row_dev", vp), ("m_dev", vp), ("a_blk_n", i32), ("a_blk_k", i32)]
 
 
 class GemmBatch(C.Structure):
@@ -104,6 +104,8 @@ SIGNATURES = {
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
     "bmt_gemm_small_outputs": (C.c_longlong, []),
     "bmt_gemm_small_batched": (i32, [C.POINTER(GemmBf16Args), C.POINTER(GemmBatch), vp]),
+    "bmt_rank_prep": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp]),
+    "bmt_rank_chain": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]),
     "bmt_memory_transposed": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp, vp]),
     "bmt_raw_softmax_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp]),
     "bmt_raw_softmax_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, i64, i64, vp]),
@@ -207,8 +209,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 10:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 10")
+    if lib.bmt_version() != 11:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 11")
     _lib = lib
     return lib
 

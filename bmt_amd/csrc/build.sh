@@ -9,7 +9,7 @@ OBJ=obj${BMT_VARIANT:+_$BMT_VARIANT}
 LIBNAME=libbmt_hip${BMT_VARIANT:+_$BMT_VARIANT}.so
 mkdir -p "$OUT" "$OUT/$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result ${BMT_VARIANT:+$BMT_VARIANT_FLAGS}"
-SRCS="runtime gemm_bf16 attention attention_bf16 norm elementwise loss optim proposal postprocess ingest raw_memory"
+SRCS="runtime gemm_bf16 attention attention_bf16 norm elementwise loss optim proposal postprocess ingest raw_memory rank_attn"
 pids=()
 for f in $SRCS; do
   if [ ! -f "$OUT/$OBJ/$f.o" ] || [ "$f.hip" -nt "$OUT/$OBJ/$f.o" ] || [ common.h -nt "$OUT/$OBJ/$f.o" ] || [ ../../include/bmt_hip.h -nt "$OUT/$OBJ/$f.o" ]; then

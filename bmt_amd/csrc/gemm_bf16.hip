@@ -54,6 +54,7 @@ struct GemmB {
     float* ws;                           // split-K partials [split][tiles_m*128][tiles_n*128] (two-pass mode), or nullptr
     int nsplit;
     int nk_rg, nk_upw;                   // gemm_k128_kernel: row groups, 32-row units per row group
+    int a_blk_n, a_blk_k;                // gemm_k128_kernel, block products (bmt_gemm_bf16_args.a_blk_n): output column block j reads A's column block j
     int rows_is_k;                       // rows_dev bounds the REDUCTION (A k-major: a weight gradient), not the output rows
     const int *c_row_dev, *m_dev;        // grouped launch, packed OUTPUT rows: C starts *c_row_dev rows lower, only *m_dev of the M rows exist
     const int* rows_dev;                 // packed rows (bmt_gemm_bf16_args.rows_dev): the rows actually present, in device memory; the launch is sized for M
@@ -244,8 +245,20 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         }
     }
     const int n0 = n0_;
-    const int kbeg = split_id * p.kchunk;
-    const int kend = min(Kp, kbeg + p.kchunk);
+    int kbeg_ = split_id * p.kchunk;
+    int kend_ = min(Kp, kbeg_ + p.kchunk);
+    int n0b_ = n0;                       // the tile's first column in B
+    if constexpr (!AKM && BKM && !PIPE && CONV == 0) {
+        // block products (bmt_gemm_bf16_args.a_blk_n, B k-major): output column block j = A[:, j a_blk_k ...] . B[j a_blk_k ..., 0 : a_blk_n] -- the
+        // tile reduces over ITS block's rows of B (= columns of A) and reads B's columns from the start
+        if (p.a_blk_n > 0) {
+            const int j = n0 / p.a_blk_n;
+            kbeg_ = j * p.a_blk_k;
+            kend_ = kbeg_ + p.a_blk_k;
+            n0b_ = n0 - j * p.a_blk_n;
+        }
+    }
+    const int kbeg = kbeg_, kend = kend_, n0b = n0b_;
     if (kbeg >= kend) return;            // (packed rows, grouped launch: this reduction chunk lies past the rows present)
 
     f32x16 acc[TI][2];
@@ -284,7 +297,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
         } else if constexpr (AKM) plane_voff_km<BM, BK, NT>(p.lda, m0, 0, tid, avo);
         else plane_voff<SPR, BM, NT>(p.lda, m0, Mr, tid, avo);
         if constexpr (CONV == 2) plane_voff_km<BN, BK, NT>(p.ldb, n0 % p.conv_cin, n0 / p.conv_cin, tid, bvo);
-        else if constexpr (BKM) plane_voff_km<BN, BK, NT>(p.ldb, n0, 0, tid, bvo);
+        else if constexpr (BKM) plane_voff_km<BN, BK, NT>(p.ldb, n0b, 0, tid, bvo);
         else plane_voff<SPR, BN, NT>(p.ldb, n0, p.N, tid, bvo);
     }
     // extents: row-major planes end after their last row; k-major planes after reduction row K (later rows read as zero); the
@@ -1021,6 +1034,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int w = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int rg = w / nch, chunk = w - rg * nch;
     const int n0 = chunk * NCW;
+    const int a_col = p.a_blk_n > 0 ? (n0 / p.a_blk_n) * p.a_blk_k : 0;      // block products: this chunk's columns of A
     const int lrow = lane >> 4, lslot = lane & 15;          // LDS-DMA: an instruction fills 4 rows of 256 B; lane = (row, 16-byte slot)
 
     // ---- the weight chunk: pieces of 4 rows (1 KB); rows >= N are outside the descriptor (zeros)
@@ -1195,7 +1209,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define BMT_K128_LDA(dst_, uu_)                                                                                     \
 do {                                                                                                             \
     const int row_ = max(0, min(32 * min((uu_), units - 1) + l31, Mr - 1));                                             \
-    const uint16_t* ap_ = p.Ah + (int64_t)row_ * p.lda + 8 * half;                                               \
+    const uint16_t* ap_ = p.Ah + (int64_t)row_ * p.lda + a_col + 8 * half;                                       \
     BMT_K128_LD(dst_, 0); BMT_K128_LD(dst_, 1); BMT_K128_LD(dst_, 2); BMT_K128_LD(dst_, 3);                      \
     BMT_K128_LD(dst_, 4); BMT_K128_LD(dst_, 5); BMT_K128_LD(dst_, 6); BMT_K128_LD(dst_, 7);                      \
 } while (0)
@@ -2018,7 +2032,16 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         if (a->precision != BMT_PREC_F16W2) p.Bl = nullptr;      // the kernel runs its second pass iff there is a second weight plane
     }
     if (p.pipe == 1) p.bm = 256;
-    if (p.pipe == 2 && a->Kpad == 128 && a->M >= 2048 && a->N >= 128 && !a->colsum &&
+    const bool blk = a->a_blk_n > 0, blk_km = blk && a->b_kmajor && !a->a_kmajor;
+    BMT_CHECK_ARG(!blk || blk_km ||
+                      (a->a_blk_k == 128 && a->Kpad == 128 && a->a_blk_n % 128 == 0 && a->N % a->a_blk_n == 0 && p.pipe == 2 &&
+                       a->lda >= (int64_t)(a->N / a->a_blk_n) * a->a_blk_k),
+                  "bmt_gemm_bf16: block products (a_blk_n) take row-major one- / two-plane operands with a_blk_k = Kpad = 128 and a_blk_n a multiple of 128 that divides N");
+    BMT_CHECK_ARG(!blk_km || (!a->conv_mode && a->a_blk_n % BN == 0 && a->N % a->a_blk_n == 0 && a->a_blk_k % 64 == 0 &&
+                              (int64_t)(a->N / a->a_blk_n) * a->a_blk_k == a->K && a->K == a->Kpad && a->splitk <= 1),
+                  "bmt_gemm_bf16: block products with a k-major B: a_blk_n a multiple of 128 that divides N, a_blk_k a multiple of 64, K = (N / a_blk_n) a_blk_k, unsplit");
+    if (blk_km) { p.a_blk_n = a->a_blk_n; p.a_blk_k = a->a_blk_k; }
+    if (p.pipe == 2 && a->Kpad == 128 && (a->M >= 2048 || blk) && a->N >= 128 && !a->colsum &&
         !(a->flags & BMT_EPI_ACCUM) && a->splitk <= 1 && (int64_t)(a->N + 256) * a->ldb * 2 < (1ll << 31) && a->alpha == 1.f &&
         // its stores are 16-byte buffer stores clipped by 32-bit descriptors, its gate / residual loads 16-byte loads
         a->N % 8 == 0 && (!p.Chi || (p.plane_vec && (int64_t)a->M * a->ldp * 2 < (1ll << 31))) &&
@@ -2033,8 +2056,10 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
         int rg = cus / nch < 1 ? 1 : cus / nch;
         const int upw = bmt_cdiv(units, rg);
         p.nk_rg = bmt_cdiv(units, upw); p.nk_upw = upw; p.tiles_n = nch;
+        p.a_blk_n = a->a_blk_n; p.a_blk_k = a->a_blk_k;
         p.pipe = 4;
     }
+    BMT_CHECK_ARG(!blk || blk_km || p.pipe == 4, "bmt_gemm_bf16: block products (a_blk_n) need the reduction-of-128 kernel's alignment (16-byte planes, N %% 8 == 0, alpha 1, no colsum / accumulate / split)");
     // pipe 5: the three-pass product over few rows (a decoder layer's own GEMMs, the greedy decoder's): 32 x 32 tiles, reduction over the waves
     if ((p.pipe == 0 || p.pipe == 2) && !a->a_kmajor && !a->b_kmajor && !a->conv_mode && a->splitk <= 1 && (int64_t)a->M * a->N <= BMT_SMALL_TILE_OUTPUTS &&
         (a->precision == BMT_PREC_BF16X3 || a->precision == BMT_PREC_BF16)) {      // (one bf16 pass: the small dX products, weight plane transposed)
@@ -2051,7 +2076,7 @@ static int gemm_prepare(const bmt_gemm_bf16_args* a, GemmB& p, int& splitk, bool
     const int tiles = p.tiles_m * p.tiles_n;
     // split-K (two passes through the workspace) for launches of fewer than 180 tiles with >= 12 stages: ~2 workgroups per CU, at least two
     // stages per split.  (Splitting the 200-tile products of the audio stream costs more in the workspace pass than their idle CUs.)
-    if (a->splitk == 0 && two_pass && tiles < 180 && ktiles >= 12 && p.pipe != 3 && p.pipe != 4 && p.pipe != 5) {
+    if (a->splitk == 0 && two_pass && tiles < 180 && ktiles >= 12 && p.pipe != 3 && p.pipe != 4 && p.pipe != 5 && !blk_km) {
         int want = 512 / tiles, cap = ktiles / 2;
         if (want > 32) want = 32;
         splitk = want < cap ? want : cap;

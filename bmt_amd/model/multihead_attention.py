@@ -80,7 +80,13 @@ class MultiheadedAttention(nn.Module):
                 self.linear_d2Q.weight, self.linear_d2Q.bias,
                 self.H, p, self._site, pol)
         # a decoder layer's attention over an encoder memory that came prepared for the reassociated form (ops.raw_memory): no key / value projections
-        fn = ops.RawCrossAttnFn if (K is V and ops.raw_form_ok(getattr(K, "_bmt_rawmem", None), Q, self, pol)) else ops.MHAFn
+        if K is V and ops.raw_form_ok(getattr(K, "_bmt_rawmem", None), Q, self, pol):
+            fn = ops.RawCrossAttnFn
+        elif ops.rank_form_ok(Q, K, V, self, pol):
+            # a self-attention over an input narrower than a head (the encoder's audio stream): the input itself is the key / value plane
+            fn = ops.RankSelfAttnFn
+        else:
+            fn = ops.MHAFn
         off = ops.take_residual()        # an enclosing ResidualConnection offers x, p, site: fused into the out-projection
         if off is None:
             return fn.apply(*args, None, 0.0, 0, None)

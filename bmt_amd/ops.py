@@ -161,7 +161,7 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "pending_post", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
                  "step_start", "planes_ready", "planes_waited", "deferred", "deferred_join")
 
     def __init__(self):
@@ -169,6 +169,7 @@ class StepContext:
         self.pending_dw = []
         self.pending_ids = set()     # parameters whose gradient product is queued: their "gradient final" report waits for the flush
         self.pending_done = []
+        self.pending_post = []       # launches that read a queued product's result (the rank-form attention's chain rule through W'): run by flush_dw behind the grouped launch
         self.pending_cs = []         # queued column-sum reductions (LayerNorm dgamma / dbeta partials, attention bias partials): colsum_multi
         self.res_offer = None        # residual offered by a ResidualConnection to its sublayer's last GEMM
         self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
@@ -644,6 +645,7 @@ class _WeightPlanes:
             e[4] = e[5]._version
         self.fresh_epoch = WEIGHT_EPOCH[0]
         self._refresh_group_biases()
+        _rank_refresh_all()          # (the rank-form attentions' W' / c are functions of the weights too: same stream, same moment)
 
     def _refresh_group_biases(self):
         """the concatenated biases of every fused projection group in ONE launch (they were 14 torch.cat launches per optimizer step, one
@@ -851,8 +853,10 @@ def _operands(A: Planes, B: Planes, prec: int):
 def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, bias=None, relu=False, drop_pre=False, drop_post=False,
               drop_p=0.0, site=0, residual=None, ldr=0, gate=None, gate_scale=1.0, accum=False, splitk=None,
               out_planes: Optional[Planes] = None, a_km: bool = False, b_km: bool = False, conv=None, two_pass: bool = True,
-              colsum: Optional[torch.Tensor] = None):
+              colsum: Optional[torch.Tensor] = None, a_blk=None):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T) on operand planes (reduction extents must match and be zero padded).
+    a_blk = (n, k): a BLOCK product -- output columns [j n, (j + 1) n) read A's columns [j k, (j + 1) k) (bmt_gemm_bf16_args.a_blk_n): row-major
+    B [N][k] (every output block against its own rows of B, k = 128), or b_km B [K][n] (every block its own reduction rows, the same columns).
     a_km / b_km: that operand is given K-MAJOR -- its plane has the reduction index as the row ([K rows][M or N columns]), i.e.
     it is the transpose of what the product needs, read through the hardware transpose unit (single-pass bf16 only).
     out_planes: the result as operand planes -- hi = bf16(c) and ONE of lo = bf16(c - hi) / fh = fp16(c)."""
@@ -872,6 +876,11 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
         Kpad = _pad64(Ktrue)
         assert (A.rows == Ktrue if a_km else ah.shape[1] == Kpad) and (B.rows == Ktrue if b_km else bh.shape[1] == Kpad), \
             (ah.shape, A.rows, bh.shape, B.rows)
+        if a_blk is not None:
+            N = (Ktrue // a_blk[1]) * a_blk[0]
+    elif a_blk is not None:
+        Kpad = a_blk[1]
+        assert bh.shape[1] == Kpad and ah.shape[1] == (N // a_blk[0]) * Kpad, (ah.shape, bh.shape, a_blk)
     else:
         Kpad = ah.shape[1]
         assert bh.shape[1] == Kpad, (ah.shape, bh.shape)
@@ -904,6 +913,8 @@ def gemm_bf16(A: Planes, B: Planes, C_out, *, precision: int, ldc=0, alpha=1.0, 
     a.C_f16 = _p(op.fh) if op else None
     a.a_kmajor, a.b_kmajor, a.K = int(a_km), int(b_km), Ktrue
     a.colsum = _p(colsum)        # += column sums of the (plane-only) output: the bias gradient of the Linear below a dX GEMM
+    if a_blk is not None:
+        a.a_blk_n, a.a_blk_k = int(a_blk[0]), int(a_blk[1])
     if conv is not None:
         a.N = N
         a.conv_mode, a.conv_cin, a.conv_rows = conv["mode"], conv["cin"], conv["rows"]
@@ -1199,6 +1210,9 @@ def flush_dw():
         cur.wait_stream(aux)
     if cs:
         _colsum_launch(cs)
+    post, ctx.pending_post = ctx.pending_post, []
+    for fn in post:           # launches that read what the products above wrote
+        fn()
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
         grad_done(p)
     hs, ctx.gen_handles = ctx.gen_handles, []
@@ -1515,7 +1529,7 @@ def _plane_buf(rows: int, cols: int, device, dtype=torch.bfloat16) -> torch.Tens
 
 
 def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop_p=0.0, site=0, precision=PREC_BF16X3, out_fmt: str = "x3",
-                    kv_shared: bool = False):
+                    kv_shared: bool = False, scale: Optional[float] = None):
     """attention core over projection planes; the post-dropout output is written as operand planes of the out-projection
     (``out_fmt``: "x3" = bf16 hi + lo, "f16" = bf16 hi + fp16, "bwd" = bf16 hi) -- no fp32 copy.
     precision: PREC_BF16X3 (hi + lo planes of q / k / v), PREC_F16 (their fp16 planes) or PREC_BF16.
@@ -1541,7 +1555,7 @@ def attn_fwd_planes(q: Planes, k: Planes, v: Planes, B, Sq, Sk, D, mask, H, drop
     a = AttnFwdBf16Args(Qh=_p(qa), Ql=_p(q.lo) if x3 else None, Kh=_p(ka), Kl=_p(k.lo) if x3 else None,
                         Vh=_p(va), Vl=_p(v.lo) if x3 else None, O=None, lse=_p(lse),
                         ldq=ldq, ldk=ldk, ldv=ldv, ldo=D, bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D,
-                        mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk),
+                        mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=(1.0 / math.sqrt(dk)) if scale is None else float(scale),
                         drop_p=drop_p if use_drop else 0.0, rng=_p(rng_tensor()) if use_drop else None, site=site, precision=precision,
                         Oh=_p(oh), Ol=_p(ol), ldop=ldop, bsop=Sq * ldop, Of=_p(of),
                         q_off=qpack.off_ptr if qpack is not None else None, k_off=kpack.off_ptr if kpack is not None else None,
@@ -1627,7 +1641,7 @@ def _attn_rc_ws(B, H, Sq, Sk, dk, dev):
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
-                    fuse: Optional[str] = None, kv_shared: bool = False):
+                    fuse: Optional[str] = None, kv_shared: bool = False, scale: Optional[float] = None):
     """attention backward (single-pass bf16 on the hi planes) with the gradients written as GEMM operands: for each of dq, dk,
     dv the bf16 plane (the A operand of the projection's dX and, k-major, of its dW) and the bias gradient (column sums).
     o: the saved output planes (hi + lo, or hi + fh: delta = rowsum(dO * O) reads the most precise form present).
@@ -1674,7 +1688,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
     a = AttnBwdBf16Args(Qh=_p(qa), Kh=_p(ka), Vh=_p(va), O=None, dO=_p(do), lse=_p(lse), dQ=None, dK=None, dV=None,
                         delta_ws=_p(delta), dOh_ws=_p(doh), ldq=ldq, ldk=ldk, ldv=ldv, ldo=D,
                         bsq=Sq * ldq, bsk=Sk * ldk, bsv=Sk * ldv, bso=Sq * D, dkv_ld=D, dkv_bs=Sk * D,
-                        mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=1.0 / math.sqrt(dk), drop_p=drop_p,
+                        mask=mptr, mask_bs=mbs, mask_qs=mqs, B=B, H=H, Sq=Sq, Sk=Sk, dk=dk, scale=(1.0 / math.sqrt(dk)) if scale is None else float(scale), drop_p=drop_p,
                         Oh=_p(o.hi), Ol=_p(o.lo), ldop=ldop, bsop=Sq * ldop,
                         dQh=_p(qh_), dKh=_p(kh_), dVh=_p(vh_), gq_ld=qh_.stride(0), gq_bs=Sq * qh_.stride(0),
                         gkv_ld=kh_.stride(0), gkv_bs=Sk * kh_.stride(0),
@@ -2814,8 +2828,8 @@ def _blockdiag_dw(dy: Planes, x: Planes, W: torch.Tensor, H: int):
     tgt = gW if gW is not None else torch.zeros_like(W)
     nb, kb, M = W.shape[0] // H, x.cols // H, dy.rows
     for h in range(H):
-        linear_dw(Planes(dy.hi[:, h * nb:(h + 1) * nb], None, M, nb), Planes(x.hi[:, h * kb:(h + 1) * kb], None, M, kb), into=tgt[h * nb:(h + 1) * nb],
-                  params=(W,) if gW is not None else ())
+        linear_dw(Planes(dy.hi[:, h * nb:(h + 1) * nb], None, M, nb, pack=dy.pack), Planes(x.hi[:, h * kb:(h + 1) * kb], None, M, kb, pack=x.pack),
+                  into=tgt[h * nb:(h + 1) * nb], params=(W,) if gW is not None else ())
     if gW is not None:
         grad_done(W)
         return None
@@ -2968,6 +2982,237 @@ class RawCrossAttnFn(torch.autograd.Function):
         st.events.append(ev)
         return (dQ, None, None, None, dWq, None if gbq is not None else dbq_t, dWk, dbk, dWv, None if gbv is not None else dbv_t, dWo, dbo,
                 None, None, None, None, (dout if has_res else None), None, None, None)
+
+
+# ---- the encoder's self-attention over an input NARROWER than a head (round 6) ---------------------------------------------------------
+# model/multihead_attention.py:62-84 projects the audio stream (d_model_audio = 128) to d_model = 1024 for H = 4 heads of d_k = 256: q_h, k_h,
+# v_h are rank-128 images of the same 128-wide LayerNorm output x.  The products reassociate exactly as the decoder's cross-attentions did
+# in round 5 (RawCrossAttnFn) -- here with the input as its own memory:
+#     S_h = q_h k_h^T = (x W_q,h^T + b_q,h)(x W_k,h^T + b_k,h)^T = (x A_h + b_q,h W_k,h) x^T + [constant along the keys: the softmax does not see it]
+#                                                         A_h = W_q,h^T W_k,h  [d_in x d_in]
+#     O_h = P_h v_h   = (P_h x) W_v,h^T + b_v,h
+# so the attention runs with queries q' = x W'^T + c of H x d_in columns (W'_h = A_h^T = W_k,h^T W_q,h, c_h = b_q,h W_k,h) against ONE key /
+# value plane of width d_in shared by the heads (kv_shared): both attention products at d_in instead of d_k, the 3 D-wide fused q / k / v
+# projection (output-bound: 19 508 x 3072 planes at configs[1]) replaced by one H d_in-wide product, its dX by one [M][3 H d_in] x [3 H d_in][d_in]
+# product (dq' through W', the per-head dK' / dV' summed by rows of identity blocks), and the value projection applied head by head to the
+# H d_in-wide attention output (a block product on the reduction-of-128 kernel: bmt_gemm_bf16_args.a_blk_n; the attention-output dropout of
+# :22-23 in its epilogue).  W' and c are functions of the weights alone: one fp32 kernel per optimizer step (bmt_rank_prep) writes them as
+# operand planes; their gradients
+#     dW_q,h = W_k,h dW'_h          dW_k,h = W_q,h dW'_h^T + b_q,h^T dc_h          db_q,h = W_k,h dc_h          (dW' = dq'^T x, dc = colsum dq')
+# come from ONE item of the step's grouped weight-gradient launch (dW') and one fp32 kernel behind it (bmt_rank_chain).  The key bias drops
+# out (its gradient is exactly zero, as the reference's is up to rounding).
+RANK_ATTN = True
+_rank_states = {}
+
+
+class _RankState:
+    __slots__ = ("refs", "epoch", "c", "WpP", "Wcomb", "dWp", "ticket", "H", "d_in", "dk")
+
+
+def _rank_prep(st: "_RankState") -> bool:
+    """W' (operand planes) and c of one module from its weights as they are now, on the current stream (bmt_rank_prep)"""
+    Wq, Wk, bq = (r() if r is not None else None for r in st.refs)
+    if Wq is None or Wk is None:
+        return False
+    Wqd, Wkd = Wq.detach(), Wk.detach()
+    _lib.check(lib.bmt_rank_prep(_p(Wqd), _p(Wkd), _p(bq.detach()) if bq is not None else None, Wqd.stride(0), st.H, st.dk, st.d_in, _p(st.WpP.hi),
+                                 _p(st.WpP.fh), _p(st.WpP.fl), st.d_in, None, _p(st.c), _st()), "bmt_rank_prep")
+    st.epoch = WEIGHT_EPOCH[0]
+    return True
+
+
+def _rank_refresh_all():
+    """called by the weight-plane registry's once-per-optimizer-step refresh (on its stream: beside the step's prologue, ops.EARLY_REFRESH)"""
+    for k_, st in list(_rank_states.items()):
+        if st.epoch != WEIGHT_EPOCH[0] and not _rank_prep(st):
+            del _rank_states[k_]
+
+
+def rank_form_ok(Q, K, V, mha, pol) -> bool:
+    """does this MultiheadedAttention call take the rank form?  Self-attention over a CUDA input of 128 columns, at most half a head, under the
+    encoder's operand policy"""
+    if not (RANK_ATTN and Q is K and K is V and isinstance(Q, torch.Tensor) and Q.is_cuda and Q.dim() == 3):
+        return False
+    d_in, D, H = mha.d_model_Q, mha.d_model, mha.H
+    return (d_in == 128 and D % H == 0 and 2 * d_in <= D // H and (D // H) % 128 == 0 and mha.d_model_K == d_in and mha.d_model_V == d_in and
+            pol.gemm == PREC_F16W2 and pol.attn == PREC_F16 and QKV_F16_ONLY and context().kv_cache is None)
+
+
+def _rank_state(Wq, bq, Wk, H) -> "_RankState":
+    import weakref
+    key = (id(Wq), id(Wk))
+    st = _rank_states.get(key)
+    D, d_in = Wq.shape
+    dk = D // H
+    dev = Wq.device
+    if st is None or any(r() is not w for r, w in zip(st.refs, (Wq, Wk))):
+        st = _RankState()
+        st.refs = [weakref.ref(Wq), weakref.ref(Wk), weakref.ref(bq) if bq is not None else None]
+        st.H, st.d_in, st.dk, st.epoch = H, d_in, dk, -1
+        st.c = torch.zeros(H * d_in, device=dev, dtype=torch.float32)
+        # W' as the forward's two-plane operand (fh + fl) and, bf16, as the first H d_in rows of the combined dX weight [W' ; I-stack ; I-stack]
+        st.Wcomb = torch.zeros(3 * H * d_in, d_in, device=dev, dtype=torch.bfloat16)
+        eye = torch.eye(d_in, device=dev, dtype=torch.bfloat16).repeat(H, 1)
+        st.Wcomb[H * d_in:2 * H * d_in] = eye
+        st.Wcomb[2 * H * d_in:] = eye
+        st.WpP = Planes(st.Wcomb[:H * d_in], None, H * d_in, d_in, fh=torch.empty(H * d_in, d_in, device=dev, dtype=torch.float16),
+                        fl=torch.empty(H * d_in, d_in, device=dev, dtype=torch.float16))
+        st.dWp = torch.zeros(H * d_in, d_in, device=dev, dtype=torch.float32)      # dW' accumulates here; bmt_rank_chain zeroes it again
+        st.ticket = torch.zeros(1, device=dev, dtype=torch.int32)
+        _rank_states[key] = st
+        if len(_rank_states) > 256:
+            for k_ in [k_ for k_, v_ in _rank_states.items() if any(r is not None and r() is None for r in v_.refs)]:
+                del _rank_states[k_]
+    # once per optimizer step, with the refresh of the weights' operand planes (inside a captured step both are part of the graph); a module
+    # the refresh did not know yet computes its own here
+    with _weights.lock:
+        _await_planes()
+        _weights.ensure_fresh()
+    if st.epoch != WEIGHT_EPOCH[0]:
+        _rank_prep(st)
+    return st
+
+
+def _value_planes(Wq, bq, Wk, bk, Wv, bv, fmt: str) -> Planes:
+    """W_v's operand planes [D][d_in]: its rows of the module's projection group (what the projected form registers: either form may meet the
+    weights first), or its own planes where projections are not grouped"""
+    grp = weight_group((Wq, Wk, Wv), (bq, bk, bv), fmt)
+    if grp is None:
+        return weight_planes(Wv, fmt)
+    g, D = grp[0], Wv.shape[0]
+    sl = lambda t: None if t is None else t[2 * D:3 * D]
+    return Planes(sl(g.hi), sl(g.lo), D, Wv.shape[1], fh=sl(g.fh), fl=sl(g.fl))
+
+
+class RankSelfAttnFn(torch.autograd.Function):
+    """MultiheadedAttention.forward (model/multihead_attention.py:55-86) for a self-attention over an input narrower than a head, in the
+    reassociated form above.  Same arguments as MHAFn (Q is K is V)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, pol, res=None, res_p=0.0, res_site=0, out_fmt=None):
+        note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        Qc = _f32c(Q)
+        B, S, d_in = Qc.shape
+        D = Wq.shape[0]
+        dk, M, Dr = D // H, B * S, H * d_in
+        dev = Qc.device
+        pack = _check_pack(pack_of(Q), M)
+        xP = planes_of(Q, "f16")
+        if xP is None:
+            _need_fp32(Q)
+            xP = make_planes(Qc.view(-1, d_in), "f16", pack=pack_of(Q))
+            attach_planes(Q, xP)
+        if xP.pack is not pack_of(Q):
+            raise RuntimeError("RankSelfAttnFn: the operand planes attached to the input are in another row layout than the input")
+        st = _rank_state(Wq, bq, Wk, H)
+        # q' = x W'^T + c as the fp16 plane the attention kernels read
+        qp = _alloc_planes(M, Dr, "f16only", dev, ld=Dr)
+        qp.pack = pack
+        gemm_bf16(xP, st.WpP, None, bias=st.c, out_planes=qp, precision=PREC_F16W2)
+        kP = Planes(None, None, M, d_in, fh=xP.fh, pack=pack)
+        scale = 1.0 / math.sqrt(dk)
+        op, lse = attn_fwd_planes(qp, kP, kP, B, S, S, Dr, mask, H, precision=pol.attn, out_fmt="f16", kv_shared=True, scale=scale)
+        # concat_h(O'_h W_v,h^T + b_v,h), dropout on the attention output (model/multihead_attention.py:22-23), as the out-projection's operand planes
+        o = _alloc_planes(M, D, act_fmt(pol.gemm), dev, ld=D)
+        o.pack = pack
+        gemm_bf16(op, _value_planes(Wq, bq, Wk, bk, Wv, bv, weight_fmt(PREC_F16W2)), None, bias=bv, out_planes=o, precision=PREC_F16W2, drop_post=True,
+                  drop_p=p, site=site, a_blk=(dk, d_in))
+        epi = {}
+        if res is not None:
+            r2 = _f32c(res).view(-1, d_in)
+            epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        opl = None
+        if out_fmt is not None and d_in % 64 == 0:
+            opl = _alloc_planes(M, d_in, out_fmt, dev)
+            epi["out_planes"] = opl
+        out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, S, d_in)
+        carry_pack(pack, out)
+        if opl is not None:
+            attach_planes(out, opl)
+        if res is not None:
+            request_grad_plane(out, res_p, res_site)
+        ctx.st, ctx.H, ctx.p, ctx.site, ctx.mask, ctx.pack = st, H, p, site, mask, pack
+        ctx.res = (res is not None, res_p, res_site)
+        ctx.dims = (B, S, d_in, D)
+        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        none = torch.empty(0, device=dev)
+        train = any(ctx.needs_input_grad)
+        ctx.save_for_backward(Wq, Wk, Wv, Wo, qp.fh, xP.fh, op.hi if train else none, op.fh if train else none, lse, o.hi if train else none,
+                              xP.hi if train else none)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Wq_, Wk_, Wv_, Wo_, qf, xf, oph, opf, lse, oh, xh = ctx.saved_tensors
+        st, H, p, pack = ctx.st, ctx.H, ctx.p, ctx.pack
+        B, S, d_in, D = ctx.dims
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo = ctx.params
+        dk, M, Dr = D // H, B * S, H * d_in
+        dev = dout.device
+        dy2 = _f32c(dout).view(-1, d_in)
+        has_res, res_p, res_site = ctx.res
+        drop = None
+        if has_res:
+            dy2, drop = drop_grad(dy2, bo, res_p, res_site)
+        # out-projection: dX with the attention-output dropout mask re-applied = gradient of concat_h(O_h); its column sums = db_v
+        P_, bias_done = grad_planes_from(dout, dy2, bo, drop, pack=pack) if has_res else grad_planes(dy2, bo, drop=drop, pack=pack)
+        gbv = static_grad(bv)
+        dbv_t = gbv if gbv is not None else (torch.zeros(D, device=dev, dtype=torch.float32) if bv is not None else None)
+        do = linear_dx(P_, Wo, out_planes=Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D, pack=pack), drop_post=True, drop_p=p,
+                       site=ctx.site, colsum=dbv_t)
+        if gbv is not None:
+            grad_done(bv)
+        dWo, dbo = wgrad(Wo, None if bias_done else bo, P_, Planes(oh, None, M, D, pack=pack), dy2_for_bias=dy2)
+        # dO'_h = dO_h W_v,h (a block product over W_v's bf16 plane, k-major: every head its own reduction rows); dW_v,h = dO_h^T O'_h
+        dop = Planes(torch.empty(M, Dr, device=dev, dtype=torch.bfloat16), None, M, Dr, pack=pack)
+        WvB = _value_planes(Wq, bq, Wk, bk, Wv, bv, "bwd")
+        gemm_bf16(do, Planes(WvB.hi, None, D, d_in), None, out_planes=dop, precision=PREC_BF16, b_km=True, a_blk=(d_in, dk), splitk=1)
+        oP = Planes(oph, None, M, Dr, fh=opf, pack=pack)
+        dWv = _blockdiag_dw(do, oP, Wv, H)
+        # attention backward against the shared plane: dq' | per-head dK' | per-head dV' in one [M][3 H d_in] plane, dc = column sums of dq'
+        qp = Planes(None, None, M, Dr, fh=qf, pack=pack)
+        kP = Planes(None, None, M, d_in, fh=xf, pack=pack)
+        res = attn_bwd_planes(qp, kP, kP, oP, dop, lse, B, S, S, Dr, ctx.mask, H, 0.0, (st.c if bq is not None else None, None, None), fuse="qkv",
+                              kv_shared=True, scale=1.0 / math.sqrt(dk))
+        (Pq, dc), comb = res[0], res[3]
+        xT = Planes(xh, None, M, d_in, pack=pack)
+        dQ = None
+        if ctx.needs_input_grad[0]:      # dx = dq' W' + sum_h (dK'_h + dV'_h): one product against [W' ; I-stack ; I-stack]
+            dx = torch.empty(M, d_in, device=dev, dtype=torch.float32)
+            gemm_bf16(comb, Planes(st.Wcomb, None, 3 * Dr, d_in), dx, ldc=d_in, precision=PREC_BF16, b_km=True)
+            dQ = dx.view(B, S, d_in)
+        # dW' = dq'^T x joins the pass's grouped weight-gradient launch; the chain rule through W' and c runs behind it (fp32, from the parameters)
+        gWq, gWk, gbq = static_grad(Wq), static_grad(Wk), static_grad(bq)
+        tq = gWq if gWq is not None else torch.zeros_like(Wq)
+        tk = gWk if gWk is not None else torch.zeros_like(Wk)
+        tb = (gbq if gbq is not None else torch.zeros_like(bq)) if bq is not None else None
+        static = [p_ for p_, g_ in ((Wq, gWq), (Wk, gWk), (bq, gbq)) if g_ is not None]
+        sctx = context()
+        deferred = sctx.defer_dw and len(static) == (3 if bq is not None else 2)      # (gradients handed back to autograd as tensors must be complete now)
+        was, sctx.defer_dw = sctx.defer_dw, deferred
+        try:
+            linear_dw(Pq, xT, into=st.dWp, params=static)
+        finally:
+            sctx.defer_dw = was
+        Wqd, Wkd = Wq.detach(), Wk.detach()
+
+        def chain():
+            _lib.check(lib.bmt_rank_chain(_p(Wqd), _p(Wkd), _p(bq.detach()) if bq is not None else None, Wqd.stride(0), H, dk, d_in, _p(st.dWp),
+                                          _p(dc) if bq is not None else None, _p(tq), _p(tk), _p(tb), tq.stride(0), _p(st.ticket), _st()), "bmt_rank_chain")
+        if deferred:
+            sctx.pending_post.append(chain)
+        else:
+            chain()
+        for p_ in static:
+            grad_done(p_)
+        dbk = None
+        if bk is not None:               # the key bias does not reach the output
+            if static_grad(bk) is not None:
+                grad_done(bk)
+            else:
+                dbk = torch.zeros_like(bk)
+        return (dQ, None, None, None, None if gWq is not None else tq, None if (gbq is not None or bq is None) else tb, None if gWk is not None else tk, dbk,
+                dWv, None if gbv is not None else dbv_t, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None, None)
 
 
 class FanoutFn(torch.autograd.Function):

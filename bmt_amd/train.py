@@ -164,6 +164,7 @@ class CaptioningTrainStep:
             sctx.defer_dw = False
             sctx.pending_dw.clear()
             sctx.pending_cs.clear()
+            sctx.pending_post.clear()
             sctx.gen_handles.clear()
             _ops.clear_step_start()
         return kl.detach(), n_tokens

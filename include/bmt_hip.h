@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 10
+#define BMT_ABI_VERSION 11
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -122,6 +122,11 @@ typedef struct {
      * only the first m_dev[0] of the M rows exist -- both read from device memory when the launch runs.  NULL = as before. */
     const int* c_row_dev;
     const int* m_dev;
+    /* ABI 11 -- BLOCK PRODUCTS (the value product of the rank-form self-attention, O_h = O'_h W_v,h^T: the heads' d_in-wide attention outputs
+     * sit side by side in A, every head multiplies its own row block of the weight): with a_blk_n > 0 the output columns
+     * [j a_blk_n, (j + 1) a_blk_n) read A's columns [j a_blk_k, (j + 1) a_blk_k) -- a_blk_k = Kpad = 128, a_blk_n a multiple of 128, row-major
+     * operands of a one- or two-plane fp16 / bf16 product (the reduction-of-128 kernel, whatever M).  0 = one product over all of A. */
+    int a_blk_n, a_blk_k;
 } bmt_gemm_bf16_args;
 int bmt_gemm_bf16(const bmt_gemm_bf16_args* args, void* stream);
 /* MANY independent single-pass GEMMs with both operands k-major and fp32 (accumulating) output in ONE launch -- the weight
@@ -173,6 +178,20 @@ typedef struct {
     int64_t a_qs, c_qs, p_qs, p2_qs;
 } bmt_gemm_batch;
 int bmt_gemm_small_batched(const bmt_gemm_bf16_args* args, const bmt_gemm_batch* batch, void* stream);
+/* ABI 11 -- the encoder's self-attention over an input narrower than a head (csrc/rank_attn.hip; model/multihead_attention.py:62-84 with
+ * d_model_Q = d_model_K = d_model_V = d_in <= d_k / 2): q_h, k_h, v_h are rank-d_in images of the same input x, so
+ *     S_h = (x W'_h^T + c_h) x^T (+ terms constant along the keys),  W'_h = W_k,h^T W_q,h [d_in][d_in],  c_h = b_q,h W_k,h;   O_h = (P_h x) W_v,h^T + b_v,h
+ * and the attention runs at width d_in against x itself (kv_shared).  The weight side, fp32 on the vector units from the fp32 parameters
+ * (W_q, W_k: [H dk][ldw], head h = rows [h dk, (h + 1) dk)):
+ *   bmt_rank_prep   W' [H d_in][d_in] (row h d_in + a = W'_h[a][.]) as bf16 / fp16 / fp16 lo planes of row stride ldp and / or fp32 (row stride
+ *                   d_in), each optional; c [H d_in] (zeros without a query bias), optional;
+ *   bmt_rank_chain  from dW' = dq'^T x (fp32 [H d_in][d_in]) and dc = column sums of dq' (or NULL):  dW_q,h += W_k,h dW'_h,
+ *                   dW_k,h += W_q,h dW'_h^T + b_q,h^T dc_h,  db_q,h += W_k,h dc_h  (row stride ldg; each output optional); dW' is zeroed by
+ *                   the last workgroup to finish (`ticket`: a device int32, zero before the first call, zero again after each). */
+int bmt_rank_prep(const float* Wq, const float* Wk, const float* bq, int64_t ldw, int H, int dk, int d_in, uint16_t* wp_bf16, uint16_t* wp_f16,
+                  uint16_t* wp_f16_lo, int64_t ldp, float* wp_f32, float* c, void* stream);
+int bmt_rank_chain(const float* Wq, const float* Wk, const float* bq, int64_t ldw, int H, int dk, int d_in, float* dWp, const float* dc,
+                   float* dWq, float* dWk, float* dbq, int64_t ldg, int* ticket, void* stream);
 /* ... and the kernels between those products (csrc/raw_memory.hip).  `off` = bmt_pack_rows' offsets of the memory (int32, off[b] = first
  * packed row of sample b, off[B] = the row count), Skp = the padded key extent of the per-sample buffers (a multiple of 64, >= every length):
  *   bmt_memory_transposed  packed fp16 plane X [rows][ld] -> xt_f16[b][d][k] = fp16(X) and xtc_bf[b][d][k] = bf16(X - mean key of sample b)

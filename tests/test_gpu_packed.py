@@ -415,6 +415,9 @@ def test_captured_step_prefetches_the_announced_batch(ops):
         losses[mode] = out
         step.uncapture()
     print("\nlosses:", losses)
+    # (a batch copied into the wrong step shows as another batch's loss -- they are 0.1 apart; two runs of the SAME mode differ by up to 2e-4 in the
+    # fourth step -- 0.88409 / 0.88429 / 0.88434 in six runs of "plain" -- because the grouped weight-gradient launch accumulates with atomics and
+    # Adam's first steps turn the rounding of a near-zero gradient into +- lr)
     for mode in ("prefetch", "wrong announcement"):
         for a, b in zip(losses["plain"], losses[mode]):
-            assert abs(a - b) < 1e-4 * max(1.0, abs(a)), losses
+            assert abs(a - b) < 1e-3 * max(1.0, abs(a)), losses
