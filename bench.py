@@ -108,6 +108,11 @@ class KernelTimer:
                 M = A.cols if akm else A.rows
                 N = B.cols if bkm else B.rows
                 K = A.rows if akm else (B.rows if bkm else A.cols)
+                blk = kw.get("a_blk")                         # a block product (ops.gemm_bf16): every output block reduces over ITS a_blk[1] indices
+                if blk is not None:
+                    if bkm:
+                        N = (K // blk[1]) * blk[0]
+                    K = blk[1]
             nb = ops.prec_operand_bytes(prec)
             cls = ("conv_planes_" if conv is not None else "gemm_planes_") + ops.prec_name(prec)
             op = kw.get("out_planes")          # output bytes per element: 4 for the fp32 tensor, 2 per 16-bit plane actually written
@@ -132,6 +137,14 @@ class KernelTimer:
                 return timer._timed("gemm_planes_memory_grad_grouped_bf16", 1, fl, by, lambda: raw_gg(items))
             return timer._timed("gemm_planes_dw_grouped_bf16", 1, fl, by, lambda: raw_gg(items), xflops=xfl, xbytes=xby)     # the step's weight gradients, one launch
 
+        def _rank_dims(D, H, kw):
+            """an attention launch in the rank form (ops.RankSelfAttnFn / RankCrossAttnFn: kv_shared, the softmax scale of the reference's head size):
+            (model width of the reference's formulation -- what the algorithmic FLOPs / bytes count --, width of the key / value plane read, class tag)"""
+            if not kw.get("kv_shared"):
+                return D, D, ""
+            dk_ref = int(round(1.0 / float(kw["scale"]) ** 2)) if kw.get("scale") else D // H
+            return H * dk_ref, D // H, f"_rank_of_dk{dk_ref}"
+
         def attn_fwd_planes(q, k, v, B_, Sq, Sk, D, mask, H, **kw):
             if not timer.enabled:
                 return raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw)
@@ -139,10 +152,11 @@ class KernelTimer:
             side = "enc" if min(Sq, Sk) >= 128 else "dec"
             nb = sum(ops.prec_operand_bytes(prec)) / 2.0          # operand plane bytes per element in, the same again out
             xqk, xq, xk = timer.xattn(B_, Sq, Sk, q.pack is not None, k.pack is not None)
-            return timer._timed(f"attn_fwd_{side}_dk{D // H}_{ops.prec_name(prec)}", ops.prec_passes(prec),
-                                4.0 * B_ * Sq * Sk * D, nb * B_ * D * (Sq + 2 * Sk) + 4.0 * B_ * D * Sq,
+            Dref, Dkv, tag = _rank_dims(D, H, kw)
+            return timer._timed(f"attn_fwd_{side}_dk{D // H}{tag}_{ops.prec_name(prec)}", ops.prec_passes(prec),
+                                4.0 * B_ * Sq * Sk * Dref, nb * B_ * Dref * (Sq + 2 * Sk) + 4.0 * B_ * Dref * Sq,
                                 lambda: raw_afp(q, k, v, B_, Sq, Sk, D, mask, H, **kw),
-                                xflops=4.0 * xqk * D, xbytes=nb * D * (xq + 2 * xk) + 4.0 * D * xq)
+                                xflops=4.0 * xqk * D, xbytes=nb * (D * xq + 2 * Dkv * xk) + 4.0 * D * xq)
 
         def attn_bwd_planes(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw):
             if not timer.enabled:
@@ -153,10 +167,11 @@ class KernelTimer:
             split = ops.ATTN_BWD_SPLIT and q.hi is None and Sq >= 64 and D // H >= 128       # (ops._attn_split_ws / bmt_attn_bwd_split_ws)
             form = ("f16+bf16_recompute" if ops.ATTN_BWD_RECOMPUTE and Sq <= 2048 else "f16+bf16_split") if split else "bf16"
             xqk, xq, xk = timer.xattn(B_, Sq, Sk, q.pack is not None, k.pack is not None)
-            return timer._timed(f"attn_bwd_{side}_dk{D // H}_" + form, 1, 10.0 * B_ * Sq * Sk * D,
-                                B_ * D * (2.0 * (Sq + 2 * Sk) + 6.0 * Sq + 2.0 * (Sq + 2 * Sk)),
+            Dref, Dkv, tag = _rank_dims(D, H, kw)
+            return timer._timed(f"attn_bwd_{side}_dk{D // H}{tag}_" + form, 1, 10.0 * B_ * Sq * Sk * Dref,
+                                B_ * Dref * (2.0 * (Sq + 2 * Sk) + 6.0 * Sq + 2.0 * (Sq + 2 * Sk)),
                                 lambda: raw_abp(q, k, v, o, do, lse, B_, Sq, Sk, D, mask, H, drop_p, biases, **kw),
-                                xflops=10.0 * xqk * D, xbytes=D * (2.0 * (xq + 2 * xk) + 6.0 * xq + 2.0 * (xq + 2 * xk)))
+                                xflops=10.0 * xqk * D, xbytes=2.0 * (D * xq + 2 * Dkv * xk) + 6.0 * D * xq + 2.0 * D * (xq + 2 * xk))
 
         raw_gbt = ops.gemm_batched
 
@@ -1168,6 +1183,9 @@ def main():
                     "executed": xalg / (ms * 1e-3) / 1e12, "frac_executed": xalg / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
                     # the same time against SURVEY.md 8d's own count (backward = 2 x forward: 4 products, the recomputed S = Q K^T not counted)
                     "frac_algorithmic_bwd_2x_fwd": alg2 / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    "rank_form": "the audio self-attention and the video stream's attention over the audio stream run at the key / value input's width "
+                                 "(128) against that input as the heads' shared key / value plane (classes *_rank_of_dk256): algorithmic = the reference's "
+                                 "formulation at d_k 256, executed / issued = the products the kernels run (half the width)",
                     "flop_conventions": "frac_algorithmic: forward 2 products + backward 5 (incl. the recomputed scores) over PADDED (B, S, S) -- "
                                         "padding is not computed under packed rows; frac_algorithmic_bwd_2x_fwd: backward counted as 4 products; "
                                         "executed / frac_executed: the same 2 + 5 products over sum_b Lq_b Lk_b of the kernel timer's batch; "

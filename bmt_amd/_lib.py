@@ -104,8 +104,8 @@ SIGNATURES = {
     "bmt_gemm_bf16_grouped_ws_bytes": (C.c_size_t, [i32]),
     "bmt_gemm_small_outputs": (C.c_longlong, []),
     "bmt_gemm_small_batched": (i32, [C.POINTER(GemmBf16Args), C.POINTER(GemmBatch), vp]),
-    "bmt_rank_prep": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp]),
-    "bmt_rank_chain": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]),
+    "bmt_rank_prep": (i32, [vp, i64, i32, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "bmt_rank_chain": (i32, [vp, i64, i32, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp, i64, vp, vp]),
     "bmt_memory_transposed": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp, vp]),
     "bmt_raw_softmax_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp]),
     "bmt_raw_softmax_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, i64, i64, vp]),

@@ -83,8 +83,9 @@ class MultiheadedAttention(nn.Module):
         if K is V and ops.raw_form_ok(getattr(K, "_bmt_rawmem", None), Q, self, pol):
             fn = ops.RawCrossAttnFn
         elif ops.rank_form_ok(Q, K, V, self, pol):
-            # a self-attention over an input narrower than a head (the encoder's audio stream): the input itself is the key / value plane
-            fn = ops.RankSelfAttnFn
+            # keys = values narrower than a head (the encoder's audio stream, attended by itself or by the video stream): that input itself is
+            # the key / value plane of every head
+            fn = ops.RankSelfAttnFn if Q is K else ops.RankCrossAttnFn
         else:
             fn = ops.MHAFn
         off = ops.take_residual()        # an enclosing ResidualConnection offers x, p, site: fused into the out-projection

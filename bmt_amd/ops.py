@@ -125,8 +125,12 @@ def precision_description(procedure: Optional[str] = None) -> str:
     raw = globals().get("RAW_MEMORY", False)
     mem = (f"the decoder's cross-attentions run against the raw encoder memories (no K/V projections: per-head block products {prec_name(x.gemm)}, "
            f"the two products against the memory {prec_name(e.attn)})" if raw else f"decoder memory K/V projections {prec_name(e.gemm)}")
+    rank = ""
+    if globals().get("RANK_ATTN", False):
+        rank = (" -- the attentions over the 128-wide audio stream (its self-attention" + (", the video stream's attention over it" if globals().get("RANK_CROSS", False) else "") +
+                f") in the rank form: queries through W' = W_k^T W_q ({prec_name(e.gemm)}, built in fp32 once per step), keys = values = the stream's own fp16 plane")
     return (f"MFMA operands per site: encoder GEMMs {prec_name(e.gemm)} ({prec_passes(e.gemm)} passes{ffn2}), {mem}, "
-            f"attention forward {prec_name(e.attn)} (1 pass), decoder GEMMs / bridge / generator {prec_name(x.gemm)} (3 passes), backward "
+            f"attention forward {prec_name(e.attn)} (1 pass){rank}, decoder GEMMs / bridge / generator {prec_name(x.gemm)} (3 passes), backward "
             f"{prec_name(BWD_PRECISION)} (1 pass; the encoder's attention backward on fp16 q / k / v with power-of-two scaled fp16 gradients); "
             f"fp32 accumulate, softmax, LayerNorm, loss, Adam")
 
@@ -161,7 +165,7 @@ class StepContext:
     """state that belongs to ONE forward / backward pass in flight: keyed by (device, stream), so two models stepping from two
     threads on two streams (or nn.DataParallel replicas on their devices) do not see each other's -- and found again from
     autograd's backward threads, which run a node on the stream its forward ran on."""
-    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "pending_post", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
+    __slots__ = ("defer_dw", "pending_dw", "pending_ids", "pending_done", "pending_cs", "pending_post", "pending_side", "res_offer", "last_ln", "kv_cache", "allow_streams", "last_gen", "gen_handles",
                  "step_start", "planes_ready", "planes_waited", "deferred", "deferred_join")
 
     def __init__(self):
@@ -169,7 +173,9 @@ class StepContext:
         self.pending_dw = []
         self.pending_ids = set()     # parameters whose gradient product is queued: their "gradient final" report waits for the flush
         self.pending_done = []
-        self.pending_post = []       # launches that read a queued product's result (the rank-form attention's chain rule through W'): run by flush_dw behind the grouped launch
+        self.pending_post = []       # launches that read a queued product's result: run by flush_dw behind the grouped launch
+        self.pending_side = []       # (product item, follow-up launch) pairs that run BESIDE the grouped launch, on the auxiliary stream: the rank-form
+                                     # attentions' dW' = dq'^T y and the chain rule through W' behind it -- small, serial, and everything waits for them
         self.pending_cs = []         # queued column-sum reductions (LayerNorm dgamma / dbeta partials, attention bias partials): colsum_multi
         self.res_offer = None        # residual offered by a ResidualConnection to its sublayer's last GEMM
         self.last_ln = None          # operand planes written by the LayerNorm kernel that just ran
@@ -1190,15 +1196,25 @@ def flush_dw():
     done, ctx.pending_done = ctx.pending_done, []
     ctx.pending_ids.clear()
     cs, ctx.pending_cs = ctx.pending_cs, []
+    side, ctx.pending_side = ctx.pending_side, []
+
+    def run_side():           # one small grouped launch over the side products, then their follow-ups
+        if side:
+            gemm_bf16_grouped([it for it, _ in side])
+            for _, fn in side:
+                fn()
     # the queued column sums (LayerNorm / bias partials -> their gradients) touch nothing the weight-gradient products touch: beside the grouped
-    # launch on the auxiliary stream instead of alone behind it (45 us with one kernel in flight, profiles/r06_n_replay_dispatches.csv)
-    aux = _aux_stream() if (cs and len(items) > 1 and GROUPED_DW and COLSUM_BESIDE_DW) else None
+    # launch on the auxiliary stream instead of alone behind it (45 us with one kernel in flight, profiles/r06_n_replay_dispatches.csv); so do
+    # the side products and what follows them (the rank-form attentions' chain rule: ~150 us behind the launch, profiles/r06_rank_f_timeline.txt)
+    aux = _aux_stream() if ((cs or side) and len(items) > 1 and GROUPED_DW and COLSUM_BESIDE_DW) else None
     if aux is not None:
         cur = torch.cuda.current_stream()
         aux.wait_stream(cur)
         with torch.cuda.stream(aux):
-            _colsum_launch(cs)
-        cs = []
+            run_side()
+            if cs:
+                _colsum_launch(cs)
+        cs, side = [], []
     if items:
         if len(items) == 1 or not GROUPED_DW:
             for dyT, xT, into in items:
@@ -1208,11 +1224,12 @@ def flush_dw():
             gemm_bf16_grouped(items)
     if aux is not None:
         cur.wait_stream(aux)
+    run_side()
     if cs:
         _colsum_launch(cs)
     post, ctx.pending_post = ctx.pending_post, []
-    for fn in post:           # launches that read what the products above wrote
-        fn()
+    for fn in post:           # launches that read what the products above wrote (side by side on streams of their own they finish no earlier: 6.64 / 6.63
+        fn()                  # against 6.64 / 6.62 ms, profiles/r06_rank_ab6.txt)
     for p in done:            # their products are on the stream now: the reducer may launch the bucket's all-reduce behind them
         grad_done(p)
     hs, ctx.gen_handles = ctx.gen_handles, []
@@ -3002,11 +3019,12 @@ class RawCrossAttnFn(torch.autograd.Function):
 # come from ONE item of the step's grouped weight-gradient launch (dW') and one fp32 kernel behind it (bmt_rank_chain).  The key bias drops
 # out (its gradient is exactly zero, as the reference's is up to rounding).
 RANK_ATTN = True
+RANK_CROSS = True       # ... and a cross-attention over such an input (the video stream's attention over the audio stream): RankCrossAttnFn
 _rank_states = {}
 
 
 class _RankState:
-    __slots__ = ("refs", "epoch", "c", "WpP", "Wcomb", "dWp", "ticket", "H", "d_in", "dk")
+    __slots__ = ("refs", "epoch", "c", "WpP", "Wcomb", "Istack", "dWp", "dirty", "H", "d_a", "d_b", "dk")
 
 
 def _rank_prep(st: "_RankState") -> bool:
@@ -3015,9 +3033,10 @@ def _rank_prep(st: "_RankState") -> bool:
     if Wq is None or Wk is None:
         return False
     Wqd, Wkd = Wq.detach(), Wk.detach()
-    _lib.check(lib.bmt_rank_prep(_p(Wqd), _p(Wkd), _p(bq.detach()) if bq is not None else None, Wqd.stride(0), st.H, st.dk, st.d_in, _p(st.WpP.hi),
-                                 _p(st.WpP.fh), _p(st.WpP.fl), st.d_in, None, _p(st.c), _st()), "bmt_rank_prep")
+    _lib.check(lib.bmt_rank_prep(_p(Wqd), Wqd.stride(0), st.d_b, _p(Wkd), Wkd.stride(0), _p(bq.detach()) if bq is not None else None, st.H, st.dk, st.d_a,
+                                 _p(st.WpP.hi), _p(st.WpP.fh), _p(st.WpP.fl), st.d_b, None, _p(st.c), _p(st.dWp), _st()), "bmt_rank_prep")
     st.epoch = WEIGHT_EPOCH[0]
+    st.dirty = False                 # (the same launch zeroed dW', the accumulator of the pass to come)
     return True
 
 
@@ -3029,36 +3048,45 @@ def _rank_refresh_all():
 
 
 def rank_form_ok(Q, K, V, mha, pol) -> bool:
-    """does this MultiheadedAttention call take the rank form?  Self-attention over a CUDA input of 128 columns, at most half a head, under the
-    encoder's operand policy"""
-    if not (RANK_ATTN and Q is K and K is V and isinstance(Q, torch.Tensor) and Q.is_cuda and Q.dim() == 3):
+    """does this MultiheadedAttention call take the rank form?  Keys = values = a CUDA input of 128 columns, at most half a head -- the queries
+    the same tensor (self-attention) or another stream of a multiple of 128 columns --, under the encoder's operand policy"""
+    if not (RANK_ATTN and K is V and isinstance(K, torch.Tensor) and K.is_cuda and K.dim() == 3 and isinstance(Q, torch.Tensor) and Q.dim() == 3):
         return False
-    d_in, D, H = mha.d_model_Q, mha.d_model, mha.H
-    return (d_in == 128 and D % H == 0 and 2 * d_in <= D // H and (D // H) % 128 == 0 and mha.d_model_K == d_in and mha.d_model_V == d_in and
-            pol.gemm == PREC_F16W2 and pol.attn == PREC_F16 and QKV_F16_ONLY and context().kv_cache is None)
+    d_a, D, H = mha.d_model_K, mha.d_model, mha.H
+    if Q is not K and not (RANK_CROSS and mha.d_model_Q % 128 == 0 and getattr(K, "_bmt_rawmem", None) is None):
+        return False
+    return (d_a == 128 and D % H == 0 and 2 * d_a <= D // H and (D // H) % 128 == 0 and mha.d_model_V == d_a and (Q is not K or mha.d_model_Q == d_a) and
+            pol.gemm == PREC_F16W2 and pol.kv_gemm == PREC_F16W2 and pol.attn == PREC_F16 and QKV_F16_ONLY and context().kv_cache is None)
 
 
 def _rank_state(Wq, bq, Wk, H) -> "_RankState":
     import weakref
     key = (id(Wq), id(Wk))
     st = _rank_states.get(key)
-    D, d_in = Wq.shape
-    dk = D // H
+    D, d_b = Wq.shape
+    d_a = Wk.shape[1]
+    dk, Dr = D // H, H * d_a
     dev = Wq.device
     if st is None or any(r() is not w for r, w in zip(st.refs, (Wq, Wk))):
         st = _RankState()
         st.refs = [weakref.ref(Wq), weakref.ref(Wk), weakref.ref(bq) if bq is not None else None]
-        st.H, st.d_in, st.dk, st.epoch = H, d_in, dk, -1
-        st.c = torch.zeros(H * d_in, device=dev, dtype=torch.float32)
-        # W' as the forward's two-plane operand (fh + fl) and, bf16, as the first H d_in rows of the combined dX weight [W' ; I-stack ; I-stack]
-        st.Wcomb = torch.zeros(3 * H * d_in, d_in, device=dev, dtype=torch.bfloat16)
-        eye = torch.eye(d_in, device=dev, dtype=torch.bfloat16).repeat(H, 1)
-        st.Wcomb[H * d_in:2 * H * d_in] = eye
-        st.Wcomb[2 * H * d_in:] = eye
-        st.WpP = Planes(st.Wcomb[:H * d_in], None, H * d_in, d_in, fh=torch.empty(H * d_in, d_in, device=dev, dtype=torch.float16),
-                        fl=torch.empty(H * d_in, d_in, device=dev, dtype=torch.float16))
-        st.dWp = torch.zeros(H * d_in, d_in, device=dev, dtype=torch.float32)      # dW' accumulates here; bmt_rank_chain zeroes it again
-        st.ticket = torch.zeros(1, device=dev, dtype=torch.int32)
+        st.H, st.d_a, st.d_b, st.dk, st.epoch = H, d_a, d_b, dk, -1
+        st.c = torch.zeros(Dr, device=dev, dtype=torch.float32)
+        eye = torch.eye(d_a, device=dev, dtype=torch.bfloat16).repeat(2 * H, 1)
+        if d_b == d_a:
+            # self-attention: W' (bf16) is the first H d_a rows of the combined dX weight [W' ; I-stack ; I-stack]
+            st.Wcomb = torch.zeros(3 * Dr, d_a, device=dev, dtype=torch.bfloat16)
+            st.Wcomb[Dr:] = eye
+            hi, st.Istack = st.Wcomb[:Dr], None
+        else:
+            st.Wcomb, st.Istack = None, eye      # dx of the key / value input = sum_h (dK'_h + dV'_h): a product against the identity stack
+            hi = torch.empty(Dr, d_b, device=dev, dtype=torch.bfloat16)
+        # W' as the forward's two-plane operand (fh + fl) and, bf16, as the k-major operand of dy = dq' W'
+        st.WpP = Planes(hi, None, Dr, d_b, fh=torch.empty(Dr, d_b, device=dev, dtype=torch.float16), fl=torch.empty(Dr, d_b, device=dev, dtype=torch.float16))
+        # dW' of a pass that queues its weight-gradient products accumulates here: zeroed by bmt_rank_prep, i.e. once per optimizer step (dirty =
+        # a pass has used it since: another one before the next refresh takes a buffer of its own)
+        st.dWp = torch.zeros(Dr, d_b, device=dev, dtype=torch.float32)
+        st.dirty = False
         _rank_states[key] = st
         if len(_rank_states) > 256:
             for k_ in [k_ for k_, v_ in _rank_states.items() if any(r is not None and r() is None for r in v_.refs)]:
@@ -3073,14 +3101,48 @@ def _rank_state(Wq, bq, Wk, H) -> "_RankState":
     return st
 
 
+def _rank_weight_grads(st, Pq: Planes, yT: Planes, dc, Wq, bq, Wk):
+    """dW' = dq'^T y into the pass's grouped weight-gradient launch, and behind it the chain rule through W' and c (bmt_rank_chain: fp32, from
+    the parameters) into the gradients of W_q, b_q, W_k -- their static buffers, or fresh tensors (returned: (dW_q, db_q, dW_k), None = accumulated)"""
+    gWq, gWk, gbq = static_grad(Wq), static_grad(Wk), static_grad(bq)
+    tq = gWq if gWq is not None else torch.zeros_like(Wq)
+    tk = gWk if gWk is not None else torch.zeros_like(Wk)
+    tb = (gbq if gbq is not None else torch.zeros_like(bq)) if bq is not None else None
+    static = [p_ for p_, g_ in ((Wq, gWq), (Wk, gWk), (bq, gbq)) if g_ is not None]
+    sctx = context()
+    # (gradients handed back to autograd as tensors must be complete now; so must a second pass over the module within one optimizer step)
+    deferred = sctx.defer_dw and len(static) == (3 if bq is not None else 2) and not st.dirty
+    acc = st.dWp if deferred else torch.zeros_like(st.dWp)
+    Wqd, Wkd = Wq.detach(), Wk.detach()
+
+    def chain():
+        _lib.check(lib.bmt_rank_chain(_p(Wqd), Wqd.stride(0), st.d_b, _p(Wkd), Wkd.stride(0), _p(bq.detach()) if bq is not None else None, st.H, st.dk, st.d_a,
+                                      _p(acc), _p(dc) if bq is not None else None, _p(tq), tq.stride(0), _p(tk), tk.stride(0), _p(tb), _st()), "bmt_rank_chain")
+    if deferred:                     # dW' and the chain rule behind it run beside the pass's grouped weight-gradient launch (flush_dw)
+        sctx.pending_side.append(((Pq, yT, acc), chain))
+        sctx.pending_ids.update(id(p_) for p_ in static)
+        st.dirty = True
+    else:
+        was, sctx.defer_dw = sctx.defer_dw, False
+        try:
+            linear_dw(Pq, yT, into=acc)
+        finally:
+            sctx.defer_dw = was
+        chain()
+    for p_ in static:
+        grad_done(p_)
+    return None if gWq is not None else tq, None if (gbq is not None or bq is None) else tb, None if gWk is not None else tk
+
+
 def _value_planes(Wq, bq, Wk, bk, Wv, bv, fmt: str) -> Planes:
-    """W_v's operand planes [D][d_in]: its rows of the module's projection group (what the projected form registers: either form may meet the
-    weights first), or its own planes where projections are not grouped"""
-    grp = weight_group((Wq, Wk, Wv), (bq, bk, bv), fmt)
+    """W_v's operand planes [D][d_a]: its rows of the module's projection group -- q | k | v of a self-attention, k | v of a cross-attention (Wq None):
+    what the projected form registers, either form may meet the weights first --, or its own planes where projections are not grouped"""
+    Ws, bs = ((Wq, Wk, Wv), (bq, bk, bv)) if Wq is not None else ((Wk, Wv), (bk, bv))
+    grp = weight_group(Ws, bs, fmt)
     if grp is None:
         return weight_planes(Wv, fmt)
-    g, D = grp[0], Wv.shape[0]
-    sl = lambda t: None if t is None else t[2 * D:3 * D]
+    g, D, r0 = grp[0], Wv.shape[0], (len(Ws) - 1) * Wv.shape[0]
+    sl = lambda t: None if t is None else t[r0:r0 + D]
     return Planes(sl(g.hi), sl(g.lo), D, Wv.shape[1], fh=sl(g.fh), fl=sl(g.fl))
 
 
@@ -3182,37 +3244,130 @@ class RankSelfAttnFn(torch.autograd.Function):
             gemm_bf16(comb, Planes(st.Wcomb, None, 3 * Dr, d_in), dx, ldc=d_in, precision=PREC_BF16, b_km=True)
             dQ = dx.view(B, S, d_in)
         # dW' = dq'^T x joins the pass's grouped weight-gradient launch; the chain rule through W' and c runs behind it (fp32, from the parameters)
-        gWq, gWk, gbq = static_grad(Wq), static_grad(Wk), static_grad(bq)
-        tq = gWq if gWq is not None else torch.zeros_like(Wq)
-        tk = gWk if gWk is not None else torch.zeros_like(Wk)
-        tb = (gbq if gbq is not None else torch.zeros_like(bq)) if bq is not None else None
-        static = [p_ for p_, g_ in ((Wq, gWq), (Wk, gWk), (bq, gbq)) if g_ is not None]
-        sctx = context()
-        deferred = sctx.defer_dw and len(static) == (3 if bq is not None else 2)      # (gradients handed back to autograd as tensors must be complete now)
-        was, sctx.defer_dw = sctx.defer_dw, deferred
-        try:
-            linear_dw(Pq, xT, into=st.dWp, params=static)
-        finally:
-            sctx.defer_dw = was
-        Wqd, Wkd = Wq.detach(), Wk.detach()
-
-        def chain():
-            _lib.check(lib.bmt_rank_chain(_p(Wqd), _p(Wkd), _p(bq.detach()) if bq is not None else None, Wqd.stride(0), H, dk, d_in, _p(st.dWp),
-                                          _p(dc) if bq is not None else None, _p(tq), _p(tk), _p(tb), tq.stride(0), _p(st.ticket), _st()), "bmt_rank_chain")
-        if deferred:
-            sctx.pending_post.append(chain)
-        else:
-            chain()
-        for p_ in static:
-            grad_done(p_)
+        dWq, dbq, dWk = _rank_weight_grads(st, Pq, xT, dc, Wq, bq, Wk)
         dbk = None
         if bk is not None:               # the key bias does not reach the output
             if static_grad(bk) is not None:
                 grad_done(bk)
             else:
                 dbk = torch.zeros_like(bk)
-        return (dQ, None, None, None, None if gWq is not None else tq, None if (gbq is not None or bq is None) else tb, None if gWk is not None else tk, dbk,
-                dWv, None if gbv is not None else dbv_t, dWo, dbo, None, None, None, None, (dout if has_res else None), None, None, None)
+        return (dQ, None, None, None, dWq, dbq, dWk, dbk, dWv, None if gbv is not None else dbv_t, dWo, dbo, None, None, None, None,
+                (dout if has_res else None), None, None, None)
+
+
+class RankCrossAttnFn(torch.autograd.Function):
+    """MultiheadedAttention.forward (model/multihead_attention.py:55-86) for an attention over keys = values narrower than a head from queries of
+    another stream (the video stream's attention over the 128-wide audio stream, model/encoders.py:69-79), in the reassociated form above:
+    q' = y W'^T + c with W'_h = W_k,h^T W_q,h [d_a][d_q] -- HALF the query projection's columns --, the attention at width d_a against the audio
+    stream's own plane, no key / value projections.  Same arguments as MHAFn (K is V)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H, p, site, pol, res=None, res_p=0.0, res_site=0, out_fmt=None):
+        note_use(Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        Qc, Kc = _f32c(Q), _f32c(K)
+        B, Sq, Dq = Qc.shape
+        Sk, d_a = Kc.shape[1], Kc.shape[2]
+        D = Wq.shape[0]
+        dk, Mq, Mk, Dr = D // H, B * Sq, B * Sk, H * d_a
+        dev = Qc.device
+        qpack, kpack = _check_pack(pack_of(Q), Mq), _check_pack(pack_of(K), Mk)
+
+        def planes(orig, x3d, fmt, pk):
+            pl = planes_of(orig, fmt)
+            if pl is None:
+                _need_fp32(orig)
+                pl = make_planes(x3d.view(-1, x3d.shape[-1]), fmt, pack=pack_of(orig))
+                attach_planes(orig, pl)
+            if pl.pack is not pack_of(orig):
+                raise RuntimeError("RankCrossAttnFn: the operand planes attached to an input are in another row layout than the input")
+            return pl
+        yP = planes(Q, Qc, act_fmt(pol.gemm), qpack)
+        xP = planes(K, Kc, "f16", kpack)
+        st = _rank_state(Wq, bq, Wk, H)
+        qp = _alloc_planes(Mq, Dr, "f16only", dev, ld=Dr)
+        qp.pack = qpack
+        gemm_bf16(yP, st.WpP, None, bias=st.c, out_planes=qp, precision=PREC_F16W2)
+        kP = Planes(None, None, Mk, d_a, fh=xP.fh, pack=kpack)
+        scale = 1.0 / math.sqrt(dk)
+        op, lse = attn_fwd_planes(qp, kP, kP, B, Sq, Sk, Dr, mask, H, precision=pol.attn, out_fmt="f16", kv_shared=True, scale=scale)
+        o = _alloc_planes(Mq, D, act_fmt(pol.gemm), dev, ld=D)
+        o.pack = qpack
+        gemm_bf16(op, _value_planes(None, None, Wk, bk, Wv, bv, weight_fmt(PREC_F16W2)), None, bias=bv, out_planes=o, precision=PREC_F16W2, drop_post=True,
+                  drop_p=p, site=site, a_blk=(dk, d_a))
+        epi = {}
+        if res is not None:
+            r2 = _f32c(res).view(-1, Dq)
+            epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
+        opl = None
+        if out_fmt is not None and Dq % 64 == 0:
+            opl = _alloc_planes(Mq, Dq, out_fmt, dev)
+            epi["out_planes"] = opl
+        out = linear_fwd(o, Wo, bo, precision=pol.gemm, **epi).view(B, Sq, Dq)
+        carry_pack(qpack, out)
+        if opl is not None:
+            attach_planes(out, opl)
+        if res is not None:
+            request_grad_plane(out, res_p, res_site)
+        ctx.st, ctx.H, ctx.p, ctx.site, ctx.mask, ctx.packs = st, H, p, site, mask, (qpack, kpack)
+        ctx.res = (res is not None, res_p, res_site)
+        ctx.dims = (B, Sq, Sk, Dq, d_a, D)
+        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        none = torch.empty(0, device=dev)
+        train = any(ctx.needs_input_grad)
+        ctx.save_for_backward(Wq, Wk, Wv, Wo, qp.fh, xP.fh, op.hi if train else none, op.fh if train else none, lse, o.hi if train else none,
+                              yP.hi if train else none)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Wq_, Wk_, Wv_, Wo_, qf, xf, oph, opf, lse, oh, yh = ctx.saved_tensors
+        st, H, p = ctx.st, ctx.H, ctx.p
+        qpack, kpack = ctx.packs
+        B, Sq, Sk, Dq, d_a, D = ctx.dims
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo = ctx.params
+        dk, Mq, Mk, Dr = D // H, B * Sq, B * Sk, H * d_a
+        dev = dout.device
+        dy2 = _f32c(dout).view(-1, Dq)
+        has_res, res_p, res_site = ctx.res
+        drop = None
+        if has_res:
+            dy2, drop = drop_grad(dy2, bo, res_p, res_site)
+        P_, bias_done = grad_planes_from(dout, dy2, bo, drop, pack=qpack) if has_res else grad_planes(dy2, bo, drop=drop, pack=qpack)
+        gbv = static_grad(bv)
+        dbv_t = gbv if gbv is not None else (torch.zeros(D, device=dev, dtype=torch.float32) if bv is not None else None)
+        do = linear_dx(P_, Wo, out_planes=Planes(torch.empty(Mq, D, device=dev, dtype=torch.bfloat16), None, Mq, D, pack=qpack), drop_post=True, drop_p=p,
+                       site=ctx.site, colsum=dbv_t)
+        if gbv is not None:
+            grad_done(bv)
+        dWo, dbo = wgrad(Wo, None if bias_done else bo, P_, Planes(oh, None, Mq, D, pack=qpack), dy2_for_bias=dy2)
+        dop = Planes(torch.empty(Mq, Dr, device=dev, dtype=torch.bfloat16), None, Mq, Dr, pack=qpack)
+        WvB = _value_planes(None, None, Wk, bk, Wv, bv, "bwd")
+        gemm_bf16(do, Planes(WvB.hi, None, D, d_a), None, out_planes=dop, precision=PREC_BF16, b_km=True, a_blk=(d_a, dk), splitk=1)
+        oP = Planes(oph, None, Mq, Dr, fh=opf, pack=qpack)
+        dWv = _blockdiag_dw(do, oP, Wv, H)
+        qp = Planes(None, None, Mq, Dr, fh=qf, pack=qpack)
+        kP = Planes(None, None, Mk, d_a, fh=xf, pack=kpack)
+        res = attn_bwd_planes(qp, kP, kP, oP, dop, lse, B, Sq, Sk, Dr, ctx.mask, H, 0.0, (st.c if bq is not None else None, None, None), fuse="kv",
+                              kv_shared=True, scale=1.0 / math.sqrt(dk))
+        (Pq, dc), comb = res[0], res[3]
+        dQ = dK = None
+        if ctx.needs_input_grad[0]:      # dy = dq' W'
+            dxq = torch.empty(Mq, Dq, device=dev, dtype=torch.float32)
+            gemm_bf16(Pq, Planes(st.WpP.hi, None, Dr, Dq), dxq, ldc=Dq, precision=PREC_BF16, b_km=True)
+            dQ = dxq.view(B, Sq, Dq)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:      # dx = sum_h (dK'_h + dV'_h): [Mk][2 H d_a] against the identity stack
+            dxk = torch.empty(Mk, d_a, device=dev, dtype=torch.float32)
+            gemm_bf16(comb, Planes(st.Istack, None, 2 * Dr, d_a), dxk, ldc=d_a, precision=PREC_BF16, b_km=True)
+            dK = dxk.view(B, Sk, d_a)    # (autograd adds dK and dV for the shared tensor; dV stays None)
+        dWq, dbq, dWk = _rank_weight_grads(st, Pq, Planes(yh, None, Mq, Dq, pack=qpack), dc, Wq, bq, Wk)
+        dbk = None
+        if bk is not None:               # the key bias does not reach the output
+            if static_grad(bk) is not None:
+                grad_done(bk)
+            else:
+                dbk = torch.zeros_like(bk)
+        return (dQ, dK, None, None, dWq, dbq, dWk, dbk, dWv, None if gbv is not None else dbv_t, dWo, dbo, None, None, None, None,
+                (dout if has_res else None), None, None, None)
 
 
 class FanoutFn(torch.autograd.Function):

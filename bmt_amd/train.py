@@ -165,6 +165,7 @@ class CaptioningTrainStep:
             sctx.pending_dw.clear()
             sctx.pending_cs.clear()
             sctx.pending_post.clear()
+            sctx.pending_side.clear()
             sctx.gen_handles.clear()
             _ops.clear_step_start()
         return kl.detach(), n_tokens

@@ -178,20 +178,22 @@ typedef struct {
     int64_t a_qs, c_qs, p_qs, p2_qs;
 } bmt_gemm_batch;
 int bmt_gemm_small_batched(const bmt_gemm_bf16_args* args, const bmt_gemm_batch* batch, void* stream);
-/* ABI 11 -- the encoder's self-attention over an input narrower than a head (csrc/rank_attn.hip; model/multihead_attention.py:62-84 with
- * d_model_Q = d_model_K = d_model_V = d_in <= d_k / 2): q_h, k_h, v_h are rank-d_in images of the same input x, so
- *     S_h = (x W'_h^T + c_h) x^T (+ terms constant along the keys),  W'_h = W_k,h^T W_q,h [d_in][d_in],  c_h = b_q,h W_k,h;   O_h = (P_h x) W_v,h^T + b_v,h
- * and the attention runs at width d_in against x itself (kv_shared).  The weight side, fp32 on the vector units from the fp32 parameters
- * (W_q, W_k: [H dk][ldw], head h = rows [h dk, (h + 1) dk)):
- *   bmt_rank_prep   W' [H d_in][d_in] (row h d_in + a = W'_h[a][.]) as bf16 / fp16 / fp16 lo planes of row stride ldp and / or fp32 (row stride
- *                   d_in), each optional; c [H d_in] (zeros without a query bias), optional;
- *   bmt_rank_chain  from dW' = dq'^T x (fp32 [H d_in][d_in]) and dc = column sums of dq' (or NULL):  dW_q,h += W_k,h dW'_h,
- *                   dW_k,h += W_q,h dW'_h^T + b_q,h^T dc_h,  db_q,h += W_k,h dc_h  (row stride ldg; each output optional); dW' is zeroed by
- *                   the last workgroup to finish (`ticket`: a device int32, zero before the first call, zero again after each). */
-int bmt_rank_prep(const float* Wq, const float* Wk, const float* bq, int64_t ldw, int H, int dk, int d_in, uint16_t* wp_bf16, uint16_t* wp_f16,
-                  uint16_t* wp_f16_lo, int64_t ldp, float* wp_f32, float* c, void* stream);
-int bmt_rank_chain(const float* Wq, const float* Wk, const float* bq, int64_t ldw, int H, int dk, int d_in, float* dWp, const float* dc,
-                   float* dWq, float* dWk, float* dbq, int64_t ldg, int* ticket, void* stream);
+/* ABI 11 -- attention whose keys and values are narrower than a head (csrc/rank_attn.hip; model/multihead_attention.py:62-84 with
+ * d_model_K = d_model_V = d_a <= d_k / 2: the encoder's audio self-attention and the video stream's attention over the audio stream): k_h and
+ * v_h are rank-d_a images of the key / value input x, so with queries projected from y (d_b columns; y = x for the self-attention)
+ *     S_h = (y W'_h^T + c_h) x^T (+ terms constant along the keys),  W'_h = W_k,h^T W_q,h [d_a][d_b],  c_h = b_q,h W_k,h;   O_h = (P_h x) W_v,h^T + b_v,h
+ * and the attention runs at width d_a against x itself (kv_shared).  The weight side, fp32 on the vector units from the fp32 parameters
+ * (W_q [H dk][ldq >= d_b], W_k [H dk][ldk >= d_a]: head h = rows [h dk, (h + 1) dk)):
+ *   bmt_rank_prep   W' [H d_a][d_b] (row h d_a + a = W'_h[a][.]) as bf16 / fp16 / fp16 lo planes of row stride ldp and / or fp32 (row stride
+ *                   d_b), each optional; c [H d_a] (zeros without a query bias), optional; dWp_zero (optional): fp32 [H d_a][d_b] set to zero --
+ *                   the accumulator of dW' for the pass to come;
+ *   bmt_rank_chain  from dW' = dq'^T y (fp32 [H d_a][d_b]) and dc = column sums of dq' (or NULL):  dW_q,h += W_k,h dW'_h,
+ *                   dW_k,h += W_q,h dW'_h^T + b_q,h^T dc_h,  db_q,h += W_k,h dc_h  (row strides ldgq / ldgk; each output optional; d_a = 128, d_b a
+ *                   multiple of 128, dk of 64; 64 x 64 fp32 tiles, dW_k by atomics when d_b > 128). */
+int bmt_rank_prep(const float* Wq, int64_t ldq, int d_b, const float* Wk, int64_t ldk, const float* bq, int H, int dk, int d_a, uint16_t* wp_bf16,
+                  uint16_t* wp_f16, uint16_t* wp_f16_lo, int64_t ldp, float* wp_f32, float* c, float* dWp_zero, void* stream);
+int bmt_rank_chain(const float* Wq, int64_t ldq, int d_b, const float* Wk, int64_t ldk, const float* bq, int H, int dk, int d_a, const float* dWp,
+                   const float* dc, float* dWq, int64_t ldgq, float* dWk, int64_t ldgk, float* dbq, void* stream);
 /* ... and the kernels between those products (csrc/raw_memory.hip).  `off` = bmt_pack_rows' offsets of the memory (int32, off[b] = first
  * packed row of sample b, off[B] = the row count), Skp = the padded key extent of the per-sample buffers (a multiple of 64, >= every length):
  *   bmt_memory_transposed  packed fp16 plane X [rows][ld] -> xt_f16[b][d][k] = fp16(X) and xtc_bf[b][d][k] = bf16(X - mean key of sample b)
