@@ -22,15 +22,29 @@ namespace {
 // (two broadcast / contiguous 16-byte LDS reads per 16 multiply-adds).
 constexpr int DA = 128, TS = 68;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void tile_mac(const float* As, const float* Bs, int ty, int tx, float (&acc)[4][4]) {
+    v2f c[4][2];                     // packed multiply-adds (v_pk_fma_f32): two columns per instruction
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c[i][0] = v2f{acc[i][0], acc[i][1]};
+        c[i][1] = v2f{acc[i][2], acc[i][3]};
+    }
 #pragma unroll 8
     for (int k = 0; k < 128; ++k) {
         const float4 a = *reinterpret_cast<const float4*>(As + k * TS + 4 * ty), b = *reinterpret_cast<const float4*>(Bs + k * TS + 4 * tx);
-        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        const v2f b0 = v2f{b.x, b.y}, b1 = v2f{b.z, b.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const v2f ai = v2f{av[i], av[i]};
+            c[i][0] = __builtin_elementwise_fma(ai, b0, c[i][0]);
+            c[i][1] = __builtin_elementwise_fma(ai, b1, c[i][1]);
+        }
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    for (int i = 0; i < 4; ++i) {
+        acc[i][0] = c[i][0].x; acc[i][1] = c[i][0].y; acc[i][2] = c[i][1].x; acc[i][3] = c[i][1].y;
     }
 }
 // rows of a [128 k][ld] source (the reduction index is the ROW): 64 columns from c0, stored as they are
