@@ -1658,13 +1658,14 @@ def _attn_rc_ws(B, H, Sq, Sk, dk, dev):
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
-                    fuse: Optional[str] = None, kv_shared: bool = False, scale: Optional[float] = None):
+                    fuse: Optional[str] = None, kv_shared: bool = False, scale: Optional[float] = None, bias_into=(None, None, None)):
     """attention backward (single-pass bf16 on the hi planes) with the gradients written as GEMM operands: for each of dq, dk,
     dv the bf16 plane (the A operand of the projection's dX and, k-major, of its dW) and the bias gradient (column sums).
     o: the saved output planes (hi + lo, or hi + fh: delta = rowsum(dO * O) reads the most precise form present).
     biases = (bq, bk, bv): a bias with a static gradient buffer is accumulated in place (returned db is None), otherwise into a
     fresh fp32 [D].  fuse = "qkv" (Sq == Sk) / "kv": the gradients share one plane [M][3D | 2D] (column blocks), the operand of
     the fused projection backward; the combined plane is returned as a 4th element.
+    bias_into: per bias, a ZEROED fp32 [D] the caller owns, to take the sums instead of a fresh tensor (the rank form's dc: no fill per call).
     Returns [(P, db)] * 3 (+ [P_all])."""
     dk = D // H
     dev = q.any.device
@@ -1683,7 +1684,7 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
         gb = static_grad(b)
         db = None
         if b is not None and gb is None:
-            db = torch.zeros(D, device=dev, dtype=torch.float32)
+            db = bias_into[idx] if bias_into[idx] is not None else torch.zeros(D, device=dev, dtype=torch.float32)
         outs.append((hi, gb if gb is not None else db, db))
     delta = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
     if isinstance(do, Planes):       # dO already as the bf16 plane the kernels read
@@ -3024,7 +3025,7 @@ _rank_states = {}
 
 
 class _RankState:
-    __slots__ = ("refs", "epoch", "c", "WpP", "Wcomb", "Istack", "dWp", "dirty", "H", "d_a", "d_b", "dk")
+    __slots__ = ("refs", "epoch", "c", "WpP", "Wcomb", "Istack", "dWp", "dc", "dc_used", "dirty", "H", "d_a", "d_b", "dk")
 
 
 def _rank_prep(st: "_RankState") -> bool:
@@ -3035,9 +3036,18 @@ def _rank_prep(st: "_RankState") -> bool:
     Wqd, Wkd = Wq.detach(), Wk.detach()
     _lib.check(lib.bmt_rank_prep(_p(Wqd), Wqd.stride(0), st.d_b, _p(Wkd), Wkd.stride(0), _p(bq.detach()) if bq is not None else None, st.H, st.dk, st.d_a,
                                  _p(st.WpP.hi), _p(st.WpP.fh), _p(st.WpP.fl), st.d_b, None, _p(st.c), _p(st.dWp), _st()), "bmt_rank_prep")
+    zero_(st.dc)                     # (dc = column sums of dq': accumulated by the pass to come, like dW' -- which the launch above zeroed)
     st.epoch = WEIGHT_EPOCH[0]
-    st.dirty = False                 # (the same launch zeroed dW', the accumulator of the pass to come)
+    st.dirty = st.dc_used = False
     return True
+
+
+def _rank_dc(st: "_RankState"):
+    """the module's zeroed dc accumulator for the FIRST backward pass since bmt_rank_prep (a second one within an optimizer step: a fresh tensor)"""
+    if st.dc_used:
+        return None
+    st.dc_used = True
+    return st.dc
 
 
 def _rank_refresh_all():
@@ -3086,7 +3096,8 @@ def _rank_state(Wq, bq, Wk, H) -> "_RankState":
         # dW' of a pass that queues its weight-gradient products accumulates here: zeroed by bmt_rank_prep, i.e. once per optimizer step (dirty =
         # a pass has used it since: another one before the next refresh takes a buffer of its own)
         st.dWp = torch.zeros(Dr, d_b, device=dev, dtype=torch.float32)
-        st.dirty = False
+        st.dc = torch.zeros(Dr, device=dev, dtype=torch.float32)
+        st.dirty = st.dc_used = False
         _rank_states[key] = st
         if len(_rank_states) > 256:
             for k_ in [k_ for k_, v_ in _rank_states.items() if any(r is not None and r() is None for r in v_.refs)]:
@@ -3235,7 +3246,7 @@ class RankSelfAttnFn(torch.autograd.Function):
         qp = Planes(None, None, M, Dr, fh=qf, pack=pack)
         kP = Planes(None, None, M, d_in, fh=xf, pack=pack)
         res = attn_bwd_planes(qp, kP, kP, oP, dop, lse, B, S, S, Dr, ctx.mask, H, 0.0, (st.c if bq is not None else None, None, None), fuse="qkv",
-                              kv_shared=True, scale=1.0 / math.sqrt(dk))
+                              kv_shared=True, scale=1.0 / math.sqrt(dk), bias_into=(_rank_dc(st), None, None))
         (Pq, dc), comb = res[0], res[3]
         xT = Planes(xh, None, M, d_in, pack=pack)
         dQ = None
@@ -3348,7 +3359,7 @@ class RankCrossAttnFn(torch.autograd.Function):
         qp = Planes(None, None, Mq, Dr, fh=qf, pack=qpack)
         kP = Planes(None, None, Mk, d_a, fh=xf, pack=kpack)
         res = attn_bwd_planes(qp, kP, kP, oP, dop, lse, B, Sq, Sk, Dr, ctx.mask, H, 0.0, (st.c if bq is not None else None, None, None), fuse="kv",
-                              kv_shared=True, scale=1.0 / math.sqrt(dk))
+                              kv_shared=True, scale=1.0 / math.sqrt(dk), bias_into=(_rank_dc(st), None, None))
         (Pq, dc), comb = res[0], res[3]
         dQ = dK = None
         if ctx.needs_input_grad[0]:      # dy = dq' W'
