@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void rank_prep_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* As = sm;
     float* Bs = sm + 128 * TS;
+    float* Sb = sm + 2 * 128 * TS;       // b_q's 128 values of the phase (the workgroups of the first column tile: c_h)
     const int tid = threadIdx.x, nq = d_b / 64, na = d_a / 64;
     const int nt = blockIdx.x % nq, at = (blockIdx.x / nq) % na, h = blockIdx.x / (nq * na);
     const int ty = tid >> 4, tx = tid & 15;
@@ -88,10 +89,13 @@ __global__ __launch_bounds__(256) void rank_prep_kernel(const float* __restrict_
         if (r0) __syncthreads();
         tile_load_kmajor(Wk + (int64_t)(h * dk + r0) * ldk, ldk, at * 64, As, tid);
         tile_load_kmajor(Wq + (int64_t)(h * dk + r0) * ldq, ldq, nt * 64, Bs, tid);
-        __syncthreads();
+        if (nt == 0 && tid < 128 && bq != nullptr) Sb[tid] = bq[h * dk + r0 + tid];      // (one load per value: the 128-step dot product below read b_q from
+        __syncthreads();                                                                    // global memory step by step, on the workgroups that finish last)
         tile_mac(As, Bs, ty, tx, acc);
-        if (nt == 0 && tid < 64 && bq != nullptr)
-            for (int k = 0; k < 128; ++k) cs = fmaf(bq[h * dk + r0 + k], As[k * TS + tid], cs);
+        if (nt == 0 && tid < 64 && bq != nullptr) {
+#pragma unroll 8
+            for (int k = 0; k < 128; ++k) cs = fmaf(Sb[k], As[k * TS + tid], cs);
+        }
     }
     if (nt == 0 && tid < 64 && c != nullptr) c[h * d_a + at * 64 + tid] = cs;
 #pragma unroll
@@ -197,7 +201,7 @@ extern "C" int bmt_rank_prep(const float* Wq, int64_t ldq, int d_b, const float*
                       ((((uintptr_t)wp_bf16) | ((uintptr_t)wp_f16) | ((uintptr_t)wp_f16_lo)) & 7) == 0 && (wp_bf16 || wp_f16 || wp_f32) &&
                       (!wp_f16_lo || wp_f16) && ldp >= d_b,
                   "bmt_rank_prep: bad arguments (H=%d dk=%d d_a=%d d_b=%d: dk a multiple of 128, d_a and d_b of 64, 16-byte aligned rows)", H, dk, d_a, d_b);
-    constexpr int lds = 2 * 128 * TS * (int)sizeof(float);
+    constexpr int lds = (2 * 128 * TS + 128) * (int)sizeof(float);
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute((const void*)rank_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

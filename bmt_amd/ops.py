@@ -3036,14 +3036,15 @@ def _rank_prep(st: "_RankState") -> bool:
     Wqd, Wkd = Wq.detach(), Wk.detach()
     _lib.check(lib.bmt_rank_prep(_p(Wqd), Wqd.stride(0), st.d_b, _p(Wkd), Wkd.stride(0), _p(bq.detach()) if bq is not None else None, st.H, st.dk, st.d_a,
                                  _p(st.WpP.hi), _p(st.WpP.fh), _p(st.WpP.fl), st.d_b, None, _p(st.c), _p(st.dWp), _st()), "bmt_rank_prep")
-    zero_(st.dc)                     # (dc = column sums of dq': accumulated by the pass to come, like dW' -- which the launch above zeroed)
     st.epoch = WEIGHT_EPOCH[0]
-    st.dirty = st.dc_used = False
+    st.dirty = False                 # (the same launch zeroed dW', the accumulator of the pass to come)
     return True
 
 
 def _rank_dc(st: "_RankState"):
-    """the module's zeroed dc accumulator for the FIRST backward pass since bmt_rank_prep (a second one within an optimizer step: a fresh tensor)"""
+    """the module's dc accumulator (column sums of dq') while it is clean: zeroed at creation and again by whoever consumed it -- the chain-rule
+    launch's issuer, behind that launch (_rank_weight_grads): no fill in front of the attention backward, none on the refresh stream in front
+    of the forward pass.  In use (a second backward before the first one's chain rule was issued): None = a fresh tensor."""
     if st.dc_used:
         return None
     st.dc_used = True
@@ -3129,6 +3130,9 @@ def _rank_weight_grads(st, Pq: Planes, yT: Planes, dc, Wq, bq, Wk):
     def chain():
         _lib.check(lib.bmt_rank_chain(_p(Wqd), Wqd.stride(0), st.d_b, _p(Wkd), Wkd.stride(0), _p(bq.detach()) if bq is not None else None, st.H, st.dk, st.d_a,
                                       _p(acc), _p(dc) if bq is not None else None, _p(tq), tq.stride(0), _p(tk), tk.stride(0), _p(tb), _st()), "bmt_rank_chain")
+        if dc is st.dc:              # consumed: clean again for the next pass (same stream, behind the launch that read it)
+            zero_(st.dc)
+            st.dc_used = False
     if deferred:                     # dW' and the chain rule behind it run beside the pass's grouped weight-gradient launch (flush_dw)
         sctx.pending_side.append(((Pq, yT, acc), chain))
         sctx.pending_ids.update(id(p_) for p_ in static)
