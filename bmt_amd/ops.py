@@ -1138,7 +1138,11 @@ def gemm_bf16_grouped(items):
     _lib.check(lib.bmt_gemm_bf16_grouped_run(_p(dtab), n, launch, _st()), "bmt_gemm_bf16_grouped_run")
 
 
-DEFER_ZERO = True         # the gradient arena's zero fill beside the decoder's forward instead of at the head of the step
+# the gradient arena's zero fill beside the decoder's forward instead of at the head of the step.  Won its A/B before the rank form (7.019 -> 6.99:
+# profiles/r06_q_ab_defer_zero.txt); with it the head of the step waits ~250 us for the rank-form preparations on the refresh stream, the fill
+# runs beside them for nothing, and the fork / join around the decoder's entry costs more than it hides: 6.410 / 6.407 -> 6.378 / 6.376 and
+# 6.623 / 6.632 -> 6.585 / 6.582 ms on two boxes (profiles/r06_y5_head_ab.txt).  The mechanism (defer_beside) stays for callers with another head.
+DEFER_ZERO = False
 
 
 def defer_beside(fn):
