@@ -173,8 +173,17 @@ class Transpose(nn.Module):
         return x.permute(0, 2, 1)
 
 
-def layer_norm(norm: nn.LayerNorm, x):
-    return ops.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+def layer_norm(norm: nn.LayerNorm, x, planes_fmt=None):
+    """nn.LayerNorm(x); planes_fmt: the kernel also writes the result's operand planes of that format, attached to the result (ops.planes_of)"""
+    if planes_fmt is None or not x.is_cuda:
+        return ops.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+    c = ops.context()
+    c.last_ln = None
+    y = ops.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, planes_fmt)
+    if c.last_ln is not None:
+        ops.attach_planes(y, c.last_ln)
+        c.last_ln = None
+    return y
 
 
 class ResidualConnection(nn.Module):
@@ -236,7 +245,7 @@ class BridgeConnection(nn.Module):
 
     def forward(self, x):
         # relu(dropout(linear(LN(x)))): dropout BEFORE the activation, no residual (blocks.py:149-153)
-        x = layer_norm(self.norm, x)
+        x = layer_norm(self.norm, x, planes_fmt=ops.act_fmt(ops.policy_of(None).gemm))      # (the Linear's operand, from the LayerNorm kernel itself)
         p = self.dout_p if self.training else 0.0
         return ops.LinearActFn.apply(x, self.linear.weight, self.linear.bias, True, "pre", p, self._site)
 

@@ -1960,7 +1960,9 @@ class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim (model/blocks.py:127,131)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fmt=None):
+        """fmt: also write the result's operand planes of that format from the same kernel (left in StepContext.last_ln for the caller to attach:
+        blocks.layer_norm) -- the bridge's Linear (model/blocks.py:149-153) reads them instead of converting the fp32 result in a pass of its own"""
         note_use(gamma, beta)
         xc = _f32c(x)
         D = xc.shape[-1]
@@ -1969,8 +1971,15 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        _lib.check(lib.bmt_layernorm_fwd(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), rows, D, eps, _st()),
-                   "bmt_layernorm_fwd")
+        if fmt is not None and D % 4 == 0:
+            pl = _alloc_planes(rows, D, fmt, x.device)
+            second = pl.lo if pl.lo is not None else pl.fh
+            _lib.check(lib.bmt_layernorm_fwd_planes(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), _p(pl.hi), _p(second),
+                                                    int(pl.fh is not None), pl.hi.stride(0), rows, D, eps, None, _st()), "bmt_layernorm_fwd_planes")
+            context().last_ln = pl
+        else:
+            _lib.check(lib.bmt_layernorm_fwd(_p(x2), D, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), rows, D, eps, _st()),
+                       "bmt_layernorm_fwd")
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.beta = beta
         return y.view(xc.shape)
@@ -1999,8 +2008,8 @@ class LayerNormFn(torch.autograd.Function):
         if fused:
             grad_done(gamma)
             grad_done(beta)
-            return dx.view(dy.shape), None, None, None
-        return dx.view(dy.shape), dg, db, None
+            return dx.view(dy.shape), None, None, None, None
+        return dx.view(dy.shape), dg, db, None, None
 
 
 class DropoutAddFn(torch.autograd.Function):
