@@ -2447,11 +2447,12 @@ FUSE_GEN_LOSS = _os.environ.get("BMT_FUSE_GEN_LOSS", "1") != "0"      # switch: 
 class GenHandle:
     """what a Generator's output carries for a LabelSmoothing that is applied to it directly (K7 as one forward and one backward kernel):
     the generator's autograd-tracked input and parameters, the 2-D log-probabilities and their row sums"""
-    __slots__ = ("x", "W", "b", "logp", "rowsum", "version", "ran")
+    __slots__ = ("x", "W", "b", "logp", "rowsum", "version", "ran", "xh")
 
-    def __init__(self, x, W, b, logp, rowsum):
+    def __init__(self, x, W, b, logp, rowsum, xh=None):
         self.x, self.W, self.b, self.logp, self.rowsum = x, W, b, logp, rowsum
         self.version, self.ran = None, False
+        self.xh = xh             # the bf16 plane of x the forward product read (k-major operand of dW: no second conversion in the backward)
 
 
 def generator_handle(pred) -> Optional["GenHandle"]:
@@ -2471,13 +2472,17 @@ class GeneratorFn(torch.autograd.Function):
         xc = _f32c(x)
         x2 = xc.view(-1, xc.shape[-1])
         V = W.shape[0]
-        logp = linear_fwd(x2, W, b, precision=policy_of(None).gemm)
+        prec = policy_of(None).gemm
+        xp = planes_of(x, act_fmt(prec))
+        if xp is None or xp.rows != x2.shape[0] or xp.pack is not None:
+            xp = make_planes(x2, act_fmt(prec))
+        logp = linear_fwd(xp, W, b, precision=prec)
         # log-softmax with the row in registers (one read, one write) + the rows' sums, which are all LabelSmoothing needs of the tensor
         rowsum = torch.empty(logp.shape[0], device=logp.device, dtype=torch.float32)
         _lib.check(lib.bmt_log_softmax_fwd_stats(_p(logp), logp.stride(0), logp.shape[0], V, _p(rowsum), _st()), "bmt_log_softmax_fwd_stats")
         ctx.save_for_backward(x2, W, logp)
         ctx.params = (W, b)
-        ctx.handle = GenHandle(x, W, b, logp, rowsum)
+        ctx.handle = GenHandle(x, W, b, logp, rowsum, xh=xp.hi)
         context().last_gen = ctx.handle
         return logp.view(*xc.shape[:-1], V)
 
@@ -2560,9 +2565,11 @@ class FusedGenLossFn(torch.autograd.Function):
         if gb is not None:
             grad_done(bp)
         dx = linear_dx(P, Wp).view(xshape) if ctx.needs_input_grad[0] else None
-        dW, _ = wgrad(Wp, None, P, bwd_planes(x2))
-        h = ctx.handle          # this pass is done with the log-probabilities: the handle keeps the parameters only (38 MB at configs[1])
-        h.x = h.logp = h.rowsum = None
+        h = ctx.handle
+        xT = Planes(h.xh, None, x2.shape[0], x2.shape[1]) if (h.xh is not None and h.xh.shape[0] == x2.shape[0]) else x2
+        dW, _ = wgrad(Wp, None, P, bwd_planes(xT))
+        # this pass is done with the log-probabilities: the handle keeps the parameters only (38 MB at configs[1])
+        h.x = h.logp = h.rowsum = h.xh = None
         return dx, dW, (None if gb is not None else cs), None, None, None, None
 
 
