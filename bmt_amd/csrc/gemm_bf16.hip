@@ -502,10 +502,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
     // once per element, and there is one bounds decision per segment.  (The element-wise form this replaces -- one divergent
     // row / column test, six flag tests and a 64-bit index per accumulator register -- took 35 % of a K = 1024 product:
     // the probes of round 2.)
-    if (p.flags == BMT_EPI_ACCUM && !p.Chi) {
+    if ((p.flags == BMT_EPI_ACCUM || (p.flags == 0 && p.c_row_dev != nullptr)) && !p.Chi) {
         float* const Cacc = p.c_row_dev ? p.C + (int64_t)(*p.c_row_dev) * p.ldc : p.C;
         // C += alpha * acc and nothing else (weight gradients, possibly several products into one buffer): atomics straight from the
-        // accumulators -- 32 lanes of an instruction hit 32 consecutive floats of a row, which the L2 handles as one 128-byte request
+        // accumulators -- 32 lanes of an instruction hit 32 consecutive floats of a row, which the L2 handles as one 128-byte request.
+        // flags 0 with a placed output (grouped launch, an unsplit reduction: ONE writer per element -- the gradient of a packed encoder
+        // memory): C = alpha * acc by plain stores, so that nobody has to zero the output first (round 6)
+        const bool add = p.flags == BMT_EPI_ACCUM;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -515,7 +518,10 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmB& p, const int tile_id
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wr * 32 * TI + i * 32 + acc_row(r, half);
-                    if (row < Mr) atomicAdd(Cacc + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+                    if (row < Mr) {
+                        if (add) atomicAdd(Cacc + (int64_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+                        else Cacc[(int64_t)row * p.ldc + col] = acc[i][j][r] * p.alpha;
+                    }
                 }
             }
         return;
@@ -2286,6 +2292,12 @@ static int grouped_tables(const bmt_gemm_bf16_args* args, int nprob, void* ws, s
         if (!(a->precision == BMT_PREC_BF16 && a->a_kmajor && a->b_kmajor && a->conv_mode == 0 && a->C && !a->C_hi && !a->colsum)) {
             bmt_set_error("bmt_gemm_bf16_grouped: problem %d: the grouped launch takes single-pass GEMMs with both operands k-major and "
                           "fp32 output", i);
+            rc = BMT_EINVAL;
+            break;
+        }
+        if (!(a->flags == BMT_EPI_ACCUM || (a->flags == 0 && a->c_row_dev != nullptr && a->Kpad / 64 <= chunk + chunk / 2))) {
+            bmt_set_error("bmt_gemm_bf16_grouped: problem %d: flags must be BMT_EPI_ACCUM, or 0 (plain stores) for a placed output whose reduction "
+                          "is not split (Kpad <= %d)", i, 64 * (chunk + chunk / 2));
             rc = BMT_EINVAL;
             break;
         }

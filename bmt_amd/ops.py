@@ -1081,8 +1081,10 @@ def finish_capture():
         pool["stream"].synchronize()
 
 
-def gemm_bf16_grouped(items):
-    """items: [(dY planes [rows][N_out], X planes [rows][K_in], dW fp32 [N_out][K_in] accumulated in place)] -> one launch"""
+def gemm_bf16_grouped(items, store: bool = False):
+    """items: [(dY planes [rows][N_out], X planes [rows][K_in], dW fp32 [N_out][K_in] accumulated in place)] -> one launch.
+    store: every item has a placed output and a reduction short enough to stay unsplit (<= 96 stages of 64) -- one writer per element: the
+    products are STORED, not accumulated (nobody zeroes the outputs first)"""
     n = len(items)
     arr = (GemmBf16Args * n)()
     for a, item in zip(arr, items):
@@ -1094,8 +1096,9 @@ def gemm_bf16_grouped(items):
         a.A_hi, a.lda, a.B_hi, a.ldb = A.hi.data_ptr(), A.hi.stride(0), B.hi.data_ptr(), B.hi.stride(0)
         a.C, a.ldc = Cm.data_ptr(), Cm.stride(0)
         a.M, a.N, a.Kpad, a.K = A.cols, B.cols, _pad64(rows), rows
-        a.alpha, a.gate_scale, a.flags, a.precision, a.splitk = 1.0, 1.0, EPI_ACCUM, PREC_BF16, 1
+        a.alpha, a.gate_scale, a.flags, a.precision, a.splitk = 1.0, 1.0, (0 if store else EPI_ACCUM), PREC_BF16, 1
         a.a_kmajor, a.b_kmajor = 1, 1
+        assert not store or (len(item) > 3 and _pad64(rows) <= 96 * 64), "gemm_bf16_grouped(store=True): placed outputs with unsplit reductions only"
         pk = A.pack if A.pack is not None else B.pack
         if pk is not None:             # packed rows: the reduction runs over the rows that exist (a device-side count)
             a.rows_dev = _check_pack(pk, rows).rows_ptr.value
@@ -2822,6 +2825,9 @@ def raw_memory(mem: torch.Tensor, n_layers: int, H: int, Tq: int, pol=None) -> t
     return out
 
 
+MEMGRAD_STORE = True      # the memory gradient's per-sample products stored instead of accumulated into a zeroed tensor (same-box A/B: tools/gpu_ab_attr.sh)
+
+
 class RawMemoryFn(torch.autograd.Function):
     """memory -> its alias for the decoder layers; backward: the memory's gradient from the operand stacks the layers' backward passes filled,
     dX_b = sum over (layer, kind, head, query) of A_b[.]^T Bk_b[.] -- one product per sample, reduction 2 L H 32, written into the packed rows
@@ -2848,11 +2854,16 @@ class RawMemoryFn(torch.autograd.Function):
         for l in range(st.L):            # a layer that did not take this form (or whose backward did not run) left its rows of the A stack unwritten:
             if l not in st.done:         # zeros there (its rows of the B stack are zeros already; 0 x garbage must not be NaN)
                 st.astack[:, l].zero_()
-        dmem = zero_(torch.empty(B, S, dm, device=st.astack.device, dtype=torch.float32))
+        # (a sample's product writes exactly its packed rows, each element once: stored, not accumulated -- no zero fill of the 33 / 10 MB in front
+        # of it; rows past the packed count are never read: the consumers are bounded by the same device-side count)
+        store = MEMGRAD_STORE and K <= 96 * 64
+        dmem = torch.empty(B, S, dm, device=st.astack.device, dtype=torch.float32)
+        if not store:
+            zero_(dmem)
         A2, B2, out2 = st.astack.view(B, K, st.Skp), st.bstack.view(B, K, dm), dmem.view(B * S, dm)
         off = st.pack.off.data_ptr()
         items = [(Planes(A2[b], None, K, S), Planes(B2[b], None, K, dm), out2, (off + 4 * b, off + 4 * (B + 1 + b))) for b in range(B)]
-        gemm_bf16_grouped(items)
+        gemm_bf16_grouped(items, store=store)
         if g is not None:                # (a consumer outside the reassociated form read the alias too)
             a, b_ = _f32c(dmem), _f32c(g)
             _lib.check(lib.bmt_add(_p(a), _p(b_), _p(a), a.numel(), _st()), "bmt_add")

@@ -119,7 +119,9 @@ typedef struct {
     const int* rows_dev;
     /* ABI 8, bmt_gemm_bf16_grouped only (a product whose OUTPUT lives in a packed row layout: the gradient of a packed encoder memory,
      * dX_b = dS_b^T . Q'_b of the decoder's cross-attention against the raw memory): the output rows start c_row_dev[0] rows below C and
-     * only the first m_dev[0] of the M rows exist -- both read from device memory when the launch runs.  NULL = as before. */
+     * only the first m_dev[0] of the M rows exist -- both read from device memory when the launch runs.  NULL = as before.
+     * flags of a grouped problem: BMT_EPI_ACCUM (C += A B; several products may share a buffer), or -- with c_row_dev set and a reduction of at
+     * most 96 x 64 rows, which the launch does not split -- 0: C = A B by plain stores, one writer per element, nothing to zero beforehand. */
     const int* c_row_dev;
     const int* m_dev;
     /* ABI 11 -- BLOCK PRODUCTS (the value product of the rank-form self-attention, O_h = O'_h W_v,h^T: the heads' d_in-wide attention outputs
