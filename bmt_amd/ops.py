@@ -1218,9 +1218,9 @@ def flush_dw():
         cur = torch.cuda.current_stream()
         aux.wait_stream(cur)
         with torch.cuda.stream(aux):
-            run_side()
-            if cs:
+            if cs:                    # (first: the rank form's chain rule reads dc, whose partial sums are among them)
                 _colsum_launch(cs)
+            run_side()
         cs, side = [], []
     if items:
         if len(items) == 1 or not GROUPED_DW:
@@ -1231,9 +1231,9 @@ def flush_dw():
             gemm_bf16_grouped(items)
     if aux is not None:
         cur.wait_stream(aux)
-    run_side()
     if cs:
         _colsum_launch(cs)
+    run_side()
     post, ctx.pending_post = ctx.pending_post, []
     for fn in post:           # launches that read what the products above wrote (side by side on streams of their own they finish no earlier: 6.64 / 6.63
         fn()                  # against 6.64 / 6.62 ms, profiles/r06_rank_ab6.txt)
@@ -1254,7 +1254,7 @@ def _colsum_launch(items):
     _lib.check(lib.bmt_colsum_multi(arr, len(items), _st()), "bmt_colsum_multi")
 
 
-def colsum_deferred(items, params=()):
+def colsum_deferred(items, params=(), queue: bool = False):
     """the second stage of small reductions whose partial sums are already on the stream (LayerNorm dgamma / dbeta, attention bias
     gradients): queued next to the weight-gradient products while a backward pass defers those (StepContext.defer_dw) and issued by
     flush_dw as ONE launch for the whole pass (~90 reductions per train_cap step, each a 4-us kernel behind a kernel boundary when
@@ -1262,8 +1262,8 @@ def colsum_deferred(items, params=()):
     for the flush, exactly as for queued weight gradients.  The queue keeps the partials' tensors alive."""
     ctx = context()
     params = [p for p in params if p is not None]
-    if ctx.defer_dw and params:       # (a result that is handed back to autograd as a tensor must be complete now)
-        ctx.pending_cs.extend(items)
+    if ctx.defer_dw and (params or queue):       # (a result that is handed back to autograd as a tensor must be complete now; queue: the caller
+        ctx.pending_cs.extend(items)             # knows its reader runs behind the flush's column-sum launch -- the rank form's dc)
         ctx.pending_ids.update(id(p) for p in params)
     else:
         _colsum_launch(items)
@@ -1665,7 +1665,7 @@ def _attn_rc_ws(B, H, Sq, Sk, dk, dev):
 
 
 def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, Sk, D, mask, H, drop_p, biases,
-                    fuse: Optional[str] = None, kv_shared: bool = False, scale: Optional[float] = None, bias_into=(None, None, None)):
+                    fuse: Optional[str] = None, kv_shared: bool = False, scale: Optional[float] = None, bias_into=(None, None, None), queue_bias: bool = False):
     """attention backward (single-pass bf16 on the hi planes) with the gradients written as GEMM operands: for each of dq, dk,
     dv the bf16 plane (the A operand of the projection's dX and, k-major, of its dW) and the bias gradient (column sums).
     o: the saved output planes (hi + lo, or hi + fh: delta = rowsum(dO * O) reads the most precise form present).
@@ -1740,8 +1740,8 @@ def attn_bwd_planes(q: Planes, k: Planes, v: Planes, o: Planes, do, lse, B, Sq, 
         rq, rk = B * ((Sq + 127) // 128), B * ((Sk + 127) // 128)
         items = [(bias_part, off * D, buf, rows, D, D) for buf, off, rows in ((qb_, 0, rq), (kb_, rq, rk), (vb_, rq + rk, rk)) if buf is not None]
         static = all(b is None or static_grad(b) is not None for b in biases)
-        if items:
-            colsum_deferred(items, params=[b for b in biases if b is not None] if static else ())
+        if items:      # (queue_bias: the sums' only reader runs behind the pass's deferred column-sum launch)
+            colsum_deferred(items, params=[b for b in biases if b is not None] if static else (), queue=queue_bias)
     res = []
     for (hi, _, db), M, b, pk in zip(outs, (Mq, Mk, Mk), biases, (qpack, kpack, kpack)):
         if b is not None and db is None:
@@ -3051,6 +3051,7 @@ class RawCrossAttnFn(torch.autograd.Function):
 # come from ONE item of the step's grouped weight-gradient launch (dW') and one fp32 kernel behind it (bmt_rank_chain).  The key bias drops
 # out (its gradient is exactly zero, as the reference's is up to rounding).
 RANK_ATTN = True
+RANK_QUEUE_DC = True      # dc's partial sums in the pass's one deferred column-sum launch instead of a launch behind every rank-form attention backward
 RANK_CROSS = True       # ... and a cross-attention over such an input (the video stream's attention over the audio stream): RankCrossAttnFn
 _rank_states = {}
 
@@ -3144,6 +3145,12 @@ def _rank_state(Wq, bq, Wk, H) -> "_RankState":
     return st
 
 
+def _rank_deferred(st, Wq, bq, Wk) -> bool:
+    """will this backward's dW' product and chain rule be queued for the pass's flush (static gradient buffers, first pass of the optimizer step)?"""
+    n = sum(1 for p_ in (Wq, Wk, bq) if static_grad(p_) is not None)
+    return context().defer_dw and n == (3 if bq is not None else 2) and not st.dirty
+
+
 def _rank_weight_grads(st, Pq: Planes, yT: Planes, dc, Wq, bq, Wk):
     """dW' = dq'^T y into the pass's grouped weight-gradient launch, and behind it the chain rule through W' and c (bmt_rank_chain: fp32, from
     the parameters) into the gradients of W_q, b_q, W_k -- their static buffers, or fresh tensors (returned: (dW_q, db_q, dW_k), None = accumulated)"""
@@ -3154,7 +3161,7 @@ def _rank_weight_grads(st, Pq: Planes, yT: Planes, dc, Wq, bq, Wk):
     static = [p_ for p_, g_ in ((Wq, gWq), (Wk, gWk), (bq, gbq)) if g_ is not None]
     sctx = context()
     # (gradients handed back to autograd as tensors must be complete now; so must a second pass over the module within one optimizer step)
-    deferred = sctx.defer_dw and len(static) == (3 if bq is not None else 2) and not st.dirty
+    deferred = _rank_deferred(st, Wq, bq, Wk)
     acc = st.dWp if deferred else torch.zeros_like(st.dWp)
     Wqd, Wkd = Wq.detach(), Wk.detach()
 
@@ -3281,7 +3288,7 @@ class RankSelfAttnFn(torch.autograd.Function):
         qp = Planes(None, None, M, Dr, fh=qf, pack=pack)
         kP = Planes(None, None, M, d_in, fh=xf, pack=pack)
         res = attn_bwd_planes(qp, kP, kP, oP, dop, lse, B, S, S, Dr, ctx.mask, H, 0.0, (st.c if bq is not None else None, None, None), fuse="qkv",
-                              kv_shared=True, scale=1.0 / math.sqrt(dk), bias_into=(_rank_dc(st), None, None))
+                              kv_shared=True, scale=1.0 / math.sqrt(dk), bias_into=(_rank_dc(st), None, None), queue_bias=RANK_QUEUE_DC and _rank_deferred(st, Wq, bq, Wk))
         (Pq, dc), comb = res[0], res[3]
         xT = Planes(xh, None, M, d_in, pack=pack)
         dQ = None
@@ -3394,7 +3401,7 @@ class RankCrossAttnFn(torch.autograd.Function):
         qp = Planes(None, None, Mq, Dr, fh=qf, pack=qpack)
         kP = Planes(None, None, Mk, d_a, fh=xf, pack=kpack)
         res = attn_bwd_planes(qp, kP, kP, oP, dop, lse, B, Sq, Sk, Dr, ctx.mask, H, 0.0, (st.c if bq is not None else None, None, None), fuse="kv",
-                              kv_shared=True, scale=1.0 / math.sqrt(dk), bias_into=(_rank_dc(st), None, None))
+                              kv_shared=True, scale=1.0 / math.sqrt(dk), bias_into=(_rank_dc(st), None, None), queue_bias=RANK_QUEUE_DC and _rank_deferred(st, Wq, bq, Wk))
         (Pq, dc), comb = res[0], res[3]
         dQ = dK = None
         if ctx.needs_input_grad[0]:      # dy = dq' W'
