@@ -70,7 +70,8 @@ class BiModalDecoderLayer(nn.Module):
             Cv.record_stream(s1)
         # (B, Sc, 2*Dc) -> bridge -> (B, Sc, Dc); no residual across the bridge
         C = self.bridge(ops.cat2(Ca, Cv))
-        C = self.res_layer_ff(C, self.feed_forward, fp32_out=False)
+        # (the LAST layer's result is the generator's operand: written as its planes by the feed-forward's last GEMM -- BiModelDecoder sets the format)
+        C = self.res_layer_ff(C, self.feed_forward, fp32_out=False, out_planes=getattr(self, "out_planes_fmt", None))
 
         return C, memory
 
@@ -124,6 +125,8 @@ class BiModelDecoder(nn.Module):
         if Av.is_cuda and torch.is_grad_enabled() and len(self.decoder.layers) > 1 and ops.context().kv_cache is None:
             # one alias pair of the memories per layer: the layers' gradients w.r.t. a memory are added by library launches in one node
             x = (C0, _LayerMemories(Av, Va, len(self.decoder.layers)))
+        if Av.is_cuda and len(layers) > 0 and isinstance(layers[-1], BiModalDecoderLayer):
+            layers[-1].out_planes_fmt = ops.act_fmt(ops.policy_of(None).gemm)      # what Generator's Linear reads (ops.GeneratorFn)
         C, memory = self.decoder(x, masks)
         if C.is_cuda:
             ops.end_of_forward()

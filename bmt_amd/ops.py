@@ -2143,7 +2143,7 @@ class FFNFn(torch.autograd.Function):
             r2 = _f32c(res).view(-1, W2.shape[0])
             epi = dict(residual=r2, ldr=r2.stride(0), drop_post=True, drop_p=res_p, site=res_site)
         opl = None
-        if out_fmt is not None and W2.shape[0] % 64 == 0:       # the reader of this result (the decoder: its memory) wants it as planes
+        if out_fmt is not None and W2.shape[0] % 4 == 0:        # the reader of this result (the decoder: its memory; the generator) wants it as planes (padded to 64 columns, zeros)
             opl = _alloc_planes(x2.shape[0], W2.shape[0], out_fmt, xc.device)
             epi["out_planes"] = opl
         y = linear_fwd(h, W2, b2, precision=pol.ffn2, **epi)
