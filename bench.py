@@ -125,17 +125,17 @@ class KernelTimer:
                                 lambda: raw_gb(A, B, C_out, **kw),
                                 xflops=2.0 * xM * N * xK, xbytes=nb[0] * xM * xK + nb[1] * N * xK + ob * xM * N)
 
-        def gemm_bf16_grouped(items):
+        def gemm_bf16_grouped(items, **kw):
             if not timer.enabled:
-                return raw_gg(items)
+                return raw_gg(items, **kw)
             fl = sum(2.0 * it[0].cols * it[1].cols * it[0].rows for it in items)
             by = sum(2.0 * it[0].rows * (it[0].cols + it[1].cols) + 4.0 * it[0].cols * it[1].cols for it in items)
             xr = [timer.xrows(it[0].rows, it[0].pack is not None or it[1].pack is not None) for it in items]     # the reduction over the rows that exist
             xfl = sum(2.0 * it[0].cols * it[1].cols * r for it, r in zip(items, xr))
             xby = sum(2.0 * r * (it[0].cols + it[1].cols) + 4.0 * it[0].cols * it[1].cols for it, r in zip(items, xr))
             if len(items[0]) > 3:                  # the gradient of an encoder memory (ops.RawMemoryFn): one product per sample, packed output rows
-                return timer._timed("gemm_planes_memory_grad_grouped_bf16", 1, fl, by, lambda: raw_gg(items))
-            return timer._timed("gemm_planes_dw_grouped_bf16", 1, fl, by, lambda: raw_gg(items), xflops=xfl, xbytes=xby)     # the step's weight gradients, one launch
+                return timer._timed("gemm_planes_memory_grad_grouped_bf16", 1, fl, by, lambda: raw_gg(items, **kw))
+            return timer._timed("gemm_planes_dw_grouped_bf16", 1, fl, by, lambda: raw_gg(items, **kw), xflops=xfl, xbytes=xby)     # the step's weight gradients, one launch
 
         def _rank_dims(D, H, kw):
             """an attention launch in the rank form (ops.RankSelfAttnFn / RankCrossAttnFn: kv_shared, the softmax scale of the reference's head size):
@@ -183,6 +183,17 @@ class KernelTimer:
             return timer._timed("gemm_small_batched_" + ops.prec_name(prec), ops.prec_passes(prec), 2.0 * M * N * Kpad * n,
                                 n * (nb[0] * M * Kpad + nb[1] * N * Kpad + ob * M * N), lambda: raw_gbt(prec, M, N, Kpad, nb_o, nb_i, *a, **kw))
 
+        raw_ral = ops.raw_attn_launch
+
+        def raw_attn_launch(bwd, B_, H, Tq, S, dm, fn):
+            if not timer.enabled:
+                return raw_ral(bwd, B_, H, Tq, S, dm, fn)
+            # two products of (H Tq) x S x dm per sample; bytes: the A rows and the result rows (16-bit), the memory both ways, P / dS (16-bit, twice)
+            fl = 2 * 2.0 * B_ * H * Tq * S * dm
+            by = B_ * (2.0 * 2 * H * Tq * dm + 2.0 * 2 * S * dm + 2.0 * 2 * H * Tq * S)
+            return timer._timed("raw_attn_fused_" + ("bf16" if bwd else "f16"), 1, fl, by, fn)
+
+        ops.raw_attn_launch = raw_attn_launch
         ops.gemm_batched = gemm_batched
         ops.gemm_bf16, ops.gemm_bf16_grouped = gemm_bf16, gemm_bf16_grouped
         ops.attn_fwd_planes, ops.attn_bwd_planes = attn_fwd_planes, attn_bwd_planes

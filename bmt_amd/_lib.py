@@ -109,6 +109,9 @@ SIGNATURES = {
     "bmt_memory_transposed": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp, vp]),
     "bmt_raw_softmax_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp]),
     "bmt_raw_softmax_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, i64, i64, vp]),
+    "bmt_raw_attn_ok": (i32, [i32, i32]),
+    "bmt_raw_attn_fwd": (i32, [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, vp, i64, vp]),
+    "bmt_raw_attn_bwd": (i32, [vp, i64, i64, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, i64, vp, i64, vp]),
     "bmt_gemm_bf16_grouped": (i32, [vp, i32, vp, C.c_size_t, vp]),
     "bmt_gemm_bf16_grouped_tables": (i32, [vp, i32, vp, C.c_size_t, C.POINTER(i32), vp]),
     "bmt_gemm_bf16_grouped_run": (i32, [vp, i32, C.POINTER(i32), vp]),
@@ -209,8 +212,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.bmt_version() != 11:
-        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 11")
+    if lib.bmt_version() != 12:
+        raise ImportError(f"libbmt_hip.so ABI version {lib.bmt_version()} != 12")
     _lib = lib
     return lib
 

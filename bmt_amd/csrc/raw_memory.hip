@@ -187,6 +187,269 @@ __global__ __launch_bounds__(256) void raw_softmax_bwd_kernel(const uint16_t* __
     }
 }
 
+
+// LDS slot (16 bytes) of (row, piece) in a wave's [32 rows][8 pieces] staging image (gemm_small_kernel's swizzle)
+__device__ __forceinline__ int raw_slot(int row, int s) { return row * 8 + (s ^ ((row >> 1) & 7)); }
+
+// One wave's share of a product  C[32][32 n] = A[32][64 nch] . B[32 n + j][64 nch]^T  for the tiles n = w, w + 8, ... < ntiles:
+//   A  the workgroup's 32-row operand in LDS (16-bit, a_stride 32-bit words per row);
+//   B  rows of a plane behind the buffer descriptor rs (row r at byte r * b_row_bytes, the reduction index contiguous; rows >= b_rows read as zeros),
+//      staged 64 reduction indices at a time through the wave's own 4-KB LDS area: coalesced 16-byte loads (eight lanes per 128-byte piece
+//      of a row), NS chunks in flight in NS register sets (one CU streams bytes-in-flight / latency: with two sets ~45 GB/s, and a video
+//      workgroup streams 1 MB), no barrier (gemm_small_kernel's scheme: a first version fetched the MFMA
+//      fragments straight from the planes, 64 scattered 16-byte requests per instruction, and was slower than the three launches it replaces);
+//   done(n, acc)  consumes a finished tile (the wave's LDS area is free by then).
+// The (tile, chunk) pairs of the wave are one flat sequence, so the loads of the next tile are in flight under the last chunk of this one.
+template <bool F16, int NS, typename Done>
+__device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_stride, const __amdgpu_buffer_rsrc_t rs, int b_row_bytes, int b_rows, int ntiles,
+                                                 int nch, char* wbase, int w, int lane, Done done) {
+    constexpr int OOB = 0x7ffffff0;
+    const int half = lane >> 5, l31 = lane & 31, lrow = lane >> 3, piece = lane & 7;
+    const int ntw = w < ntiles ? (ntiles - w + 7) >> 3 : 0, total = ntw * nch;
+    if (total == 0) return;
+    int lds_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_w[i] = raw_slot(i * 8 + lrow, piece) * 16;
+    u32x4 rg[NS][4];
+    int lt = w, lc = 0, li = 0;                                // the next chunk to request: tile, chunk, flat index
+#define BMT_RA_LOAD(set_)                                                                              \
+    do {                                                                                               \
+        const bool in_ = li < total;                        /* wave-uniform */                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            const int r_ = lt * 32 + i * 8 + lrow;                                                     \
+            const int vo_ = (in_ && r_ < b_rows) ? r_ * b_row_bytes + piece * 16 : OOB;                \
+            rg[set_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_, lc * 128, 0);                 \
+        }                                                                                              \
+        ++li;                                                                                          \
+        if (++lc == nch) { lc = 0; lt += 8; }                                                          \
+    } while (0)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) BMT_RA_LOAD(j);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int ct = w, cc = 0;
+    const uint32_t* ar = As + l31 * a_stride + half * 4;
+    for (int idx = 0; idx < total; idx += NS) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + lds_w[i]) = rg[j][i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fb[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));
+                fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar + cc * 32 + u * 8));
+            }
+            BMT_RA_LOAD(j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa[u], fb[u], acc);
+            if (++cc == nch) {
+                if (idx + j < total) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    done(ct, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                cc = 0;
+                ct += 8;
+            }
+        }
+    }
+#undef BMT_RA_LOAD
+}
+
+// The row operation of raw_attn_kernel on a wave's four rows of the score tile in LDS (row t at Ss + t * lds_s, fp32 bits): raw_softmax_fwd_kernel's
+// / raw_softmax_bwd_kernel's arithmetic; P (fp16 -> p_f16, bf16 -> the stack) or dS (bf16 -> the stack) to memory, and the 16-bit row -- the A operand
+// of the second product -- over the head of its own fp32 row.  NG groups of 8 keys per lane; HALF: a row per half wave (Skp <= 256).
+template <bool BWD, int NG, bool HALF>
+__device__ __forceinline__ void raw_row_op(uint32_t* Ss, int lds_s, int w, int l, int b, int h, int H, int Tq, int Skp, int len, float scale, uint16_t* p_f16,
+                                           uint16_t* stk, int64_t s_sb, int64_t s_sh) {
+    constexpr int NP = HALF ? 2 : 4;                          // passes over the wave's four rows
+    constexpr int LW = HALF ? 32 : 64;                        // lanes of a row
+    const int ll = HALF ? (l & 31) : l;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int t = w * 4 + (HALF ? i * 2 + (l >> 5) : i);
+        uint32_t* s = Ss + t * lds_s;
+        const int64_t row = (int64_t)(b * H + h) * 32 + t;
+        uint16_t* pf = p_f16 + row * Skp;
+        uint16_t* sk = stk ? stk + b * s_sb + h * s_sh + (int64_t)t * Skp : nullptr;
+        const bool live = t < Tq && len > 0;
+        float v[NG][8];
+        if constexpr (!BWD) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int k0 = (ll + LW * g) * 8;
+                u32x4 a0 = {0u, 0u, 0u, 0u}, a1_ = a0;
+                if (live && k0 < len) {                       // (a group that straddles the length: its tail may hold anything)
+                    a0 = *reinterpret_cast<const u32x4*>(s + k0);
+                    a1_ = *reinterpret_cast<const u32x4*>(s + k0 + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[g][q] = (live && k0 + q < len) ? __uint_as_float(q < 4 ? a0[q & 3] : a1_[q & 3]) : -INFINITY;
+                    m = fmaxf(m, v[g][q]);
+                }
+            }
+#pragma unroll
+            for (int o = LW / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float sc = scale * 1.4426950408889634f;    // exp(x * scale) = exp2(x * scale * log2 e)
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[g][q] = (live && (ll + LW * g) * 8 + q < len) ? exp2f((v[g][q] - m) * sc) : 0.f;
+                    sum += v[g][q];
+                }
+#pragma unroll
+            for (int o = LW / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = live ? 1.f / sum : 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int k0 = (ll + LW * g) * 8;
+                if (k0 >= Skp) continue;
+                u32x4 f, bfv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float p0 = v[g][2 * q] * inv, p1 = v[g][2 * q + 1] * inv;
+                    f[q] = pack_h2(p0, p1);
+                    bfv[q] = pack_bf2(p0, p1);
+                }
+                *reinterpret_cast<u32x4*>(pf + k0) = f;
+                if (sk) *reinterpret_cast<u32x4*>(sk + k0) = bfv;
+                *reinterpret_cast<u32x4*>(s + (k0 >> 1)) = f;                 // the A operand of the second product, in place
+            }
+        } else {
+            float pv[NG][8];
+            float delta = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int k0 = (ll + LW * g) * 8;
+                u32x4 ph = {0u, 0u, 0u, 0u}, a0 = ph, a1_ = ph;
+                if (live && k0 < len) {
+                    ph = *reinterpret_cast<const u32x4*>(pf + k0);
+                    a0 = *reinterpret_cast<const u32x4*>(s + k0);
+                    a1_ = *reinterpret_cast<const u32x4*>(s + k0 + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool in = live && k0 + q < len;
+                    pv[g][q] = in ? h_bits2f((ph[q >> 1] >> (16 * (q & 1))) & 0xffffu) : 0.f;
+                    v[g][q] = in ? __uint_as_float(q < 4 ? a0[q & 3] : a1_[q & 3]) : 0.f;
+                    delta += pv[g][q] * v[g][q];
+                }
+            }
+#pragma unroll
+            for (int o = LW / 2; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int k0 = (ll + LW * g) * 8;
+                if (k0 >= Skp) continue;
+                u32x4 o_;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o_[q] = pack_bf2(pv[g][2 * q] * (v[g][2 * q] - delta) * scale, pv[g][2 * q + 1] * (v[g][2 * q + 1] - delta) * scale);
+                if (sk) *reinterpret_cast<u32x4*>(sk + k0) = o_;
+                *reinterpret_cast<u32x4*>(s + (k0 >> 1)) = o_;
+            }
+        }
+    }
+}
+
+// ---- the three steps between the block products as ONE launch per attention (round 6): workgroup = (sample, head), 8 waves.
+//   forward   S = Q'_h X^T (fp16, one pass)  ->  P = softmax(S * scale) over the sample's keys  ->  O'_h = P X            (X^T from xt_f16)
+//   backward  dP = dO'_h X^T (bf16)          ->  dS = P o (dP - rowsum(P o dP)) * scale         ->  dQ'_h = dS (X - mean)  (from xtc_bf)
+// The 32 x Skp score tile never leaves LDS (the unfused form wrote it as fp32 and read it back: 2 x B H 32 Skp 4 bytes per attention and
+// two dependent launches on the decoder's one-kernel-in-flight chain).  Same arithmetic as the three launches it replaces: the products
+// accumulate over the reduction index in ascending 16-element steps into one fp32 accumulator (what gemm_small_kernel does), the row
+// operations are raw_softmax_fwd_kernel's / raw_softmax_bwd_kernel's own, P (fp16 for the backward, bf16 for the memory's gradient) and dS
+// (bf16) are written where those kernels wrote them.
+// LDS: A [32][dm + 8] 16-bit | S [32][Skp + 4] fp32 -- the 16-bit P / dS row overwrites the head of its own fp32 row (one wave owns a row) --
+// | 8 x 4 KB: the waves' staging areas for the memory's rows (raw_wave_product).
+// All LDS traffic goes through 32-bit unsigned types (the in-place conversion must not be reordered under type-based aliasing).
+template <bool BWD>
+__global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restrict__ A1, int64_t a_sb, int64_t a_sh, int64_t a_ld,
+                                                        const uint16_t* __restrict__ X, int64_t ldx, const int* __restrict__ off,
+                                                        const uint16_t* __restrict__ XT, uint16_t* p_f16, uint16_t* __restrict__ stk, int64_t s_sb,
+                                                        int64_t s_sh, uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo, int64_t ldo, int H, int Tq,
+                                                        int dm, int Skp, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 31, half = l >> 5;
+    // (the H workgroups of a sample on ONE XCD, in consecutive dispatch slots: the sample's rows come over the fabric once, not once per head)
+    const int wg = xcd_remap(blockIdx.x, gridDim.x), b = wg / H, h = wg - b * H;
+    const int r0 = off[b], len = min(off[b + 1] - r0, Skp);
+    const int lda_s = dm + 8;                                  // 16-bit elements per A row
+    const int lds_s = Skp + 4;                                 // 32-bit elements per S row (rows 4 banks apart: the second product's 16-byte fragment reads of 16 rows are conflict-free)
+    uint32_t* As = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* Ss = reinterpret_cast<uint32_t*>(smem + (size_t)32 * lda_s * 2);
+    char* const wbase = smem + (size_t)32 * lda_s * 2 + (size_t)32 * lds_s * 4 + w * 4096;
+    // ---- A (the 32 query rows of this head; rows t >= Tq are zeros) -> LDS
+    {
+        const uint16_t* a1 = A1 + b * a_sb + h * a_sh;
+        const int pc = dm >> 3;
+        for (int i = tid; i < 32 * pc; i += 512) {
+            const int t = i / pc, c = (i - t * pc) * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (t < Tq) v = *reinterpret_cast<const u32x4*>(a1 + (int64_t)t * a_ld + c);
+            *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = v;
+        }
+    }
+    __syncthreads();
+    // ---- first product: a wave per 32 keys (keys past the sample's length read as zeros: the row operation masks them)
+    {
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (int64_t)r0 * ldx), 0, (int)((int64_t)len * ldx * 2), 0x00020000);
+        raw_wave_product<!BWD, 4>(As, lda_s >> 1, rsX, (int)(ldx * 2), len, (len + 31) >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ss[acc_row(r, half) * lds_s + n * 32 + lr] = __float_as_uint(acc[r]);
+        });
+    }
+    __syncthreads();
+    // ---- the row operation: four rows per wave.  The lanes of a row hold groups of 8 consecutive keys; with Skp <= 256 a row is HALF a wave (two
+    // rows per pass), with Skp <= 512 one group per lane: the VALU work follows the keys that exist (a lane's 16 masked keys cost what live ones do)
+    if (Skp <= 256) raw_row_op<BWD, 1, true>(Ss, lds_s, w, l, b, h, H, Tq, Skp, len, scale, p_f16, stk, s_sb, s_sh);
+    else if (Skp <= 512) raw_row_op<BWD, 1, false>(Ss, lds_s, w, l, b, h, H, Tq, Skp, len, scale, p_f16, stk, s_sb, s_sh);
+    else raw_row_op<BWD, 2, false>(Ss, lds_s, w, l, b, h, H, Tq, Skp, len, scale, p_f16, stk, s_sb, s_sh);
+    __syncthreads();
+    // ---- second product: a wave per 32 columns of the memory; the reduction runs over the sample's keys in chunks of 64 (P / dS and the
+    // transposed memory are zero from the length to Skp, a multiple of 64)
+    {
+        const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(XT + (int64_t)b * dm * Skp), 0, (int)((int64_t)dm * Skp * 2), 0x00020000);
+        float* const mine = reinterpret_cast<float*>(wbase);
+        raw_wave_product<!BWD, 4>(Ss, lds_s, rsT, Skp * 2, dm, dm >> 5, max(1, (len + 63) >> 6), wbase, w, l, [&](int n, const f32x16& acc) {
+            // the tile through the wave's area ([32][32] fp32, 16-byte granules XOR-swizzled by the row): a lane then owns 8 consecutive columns of a row
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = acc_row(r, half);
+                mine[t * 32 + (((lr >> 2) ^ (t & 7)) << 2) + (lr & 3)] = acc[r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int t = it * 16 + (l >> 2), g = (l & 3) * 2;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(mine + t * 32 + ((g ^ (t & 7)) << 2));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(mine + t * 32 + (((g + 1) ^ (t & 7)) << 2));
+                if (t >= Tq) continue;
+                const int64_t o = (int64_t)(b * Tq + t) * ldo + (int64_t)h * dm + n * 32 + (l & 3) * 8;
+                uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split_bf2(v0[0], v0[1], h0, l0);
+                split_bf2(v0[2], v0[3], h1, l1);
+                split_bf2(v1[0], v1[1], h2, l2);
+                split_bf2(v1[2], v1[3], h3, l3);
+                const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                *reinterpret_cast<u32x4*>(o_hi + o) = hi;
+                if (o_lo) *reinterpret_cast<u32x4*>(o_lo + o) = lo;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+    }
+}
+
+inline size_t raw_attn_lds(int dm, int Skp) { return (size_t)32 * (dm + 8) * 2 + (size_t)32 * (Skp + 4) * 4 + 8 * 4096; }
 }  // namespace
 
 extern "C" int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const int* off, int B, int D, int Skp, uint16_t* xt_f16, uint16_t* xtc_bf,
@@ -223,5 +486,49 @@ extern "C" int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const
     hipLaunchKernelGGL(raw_softmax_bwd_kernel, dim3(bmt_cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, p_f16, dP, off, H, Tq, Skp, scale, ds_bf, ds_sb, ds_sh,
                        nrows);
     BMT_CHECK_LAUNCH("bmt_raw_softmax_bwd");
+    return BMT_OK;
+}
+
+extern "C" int bmt_raw_attn_ok(int dm, int Skp) {
+    return dm > 0 && dm % 64 == 0 && Skp > 0 && Skp % 64 == 0 && Skp <= 1024 && raw_attn_lds(dm, Skp) <= (size_t)160 * 1024;
+}
+
+extern "C" int bmt_raw_attn_fwd(const uint16_t* q_f16, int64_t q_sb, int64_t q_sh, int64_t ldq, const uint16_t* x_f16, int64_t ldx, const int* off,
+                                const uint16_t* xt_f16, int B, int H, int Tq, int dm, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf,
+                                int64_t p_bf_sb, int64_t p_bf_sh, uint16_t* o_hi, uint16_t* o_lo, int64_t ldo, void* stream) {
+    BMT_CHECK_ARG(q_f16 && x_f16 && off && xt_f16 && p_f16 && o_hi && B > 0 && H > 0 && Tq > 0 && Tq <= 32, "bmt_raw_attn_fwd: null pointer or bad extents (at most 32 queries per sample and head)");
+    BMT_CHECK_ARG(bmt_raw_attn_ok(dm, Skp), "bmt_raw_attn_fwd: dm and Skp multiples of 64, Skp <= 1024, and 64 (dm + 8) + 128 (Skp + 4) + 32 768 bytes of LDS <= 160 KB (bmt_raw_attn_ok)");
+    BMT_CHECK_ARG(!((reinterpret_cast<uintptr_t>(q_f16) | reinterpret_cast<uintptr_t>(x_f16) | reinterpret_cast<uintptr_t>(xt_f16) | reinterpret_cast<uintptr_t>(p_f16) |
+                     reinterpret_cast<uintptr_t>(p_bf)) & 15) && !((q_sb | q_sh | ldq | ldx | p_bf_sb | p_bf_sh) & 7) && ldx >= dm && ldo >= (int64_t)H * dm,
+                  "bmt_raw_attn_fwd: 16-byte aligned operands, strides that are multiples of 8 elements");
+    const size_t lds = raw_attn_lds(dm, Skp);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(raw_attn_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, q_f16, q_sb, q_sh, ldq, x_f16, ldx, off, xt_f16, p_f16, p_bf, p_bf_sb,
+                       p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale);
+    BMT_CHECK_LAUNCH("bmt_raw_attn_fwd");
+    return BMT_OK;
+}
+
+extern "C" int bmt_raw_attn_bwd(const uint16_t* do_bf, int64_t do_sb, int64_t do_sh, int64_t lddo, const uint16_t* x_bf, int64_t ldx, const int* off,
+                                const uint16_t* xtc_bf, const uint16_t* p_f16, int B, int H, int Tq, int dm, int Skp, float scale, uint16_t* ds_bf,
+                                int64_t ds_sb, int64_t ds_sh, uint16_t* dq_bf, int64_t lddq, void* stream) {
+    BMT_CHECK_ARG(do_bf && x_bf && off && xtc_bf && p_f16 && dq_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32, "bmt_raw_attn_bwd: null pointer or bad extents (at most 32 queries per sample and head)");
+    BMT_CHECK_ARG(bmt_raw_attn_ok(dm, Skp), "bmt_raw_attn_bwd: dm and Skp multiples of 64, Skp <= 1024, and 64 (dm + 8) + 128 (Skp + 4) + 32 768 bytes of LDS <= 160 KB (bmt_raw_attn_ok)");
+    BMT_CHECK_ARG(!((reinterpret_cast<uintptr_t>(do_bf) | reinterpret_cast<uintptr_t>(x_bf) | reinterpret_cast<uintptr_t>(xtc_bf) | reinterpret_cast<uintptr_t>(p_f16) |
+                     reinterpret_cast<uintptr_t>(ds_bf)) & 15) && !((do_sb | do_sh | lddo | ldx | ds_sb | ds_sh) & 7) && ldx >= dm && lddq >= (int64_t)H * dm,
+                  "bmt_raw_attn_bwd: 16-byte aligned operands, strides that are multiples of 8 elements");
+    const size_t lds = raw_attn_lds(dm, Skp);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(raw_attn_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, do_bf, do_sb, do_sh, lddo, x_bf, ldx, off, xtc_bf,
+                       const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dq_bf, (uint16_t*)nullptr, lddq, H, Tq, dm, Skp, scale);
+    BMT_CHECK_LAUNCH("bmt_raw_attn_bwd");
     return BMT_OK;
 }

@@ -2726,6 +2726,9 @@ def cat2(a, b):
 # tests/study_cross_attention_reassociation.py): the per-head block products q_h W_k,h and (P_h X) W_v,h^T split-bf16 (three passes), the two
 # products against the memory one fp16 pass, backward one bf16 pass.  RAW_MEMORY switch: "0" = keys and values are projected, as before.
 RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
+# RAW_FUSED: the two products against the memory and the row operation between them as ONE launch per attention (bmt_raw_attn_fwd / _bwd,
+# ABI 12); "0" = the three launches of round 5 (the same arithmetic: tests/test_gpu_raw_memory.py compares the two)
+RAW_FUSED = _os.environ.get("BMT_RAW_FUSED", "1") != "0"
 
 
 class RawMemoryState:
@@ -2765,6 +2768,12 @@ def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, ah, al, lda, bh, bl, ldb, *, a_of
     bt = _lib.GemmBatch(nb_o, nb_i, a_off[0], a_off[1], b_off[0], b_off[1], b_rows, c_off[0], c_off[1], p_off[0], p_off[1], p2_off[0], p2_off[1], ldp2,
                         bias_off_i, drop_off[0], drop_off[1], a_div[0], c_div[0], p_div[0], p2_div[0], a_div[1], c_div[1], p_div[1], p2_div[1])
     _lib.check(lib.bmt_gemm_small_batched(C.byref(a), C.byref(bt), _st()), "bmt_gemm_small_batched")
+
+
+def raw_attn_launch(bwd: bool, B: int, H: int, Tq: int, S: int, dm: int, fn):
+    """one fused launch of the reassociated cross-attention's middle (bmt_raw_attn_fwd / _bwd): two products of H Tq x S x dm per sample and the
+    row operation between them.  ``fn`` issues it -- a seam of its own so that bench.py's kernel timer sees the launch as a class"""
+    return fn()
 
 
 def raw_form_ok(st: "RawMemoryState", Q, mha, pol) -> bool:
@@ -2922,20 +2931,26 @@ class RawCrossAttnFn(torch.autograd.Function):
         gemm_batched(X3, M, dm, D // H, 1, H, _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
                      a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb), p2=_addr(qf), p2_f16=True,
                      ldp2=H * dm, p2_off=(0, dm), p2_div=(0, 0))
-        # S = Q' X^T against the sample's packed rows
-        S_ = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
-        # (one product per sample over the H Tq queries of all heads -- row (h, t): the memory's rows are fetched once for the four heads)
-        gemm_batched(PREC_F16, H * Tq, st.S, dm, B, 1, _addr(qf), None, H * dm, _addr(st.x.fh), None, st.x.fh.stride(0),
-                     a_off=(Tq * H * dm, 0), a_div=(Tq, dm), b_rows=st.pack.off_ptr, C_=_addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
         Pf = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float16)
         ao, asb, ash = st.a_block(l, 1) if st.astack is not None else (0, 0, 0)
-        _lib.check(lib.bmt_raw_softmax_fwd(_p(S_), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), _p(Pf),
-                                           C.c_void_p(_addr(st.astack, ao)) if st.astack is not None else None, asb, ash, _st()), "bmt_raw_softmax_fwd")
+        p_bf = C.c_void_p(_addr(st.astack, ao)) if st.astack is not None else None
         # O' = P X (natural layout, split-bf16 planes: the A operand of the value block product)
         Op = _alloc_planes(M, H * dm, "x3", dev, ld=H * dm)
-        gemm_batched(PREC_F16, H * Tq, dm, Skp, B, 1, _addr(Pf), None, Skp, _addr(st.xt_f16), None, Skp,
-                     a_off=(H * 32 * Skp, 0), a_div=(Tq, 32 * Skp), b_off=(dm * Skp, 0), p1=_addr(Op.hi), p2=_addr(Op.lo), ldp=H * dm,
-                     p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
+        if RAW_FUSED and lib.bmt_raw_attn_ok(dm, Skp):
+            # S = Q' X^T -> P = softmax -> O' = P X as one launch per attention, workgroup = (sample, head): the score tile stays in LDS
+            raw_attn_launch(False, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_fwd(
+                _addr(qf), Tq * H * dm, dm, H * dm, _addr(st.x.fh), st.x.fh.stride(0), st.pack.off_ptr, _addr(st.xt_f16), B, H, Tq, dm, Skp,
+                1.0 / math.sqrt(dk), _p(Pf), p_bf, asb, ash, _addr(Op.hi), _addr(Op.lo), H * dm, _st()), "bmt_raw_attn_fwd"))
+        else:
+            # S = Q' X^T against the sample's packed rows
+            S_ = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
+            # (one product per sample over the H Tq queries of all heads -- row (h, t): the memory's rows are fetched once for the four heads)
+            gemm_batched(PREC_F16, H * Tq, st.S, dm, B, 1, _addr(qf), None, H * dm, _addr(st.x.fh), None, st.x.fh.stride(0),
+                         a_off=(Tq * H * dm, 0), a_div=(Tq, dm), b_rows=st.pack.off_ptr, C_=_addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
+            _lib.check(lib.bmt_raw_softmax_fwd(_p(S_), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), _p(Pf), p_bf, asb, ash, _st()), "bmt_raw_softmax_fwd")
+            gemm_batched(PREC_F16, H * Tq, dm, Skp, B, 1, _addr(Pf), None, Skp, _addr(st.xt_f16), None, Skp,
+                         a_off=(H * 32 * Skp, 0), a_div=(Tq, 32 * Skp), b_off=(dm * Skp, 0), p1=_addr(Op.hi), p2=_addr(Op.lo), ldp=H * dm,
+                         p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
         # concat_h(O'_h W_v,h^T + b_v), dropout on the attention output (model/multihead_attention.py:22-23), as split-bf16 planes
         o = _alloc_planes(M, D, "x3", dev, ld=D)
         gv_hi, gv_lo = grp.hi[D:], grp.lo[D:]                                               # W_v's rows of the group
@@ -2996,17 +3011,23 @@ class RawCrossAttnFn(torch.autograd.Function):
         gemm_batched(PREC_BF16, M, dm, dk, 1, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
                      a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb))
         dWv = _blockdiag_dw(do, Planes(Oph, None, M, H * dm), Wv, H)
-        # dP = dO' X^T
-        dP = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
-        gemm_batched(PREC_BF16, H * Tq, st.S, dm, B, 1, _addr(st.bstack, bo_), None, dm, _addr(st.x.hi), None, st.x.hi.stride(0),
-                     a_off=(bsb, 0), a_div=(Tq, bsh), b_rows=st.pack.off_ptr, C_=_addr(dP), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
         ao, asb, ash = st.a_block(l, 0)
-        _lib.check(lib.bmt_raw_softmax_bwd(_p(Pf), _p(dP), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _st()),
-                   "bmt_raw_softmax_bwd")
         # dQ' = dS (X - mean key): natural layout, bf16
         dQp = Planes(torch.empty(M, H * dm, device=dev, dtype=torch.bfloat16), None, M, H * dm)
-        gemm_batched(PREC_BF16, H * Tq, dm, Skp, B, 1, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
-                     a_off=(asb, 0), a_div=(Tq, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
+        if RAW_FUSED and lib.bmt_raw_attn_ok(dm, Skp):
+            # dP = dO' X^T -> dS = P o (dP - rowsum(P o dP)) scale -> dQ' = dS (X - mean key) as one launch (the forward's kernel, bf16 operands)
+            raw_attn_launch(True, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_bwd(
+                _addr(st.bstack, bo_), bsb, bsh, dm, _addr(st.x.hi), st.x.hi.stride(0), st.pack.off_ptr, _addr(st.xtc_bf), _p(Pf), B, H, Tq, dm, Skp,
+                1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _addr(dQp.hi), H * dm, _st()), "bmt_raw_attn_bwd"))
+        else:
+            # dP = dO' X^T
+            dP = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float32)
+            gemm_batched(PREC_BF16, H * Tq, st.S, dm, B, 1, _addr(st.bstack, bo_), None, dm, _addr(st.x.hi), None, st.x.hi.stride(0),
+                         a_off=(bsb, 0), a_div=(Tq, bsh), b_rows=st.pack.off_ptr, C_=_addr(dP), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
+            _lib.check(lib.bmt_raw_softmax_bwd(_p(Pf), _p(dP), st.pack.off_ptr, B, H, Tq, Skp, 1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _st()),
+                       "bmt_raw_softmax_bwd")
+            gemm_batched(PREC_BF16, H * Tq, dm, Skp, B, 1, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
+                         a_off=(asb, 0), a_div=(Tq, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
         # dq_h = dQ'_h W_k,h^T (+ its column sums = db_q)
         gbq = static_grad(bq)
         dbq_t = gbq if gbq is not None else torch.zeros(D, device=dev, dtype=torch.float32)

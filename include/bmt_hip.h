@@ -34,7 +34,7 @@ extern "C" {
 #define BMT_ENOENT (-3)   /* a feature file does not exist / cannot be opened (the reference catches FileNotFoundError) */
 #define BMT_EALIGN (-4)   /* pointer or stride alignment requirement violated */
 
-#define BMT_ABI_VERSION 11
+#define BMT_ABI_VERSION 12
 
 int bmt_version(void);
 const char* bmt_last_error(void);
@@ -210,6 +210,24 @@ int bmt_raw_softmax_fwd(const float* S, const int* off, int B, int H, int Tq, in
                         int64_t p_bf_sh, void* stream);
 int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const int* off, int B, int H, int Tq, int Skp, float scale, uint16_t* ds_bf, int64_t ds_sb,
                         int64_t ds_sh, void* stream);
+/* ABI 12 -- the two products against the memory and the row operation between them as ONE launch per attention (workgroup = (sample, head);
+ * the 32 x Skp score tile stays in LDS).  Replaces, with the same arithmetic and the same outputs, bmt_gemm_small_batched (S or dP) ->
+ * bmt_raw_softmax_fwd / _bwd -> bmt_gemm_small_batched (O' or dQ') of model/multihead_attention.py:8-26 in the reassociated form:
+ *   bmt_raw_attn_fwd  q_f16: row t of (b, h) at q_f16 + b * q_sb + h * q_sh + t * ldq (dm fp16 values = Q'_h, rows t < Tq); x_f16 the packed
+ *                     memory plane, xt_f16 its per-sample transposed copy (bmt_memory_transposed) -> p_f16 [B][H][32][Skp], p_bf (optional) as
+ *                     bmt_raw_softmax_fwd writes them, and O' = P X as split-bf16 planes o_hi / o_lo (o_lo optional) at row b * Tq + t,
+ *                     column h * dm + d, row stride ldo;
+ *   bmt_raw_attn_bwd  do_bf: row t of (b, h) at do_bf + b * do_sb + h * do_sh + t * lddo (dO'_h, bf16); x_bf the memory's bf16 plane, xtc_bf its
+ *                     centred transposed copy, p_f16 the forward's P -> ds_bf (optional) as bmt_raw_softmax_bwd writes it and dQ' = dS (X - mean key)
+ *                     as a bf16 plane dq_bf (row b * Tq + t, column h * dm + d, row stride lddq);
+ *   bmt_raw_attn_ok   1 where the form applies: dm and Skp multiples of 64, Skp <= 1024, 64 (dm + 8) + 128 (Skp + 4) + 32 768 bytes of LDS <= 160 KB. */
+int bmt_raw_attn_ok(int dm, int Skp);
+int bmt_raw_attn_fwd(const uint16_t* q_f16, int64_t q_sb, int64_t q_sh, int64_t ldq, const uint16_t* x_f16, int64_t ldx, const int* off,
+                     const uint16_t* xt_f16, int B, int H, int Tq, int dm, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb,
+                     int64_t p_bf_sh, uint16_t* o_hi, uint16_t* o_lo, int64_t ldo, void* stream);
+int bmt_raw_attn_bwd(const uint16_t* do_bf, int64_t do_sb, int64_t do_sh, int64_t lddo, const uint16_t* x_bf, int64_t ldx, const int* off,
+                     const uint16_t* xtc_bf, const uint16_t* p_f16, int B, int H, int Tq, int dm, int Skp, float scale, uint16_t* ds_bf, int64_t ds_sb,
+                     int64_t ds_sh, uint16_t* dq_bf, int64_t lddq, void* stream);
 /* x fp32 (B,S,C) -> halo-padded planes [B*(S+2*halo) + tail][ldp] (zero halo rows, zero columns >= C): hi = bf16(x) and, optionally,
  * lo = bf16(x - hi) or (lo_f16) fp16(x) */
 int bmt_pad_planes(const float* x, int B, int S, int C, int halo, int tail, uint16_t* hi, uint16_t* lo, int lo_f16, int64_t ldp,

@@ -149,6 +149,92 @@ def test_batched_small_products(ops):
     assert_close(cs, want.sum(0), atol=2e-2, rtol=1e-4, name="column sums")
 
 
+@pytest.mark.parametrize("dm,S,Tq,H", [(128, 800, 29, 4), (1024, 256, 29, 4), (128, 100, 7, 2), (256, 768, 32, 8), (64, 64, 1, 1)])
+def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
+    """bmt_raw_attn_fwd / _bwd (ABI 12: both products against the memory and the row operation between them in one launch, the score tile in
+    LDS) against the three launches they replace, on the same operands (P fp16 and bf16, O' hi + lo, dS, dQ'): the same arithmetic up to the
+    order of the fp32 sums (the small-product kernel splits a long reduction over its four waves), so the outputs agree to a rounding of
+    their 16-bit formats; ragged samples, one sample WITHOUT a key, query rows t >= Tq"""
+    import ctypes as C
+    lib = ops.lib
+    B = 5
+    assert lib.bmt_raw_attn_ok(dm, ops._pad64(S)) == 1
+    m = _mask(B, S, seed=S + dm)
+    m[2] = False                                         # a sample without a valid key: zeros, not NaN (bmt_raw_softmax_fwd's convention)
+    lens = m.view(B, S).sum(1)
+    X = rnd(B, S, dm, seed=1) * 0.7 + 0.3
+    xp, rows = _packed(ops, X, m)
+    pk = ops.pack_of(xp)
+    Skp = ops._pad64(S)
+    xpl = ops.make_planes(xp.view(-1, dm), "f16", pack=pk)
+    xt = torch.empty(B, dm, Skp, device=DEV, dtype=torch.float16)
+    xtc = torch.empty(B, dm, Skp, device=DEV, dtype=torch.bfloat16)
+    ksum = torch.zeros(B, dm, device=DEV)
+    ops._lib.check(lib.bmt_memory_transposed(ops._p(xpl.fh), xpl.fh.stride(0), pk.off_ptr, B, dm, Skp, ops._p(xt), ops._p(xtc), ops._p(ksum), None), "t")
+    M = B * Tq
+    scale = 1.0 / math.sqrt(256)
+    qf = (rnd(M, H * dm, seed=2) * 0.5).to(DEV).to(torch.float16)
+    sb, sh = 2 * H * 32 * Skp, 32 * Skp                  # a stack [B][2][H][32][Skp]: kind 0 = dS, kind 1 = P
+    bsb, bsh = H * 32 * dm, 32 * dm
+
+    def forward(fused):
+        Pf = torch.full((B, H, 32, Skp), 3.0, device=DEV, dtype=torch.float16)
+        stack = torch.full((B, 2, H, 32, Skp), 5.0, device=DEV, dtype=torch.bfloat16)
+        hi = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+        lo = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+        pb = C.c_void_p(ops._addr(stack, H * 32 * Skp))
+        if fused:
+            ops._lib.check(lib.bmt_raw_attn_fwd(ops._addr(qf), Tq * H * dm, dm, H * dm, ops._addr(xpl.fh), xpl.fh.stride(0), pk.off_ptr, ops._addr(xt), B, H, Tq,
+                                                dm, Skp, scale, ops._p(Pf), pb, sb, sh, ops._addr(hi), ops._addr(lo), H * dm, None), "f")
+        else:
+            S_ = torch.empty(B, H, 32, Skp, device=DEV)
+            ops.gemm_batched(ops.PREC_F16, H * Tq, S, dm, B, 1, ops._addr(qf), None, H * dm, ops._addr(xpl.fh), None, xpl.fh.stride(0),
+                             a_off=(Tq * H * dm, 0), a_div=(Tq, dm), b_rows=pk.off_ptr, C_=ops._addr(S_), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
+            ops._lib.check(lib.bmt_raw_softmax_fwd(ops._p(S_), pk.off_ptr, B, H, Tq, Skp, scale, ops._p(Pf), pb, sb, sh, None), "s")
+            ops.gemm_batched(ops.PREC_F16, H * Tq, dm, Skp, B, 1, ops._addr(Pf), None, Skp, ops._addr(xt), None, Skp, a_off=(H * 32 * Skp, 0),
+                             a_div=(Tq, 32 * Skp), b_off=(dm * Skp, 0), p1=ops._addr(hi), p2=ops._addr(lo), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
+        torch.cuda.synchronize()
+        return Pf, stack, hi, lo
+
+    a, b_ = forward(True), forward(False)
+    # (one fp16 / bf16 rounding step of the largest value: 2^-11 / 2^-8 relative)
+    assert_close(a[0].float(), b_[0].float(), atol=1.1 * 2.0 ** -11 * amax(b_[0]), rtol=0, name="P fp16")
+    assert_close(a[1].float(), b_[1].float(), atol=1.1 * 2.0 ** -8 * amax(b_[0]), rtol=0, name="P bf16 (stack; kind 0 untouched)")
+    oa, ob = a[2].float() + a[3].float(), b_[2].float() + b_[3].float()
+    assert_close(oa, ob, atol=2e-3 * amax(ob), rtol=0, name="O' (hi + lo)")
+    assert rel_err(oa, ob) < 5e-4
+    Pf = a[0]
+    assert amax(Pf[2]) == 0.0 and amax(Pf[:, :, Tq:]) == 0.0
+    rs = Pf[:, :, :Tq].float().sum(-1)
+    assert bool(((rs - 1).abs() < 2e-3)[lens > 0].all())
+    # backward: dO' rows from a B stack [B][H][32][dm] whose rows t >= Tq are zero
+    dO = torch.zeros(B, H, 32, dm, device=DEV, dtype=torch.bfloat16)
+    dO[:, :, :Tq] = (rnd(B, H, Tq, dm, seed=3) * 0.3).to(DEV).to(torch.bfloat16)
+
+    def backward(fused):
+        stack = torch.full((B, 2, H, 32, Skp), 5.0, device=DEV, dtype=torch.bfloat16)
+        dq = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+        ds = C.c_void_p(ops._addr(stack))
+        if fused:
+            ops._lib.check(lib.bmt_raw_attn_bwd(ops._addr(dO), bsb, bsh, dm, ops._addr(xpl.hi), xpl.hi.stride(0), pk.off_ptr, ops._addr(xtc), ops._p(Pf), B, H, Tq,
+                                                dm, Skp, scale, ds, sb, sh, ops._addr(dq), H * dm, None), "b")
+        else:
+            dP = torch.empty(B, H, 32, Skp, device=DEV)
+            ops.gemm_batched(ops.PREC_BF16, H * Tq, S, dm, B, 1, ops._addr(dO), None, dm, ops._addr(xpl.hi), None, xpl.hi.stride(0),
+                             a_off=(bsb, 0), a_div=(Tq, bsh), b_rows=pk.off_ptr, C_=ops._addr(dP), ldc=Skp, c_off=(H * 32 * Skp, 0), c_div=(Tq, 32 * Skp))
+            ops._lib.check(lib.bmt_raw_softmax_bwd(ops._p(Pf), ops._p(dP), pk.off_ptr, B, H, Tq, Skp, scale, ds, sb, sh, None), "sb")
+            ops.gemm_batched(ops.PREC_BF16, H * Tq, dm, Skp, B, 1, ops._addr(stack), None, Skp, ops._addr(xtc), None, Skp,
+                             a_off=(sb, 0), a_div=(Tq, sh), b_off=(dm * Skp, 0), p1=ops._addr(dq), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
+        torch.cuda.synchronize()
+        return stack, dq
+
+    a, b_ = backward(True), backward(False)
+    assert_close(a[0][:, 0].float(), b_[0][:, 0].float(), atol=1.1 * 2.0 ** -8 * amax(b_[0][:, 0]), rtol=0, name="dS (stack)")
+    assert bool((a[0][:, 1] == 5.0).all())
+    assert_close(a[1].float(), b_[1].float(), atol=1e-2 * amax(b_[1]), rtol=0, name="dQ'")
+    assert rel_err(a[1].float(), b_[1].float()) < 4e-3 and amax(a[1]) > 0.0
+
+
 # ------------------------------------------------------------------------------------------ one attention module, both forms, against fp64
 def _reference_mha(Q, X, m, P, H):
     """model/multihead_attention.py:55-86 in fp64 (dropout off); X padded (B, S, dm), m (B, 1, S)"""

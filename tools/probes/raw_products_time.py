@@ -58,7 +58,18 @@ def main():
             "dq_h = dQ'_h W_k,h^T (bf16)": lambda sp: ops.gemm_batched(ops.PREC_BF16, M, dk, dm, 1, H, A(nat_hi), None, H * dm, A(w_hi), None, dm, a_off=(0, dm), b_off=(0, dk * dm),
                                                                       p1=A(o_hi), ldp=D, p_off=(0, dk), split=sp),
         }
+        lib, ck = ops.lib, ops._lib.check
+        fused = {
+            "fused S -> softmax -> O' (f16)": lambda: ck(lib.bmt_raw_attn_fwd(A(qf), Tq * H * dm, dm, H * dm, A(x_fh), dm, pk.off_ptr, A(xt), B, H, Tq, dm, Skp, 0.0625, A(Pf),
+                                                                                A(stackA), asb, ash, A(nat_hi), A(nat_lo), H * dm, ops._st()), "f"),
+            "fused dP -> dS -> dQ' (bf16)": lambda: ck(lib.bmt_raw_attn_bwd(A(stackB), bsb, bsh, dm, A(x_hi), dm, pk.off_ptr, A(xtc), A(Pf), B, H, Tq, dm, Skp, 0.0625,
+                                                                              A(stackA), asb, ash, A(nat_hi), H * dm, ops._st()), "b"),
+            "softmax forward alone": lambda: ck(lib.bmt_raw_softmax_fwd(A(S_), pk.off_ptr, B, H, Tq, Skp, 0.0625, A(Pf), A(stackA), asb, ash, ops._st()), "s"),
+        }
         print(f"--- {name} memory: d = {dm}, {S} keys (capacity), {B} samples x {H} heads x {Tq} queries")
+        for label, f in fused.items():
+            f()
+            print(f"{label:32s} {timed(f, 20):6.1f} us hot {timed(f, 10, flush):6.1f} us cold", flush=True)
         for label, fn in cases.items():
             row = []
             for sp in (1, 4):
