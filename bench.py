@@ -185,13 +185,16 @@ class KernelTimer:
 
         raw_ral = ops.raw_attn_launch
 
-        def raw_attn_launch(bwd, B_, H, Tq, S, dm, fn):
+        def raw_attn_launch(bwd, B_, H, Tq, S, dm, fn, edges_dk=0):
             if not timer.enabled:
-                return raw_ral(bwd, B_, H, Tq, S, dm, fn)
+                return raw_ral(bwd, B_, H, Tq, S, dm, fn, edges_dk=edges_dk)
             # two products of (H Tq) x S x dm per sample; bytes: the A rows and the result rows (16-bit), the memory both ways, P / dS (16-bit, twice)
             fl = 2 * 2.0 * B_ * H * Tq * S * dm
             by = B_ * (2.0 * 2 * H * Tq * dm + 2.0 * 2 * S * dm + 2.0 * 2 * H * Tq * S)
-            return timer._timed("raw_attn_fused_" + ("bf16" if bwd else "f16"), 1, fl, by, fn)
+            if edges_dk:      # + the two block products either side (H Tq x dm x d_k each), their d_k-wide rows and the two weight blocks
+                fl += 2 * 2.0 * B_ * H * Tq * dm * edges_dk
+                by += B_ * 2.0 * 2 * H * Tq * edges_dk + 2.0 * 2 * H * edges_dk * dm
+            return timer._timed("raw_attn_fused_" + ("bf16_edges" if edges_dk else "bf16" if bwd else "f16"), 1, fl, by, fn)
 
         ops.raw_attn_launch = raw_attn_launch
         ops.gemm_batched = gemm_batched
@@ -506,6 +509,8 @@ def PMC_FAMILY_OF_KERNEL(name: str) -> str:
 
 # kernel class of the KernelTimer -> family key(s) of the PMC record (a backward attention launch is the dQ and the dK / dV kernel)
 def pmc_keys_of_class(cls: str):
+    if cls.startswith("raw_attn_fused"):       # the decoder's cross-attention middle against a raw memory, one launch (csrc/raw_memory.hip)
+        return ("raw_attn_kernel",)
     if cls.startswith("attn_fwd"):
         return ("attn_fwd",)
     if cls.startswith("attn_bwd"):

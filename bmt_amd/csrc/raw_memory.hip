@@ -372,12 +372,50 @@ __device__ __forceinline__ void raw_row_op(uint32_t* Ss, int lds_s, int w, int l
 // LDS: A [32][dm + 8] 16-bit | S [32][Skp + 4] fp32 -- the 16-bit P / dS row overwrites the head of its own fp32 row (one wave owns a row) --
 // | 8 x 4 KB: the waves' staging areas for the memory's rows (raw_wave_product).
 // All LDS traffic goes through 32-bit unsigned types (the in-place conversion must not be reordered under type-based aliasing).
-template <bool BWD>
+// EDGES (backward): the block products either side of the three steps in the same launch --
+//   in front   dO'_h = do_h W_v,h  (bf16, reduction over d_k): the A operand of the first product, computed into LDS instead of fetched, and
+//              written to the memory gradient's B stack as the unfused product wrote it (32 rows per (sample, head); rows t >= Tq zeros);
+//   behind     dq_h = dQ'_h W_k,h^T (bf16, reduction over dm) + its column sums (db_q): dQ'_h stays in the A operand's LDS area (free after the
+//              first product) beside its copy in memory (the operand of dW_k).
+// Two launches fewer per attention backward on the decoder's chain, and no fetch of dO' / re-fetch of dQ'.
+struct RawEdges {
+    const uint16_t* dO; int64_t ld_do;             // do [M][ld_do] bf16: this head's columns at h * dk
+    const uint16_t* wvT; int64_t ld_wvT;           // row d of dm: W_v[h dk + k][d] at wvT + d * ld_wvT + h * dk + k  (the transposed weight group's plane)
+    uint16_t* bst; int64_t bst_sb, bst_sh;         // dO'_h -> bst + b * bst_sb + h * bst_sh + t * dm
+    const uint16_t* wk; int64_t ld_wk;             // row h dk + n of W_k's plane, dm contiguous
+    uint16_t* dq; int64_t ld_dq;                   // dq [M][ld_dq] bf16, column h dk + n
+    float* dbq;                                    // [H dk] += column sums of dq over the rows that exist (or null)
+    int dk;
+};
+
+// a finished 32 x 32 fp32 tile through the wave's 4-KB area ([32][32] fp32, 16-byte granules XOR-swizzled by the row): lane -> rows
+// t = (l >> 2) + 16 it, 8 consecutive columns (l & 3) * 8; f(it, t, v0, v1)
+template <typename F>
+__device__ __forceinline__ void raw_tile_rows(float* mine, const f32x16& acc, int l, F f) {
+    const int lr = l & 31, half = l >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = acc_row(r, half);
+        mine[t * 32 + (((lr >> 2) ^ (t & 7)) << 2) + (lr & 3)] = acc[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int t = it * 16 + (l >> 2), g = (l & 3) * 2;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(mine + t * 32 + ((g ^ (t & 7)) << 2));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(mine + t * 32 + (((g + 1) ^ (t & 7)) << 2));
+        f(it, t, v0, v1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <bool BWD, bool EDGES = false>
 __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restrict__ A1, int64_t a_sb, int64_t a_sh, int64_t a_ld,
                                                         const uint16_t* __restrict__ X, int64_t ldx, const int* __restrict__ off,
                                                         const uint16_t* __restrict__ XT, uint16_t* p_f16, uint16_t* __restrict__ stk, int64_t s_sb,
                                                         int64_t s_sh, uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo, int64_t ldo, int H, int Tq,
-                                                        int dm, int Skp, float scale) {
+                                                        int dm, int Skp, float scale, const RawEdges eg) {
+    static_assert(BWD || !EDGES, "the edge products are the backward's");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 31, half = l >> 5;
     // (the H workgroups of a sample on ONE XCD, in consecutive dispatch slots: the sample's rows come over the fabric once, not once per head)
@@ -388,8 +426,29 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     uint32_t* As = reinterpret_cast<uint32_t*>(smem);
     uint32_t* Ss = reinterpret_cast<uint32_t*>(smem + (size_t)32 * lda_s * 2);
     char* const wbase = smem + (size_t)32 * lda_s * 2 + (size_t)32 * lds_s * 4 + w * 4096;
+    if constexpr (EDGES) {
+        // ---- do_h (32 x d_k, rows t >= Tq zeros) -> LDS (the score tile's area, free until the first product), then dO'_h = do_h W_v,h -> the A area + the B stack
+        const int dk = eg.dk, ldd_s = dk + 8, pc = dk >> 3;
+        const uint16_t* d1 = eg.dO + (int64_t)b * Tq * eg.ld_do + (int64_t)h * dk;
+        for (int i = tid; i < 32 * pc; i += 512) {
+            const int t = i / pc, c = (i - t * pc) * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (t < Tq) v = *reinterpret_cast<const u32x4*>(d1 + (int64_t)t * eg.ld_do + c);
+            *reinterpret_cast<u32x4*>(Ss + ((t * ldd_s + c) >> 1)) = v;
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wvT + (int64_t)h * dk), 0, (int)((((int64_t)dm - 1) * eg.ld_wvT + dk) * 2), 0x00020000);
+        uint16_t* bs = eg.bst + b * eg.bst_sb + h * eg.bst_sh;
+        raw_wave_product<false, 4>(Ss, ldd_s >> 1, rsW, (int)(eg.ld_wvT * 2), dm, dm >> 5, dk >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+            raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
+                const u32x4 hv = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+                const int c = n * 32 + (l & 3) * 8;
+                *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = hv;
+                *reinterpret_cast<u32x4*>(bs + (int64_t)t * dm + c) = hv;
+            });
+        });
+    } else {
     // ---- A (the 32 query rows of this head; rows t >= Tq are zeros) -> LDS
-    {
         const uint16_t* a1 = A1 + b * a_sb + h * a_sh;
         const int pc = dm >> 3;
         for (int i = tid; i < 32 * pc; i += 512) {
@@ -419,32 +478,51 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     // transposed memory are zero from the length to Skp, a multiple of 64)
     {
         const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(XT + (int64_t)b * dm * Skp), 0, (int)((int64_t)dm * Skp * 2), 0x00020000);
-        float* const mine = reinterpret_cast<float*>(wbase);
         raw_wave_product<!BWD, 4>(Ss, lds_s, rsT, Skp * 2, dm, dm >> 5, max(1, (len + 63) >> 6), wbase, w, l, [&](int n, const f32x16& acc) {
-            // the tile through the wave's area ([32][32] fp32, 16-byte granules XOR-swizzled by the row): a lane then owns 8 consecutive columns of a row
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = acc_row(r, half);
-                mine[t * 32 + (((lr >> 2) ^ (t & 7)) << 2) + (lr & 3)] = acc[r];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int t = it * 16 + (l >> 2), g = (l & 3) * 2;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(mine + t * 32 + ((g ^ (t & 7)) << 2));
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(mine + t * 32 + (((g + 1) ^ (t & 7)) << 2));
-                if (t >= Tq) continue;
-                const int64_t o = (int64_t)(b * Tq + t) * ldo + (int64_t)h * dm + n * 32 + (l & 3) * 8;
+            raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
                 uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
                 split_bf2(v0[0], v0[1], h0, l0);
                 split_bf2(v0[2], v0[3], h1, l1);
                 split_bf2(v1[0], v1[1], h2, l2);
                 split_bf2(v1[2], v1[3], h3, l3);
                 const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                const int c = n * 32 + (l & 3) * 8;
+                if constexpr (EDGES) *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = hi;      // (rows t >= Tq: zeros, dS's are)
+                if (t >= Tq) return;
+                const int64_t o = (int64_t)(b * Tq + t) * ldo + (int64_t)h * dm + c;
                 *reinterpret_cast<u32x4*>(o_hi + o) = hi;
                 if (o_lo) *reinterpret_cast<u32x4*>(o_lo + o) = lo;
+            });
+        });
+    }
+    if constexpr (EDGES) {
+        // ---- dq_h = dQ'_h W_k,h^T: a wave per 32 columns of the head, the reduction over dm; column sums over the rows that exist -> db_q
+        __syncthreads();
+        const int dk = eg.dk;
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wk + (int64_t)h * dk * eg.ld_wk), 0, (int)((((int64_t)dk - 1) * eg.ld_wk + dm) * 2), 0x00020000);
+        raw_wave_product<false, 4>(As, lda_s >> 1, rsK, (int)(eg.ld_wk * 2), dk, dk >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+            float cs[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs[q] = 0.f;
+            const int c = h * dk + n * 32 + (l & 3) * 8;
+            raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
+                if (t >= Tq) return;
+                const u32x4 hv = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+                *reinterpret_cast<u32x4*>(eg.dq + (int64_t)(b * Tq + t) * eg.ld_dq + c) = hv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cs[q] += v0[q]; cs[4 + q] += v1[q]; }
+            });
+            if (eg.dbq) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int o = 4; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+                }
+                if (l < 4) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) atomicAdd(eg.dbq + c + q, cs[q]);
+                }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
     }
 }
@@ -508,7 +586,7 @@ extern "C" int bmt_raw_attn_fwd(const uint16_t* q_f16, int64_t q_sb, int64_t q_s
         lds_set = lds;
     }
     hipLaunchKernelGGL(raw_attn_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, q_f16, q_sb, q_sh, ldq, x_f16, ldx, off, xt_f16, p_f16, p_bf, p_bf_sb,
-                       p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale);
+                       p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, RawEdges{});
     BMT_CHECK_LAUNCH("bmt_raw_attn_fwd");
     return BMT_OK;
 }
@@ -528,7 +606,37 @@ extern "C" int bmt_raw_attn_bwd(const uint16_t* do_bf, int64_t do_sb, int64_t do
         lds_set = lds;
     }
     hipLaunchKernelGGL(raw_attn_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, do_bf, do_sb, do_sh, lddo, x_bf, ldx, off, xtc_bf,
-                       const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dq_bf, (uint16_t*)nullptr, lddq, H, Tq, dm, Skp, scale);
+                       const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dq_bf, (uint16_t*)nullptr, lddq, H, Tq, dm, Skp, scale, RawEdges{});
     BMT_CHECK_LAUNCH("bmt_raw_attn_bwd");
+    return BMT_OK;
+}
+
+extern "C" int bmt_raw_attn_edges_ok(int dm, int Skp, int dk) {
+    return bmt_raw_attn_ok(dm, Skp) && dk > 0 && dk % 64 == 0 && (size_t)32 * (dk + 8) * 2 <= (size_t)32 * (Skp + 4) * 4;
+}
+
+extern "C" int bmt_raw_attn_bwd_edges(const uint16_t* do_bf, int64_t ld_do, const uint16_t* wvT_bf, int64_t ld_wvT, uint16_t* bstack, int64_t b_sb, int64_t b_sh,
+                                      const uint16_t* x_bf, int64_t ldx, const int* off, const uint16_t* xtc_bf, const uint16_t* p_f16, int B, int H, int Tq,
+                                      int dm, int Skp, int dk, float scale, uint16_t* ds_bf, int64_t ds_sb, int64_t ds_sh, uint16_t* dqp_bf, int64_t lddqp,
+                                      const uint16_t* wk_bf, int64_t ld_wk, uint16_t* dq_bf, int64_t ld_dq, float* dbq, void* stream) {
+    BMT_CHECK_ARG(do_bf && wvT_bf && bstack && x_bf && off && xtc_bf && p_f16 && dqp_bf && wk_bf && dq_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32,
+                  "bmt_raw_attn_bwd_edges: null pointer or bad extents (at most 32 queries per sample and head)");
+    BMT_CHECK_ARG(bmt_raw_attn_edges_ok(dm, Skp, dk), "bmt_raw_attn_bwd_edges: bmt_raw_attn_ok(dm, Skp), d_k a multiple of 64 with 64 (d_k + 8) <= 128 (Skp + 4)");
+    BMT_CHECK_ARG(!((reinterpret_cast<uintptr_t>(do_bf) | reinterpret_cast<uintptr_t>(wvT_bf) | reinterpret_cast<uintptr_t>(bstack) | reinterpret_cast<uintptr_t>(x_bf) |
+                     reinterpret_cast<uintptr_t>(xtc_bf) | reinterpret_cast<uintptr_t>(p_f16) | reinterpret_cast<uintptr_t>(ds_bf) | reinterpret_cast<uintptr_t>(dqp_bf) |
+                     reinterpret_cast<uintptr_t>(wk_bf) | reinterpret_cast<uintptr_t>(dq_bf)) & 15) &&
+                      !((ld_do | ld_wvT | b_sb | b_sh | ldx | ds_sb | ds_sh | lddqp | ld_wk | ld_dq) & 7) && ldx >= dm && lddqp >= (int64_t)H * dm && ld_wk >= dm &&
+                      ld_do >= (int64_t)H * dk && ld_dq >= (int64_t)H * dk && ld_wvT >= (int64_t)H * dk,
+                  "bmt_raw_attn_bwd_edges: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
+    const size_t lds = raw_attn_lds(dm, Skp);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    const RawEdges eg{do_bf, ld_do, wvT_bf, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk};
+    hipLaunchKernelGGL((raw_attn_kernel<true, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_bf,
+                       ldx, off, xtc_bf, const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dqp_bf, (uint16_t*)nullptr, lddqp, H, Tq, dm, Skp, scale, eg);
+    BMT_CHECK_LAUNCH("bmt_raw_attn_bwd_edges");
     return BMT_OK;
 }

@@ -2729,6 +2729,7 @@ RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
 # RAW_FUSED: the two products against the memory and the row operation between them as ONE launch per attention (bmt_raw_attn_fwd / _bwd,
 # ABI 12); "0" = the three launches of round 5 (the same arithmetic: tests/test_gpu_raw_memory.py compares the two)
 RAW_FUSED = _os.environ.get("BMT_RAW_FUSED", "1") != "0"
+RAW_FUSED_EDGES = _os.environ.get("BMT_RAW_FUSED_EDGES", "1") != "0"      # ... and the backward's block products either side of it (bmt_raw_attn_bwd_edges)
 
 
 class RawMemoryState:
@@ -2770,9 +2771,10 @@ def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, ah, al, lda, bh, bl, ldb, *, a_of
     _lib.check(lib.bmt_gemm_small_batched(C.byref(a), C.byref(bt), _st()), "bmt_gemm_small_batched")
 
 
-def raw_attn_launch(bwd: bool, B: int, H: int, Tq: int, S: int, dm: int, fn):
+def raw_attn_launch(bwd: bool, B: int, H: int, Tq: int, S: int, dm: int, fn, edges_dk: int = 0):
     """one fused launch of the reassociated cross-attention's middle (bmt_raw_attn_fwd / _bwd): two products of H Tq x S x dm per sample and the
-    row operation between them.  ``fn`` issues it -- a seam of its own so that bench.py's kernel timer sees the launch as a class"""
+    row operation between them (edges_dk: + the two block products of H Tq x dm x d_k either side, bmt_raw_attn_bwd_edges).  ``fn`` issues it --
+    a seam of its own so that bench.py's kernel timer sees the launch as a class"""
     return fn()
 
 
@@ -3008,13 +3010,24 @@ class RawCrossAttnFn(torch.autograd.Function):
         gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))
         # dO'_h = do_h W_v,h  -> B stack (b, l, 1, h)
         bo_, bsb, bsh = st.b_block(l, 1)
-        gemm_batched(PREC_BF16, M, dm, dk, 1, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
-                     a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb))
+        edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_edges_ok(dm, Skp, dk))      # ... inside the fused launch below, with dq_h behind it
+        if not edges:
+            gemm_batched(PREC_BF16, M, dm, dk, 1, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
+                         a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb))
         dWv = _blockdiag_dw(do, Planes(Oph, None, M, H * dm), Wv, H)
         ao, asb, ash = st.a_block(l, 0)
         # dQ' = dS (X - mean key): natural layout, bf16
         dQp = Planes(torch.empty(M, H * dm, device=dev, dtype=torch.bfloat16), None, M, H * dm)
-        if RAW_FUSED and lib.bmt_raw_attn_ok(dm, Skp):
+        gbq = static_grad(bq)
+        dbq_t = gbq if gbq is not None else torch.zeros(D, device=dev, dtype=torch.float32)
+        dq = Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D)
+        if edges:
+            # dO'_h = do_h W_v,h -> dP -> dS -> dQ' -> dq_h = dQ'_h W_k,h^T (+ column sums = db_q): one launch, workgroup = (sample, head)
+            raw_attn_launch(True, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_bwd_edges(
+                _addr(do.hi), D, _addr(gT.hi, D), gT.hi.stride(0), _addr(st.bstack, bo_), bsb, bsh, _addr(st.x.hi), st.x.hi.stride(0), st.pack.off_ptr,
+                _addr(st.xtc_bf), _p(Pf), B, H, Tq, dm, Skp, dk, 1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _addr(dQp.hi), H * dm,
+                _addr(grp.hi), grp.hi.stride(0), _addr(dq.hi), D, _p(dbq_t), _st()), "bmt_raw_attn_bwd_edges"), edges_dk=dk)
+        elif RAW_FUSED and lib.bmt_raw_attn_ok(dm, Skp):
             # dP = dO' X^T -> dS = P o (dP - rowsum(P o dP)) scale -> dQ' = dS (X - mean key) as one launch (the forward's kernel, bf16 operands)
             raw_attn_launch(True, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_bwd(
                 _addr(st.bstack, bo_), bsb, bsh, dm, _addr(st.x.hi), st.x.hi.stride(0), st.pack.off_ptr, _addr(st.xtc_bf), _p(Pf), B, H, Tq, dm, Skp,
@@ -3029,11 +3042,9 @@ class RawCrossAttnFn(torch.autograd.Function):
             gemm_batched(PREC_BF16, H * Tq, dm, Skp, B, 1, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
                          a_off=(asb, 0), a_div=(Tq, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
         # dq_h = dQ'_h W_k,h^T (+ its column sums = db_q)
-        gbq = static_grad(bq)
-        dbq_t = gbq if gbq is not None else torch.zeros(D, device=dev, dtype=torch.float32)
-        dq = Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D)
-        gemm_batched(PREC_BF16, M, dk, dm, 1, H, _addr(dQp.hi), None, H * dm, _addr(grp.hi), None, grp.hi.stride(0),
-                     a_off=(0, dm), b_off=(0, dk * grp.hi.stride(0)), p1=_addr(dq.hi), ldp=D, p_off=(0, dk), colsum=dbq_t, bias_off_i=dk)
+        if not edges:
+            gemm_batched(PREC_BF16, M, dk, dm, 1, H, _addr(dQp.hi), None, H * dm, _addr(grp.hi), None, grp.hi.stride(0),
+                         a_off=(0, dm), b_off=(0, dk * grp.hi.stride(0)), p1=_addr(dq.hi), ldp=D, p_off=(0, dk), colsum=dbq_t, bias_off_i=dk)
         if gbq is not None:
             grad_done(bq)
         dWk = _blockdiag_dw(Planes(qh, None, M, D), dQp, Wk, H)

@@ -222,6 +222,17 @@ int bmt_raw_softmax_bwd(const uint16_t* p_f16, const float* dP, const int* off, 
  *                     as a bf16 plane dq_bf (row b * Tq + t, column h * dm + d, row stride lddq);
  *   bmt_raw_attn_ok   1 where the form applies: dm and Skp multiples of 64, Skp <= 1024, 64 (dm + 8) + 128 (Skp + 4) + 32 768 bytes of LDS <= 160 KB. */
 int bmt_raw_attn_ok(int dm, int Skp);
+/*   bmt_raw_attn_bwd_edges  bmt_raw_attn_bwd with the block products either side of it in the same launch: in front dO'_h = do_h W_v,h (do_bf [B Tq][ld_do]
+ *                     bf16, this head's columns at h dk; wvT_bf: row d of dm holds W_v[h dk + k][d] at d * ld_wvT + h dk + k -- the transposed weight
+ *                     group's plane) -> the A operand, and to bstack + b * b_sb + h * b_sh + t * dm (32 rows per (sample, head), rows t >= Tq zeros);
+ *                     behind dq_h = dQ'_h W_k,h^T (wk_bf: W_k's plane, row h dk + n, dm contiguous) -> dq_bf [B Tq][ld_dq] bf16 at column h dk + n, its
+ *                     column sums ADDED to dbq [H dk] (optional).  dqp_bf = dQ' as bmt_raw_attn_bwd writes it.  bmt_raw_attn_edges_ok: the form
+ *                     applies (bmt_raw_attn_ok, dk a multiple of 64, 64 (dk + 8) <= 128 (Skp + 4)). */
+int bmt_raw_attn_edges_ok(int dm, int Skp, int dk);
+int bmt_raw_attn_bwd_edges(const uint16_t* do_bf, int64_t ld_do, const uint16_t* wvT_bf, int64_t ld_wvT, uint16_t* bstack, int64_t b_sb, int64_t b_sh,
+                           const uint16_t* x_bf, int64_t ldx, const int* off, const uint16_t* xtc_bf, const uint16_t* p_f16, int B, int H, int Tq, int dm,
+                           int Skp, int dk, float scale, uint16_t* ds_bf, int64_t ds_sb, int64_t ds_sh, uint16_t* dqp_bf, int64_t lddqp,
+                           const uint16_t* wk_bf, int64_t ld_wk, uint16_t* dq_bf, int64_t ld_dq, float* dbq, void* stream);
 int bmt_raw_attn_fwd(const uint16_t* q_f16, int64_t q_sb, int64_t q_sh, int64_t ldq, const uint16_t* x_f16, int64_t ldx, const int* off,
                      const uint16_t* xt_f16, int B, int H, int Tq, int dm, int Skp, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb,
                      int64_t p_bf_sh, uint16_t* o_hi, uint16_t* o_lo, int64_t ldo, void* stream);

@@ -122,6 +122,10 @@ def test_kernel_classes_map_to_pmc_families():
     assert bench.pmc_keys_of_class("gemm_planes_fp16 x (fp16 hi+lo)") == ("gemm_w2",)
     assert bench.pmc_keys_of_class("attn_bwd_enc_dk256_bf16") == ("attn_bwd_dq", "attn_bwd_dkv")
     assert bench.pmc_keys_of_class("gemm_planes_dw_grouped_bf16") == ("gemm_dw_grouped",)
+    # the decoder's fused cross-attention launches (csrc/raw_memory.hip): one family, whatever the operand format in the class name
+    assert fam("void (anonymous namespace)::raw_attn_kernel<true, true>(unsigned short const*, long)") == "raw_attn_kernel"
+    for c in ("raw_attn_fused_f16", "raw_attn_fused_bf16", "raw_attn_fused_bf16_edges"):
+        assert bench.pmc_keys_of_class(c) == ("raw_attn_kernel",)
 
 
 def test_rocm_smi_clock_parser_on_a_recorded_sample():

@@ -149,7 +149,7 @@ def test_batched_small_products(ops):
     assert_close(cs, want.sum(0), atol=2e-2, rtol=1e-4, name="column sums")
 
 
-@pytest.mark.parametrize("dm,S,Tq,H", [(128, 800, 29, 4), (1024, 256, 29, 4), (128, 100, 7, 2), (256, 768, 32, 8), (64, 64, 1, 1)])
+@pytest.mark.parametrize("dm,S,Tq,H", [(128, 800, 29, 4), (1024, 256, 29, 4), (128, 128, 7, 2), (256, 768, 32, 8), (64, 64, 1, 1)])
 def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
     """bmt_raw_attn_fwd / _bwd (ABI 12: both products against the memory and the row operation between them in one launch, the score tile in
     LDS) against the three launches they replace, on the same operands (P fp16 and bf16, O' hi + lo, dS, dQ'): the same arithmetic up to the
@@ -233,6 +233,44 @@ def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
     assert bool((a[0][:, 1] == 5.0).all())
     assert_close(a[1].float(), b_[1].float(), atol=1e-2 * amax(b_[1]), rtol=0, name="dQ'")
     assert rel_err(a[1].float(), b_[1].float()) < 4e-3 and amax(a[1]) > 0.0
+    # ... and with the block products either side in the same launch (bmt_raw_attn_bwd_edges): dO'_h = do_h W_v,h in front, dq_h = dQ'_h W_k,h^T and
+    # its column sums behind, against the three launches + the two block products
+    dk = 128 if dm == 64 else 256
+    if not lib.bmt_raw_attn_edges_ok(dm, Skp, dk):
+        assert (dm, S) == (64, 64)
+        return
+    D = H * dk
+    do = (rnd(M, D, seed=4) * 0.3).to(DEV).to(torch.bfloat16)
+    wvT = (rnd(dm, D + 64, seed=5) * 0.1).to(DEV).to(torch.bfloat16)          # row d: W_v[h dk + k][d] at column 64 + h dk + k (a plane with other columns in front)
+    wk = (rnd(D, dm, seed=6) * 0.1).to(DEV).to(torch.bfloat16)
+
+    def chain(fused):
+        stack = torch.full((B, 2, H, 32, Skp), 5.0, device=DEV, dtype=torch.bfloat16)
+        bst = torch.zeros(B, H, 32, dm, device=DEV, dtype=torch.bfloat16)
+        dqp = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+        dq = torch.zeros(M, D, device=DEV, dtype=torch.bfloat16)
+        dbq = torch.ones(D, device=DEV)
+        ds = C.c_void_p(ops._addr(stack))
+        if fused:
+            ops._lib.check(lib.bmt_raw_attn_bwd_edges(ops._addr(do), D, ops._addr(wvT, 64), wvT.stride(0), ops._addr(bst), bsb, bsh, ops._addr(xpl.hi), xpl.hi.stride(0),
+                                                      pk.off_ptr, ops._addr(xtc), ops._p(Pf), B, H, Tq, dm, Skp, dk, scale, ds, sb, sh, ops._addr(dqp), H * dm,
+                                                      ops._addr(wk), wk.stride(0), ops._addr(dq), D, ops._p(dbq), None), "e")
+        else:
+            ops.gemm_batched(ops.PREC_BF16, M, dm, dk, 1, H, ops._addr(do), None, D, ops._addr(wvT, 64), None, wvT.stride(0), a_off=(0, dk), b_off=(0, dk),
+                             p1=ops._addr(bst), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb))
+            ops._lib.check(lib.bmt_raw_attn_bwd(ops._addr(bst), bsb, bsh, dm, ops._addr(xpl.hi), xpl.hi.stride(0), pk.off_ptr, ops._addr(xtc), ops._p(Pf), B, H, Tq,
+                                                dm, Skp, scale, ds, sb, sh, ops._addr(dqp), H * dm, None), "b")
+            ops.gemm_batched(ops.PREC_BF16, M, dk, dm, 1, H, ops._addr(dqp), None, H * dm, ops._addr(wk), None, wk.stride(0), a_off=(0, dm),
+                             b_off=(0, dk * wk.stride(0)), p1=ops._addr(dq), ldp=D, p_off=(0, dk), colsum=dbq, bias_off_i=dk)
+        torch.cuda.synchronize()
+        return bst, stack, dqp, dq, dbq
+
+    a, b_ = chain(True), chain(False)
+    assert amax(a[0][:, :, Tq:]) == 0.0 and amax(a[0]) > 0.0
+    for x_, y_, n, bar in zip(a, b_, ("dO' (B stack)", "dS (stack)", "dQ'", "dq", "db_q (accumulated onto ones)"), (4e-3, 1e-2, 1e-2, 1e-2, 1e-3)):
+        e = rel_err(x_.float(), y_.float())
+        assert e < bar, f"{n}: {e:.3e}"
+    assert bool((a[1][:, 1] == 5.0).all())
 
 
 # ------------------------------------------------------------------------------------------ one attention module, both forms, against fp64

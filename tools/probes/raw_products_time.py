@@ -59,11 +59,15 @@ def main():
                                                                       p1=A(o_hi), ldp=D, p_off=(0, dk), split=sp),
         }
         lib, ck = ops.lib, ops._lib.check
+        dbq = torch.zeros(D, device=DEV)
         fused = {
             "fused S -> softmax -> O' (f16)": lambda: ck(lib.bmt_raw_attn_fwd(A(qf), Tq * H * dm, dm, H * dm, A(x_fh), dm, pk.off_ptr, A(xt), B, H, Tq, dm, Skp, 0.0625, A(Pf),
                                                                                 A(stackA), asb, ash, A(nat_hi), A(nat_lo), H * dm, ops._st()), "f"),
             "fused dP -> dS -> dQ' (bf16)": lambda: ck(lib.bmt_raw_attn_bwd(A(stackB), bsb, bsh, dm, A(x_hi), dm, pk.off_ptr, A(xtc), A(Pf), B, H, Tq, dm, Skp, 0.0625,
                                                                               A(stackA), asb, ash, A(nat_hi), H * dm, ops._st()), "b"),
+            "fused dO' -> ... -> dq (bf16)": lambda: ck(lib.bmt_raw_attn_bwd_edges(A(o_hi), D, A(wT_hi, D), 2 * D, A(stackB), bsb, bsh, A(x_hi), dm, pk.off_ptr, A(xtc), A(Pf), B, H, Tq,
+                                                                                     dm, Skp, dk, 0.0625, A(stackA), asb, ash, A(nat_hi), H * dm, A(w_hi), dm, A(q_hi), D, A(dbq),
+                                                                                     ops._st()), "e"),
             "softmax forward alone": lambda: ck(lib.bmt_raw_softmax_fwd(A(S_), pk.off_ptr, B, H, Tq, Skp, 0.0625, A(Pf), A(stackA), asb, ash, ops._st()), "s"),
         }
         print(f"--- {name} memory: d = {dm}, {S} keys (capacity), {B} samples x {H} heads x {Tq} queries")
