@@ -191,10 +191,11 @@ class KernelTimer:
             # two products of (H Tq) x S x dm per sample; bytes: the A rows and the result rows (16-bit), the memory both ways, P / dS (16-bit, twice)
             fl = 2 * 2.0 * B_ * H * Tq * S * dm
             by = B_ * (2.0 * 2 * H * Tq * dm + 2.0 * 2 * S * dm + 2.0 * 2 * H * Tq * S)
-            if edges_dk:      # + the two block products either side (H Tq x dm x d_k each), their d_k-wide rows and the two weight blocks
-                fl += 2 * 2.0 * B_ * H * Tq * dm * edges_dk
-                by += B_ * 2.0 * 2 * H * Tq * edges_dk + 2.0 * 2 * H * edges_dk * dm
-            return timer._timed("raw_attn_fused_" + ("bf16_edges" if edges_dk else "bf16" if bwd else "f16"), 1, fl, by, fn)
+            if edges_dk:      # + the block products either side (H Tq x dm x d_k each: two behind / in front of the backward, one -- split-bf16 -- in front
+                n_e = 2 if bwd else 1      # of the forward), their d_k-wide rows and the weight blocks
+                fl += n_e * 2.0 * B_ * H * Tq * dm * edges_dk
+                by += B_ * 2.0 * n_e * (1 if bwd else 2) * H * Tq * edges_dk + 2.0 * n_e * (1 if bwd else 2) * H * edges_dk * dm
+            return timer._timed("raw_attn_fused_" + ("bf16" if bwd else "f16") + ("_edges" if edges_dk else ""), 1, fl, by, fn)
 
         ops.raw_attn_launch = raw_attn_launch
         ops.gemm_batched = gemm_batched

@@ -111,6 +111,8 @@ SIGNATURES = {
     "bmt_raw_softmax_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, i64, i64, vp]),
     "bmt_raw_attn_ok": (i32, [i32, i32]),
     "bmt_raw_attn_edges_ok": (i32, [i32, i32, i32]),
+    "bmt_raw_attn_fwd_edges_ok": (i32, [i32, i32, i32]),
+    "bmt_raw_attn_fwd_edges": (i32, [vp, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, vp, i64, vp]),
     "bmt_raw_attn_bwd_edges": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, i64, vp, i64, vp, i64, vp, i64,
                                       vp, vp]),
     "bmt_raw_attn_fwd": (i32, [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, vp, i64, vp]),

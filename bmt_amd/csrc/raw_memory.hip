@@ -200,36 +200,44 @@ __device__ __forceinline__ int raw_slot(int row, int s) { return row * 8 + (s ^ 
 //      fragments straight from the planes, 64 scattered 16-byte requests per instruction, and was slower than the three launches it replaces);
 //   done(n, acc)  consumes a finished tile (the wave's LDS area is free by then).
 // The (tile, chunk) pairs of the wave are one flat sequence, so the loads of the next tile are in flight under the last chunk of this one.
-template <bool F16, int NS, typename Done>
+template <bool F16, int NS, bool X3, typename Done>
 __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_stride, const __amdgpu_buffer_rsrc_t rs, int b_row_bytes, int b_rows, int ntiles,
-                                                 int nch, char* wbase, int w, int lane, Done done) {
-    constexpr int OOB = 0x7ffffff0;
+                                                 int nch, char* wbase, int w, int lane, Done done, const uint32_t* As2 = nullptr,
+                                                 const __amdgpu_buffer_rsrc_t rs2 = __amdgpu_buffer_rsrc_t()) {
+    // X3: a split-bf16 product -- the reduction runs three times into the same accumulator: (A, B), (A2 = the low plane of A, B), (A, B2 = the low
+    // plane of B behind rs2)
+    constexpr int OOB = 0x7ffffff0, NSEG = X3 ? 3 : 1;
     const int half = lane >> 5, l31 = lane & 31, lrow = lane >> 3, piece = lane & 7;
-    const int ntw = w < ntiles ? (ntiles - w + 7) >> 3 : 0, total = ntw * nch;
+    const int ntw = w < ntiles ? (ntiles - w + 7) >> 3 : 0, total = ntw * nch * NSEG;
     if (total == 0) return;
     int lds_w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) lds_w[i] = raw_slot(i * 8 + lrow, piece) * 16;
     u32x4 rg[NS][4];
-    int lt = w, lc = 0, li = 0;                                // the next chunk to request: tile, chunk, flat index
+    int lt = w, lc = 0, lseg = 0, li = 0;                      // the next chunk to request: tile, chunk, segment, flat index
 #define BMT_RA_LOAD(set_)                                                                              \
     do {                                                                                               \
         const bool in_ = li < total;                        /* wave-uniform */                         \
+        const __amdgpu_buffer_rsrc_t rs_ = (X3 && lseg == 2) ? rs2 : rs;                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
             const int r_ = lt * 32 + i * 8 + lrow;                                                     \
             const int vo_ = (in_ && r_ < b_rows) ? r_ * b_row_bytes + piece * 16 : OOB;                \
-            rg[set_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_, lc * 128, 0);                 \
+            rg[set_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, vo_, lc * 128, 0);                \
         }                                                                                              \
         ++li;                                                                                          \
-        if (++lc == nch) { lc = 0; lt += 8; }                                                          \
+        if (++lc == nch) {                                                                             \
+            lc = 0;                                                                                    \
+            if (++lseg == NSEG) { lseg = 0; lt += 8; }                                                 \
+        }                                                                                              \
     } while (0)
 #pragma unroll
     for (int j = 0; j < NS; ++j) BMT_RA_LOAD(j);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    int ct = w, cc = 0;
+    int ct = w, cc = 0, cseg = 0;
     const uint32_t* ar = As + l31 * a_stride + half * 4;
+    const uint32_t* ar2 = X3 ? As2 + l31 * a_stride + half * 4 : ar;
     for (int idx = 0; idx < total; idx += NS) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -237,24 +245,28 @@ __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_strid
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + lds_w[i]) = rg[j][i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bf16x8 fa[4], fb[4];
+            const uint32_t* ac = ((X3 && cseg == 1) ? ar2 : ar) + cc * 32;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 fb[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));
-                fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar + cc * 32 + u * 8));
+                fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ac + u * 8));
             }
             BMT_RA_LOAD(j);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa[u], fb[u], acc);
             if (++cc == nch) {
-                if (idx + j < total) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    done(ct, acc);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 cc = 0;
-                ct += 8;
+                if (++cseg == NSEG) {
+                    if (idx + j < total) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        done(ct, acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    cseg = 0;
+                    ct += 8;
+                }
             }
         }
     }
@@ -372,19 +384,21 @@ __device__ __forceinline__ void raw_row_op(uint32_t* Ss, int lds_s, int w, int l
 // LDS: A [32][dm + 8] 16-bit | S [32][Skp + 4] fp32 -- the 16-bit P / dS row overwrites the head of its own fp32 row (one wave owns a row) --
 // | 8 x 4 KB: the waves' staging areas for the memory's rows (raw_wave_product).
 // All LDS traffic goes through 32-bit unsigned types (the in-place conversion must not be reordered under type-based aliasing).
-// EDGES (backward): the block products either side of the three steps in the same launch --
-//   in front   dO'_h = do_h W_v,h  (bf16, reduction over d_k): the A operand of the first product, computed into LDS instead of fetched, and
-//              written to the memory gradient's B stack as the unfused product wrote it (32 rows per (sample, head); rows t >= Tq zeros);
-//   behind     dq_h = dQ'_h W_k,h^T (bf16, reduction over dm) + its column sums (db_q): dQ'_h stays in the A operand's LDS area (free after the
-//              first product) beside its copy in memory (the operand of dW_k).
-// Two launches fewer per attention backward on the decoder's chain, and no fetch of dO' / re-fetch of dQ'.
+// EDGES: the block products either side of the three steps in the same launch --
+//   backward, in front   dO'_h = do_h W_v,h  (bf16, reduction over d_k): the A operand of the first product, computed into LDS instead of fetched, and
+//                        written to the memory gradient's B stack as the unfused product wrote it (32 rows per (sample, head); rows t >= Tq zeros);
+//   backward, behind     dq_h = dQ'_h W_k,h^T (bf16, reduction over dm) + its column sums (db_q): dQ'_h stays in the A operand's LDS area (free after
+//                        the first product) beside its copy in memory (the operand of dW_k);
+//   forward, in front    Q'_h = q_h W_k,h (split-bf16: three passes over d_k into one accumulator) -> fp16 into the A area (its copy in memory is gone:
+//                        nobody else read it) and bf16 into the B stack.
+// Two launches fewer per attention backward and one per forward on the decoder's chain.
 struct RawEdges {
-    const uint16_t* dO; int64_t ld_do;             // do [M][ld_do] bf16: this head's columns at h * dk
-    const uint16_t* wvT; int64_t ld_wvT;           // row d of dm: W_v[h dk + k][d] at wvT + d * ld_wvT + h * dk + k  (the transposed weight group's plane)
-    uint16_t* bst; int64_t bst_sb, bst_sh;         // dO'_h -> bst + b * bst_sb + h * bst_sh + t * dm
-    const uint16_t* wk; int64_t ld_wk;             // row h dk + n of W_k's plane, dm contiguous
-    uint16_t* dq; int64_t ld_dq;                   // dq [M][ld_dq] bf16, column h dk + n
-    float* dbq;                                    // [H dk] += column sums of dq over the rows that exist (or null)
+    const uint16_t* in_hi; const uint16_t* in_lo; int64_t ld_in;      // [M][ld_in] bf16, this head's columns at h * dk: do (backward) / q hi, lo (forward)
+    const uint16_t* w_hi; const uint16_t* w_lo; int64_t ld_w;         // row d of dm: W[h dk + k][d] at d * ld_w + h * dk + k -- W_v^T (backward) / W_k^T hi, lo (forward)
+    uint16_t* bst; int64_t bst_sb, bst_sh;         // the in-front product (bf16) -> bst + b * bst_sb + h * bst_sh + t * dm
+    const uint16_t* wk; int64_t ld_wk;             // backward: row h dk + n of W_k's plane, dm contiguous
+    uint16_t* dq; int64_t ld_dq;                   // backward: dq [M][ld_dq] bf16, column h dk + n
+    float* dbq;                                    // backward: [H dk] += column sums of dq over the rows that exist (or null)
     int dk;
 };
 
@@ -415,7 +429,6 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
                                                         const uint16_t* __restrict__ XT, uint16_t* p_f16, uint16_t* __restrict__ stk, int64_t s_sb,
                                                         int64_t s_sh, uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo, int64_t ldo, int H, int Tq,
                                                         int dm, int Skp, float scale, const RawEdges eg) {
-    static_assert(BWD || !EDGES, "the edge products are the backward's");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 31, half = l >> 5;
     // (the H workgroups of a sample on ONE XCD, in consecutive dispatch slots: the sample's rows come over the fabric once, not once per head)
@@ -425,28 +438,43 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     const int lds_s = Skp + 4;                                 // 32-bit elements per S row (rows 4 banks apart: the second product's 16-byte fragment reads of 16 rows are conflict-free)
     uint32_t* As = reinterpret_cast<uint32_t*>(smem);
     uint32_t* Ss = reinterpret_cast<uint32_t*>(smem + (size_t)32 * lda_s * 2);
-    char* const wbase = smem + (size_t)32 * lda_s * 2 + (size_t)32 * lds_s * 4 + w * 4096;
+    // (the forward's edge product parks TWO planes of q_h in the score tile's area: hi | lo)
+    const size_t ss_bytes = (EDGES && !BWD) ? max((size_t)32 * lds_s * 4, (size_t)2 * 32 * (eg.dk + 8) * 2) : (size_t)32 * lds_s * 4;
+    char* const wbase = smem + (size_t)32 * lda_s * 2 + ss_bytes + w * 4096;
     if constexpr (EDGES) {
-        // ---- do_h (32 x d_k, rows t >= Tq zeros) -> LDS (the score tile's area, free until the first product), then dO'_h = do_h W_v,h -> the A area + the B stack
+        // ---- do_h / q_h hi, lo (32 x d_k, rows t >= Tq zeros) -> LDS (the score tile's area, free until the first product), then the in-front
+        // product dO'_h = do_h W_v,h / Q'_h = q_h W_k,h -> the A area + the B stack
         const int dk = eg.dk, ldd_s = dk + 8, pc = dk >> 3;
-        const uint16_t* d1 = eg.dO + (int64_t)b * Tq * eg.ld_do + (int64_t)h * dk;
+        uint32_t* const D2 = Ss + 16 * ldd_s;                  // (the low plane: 32 rows of ldd_s 16-bit elements further)
+        const int64_t ro = (int64_t)b * Tq * eg.ld_in + (int64_t)h * dk;
         for (int i = tid; i < 32 * pc; i += 512) {
             const int t = i / pc, c = (i - t * pc) * 8;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (t < Tq) v = *reinterpret_cast<const u32x4*>(d1 + (int64_t)t * eg.ld_do + c);
+            u32x4 v = {0u, 0u, 0u, 0u}, v2 = v;
+            if (t < Tq) {
+                v = *reinterpret_cast<const u32x4*>(eg.in_hi + ro + (int64_t)t * eg.ld_in + c);
+                if constexpr (!BWD) v2 = *reinterpret_cast<const u32x4*>(eg.in_lo + ro + (int64_t)t * eg.ld_in + c);
+            }
             *reinterpret_cast<u32x4*>(Ss + ((t * ldd_s + c) >> 1)) = v;
+            if constexpr (!BWD) *reinterpret_cast<u32x4*>(D2 + ((t * ldd_s + c) >> 1)) = v2;
         }
         __syncthreads();
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wvT + (int64_t)h * dk), 0, (int)((((int64_t)dm - 1) * eg.ld_wvT + dk) * 2), 0x00020000);
+        const int wbytes = (int)((((int64_t)dm - 1) * eg.ld_w + dk) * 2);
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.w_hi + (int64_t)h * dk), 0, wbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)((BWD ? eg.w_hi : eg.w_lo) + (int64_t)h * dk), 0, wbytes, 0x00020000);
         uint16_t* bs = eg.bst + b * eg.bst_sb + h * eg.bst_sh;
-        raw_wave_product<false, 4>(Ss, ldd_s >> 1, rsW, (int)(eg.ld_wvT * 2), dm, dm >> 5, dk >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<false, 4, !BWD>(Ss, ldd_s >> 1, rsW, (int)(eg.ld_w * 2), dm, dm >> 5, dk >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
             raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
-                const u32x4 hv = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+                const u32x4 bv = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
                 const int c = n * 32 + (l & 3) * 8;
-                *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = hv;
-                *reinterpret_cast<u32x4*>(bs + (int64_t)t * dm + c) = hv;
+                if constexpr (BWD) {
+                    *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = bv;
+                } else {
+                    const u32x4 hv = {pack_h2(v0[0], v0[1]), pack_h2(v0[2], v0[3]), pack_h2(v1[0], v1[1]), pack_h2(v1[2], v1[3])};
+                    *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = hv;
+                }
+                *reinterpret_cast<u32x4*>(bs + (int64_t)t * dm + c) = bv;
             });
-        });
+        }, D2, rsW2);
     } else {
     // ---- A (the 32 query rows of this head; rows t >= Tq are zeros) -> LDS
         const uint16_t* a1 = A1 + b * a_sb + h * a_sh;
@@ -462,7 +490,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     // ---- first product: a wave per 32 keys (keys past the sample's length read as zeros: the row operation masks them)
     {
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (int64_t)r0 * ldx), 0, (int)((int64_t)len * ldx * 2), 0x00020000);
-        raw_wave_product<!BWD, 4>(As, lda_s >> 1, rsX, (int)(ldx * 2), len, (len + 31) >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<!BWD, 4, false>(As, lda_s >> 1, rsX, (int)(ldx * 2), len, (len + 31) >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Ss[acc_row(r, half) * lds_s + n * 32 + lr] = __float_as_uint(acc[r]);
         });
@@ -478,7 +506,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     // transposed memory are zero from the length to Skp, a multiple of 64)
     {
         const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(XT + (int64_t)b * dm * Skp), 0, (int)((int64_t)dm * Skp * 2), 0x00020000);
-        raw_wave_product<!BWD, 4>(Ss, lds_s, rsT, Skp * 2, dm, dm >> 5, max(1, (len + 63) >> 6), wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<!BWD, 4, false>(Ss, lds_s, rsT, Skp * 2, dm, dm >> 5, max(1, (len + 63) >> 6), wbase, w, l, [&](int n, const f32x16& acc) {
             raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
                 uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
                 split_bf2(v0[0], v0[1], h0, l0);
@@ -487,7 +515,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
                 split_bf2(v1[2], v1[3], h3, l3);
                 const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 const int c = n * 32 + (l & 3) * 8;
-                if constexpr (EDGES) *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = hi;      // (rows t >= Tq: zeros, dS's are)
+                if constexpr (EDGES && BWD) *reinterpret_cast<u32x4*>(As + ((t * lda_s + c) >> 1)) = hi;      // (rows t >= Tq: zeros, dS's are)
                 if (t >= Tq) return;
                 const int64_t o = (int64_t)(b * Tq + t) * ldo + (int64_t)h * dm + c;
                 *reinterpret_cast<u32x4*>(o_hi + o) = hi;
@@ -495,12 +523,12 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
             });
         });
     }
-    if constexpr (EDGES) {
+    if constexpr (EDGES && BWD) {
         // ---- dq_h = dQ'_h W_k,h^T: a wave per 32 columns of the head, the reduction over dm; column sums over the rows that exist -> db_q
         __syncthreads();
         const int dk = eg.dk;
         const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wk + (int64_t)h * dk * eg.ld_wk), 0, (int)((((int64_t)dk - 1) * eg.ld_wk + dm) * 2), 0x00020000);
-        raw_wave_product<false, 4>(As, lda_s >> 1, rsK, (int)(eg.ld_wk * 2), dk, dk >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<false, 4, false>(As, lda_s >> 1, rsK, (int)(eg.ld_wk * 2), dk, dk >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
             float cs[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs[q] = 0.f;
@@ -528,6 +556,10 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
 }
 
 inline size_t raw_attn_lds(int dm, int Skp) { return (size_t)32 * (dm + 8) * 2 + (size_t)32 * (Skp + 4) * 4 + 8 * 4096; }
+inline size_t raw_attn_lds_fwd_edges(int dm, int Skp, int dk) {
+    const size_t ss = (size_t)32 * (Skp + 4) * 4, d2 = (size_t)2 * 32 * (dk + 8) * 2;
+    return (size_t)32 * (dm + 8) * 2 + (ss > d2 ? ss : d2) + 8 * 4096;
+}
 }  // namespace
 
 extern "C" int bmt_memory_transposed(const uint16_t* x_f16, int64_t ld, const int* off, int B, int D, int Skp, uint16_t* xt_f16, uint16_t* xtc_bf,
@@ -634,9 +666,39 @@ extern "C" int bmt_raw_attn_bwd_edges(const uint16_t* do_bf, int64_t ld_do, cons
         (void)hipFuncSetAttribute((const void*)raw_attn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    const RawEdges eg{do_bf, ld_do, wvT_bf, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk};
+    const RawEdges eg{do_bf, nullptr, ld_do, wvT_bf, nullptr, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk};
     hipLaunchKernelGGL((raw_attn_kernel<true, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_bf,
                        ldx, off, xtc_bf, const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dqp_bf, (uint16_t*)nullptr, lddqp, H, Tq, dm, Skp, scale, eg);
     BMT_CHECK_LAUNCH("bmt_raw_attn_bwd_edges");
+    return BMT_OK;
+}
+
+extern "C" int bmt_raw_attn_fwd_edges_ok(int dm, int Skp, int dk) {
+    return bmt_raw_attn_ok(dm, Skp) && dk > 0 && dk % 64 == 0 && raw_attn_lds_fwd_edges(dm, Skp, dk) <= (size_t)160 * 1024;
+}
+
+extern "C" int bmt_raw_attn_fwd_edges(const uint16_t* q_hi, const uint16_t* q_lo, int64_t ld_q, const uint16_t* wkT_hi, const uint16_t* wkT_lo, int64_t ld_wkT,
+                                      uint16_t* bstack, int64_t b_sb, int64_t b_sh, const uint16_t* x_f16, int64_t ldx, const int* off, const uint16_t* xt_f16,
+                                      int B, int H, int Tq, int dm, int Skp, int dk, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb,
+                                      int64_t p_bf_sh, uint16_t* o_hi, uint16_t* o_lo, int64_t ldo, void* stream) {
+    BMT_CHECK_ARG(q_hi && q_lo && wkT_hi && wkT_lo && bstack && x_f16 && off && xt_f16 && p_f16 && o_hi && B > 0 && H > 0 && Tq > 0 && Tq <= 32,
+                  "bmt_raw_attn_fwd_edges: null pointer or bad extents (at most 32 queries per sample and head)");
+    BMT_CHECK_ARG(bmt_raw_attn_fwd_edges_ok(dm, Skp, dk), "bmt_raw_attn_fwd_edges: bmt_raw_attn_ok(dm, Skp), d_k a multiple of 64, LDS with two planes of q_h <= 160 KB");
+    BMT_CHECK_ARG(!((reinterpret_cast<uintptr_t>(q_hi) | reinterpret_cast<uintptr_t>(q_lo) | reinterpret_cast<uintptr_t>(wkT_hi) | reinterpret_cast<uintptr_t>(wkT_lo) |
+                     reinterpret_cast<uintptr_t>(bstack) | reinterpret_cast<uintptr_t>(x_f16) | reinterpret_cast<uintptr_t>(xt_f16) | reinterpret_cast<uintptr_t>(p_f16) |
+                     reinterpret_cast<uintptr_t>(p_bf) | reinterpret_cast<uintptr_t>(o_hi) | reinterpret_cast<uintptr_t>(o_lo)) & 15) &&
+                      !((ld_q | ld_wkT | b_sb | b_sh | ldx | p_bf_sb | p_bf_sh | ldo) & 7) && ldx >= dm && ldo >= (int64_t)H * dm && ld_q >= (int64_t)H * dk &&
+                      ld_wkT >= (int64_t)H * dk,
+                  "bmt_raw_attn_fwd_edges: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
+    const size_t lds = raw_attn_lds_fwd_edges(dm, Skp, dk);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    const RawEdges eg{q_hi, q_lo, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk};
+    hipLaunchKernelGGL((raw_attn_kernel<false, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_f16,
+                       ldx, off, xt_f16, p_f16, p_bf, p_bf_sb, p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, eg);
+    BMT_CHECK_LAUNCH("bmt_raw_attn_fwd_edges");
     return BMT_OK;
 }

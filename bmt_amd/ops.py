@@ -2927,18 +2927,26 @@ class RawCrossAttnFn(torch.autograd.Function):
         gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))                                 # [dm][2 D] hi + lo: columns [0, D) = W_k^T
         train = any(ctx.needs_input_grad)      # (the queries, the memory or ANY of the module's parameters: a partly frozen module saves what its backward reads)
         # Q'[(b, t)][h dm + d] = q_h W_k,h: fp16 (the A operand of S) in the natural layout, bf16 into the B stack (b, l, 0, h)
-        qf = torch.empty(M, H * dm, device=dev, dtype=torch.float16)
         bo_, bsb, bsh = st.b_block(l, 0)
-        # (one product per head over all the samples' rows: a weight tile is fetched once, not once per sample; row (b, t) -> block b of the stack)
-        gemm_batched(X3, M, dm, D // H, 1, H, _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
-                     a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb), p2=_addr(qf), p2_f16=True,
-                     ldp2=H * dm, p2_off=(0, dm), p2_div=(0, 0))
+        f_edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_fwd_edges_ok(dm, Skp, dk))     # ... inside the fused launch below (no fp16 copy in memory)
+        if not f_edges:
+            qf = torch.empty(M, H * dm, device=dev, dtype=torch.float16)
+            # (one product per head over all the samples' rows: a weight tile is fetched once, not once per sample; row (b, t) -> block b of the stack)
+            gemm_batched(X3, M, dm, D // H, 1, H, _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
+                         a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb), p2=_addr(qf), p2_f16=True,
+                         ldp2=H * dm, p2_off=(0, dm), p2_div=(0, 0))
         Pf = torch.empty(B, H, 32, Skp, device=dev, dtype=torch.float16)
         ao, asb, ash = st.a_block(l, 1) if st.astack is not None else (0, 0, 0)
         p_bf = C.c_void_p(_addr(st.astack, ao)) if st.astack is not None else None
         # O' = P X (natural layout, split-bf16 planes: the A operand of the value block product)
         Op = _alloc_planes(M, H * dm, "x3", dev, ld=H * dm)
-        if RAW_FUSED and lib.bmt_raw_attn_ok(dm, Skp):
+        if f_edges:
+            # Q'_h = q_h W_k,h -> S = Q' X^T -> P = softmax -> O' = P X: one launch per attention, workgroup = (sample, head)
+            raw_attn_launch(False, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_fwd_edges(
+                _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0), _addr(st.bstack, bo_), bsb, bsh, _addr(st.x.fh), st.x.fh.stride(0),
+                st.pack.off_ptr, _addr(st.xt_f16), B, H, Tq, dm, Skp, dk, 1.0 / math.sqrt(dk), _p(Pf), p_bf, asb, ash, _addr(Op.hi), _addr(Op.lo), H * dm, _st()),
+                "bmt_raw_attn_fwd_edges"), edges_dk=dk)
+        elif RAW_FUSED and lib.bmt_raw_attn_ok(dm, Skp):
             # S = Q' X^T -> P = softmax -> O' = P X as one launch per attention, workgroup = (sample, head): the score tile stays in LDS
             raw_attn_launch(False, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_fwd(
                 _addr(qf), Tq * H * dm, dm, H * dm, _addr(st.x.fh), st.x.fh.stride(0), st.pack.off_ptr, _addr(st.xt_f16), B, H, Tq, dm, Skp,

@@ -229,6 +229,15 @@ int bmt_raw_attn_ok(int dm, int Skp);
  *                     column sums ADDED to dbq [H dk] (optional).  dqp_bf = dQ' as bmt_raw_attn_bwd writes it.  bmt_raw_attn_edges_ok: the form
  *                     applies (bmt_raw_attn_ok, dk a multiple of 64, 64 (dk + 8) <= 128 (Skp + 4)). */
 int bmt_raw_attn_edges_ok(int dm, int Skp, int dk);
+/*   bmt_raw_attn_fwd_edges  bmt_raw_attn_fwd with the block product in front of it in the same launch: Q'_h = q_h W_k,h (split-bf16: q_hi / q_lo [B Tq][ld_q],
+ *                     this head's columns at h dk; wkT_hi / wkT_lo: row d of dm holds W_k[h dk + k][d] at d * ld_wkT + h dk + k) -> fp16 into the A operand
+ *                     (no copy in memory) and bf16 to bstack + b * b_sb + h * b_sh + t * dm (32 rows, rows t >= Tq zeros).  bmt_raw_attn_fwd_edges_ok:
+ *                     bmt_raw_attn_ok, dk a multiple of 64, and the LDS with two planes of q_h parked in the score tile's area <= 160 KB. */
+int bmt_raw_attn_fwd_edges_ok(int dm, int Skp, int dk);
+int bmt_raw_attn_fwd_edges(const uint16_t* q_hi, const uint16_t* q_lo, int64_t ld_q, const uint16_t* wkT_hi, const uint16_t* wkT_lo, int64_t ld_wkT,
+                           uint16_t* bstack, int64_t b_sb, int64_t b_sh, const uint16_t* x_f16, int64_t ldx, const int* off, const uint16_t* xt_f16, int B, int H,
+                           int Tq, int dm, int Skp, int dk, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb, int64_t p_bf_sh, uint16_t* o_hi,
+                           uint16_t* o_lo, int64_t ldo, void* stream);
 int bmt_raw_attn_bwd_edges(const uint16_t* do_bf, int64_t ld_do, const uint16_t* wvT_bf, int64_t ld_wvT, uint16_t* bstack, int64_t b_sb, int64_t b_sh,
                            const uint16_t* x_bf, int64_t ldx, const int* off, const uint16_t* xtc_bf, const uint16_t* p_f16, int B, int H, int Tq, int dm,
                            int Skp, int dk, float scale, uint16_t* ds_bf, int64_t ds_sb, int64_t ds_sh, uint16_t* dqp_bf, int64_t lddqp,

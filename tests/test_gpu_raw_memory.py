@@ -267,6 +267,40 @@ def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
 
     a, b_ = chain(True), chain(False)
     assert amax(a[0][:, :, Tq:]) == 0.0 and amax(a[0]) > 0.0
+    # the forward with ITS in-front block product in the launch (bmt_raw_attn_fwd_edges): Q'_h = q_h W_k,h (split-bf16, three passes) -> the A operand
+    # (fp16, no copy in memory) + the B stack (bf16), against bmt_gemm_small_batched (x3) + bmt_raw_attn_fwd
+    if lib.bmt_raw_attn_fwd_edges_ok(dm, Skp, dk):
+        qv = rnd(M, D, seed=7) * 0.5
+        q_pl = ops.make_planes(qv.to(DEV), "x3")
+        wkT = ops.make_planes((rnd(dm, D, seed=8) * 0.1).to(DEV), "x3")
+
+        def fchain(fused):
+            Pf2 = torch.full((B, H, 32, Skp), 3.0, device=DEV, dtype=torch.float16)
+            stack = torch.full((B, 2, H, 32, Skp), 5.0, device=DEV, dtype=torch.bfloat16)
+            bst = torch.zeros(B, H, 32, dm, device=DEV, dtype=torch.bfloat16)
+            hi = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+            lo = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+            pb = C.c_void_p(ops._addr(stack, H * 32 * Skp))
+            if fused:
+                ops._lib.check(lib.bmt_raw_attn_fwd_edges(ops._addr(q_pl.hi), ops._addr(q_pl.lo), q_pl.hi.stride(0), ops._addr(wkT.hi), ops._addr(wkT.lo), wkT.hi.stride(0),
+                                                          ops._addr(bst), bsb, bsh, ops._addr(xpl.fh), xpl.fh.stride(0), pk.off_ptr, ops._addr(xt), B, H, Tq, dm, Skp, dk, scale,
+                                                          ops._p(Pf2), pb, sb, sh, ops._addr(hi), ops._addr(lo), H * dm, None), "fe")
+            else:
+                qf2 = torch.empty(M, H * dm, device=DEV, dtype=torch.float16)
+                ops.gemm_batched(ops.PREC_BF16X3, M, dm, dk, 1, H, ops._addr(q_pl.hi), ops._addr(q_pl.lo), q_pl.hi.stride(0), ops._addr(wkT.hi), ops._addr(wkT.lo),
+                                 wkT.hi.stride(0), a_off=(0, dk), b_off=(0, dk), p1=ops._addr(bst), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb), p2=ops._addr(qf2), p2_f16=True,
+                                 ldp2=H * dm, p2_off=(0, dm), p2_div=(0, 0))
+                ops._lib.check(lib.bmt_raw_attn_fwd(ops._addr(qf2), Tq * H * dm, dm, H * dm, ops._addr(xpl.fh), xpl.fh.stride(0), pk.off_ptr, ops._addr(xt), B, H, Tq,
+                                                    dm, Skp, scale, ops._p(Pf2), pb, sb, sh, ops._addr(hi), ops._addr(lo), H * dm, None), "f")
+            torch.cuda.synchronize()
+            return bst, Pf2, stack, hi.float() + lo.float()
+
+        fa, fb = fchain(True), fchain(False)
+        assert amax(fa[0][:, :, Tq:]) == 0.0 and amax(fa[0]) > 0.0
+        for x_, y_, n, bar in zip(fa, fb, ("Q' (B stack)", "P fp16", "P bf16 (stack)", "O'"), (4e-3, 3e-3, 6e-3, 3e-3)):
+            e = rel_err(x_.float(), y_.float())
+            assert e < bar, f"forward edges: {n}: {e:.3e}"
+        assert bool((fa[2][:, 0] == 5.0).all())
     for x_, y_, n, bar in zip(a, b_, ("dO' (B stack)", "dS (stack)", "dQ'", "dq", "db_q (accumulated onto ones)"), (4e-3, 1e-2, 1e-2, 1e-2, 1e-3)):
         e = rel_err(x_.float(), y_.float())
         assert e < bar, f"{n}: {e:.3e}"
