@@ -2727,9 +2727,12 @@ def cat2(a, b):
 # products against the memory one fp16 pass, backward one bf16 pass.  RAW_MEMORY switch: "0" = keys and values are projected, as before.
 RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
 # RAW_FUSED: the two products against the memory and the row operation between them as ONE launch per attention (bmt_raw_attn_fwd / _bwd,
-# ABI 12); "0" = the three launches of round 5 (the same arithmetic: tests/test_gpu_raw_memory.py compares the two)
-RAW_FUSED = _os.environ.get("BMT_RAW_FUSED", "1") != "0"
-RAW_FUSED_EDGES = _os.environ.get("BMT_RAW_FUSED_EDGES", "1") != "0"      # ... and the backward's block products either side of it (bmt_raw_attn_bwd_edges)
+# ABI 12); False = the three launches of round 5 (the same arithmetic: tests/test_gpu_raw_memory.py compares the two).  RAW_FUSED_EDGES: ... and
+# the block products either side of it (Q'_h = q_h W_k,h in front of the forward; dO'_h = do_h W_v,h in front of, dq_h = dQ'_h W_k,h^T behind the
+# backward: bmt_raw_attn_fwd_edges / _bwd_edges).  Module attributes, not environment switches (tools/gpu_ab_attr.sh sets them for a same-box A/B:
+# profiles/r06_z6_raw_fused_ab.txt).
+RAW_FUSED = True
+RAW_FUSED_EDGES = True
 
 
 class RawMemoryState:
