@@ -149,7 +149,7 @@ def test_batched_small_products(ops):
     assert_close(cs, want.sum(0), atol=2e-2, rtol=1e-4, name="column sums")
 
 
-@pytest.mark.parametrize("dm,S,Tq,H", [(128, 800, 29, 4), (1024, 256, 29, 4), (128, 128, 7, 2), (256, 768, 32, 8), (64, 64, 1, 1)])
+@pytest.mark.parametrize("dm,S,Tq,H", [(128, 800, 29, 4), (1024, 256, 29, 4), (128, 128, 7, 2), (256, 768, 32, 8), (64, 64, 1, 1), (128, 300, 30, 4)])
 def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
     """bmt_raw_attn_fwd / _bwd (ABI 12: both products against the memory and the row operation between them in one launch, the score tile in
     LDS) against the three launches they replace, on the same operands (P fp16 and bf16, O' hi + lo, dS, dQ'): the same arithmetic up to the
