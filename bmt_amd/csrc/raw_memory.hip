@@ -204,9 +204,9 @@ template <bool F16, int NS, bool X3, typename Done>
 __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_stride, const __amdgpu_buffer_rsrc_t rs, int b_row_bytes, int b_rows, int ntiles,
                                                  int nch, char* wbase, int w, int lane, Done done, const uint32_t* As2 = nullptr,
                                                  const __amdgpu_buffer_rsrc_t rs2 = __amdgpu_buffer_rsrc_t()) {
-    // X3: a split-bf16 product -- the reduction runs three times into the same accumulator: (A, B), (A2 = the low plane of A, B), (A, B2 = the low
-    // plane of B behind rs2)
-    constexpr int OOB = 0x7ffffff0, NSEG = X3 ? 3 : 1;
+    // X3: a split-bf16 product -- the reduction runs twice into the same accumulator: over B with BOTH planes of A (A, and A2 = its low plane: one
+    // staged chunk of B feeds two MFMA chains), then over B2 (the low plane of B, behind rs2) with A
+    constexpr int OOB = 0x7ffffff0, NSEG = X3 ? 2 : 1;
     const int half = lane >> 5, l31 = lane & 31, lrow = lane >> 3, piece = lane & 7;
     const int ntw = w < ntiles ? (ntiles - w + 7) >> 3 : 0, total = ntw * nch * NSEG;
     if (total == 0) return;
@@ -218,7 +218,7 @@ __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_strid
 #define BMT_RA_LOAD(set_)                                                                              \
     do {                                                                                               \
         const bool in_ = li < total;                        /* wave-uniform */                         \
-        const __amdgpu_buffer_rsrc_t rs_ = (X3 && lseg == 2) ? rs2 : rs;                               \
+        const __amdgpu_buffer_rsrc_t rs_ = (X3 && lseg == 1) ? rs2 : rs;                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
             const int r_ = lt * 32 + i * 8 + lrow;                                                     \
             const int vo_ = (in_ && r_ < b_rows) ? r_ * b_row_bytes + piece * 16 : OOB;                \
@@ -244,15 +244,23 @@ __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_strid
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + lds_w[i]) = rg[j][i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bf16x8 fa[4], fb[4];
-            const uint32_t* ac = ((X3 && cseg == 1) ? ar2 : ar) + cc * 32;
+            bf16x8 fa[4], fb[4], fa2[4];
+            const bool both = X3 && cseg == 0;                /* wave-uniform */
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 fb[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));
-                fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ac + u * 8));
+                fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar + cc * 32 + u * 8));
+            }
+            if (both) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fa2[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar2 + cc * 32 + u * 8));
             }
             BMT_RA_LOAD(j);
             __builtin_amdgcn_sched_barrier(0);
+            if (both) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa2[u], fb[u], acc);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa[u], fb[u], acc);
             if (++cc == nch) {

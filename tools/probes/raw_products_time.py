@@ -68,6 +68,9 @@ def main():
             "fused dO' -> ... -> dq (bf16)": lambda: ck(lib.bmt_raw_attn_bwd_edges(A(o_hi), D, A(wT_hi, D), 2 * D, A(stackB), bsb, bsh, A(x_hi), dm, pk.off_ptr, A(xtc), A(Pf), B, H, Tq,
                                                                                      dm, Skp, dk, 0.0625, A(stackA), asb, ash, A(nat_hi), H * dm, A(w_hi), dm, A(q_hi), D, A(dbq),
                                                                                      ops._st()), "e"),
+            "fused Q' -> ... -> O' (x3 + f16)": lambda: ck(lib.bmt_raw_attn_fwd_edges(A(q_hi), A(q_lo), D, A(wT_hi), A(wT_lo), 2 * D, A(stackB), bsb, bsh, A(x_fh), dm, pk.off_ptr, A(xt),
+                                                                                       B, H, Tq, dm, Skp, dk, 0.0625, A(Pf), A(stackA), asb, ash, A(nat_hi), A(nat_lo), H * dm,
+                                                                                       ops._st()), "fe"),
             "softmax forward alone": lambda: ck(lib.bmt_raw_softmax_fwd(A(S_), pk.off_ptr, B, H, Tq, Skp, 0.0625, A(Pf), A(stackA), asb, ash, ops._st()), "s"),
         }
         print(f"--- {name} memory: d = {dm}, {S} keys (capacity), {B} samples x {H} heads x {Tq} queries")
