@@ -185,9 +185,9 @@ class KernelTimer:
 
         raw_ral = ops.raw_attn_launch
 
-        def raw_attn_launch(bwd, B_, H, Tq, S, dm, fn, edges_dk=0):
+        def raw_attn_launch(bwd, B_, H, Tq, S, dm, fn, edges_dk=0, proj_k=0):
             if not timer.enabled:
-                return raw_ral(bwd, B_, H, Tq, S, dm, fn, edges_dk=edges_dk)
+                return raw_ral(bwd, B_, H, Tq, S, dm, fn, edges_dk=edges_dk, proj_k=proj_k)
             # two products of (H Tq) x S x dm per sample; bytes: the A rows and the result rows (16-bit), the memory both ways, P / dS (16-bit, twice)
             fl = 2 * 2.0 * B_ * H * Tq * S * dm
             by = B_ * (2.0 * 2 * H * Tq * dm + 2.0 * 2 * S * dm + 2.0 * 2 * H * Tq * S)
@@ -195,7 +195,10 @@ class KernelTimer:
                 n_e = 2 if bwd else 1      # of the forward), their d_k-wide rows and the weight blocks
                 fl += n_e * 2.0 * B_ * H * Tq * dm * edges_dk
                 by += B_ * 2.0 * n_e * (1 if bwd else 2) * H * Tq * edges_dk + 2.0 * n_e * (1 if bwd else 2) * H * edges_dk * dm
-            return timer._timed("raw_attn_fused_" + ("bf16" if bwd else "f16") + ("_edges" if edges_dk else ""), 1, fl, by, fn)
+            if proj_k:        # + the query projection (H Tq x d_k x proj_k, split-bf16): y's two planes, W_q's two planes, q's high plane
+                fl += 2.0 * B_ * H * Tq * edges_dk * proj_k
+                by += B_ * 2.0 * 2 * Tq * proj_k + 2.0 * 2 * H * edges_dk * proj_k + B_ * 2.0 * H * Tq * edges_dk
+            return timer._timed("raw_attn_fused_" + ("bf16" if bwd else "f16") + ("_proj" if proj_k else "_edges" if edges_dk else ""), 1, fl, by, fn)
 
         ops.raw_attn_launch = raw_attn_launch
         ops.gemm_batched = gemm_batched

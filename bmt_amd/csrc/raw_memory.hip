@@ -408,6 +408,11 @@ struct RawEdges {
     uint16_t* dq; int64_t ld_dq;                   // backward: dq [M][ld_dq] bf16, column h dk + n
     float* dbq;                                    // backward: [H dk] += column sums of dq over the rows that exist (or null)
     int dk;
+    // forward, optional (y_hi != null): the query projection in front of the in-front product, q_h = y W_q,h^T + b_q,h (split-bf16) -- then in_hi is
+    // an OUTPUT (q's high plane, what the backward reads), in_lo is unused
+    const uint16_t* y_hi; const uint16_t* y_lo; int64_t ld_y; int Kq;      // y [M][ld_y], Kq = its padded width (a multiple of 64, zeros past the true width)
+    const uint16_t* wq_hi; const uint16_t* wq_lo; int64_t ld_wq;           // W_q's planes: row h dk + n, Kq contiguous
+    const float* bq;                                                        // [H dk] or null
 };
 
 // a finished 32 x 32 fp32 tile through the wave's 4-KB area ([32][32] fp32, 16-byte granules XOR-swizzled by the row): lane -> rows
@@ -447,7 +452,10 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     uint32_t* As = reinterpret_cast<uint32_t*>(smem);
     uint32_t* Ss = reinterpret_cast<uint32_t*>(smem + (size_t)32 * lda_s * 2);
     // (the forward's edge product parks TWO planes of q_h in the score tile's area: hi | lo)
-    const size_t ss_bytes = (EDGES && !BWD) ? max((size_t)32 * lds_s * 4, (size_t)2 * 32 * (eg.dk + 8) * 2) : (size_t)32 * lds_s * 4;
+    // (... and the query projection in front of it two planes of y: in the A area where they fit, else behind q_h's)
+    const size_t d2_bytes = (EDGES && !BWD) ? (size_t)2 * 32 * (eg.dk + 8) * 2 : 0, y_bytes = (EDGES && !BWD && eg.y_hi) ? (size_t)2 * 32 * (eg.Kq + 8) * 2 : 0;
+    const bool y_in_a = y_bytes <= (size_t)32 * lda_s * 2;
+    const size_t ss_bytes = max((size_t)32 * lds_s * 4, d2_bytes + (y_in_a ? 0 : y_bytes));
     char* const wbase = smem + (size_t)32 * lda_s * 2 + ss_bytes + w * 4096;
     if constexpr (EDGES) {
         // ---- do_h / q_h hi, lo (32 x d_k, rows t >= Tq zeros) -> LDS (the score tile's area, free until the first product), then the in-front
@@ -455,15 +463,61 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
         const int dk = eg.dk, ldd_s = dk + 8, pc = dk >> 3;
         uint32_t* const D2 = Ss + 16 * ldd_s;                  // (the low plane: 32 rows of ldd_s 16-bit elements further)
         const int64_t ro = (int64_t)b * Tq * eg.ld_in + (int64_t)h * dk;
-        for (int i = tid; i < 32 * pc; i += 512) {
-            const int t = i / pc, c = (i - t * pc) * 8;
-            u32x4 v = {0u, 0u, 0u, 0u}, v2 = v;
-            if (t < Tq) {
-                v = *reinterpret_cast<const u32x4*>(eg.in_hi + ro + (int64_t)t * eg.ld_in + c);
-                if constexpr (!BWD) v2 = *reinterpret_cast<const u32x4*>(eg.in_lo + ro + (int64_t)t * eg.ld_in + c);
+        bool projected = false;
+        if constexpr (!BWD) projected = eg.y_hi != nullptr;
+        if (projected) {
+            if constexpr (!BWD) {
+                // ---- q_h = y W_q,h^T + b_q,h (split-bf16) from the sample's 32 rows of y: its two planes into LDS, the product's hi / lo planes where
+                // the loaded q_h would have gone, the high plane to memory too (the backward's operand of dW_k)
+                const int Kq = eg.Kq, ldy_s = Kq + 8, pcq = Kq >> 3;
+                uint32_t* const Y1 = y_in_a ? As : Ss + (d2_bytes >> 2);
+                uint32_t* const Y2 = Y1 + 16 * ldy_s;
+                const int64_t yo = (int64_t)b * Tq * eg.ld_y;
+                for (int i = tid; i < 32 * pcq; i += 512) {
+                    const int t = i / pcq, c = (i - t * pcq) * 8;
+                    u32x4 v = {0u, 0u, 0u, 0u}, v2 = v;
+                    if (t < Tq) {
+                        v = *reinterpret_cast<const u32x4*>(eg.y_hi + yo + (int64_t)t * eg.ld_y + c);
+                        v2 = *reinterpret_cast<const u32x4*>(eg.y_lo + yo + (int64_t)t * eg.ld_y + c);
+                    }
+                    *reinterpret_cast<u32x4*>(Y1 + ((t * ldy_s + c) >> 1)) = v;
+                    *reinterpret_cast<u32x4*>(Y2 + ((t * ldy_s + c) >> 1)) = v2;
+                }
+                __syncthreads();
+                const int qbytes = (int)((((int64_t)dk - 1) * eg.ld_wq + Kq) * 2);
+                const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wq_hi + (int64_t)h * dk * eg.ld_wq), 0, qbytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsQ2 = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wq_lo + (int64_t)h * dk * eg.ld_wq), 0, qbytes, 0x00020000);
+                uint16_t* const qout = const_cast<uint16_t*>(eg.in_hi);
+                raw_wave_product<false, 4, true>(Y1, ldy_s >> 1, rsQ, (int)(eg.ld_wq * 2), dk, dk >> 5, Kq >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+                    const int c = n * 32 + (l & 3) * 8;
+                    float bb[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bb[q] = eg.bq ? eg.bq[h * dk + c + q] : 0.f;
+                    raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
+                        const bool on = t < Tq;                 // (rows t >= Tq stay zeros: the bias must not reach them)
+                        uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+                        split_bf2(on ? v0[0] + bb[0] : 0.f, on ? v0[1] + bb[1] : 0.f, h0, l0);
+                        split_bf2(on ? v0[2] + bb[2] : 0.f, on ? v0[3] + bb[3] : 0.f, h1, l1);
+                        split_bf2(on ? v1[0] + bb[4] : 0.f, on ? v1[1] + bb[5] : 0.f, h2, l2);
+                        split_bf2(on ? v1[2] + bb[6] : 0.f, on ? v1[3] + bb[7] : 0.f, h3, l3);
+                        const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                        *reinterpret_cast<u32x4*>(Ss + ((t * ldd_s + c) >> 1)) = hi;
+                        *reinterpret_cast<u32x4*>(D2 + ((t * ldd_s + c) >> 1)) = lo;
+                        if (on) *reinterpret_cast<u32x4*>(qout + ro + (int64_t)t * eg.ld_in + c) = hi;
+                    });
+                }, Y2, rsQ2);
             }
-            *reinterpret_cast<u32x4*>(Ss + ((t * ldd_s + c) >> 1)) = v;
-            if constexpr (!BWD) *reinterpret_cast<u32x4*>(D2 + ((t * ldd_s + c) >> 1)) = v2;
+        } else {
+            for (int i = tid; i < 32 * pc; i += 512) {
+                const int t = i / pc, c = (i - t * pc) * 8;
+                u32x4 v = {0u, 0u, 0u, 0u}, v2 = v;
+                if (t < Tq) {
+                    v = *reinterpret_cast<const u32x4*>(eg.in_hi + ro + (int64_t)t * eg.ld_in + c);
+                    if constexpr (!BWD) v2 = *reinterpret_cast<const u32x4*>(eg.in_lo + ro + (int64_t)t * eg.ld_in + c);
+                }
+                *reinterpret_cast<u32x4*>(Ss + ((t * ldd_s + c) >> 1)) = v;
+                if constexpr (!BWD) *reinterpret_cast<u32x4*>(D2 + ((t * ldd_s + c) >> 1)) = v2;
+            }
         }
         __syncthreads();
         const int wbytes = (int)((((int64_t)dm - 1) * eg.ld_w + dk) * 2);
@@ -564,9 +618,19 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
 }
 
 inline size_t raw_attn_lds(int dm, int Skp) { return (size_t)32 * (dm + 8) * 2 + (size_t)32 * (Skp + 4) * 4 + 8 * 4096; }
-inline size_t raw_attn_lds_fwd_edges(int dm, int Skp, int dk) {
-    const size_t ss = (size_t)32 * (Skp + 4) * 4, d2 = (size_t)2 * 32 * (dk + 8) * 2;
-    return (size_t)32 * (dm + 8) * 2 + (ss > d2 ? ss : d2) + 8 * 4096;
+inline size_t raw_attn_lds_fwd_edges(int dm, int Skp, int dk, int Kq = 0) {
+    const size_t a = (size_t)32 * (dm + 8) * 2, ss = (size_t)32 * (Skp + 4) * 4, d2 = (size_t)2 * 32 * (dk + 8) * 2;
+    const size_t y = Kq > 0 ? (size_t)2 * 32 * (Kq + 8) * 2 : 0, need = d2 + (y <= a ? 0 : y);
+    return a + (ss > need ? ss : need) + 8 * 4096;
+}
+// the kernel's dynamic-LDS ceiling only ever grows (one record per instantiation, whichever entry point launches it)
+template <bool BWD, bool EDGES>
+void raw_attn_set_lds(size_t lds) {
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<BWD, EDGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
 }
 }  // namespace
 
@@ -620,11 +684,7 @@ extern "C" int bmt_raw_attn_fwd(const uint16_t* q_f16, int64_t q_sb, int64_t q_s
                      reinterpret_cast<uintptr_t>(p_bf)) & 15) && !((q_sb | q_sh | ldq | ldx | p_bf_sb | p_bf_sh) & 7) && ldx >= dm && ldo >= (int64_t)H * dm,
                   "bmt_raw_attn_fwd: 16-byte aligned operands, strides that are multiples of 8 elements");
     const size_t lds = raw_attn_lds(dm, Skp);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    raw_attn_set_lds<false, false>(lds);
     hipLaunchKernelGGL(raw_attn_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, q_f16, q_sb, q_sh, ldq, x_f16, ldx, off, xt_f16, p_f16, p_bf, p_bf_sb,
                        p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, RawEdges{});
     BMT_CHECK_LAUNCH("bmt_raw_attn_fwd");
@@ -640,11 +700,7 @@ extern "C" int bmt_raw_attn_bwd(const uint16_t* do_bf, int64_t do_sb, int64_t do
                      reinterpret_cast<uintptr_t>(ds_bf)) & 15) && !((do_sb | do_sh | lddo | ldx | ds_sb | ds_sh) & 7) && ldx >= dm && lddq >= (int64_t)H * dm,
                   "bmt_raw_attn_bwd: 16-byte aligned operands, strides that are multiples of 8 elements");
     const size_t lds = raw_attn_lds(dm, Skp);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    raw_attn_set_lds<true, false>(lds);
     hipLaunchKernelGGL(raw_attn_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, do_bf, do_sb, do_sh, lddo, x_bf, ldx, off, xtc_bf,
                        const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dq_bf, (uint16_t*)nullptr, lddq, H, Tq, dm, Skp, scale, RawEdges{});
     BMT_CHECK_LAUNCH("bmt_raw_attn_bwd");
@@ -669,12 +725,8 @@ extern "C" int bmt_raw_attn_bwd_edges(const uint16_t* do_bf, int64_t ld_do, cons
                       ld_do >= (int64_t)H * dk && ld_dq >= (int64_t)H * dk && ld_wvT >= (int64_t)H * dk,
                   "bmt_raw_attn_bwd_edges: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
     const size_t lds = raw_attn_lds(dm, Skp);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
-    const RawEdges eg{do_bf, nullptr, ld_do, wvT_bf, nullptr, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk};
+    raw_attn_set_lds<true, true>(lds);
+    const RawEdges eg{do_bf, nullptr, ld_do, wvT_bf, nullptr, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
     hipLaunchKernelGGL((raw_attn_kernel<true, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_bf,
                        ldx, off, xtc_bf, const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dqp_bf, (uint16_t*)nullptr, lddqp, H, Tq, dm, Skp, scale, eg);
     BMT_CHECK_LAUNCH("bmt_raw_attn_bwd_edges");
@@ -699,14 +751,39 @@ extern "C" int bmt_raw_attn_fwd_edges(const uint16_t* q_hi, const uint16_t* q_lo
                       ld_wkT >= (int64_t)H * dk,
                   "bmt_raw_attn_fwd_edges: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
     const size_t lds = raw_attn_lds_fwd_edges(dm, Skp, dk);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)raw_attn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
-    const RawEdges eg{q_hi, q_lo, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk};
+    raw_attn_set_lds<false, true>(lds);
+    const RawEdges eg{q_hi, q_lo, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
     hipLaunchKernelGGL((raw_attn_kernel<false, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_f16,
                        ldx, off, xt_f16, p_f16, p_bf, p_bf_sb, p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, eg);
     BMT_CHECK_LAUNCH("bmt_raw_attn_fwd_edges");
+    return BMT_OK;
+}
+
+extern "C" int bmt_raw_attn_fwd_proj_ok(int dm, int Skp, int dk, int Kq) {
+    return bmt_raw_attn_ok(dm, Skp) && dk > 0 && dk % 64 == 0 && Kq > 0 && Kq % 64 == 0 && raw_attn_lds_fwd_edges(dm, Skp, dk, Kq) <= (size_t)160 * 1024;
+}
+
+extern "C" int bmt_raw_attn_fwd_proj(const uint16_t* y_hi, const uint16_t* y_lo, int64_t ld_y, int Kq, const uint16_t* wq_hi, const uint16_t* wq_lo, int64_t ld_wq,
+                                     const float* bq, uint16_t* q_hi_out, int64_t ld_q, const uint16_t* wkT_hi, const uint16_t* wkT_lo, int64_t ld_wkT,
+                                     uint16_t* bstack, int64_t b_sb, int64_t b_sh, const uint16_t* x_f16, int64_t ldx, const int* off, const uint16_t* xt_f16,
+                                     int B, int H, int Tq, int dm, int Skp, int dk, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb,
+                                     int64_t p_bf_sh, uint16_t* o_hi, uint16_t* o_lo, int64_t ldo, void* stream) {
+    BMT_CHECK_ARG(y_hi && y_lo && wq_hi && wq_lo && q_hi_out && wkT_hi && wkT_lo && bstack && x_f16 && off && xt_f16 && p_f16 && o_hi && B > 0 && H > 0 && Tq > 0 &&
+                      Tq <= 32,
+                  "bmt_raw_attn_fwd_proj: null pointer or bad extents (at most 32 queries per sample and head)");
+    BMT_CHECK_ARG(bmt_raw_attn_fwd_proj_ok(dm, Skp, dk, Kq), "bmt_raw_attn_fwd_proj: bmt_raw_attn_ok(dm, Skp), d_k and Kq multiples of 64, LDS with the planes of y and q_h <= 160 KB");
+    BMT_CHECK_ARG(!((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo) | reinterpret_cast<uintptr_t>(wq_hi) | reinterpret_cast<uintptr_t>(wq_lo) |
+                     reinterpret_cast<uintptr_t>(q_hi_out) | reinterpret_cast<uintptr_t>(wkT_hi) | reinterpret_cast<uintptr_t>(wkT_lo) | reinterpret_cast<uintptr_t>(bstack) |
+                     reinterpret_cast<uintptr_t>(x_f16) | reinterpret_cast<uintptr_t>(xt_f16) | reinterpret_cast<uintptr_t>(p_f16) | reinterpret_cast<uintptr_t>(p_bf) |
+                     reinterpret_cast<uintptr_t>(o_hi) | reinterpret_cast<uintptr_t>(o_lo)) & 15) &&
+                      !((ld_y | ld_wq | ld_q | ld_wkT | b_sb | b_sh | ldx | p_bf_sb | p_bf_sh | ldo) & 7) && ldx >= dm && ldo >= (int64_t)H * dm && ld_q >= (int64_t)H * dk &&
+                      ld_wkT >= (int64_t)H * dk && ld_y >= Kq && ld_wq >= Kq,
+                  "bmt_raw_attn_fwd_proj: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
+    const size_t lds = raw_attn_lds_fwd_edges(dm, Skp, dk, Kq);
+    raw_attn_set_lds<false, true>(lds);
+    const RawEdges eg{q_hi_out, nullptr, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk, y_hi, y_lo, ld_y, Kq, wq_hi, wq_lo, ld_wq, bq};
+    hipLaunchKernelGGL((raw_attn_kernel<false, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_f16,
+                       ldx, off, xt_f16, p_f16, p_bf, p_bf_sb, p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, eg);
+    BMT_CHECK_LAUNCH("bmt_raw_attn_fwd_proj");
     return BMT_OK;
 }

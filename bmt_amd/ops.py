@@ -2733,6 +2733,7 @@ RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
 # profiles/r06_z6_raw_fused_ab.txt).
 RAW_FUSED = True
 RAW_FUSED_EDGES = True
+RAW_FUSED_PROJ = True        # ... and the query projection in front of the forward's (bmt_raw_attn_fwd_proj)
 
 
 class RawMemoryState:
@@ -2774,9 +2775,9 @@ def gemm_batched(prec, M, N, Kpad, nb_o, nb_i, ah, al, lda, bh, bl, ldb, *, a_of
     _lib.check(lib.bmt_gemm_small_batched(C.byref(a), C.byref(bt), _st()), "bmt_gemm_small_batched")
 
 
-def raw_attn_launch(bwd: bool, B: int, H: int, Tq: int, S: int, dm: int, fn, edges_dk: int = 0):
+def raw_attn_launch(bwd: bool, B: int, H: int, Tq: int, S: int, dm: int, fn, edges_dk: int = 0, proj_k: int = 0):
     """one fused launch of the reassociated cross-attention's middle (bmt_raw_attn_fwd / _bwd): two products of H Tq x S x dm per sample and the
-    row operation between them (edges_dk: + the two block products of H Tq x dm x d_k either side, bmt_raw_attn_bwd_edges).  ``fn`` issues it --
+    row operation between them (edges_dk: + the block products of H Tq x dm x d_k either side; proj_k: + the query projection H Tq x d_k x proj_k in front).  ``fn`` issues it --
     a seam of its own so that bench.py's kernel timer sees the launch as a class"""
     return fn()
 
@@ -2924,14 +2925,23 @@ class RawCrossAttnFn(torch.autograd.Function):
             _need_fp32(Q)
             Qp = make_planes(Qc.view(-1, Dq), "x3")
             attach_planes(Q, Qp)
-        q = linear_fwd_planes(Qp, Wq, bq, precision=X3, out_fmt="x3")                         # [M][D] hi + lo
+        f_edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_fwd_edges_ok(dm, Skp, dk))     # Q' inside the fused launch below (no fp16 copy in memory)
+        Kq = Qp.hi.stride(0)
+        # ... and the query projection in front of it: q_h = y W_q,h^T + b_q,h from the sample's rows of y (only its high plane reaches memory)
+        f_proj = f_edges and RAW_FUSED_PROJ and Qp.lo is not None and Wq.dim() == 2 and bool(lib.bmt_raw_attn_fwd_proj_ok(dm, Skp, dk, Kq))
+        if f_proj:
+            wq = weight_planes(Wq, "x3")
+            f_proj = wq.lo is not None and wq.hi.stride(0) >= Kq
+        if f_proj:
+            q = Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D)
+        else:
+            q = linear_fwd_planes(Qp, Wq, bq, precision=X3, out_fmt="x3")                     # [M][D] hi + lo
         # the memory's two projections as one weight group (what the projected form and greedy decoding register too): member planes
         grp, _ = weight_group((Wk, Wv), (bk, bv), "x3")
         gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))                                 # [dm][2 D] hi + lo: columns [0, D) = W_k^T
         train = any(ctx.needs_input_grad)      # (the queries, the memory or ANY of the module's parameters: a partly frozen module saves what its backward reads)
         # Q'[(b, t)][h dm + d] = q_h W_k,h: fp16 (the A operand of S) in the natural layout, bf16 into the B stack (b, l, 0, h)
         bo_, bsb, bsh = st.b_block(l, 0)
-        f_edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_fwd_edges_ok(dm, Skp, dk))     # ... inside the fused launch below (no fp16 copy in memory)
         if not f_edges:
             qf = torch.empty(M, H * dm, device=dev, dtype=torch.float16)
             # (one product per head over all the samples' rows: a weight tile is fetched once, not once per sample; row (b, t) -> block b of the stack)
@@ -2943,7 +2953,13 @@ class RawCrossAttnFn(torch.autograd.Function):
         p_bf = C.c_void_p(_addr(st.astack, ao)) if st.astack is not None else None
         # O' = P X (natural layout, split-bf16 planes: the A operand of the value block product)
         Op = _alloc_planes(M, H * dm, "x3", dev, ld=H * dm)
-        if f_edges:
+        if f_proj:
+            # q_h = y W_q,h^T + b_q,h -> Q'_h = q_h W_k,h -> S = Q' X^T -> P = softmax -> O' = P X: one launch per attention, workgroup = (sample, head)
+            raw_attn_launch(False, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_fwd_proj(
+                _addr(Qp.hi), _addr(Qp.lo), Kq, Kq, _addr(wq.hi), _addr(wq.lo), wq.hi.stride(0), _p(bq), _addr(q.hi), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0),
+                _addr(st.bstack, bo_), bsb, bsh, _addr(st.x.fh), st.x.fh.stride(0), st.pack.off_ptr, _addr(st.xt_f16), B, H, Tq, dm, Skp, dk, 1.0 / math.sqrt(dk),
+                _p(Pf), p_bf, asb, ash, _addr(Op.hi), _addr(Op.lo), H * dm, _st()), "bmt_raw_attn_fwd_proj"), edges_dk=dk, proj_k=Dq)
+        elif f_edges:
             # Q'_h = q_h W_k,h -> S = Q' X^T -> P = softmax -> O' = P X: one launch per attention, workgroup = (sample, head)
             raw_attn_launch(False, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_fwd_edges(
                 _addr(q.hi), _addr(q.lo), D, _addr(gT.hi), _addr(gT.lo), gT.hi.stride(0), _addr(st.bstack, bo_), bsb, bsh, _addr(st.x.fh), st.x.fh.stride(0),

@@ -234,6 +234,16 @@ int bmt_raw_attn_edges_ok(int dm, int Skp, int dk);
  *                     (no copy in memory) and bf16 to bstack + b * b_sb + h * b_sh + t * dm (32 rows, rows t >= Tq zeros).  bmt_raw_attn_fwd_edges_ok:
  *                     bmt_raw_attn_ok, dk a multiple of 64, and the LDS with two planes of q_h parked in the score tile's area <= 160 KB. */
 int bmt_raw_attn_fwd_edges_ok(int dm, int Skp, int dk);
+/*   bmt_raw_attn_fwd_proj   ... and the query projection in front of that: q_h = y W_q,h^T + b_q,h (split-bf16) from the sample's rows of y (y_hi / y_lo
+ *                     [B Tq][ld_y], Kq = the padded width, a multiple of 64 with zeros past the true width; wq_hi / wq_lo: W_q's planes, row h dk + n,
+ *                     Kq contiguous; bq [H dk] or NULL) -> q_h's two planes in LDS (the operand of Q'_h = q_h W_k,h) and its high plane to
+ *                     q_hi_out [B Tq][ld_q] (what the backward reads).  linear_Q2d of model/multihead_attention.py:62 inside the launch. */
+int bmt_raw_attn_fwd_proj_ok(int dm, int Skp, int dk, int Kq);
+int bmt_raw_attn_fwd_proj(const uint16_t* y_hi, const uint16_t* y_lo, int64_t ld_y, int Kq, const uint16_t* wq_hi, const uint16_t* wq_lo, int64_t ld_wq,
+                          const float* bq, uint16_t* q_hi_out, int64_t ld_q, const uint16_t* wkT_hi, const uint16_t* wkT_lo, int64_t ld_wkT, uint16_t* bstack,
+                          int64_t b_sb, int64_t b_sh, const uint16_t* x_f16, int64_t ldx, const int* off, const uint16_t* xt_f16, int B, int H, int Tq, int dm,
+                          int Skp, int dk, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb, int64_t p_bf_sh, uint16_t* o_hi, uint16_t* o_lo,
+                          int64_t ldo, void* stream);
 int bmt_raw_attn_fwd_edges(const uint16_t* q_hi, const uint16_t* q_lo, int64_t ld_q, const uint16_t* wkT_hi, const uint16_t* wkT_lo, int64_t ld_wkT,
                            uint16_t* bstack, int64_t b_sb, int64_t b_sh, const uint16_t* x_f16, int64_t ldx, const int* off, const uint16_t* xt_f16, int B, int H,
                            int Tq, int dm, int Skp, int dk, float scale, uint16_t* p_f16, uint16_t* p_bf, int64_t p_bf_sb, int64_t p_bf_sh, uint16_t* o_hi,

@@ -301,6 +301,44 @@ def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
             e = rel_err(x_.float(), y_.float())
             assert e < bar, f"forward edges: {n}: {e:.3e}"
         assert bool((fa[2][:, 0] == 5.0).all())
+        # ... and with the query projection in front of that (bmt_raw_attn_fwd_proj): q_h = y W_q,h^T + b_q,h from the sample's rows of y (300 columns padded to
+        # 320), against the product of the operands' hi + lo planes in fp64 fed to bmt_raw_attn_fwd_edges
+        Kq = 320
+        if lib.bmt_raw_attn_fwd_proj_ok(dm, Skp, dk, Kq):
+            y_pl = ops.make_planes((rnd(M, 300, seed=9) * 0.8).to(DEV), "x3")
+            wq_pl = ops.make_planes((rnd(D, 300, seed=10) * 0.06).to(DEV), "x3")
+            bq = (rnd(D, seed=11) * 0.2).to(DEV)
+            assert y_pl.hi.stride(0) == Kq and wq_pl.hi.stride(0) == Kq
+            q64 = (y_pl.hi.double() + y_pl.lo.double()) @ (wq_pl.hi.double() + wq_pl.lo.double()).t() + bq.double()
+            q_ref = ops.make_planes(q64.float().contiguous(), "x3")
+
+            def pchain(fused):
+                Pf2 = torch.full((B, H, 32, Skp), 3.0, device=DEV, dtype=torch.float16)
+                stack = torch.full((B, 2, H, 32, Skp), 5.0, device=DEV, dtype=torch.bfloat16)
+                bst = torch.zeros(B, H, 32, dm, device=DEV, dtype=torch.bfloat16)
+                hi = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+                lo = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+                qo = torch.zeros(M, D, device=DEV, dtype=torch.bfloat16)
+                pb = C.c_void_p(ops._addr(stack, H * 32 * Skp))
+                if fused:
+                    ops._lib.check(lib.bmt_raw_attn_fwd_proj(ops._addr(y_pl.hi), ops._addr(y_pl.lo), Kq, Kq, ops._addr(wq_pl.hi), ops._addr(wq_pl.lo), Kq, ops._p(bq), ops._addr(qo), D,
+                                                             ops._addr(wkT.hi), ops._addr(wkT.lo), wkT.hi.stride(0), ops._addr(bst), bsb, bsh, ops._addr(xpl.fh), xpl.fh.stride(0),
+                                                             pk.off_ptr, ops._addr(xt), B, H, Tq, dm, Skp, dk, scale, ops._p(Pf2), pb, sb, sh, ops._addr(hi), ops._addr(lo), H * dm,
+                                                             None), "fp")
+                else:
+                    qo = q_ref.hi.clone()
+                    ops._lib.check(lib.bmt_raw_attn_fwd_edges(ops._addr(q_ref.hi), ops._addr(q_ref.lo), q_ref.hi.stride(0), ops._addr(wkT.hi), ops._addr(wkT.lo), wkT.hi.stride(0),
+                                                              ops._addr(bst), bsb, bsh, ops._addr(xpl.fh), xpl.fh.stride(0), pk.off_ptr, ops._addr(xt), B, H, Tq, dm, Skp, dk, scale,
+                                                              ops._p(Pf2), pb, sb, sh, ops._addr(hi), ops._addr(lo), H * dm, None), "fe")
+                torch.cuda.synchronize()
+                return qo, bst, Pf2, hi.float() + lo.float()
+
+            pa, pb_ = pchain(True), pchain(False)
+            assert_close(pa[0].float(), pb_[0].float(), atol=1.1 * 2.0 ** -8 * amax(pb_[0]), rtol=0, name="q (high plane)")
+            for x_, y_, n, bar in zip(pa[1:], pb_[1:], ("Q' (B stack)", "P fp16", "O'"), (4e-3, 3e-3, 3e-3)):
+                e = rel_err(x_.float(), y_.float())
+                assert e < bar, f"query projection in the launch: {n}: {e:.3e}"
+            assert amax(pa[1][:, :, Tq:]) == 0.0
     for x_, y_, n, bar in zip(a, b_, ("dO' (B stack)", "dS (stack)", "dQ'", "dq", "db_q (accumulated onto ones)"), (4e-3, 1e-2, 1e-2, 1e-2, 1e-3)):
         e = rel_err(x_.float(), y_.float())
         assert e < bar, f"{n}: {e:.3e}"
