@@ -195,7 +195,7 @@ class KernelTimer:
                 n_e = 2 if bwd else 1      # of the forward), their d_k-wide rows and the weight blocks
                 fl += n_e * 2.0 * B_ * H * Tq * dm * edges_dk
                 by += B_ * 2.0 * n_e * (1 if bwd else 2) * H * Tq * edges_dk + 2.0 * n_e * (1 if bwd else 2) * H * edges_dk * dm
-            if proj_k:        # + the query projection (H Tq x d_k x proj_k, split-bf16): y's two planes, W_q's two planes, q's high plane
+            if proj_k:        # + the query projection / the out-projection's dX (H Tq x d_k x proj_k): the stream's rows, the weight's planes, the d_k-wide result
                 fl += 2.0 * B_ * H * Tq * edges_dk * proj_k
                 by += B_ * 2.0 * 2 * Tq * proj_k + 2.0 * 2 * H * edges_dk * proj_k + B_ * 2.0 * H * Tq * edges_dk
             return timer._timed("raw_attn_fused_" + ("bf16" if bwd else "f16") + ("_proj" if proj_k else "_edges" if edges_dk else ""), 1, fl, by, fn)

@@ -113,6 +113,9 @@ SIGNATURES = {
     "bmt_raw_attn_edges_ok": (i32, [i32, i32, i32]),
     "bmt_raw_attn_fwd_edges_ok": (i32, [i32, i32, i32]),
     "bmt_raw_attn_fwd_proj_ok": (i32, [i32, i32, i32, i32]),
+    "bmt_raw_attn_bwd_proj_ok": (i32, [i32, i32, i32, i32]),
+    "bmt_raw_attn_bwd_proj": (i32, [vp, i64, i32, vp, i64, f32, vp, u32, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp,
+                                     i64, i64, vp, i64, vp, i64, vp, i64, vp, vp]),
     "bmt_raw_attn_fwd_proj": (i32, [vp, vp, i64, i32, vp, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp,
                                      i64, i64, vp, vp, i64, vp]),
     "bmt_raw_attn_fwd_edges": (i32, [vp, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, i64, i64, vp, vp, i64, vp]),

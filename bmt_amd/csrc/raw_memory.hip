@@ -413,6 +413,11 @@ struct RawEdges {
     const uint16_t* y_hi; const uint16_t* y_lo; int64_t ld_y; int Kq;      // y [M][ld_y], Kq = its padded width (a multiple of 64, zeros past the true width)
     const uint16_t* wq_hi; const uint16_t* wq_lo; int64_t ld_wq;           // W_q's planes: row h dk + n, Kq contiguous
     const float* bq;                                                        // [H dk] or null
+    // backward, optional (y_hi != null): the out-projection's dX in front of everything, do_h = dropout_mask(dy W_o[:, h dk ...]) (bf16, one pass): y_hi = dy's
+    // plane [M][ld_y] (Kq its padded width), wq_hi = W_o^T's plane (row h dk + n, Kq contiguous) -- then in_hi is an OUTPUT (do's plane, the operand of
+    // dW_v), its column sums are ADDED to dbv [H dk] (or null), and the attention-output dropout of the forward (p, site, the {seed, step} pair at rng; element
+    // index row * in_ld + column) is re-applied
+    float* dbv; float drop_p; const uint64_t* rng; uint32_t site;
 };
 
 // a finished 32 x 32 fp32 tile through the wave's 4-KB area ([32][32] fp32, 16-byte granules XOR-swizzled by the row): lane -> rows
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     uint32_t* Ss = reinterpret_cast<uint32_t*>(smem + (size_t)32 * lda_s * 2);
     // (the forward's edge product parks TWO planes of q_h in the score tile's area: hi | lo)
     // (... and the query projection in front of it two planes of y: in the A area where they fit, else behind q_h's)
-    const size_t d2_bytes = (EDGES && !BWD) ? (size_t)2 * 32 * (eg.dk + 8) * 2 : 0, y_bytes = (EDGES && !BWD && eg.y_hi) ? (size_t)2 * 32 * (eg.Kq + 8) * 2 : 0;
+    const size_t d2_bytes = !EDGES ? 0 : (size_t)(BWD ? 1 : 2) * 32 * (eg.dk + 8) * 2, y_bytes = (EDGES && eg.y_hi) ? (size_t)(BWD ? 1 : 2) * 32 * (eg.Kq + 8) * 2 : 0;
     const bool y_in_a = y_bytes <= (size_t)32 * lda_s * 2;
     const size_t ss_bytes = max((size_t)32 * lds_s * 4, d2_bytes + (y_in_a ? 0 : y_bytes));
     char* const wbase = smem + (size_t)32 * lda_s * 2 + ss_bytes + w * 4096;
@@ -463,9 +468,56 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
         const int dk = eg.dk, ldd_s = dk + 8, pc = dk >> 3;
         uint32_t* const D2 = Ss + 16 * ldd_s;                  // (the low plane: 32 rows of ldd_s 16-bit elements further)
         const int64_t ro = (int64_t)b * Tq * eg.ld_in + (int64_t)h * dk;
-        bool projected = false;
-        if constexpr (!BWD) projected = eg.y_hi != nullptr;
+        const bool projected = eg.y_hi != nullptr;
         if (projected) {
+            if constexpr (BWD) {
+                // ---- do_h = mask(dy W_o[:, h dk ...]) from the sample's 32 rows of dy: its plane into LDS, the product (bf16) where the loaded do_h would
+                // have gone and to memory (the operand of dW_v); the forward's attention-output dropout re-applied, column sums -> db_v
+                const int Kq = eg.Kq, ldy_s = Kq + 8, pcq = Kq >> 3;
+                uint32_t* const Y1 = y_in_a ? As : Ss + (d2_bytes >> 2);
+                const int64_t yo = (int64_t)b * Tq * eg.ld_y;
+                for (int i = tid; i < 32 * pcq; i += 512) {
+                    const int t = i / pcq, c = (i - t * pcq) * 8;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (t < Tq) v = *reinterpret_cast<const u32x4*>(eg.y_hi + yo + (int64_t)t * eg.ld_y + c);
+                    *reinterpret_cast<u32x4*>(Y1 + ((t * ldy_s + c) >> 1)) = v;
+                }
+                __syncthreads();
+                const int qbytes = (int)((((int64_t)dk - 1) * eg.ld_wq + Kq) * 2);
+                const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wq_hi + (int64_t)h * dk * eg.ld_wq), 0, qbytes, 0x00020000);
+                uint16_t* const dout = const_cast<uint16_t*>(eg.in_hi);
+                const DropCtx dc = make_drop(eg.drop_p, eg.rng, eg.site);
+                raw_wave_product<false, 4, false>(Y1, ldy_s >> 1, rsQ, (int)(eg.ld_wq * 2), dk, dk >> 5, Kq >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+                    const int c = n * 32 + (l & 3) * 8;
+                    float cs[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cs[q] = 0.f;
+                    raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
+                        const bool on = t < Tq;
+                        const uint64_t e0 = (uint64_t)((int64_t)(b * Tq + t) * eg.ld_in + (int64_t)h * dk + c);
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            v[q] = on ? drop_apply(dc, q < 4 ? v0[q & 3] : v1[q & 3], e0 + q) : 0.f;
+                            cs[q] += v[q];
+                        }
+                        const u32x4 hv = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                        *reinterpret_cast<u32x4*>(Ss + ((t * ldd_s + c) >> 1)) = hv;
+                        if (on) *reinterpret_cast<u32x4*>(dout + ro + (int64_t)t * eg.ld_in + c) = hv;
+                    });
+                    if (eg.dbv) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                            for (int o = 4; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+                        }
+                        if (l < 4) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) atomicAdd(eg.dbv + h * dk + c + q, cs[q]);
+                        }
+                    }
+                });
+            }
             if constexpr (!BWD) {
                 // ---- q_h = y W_q,h^T + b_q,h (split-bf16) from the sample's 32 rows of y: its two planes into LDS, the product's hi / lo planes where
                 // the loaded q_h would have gone, the high plane to memory too (the backward's operand of dW_k)
@@ -618,6 +670,11 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
 }
 
 inline size_t raw_attn_lds(int dm, int Skp) { return (size_t)32 * (dm + 8) * 2 + (size_t)32 * (Skp + 4) * 4 + 8 * 4096; }
+inline size_t raw_attn_lds_bwd_proj(int dm, int Skp, int dk, int Kq) {
+    const size_t a = (size_t)32 * (dm + 8) * 2, ss = (size_t)32 * (Skp + 4) * 4, d1 = (size_t)32 * (dk + 8) * 2, y = (size_t)32 * (Kq + 8) * 2;
+    const size_t need = d1 + (y <= a ? 0 : y);
+    return a + (ss > need ? ss : need) + 8 * 4096;
+}
 inline size_t raw_attn_lds_fwd_edges(int dm, int Skp, int dk, int Kq = 0) {
     const size_t a = (size_t)32 * (dm + 8) * 2, ss = (size_t)32 * (Skp + 4) * 4, d2 = (size_t)2 * 32 * (dk + 8) * 2;
     const size_t y = Kq > 0 ? (size_t)2 * 32 * (Kq + 8) * 2 : 0, need = d2 + (y <= a ? 0 : y);
@@ -726,7 +783,7 @@ extern "C" int bmt_raw_attn_bwd_edges(const uint16_t* do_bf, int64_t ld_do, cons
                   "bmt_raw_attn_bwd_edges: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
     const size_t lds = raw_attn_lds(dm, Skp);
     raw_attn_set_lds<true, true>(lds);
-    const RawEdges eg{do_bf, nullptr, ld_do, wvT_bf, nullptr, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
+    const RawEdges eg{do_bf, nullptr, ld_do, wvT_bf, nullptr, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, 0.f, nullptr, 0u};
     hipLaunchKernelGGL((raw_attn_kernel<true, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_bf,
                        ldx, off, xtc_bf, const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dqp_bf, (uint16_t*)nullptr, lddqp, H, Tq, dm, Skp, scale, eg);
     BMT_CHECK_LAUNCH("bmt_raw_attn_bwd_edges");
@@ -752,7 +809,7 @@ extern "C" int bmt_raw_attn_fwd_edges(const uint16_t* q_hi, const uint16_t* q_lo
                   "bmt_raw_attn_fwd_edges: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
     const size_t lds = raw_attn_lds_fwd_edges(dm, Skp, dk);
     raw_attn_set_lds<false, true>(lds);
-    const RawEdges eg{q_hi, q_lo, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
+    const RawEdges eg{q_hi, q_lo, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, 0.f, nullptr, 0u};
     hipLaunchKernelGGL((raw_attn_kernel<false, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_f16,
                        ldx, off, xt_f16, p_f16, p_bf, p_bf_sb, p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, eg);
     BMT_CHECK_LAUNCH("bmt_raw_attn_fwd_edges");
@@ -781,9 +838,39 @@ extern "C" int bmt_raw_attn_fwd_proj(const uint16_t* y_hi, const uint16_t* y_lo,
                   "bmt_raw_attn_fwd_proj: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
     const size_t lds = raw_attn_lds_fwd_edges(dm, Skp, dk, Kq);
     raw_attn_set_lds<false, true>(lds);
-    const RawEdges eg{q_hi_out, nullptr, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk, y_hi, y_lo, ld_y, Kq, wq_hi, wq_lo, ld_wq, bq};
+    const RawEdges eg{q_hi_out, nullptr, ld_q, wkT_hi, wkT_lo, ld_wkT, bstack, b_sb, b_sh, nullptr, 0, nullptr, 0, nullptr, dk, y_hi, y_lo, ld_y, Kq, wq_hi, wq_lo, ld_wq, bq, nullptr, 0.f, nullptr, 0u};
     hipLaunchKernelGGL((raw_attn_kernel<false, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_f16,
                        ldx, off, xt_f16, p_f16, p_bf, p_bf_sb, p_bf_sh, o_hi, o_lo, ldo, H, Tq, dm, Skp, scale, eg);
     BMT_CHECK_LAUNCH("bmt_raw_attn_fwd_proj");
+    return BMT_OK;
+}
+
+extern "C" int bmt_raw_attn_bwd_proj_ok(int dm, int Skp, int dk, int Kq) {
+    return bmt_raw_attn_edges_ok(dm, Skp, dk) && Kq > 0 && Kq % 64 == 0 && raw_attn_lds_bwd_proj(dm, Skp, dk, Kq) <= (size_t)160 * 1024;
+}
+
+extern "C" int bmt_raw_attn_bwd_proj(const uint16_t* dy_bf, int64_t ld_dy, int Kq, const uint16_t* woT_bf, int64_t ld_woT, float drop_p, const uint64_t* rng,
+                                     uint32_t site, float* dbv, uint16_t* do_out, int64_t ld_do, const uint16_t* wvT_bf, int64_t ld_wvT, uint16_t* bstack,
+                                     int64_t b_sb, int64_t b_sh, const uint16_t* x_bf, int64_t ldx, const int* off, const uint16_t* xtc_bf, const uint16_t* p_f16,
+                                     int B, int H, int Tq, int dm, int Skp, int dk, float scale, uint16_t* ds_bf, int64_t ds_sb, int64_t ds_sh, uint16_t* dqp_bf,
+                                     int64_t lddqp, const uint16_t* wk_bf, int64_t ld_wk, uint16_t* dq_bf, int64_t ld_dq, float* dbq, void* stream) {
+    BMT_CHECK_ARG(dy_bf && woT_bf && do_out && wvT_bf && bstack && x_bf && off && xtc_bf && p_f16 && dqp_bf && wk_bf && dq_bf && B > 0 && H > 0 && Tq > 0 && Tq <= 32 &&
+                      drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (rng && ld_do == (int64_t)H * dk)),
+                  "bmt_raw_attn_bwd_proj: null pointer or bad extents (at most 32 queries per sample and head; a dropout rate needs its {seed, step} pair and the "
+                  "forward's element index: ld_do = H d_k)");
+    BMT_CHECK_ARG(bmt_raw_attn_bwd_proj_ok(dm, Skp, dk, Kq), "bmt_raw_attn_bwd_proj: bmt_raw_attn_edges_ok(dm, Skp, dk), Kq a multiple of 64, LDS with the plane of dy <= 160 KB");
+    BMT_CHECK_ARG(!((reinterpret_cast<uintptr_t>(dy_bf) | reinterpret_cast<uintptr_t>(woT_bf) | reinterpret_cast<uintptr_t>(do_out) | reinterpret_cast<uintptr_t>(wvT_bf) |
+                     reinterpret_cast<uintptr_t>(bstack) | reinterpret_cast<uintptr_t>(x_bf) | reinterpret_cast<uintptr_t>(xtc_bf) | reinterpret_cast<uintptr_t>(p_f16) |
+                     reinterpret_cast<uintptr_t>(ds_bf) | reinterpret_cast<uintptr_t>(dqp_bf) | reinterpret_cast<uintptr_t>(wk_bf) | reinterpret_cast<uintptr_t>(dq_bf)) & 15) &&
+                      !((ld_dy | ld_woT | ld_do | ld_wvT | b_sb | b_sh | ldx | ds_sb | ds_sh | lddqp | ld_wk | ld_dq) & 7) && ldx >= dm && lddqp >= (int64_t)H * dm &&
+                      ld_wk >= dm && ld_do >= (int64_t)H * dk && ld_dq >= (int64_t)H * dk && ld_wvT >= (int64_t)H * dk && ld_dy >= Kq && ld_woT >= Kq,
+                  "bmt_raw_attn_bwd_proj: 16-byte aligned operands, strides that are multiples of 8 elements and cover their rows");
+    const size_t lds = raw_attn_lds_bwd_proj(dm, Skp, dk, Kq);
+    raw_attn_set_lds<true, true>(lds);
+    const RawEdges eg{do_out, nullptr, ld_do, wvT_bf, nullptr, ld_wvT, bstack, b_sb, b_sh, wk_bf, ld_wk, dq_bf, ld_dq, dbq, dk,
+                      dy_bf, nullptr, ld_dy, Kq, woT_bf, nullptr, ld_woT, nullptr, dbv, drop_p, rng, site};
+    hipLaunchKernelGGL((raw_attn_kernel<true, true>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, x_bf,
+                       ldx, off, xtc_bf, const_cast<uint16_t*>(p_f16), ds_bf, ds_sb, ds_sh, dqp_bf, (uint16_t*)nullptr, lddqp, H, Tq, dm, Skp, scale, eg);
+    BMT_CHECK_LAUNCH("bmt_raw_attn_bwd_proj");
     return BMT_OK;
 }

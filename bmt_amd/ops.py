@@ -3028,8 +3028,19 @@ class RawCrossAttnFn(torch.autograd.Function):
         P_, bias_done = grad_planes_from(dout, dy2, bo, drop) if has_res else grad_planes(dy2, bo, drop=drop)
         gbv = static_grad(bv)
         dbv_t = gbv if gbv is not None else torch.zeros(D, device=dev, dtype=torch.float32)
-        do = linear_dx(P_, Wo, out_planes=Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D), drop_post=True, drop_p=p, site=ctx.site,
-                       colsum=dbv_t)
+        edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_edges_ok(dm, Skp, dk))      # dO'_h and dq_h inside the fused launch below
+        Kd = P_.hi.stride(0)
+        # ... and this dX in front of them (do_h = mask(dy W_o[:, h-th block]) from the sample's rows of dy; the same transposed plane of W_o linear_dx reads)
+        b_proj = (edges and RAW_FUSED_PROJ and M * D <= SMALL_DX_OUTPUTS and Wo.dim() == 2 and Wo.is_contiguous() and Wo.shape[0] <= 2048 and
+                  bool(lib.bmt_raw_attn_bwd_proj_ok(dm, Skp, dk, Kd)))
+        if b_proj:
+            woT = weight_planes_t(Wo)
+            b_proj = woT.hi.stride(0) >= Kd
+        if b_proj:
+            do = Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D)
+        else:
+            do = linear_dx(P_, Wo, out_planes=Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D), drop_post=True, drop_p=p, site=ctx.site,
+                           colsum=dbv_t)
         if gbv is not None:
             grad_done(bv)
         dWo, dbo = wgrad(Wo, None if bias_done else bo, P_, Planes(oh, None, M, D), dy2_for_bias=dy2)
@@ -3037,18 +3048,24 @@ class RawCrossAttnFn(torch.autograd.Function):
         gT = weight_group_t((Wk, Wv), lo=True, bs=(bk, bv))
         # dO'_h = do_h W_v,h  -> B stack (b, l, 1, h)
         bo_, bsb, bsh = st.b_block(l, 1)
-        edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_edges_ok(dm, Skp, dk))      # ... inside the fused launch below, with dq_h behind it
         if not edges:
             gemm_batched(PREC_BF16, M, dm, dk, 1, H, _addr(do.hi), None, D, _addr(gT.hi, D), None, gT.hi.stride(0),
                          a_off=(0, dk), b_off=(0, dk), p1=_addr(st.bstack, bo_), ldp=dm, p_off=(0, bsh), p_div=(Tq, bsb))
-        dWv = _blockdiag_dw(do, Planes(Oph, None, M, H * dm), Wv, H)
         ao, asb, ash = st.a_block(l, 0)
         # dQ' = dS (X - mean key): natural layout, bf16
         dQp = Planes(torch.empty(M, H * dm, device=dev, dtype=torch.bfloat16), None, M, H * dm)
         gbq = static_grad(bq)
         dbq_t = gbq if gbq is not None else torch.zeros(D, device=dev, dtype=torch.float32)
         dq = Planes(torch.empty(M, D, device=dev, dtype=torch.bfloat16), None, M, D)
-        if edges:
+        if b_proj:
+            # do_h = mask(dy W_o) (+ db_v) -> dO'_h = do_h W_v,h -> dP -> dS -> dQ' -> dq_h = dQ'_h W_k,h^T (+ db_q): one launch, workgroup = (sample, head)
+            use_drop = p > 0.0
+            raw_attn_launch(True, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_bwd_proj(
+                _addr(P_.hi), Kd, Kd, _addr(woT.hi), woT.hi.stride(0), p if use_drop else 0.0, _p(rng_tensor()) if use_drop else None, ctx.site, _p(dbv_t),
+                _addr(do.hi), D, _addr(gT.hi, D), gT.hi.stride(0), _addr(st.bstack, bo_), bsb, bsh, _addr(st.x.hi), st.x.hi.stride(0), st.pack.off_ptr,
+                _addr(st.xtc_bf), _p(Pf), B, H, Tq, dm, Skp, dk, 1.0 / math.sqrt(dk), C.c_void_p(_addr(st.astack, ao)), asb, ash, _addr(dQp.hi), H * dm,
+                _addr(grp.hi), grp.hi.stride(0), _addr(dq.hi), D, _p(dbq_t), _st()), "bmt_raw_attn_bwd_proj"), edges_dk=dk, proj_k=Dq)
+        elif edges:
             # dO'_h = do_h W_v,h -> dP -> dS -> dQ' -> dq_h = dQ'_h W_k,h^T (+ column sums = db_q): one launch, workgroup = (sample, head)
             raw_attn_launch(True, B, H, Tq, st.S, dm, lambda: _lib.check(lib.bmt_raw_attn_bwd_edges(
                 _addr(do.hi), D, _addr(gT.hi, D), gT.hi.stride(0), _addr(st.bstack, bo_), bsb, bsh, _addr(st.x.hi), st.x.hi.stride(0), st.pack.off_ptr,
@@ -3068,6 +3085,7 @@ class RawCrossAttnFn(torch.autograd.Function):
                        "bmt_raw_softmax_bwd")
             gemm_batched(PREC_BF16, H * Tq, dm, Skp, B, 1, _addr(st.astack, ao), None, Skp, _addr(st.xtc_bf), None, Skp,
                          a_off=(asb, 0), a_div=(Tq, ash), b_off=(dm * Skp, 0), p1=_addr(dQp.hi), ldp=H * dm, p_off=(Tq * H * dm, 0), p_div=(Tq, dm))
+        dWv = _blockdiag_dw(do, Planes(Oph, None, M, H * dm), Wv, H)      # (behind the launch that may have produced do)
         # dq_h = dQ'_h W_k,h^T (+ its column sums = db_q)
         if not edges:
             gemm_batched(PREC_BF16, M, dk, dm, 1, H, _addr(dQp.hi), None, H * dm, _addr(grp.hi), None, grp.hi.stride(0),

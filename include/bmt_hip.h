@@ -239,6 +239,17 @@ int bmt_raw_attn_fwd_edges_ok(int dm, int Skp, int dk);
  *                     Kq contiguous; bq [H dk] or NULL) -> q_h's two planes in LDS (the operand of Q'_h = q_h W_k,h) and its high plane to
  *                     q_hi_out [B Tq][ld_q] (what the backward reads).  linear_Q2d of model/multihead_attention.py:62 inside the launch. */
 int bmt_raw_attn_fwd_proj_ok(int dm, int Skp, int dk, int Kq);
+/*   bmt_raw_attn_bwd_proj   bmt_raw_attn_bwd_edges with the out-projection's dX in front of it: do_h = mask(dy W_o[:, h dk ...]) (bf16, one pass; dy_bf [B Tq][ld_dy],
+ *                     Kq = its padded width; woT_bf = W_o^T's plane: row h dk + n, Kq contiguous) with the forward's attention-output dropout re-applied
+ *                     (drop_p, the {seed, step} pair at rng, site; element index row * ld_do + column, ld_do = H dk) -> do_out [B Tq][ld_do] (the operand of
+ *                     dW_v) and the A operand of dO'_h = do_h W_v,h; its column sums are ADDED to dbv [H dk] (optional).  The backward of
+ *                     model/multihead_attention.py:84-86 (linear_d2Q's dX and the dropout of :22-23) inside the launch. */
+int bmt_raw_attn_bwd_proj_ok(int dm, int Skp, int dk, int Kq);
+int bmt_raw_attn_bwd_proj(const uint16_t* dy_bf, int64_t ld_dy, int Kq, const uint16_t* woT_bf, int64_t ld_woT, float drop_p, const uint64_t* rng, uint32_t site,
+                          float* dbv, uint16_t* do_out, int64_t ld_do, const uint16_t* wvT_bf, int64_t ld_wvT, uint16_t* bstack, int64_t b_sb, int64_t b_sh,
+                          const uint16_t* x_bf, int64_t ldx, const int* off, const uint16_t* xtc_bf, const uint16_t* p_f16, int B, int H, int Tq, int dm, int Skp,
+                          int dk, float scale, uint16_t* ds_bf, int64_t ds_sb, int64_t ds_sh, uint16_t* dqp_bf, int64_t lddqp, const uint16_t* wk_bf, int64_t ld_wk,
+                          uint16_t* dq_bf, int64_t ld_dq, float* dbq, void* stream);
 int bmt_raw_attn_fwd_proj(const uint16_t* y_hi, const uint16_t* y_lo, int64_t ld_y, int Kq, const uint16_t* wq_hi, const uint16_t* wq_lo, int64_t ld_wq,
                           const float* bq, uint16_t* q_hi_out, int64_t ld_q, const uint16_t* wkT_hi, const uint16_t* wkT_lo, int64_t ld_wkT, uint16_t* bstack,
                           int64_t b_sb, int64_t b_sh, const uint16_t* x_f16, int64_t ldx, const int* off, const uint16_t* xt_f16, int B, int H, int Tq, int dm,

@@ -124,7 +124,7 @@ def test_kernel_classes_map_to_pmc_families():
     assert bench.pmc_keys_of_class("gemm_planes_dw_grouped_bf16") == ("gemm_dw_grouped",)
     # the decoder's fused cross-attention launches (csrc/raw_memory.hip): one family, whatever the operand format in the class name
     assert fam("void (anonymous namespace)::raw_attn_kernel<true, true>(unsigned short const*, long)") == "raw_attn_kernel"
-    for c in ("raw_attn_fused_f16", "raw_attn_fused_f16_edges", "raw_attn_fused_f16_proj", "raw_attn_fused_bf16", "raw_attn_fused_bf16_edges"):
+    for c in ("raw_attn_fused_f16", "raw_attn_fused_f16_edges", "raw_attn_fused_f16_proj", "raw_attn_fused_bf16", "raw_attn_fused_bf16_edges", "raw_attn_fused_bf16_proj"):
         assert bench.pmc_keys_of_class(c) == ("raw_attn_kernel",)
 
 

@@ -267,6 +267,43 @@ def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
 
     a, b_ = chain(True), chain(False)
     assert amax(a[0][:, :, Tq:]) == 0.0 and amax(a[0]) > 0.0
+    # ... and with the out-projection's dX in front of that (bmt_raw_attn_bwd_proj): do_h = mask(dy W_o[:, h-th block]) with the forward's dropout mask
+    # re-applied and its column sums, against ops.linear_dx (the same transposed plane of W_o, the same element index of the mask) + bmt_raw_attn_bwd_edges
+    if lib.bmt_raw_attn_bwd_proj_ok(dm, Skp, dk, 320) and M * D <= ops.SMALL_DX_OUTPUTS:
+        Wo = (rnd(300, D, seed=12) * 0.05).to(DEV)
+        P_ = ops.make_planes((rnd(M, 300, seed=13) * 0.3).to(DEV), "bwd")
+        woT = ops.weight_planes_t(Wo)
+        assert P_.hi.stride(0) == 320 and woT.hi.shape[0] == D
+        for pdrop in (0.0, 0.1):
+            def ochain(fused):
+                stack = torch.full((B, 2, H, 32, Skp), 5.0, device=DEV, dtype=torch.bfloat16)
+                bst = torch.zeros(B, H, 32, dm, device=DEV, dtype=torch.bfloat16)
+                dqp = torch.zeros(M, H * dm, device=DEV, dtype=torch.bfloat16)
+                dq = torch.zeros(M, D, device=DEV, dtype=torch.bfloat16)
+                dbq, dbv = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+                do_ = torch.zeros(M, D, device=DEV, dtype=torch.bfloat16)
+                ds = C.c_void_p(ops._addr(stack))
+                if fused:
+                    ops._lib.check(lib.bmt_raw_attn_bwd_proj(ops._addr(P_.hi), 320, 320, ops._addr(woT.hi), woT.hi.stride(0), pdrop, ops._p(ops.rng_tensor()) if pdrop else None, 7,
+                                                             ops._p(dbv), ops._addr(do_), D, ops._addr(wvT, 64), wvT.stride(0), ops._addr(bst), bsb, bsh, ops._addr(xpl.hi),
+                                                             xpl.hi.stride(0), pk.off_ptr, ops._addr(xtc), ops._p(Pf), B, H, Tq, dm, Skp, dk, scale, ds, sb, sh, ops._addr(dqp), H * dm,
+                                                             ops._addr(wk), wk.stride(0), ops._addr(dq), D, ops._p(dbq), None), "bp")
+                else:
+                    ops.linear_dx(P_, Wo, out_planes=ops.Planes(do_, None, M, D), drop_post=True, drop_p=pdrop, site=7, colsum=dbv)
+                    ops._lib.check(lib.bmt_raw_attn_bwd_edges(ops._addr(do_), D, ops._addr(wvT, 64), wvT.stride(0), ops._addr(bst), bsb, bsh, ops._addr(xpl.hi), xpl.hi.stride(0),
+                                                              pk.off_ptr, ops._addr(xtc), ops._p(Pf), B, H, Tq, dm, Skp, dk, scale, ds, sb, sh, ops._addr(dqp), H * dm,
+                                                              ops._addr(wk), wk.stride(0), ops._addr(dq), D, ops._p(dbq), None), "e")
+                torch.cuda.synchronize()
+                return do_, dbv, bst, dqp, dq, dbq
+
+            oa, ob = ochain(True), ochain(False)
+            assert_close(oa[0].float(), ob[0].float(), atol=1.1 * 2.0 ** -8 * amax(ob[0]), rtol=0, name=f"do (p = {pdrop})")
+            if pdrop:
+                za, zb = (oa[0] == 0), (ob[0] == 0)
+                assert 0.05 < float(zb.float().mean()) < 0.15 and bool((za == zb).all()), "the dropout mask of the launch is not linear_dx's"
+            for x_, y_, n, bar in zip(oa[1:], ob[1:], ("db_v", "dO' (B stack)", "dQ'", "dq", "db_q"), (1e-3, 4e-3, 1e-2, 1e-2, 1e-3)):
+                e = rel_err(x_.float(), y_.float())
+                assert e < bar, f"out-projection dX in the launch (p = {pdrop}): {n}: {e:.3e}"
     # the forward with ITS in-front block product in the launch (bmt_raw_attn_fwd_edges): Q'_h = q_h W_k,h (split-bf16, three passes) -> the A operand
     # (fp16, no copy in memory) + the B stack (bf16), against bmt_gemm_small_batched (x3) + bmt_raw_attn_fwd
     if lib.bmt_raw_attn_fwd_edges_ok(dm, Skp, dk):
