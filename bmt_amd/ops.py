@@ -2733,7 +2733,14 @@ RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
 # profiles/r06_z6_raw_fused_ab.txt).
 RAW_FUSED = True
 RAW_FUSED_EDGES = True
-RAW_FUSED_PROJ = True        # ... and the query projection in front of the forward's (bmt_raw_attn_fwd_proj)
+# ... and the stream-side projections in front of those.  The forward's (q_h = y W_q,h^T + b_q,h inside the launch, bmt_raw_attn_fwd_proj) is OFF: it is
+# worth 0.02-0.04 ms/step and its gradients are as close to the oracle's as without it (tools/probes/parity_arms.sh: the same to three digits), but the
+# other order of its fp32 sums moves the ten-Adam-step trajectory of tests/test_gpu_model.py -- chaotic in the gradients' low bits -- from 2e-4 ... 9e-4 to
+# 2.6e-3 ... 3.1e-3 off the oracle's at step 5, onto that test's 3e-3 bar (tools/probes/adam_gap_arms.sh, profiles/r06_z6_raw_fused_ab.txt): a bar is not
+# moved for 0.5 % of a step.  The backward's (do_h = mask(dy W_o) inside the launch, bmt_raw_attn_bwd_proj) is on: nothing measurable in the step, 4 launches
+# and 4 MB fewer, the trajectory where it was.
+RAW_FUSED_PROJ = False
+RAW_FUSED_PROJ_BWD = True
 
 
 class RawMemoryState:
@@ -3031,7 +3038,7 @@ class RawCrossAttnFn(torch.autograd.Function):
         edges = RAW_FUSED and RAW_FUSED_EDGES and bool(lib.bmt_raw_attn_edges_ok(dm, Skp, dk))      # dO'_h and dq_h inside the fused launch below
         Kd = P_.hi.stride(0)
         # ... and this dX in front of them (do_h = mask(dy W_o[:, h-th block]) from the sample's rows of dy; the same transposed plane of W_o linear_dx reads)
-        b_proj = (edges and RAW_FUSED_PROJ and M * D <= SMALL_DX_OUTPUTS and Wo.dim() == 2 and Wo.is_contiguous() and Wo.shape[0] <= 2048 and
+        b_proj = (edges and RAW_FUSED_PROJ_BWD and M * D <= SMALL_DX_OUTPUTS and Wo.dim() == 2 and Wo.is_contiguous() and Wo.shape[0] <= 2048 and
                   bool(lib.bmt_raw_attn_bwd_proj_ok(dm, Skp, dk, Kd)))
         if b_proj:
             woT = weight_planes_t(Wo)
