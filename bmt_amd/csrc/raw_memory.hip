@@ -200,13 +200,17 @@ __device__ __forceinline__ int raw_slot(int row, int s) { return row * 8 + (s ^ 
 //      fragments straight from the planes, 64 scattered 16-byte requests per instruction, and was slower than the three launches it replaces);
 //   done(n, acc)  consumes a finished tile (the wave's LDS area is free by then).
 // The (tile, chunk) pairs of the wave are one flat sequence, so the loads of the next tile are in flight under the last chunk of this one.
-template <bool F16, int NS, bool X3, typename Done>
+template <bool F16, int NS, int X3, typename Done>
 __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_stride, const __amdgpu_buffer_rsrc_t rs, int b_row_bytes, int b_rows, int ntiles,
                                                  int nch, char* wbase, int w, int lane, Done done, const uint32_t* As2 = nullptr,
                                                  const __amdgpu_buffer_rsrc_t rs2 = __amdgpu_buffer_rsrc_t()) {
-    // X3: a split-bf16 product -- the reduction runs twice into the same accumulator: over B with BOTH planes of A (A, and A2 = its low plane: one
-    // staged chunk of B feeds two MFMA chains), then over B2 (the low plane of B, behind rs2) with A
+    // X3 (a split-bf16 product: A2 = the low plane of A, rs2 = the low plane of B):
+    //   1  the reduction runs twice into the same accumulator: over B with BOTH planes of A (one staged chunk of B feeds two MFMA chains), then over
+    //      B2 with A;
+    //   2  gemm_small_kernel's order, bit for bit: chunk by chunk both planes of B are staged (two register sets), and per 16 reduction indices the
+    //      accumulator takes A2 . B, A . B2, A . B -- a caller that replaces a launch of that kernel hands on the same bits
     constexpr int OOB = 0x7ffffff0, NSEG = X3 ? 2 : 1;
+    static_assert(X3 != 2 || NS % 2 == 0, "the interleaved form pairs the register sets");
     const int half = lane >> 5, l31 = lane & 31, lrow = lane >> 3, piece = lane & 7;
     const int ntw = w < ntiles ? (ntiles - w + 7) >> 3 : 0, total = ntw * nch * NSEG;
     if (total == 0) return;
@@ -225,9 +229,16 @@ __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_strid
             rg[set_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, vo_, lc * 128, 0);                \
         }                                                                                              \
         ++li;                                                                                          \
-        if (++lc == nch) {                                                                             \
-            lc = 0;                                                                                    \
-            if (++lseg == NSEG) { lseg = 0; lt += 8; }                                                 \
+        if constexpr (X3 == 2) {                            /* the plane is the inner index */         \
+            if (++lseg == 2) {                                                                         \
+                lseg = 0;                                                                              \
+                if (++lc == nch) { lc = 0; lt += 8; }                                                  \
+            }                                                                                          \
+        } else {                                                                                       \
+            if (++lc == nch) {                                                                         \
+                lc = 0;                                                                                \
+                if (++lseg == NSEG) { lseg = 0; lt += 8; }                                             \
+            }                                                                                          \
         }                                                                                              \
     } while (0)
 #pragma unroll
@@ -238,6 +249,7 @@ __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_strid
     int ct = w, cc = 0, cseg = 0;
     const uint32_t* ar = As + l31 * a_stride + half * 4;
     const uint32_t* ar2 = X3 ? As2 + l31 * a_stride + half * 4 : ar;
+    bf16x8 fbh[4];                                            // (X3 == 2: the high plane's fragments of the chunk, kept while the low plane is staged)
     for (int idx = 0; idx < total; idx += NS) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -245,35 +257,69 @@ __device__ __forceinline__ void raw_wave_product(const uint32_t* As, int a_strid
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wbase + lds_w[i]) = rg[j][i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bf16x8 fa[4], fb[4], fa2[4];
-            const bool both = X3 && cseg == 0;                /* wave-uniform */
+            if constexpr (X3 == 2) {
+                if ((j & 1) == 0) {                           // the high plane of B: fragments out, nothing else
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                fb[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));
-                fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar + cc * 32 + u * 8));
-            }
-            if (both) {
+                    for (int u = 0; u < 4; ++u) fbh[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));
+                    BMT_RA_LOAD(j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) fa2[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar2 + cc * 32 + u * 8));
-            }
-            BMT_RA_LOAD(j);
-            __builtin_amdgcn_sched_barrier(0);
-            if (both) {
+                for (int u = 0; u < 4; ++u) {
+                    fb[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));      // the low plane
+                    fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar + cc * 32 + u * 8));
+                    fa2[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar2 + cc * 32 + u * 8));
+                }
+                BMT_RA_LOAD(j);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa2[u], fb[u], acc);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa[u], fb[u], acc);
-            if (++cc == nch) {
-                cc = 0;
-                if (++cseg == NSEG) {
+                for (int u = 0; u < 4; ++u) {
+                    acc = mfma32t<F16>(fa2[u], fbh[u], acc);
+                    acc = mfma32t<F16>(fa[u], fb[u], acc);
+                    acc = mfma32t<F16>(fa[u], fbh[u], acc);
+                }
+                if (++cc == nch) {
                     if (idx + j < total) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         done(ct, acc);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    cseg = 0;
+                    cc = 0;
                     ct += 8;
+                }
+            } else {
+                const bool both = X3 && cseg == 0;            /* wave-uniform */
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fb[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(wbase + raw_slot(l31, 2 * u + half) * 16));
+                    fa[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar + cc * 32 + u * 8));
+                }
+                if (both) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fa2[u] = as_bf16x8(*reinterpret_cast<const u32x4*>(ar2 + cc * 32 + u * 8));
+                }
+                BMT_RA_LOAD(j);
+                __builtin_amdgcn_sched_barrier(0);
+                if (both) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa2[u], fb[u], acc);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = mfma32t<F16>(fa[u], fb[u], acc);
+                if (++cc == nch) {
+                    cc = 0;
+                    if (++cseg == NSEG) {
+                        if (idx + j < total) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            done(ct, acc);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        cseg = 0;
+                        ct += 8;
+                    }
                 }
             }
         }
@@ -487,7 +533,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
                 const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wq_hi + (int64_t)h * dk * eg.ld_wq), 0, qbytes, 0x00020000);
                 uint16_t* const dout = const_cast<uint16_t*>(eg.in_hi);
                 const DropCtx dc = make_drop(eg.drop_p, eg.rng, eg.site);
-                raw_wave_product<false, 4, false>(Y1, ldy_s >> 1, rsQ, (int)(eg.ld_wq * 2), dk, dk >> 5, Kq >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+                raw_wave_product<false, 4, 0>(Y1, ldy_s >> 1, rsQ, (int)(eg.ld_wq * 2), dk, dk >> 5, Kq >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
                     const int c = n * 32 + (l & 3) * 8;
                     float cs[8];
 #pragma unroll
@@ -540,7 +586,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
                 const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wq_hi + (int64_t)h * dk * eg.ld_wq), 0, qbytes, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsQ2 = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wq_lo + (int64_t)h * dk * eg.ld_wq), 0, qbytes, 0x00020000);
                 uint16_t* const qout = const_cast<uint16_t*>(eg.in_hi);
-                raw_wave_product<false, 4, true>(Y1, ldy_s >> 1, rsQ, (int)(eg.ld_wq * 2), dk, dk >> 5, Kq >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+                raw_wave_product<false, 4, 2>(Y1, ldy_s >> 1, rsQ, (int)(eg.ld_wq * 2), dk, dk >> 5, Kq >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
                     const int c = n * 32 + (l & 3) * 8;
                     float bb[8];
 #pragma unroll
@@ -576,7 +622,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.w_hi + (int64_t)h * dk), 0, wbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)((BWD ? eg.w_hi : eg.w_lo) + (int64_t)h * dk), 0, wbytes, 0x00020000);
         uint16_t* bs = eg.bst + b * eg.bst_sb + h * eg.bst_sh;
-        raw_wave_product<false, 4, !BWD>(Ss, ldd_s >> 1, rsW, (int)(eg.ld_w * 2), dm, dm >> 5, dk >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<false, 4, BWD ? 0 : 1>(Ss, ldd_s >> 1, rsW, (int)(eg.ld_w * 2), dm, dm >> 5, dk >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
             raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
                 const u32x4 bv = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
                 const int c = n * 32 + (l & 3) * 8;
@@ -604,7 +650,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     // ---- first product: a wave per 32 keys (keys past the sample's length read as zeros: the row operation masks them)
     {
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (int64_t)r0 * ldx), 0, (int)((int64_t)len * ldx * 2), 0x00020000);
-        raw_wave_product<!BWD, 4, false>(As, lda_s >> 1, rsX, (int)(ldx * 2), len, (len + 31) >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<!BWD, 4, 0>(As, lda_s >> 1, rsX, (int)(ldx * 2), len, (len + 31) >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Ss[acc_row(r, half) * lds_s + n * 32 + lr] = __float_as_uint(acc[r]);
         });
@@ -620,7 +666,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
     // transposed memory are zero from the length to Skp, a multiple of 64)
     {
         const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(XT + (int64_t)b * dm * Skp), 0, (int)((int64_t)dm * Skp * 2), 0x00020000);
-        raw_wave_product<!BWD, 4, false>(Ss, lds_s, rsT, Skp * 2, dm, dm >> 5, max(1, (len + 63) >> 6), wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<!BWD, 4, 0>(Ss, lds_s, rsT, Skp * 2, dm, dm >> 5, max(1, (len + 63) >> 6), wbase, w, l, [&](int n, const f32x16& acc) {
             raw_tile_rows(reinterpret_cast<float*>(wbase), acc, l, [&](int, int t, const f32x4& v0, const f32x4& v1) {
                 uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
                 split_bf2(v0[0], v0[1], h0, l0);
@@ -642,7 +688,7 @@ __global__ __launch_bounds__(512) void raw_attn_kernel(const uint16_t* __restric
         __syncthreads();
         const int dk = eg.dk;
         const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(eg.wk + (int64_t)h * dk * eg.ld_wk), 0, (int)((((int64_t)dk - 1) * eg.ld_wk + dm) * 2), 0x00020000);
-        raw_wave_product<false, 4, false>(As, lda_s >> 1, rsK, (int)(eg.ld_wk * 2), dk, dk >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
+        raw_wave_product<false, 4, 0>(As, lda_s >> 1, rsK, (int)(eg.ld_wk * 2), dk, dk >> 5, dm >> 6, wbase, w, l, [&](int n, const f32x16& acc) {
             float cs[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs[q] = 0.f;

@@ -2733,13 +2733,14 @@ RAW_MEMORY = _os.environ.get("BMT_RAW_MEMORY", "1") != "0"
 # profiles/r06_z6_raw_fused_ab.txt).
 RAW_FUSED = True
 RAW_FUSED_EDGES = True
-# ... and the stream-side projections in front of those.  The forward's (q_h = y W_q,h^T + b_q,h inside the launch, bmt_raw_attn_fwd_proj) is OFF: it is
-# worth 0.02-0.04 ms/step and its gradients are as close to the oracle's as without it (tools/probes/parity_arms.sh: the same to three digits), but the
-# other order of its fp32 sums moves the ten-Adam-step trajectory of tests/test_gpu_model.py -- chaotic in the gradients' low bits -- from 2e-4 ... 9e-4 to
-# 2.6e-3 ... 3.1e-3 off the oracle's at step 5, onto that test's 3e-3 bar (tools/probes/adam_gap_arms.sh, profiles/r06_z6_raw_fused_ab.txt): a bar is not
-# moved for 0.5 % of a step.  The backward's (do_h = mask(dy W_o) inside the launch, bmt_raw_attn_bwd_proj) is on: nothing measurable in the step, 4 launches
-# and 4 MB fewer, the trajectory where it was.
-RAW_FUSED_PROJ = False
+# ... and the stream-side projections in front of those: the forward's (q_h = y W_q,h^T + b_q,h inside the launch, bmt_raw_attn_fwd_proj: -0.02 ... -0.04
+# ms/step) and the backward's (do_h = mask(dy W_o) inside the launch, bmt_raw_attn_bwd_proj: nothing measurable in the step, 4 launches and 4 MB fewer).  The
+# forward's adds in the order of the launch it replaces -- per 16 reduction indices lo . hi, hi . lo, hi . hi into one accumulator -- and hands on the same
+# bits (tests/test_gpu_raw_memory.py::test_query_projection_inside_the_launch_changes_no_bit).  Its first form (one staged chunk of W_q's high plane feeding
+# both planes of y, the low plane in a second pass: fewer LDS bytes) was as close to the oracle as this one in every parity number and put the ten-Adam-step
+# trajectory of tests/test_gpu_model.py -- chaotic in the gradients' low bits -- on another path, 2.6e-3 ... 3.1e-3 off the oracle's at step 5 against a
+# 3e-3 bar (2e-4 ... 9e-4 before and now): profiles/r06_z6_raw_fused_ab.txt, tools/probes/adam_gap_arms.sh.
+RAW_FUSED_PROJ = True
 RAW_FUSED_PROJ_BWD = True
 
 

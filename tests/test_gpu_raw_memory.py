@@ -343,7 +343,8 @@ def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
         Kq = 320
         if lib.bmt_raw_attn_fwd_proj_ok(dm, Skp, dk, Kq):
             y_pl = ops.make_planes((rnd(M, 300, seed=9) * 0.8).to(DEV), "x3")
-            wq_pl = ops.make_planes((rnd(D, 300, seed=10) * 0.06).to(DEV), "x3")
+            Wq32 = (rnd(D, 300, seed=10) * 0.06).to(DEV)
+            wq_pl = ops.make_planes(Wq32, "x3")
             bq = (rnd(D, seed=11) * 0.2).to(DEV)
             assert y_pl.hi.stride(0) == Kq and wq_pl.hi.stride(0) == Kq
             q64 = (y_pl.hi.double() + y_pl.lo.double()) @ (wq_pl.hi.double() + wq_pl.lo.double()).t() + bq.double()
@@ -372,6 +373,15 @@ def test_fused_launch_equals_the_three_launches(ops, dm, S, Tq, H):
 
             pa, pb_ = pchain(True), pchain(False)
             assert_close(pa[0].float(), pb_[0].float(), atol=1.1 * 2.0 ** -8 * amax(pb_[0]), rtol=0, name="q (high plane)")
+            # the projection inside the launch adds in gemm_small_kernel's order (per 16 reduction indices: lo . hi, hi . lo, hi . hi into one accumulator):
+            # q's high plane is, bit for bit, what ops.linear_fwd_planes -- the launch it replaces -- writes from the same operands
+            wreg = ops.weight_planes(Wq32, "x3")
+            assert torch.equal(wreg.hi.view(torch.int16), wq_pl.hi.view(torch.int16)) and torch.equal(wreg.lo.view(torch.int16), wq_pl.lo.view(torch.int16))
+            q_lin = ops.linear_fwd_planes(y_pl, Wq32, bq, precision=ops.PREC_BF16X3, out_fmt="x3")
+            torch.cuda.synchronize()
+            neq = pa[0].view(torch.int16) != q_lin.hi.view(torch.int16)
+            assert not bool(neq.any()), (f"q differs from the replaced launch's in {int(neq.sum())} of {neq.numel()} elements (max {amax(pa[0].float() - q_lin.hi.float()):.3e}; "
+                                         f"rows {sorted(set(torch.nonzero(neq)[:, 0].tolist()))[:8]}, columns {sorted(set(torch.nonzero(neq)[:, 1].tolist()))[:8]})")
             for x_, y_, n, bar in zip(pa[1:], pb_[1:], ("Q' (B stack)", "P fp16", "O'"), (4e-3, 3e-3, 3e-3)):
                 e = rel_err(x_.float(), y_.float())
                 assert e < bar, f"query projection in the launch: {n}: {e:.3e}"
@@ -452,6 +462,37 @@ def test_cross_attention_against_the_raw_memory(ops, dm, S, holes):
     assert_close(y, y2.detach(), atol=3e-3 * float(y64.detach().abs().max()), rtol=0, name="reassociated vs projected output")
     n = rows.numel()                                    # (the projected form leaves the rows past the count unwritten)
     assert rel_err(Qd.grad, Q2.grad) < 3e-2 and rel_err(xp.grad.view(-1, dm)[:n], xp2.grad.view(-1, dm)[:n]) < 3e-2
+
+
+@pytest.mark.parametrize("dm,S", [(128, 800), (1024, 256)])
+def test_query_projection_inside_the_launch_changes_no_bit(ops, dm, S, monkeypatch):
+    """ops.RAW_FUSED_PROJ: q_h = y W_q,h^T + b_q,h inside the fused forward launch adds in the order of the launch it replaces, so the module's output
+    is the same tensor, bit for bit, with and without it (a forward that differed in its low bits put the ten-Adam-step trajectory of
+    tests/test_gpu_model.py on another path: profiles/r06_z6_raw_fused_ab.txt)"""
+    from bmt_amd.model.multihead_attention import MultiheadedAttention
+    B, Tq, Dq, D, H, L = 4, 29, 300, 1024, 4, 1
+    torch.manual_seed(0)
+    att = ops.tag_policy(MultiheadedAttention(Dq, dm, dm, H, 0.0, D), "dec").to(DEV)
+    m = _mask(B, S, seed=S + dm)
+    X = rnd(B, S, dm, seed=1) * 0.7 + 0.3
+    Q = rnd(B, Tq, Dq, seed=2)
+    assert lib_ok(ops, dm, ops._pad64(S), D // H)
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "RAW_FUSED_PROJ", flag)
+        xp, _ = _packed(ops, X, m)
+        xp.requires_grad_(True)
+        mem = ops.raw_memory(xp, L, H, Tq, ops.policy_of(att))
+        assert getattr(mem, "_bmt_rawmem", None) is not None
+        y = att(Q.to(DEV).requires_grad_(True), mem, mem, m.to(DEV))
+        assert mem._bmt_rawmem.used
+        torch.cuda.synchronize()
+        outs.append(y.detach().clone())
+    assert torch.equal(outs[0], outs[1]), f"{amax(outs[0] - outs[1]):.3e}"
+
+
+def lib_ok(ops, dm, Skp, dk):
+    return bool(ops.lib.bmt_raw_attn_fwd_proj_ok(dm, Skp, dk, 320))
 
 
 @pytest.mark.parametrize("dm,S", [(128, 300), (1024, 256)])
