@@ -60,6 +60,7 @@ def main():
         }
         lib, ck = ops.lib, ops._lib.check
         dbq = torch.zeros(D, device=DEV)
+        y_hi, y_lo, wq_hi, wq_lo = bf(M, 320), bf(M, 320), bf(D, 320), bf(D, 320)
         fused = {
             "fused S -> softmax -> O' (f16)": lambda: ck(lib.bmt_raw_attn_fwd(A(qf), Tq * H * dm, dm, H * dm, A(x_fh), dm, pk.off_ptr, A(xt), B, H, Tq, dm, Skp, 0.0625, A(Pf),
                                                                                 A(stackA), asb, ash, A(nat_hi), A(nat_lo), H * dm, ops._st()), "f"),
@@ -71,6 +72,12 @@ def main():
             "fused Q' -> ... -> O' (x3 + f16)": lambda: ck(lib.bmt_raw_attn_fwd_edges(A(q_hi), A(q_lo), D, A(wT_hi), A(wT_lo), 2 * D, A(stackB), bsb, bsh, A(x_fh), dm, pk.off_ptr, A(xt),
                                                                                        B, H, Tq, dm, Skp, dk, 0.0625, A(Pf), A(stackA), asb, ash, A(nat_hi), A(nat_lo), H * dm,
                                                                                        ops._st()), "fe"),
+            "fused q -> Q' -> ... -> O' (proj)": lambda: ck(lib.bmt_raw_attn_fwd_proj(A(y_hi), A(y_lo), 320, 320, A(wq_hi), A(wq_lo), 320, A(dbq), A(q_hi), D, A(wT_hi), A(wT_lo), 2 * D,
+                                                                                        A(stackB), bsb, bsh, A(x_fh), dm, pk.off_ptr, A(xt), B, H, Tq, dm, Skp, dk, 0.0625, A(Pf),
+                                                                                        A(stackA), asb, ash, A(nat_hi), A(nat_lo), H * dm, ops._st()), "fp"),
+            "fused do -> dO' -> ... -> dq (proj)": lambda: ck(lib.bmt_raw_attn_bwd_proj(A(y_hi), 320, 320, A(wq_hi), 320, 0.1, A(ops.rng_tensor()), 7, A(dbq), A(o_hi), D, A(wT_hi, D), 2 * D,
+                                                                                          A(stackB), bsb, bsh, A(x_hi), dm, pk.off_ptr, A(xtc), A(Pf), B, H, Tq, dm, Skp, dk, 0.0625,
+                                                                                          A(stackA), asb, ash, A(nat_hi), H * dm, A(w_hi), dm, A(q_hi), D, A(dbq), ops._st()), "bp"),
             "softmax forward alone": lambda: ck(lib.bmt_raw_softmax_fwd(A(S_), pk.off_ptr, B, H, Tq, Skp, 0.0625, A(Pf), A(stackA), asb, ash, ops._st()), "s"),
         }
         print(f"--- {name} memory: d = {dm}, {S} keys (capacity), {B} samples x {H} heads x {Tq} queries")
