@@ -47,6 +47,24 @@ def test_errors_are_reported_not_thrown():
     assert rc == -1
 
 
+def test_fused_cross_attention_entry_points_validate_before_any_device_work():
+    """ABI 12: the predicates are pure host arithmetic (LDS budget of a (sample, head) workgroup), the launches refuse null pointers and shapes the
+    predicate rejects without touching a device"""
+    from bmt_amd import _lib
+    lib = _lib.load()
+    # configs[1]'s two memories fit; a 1024-wide memory with 1024 keys does not (64 (dm + 8) + 128 (Skp + 4) + 32 768 bytes <= 160 KB)
+    assert lib.bmt_raw_attn_ok(128, 832) == 1 and lib.bmt_raw_attn_ok(1024, 256) == 1
+    assert lib.bmt_raw_attn_ok(1024, 1024) == 0 and lib.bmt_raw_attn_ok(100, 256) == 0 and lib.bmt_raw_attn_ok(128, 1088) == 0
+    assert lib.bmt_raw_attn_edges_ok(1024, 256, 256) == 1 and lib.bmt_raw_attn_edges_ok(1024, 64, 256) == 0        # (do_h is parked in the score tile's area)
+    assert lib.bmt_raw_attn_fwd_edges_ok(1024, 256, 256) == 1 and lib.bmt_raw_attn_fwd_edges_ok(1024, 256, 100) == 0
+    assert lib.bmt_raw_attn_fwd_proj_ok(1024, 256, 256, 320) == 1 and lib.bmt_raw_attn_fwd_proj_ok(128, 832, 256, 320) == 1
+    assert lib.bmt_raw_attn_fwd_proj_ok(1024, 256, 256, 300) == 0 and lib.bmt_raw_attn_bwd_proj_ok(1024, 256, 256, 320) == 1
+    rc = lib.bmt_raw_attn_fwd(None, 0, 0, 0, None, 0, None, None, 1, 1, 1, 128, 64, 1.0, None, None, 0, 0, None, None, 0, None)
+    assert rc == -1 and b"bmt_raw_attn_fwd" in lib.bmt_last_error()
+    rc = lib.bmt_raw_attn_bwd(None, 0, 0, 0, None, 0, None, None, None, 1, 1, 1, 128, 64, 1.0, None, 0, 0, None, 0, None)
+    assert rc == -1 and b"bmt_raw_attn_bwd" in lib.bmt_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from bmt_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
